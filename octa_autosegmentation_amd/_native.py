@@ -1,0 +1,78 @@
+"""ctypes binding of liboctahip.so (include/octa_hip.h). Fails loudly when the library is missing."""
+import ctypes
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboctahip.so")
+
+_lib = None
+_ctxs = {}
+_lock = threading.Lock()
+
+c_void_p, c_int, c_double, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+
+# symbol -> (restype, argtypes); must list every function include/octa_hip.h declares
+SIGNATURES = {
+    "octa_abi_version": (c_int, []),
+    "octa_last_error": (ctypes.c_char_p, []),
+    "octa_ctx_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
+    "octa_ctx_destroy": (None, [c_void_p]),
+    "octa_ctx_scratch_bytes": (c_size_t, [c_void_p]),
+    "octa_rasterize_2d": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double,
+                                  c_double, c_void_p, c_void_p]),
+    "octa_fs_dither": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "octa_max_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+
+class OctaHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load liboctahip.so once. Raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise OctaHipError(
+                        f"{LIB_PATH} is missing: build it with `python -m octa_autosegmentation_amd.build` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+                l = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(l, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().octa_last_error().decode("utf-8", "replace")
+        raise OctaHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ctx(device_index=None):
+    """Per-process context for one GPU (created on first use)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise OctaHipError("no ROCm GPU visible to torch; the HIP path cannot run (no CPU fallback)")
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    with _lock:
+        h = _ctxs.get(device_index)
+    if h is None:
+        out = c_void_p()
+        check(lib().octa_ctx_create(int(device_index), ctypes.byref(out)), "octa_ctx_create")
+        with _lock:
+            _ctxs[device_index] = out
+        h = out
+    return h
+
+
+def current_stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,79 @@
+// common.h -- context, error reporting and scratch management shared by the HIP sources.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/octa_hip.h"
+
+namespace octa {
+
+void set_error(const char *fmt, ...);
+
+#define OCTA_HIP_CHECK(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            octa::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
+                            __LINE__);                                                         \
+            return -1;                                                                         \
+        }                                                                                      \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) {
+            hipError_t e = hipFree(p);
+            (void)e;
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            p = nullptr;
+            return -1;
+        }
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) {
+            hipError_t e = hipFree(p);
+            (void)e;
+        }
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace octa
+
+struct octa_ctx {
+    int device = 0;
+    int num_cus = 256;
+    // rasteriser scratch
+    octa::DevBuf r_edge_off;    // int64 [B+1]
+    octa::DevBuf r_ucount;      // int32 [n_total] upper bound of sides per edge -> local exclusive scan
+    octa::DevBuf r_seg_total;   // int64 [B] per-graph totals, then exclusive bases
+    octa::DevBuf r_sides;       // int4  [sum U]
+    octa::DevBuf r_edge_meta;   // EdgeMeta [n_total]
+    octa::DevBuf r_tile_count;  // int32 [B*ntiles] -> local exclusive scan
+    octa::DevBuf r_tile_fill;   // int32 [B*ntiles]
+    octa::DevBuf r_tile_total;  // int64 [B]
+    octa::DevBuf r_tile_list;   // int32 [sum tile counts]
+    octa::DevBuf r_counters;    // int64 [8] misc device counters
+    size_t scratch_bytes() const {
+        return r_edge_off.cap + r_ucount.cap + r_seg_total.cap + r_sides.cap + r_edge_meta.cap + r_tile_count.cap +
+               r_tile_fill.cap + r_tile_total.cap + r_tile_list.cap + r_counters.cap;
+    }
+};

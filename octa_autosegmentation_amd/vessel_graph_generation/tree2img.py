@@ -1,0 +1,138 @@
+"""Drop-in for the reference's vessel_graph_generation/tree2img.py (2-D path), running on MI355X.
+
+`rasterize_forest` keeps the reference signature, return types and side effects
+(tree2img.py:12-114): edges are filtered by radius, optionally dropped (Python `random` stream,
+blackdict bookkeeping) on the host exactly in the reference's order, and the surviving edges are
+rendered by the HIP kernel behind `octa_rasterize_2d` -- bit-exact with what matplotlib's Agg
+backend draws for the reference. There is no CPU path here.
+"""
+from random import random
+from typing import Sequence, Tuple
+
+import ctypes
+import numpy as np
+
+from .. import _native
+
+
+def _parse_legacy(s: str):
+    # tree2img.py:73-76 ("Legacy" string positions as read back from the CSV)
+    return tuple([float(coord) for coord in s[1:-1].split(" ") if len(coord) > 0])
+
+
+def select_edges(forest, min_radius=0, max_radius=1, max_dropout_prob=0, blackdict=None, radius_list=None,
+                 radius_factor=1.3):
+    """Host-side edge selection of tree2img.py:58-86 (also used by voxelize_forest, :212-235).
+
+    Returns (edges float64 [n,7] of the edges to draw, blackdict). Consumes the global Python
+    `random` stream exactly like the reference: one draw when no blackdict is passed, then one
+    draw per in-range edge whose parent is not already black-listed.
+    """
+    if radius_list is None:
+        radius_list = []
+    if blackdict is None:
+        blackdict = dict()
+        p = random() ** 10 * max_dropout_prob
+    else:
+        p = 0
+    rows = []
+    for edge in forest:
+        radius = float(edge["radius"])
+        if radius < min_radius or radius > max_radius:
+            continue
+        n1 = edge["node1"]
+        if isinstance(n1, np.ndarray) or isinstance(n1, list):
+            current_node = tuple(n1)
+            proximal_node = tuple(edge["node2"])
+        elif isinstance(n1, str):
+            current_node = _parse_legacy(n1)
+            proximal_node = _parse_legacy(edge["node2"])
+        else:
+            raise TypeError(f"edge['node1'] must be ndarray, list or str, got {type(n1).__name__}")
+        if proximal_node in blackdict or random() < p:
+            blackdict[current_node] = True
+            continue
+        radius_list.append(radius * radius_factor)
+        rows.append((*current_node, *proximal_node, radius))
+    edges = np.asarray(rows, dtype=np.float64).reshape(-1, 7)
+    return edges, blackdict
+
+
+def rasterize_edges_device(d_edges, edge_off, image_resolution, MIP_axis=2, min_radius=0.0, max_radius=1.0,
+                           d_keep=None, out=None):
+    """Batched device entry: d_edges float64 CUDA tensor [n_total,7], edge_off int64 host array [B+1].
+
+    Returns a uint8 CUDA tensor [B, no_pixels_y, no_pixels_x]. Asynchronous on the current stream.
+    """
+    import torch
+    no_pixels_x, no_pixels_y = int(image_resolution[0]), int(image_resolution[1])
+    edge_off = np.ascontiguousarray(edge_off, dtype=np.int64)
+    B = len(edge_off) - 1
+    if d_edges.dtype != torch.float64 or not d_edges.is_cuda or not d_edges.is_contiguous():
+        raise ValueError("d_edges must be a contiguous float64 CUDA tensor")
+    if d_edges.numel() != int(edge_off[-1]) * 7:
+        raise ValueError("edge_off[-1] does not match the number of edges")
+    if out is None:
+        out = torch.empty((B, no_pixels_y, no_pixels_x), dtype=torch.uint8, device=d_edges.device)
+    h = _native.ctx(d_edges.device.index)
+    rc = _native.lib().octa_rasterize_2d(
+        h, B, ctypes.c_void_p(d_edges.data_ptr()), ctypes.c_void_p(edge_off.ctypes.data),
+        ctypes.c_void_p(d_keep.data_ptr()) if d_keep is not None else None,
+        no_pixels_x, no_pixels_y, int(MIP_axis), float(min_radius), float(max_radius),
+        ctypes.c_void_p(out.data_ptr()), _native.current_stream_ptr())
+    _native.check(rc, "octa_rasterize_2d")
+    return out
+
+
+def rasterize_forest(forest, image_resolution: Sequence[float], MIP_axis: int = 2, radius_list: list = None,
+                     min_radius: float = 0, max_radius: float = 1, max_dropout_prob=0, blackdict=None,
+                     colorize: str = None) -> Tuple[np.ndarray, dict]:
+    """Same contract as the reference's rasterize_forest (tree2img.py:12-114): returns
+    (uint16 [no_pixels_y, no_pixels_x] grey image in 0..255, blackdict)."""
+    import torch
+    if colorize is not None:
+        raise NotImplementedError("colorize is a visualisation option outside the MI355X hot path")
+    edges, blackdict = select_edges(forest, min_radius, max_radius, max_dropout_prob, blackdict, radius_list)
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if dev is None:
+        _native.ctx()  # raises: no CPU fallback
+    d_edges = torch.from_numpy(edges).to(dev)
+    # the radius window was applied on the host (it gates the RNG draws); pass the widest window
+    img = rasterize_edges_device(d_edges, np.array([0, len(edges)]), image_resolution, MIP_axis,
+                                 -np.inf, np.inf)
+    return img[0].cpu().numpy().astype(np.uint16), blackdict
+
+
+def binarize_label_device(d_img):
+    """Pillow `convert("1")` (Floyd-Steinberg) of uint8 CUDA images [B,H,W] -> uint8 {0,255}.
+    Mirrors visualize_vessel_graphs.py:97-99."""
+    import torch
+    if d_img.dtype != torch.uint8 or not d_img.is_cuda or not d_img.is_contiguous() or d_img.dim() != 3:
+        raise ValueError("d_img must be a contiguous uint8 CUDA tensor [B,H,W]")
+    B, H, W = d_img.shape
+    out = torch.empty_like(d_img)
+    h = _native.ctx(d_img.device.index)
+    rc = _native.lib().octa_fs_dither(h, B, ctypes.c_void_p(d_img.data_ptr()), W, H,
+                                      ctypes.c_void_p(out.data_ptr()), _native.current_stream_ptr())
+    _native.check(rc, "octa_fs_dither")
+    return out
+
+
+def maximum_u8_device(a, b):
+    """np.maximum(art_mat, ven_mat) of generate_vessel_graph.py:83 on device."""
+    import torch
+    if a.shape != b.shape or a.dtype != torch.uint8 or b.dtype != torch.uint8:
+        raise ValueError("inputs must be uint8 tensors of equal shape")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    h = _native.ctx(a.device.index)
+    rc = _native.lib().octa_max_u8(h, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                                   ctypes.c_void_p(out.data_ptr()), a.numel(), _native.current_stream_ptr())
+    _native.check(rc, "octa_max_u8")
+    return out
+
+
+def save_2d_img(img: np.ndarray, out_dir: str, name: str):
+    """tree2img.py:282-292."""
+    from PIL import Image
+    Image.fromarray(img.astype(np.uint8)).save(f'{out_dir}/{name}.png')
