@@ -40,6 +40,9 @@ def lib():
                     raise OctaHipError(
                         f"{LIB_PATH} is missing: build it with `python -m octa_autosegmentation_amd.build` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+                # torch bundles its own libamdhip64 (same soname as /opt/rocm's): import it first so that
+                # liboctahip.so binds to the runtime torch's allocator and streams live in.
+                import torch  # noqa: F401
                 l = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(l, name)

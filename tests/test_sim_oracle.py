@@ -1,0 +1,111 @@
+"""CPU: pins the simulator oracle (oracle/sim_oracle.cpp + .py) against fixtures captured from the
+imported reference (tools/make_golden_sim.py) and its RNG / hashing / kd-order restatements against
+the live numpy, CPython and scipy they restate."""
+import ctypes
+import hashlib
+import random
+
+import numpy as np
+import pytest
+import yaml
+
+from oracle import sim_oracle
+
+
+@pytest.fixture(scope="module")
+def golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_golden.npz"))
+
+
+def _cfg(golden, i1, i2):
+    cfg = yaml.safe_load(str(golden["config_yaml"]))
+    cfg["Greenhouse"]["modes"][0]["I"] = int(i1)
+    cfg["Greenhouse"]["modes"][1]["I"] = int(i2)
+    return cfg
+
+
+def test_short_runs_csv_bit_exact(golden):
+    names = [str(n) for n in golden["names"] if str(n).startswith("run_")]
+    assert len(names) >= 8
+    for name in names:
+        seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])
+        edges, info = sim_oracle.simulate(_cfg(golden, i1, i2), seed, return_fields=True)
+        assert info["faz_radius"] == float(golden[name + "_faz"])
+        assert (info["trace"] == golden[name + "_trace"]).all(), name
+        assert info["n_art_edges"] == int(golden[name + "_n_art"])
+        text = sim_oracle.edges_to_csv_text(edges)
+        assert text.encode() == golden[name + "_csv"].tobytes(), name
+        # fields: same element order; coordinates are exact (pure RNG arithmetic, no transcendentals)
+        assert (info["oxy"] == golden[name + "_oxy"]).all() and (info["co2"] == golden[name + "_co2"]).all()
+
+
+def test_full_length_run_sha(golden):
+    names = [str(n) for n in golden["names"] if str(n).startswith("full_")]
+    if not names:
+        pytest.skip("no full-length fixture")
+    name = names[0]
+    seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])
+    edges, info = sim_oracle.simulate(_cfg(golden, i1, i2), seed)
+    assert (info["trace"] == golden[name + "_trace"]).all()
+    text = sim_oracle.edges_to_csv_text(edges)
+    assert hashlib.sha256(text.encode()).hexdigest() == str(golden[name + "_csv_sha256"])
+
+
+def test_numpy_legacy_stream():
+    l = sim_oracle.lib()
+    for seed in (0, 1, 12345, 2 ** 32 - 1):
+        u32 = np.zeros(8, np.uint32); dbl = np.zeros(16); ri = np.zeros(2000, np.uint32); nrm = np.zeros(7)
+        l.octa_oracle_np_stream(seed, 8, u32.ctypes.data, 16, dbl.ctypes.data, 5679, 2000, ri.ctypes.data, 7, nrm.ctypes.data)
+        rs = np.random.RandomState(seed)
+        ref_u32 = rs.randint(0, 2 ** 32, 8, dtype=np.uint32)
+        assert (u32 == ref_u32).all()
+        assert (dbl == rs.random_sample(16)).all()
+        assert (ri == rs.randint(0, 5679, 2000)).all()
+        assert (nrm == np.array([rs.normal(0.5, 2.0) for _ in range(7)])).all()
+
+
+def test_cpython_random_stream():
+    l = sim_oracle.lib()
+    for seed in (0, 1, 987654321, 2 ** 40 + 17):
+        dbl = np.zeros(16); ch = np.zeros(40, np.uint32)
+        l.octa_oracle_py_stream(seed, 16, dbl.ctypes.data, 4, 40, ch.ctypes.data)
+        r = random.Random(seed)
+        assert dbl.tolist() == [r.random() for _ in range(16)]
+        assert ch.tolist() == [r.choice(range(4)) for _ in range(40)]
+
+
+def test_tuple_hash_and_set_order():
+    l = sim_oracle.lib()
+    rng = np.random.default_rng(4)
+    pts = np.concatenate([rng.uniform(0, 1, (3000, 3)), rng.uniform(-1e-3, 1e-3, (50, 3)), [[0.0, -0.0, 1.0], [0.5, 0.25, 1e-300]]])
+    for p in pts[:500]:
+        t = tuple(float(x) for x in p)
+        assert l.octa_oracle_hash_tuple3(np.array(t).ctypes.data) == (hash(t) & (2 ** 64 - 1))
+    for trial in range(40):
+        n = int(rng.integers(1, 700))
+        ids = rng.integers(0, n, int(n * 1.3)).astype(np.int32)   # with repeats
+        tuples = [tuple(float(x) for x in pts[i]) for i in range(n)]
+        s = set()
+        for i in ids:
+            s.add(tuples[i])
+        want = [tuples.index(t) for t in s]
+        out = np.zeros(n, np.int32)
+        k = l.octa_oracle_set_order(np.ascontiguousarray(pts[:n]).ctypes.data, ids.ctypes.data, len(ids), out.ctypes.data)
+        assert out[:k].tolist() == want
+
+
+def test_ckdtree_index_order_and_ball_order():
+    from scipy.spatial import cKDTree
+    l = sim_oracle.lib()
+    rng = np.random.default_rng(8)
+    for n in (1, 16, 17, 33, 500, 4096, 12000):
+        pts = rng.uniform(0, 1, (n, 3)) * np.array([1, 1, 0.0131])
+        out = np.zeros(n, np.int32)
+        l.octa_oracle_kd_indices(np.ascontiguousarray(pts).ctypes.data, n, out.ctypes.data)
+        tree = cKDTree(pts)
+        assert (out == tree.indices).all(), n
+        rank = np.empty(n, np.int64); rank[tree.indices] = np.arange(n)
+        for q in pts[:: max(1, n // 25)]:
+            hits = tree.query_ball_point(q, 0.045)
+            assert hits == sorted(hits, key=lambda i: rank[i])
