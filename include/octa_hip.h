@@ -83,6 +83,68 @@ int octa_fs_dither(octa_ctx *ctx, int B, const uint8_t *d_in, int W, int H, uint
  */
 int octa_max_u8(octa_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, uint8_t *d_out, size_t n, void *stream);
 
+/* ---- N1-N4: space-colonisation vessel-graph simulator --------------------
+ * Replaces, for B independent samples advanced in lock-step on the GPU:
+ *   vessel_graph_generation/greenhouse.py:57-137 (Greenhouse.develop_forest) with
+ *   :319-341 sample_oxygen_sinks, :343-366 assign_attraction_points_to_node,
+ *   :157-307 grow_vessels, :99-123 O2/CO2 bookkeeping, :139-155 expansion;
+ *   forest.py:68-181 (stumps), simulation_space.py:36-110, arterial_tree.py:174-184 (Murray),
+ *   element_mesh.py:87-232 (KD_Tree query semantics incl. cKDTree result order),
+ *   and the edge list order of generate_vessel_graph.py:43-56.
+ * Sample k behaves like `random.seed(py_seeds[k]); np.random.seed(np_seeds[k])` followed by
+ * the reference's main() (generate_vessel_graph.py:24-39).
+ * The only arithmetic left to the caller is the leaf-bifurcation geometry that the reference
+ * computes with numpy/LAPACK (np.cov + np.linalg.eig, greenhouse.py:221-233; the sign of the dgeev
+ * eigenvector is part of the result): the library hands batches of requests to `bif`.
+ */
+typedef struct octa_sim octa_sim;
+
+typedef struct {
+    double param_scale, d, r;             /* Greenhouse: param_scale, d, r                 */
+    double faz_radius_mean, faz_radius_std; /* FAZ_radius_bound                             */
+    double rotation_radius;
+    double faz_center[2];
+    double size[3];                       /* SimulationSpace no_voxel_x/y/z                 */
+    int n_trees;                          /* Forest.N_trees                                 */
+    int walls[4];                         /* source_walls x0, x1, y0, y1                    */
+    int n_modes;
+    /* per mode: I, N, eps_n, eps_s, eps_k, delta_art, delta_ven, gamma_art, gamma_ven, phi, omega, kappa, delta_sigma */
+    double modes[8][13];
+} octa_sim_config;
+
+#define OCTA_BIF_MAX_ATTS 256
+typedef struct {
+    int sample, n;                        /* sample index in the batch, number of attractors */
+    double pos[3];                        /* position of the bifurcating leaf               */
+    double r, kappa, d;                   /* child radius, bifurcation exponent, segment length */
+    double atts[OCTA_BIF_MAX_ATTS * 3];   /* the attractors kept by the angle filter, in order */
+} octa_bif_request;
+
+/* Fill out6[i] = (p_new_1.xyz, p_new_2.xyz) for every request (greenhouse.py:205-233). */
+typedef void (*octa_bif_fn)(int n_req, const octa_bif_request *reqs, double *out6, void *user);
+
+int octa_sim_create(octa_ctx *ctx, const octa_sim_config *cfg, int B, octa_sim **out);
+void octa_sim_destroy(octa_sim *sim);
+
+/* Run all iterations for B samples. Synchronous (the bifurcation service needs the host). */
+int octa_sim_run(octa_sim *sim, const uint32_t *h_np_seeds, const uint64_t *h_py_seeds, octa_bif_fn bif, void *user,
+                 void *stream);
+
+/* After octa_sim_run: per-sample edge offsets (h_edge_off[B+1]) and arterial edge counts (h_n_art[B]). */
+int octa_sim_edge_offsets(octa_sim *sim, int64_t *h_edge_off, int64_t *h_n_art);
+
+/* Edge list [total][7] doubles (node xyz, parent xyz, radius), arterial trees then venous, BFS per
+ * tree -- the CSV row order of generate_vessel_graph.py:59-66. h_edges: host buffer. */
+int octa_sim_export_edges(octa_sim *sim, double *h_edges);
+
+/* Per-sample statistics, h_stats[B][8] int64: error bits, random.uniform draws, Murray steps,
+ * bifurcations, re-speculated inter-nodes, arterial nodes, venous nodes, FAZ radius bits. */
+int octa_sim_stats(octa_sim *sim, int64_t *h_stats);
+
+/* Final O2 / CO2 fields of one sample (host buffers, capacity in points); returns counts. */
+int octa_sim_fields(octa_sim *sim, int sample, double *h_oxy, int64_t cap_oxy, int64_t *n_oxy, double *h_co2,
+                    int64_t cap_co2, int64_t *n_co2);
+
 #ifdef __cplusplus
 }
 #endif

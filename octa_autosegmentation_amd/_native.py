@@ -23,6 +23,13 @@ SIGNATURES = {
                                   c_double, c_void_p, c_void_p]),
     "octa_fs_dither": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "octa_max_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "octa_sim_create": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
+    "octa_sim_destroy": (None, [c_void_p]),
+    "octa_sim_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "octa_sim_edge_offsets": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "octa_sim_export_edges": (c_int, [c_void_p, c_void_p]),
+    "octa_sim_stats": (c_int, [c_void_p, c_void_p]),
+    "octa_sim_fields": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, ctypes.c_int64, c_void_p]),
 }
 
 

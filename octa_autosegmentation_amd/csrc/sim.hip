@@ -1,0 +1,483 @@
+// sim.hip -- N1-N4: the vessel-graph simulator on gfx950. One 256-thread workgroup advances one
+// sample through the block-cooperative phases of sim_core.h; B samples advance in lock-step with
+// two launches per iteration (the host only serves the rare leaf-bifurcation LAPACK requests in
+// between). No collective, no inter-workgroup communication: samples are independent.
+//
+//   launch A(it):  [venous ordered pass + CO2 removal of it-1]  O2 sampling, arterial nearest-node
+//                  assignment (LDS-tiled), dict-order sort (LDS bitonic), per-node speculation
+//   host:          bifurcation requests -> numpy/LAPACK callback -> results
+//   launch B(it):  arterial ordered pass (RNG draws, node creation, Murray with bit-exact glibc pow),
+//                  O2->CO2 conversion (cKDTree order + CPython set order emulated in LDS / by one
+//                  lane), venous assignment + speculation
+//   host:          bifurcation requests
+// Per-sample state stays resident in HBM (about 16 MB per sample, dominated by the pre-generated
+// candidate stream); LDS (155,648 B dynamic) holds tiles, sort keys and the kd key/index arrays.
+
+#include <vector>
+
+#include "common.h"
+#include "sim_host.h"
+
+using namespace octa_simk;
+
+namespace {
+
+constexpr int SIM_THREADS = 256;
+constexpr size_t SIM_LDS = 2048 + (size_t)OCAP * 10 + 5 * KD_RANGES * 4;  // 155,648 B
+constexpr int REQ_CAP = 8192;
+
+static_assert(sizeof(BifRequest) == sizeof(octa_bif_request), "request layout must match the public header");
+static_assert(MAXKEPT == OCTA_BIF_MAX_ATTS, "request capacity must match the public header");
+
+struct BatchPtrs {
+    double *npos[2], *nrad[2], *nkap[2];
+    int *npar[2], *nch0[2], *nch1[2];
+    unsigned char *nnch[2], *nact[2];
+    double *oxy, *co2, *cand, *py_u;
+    int *nn, *first_att, *act_list;
+    unsigned *sorted;
+    int *gnode, *gstart, *gcount;
+    Rec *rec;
+    unsigned short *kd_idx, *kd_rank;
+    unsigned char *removed, *ven_near;
+    unsigned long long *hashes;
+    unsigned *pairs;
+    unsigned long long *set_hash;
+    int *set_key, *tmp_int;
+    double *tmp_dbl;
+    SampleScalars *sc;
+    IterParams *iters;
+    BifRequest *reqs;
+    int *req_count;
+    double *bif_results;
+    unsigned *mt_state;          // [B][625] numpy stream after init (624 words + idx)
+    unsigned short *valid;       // [B][76*76*2]
+    unsigned *valid_count;       // [B]
+    int *n_per_iter;             // [n_iter]
+    size_t cand_stride;
+    SimConst C;
+};
+
+__device__ __forceinline__ SimArrays sample_arrays(const BatchPtrs &B, int s) {
+    SimArrays A;
+    for (int f = 0; f < 2; f++) {
+        A.npos[f] = B.npos[f] + (size_t)s * NCAP * 3;
+        A.nrad[f] = B.nrad[f] + (size_t)s * NCAP;
+        A.nkap[f] = B.nkap[f] + (size_t)s * NCAP;
+        A.npar[f] = B.npar[f] + (size_t)s * NCAP;
+        A.nch0[f] = B.nch0[f] + (size_t)s * NCAP;
+        A.nch1[f] = B.nch1[f] + (size_t)s * NCAP;
+        A.nnch[f] = B.nnch[f] + (size_t)s * NCAP;
+        A.nact[f] = B.nact[f] + (size_t)s * NCAP;
+    }
+    A.oxy = B.oxy + (size_t)s * OCAP * 3;
+    A.co2 = B.co2 + (size_t)s * CCAP * 3;
+    A.cand = B.cand + (size_t)s * B.cand_stride;
+    A.py_u = B.py_u + (size_t)s * PYCAP;
+    A.nn = B.nn + (size_t)s * OCAP;
+    A.first_att = B.first_att + (size_t)s * NCAP;
+    A.act_list = B.act_list + (size_t)s * NCAP;
+    A.sorted = B.sorted + (size_t)s * SORTCAP;
+    A.gnode = B.gnode + (size_t)s * GCAP;
+    A.gstart = B.gstart + (size_t)s * GCAP;
+    A.gcount = B.gcount + (size_t)s * GCAP;
+    A.rec = B.rec + (size_t)s * GCAP;
+    A.kd_idx = B.kd_idx + (size_t)s * OCAP;
+    A.kd_rank = B.kd_rank + (size_t)s * OCAP;
+    A.removed = B.removed + (size_t)s * OCAP;
+    A.ven_near = B.ven_near + (size_t)s * OCAP;
+    A.hashes = B.hashes + (size_t)s * OCAP;
+    A.pairs = B.pairs + (size_t)s * PCAP;
+    A.set_hash = B.set_hash + (size_t)s * SETCAP;
+    A.set_key = B.set_key + (size_t)s * SETCAP;
+    A.tmp_int = B.tmp_int + (size_t)s * (OCAP + 2 * NCANDCAP);
+    A.tmp_dbl = B.tmp_dbl + (size_t)s * OCAP * 3;
+    A.sc = B.sc + s;
+    return A;
+}
+
+// ---- candidate stream: one lane per sample runs the numpy MT19937 stream (state in LDS, word-major
+// so that the 32 lanes of a block hit 32 different banks)
+constexpr int GEN_LANES = 32;
+struct LdsMt {
+    unsigned *w;  // base + lane, stride GEN_LANES
+    int idx;
+    __device__ unsigned &at(int k) { return w[k * GEN_LANES]; }
+    __device__ void refill() {
+        int kk;
+        for (kk = 0; kk < 624 - 397; kk++) {
+            unsigned y = (at(kk) & 0x80000000u) | (at(kk + 1) & 0x7fffffffu);
+            at(kk) = at(kk + 397) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        for (; kk < 623; kk++) {
+            unsigned y = (at(kk) & 0x80000000u) | (at(kk + 1) & 0x7fffffffu);
+            at(kk) = at(kk - 227) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        unsigned y = (at(623) & 0x80000000u) | (at(0) & 0x7fffffffu);
+        at(623) = at(396) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        idx = 0;
+    }
+    __device__ unsigned next() {
+        if (idx >= 624) refill();
+        unsigned y = at(idx++);
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+    __device__ double next_double() {
+        unsigned a = next() >> 5, b = next() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+};
+
+__global__ void __launch_bounds__(GEN_LANES)
+sim_gen_candidates_kernel(BatchPtrs B, int n_samples) {
+    __shared__ unsigned s_mt[624 * GEN_LANES];
+    const int s = blockIdx.x * GEN_LANES + threadIdx.x;
+    if (s >= n_samples) return;
+    LdsMt g;
+    g.w = s_mt + threadIdx.x;
+    const unsigned *st = B.mt_state + (size_t)s * 625;
+    for (int k = 0; k < 624; k++) g.at(k) = st[k];
+    g.idx = (int)st[624];
+    const unsigned K = B.valid_count[s];
+    const unsigned short *valid = B.valid + (size_t)s * 76 * 76 * 2;
+    unsigned *idx_scratch = reinterpret_cast<unsigned *>(B.tmp_int + (size_t)s * (OCAP + 2 * NCANDCAP));
+    unsigned rng = K - 1, mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    double *out = B.cand + (size_t)s * B.cand_stride;
+    for (int it = 0; it < B.C.n_iter; it++) {
+        const int N = B.n_per_iter[it];
+        for (int i = 0; i < N; i++) {
+            unsigned v = 0;
+            if (rng != 0) { do { v = g.next() & mask; } while (v > rng); }
+            idx_scratch[i] = v;
+        }
+        double *o = out + (size_t)it * B.C.n_max * 3;
+        for (int i = 0; i < N; i++) {
+            double u0 = g.next_double(), u1 = g.next_double(), u2 = g.next_double();
+            const unsigned short *v = valid + 2 * idx_scratch[i];
+            o[3 * i] = ((double)v[0] + u0) / 76.0;
+            o[3 * i + 1] = ((double)v[1] + u1) / 76.0;
+            o[3 * i + 2] = (0.0 + u2) / 76.0;
+        }
+    }
+}
+
+// ---- iteration kernels
+__global__ void __launch_bounds__(SIM_THREADS)
+sim_iter_a_kernel(BatchPtrs B, int it, int finish_prev) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x;
+    SimArrays A = sample_arrays(B, s);
+    Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
+    if (A.sc->err) return;
+    if (finish_prev) {
+        const IterParams Pp = B.iters[it - 1];
+        phase_seq(b, A, B.C, Pp, 1, A.co2, B.bif_results);
+        phase_satisfy_ven(b, A, Pp);
+    }
+    if (it >= B.C.n_iter) return;
+    const IterParams P = B.iters[it];
+    phase_sample(b, A, B.C, P, it);
+    phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art);
+    phase_pre(b, A, B.C, P, 0, A.oxy, B.reqs, B.req_count, REQ_CAP, s);
+}
+
+__global__ void __launch_bounds__(SIM_THREADS)
+sim_iter_b_kernel(BatchPtrs B, int it) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x;
+    SimArrays A = sample_arrays(B, s);
+    Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
+    if (A.sc->err) return;
+    const IterParams P = B.iters[it];
+    phase_seq(b, A, B.C, P, 0, A.oxy, B.bif_results);
+    phase_satisfy_art(b, A, P);
+    phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven);
+    phase_pre(b, A, B.C, P, 1, A.co2, B.reqs + REQ_CAP, B.req_count + 1, REQ_CAP, s);
+}
+
+}  // namespace
+
+struct octa_sim {
+    octa_ctx *ctx = nullptr;
+    int B = 0;
+    SimConfig cfg;
+    SimConst C;
+    std::vector<IterParams> iters;
+    BatchPtrs P;
+    std::vector<void *> allocs;
+    BifRequest *h_reqs = nullptr;   // pinned [2*REQ_CAP]
+    double *h_results = nullptr;    // pinned [2*REQ_CAP*6]
+    int *h_req_count = nullptr;     // pinned [2]
+    bool ran = false;
+    // host copies for export
+    std::vector<SampleScalars> h_sc;
+    size_t bytes = 0;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(octa_sim *S, T **p, size_t count) {
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+    if (e != hipSuccess) { octa::set_error("octa_sim: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return -1; }
+    S->allocs.push_back(q);
+    S->bytes += bytes;
+    *p = reinterpret_cast<T *>(q);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, octa_sim **out) {
+    if (!ctx || !c || !out || B <= 0) { octa::set_error("octa_sim_create: bad arguments"); return -2; }
+    *out = nullptr;
+    if (c->n_modes < 1 || c->n_modes > 8) { octa::set_error("octa_sim_create: n_modes must be 1..8"); return -2; }
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    octa_sim *S = new (std::nothrow) octa_sim();
+    if (!S) { octa::set_error("octa_sim_create: out of host memory"); return -1; }
+    S->ctx = ctx;
+    S->B = B;
+    SimConfig &cfg = S->cfg;
+    cfg.param_scale = c->param_scale; cfg.d = c->d; cfg.r = c->r; cfg.faz_mean = c->faz_radius_mean; cfg.faz_std = c->faz_radius_std;
+    cfg.rotation_radius = c->rotation_radius; cfg.fc0 = c->faz_center[0]; cfg.fc1 = c->faz_center[1];
+    cfg.sx = c->size[0]; cfg.sy = c->size[1]; cfg.sz = c->size[2]; cfg.n_trees = c->n_trees;
+    int nw = 0;
+    for (int w = 0; w < 4; w++) { cfg.walls[w] = c->walls[w]; nw += c->walls[w] ? 1 : 0; }
+    for (int m = 0; m < c->n_modes; m++) {
+        const double *q = c->modes[m];
+        cfg.modes.push_back(ModeCfg{(int)q[0], (int)q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11], q[12]});
+        if ((int)q[1] > NCANDCAP || (int)q[1] < 0) { octa::set_error("octa_sim_create: N=%d exceeds %d", (int)q[1], NCANDCAP); delete S; return -2; }
+    }
+    if (nw == 0 || cfg.n_trees < 1 || 2 * cfg.n_trees > NCAP) { octa::set_error("octa_sim_create: bad forest config"); delete S; return -2; }
+    if (std::ceil(cfg.sx * 76) > 76 || std::ceil(cfg.sy * 76) > 76) { octa::set_error("octa_sim_create: simulation space larger than the unit square"); delete S; return -2; }
+    S->iters = build_iter_table(cfg, &S->C);
+    BatchPtrs &P = S->P;
+    memset(&P, 0, sizeof(P));
+    P.C = S->C;
+    const size_t nb = (size_t)B;
+    P.cand_stride = (size_t)S->C.n_iter * (size_t)(S->C.n_max > 0 ? S->C.n_max : 1) * 3;
+    int rc = 0;
+    for (int f = 0; f < 2 && !rc; f++) {
+        rc |= dev_alloc(S, &P.npos[f], nb * NCAP * 3); rc |= dev_alloc(S, &P.nrad[f], nb * NCAP); rc |= dev_alloc(S, &P.nkap[f], nb * NCAP);
+        rc |= dev_alloc(S, &P.npar[f], nb * NCAP); rc |= dev_alloc(S, &P.nch0[f], nb * NCAP); rc |= dev_alloc(S, &P.nch1[f], nb * NCAP);
+        rc |= dev_alloc(S, &P.nnch[f], nb * NCAP); rc |= dev_alloc(S, &P.nact[f], nb * NCAP);
+    }
+    rc |= dev_alloc(S, &P.oxy, nb * OCAP * 3); rc |= dev_alloc(S, &P.co2, nb * CCAP * 3);
+    rc |= dev_alloc(S, &P.cand, nb * P.cand_stride + 8); rc |= dev_alloc(S, &P.py_u, nb * PYCAP);
+    rc |= dev_alloc(S, &P.nn, nb * OCAP); rc |= dev_alloc(S, &P.first_att, nb * NCAP); rc |= dev_alloc(S, &P.act_list, nb * NCAP);
+    rc |= dev_alloc(S, &P.sorted, nb * SORTCAP); rc |= dev_alloc(S, &P.gnode, nb * GCAP); rc |= dev_alloc(S, &P.gstart, nb * GCAP);
+    rc |= dev_alloc(S, &P.gcount, nb * GCAP); rc |= dev_alloc(S, &P.rec, nb * GCAP);
+    rc |= dev_alloc(S, &P.kd_idx, nb * OCAP); rc |= dev_alloc(S, &P.kd_rank, nb * OCAP);
+    rc |= dev_alloc(S, &P.removed, nb * OCAP); rc |= dev_alloc(S, &P.ven_near, nb * OCAP); rc |= dev_alloc(S, &P.hashes, nb * OCAP);
+    rc |= dev_alloc(S, &P.pairs, nb * PCAP); rc |= dev_alloc(S, &P.set_hash, nb * SETCAP); rc |= dev_alloc(S, &P.set_key, nb * SETCAP);
+    rc |= dev_alloc(S, &P.tmp_int, nb * (OCAP + 2 * NCANDCAP)); rc |= dev_alloc(S, &P.tmp_dbl, nb * OCAP * 3);
+    rc |= dev_alloc(S, &P.sc, nb); rc |= dev_alloc(S, &P.iters, S->iters.size() + 1);
+    rc |= dev_alloc(S, &P.reqs, (size_t)2 * REQ_CAP); rc |= dev_alloc(S, &P.req_count, 4); rc |= dev_alloc(S, &P.bif_results, (size_t)2 * REQ_CAP * 6);
+    rc |= dev_alloc(S, &P.mt_state, nb * 625); rc |= dev_alloc(S, &P.valid, nb * 76 * 76 * 2); rc |= dev_alloc(S, &P.valid_count, nb);
+    rc |= dev_alloc(S, &P.n_per_iter, S->iters.size() + 1);
+    if (!rc) {
+        hipError_t e1 = hipHostMalloc((void **)&S->h_reqs, sizeof(BifRequest) * 2 * REQ_CAP);
+        hipError_t e2 = hipHostMalloc((void **)&S->h_results, sizeof(double) * 2 * REQ_CAP * 6);
+        hipError_t e3 = hipHostMalloc((void **)&S->h_req_count, sizeof(int) * 4);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { octa::set_error("octa_sim_create: hipHostMalloc failed"); rc = -1; }
+    }
+    if (!rc) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_iter_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIM_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_iter_b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIM_LDS);
+        if (e != hipSuccess) { octa::set_error("octa_sim_create: cannot reserve %zu B of LDS: %s", SIM_LDS, hipGetErrorString(e)); rc = -1; }
+    }
+    if (rc) { octa_sim_destroy(S); return -1; }
+    *out = S;
+    return 0;
+}
+
+extern "C" void octa_sim_destroy(octa_sim *S) {
+    if (!S) return;
+    hipError_t e = hipSetDevice(S->ctx->device);
+    for (void *p : S->allocs) e = hipFree(p);
+    if (S->h_reqs) e = hipHostFree(S->h_reqs);
+    if (S->h_results) e = hipHostFree(S->h_results);
+    if (S->h_req_count) e = hipHostFree(S->h_req_count);
+    (void)e;
+    delete S;
+}
+
+extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint64_t *h_py_seeds, octa_bif_fn bif, void *user,
+                            void *stream_) {
+    if (!S || !h_np_seeds || !h_py_seeds || !bif) { octa::set_error("octa_sim_run: bad arguments"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
+    const int B = S->B;
+    BatchPtrs &P = S->P;
+    const SimConst &C = S->C;
+    // ---- host init of every sample (FAZ radius, validity mask, stumps, RNG streams)
+    {
+        std::vector<SampleScalars> sc(B);
+        std::vector<unsigned> mt((size_t)B * 625);
+        std::vector<unsigned short> valid((size_t)B * 76 * 76 * 2, 0);
+        std::vector<unsigned> vcount(B);
+        std::vector<double> py_u((size_t)B * PYCAP);
+        const int n0 = 2 * S->cfg.n_trees;
+        std::vector<double> npos((size_t)B * 2 * n0 * 3);
+        SampleInit I;
+        for (int s = 0; s < B; s++) {
+            init_sample(S->cfg, h_np_seeds[s], h_py_seeds[s], &I);
+            memset(&sc[s], 0, sizeof(SampleScalars));
+            sc[s].faz_radius = I.faz_radius;
+            sc[s].py_cap = PYCAP;
+            sc[s].n_nodes[0] = sc[s].n_nodes[1] = n0;
+            memcpy(&mt[(size_t)s * 625], I.np_state.mt, 624 * 4);
+            mt[(size_t)s * 625 + 624] = (unsigned)I.np_state.idx;
+            vcount[s] = (unsigned)(I.valid.size() / 2);
+            if (vcount[s] == 0) { octa::set_error("octa_sim_run: sample %d has no valid voxel", s); return -2; }
+            memcpy(&valid[(size_t)s * 76 * 76 * 2], I.valid.data(), I.valid.size() * 2);
+            memcpy(&py_u[(size_t)s * PYCAP], I.py_u.data(), sizeof(double) * PYCAP);
+            for (int f = 0; f < 2; f++) memcpy(&npos[((size_t)s * 2 + f) * n0 * 3], I.pos[f].data(), sizeof(double) * n0 * 3);
+        }
+        OCTA_HIP_CHECK(hipMemcpyAsync(P.sc, sc.data(), sizeof(SampleScalars) * B, hipMemcpyHostToDevice, stream));
+        OCTA_HIP_CHECK(hipMemcpyAsync(P.mt_state, mt.data(), mt.size() * 4, hipMemcpyHostToDevice, stream));
+        OCTA_HIP_CHECK(hipMemcpyAsync(P.valid, valid.data(), valid.size() * 2, hipMemcpyHostToDevice, stream));
+        OCTA_HIP_CHECK(hipMemcpyAsync(P.valid_count, vcount.data(), vcount.size() * 4, hipMemcpyHostToDevice, stream));
+        OCTA_HIP_CHECK(hipMemcpyAsync(P.py_u, py_u.data(), py_u.size() * 8, hipMemcpyHostToDevice, stream));
+        OCTA_HIP_CHECK(hipMemcpyAsync(P.iters, S->iters.data(), sizeof(IterParams) * S->iters.size(), hipMemcpyHostToDevice, stream));
+        std::vector<int> Ns(S->iters.size() + 1, 0);
+        for (size_t i = 0; i < S->iters.size(); i++) Ns[i] = S->iters[i].N;
+        OCTA_HIP_CHECK(hipMemcpyAsync(P.n_per_iter, Ns.data(), sizeof(int) * Ns.size(), hipMemcpyHostToDevice, stream));
+        // stump nodes: root (kappa 4, no parent) + one child per tree
+        std::vector<double> rad((size_t)n0, C.r), kap((size_t)n0, 4.0);
+        std::vector<int> par(n0), c0(n0), c1(n0, -1);
+        std::vector<unsigned char> nch(n0), act(n0, 1);
+        for (int i = 0; i < n0; i++) { par[i] = (i & 1) ? i - 1 : -1; c0[i] = (i & 1) ? -1 : i + 1; nch[i] = (i & 1) ? 0 : 1; }
+        for (int f = 0; f < 2; f++) {
+            OCTA_HIP_CHECK(hipMemsetAsync(P.nact[f], 0, (size_t)B * NCAP, stream));
+            for (int s = 0; s < B; s++) {
+                OCTA_HIP_CHECK(hipMemcpyAsync(P.npos[f] + (size_t)s * NCAP * 3, &npos[((size_t)s * 2 + f) * n0 * 3], sizeof(double) * n0 * 3, hipMemcpyHostToDevice, stream));
+                OCTA_HIP_CHECK(hipMemcpyAsync(P.nrad[f] + (size_t)s * NCAP, rad.data(), sizeof(double) * n0, hipMemcpyHostToDevice, stream));
+                OCTA_HIP_CHECK(hipMemcpyAsync(P.nkap[f] + (size_t)s * NCAP, kap.data(), sizeof(double) * n0, hipMemcpyHostToDevice, stream));
+                OCTA_HIP_CHECK(hipMemcpyAsync(P.npar[f] + (size_t)s * NCAP, par.data(), sizeof(int) * n0, hipMemcpyHostToDevice, stream));
+                OCTA_HIP_CHECK(hipMemcpyAsync(P.nch0[f] + (size_t)s * NCAP, c0.data(), sizeof(int) * n0, hipMemcpyHostToDevice, stream));
+                OCTA_HIP_CHECK(hipMemcpyAsync(P.nch1[f] + (size_t)s * NCAP, c1.data(), sizeof(int) * n0, hipMemcpyHostToDevice, stream));
+                OCTA_HIP_CHECK(hipMemcpyAsync(P.nnch[f] + (size_t)s * NCAP, nch.data(), n0, hipMemcpyHostToDevice, stream));
+                OCTA_HIP_CHECK(hipMemcpyAsync(P.nact[f] + (size_t)s * NCAP, act.data(), n0, hipMemcpyHostToDevice, stream));
+            }
+        }
+        OCTA_HIP_CHECK(hipMemsetAsync(P.req_count, 0, sizeof(int) * 4, stream));
+        OCTA_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
+    }
+    // ---- candidate stream for all iterations
+    if (C.n_iter > 0) {
+        hipLaunchKernelGGL(sim_gen_candidates_kernel, dim3((unsigned)((B + GEN_LANES - 1) / GEN_LANES)), dim3(GEN_LANES), 0, stream, P, B);
+        OCTA_HIP_CHECK(hipGetLastError());
+    }
+    // ---- iterations
+    auto serve = [&](int slot) -> int {
+        OCTA_HIP_CHECK(hipMemcpyAsync(S->h_req_count, P.req_count, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+        OCTA_HIP_CHECK(hipStreamSynchronize(stream));
+        int n = S->h_req_count[slot];
+        if (n > REQ_CAP) n = REQ_CAP;
+        if (n > 0) {
+            OCTA_HIP_CHECK(hipMemcpyAsync(S->h_reqs, P.reqs + (size_t)slot * REQ_CAP, sizeof(BifRequest) * n, hipMemcpyDeviceToHost, stream));
+            OCTA_HIP_CHECK(hipStreamSynchronize(stream));
+            bif(n, reinterpret_cast<const octa_bif_request *>(S->h_reqs), S->h_results, user);
+            OCTA_HIP_CHECK(hipMemcpyAsync(P.bif_results, S->h_results, sizeof(double) * 6 * n, hipMemcpyHostToDevice, stream));
+            OCTA_HIP_CHECK(hipMemsetAsync(P.req_count + slot, 0, sizeof(int), stream));
+        }
+        return 0;
+    };
+    for (int it = 0; it <= C.n_iter; it++) {
+        hipLaunchKernelGGL(sim_iter_a_kernel, dim3((unsigned)B), dim3(SIM_THREADS), SIM_LDS, stream, P, it, it > 0 ? 1 : 0);
+        OCTA_HIP_CHECK(hipGetLastError());
+        if (it == C.n_iter) break;
+        if (serve(0)) return -1;
+        hipLaunchKernelGGL(sim_iter_b_kernel, dim3((unsigned)B), dim3(SIM_THREADS), SIM_LDS, stream, P, it);
+        OCTA_HIP_CHECK(hipGetLastError());
+        if (serve(1)) return -1;
+    }
+    S->h_sc.resize(B);
+    OCTA_HIP_CHECK(hipMemcpyAsync(S->h_sc.data(), P.sc, sizeof(SampleScalars) * B, hipMemcpyDeviceToHost, stream));
+    OCTA_HIP_CHECK(hipStreamSynchronize(stream));
+    S->ran = true;
+    for (int s = 0; s < B; s++)
+        if (S->h_sc[s].err) { octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x", s, S->h_sc[s].err); return -3; }
+    return 0;
+}
+
+extern "C" int octa_sim_edge_offsets(octa_sim *S, int64_t *h_edge_off, int64_t *h_n_art) {
+    if (!S || !S->ran || !h_edge_off) { octa::set_error("octa_sim_edge_offsets: run the simulation first"); return -2; }
+    h_edge_off[0] = 0;
+    for (int s = 0; s < S->B; s++) {
+        const SampleScalars &sc = S->h_sc[s];
+        int64_t na = sc.n_nodes[0] - S->cfg.n_trees, nv = sc.n_nodes[1] - S->cfg.n_trees;
+        h_edge_off[s + 1] = h_edge_off[s] + na + nv;
+        if (h_n_art) h_n_art[s] = na;
+    }
+    return 0;
+}
+
+extern "C" int octa_sim_export_edges(octa_sim *S, double *h_edges) {
+    if (!S || !S->ran || !h_edges) { octa::set_error("octa_sim_export_edges: run the simulation first"); return -2; }
+    OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
+    const BatchPtrs &P = S->P;
+    std::vector<double> pos[2], rad[2];
+    std::vector<int> par[2], c0[2], c1[2];
+    std::vector<unsigned char> nch[2];
+    long off = 0;
+    for (int s = 0; s < S->B; s++) {
+        const SampleScalars &sc = S->h_sc[s];
+        for (int f = 0; f < 2; f++) {
+            int n = sc.n_nodes[f];
+            pos[f].resize((size_t)n * 3); rad[f].resize(n); par[f].resize(n); c0[f].resize(n); c1[f].resize(n); nch[f].resize(n);
+            OCTA_HIP_CHECK(hipMemcpy(pos[f].data(), P.npos[f] + (size_t)s * NCAP * 3, sizeof(double) * n * 3, hipMemcpyDeviceToHost));
+            OCTA_HIP_CHECK(hipMemcpy(rad[f].data(), P.nrad[f] + (size_t)s * NCAP, sizeof(double) * n, hipMemcpyDeviceToHost));
+            OCTA_HIP_CHECK(hipMemcpy(par[f].data(), P.npar[f] + (size_t)s * NCAP, sizeof(int) * n, hipMemcpyDeviceToHost));
+            OCTA_HIP_CHECK(hipMemcpy(c0[f].data(), P.nch0[f] + (size_t)s * NCAP, sizeof(int) * n, hipMemcpyDeviceToHost));
+            OCTA_HIP_CHECK(hipMemcpy(c1[f].data(), P.nch1[f] + (size_t)s * NCAP, sizeof(int) * n, hipMemcpyDeviceToHost));
+            OCTA_HIP_CHECK(hipMemcpy(nch[f].data(), P.nnch[f] + (size_t)s * NCAP, n, hipMemcpyDeviceToHost));
+        }
+        const double *cp[2] = {pos[0].data(), pos[1].data()}, *cr[2] = {rad[0].data(), rad[1].data()};
+        const int *cpar[2] = {par[0].data(), par[1].data()}, *cc0[2] = {c0[0].data(), c0[1].data()}, *cc1[2] = {c1[0].data(), c1[1].data()};
+        const unsigned char *cn[2] = {nch[0].data(), nch[1].data()};
+        long n_art = 0;
+        long ne = export_edges(cp, cr, cpar, cc0, cc1, cn, sc.n_nodes, S->cfg.n_trees, h_edges + 7 * off, 1L << 40, &n_art);
+        if (ne < 0) { octa::set_error("octa_sim_export_edges: export failed"); return -1; }
+        off += ne;
+    }
+    return 0;
+}
+
+extern "C" int octa_sim_stats(octa_sim *S, int64_t *h_stats) {
+    if (!S || !S->ran || !h_stats) { octa::set_error("octa_sim_stats: run the simulation first"); return -2; }
+    for (int s = 0; s < S->B; s++) {
+        const SampleScalars &sc = S->h_sc[s];
+        int64_t *o = h_stats + 8 * s;
+        o[0] = sc.err; o[1] = sc.py_pos; o[2] = sc.murray_steps; o[3] = sc.n_bif; o[4] = sc.respec;
+        o[5] = sc.n_nodes[0]; o[6] = sc.n_nodes[1];
+        memcpy(&o[7], &sc.faz_radius, 8);
+    }
+    return 0;
+}
+
+extern "C" int octa_sim_fields(octa_sim *S, int sample, double *h_oxy, int64_t cap_oxy, int64_t *n_oxy, double *h_co2,
+                               int64_t cap_co2, int64_t *n_co2) {
+    if (!S || !S->ran || sample < 0 || sample >= S->B) { octa::set_error("octa_sim_fields: bad arguments"); return -2; }
+    OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
+    const SampleScalars &sc = S->h_sc[sample];
+    if (n_oxy) *n_oxy = sc.n_oxy;
+    if (n_co2) *n_co2 = sc.n_co2;
+    if (h_oxy) {
+        int64_t n = sc.n_oxy < cap_oxy ? sc.n_oxy : cap_oxy;
+        OCTA_HIP_CHECK(hipMemcpy(h_oxy, S->P.oxy + (size_t)sample * OCAP * 3, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+    }
+    if (h_co2) {
+        int64_t n = sc.n_co2 < cap_co2 ? sc.n_co2 : cap_co2;
+        OCTA_HIP_CHECK(hipMemcpy(h_co2, S->P.co2 + (size_t)sample * CCAP * 3, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}

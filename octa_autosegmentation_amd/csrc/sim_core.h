@@ -1,0 +1,1177 @@
+// sim_core.h -- the space-colonisation vessel-graph simulator as per-sample, block-cooperative
+// phases for gfx950 (one 256-thread workgroup advances one sample; B samples advance in lock-step,
+// one launch per phase group). The same source compiles as plain host C++ (one "thread") for
+// tests/native/sim_core_host.cpp so that the phase logic can be checked against the oracle on a
+// machine without a GPU -- test infrastructure, never a product fallback.
+//
+// Reference semantics restated here (file:line under the reference tree):
+//   greenhouse.py:319-341  sample_oxygen_sinks      -> phase_sample
+//   greenhouse.py:343-366  assign_attraction_points -> phase_assign (nearest ACTIVE node within delta,
+//                                                      dict order = order of first hit)
+//   greenhouse.py:157-307  grow_vessels             -> phase_pre (per-node geometry, parallel) +
+//                                                      phase_seq (ordered pass: RNG draws, node creation,
+//                                                      Murray propagation arterial_tree.py:174-184)
+//   greenhouse.py:98-112   O2 -> CO2 conversion     -> phase_satisfy_art (cKDTree result order + CPython
+//                                                      set iteration order are part of the result)
+//   greenhouse.py:120-123  CO2 removal              -> phase_satisfy_ven
+// Parameters per iteration (greenhouse.py:139-155 expansion, :34-51 mode switch) do not depend on the
+// data, so the host tabulates them (IterParams).
+//
+// Data layout in HBM (per sample, struct-of-arrays, fixed capacities; see SimArrays): node positions
+// xyz-interleaved doubles, radii, kappa, parent/child ids, active flags; ordered O2 / CO2 lists; the
+// pre-generated candidate stream and Python-uniform stream; scratch for assignment / grouping.
+// All arithmetic is IEEE double, -ffp-contract=off, fma() explicit where the reference goes through
+// OpenBLAS ddot; pow through gpow (bit-exact glibc pow).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <algorithm>
+#include "gpow.h"
+
+namespace octa_simk {
+
+constexpr int NCAP = 16384;    // nodes per forest
+constexpr int OCAP = 13312;    // live O2 sinks (LDS-resident kd keys bound this)
+constexpr int CCAP = 8192;     // live CO2 sources
+constexpr int GCAP = 8192;     // nodes with attractors per growth pass
+constexpr int SORTCAP = 16384; // keys per block sort
+constexpr int PCAP = 16384;    // (new node, sink) hit pairs per iteration
+constexpr int SETCAP = 16384;  // slots of the emulated CPython set
+constexpr int PYCAP = 32768;   // pre-generated random.uniform draws per sample
+constexpr int MAXKEPT = 256;   // attractors shipped with one bifurcation request
+constexpr int NCANDCAP = 8192; // candidates per iteration
+constexpr int TILE = 1024;     // points per LDS tile in brute-force queries
+constexpr int ACCCAP = 2048;   // accepted sinks per iteration
+constexpr int KD_RANGES = 1024; // ranges per kd level (> OCAP / 17)
+
+enum ErrBits { ERR_NODE_CAP = 1, ERR_OXY_CAP = 2, ERR_CO2_CAP = 4, ERR_GROUP_CAP = 8, ERR_PAIR_CAP = 16, ERR_SET_CAP = 32,
+               ERR_PY_CAP = 64, ERR_KEPT_CAP = 128, ERR_REQ_CAP = 256, ERR_ACC_CAP = 512, ERR_MISSING_BIF = 1024 };
+
+struct IterParams {
+    int t, first_mode, N, pad;
+    double eps_n, eps_s, eps_k, delta_art, delta_ven, d, gamma_art, gamma_ven, phi, omega, kappa;
+};
+
+struct SimConst {
+    double ps, r, rotation_radius, fc0, fc1, sx, sy, sz;
+    int n_iter, n_max;  // iterations, max candidates per iteration (stride of the candidate stream)
+};
+
+// growth record of one node with attractors (one per group, dict order)
+struct __attribute__((aligned(8))) Rec {
+    double newpos[3];
+    double thr;       // (dist_to_center / (2 FAZ_radius)) ** 5
+    double r1_used;   // inter nodes: child radius the speculation used
+    int node;
+    int req;          // bifurcation request id or -1
+    unsigned char type;     // 0 none, 1 leaf that grows, 3 inter node (grow says whether it sprouts)
+    unsigned char draw;     // consumes one random.uniform
+    unsigned char ang_gt90; // angle(vector_to_center, avg_xy) > 90
+    unsigned char grow;     // inter nodes: reaches the draw with the radius used
+    unsigned char pad[4];
+};
+
+struct __attribute__((aligned(8))) BifRequest {
+    int sample, n;
+    double pos[3];
+    double r, kappa, d;
+    double atts[MAXKEPT * 3];
+};
+
+struct SampleScalars {
+    double faz_radius;
+    int n_nodes[2];
+    int n_oxy, n_co2;
+    int py_pos, py_cap;
+    int err;
+    int new_begin[2], new_end[2];
+    int n_groups[2];
+    int n_sorted[2];
+    long murray_steps;
+    long n_bif;
+    long respec;
+};
+
+// pointers to ONE sample's slices
+struct SimArrays {
+    double *npos[2];   // [NCAP*3]
+    double *nrad[2];   // [NCAP]
+    double *nkap[2];   // [NCAP]
+    int *npar[2], *nch0[2], *nch1[2];  // [NCAP]
+    unsigned char *nnch[2], *nact[2];  // [NCAP]
+    double *oxy;       // [OCAP*3]
+    double *co2;       // [CCAP*3]
+    const double *cand;  // [n_iter][n_max][3]
+    const double *py_u;  // [PYCAP]
+    // scratch
+    int *nn;             // [OCAP] nearest active node per attractor
+    int *first_att;      // [NCAP]
+    int *act_list;       // [NCAP]
+    unsigned *sorted;    // [SORTCAP] sorted (first_att<<14 | attractor) keys
+    int *gnode, *gstart, *gcount;  // [GCAP]
+    Rec *rec;            // [GCAP]
+    unsigned short *kd_idx, *kd_rank;  // [OCAP]
+    unsigned char *removed;  // [OCAP]
+    unsigned char *ven_near; // [OCAP]
+    unsigned long long *hashes;  // [OCAP]
+    unsigned *pairs;     // [PCAP]
+    unsigned long long *set_hash;  // [SETCAP]
+    int *set_key;        // [SETCAP]
+    int *tmp_int;        // [OCAP + NCANDCAP] general scratch
+    double *tmp_dbl;     // [OCAP*3] general scratch (stable compaction staging)
+    SampleScalars *sc;
+};
+
+// ------------------------------------------------------------------ execution abstraction
+struct Blk {
+    int tid, nth;
+    unsigned char *smem;  // LDS (device) or heap (host emulation); first 2 KiB reserved for collectives
+    OCTA_HD inline void sync() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __syncthreads();
+#endif
+    }
+    OCTA_HD inline int *coll() const { return reinterpret_cast<int *>(smem); }
+    OCTA_HD inline unsigned char *user() const { return smem + 2048; }
+};
+
+// exclusive scan of one int per thread; returns block total. Contains block syncs.
+OCTA_HD inline int blk_scan(const Blk &b, int v, int *excl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = b.tid & 63, wv = b.tid >> 6, nw = (b.nth + 63) >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int u = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += u;
+    }
+    int *sh = b.coll();
+    b.sync();
+    if (lane == 63 || b.tid == b.nth - 1) sh[wv] = inc;
+    b.sync();
+    if (b.tid == 0) {
+        int s = 0;
+        for (int k = 0; k < nw; k++) { int t = sh[k]; sh[k] = s; s += t; }
+        sh[64] = s;
+    }
+    b.sync();
+    *excl = sh[wv] + inc - v;
+    int tot = sh[64];
+    return tot;
+#else
+    (void)b;
+    *excl = 0;
+    return v;
+#endif
+}
+
+OCTA_HD inline void atomic_min_int(int *p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
+OCTA_HD inline int atomic_add_int(int *p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, v);
+#else
+    int o = *p; *p = o + v; return o;
+#endif
+}
+OCTA_HD inline void atomic_or_int(int *p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(p, v);
+#else
+    *p |= v;
+#endif
+}
+
+// ascending sort of n_pow2 32-bit keys that live in LDS
+OCTA_HD inline void blk_sort_u32(const Blk &b, unsigned *keys, int n_pow2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int k = 2; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            b.sync();
+            for (int i = b.tid; i < n_pow2; i += b.nth) {
+                int l = i ^ j;
+                if (l > i) {
+                    unsigned a = keys[i], c = keys[l];
+                    bool up = (i & k) == 0;
+                    if ((a > c) == up) { keys[i] = c; keys[l] = a; }
+                }
+            }
+        }
+    }
+    b.sync();
+#else
+    (void)b;
+    std::sort(keys, keys + n_pow2);
+#endif
+}
+
+// ------------------------------------------------------------------ vector helpers (as in the oracle)
+struct V3 { double x, y, z; };
+OCTA_HD inline V3 v3(double x, double y, double z) { V3 v = {x, y, z}; return v; }
+OCTA_HD inline V3 ld3(const double *p) { return v3(p[0], p[1], p[2]); }
+OCTA_HD inline void st3(double *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+OCTA_HD inline V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+OCTA_HD inline V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+OCTA_HD inline V3 mul(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+OCTA_HD inline V3 divs(V3 a, double s) { return v3(a.x / s, a.y / s, a.z / s); }
+OCTA_HD inline double norm3(V3 v) { return sqrt(fma(v.z, v.z, fma(v.y, v.y, v.x * v.x))); }  // OpenBLAS ddot form
+OCTA_HD inline double norm2(double a, double c) { return sqrt(fma(c, c, a * a)); }
+OCTA_HD inline double dot3_blas(V3 a, V3 c) { return fma(a.z, c.z, fma(a.y, c.y, a.x * c.x)); }
+OCTA_HD inline double dot2_blas(double a0, double a1, double b0, double b1) { return fma(a1, b1, a0 * b0); }
+OCTA_HD inline V3 unit(V3 v) { return divs(v, norm3(v)); }
+OCTA_HD inline double rownorm(V3 v) { return sqrt((v.x * v.x + v.y * v.y) + v.z * v.z); }
+OCTA_HD inline V3 cross(V3 a, V3 c) { return v3(a.y * c.z - a.z * c.y, a.z * c.x - a.x * c.z, a.x * c.y - a.y * c.x); }
+OCTA_HD inline double sqdist(V3 a, V3 c) {
+    double dx = a.x - c.x, dy = a.y - c.y, dz = a.z - c.z;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+OCTA_HD inline double clip1(double c) { return fmin(fmax(c, -1.0), 1.0); }
+OCTA_HD inline double rad2deg() { return 180.0 / 3.14159265358979323846; }
+OCTA_HD inline double deg2rad() { return 3.14159265358979323846 / 180.0; }
+OCTA_HD inline double angle_uv(V3 u, double nu, V3 v) {
+    double c = ((u.x * v.x + u.y * v.y) + u.z * v.z) / nu / rownorm(v);
+    return acos(clip1(c)) * rad2deg();
+}
+OCTA_HD inline double angle2(double u0, double u1, double v0, double v1) {
+    double c = dot2_blas(u0, u1, v0, v1) / norm2(u0, u1) / norm2(v0, v1);
+    return acos(clip1(c)) * rad2deg();
+}
+OCTA_HD inline double oxygen_distance(double rad, double ps) {  // greenhouse.py:309-317
+    const double c_oxygen = 203.9e-3, kap = 0.02 * c_oxygen, r0 = 3.5e-3;
+    double q = rad * ps / r0;
+    double c1 = kap * q * exp(1 - q);
+    return c1 * 6 / ps;
+}
+
+// ------------------------------------------------------------------ CPython hashing (float, 3-tuple)
+OCTA_HD inline unsigned long long py_hash_double(double v) {
+    const unsigned long long MOD = (1ULL << 61) - 1;
+    int e;
+    double m = frexp(v, &e);
+    int sign = 1;
+    if (m < 0) { sign = -1; m = -m; }
+    unsigned long long x = 0;
+    while (m != 0.0) {
+        x = ((x << 28) & MOD) | x >> (61 - 28);
+        m *= 268435456.0;
+        e -= 28;
+        unsigned long long y = (unsigned long long)m;
+        m -= (double)y;
+        x += y;
+        if (x >= MOD) x -= MOD;
+    }
+    e = e >= 0 ? e % 61 : 61 - 1 - ((-1 - e) % 61);
+    x = ((x << e) & MOD) | x >> (61 - e);
+    if (sign < 0) x = 0ULL - x;
+    if (x == ~0ULL) x = ~0ULL - 1;
+    return x;
+}
+OCTA_HD inline unsigned long long py_hash_tuple3(V3 t) {
+    const unsigned long long P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P5 = 2870177450012600261ULL;
+    unsigned long long acc = P5;
+    double c[3] = {t.x, t.y, t.z};
+    for (int i = 0; i < 3; i++) {
+        acc += py_hash_double(c[i]) * P2;
+        acc = (acc << 31) | (acc >> 33);
+        acc *= P1;
+    }
+    acc += 3ULL ^ (P5 ^ 3527539ULL);
+    if (acc == ~0ULL) return 1546275796ULL;
+    return acc;
+}
+
+// CPython 3.10 set (add only): table arrays in global scratch, run by ONE thread
+struct PySetView {
+    unsigned long long *hash;
+    int *key;
+    int mask, fill, used;
+    int *err;
+};
+OCTA_HD inline void pyset_init(PySetView &s) {
+    for (int i = 0; i < 8; i++) s.key[i] = -1;
+    s.mask = 7; s.fill = 0; s.used = 0;
+}
+OCTA_HD inline void pyset_insert_clean(unsigned long long *h, int *k, int mask, int key, unsigned long long hash) {
+    unsigned long long perturb = hash;
+    unsigned long long i = hash & (unsigned long long)mask;
+    while (true) {
+        unsigned long long e = i;
+        int probes = (i + 9 <= (unsigned long long)mask) ? 9 : 0;
+        do {
+            if (k[e] < 0) { k[e] = key; h[e] = hash; return; }
+            e++;
+        } while (probes--);
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & (unsigned long long)mask;
+    }
+}
+// resize into the upper half of the scratch arrays, then move down (SETCAP bounds the table)
+OCTA_HD inline void pyset_resize(PySetView &s, int minused) {
+    int newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    if (newsize > SETCAP / 2) { atomic_or_int(s.err, ERR_SET_CAP); return; }
+    unsigned long long *nh = s.hash + SETCAP / 2;
+    int *nk = s.key + SETCAP / 2;
+    for (int i = 0; i < newsize; i++) nk[i] = -1;
+    for (int i = 0; i <= s.mask; i++)
+        if (s.key[i] >= 0) pyset_insert_clean(nh, nk, newsize - 1, s.key[i], s.hash[i]);
+    for (int i = 0; i < newsize; i++) { s.key[i] = nk[i]; s.hash[i] = nh[i]; }
+    s.mask = newsize - 1;
+    s.fill = s.used;
+}
+OCTA_HD inline void pyset_add(PySetView &s, int key, unsigned long long hash) {
+    unsigned long long perturb = hash;
+    unsigned long long i = hash & (unsigned long long)s.mask;
+    while (true) {
+        unsigned long long e = i;
+        int probes = (i + 9 <= (unsigned long long)s.mask) ? 9 : 0;
+        do {
+            if (s.key[e] < 0) {
+                s.fill++; s.used++;
+                s.key[e] = key; s.hash[e] = hash;
+                if ((long)s.fill * 5 < (long)s.mask * 3) return;
+                pyset_resize(s, s.used > 50000 ? s.used * 2 : s.used * 4);
+                return;
+            }
+            if (s.hash[e] == hash && s.key[e] == key) return;
+            e++;
+        } while (probes--);
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & (unsigned long long)s.mask;
+    }
+}
+
+// ------------------------------------------------------------------ libstdc++ std::nth_element restated
+// Elements are (key, idx) pairs ordered by (key, idx) -- scipy's index_compare for one split dimension.
+struct KdPair {
+    double *key;
+    unsigned short *idx;
+};
+OCTA_HD inline bool kd_less(const KdPair &a, int i, int j) {
+    double x = a.key[i], y = a.key[j];
+    if (x == y) return a.idx[i] < a.idx[j];
+    return x < y;
+}
+OCTA_HD inline bool kd_less_vi(double xv, unsigned short xi, const KdPair &a, int j) {
+    double y = a.key[j];
+    if (xv == y) return xi < a.idx[j];
+    return xv < y;
+}
+OCTA_HD inline bool kd_less_iv(const KdPair &a, int i, double yv, unsigned short yi) {
+    double x = a.key[i];
+    if (x == yv) return a.idx[i] < yi;
+    return x < yv;
+}
+OCTA_HD inline void kd_swap(const KdPair &a, int i, int j) {
+    double t = a.key[i]; a.key[i] = a.key[j]; a.key[j] = t;
+    unsigned short u = a.idx[i]; a.idx[i] = a.idx[j]; a.idx[j] = u;
+}
+OCTA_HD inline void kd_push_heap(const KdPair &a, int first, int hole, int top, double vv, unsigned short vi) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && kd_less_iv(a, first + parent, vv, vi)) {
+        a.key[first + hole] = a.key[first + parent]; a.idx[first + hole] = a.idx[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a.key[first + hole] = vv; a.idx[first + hole] = vi;
+}
+OCTA_HD inline void kd_adjust_heap(const KdPair &a, int first, int hole, int len, double vv, unsigned short vi) {
+    const int top = hole;
+    int second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (kd_less(a, first + second, first + (second - 1))) second--;
+        a.key[first + hole] = a.key[first + second]; a.idx[first + hole] = a.idx[first + second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        a.key[first + hole] = a.key[first + (second - 1)]; a.idx[first + hole] = a.idx[first + (second - 1)];
+        hole = second - 1;
+    }
+    kd_push_heap(a, first, hole, top, vv, vi);
+}
+OCTA_HD inline void kd_heap_select(const KdPair &a, int first, int middle, int last) {
+    int len = middle - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        while (true) {
+            double vv = a.key[first + parent]; unsigned short vi = a.idx[first + parent];
+            kd_adjust_heap(a, first, parent, len, vv, vi);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    for (int i = middle; i < last; ++i)
+        if (kd_less(a, i, first)) {
+            double vv = a.key[i]; unsigned short vi = a.idx[i];
+            a.key[i] = a.key[first]; a.idx[i] = a.idx[first];
+            kd_adjust_heap(a, first, 0, middle - first, vv, vi);
+        }
+}
+OCTA_HD inline void kd_nth_element(const KdPair &a, int first, int nth, int last) {
+    if (first == last || nth == last) return;
+    int n = last - first, lg = 0;
+    while ((n >> (lg + 1)) > 0) lg++;
+    int depth = lg * 2;
+    while (last - first > 3) {
+        if (depth == 0) {
+            kd_heap_select(a, first, nth + 1, last);
+            kd_swap(a, first, nth);
+            return;
+        }
+        --depth;
+        // __unguarded_partition_pivot
+        int mid = first + (last - first) / 2;
+        int A = first + 1, B = mid, C = last - 1;
+        if (kd_less(a, A, B)) {
+            if (kd_less(a, B, C)) kd_swap(a, first, B);
+            else if (kd_less(a, A, C)) kd_swap(a, first, C);
+            else kd_swap(a, first, A);
+        } else if (kd_less(a, A, C)) kd_swap(a, first, A);
+        else if (kd_less(a, B, C)) kd_swap(a, first, C);
+        else kd_swap(a, first, B);
+        int lo = first + 1, hi = last;
+        while (true) {
+            while (kd_less(a, lo, first)) ++lo;
+            --hi;
+            while (kd_less(a, first, hi)) --hi;
+            if (!(lo < hi)) break;
+            kd_swap(a, lo, hi);
+            ++lo;
+        }
+        int cut = lo;
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    // __insertion_sort
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        double vv = a.key[i]; unsigned short vi = a.idx[i];
+        if (kd_less(a, i, first)) {
+            for (int k = i; k > first; --k) { a.key[k] = a.key[k - 1]; a.idx[k] = a.idx[k - 1]; }
+            a.key[first] = vv; a.idx[first] = vi;
+        } else {
+            int lastp = i, next = i - 1;
+            while (kd_less_vi(vv, vi, a, next)) {
+                a.key[lastp] = a.key[next]; a.idx[lastp] = a.idx[next];
+                lastp = next; --next;
+            }
+            a.key[lastp] = vv; a.idx[lastp] = vi;
+        }
+    }
+}
+
+// scipy cKDTree build order (leafsize 16, compact, median): fills kd_idx (tree.indices) and kd_rank.
+// Level-synchronous: range boundaries depend only on n; a range that became a leaf is marked done.
+// LDS: key double[OCAP] + idx u16[OCAP] + per-level range table.
+OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned short *out_idx, unsigned short *out_rank) {
+    double *key = reinterpret_cast<double *>(b.user());
+    unsigned short *idx = reinterpret_cast<unsigned short *>(b.user() + (size_t)OCAP * 8);
+    int *tab = reinterpret_cast<int *>(b.user() + (size_t)OCAP * 10);  // 5 tables of KD_RANGES ints
+    int *rs = tab, *re = tab + KD_RANGES, *rd = tab + 2 * KD_RANGES;     // range start / end / split dim (-1 = leaf)
+    int *rs2 = tab + 3 * KD_RANGES, *re2 = tab + 4 * KD_RANGES;          // next level
+    for (int i = b.tid; i < n; i += b.nth) idx[i] = (unsigned short)i;
+    if (b.tid == 0) { rs[0] = 0; re[0] = n; }
+    b.sync();
+    int nr = (n > 0) ? 1 : 0;
+    KdPair kp = {key, idx};
+    while (nr > 0) {
+        // 1. split dimension per range (first dim with the largest spread), cooperative for long ranges
+        for (int q = 0; q < nr; q++) {
+            int s = rs[q], e = re[q];
+            if (e - s <= 16) { if (b.tid == 0) rd[q] = -1; continue; }
+            if (e - s >= 4 * b.nth || b.nth == 1) {
+                double mx[3], mn[3];
+                bool any = false;
+                for (int i = s + b.tid; i < e; i += b.nth) {
+                    const double *p = pts + 3 * (int)idx[i];
+                    for (int k = 0; k < 3; k++) {
+                        if (!any) { mx[k] = mn[k] = p[k]; }
+                        else { mx[k] = mx[k] > p[k] ? mx[k] : p[k]; mn[k] = mn[k] < p[k] ? mn[k] : p[k]; }
+                    }
+                    any = true;
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+                // wave reduce then cross-wave via atomics on LDS doubles encoded as ordered ints
+                for (int k = 0; k < 3; k++) {
+                    double a1 = any ? mx[k] : -INFINITY, a2 = any ? mn[k] : INFINITY;
+                    for (int d = 32; d > 0; d >>= 1) {
+                        double o1 = __shfl_xor(a1, d, 64), o2 = __shfl_xor(a2, d, 64);
+                        a1 = a1 > o1 ? a1 : o1; a2 = a2 < o2 ? a2 : o2;
+                    }
+                    mx[k] = a1; mn[k] = a2;
+                }
+                double *wred = reinterpret_cast<double *>(b.smem + 512);  // [nwaves][6] doubles, nwaves <= 16
+                b.sync();
+                if ((b.tid & 63) == 0) for (int k = 0; k < 3; k++) { wred[(b.tid >> 6) * 6 + k] = mx[k]; wred[(b.tid >> 6) * 6 + 3 + k] = mn[k]; }
+                b.sync();
+                if (b.tid == 0) {
+                    int nw = (b.nth + 63) >> 6;
+                    for (int k = 0; k < 3; k++) {
+                        double a1 = wred[k], a2 = wred[3 + k];
+                        for (int w = 1; w < nw; w++) { a1 = a1 > wred[w * 6 + k] ? a1 : wred[w * 6 + k]; a2 = a2 < wred[w * 6 + 3 + k] ? a2 : wred[w * 6 + 3 + k]; }
+                        mx[k] = a1; mn[k] = a2;
+                    }
+                }
+#endif
+                if (b.tid == 0) {
+                    int d = 0; double size = 0;
+                    for (int k = 0; k < 3; k++) if (mx[k] - mn[k] > size) { d = k; size = mx[k] - mn[k]; }
+                    rd[q] = (mx[d] == mn[d]) ? -1 : d;
+                }
+                b.sync();
+            }
+        }
+        b.sync();
+        // short ranges: one thread per range
+        for (int q = b.tid; q < nr; q += b.nth) {
+            int s = rs[q], e = re[q];
+            if (e - s <= 16 || e - s >= 4 * b.nth || b.nth == 1) continue;
+            double mx[3], mn[3];
+            const double *p0 = pts + 3 * (int)idx[s];
+            for (int k = 0; k < 3; k++) mx[k] = mn[k] = p0[k];
+            for (int i = s + 1; i < e; i++) {
+                const double *p = pts + 3 * (int)idx[i];
+                for (int k = 0; k < 3; k++) { mx[k] = mx[k] > p[k] ? mx[k] : p[k]; mn[k] = mn[k] < p[k] ? mn[k] : p[k]; }
+            }
+            int d = 0; double size = 0;
+            for (int k = 0; k < 3; k++) if (mx[k] - mn[k] > size) { d = k; size = mx[k] - mn[k]; }
+            rd[q] = (mx[d] == mn[d]) ? -1 : d;
+        }
+        b.sync();
+        // 2. gather the split-dimension keys (ranges are disjoint slices of the key array)
+        for (int q = 0; q < nr; q++) {
+            int d = rd[q];
+            if (d < 0) continue;
+            int s = rs[q], e = re[q];
+            if (e - s >= 4 * b.nth || b.nth == 1)
+                for (int i = s + b.tid; i < e; i += b.nth) key[i] = pts[3 * (int)idx[i] + d];
+        }
+        for (int q = b.tid; q < nr; q += b.nth) {
+            int d = rd[q];
+            if (d < 0) continue;
+            int s = rs[q], e = re[q];
+            if (e - s >= 4 * b.nth || b.nth == 1) continue;
+            for (int i = s; i < e; i++) key[i] = pts[3 * (int)idx[i] + d];
+        }
+        b.sync();
+        // 3. nth_element per range (one thread each)
+        for (int q = b.tid; q < nr; q += b.nth) {
+            int d = rd[q];
+            if (d < 0) continue;
+            int s = rs[q], e = re[q];
+            kd_nth_element(kp, s, s + (e - s) / 2, e);
+        }
+        b.sync();
+        // 4. children that are still longer than a leaf form the next level
+        if (b.tid == 0) {
+            int cnt = 0;
+            for (int q = 0; q < nr; q++) {
+                if (rd[q] < 0) continue;
+                int s = rs[q], e = re[q], m = s + (e - s) / 2;
+                if (m - s > 16 && cnt < KD_RANGES) { rs2[cnt] = s; re2[cnt] = m; cnt++; }
+                if (e - m > 16 && cnt < KD_RANGES) { rs2[cnt] = m; re2[cnt] = e; cnt++; }
+            }
+            b.coll()[101] = cnt;
+        }
+        b.sync();
+        nr = b.coll()[101];
+        { int *t = rs; rs = rs2; rs2 = t; t = re; re = re2; re2 = t; }
+        b.sync();
+    }
+    for (int i = b.tid; i < n; i += b.nth) { out_idx[i] = idx[i]; out_rank[idx[i]] = (unsigned short)i; }
+    b.sync();
+}
+
+// ------------------------------------------------------------------ Murray propagation (one thread)
+OCTA_HD inline void murray_to_root(const SimArrays &A, int f, int id) {
+    double *rad = A.nrad[f];
+    const double *kap = A.nkap[f];
+    long steps = 0;
+    while (id >= 0) {
+        int par = A.npar[f][id];
+        int nch = A.nnch[f][id];
+        if (par < 0 || nch == 0) break;
+        double k = kap[id];
+        double s = octa_gpow::gpow(rad[A.nch0[f][id]], k);
+        if (nch >= 2) s = s + octa_gpow::gpow(rad[A.nch1[f][id]], k);
+        double rp = octa_gpow::gpow(s, 1.0 / k);
+        steps++;
+        if (rad[id] == rp) break;
+        rad[id] = rp;
+        id = par;
+    }
+    A.sc->murray_steps += steps;
+}
+
+OCTA_HD inline int add_node(const SimArrays &A, int f, V3 p, double r, int parent, double kappa) {
+    int id = A.sc->n_nodes[f];
+    if (id >= NCAP) { atomic_or_int(&A.sc->err, ERR_NODE_CAP); return -1; }
+    A.sc->n_nodes[f] = id + 1;
+    st3(A.npos[f] + 3 * id, p);
+    A.nrad[f][id] = r; A.nkap[f][id] = kappa; A.npar[f][id] = parent;
+    A.nch0[f][id] = -1; A.nch1[f][id] = -1; A.nnch[f][id] = 0; A.nact[f][id] = 1;
+    if (parent >= 0) {
+        int c = A.nnch[f][parent];
+        if (c == 0) A.nch0[f][parent] = id; else if (c == 1) A.nch1[f][parent] = id;
+        A.nnch[f][parent] = (unsigned char)(c + 1);
+    }
+    return id;
+}
+
+// ------------------------------------------------------------------ phase: sample oxygen sinks
+OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int iter) {
+    SampleScalars *sc = A.sc;
+    const int N = P.N;
+    const double *cand = A.cand + (size_t)iter * C.n_max * 3;
+    const double en = fmax(P.eps_n, P.eps_k), es = P.eps_s;
+    const double en2 = en * en;
+    const double GSd = 76.0;
+    const double fcx = C.fc0 * GSd, fcy = C.fc1 * GSd, fr = sc->faz_radius * GSd * 0.5;
+    int *vlist = A.tmp_int;               // valid candidate indices, in order
+    int *plist = A.tmp_int + NCANDCAP;    // passing candidate indices, in order
+    // 1. is_valid_position (simulation_space.py:89-98), ordered compaction
+    int n_valid = 0;
+    for (int base = 0; base < N; base += b.nth) {
+        int i = base + b.tid;
+        int ok = 0;
+        if (i < N) {
+            V3 p = ld3(cand + 3 * i);
+            ok = !(p.x >= C.sx || p.y >= C.sy || p.z >= C.sz || p.x < 0 || p.y < 0 || p.z < 0);
+            if (ok) {
+                double dd = sqrt((p.x - fcx) * (p.x - fcx) + (p.y - fcy) * (p.y - fcy));
+                ok = dd > fr;
+            }
+        }
+        int ex;
+        int tot = blk_scan(b, ok, &ex);
+        if (ok) vlist[n_valid + ex] = i;
+        n_valid += tot;
+    }
+    b.sync();
+    // 2. tests against all arterial nodes (ball en, oxygen distance) and existing sinks (NN <= es)
+    double *tile = reinterpret_cast<double *>(b.user());   // [TILE][4]
+    const int n_art = sc->n_nodes[0];
+    const int n_oxy = sc->n_oxy;
+    int n_pass = 0;
+    for (int base = 0; base < n_valid; base += b.nth) {
+        int vi = base + b.tid;
+        bool live = vi < n_valid;
+        V3 c = live ? ld3(cand + 3 * vlist[vi]) : v3(0, 0, 0);
+        bool ok = live;
+        for (int t0 = 0; t0 < n_art; t0 += TILE) {
+            int cnt = n_art - t0 < TILE ? n_art - t0 : TILE;
+            b.sync();
+            for (int j = b.tid; j < cnt; j += b.nth) {
+                const double *p = A.npos[0] + 3 * (t0 + j);
+                tile[4 * j] = p[0]; tile[4 * j + 1] = p[1]; tile[4 * j + 2] = p[2];
+                tile[4 * j + 3] = oxygen_distance(A.nrad[0][t0 + j], C.ps);
+            }
+            b.sync();
+            if (ok)
+                for (int j = 0; j < cnt; j++) {
+                    double d2 = sqdist(v3(tile[4 * j], tile[4 * j + 1], tile[4 * j + 2]), c);
+                    if (d2 <= en2 && !(sqrt(d2) > tile[4 * j + 3])) { ok = false; break; }
+                }
+        }
+        for (int t0 = 0; t0 < n_oxy; t0 += TILE) {
+            int cnt = n_oxy - t0 < TILE ? n_oxy - t0 : TILE;
+            b.sync();
+            for (int j = b.tid; j < cnt; j += b.nth) {
+                const double *p = A.oxy + 3 * (t0 + j);
+                tile[4 * j] = p[0]; tile[4 * j + 1] = p[1]; tile[4 * j + 2] = p[2];
+            }
+            b.sync();
+            if (ok)
+                for (int j = 0; j < cnt; j++) {
+                    double d2 = sqdist(v3(tile[4 * j], tile[4 * j + 1], tile[4 * j + 2]), c);
+                    if (sqrt(d2) <= es) { ok = false; break; }
+                }
+        }
+        int ex;
+        int tot = blk_scan(b, ok ? 1 : 0, &ex);
+        if (ok) plist[n_pass + ex] = vlist[vi];
+        n_pass += tot;
+    }
+    b.sync();
+    // 3. ordered greedy acceptance against the sinks accepted earlier in this call (strict >)
+    double *acc = reinterpret_cast<double *>(b.user());  // [ACCCAP][3]
+    int *ctl = b.coll() + 100;
+    if (b.tid == 0) ctl[0] = 0;
+    b.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (b.tid < 64) {
+        const int lane = b.tid;
+        int acc_n = 0;
+        for (int q = 0; q < n_pass; q++) {
+            V3 c = ld3(cand + 3 * plist[q]);
+            bool conflict = false;
+            for (int j = lane; j < acc_n; j += 64)
+                if (!(rownorm(sub(c, ld3(acc + 3 * j))) > es)) conflict = true;
+            if (!__any(conflict)) {
+                if (acc_n < ACCCAP) { if (lane == 0) st3(acc + 3 * acc_n, c); }
+                else if (lane == 0) atomic_or_int(&sc->err, ERR_ACC_CAP);
+                acc_n++;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane == 0) ctl[0] = acc_n < ACCCAP ? acc_n : ACCCAP;
+    }
+#else
+    {
+        int acc_n = 0;
+        for (int q = 0; q < n_pass; q++) {
+            V3 c = ld3(cand + 3 * plist[q]);
+            bool conflict = false;
+            for (int j = 0; j < acc_n; j++)
+                if (!(rownorm(sub(c, ld3(acc + 3 * j))) > es)) { conflict = true; break; }
+            if (!conflict) {
+                if (acc_n < ACCCAP) st3(acc + 3 * acc_n, c); else atomic_or_int(&sc->err, ERR_ACC_CAP);
+                acc_n++;
+            }
+        }
+        ctl[0] = acc_n < ACCCAP ? acc_n : ACCCAP;
+    }
+#endif
+    b.sync();
+    int acc_n = ctl[0];
+    if (n_oxy + acc_n > OCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_OXY_CAP); acc_n = OCAP - n_oxy; }
+    for (int j = b.tid; j < acc_n * 3; j += b.nth) A.oxy[3 * n_oxy + j] = acc[j];
+    b.sync();
+    if (b.tid == 0) sc->n_oxy = n_oxy + acc_n;
+    b.sync();
+}
+
+// ------------------------------------------------------------------ phase: nearest active node + dict order
+OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const double *att, int n_att, double delta) {
+    SampleScalars *sc = A.sc;
+    const int n_nodes = sc->n_nodes[f];
+    // active node list (ascending id) and first_att reset
+    int n_act = 0;
+    for (int base = 0; base < n_nodes; base += b.nth) {
+        int i = base + b.tid;
+        int ok = (i < n_nodes) && A.nact[f][i];
+        if (i < n_nodes) A.first_att[i] = 0x7fffffff;
+        int ex;
+        int tot = blk_scan(b, ok, &ex);
+        if (ok) A.act_list[n_act + ex] = i;
+        n_act += tot;
+    }
+    b.sync();
+    double *tile = reinterpret_cast<double *>(b.user());  // [TILE][3]
+    int *tid_ids = reinterpret_cast<int *>(b.user() + (size_t)TILE * 24);  // [TILE]
+    for (int base = 0; base < n_att; base += b.nth) {
+        int a = base + b.tid;
+        bool live = a < n_att;
+        V3 p = live ? ld3(att + 3 * a) : v3(0, 0, 0);
+        double bd = INFINITY;
+        int best = -1;
+        for (int t0 = 0; t0 < n_act; t0 += TILE) {
+            int cnt = n_act - t0 < TILE ? n_act - t0 : TILE;
+            b.sync();
+            for (int j = b.tid; j < cnt; j += b.nth) {
+                int id = A.act_list[t0 + j];
+                const double *q = A.npos[f] + 3 * id;
+                tile[3 * j] = q[0]; tile[3 * j + 1] = q[1]; tile[3 * j + 2] = q[2];
+                tid_ids[j] = id;
+            }
+            b.sync();
+            if (live)
+                for (int j = 0; j < cnt; j++) {
+                    double d2 = sqdist(v3(tile[3 * j], tile[3 * j + 1], tile[3 * j + 2]), p);
+                    if (d2 < bd) { bd = d2; best = tid_ids[j]; }
+                }
+        }
+        if (live) {
+            int r = (best >= 0 && sqrt(bd) <= delta) ? best : -1;
+            A.nn[a] = r;
+            if (r >= 0) atomic_min_int(&A.first_att[r], a);
+        }
+    }
+    b.sync();
+    // sort keys (first_att[nn[a]] << 14 | a); unassigned -> 0xffffffff
+    unsigned *keys = reinterpret_cast<unsigned *>(b.user());
+    int n_pow2 = 1;
+    while (n_pow2 < n_att) n_pow2 <<= 1;
+    if (n_pow2 > SORTCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_OXY_CAP); n_pow2 = SORTCAP; }
+    for (int i = b.tid; i < n_pow2; i += b.nth) {
+        unsigned k = 0xffffffffu;
+        if (i < n_att) { int r = A.nn[i]; if (r >= 0) k = ((unsigned)A.first_att[r] << 14) | (unsigned)i; }
+        keys[i] = k;
+    }
+    b.sync();
+    blk_sort_u32(b, keys, n_pow2);
+    // groups (dict order) = runs of equal first_att
+    int n_sorted = 0, n_groups = 0;
+    for (int base = 0; base < n_pow2; base += b.nth) {
+        int i = base + b.tid;
+        unsigned k = (i < n_pow2) ? keys[i] : 0xffffffffu;
+        int valid = k != 0xffffffffu;
+        int head = valid && (i == 0 || (keys[i - 1] >> 14) != (k >> 14));
+        if (i < n_pow2) A.sorted[i] = k;
+        int ex;
+        int tot = blk_scan(b, head, &ex);
+        if (head) {
+            int g = n_groups + ex;
+            if (g < GCAP) { A.gnode[g] = A.nn[k & 16383u]; A.gstart[g] = i; }
+        }
+        n_groups += tot;
+        int ex2;
+        n_sorted += blk_scan(b, valid, &ex2);
+    }
+    b.sync();
+    if (n_groups > GCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_GROUP_CAP); n_groups = GCAP; }
+    for (int g = b.tid; g < n_groups; g += b.nth) A.gcount[g] = ((g + 1 < n_groups) ? A.gstart[g + 1] : n_sorted) - A.gstart[g];
+    if (b.tid == 0) { sc->n_groups[f] = n_groups; sc->n_sorted[f] = n_sorted; }
+    b.sync();
+}
+
+// ------------------------------------------------------------------ per-node growth geometry
+struct GrowCtx {
+    const SimArrays *A;
+    const SimConst *C;
+    const IterParams *P;
+    int f;
+    const double *att;
+    double gamma;
+};
+
+// inter-node sprouting (greenhouse.py:259-306) for group g with the CURRENT child radius
+OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
+    const SimArrays &A = *G.A;
+    const int f = G.f, id = A.gnode[g];
+    const double kappa = G.P->kappa, r = G.C->r, gamma = G.gamma, omega = G.P->omega, d = G.P->d;
+    R.type = 3; R.grow = 0; R.draw = 0; R.req = -1; R.node = id;
+    const V3 pos = ld3(A.npos[f] + 3 * id);
+    const int ch = A.nch0[f][id];
+    const double r1 = A.nrad[f][ch], r2 = r;
+    R.r1_used = r1;
+    using octa_gpow::gpow;
+    double rp = gpow(gpow(r1, kappa) + gpow(r2, kappa), 1 / kappa);
+    double rp4 = gpow(rp, 4.0), rp2 = gpow(rp, 2.0);
+    double phi1 = acos((rp4 + gpow(r1, 4.0) - gpow(r2, 4.0)) / (2 * rp2 * gpow(r1, 2.0))) * rad2deg();
+    double phi2 = acos((rp4 + gpow(r2, 4.0) - gpow(r1, 4.0)) / (2 * rp2 * gpow(r2, 2.0))) * rad2deg();
+    V3 dist_seg = sub(ld3(A.npos[f] + 3 * ch), pos);
+    V3 prox_seg = sub(pos, ld3(A.npos[f] + 3 * A.npar[f][id]));
+    double nd = norm3(dist_seg), npx = norm3(prox_seg);
+    double lo = phi1 + phi2 - gamma / 2, hi = phi1 + phi2 + gamma / 2, pl = phi2 + gamma / 2;
+    V3 avg = v3(0, 0, 0);
+    int kept = 0;
+    const int s = A.gstart[g], cnt = A.gcount[g];
+    for (int k = 0; k < cnt; k++) {
+        int a = (int)(A.sorted[s + k] & 16383u);
+        V3 w = sub(ld3(G.att + 3 * a), pos);
+        double ad = angle_uv(dist_seg, nd, w), ap = angle_uv(prox_seg, npx, w);
+        if (lo <= ad && ad <= hi && ap <= pl) {
+            V3 u = unit(w);
+            avg = kept == 0 ? u : add(avg, u);
+            kept++;
+        }
+    }
+    if (kept == 0) return;
+    V3 dv = unit(dist_seg);
+    V3 cr = cross(dv, avg);
+    if (cr.x == 0 && cr.y == 0 && cr.z == 0) return;
+    const double vc0 = G.C->fc0 - pos.x, vc1 = G.C->fc1 - pos.y;
+    R.grow = 1; R.draw = 1;
+    R.thr = gpow(norm2(vc0, vc1) / (2 * A.sc->faz_radius), 5.0);
+    R.ang_gt90 = angle2(vc0, vc1, avg.x, avg.y) > 90 ? 1 : 0;
+    V3 k = unit(cr);
+    double th = phi2 * deg2rad();
+    double ct = cos(th), st = sin(th);
+    V3 kxd = cross(k, dv);
+    V3 vrot = add(add(mul(dv, ct), mul(kxd, st)), mul(mul(k, dot3_blas(k, dv)), 1 - ct));
+    V3 gg = add(mul(unit(vrot), omega), mul(unit(avg), 1 - omega));
+    st3(R.newpos, add(pos, mul(unit(gg), d)));
+}
+
+// leaf growth (greenhouse.py:177-258); bifurcation candidates ship a request to the host
+OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs, int *req_count, int req_cap, int sample) {
+    const SimArrays &A = *G.A;
+    const int f = G.f, id = A.gnode[g];
+    const double r = G.C->r, gamma = G.gamma, omega = G.P->omega, d = G.P->d, kappa = G.P->kappa;
+    R.type = 0; R.grow = 0; R.draw = 0; R.req = -1; R.node = id; R.r1_used = 0;
+    const V3 pos = ld3(A.npos[f] + 3 * id);
+    V3 v = sub(pos, ld3(A.npos[f] + 3 * A.npar[f][id]));
+    double nv = norm3(v);
+    double lim = fmax(gamma / 2, 0.0);
+    V3 avg = v3(0, 0, 0);
+    int kept = 0;
+    double sum = 0;
+    const int s = A.gstart[g], cnt = A.gcount[g];
+    for (int k = 0; k < cnt; k++) {
+        int a = (int)(A.sorted[s + k] & 16383u);
+        V3 w = sub(ld3(G.att + 3 * a), pos);
+        double an = angle_uv(v, nv, w);
+        if (an <= lim) {
+            V3 u = unit(w);
+            avg = kept == 0 ? u : add(avg, u);
+            sum += an;
+            kept++;
+        }
+    }
+    if (kept == 0) return;
+    double mean = sum / (double)kept, var = 0;
+    for (int k = 0; k < cnt; k++) {
+        int a = (int)(A.sorted[s + k] & 16383u);
+        double an = angle_uv(v, nv, sub(ld3(G.att + 3 * a), pos));
+        if (an <= lim) var += (an - mean) * (an - mean);
+    }
+    double sd = sqrt(var / (double)kept);
+    const double vc0 = G.C->fc0 - pos.x, vc1 = G.C->fc1 - pos.y;
+    R.type = 1;
+    if (sd > G.P->phi) {
+        R.draw = 1;
+        R.thr = octa_gpow::gpow(norm2(vc0, vc1) / (2 * A.sc->faz_radius), 5.0);
+        R.ang_gt90 = angle2(vc0, vc1, avg.x, avg.y) > 90 ? 1 : 0;
+        if (R.ang_gt90) {
+            int q = atomic_add_int(req_count, 1);
+            if (q < req_cap && kept <= MAXKEPT) {
+                BifRequest &Q = reqs[q];
+                Q.sample = sample; Q.n = kept;
+                st3(Q.pos, pos);
+                Q.r = r; Q.kappa = kappa; Q.d = d;
+                int w = 0;
+                for (int k = 0; k < cnt; k++) {
+                    int a = (int)(A.sorted[s + k] & 16383u);
+                    V3 p = ld3(G.att + 3 * a);
+                    if (angle_uv(v, nv, sub(p, pos)) <= lim) { st3(Q.atts + 3 * w, p); w++; }
+                }
+                R.req = q;
+            } else {
+                atomic_or_int(&A.sc->err, kept > MAXKEPT ? ERR_KEPT_CAP : ERR_REQ_CAP);
+            }
+        }
+    }
+    // elongation (used unless the node bifurcates)
+    V3 gg = add(mul(unit(v), omega), mul(unit(avg), 1 - omega));
+    if (G.C->rotation_radius > 0 && G.P->t > 15) {
+        gg = unit(gg);
+        double cn = norm2(vc0, vc1);
+        double cv0 = vc0 / cn, cv1 = vc1 / cn;
+        V3 np_ = add(pos, mul(gg, d));
+        double dist_new = norm2(G.C->fc0 - np_.x, G.C->fc1 - np_.y);
+        double weight = fmax(G.P->first_mode ? 0.0 : 0.01, G.C->rotation_radius - dist_new);
+        weight = sqrt(weight);
+        V3 ort = v3(-cv1, cv0, 0);
+        if (angle2(gg.x, gg.y, ort.x, ort.y) > 90) ort = mul(ort, -1.0);
+        V3 outv = v3(-cv0, -cv1, 0);
+        gg = add(add(mul(gg, 1 - weight), mul(ort, 0.7 * weight)), mul(outv, 0.3 * weight));
+    }
+    st3(R.newpos, add(pos, mul(unit(gg), d)));
+}
+
+// parallel speculation over all groups of forest f
+OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
+                              const double *att, BifRequest *reqs, int *req_count, int req_cap, int sample) {
+    GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven};
+    const int ng = A.sc->n_groups[f];
+    for (int g = b.tid; g < ng; g += b.nth) {
+        Rec R;
+        memset(&R, 0, sizeof(R));
+        int id = A.gnode[g];
+        int nch = A.nnch[f][id], par = A.npar[f][id];
+        if (nch == 0) eval_leaf(G, g, R, reqs, req_count, req_cap, sample);
+        else if (par >= 0 && nch == 1) eval_inter(G, g, R);
+        else { R.type = 0; R.node = id; R.req = -1; }
+        A.rec[g] = R;
+    }
+    b.sync();
+}
+
+// ordered pass (one thread): RNG draws, node creation, Murray propagation, deactivation
+OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
+                              const double *att, const double *bif_results /* [req][6] */) {
+    SampleScalars *sc = A.sc;
+    if (b.tid == 0) {
+        GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven};
+        const int ng = sc->n_groups[f];
+        sc->new_begin[f] = sc->n_nodes[f];
+        for (int g = 0; g < ng; g++) {
+            Rec R = A.rec[g];
+            if (R.type == 0) continue;
+            const int id = R.node;
+            if (R.type == 1) {
+                bool bif = false;
+                if (R.draw) {
+                    if (sc->py_pos >= sc->py_cap) { sc->err |= ERR_PY_CAP; break; }
+                    double u = A.py_u[sc->py_pos++];
+                    bif = (R.thr > u) && R.ang_gt90;
+                }
+                if (bif) {
+                    if (R.req < 0) { sc->err |= ERR_MISSING_BIF; continue; }
+                    const double *o = bif_results + 6 * (size_t)R.req;
+                    add_node(A, f, v3(o[0], o[1], o[2]), C.r, id, P.kappa);
+                    add_node(A, f, v3(o[3], o[4], o[5]), C.r, id, P.kappa);
+                    murray_to_root(A, f, id);
+                    A.nact[f][id] = 0;
+                    sc->n_bif++;
+                } else {
+                    add_node(A, f, ld3(R.newpos), C.r, id, P.kappa);
+                }
+            } else {
+                // the speculation used the child radius at the start of the pass; redo it if an earlier
+                // Murray update in this pass changed that radius (sequential semantics of the reference)
+                if (A.nrad[f][A.nch0[f][id]] != R.r1_used) {
+                    eval_inter(G, g, R);
+                    sc->respec++;
+                }
+                if (!R.grow) continue;
+                if (sc->py_pos >= sc->py_cap) { sc->err |= ERR_PY_CAP; break; }
+                double u = A.py_u[sc->py_pos++];
+                if (R.thr <= u && !R.ang_gt90) continue;
+                add_node(A, f, ld3(R.newpos), C.r, id, P.kappa);
+                murray_to_root(A, f, id);
+                A.nact[f][id] = 0;
+            }
+        }
+        sc->new_end[f] = sc->n_nodes[f];
+    }
+    b.sync();
+}
+
+// stable removal of flagged points from an ordered list (element_mesh.py:196-211 delete_all)
+OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsigned char *removed, double *stage) {
+    int n_keep = 0;
+    for (int base = 0; base < n; base += b.nth) {
+        int i = base + b.tid;
+        int keep = (i < n) && !removed[i];
+        int ex;
+        int tot = blk_scan(b, keep, &ex);
+        if (keep) { int w = n_keep + ex; stage[3 * w] = pts[3 * i]; stage[3 * w + 1] = pts[3 * i + 1]; stage[3 * w + 2] = pts[3 * i + 2]; }
+        n_keep += tot;
+    }
+    b.sync();
+    for (int j = b.tid; j < n_keep * 3; j += b.nth) pts[j] = stage[j];
+    b.sync();
+    return n_keep;
+}
+
+// ------------------------------------------------------------------ phase: satisfied O2 sinks -> CO2
+OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const IterParams &P) {
+    SampleScalars *sc = A.sc;
+    const int nb = sc->new_begin[0], ne = sc->new_end[0];
+    const int n_new = ne - nb, n_oxy = sc->n_oxy;
+    if (n_new <= 0 || n_oxy <= 0) return;
+    const double ek = P.eps_k, ek2 = ek * ek;
+    // 1. cKDTree order of the O2 list
+    kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank);
+    for (int i = b.tid; i < n_oxy; i += b.nth) A.removed[i] = 0;
+    int *ctl = b.coll() + 100;
+    if (b.tid == 0) ctl[0] = 0;
+    b.sync();
+    // 2. (new node, sink) hit pairs, key = node_local << 14 | kd rank
+    double *tile = reinterpret_cast<double *>(b.user());  // new node positions [n_new][3] (<= TILE chunks)
+    for (int c0 = 0; c0 < n_new; c0 += TILE) {
+        int cc = n_new - c0 < TILE ? n_new - c0 : TILE;
+        b.sync();
+        for (int j = b.tid; j < cc * 3; j += b.nth) tile[j] = A.npos[0][3 * (nb + c0) + j];
+        b.sync();
+        for (int o = b.tid; o < n_oxy; o += b.nth) {
+            V3 p = ld3(A.oxy + 3 * o);
+            for (int j = 0; j < cc; j++) {
+                if (sqdist(p, v3(tile[3 * j], tile[3 * j + 1], tile[3 * j + 2])) <= ek2) {
+                    int q = atomic_add_int(&ctl[0], 1);
+                    if (q < PCAP) A.pairs[q] = ((unsigned)(c0 + j) << 14) | (unsigned)A.kd_rank[o];
+                    A.removed[o] = 1;
+                }
+            }
+        }
+    }
+    b.sync();
+    int n_pairs = ctl[0];
+    if (n_pairs > PCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_PAIR_CAP); n_pairs = PCAP; }
+    if (n_new > (1 << 18)) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_PAIR_CAP); }
+    // 3. venous proximity + tuple hash for every removed sink
+    const int n_ven = sc->n_nodes[1];
+    for (int base = 0; base < n_oxy; base += b.nth) {
+        int o = base + b.tid;
+        bool live = (o < n_oxy) && A.removed[o];
+        V3 p = live ? ld3(A.oxy + 3 * o) : v3(0, 0, 0);
+        double bd = INFINITY;
+        for (int t0 = 0; t0 < n_ven; t0 += TILE) {
+            int cnt = n_ven - t0 < TILE ? n_ven - t0 : TILE;
+            b.sync();
+            for (int j = b.tid; j < cnt * 3; j += b.nth) tile[j] = A.npos[1][3 * t0 + j];
+            b.sync();
+            if (live)
+                for (int j = 0; j < cnt; j++) {
+                    double d2 = sqdist(v3(tile[3 * j], tile[3 * j + 1], tile[3 * j + 2]), p);
+                    if (d2 < bd) bd = d2;
+                }
+        }
+        if (live) {
+            A.ven_near[o] = (n_ven > 0 && sqrt(bd) <= ek) ? 1 : 0;
+            A.hashes[o] = py_hash_tuple3(p);
+        }
+    }
+    b.sync();
+    // 4. sort the pairs: new nodes in order, hits in cKDTree order
+    unsigned *keys = reinterpret_cast<unsigned *>(b.user());
+    int n_pow2 = 1;
+    while (n_pow2 < n_pairs) n_pow2 <<= 1;
+    for (int i = b.tid; i < n_pow2; i += b.nth) keys[i] = i < n_pairs ? A.pairs[i] : 0xffffffffu;
+    b.sync();
+    if (n_pairs > 0) blk_sort_u32(b, keys, n_pow2);
+    for (int i = b.tid; i < n_pairs; i += b.nth) A.pairs[i] = keys[i];
+    b.sync();
+    // 5. CPython set insertion order -> CO2 append order (one thread)
+    if (b.tid == 0) {
+        PySetView S;
+        S.hash = A.set_hash; S.key = A.set_key; S.err = &sc->err;
+        pyset_init(S);
+        for (int i = 0; i < n_pairs; i++) {
+            int o = (int)A.kd_idx[A.pairs[i] & 16383u];
+            if (!A.ven_near[o]) pyset_add(S, o, A.hashes[o]);
+        }
+        int n_co2 = sc->n_co2;
+        for (int e = 0; e <= S.mask; e++)
+            if (S.key[e] >= 0) {
+                if (n_co2 >= CCAP) { sc->err |= ERR_CO2_CAP; break; }
+                int o = S.key[e];
+                A.co2[3 * n_co2] = A.oxy[3 * o]; A.co2[3 * n_co2 + 1] = A.oxy[3 * o + 1]; A.co2[3 * n_co2 + 2] = A.oxy[3 * o + 2];
+                n_co2++;
+            }
+        sc->n_co2 = n_co2;
+    }
+    b.sync();
+    // 6. delete the satisfied sinks (order-preserving)
+    int keep = compact_points(b, A.oxy, n_oxy, A.removed, A.tmp_dbl);
+    if (b.tid == 0) sc->n_oxy = keep;
+    b.sync();
+}
+
+// ------------------------------------------------------------------ phase: CO2 near new venous nodes removed
+OCTA_HD inline void phase_satisfy_ven(const Blk &b, const SimArrays &A, const IterParams &P) {
+    SampleScalars *sc = A.sc;
+    const int nb = sc->new_begin[1], ne = sc->new_end[1];
+    const int n_new = ne - nb, n_co2 = sc->n_co2;
+    if (n_new <= 0 || n_co2 <= 0) return;
+    const double ek2 = P.eps_k * P.eps_k;
+    double *tile = reinterpret_cast<double *>(b.user());
+    for (int i = b.tid; i < n_co2; i += b.nth) A.removed[i] = 0;
+    b.sync();
+    for (int c0 = 0; c0 < n_new; c0 += TILE) {
+        int cc = n_new - c0 < TILE ? n_new - c0 : TILE;
+        b.sync();
+        for (int j = b.tid; j < cc * 3; j += b.nth) tile[j] = A.npos[1][3 * (nb + c0) + j];
+        b.sync();
+        for (int o = b.tid; o < n_co2; o += b.nth) {
+            V3 p = ld3(A.co2 + 3 * o);
+            for (int j = 0; j < cc; j++)
+                if (sqdist(p, v3(tile[3 * j], tile[3 * j + 1], tile[3 * j + 2])) <= ek2) { A.removed[o] = 1; break; }
+        }
+    }
+    b.sync();
+    int keep = compact_points(b, A.co2, n_co2, A.removed, A.tmp_dbl);
+    if (b.tid == 0) sc->n_co2 = keep;
+    b.sync();
+}
+
+}  // namespace octa_simk

@@ -1,0 +1,189 @@
+"""Batched drop-in for the reference's Greenhouse.develop_forest (vessel_graph_generation/greenhouse.py)
+on MI355X: B independent samples advance in lock-step inside liboctahip.so (octa_sim_* entry points).
+
+Sample k behaves like `random.seed(seeds[k]); np.random.seed(seeds[k])` followed by the reference's
+generate_vessel_graph.main(config) (generate_vessel_graph.py:24-56): same CSV rows, same radii.
+The host keeps only what the reference itself delegates to numpy/LAPACK: the leaf-bifurcation
+geometry (np.mean / np.cov / np.linalg.eig, greenhouse.py:205-233), served to the device in batches.
+"""
+import csv
+import ctypes
+import io
+
+import numpy as np
+
+from .. import _native
+
+MODE_KEYS = ["I", "N", "eps_n", "eps_s", "eps_k", "delta_art", "delta_ven", "gamma_art", "gamma_ven", "phi", "omega",
+             "kappa", "delta_sigma"]
+MAX_ATTS = 256
+
+
+class SimConfigStruct(ctypes.Structure):
+    _fields_ = [("param_scale", ctypes.c_double), ("d", ctypes.c_double), ("r", ctypes.c_double),
+                ("faz_radius_mean", ctypes.c_double), ("faz_radius_std", ctypes.c_double),
+                ("rotation_radius", ctypes.c_double), ("faz_center", ctypes.c_double * 2),
+                ("size", ctypes.c_double * 3), ("n_trees", ctypes.c_int), ("walls", ctypes.c_int * 4),
+                ("n_modes", ctypes.c_int), ("modes", (ctypes.c_double * 13) * 8)]
+
+
+REQ_DTYPE = np.dtype([("sample", np.int32), ("n", np.int32), ("pos", np.float64, 3), ("r", np.float64),
+                      ("kappa", np.float64), ("d", np.float64), ("atts", np.float64, (MAX_ATTS, 3))])
+BIF_FN = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p)
+
+
+def config_to_struct(config):
+    """Generator YAML dict (Greenhouse / Forest sections, docker/vessel_graph_gen_docker_config.yml) -> C struct."""
+    g, f = config["Greenhouse"], config["Forest"]
+    if f["type"] != "stumps":
+        raise NotImplementedError("only Forest.type == 'stumps' runs on the GPU path (forest.py:68-181)")
+    if g["SimulationSpace"].get("oxygen_sample_geometry_path") is not None:
+        raise NotImplementedError("fixed-geometry simulation spaces are not on the GPU path yet")
+    nc, nr = np.array(g["nerve_center"]) / g["param_scale"], np.array(g["nerve_radius"]) / g["param_scale"]
+    if all(nc - nr <= 1):
+        raise NotImplementedError("a nerve disc inside the field of view is not on the GPU path yet")
+    walls = f["source_walls"]
+    if walls.get("z0") or walls.get("z1"):
+        raise NotImplementedError("z source walls are not on the GPU path yet")
+    if [k for k, v in walls.items() if v] != [k for k in ("x0", "x1", "y0", "y1") if walls.get(k)]:
+        raise NotImplementedError("source_walls must be listed in x0, x1, y0, y1 order")
+    p = SimConfigStruct()
+    p.param_scale, p.d, p.r = g["param_scale"], g["d"], g["r"]
+    p.faz_radius_mean, p.faz_radius_std = g["FAZ_radius_bound"]
+    p.rotation_radius = g["rotation_radius"]
+    p.faz_center[0], p.faz_center[1] = g["FAZ_center"]
+    s = g["SimulationSpace"]
+    p.size[0], p.size[1], p.size[2] = s["no_voxel_x"], s["no_voxel_y"], s["no_voxel_z"]
+    p.n_trees = f["N_trees"]
+    for i, k in enumerate(("x0", "x1", "y0", "y1")):
+        p.walls[i] = 1 if walls.get(k) else 0
+    if len(g["modes"]) > 8:
+        raise NotImplementedError("at most 8 modes")
+    p.n_modes = len(g["modes"])
+    for m, mode in enumerate(g["modes"]):
+        for j, key in enumerate(MODE_KEYS):
+            p.modes[m][j] = float(mode[key])
+    return p
+
+
+def _unit(v):
+    return v / np.linalg.norm(v)
+
+
+def bifurcation_children(position, atts, r, kappa, d):
+    """Child positions of a bifurcating leaf (greenhouse.py:205-233). Must go through the same
+    numpy / LAPACK entry points as the reference: the sign dgeev gives the dominant eigenvector
+    decides which child comes first."""
+    r_p = (r ** kappa + r ** kappa) ** (1 / kappa)
+    phi = np.degrees(np.arccos((r_p ** 4 + r ** 4 - r ** 4) / (2 * r_p ** 2 * r ** 2)))
+    c = np.mean(atts, axis=0)
+    axis_c = c - position
+    if np.linalg.norm(axis_c) != 0.0:
+        axis_c = axis_c / np.linalg.norm(axis_c)
+    X = np.array([a - c for a in atts]).transpose()
+    w, v = np.linalg.eig(np.cov(X))
+    d_l = v[:, np.argmax(w)]
+    cs, sn = np.cos(np.radians(phi)), np.sin(np.radians(phi))
+    p1 = np.real(position + _unit(cs * axis_c + sn * d_l) * d)
+    p2 = np.real(position + _unit(cs * axis_c - sn * d_l) * d)
+    return p1, p2
+
+
+@BIF_FN
+def _serve_bifurcations(n_req, reqs_ptr, out6, _user):
+    buf = (ctypes.c_char * (REQ_DTYPE.itemsize * n_req)).from_address(reqs_ptr)
+    reqs = np.frombuffer(buf, dtype=REQ_DTYPE, count=n_req)
+    out = np.ctypeslib.as_array(out6, shape=(n_req, 6))
+    for i in range(n_req):
+        q = reqs[i]
+        n = int(q["n"])
+        p1, p2 = bifurcation_children(np.array(q["pos"]), np.array(q["atts"][:n]), float(q["r"]), float(q["kappa"]),
+                                      float(q["d"]))
+        out[i, 0:3] = p1
+        out[i, 3:6] = p2
+
+
+class SimulationResult:
+    """Edges of B samples in the reference's CSV row order plus per-sample statistics."""
+
+    def __init__(self, edges, edge_off, n_art, stats):
+        self.edges, self.edge_off, self.n_art, self.stats = edges, edge_off, n_art, stats
+
+    def __len__(self):
+        return len(self.edge_off) - 1
+
+    def sample_edges(self, k):
+        return self.edges[self.edge_off[k]:self.edge_off[k + 1]]
+
+    def arterial_venous(self, k):
+        e = self.sample_edges(k)
+        return e[: self.n_art[k]], e[self.n_art[k]:]
+
+
+class BatchSimulator:
+    """Owns the device state of B lock-step samples for one generator config."""
+
+    def __init__(self, config, batch, device_index=None):
+        self._lib = _native.lib()
+        self._ctx = _native.ctx(device_index)
+        self._cfg = config_to_struct(config)
+        self.batch = int(batch)
+        h = ctypes.c_void_p()
+        _native.check(self._lib.octa_sim_create(self._ctx, ctypes.byref(self._cfg), self.batch, ctypes.byref(h)),
+                      "octa_sim_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.octa_sim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, seeds, py_seeds=None):
+        """seeds[k] seeds numpy's stream of sample k; py_seeds (default: the same values) CPython's."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        if len(seeds) != self.batch:
+            raise ValueError(f"expected {self.batch} seeds")
+        py = np.ascontiguousarray(seeds if py_seeds is None else py_seeds, dtype=np.uint64)
+        rc = self._lib.octa_sim_run(self._h, seeds.ctypes.data, py.ctypes.data, ctypes.cast(_serve_bifurcations, ctypes.c_void_p),
+                                    None, _native.current_stream_ptr())
+        _native.check(rc, "octa_sim_run")
+        off = np.zeros(self.batch + 1, np.int64)
+        n_art = np.zeros(self.batch, np.int64)
+        _native.check(self._lib.octa_sim_edge_offsets(self._h, off.ctypes.data, n_art.ctypes.data), "octa_sim_edge_offsets")
+        edges = np.zeros((int(off[-1]), 7))
+        _native.check(self._lib.octa_sim_export_edges(self._h, edges.ctypes.data), "octa_sim_export_edges")
+        stats = np.zeros((self.batch, 8), np.int64)
+        _native.check(self._lib.octa_sim_stats(self._h, stats.ctypes.data), "octa_sim_stats")
+        return SimulationResult(edges, off, n_art, stats)
+
+    def fields(self, k):
+        oxy, co2 = np.zeros((16384, 3)), np.zeros((16384, 3))
+        no, nc = ctypes.c_int64(), ctypes.c_int64()
+        _native.check(self._lib.octa_sim_fields(self._h, int(k), oxy.ctypes.data, len(oxy), ctypes.byref(no),
+                                                co2.ctypes.data, len(co2), ctypes.byref(nc)), "octa_sim_fields")
+        return oxy[: no.value].copy(), co2[: nc.value].copy()
+
+
+def simulate_batch(config, seeds, device_index=None):
+    sim = BatchSimulator(config, len(seeds), device_index)
+    try:
+        return sim.run(seeds)
+    finally:
+        sim.close()
+
+
+def edges_to_csv_text(edges):
+    """CSV bytes exactly as generate_vessel_graph.py:59-66 writes them (numpy array str() for the
+    positions, float repr for the radius, csv.writer default dialect)."""
+    buf = io.StringIO(newline="")
+    w = csv.writer(buf)
+    w.writerow(["node1", "node2", "radius"])
+    for e in edges:
+        w.writerow([np.array(e[0:3]), np.array(e[3:6]), float(e[6])])
+    return buf.getvalue()

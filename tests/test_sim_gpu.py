@@ -1,0 +1,78 @@
+"""GPU parity: the HIP simulator through the C-ABI vs the oracle and the reference-made fixtures."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def gh(hip_lib_built):
+    import torch
+    assert torch.cuda.is_available()
+    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
+    return greenhouse
+
+
+def _cfg(golden, i1, i2):
+    cfg = yaml.safe_load(str(golden["config_yaml"]))
+    cfg["Greenhouse"]["modes"][0]["I"] = int(i1)
+    cfg["Greenhouse"]["modes"][1]["I"] = int(i2)
+    return cfg
+
+
+def test_short_runs_match_reference_csv(gh, golden):
+    """Seeds 0..3 at I=30+20 in ONE batch: CSV text identical to the reference's."""
+    sim = gh.BatchSimulator(_cfg(golden, 30, 20), 4)
+    res = sim.run([0, 1, 2, 3])
+    for k in range(4):
+        name = f"run_s{k}_30_20"
+        assert res.n_art[k] == int(golden[name + "_n_art"])
+        text = gh.edges_to_csv_text(res.sample_edges(k))
+        assert text.encode() == golden[name + "_csv"].tobytes(), name
+        oxy, co2 = sim.fields(k)
+        assert (oxy == golden[name + "_oxy"]).all() and (co2 == golden[name + "_co2"]).all()
+        assert res.stats[k, 0] == 0
+    sim.close()
+
+
+def test_mode_edge_cases(gh, golden):
+    for name in ("run_s0_10_5", "run_s5_10_5", "run_s11_20_0", "run_s4_0_12"):
+        seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])
+        res = gh.simulate_batch(_cfg(golden, i1, i2), [seed])
+        assert gh.edges_to_csv_text(res.sample_edges(0)).encode() == golden[name + "_csv"].tobytes(), name
+
+
+def test_batch_vs_oracle_radii_bit_exact(gh, golden):
+    """A ragged batch of other seeds vs the CPU oracle: radii bit-exact, positions equal as text."""
+    from oracle import sim_oracle
+    cfg = _cfg(golden, 12, 8)
+    seeds = [21, 22, 23, 24, 25, 26]
+    res = gh.simulate_batch(cfg, seeds)
+    for k, s in enumerate(seeds):
+        e, info = sim_oracle.simulate(cfg, s)
+        g = res.sample_edges(k)
+        assert g.shape == e.shape
+        assert (g[:, 6] == e[:, 6]).all()
+        assert gh.edges_to_csv_text(g) == sim_oracle.edges_to_csv_text(e)
+        assert res.stats[k, 1] == info["py_random_draws"] and res.stats[k, 2] == info["murray_steps"]
+
+
+def test_full_length_run_sha(gh, golden):
+    names = [str(n) for n in golden["names"] if str(n).startswith("full_")]
+    if not names:
+        pytest.skip("no full-length fixture")
+    cfg = _cfg(golden, 100, 150)
+    seeds = [int(golden[n + "_seed_I"][0]) for n in names]
+    res = gh.simulate_batch(cfg, seeds)
+    for k, n in enumerate(names):
+        text = gh.edges_to_csv_text(res.sample_edges(k))
+        assert hashlib.sha256(text.encode()).hexdigest() == str(golden[n + "_csv_sha256"]), n

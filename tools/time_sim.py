@@ -1,0 +1,18 @@
+"""Quick device timing of the batched simulator (development aid)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, yaml
+from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "sim_golden.npz"))
+cfg = yaml.safe_load(str(g["config_yaml"]))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+i1 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+i2 = int(sys.argv[3]) if len(sys.argv) > 3 else 150
+cfg["Greenhouse"]["modes"][0]["I"] = i1; cfg["Greenhouse"]["modes"][1]["I"] = i2
+sim = greenhouse.BatchSimulator(cfg, B)
+for rep in range(2):
+    torch.cuda.synchronize(); t = time.time()
+    res = sim.run(np.arange(B) + 1000 * rep)
+    torch.cuda.synchronize(); dt = time.time() - t
+    print(f"sim B={B} I={i1}+{i2}: {dt:.3f} s -> {B/dt:.1f} samples/s; edges/sample {np.diff(res.edge_off).mean():.0f}; "
+          f"stats err={res.stats[:,0].max()} draws~{res.stats[:,1].mean():.0f} murray~{res.stats[:,2].mean():.0f} bif~{res.stats[:,3].mean():.1f} respec~{res.stats[:,4].mean():.0f}")
