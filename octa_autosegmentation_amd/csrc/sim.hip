@@ -43,7 +43,7 @@ struct BatchPtrs {
     unsigned long long *hashes;
     unsigned *pairs;
     unsigned long long *set_hash;
-    int *set_key, *tmp_int;
+    int *set_key, *tmp_int, *grid_start, *grid_items;
     double *tmp_dbl;
     SampleScalars *sc;
     IterParams *iters;
@@ -54,7 +54,6 @@ struct BatchPtrs {
     unsigned short *valid;       // [B][76*76*2]
     unsigned *valid_count;       // [B]
     int *n_per_iter;             // [n_iter]
-    size_t cand_stride;
     SimConst C;
 };
 
@@ -72,7 +71,7 @@ __device__ __forceinline__ SimArrays sample_arrays(const BatchPtrs &B, int s) {
     }
     A.oxy = B.oxy + (size_t)s * OCAP * 3;
     A.co2 = B.co2 + (size_t)s * CCAP * 3;
-    A.cand = B.cand + (size_t)s * B.cand_stride;
+    A.cand = B.cand + (size_t)s * NCANDCAP * 3;
     A.py_u = B.py_u + (size_t)s * PYCAP;
     A.nn = B.nn + (size_t)s * OCAP;
     A.first_att = B.first_att + (size_t)s * NCAP;
@@ -91,82 +90,135 @@ __device__ __forceinline__ SimArrays sample_arrays(const BatchPtrs &B, int s) {
     A.set_hash = B.set_hash + (size_t)s * SETCAP;
     A.set_key = B.set_key + (size_t)s * SETCAP;
     A.tmp_int = B.tmp_int + (size_t)s * (OCAP + 2 * NCANDCAP);
+    A.grid_start = B.grid_start + (size_t)s * (GRID_MAX * GRID_MAX + 1);
+    A.grid_items = B.grid_items + (size_t)s * NCAP;
     A.tmp_dbl = B.tmp_dbl + (size_t)s * OCAP * 3;
     A.sc = B.sc + s;
     return A;
 }
 
-// ---- candidate stream: one lane per sample runs the numpy MT19937 stream (state in LDS, word-major
-// so that the 32 lanes of a block hit 32 different banks)
-constexpr int GEN_LANES = 32;
-struct LdsMt {
-    unsigned *w;  // base + lane, stride GEN_LANES
-    int idx;
-    __device__ unsigned &at(int k) { return w[k * GEN_LANES]; }
-    __device__ void refill() {
-        int kk;
-        for (kk = 0; kk < 624 - 397; kk++) {
-            unsigned y = (at(kk) & 0x80000000u) | (at(kk + 1) & 0x7fffffffu);
-            at(kk) = at(kk + 397) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+// ---- candidate stream (simulation_space.py:57-67): numpy's MT19937 run by ONE WAVE per sample.
+// The 624-word state lives in LDS; a block of outputs is regenerated with lane-parallel sweeps (the
+// recurrence only reaches 227 words back, further than one 64-lane chunk), tempered into an LDS
+// output queue, and consumed lane-parallel: masked-rejection voxel picks are compacted in stream
+// order with ballot/popcount, the N x 3 uniforms are formed from consecutive output pairs.
+struct WaveMt {
+    unsigned *st;   // [624] LDS
+    unsigned *ob;   // [1248] LDS output queue
+    int cur, avail;
+    int lane;
+    __device__ void regen_block() {
+        for (int c = 0; c < 623; c += 64) {
+            int k = c + lane;
+            unsigned nv = 0;
+            if (k < 623) {
+                unsigned y = (st[k] & 0x80000000u) | (st[k + 1] & 0x7fffffffu);
+                unsigned m = (k < 227) ? st[k + 397] : st[k - 227];
+                nv = m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (k < 623) st[k] = nv;
+            __builtin_amdgcn_wave_barrier();
         }
-        for (; kk < 623; kk++) {
-            unsigned y = (at(kk) & 0x80000000u) | (at(kk + 1) & 0x7fffffffu);
-            at(kk) = at(kk - 227) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        if (lane == 0) {
+            unsigned y = (st[623] & 0x80000000u) | (st[0] & 0x7fffffffu);
+            st[623] = st[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
         }
-        unsigned y = (at(623) & 0x80000000u) | (at(0) & 0x7fffffffu);
-        at(623) = at(396) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        idx = 0;
+        __builtin_amdgcn_wave_barrier();
     }
-    __device__ unsigned next() {
-        if (idx >= 624) refill();
-        unsigned y = at(idx++);
+    __device__ static unsigned temper(unsigned y) {
         y ^= (y >> 11);
         y ^= (y << 7) & 0x9d2c5680u;
         y ^= (y << 15) & 0xefc60000u;
         y ^= (y >> 18);
         return y;
     }
-    __device__ double next_double() {
-        unsigned a = next() >> 5, b = next() >> 6;
-        return (a * 67108864.0 + b) / 9007199254740992.0;
+    // make at least k (<= 624) outputs available at ob[cur..]
+    __device__ void ensure(int k) {
+        if (avail - cur >= k) return;
+        const int rem = avail - cur;
+        for (int c = 0; c < rem; c += 64) {
+            int i = c + lane;
+            unsigned v = (i < rem) ? ob[cur + i] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (i < rem) ob[i] = v;
+            __builtin_amdgcn_wave_barrier();
+        }
+        cur = 0;
+        regen_block();
+        for (int i = lane; i < 624; i += 64) ob[rem + i] = temper(st[i]);
+        avail = rem + 624;
+        __builtin_amdgcn_wave_barrier();
     }
 };
 
-__global__ void __launch_bounds__(GEN_LANES)
-sim_gen_candidates_kernel(BatchPtrs B, int n_samples) {
-    __shared__ unsigned s_mt[624 * GEN_LANES];
-    const int s = blockIdx.x * GEN_LANES + threadIdx.x;
-    if (s >= n_samples) return;
-    LdsMt g;
-    g.w = s_mt + threadIdx.x;
-    const unsigned *st = B.mt_state + (size_t)s * 625;
-    for (int k = 0; k < 624; k++) g.at(k) = st[k];
-    g.idx = (int)st[624];
-    const unsigned K = B.valid_count[s];
-    const unsigned short *valid = B.valid + (size_t)s * 76 * 76 * 2;
-    unsigned *idx_scratch = reinterpret_cast<unsigned *>(B.tmp_int + (size_t)s * (OCAP + 2 * NCANDCAP));
-    unsigned rng = K - 1, mask = rng;
+// executed by wave 0 of the sample's workgroup; lds: 624 + 1248 + N words
+__device__ void gen_candidates_wave(unsigned *g_state /*[625]*/, const unsigned short *valid, unsigned K, int N, double *out,
+                                    unsigned *lds, int lane) {
+    WaveMt g;
+    g.st = lds; g.ob = lds + 624; g.lane = lane;
+    unsigned *idx = lds + 624 + 1248;
+    for (int i = lane; i < 624; i += 64) g.st[i] = g_state[i];
+    int sidx = (int)g_state[624];
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 624 - sidx; i += 64) g.ob[i] = WaveMt::temper(g.st[sidx + i]);
+    g.cur = 0; g.avail = 624 - sidx;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned rng = K - 1;
+    unsigned mask = rng;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-    double *out = B.cand + (size_t)s * B.cand_stride;
-    for (int it = 0; it < B.C.n_iter; it++) {
-        const int N = B.n_per_iter[it];
-        for (int i = 0; i < N; i++) {
-            unsigned v = 0;
-            if (rng != 0) { do { v = g.next() & mask; } while (v > rng); }
-            idx_scratch[i] = v;
-        }
-        double *o = out + (size_t)it * B.C.n_max * 3;
-        for (int i = 0; i < N; i++) {
-            double u0 = g.next_double(), u1 = g.next_double(), u2 = g.next_double();
-            const unsigned short *v = valid + 2 * idx_scratch[i];
-            o[3 * i] = ((double)v[0] + u0) / 76.0;
-            o[3 * i + 1] = ((double)v[1] + u1) / 76.0;
-            o[3 * i + 2] = (0.0 + u2) / 76.0;
+    if (rng == 0) {
+        for (int i = lane; i < N; i += 64) idx[i] = 0;
+    } else {
+        int count = 0;
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        while (count < N) {
+            g.ensure(64);
+            unsigned v = g.ob[g.cur + lane] & mask;
+            bool acc = v <= rng;
+            unsigned long long bal = __ballot(acc);
+            int pre = __popcll(bal & lt);
+            int pc = __popcll(bal);
+            int need = N - count;
+            if (pc >= need) {
+                unsigned long long last = __ballot(acc && pre == need - 1);
+                int consumed = __ffsll((long long)last);  // 1-based lane index = lanes consumed
+                if (acc && pre < need) idx[count + pre] = v;
+                g.cur += consumed;
+                count = N;
+            } else {
+                if (acc) idx[count + pre] = v;
+                g.cur += 64;
+                count += pc;
+            }
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    const int total = 3 * N;
+    for (int j0 = 0; j0 < total; j0 += 64) {
+        int m = total - j0 < 64 ? total - j0 : 64;
+        g.ensure(2 * m);
+        if (lane < m) {
+            unsigned a = g.ob[g.cur + 2 * lane] >> 5, bb = g.ob[g.cur + 2 * lane + 1] >> 6;
+            double u = (a * 67108864.0 + bb) / 9007199254740992.0;
+            int j = j0 + lane, i = j / 3, c = j - 3 * i;
+            double vox = (c == 2) ? 0.0 : (double)valid[2 * idx[i] + c];
+            out[j] = (vox + u) / 76.0;
+        }
+        g.cur += 2 * m;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 624; i += 64) g_state[i] = g.st[i];
+    if (lane == 0) g_state[624] = (unsigned)(624 - (g.avail - g.cur));
 }
 
 // ---- iteration kernels
+#define OCTA_PROF(slot, stmt)                                              \
+    do {                                                                   \
+        long _t0 = (long)wall_clock64();                                   \
+        stmt;                                                              \
+        if (threadIdx.x == 0) A.sc->prof[slot] += (long)wall_clock64() - _t0; \
+    } while (0)
 __global__ void __launch_bounds__(SIM_THREADS)
 sim_iter_a_kernel(BatchPtrs B, int it, int finish_prev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -176,14 +228,22 @@ sim_iter_a_kernel(BatchPtrs B, int it, int finish_prev) {
     if (A.sc->err) return;
     if (finish_prev) {
         const IterParams Pp = B.iters[it - 1];
-        phase_seq(b, A, B.C, Pp, 1, A.co2, B.bif_results);
-        phase_satisfy_ven(b, A, Pp);
+        OCTA_PROF(8, phase_seq(b, A, B.C, Pp, 1, A.co2, B.bif_results));
+        OCTA_PROF(9, phase_satisfy_ven(b, A, Pp));
     }
     if (it >= B.C.n_iter) return;
     const IterParams P = B.iters[it];
-    phase_sample(b, A, B.C, P, it);
-    phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art);
-    phase_pre(b, A, B.C, P, 0, A.oxy, B.reqs, B.req_count, REQ_CAP, s);
+    {
+        long _t0 = (long)wall_clock64();
+        if (threadIdx.x < 64)
+            gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], P.N,
+                                B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()), (int)threadIdx.x);
+        __syncthreads();
+        if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
+    }
+    OCTA_PROF(0, phase_sample(b, A, B.C, P, it));
+    OCTA_PROF(1, phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art));
+    OCTA_PROF(2, phase_pre(b, A, B.C, P, 0, A.oxy, B.reqs, B.req_count, REQ_CAP, s));
 }
 
 __global__ void __launch_bounds__(SIM_THREADS)
@@ -194,10 +254,10 @@ sim_iter_b_kernel(BatchPtrs B, int it) {
     Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
     if (A.sc->err) return;
     const IterParams P = B.iters[it];
-    phase_seq(b, A, B.C, P, 0, A.oxy, B.bif_results);
-    phase_satisfy_art(b, A, P);
-    phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven);
-    phase_pre(b, A, B.C, P, 1, A.co2, B.reqs + REQ_CAP, B.req_count + 1, REQ_CAP, s);
+    OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, B.bif_results));
+    OCTA_PROF(4, phase_satisfy_art(b, A, P));
+    OCTA_PROF(6, phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven));
+    OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, B.reqs + REQ_CAP, B.req_count + 1, REQ_CAP, s));
 }
 
 }  // namespace
@@ -262,7 +322,6 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     memset(&P, 0, sizeof(P));
     P.C = S->C;
     const size_t nb = (size_t)B;
-    P.cand_stride = (size_t)S->C.n_iter * (size_t)(S->C.n_max > 0 ? S->C.n_max : 1) * 3;
     int rc = 0;
     for (int f = 0; f < 2 && !rc; f++) {
         rc |= dev_alloc(S, &P.npos[f], nb * NCAP * 3); rc |= dev_alloc(S, &P.nrad[f], nb * NCAP); rc |= dev_alloc(S, &P.nkap[f], nb * NCAP);
@@ -270,18 +329,19 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
         rc |= dev_alloc(S, &P.nnch[f], nb * NCAP); rc |= dev_alloc(S, &P.nact[f], nb * NCAP);
     }
     rc |= dev_alloc(S, &P.oxy, nb * OCAP * 3); rc |= dev_alloc(S, &P.co2, nb * CCAP * 3);
-    rc |= dev_alloc(S, &P.cand, nb * P.cand_stride + 8); rc |= dev_alloc(S, &P.py_u, nb * PYCAP);
+    rc |= dev_alloc(S, &P.cand, nb * NCANDCAP * 3); rc |= dev_alloc(S, &P.py_u, nb * PYCAP);
     rc |= dev_alloc(S, &P.nn, nb * OCAP); rc |= dev_alloc(S, &P.first_att, nb * NCAP); rc |= dev_alloc(S, &P.act_list, nb * NCAP);
     rc |= dev_alloc(S, &P.sorted, nb * SORTCAP); rc |= dev_alloc(S, &P.gnode, nb * GCAP); rc |= dev_alloc(S, &P.gstart, nb * GCAP);
     rc |= dev_alloc(S, &P.gcount, nb * GCAP); rc |= dev_alloc(S, &P.rec, nb * GCAP);
     rc |= dev_alloc(S, &P.kd_idx, nb * OCAP); rc |= dev_alloc(S, &P.kd_rank, nb * OCAP);
     rc |= dev_alloc(S, &P.removed, nb * OCAP); rc |= dev_alloc(S, &P.ven_near, nb * OCAP); rc |= dev_alloc(S, &P.hashes, nb * OCAP);
     rc |= dev_alloc(S, &P.pairs, nb * PCAP); rc |= dev_alloc(S, &P.set_hash, nb * SETCAP); rc |= dev_alloc(S, &P.set_key, nb * SETCAP);
+    rc |= dev_alloc(S, &P.grid_start, nb * (GRID_MAX * GRID_MAX + 1)); rc |= dev_alloc(S, &P.grid_items, nb * NCAP);
     rc |= dev_alloc(S, &P.tmp_int, nb * (OCAP + 2 * NCANDCAP)); rc |= dev_alloc(S, &P.tmp_dbl, nb * OCAP * 3);
     rc |= dev_alloc(S, &P.sc, nb); rc |= dev_alloc(S, &P.iters, S->iters.size() + 1);
     rc |= dev_alloc(S, &P.reqs, (size_t)2 * REQ_CAP); rc |= dev_alloc(S, &P.req_count, 4); rc |= dev_alloc(S, &P.bif_results, (size_t)2 * REQ_CAP * 6);
     rc |= dev_alloc(S, &P.mt_state, nb * 625); rc |= dev_alloc(S, &P.valid, nb * 76 * 76 * 2); rc |= dev_alloc(S, &P.valid_count, nb);
-    rc |= dev_alloc(S, &P.n_per_iter, S->iters.size() + 1);
+    rc |= dev_alloc(S, &P.n_per_iter, S->iters.size() + 1);  // kept for diagnostics
     if (!rc) {
         hipError_t e1 = hipHostMalloc((void **)&S->h_reqs, sizeof(BifRequest) * 2 * REQ_CAP);
         hipError_t e2 = hipHostMalloc((void **)&S->h_results, sizeof(double) * 2 * REQ_CAP * 6);
@@ -371,11 +431,6 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
         OCTA_HIP_CHECK(hipMemsetAsync(P.req_count, 0, sizeof(int) * 4, stream));
         OCTA_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
     }
-    // ---- candidate stream for all iterations
-    if (C.n_iter > 0) {
-        hipLaunchKernelGGL(sim_gen_candidates_kernel, dim3((unsigned)((B + GEN_LANES - 1) / GEN_LANES)), dim3(GEN_LANES), 0, stream, P, B);
-        OCTA_HIP_CHECK(hipGetLastError());
-    }
     // ---- iterations
     auto serve = [&](int slot) -> int {
         OCTA_HIP_CHECK(hipMemcpyAsync(S->h_req_count, P.req_count, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
@@ -456,10 +511,11 @@ extern "C" int octa_sim_stats(octa_sim *S, int64_t *h_stats) {
     if (!S || !S->ran || !h_stats) { octa::set_error("octa_sim_stats: run the simulation first"); return -2; }
     for (int s = 0; s < S->B; s++) {
         const SampleScalars &sc = S->h_sc[s];
-        int64_t *o = h_stats + 8 * s;
+        int64_t *o = h_stats + 24 * s;
         o[0] = sc.err; o[1] = sc.py_pos; o[2] = sc.murray_steps; o[3] = sc.n_bif; o[4] = sc.respec;
         o[5] = sc.n_nodes[0]; o[6] = sc.n_nodes[1];
         memcpy(&o[7], &sc.faz_radius, 8);
+        for (int k = 0; k < 16; k++) o[8 + k] = sc.prof[k];
     }
     return 0;
 }

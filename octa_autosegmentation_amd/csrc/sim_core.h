@@ -44,6 +44,7 @@ constexpr int NCANDCAP = 8192; // candidates per iteration
 constexpr int TILE = 1024;     // points per LDS tile in brute-force queries
 constexpr int ACCCAP = 2048;   // accepted sinks per iteration
 constexpr int KD_RANGES = 1024; // ranges per kd level (> OCAP / 17)
+constexpr int GRID_MAX = 128;   // uniform-grid cells per axis (x, y); the thin z extent is not binned
 
 enum ErrBits { ERR_NODE_CAP = 1, ERR_OXY_CAP = 2, ERR_CO2_CAP = 4, ERR_GROUP_CAP = 8, ERR_PAIR_CAP = 16, ERR_SET_CAP = 32,
                ERR_PY_CAP = 64, ERR_KEPT_CAP = 128, ERR_REQ_CAP = 256, ERR_ACC_CAP = 512, ERR_MISSING_BIF = 1024 };
@@ -91,6 +92,7 @@ struct SampleScalars {
     long murray_steps;
     long n_bif;
     long respec;
+    long prof[16];  // accumulated 100 MHz ticks per phase (thread 0), see sim.hip
 };
 
 // pointers to ONE sample's slices
@@ -102,7 +104,7 @@ struct SimArrays {
     unsigned char *nnch[2], *nact[2];  // [NCAP]
     double *oxy;       // [OCAP*3]
     double *co2;       // [CCAP*3]
-    const double *cand;  // [n_iter][n_max][3]
+    const double *cand;  // [n_max][3] candidate sinks of the CURRENT iteration
     const double *py_u;  // [PYCAP]
     // scratch
     int *nn;             // [OCAP] nearest active node per attractor
@@ -118,7 +120,9 @@ struct SimArrays {
     unsigned *pairs;     // [PCAP]
     unsigned long long *set_hash;  // [SETCAP]
     int *set_key;        // [SETCAP]
-    int *tmp_int;        // [OCAP + NCANDCAP] general scratch
+    int *grid_start;     // [GRID_MAX*GRID_MAX + 1] cell offsets of the current uniform grid
+    int *grid_items;     // [NCAP] point ids sorted by cell
+    int *tmp_int;        // [OCAP + 2*NCANDCAP] general scratch
     double *tmp_dbl;     // [OCAP*3] general scratch (stable compaction staging)
     SampleScalars *sc;
 };
@@ -589,6 +593,67 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
     b.sync();
 }
 
+
+// ------------------------------------------------------------------ uniform grid (LDS-binned counting sort)
+// Points are binned on (x, y) with a cell edge >= the query radius, so a radius query visits the
+// 3x3 cell neighbourhood. Cell offsets are built in LDS (histogram -> scan -> scatter) and kept in
+// HBM/L2 for the queries. Item order inside a cell is not defined; every consumer is order-free
+// (existence tests, arg-min with an explicit id tie-break, pair lists that are sorted afterwards).
+struct Grid {
+    int nx, ny;
+    double x0, y0, inv;
+    const int *start;
+    const int *items;
+};
+OCTA_HD inline int grid_clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+OCTA_HD inline int grid_cx(const Grid &G, double x) { return grid_clampi((int)floor((x - G.x0) * G.inv), G.nx - 1); }
+OCTA_HD inline int grid_cy(const Grid &G, double y) { return grid_clampi((int)floor((y - G.y0) * G.inv), G.ny - 1); }
+
+// ids: optional list of point ids (n entries) -- point i is pts[3*ids[i]]; items then hold ids[i]
+OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius) {
+    Grid G;
+    const double span = 1.2;
+    double cell = fmax(radius, span / GRID_MAX);
+    int nc = (int)ceil(span / cell);
+    if (nc < 1) nc = 1;
+    if (nc > GRID_MAX) nc = GRID_MAX;
+    G.nx = G.ny = nc; G.x0 = G.y0 = -0.1; G.inv = 1.0 / cell;
+    G.start = A.grid_start; G.items = A.grid_items;
+    const int ncell = nc * nc;
+    int *hist = reinterpret_cast<int *>(b.user());  // [ncell + 1]
+    b.sync();
+    for (int c = b.tid; c <= ncell; c += b.nth) hist[c] = 0;
+    b.sync();
+    for (int i = b.tid; i < n; i += b.nth) {
+        const double *p = pts + 3 * (ids ? ids[i] : i);
+        atomic_add_int(&hist[grid_cy(G, p[1]) * nc + grid_cx(G, p[0])], 1);
+    }
+    b.sync();
+    int run = 0;
+    for (int base = 0; base <= ncell; base += b.nth) {
+        int c = base + b.tid;
+        int v = c <= ncell ? hist[c] : 0;
+        int ex;
+        int tot = blk_scan(b, v, &ex);
+        if (c <= ncell) { hist[c] = run + ex; A.grid_start[c] = run + ex; }
+        run += tot;
+    }
+    b.sync();
+    for (int i = b.tid; i < n; i += b.nth) {
+        int id = ids ? ids[i] : i;
+        const double *p = pts + 3 * id;
+        int pos = atomic_add_int(&hist[grid_cy(G, p[1]) * nc + grid_cx(G, p[0])], 1);
+        A.grid_items[pos] = id;
+    }
+    b.sync();
+    return G;
+}
+#define OCTA_GRID_FOR(G, px, py, radius, ITEM)                                                   \
+    for (int _cy = grid_cy(G, (py) - (radius)), _cy1 = grid_cy(G, (py) + (radius)); _cy <= _cy1; _cy++)   \
+        for (int _cx = grid_cx(G, (px) - (radius)), _cx1 = grid_cx(G, (px) + (radius)); _cx <= _cx1; _cx++) \
+            for (int _k = (G).start[_cy * (G).nx + _cx], _k1 = (G).start[_cy * (G).nx + _cx + 1]; _k < _k1; _k++) \
+                for (int ITEM = (G).items[_k], _once = 1; _once; _once = 0)
+
 // ------------------------------------------------------------------ Murray propagation (one thread)
 OCTA_HD inline void murray_to_root(const SimArrays &A, int f, int id) {
     double *rad = A.nrad[f];
@@ -629,7 +694,8 @@ OCTA_HD inline int add_node(const SimArrays &A, int f, V3 p, double r, int paren
 OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int iter) {
     SampleScalars *sc = A.sc;
     const int N = P.N;
-    const double *cand = A.cand + (size_t)iter * C.n_max * 3;
+    const double *cand = A.cand;
+    (void)iter;
     const double en = fmax(P.eps_n, P.eps_k), es = P.eps_s;
     const double en2 = en * en;
     const double GSd = 76.0;
@@ -656,46 +722,45 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     }
     b.sync();
     // 2. tests against all arterial nodes (ball en, oxygen distance) and existing sinks (NN <= es)
-    double *tile = reinterpret_cast<double *>(b.user());   // [TILE][4]
     const int n_art = sc->n_nodes[0];
     const int n_oxy = sc->n_oxy;
+    unsigned char *okf = A.removed;  // per valid candidate
+    double *oxd = A.tmp_dbl;         // oxygen distance per arterial node
+    for (int i = b.tid; i < n_art; i += b.nth) oxd[i] = oxygen_distance(A.nrad[0][i], C.ps);
+    {
+        Grid G = grid_build(b, A, A.npos[0], nullptr, n_art, en);
+        for (int vi = b.tid; vi < n_valid; vi += b.nth) {
+            V3 c = ld3(cand + 3 * vlist[vi]);
+            bool ok = true;
+            OCTA_GRID_FOR(G, c.x, c.y, en, j) {
+                if (ok) {
+                    double d2 = sqdist(ld3(A.npos[0] + 3 * j), c);
+                    if (d2 <= en2 && !(sqrt(d2) > oxd[j])) ok = false;
+                }
+            }
+            okf[vi] = ok ? 1 : 0;
+        }
+        b.sync();
+    }
+    {
+        Grid G = grid_build(b, A, A.oxy, nullptr, n_oxy, es);
+        for (int vi = b.tid; vi < n_valid; vi += b.nth) {
+            if (!okf[vi]) continue;
+            V3 c = ld3(cand + 3 * vlist[vi]);
+            bool ok = true;
+            OCTA_GRID_FOR(G, c.x, c.y, es, j) {
+                if (ok && sqrt(sqdist(ld3(A.oxy + 3 * j), c)) <= es) ok = false;
+            }
+            okf[vi] = ok ? 1 : 0;
+        }
+        b.sync();
+    }
     int n_pass = 0;
     for (int base = 0; base < n_valid; base += b.nth) {
         int vi = base + b.tid;
-        bool live = vi < n_valid;
-        V3 c = live ? ld3(cand + 3 * vlist[vi]) : v3(0, 0, 0);
-        bool ok = live;
-        for (int t0 = 0; t0 < n_art; t0 += TILE) {
-            int cnt = n_art - t0 < TILE ? n_art - t0 : TILE;
-            b.sync();
-            for (int j = b.tid; j < cnt; j += b.nth) {
-                const double *p = A.npos[0] + 3 * (t0 + j);
-                tile[4 * j] = p[0]; tile[4 * j + 1] = p[1]; tile[4 * j + 2] = p[2];
-                tile[4 * j + 3] = oxygen_distance(A.nrad[0][t0 + j], C.ps);
-            }
-            b.sync();
-            if (ok)
-                for (int j = 0; j < cnt; j++) {
-                    double d2 = sqdist(v3(tile[4 * j], tile[4 * j + 1], tile[4 * j + 2]), c);
-                    if (d2 <= en2 && !(sqrt(d2) > tile[4 * j + 3])) { ok = false; break; }
-                }
-        }
-        for (int t0 = 0; t0 < n_oxy; t0 += TILE) {
-            int cnt = n_oxy - t0 < TILE ? n_oxy - t0 : TILE;
-            b.sync();
-            for (int j = b.tid; j < cnt; j += b.nth) {
-                const double *p = A.oxy + 3 * (t0 + j);
-                tile[4 * j] = p[0]; tile[4 * j + 1] = p[1]; tile[4 * j + 2] = p[2];
-            }
-            b.sync();
-            if (ok)
-                for (int j = 0; j < cnt; j++) {
-                    double d2 = sqdist(v3(tile[4 * j], tile[4 * j + 1], tile[4 * j + 2]), c);
-                    if (sqrt(d2) <= es) { ok = false; break; }
-                }
-        }
+        int ok = (vi < n_valid) && okf[vi];
         int ex;
-        int tot = blk_scan(b, ok ? 1 : 0, &ex);
+        int tot = blk_scan(b, ok, &ex);
         if (ok) plist[n_pass + ex] = vlist[vi];
         n_pass += tot;
     }
@@ -764,37 +829,23 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
         n_act += tot;
     }
     b.sync();
-    double *tile = reinterpret_cast<double *>(b.user());  // [TILE][3]
-    int *tid_ids = reinterpret_cast<int *>(b.user() + (size_t)TILE * 24);  // [TILE]
-    for (int base = 0; base < n_att; base += b.nth) {
-        int a = base + b.tid;
-        bool live = a < n_att;
-        V3 p = live ? ld3(att + 3 * a) : v3(0, 0, 0);
-        double bd = INFINITY;
-        int best = -1;
-        for (int t0 = 0; t0 < n_act; t0 += TILE) {
-            int cnt = n_act - t0 < TILE ? n_act - t0 : TILE;
-            b.sync();
-            for (int j = b.tid; j < cnt; j += b.nth) {
-                int id = A.act_list[t0 + j];
-                const double *q = A.npos[f] + 3 * id;
-                tile[3 * j] = q[0]; tile[3 * j + 1] = q[1]; tile[3 * j + 2] = q[2];
-                tid_ids[j] = id;
+    {
+        Grid G = grid_build(b, A, A.npos[f], A.act_list, n_act, delta);
+        const double *np_ = A.npos[f];
+        for (int a = b.tid; a < n_att; a += b.nth) {
+            V3 p = ld3(att + 3 * a);
+            double bd = INFINITY;
+            int best = -1;
+            OCTA_GRID_FOR(G, p.x, p.y, delta, j) {
+                double d2 = sqdist(ld3(np_ + 3 * j), p);
+                if (d2 < bd || (d2 == bd && j < best)) { bd = d2; best = j; }
             }
-            b.sync();
-            if (live)
-                for (int j = 0; j < cnt; j++) {
-                    double d2 = sqdist(v3(tile[3 * j], tile[3 * j + 1], tile[3 * j + 2]), p);
-                    if (d2 < bd) { bd = d2; best = tid_ids[j]; }
-                }
-        }
-        if (live) {
             int r = (best >= 0 && sqrt(bd) <= delta) ? best : -1;
             A.nn[a] = r;
             if (r >= 0) atomic_min_int(&A.first_att[r], a);
         }
+        b.sync();
     }
-    b.sync();
     // sort keys (first_att[nn[a]] << 14 | a); unassigned -> 0xffffffff
     unsigned *keys = reinterpret_cast<unsigned *>(b.user());
     int n_pow2 = 1;
@@ -1067,51 +1118,43 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
     if (b.tid == 0) ctl[0] = 0;
     b.sync();
     // 2. (new node, sink) hit pairs, key = node_local << 14 | kd rank
-    double *tile = reinterpret_cast<double *>(b.user());  // new node positions [n_new][3] (<= TILE chunks)
-    for (int c0 = 0; c0 < n_new; c0 += TILE) {
-        int cc = n_new - c0 < TILE ? n_new - c0 : TILE;
+    {
+        int *new_ids = A.tmp_int;
+        for (int j = b.tid; j < n_new; j += b.nth) new_ids[j] = nb + j;
         b.sync();
-        for (int j = b.tid; j < cc * 3; j += b.nth) tile[j] = A.npos[0][3 * (nb + c0) + j];
-        b.sync();
+        Grid G = grid_build(b, A, A.npos[0], new_ids, n_new, ek);
         for (int o = b.tid; o < n_oxy; o += b.nth) {
             V3 p = ld3(A.oxy + 3 * o);
-            for (int j = 0; j < cc; j++) {
-                if (sqdist(p, v3(tile[3 * j], tile[3 * j + 1], tile[3 * j + 2])) <= ek2) {
+            OCTA_GRID_FOR(G, p.x, p.y, ek, j) {
+                if (sqdist(p, ld3(A.npos[0] + 3 * j)) <= ek2) {
                     int q = atomic_add_int(&ctl[0], 1);
-                    if (q < PCAP) A.pairs[q] = ((unsigned)(c0 + j) << 14) | (unsigned)A.kd_rank[o];
+                    if (q < PCAP) A.pairs[q] = ((unsigned)(j - nb) << 14) | (unsigned)A.kd_rank[o];
                     A.removed[o] = 1;
                 }
             }
         }
+        b.sync();
     }
-    b.sync();
     int n_pairs = ctl[0];
     if (n_pairs > PCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_PAIR_CAP); n_pairs = PCAP; }
     if (n_new > (1 << 18)) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_PAIR_CAP); }
+    b.sync();
     // 3. venous proximity + tuple hash for every removed sink
-    const int n_ven = sc->n_nodes[1];
-    for (int base = 0; base < n_oxy; base += b.nth) {
-        int o = base + b.tid;
-        bool live = (o < n_oxy) && A.removed[o];
-        V3 p = live ? ld3(A.oxy + 3 * o) : v3(0, 0, 0);
-        double bd = INFINITY;
-        for (int t0 = 0; t0 < n_ven; t0 += TILE) {
-            int cnt = n_ven - t0 < TILE ? n_ven - t0 : TILE;
-            b.sync();
-            for (int j = b.tid; j < cnt * 3; j += b.nth) tile[j] = A.npos[1][3 * t0 + j];
-            b.sync();
-            if (live)
-                for (int j = 0; j < cnt; j++) {
-                    double d2 = sqdist(v3(tile[3 * j], tile[3 * j + 1], tile[3 * j + 2]), p);
-                    if (d2 < bd) bd = d2;
-                }
-        }
-        if (live) {
-            A.ven_near[o] = (n_ven > 0 && sqrt(bd) <= ek) ? 1 : 0;
+    {
+        const int n_ven = sc->n_nodes[1];
+        Grid G = grid_build(b, A, A.npos[1], nullptr, n_ven, ek);
+        for (int o = b.tid; o < n_oxy; o += b.nth) {
+            if (!A.removed[o]) continue;
+            V3 p = ld3(A.oxy + 3 * o);
+            bool near = false;
+            OCTA_GRID_FOR(G, p.x, p.y, ek, j) {
+                if (!near && sqrt(sqdist(ld3(A.npos[1] + 3 * j), p)) <= ek) near = true;
+            }
+            A.ven_near[o] = near ? 1 : 0;
             A.hashes[o] = py_hash_tuple3(p);
         }
+        b.sync();
     }
-    b.sync();
     // 4. sort the pairs: new nodes in order, hits in cKDTree order
     unsigned *keys = reinterpret_cast<unsigned *>(b.user());
     int n_pow2 = 1;
@@ -1154,21 +1197,22 @@ OCTA_HD inline void phase_satisfy_ven(const Blk &b, const SimArrays &A, const It
     const int n_new = ne - nb, n_co2 = sc->n_co2;
     if (n_new <= 0 || n_co2 <= 0) return;
     const double ek2 = P.eps_k * P.eps_k;
-    double *tile = reinterpret_cast<double *>(b.user());
-    for (int i = b.tid; i < n_co2; i += b.nth) A.removed[i] = 0;
-    b.sync();
-    for (int c0 = 0; c0 < n_new; c0 += TILE) {
-        int cc = n_new - c0 < TILE ? n_new - c0 : TILE;
+    const double ek = P.eps_k;
+    {
+        int *new_ids = A.tmp_int;
+        for (int j = b.tid; j < n_new; j += b.nth) new_ids[j] = nb + j;
         b.sync();
-        for (int j = b.tid; j < cc * 3; j += b.nth) tile[j] = A.npos[1][3 * (nb + c0) + j];
-        b.sync();
+        Grid G = grid_build(b, A, A.npos[1], new_ids, n_new, ek);
         for (int o = b.tid; o < n_co2; o += b.nth) {
             V3 p = ld3(A.co2 + 3 * o);
-            for (int j = 0; j < cc; j++)
-                if (sqdist(p, v3(tile[3 * j], tile[3 * j + 1], tile[3 * j + 2])) <= ek2) { A.removed[o] = 1; break; }
+            bool hit = false;
+            OCTA_GRID_FOR(G, p.x, p.y, ek, j) {
+                if (!hit && sqdist(p, ld3(A.npos[1] + 3 * j)) <= ek2) hit = true;
+            }
+            A.removed[o] = hit ? 1 : 0;
         }
+        b.sync();
     }
-    b.sync();
     int keep = compact_points(b, A.co2, n_co2, A.removed, A.tmp_dbl);
     if (b.tid == 0) sc->n_co2 = keep;
     b.sync();

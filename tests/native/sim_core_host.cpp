@@ -79,7 +79,9 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
             int root = add_node(A, f, ld3(&S.pos[f][6 * t]), C.r, -1, 4.0);
             add_node(A, f, ld3(&S.pos[f][6 * t + 3]), C.r, root, 4.0);
         }
-    std::vector<double> oxy((size_t)OCAP * 3), co2((size_t)CCAP * 3), cand((size_t)C.n_iter * C.n_max * 3 + 3), tmp_dbl((size_t)OCAP * 3);
+    std::vector<double> oxy((size_t)OCAP * 3), co2((size_t)CCAP * 3), cand((size_t)NCANDCAP * 3), tmp_dbl((size_t)OCAP * 3);
+    std::vector<int> grid_start(GRID_MAX * GRID_MAX + 1), grid_items(NCAP);
+    A.grid_start = grid_start.data(); A.grid_items = grid_items.data();
     std::vector<int> nn(OCAP), first_att(NCAP), act_list(NCAP), gnode(GCAP), gstart(GCAP), gcount(GCAP), set_key(SETCAP), tmp_int(OCAP + 2 * NCANDCAP);
     std::vector<unsigned> sorted(SORTCAP), pairs(PCAP);
     std::vector<Rec> rec(GCAP);
@@ -92,11 +94,8 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     A.kd_idx = kd_idx.data(); A.kd_rank = kd_rank.data(); A.removed = removed.data(); A.ven_near = ven_near.data();
     A.hashes = hashes.data(); A.pairs = pairs.data(); A.set_hash = set_hash.data(); A.set_key = set_key.data();
     A.tmp_int = tmp_int.data(); A.tmp_dbl = tmp_dbl.data();
-    // candidate stream
-    std::vector<int> Ns(C.n_iter);
-    for (int i = 0; i < C.n_iter; i++) Ns[i] = tab[i].N;
-    std::vector<unsigned> idx_scratch(C.n_max + 1);
-    gen_candidates(S.np_state, S.valid.data(), (uint32_t)(S.valid.size() / 2), Ns.data(), C.n_iter, C.n_max, cand.data(), idx_scratch.data());
+    std::vector<unsigned> idx_scratch(NCANDCAP + 1);
+    const uint32_t Kvox = (uint32_t)(S.valid.size() / 2);
 
     std::vector<unsigned char> smem(160 * 1024);
     Blk b = {0, 1, smem.data()};
@@ -110,6 +109,7 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     for (int it = 0; it < C.n_iter; it++) {
         const IterParams &P = tab[it];
         int req_count = 0;
+        { int Nn = P.N; gen_candidates(S.np_state, S.valid.data(), Kvox, &Nn, 1, Nn, cand.data(), idx_scratch.data()); }
         phase_sample(b, A, C, P, it);
         phase_assign(b, A, 0, A.oxy, sc.n_oxy, P.delta_art);
         phase_pre(b, A, C, P, 0, A.oxy, reqs.data(), &req_count, REQ_CAP, 0);

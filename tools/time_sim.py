@@ -16,3 +16,6 @@ for rep in range(2):
     torch.cuda.synchronize(); dt = time.time() - t
     print(f"sim B={B} I={i1}+{i2}: {dt:.3f} s -> {B/dt:.1f} samples/s; edges/sample {np.diff(res.edge_off).mean():.0f}; "
           f"stats err={res.stats[:,0].max()} draws~{res.stats[:,1].mean():.0f} murray~{res.stats[:,2].mean():.0f} bif~{res.stats[:,3].mean():.1f} respec~{res.stats[:,4].mean():.0f}")
+    names = ["sample", "assign_art", "pre_art", "seq_art", "satisfy_art", "-", "assign_ven", "pre_ven", "seq_ven", "satisfy_ven"]
+    prof = res.stats[:, 8:18].mean(axis=0) / 1e5  # ms
+    print("  phase ms (mean over samples): " + ", ".join(f"{n}={v:.0f}" for n, v in zip(names, prof) if n != "-") + f"  total={prof.sum():.0f}")
