@@ -1,0 +1,144 @@
+"""bench.py -- headline benchmark: synthetic OCTA triples per second on MI355X.
+
+A step = one pass of the hot path over one batch of seeded samples with the reference's own
+generator config (docker/vessel_graph_gen_docker_config.yml, embedded in tests/golden/sim_golden.npz):
+space-colonisation simulation of B vessel graphs (HIP), 304x304 arterial/venous rasterisation and
+max-combine, 1216x1216 label rasterisation + Floyd-Steinberg binarisation. Outputs stay in memory
+(edge arrays on the host, images/labels in HBM); writing CSV/PNG files is not part of the step.
+Workload = BASELINE.json configs[1] (128-sample batch, rasterise to 1216x1216).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+Multi-GPU (driver-launched with torch.distributed.run): samples are independent, every rank
+generates its own batch with its own seeds; no data-path collective (weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_SAMPLE = 84e6       # point traffic of one full-length sample (all iterations)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def load_config():
+    import yaml
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
+    return yaml.safe_load(str(g["config_yaml"]))
+
+
+def cpu_baseline(cfg, budget_s=30.0):
+    """The oracle (CPU restatement of the reference) on host cores: full-length samples, one core."""
+    from oracle import octa_oracle, sim_oracle
+    from octa_autosegmentation_amd import graph_io
+    t0 = time.time()
+    n = 0
+    while True:
+        e, info = sim_oracle.simulate(cfg, 900 + n)
+        na = info["n_art_edges"]
+        np.maximum(octa_oracle.rasterize(e[:na], [304, 304]), octa_oracle.rasterize(e[na:], [304, 304]))
+        octa_oracle.fs_dither(octa_oracle.rasterize(graph_io.edges_as_read_back(e), [1216, 1216]))
+        n += 1
+        if time.time() - t0 > budget_s * 0.6 or n >= 3:
+            break
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{n} full-length samples (I=100+150, N=2000) incl. 304x304 image + 1216x1216 label, oracle/ C++ on one core"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from octa_autosegmentation_amd import pipeline
+    cfg = load_config()
+    B = args.batch
+    gen = pipeline.TripleGenerator(cfg, B)
+
+    def step(i):
+        seeds = (np.arange(B, dtype=np.int64) + 100000 * rank + 1000 * i + 7).astype(np.uint32)
+        return gen.generate(seeds)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step(i)
+    barrier()
+    ka = kb = 0.0
+    la = lb = 0
+    bif_ms = 0.0
+    raster_ms = 0.0
+    t0 = time.time()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+        tm = out["result"].timing
+        ka += tm["kernel_a_ms"]; kb += tm["kernel_b_ms"]; la += tm["launches_a"]; lb += tm["launches_b"]
+        bif_ms += tm["host_bif_ms"]
+    barrier()
+    dt = time.time() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    err = int(out["result"].stats[:, 0].max())
+    assert err == 0, f"simulator reported error bits {err:#x}"
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        # dominant kernel: launch B (ordered arterial growth + O2->CO2 conversion + venous assignment)
+        dom_ms, dom_n, dom_name = (kb, lb, "sim_iter_b_kernel") if kb >= ka else (ka, la, "sim_iter_a_kernel")
+        n_iter = max(lb // max(args.steps, 1), 1)
+        bytes_per_launch = ALGO_BYTES_PER_SAMPLE / (2.0 * n_iter) * B
+        achieved = bytes_per_launch / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9
+        line = {
+            "metric": "synthetic OCTA samples/sec (graph + 304x304 image + 1216x1216 label triples)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {B}-sample vessel-graph batch (docker/vessel_graph_gen_docker_config.yml, "
+                                   f"I=100+150, N=2000) + tree2img rasterise 304x304 image and 1216x1216 label",
+                       "batch_per_gpu": B, "parallelism": f"sample-sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
+                         "note": "simulator launches are dependency/latency-bound (250 dependent iterations x 2 launches), "
+                                 "not HBM-bound; see DESIGN.md"},
+            "kernel_ms_per_step": {"sim_iter_a": ka / args.steps, "sim_iter_b": kb / args.steps,
+                                   "host_bifurcation_callback": bif_ms / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line))
+    gen.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -143,6 +143,12 @@ int octa_sim_export_edges(octa_sim *sim, double *h_edges);
  * 4 O2->CO2, 6 assign-ven, 7 speculate-ven, 8 ordered-ven, 9 CO2 removal). */
 int octa_sim_stats(octa_sim *sim, int64_t *h_stats);
 
+/* Timing of the last octa_sim_run, h_out8: [0] sum of launch-A kernel durations (ms, HIP events on
+ * the launch stream), [1] launches A, [2] sum of launch-B durations (ms), [3] launches B, [4] wall ms
+ * of the iteration loop, [5] host ms spent in the bifurcation callback, [6] requests served,
+ * [7] bytes of HBM held by the simulator. */
+int octa_sim_timing(octa_sim *sim, double *h_out8);
+
 /* Final O2 / CO2 fields of one sample (host buffers, capacity in points); returns counts. */
 int octa_sim_fields(octa_sim *sim, int sample, double *h_oxy, int64_t cap_oxy, int64_t *n_oxy, double *h_co2,
                     int64_t cap_co2, int64_t *n_co2);

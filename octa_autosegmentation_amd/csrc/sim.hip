@@ -13,6 +13,7 @@
 // Per-sample state stays resident in HBM (about 16 MB per sample, dominated by the pre-generated
 // candidate stream); LDS (155,648 B dynamic) holds tiles, sort keys and the kd key/index arrays.
 
+#include <chrono>
 #include <vector>
 
 #include "common.h"
@@ -276,6 +277,10 @@ struct octa_sim {
     bool ran = false;
     // host copies for export
     std::vector<SampleScalars> h_sc;
+    // kernel timing of the last run (HIP events on the launch stream)
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    double ms_a = 0, ms_b = 0, ms_total = 0, ms_host_bif = 0;
+    long n_a = 0, n_b = 0, n_bif_req = 0;
     size_t bytes = 0;
 };
 
@@ -353,6 +358,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_iter_b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIM_LDS);
         if (e != hipSuccess) { octa::set_error("octa_sim_create: cannot reserve %zu B of LDS: %s", SIM_LDS, hipGetErrorString(e)); rc = -1; }
     }
+    if (!rc) for (int k = 0; k < 3; k++) if (hipEventCreate(&S->ev[k]) != hipSuccess) { octa::set_error("octa_sim_create: hipEventCreate failed"); rc = -1; }
     if (rc) { octa_sim_destroy(S); return -1; }
     *out = S;
     return 0;
@@ -365,6 +371,7 @@ extern "C" void octa_sim_destroy(octa_sim *S) {
     if (S->h_reqs) e = hipHostFree(S->h_reqs);
     if (S->h_results) e = hipHostFree(S->h_results);
     if (S->h_req_count) e = hipHostFree(S->h_req_count);
+    for (int k = 0; k < 3; k++) if (S->ev[k]) e = hipEventDestroy(S->ev[k]);
     (void)e;
     delete S;
 }
@@ -440,21 +447,41 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
         if (n > 0) {
             OCTA_HIP_CHECK(hipMemcpyAsync(S->h_reqs, P.reqs + (size_t)slot * REQ_CAP, sizeof(BifRequest) * n, hipMemcpyDeviceToHost, stream));
             OCTA_HIP_CHECK(hipStreamSynchronize(stream));
+            auto t0 = std::chrono::steady_clock::now();
             bif(n, reinterpret_cast<const octa_bif_request *>(S->h_reqs), S->h_results, user);
+            S->ms_host_bif += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            S->n_bif_req += n;
             OCTA_HIP_CHECK(hipMemcpyAsync(P.bif_results, S->h_results, sizeof(double) * 6 * n, hipMemcpyHostToDevice, stream));
             OCTA_HIP_CHECK(hipMemsetAsync(P.req_count + slot, 0, sizeof(int), stream));
         }
         return 0;
     };
+    S->ms_a = S->ms_b = S->ms_total = S->ms_host_bif = 0; S->n_a = S->n_b = S->n_bif_req = 0;
+    auto wall0 = std::chrono::steady_clock::now();
     for (int it = 0; it <= C.n_iter; it++) {
+        float ms = 0;
+        OCTA_HIP_CHECK(hipEventRecord(S->ev[0], stream));
         hipLaunchKernelGGL(sim_iter_a_kernel, dim3((unsigned)B), dim3(SIM_THREADS), SIM_LDS, stream, P, it, it > 0 ? 1 : 0);
         OCTA_HIP_CHECK(hipGetLastError());
-        if (it == C.n_iter) break;
+        OCTA_HIP_CHECK(hipEventRecord(S->ev[1], stream));
+        if (it == C.n_iter) {
+            OCTA_HIP_CHECK(hipEventSynchronize(S->ev[1]));
+            OCTA_HIP_CHECK(hipEventElapsedTime(&ms, S->ev[0], S->ev[1]));
+            S->ms_a += ms; S->n_a++;
+            break;
+        }
         if (serve(0)) return -1;
+        OCTA_HIP_CHECK(hipEventElapsedTime(&ms, S->ev[0], S->ev[1]));
+        S->ms_a += ms; S->n_a++;
+        OCTA_HIP_CHECK(hipEventRecord(S->ev[0], stream));
         hipLaunchKernelGGL(sim_iter_b_kernel, dim3((unsigned)B), dim3(SIM_THREADS), SIM_LDS, stream, P, it);
         OCTA_HIP_CHECK(hipGetLastError());
+        OCTA_HIP_CHECK(hipEventRecord(S->ev[1], stream));
         if (serve(1)) return -1;
+        OCTA_HIP_CHECK(hipEventElapsedTime(&ms, S->ev[0], S->ev[1]));
+        S->ms_b += ms; S->n_b++;
     }
+    S->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     S->h_sc.resize(B);
     OCTA_HIP_CHECK(hipMemcpyAsync(S->h_sc.data(), P.sc, sizeof(SampleScalars) * B, hipMemcpyDeviceToHost, stream));
     OCTA_HIP_CHECK(hipStreamSynchronize(stream));
@@ -535,5 +562,12 @@ extern "C" int octa_sim_fields(octa_sim *S, int sample, double *h_oxy, int64_t c
         int64_t n = sc.n_co2 < cap_co2 ? sc.n_co2 : cap_co2;
         OCTA_HIP_CHECK(hipMemcpy(h_co2, S->P.co2 + (size_t)sample * CCAP * 3, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+extern "C" int octa_sim_timing(octa_sim *S, double *h_out8) {
+    if (!S || !S->ran || !h_out8) { octa::set_error("octa_sim_timing: run the simulation first"); return -2; }
+    h_out8[0] = S->ms_a; h_out8[1] = (double)S->n_a; h_out8[2] = S->ms_b; h_out8[3] = (double)S->n_b;
+    h_out8[4] = S->ms_total; h_out8[5] = S->ms_host_bif; h_out8[6] = (double)S->n_bif_req; h_out8[7] = (double)S->bytes;
     return 0;
 }

@@ -471,6 +471,84 @@ OCTA_HD inline void kd_nth_element(const KdPair &a, int first, int nth, int last
     }
 }
 
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same algorithm as kd_nth_element executed by one wave: the two unguarded linear scans of the
+// Hoare partition test 64 consecutive elements per step (ballot + count-trailing-zeros), everything
+// else (median of three, swaps, final insertion sort, the rare heap fallback) is done by lane 0.
+// The element moves are identical to the sequential algorithm, so the permutation is too.
+__device__ inline void kd_nth_element_wave(const KdPair &a, int first, int nth, int last, int lane) {
+    if (first == last || nth == last) return;
+    int n = last - first, lg = 0;
+    while ((n >> (lg + 1)) > 0) lg++;
+    int depth = lg * 2;
+    while (last - first > 3) {
+        if (depth == 0) {
+            if (lane == 0) { kd_heap_select(a, first, nth + 1, last); kd_swap(a, first, nth); }
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
+        --depth;
+        if (lane == 0) {
+            int mid = first + (last - first) / 2;
+            int A = first + 1, B = mid, C = last - 1;
+            if (kd_less(a, A, B)) {
+                if (kd_less(a, B, C)) kd_swap(a, first, B);
+                else if (kd_less(a, A, C)) kd_swap(a, first, C);
+                else kd_swap(a, first, A);
+            } else if (kd_less(a, A, C)) kd_swap(a, first, A);
+            else if (kd_less(a, B, C)) kd_swap(a, first, C);
+            else kd_swap(a, first, B);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double pv = a.key[first];
+        const unsigned short pi = a.idx[first];
+        int lo = first + 1, hi = last;
+        while (true) {
+            while (true) {  // while (less(lo, pivot)) ++lo;
+                int i = lo + lane;
+                bool stop = (i >= last) || !kd_less_iv(a, i, pv, pi);
+                unsigned long long bal = __ballot(stop);
+                if (bal) { lo += (int)__ffsll((long long)bal) - 1; break; }
+                lo += 64;
+            }
+            int h = hi - 1;  // --hi; while (less(pivot, hi)) --hi;
+            while (true) {
+                int j = h - lane;
+                bool stop = (j < first) || !kd_less_vi(pv, pi, a, j);
+                unsigned long long bal = __ballot(stop);
+                if (bal) { h -= (int)__ffsll((long long)bal) - 1; break; }
+                h -= 64;
+            }
+            hi = h;
+            if (!(lo < hi)) break;
+            if (lane == 0) kd_swap(a, lo, hi);
+            __builtin_amdgcn_wave_barrier();
+            ++lo;
+        }
+        int cut = lo;
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    if (lane == 0) {
+        for (int i = first + 1; i < last; ++i) {
+            double vv = a.key[i]; unsigned short vi = a.idx[i];
+            if (kd_less(a, i, first)) {
+                for (int k = i; k > first; --k) { a.key[k] = a.key[k - 1]; a.idx[k] = a.idx[k - 1]; }
+                a.key[first] = vv; a.idx[first] = vi;
+            } else {
+                int lastp = i, next = i - 1;
+                while (kd_less_vi(vv, vi, a, next)) {
+                    a.key[lastp] = a.key[next]; a.idx[lastp] = a.idx[next];
+                    lastp = next; --next;
+                }
+                a.key[lastp] = vv; a.idx[lastp] = vi;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+#endif
+
 // scipy cKDTree build order (leafsize 16, compact, median): fills kd_idx (tree.indices) and kd_rank.
 // Level-synchronous: range boundaries depend only on n; a range that became a leaf is marked done.
 // LDS: key double[OCAP] + idx u16[OCAP] + per-level range table.
@@ -565,13 +643,32 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
             for (int i = s; i < e; i++) key[i] = pts[3 * (int)idx[i] + d];
         }
         b.sync();
-        // 3. nth_element per range (one thread each)
+        // 3. nth_element per range: long ranges by one wave each, short ranges by one thread each
+#if defined(__HIP_DEVICE_COMPILE__)
+        {
+            const int wv = b.tid >> 6, nw = (b.nth + 63) >> 6, lane = b.tid & 63;
+            for (int q = wv; q < nr; q += nw) {
+                int d = rd[q];
+                int s = rs[q], e = re[q];
+                if (d < 0 || e - s < 192) continue;
+                kd_nth_element_wave(kp, s, s + (e - s) / 2, e, lane);
+            }
+        }
+        b.sync();
+        for (int q = b.tid; q < nr; q += b.nth) {
+            int d = rd[q];
+            int s = rs[q], e = re[q];
+            if (d < 0 || e - s >= 192) continue;
+            kd_nth_element(kp, s, s + (e - s) / 2, e);
+        }
+#else
         for (int q = b.tid; q < nr; q += b.nth) {
             int d = rd[q];
             if (d < 0) continue;
             int s = rs[q], e = re[q];
             kd_nth_element(kp, s, s + (e - s) / 2, e);
         }
+#endif
         b.sync();
         // 4. children that are still longer than a leaf form the next level
         if (b.tid == 0) {

@@ -1,0 +1,87 @@
+"""Graph file formats of the reference: the `node1,node2,radius` CSV (generate_vessel_graph.py:59-66,
+forest.py:196-207) and its read-back (visualize_vessel_graphs.py:71-75, data_transforms.py:369-375).
+
+Positions are written with str(np.ndarray) -- numpy's default print options, 8 fractional digits,
+fixed or (for the whole 3-vector) scientific notation -- so everything downstream of a CSV (the label
+rasteriser in particular) sees positions rounded to that text. `positions_as_read_back` reproduces
+that rounding arithmetically for whole arrays, so a batch can be rasterised on the GPU exactly as if
+it had gone through the file, without formatting and re-parsing millions of numbers.
+"""
+import csv
+import io
+
+import numpy as np
+
+
+def edges_to_csv_text(edges):
+    """CSV text exactly as the reference writes it (numpy str() of the positions, float repr of the radius)."""
+    buf = io.StringIO(newline="")
+    w = csv.writer(buf)
+    w.writerow(["node1", "node2", "radius"])
+    for e in edges:
+        w.writerow([np.array(e[0:3]), np.array(e[3:6]), float(e[6])])
+    return buf.getvalue()
+
+
+def write_csv(edges, path):
+    with open(path, "w+", newline="") as f:
+        f.write(edges_to_csv_text(edges))
+
+
+def parse_legacy_position(s):
+    # tree2img.py:73-76
+    return [float(c) for c in s[1:-1].split(" ") if len(c) > 0]
+
+
+def read_csv(path):
+    """CSV -> float64 [n,7] (the positions as the reference's 'Legacy' string branch parses them)."""
+    rows = []
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            rows.append(parse_legacy_position(row["node1"]) + parse_legacy_position(row["node2"]) + [float(row["radius"])])
+    return np.asarray(rows, dtype=np.float64).reshape(-1, 7)
+
+
+def _round_decimals(x, scale):
+    """nearest double to round(x * scale) / scale for exactly representable powers of ten `scale`."""
+    k = np.rint(np.asarray(x, dtype=np.longdouble) * np.asarray(scale, dtype=np.longdouble)).astype(np.float64)
+    return k / scale
+
+
+def positions_as_read_back(pos):
+    """float64 [n,3] -> the values float(str(np.array(row))) would give (numpy 2.x default printing):
+    scientific notation with 8 mantissa decimals when min|x| < 1e-4 or max|x|/min|x| > 1e3 over the
+    non-zero entries of the row (or max >= 1e8), otherwise fixed notation with 8 decimals."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 3)
+    a = np.abs(pos)
+    nz = np.where(a > 0, a, np.nan)
+    with np.errstate(all="ignore"):
+        mx = np.nanmax(nz, axis=1)
+        mn = np.nanmin(nz, axis=1)
+        sci = (mx >= 1e8) | (mn < 1e-4) | (mx / mn > 1000.0)
+    sci = np.where(np.isnan(mx), False, sci)
+    out = _round_decimals(pos, 1e8)
+    if sci.any():
+        p = pos[sci]
+        ap = np.abs(p)
+        with np.errstate(divide="ignore"):
+            e = np.floor(np.log10(np.where(ap > 0, ap, 1.0))).astype(np.int64)
+        # guard the log10 edge: mantissa must be in [1, 10)
+        m = ap / np.power(10.0, e)
+        e = np.where(m >= 10.0, e + 1, np.where((m < 1.0) & (ap > 0), e - 1, e))
+        pw = 8 - e
+        big = pw > 22  # not reachable for simulator coordinates; fall back to text for exactness
+        scale = np.power(10.0, np.clip(pw, 0, 22).astype(np.float64))
+        r = np.where(pw >= 0, _round_decimals(p, scale), p)
+        if big.any() or (pw < 0).any():
+            for i, j in zip(*np.nonzero(big | (pw < 0))):
+                r[i, j] = float(np.format_float_scientific(p[i, j], precision=8, unique=True))
+        out[sci] = np.where(ap > 0, r, p)
+    return out
+
+
+def edges_as_read_back(edges):
+    e = np.array(edges, dtype=np.float64, copy=True).reshape(-1, 7)
+    e[:, 0:3] = positions_as_read_back(e[:, 0:3])
+    e[:, 3:6] = positions_as_read_back(e[:, 3:6])
+    return e

@@ -1,0 +1,57 @@
+"""End-to-end synthetic OCTA triples on one MI355X: graph (CSV rows) + 304x304 image + 1216x1216 label.
+
+Mirrors what the reference produces with
+    generate_vessel_graph.py --config_file docker/vessel_graph_gen_docker_config.yml     (graph + image)
+    visualize_vessel_graphs.py --resolution 1216,1216,16 --binarize                      (label)
+(docker/dockershell.sh:10-17), for a whole batch of seeded samples at once:
+  * graphs: BatchSimulator (HIP simulator, bit-exact CSV rows),
+  * image : arterial and venous edges rasterised separately at 304x304 and max-combined
+            (generate_vessel_graph.py:79-86),
+  * label : all edges, positions as read back from the CSV text, rasterised at 1216x1216 and
+            Floyd-Steinberg binarised (visualize_vessel_graphs.py:95-99).
+"""
+import numpy as np
+
+from . import graph_io
+from .vessel_graph_generation import greenhouse, tree2img
+
+
+class TripleGenerator:
+    def __init__(self, config, batch, device_index=None, label_resolution=(1216, 1216)):
+        import torch
+        self.config = config
+        self.batch = int(batch)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device_index is None else device_index)
+        self.sim = greenhouse.BatchSimulator(config, batch, self.device.index)
+        g, o = config["Greenhouse"], config.get("output", {})
+        shape = np.array([g["SimulationSpace"][k] for k in ("no_voxel_x", "no_voxel_y", "no_voxel_z")])
+        vol = [int(d) for d in shape * o.get("image_scale_factor", 304)]          # generate_vessel_graph.py:43
+        self.proj_axis = int(o.get("proj_axis", 2))
+        self.image_res = [v for i, v in enumerate(vol) if i != self.proj_axis]     # :81-82
+        self.label_res = list(label_resolution)
+
+    def close(self):
+        self.sim.close()
+
+    def generate(self, seeds, want_label=True):
+        """Returns dict(result=SimulationResult, image=uint8 CUDA [B,H,W], label=uint8 CUDA {0,255} [B,1216,1216])."""
+        import torch
+        res = self.sim.run(seeds)
+        B = self.batch
+        off, n_art = res.edge_off, res.n_art
+        d_edges = torch.from_numpy(res.edges).to(self.device, non_blocking=True)
+        # 2B graphs: arterial_k, venous_k interleaved -> max of the pairs (np.maximum(art_mat, ven_mat))
+        split = np.empty(2 * B + 1, np.int64)
+        split[0::2] = off
+        split[1::2] = off[:-1] + n_art
+        pair = tree2img.rasterize_edges_device(d_edges, split, self.image_res, self.proj_axis)
+        pair = pair.view(B, 2, pair.shape[1], pair.shape[2])
+        image = tree2img.maximum_u8_device(pair[:, 0].contiguous(), pair[:, 1].contiguous())
+        out = dict(result=res, image=image)
+        if want_label:
+            rb = graph_io.edges_as_read_back(res.edges)
+            d_rb = torch.from_numpy(rb).to(self.device, non_blocking=True)
+            grey = tree2img.rasterize_edges_device(d_rb, off, self.label_res, 2)
+            out["label_grey"] = grey
+            out["label"] = tree2img.binarize_label_device(grey)
+        return out

@@ -160,7 +160,12 @@ class BatchSimulator:
         _native.check(self._lib.octa_sim_export_edges(self._h, edges.ctypes.data), "octa_sim_export_edges")
         stats = np.zeros((self.batch, 24), np.int64)
         _native.check(self._lib.octa_sim_stats(self._h, stats.ctypes.data), "octa_sim_stats")
-        return SimulationResult(edges, off, n_art, stats)
+        timing = np.zeros(8)
+        _native.check(self._lib.octa_sim_timing(self._h, timing.ctypes.data), "octa_sim_timing")
+        res = SimulationResult(edges, off, n_art, stats)
+        res.timing = dict(kernel_a_ms=timing[0], launches_a=int(timing[1]), kernel_b_ms=timing[2], launches_b=int(timing[3]),
+                          loop_wall_ms=timing[4], host_bif_ms=timing[5], bif_requests=int(timing[6]), hbm_bytes=int(timing[7]))
+        return res
 
     def fields(self, k):
         oxy, co2 = np.zeros((16384, 3)), np.zeros((16384, 3))

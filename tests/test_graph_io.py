@@ -1,0 +1,43 @@
+"""CPU: CSV text format helpers and the arithmetic emulation of numpy's position printing."""
+import numpy as np
+import yaml
+
+from octa_autosegmentation_amd import graph_io
+
+
+def _parse_text_rows(pos):
+    out = np.zeros_like(pos)
+    for i, row in enumerate(pos):
+        out[i] = graph_io.parse_legacy_position(str(np.array(row)))
+    return out
+
+
+def test_read_back_emulation_matches_numpy_printing():
+    rng = np.random.default_rng(0)
+    n = 6000
+    pos = rng.uniform(-0.01, 1.02, (n, 3))
+    pos[:, 2] = rng.uniform(-2e-3, 0.0131, n)          # thin z: many rows switch to scientific notation
+    pos[::7, 2] = rng.uniform(-9e-5, 9e-5, n)[::7]
+    pos[::11, 0] = 0.0                                 # wall roots
+    pos[::13, 1] = 1 - 1e-6
+    pos[5] = [0.5, 0.25, 0.125]
+    pos[6] = [1e-5, 2e-6, 3e-9]
+    want = _parse_text_rows(pos)
+    got = graph_io.positions_as_read_back(pos)
+    assert (want == got).all(), np.nonzero((want != got).any(axis=1))[0][:10]
+
+
+def test_read_back_on_simulated_graph():
+    import os
+    from oracle import sim_oracle
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_golden.npz"))
+    cfg = yaml.safe_load(str(g["config_yaml"]))
+    cfg["Greenhouse"]["modes"][0]["I"] = 30
+    cfg["Greenhouse"]["modes"][1]["I"] = 20
+    edges, _ = sim_oracle.simulate(cfg, 0)
+    text = graph_io.edges_to_csv_text(edges)
+    assert text.encode() == g["run_s0_30_20_csv"].tobytes()
+    import csv, io
+    rows = list(csv.DictReader(io.StringIO(text)))
+    parsed = np.array([graph_io.parse_legacy_position(r["node1"]) + graph_io.parse_legacy_position(r["node2"]) + [float(r["radius"])] for r in rows])
+    assert (graph_io.edges_as_read_back(edges) == parsed).all()

@@ -1,0 +1,34 @@
+"""GPU: one batch through simulator -> image / label, every stage checked against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+
+def test_triples_match_oracle(hip_lib_built):
+    import torch
+    from octa_autosegmentation_amd import graph_io, pipeline
+    from oracle import octa_oracle, sim_oracle
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_golden.npz"))
+    cfg = yaml.safe_load(str(g["config_yaml"]))
+    cfg["Greenhouse"]["modes"][0]["I"] = 30
+    cfg["Greenhouse"]["modes"][1]["I"] = 20
+    gen = pipeline.TripleGenerator(cfg, 3)
+    out = gen.generate([0, 1, 2])
+    torch.cuda.synchronize()
+    res = out["result"]
+    for k in range(3):
+        name = f"run_s{k}_30_20"
+        edges = res.sample_edges(k)
+        assert graph_io.edges_to_csv_text(edges).encode() == g[name + "_csv"].tobytes()
+        e_or, info = sim_oracle.simulate(cfg, k)
+        na = info["n_art_edges"]
+        img = np.maximum(octa_oracle.rasterize(e_or[:na], [304, 304]), octa_oracle.rasterize(e_or[na:], [304, 304]))
+        assert (out["image"][k].cpu().numpy() == img).all()
+        grey = octa_oracle.rasterize(graph_io.edges_as_read_back(e_or), [1216, 1216])
+        assert (out["label_grey"][k].cpu().numpy() == grey).all()
+        assert (out["label"][k].cpu().numpy() == octa_oracle.fs_dither(grey)).all()
+    gen.close()
