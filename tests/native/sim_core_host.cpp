@@ -21,6 +21,24 @@ struct host_sim_params {
 
 double octa_simcore_gpow(double x, double y) { return octa_gpow::gpow(x, y); }
 
+// gpow vs the C library's pow on n pseudo-random inputs from the simulator's domain; returns mismatches
+long octa_simcore_gpow_check(long n, unsigned long long seed) {
+    const double ys[8] = {2.55, 2.9, 4.0, 1 / 2.55, 1 / 2.9, 0.25, 2.0, 5.0};
+    unsigned long long s = seed ? seed : 88172645463325252ULL;
+    long bad = 0;
+    for (long i = 0; i < n; i++) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        double u = (double)(s >> 11) / 9007199254740992.0;
+        double y = ys[i & 7], x;
+        if ((i & 7) >= 3 && (i & 7) <= 5) x = 1e-12 * pow(1e9, u);
+        else if ((i & 7) == 7) x = u * 3 + 1e-9;
+        else x = 1e-4 + u * 0.05;
+        double a = pow(x, y), m = octa_gpow::gpow(x, y);
+        if (a != m && !(a != a && m != m)) bad++;
+    }
+    return bad;
+}
+
 // nth_element restatement vs the real std::nth_element is checked from Python through this hook
 void octa_simcore_kd_indices(const double *pts, int n, unsigned short *out_idx) {
     std::vector<unsigned char> smem(2048 + (size_t)OCAP * 10 + 5 * KD_RANGES * 4 + 64);

@@ -1,0 +1,87 @@
+"""CPU: the simulator's device code (csrc/sim_core.h, gpow.h, sim_host.h) compiled as host C++ with a
+one-thread block (tests/native/sim_core_host.cpp) against the reference-made fixtures and the live
+libraries it restates. Catches kernel-logic regressions without a GPU; not a product path."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import yaml
+
+from oracle import sim_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def core():
+    src = os.path.join(ROOT, "tests", "native", "sim_core_host.cpp")
+    so = os.path.join(ROOT, "tests", "native", "libsimcorehost.so")
+    deps = [src] + [os.path.join(ROOT, "octa_autosegmentation_amd", "csrc", f) for f in ("sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h")]
+    if not os.path.exists(so) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
+    l = ctypes.CDLL(so)
+    l.octa_simcore_gpow_check.restype = ctypes.c_long
+    l.octa_simcore_gpow_check.argtypes = [ctypes.c_long, ctypes.c_ulonglong]
+    l.octa_simcore_kd_indices.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    l.octa_simcore_set_order.restype = ctypes.c_long
+    l.octa_simcore_set_order.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    l.octa_simcore_host_run.restype = ctypes.c_int
+    l.octa_simcore_host_run.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_ulonglong, sim_oracle.BIF_CB, ctypes.c_void_p,
+                                        ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
+    return l
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
+
+
+def test_gpow_is_glibc_pow(core):
+    assert core.octa_simcore_gpow_check(3_000_000, 1) == 0
+    assert core.octa_simcore_gpow_check(1_000_000, 987654321) == 0
+
+
+def test_nth_element_restatement_matches_scipy(core):
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(12)
+    for n in (1, 16, 17, 40, 300, 5000, 13000):
+        pts = np.ascontiguousarray(rng.uniform(0, 1, (n, 3)) * np.array([1, 1, 0.0131]))
+        out = np.zeros(n, np.uint16)
+        core.octa_simcore_kd_indices(pts.ctypes.data, n, out.ctypes.data)
+        assert (out == cKDTree(pts).indices).all(), n
+
+
+def test_set_emulation_matches_cpython(core):
+    rng = np.random.default_rng(5)
+    pts = np.ascontiguousarray(rng.uniform(0, 1, (2500, 3)))
+    for trial in range(25):
+        n = int(rng.integers(1, 900))
+        ids = rng.integers(0, n, int(n * 1.4)).astype(np.int32)
+        tuples = [tuple(float(x) for x in pts[i]) for i in range(n)]
+        s = set()
+        for i in ids:
+            s.add(tuples[i])
+        want = [tuples.index(t) for t in s]
+        out = np.zeros(n, np.int32)
+        k = core.octa_simcore_set_order(pts.ctypes.data, ids.ctypes.data, len(ids), out.ctypes.data)
+        assert out[:k].tolist() == want
+
+
+def test_phases_reproduce_reference_csv(core, golden):
+    for name in ("run_s0_30_20", "run_s3_30_20", "run_s5_10_5", "run_s11_20_0", "run_s4_0_12"):
+        seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])
+        cfg = yaml.safe_load(str(golden["config_yaml"]))
+        cfg["Greenhouse"]["modes"][0]["I"] = i1
+        cfg["Greenhouse"]["modes"][1]["I"] = i2
+        p = sim_oracle.params_from_config(cfg)
+        edges = np.zeros((40000, 7))
+        trace = np.zeros((max(i1 + i2, 1), 4), np.int64)
+        info = np.zeros(8, np.int64)
+        rc = core.octa_simcore_host_run(ctypes.addressof(p), seed, seed, sim_oracle._bif_cb, edges.ctypes.data, 40000,
+                                        trace.ctypes.data, info.ctypes.data)
+        assert rc == 0 and info[2] == 0
+        assert (trace[: info[7]] == golden[name + "_trace"]).all(), name
+        text = sim_oracle.edges_to_csv_text(edges[: info[0]])
+        assert text.encode() == golden[name + "_csv"].tobytes(), name
