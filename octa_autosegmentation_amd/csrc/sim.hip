@@ -24,7 +24,9 @@ using namespace octa_simk;
 namespace {
 
 constexpr int SIM_THREADS = 256;
-constexpr size_t SIM_LDS = 2048 + (size_t)OCAP * 10 + 5 * KD_RANGES * 4;  // 155,648 B
+constexpr size_t SIM_LDS = 2048 + (size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES;  // 160,768 B
+static_assert(SIM_LDS <= 160 * 1024, "LDS budget");
+static_assert(SIM_THREADS == 256, "kd mailboxes are sized for 4 waves");
 constexpr int REQ_CAP = 8192;
 
 static_assert(sizeof(BifRequest) == sizeof(octa_bif_request), "request layout must match the public header");

@@ -44,6 +44,8 @@ constexpr int NCANDCAP = 8192; // candidates per iteration
 constexpr int TILE = 1024;     // points per LDS tile in brute-force queries
 constexpr int ACCCAP = 2048;   // accepted sinks per iteration
 constexpr int KD_RANGES = 1024; // ranges per kd level (> OCAP / 17)
+constexpr int KD_MAILBOX_OFF = OCAP * 10 + 5 * KD_RANGES * 4;  // LDS offset (after user()) of the per-wave swap mailboxes
+constexpr int KD_MAILBOX_BYTES = 4 * 128 * 10;                 // 4 waves x 128 x (double + u16)
 constexpr int GRID_MAX = 128;   // uniform-grid cells per axis (x, y); the thin z extent is not binned
 
 enum ErrBits { ERR_NODE_CAP = 1, ERR_OXY_CAP = 2, ERR_CO2_CAP = 4, ERR_GROUP_CAP = 8, ERR_PAIR_CAP = 16, ERR_SET_CAP = 32,
@@ -189,6 +191,30 @@ OCTA_HD inline void atomic_or_int(int *p, int v) {
     atomicOr(p, v);
 #else
     *p |= v;
+#endif
+}
+
+
+OCTA_HD inline unsigned long long dbl_sortable(double v) {
+    unsigned long long u = octa_gpow::asu64(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+OCTA_HD inline double dbl_unsortable(unsigned long long e) {
+    unsigned long long u = (e >> 63) ? (e & 0x7fffffffffffffffULL) : ~e;
+    return octa_gpow::asf64(u);
+}
+OCTA_HD inline void atomic_max_u64(unsigned long long *p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax(p, v);
+#else
+    if (v > *p) *p = v;
+#endif
+}
+OCTA_HD inline void atomic_min_u64(unsigned long long *p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
 #endif
 }
 
@@ -477,7 +503,8 @@ OCTA_HD inline void kd_nth_element(const KdPair &a, int first, int nth, int last
 // Hoare partition test 64 consecutive elements per step (ballot + count-trailing-zeros), everything
 // else (median of three, swaps, final insertion sort, the rare heap fallback) is done by lane 0.
 // The element moves are identical to the sequential algorithm, so the permutation is too.
-__device__ inline void kd_nth_element_wave(const KdPair &a, int first, int nth, int last, int lane) {
+__device__ inline void kd_nth_element_wave(const KdPair &a, int first, int nth, int last, int lane, double *mbk /*[128]*/,
+                                           unsigned short *mbi /*[128]*/) {
     if (first == last || nth == last) return;
     int n = last - first, lg = 0;
     while ((n >> (lg + 1)) > 0) lg++;
@@ -504,6 +531,45 @@ __device__ inline void kd_nth_element_wave(const KdPair &a, int first, int nth, 
         const double pv = a.key[first];
         const unsigned short pi = a.idx[first];
         int lo = first + 1, hi = last;
+        // Block phase. Hoare's partition swaps the k-th element from the left that is not < pivot with
+        // the k-th element from the right that is not > pivot, while they have not crossed. Examine 64
+        // elements per side at a time, pair the stoppers by rank and swap them in parallel through a
+        // small LDS mailbox; the unexamined middle [lo, hi) never lets the two sides overlap here.
+        {
+            unsigned long long mL = 0, mR = 0;
+            int Lb = 0, Rb = 0;
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            while (true) {
+                if (mL == 0) {
+                    if (hi - lo < 64) break;
+                    Lb = lo;
+                    mL = __ballot(!kd_less_iv(a, Lb + lane, pv, pi));
+                    lo += 64;
+                }
+                if (mR == 0) {
+                    if (hi - lo < 64) break;
+                    Rb = hi - 1;
+                    mR = __ballot(!kd_less_vi(pv, pi, a, Rb - lane));
+                    hi -= 64;
+                }
+                if (mL == 0 || mR == 0) continue;
+                const int cl = __popcll(mL), cr = __popcll(mR), c = cl < cr ? cl : cr;
+                const bool isL = (mL >> lane) & 1ull, isR = (mR >> lane) & 1ull;
+                const int rl = __popcll(mL & lt), rr = __popcll(mR & lt);
+                const int pL = Lb + lane, pR = Rb - lane;
+                if (isL && rl < c) { mbk[rl] = a.key[pL]; mbi[rl] = a.idx[pL]; }
+                if (isR && rr < c) { mbk[64 + rr] = a.key[pR]; mbi[64 + rr] = a.idx[pR]; }
+                __builtin_amdgcn_wave_barrier();
+                if (isL && rl < c) { a.key[pL] = mbk[64 + rl]; a.idx[pL] = mbi[64 + rl]; }
+                if (isR && rr < c) { a.key[pR] = mbk[rr]; a.idx[pR] = mbi[rr]; }
+                __builtin_amdgcn_wave_barrier();
+                mL = __ballot(isL && rl >= c);
+                mR = __ballot(isR && rr >= c);
+            }
+            // hand over to the cursor form: the sequential algorithm would stand on the next pending stoppers
+            if (mL) lo = Lb + (int)__ffsll((long long)mL) - 1;
+            if (mR) hi = Rb - ((int)__ffsll((long long)mR) - 1) + 1;
+        }
         while (true) {
             while (true) {  // while (less(lo, pivot)) ++lo;
                 int i = lo + lane;
@@ -561,86 +627,74 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
     for (int i = b.tid; i < n; i += b.nth) idx[i] = (unsigned short)i;
     if (b.tid == 0) { rs[0] = 0; re[0] = n; }
     b.sync();
-    int nr = (n > 0) ? 1 : 0;
+    int nr = (n > 16) ? 1 : 0;  // a range of <= leafsize points is a leaf: left in input order
     KdPair kp = {key, idx};
     while (nr > 0) {
-        // 1. split dimension per range (first dim with the largest spread), cooperative for long ranges
-        for (int q = 0; q < nr; q++) {
-            int s = rs[q], e = re[q];
-            if (e - s <= 16) { if (b.tid == 0) rd[q] = -1; continue; }
-            if (e - s >= 4 * b.nth || b.nth == 1) {
-                double mx[3], mn[3];
-                bool any = false;
-                for (int i = s + b.tid; i < e; i += b.nth) {
-                    const double *p = pts + 3 * (int)idx[i];
-                    for (int k = 0; k < 3; k++) {
-                        if (!any) { mx[k] = mn[k] = p[k]; }
-                        else { mx[k] = mx[k] > p[k] ? mx[k] : p[k]; mn[k] = mn[k] < p[k] ? mn[k] : p[k]; }
-                    }
-                    any = true;
-                }
-#if defined(__HIP_DEVICE_COMPILE__)
-                // wave reduce then cross-wave via atomics on LDS doubles encoded as ordered ints
-                for (int k = 0; k < 3; k++) {
-                    double a1 = any ? mx[k] : -INFINITY, a2 = any ? mn[k] : INFINITY;
-                    for (int d = 32; d > 0; d >>= 1) {
-                        double o1 = __shfl_xor(a1, d, 64), o2 = __shfl_xor(a2, d, 64);
-                        a1 = a1 > o1 ? a1 : o1; a2 = a2 < o2 ? a2 : o2;
-                    }
-                    mx[k] = a1; mn[k] = a2;
-                }
-                double *wred = reinterpret_cast<double *>(b.smem + 512);  // [nwaves][6] doubles, nwaves <= 16
-                b.sync();
-                if ((b.tid & 63) == 0) for (int k = 0; k < 3; k++) { wred[(b.tid >> 6) * 6 + k] = mx[k]; wred[(b.tid >> 6) * 6 + 3 + k] = mn[k]; }
-                b.sync();
-                if (b.tid == 0) {
-                    int nw = (b.nth + 63) >> 6;
-                    for (int k = 0; k < 3; k++) {
-                        double a1 = wred[k], a2 = wred[3 + k];
-                        for (int w = 1; w < nw; w++) { a1 = a1 > wred[w * 6 + k] ? a1 : wred[w * 6 + k]; a2 = a2 < wred[w * 6 + 3 + k] ? a2 : wred[w * 6 + 3 + k]; }
-                        mx[k] = a1; mn[k] = a2;
-                    }
-                }
-#endif
-                if (b.tid == 0) {
-                    int d = 0; double size = 0;
-                    for (int k = 0; k < 3; k++) if (mx[k] - mn[k] > size) { d = k; size = mx[k] - mn[k]; }
-                    rd[q] = (mx[d] == mn[d]) ? -1 : d;
-                }
-                b.sync();
-            }
-        }
+        // 1. bounding box per range, element-parallel: every thread walks a contiguous chunk of the index
+        //    array (ranges are sorted, disjoint slices of it), gathers the three coordinates and folds
+        //    them into a per-range min/max table with LDS 64-bit atomics on order-preserving encodings.
+        //    The key array is free at this point and hosts the table.
+        unsigned long long *bb = reinterpret_cast<unsigned long long *>(key);  // [nr][6]: max xyz, min xyz
+        for (int q = b.tid; q < nr; q += b.nth)
+            for (int k = 0; k < 3; k++) { bb[6 * q + k] = 0ull; bb[6 * q + 3 + k] = ~0ull; }
         b.sync();
-        // short ranges: one thread per range
-        for (int q = b.tid; q < nr; q += b.nth) {
-            int s = rs[q], e = re[q];
-            if (e - s <= 16 || e - s >= 4 * b.nth || b.nth == 1) continue;
-            double mx[3], mn[3];
-            const double *p0 = pts + 3 * (int)idx[s];
-            for (int k = 0; k < 3; k++) mx[k] = mn[k] = p0[k];
-            for (int i = s + 1; i < e; i++) {
+        {
+            const int chunk = (n + b.nth - 1) / b.nth;
+            const int i0 = b.tid * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+            int q = 0;
+            if (i0 < i1) {  // last range starting at or before i0
+                int lo_ = 0, hi_ = nr - 1;
+                while (lo_ < hi_) { int mid = (lo_ + hi_ + 1) >> 1; if (rs[mid] <= i0) lo_ = mid; else hi_ = mid - 1; }
+                q = lo_;
+            }
+            bool have = false;
+            unsigned long long mx[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+            for (int i = i0; i < i1; i++) {
+                while (q + 1 < nr && rs[q + 1] <= i) {
+                    if (have) { for (int k = 0; k < 3; k++) { atomic_max_u64(&bb[6 * q + k], mx[k]); atomic_min_u64(&bb[6 * q + 3 + k], mn[k]); } have = false; }
+                    q++;
+                }
+                if (i < rs[q] || i >= re[q]) continue;  // element of a finished leaf
                 const double *p = pts + 3 * (int)idx[i];
-                for (int k = 0; k < 3; k++) { mx[k] = mx[k] > p[k] ? mx[k] : p[k]; mn[k] = mn[k] < p[k] ? mn[k] : p[k]; }
+                for (int k = 0; k < 3; k++) {
+                    unsigned long long e = dbl_sortable(p[k]);
+                    if (!have) { mx[k] = mn[k] = e; }
+                    else { mx[k] = mx[k] > e ? mx[k] : e; mn[k] = mn[k] < e ? mn[k] : e; }
+                }
+                have = true;
             }
-            int d = 0; double size = 0;
-            for (int k = 0; k < 3; k++) if (mx[k] - mn[k] > size) { d = k; size = mx[k] - mn[k]; }
-            rd[q] = (mx[d] == mn[d]) ? -1 : d;
+            if (have) for (int k = 0; k < 3; k++) { atomic_max_u64(&bb[6 * q + k], mx[k]); atomic_min_u64(&bb[6 * q + 3 + k], mn[k]); }
         }
         b.sync();
-        // 2. gather the split-dimension keys (ranges are disjoint slices of the key array)
-        for (int q = 0; q < nr; q++) {
-            int d = rd[q];
-            if (d < 0) continue;
-            int s = rs[q], e = re[q];
-            if (e - s >= 4 * b.nth || b.nth == 1)
-                for (int i = s + b.tid; i < e; i += b.nth) key[i] = pts[3 * (int)idx[i] + d];
-        }
         for (int q = b.tid; q < nr; q += b.nth) {
-            int d = rd[q];
-            if (d < 0) continue;
-            int s = rs[q], e = re[q];
-            if (e - s >= 4 * b.nth || b.nth == 1) continue;
-            for (int i = s; i < e; i++) key[i] = pts[3 * (int)idx[i] + d];
+            int d = 0;
+            double size = 0;
+            double mxd = 0, mnd = 0;
+            for (int k = 0; k < 3; k++) {
+                double hi_ = dbl_unsortable(bb[6 * q + k]), lo_ = dbl_unsortable(bb[6 * q + 3 + k]);
+                if (hi_ - lo_ > size) { d = k; size = hi_ - lo_; }
+                if (k == 0) { mxd = hi_; mnd = lo_; }
+            }
+            mxd = dbl_unsortable(bb[6 * q + d]); mnd = dbl_unsortable(bb[6 * q + 3 + d]);
+            rd[q] = (mxd == mnd) ? -1 : d;
+        }
+        b.sync();
+        // 2. gather the split-dimension keys, element-parallel with the same chunking
+        {
+            const int chunk = (n + b.nth - 1) / b.nth;
+            const int i0 = b.tid * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+            int q = 0;
+            if (i0 < i1) {
+                int lo_ = 0, hi_ = nr - 1;
+                while (lo_ < hi_) { int mid = (lo_ + hi_ + 1) >> 1; if (rs[mid] <= i0) lo_ = mid; else hi_ = mid - 1; }
+                q = lo_;
+            }
+            for (int i = i0; i < i1; i++) {
+                while (q + 1 < nr && rs[q + 1] <= i) q++;
+                if (i < rs[q] || i >= re[q]) continue;
+                int d = rd[q];
+                if (d >= 0) key[i] = pts[3 * (int)idx[i] + d];
+            }
         }
         b.sync();
         // 3. nth_element per range: long ranges by one wave each, short ranges by one thread each
@@ -651,7 +705,9 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 int d = rd[q];
                 int s = rs[q], e = re[q];
                 if (d < 0 || e - s < 192) continue;
-                kd_nth_element_wave(kp, s, s + (e - s) / 2, e, lane);
+                double *mbk = reinterpret_cast<double *>(b.user() + KD_MAILBOX_OFF) + 128 * wv;
+                unsigned short *mbi = reinterpret_cast<unsigned short *>(b.user() + KD_MAILBOX_OFF + 4 * 128 * 8) + 128 * wv;
+                kd_nth_element_wave(kp, s, s + (e - s) / 2, e, lane, mbk, mbi);
             }
         }
         b.sync();
@@ -1201,6 +1257,14 @@ OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsign
     return n_keep;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OCTA_SUBPROF(sc, slot, t0) do { if (b.tid == 0) { long _t1 = (long)wall_clock64(); (sc)->prof[slot] += _t1 - (t0); (t0) = _t1; } } while (0)
+#define OCTA_SUBPROF_T0() ((long)wall_clock64())
+#else
+#define OCTA_SUBPROF(sc, slot, t0) do { (void)(t0); } while (0)
+#define OCTA_SUBPROF_T0() 0L
+#endif
+
 // ------------------------------------------------------------------ phase: satisfied O2 sinks -> CO2
 OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const IterParams &P) {
     SampleScalars *sc = A.sc;
@@ -1208,8 +1272,10 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
     const int n_new = ne - nb, n_oxy = sc->n_oxy;
     if (n_new <= 0 || n_oxy <= 0) return;
     const double ek = P.eps_k, ek2 = ek * ek;
+    long t0 = OCTA_SUBPROF_T0();
     // 1. cKDTree order of the O2 list
     kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank);
+    OCTA_SUBPROF(sc, 11, t0);
     for (int i = b.tid; i < n_oxy; i += b.nth) A.removed[i] = 0;
     int *ctl = b.coll() + 100;
     if (b.tid == 0) ctl[0] = 0;
@@ -1252,6 +1318,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
         }
         b.sync();
     }
+    OCTA_SUBPROF(sc, 12, t0);
     // 4. sort the pairs: new nodes in order, hits in cKDTree order
     unsigned *keys = reinterpret_cast<unsigned *>(b.user());
     int n_pow2 = 1;
@@ -1261,6 +1328,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
     if (n_pairs > 0) blk_sort_u32(b, keys, n_pow2);
     for (int i = b.tid; i < n_pairs; i += b.nth) A.pairs[i] = keys[i];
     b.sync();
+    OCTA_SUBPROF(sc, 13, t0);
     // 5. CPython set insertion order -> CO2 append order (one thread)
     if (b.tid == 0) {
         PySetView S;
@@ -1281,10 +1349,12 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
         sc->n_co2 = n_co2;
     }
     b.sync();
+    OCTA_SUBPROF(sc, 14, t0);
     // 6. delete the satisfied sinks (order-preserving)
     int keep = compact_points(b, A.oxy, n_oxy, A.removed, A.tmp_dbl);
     if (b.tid == 0) sc->n_oxy = keep;
     b.sync();
+    OCTA_SUBPROF(sc, 15, t0);
 }
 
 // ------------------------------------------------------------------ phase: CO2 near new venous nodes removed

@@ -18,4 +18,7 @@ for rep in range(2):
           f"stats err={res.stats[:,0].max()} draws~{res.stats[:,1].mean():.0f} murray~{res.stats[:,2].mean():.0f} bif~{res.stats[:,3].mean():.1f} respec~{res.stats[:,4].mean():.0f}")
     names = ["sample", "assign_art", "pre_art", "seq_art", "satisfy_art", "-", "assign_ven", "pre_ven", "seq_ven", "satisfy_ven"]
     prof = res.stats[:, 8:18].mean(axis=0) / 1e5  # ms
+    sub = res.stats[:, 18:24].mean(axis=0) / 1e5
+    print("  candidates=%.0f | satisfy_art: kd=%.0f pairs+ven=%.0f sort=%.0f set=%.0f compact=%.0f" % tuple(sub))
+    print("  timing:", {k: (round(v, 1) if isinstance(v, float) else v) for k, v in res.timing.items()})
     print("  phase ms (mean over samples): " + ", ".join(f"{n}={v:.0f}" for n, v in zip(names, prof) if n != "-") + f"  total={prof.sum():.0f}")
