@@ -41,6 +41,7 @@ struct BatchPtrs {
     unsigned *sorted;
     int *gnode, *gstart, *gcount;
     Rec *rec;
+    int *glist, *child_group;
     unsigned short *kd_idx, *kd_rank;
     unsigned char *removed, *ven_near;
     unsigned long long *hashes;
@@ -84,6 +85,8 @@ __device__ __forceinline__ SimArrays sample_arrays(const BatchPtrs &B, int s) {
     A.gstart = B.gstart + (size_t)s * GCAP;
     A.gcount = B.gcount + (size_t)s * GCAP;
     A.rec = B.rec + (size_t)s * GCAP;
+    A.glist = B.glist + (size_t)s * GCAP;
+    A.child_group = B.child_group + (size_t)s * NCAP;
     A.kd_idx = B.kd_idx + (size_t)s * OCAP;
     A.kd_rank = B.kd_rank + (size_t)s * OCAP;
     A.removed = B.removed + (size_t)s * OCAP;
@@ -340,6 +343,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     rc |= dev_alloc(S, &P.nn, nb * OCAP); rc |= dev_alloc(S, &P.first_att, nb * NCAP); rc |= dev_alloc(S, &P.act_list, nb * NCAP);
     rc |= dev_alloc(S, &P.sorted, nb * SORTCAP); rc |= dev_alloc(S, &P.gnode, nb * GCAP); rc |= dev_alloc(S, &P.gstart, nb * GCAP);
     rc |= dev_alloc(S, &P.gcount, nb * GCAP); rc |= dev_alloc(S, &P.rec, nb * GCAP);
+    rc |= dev_alloc(S, &P.glist, nb * GCAP); rc |= dev_alloc(S, &P.child_group, nb * NCAP);
     rc |= dev_alloc(S, &P.kd_idx, nb * OCAP); rc |= dev_alloc(S, &P.kd_rank, nb * OCAP);
     rc |= dev_alloc(S, &P.removed, nb * OCAP); rc |= dev_alloc(S, &P.ven_near, nb * OCAP); rc |= dev_alloc(S, &P.hashes, nb * OCAP);
     rc |= dev_alloc(S, &P.pairs, nb * PCAP); rc |= dev_alloc(S, &P.set_hash, nb * SETCAP); rc |= dev_alloc(S, &P.set_key, nb * SETCAP);
@@ -438,6 +442,7 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
             }
         }
         OCTA_HIP_CHECK(hipMemsetAsync(P.req_count, 0, sizeof(int) * 4, stream));
+        OCTA_HIP_CHECK(hipMemsetAsync(P.child_group, 0, sizeof(int) * (size_t)B * NCAP, stream));
         OCTA_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
     }
     // ---- iterations

@@ -91,6 +91,9 @@ struct SampleScalars {
     int new_begin[2], new_end[2];
     int n_groups[2];
     int n_sorted[2];
+    int n_grow[2];
+    int pass_tag[2];
+    int pass_counter;
     long murray_steps;
     long n_bif;
     long respec;
@@ -115,6 +118,8 @@ struct SimArrays {
     unsigned *sorted;    // [SORTCAP] sorted (first_att<<14 | attractor) keys
     int *gnode, *gstart, *gcount;  // [GCAP]
     Rec *rec;            // [GCAP]
+    int *glist;          // [GCAP] groups that grow under the speculation, ascending (dict order)
+    int *child_group;    // [NCAP] tag<<14 | grow<<13 | group of the inter-node whose first child this node is
     unsigned short *kd_idx, *kd_rank;  // [OCAP]
     unsigned char *removed;  // [OCAP]
     unsigned char *ven_near; // [OCAP]
@@ -808,7 +813,24 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
                 for (int ITEM = (G).items[_k], _once = 1; _once; _once = 0)
 
 // ------------------------------------------------------------------ Murray propagation (one thread)
-OCTA_HD inline void murray_to_root(const SimArrays &A, int f, int id) {
+// dirty list of the ordered pass: inter-node groups that did not sprout under the speculation but whose
+// child radius was changed by an earlier node of the same pass (they must be re-evaluated at their turn)
+struct DirtyList {
+    int *v;      // ascending, unique
+    int n, cap;
+    bool overflow;
+};
+OCTA_HD inline void dirty_insert(DirtyList &D, int g) {
+    int i = 0;
+    while (i < D.n && D.v[i] < g) i++;
+    if (i < D.n && D.v[i] == g) return;
+    if (D.n >= D.cap) { D.overflow = true; return; }
+    for (int k = D.n; k > i; k--) D.v[k] = D.v[k - 1];
+    D.v[i] = g;
+    D.n++;
+}
+
+OCTA_HD inline void murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D) {
     double *rad = A.nrad[f];
     const double *kap = A.nkap[f];
     long steps = 0;
@@ -823,6 +845,13 @@ OCTA_HD inline void murray_to_root(const SimArrays &A, int f, int id) {
         steps++;
         if (rad[id] == rp) break;
         rad[id] = rp;
+        if (D) {
+            int cg = A.child_group[id];
+            if ((cg >> 14) == pass_tag && !((cg >> 13) & 1)) {
+                int g2 = cg & 8191;
+                if (g2 > cur_g) dirty_insert(*D, g2);
+            }
+        }
         id = par;
     }
     A.sc->murray_steps += steps;
@@ -1176,28 +1205,65 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
                               const double *att, BifRequest *reqs, int *req_count, int req_cap, int sample) {
     GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven};
     const int ng = A.sc->n_groups[f];
-    for (int g = b.tid; g < ng; g += b.nth) {
-        Rec R;
-        memset(&R, 0, sizeof(R));
-        int id = A.gnode[g];
-        int nch = A.nnch[f][id], par = A.npar[f][id];
-        if (nch == 0) eval_leaf(G, g, R, reqs, req_count, req_cap, sample);
-        else if (par >= 0 && nch == 1) eval_inter(G, g, R);
-        else { R.type = 0; R.node = id; R.req = -1; }
-        A.rec[g] = R;
+    if (b.tid == 0) { A.sc->pass_counter++; A.sc->pass_tag[f] = A.sc->pass_counter; }
+    b.sync();
+    const int tag = A.sc->pass_tag[f];
+    int n_grow = 0;
+    for (int base = 0; base < ng; base += b.nth) {
+        int g = base + b.tid;
+        int grows = 0;
+        if (g < ng) {
+            Rec R;
+            memset(&R, 0, sizeof(R));
+            int id = A.gnode[g];
+            int nch = A.nnch[f][id], par = A.npar[f][id];
+            if (nch == 0) eval_leaf(G, g, R, reqs, req_count, req_cap, sample);
+            else if (par >= 0 && nch == 1) eval_inter(G, g, R);
+            else { R.type = 0; R.node = id; R.req = -1; }
+            A.rec[g] = R;
+            grows = (R.type == 1) || (R.type == 3 && R.grow);
+            if (R.type == 3) A.child_group[A.nch0[f][id]] = (tag << 14) | ((int)R.grow << 13) | g;
+        }
+        int ex;
+        int tot = blk_scan(b, grows, &ex);
+        if (grows) A.glist[n_grow + ex] = g;
+        n_grow += tot;
     }
+    if (b.tid == 0) A.sc->n_grow[f] = n_grow;
     b.sync();
 }
 
-// ordered pass (one thread): RNG draws, node creation, Murray propagation, deactivation
+// ordered pass (one thread): RNG draws, node creation, Murray propagation, deactivation.
+// Only the groups that grow under the speculation are visited, plus the (rare) inter-nodes whose child
+// radius an earlier node of this pass changed (dirty list fed by murray_to_root); this visits exactly the
+// groups for which the reference's sequential loop does anything.
 OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
                               const double *att, const double *bif_results /* [req][6] */) {
     SampleScalars *sc = A.sc;
     if (b.tid == 0) {
         GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven};
         const int ng = sc->n_groups[f];
+        const int n_grow = sc->n_grow[f];
+        const int tag = sc->pass_tag[f];
+        DirtyList D;
+        D.v = b.coll() + 128; D.n = 0; D.cap = 256; D.overflow = false;
         sc->new_begin[f] = sc->n_nodes[f];
-        for (int g = 0; g < ng; g++) {
+        int gi = 0, last_g = -1;
+        bool scan_all = false;  // fallback when the dirty list overflows: visit every remaining group
+        while (true) {
+            int g;
+            if (scan_all) {
+                g = last_g + 1;
+                if (g >= ng) break;
+            } else {
+                int g1 = gi < n_grow ? A.glist[gi] : 0x7fffffff;
+                int g2 = D.n > 0 ? D.v[0] : 0x7fffffff;
+                g = g1 < g2 ? g1 : g2;
+                if (g == 0x7fffffff) break;
+                if (g == g1) gi++;
+                if (g == g2) { for (int k = 1; k < D.n; k++) D.v[k - 1] = D.v[k]; D.n--; }
+            }
+            last_g = g;
             Rec R = A.rec[g];
             if (R.type == 0) continue;
             const int id = R.node;
@@ -1213,15 +1279,13 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                     const double *o = bif_results + 6 * (size_t)R.req;
                     add_node(A, f, v3(o[0], o[1], o[2]), C.r, id, P.kappa);
                     add_node(A, f, v3(o[3], o[4], o[5]), C.r, id, P.kappa);
-                    murray_to_root(A, f, id);
+                    murray_to_root(A, f, id, g, tag, &D);
                     A.nact[f][id] = 0;
                     sc->n_bif++;
                 } else {
                     add_node(A, f, ld3(R.newpos), C.r, id, P.kappa);
                 }
             } else {
-                // the speculation used the child radius at the start of the pass; redo it if an earlier
-                // Murray update in this pass changed that radius (sequential semantics of the reference)
                 if (A.nrad[f][A.nch0[f][id]] != R.r1_used) {
                     eval_inter(G, g, R);
                     sc->respec++;
@@ -1231,9 +1295,10 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 double u = A.py_u[sc->py_pos++];
                 if (R.thr <= u && !R.ang_gt90) continue;
                 add_node(A, f, ld3(R.newpos), C.r, id, P.kappa);
-                murray_to_root(A, f, id);
+                murray_to_root(A, f, id, g, tag, &D);
                 A.nact[f][id] = 0;
             }
+            if (D.overflow && !scan_all) { scan_all = true; D.n = 0; }
         }
         sc->new_end[f] = sc->n_nodes[f];
     }

@@ -103,6 +103,8 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     std::vector<int> nn(OCAP), first_att(NCAP), act_list(NCAP), gnode(GCAP), gstart(GCAP), gcount(GCAP), set_key(SETCAP), tmp_int(OCAP + 2 * NCANDCAP);
     std::vector<unsigned> sorted(SORTCAP), pairs(PCAP);
     std::vector<Rec> rec(GCAP);
+    std::vector<int> glist(GCAP), child_group(NCAP, 0);
+    A.glist = glist.data(); A.child_group = child_group.data();
     std::vector<unsigned short> kd_idx(OCAP), kd_rank(OCAP);
     std::vector<unsigned char> removed(OCAP), ven_near(OCAP);
     std::vector<unsigned long long> hashes(OCAP), set_hash(SETCAP);
