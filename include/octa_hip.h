@@ -72,6 +72,10 @@ int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, const int64_t
                       const uint8_t *d_keep, int no_pixels_x, int no_pixels_y, int mip_axis,
                       double min_radius, double max_radius, uint8_t *d_out, void *stream);
 
+/* Diagnostics of the last octa_rasterize_2d call: h_out4 = {error flag, ticks in edge binning, ticks in
+ * stroke tessellation, ticks in the ordered fold}; ticks are 100 MHz wall-clock ticks summed over workgroups. */
+int octa_raster_prof(octa_ctx *ctx, int64_t *h_out4);
+
 /* ---- N7: Floyd-Steinberg binarisation -----------------------------------
  * Replaces: Pillow Image.convert("1") as called at visualize_vessel_graphs.py:99
  * (label PNGs). d_in/d_out: [B][H][W] uint8; output values are 0 or 255.

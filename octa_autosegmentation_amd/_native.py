@@ -21,6 +21,7 @@ SIGNATURES = {
     "octa_ctx_scratch_bytes": (c_size_t, [c_void_p]),
     "octa_rasterize_2d": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double,
                                   c_double, c_void_p, c_void_p]),
+    "octa_raster_prof": (c_int, [c_void_p, c_void_p]),
     "octa_fs_dither": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "octa_max_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "octa_sim_create": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),

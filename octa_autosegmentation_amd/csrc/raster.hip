@@ -32,7 +32,8 @@
 namespace {
 using namespace octa_raster;
 
-constexpr int ST = 64;          // super-tile edge (pixels)
+constexpr int ST = 64;          // super-tile width (pixels)
+constexpr int ST_Y = 64;        // super-tile height: 16 waves x (16x16 block)
 constexpr int WG = 1024;        // threads per render workgroup
 constexpr int EPT = 4;          // edges tested per thread per scan round
 constexpr int LIST_CAP = 1024;  // edges per chunk
@@ -60,6 +61,8 @@ struct ListEntry {
     int slot_off;   // first LDS slot
     int nv;         // polygon sides (primary slots)
     BBox16 bb;
+    float ax, ay, vx, vy;  // segment start and direction (pixels), for the conservative miss test
+    float inv_len2, reach; // 1/|v|^2 and half width + margin
 };
 
 // block-wide exclusive scan of two ints per thread over WG threads (wave shuffles + LDS)
@@ -102,8 +105,8 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
 
     const int img = blockIdx.y;
     const int tile = blockIdx.x;
-    const int tx0 = (tile % tiles_x) * ST, ty0 = (tile / tiles_x) * ST;
-    const int tx1 = min(tx0 + ST, W) - 1, ty1 = min(ty0 + ST, H) - 1;
+    const int tx0 = (tile % tiles_x) * ST, ty0 = (tile / tiles_x) * ST_Y;
+    const int tx1 = min(tx0 + ST, W) - 1, ty1 = min(ty0 + ST_Y, H) - 1;
     const long e_begin = edge_off[img], e_end = edge_off[img + 1];
     const int n_edges = (int)(e_end - e_begin);
     const EdgeMeta *gm = meta + e_begin;
@@ -118,6 +121,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
 
     int cursor = 0;
     while (cursor < n_edges) {
+        long _tp = (long)wall_clock64();
         // ---- phase 1: ordered compaction of the edges that touch this super-tile
         if (threadIdx.x == 0) { s_ctl[1] = 0; s_ctl[2] = 0; }
         __syncthreads();
@@ -156,6 +160,14 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                         le.slot_off = sp;
                         le.nv = cnt[q] - EXTRA_SLOTS;
                         le.bb = bb[q];
+                        {
+                            const EdgeMeta &em = gm[e0 + q];
+                            float vx = (float)(em.x1 - em.x0), vy = (float)(em.y1 - em.y0);
+                            le.ax = (float)em.x0; le.ay = (float)em.y0; le.vx = vx; le.vy = vy;
+                            float l2 = vx * vx + vy * vy;
+                            le.inv_len2 = l2 > 0.f ? 1.0f / l2 : 0.f;
+                            le.reach = (float)em.w + 0.25f;
+                        }
                         s_list[pos] = le;
                         s_extra[pos] = 0;
                     } else {
@@ -192,6 +204,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
             }
             __syncthreads();
         }
+        if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 2), (unsigned long long)(_t - _tp)); _tp = _t; }
         if (list_n == 0) continue;
 
         // ---- phase 2: tessellate + clip the stroke polygons into LDS side slots
@@ -231,12 +244,24 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         }
         __syncthreads();
 
+        if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 4), (unsigned long long)(_t - _tp)); _tp = _t; }
         // ---- phase 3: ordered fold of the edges over this wave's 16x16 block
         for (int i = 0; i < list_n; i++) {
             const ListEntry le = s_list[i];
             // wave-uniform reject
             if (le.bb.x1 < bx0 || le.bb.x0 > bx0 + 15 || le.bb.y1 < by0 || le.bb.y0 > by0 + 15) continue;
             if (prow < le.bb.y0 || prow > le.bb.y1 || pcol + 3 < le.bb.x0 || pcol > le.bb.x1) continue;
+            {
+                // the 4x1 pixel span of this lane cannot be touched if its centre is farther from the
+                // segment than half width + half diagonal of the span (2.07) + slack for the fp32 test,
+                // the 1/256 vertex rounding and the snap of axis-aligned paths (already in ax..vy)
+                float cx = (float)pcol + 2.0f - le.ax, cy = (float)prow + 0.5f - le.ay;
+                float t = (cx * le.vx + cy * le.vy) * le.inv_len2;
+                t = fminf(fmaxf(t, 0.f), 1.f);
+                float ex = cx - t * le.vx, ey = cy - t * le.vy;
+                float lim = le.reach + 2.07f;
+                if (ex * ex + ey * ey > lim * lim) continue;
+            }
             int C[4] = {0, 0, 0, 0}, A[4] = {0, 0, 0, 0};
             const int ns = le.nv + EXTRA_SLOTS;
             const int4 *sl = s_slots + le.slot_off;
@@ -255,6 +280,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
             }
         }
         __syncthreads();
+        if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 6), (unsigned long long)(_t - _tp)); }
     }
 
     if (prow < H) {
@@ -412,7 +438,7 @@ extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, co
         hipLaunchKernelGGL(raster_meta_kernel, g, dim3(256), 0, stream, d_edges, d_keep, n_total, W, H, ax_x, ax_y,
                            min_radius, max_radius, ctx->r_edge_meta.as<EdgeMeta>(), ctx->r_ucount.as<BBox16>());
     }
-    const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST - 1) / ST;
+    const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST_Y - 1) / ST_Y;
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)B);
     hipLaunchKernelGGL(raster_render_kernel, grid, dim3(WG), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(),
                        ctx->r_ucount.as<BBox16>(), ctx->r_edge_off.as<long>(), W, H, tiles_x, tiles_y, d_out,
@@ -448,5 +474,15 @@ extern "C" int octa_max_u8(octa_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b
     size_t nthreads = (n + 15) / 16;
     hipLaunchKernelGGL(max_u8_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, d_a, d_b, d_out, n);
     OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// diagnostics: ticks (100 MHz) summed over workgroups for the three phases of the last raster launches
+extern "C" int octa_raster_prof(octa_ctx *ctx, int64_t *h_out4) {
+    if (!ctx || !h_out4) return -2;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    long tmp[8] = {0};
+    if (ctx->r_counters.p) OCTA_HIP_CHECK(hipMemcpy(tmp, ctx->r_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
+    h_out4[0] = tmp[0] & 0xffffffff; h_out4[1] = tmp[1]; h_out4[2] = tmp[2]; h_out4[3] = tmp[3];
     return 0;
 }

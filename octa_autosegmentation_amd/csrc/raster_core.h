@@ -268,70 +268,85 @@ OCTA_HD void clip_side(SideSink &s, double W, double H, double x1, double y1, do
 
 // floor(a / b) for b > 0, |a| < 2^52 and floor(a/b)*b < 2^52: the correctly rounded double quotient
 // of two exactly representable integers cannot cross an integer boundary.
-OCTA_HD inline long floordiv_d(long a, long b) { return (long)floor((double)a / (double)b); }
-OCTA_HD inline int floordiv_i(int a, int b) { return (int)floor((double)a / (double)b); }
+OCTA_HD inline double rcp_approx(double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(b);   // v_rcp_f64, ~1 ulp: the quotient estimate is fixed up exactly below
+#else
+    return 1.0 / b;
+#endif
+}
+// exact floor(a / b) for b > 0: reciprocal estimate (off by at most one for |a| < 2^50) + integer fix-up
+OCTA_HD inline long floordiv_d(long a, long b) {
+    long q = (long)floor((double)a * rcp_approx((double)b));
+    long r = a - q * b;
+    if (r < 0) { q--; r += b; }
+    if (r < 0) { q--; r += b; }
+    if (r >= b) { q++; r -= b; }
+    if (r >= b) { q++; }
+    return q;
+}
+OCTA_HD inline int floordiv_i(int a, int b) {
+    int q = (int)floor((double)a * rcp_approx((double)b));
+    int r = a - q * b;
+    if (r < 0) { q--; r += b; }
+    if (r >= b) { q++; }
+    return q;
+}
+OCTA_HD inline int floordiv_prod(int num, long dx, long dy) { return (int)floordiv_d((long)num * dx, dy); }
 
 // One scanline piece (agg render_hline semantics) evaluated for NP adjacent pixels px0..px0+NP-1.
 // Adds, per pixel, C += sum of cover over cells with ex <= px, A += area of cell px.
+// Y[b] is the fractional y reached when the piece crosses the cell boundary x = (px0 + b) * 256, clamped
+// to the piece's ends, in traversal direction; cell px then has cover = Y_out - Y_in.
 template <int NP>
 OCTA_HD inline void hline_eval(int hx1, int hy1, int hx2, int hy2, int px0, int (&C)[NP], int (&A)[NP]) {
     if (hy1 == hy2) return;
     const int ex1 = hx1 >> 8, ex2 = hx2 >> 8;
     const int fx1 = hx1 & 255, fx2 = hx2 & 255;
     const int dy = hy2 - hy1;
-    if (ex1 == ex2) {
-#pragma unroll
-        for (int q = 0; q < NP; q++) {
-            int px = px0 + q;
-            if (px >= ex1) C[q] += dy;
-            if (px == ex1) A[q] += (fx1 + fx2) * dy;
-        }
-        return;
-    }
-    if (hx2 > hx1) {
+    int Y[NP + 1];
+    if (hx2 >= hx1) {
+        // cells ex1 .. ex2 left to right; boundary xb lies between cells xb-1 and xb
         const int dxh = hx2 - hx1;
         const int base = (256 - fx1) * dy;
-        const int J = ex2 - ex1;
-        // boundary value entering cell ex1+j (j>=1): yb(j) = hy1 + floor((base + (j-1)*256*dy)/dxh)
-        int yb_prev = 0;
-        bool have_prev = false;
+#pragma unroll
+        for (int bq = 0; bq <= NP; bq++) {
+            int xb = px0 + bq;
+            int v;
+            if (xb <= ex1) v = hy1;
+            else if (xb > ex2) v = hy2;
+            else v = hy1 + floordiv_i(base + (xb - ex1 - 1) * 256 * dy, dxh);
+            Y[bq] = v;
+        }
 #pragma unroll
         for (int q = 0; q < NP; q++) {
             int px = px0 + q;
-            if (px < ex1) continue;
-            if (px > ex2) { C[q] += dy; continue; }
-            int j = px - ex1;
-            int y_in = (j == 0) ? hy1 : (have_prev ? yb_prev : hy1 + floordiv_i(base + (j - 1) * 256 * dy, dxh));
-            int y_out = (j == J) ? hy2 : hy1 + floordiv_i(base + j * 256 * dy, dxh);
-            yb_prev = y_out;
-            have_prev = true;
-            int cov = y_out - y_in;
-            C[q] += y_out - hy1;
-            int fxin = (j == 0) ? fx1 : 0;
-            int fxout = (j == J) ? fx2 : 256;
+            int cov = Y[q + 1] - Y[q];
+            C[q] += Y[q + 1] - hy1;
+            int fxin = (px == ex1) ? fx1 : 0;
+            int fxout = (px == ex2) ? fx2 : 256;
             A[q] += (fxin + fxout) * cov;
         }
     } else {
+        // cells ex1 .. ex2 right to left; boundary xb is crossed when entering cell xb-1
         const int dxh = hx1 - hx2;
         const int base = fx1 * dy;
-        const int J = ex1 - ex2;
-        // cells are visited ex1, ex1-1, ..., ex2; boundary entering cell ex1-j: yb(j)
-        int yb_next = 0;  // y_in of the previously handled pixel (one column to the left) = y_out of this one
-        bool have_next = false;
+#pragma unroll
+        for (int bq = 0; bq <= NP; bq++) {
+            int xb = px0 + bq;
+            int v;
+            if (xb > ex1) v = hy1;
+            else if (xb <= ex2) v = hy2;
+            else v = hy1 + floordiv_i(base + (ex1 - xb) * 256 * dy, dxh);
+            Y[bq] = v;
+        }
 #pragma unroll
         for (int q = 0; q < NP; q++) {
             int px = px0 + q;
-            if (px < ex2) continue;
-            if (px > ex1) { C[q] += dy; continue; }
-            int j = ex1 - px;
-            int y_out = (j == J) ? hy2 : (have_next ? yb_next : hy1 + floordiv_i(base + j * 256 * dy, dxh));
-            int y_in = (j == 0) ? hy1 : hy1 + floordiv_i(base + (j - 1) * 256 * dy, dxh);
-            yb_next = y_in;
-            have_next = true;
-            int cov = y_out - y_in;
-            C[q] += hy2 - y_in;
-            int fxin = (j == 0) ? fx1 : 256;
-            int fxout = (j == J) ? fx2 : 0;
+            int cov = Y[q] - Y[q + 1];
+            C[q] += hy2 - Y[q + 1];
+            int fxin = (px == ex1) ? fx1 : 256;
+            int fxout = (px == ex2) ? fx2 : 0;
             A[q] += (fxin + fxout) * cov;
         }
     }
@@ -354,16 +369,16 @@ OCTA_HD inline void side_eval(int4 s, int py, int px0, int (&C)[NP], int (&A)[NP
     if (y2 > y1) {
         const long dy = (long)y2 - (long)y1;
         const int K = ey2 - ey1, k = py - ey1;
-        hx1 = (k == 0) ? x1 : x1 + (int)floordiv_d(((long)(256 - fy1) + 256L * (k - 1)) * dx, dy);
+        hx1 = (k == 0) ? x1 : x1 + floordiv_prod((256 - fy1) + 256 * (k - 1), dx, dy);
         hy1 = (k == 0) ? fy1 : 0;
-        hx2 = (k == K) ? x2 : x1 + (int)floordiv_d(((long)(256 - fy1) + 256L * k) * dx, dy);
+        hx2 = (k == K) ? x2 : x1 + floordiv_prod((256 - fy1) + 256 * k, dx, dy);
         hy2 = (k == K) ? fy2 : 256;
     } else {
         const long dy = (long)y1 - (long)y2;
         const int K = ey1 - ey2, k = ey1 - py;
-        hx1 = (k == 0) ? x1 : x1 + (int)floordiv_d(((long)fy1 + 256L * (k - 1)) * dx, dy);
+        hx1 = (k == 0) ? x1 : x1 + floordiv_prod(fy1 + 256 * (k - 1), dx, dy);
         hy1 = (k == 0) ? fy1 : 256;
-        hx2 = (k == K) ? x2 : x1 + (int)floordiv_d(((long)fy1 + 256L * k) * dx, dy);
+        hx2 = (k == K) ? x2 : x1 + floordiv_prod(fy1 + 256 * k, dx, dy);
         hy2 = (k == K) ? fy2 : 0;
     }
     hline_eval<NP>(hx1, hy1, hx2, hy2, px0, C, A);
@@ -376,7 +391,12 @@ OCTA_HD inline unsigned blend_white(unsigned p, unsigned alpha) {
     unsigned r = p * 255u;
     unsigned a = alpha + 65280u;
     unsigned num = ((255u << 8) - r) * alpha + (r << 8);
-    return (unsigned)floor((double)num / (double)a);
+    // exact num / a (a in [65281, 65534], num < 2^26): float estimate + fix-up
+    unsigned q = (unsigned)((float)num * (1.0f / (float)a));
+    int rem = (int)num - (int)(q * a);
+    if (rem < 0) { q--; rem += (int)a; }
+    if (rem >= (int)a) { q++; }
+    return q;
 }
 
 

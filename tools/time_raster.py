@@ -15,7 +15,10 @@ for res in ([304, 304], [1216, 1216]):
         torch.cuda.synchronize(); t = time.time()
         tree2img.rasterize_edges_device(d, off, res, out=out)
         torch.cuda.synchronize(); dt = time.time() - t
-        print(f"raster {res} B={B}: {dt*1e3:.2f} ms  -> {B/dt:.0f} img/s")
+        import ctypes
+        from octa_autosegmentation_amd import _native
+        prof = np.zeros(4, np.int64); _native.lib().octa_raster_prof(_native.ctx(), prof.ctypes.data)
+        print(f"raster {res} B={B}: {dt*1e3:.2f} ms  -> {B/dt:.0f} img/s   WG-ms: bin={prof[1]/1e5:.1f} tess={prof[2]/1e5:.1f} fold={prof[3]/1e5:.1f} err={prof[0]}")
     for it in range(2):
         torch.cuda.synchronize(); t = time.time()
         lab = tree2img.binarize_label_device(out)
