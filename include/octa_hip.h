@@ -141,10 +141,10 @@ int octa_sim_edge_offsets(octa_sim *sim, int64_t *h_edge_off, int64_t *h_n_art);
  * tree -- the CSV row order of generate_vessel_graph.py:59-66. h_edges: host buffer. */
 int octa_sim_export_edges(octa_sim *sim, double *h_edges);
 
-/* Per-sample statistics, h_stats[B][24] int64: error bits, random.uniform draws, Murray steps,
+/* Per-sample statistics, h_stats[B][32] int64: error bits, random.uniform draws, Murray steps,
  * bifurcations, re-speculated inter-nodes, arterial nodes, venous nodes, FAZ radius bits, then 16
  * per-phase device timers (100 MHz ticks: 0 sample, 1 assign-art, 2 speculate-art, 3 ordered-art,
- * 4 O2->CO2, 6 assign-ven, 7 speculate-ven, 8 ordered-ven, 9 CO2 removal). */
+ * 4 O2->CO2, 6 assign-ven, 7 speculate-ven, 8 ordered-ven, 9 CO2 removal), then 8 timers of the kd-order build. */
 int octa_sim_stats(octa_sim *sim, int64_t *h_stats);
 
 /* Timing of the last octa_sim_run, h_out8: [0] sum of launch-A kernel durations (ms, HIP events on

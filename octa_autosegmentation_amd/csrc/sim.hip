@@ -23,10 +23,10 @@ using namespace octa_simk;
 
 namespace {
 
-constexpr int SIM_THREADS = 256;
+constexpr int SIM_THREADS = 512;
 constexpr size_t SIM_LDS = 2048 + (size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES;  // 160,768 B
 static_assert(SIM_LDS <= 160 * 1024, "LDS budget");
-static_assert(SIM_THREADS == 256, "kd mailboxes are sized for 4 waves");
+static_assert(SIM_THREADS == 64 * KD_WAVES, "kd mailboxes are sized for KD_WAVES waves");
 constexpr int REQ_CAP = 8192;
 
 static_assert(sizeof(BifRequest) == sizeof(octa_bif_request), "request layout must match the public header");
@@ -41,7 +41,7 @@ struct BatchPtrs {
     unsigned *sorted;
     int *gnode, *gstart, *gcount;
     Rec *rec;
-    int *glist, *child_group;
+    int *glist, *child_group, *node_group;
     unsigned short *kd_idx, *kd_rank;
     unsigned char *removed, *ven_near;
     unsigned long long *hashes;
@@ -87,6 +87,7 @@ __device__ __forceinline__ SimArrays sample_arrays(const BatchPtrs &B, int s) {
     A.rec = B.rec + (size_t)s * GCAP;
     A.glist = B.glist + (size_t)s * GCAP;
     A.child_group = B.child_group + (size_t)s * NCAP;
+    A.node_group = B.node_group + (size_t)s * NCAP;
     A.kd_idx = B.kd_idx + (size_t)s * OCAP;
     A.kd_rank = B.kd_rank + (size_t)s * OCAP;
     A.removed = B.removed + (size_t)s * OCAP;
@@ -343,7 +344,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     rc |= dev_alloc(S, &P.nn, nb * OCAP); rc |= dev_alloc(S, &P.first_att, nb * NCAP); rc |= dev_alloc(S, &P.act_list, nb * NCAP);
     rc |= dev_alloc(S, &P.sorted, nb * SORTCAP); rc |= dev_alloc(S, &P.gnode, nb * GCAP); rc |= dev_alloc(S, &P.gstart, nb * GCAP);
     rc |= dev_alloc(S, &P.gcount, nb * GCAP); rc |= dev_alloc(S, &P.rec, nb * GCAP);
-    rc |= dev_alloc(S, &P.glist, nb * GCAP); rc |= dev_alloc(S, &P.child_group, nb * NCAP);
+    rc |= dev_alloc(S, &P.glist, nb * GCAP); rc |= dev_alloc(S, &P.child_group, nb * NCAP); rc |= dev_alloc(S, &P.node_group, nb * NCAP);
     rc |= dev_alloc(S, &P.kd_idx, nb * OCAP); rc |= dev_alloc(S, &P.kd_rank, nb * OCAP);
     rc |= dev_alloc(S, &P.removed, nb * OCAP); rc |= dev_alloc(S, &P.ven_near, nb * OCAP); rc |= dev_alloc(S, &P.hashes, nb * OCAP);
     rc |= dev_alloc(S, &P.pairs, nb * PCAP); rc |= dev_alloc(S, &P.set_hash, nb * SETCAP); rc |= dev_alloc(S, &P.set_key, nb * SETCAP);
@@ -545,11 +546,12 @@ extern "C" int octa_sim_stats(octa_sim *S, int64_t *h_stats) {
     if (!S || !S->ran || !h_stats) { octa::set_error("octa_sim_stats: run the simulation first"); return -2; }
     for (int s = 0; s < S->B; s++) {
         const SampleScalars &sc = S->h_sc[s];
-        int64_t *o = h_stats + 24 * s;
+        int64_t *o = h_stats + 32 * s;
         o[0] = sc.err; o[1] = sc.py_pos; o[2] = sc.murray_steps; o[3] = sc.n_bif; o[4] = sc.respec;
         o[5] = sc.n_nodes[0]; o[6] = sc.n_nodes[1];
         memcpy(&o[7], &sc.faz_radius, 8);
         for (int k = 0; k < 16; k++) o[8 + k] = sc.prof[k];
+        for (int k = 0; k < 8; k++) o[24 + k] = sc.kdprof[k];
     }
     return 0;
 }

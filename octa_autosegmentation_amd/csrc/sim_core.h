@@ -43,9 +43,10 @@ constexpr int MAXKEPT = 256;   // attractors shipped with one bifurcation reques
 constexpr int NCANDCAP = 8192; // candidates per iteration
 constexpr int TILE = 1024;     // points per LDS tile in brute-force queries
 constexpr int ACCCAP = 2048;   // accepted sinks per iteration
-constexpr int KD_RANGES = 1024; // ranges per kd level (> OCAP / 17)
+constexpr int KD_RANGES = 896;  // ranges per kd level (> OCAP / 17)
 constexpr int KD_MAILBOX_OFF = OCAP * 10 + 5 * KD_RANGES * 4;  // LDS offset (after user()) of the per-wave swap mailboxes
-constexpr int KD_MAILBOX_BYTES = 4 * 128 * 10;                 // 4 waves x 128 x (double + u16)
+constexpr int KD_WAVES = 8;                                    // waves per workgroup the mailboxes are sized for
+constexpr int KD_MAILBOX_BYTES = KD_WAVES * 128 * 10;          // per wave 128 x (double + u16)
 constexpr int GRID_MAX = 128;   // uniform-grid cells per axis (x, y); the thin z extent is not binned
 
 enum ErrBits { ERR_NODE_CAP = 1, ERR_OXY_CAP = 2, ERR_CO2_CAP = 4, ERR_GROUP_CAP = 8, ERR_PAIR_CAP = 16, ERR_SET_CAP = 32,
@@ -98,6 +99,7 @@ struct SampleScalars {
     long n_bif;
     long respec;
     long prof[16];  // accumulated 100 MHz ticks per phase (thread 0), see sim.hip
+    long kdprof[8]; // kd_build breakdown: bbox, dim, gather, nth(wave), nth(thread), next-level, finalize
 };
 
 // pointers to ONE sample's slices
@@ -119,6 +121,7 @@ struct SimArrays {
     int *gnode, *gstart, *gcount;  // [GCAP]
     Rec *rec;            // [GCAP]
     int *glist;          // [GCAP] groups that grow under the speculation, ascending (dict order)
+    int *node_group;     // [NCAP] group index of a node during assignment
     int *child_group;    // [NCAP] tag<<14 | grow<<13 | group of the inter-node whose first child this node is
     unsigned short *kd_idx, *kd_rank;  // [OCAP]
     unsigned char *removed;  // [OCAP]
@@ -622,8 +625,17 @@ __device__ inline void kd_nth_element_wave(const KdPair &a, int first, int nth, 
 
 // scipy cKDTree build order (leafsize 16, compact, median): fills kd_idx (tree.indices) and kd_rank.
 // Level-synchronous: range boundaries depend only on n; a range that became a leaf is marked done.
+// `need` (optional) flags the points whose rank will be read: a range without any such point is not
+// partitioned further (its internal order is never observed), which prunes most of the deep levels.
 // LDS: key double[OCAP] + idx u16[OCAP] + per-level range table.
-OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned short *out_idx, unsigned short *out_rank) {
+OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned short *out_idx, unsigned short *out_rank,
+                              long *kdprof = nullptr, const unsigned char *need = nullptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KDP(slot) do { if (kdprof && b.tid == 0) { long _t = (long)wall_clock64(); kdprof[slot] += _t - _kt; _kt = _t; } } while (0)
+    long _kt = (long)wall_clock64();
+#else
+#define KDP(slot) do { } while (0)
+#endif
     double *key = reinterpret_cast<double *>(b.user());
     unsigned short *idx = reinterpret_cast<unsigned short *>(b.user() + (size_t)OCAP * 8);
     int *tab = reinterpret_cast<int *>(b.user() + (size_t)OCAP * 10);  // 5 tables of KD_RANGES ints
@@ -640,8 +652,10 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
         //    them into a per-range min/max table with LDS 64-bit atomics on order-preserving encodings.
         //    The key array is free at this point and hosts the table.
         unsigned long long *bb = reinterpret_cast<unsigned long long *>(key);  // [nr][6]: max xyz, min xyz
-        for (int q = b.tid; q < nr; q += b.nth)
+        for (int q = b.tid; q < nr; q += b.nth) {
             for (int k = 0; k < 3; k++) { bb[6 * q + k] = 0ull; bb[6 * q + 3 + k] = ~0ull; }
+            rd[q] = 0;  // counts the needed points of the range during the bbox pass
+        }
         b.sync();
         {
             const int chunk = (n + b.nth - 1) / b.nth;
@@ -653,13 +667,16 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 q = lo_;
             }
             bool have = false;
+            int hits = 0;
             unsigned long long mx[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
             for (int i = i0; i < i1; i++) {
                 while (q + 1 < nr && rs[q + 1] <= i) {
                     if (have) { for (int k = 0; k < 3; k++) { atomic_max_u64(&bb[6 * q + k], mx[k]); atomic_min_u64(&bb[6 * q + 3 + k], mn[k]); } have = false; }
+                    if (hits) { atomic_add_int(&rd[q], hits); hits = 0; }
                     q++;
                 }
                 if (i < rs[q] || i >= re[q]) continue;  // element of a finished leaf
+                if (!need || need[idx[i]]) hits++;
                 const double *p = pts + 3 * (int)idx[i];
                 for (int k = 0; k < 3; k++) {
                     unsigned long long e = dbl_sortable(p[k]);
@@ -669,8 +686,10 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 have = true;
             }
             if (have) for (int k = 0; k < 3; k++) { atomic_max_u64(&bb[6 * q + k], mx[k]); atomic_min_u64(&bb[6 * q + 3 + k], mn[k]); }
+            if (hits) atomic_add_int(&rd[q], hits);
         }
         b.sync();
+        KDP(0);
         for (int q = b.tid; q < nr; q += b.nth) {
             int d = 0;
             double size = 0;
@@ -681,9 +700,10 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 if (k == 0) { mxd = hi_; mnd = lo_; }
             }
             mxd = dbl_unsortable(bb[6 * q + d]); mnd = dbl_unsortable(bb[6 * q + 3 + d]);
-            rd[q] = (mxd == mnd) ? -1 : d;
+            rd[q] = (mxd == mnd || rd[q] == 0) ? -1 : d;
         }
         b.sync();
+        KDP(1);
         // 2. gather the split-dimension keys, element-parallel with the same chunking
         {
             const int chunk = (n + b.nth - 1) / b.nth;
@@ -702,6 +722,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
             }
         }
         b.sync();
+        KDP(2);
         // 3. nth_element per range: long ranges by one wave each, short ranges by one thread each
 #if defined(__HIP_DEVICE_COMPILE__)
         {
@@ -711,11 +732,12 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 int s = rs[q], e = re[q];
                 if (d < 0 || e - s < 192) continue;
                 double *mbk = reinterpret_cast<double *>(b.user() + KD_MAILBOX_OFF) + 128 * wv;
-                unsigned short *mbi = reinterpret_cast<unsigned short *>(b.user() + KD_MAILBOX_OFF + 4 * 128 * 8) + 128 * wv;
+                unsigned short *mbi = reinterpret_cast<unsigned short *>(b.user() + KD_MAILBOX_OFF + KD_WAVES * 128 * 8) + 128 * wv;
                 kd_nth_element_wave(kp, s, s + (e - s) / 2, e, lane, mbk, mbi);
             }
         }
         b.sync();
+        KDP(3);
         for (int q = b.tid; q < nr; q += b.nth) {
             int d = rd[q];
             int s = rs[q], e = re[q];
@@ -731,6 +753,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
         }
 #endif
         b.sync();
+        KDP(4);
         // 4. children that are still longer than a leaf form the next level
         if (b.tid == 0) {
             int cnt = 0;
@@ -746,9 +769,12 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
         nr = b.coll()[101];
         { int *t = rs; rs = rs2; rs2 = t; t = re; re = re2; re2 = t; }
         b.sync();
+        KDP(5);
     }
     for (int i = b.tid; i < n; i += b.nth) { out_idx[i] = idx[i]; out_rank[idx[i]] = (unsigned short)i; }
     b.sync();
+    KDP(6);
+#undef KDP
 }
 
 
@@ -787,14 +813,16 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
         atomic_add_int(&hist[grid_cy(G, p[1]) * nc + grid_cx(G, p[0])], 1);
     }
     b.sync();
-    int run = 0;
-    for (int base = 0; base <= ncell; base += b.nth) {
-        int c = base + b.tid;
-        int v = c <= ncell ? hist[c] : 0;
+    {   // exclusive scan over the cells: contiguous chunk per thread + ONE block scan
+        const int total = ncell + 1;
+        const int chunk = (total + b.nth - 1) / b.nth;
+        const int c0 = b.tid * chunk, c1 = (c0 + chunk < total) ? c0 + chunk : total;
+        int local = 0;
+        for (int c = c0; c < c1; c++) local += hist[c];
         int ex;
-        int tot = blk_scan(b, v, &ex);
-        if (c <= ncell) { hist[c] = run + ex; A.grid_start[c] = run + ex; }
-        run += tot;
+        blk_scan(b, local, &ex);
+        int run = ex;
+        for (int c = c0; c < c1; c++) { int v = hist[c]; hist[c] = run; A.grid_start[c] = run; run += v; }
     }
     b.sync();
     for (int i = b.tid; i < n; i += b.nth) {
@@ -886,21 +914,24 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     int *plist = A.tmp_int + NCANDCAP;    // passing candidate indices, in order
     // 1. is_valid_position (simulation_space.py:89-98), ordered compaction
     int n_valid = 0;
-    for (int base = 0; base < N; base += b.nth) {
-        int i = base + b.tid;
-        int ok = 0;
-        if (i < N) {
+    {
+        const int chunk = (N + b.nth - 1) / b.nth;   // <= 64 for N <= 8192 with 128+ threads; mask below needs chunk <= 64
+        const int i0 = b.tid * chunk, i1 = (i0 + chunk < N) ? i0 + chunk : N;
+        int local = 0;
+        for (int i = i0; i < i1; i++) {
             V3 p = ld3(cand + 3 * i);
-            ok = !(p.x >= C.sx || p.y >= C.sy || p.z >= C.sz || p.x < 0 || p.y < 0 || p.z < 0);
+            int ok = !(p.x >= C.sx || p.y >= C.sy || p.z >= C.sz || p.x < 0 || p.y < 0 || p.z < 0);
             if (ok) {
                 double dd = sqrt((p.x - fcx) * (p.x - fcx) + (p.y - fcy) * (p.y - fcy));
                 ok = dd > fr;
             }
+            A.removed[i] = (unsigned char)ok;
+            local += ok;
         }
         int ex;
-        int tot = blk_scan(b, ok, &ex);
-        if (ok) vlist[n_valid + ex] = i;
-        n_valid += tot;
+        n_valid = blk_scan(b, local, &ex);
+        int run = ex;
+        for (int i = i0; i < i1; i++) if (A.removed[i]) vlist[run++] = i;
     }
     b.sync();
     // 2. tests against all arterial nodes (ball en, oxygen distance) and existing sinks (NN <= es)
@@ -938,13 +969,15 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
         b.sync();
     }
     int n_pass = 0;
-    for (int base = 0; base < n_valid; base += b.nth) {
-        int vi = base + b.tid;
-        int ok = (vi < n_valid) && okf[vi];
+    {
+        const int chunk = (n_valid + b.nth - 1) / b.nth;
+        const int i0 = b.tid * chunk, i1 = (i0 + chunk < n_valid) ? i0 + chunk : n_valid;
+        int local = 0;
+        for (int vi = i0; vi < i1; vi++) local += okf[vi] ? 1 : 0;
         int ex;
-        int tot = blk_scan(b, ok, &ex);
-        if (ok) plist[n_pass + ex] = vlist[vi];
-        n_pass += tot;
+        n_pass = blk_scan(b, local, &ex);
+        int run = ex;
+        for (int vi = i0; vi < i1; vi++) if (okf[vi]) plist[run++] = vlist[vi];
     }
     b.sync();
     // 3. ordered greedy acceptance against the sinks accepted earlier in this call (strict >)
@@ -1001,14 +1034,15 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
     const int n_nodes = sc->n_nodes[f];
     // active node list (ascending id) and first_att reset
     int n_act = 0;
-    for (int base = 0; base < n_nodes; base += b.nth) {
-        int i = base + b.tid;
-        int ok = (i < n_nodes) && A.nact[f][i];
-        if (i < n_nodes) A.first_att[i] = 0x7fffffff;
+    {
+        const int chunk = (n_nodes + b.nth - 1) / b.nth;
+        const int i0 = b.tid * chunk, i1 = (i0 + chunk < n_nodes) ? i0 + chunk : n_nodes;
+        int local = 0;
+        for (int i = i0; i < i1; i++) { A.first_att[i] = 0x7fffffff; local += A.nact[f][i] ? 1 : 0; }
         int ex;
-        int tot = blk_scan(b, ok, &ex);
-        if (ok) A.act_list[n_act + ex] = i;
-        n_act += tot;
+        n_act = blk_scan(b, local, &ex);
+        int run = ex;
+        for (int i = i0; i < i1; i++) if (A.nact[f][i]) A.act_list[run++] = i;
     }
     b.sync();
     {
@@ -1028,39 +1062,65 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
         }
         b.sync();
     }
-    // sort keys (first_att[nn[a]] << 14 | a); unassigned -> 0xffffffff
-    unsigned *keys = reinterpret_cast<unsigned *>(b.user());
-    int n_pow2 = 1;
-    while (n_pow2 < n_att) n_pow2 <<= 1;
-    if (n_pow2 > SORTCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_OXY_CAP); n_pow2 = SORTCAP; }
-    for (int i = b.tid; i < n_pow2; i += b.nth) {
-        unsigned k = 0xffffffffu;
-        if (i < n_att) { int r = A.nn[i]; if (r >= 0) k = ((unsigned)A.first_att[r] << 14) | (unsigned)i; }
-        keys[i] = k;
-    }
-    b.sync();
-    blk_sort_u32(b, keys, n_pow2);
-    // groups (dict order) = runs of equal first_att
-    int n_sorted = 0, n_groups = 0;
-    for (int base = 0; base < n_pow2; base += b.nth) {
-        int i = base + b.tid;
-        unsigned k = (i < n_pow2) ? keys[i] : 0xffffffffu;
-        int valid = k != 0xffffffffu;
-        int head = valid && (i == 0 || (keys[i - 1] >> 14) != (k >> 14));
-        if (i < n_pow2) A.sorted[i] = k;
+    // dict order without a sort: attractor a heads a group iff it is the first hit of its node, so an
+    // ordered compaction of the heads IS the dict order; members are scattered with a per-group cursor
+    // and each (short) member list is put back into attractor order by one thread.
+    int n_groups = 0;
+    {
+        const int chunk = (n_att + b.nth - 1) / b.nth;
+        const int i0 = b.tid * chunk, i1 = (i0 + chunk < n_att) ? i0 + chunk : n_att;
+        int local = 0;
+        for (int a = i0; a < i1; a++) { int r = A.nn[a]; local += (r >= 0 && A.first_att[r] == a) ? 1 : 0; }
         int ex;
-        int tot = blk_scan(b, head, &ex);
-        if (head) {
-            int g = n_groups + ex;
-            if (g < GCAP) { A.gnode[g] = A.nn[k & 16383u]; A.gstart[g] = i; }
+        n_groups = blk_scan(b, local, &ex);
+        int g = ex;
+        for (int a = i0; a < i1; a++) {
+            int r = A.nn[a];
+            if (r >= 0 && A.first_att[r] == a) {
+                if (g < GCAP) { A.gnode[g] = r; A.node_group[r] = g; A.gcount[g] = 0; }
+                g++;
+            }
         }
-        n_groups += tot;
-        int ex2;
-        n_sorted += blk_scan(b, valid, &ex2);
     }
     b.sync();
     if (n_groups > GCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_GROUP_CAP); n_groups = GCAP; }
-    for (int g = b.tid; g < n_groups; g += b.nth) A.gcount[g] = ((g + 1 < n_groups) ? A.gstart[g + 1] : n_sorted) - A.gstart[g];
+    int *cursor = A.tmp_int;
+    for (int a = b.tid; a < n_att; a += b.nth) {
+        int r = A.nn[a];
+        if (r >= 0) { int g = A.node_group[r]; if (g < GCAP) atomic_add_int(&A.gcount[g], 1); }
+    }
+    b.sync();
+    int n_sorted = 0;
+    {
+        const int chunk = (n_groups + b.nth - 1) / b.nth;
+        const int g0 = b.tid * chunk, g1 = (g0 + chunk < n_groups) ? g0 + chunk : n_groups;
+        int local = 0;
+        for (int g = g0; g < g1; g++) local += A.gcount[g];
+        int ex;
+        n_sorted = blk_scan(b, local, &ex);
+        int run = ex;
+        for (int g = g0; g < g1; g++) { A.gstart[g] = run; cursor[g] = run; run += A.gcount[g]; }
+    }
+    b.sync();
+    if (n_sorted > SORTCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_OXY_CAP); }
+    for (int a = b.tid; a < n_att; a += b.nth) {
+        int r = A.nn[a];
+        if (r >= 0) {
+            int g = A.node_group[r];
+            if (g < GCAP) { int pos = atomic_add_int(&cursor[g], 1); if (pos < SORTCAP) A.sorted[pos] = (unsigned)a; }
+        }
+    }
+    b.sync();
+    for (int g = b.tid; g < n_groups; g += b.nth) {
+        unsigned *v = A.sorted + A.gstart[g];
+        const int cnt = A.gcount[g];
+        for (int i = 1; i < cnt; i++) {
+            unsigned x = v[i];
+            int j = i - 1;
+            while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; j--; }
+            v[j + 1] = x;
+        }
+    }
     if (b.tid == 0) { sc->n_groups[f] = n_groups; sc->n_sorted[f] = n_sorted; }
     b.sync();
 }
@@ -1308,13 +1368,16 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
 // stable removal of flagged points from an ordered list (element_mesh.py:196-211 delete_all)
 OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsigned char *removed, double *stage) {
     int n_keep = 0;
-    for (int base = 0; base < n; base += b.nth) {
-        int i = base + b.tid;
-        int keep = (i < n) && !removed[i];
+    {
+        const int chunk = (n + b.nth - 1) / b.nth;
+        const int i0 = b.tid * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+        int local = 0;
+        for (int i = i0; i < i1; i++) local += removed[i] ? 0 : 1;
         int ex;
-        int tot = blk_scan(b, keep, &ex);
-        if (keep) { int w = n_keep + ex; stage[3 * w] = pts[3 * i]; stage[3 * w + 1] = pts[3 * i + 1]; stage[3 * w + 2] = pts[3 * i + 2]; }
-        n_keep += tot;
+        n_keep = blk_scan(b, local, &ex);
+        int w = ex;
+        for (int i = i0; i < i1; i++)
+            if (!removed[i]) { stage[3 * w] = pts[3 * i]; stage[3 * w + 1] = pts[3 * i + 1]; stage[3 * w + 2] = pts[3 * i + 2]; w++; }
     }
     b.sync();
     for (int j = b.tid; j < n_keep * 3; j += b.nth) pts[j] = stage[j];
@@ -1338,14 +1401,11 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
     if (n_new <= 0 || n_oxy <= 0) return;
     const double ek = P.eps_k, ek2 = ek * ek;
     long t0 = OCTA_SUBPROF_T0();
-    // 1. cKDTree order of the O2 list
-    kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank);
-    OCTA_SUBPROF(sc, 11, t0);
     for (int i = b.tid; i < n_oxy; i += b.nth) A.removed[i] = 0;
     int *ctl = b.coll() + 100;
     if (b.tid == 0) ctl[0] = 0;
     b.sync();
-    // 2. (new node, sink) hit pairs, key = node_local << 14 | kd rank
+    // 1. (new node, sink) hits from a grid over the new nodes: raw pairs node_local << 14 | sink
     {
         int *new_ids = A.tmp_int;
         for (int j = b.tid; j < n_new; j += b.nth) new_ids[j] = nb + j;
@@ -1356,17 +1416,27 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
             OCTA_GRID_FOR(G, p.x, p.y, ek, j) {
                 if (sqdist(p, ld3(A.npos[0] + 3 * j)) <= ek2) {
                     int q = atomic_add_int(&ctl[0], 1);
-                    if (q < PCAP) A.pairs[q] = ((unsigned)(j - nb) << 14) | (unsigned)A.kd_rank[o];
+                    if (q < PCAP) A.pairs[q] = ((unsigned)(j - nb) << 14) | (unsigned)o;
                     A.removed[o] = 1;
                 }
             }
         }
         b.sync();
     }
+    OCTA_SUBPROF(sc, 12, t0);
     int n_pairs = ctl[0];
     if (n_pairs > PCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_PAIR_CAP); n_pairs = PCAP; }
     if (n_new > (1 << 18)) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_PAIR_CAP); }
     b.sync();
+    if (n_pairs == 0) return;  // nothing satisfied: no conversion, no deletion (uniform across the block)
+    // 2. cKDTree order of the O2 list, only as deep as the hit sinks need it; pairs get kd ranks
+    kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank, sc->kdprof, A.removed);
+    for (int i = b.tid; i < n_pairs; i += b.nth) {
+        unsigned pr = A.pairs[i];
+        A.pairs[i] = (pr & ~16383u) | (unsigned)A.kd_rank[pr & 16383u];
+    }
+    b.sync();
+    OCTA_SUBPROF(sc, 11, t0);
     // 3. venous proximity + tuple hash for every removed sink
     {
         const int n_ven = sc->n_nodes[1];

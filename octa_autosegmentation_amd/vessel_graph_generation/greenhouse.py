@@ -158,7 +158,7 @@ class BatchSimulator:
         _native.check(self._lib.octa_sim_edge_offsets(self._h, off.ctypes.data, n_art.ctypes.data), "octa_sim_edge_offsets")
         edges = np.zeros((int(off[-1]), 7))
         _native.check(self._lib.octa_sim_export_edges(self._h, edges.ctypes.data), "octa_sim_export_edges")
-        stats = np.zeros((self.batch, 24), np.int64)
+        stats = np.zeros((self.batch, 32), np.int64)
         _native.check(self._lib.octa_sim_stats(self._h, stats.ctypes.data), "octa_sim_stats")
         timing = np.zeros(8)
         _native.check(self._lib.octa_sim_timing(self._h, timing.ctypes.data), "octa_sim_timing")

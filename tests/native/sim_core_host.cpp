@@ -41,7 +41,7 @@ long octa_simcore_gpow_check(long n, unsigned long long seed) {
 
 // nth_element restatement vs the real std::nth_element is checked from Python through this hook
 void octa_simcore_kd_indices(const double *pts, int n, unsigned short *out_idx) {
-    std::vector<unsigned char> smem(2048 + (size_t)OCAP * 10 + 5 * KD_RANGES * 4 + 64);
+    std::vector<unsigned char> smem(2048 + (size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES + 64);
     Blk b = {0, 1, smem.data()};
     std::vector<unsigned short> rank(n);
     kd_build(b, pts, n, out_idx, rank.data());
@@ -104,7 +104,8 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     std::vector<unsigned> sorted(SORTCAP), pairs(PCAP);
     std::vector<Rec> rec(GCAP);
     std::vector<int> glist(GCAP), child_group(NCAP, 0);
-    A.glist = glist.data(); A.child_group = child_group.data();
+    std::vector<int> node_group(NCAP, 0);
+    A.glist = glist.data(); A.child_group = child_group.data(); A.node_group = node_group.data();
     std::vector<unsigned short> kd_idx(OCAP), kd_rank(OCAP);
     std::vector<unsigned char> removed(OCAP), ven_near(OCAP);
     std::vector<unsigned long long> hashes(OCAP), set_hash(SETCAP);
