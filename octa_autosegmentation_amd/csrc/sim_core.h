@@ -858,39 +858,45 @@ OCTA_HD inline void dirty_insert(DirtyList &D, int g) {
     D.n++;
 }
 
-OCTA_HD inline void murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D) {
-    double *rad = A.nrad[f];
+// rad: radii of forest f (the LDS copy during the ordered pass). The parent's topology is requested
+// before the three pow evaluations of the current node so that its HBM/L2 latency hides behind them.
+OCTA_HD inline void murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, double *rad) {
     const double *kap = A.nkap[f];
+    const int *npar = A.npar[f], *nch0 = A.nch0[f], *nch1 = A.nch1[f];
+    const unsigned char *nnch = A.nnch[f];
     long steps = 0;
-    while (id >= 0) {
-        int par = A.npar[f][id];
-        int nch = A.nnch[f][id];
+    if (id < 0) return;
+    int par = npar[id], nch = nnch[id], c0 = nch0[id], c1 = nch1[id], cg = D ? A.child_group[id] : 0;
+    double k = kap[id];
+    while (true) {
         if (par < 0 || nch == 0) break;
-        double k = kap[id];
-        double s = octa_gpow::gpow(rad[A.nch0[f][id]], k);
-        if (nch >= 2) s = s + octa_gpow::gpow(rad[A.nch1[f][id]], k);
+        // prefetch the parent's record (used only if the walk continues)
+        const int p_par = npar[par], p_nch = nnch[par], p_c0 = nch0[par], p_c1 = nch1[par];
+        const int p_cg = D ? A.child_group[par] : 0;
+        const double p_k = kap[par];
+        double s = octa_gpow::gpow(rad[c0], k);
+        if (nch >= 2) s = s + octa_gpow::gpow(rad[c1], k);
         double rp = octa_gpow::gpow(s, 1.0 / k);
         steps++;
         if (rad[id] == rp) break;
         rad[id] = rp;
-        if (D) {
-            int cg = A.child_group[id];
-            if ((cg >> 14) == pass_tag && !((cg >> 13) & 1)) {
-                int g2 = cg & 8191;
-                if (g2 > cur_g) dirty_insert(*D, g2);
-            }
+        if (D && (cg >> 14) == pass_tag && !((cg >> 13) & 1)) {
+            int g2 = cg & 8191;
+            if (g2 > cur_g) dirty_insert(*D, g2);
         }
         id = par;
+        par = p_par; nch = p_nch; c0 = p_c0; c1 = p_c1; cg = p_cg; k = p_k;
     }
     A.sc->murray_steps += steps;
 }
 
-OCTA_HD inline int add_node(const SimArrays &A, int f, V3 p, double r, int parent, double kappa) {
+OCTA_HD inline int add_node(const SimArrays &A, int f, V3 p, double r, int parent, double kappa, double *rad_mirror = nullptr) {
     int id = A.sc->n_nodes[f];
     if (id >= NCAP) { atomic_or_int(&A.sc->err, ERR_NODE_CAP); return -1; }
     A.sc->n_nodes[f] = id + 1;
     st3(A.npos[f] + 3 * id, p);
     A.nrad[f][id] = r; A.nkap[f][id] = kappa; A.npar[f][id] = parent;
+    if (rad_mirror) rad_mirror[id] = r;
     A.nch0[f][id] = -1; A.nch1[f][id] = -1; A.nnch[f][id] = 0; A.nact[f][id] = 1;
     if (parent >= 0) {
         int c = A.nnch[f][parent];
@@ -1133,6 +1139,7 @@ struct GrowCtx {
     int f;
     const double *att;
     double gamma;
+    const double *rad;  // radii of forest f: HBM array, or the LDS copy during the ordered pass
 };
 
 // inter-node sprouting (greenhouse.py:259-306) for group g with the CURRENT child radius
@@ -1143,7 +1150,7 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     R.type = 3; R.grow = 0; R.draw = 0; R.req = -1; R.node = id;
     const V3 pos = ld3(A.npos[f] + 3 * id);
     const int ch = A.nch0[f][id];
-    const double r1 = A.nrad[f][ch], r2 = r;
+    const double r1 = G.rad[ch], r2 = r;
     R.r1_used = r1;
     using octa_gpow::gpow;
     double rp = gpow(gpow(r1, kappa) + gpow(r2, kappa), 1 / kappa);
@@ -1263,7 +1270,7 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
 // parallel speculation over all groups of forest f
 OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
                               const double *att, BifRequest *reqs, int *req_count, int req_cap, int sample) {
-    GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven};
+    GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, A.nrad[f]};
     const int ng = A.sc->n_groups[f];
     if (b.tid == 0) { A.sc->pass_counter++; A.sc->pass_tag[f] = A.sc->pass_counter; }
     b.sync();
@@ -1300,8 +1307,13 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
 OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
                               const double *att, const double *bif_results /* [req][6] */) {
     SampleScalars *sc = A.sc;
+    // the radii of this forest live in LDS for the duration of the pass (NCAP doubles = 128 KiB)
+    double *lrad = reinterpret_cast<double *>(b.user());
+    const int n_before = sc->n_nodes[f];
+    for (int i = b.tid; i < n_before; i += b.nth) lrad[i] = A.nrad[f][i];
+    b.sync();
     if (b.tid == 0) {
-        GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven};
+        GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, lrad};
         const int ng = sc->n_groups[f];
         const int n_grow = sc->n_grow[f];
         const int tag = sc->pass_tag[f];
@@ -1337,16 +1349,16 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 if (bif) {
                     if (R.req < 0) { sc->err |= ERR_MISSING_BIF; continue; }
                     const double *o = bif_results + 6 * (size_t)R.req;
-                    add_node(A, f, v3(o[0], o[1], o[2]), C.r, id, P.kappa);
-                    add_node(A, f, v3(o[3], o[4], o[5]), C.r, id, P.kappa);
-                    murray_to_root(A, f, id, g, tag, &D);
+                    add_node(A, f, v3(o[0], o[1], o[2]), C.r, id, P.kappa, lrad);
+                    add_node(A, f, v3(o[3], o[4], o[5]), C.r, id, P.kappa, lrad);
+                    murray_to_root(A, f, id, g, tag, &D, lrad);
                     A.nact[f][id] = 0;
                     sc->n_bif++;
                 } else {
-                    add_node(A, f, ld3(R.newpos), C.r, id, P.kappa);
+                    add_node(A, f, ld3(R.newpos), C.r, id, P.kappa, lrad);
                 }
             } else {
-                if (A.nrad[f][A.nch0[f][id]] != R.r1_used) {
+                if (lrad[A.nch0[f][id]] != R.r1_used) {
                     eval_inter(G, g, R);
                     sc->respec++;
                 }
@@ -1354,14 +1366,17 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 if (sc->py_pos >= sc->py_cap) { sc->err |= ERR_PY_CAP; break; }
                 double u = A.py_u[sc->py_pos++];
                 if (R.thr <= u && !R.ang_gt90) continue;
-                add_node(A, f, ld3(R.newpos), C.r, id, P.kappa);
-                murray_to_root(A, f, id, g, tag, &D);
+                add_node(A, f, ld3(R.newpos), C.r, id, P.kappa, lrad);
+                murray_to_root(A, f, id, g, tag, &D, lrad);
                 A.nact[f][id] = 0;
             }
             if (D.overflow && !scan_all) { scan_all = true; D.n = 0; }
         }
         sc->new_end[f] = sc->n_nodes[f];
     }
+    b.sync();
+    // radii changed by Murray go back to HBM (new nodes were written through)
+    for (int i = b.tid; i < n_before; i += b.nth) A.nrad[f][i] = lrad[i];
     b.sync();
 }
 
