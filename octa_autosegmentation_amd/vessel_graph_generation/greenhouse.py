@@ -89,18 +89,77 @@ def bifurcation_children(position, atts, r, kappa, d):
     return p1, p2
 
 
+_REC_DOUBLES = 1 + 3 + 3 + MAX_ATTS * 3   # (sample, n) packed in one double slot, pos, r/kappa/d, attractors
+_angle_cache = {}
+
+
+def _murray_cos_sin(r, kappa):
+    """cos / sin of the bifurcation half-angle for two equal children (greenhouse.py:204-215)."""
+    key = (r, kappa)
+    v = _angle_cache.get(key)
+    if v is None:
+        r_p = (r ** kappa + r ** kappa) ** (1 / kappa)
+        phi = np.degrees(np.arccos((r_p ** 4 + r ** 4 - r ** 4) / (2 * r_p ** 2 * r ** 2)))
+        v = (np.cos(np.radians(phi)), np.sin(np.radians(phi)))
+        _angle_cache[key] = v
+    return v
+
+
+def _covariance_like_numpy(atts, c):
+    """np.cov(np.array([a - c for a in atts]).transpose()) through the same numpy calls np.cov makes
+    (mean over the strided axis, in-place centring, dot with the conjugated transpose, scaling), minus
+    its Python-level argument handling."""
+    n = len(atts)
+    X = np.array((atts - c).transpose(), ndmin=2, dtype=np.float64)
+    avg = X.mean(axis=1)
+    X -= avg[:, None]
+    cm = np.dot(X, X.T.conj())
+    cm *= np.true_divide(1, n - 1)
+    return cm
+
+
+def bifurcation_children_batch(recs, counts):
+    """recs: float64 [m, _REC_DOUBLES] request records, counts: attractors per request -> float64 [m, 6].
+    Same arithmetic as bifurcation_children (the eigen-decompositions run as one stacked LAPACK call)."""
+    m = len(recs)
+    out = np.empty((m, 6))
+    covs = np.empty((m, 3, 3))
+    axes = []
+    for i in range(m):
+        rec = recs[i]
+        n = int(counts[i])
+        pos = rec[1:4]
+        atts = rec[7:7 + 3 * n].reshape(n, 3)
+        c = np.add.reduce(atts, axis=0) / n           # == np.mean(atts, axis=0)
+        axis_c = c - pos
+        nrm = np.sqrt(axis_c.dot(axis_c))             # == np.linalg.norm(axis_c)
+        if nrm != 0.0:
+            axis_c = axis_c / nrm
+        axes.append(axis_c)
+        covs[i] = _covariance_like_numpy(atts, c)
+    w_all, v_all = np.linalg.eig(covs)
+    for i in range(m):
+        rec = recs[i]
+        pos, r, kappa, d = rec[1:4], float(rec[4]), float(rec[5]), float(rec[6])
+        cs, sn = _murray_cos_sin(r, kappa)
+        w, v = w_all[i], v_all[i]
+        if np.iscomplexobj(w) and np.all(w.imag == 0.0):
+            w, v = w.real, v.real
+        d_l = v[:, np.argmax(w)]
+        a1 = cs * axes[i] + sn * d_l
+        a2 = cs * axes[i] - sn * d_l
+        out[i, 0:3] = np.real(pos + a1 / np.linalg.norm(a1) * d)
+        out[i, 3:6] = np.real(pos + a2 / np.linalg.norm(a2) * d)
+    return out
+
+
 @BIF_FN
 def _serve_bifurcations(n_req, reqs_ptr, out6, _user):
     buf = (ctypes.c_char * (REQ_DTYPE.itemsize * n_req)).from_address(reqs_ptr)
-    reqs = np.frombuffer(buf, dtype=REQ_DTYPE, count=n_req)
+    recs = np.frombuffer(buf, dtype=np.float64).reshape(n_req, _REC_DOUBLES)
+    counts = np.frombuffer(buf, dtype=np.int32).reshape(n_req, 2 * _REC_DOUBLES)[:, 1]
     out = np.ctypeslib.as_array(out6, shape=(n_req, 6))
-    for i in range(n_req):
-        q = reqs[i]
-        n = int(q["n"])
-        p1, p2 = bifurcation_children(np.array(q["pos"]), np.array(q["atts"][:n]), float(q["r"]), float(q["kappa"]),
-                                      float(q["d"]))
-        out[i, 0:3] = p1
-        out[i, 3:6] = p2
+    out[:] = bifurcation_children_batch(recs, counts)
 
 
 class SimulationResult:

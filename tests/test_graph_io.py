@@ -41,3 +41,28 @@ def test_read_back_on_simulated_graph():
     rows = list(csv.DictReader(io.StringIO(text)))
     parsed = np.array([graph_io.parse_legacy_position(r["node1"]) + graph_io.parse_legacy_position(r["node2"]) + [float(r["radius"])] for r in rows])
     assert (graph_io.edges_as_read_back(edges) == parsed).all()
+
+
+def test_batched_bifurcation_service_is_bitwise_the_reference_formula():
+    """The batched host service (inlined np.cov, stacked eig, cached angles) against the plain
+    per-request formula that mirrors greenhouse.py:205-233 line by line."""
+    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse as gh
+    rng = np.random.default_rng(42)
+    m = 300
+    recs = np.zeros((m, gh._REC_DOUBLES))
+    counts = np.zeros(m, np.int32)
+    for i in range(m):
+        n = int(rng.integers(2, 60))
+        counts[i] = n
+        pos = rng.uniform(0.1, 0.9, 3) * np.array([1, 1, 0.0131])
+        spread = rng.uniform(0.002, 0.08)
+        atts = pos + rng.normal(0, spread, (n, 3)) * np.array([1, 1, 0.05]) + rng.normal(0, 0.02, 3) * np.array([1, 1, 0])
+        recs[i, 1:4] = pos
+        recs[i, 4:7] = [0.0025 / 3, [2.55, 2.9][i % 2], rng.uniform(0.012, 0.034)]
+        recs[i, 7:7 + 3 * n] = atts.ravel()
+    fast = gh.bifurcation_children_batch(recs, counts)
+    for i in range(m):
+        n = counts[i]
+        p1, p2 = gh.bifurcation_children(recs[i, 1:4].copy(), recs[i, 7:7 + 3 * n].reshape(n, 3).copy(),
+                                         float(recs[i, 4]), float(recs[i, 5]), float(recs[i, 6]))
+        assert (fast[i, 0:3] == p1).all() and (fast[i, 3:6] == p2).all(), i
