@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--inflight", type=int, default=2, help="steps in flight per GPU (each on its own HIP stream)")
+    ap.add_argument("--inflight", type=int, default=3, help="steps in flight per GPU (each on its own HIP stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

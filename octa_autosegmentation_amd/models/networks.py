@@ -1,0 +1,147 @@
+"""Networks on the hot path (reference: models/networks.py; DynUNet is imported from MONAI there,
+networks.py:6,1010 -- MONAI is not installed here, so the architecture is restated in plain torch).
+
+DynUNet as configured by configs/config_ves_seg-S.yml:6-13 (spatial_dims 2, kernel 3, strides
+[1,2,2,2,1], upsample kernels [1,2,2,2], filters [32,64,128,256,512], instance norm (affine) +
+LeakyReLU(0.01), bias-free convs, 1x1 head with bias, no deep supervision, no residual blocks).
+Module and parameter names follow MONAI's DynUNet (input_block / downsamples / bottleneck / upsamples /
+output_block with conv1.conv, norm1, transp_conv.conv, conv_block...) so that reference checkpoints
+(`{'epoch','model','optimizer','config'}`, utils/visualizer.py:225-238) load; MONAI's state_dict also
+carries the same tensors a second time under `skip_layers.*` -- those aliases are emitted on save and
+ignored on load. Parity with MONAI itself is UNPINNED (no MONAI, no checkpoint in the container);
+numerics are pinned against this module run in fp32 on the CPU.
+"""
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+
+class _Conv(nn.Module):
+    """MONAI `Convolution(conv_only=True)`: a container whose only child is `conv`."""
+
+    def __init__(self, cin, cout, kernel, stride, bias=False, transposed=False):
+        super().__init__()
+        if transposed:
+            pad = int((kernel - stride + 1) / 2)
+            self.conv = nn.ConvTranspose2d(cin, cout, kernel, stride, padding=pad,
+                                           output_padding=2 * pad + stride - kernel, bias=bias)
+        else:
+            self.conv = nn.Conv2d(cin, cout, kernel, stride, padding=int((kernel - stride + 1) / 2), bias=bias)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class UnetBasicBlock(nn.Module):
+    def __init__(self, cin, cout, kernel, stride):
+        super().__init__()
+        self.conv1 = _Conv(cin, cout, kernel, stride)
+        self.conv2 = _Conv(cout, cout, kernel, 1)
+        self.lrelu = nn.LeakyReLU(0.01, inplace=True)
+        self.norm1 = nn.InstanceNorm2d(cout, affine=True)
+        self.norm2 = nn.InstanceNorm2d(cout, affine=True)
+
+    def forward(self, x):
+        x = self.lrelu(self.norm1(self.conv1(x)))
+        return self.lrelu(self.norm2(self.conv2(x)))
+
+
+class UnetUpBlock(nn.Module):
+    def __init__(self, cin, cout, kernel, up_kernel):
+        super().__init__()
+        self.transp_conv = _Conv(cin, cout, up_kernel, up_kernel, transposed=True)
+        self.conv_block = UnetBasicBlock(cout + cout, cout, kernel, 1)
+
+    def forward(self, x, skip):
+        return self.conv_block(torch.cat((self.transp_conv(x), skip), dim=1))
+
+
+class UnetOutBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = _Conv(cin, cout, 1, 1, bias=True)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class DynUNet(nn.Module):
+    def __init__(self, spatial_dims: int = 2, in_channels: int = 1, out_channels: int = 1,
+                 kernel_size: Sequence[int] = (3, 3, 3, 3, 3), strides: Sequence[int] = (1, 2, 2, 2, 1),
+                 upsample_kernel_size: Sequence[int] = (1, 2, 2, 2, 1), filters: Sequence[int] = None, **unused):
+        super().__init__()
+        if spatial_dims != 2:
+            raise NotImplementedError("only the 2-D DynUNet of the OCTA configs is implemented")
+        ks = [k if isinstance(k, int) else k[0] for k in kernel_size]
+        st = [s if isinstance(s, int) else s[0] for s in strides]
+        up = [u if isinstance(u, int) else u[0] for u in upsample_kernel_size]
+        if filters is None:
+            filters = [min(2 ** (5 + i), 512) for i in range(len(st))]
+        self.filters = list(filters)
+        self.input_block = UnetBasicBlock(in_channels, filters[0], ks[0], st[0])
+        self.downsamples = nn.ModuleList(
+            [UnetBasicBlock(filters[i - 1], filters[i], ks[i], st[i]) for i in range(1, len(st) - 1)])
+        self.bottleneck = UnetBasicBlock(filters[-2], filters[-1], ks[-1], st[-1])
+        inp, out = filters[1:][::-1], filters[:-1][::-1]
+        kern, ups = ks[1:][::-1], up[::-1]
+        self.upsamples = nn.ModuleList([UnetUpBlock(i, o, k, u) for i, o, k, u in zip(inp, out, kern, ups)])
+        self.output_block = UnetOutBlock(filters[0], out_channels)
+        self._register_state_dict_hook(self._add_skip_layer_aliases)
+        self._register_load_state_dict_pre_hook(self._drop_skip_layer_aliases)
+
+    # MONAI keeps the same modules a second time inside the recursive `skip_layers` wrapper
+    def _alias_prefixes(self):
+        depth = len(self.downsamples) + 1
+        m = {"input_block.": "skip_layers.downsample.", f"upsamples.{depth - 1}.": "skip_layers.upsample."}
+        nl = "skip_layers."
+        for i in range(len(self.downsamples)):
+            nl += "next_layer."
+            m[f"downsamples.{i}."] = nl + "downsample."
+            m[f"upsamples.{depth - 2 - i}."] = nl + "upsample."
+        m["bottleneck."] = nl + "next_layer."
+        return m
+
+    @staticmethod
+    def _add_skip_layer_aliases(module, state_dict, prefix, local_metadata):
+        for src, dst in module._alias_prefixes().items():
+            for k in [k for k in state_dict if k.startswith(prefix + src)]:
+                state_dict[prefix + dst + k[len(prefix + src):]] = state_dict[k]
+        return state_dict
+
+    def _drop_skip_layer_aliases(self, state_dict, prefix, *args):
+        for k in [k for k in state_dict if k.startswith(prefix + "skip_layers.")]:
+            del state_dict[k]
+
+    def forward(self, x):
+        skips = [self.input_block(x)]
+        for d in self.downsamples:
+            skips.append(d(skips[-1]))
+        y = self.bottleneck(skips[-1])
+        for u, s in zip(self.upsamples, skips[::-1]):
+            y = u(y, s)
+        return self.output_block(y)
+
+
+def init_weights(net: nn.Module, init_type='normal', init_gain=0.02, debug=False, nonlinearity='leaky_relu'):
+    """Same rule as models/networks.py:152-184: every module whose class name contains Conv or Linear."""
+    def init_func(m):
+        name = m.__class__.__name__
+        if hasattr(m, 'weight') and (name.find('Conv') != -1 or name.find('Linear') != -1):
+            if init_type == 'normal':
+                nn.init.normal_(m.weight.data, 0.0, init_gain)
+            elif init_type == 'xavier':
+                nn.init.xavier_normal_(m.weight.data, gain=init_gain)
+            elif init_type == 'kaiming':
+                nn.init.kaiming_normal_(m.weight.data, a=0, mode='fan_in', nonlinearity=nonlinearity)
+            elif init_type == 'orthogonal':
+                nn.init.orthogonal_(m.weight.data, gain=init_gain)
+            else:
+                raise NotImplementedError(f'initialization method [{init_type}] is not implemented')
+        elif name.find('BatchNorm') != -1:
+            nn.init.normal_(m.weight.data, 1.0, init_gain)
+            nn.init.constant_(m.bias.data, 0.0)
+    net.apply(init_func)
+
+
+MODEL_DICT = {"DynUNet": DynUNet}
