@@ -82,6 +82,17 @@ int octa_raster_prof(octa_ctx *ctx, int64_t *h_out4);
  */
 int octa_fs_dither(octa_ctx *ctx, int B, const uint8_t *d_in, int W, int H, uint8_t *d_out, void *stream);
 
+/* ---- N6: 3-D tube voxeliser ------------------------------------------------
+ * Replaces: vessel_graph_generation/tree2img.py:176-280 (voxelize_forest, cuboid getCrossSlice :151-172)
+ * for B graphs. dims3 = volume_dimensions; every axis is padded to at least
+ * ceil(scale/76 + 0.03*scale) voxels (scale = max(dims3)) exactly as the reference does -- query the
+ * padded shape with octa_voxel_padded_dims. d_out: uint16 [B][X'][Y'][Z'] (padded dims), overwritten.
+ * d_keep as in octa_rasterize_2d. Callers: generate_vessel_graph.py:69-77, visualize_vessel_graphs.py:77-94.
+ */
+int octa_voxel_padded_dims(const int *dims3, int *padded3);
+int octa_voxelize_3d(octa_ctx *ctx, int B, const double *d_edges, const int64_t *h_edge_off, const uint8_t *d_keep,
+                     const int *dims3, double min_radius, double max_radius, int ignore_z, uint16_t *d_out, void *stream);
+
 /* ---- element-wise max of two uint8 images -------------------------------
  * Replaces: np.maximum(art_mat, ven_mat) at generate_vessel_graph.py:83.
  */

@@ -23,6 +23,8 @@ SIGNATURES = {
                                   c_double, c_void_p, c_void_p]),
     "octa_raster_prof": (c_int, [c_void_p, c_void_p]),
     "octa_fs_dither": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "octa_voxel_padded_dims": (c_int, [c_void_p, c_void_p]),
+    "octa_voxelize_3d": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p]),
     "octa_max_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "octa_sim_create": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
     "octa_sim_destroy": (None, [c_void_p]),

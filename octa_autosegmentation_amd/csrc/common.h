@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <vector>
 

@@ -5,6 +5,12 @@ autocast forward + DiceBCE loss, backward, optimizer step. Mixed precision is bf
 needed; the reference's fp16 + GradScaler is an artefact of its CUDA target). With
 torch.distributed initialised (backend "nccl" = RCCL over xGMI), gradients of all ranks are averaged
 with ONE all-reduce over a flat bucket per step (7.4 M parameters = 29.5 MB fp32)."""
+import os
+
+# MIOpen's exhaustive find mode benchmarks every solver (incl. naive reference kernels) on first use:
+# minutes per process on a fresh box. The fast heuristic mode starts in seconds (set before torch loads MIOpen).
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 import torch
 import torch.distributed as dist
 
@@ -15,7 +21,7 @@ from .networks import MODEL_DICT, init_weights
 class SegmentationTrainer:
     optimizer_mapping = {"optimizer": ["model"]}
 
-    def __init__(self, config, device, channels_last=True):
+    def __init__(self, config, device, channels_last=False):
         kw = dict(config["General"]["model"])
         name = kw.pop("name")
         self.device = torch.device(device)

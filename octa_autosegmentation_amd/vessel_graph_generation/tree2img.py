@@ -103,6 +103,41 @@ def rasterize_forest(forest, image_resolution: Sequence[float], MIP_axis: int = 
     return img[0].cpu().numpy().astype(np.uint16), blackdict
 
 
+def voxelize_edges_device(d_edges, edge_off, volume_dimensions, min_radius=-np.inf, max_radius=np.inf, d_keep=None,
+                          ignore_z=False):
+    """Batched device entry of the 3-D voxeliser: uint16 CUDA tensor [B, X', Y', Z'] (padded dims)."""
+    import torch
+    edge_off = np.ascontiguousarray(edge_off, dtype=np.int64)
+    B = len(edge_off) - 1
+    dims = np.ascontiguousarray([int(v) for v in volume_dimensions], dtype=np.int32)
+    pd = np.zeros(3, np.int32)
+    _native.lib().octa_voxel_padded_dims(dims.ctypes.data, pd.ctypes.data)
+    if d_edges.dtype != torch.float64 or not d_edges.is_cuda or not d_edges.is_contiguous():
+        raise ValueError("d_edges must be a contiguous float64 CUDA tensor")
+    out = torch.empty((B, int(pd[0]), int(pd[1]), int(pd[2])), dtype=torch.int16, device=d_edges.device)
+    h = _native.ctx(d_edges.device.index)
+    rc = _native.lib().octa_voxelize_3d(
+        h, B, ctypes.c_void_p(d_edges.data_ptr()), ctypes.c_void_p(edge_off.ctypes.data),
+        ctypes.c_void_p(d_keep.data_ptr()) if d_keep is not None else None, ctypes.c_void_p(dims.ctypes.data),
+        float(min_radius), float(max_radius), int(bool(ignore_z)), ctypes.c_void_p(out.data_ptr()),
+        _native.current_stream_ptr())
+    _native.check(rc, "octa_voxelize_3d")
+    return out
+
+
+def voxelize_forest(forest, volume_dimensions: Sequence[float], radius_list: list = None, min_radius=0, max_radius=1,
+                    max_dropout_prob=0, blackdict=None, ignore_z=False) -> Tuple[np.ndarray, dict]:
+    """Same contract as the reference's voxelize_forest (tree2img.py:176-280): (uint16 [X',Y',Z'], blackdict);
+    radius_list receives the unscaled radii (tree2img.py:235)."""
+    import torch
+    edges, blackdict = select_edges(forest, min_radius, max_radius, max_dropout_prob, blackdict, radius_list, radius_factor=1.0)
+    if not torch.cuda.is_available():
+        _native.ctx()
+    d_edges = torch.from_numpy(edges).to(torch.device("cuda", torch.cuda.current_device()))
+    vol = voxelize_edges_device(d_edges, np.array([0, len(edges)]), volume_dimensions, -np.inf, np.inf, None, ignore_z)
+    return vol[0].cpu().numpy().view(np.uint16), blackdict
+
+
 def binarize_label_device(d_img):
     """Pillow `convert("1")` (Floyd-Steinberg) of uint8 CUDA images [B,H,W] -> uint8 {0,255}.
     Mirrors visualize_vessel_graphs.py:97-99."""

@@ -36,6 +36,11 @@ def lib():
                                             ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
         l.octa_oracle_fs_dither.restype = None
         l.octa_oracle_fs_dither.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        l.octa_oracle_voxel_dims.restype = None
+        l.octa_oracle_voxel_dims.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        l.octa_oracle_voxelize.restype = ctypes.c_long
+        l.octa_oracle_voxelize.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         _lib = l
     return _lib
 
@@ -62,4 +67,20 @@ def fs_dither(img):
     H, W = img.shape
     out = np.zeros_like(img)
     lib().octa_oracle_fs_dither(img.ctypes.data, W, H, out.ctypes.data)
+    return out
+
+
+def voxelize(edges, volume_dimensions, min_radius=-np.inf, max_radius=np.inf, keep=None, ignore_z=False):
+    """edges float64 [n,7] -> uint16 [X,Y,Z] with the reference's padded dims (tree2img.py:176-280 restated)."""
+    edges = np.ascontiguousarray(edges, dtype=np.float64).reshape(-1, 7)
+    dims = np.ascontiguousarray(volume_dimensions, dtype=np.int32)
+    pd = np.zeros(3, np.int32)
+    lib().octa_oracle_voxel_dims(dims.ctypes.data, pd.ctypes.data)
+    out = np.zeros(tuple(int(v) for v in pd), np.uint16)
+    kp = None
+    if keep is not None:
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        kp = keep.ctypes.data
+    lib().octa_oracle_voxelize(edges.ctypes.data, len(edges), dims.ctypes.data, float(min_radius), float(max_radius), kp,
+                               int(bool(ignore_z)), out.ctypes.data)
     return out
