@@ -1,0 +1,46 @@
+"""GPU: the drop-in CLIs produce the reference's files with the reference's contents."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generate_and_visualize_cli(tmp_path, hip_lib_built):
+    import sys
+    sys.path.insert(0, ROOT)
+    import generate_vessel_graph
+    import visualize_vessel_graphs
+    from PIL import Image
+    from octa_autosegmentation_amd import graph_io
+    from oracle import octa_oracle, sim_oracle
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
+    cfg = yaml.safe_load(str(g["config_yaml"]))
+    cfg_path = tmp_path / "cfg.yml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    out_dir = tmp_path / "graphs"
+    generate_vessel_graph.main(["--config_file", str(cfg_path), "--num_samples", "2", "--seed", "0",
+                                "--output.directory", str(out_dir), "--Greenhouse.modes", yaml.safe_dump(
+                                    [dict(cfg["Greenhouse"]["modes"][0], I=30), dict(cfg["Greenhouse"]["modes"][1], I=20)], default_flow_style=True).strip()])
+    dirs = sorted(glob.glob(str(out_dir / "*")))
+    assert len(dirs) == 2
+    texts = set()
+    for d in dirs:
+        name = os.path.basename(d)
+        assert os.path.exists(os.path.join(d, "config.yml")) and os.path.exists(os.path.join(d, "art_ven_img_gray.png"))
+        texts.add(open(os.path.join(d, name + ".csv"), newline="").read())
+    assert {g["run_s0_30_20_csv"].tobytes().decode(), g["run_s1_30_20_csv"].tobytes().decode()} == texts
+    # visualize: label PNG == oracle raster of the read-back CSV + Floyd-Steinberg
+    vis = tmp_path / "vis"
+    visualize_vessel_graphs.main(["--source_dir", str(out_dir), "--out_dir", str(vis), "--resolution", "1216,1216,16", "--binarize"])
+    for d in dirs:
+        name = os.path.basename(d)
+        e = graph_io.read_csv(os.path.join(d, name + ".csv"))
+        want = octa_oracle.fs_dither(octa_oracle.rasterize(e, [1216, 1216]))
+        got = np.array(Image.open(str(vis / (name + "_label.png"))).convert("L"))
+        assert Image.open(str(vis / (name + "_label.png"))).mode == "1"
+        assert (got == want).all()
