@@ -93,6 +93,15 @@ int octa_voxel_padded_dims(const int *dims3, int *padded3);
 int octa_voxelize_3d(octa_ctx *ctx, int B, const double *d_edges, const int64_t *h_edge_off, const uint8_t *d_keep,
                      const int *dims3, double min_radius, double max_radius, int ignore_z, uint16_t *d_out, void *stream);
 
+/* ---- CSV round trip of node positions ------------------------------------
+ * Replaces the text round trip str(np.ndarray) -> float() of generate_vessel_graph.py:59-66 +
+ * tree2img.py:73-76 for a whole edge array on the device: d_out[n][7] receives the positions exactly as
+ * they read back from the CSV (radius copied). *h_n_unhandled (optional, forces a stream sync) counts
+ * 3-vectors outside the exact range of the kernel (non-finite, |x| < 1e-14 in scientific rows, |x| >= 4e7);
+ * they are copied through unchanged and the caller must redo those rows on the host.
+ */
+int octa_edges_read_back(octa_ctx *ctx, const double *d_edges, double *d_out, int64_t n_edges, int *h_n_unhandled, void *stream);
+
 /* ---- element-wise max of two uint8 images -------------------------------
  * Replaces: np.maximum(art_mat, ven_mat) at generate_vessel_graph.py:83.
  */

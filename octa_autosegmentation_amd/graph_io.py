@@ -85,3 +85,23 @@ def edges_as_read_back(edges):
     e[:, 0:3] = positions_as_read_back(e[:, 0:3])
     e[:, 3:6] = positions_as_read_back(e[:, 3:6])
     return e
+
+
+def edges_as_read_back_device(d_edges):
+    """CUDA float64 [n,7] -> the same edges with positions as they read back from the CSV text, computed on the
+    GPU (octa_edges_read_back); rows outside the kernel's exact range (never produced by the simulator) fall
+    back to the host formula."""
+    import ctypes
+    import torch
+    from . import _native
+    if d_edges.dtype != torch.float64 or not d_edges.is_cuda or not d_edges.is_contiguous():
+        raise ValueError("d_edges must be a contiguous float64 CUDA tensor")
+    out = torch.empty_like(d_edges)
+    bad = ctypes.c_int(0)
+    rc = _native.lib().octa_edges_read_back(_native.ctx(d_edges.device.index), ctypes.c_void_p(d_edges.data_ptr()),
+                                            ctypes.c_void_p(out.data_ptr()), d_edges.shape[0], ctypes.byref(bad),
+                                            _native.current_stream_ptr())
+    _native.check(rc, "octa_edges_read_back")
+    if bad.value:
+        out = torch.from_numpy(edges_as_read_back(d_edges.cpu().numpy())).to(d_edges.device)
+    return out

@@ -49,8 +49,7 @@ class TripleGenerator:
         image = tree2img.maximum_u8_device(pair[:, 0].contiguous(), pair[:, 1].contiguous())
         out = dict(result=res, image=image)
         if want_label:
-            rb = graph_io.edges_as_read_back(res.edges)
-            d_rb = torch.from_numpy(rb).to(self.device, non_blocking=True)
+            d_rb = graph_io.edges_as_read_back_device(d_edges)
             grey = tree2img.rasterize_edges_device(d_rb, off, self.label_res, 2)
             out["label_grey"] = grey
             out["label"] = tree2img.binarize_label_device(grey)

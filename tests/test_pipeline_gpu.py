@@ -32,3 +32,19 @@ def test_triples_match_oracle(hip_lib_built):
         assert (out["label_grey"][k].cpu().numpy() == grey).all()
         assert (out["label"][k].cpu().numpy() == octa_oracle.fs_dither(grey)).all()
     gen.close()
+
+
+def test_device_read_back_matches_host_emulation(hip_lib_built):
+    import torch
+    from octa_autosegmentation_amd import graph_io
+    rng = np.random.default_rng(3)
+    n = 20000
+    e = np.zeros((n, 7))
+    e[:, 0:3] = rng.uniform(-0.01, 1.02, (n, 3)); e[:, 3:6] = rng.uniform(-0.01, 1.02, (n, 3))
+    e[:, 2] = rng.uniform(-2e-3, 0.0131, n); e[:, 5] = rng.uniform(-2e-3, 0.0131, n)
+    e[::7, 2] = rng.uniform(-9e-5, 9e-5, n)[::7]; e[::11, 0] = 0.0; e[::13, 4] = 1 - 1e-6
+    e[5, 0:3] = [0.5, 0.25, 0.125]; e[6, 3:6] = [1e-5, 2e-6, 3e-9]; e[7, 0:3] = [0.99999999499, 0.123456785, 0.000123456789]
+    e[:, 6] = rng.uniform(1e-4, 1e-2, n)
+    got = graph_io.edges_as_read_back_device(torch.from_numpy(e).cuda()).cpu().numpy()
+    want = graph_io.edges_as_read_back(e)
+    assert (got == want).all(), np.nonzero((got != want).any(axis=1))[0][:10]
