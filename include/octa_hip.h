@@ -147,6 +147,16 @@ typedef struct {
 /* Fill out6[i] = (p_new_1.xyz, p_new_2.xyz) for every request (greenhouse.py:205-233). */
 typedef void (*octa_bif_fn)(int n_req, const octa_bif_request *reqs, double *out6, void *user);
 
+/* Native bifurcation service: an octa_bif_fn that evaluates requests in C++ through the BLAS/LAPACK library
+ * numpy itself is linked against (path of numpy.libs/libscipy_openblas64_*.so), falling back to `fallback`
+ * (the numpy callback) per request where it cannot guarantee numpy's bits (complex eigenpairs, unknown kappa).
+ * kappas/cs/sn: the bifurcation exponents of the config's modes with cos/sin of the Murray half-angle as numpy
+ * computes them. The Python host validates the native path against the numpy formula before using it. */
+int octa_bif_native_init(const char *blas_path, int n_kappa, const double *kappas, const double *cs, const double *sn,
+                         octa_bif_fn fallback, void *fallback_user);
+void octa_bif_native(int n_req, const octa_bif_request *reqs, double *out6, void *user);
+int octa_bif_native_counts(int64_t *h_out2);
+
 int octa_sim_create(octa_ctx *ctx, const octa_sim_config *cfg, int B, octa_sim **out);
 void octa_sim_destroy(octa_sim *sim);
 

@@ -27,6 +27,9 @@ SIGNATURES = {
     "octa_voxelize_3d": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p]),
     "octa_edges_read_back": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]),
     "octa_max_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "octa_bif_native_init": (c_int, [ctypes.c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "octa_bif_native": (None, [c_int, c_void_p, c_void_p, c_void_p]),
+    "octa_bif_native_counts": (c_int, [c_void_p]),
     "octa_sim_create": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
     "octa_sim_destroy": (None, [c_void_p]),
     "octa_sim_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -162,6 +162,56 @@ def _serve_bifurcations(n_req, reqs_ptr, out6, _user):
     out[:] = bifurcation_children_batch(recs, counts)
 
 
+_native_state = {"ready": None, "kappas": ()}
+
+
+def _numpy_blas_path():
+    import glob
+    import os
+    cands = glob.glob(os.path.join(os.path.dirname(np.__file__), "..", "numpy.libs", "libscipy_openblas64_*.so"))
+    return cands[0] if cands else None
+
+
+def _enable_native_bifurcation_service(config):
+    """Switch the bifurcation service to the C++ path (same BLAS/LAPACK as numpy) after checking it bit-for-bit
+    against the numpy formula on random requests. Returns the function pointer to hand to octa_sim_run."""
+    py_cb = ctypes.cast(_serve_bifurcations, ctypes.c_void_p)
+    g = config["Greenhouse"]
+    r = g["r"] / g["param_scale"]
+    kappas = tuple(sorted({float(m["kappa"]) for m in g["modes"]}))
+    key = (r, kappas)
+    if _native_state["ready"] is not None and _native_state["kappas"] == key:
+        return _native_state["ready"]
+    lib = _native.lib()
+    path = _numpy_blas_path()
+    fn = py_cb
+    if path is not None:
+        kap = np.array(kappas)
+        cs = np.array([_murray_cos_sin(r, k)[0] for k in kappas])
+        sn = np.array([_murray_cos_sin(r, k)[1] for k in kappas])
+        if lib.octa_bif_native_init(path.encode(), len(kappas), kap.ctypes.data, cs.ctypes.data, sn.ctypes.data, py_cb, None) == 0:
+            rng = np.random.default_rng(20240607)
+            m = 256
+            recs = np.zeros((m, _REC_DOUBLES))
+            counts = np.zeros(m, np.int32)
+            for i in range(m):
+                n = int(rng.integers(2, 48))
+                counts[i] = n
+                pos = rng.uniform(0.1, 0.9, 3) * np.array([1, 1, 0.0131])
+                atts = pos + rng.normal(0, rng.uniform(0.002, 0.08), (n, 3)) * np.array([1, 1, 0.05]) + rng.normal(0, 0.02, 3) * np.array([1, 1, 0])
+                recs[i, 1:4] = pos
+                recs[i, 4:7] = [r, kappas[i % len(kappas)], rng.uniform(0.012, 0.034)]
+                recs[i, 7:7 + 3 * n] = atts.ravel()
+            recs.view(np.int32).reshape(m, -1)[:, 1] = counts
+            want = bifurcation_children_batch(recs, counts)
+            got = np.zeros((m, 6))
+            lib.octa_bif_native(m, recs.ctypes.data, got.ctypes.data, None)
+            if (got == want).all():
+                fn = ctypes.cast(lib.octa_bif_native, ctypes.c_void_p)
+    _native_state["ready"], _native_state["kappas"] = fn, key
+    return fn
+
+
 class SimulationResult:
     """Edges of B samples in the reference's CSV row order plus per-sample statistics."""
 
@@ -186,6 +236,7 @@ class BatchSimulator:
         self._lib = _native.lib()
         self._ctx = _native.ctx(device_index)
         self._cfg = config_to_struct(config)
+        self._bif_fn = _enable_native_bifurcation_service(config)
         self.batch = int(batch)
         h = ctypes.c_void_p()
         _native.check(self._lib.octa_sim_create(self._ctx, ctypes.byref(self._cfg), self.batch, ctypes.byref(h)),
@@ -209,8 +260,7 @@ class BatchSimulator:
         if len(seeds) != self.batch:
             raise ValueError(f"expected {self.batch} seeds")
         py = np.ascontiguousarray(seeds if py_seeds is None else py_seeds, dtype=np.uint64)
-        rc = self._lib.octa_sim_run(self._h, seeds.ctypes.data, py.ctypes.data, ctypes.cast(_serve_bifurcations, ctypes.c_void_p),
-                                    None, _native.current_stream_ptr())
+        rc = self._lib.octa_sim_run(self._h, seeds.ctypes.data, py.ctypes.data, self._bif_fn, None, _native.current_stream_ptr())
         _native.check(rc, "octa_sim_run")
         off = np.zeros(self.batch + 1, np.int64)
         n_art = np.zeros(self.batch, np.int64)
