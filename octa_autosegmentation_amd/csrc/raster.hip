@@ -13,8 +13,8 @@
 //  * raster_render_kernel: one 1024-thread workgroup per 64x64 pixel super-tile. It streams the
 //    graph's bbox array (coalesced 8 B/edge), keeps the edges that touch the tile IN LIST ORDER
 //    with a ballot/prefix compaction into LDS, tessellates their stroke polygons into 24.8
-//    fixed-point sides in LDS (one thread per polygon side), then every wave owns a 16x16 block
-//    (4 pixels per lane, same row) and folds the edges in order: the Agg cell sums (cover, area)
+//    fixed-point sides in LDS (one thread per polygon side), then every wave owns a 16 x (4*NPX) block
+//    (NPX pixels per lane, same row) and folds the edges in order: the Agg cell sums (cover, area)
 //    of a pixel are evaluated in CLOSED FORM per polygon side -- Agg's two nested integer DDAs
 //    are exact floor divisions, so x at scanline boundary j is x1 + floor(((256-fy1)+256(j-1))dx/dy)
 //    and likewise for y at cell boundaries inside a scanline -- so no per-edge cell list, no
@@ -32,8 +32,10 @@
 namespace {
 using namespace octa_raster;
 
-constexpr int ST = 64;          // super-tile width (pixels)
-constexpr int ST_Y = 64;        // super-tile height: 16 waves x (16x16 block)
+constexpr int NPX = 4;          // adjacent pixels of one row per lane (register pressure vs. division reuse)
+constexpr int BLK_H = 4 * NPX;  // a wave owns a 16 x BLK_H pixel block (16/NPX lanes per row)
+constexpr int ST = 64;          // super-tile width (pixels): 4 blocks
+constexpr int ST_Y = 4 * BLK_H; // super-tile height: 4 blocks (16 waves)
 constexpr int WG = 1024;        // threads per render workgroup
 constexpr int EPT = 4;          // edges tested per thread per scan round
 constexpr int LIST_CAP = 1024;  // edges per chunk
@@ -114,10 +116,12 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
 
     // wave -> 16x16 block, lane -> 4 adjacent pixels of one row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int bx0 = tx0 + (wv & 3) * 16, by0 = ty0 + (wv >> 2) * 16;
-    const int prow = by0 + (lane >> 2);
-    const int pcol = bx0 + (lane & 3) * 4;
-    unsigned pix[4] = {0u, 0u, 0u, 0u};
+    const int bx0 = tx0 + (wv & 3) * 16, by0 = ty0 + (wv >> 2) * BLK_H;
+    const int prow = by0 + lane / (16 / NPX);
+    const int pcol = bx0 + (lane % (16 / NPX)) * NPX;
+    unsigned pix[NPX];
+#pragma unroll
+    for (int q = 0; q < NPX; q++) pix[q] = 0u;
 
     int cursor = 0;
     while (cursor < n_edges) {
@@ -249,29 +253,31 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         for (int i = 0; i < list_n; i++) {
             const ListEntry le = s_list[i];
             // wave-uniform reject
-            if (le.bb.x1 < bx0 || le.bb.x0 > bx0 + 15 || le.bb.y1 < by0 || le.bb.y0 > by0 + 15) continue;
-            if (prow < le.bb.y0 || prow > le.bb.y1 || pcol + 3 < le.bb.x0 || pcol > le.bb.x1) continue;
+            if (le.bb.x1 < bx0 || le.bb.x0 > bx0 + 15 || le.bb.y1 < by0 || le.bb.y0 > by0 + BLK_H - 1) continue;
+            if (prow < le.bb.y0 || prow > le.bb.y1 || pcol + NPX - 1 < le.bb.x0 || pcol > le.bb.x1) continue;
             {
-                // the 4x1 pixel span of this lane cannot be touched if its centre is farther from the
-                // segment than half width + half diagonal of the span (2.07) + slack for the fp32 test,
+                // the NPX x 1 pixel span of this lane cannot be touched if its centre is farther from the
+                // segment than half width + half diagonal of the span + slack for the fp32 test,
                 // the 1/256 vertex rounding and the snap of axis-aligned paths (already in ax..vy)
-                float cx = (float)pcol + 2.0f - le.ax, cy = (float)prow + 0.5f - le.ay;
+                float cx = (float)pcol + 0.5f * NPX - le.ax, cy = (float)prow + 0.5f - le.ay;
                 float t = (cx * le.vx + cy * le.vy) * le.inv_len2;
                 t = fminf(fmaxf(t, 0.f), 1.f);
                 float ex = cx - t * le.vx, ey = cy - t * le.vy;
-                float lim = le.reach + 2.07f;
+                float lim = le.reach + 0.5f * sqrtf((float)(NPX * NPX + 1)) + 0.01f;
                 if (ex * ex + ey * ey > lim * lim) continue;
             }
-            int C[4] = {0, 0, 0, 0}, A[4] = {0, 0, 0, 0};
+            int C[NPX], A[NPX];
+#pragma unroll
+            for (int q = 0; q < NPX; q++) { C[q] = 0; A[q] = 0; }
             const int ns = le.nv + EXTRA_SLOTS;
             const int4 *sl = s_slots + le.slot_off;
             for (int k = 0; k < ns; k++) {
                 int4 s = sl[k];
                 if (s.y == s.w) continue;
-                side_eval<4>(s, prow, pcol, C, A);
+                side_eval<NPX>(s, prow, pcol, C, A);
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NPX; q++) {
                 int v = (C[q] << 9) - A[q];
                 int c = v >> 9;
                 if (c < 0) c = -c;
@@ -285,11 +291,16 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
 
     if (prow < H) {
         unsigned char *o = out + ((size_t)img * H + prow) * (size_t)W + pcol;
-        if (pcol + 3 < W && ((((size_t)img * H + prow) * (size_t)W + pcol) & 3) == 0) {
-            *reinterpret_cast<unsigned *>(o) = pix[0] | (pix[1] << 8) | (pix[2] << 16) | (pix[3] << 24);
+        if (NPX == 4 && pcol + 3 < W && ((((size_t)img * H + prow) * (size_t)W + pcol) & 3) == 0) {
+            unsigned v = 0;
+#pragma unroll
+            for (int q = 0; q < NPX; q++) v |= pix[q] << (8 * q);
+            *reinterpret_cast<unsigned *>(o) = v;
+        } else if (NPX == 2 && pcol + 1 < W && ((((size_t)img * H + prow) * (size_t)W + pcol) & 1) == 0) {
+            *reinterpret_cast<unsigned short *>(o) = (unsigned short)(pix[0] | (pix[NPX - 1] << 8));
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < NPX; q++)
                 if (pcol + q < W) o[q] = (unsigned char)pix[q];
         }
     }
