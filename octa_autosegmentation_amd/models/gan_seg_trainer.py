@@ -1,0 +1,108 @@
+"""Joint contrast-adaptation + segmentation step (reference models/gan_seg_model.py:12-173, config
+configs/config_gan_ves_seg.yml): generator G, PatchGAN D, segmentor S with three Adam optimisers
+(G, D: betas (0.5, 0.999); S: (0.9, 0.999)), LSGAN + identity-L1 for G, DiceBCE for S on
+bilinearly upsampled fake / identity images, pseudo-labels from thresholding S(real_B) at 0.5.
+bf16 autocast; with torch.distributed initialised each optimiser's gradients are averaged with one flat
+RCCL all-reduce (D after its backward; G and S together after theirs)."""
+import itertools
+
+import torch
+import torch.distributed as dist
+
+from .losses import get_loss_function_by_name
+from .networks import MODEL_DICT, init_weights
+
+
+def _flat_allreduce(params):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1).float() for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+class GanSegTrainer:
+    optimizer_mapping = {"optimizer_G": ["generator"], "optimizer_D": ["discriminator"], "optimizer_S": ["segmentor"]}
+
+    def __init__(self, config, device, upshape=(1216, 1216)):
+        m = config["General"]["model"]
+        self.device = torch.device(device)
+        mk = lambda d: MODEL_DICT[dict(d).pop("name")](**{k: v for k, v in d.items() if k != "name"})
+        self.generator = mk(m["model_g"]).to(self.device)
+        self.discriminator = mk(m["model_d"]).to(self.device)
+        self.segmentor = mk(m["model_s"]).to(self.device)
+        init_weights(self.generator, "kaiming", nonlinearity="relu")
+        init_weights(self.discriminator, "kaiming", nonlinearity="leaky_relu")
+        init_weights(self.segmentor, "kaiming", nonlinearity="leaky_relu")
+        self.compute_identity = m.get("compute_identity", True)
+        self.compute_identity_seg = m.get("compute_identity_seg", True)
+        self.upshape = tuple(m.get("upshape", upshape))
+        tr = config["Train"]
+        lr = tr["lr"]
+        self.optimizer_G = torch.optim.Adam(self.generator.parameters(), lr=lr, betas=(0.5, 0.999))
+        self.optimizer_D = torch.optim.Adam(self.discriminator.parameters(), lr=lr, betas=(0.5, 0.999))
+        self.optimizer_S = torch.optim.Adam(self.segmentor.parameters(), lr=lr, betas=(0.9, 0.999))
+        self.dg_loss = get_loss_function_by_name(tr.get("loss_dg", "LSGANLoss"), config)
+        self.s_loss = get_loss_function_by_name(tr.get("loss_s", "DiceBCELoss"), config)
+        self.l1 = torch.nn.L1Loss()
+        self.amp = bool(config["General"].get("amp", True)) and self.device.type == "cuda"
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            for p in itertools.chain(self.generator.parameters(), self.discriminator.parameters(), self.segmentor.parameters()):
+                dist.broadcast(p.data, src=0)
+
+    def _up(self, x):
+        return torch.nn.functional.interpolate(x, size=self.upshape, mode="bilinear")
+
+    def perform_training_step(self, mini_batch, scaler=None, post_transformations=None, device=None):
+        real_A = mini_batch["real_A"].to(self.device, non_blocking=True)
+        real_B = mini_batch["real_B"].to(self.device, non_blocking=True)
+        real_A_seg = mini_batch["real_A_seg"].to(self.device, non_blocking=True)
+        ac = lambda: torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp)
+        # ---- D step
+        self.optimizer_D.zero_grad(set_to_none=True)
+        with ac():
+            fake_B = self.generator(real_A)
+            idt_B = self.generator(real_B) if (self.compute_identity or self.compute_identity_seg) else None
+            self.discriminator.requires_grad_(True)
+            loss_D_fake = self.dg_loss(self.discriminator(fake_B.detach()).float(), False)
+            loss_D_real = self.dg_loss(self.discriminator(real_B).float(), True)
+            loss_D = 0.5 * (loss_D_fake + loss_D_real)
+        loss_D.backward()
+        _flat_allreduce(list(self.discriminator.parameters()))
+        self.optimizer_D.step()
+        # ---- G + S step
+        self.optimizer_G.zero_grad(set_to_none=True)
+        self.optimizer_S.zero_grad(set_to_none=True)
+        with ac():
+            self.discriminator.requires_grad_(False)
+            pred_fake_B = self.discriminator(fake_B)
+            real_B_seg = self.segmentor(self._up(real_B))
+            idt_B_seg = self.segmentor(self._up(idt_B)) if self.compute_identity_seg else None
+            fake_B_seg = self.segmentor(self._up(fake_B))
+            pseudo = (real_B_seg.detach() > 0.5).float()
+            loss_G = self.dg_loss(pred_fake_B.float(), True)
+            loss_G_idt = self.l1(idt_B.float(), real_B.float()) if self.compute_identity else torch.zeros((), device=self.device)
+            loss_G = loss_G + loss_G_idt
+            loss_S = self.s_loss(fake_B_seg.float(), real_A_seg.float())
+            if self.compute_identity_seg:
+                loss_S_idt = self.s_loss(idt_B_seg.float(), pseudo)
+                loss_SS = 0.5 * (loss_S + loss_S_idt)
+            else:
+                loss_S_idt = torch.zeros((), device=self.device)
+                loss_SS = loss_S
+            loss_GS = loss_G + loss_SS
+        loss_GS.backward()
+        _flat_allreduce(list(itertools.chain(self.generator.parameters(), self.segmentor.parameters())))
+        self.optimizer_G.step()
+        self.optimizer_S.step()
+        outputs = {"prediction": fake_B_seg[0:1, 0:1].detach(), "label": real_A_seg[0:1, 0:1], "fake_B": fake_B[0:1, 0:1].detach(),
+                   "idt_B": None if idt_B is None else idt_B[0:1, 0:1].detach(), "real_B_seg": pseudo}
+        losses = {"S": loss_S, "D_fake": loss_D_fake, "D_real": loss_D_real, "G": loss_G, "G_idt": loss_G_idt, "S_idt": loss_S_idt}
+        return outputs, losses

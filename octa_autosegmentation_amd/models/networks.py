@@ -144,4 +144,114 @@ def init_weights(net: nn.Module, init_type='normal', init_gain=0.02, debug=False
     net.apply(init_func)
 
 
-MODEL_DICT = {"DynUNet": DynUNet}
+# ---------------------------------------------------------------------------------------------------
+# Contrast-adaptation GAN (reference models/networks.py:186-289 blur filters / Down-/Upsample, :291-443
+# ResnetBlock / ResnetGenerator, :445-506 NLayerDiscriminator and the resnetGenerator9 / patchGAN70x70
+# factories). Restated so that state_dict keys (`model.<i>.weight`, blur buffers `model.<i>.filt`) and
+# parameter counts (11,365,633 / 2,762,689) match reference checkpoints.
+
+_BINOMIAL = {1: [1.], 2: [1., 1.], 3: [1., 2., 1.], 4: [1., 3., 3., 1.], 5: [1., 4., 6., 4., 1.],
+             6: [1., 5., 10., 10., 5., 1.], 7: [1., 6., 15., 20., 15., 6., 1.]}
+
+
+def _blur_kernel(size):
+    a = torch.tensor(_BINOMIAL[size])
+    k = a[:, None] * a[None, :]
+    return k / k.sum()
+
+
+class Downsample(nn.Module):
+    """Anti-aliased stride-2 subsampling: reflect pad, depth-wise binomial blur, stride."""
+
+    def __init__(self, channels, filt_size=3, stride=2):
+        super().__init__()
+        lo, hi = int((filt_size - 1) / 2), int(-(-(filt_size - 1) // 2))
+        self.pad = nn.ReflectionPad2d([lo, hi, lo, hi])
+        self.stride, self.channels = stride, channels
+        self.register_buffer("filt", _blur_kernel(filt_size)[None, None].repeat(channels, 1, 1, 1))
+
+    def forward(self, x):
+        return nn.functional.conv2d(self.pad(x), self.filt, stride=self.stride, groups=x.shape[1])
+
+
+class Upsample(nn.Module):
+    """Anti-aliased x2 upsampling: replicate pad, depth-wise transposed binomial blur (x stride^2), crop."""
+
+    def __init__(self, channels, filt_size=4, stride=2):
+        super().__init__()
+        self.odd = filt_size % 2 == 1
+        self.pad_size = int((filt_size - 1) / 2)
+        self.stride = stride
+        self.pad = nn.ReplicationPad2d([1, 1, 1, 1])
+        self.register_buffer("filt", (_blur_kernel(filt_size) * stride ** 2)[None, None].repeat(channels, 1, 1, 1))
+
+    def forward(self, x):
+        y = nn.functional.conv_transpose2d(self.pad(x), self.filt, stride=self.stride, padding=1 + self.pad_size,
+                                           groups=x.shape[1])[:, :, 1:, 1:]
+        return y if self.odd else y[:, :, :-1, :-1]
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, dim, use_bias=True):
+        super().__init__()
+        inorm = lambda: nn.InstanceNorm2d(dim, affine=False, track_running_stats=False)
+        self.conv_block = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3, bias=use_bias), inorm(), nn.ReLU(True),
+                                        nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3, bias=use_bias), inorm())
+
+    def forward(self, x):
+        return x + self.conv_block(x)
+
+
+class ResnetGenerator(nn.Module):
+    """7x7 stem, two blur-downsampling stages, n_blocks residual blocks at 4*ngf, two blur-upsampling stages,
+    7x7 head + sigmoid; instance norm without affine, hence biased convolutions."""
+
+    def __init__(self, input_nc=1, output_nc=1, ngf=64, n_blocks=9):
+        super().__init__()
+        inorm = lambda c: nn.InstanceNorm2d(c, affine=False, track_running_stats=False)
+        m = [nn.ReflectionPad2d(3), nn.Conv2d(input_nc, ngf, 7, bias=True), inorm(ngf), nn.ReLU(True)]
+        for i in range(2):
+            c = ngf * 2 ** i
+            m += [nn.Conv2d(c, 2 * c, 3, padding=1, bias=True), inorm(2 * c), nn.ReLU(True), Downsample(2 * c)]
+        m += [ResnetBlock(4 * ngf) for _ in range(n_blocks)]
+        for i in range(2):
+            c = ngf * 2 ** (2 - i)
+            m += [Upsample(c), nn.Conv2d(c, c // 2, 3, padding=1, bias=True), inorm(c // 2), nn.ReLU(True)]
+        m += [nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, 7), nn.Sigmoid()]
+        self.model = nn.Sequential(*m)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class NLayerDiscriminator(nn.Module):
+    """PatchGAN with 4x4 stride-1 convolutions followed by blur-downsampling (anti-aliased variant)."""
+
+    def __init__(self, input_nc=1, ndf=64, n_layers=3):
+        super().__init__()
+        inorm = lambda c: nn.InstanceNorm2d(c, affine=False, track_running_stats=False)
+        seq = [nn.Conv2d(input_nc, ndf, 4, 1, 1), nn.LeakyReLU(0.2, True), Downsample(ndf)]
+        prev = 1
+        for n in range(1, n_layers):
+            mult = min(2 ** n, 8)
+            seq += [nn.Conv2d(ndf * prev, ndf * mult, 4, 1, 1, bias=True), inorm(ndf * mult), nn.LeakyReLU(0.2, True),
+                    Downsample(ndf * mult)]
+            prev = mult
+        mult = min(2 ** n_layers, 8)
+        seq += [nn.Conv2d(ndf * prev, ndf * mult, 4, 1, 1, bias=True), inorm(ndf * mult), nn.LeakyReLU(0.2, True),
+                nn.Conv2d(ndf * mult, 1, 4, 1, 1)]
+        self.model = nn.Sequential(*seq)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+def resnetGenerator9():
+    return ResnetGenerator(1, 1, ngf=64, n_blocks=9)
+
+
+def patchGAN70x70():
+    return NLayerDiscriminator(1, ndf=64, n_layers=3)
+
+
+MODEL_DICT = {"DynUNet": DynUNet, "resnetGenerator9": resnetGenerator9, "patchGAN70x70": patchGAN70x70}

@@ -78,3 +78,60 @@ def test_two_rank_data_parallel_step_equals_single_process_batch(tmp_path):
         if k.startswith("skip_layers"):
             continue
         assert torch.allclose(got[k], v, atol=1e-6), k
+
+
+def test_gan_networks_shapes_params_and_keys():
+    g, d = networks.resnetGenerator9(), networks.patchGAN70x70()
+    assert sum(p.numel() for p in g.parameters()) == 11_365_633
+    assert sum(p.numel() for p in d.parameters()) == 2_762_689
+    x = torch.rand(1, 1, 64, 64)
+    y = g(x)
+    assert y.shape == x.shape and float(y.min()) >= 0 and float(y.max()) <= 1
+    assert networks.patchGAN70x70()(torch.rand(1, 1, 304, 304)).shape == (1, 1, 36, 36)
+    sd = g.state_dict()
+    for k in ("model.1.weight", "model.1.bias", "model.7.filt", "model.12.conv_block.1.weight", "model.20.conv_block.5.bias",
+              "model.21.filt", "model.22.weight", "model.30.weight"):
+        assert k in sd, k
+    assert "model.2.filt" in d.state_dict() and "model.11.weight" in d.state_dict()
+    # blur filters: 3-tap down (sum 1), 4-tap up (sum stride^2)
+    assert abs(float(sd["model.7.filt"][0].sum()) - 1) < 1e-6 and abs(float(sd["model.21.filt"][0].sum()) - 4) < 1e-6
+
+
+def test_gan_seg_training_step_runs_on_cpu():
+    from octa_autosegmentation_amd.models.gan_seg_trainer import GanSegTrainer
+    cfg = {"General": {"amp": False, "model": {"name": "GanSegModel", "model_g": {"name": "resnetGenerator9"},
+                                                 "model_d": {"name": "patchGAN70x70"},
+                                                 "model_s": dict(CFG["General"]["model"]), "upshape": (64, 64)}},
+           "Train": {"lr": 2e-4, "loss_dg": "LSGANLoss", "loss_s": "DiceBCELoss"}}
+    torch.manual_seed(0)
+    tr = GanSegTrainer(cfg, "cpu")
+    batch = {"real_A": torch.rand(1, 1, 32, 32), "real_B": torch.rand(1, 1, 32, 32), "real_A_seg": (torch.rand(1, 1, 64, 64) > 0.7).float()}
+    w0 = tr.segmentor.output_block.conv.conv.weight.clone()
+    out, losses = tr.perform_training_step(batch)
+    assert set(losses) == {"S", "D_fake", "D_real", "G", "G_idt", "S_idt"} and all(torch.isfinite(v) for v in losses.values())
+    assert not torch.equal(w0, tr.segmentor.output_block.conv.conv.weight)
+    assert out["prediction"].shape == (1, 1, 64, 64)
+
+
+def test_noise_transforms_follow_reference_formulas():
+    import numpy as np
+    from octa_autosegmentation_amd.data import data_transforms as T
+    torch.manual_seed(3); np.random.seed(3)
+    img = torch.rand(1, 40, 40)
+    out = T.SpeckleBrightnesd(["image"])({"image": img})["image"]
+    torch.manual_seed(3)
+    c = torch.rand((1, 1, 9, 9)) * 0.5 + 0.5
+    C = torch.nn.functional.interpolate(c, size=(40, 40), mode="bilinear").squeeze(0)
+    R = C - (torch.rand_like(C) * (1 - C))
+    want = img * R; want = want / want.max(); want = want - want.min()
+    assert torch.equal(out, want)
+    bg = torch.rand(1, 40, 40)
+    np.random.seed(5)
+    o2 = T.AddRandomBackgroundNoised(["image"])({"image": img, "background": bg})
+    np.random.seed(5)
+    assert "background" not in o2
+    assert torch.allclose(o2["image"], torch.maximum(img, bg * torch.from_numpy(np.random.uniform(0, 1, (1, 40, 40))).float()))
+    g = networks.resnetGenerator9()
+    o3 = T.ImageToImageTranslationd(keys=["image"], model=g, device="cpu")({"image": img})["image"]
+    with torch.no_grad():
+        assert torch.equal(o3, g.eval()(img.unsqueeze(0)).squeeze(0))
