@@ -116,8 +116,8 @@ def test_gan_seg_training_step_runs_on_cpu():
 def test_noise_transforms_follow_reference_formulas():
     import numpy as np
     from octa_autosegmentation_amd.data import data_transforms as T
-    torch.manual_seed(3); np.random.seed(3)
     img = torch.rand(1, 40, 40)
+    torch.manual_seed(3)
     out = T.SpeckleBrightnesd(["image"])({"image": img})["image"]
     torch.manual_seed(3)
     c = torch.rand((1, 1, 9, 9)) * 0.5 + 0.5
