@@ -100,12 +100,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")
-    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        # one process per GPU; "nccl" is RCCL on ROCm. The device is bound first so that the communicator
+        # and its barrier live on this rank's GPU.
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from concurrent.futures import ThreadPoolExecutor

@@ -107,6 +107,19 @@ int octa_edges_read_back(octa_ctx *ctx, const double *d_edges, double *d_out, in
  */
 int octa_max_u8(octa_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, uint8_t *d_out, size_t n, void *stream);
 
+/* ---- N8 (part): fused InstanceNorm2d(affine) + LeakyReLU ---------------------
+ * Replaces the norm1+lrelu / norm2+lrelu pairs of every UnetBasicBlock of DynUNet (MONAI, imported at
+ * models/networks.py:6; configs/config_ves_seg-S.yml:6-13) in the training step of
+ * models/base_model_abc.py:152-167. NCHW contiguous activations, dtype 0 = float32, 1 = bfloat16;
+ * d_w / d_b: per-channel affine (float32, may be NULL); statistics in float32 [B*C].
+ * Forward: y = lrelu((x - mean) * rstd * w + b). Backward: dx, and dw/db accumulated over the batch.
+ */
+int octa_instnorm_lrelu_fwd(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b, float *d_mean,
+                            float *d_rstd, int B, int C, int64_t hw, int dtype, float slope, float eps, void *stream);
+int octa_instnorm_lrelu_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, const float *d_w, const float *d_b,
+                            const float *d_mean, const float *d_rstd, void *d_dx, float *d_dw, float *d_db, int B, int C,
+                            int64_t hw, int dtype, float slope, void *stream);
+
 /* ---- N1-N4: space-colonisation vessel-graph simulator --------------------
  * Replaces, for B independent samples advanced in lock-step on the GPU:
  *   vessel_graph_generation/greenhouse.py:57-137 (Greenhouse.develop_forest) with

@@ -30,6 +30,8 @@ SIGNATURES = {
     "octa_bif_native_init": (c_int, [ctypes.c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "octa_bif_native": (None, [c_int, c_void_p, c_void_p, c_void_p]),
     "octa_bif_native_counts": (c_int, [c_void_p]),
+    "octa_instnorm_lrelu_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, ctypes.c_int64, c_int, ctypes.c_float, ctypes.c_float, c_void_p]),
+    "octa_instnorm_lrelu_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, ctypes.c_int64, c_int, ctypes.c_float, c_void_p]),
     "octa_sim_create": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
     "octa_sim_destroy": (None, [c_void_p]),
     "octa_sim_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,266 @@
+// norm.hip -- fused InstanceNorm2d(affine) + LeakyReLU, forward and backward, for NCHW activations in
+// bf16 or fp32 (statistics and affine parameters in fp32). Reference: the norm1/lrelu and norm2/lrelu pairs
+// of MONAI's UnetBasicBlock that DynUNet is made of (models/networks.py:6 imports it; restated in
+// octa_autosegmentation_amd/models/networks.py). torch runs this as batch-norm + a separate activation
+// pass (and, under autocast, extra casts); at 1216x1216 every pass over a 32-channel map moves 95 MB, so
+// the step is HBM-bound. Here: forward = 2 reads + 1 write of the plane, backward =
+// 2 x (x, dy) reads + 1 write, nothing else.
+//
+// A (b, c) plane is split over `splits` workgroups so that >= ~2 workgroups per CU are in flight even for
+// the 128-plane top level; kernel 1 leaves per-split partial sums, kernel 2 folds them (a few floats) and
+// streams the plane with 16-byte accesses.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+template <class T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    __device__ static void load(const float *p, float (&v)[8]) { float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    __device__ static void store(float *p, const float (&v)[8]) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    __device__ static float ld1(const float *p) { return *p; }
+    __device__ static void st1(float *p, float v) { *p = v; }
+};
+template <> struct Vec<unsigned short> {  // bf16 bits
+    static constexpr int N = 8;
+    __device__ static float up(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+    __device__ static unsigned short down(float f) {  // round to nearest even, NaN preserved
+        unsigned u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    }
+    __device__ static void load(const unsigned short *p, float (&v)[8]) {
+        uint4 t = *reinterpret_cast<const uint4 *>(p);
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+    }
+    __device__ static void store(unsigned short *p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = (unsigned)down(v[2 * k]) | ((unsigned)down(v[2 * k + 1]) << 16);
+        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __device__ static float ld1(const unsigned short *p) { return up(*p); }
+    __device__ static void st1(unsigned short *p, float v) { *p = down(v); }
+};
+
+__device__ __forceinline__ void block_reduce2(double &a, double &b, double *sh) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) { sh[2 * wv] = a; sh[2 * wv + 1] = b; }
+    __syncthreads();
+    a = 0; b = 0;
+    for (int k = 0; k < NT / 64; k++) { a += sh[2 * k]; b += sh[2 * k + 1]; }
+}
+
+// chunk [e0, e1) of plane p handled by split s
+__device__ __forceinline__ void chunk_of(long hw, int splits, int s, int vecn, long &e0, long &e1) {
+    long per = ((hw + splits - 1) / splits + vecn - 1) / vecn * vecn;
+    e0 = (long)s * per;
+    e1 = e0 + per < hw ? e0 + per : hw;
+    if (e0 > hw) e0 = hw;
+}
+
+template <class T>
+__global__ void __launch_bounds__(NT) in_fwd_stats(const T *__restrict__ x, long hw, int splits, double *__restrict__ partial) {
+    __shared__ double sh[2 * NT / 64];
+    const long plane = blockIdx.y;
+    const int s = blockIdx.x;
+    long e0, e1;
+    chunk_of(hw, splits, s, Vec<T>::N, e0, e1);
+    const T *px = x + plane * hw;
+    float sum = 0.f, sq = 0.f;
+    const bool vec = (hw % Vec<T>::N == 0) && ((reinterpret_cast<size_t>(px) & 15) == 0);
+    if (vec) {
+        for (long i = e0 + (long)threadIdx.x * Vec<T>::N; i + Vec<T>::N <= e1; i += (long)NT * Vec<T>::N) {
+            float v[8];
+            Vec<T>::load(px + i, v);
+#pragma unroll
+            for (int k = 0; k < Vec<T>::N; k++) { sum += v[k]; sq += v[k] * v[k]; }
+        }
+    } else {
+        for (long i = e0 + threadIdx.x; i < e1; i += NT) { float v = Vec<T>::ld1(px + i); sum += v; sq += v * v; }
+    }
+    double a = sum, b = sq;
+    block_reduce2(a, b, sh);
+    if (threadIdx.x == 0) { partial[(plane * splits + s) * 2] = a; partial[(plane * splits + s) * 2 + 1] = b; }
+}
+
+template <class T>
+__global__ void __launch_bounds__(NT) in_fwd_apply(const T *__restrict__ x, T *__restrict__ y, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, long hw, int C, int splits,
+                                                   const double *__restrict__ partial, float slope, float eps,
+                                                   float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+    const long plane = blockIdx.y;
+    const int s = blockIdx.x, c = (int)(plane % C);
+    double a = 0, b = 0;
+    for (int k = 0; k < splits; k++) { a += partial[(plane * splits + k) * 2]; b += partial[(plane * splits + k) * 2 + 1]; }
+    const double mean_d = a / (double)hw;
+    double var = b / (double)hw - mean_d * mean_d;
+    if (var < 0) var = 0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (s == 0 && threadIdx.x == 0) { mean_out[plane] = mean; rstd_out[plane] = rstd; }
+    const float g = w ? w[c] * rstd : rstd, sh = (bias ? bias[c] : 0.f) - mean * g;
+    long e0, e1;
+    chunk_of(hw, splits, s, Vec<T>::N, e0, e1);
+    const T *px = x + plane * hw;
+    T *py = y + plane * hw;
+    const bool vec = (hw % Vec<T>::N == 0) && ((reinterpret_cast<size_t>(px) & 15) == 0) && ((reinterpret_cast<size_t>(py) & 15) == 0);
+    if (vec) {
+        for (long i = e0 + (long)threadIdx.x * Vec<T>::N; i + Vec<T>::N <= e1; i += (long)NT * Vec<T>::N) {
+            float v[8];
+            Vec<T>::load(px + i, v);
+#pragma unroll
+            for (int k = 0; k < Vec<T>::N; k++) { float z = v[k] * g + sh; v[k] = z > 0.f ? z : z * slope; }
+            Vec<T>::store(py + i, v);
+        }
+    } else {
+        for (long i = e0 + threadIdx.x; i < e1; i += NT) { float z = Vec<T>::ld1(px + i) * g + sh; Vec<T>::st1(py + i, z > 0.f ? z : z * slope); }
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(NT) in_bwd_stats(const T *__restrict__ x, const T *__restrict__ dy, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, const float *__restrict__ mean,
+                                                   const float *__restrict__ rstd, long hw, int C, int splits, float slope,
+                                                   double *__restrict__ partial) {
+    __shared__ double sh[2 * NT / 64];
+    const long plane = blockIdx.y;
+    const int s = blockIdx.x, c = (int)(plane % C);
+    const float mu = mean[plane], rs = rstd[plane], wc = w ? w[c] : 1.f, bc = bias ? bias[c] : 0.f;
+    long e0, e1;
+    chunk_of(hw, splits, s, Vec<T>::N, e0, e1);
+    const T *px = x + plane * hw, *pd = dy + plane * hw;
+    float sg = 0.f, sgx = 0.f;
+    const bool vec = (hw % Vec<T>::N == 0) && ((reinterpret_cast<size_t>(px) & 15) == 0) && ((reinterpret_cast<size_t>(pd) & 15) == 0);
+    if (vec) {
+        for (long i = e0 + (long)threadIdx.x * Vec<T>::N; i + Vec<T>::N <= e1; i += (long)NT * Vec<T>::N) {
+            float v[8], d[8];
+            Vec<T>::load(px + i, v);
+            Vec<T>::load(pd + i, d);
+#pragma unroll
+            for (int k = 0; k < Vec<T>::N; k++) {
+                float xh = (v[k] - mu) * rs;
+                float g = (xh * wc + bc) > 0.f ? d[k] : d[k] * slope;
+                sg += g; sgx += g * xh;
+            }
+        }
+    } else {
+        for (long i = e0 + threadIdx.x; i < e1; i += NT) {
+            float xh = (Vec<T>::ld1(px + i) - mu) * rs, d = Vec<T>::ld1(pd + i);
+            float g = (xh * wc + bc) > 0.f ? d : d * slope;
+            sg += g; sgx += g * xh;
+        }
+    }
+    double a = sg, b = sgx;
+    block_reduce2(a, b, sh);
+    if (threadIdx.x == 0) { partial[(plane * splits + s) * 2] = a; partial[(plane * splits + s) * 2 + 1] = b; }
+}
+
+template <class T>
+__global__ void __launch_bounds__(NT) in_bwd_apply(const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ dx,
+                                                   const float *__restrict__ w, const float *__restrict__ bias,
+                                                   const float *__restrict__ mean, const float *__restrict__ rstd, long hw, int C,
+                                                   int splits, float slope, const double *__restrict__ partial,
+                                                   float *__restrict__ dw, float *__restrict__ db) {
+    const long plane = blockIdx.y;
+    const int s = blockIdx.x, c = (int)(plane % C);
+    double a = 0, b = 0;
+    for (int k = 0; k < splits; k++) { a += partial[(plane * splits + k) * 2]; b += partial[(plane * splits + k) * 2 + 1]; }
+    if (s == 0 && threadIdx.x == 0) {
+        if (db) atomicAdd(&db[c], (float)a);
+        if (dw) atomicAdd(&dw[c], (float)b);
+    }
+    const float mu = mean[plane], rs = rstd[plane], wc = w ? w[c] : 1.f, bc = bias ? bias[c] : 0.f;
+    const float mg = (float)(a / (double)hw), mgx = (float)(b / (double)hw), k0 = wc * rs;
+    long e0, e1;
+    chunk_of(hw, splits, s, Vec<T>::N, e0, e1);
+    const T *px = x + plane * hw, *pd = dy + plane * hw;
+    T *po = dx + plane * hw;
+    const bool vec = (hw % Vec<T>::N == 0) && ((reinterpret_cast<size_t>(px) & 15) == 0) && ((reinterpret_cast<size_t>(pd) & 15) == 0) &&
+                     ((reinterpret_cast<size_t>(po) & 15) == 0);
+    if (vec) {
+        for (long i = e0 + (long)threadIdx.x * Vec<T>::N; i + Vec<T>::N <= e1; i += (long)NT * Vec<T>::N) {
+            float v[8], d[8];
+            Vec<T>::load(px + i, v);
+            Vec<T>::load(pd + i, d);
+#pragma unroll
+            for (int k = 0; k < Vec<T>::N; k++) {
+                float xh = (v[k] - mu) * rs;
+                float g = (xh * wc + bc) > 0.f ? d[k] : d[k] * slope;
+                v[k] = k0 * (g - mg - xh * mgx);
+            }
+            Vec<T>::store(po + i, v);
+        }
+    } else {
+        for (long i = e0 + threadIdx.x; i < e1; i += NT) {
+            float xh = (Vec<T>::ld1(px + i) - mu) * rs, d = Vec<T>::ld1(pd + i);
+            float g = (xh * wc + bc) > 0.f ? d : d * slope;
+            Vec<T>::st1(po + i, k0 * (g - mg - xh * mgx));
+        }
+    }
+}
+
+int pick_splits(const octa_ctx *ctx, long planes, long hw) {
+    long want = 2L * ctx->num_cus;
+    int s = (int)((want + planes - 1) / planes);
+    if (s < 1) s = 1;
+    long max_by_size = hw / (NT * 8) > 0 ? hw / (NT * 8) : 1;   // at least one vector per thread
+    if (s > max_by_size) s = (int)max_by_size;
+    if (s > 64) s = 64;
+    return s;
+}
+
+}  // namespace
+
+extern "C" int octa_instnorm_lrelu_fwd(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b, float *d_mean,
+                                       float *d_rstd, int B, int C, int64_t hw, int dtype, float slope, float eps, void *stream_) {
+    if (!ctx || !d_x || !d_y || !d_mean || !d_rstd || B <= 0 || C <= 0 || hw <= 0) { octa::set_error("octa_instnorm_lrelu_fwd: bad arguments"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const long planes = (long)B * C;
+    if (planes > 65535L * 16) { octa::set_error("octa_instnorm_lrelu_fwd: too many planes"); return -2; }
+    const int splits = pick_splits(ctx, planes, hw);
+    if (ctx->r_tile_total.reserve(sizeof(double) * 2 * planes * splits)) return -1;
+    double *partial = ctx->r_tile_total.as<double>();
+    dim3 grid((unsigned)splits, (unsigned)planes);
+    if (dtype == 0) {
+        hipLaunchKernelGGL(in_fwd_stats<float>, grid, dim3(NT), 0, stream, (const float *)d_x, (long)hw, splits, partial);
+        hipLaunchKernelGGL(in_fwd_apply<float>, grid, dim3(NT), 0, stream, (const float *)d_x, (float *)d_y, d_w, d_b, (long)hw, C, splits, partial, slope, eps, d_mean, d_rstd);
+    } else if (dtype == 1) {
+        hipLaunchKernelGGL(in_fwd_stats<unsigned short>, grid, dim3(NT), 0, stream, (const unsigned short *)d_x, (long)hw, splits, partial);
+        hipLaunchKernelGGL(in_fwd_apply<unsigned short>, grid, dim3(NT), 0, stream, (const unsigned short *)d_x, (unsigned short *)d_y, d_w, d_b, (long)hw, C, splits, partial, slope, eps, d_mean, d_rstd);
+    } else { octa::set_error("octa_instnorm_lrelu_fwd: dtype must be 0 (f32) or 1 (bf16)"); return -2; }
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_instnorm_lrelu_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, const float *d_w, const float *d_b,
+                                       const float *d_mean, const float *d_rstd, void *d_dx, float *d_dw, float *d_db, int B, int C,
+                                       int64_t hw, int dtype, float slope, void *stream_) {
+    if (!ctx || !d_x || !d_dy || !d_dx || !d_mean || !d_rstd || B <= 0 || C <= 0 || hw <= 0) { octa::set_error("octa_instnorm_lrelu_bwd: bad arguments"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const long planes = (long)B * C;
+    const int splits = pick_splits(ctx, planes, hw);
+    if (ctx->r_tile_total.reserve(sizeof(double) * 2 * planes * splits)) return -1;
+    double *partial = ctx->r_tile_total.as<double>();
+    dim3 grid((unsigned)splits, (unsigned)planes);
+    if (d_dw) OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
+    if (d_db) OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float) * C, stream));
+    if (dtype == 0) {
+        hipLaunchKernelGGL(in_bwd_stats<float>, grid, dim3(NT), 0, stream, (const float *)d_x, (const float *)d_dy, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, partial);
+        hipLaunchKernelGGL(in_bwd_apply<float>, grid, dim3(NT), 0, stream, (const float *)d_x, (const float *)d_dy, (float *)d_dx, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, partial, d_dw, d_db);
+    } else if (dtype == 1) {
+        hipLaunchKernelGGL(in_bwd_stats<unsigned short>, grid, dim3(NT), 0, stream, (const unsigned short *)d_x, (const unsigned short *)d_dy, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, partial);
+        hipLaunchKernelGGL(in_bwd_apply<unsigned short>, grid, dim3(NT), 0, stream, (const unsigned short *)d_x, (const unsigned short *)d_dy, (unsigned short *)d_dx, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, partial, d_dw, d_db);
+    } else { octa::set_error("octa_instnorm_lrelu_bwd: dtype must be 0 (f32) or 1 (bf16)"); return -2; }
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -17,6 +17,11 @@ import torch
 import torch.nn as nn
 
 
+# CUDA tensors go through the fused HIP InstanceNorm+LeakyReLU kernels (csrc/norm.hip); set to False to run the
+# plain torch modules (used by the parity tests as the reference).
+USE_FUSED_NORM = True
+
+
 class _Conv(nn.Module):
     """MONAI `Convolution(conv_only=True)`: a container whose only child is `conv`."""
 
@@ -42,9 +47,15 @@ class UnetBasicBlock(nn.Module):
         self.norm1 = nn.InstanceNorm2d(cout, affine=True)
         self.norm2 = nn.InstanceNorm2d(cout, affine=True)
 
+    def _norm_act(self, norm, x):
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and USE_FUSED_NORM:
+            from .fused_ops import instance_norm_leaky_relu
+            return instance_norm_leaky_relu(x, norm.weight, norm.bias, self.lrelu.negative_slope, norm.eps)
+        return self.lrelu(norm(x))
+
     def forward(self, x):
-        x = self.lrelu(self.norm1(self.conv1(x)))
-        return self.lrelu(self.norm2(self.conv2(x)))
+        x = self._norm_act(self.norm1, self.conv1(x))
+        return self._norm_act(self.norm2, self.conv2(x))
 
 
 class UnetUpBlock(nn.Module):

@@ -14,7 +14,7 @@ def test_dynunet_logits_match_cpu_fp32():
     x = torch.rand(2, 1, 96, 96)
     with torch.no_grad():
         ref = net(x)
-        got = net.cuda()(x.cuda()).cpu()
+        got = net.cuda()(x.cuda()).cpu()          # fused HIP InstanceNorm+LeakyReLU path
     assert torch.allclose(got, ref, atol=1e-4, rtol=1e-4), float((got - ref).abs().max())
 
 
@@ -32,3 +32,26 @@ def test_training_step_bf16_runs_and_learns():
         assert v == v
         first = v if first is None else first
     assert v < first
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_instnorm_lrelu_matches_torch(dtype):
+    from octa_autosegmentation_amd.models.fused_ops import instance_norm_leaky_relu
+    torch.manual_seed(0)
+    for shape in [(2, 5, 37, 41), (3, 32, 64, 64), (1, 8, 304, 304)]:
+        x = (torch.randn(*shape, device="cuda") * 2 + 0.7).to(dtype).requires_grad_(True)
+        w = torch.randn(shape[1], device="cuda", requires_grad=True)
+        b = torch.randn(shape[1], device="cuda", requires_grad=True)
+        dy = torch.randn(*shape, device="cuda").to(dtype)
+        y = instance_norm_leaky_relu(x, w, b, 0.01, 1e-5)
+        y.backward(dy)
+        gx, gw, gb = x.grad.clone(), w.grad.clone(), b.grad.clone()
+        # float64 torch reference (MIOpen's own fp32 instance-norm backward is off by up to 6e-3 on odd plane sizes)
+        x2 = x.detach().double().requires_grad_(True); w2 = w.detach().double().requires_grad_(True); b2 = b.detach().double().requires_grad_(True)
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(x2, weight=w2, bias=b2, eps=1e-5), 0.01)
+        ref.backward(dy.double())
+        tol = 1e-4 if dtype == torch.float32 else 2e-2
+        assert torch.allclose(y.double(), ref, atol=tol, rtol=tol), (shape, float((y.double() - ref).abs().max()))
+        assert torch.allclose(gx.double(), x2.grad, atol=tol, rtol=tol), (shape, float((gx.double() - x2.grad).abs().max()))
+        assert torch.allclose(gw.double(), w2.grad, atol=tol * 50, rtol=tol), float((gw.double() - w2.grad).abs().max())
+        assert torch.allclose(gb.double(), b2.grad, atol=tol * 50, rtol=tol)
