@@ -76,19 +76,21 @@ def check(rc, what):
 
 
 def ctx(device_index=None):
-    """Per-process context for one GPU (created on first use)."""
+    """Context (grow-only device scratch) for one GPU, one per calling THREAD: an octa_ctx must not be used from
+    two threads at once (include/octa_hip.h), and pipelines keep several steps in flight from a thread pool."""
     import torch
     if not torch.cuda.is_available():
         raise OctaHipError("no ROCm GPU visible to torch; the HIP path cannot run (no CPU fallback)")
     if device_index is None:
         device_index = torch.cuda.current_device()
+    key = (int(device_index), threading.get_ident())
     with _lock:
-        h = _ctxs.get(device_index)
+        h = _ctxs.get(key)
     if h is None:
         out = c_void_p()
         check(lib().octa_ctx_create(int(device_index), ctypes.byref(out)), "octa_ctx_create")
         with _lock:
-            _ctxs[device_index] = out
+            _ctxs[key] = out
         h = out
     return h
 

@@ -48,3 +48,46 @@ def test_device_read_back_matches_host_emulation(hip_lib_built):
     got = graph_io.edges_as_read_back_device(torch.from_numpy(e).cuda()).cpu().numpy()
     want = graph_io.edges_as_read_back(e)
     assert (got == want).all(), np.nonzero((got != want).any(axis=1))[0][:10]
+
+
+def test_three_steps_in_flight_are_independent(hip_lib_built):
+    """bench.py keeps several steps in flight from a thread pool: each thread must get its own scratch context
+    and stream, and every image / label must still be the oracle's."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from octa_autosegmentation_amd import graph_io, pipeline
+    from oracle import octa_oracle, sim_oracle
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_golden.npz"))
+    cfg = yaml.safe_load(str(g["config_yaml"]))
+    cfg["Greenhouse"]["modes"][0]["I"] = 14
+    cfg["Greenhouse"]["modes"][1]["I"] = 8
+    B, n_fly = 4, 3
+    gens = [pipeline.TripleGenerator(cfg, B) for _ in range(n_fly)]
+    streams = [torch.cuda.Stream() for _ in range(n_fly)]
+    dev = torch.cuda.current_device()
+
+    def work(slot):
+        torch.cuda.set_device(dev)
+        outs = []
+        with torch.cuda.stream(streams[slot]):
+            for rep in range(3):
+                seeds = np.arange(B) + 10 * slot + 100 * rep
+                out = gens[slot].generate(seeds)
+                streams[slot].synchronize()
+                outs.append((seeds, out["image"].cpu().numpy(), out["label"].cpu().numpy(), out["result"]))
+        return outs
+
+    with ThreadPoolExecutor(n_fly) as ex:
+        results = list(ex.map(work, range(n_fly)))
+    for outs in results:
+        for seeds, image, label, res in outs[-1:]:
+            for k, s in enumerate(seeds):
+                e, info = sim_oracle.simulate(cfg, int(s))
+                na = info["n_art_edges"]
+                assert graph_io.edges_to_csv_text(res.sample_edges(k)) == sim_oracle.edges_to_csv_text(e)
+                img = np.maximum(octa_oracle.rasterize(e[:na], [304, 304]), octa_oracle.rasterize(e[na:], [304, 304]))
+                assert (image[k] == img).all()
+                grey = octa_oracle.rasterize(graph_io.edges_as_read_back(e), [1216, 1216])
+                assert (label[k] == octa_oracle.fs_dither(grey)).all()
+    for gen in gens:
+        gen.close()
