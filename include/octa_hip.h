@@ -200,6 +200,12 @@ int octa_sim_timing(octa_sim *sim, double *h_out8);
 int octa_sim_fields(octa_sim *sim, int sample, double *h_oxy, int64_t cap_oxy, int64_t *n_oxy, double *h_co2,
                     int64_t cap_co2, int64_t *n_co2);
 
+/* Known-answer hook for the device restatement of scipy.spatial.cKDTree's build order (the order
+ * `query_ball_point` reports neighbours in, greenhouse.py:101-107): host points [n][3] (n <= 13312),
+ * optional host flags need[n] (NULL = every rank is read) -> host tree.indices as int32[n]. With `need`
+ * only the relative order of flagged points is defined. */
+int octa_sim_kat_kd_order(octa_ctx *ctx, const double *h_pts, int64_t n, const uint8_t *h_need, int32_t *h_indices);
+
 #ifdef __cplusplus
 }
 #endif

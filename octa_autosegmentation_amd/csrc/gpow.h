@@ -32,7 +32,8 @@ OCTA_HD inline uint64_t asu64(double f) { uint64_t u; memcpy(&u, &f, 8); return 
 OCTA_HD inline double asf64(uint64_t u) { double f; memcpy(&f, &u, 8); return f; }
 OCTA_HD inline double fma_(double a, double b, double c) { return ::fma(a, b, c); }
 
-OCTA_HD inline double gpow(double x, double y) {
+// log_tab / exp_tab: LOG_TAB / EXP_TAB or copies of them (the ordered pass keeps copies in LDS)
+OCTA_HD inline double gpow_t(double x, double y, const double *log_tab, const uint64_t *exp_tab) {
     const uint64_t ix = asu64(x), iy = asu64(y);
     const uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52);
     // glibc's special-case gate: x subnormal/zero/negative/inf/nan, or |y| tiny/huge/inf/nan
@@ -44,7 +45,7 @@ OCTA_HD inline double gpow(double x, double y) {
     int k = (int)((int64_t)tmp >> 52);
     uint64_t iz = ix - (tmp & (0xfffULL << 52));
     double z = asf64(iz), kd = (double)k;
-    double invc = LOG_TAB[3 * i], logc = LOG_TAB[3 * i + 1], logctail = LOG_TAB[3 * i + 2];
+    double invc = log_tab[3 * i], logc = log_tab[3 * i + 1], logctail = log_tab[3 * i + 2];
     double r = fma_(z, invc, -1.0);
     double t1 = fma_(kd, LN2HI, logc);
     double t2 = t1 + r;
@@ -80,8 +81,8 @@ OCTA_HD inline double gpow(double x, double y) {
     rr += elo;
     uint64_t idx = 2 * (ki % 128);
     uint64_t top = ki << (52 - 7);
-    double etail = asf64(EXP_TAB[idx]);
-    uint64_t sbits = EXP_TAB[idx + 1] + top;
+    double etail = asf64(exp_tab[idx]);
+    uint64_t sbits = exp_tab[idx + 1] + top;
     double r2 = rr * rr;
     double s1 = etail + rr;
     double s2 = fma_(r2, fma_(rr, EXP_POLY[1], EXP_POLY[0]), s1);
@@ -89,5 +90,7 @@ OCTA_HD inline double gpow(double x, double y) {
     double scale = asf64(sbits);
     return fma_(scale, tm, scale);
 }
+
+OCTA_HD inline double gpow(double x, double y) { return gpow_t(x, y, LOG_TAB, EXP_TAB); }
 
 }  // namespace octa_gpow

@@ -24,8 +24,8 @@ using namespace octa_simk;
 namespace {
 
 constexpr int SIM_THREADS = 512;
-constexpr size_t SIM_LDS = 2048 + (size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES;  // 160,768 B
-static_assert(SIM_LDS <= 160 * 1024, "LDS budget");
+constexpr size_t SIM_LDS = SIM_LDS_BYTES;
+static_assert(2048 + (size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES <= SIM_LDS && SIM_LDS <= 160 * 1024, "LDS budget");
 static_assert(SIM_THREADS == 64 * KD_WAVES, "kd mailboxes are sized for KD_WAVES waves");
 constexpr int REQ_CAP = 8192;
 
@@ -571,6 +571,39 @@ extern "C" int octa_sim_fields(octa_sim *S, int sample, double *h_oxy, int64_t c
         int64_t n = sc.n_co2 < cap_co2 ? sc.n_co2 : cap_co2;
         OCTA_HIP_CHECK(hipMemcpy(h_co2, S->P.co2 + (size_t)sample * CCAP * 3, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+namespace {
+__global__ void __launch_bounds__(SIM_THREADS)
+sim_kat_kd_kernel(const double *pts, int n, const unsigned char *need, unsigned short *out_idx, unsigned short *out_rank) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
+    kd_build(b, pts, n, out_idx, out_rank, nullptr, need);
+}
+}  // namespace
+
+extern "C" int octa_sim_kat_kd_order(octa_ctx *ctx, const double *h_pts, int64_t n, const uint8_t *h_need, int32_t *h_indices) {
+    if (!ctx || !h_pts || !h_indices || n < 0 || n > OCAP) { octa::set_error("octa_sim_kat_kd_order: bad arguments"); return -2; }
+    if (n == 0) return 0;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    double *d_pts = nullptr;
+    unsigned char *d_need = nullptr;
+    unsigned short *d_idx = nullptr;
+    OCTA_HIP_CHECK(hipMalloc(&d_pts, sizeof(double) * 3 * n));
+    OCTA_HIP_CHECK(hipMalloc(&d_idx, sizeof(unsigned short) * 2 * n));
+    OCTA_HIP_CHECK(hipMemcpy(d_pts, h_pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+    if (h_need) {
+        OCTA_HIP_CHECK(hipMalloc(&d_need, n));
+        OCTA_HIP_CHECK(hipMemcpy(d_need, h_need, n, hipMemcpyHostToDevice));
+    }
+    OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(sim_kat_kd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIM_LDS));
+    hipLaunchKernelGGL(sim_kat_kd_kernel, dim3(1), dim3(SIM_THREADS), SIM_LDS, 0, d_pts, (int)n, d_need, d_idx, d_idx + n);
+    OCTA_HIP_CHECK(hipGetLastError());
+    std::vector<unsigned short> h(n);
+    OCTA_HIP_CHECK(hipMemcpy(h.data(), d_idx, sizeof(unsigned short) * n, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; i++) h_indices[i] = (int32_t)h[i];
+    (void)hipFree(d_pts); (void)hipFree(d_idx); if (d_need) (void)hipFree(d_need);
     return 0;
 }
 

@@ -31,7 +31,7 @@
 
 namespace octa_simk {
 
-constexpr int NCAP = 16384;    // nodes per forest
+constexpr int NCAP = 15360;    // nodes per forest (radii f64 + parent u16 of one forest fit the LDS in the ordered pass)
 constexpr int OCAP = 13312;    // live O2 sinks (LDS-resident kd keys bound this)
 constexpr int CCAP = 8192;     // live CO2 sources
 constexpr int GCAP = 8192;     // nodes with attractors per growth pass
@@ -44,9 +44,11 @@ constexpr int NCANDCAP = 8192; // candidates per iteration
 constexpr int TILE = 1024;     // points per LDS tile in brute-force queries
 constexpr int ACCCAP = 2048;   // accepted sinks per iteration
 constexpr int KD_RANGES = 896;  // ranges per kd level (> OCAP / 17)
-constexpr int KD_MAILBOX_OFF = OCAP * 10 + 5 * KD_RANGES * 4;  // LDS offset (after user()) of the per-wave swap mailboxes
-constexpr int KD_WAVES = 8;                                    // waves per workgroup the mailboxes are sized for
-constexpr int KD_MAILBOX_BYTES = KD_WAVES * 128 * 10;          // per wave 128 x (double + u16)
+constexpr int KD_MAILBOX_OFF = OCAP * 10 + KD_RANGES * (4 * 2 + 4);  // LDS offset (after user()) of the swap mailbox
+constexpr int KD_TEAM_MIN = 192;   // ranges at least this long get a whole wave, shorter ones 16 lanes
+constexpr int KD_WAVES = 8;                                    // waves per workgroup
+constexpr int KD_MAILBOX_BYTES = (OCAP / 2 + 64) * 2;          // one u16 slot per possible swap: ranges are disjoint
+constexpr int SIM_LDS_BYTES = 160 * 1024;  // dynamic LDS of the simulator kernels (one workgroup per CU)
 constexpr int GRID_MAX = 128;   // uniform-grid cells per axis (x, y); the thin z extent is not binned
 
 enum ErrBits { ERR_NODE_CAP = 1, ERR_OXY_CAP = 2, ERR_CO2_CAP = 4, ERR_GROUP_CAP = 8, ERR_PAIR_CAP = 16, ERR_SET_CAP = 32,
@@ -73,7 +75,8 @@ struct __attribute__((aligned(8))) Rec {
     unsigned char draw;     // consumes one random.uniform
     unsigned char ang_gt90; // angle(vector_to_center, avg_xy) > 90
     unsigned char grow;     // inter nodes: reaches the draw with the radius used
-    unsigned char pad[4];
+    unsigned short child;   // inter nodes: the (only) child
+    unsigned char pad[2];
 };
 
 struct __attribute__((aligned(8))) BifRequest {
@@ -507,24 +510,32 @@ OCTA_HD inline void kd_nth_element(const KdPair &a, int first, int nth, int last
 
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// The same algorithm as kd_nth_element executed by one wave: the two unguarded linear scans of the
-// Hoare partition test 64 consecutive elements per step (ballot + count-trailing-zeros), everything
-// else (median of three, swaps, final insertion sort, the rare heap fallback) is done by lane 0.
-// The element moves are identical to the sequential algorithm, so the permutation is too.
-__device__ inline void kd_nth_element_wave(const KdPair &a, int first, int nth, int last, int lane, double *mbk /*[128]*/,
-                                           unsigned short *mbi /*[128]*/) {
-    if (first == last || nth == last) return;
+// The same algorithm as kd_nth_element executed by a team of TW lanes (a whole wave or a 16-lane
+// quarter). Elements are distinct under (key, idx), so one Hoare pass with pivot p is a pure function
+// of the array: with S = #{x < p} the cut is first+1+S, and the sequential cursors swap the k-th
+// element > p that lies left of the cut (counted from the left) with the k-th element < p right of
+// the cut (counted from the right). Every lane takes one contiguous chunk, remembers "x < p" in a bit
+// mask, a team scan of the chunk counts gives the cut and every rank, the left side posts its
+// positions to an LDS mailbox and the right side performs the swaps. Median-of-three, the <= 3
+// element insertion sort and the heap fallback stay with lane 0 of the team.
+// mb: u16 mailbox; a range [s, e) owns the slots from (s+1)/2 (ranges of one level are disjoint).
+template <int TW, int NW>
+__device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, int last, bool live,
+                                           unsigned short *mb) {
+    const int tl = (int)(threadIdx.x & (TW - 1));
+    if (!live || first == last || nth == last) return;
+    unsigned short *box = mb + ((first + 1) >> 1);
     int n = last - first, lg = 0;
     while ((n >> (lg + 1)) > 0) lg++;
     int depth = lg * 2;
     while (last - first > 3) {
         if (depth == 0) {
-            if (lane == 0) { kd_heap_select(a, first, nth + 1, last); kd_swap(a, first, nth); }
+            if (tl == 0) { kd_heap_select(a, first, nth + 1, last); kd_swap(a, first, nth); }
             __builtin_amdgcn_wave_barrier();
             return;
         }
         --depth;
-        if (lane == 0) {
+        if (tl == 0) {
             int mid = first + (last - first) / 2;
             int A = first + 1, B = mid, C = last - 1;
             if (kd_less(a, A, B)) {
@@ -538,72 +549,72 @@ __device__ inline void kd_nth_element_wave(const KdPair &a, int first, int nth, 
         __builtin_amdgcn_wave_barrier();
         const double pv = a.key[first];
         const unsigned short pi = a.idx[first];
-        int lo = first + 1, hi = last;
-        // Block phase. Hoare's partition swaps the k-th element from the left that is not < pivot with
-        // the k-th element from the right that is not > pivot, while they have not crossed. Examine 64
-        // elements per side at a time, pair the stoppers by rank and swap them in parallel through a
-        // small LDS mailbox; the unexamined middle [lo, hi) never lets the two sides overlap here.
+        const int base = first + 1, m = last - base;
+        const int c = ((m + TW - 1) / TW) | 1;  // odd chunk length: lanes hit distinct LDS banks
+        int p0 = base + tl * c;
+        if (p0 > last) p0 = last;
+        const int p1 = (p0 + c < last) ? p0 + c : last;
+        unsigned long long ms[NW];
+        int nS = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const int q0 = p0 + 64 * w;
+            int lim = p1 - q0;
+            lim = lim > 64 ? 64 : lim;
+            unsigned long long bits = 0;
+#pragma unroll 4
+            for (int i = 0; i < lim; i++)
+                if (kd_less_iv(a, q0 + i, pv, pi)) bits |= 1ull << i;
+            ms[w] = bits;
+            nS += __popcll(bits);
+        }
+        int inc = nS;
+#pragma unroll
+        for (int d = 1; d < TW; d <<= 1) {
+            int u = __shfl_up(inc, d, TW);
+            if (tl >= d) inc += u;
+        }
+        const int totS = __shfl(inc, TW - 1, TW);
+        const int preS = inc - nS;
+        const int cut = base + totS;
+        // left of the cut: post the positions of the elements > pivot, ranked from the left
         {
-            unsigned long long mL = 0, mR = 0;
-            int Lb = 0, Rb = 0;
-            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            while (true) {
-                if (mL == 0) {
-                    if (hi - lo < 64) break;
-                    Lb = lo;
-                    mL = __ballot(!kd_less_iv(a, Lb + lane, pv, pi));
-                    lo += 64;
+            int g = (p0 - base) - preS;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const int q0 = p0 + 64 * w;
+                int lim = ((p1 < cut) ? p1 : cut) - q0;
+                if (lim <= 0) continue;
+                unsigned long long inv = ~ms[w];
+                if (lim < 64) inv &= (1ull << lim) - 1ull;
+                while (inv) {
+                    int i = (int)__ffsll((long long)inv) - 1;
+                    inv &= inv - 1ull;
+                    box[g++] = (unsigned short)(q0 + i);
                 }
-                if (mR == 0) {
-                    if (hi - lo < 64) break;
-                    Rb = hi - 1;
-                    mR = __ballot(!kd_less_vi(pv, pi, a, Rb - lane));
-                    hi -= 64;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // right of the cut: the elements < pivot, ranked from the right, swap with their partners
+        {
+            int r = totS - preS - nS;
+#pragma unroll
+            for (int w = NW - 1; w >= 0; w--) {
+                const int q0 = p0 + 64 * w;
+                if (q0 >= p1) continue;
+                unsigned long long sm = ms[w];
+                if (cut > q0) { int sh = cut - q0; sm = (sh >= 64) ? 0ull : (sm >> sh) << sh; }
+                while (sm) {
+                    int i = 63 - __clzll((long long)sm);
+                    sm &= ~(1ull << i);
+                    kd_swap(a, q0 + i, (int)box[r++]);
                 }
-                if (mL == 0 || mR == 0) continue;
-                const int cl = __popcll(mL), cr = __popcll(mR), c = cl < cr ? cl : cr;
-                const bool isL = (mL >> lane) & 1ull, isR = (mR >> lane) & 1ull;
-                const int rl = __popcll(mL & lt), rr = __popcll(mR & lt);
-                const int pL = Lb + lane, pR = Rb - lane;
-                if (isL && rl < c) { mbk[rl] = a.key[pL]; mbi[rl] = a.idx[pL]; }
-                if (isR && rr < c) { mbk[64 + rr] = a.key[pR]; mbi[64 + rr] = a.idx[pR]; }
-                __builtin_amdgcn_wave_barrier();
-                if (isL && rl < c) { a.key[pL] = mbk[64 + rl]; a.idx[pL] = mbi[64 + rl]; }
-                if (isR && rr < c) { a.key[pR] = mbk[rr]; a.idx[pR] = mbi[rr]; }
-                __builtin_amdgcn_wave_barrier();
-                mL = __ballot(isL && rl >= c);
-                mR = __ballot(isR && rr >= c);
             }
-            // hand over to the cursor form: the sequential algorithm would stand on the next pending stoppers
-            if (mL) lo = Lb + (int)__ffsll((long long)mL) - 1;
-            if (mR) hi = Rb - ((int)__ffsll((long long)mR) - 1) + 1;
         }
-        while (true) {
-            while (true) {  // while (less(lo, pivot)) ++lo;
-                int i = lo + lane;
-                bool stop = (i >= last) || !kd_less_iv(a, i, pv, pi);
-                unsigned long long bal = __ballot(stop);
-                if (bal) { lo += (int)__ffsll((long long)bal) - 1; break; }
-                lo += 64;
-            }
-            int h = hi - 1;  // --hi; while (less(pivot, hi)) --hi;
-            while (true) {
-                int j = h - lane;
-                bool stop = (j < first) || !kd_less_vi(pv, pi, a, j);
-                unsigned long long bal = __ballot(stop);
-                if (bal) { h -= (int)__ffsll((long long)bal) - 1; break; }
-                h -= 64;
-            }
-            hi = h;
-            if (!(lo < hi)) break;
-            if (lane == 0) kd_swap(a, lo, hi);
-            __builtin_amdgcn_wave_barrier();
-            ++lo;
-        }
-        int cut = lo;
+        __builtin_amdgcn_wave_barrier();
         if (cut <= nth) first = cut; else last = cut;
     }
-    if (lane == 0) {
+    if (tl == 0) {
         for (int i = first + 1; i < last; ++i) {
             double vv = a.key[i]; unsigned short vi = a.idx[i];
             if (kd_less(a, i, first)) {
@@ -638,11 +649,12 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
 #endif
     double *key = reinterpret_cast<double *>(b.user());
     unsigned short *idx = reinterpret_cast<unsigned short *>(b.user() + (size_t)OCAP * 8);
-    int *tab = reinterpret_cast<int *>(b.user() + (size_t)OCAP * 10);  // 5 tables of KD_RANGES ints
-    int *rs = tab, *re = tab + KD_RANGES, *rd = tab + 2 * KD_RANGES;     // range start / end / split dim (-1 = leaf)
-    int *rs2 = tab + 3 * KD_RANGES, *re2 = tab + 4 * KD_RANGES;          // next level
+    unsigned short *tab = reinterpret_cast<unsigned short *>(b.user() + (size_t)OCAP * 10);  // 4 u16 tables + 1 int table
+    unsigned short *rs = tab, *re = tab + KD_RANGES;                     // range start / end
+    unsigned short *rs2 = tab + 2 * KD_RANGES, *re2 = tab + 3 * KD_RANGES;  // next level
+    int *rd = reinterpret_cast<int *>(tab + 4 * KD_RANGES);              // split dim (-1 = leaf / not needed)
     for (int i = b.tid; i < n; i += b.nth) idx[i] = (unsigned short)i;
-    if (b.tid == 0) { rs[0] = 0; re[0] = n; }
+    if (b.tid == 0) { rs[0] = 0; re[0] = (unsigned short)n; }
     b.sync();
     int nr = (n > 16) ? 1 : 0;  // a range of <= leafsize points is a leaf: left in input order
     KdPair kp = {key, idx};
@@ -723,26 +735,34 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
         }
         b.sync();
         KDP(2);
-        // 3. nth_element per range: long ranges by one wave each, short ranges by one thread each
+        // 3. nth_element per range: long ranges by one wave each, short ranges by a quarter wave each
 #if defined(__HIP_DEVICE_COMPILE__)
         {
-            const int wv = b.tid >> 6, nw = (b.nth + 63) >> 6, lane = b.tid & 63;
+            unsigned short *mb = reinterpret_cast<unsigned short *>(b.user() + KD_MAILBOX_OFF);
+            const int wv = b.tid >> 6, nw = (b.nth + 63) >> 6;
             for (int q = wv; q < nr; q += nw) {
                 int d = rd[q];
                 int s = rs[q], e = re[q];
-                if (d < 0 || e - s < 192) continue;
-                double *mbk = reinterpret_cast<double *>(b.user() + KD_MAILBOX_OFF) + 128 * wv;
-                unsigned short *mbi = reinterpret_cast<unsigned short *>(b.user() + KD_MAILBOX_OFF + KD_WAVES * 128 * 8) + 128 * wv;
-                kd_nth_element_wave(kp, s, s + (e - s) / 2, e, lane, mbk, mbi);
+                if (d < 0 || e - s < KD_TEAM_MIN) continue;
+                if (e - s > 4000) kd_nth_element_team<64, 4>(kp, s, s + (e - s) / 2, e, true, mb);
+                else kd_nth_element_team<64, 1>(kp, s, s + (e - s) / 2, e, true, mb);
             }
         }
         b.sync();
         KDP(3);
-        for (int q = b.tid; q < nr; q += b.nth) {
-            int d = rd[q];
-            int s = rs[q], e = re[q];
-            if (d < 0 || e - s >= 192) continue;
-            kd_nth_element(kp, s, s + (e - s) / 2, e);
+        {
+            unsigned short *mb = reinterpret_cast<unsigned short *>(b.user() + KD_MAILBOX_OFF);
+            const int team = b.tid >> 4, nteam = b.nth >> 4;
+            for (int q0 = 0; q0 < nr; q0 += nteam) {
+                int q = q0 + team;
+                bool live = q < nr;
+                int s = 0, e = 0;
+                if (live) {
+                    s = rs[q]; e = re[q];
+                    live = rd[q] >= 0 && e - s < KD_TEAM_MIN;
+                }
+                kd_nth_element_team<16, 1>(kp, s, s + (e - s) / 2, e, live, mb);
+            }
         }
 #else
         for (int q = b.tid; q < nr; q += b.nth) {
@@ -754,20 +774,27 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
 #endif
         b.sync();
         KDP(4);
-        // 4. children that are still longer than a leaf form the next level
-        if (b.tid == 0) {
-            int cnt = 0;
-            for (int q = 0; q < nr; q++) {
-                if (rd[q] < 0) continue;
-                int s = rs[q], e = re[q], m = s + (e - s) / 2;
-                if (m - s > 16 && cnt < KD_RANGES) { rs2[cnt] = s; re2[cnt] = m; cnt++; }
-                if (e - m > 16 && cnt < KD_RANGES) { rs2[cnt] = m; re2[cnt] = e; cnt++; }
+        // 4. children that are still longer than a leaf form the next level (ordered compaction)
+        {
+            int base = 0;
+            for (int q0 = 0; q0 < nr; q0 += b.nth) {
+                const int q = q0 + b.tid;
+                int s = 0, e = 0, m = 0, c = 0;
+                if (q < nr && rd[q] >= 0) {
+                    s = rs[q]; e = re[q]; m = s + (e - s) / 2;
+                    c = (m - s > 16 ? 1 : 0) + (e - m > 16 ? 1 : 0);
+                }
+                int ex;
+                const int tot = blk_scan(b, c, &ex);
+                int pos = base + ex;
+                if (m - s > 16) { if (pos < KD_RANGES) { rs2[pos] = (unsigned short)s; re2[pos] = (unsigned short)m; } pos++; }
+                if (e - m > 16) { if (pos < KD_RANGES) { rs2[pos] = (unsigned short)m; re2[pos] = (unsigned short)e; } }
+                base += tot;
             }
-            b.coll()[101] = cnt;
+            nr = base < KD_RANGES ? base : KD_RANGES;
         }
         b.sync();
-        nr = b.coll()[101];
-        { int *t = rs; rs = rs2; rs2 = t; t = re; re = re2; re2 = t; }
+        { unsigned short *t = rs; rs = rs2; rs2 = t; t = re; re = re2; re2 = t; }
         b.sync();
         KDP(5);
     }
@@ -858,36 +885,156 @@ OCTA_HD inline void dirty_insert(DirtyList &D, int g) {
     D.n++;
 }
 
-// rad: radii of forest f (the LDS copy during the ordered pass). The parent's topology is requested
-// before the three pow evaluations of the current node so that its HBM/L2 latency hides behind them.
-OCTA_HD inline void murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, double *rad) {
-    const double *kap = A.nkap[f];
-    const int *npar = A.npar[f], *nch0 = A.nch0[f], *nch1 = A.nch1[f];
-    const unsigned char *nnch = A.nnch[f];
+// State of the ordered pass that lives in LDS / registers instead of HBM.
+struct SeqLds {
+    double *rad;               // [NCAP] radii of the forest
+    unsigned short *par;       // [NCAP] parent id, 0xffff = none
+    const double *log_tab;     // glibc pow tables (gpow.h)
+    const uint64_t *exp_tab;
+    unsigned char *stage;      // 2 KiB of per-chunk operands of the wave-form Murray walk
+};
+struct WalkRec { int nch, c0, c1, cg; double k; };
+OCTA_HD inline WalkRec walk_load(const SimArrays &A, int f, int id, bool want_cg) {
+    WalkRec r;
+    const int j = id < 0 ? 0 : id;
+    r.nch = A.nnch[f][j]; r.c0 = A.nch0[f][j]; r.c1 = A.nch1[f][j];
+    r.cg = want_cg ? A.child_group[j] : 0;
+    r.k = A.nkap[f][j];
+    return r;
+}
+OCTA_HD inline int walk_parent(const SeqLds &L, int id) {
+    if (id < 0) return -1;
+    unsigned short p = L.par[id];
+    return p == 0xffffu ? -1 : (int)p;
+}
+
+// Murray's law from node id up to the root (arterial_tree.py:174-184). Radii and the parent chain are read
+// from LDS; the topology records of the next four ancestors are always in flight from HBM/L2, so a step
+// costs its three pow evaluations (tables in LDS) and not a memory round trip.
+// Murray's law from node id up to the root (arterial_tree.py:174-184): every node on the way gets
+// (r_c0^k + r_c1^k)^(1/k) until a radius does not change or the root (never updated) is reached.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline double readlane_f64(double v, int j /* wave-uniform */) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+    return __hiloint2double(hi, lo);
+}
+// Wave form; all 64 lanes call it with identical arguments. Per chunk of 64 ancestors: (1) the chain is
+// followed through the LDS parent array, lane j keeps the j-th node; (2) lane-parallel, every lane fetches
+// its node's topology from HBM/L2 (one round trip for the whole chunk) and raises the children that are
+// NOT on the path (their radii cannot change during this walk) to the node's kappa; (3) the sequential
+// chain -- two pow evaluations per node, operands fetched with readlane -- is executed uniformly; (4) the lanes
+// store the new radii. Floating-point addition is commutative, so "on-path power + other power" is
+// bit-identical to the reference's c0-then-c1 order.
+__device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L) {
+    if (id < 0) return 0;
+    const int lane = (int)(threadIdx.x & 63);
+    double *rad = L.rad;
     long steps = 0;
-    if (id < 0) return;
-    int par = npar[id], nch = nnch[id], c0 = nch0[id], c1 = nch1[id], cg = D ? A.child_group[id] : 0;
-    double k = kap[id];
+    int first = id, below = -1;  // first node of the chunk and its on-path child (-1 at the start of the walk)
+    double rp_prev = 0, k_last = 0, inv_k = 0;
     while (true) {
-        if (par < 0 || nch == 0) break;
-        // prefetch the parent's record (used only if the walk continues)
-        const int p_par = npar[par], p_nch = nnch[par], p_c0 = nch0[par], p_c1 = nch1[par];
-        const int p_cg = D ? A.child_group[par] : 0;
-        const double p_k = kap[par];
-        double s = octa_gpow::gpow(rad[c0], k);
-        if (nch >= 2) s = s + octa_gpow::gpow(rad[c1], k);
-        double rp = octa_gpow::gpow(s, 1.0 / k);
+        int cur = first, nn = 0, mine = -1;
+        for (; nn < 64; nn++) {
+            const int p = walk_parent(L, cur);
+            if (p < 0) break;
+            if (lane == nn) mine = cur;
+            cur = p;
+        }
+        if (nn == 0) break;
+        int onpath = __shfl_up(mine, 1, 64);
+        if (lane == 0) onpath = below;
+        double v_k = 0, v_pw = 0, v_old = 0;  // lane j: kappa, sum of the off-path child powers, radius before the walk
+        int v_cg = 0, v_nch = 0;
+        if (lane < nn) {
+            const WalkRec r = walk_load(A, f, mine, D != nullptr);
+            double pw = 0;
+            if (onpath < 0) {
+                if (r.nch >= 1) {
+                    pw = octa_gpow::gpow_t(rad[r.c0], r.k, L.log_tab, L.exp_tab);
+                    if (r.nch >= 2) pw = pw + octa_gpow::gpow_t(rad[r.c1], r.k, L.log_tab, L.exp_tab);
+                }
+            } else if (r.nch >= 2) {
+                pw = octa_gpow::gpow_t(rad[r.c0 == onpath ? r.c1 : r.c0], r.k, L.log_tab, L.exp_tab);
+            }
+            v_k = r.k; v_pw = pw; v_old = rad[mine]; v_cg = r.cg; v_nch = r.nch;
+        }
+        int done = 0;
+        bool stop = false;
+        double my_rp = 0;
+        for (int jj = 0; jj < nn; jj++) {
+            const int j = __builtin_amdgcn_readfirstlane(jj);
+            const int nch = __builtin_amdgcn_readlane(v_nch, j);
+            if (nch == 0) { stop = true; break; }
+            const double k = readlane_f64(v_k, j), pw_j = readlane_f64(v_pw, j), old_j = readlane_f64(v_old, j);
+            if (k != k_last) { k_last = k; inv_k = 1.0 / k; }
+            double s;
+            if (j == 0 && below < 0) {
+                s = pw_j;
+            } else {
+                s = octa_gpow::gpow_t(rp_prev, k, L.log_tab, L.exp_tab);
+                if (nch >= 2) s = s + pw_j;
+            }
+            const double rp = octa_gpow::gpow_t(s, inv_k, L.log_tab, L.exp_tab);
+            steps++;
+            if (old_j == rp) { stop = true; break; }
+            if (lane == j) my_rp = rp;
+            done = j + 1;
+            rp_prev = rp;
+            if (D) {
+                const int cg = __builtin_amdgcn_readlane(v_cg, j);
+                if ((cg >> 14) == pass_tag && !((cg >> 13) & 1)) {
+                    int g2 = cg & 8191;
+                    if (g2 > cur_g) dirty_insert(*D, g2);
+                }
+            }
+        }
+        if (lane < done) rad[mine] = my_rp;
+        __builtin_amdgcn_wave_barrier();
+        if (stop || nn < 64) break;
+        below = __shfl(mine, 63, 64);
+        first = cur;
+    }
+    return steps;
+}
+#else
+OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L) {
+    long steps = 0;
+    double *rad = L.rad;
+    while (id >= 0) {
+        const int par = walk_parent(L, id);
+        const WalkRec r = walk_load(A, f, id, D != nullptr);
+        if (par < 0 || r.nch == 0) break;
+        double s = octa_gpow::gpow_t(rad[r.c0], r.k, L.log_tab, L.exp_tab);
+        if (r.nch >= 2) s = s + octa_gpow::gpow_t(rad[r.c1], r.k, L.log_tab, L.exp_tab);
+        double rp = octa_gpow::gpow_t(s, 1.0 / r.k, L.log_tab, L.exp_tab);
         steps++;
         if (rad[id] == rp) break;
         rad[id] = rp;
-        if (D && (cg >> 14) == pass_tag && !((cg >> 13) & 1)) {
-            int g2 = cg & 8191;
+        if (D && (r.cg >> 14) == pass_tag && !((r.cg >> 13) & 1)) {
+            int g2 = r.cg & 8191;
             if (g2 > cur_g) dirty_insert(*D, g2);
         }
         id = par;
-        par = p_par; nch = p_nch; c0 = p_c0; c1 = p_c1; cg = p_cg; k = p_k;
     }
-    A.sc->murray_steps += steps;
+    return steps;
+}
+#endif
+
+// node creation of the ordered pass: the counter, the parent's child count and the LDS mirrors are kept by
+// the caller (parent_nch = children the parent has before this call)
+OCTA_HD inline int seq_add_node(const SimArrays &A, int f, int &n_nodes, V3 p, double r, int parent, int parent_nch,
+                                double kappa, const SeqLds &L) {
+    int id = n_nodes;
+    if (id >= NCAP) { atomic_or_int(&A.sc->err, ERR_NODE_CAP); return -1; }
+    n_nodes = id + 1;
+    st3(A.npos[f] + 3 * id, p);
+    A.nrad[f][id] = r; A.nkap[f][id] = kappa; A.npar[f][id] = parent;
+    L.rad[id] = r;
+    L.par[id] = (unsigned short)parent;
+    A.nch0[f][id] = -1; A.nch1[f][id] = -1; A.nnch[f][id] = 0; A.nact[f][id] = 1;
+    if (parent_nch == 0) A.nch0[f][parent] = id; else if (parent_nch == 1) A.nch1[f][parent] = id;
+    A.nnch[f][parent] = (unsigned char)(parent_nch + 1);
+    return id;
 }
 
 OCTA_HD inline int add_node(const SimArrays &A, int f, V3 p, double r, int parent, double kappa, double *rad_mirror = nullptr) {
@@ -1152,6 +1299,7 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     const int ch = A.nch0[f][id];
     const double r1 = G.rad[ch], r2 = r;
     R.r1_used = r1;
+    R.child = (unsigned short)ch;
     using octa_gpow::gpow;
     double rp = gpow(gpow(r1, kappa) + gpow(r2, kappa), 1 / kappa);
     double rp4 = gpow(rp, 4.0), rp2 = gpow(rp, 2.0);
@@ -1307,76 +1455,130 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
 OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
                               const double *att, const double *bif_results /* [req][6] */) {
     SampleScalars *sc = A.sc;
-    // the radii of this forest live in LDS for the duration of the pass (NCAP doubles = 128 KiB)
-    double *lrad = reinterpret_cast<double *>(b.user());
+    // LDS for the duration of the pass: radii (NCAP f64) and parents (NCAP u16) of this forest, the pow tables
+    SeqLds L;
+    L.rad = reinterpret_cast<double *>(b.user());
+    L.par = reinterpret_cast<unsigned short *>(b.user() + (size_t)NCAP * 8);
+    double *ltab = reinterpret_cast<double *>(b.user() + (size_t)NCAP * 10);
+    uint64_t *etab = reinterpret_cast<uint64_t *>(ltab + 384);
+    static_assert((size_t)NCAP * 10 + 384 * 8 + 256 * 8 + 2048 + 2048 <= (size_t)SIM_LDS_BYTES, "ordered-pass LDS layout");
+    L.log_tab = ltab; L.exp_tab = etab;
+    L.stage = reinterpret_cast<unsigned char *>(etab + 256);
     const int n_before = sc->n_nodes[f];
-    for (int i = b.tid; i < n_before; i += b.nth) lrad[i] = A.nrad[f][i];
+    for (int i = b.tid; i < n_before; i += b.nth) {
+        L.rad[i] = A.nrad[f][i];
+        int p = A.npar[f][i];
+        L.par[i] = p < 0 ? (unsigned short)0xffffu : (unsigned short)p;
+    }
+    for (int i = b.tid; i < 384; i += b.nth) ltab[i] = octa_gpow::LOG_TAB[i];
+    for (int i = b.tid; i < 256; i += b.nth) etab[i] = octa_gpow::EXP_TAB[i];
     b.sync();
-    if (b.tid == 0) {
-        GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, lrad};
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SEQT(slot, stmt) do { long _t0 = (long)wall_clock64(); stmt; t_acc[slot] += (long)wall_clock64() - _t0; } while (0)
+#else
+#define SEQT(slot, stmt) do { stmt; } while (0)
+#endif
+    long t_acc[4] = {0, 0, 0, 0};  // murray, re-speculation, visits, -
+    // The first wave runs the pass with all lanes doing the same thing (same values, same stores); the lanes
+    // only differ inside murray_to_root. One thread alone on the host build.
+    if (b.tid < (b.nth >= 64 ? 64 : 1)) {
+        GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, L.rad};
         const int ng = sc->n_groups[f];
         const int n_grow = sc->n_grow[f];
         const int tag = sc->pass_tag[f];
         DirtyList D;
         D.v = b.coll() + 128; D.n = 0; D.cap = 256; D.overflow = false;
-        sc->new_begin[f] = sc->n_nodes[f];
-        int gi = 0, last_g = -1;
+        // scalars of the sample stay in registers during the pass
+        int n_nodes = n_before, py_pos = sc->py_pos, err = 0;
+        const int py_cap = sc->py_cap;
+        long steps = 0, n_bif = 0, respec = 0;
+        double u_next = py_pos < py_cap ? A.py_u[py_pos] : 0.0;
+        // the next record of the grow list is always in flight
+        const int INF = 0x7fffffff;
+        int gi = 0;
+        int g1 = n_grow > 0 ? A.glist[0] : INF;
+        int g1n = n_grow > 1 ? A.glist[1] : INF;
+        Rec R1;
+        if (g1 != INF) R1 = A.rec[g1];
+        int last_g = -1;
         bool scan_all = false;  // fallback when the dirty list overflows: visit every remaining group
         while (true) {
             int g;
+            Rec R;
             if (scan_all) {
                 g = last_g + 1;
                 if (g >= ng) break;
+                R = A.rec[g];
             } else {
-                int g1 = gi < n_grow ? A.glist[gi] : 0x7fffffff;
-                int g2 = D.n > 0 ? D.v[0] : 0x7fffffff;
+                int g2 = D.n > 0 ? D.v[0] : INF;
                 g = g1 < g2 ? g1 : g2;
-                if (g == 0x7fffffff) break;
-                if (g == g1) gi++;
+                if (g == INF) break;
                 if (g == g2) { for (int k = 1; k < D.n; k++) D.v[k - 1] = D.v[k]; D.n--; }
+                if (g == g1) {
+                    R = R1;
+                    gi++;
+                    g1 = g1n;
+                    g1n = gi + 1 < n_grow ? A.glist[gi + 1] : INF;
+                    if (g1 != INF) R1 = A.rec[g1];
+                } else {
+                    R = A.rec[g];
+                }
             }
             last_g = g;
-            Rec R = A.rec[g];
+            t_acc[2]++;
             if (R.type == 0) continue;
             const int id = R.node;
             if (R.type == 1) {
                 bool bif = false;
                 if (R.draw) {
-                    if (sc->py_pos >= sc->py_cap) { sc->err |= ERR_PY_CAP; break; }
-                    double u = A.py_u[sc->py_pos++];
+                    if (py_pos >= py_cap) { err |= ERR_PY_CAP; break; }
+                    double u = u_next;
+                    py_pos++;
+                    u_next = py_pos < py_cap ? A.py_u[py_pos] : 0.0;
                     bif = (R.thr > u) && R.ang_gt90;
                 }
                 if (bif) {
-                    if (R.req < 0) { sc->err |= ERR_MISSING_BIF; continue; }
+                    if (R.req < 0) { err |= ERR_MISSING_BIF; continue; }
                     const double *o = bif_results + 6 * (size_t)R.req;
-                    add_node(A, f, v3(o[0], o[1], o[2]), C.r, id, P.kappa, lrad);
-                    add_node(A, f, v3(o[3], o[4], o[5]), C.r, id, P.kappa, lrad);
-                    murray_to_root(A, f, id, g, tag, &D, lrad);
+                    seq_add_node(A, f, n_nodes, v3(o[0], o[1], o[2]), C.r, id, 0, P.kappa, L);
+                    seq_add_node(A, f, n_nodes, v3(o[3], o[4], o[5]), C.r, id, 1, P.kappa, L);
+                    SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L));
                     A.nact[f][id] = 0;
-                    sc->n_bif++;
+                    n_bif++;
                 } else {
-                    add_node(A, f, ld3(R.newpos), C.r, id, P.kappa, lrad);
+                    seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 0, P.kappa, L);
                 }
             } else {
-                if (lrad[A.nch0[f][id]] != R.r1_used) {
-                    eval_inter(G, g, R);
-                    sc->respec++;
+                if (L.rad[R.child] != R.r1_used) {
+                    SEQT(1, eval_inter(G, g, R));
+                    respec++;
                 }
                 if (!R.grow) continue;
-                if (sc->py_pos >= sc->py_cap) { sc->err |= ERR_PY_CAP; break; }
-                double u = A.py_u[sc->py_pos++];
+                if (py_pos >= py_cap) { err |= ERR_PY_CAP; break; }
+                double u = u_next;
+                py_pos++;
+                u_next = py_pos < py_cap ? A.py_u[py_pos] : 0.0;
                 if (R.thr <= u && !R.ang_gt90) continue;
-                add_node(A, f, ld3(R.newpos), C.r, id, P.kappa, lrad);
-                murray_to_root(A, f, id, g, tag, &D, lrad);
+                seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 1, P.kappa, L);
+                SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L));
                 A.nact[f][id] = 0;
             }
             if (D.overflow && !scan_all) { scan_all = true; D.n = 0; }
         }
-        sc->new_end[f] = sc->n_nodes[f];
+        sc->new_begin[f] = n_before;
+        sc->new_end[f] = n_nodes;
+        sc->n_nodes[f] = n_nodes;
+        sc->py_pos = py_pos;
+        if (err) sc->err |= err;
+        sc->murray_steps += steps;
+        sc->n_bif += n_bif;
+        sc->respec += respec;
+        if (b.tid == 0) { sc->kdprof[7] += t_acc[0]; (void)t_acc[1]; (void)t_acc[2]; }
     }
+#undef SEQT
     b.sync();
     // radii changed by Murray go back to HBM (new nodes were written through)
-    for (int i = b.tid; i < n_before; i += b.nth) A.nrad[f][i] = lrad[i];
+    for (int i = b.tid; i < n_before; i += b.nth) A.nrad[f][i] = L.rad[i];
     b.sync();
 }
 

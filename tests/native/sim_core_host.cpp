@@ -41,7 +41,7 @@ long octa_simcore_gpow_check(long n, unsigned long long seed) {
 
 // nth_element restatement vs the real std::nth_element is checked from Python through this hook
 void octa_simcore_kd_indices(const double *pts, int n, unsigned short *out_idx) {
-    std::vector<unsigned char> smem(2048 + (size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES + 64);
+    std::vector<unsigned char> smem((size_t)SIM_LDS_BYTES + 64);
     Blk b = {0, 1, smem.data()};
     std::vector<unsigned short> rank(n);
     kd_build(b, pts, n, out_idx, rank.data());

@@ -76,3 +76,18 @@ def test_full_length_run_sha(gh, golden):
     for k, n in enumerate(names):
         text = gh.edges_to_csv_text(res.sample_edges(k))
         assert hashlib.sha256(text.encode()).hexdigest() == str(golden[n + "_csv_sha256"]), n
+
+
+def test_device_kd_order_matches_scipy(hip_lib_built):
+    """The team-parallel introselect on the device must give scipy's tree.indices (no ties in the data)."""
+    from scipy.spatial import cKDTree
+    from octa_autosegmentation_amd import _native
+    L = _native.lib()
+    ctx = _native.ctx(0)
+    rng = np.random.default_rng(77)
+    for n in (1, 16, 17, 33, 40, 190, 191, 192, 193, 300, 383, 384, 1000, 4000, 4001, 4033, 4096, 4097, 5000, 8001, 8065,
+              8191, 8192, 8193, 13000, 13312):
+        pts = np.ascontiguousarray(rng.uniform(0, 1, (n, 3)) * np.array([1, 1, 0.0131]))
+        out = np.zeros(n, np.int32)
+        _native.check(L.octa_sim_kat_kd_order(ctx, pts.ctypes.data, n, None, out.ctypes.data), "octa_sim_kat_kd_order")
+        assert (out == cKDTree(pts).indices).all(), n

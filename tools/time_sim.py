@@ -20,6 +20,7 @@ for rep in range(2):
     prof = res.stats[:, 8:18].mean(axis=0) / 1e5  # ms
     sub = res.stats[:, 18:24].mean(axis=0) / 1e5
     print("  candidates=%.0f | satisfy_art: kd=%.0f pairs+ven=%.0f sort=%.0f set=%.0f compact=%.0f" % tuple(sub))
+    print("  murray walks (both forests): %.0f ms" % (res.stats[:, 31].mean() / 1e5))
     kd = res.stats[:, 24:31].mean(axis=0) / 1e5
     print("  kd: bbox=%.0f dim=%.0f gather=%.0f nth_wave=%.0f nth_thread=%.0f next=%.0f final=%.0f" % tuple(kd))
     print("  timing:", {k: (round(v, 1) if isinstance(v, float) else v) for k, v in res.timing.items()})
