@@ -18,6 +18,8 @@
 
 #include "common.h"
 #include "sim_host.h"
+#include <thread>
+#include <cstdlib>
 
 using namespace octa_simk;
 
@@ -47,7 +49,8 @@ struct BatchPtrs {
     unsigned long long *hashes;
     unsigned *pairs;
     unsigned long long *set_hash;
-    int *set_key, *tmp_int, *grid_start, *grid_items;
+    int *set_key, *tmp_int;
+    double *grid_pts;
     double *tmp_dbl;
     SampleScalars *sc;
     IterParams *iters;
@@ -97,8 +100,7 @@ __device__ __forceinline__ SimArrays sample_arrays(const BatchPtrs &B, int s) {
     A.set_hash = B.set_hash + (size_t)s * SETCAP;
     A.set_key = B.set_key + (size_t)s * SETCAP;
     A.tmp_int = B.tmp_int + (size_t)s * (OCAP + 2 * NCANDCAP);
-    A.grid_start = B.grid_start + (size_t)s * (GRID_MAX * GRID_MAX + 1);
-    A.grid_items = B.grid_items + (size_t)s * NCAP;
+    A.grid_pts = B.grid_pts + (size_t)s * GRID_N * 3;
     A.tmp_dbl = B.tmp_dbl + (size_t)s * OCAP * 3;
     A.sc = B.sc + s;
     return A;
@@ -267,6 +269,94 @@ sim_iter_b_kernel(BatchPtrs B, int it) {
     OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, B.reqs + REQ_CAP, B.req_count + 1, REQ_CAP, s));
 }
 
+// ---- persistent form: one launch runs all iterations of every sample; a workgroup only waits for the host
+// when ITS sample posted leaf-bifurcation requests (about one pass in ten), through a mailbox in pinned host
+// memory. Samples are no longer in lock step, so a launch lasts as long as its slowest sample's SUM of phases
+// instead of the sum of per-iteration maxima, and there are no per-iteration launches or stream syncs.
+struct HostMail {
+    BifRequest *reqs;    // pinned host [B][REQ_PER_SAMPLE]     device -> host
+    double *results;     // pinned host [B][REQ_PER_SAMPLE][6]  host -> device
+    int *req_n;          // pinned host [B]                     device -> host
+    int *req_ticket;     // pinned host [B]                     device -> host (2*it+1: arterial pass, 2*it+2: venous)
+    int *resp_ticket;    // pinned host [B]                     host -> device
+};
+constexpr int REQ_PER_SAMPLE = 32;
+constexpr long MAIL_TIMEOUT_TICKS = 30L * 100000000L;  // 30 s of the 100 MHz wall clock
+constexpr int ERR_HOST_TIMEOUT = 2048;
+
+__device__ inline void mail_roundtrip(const Blk &b, const SimArrays &A, const HostMail &M, int s, int n_req, int ticket) {
+    if (n_req == 0) return;  // block-uniform
+    if (b.tid == 0) {
+        if (n_req > REQ_PER_SAMPLE) { atomicOr(&A.sc->err, ERR_REQ_CAP); n_req = REQ_PER_SAMPLE; }
+        __threadfence_system();
+        __hip_atomic_store(M.req_n + s, n_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(M.req_ticket + s, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long t0 = (long)wall_clock64();
+        while (__hip_atomic_load(M.resp_ticket + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ticket) {
+            __builtin_amdgcn_s_sleep(64);
+            if ((long)wall_clock64() - t0 > MAIL_TIMEOUT_TICKS) { atomicOr(&A.sc->err, ERR_HOST_TIMEOUT); break; }
+        }
+        A.sc->prof[5] += (long)wall_clock64() - t0;
+        __threadfence_system();
+    }
+    b.sync();
+}
+
+// block-uniform read of the sample's error bits
+__device__ inline int uniform_err(const Blk &b, const SimArrays &A) {
+    int *slot = b.coll() + 97;
+    b.sync();
+    if (b.tid == 0) *slot = atomicOr(&A.sc->err, 0);
+    b.sync();
+    int e = *slot;
+    b.sync();
+    return e;
+}
+
+__global__ void __launch_bounds__(SIM_THREADS)
+sim_persistent_kernel(BatchPtrs B, HostMail M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x;
+    SimArrays A = sample_arrays(B, s);
+    Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
+    int *req_n = b.coll() + 96;
+    BifRequest *reqs = M.reqs + (size_t)s * REQ_PER_SAMPLE;
+    const double *results = M.results + (size_t)s * REQ_PER_SAMPLE * 6;
+    const int n_iter = B.C.n_iter;
+    for (int it = 0; it <= n_iter; it++) {
+        if (uniform_err(b, A)) break;
+        if (it > 0) {
+            const IterParams Pp = B.iters[it - 1];
+            OCTA_PROF(8, phase_seq(b, A, B.C, Pp, 1, A.co2, results));
+            OCTA_PROF(9, phase_satisfy_ven(b, A, Pp));
+        }
+        if (it >= n_iter) break;
+        const IterParams P = B.iters[it];
+        {
+            long _t0 = (long)wall_clock64();
+            if (threadIdx.x < 64)
+                gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], P.N,
+                                    B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()), (int)threadIdx.x);
+            __syncthreads();
+            if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
+        }
+        OCTA_PROF(0, phase_sample(b, A, B.C, P, it));
+        OCTA_PROF(1, phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art));
+        if (b.tid == 0) *req_n = 0;
+        b.sync();
+        OCTA_PROF(2, phase_pre(b, A, B.C, P, 0, A.oxy, reqs, req_n, REQ_PER_SAMPLE, s));
+        mail_roundtrip(b, A, M, s, *req_n, 2 * it + 1);
+        if (uniform_err(b, A)) break;
+        OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, results));
+        OCTA_PROF(4, phase_satisfy_art(b, A, P));
+        OCTA_PROF(6, phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven));
+        if (b.tid == 0) *req_n = 0;
+        b.sync();
+        OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, reqs, req_n, REQ_PER_SAMPLE, s));
+        mail_roundtrip(b, A, M, s, *req_n, 2 * it + 2);
+    }
+}
+
 }  // namespace
 
 struct octa_sim {
@@ -280,6 +370,8 @@ struct octa_sim {
     BifRequest *h_reqs = nullptr;   // pinned [2*REQ_CAP]
     double *h_results = nullptr;    // pinned [2*REQ_CAP*6]
     int *h_req_count = nullptr;     // pinned [2]
+    HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr};  // pinned mailbox of the persistent form
+    bool lockstep = false;          // OCTA_SIM_LOCKSTEP=1: two launches per iteration (the round-1 form)
     bool ran = false;
     // host copies for export
     std::vector<SampleScalars> h_sc;
@@ -348,7 +440,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     rc |= dev_alloc(S, &P.kd_idx, nb * OCAP); rc |= dev_alloc(S, &P.kd_rank, nb * OCAP);
     rc |= dev_alloc(S, &P.removed, nb * OCAP); rc |= dev_alloc(S, &P.ven_near, nb * OCAP); rc |= dev_alloc(S, &P.hashes, nb * OCAP);
     rc |= dev_alloc(S, &P.pairs, nb * PCAP); rc |= dev_alloc(S, &P.set_hash, nb * SETCAP); rc |= dev_alloc(S, &P.set_key, nb * SETCAP);
-    rc |= dev_alloc(S, &P.grid_start, nb * (GRID_MAX * GRID_MAX + 1)); rc |= dev_alloc(S, &P.grid_items, nb * NCAP);
+    rc |= dev_alloc(S, &P.grid_pts, nb * GRID_N * 3);
     rc |= dev_alloc(S, &P.tmp_int, nb * (OCAP + 2 * NCANDCAP)); rc |= dev_alloc(S, &P.tmp_dbl, nb * OCAP * 3);
     rc |= dev_alloc(S, &P.sc, nb); rc |= dev_alloc(S, &P.iters, S->iters.size() + 1);
     rc |= dev_alloc(S, &P.reqs, (size_t)2 * REQ_CAP); rc |= dev_alloc(S, &P.req_count, 4); rc |= dev_alloc(S, &P.bif_results, (size_t)2 * REQ_CAP * 6);
@@ -359,6 +451,20 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
         hipError_t e2 = hipHostMalloc((void **)&S->h_results, sizeof(double) * 2 * REQ_CAP * 6);
         hipError_t e3 = hipHostMalloc((void **)&S->h_req_count, sizeof(int) * 4);
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { octa::set_error("octa_sim_create: hipHostMalloc failed"); rc = -1; }
+    }
+    if (!rc) {
+        const unsigned fl = hipHostMallocCoherent | hipHostMallocMapped;
+        hipError_t e1 = hipHostMalloc((void **)&S->mail.reqs, sizeof(BifRequest) * nb * REQ_PER_SAMPLE, fl);
+        hipError_t e2 = hipHostMalloc((void **)&S->mail.results, sizeof(double) * nb * REQ_PER_SAMPLE * 6, fl);
+        hipError_t e3 = hipHostMalloc((void **)&S->mail.req_n, sizeof(int) * nb * 3, fl);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { octa::set_error("octa_sim_create: hipHostMalloc (mailbox) failed"); rc = -1; }
+        else { S->mail.req_ticket = S->mail.req_n + nb; S->mail.resp_ticket = S->mail.req_n + 2 * nb; }
+        const char *ls = getenv("OCTA_SIM_LOCKSTEP");
+        S->lockstep = ls && ls[0] == '1';
+    }
+    if (!rc) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIM_LDS);
+        if (e != hipSuccess) { octa::set_error("octa_sim_create: cannot reserve %zu B of LDS: %s", SIM_LDS, hipGetErrorString(e)); rc = -1; }
     }
     if (!rc) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_iter_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIM_LDS);
@@ -378,6 +484,9 @@ extern "C" void octa_sim_destroy(octa_sim *S) {
     if (S->h_reqs) e = hipHostFree(S->h_reqs);
     if (S->h_results) e = hipHostFree(S->h_results);
     if (S->h_req_count) e = hipHostFree(S->h_req_count);
+    if (S->mail.reqs) e = hipHostFree(S->mail.reqs);
+    if (S->mail.results) e = hipHostFree(S->mail.results);
+    if (S->mail.req_n) e = hipHostFree(S->mail.req_n);
     for (int k = 0; k < 3; k++) if (S->ev[k]) e = hipEventDestroy(S->ev[k]);
     (void)e;
     delete S;
@@ -466,6 +575,52 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
     };
     S->ms_a = S->ms_b = S->ms_total = S->ms_host_bif = 0; S->n_a = S->n_b = S->n_bif_req = 0;
     auto wall0 = std::chrono::steady_clock::now();
+    if (!S->lockstep) {
+        // ---- persistent form: one launch, the host answers mailbox tickets until the kernel has finished
+        HostMail &M = S->mail;
+        for (int s = 0; s < 3 * B; s++) M.req_n[s] = 0;
+        std::vector<int> seen(B, 0);
+        OCTA_HIP_CHECK(hipEventRecord(S->ev[0], stream));
+        hipLaunchKernelGGL(sim_persistent_kernel, dim3((unsigned)B), dim3(SIM_THREADS), SIM_LDS, stream, P, M);
+        OCTA_HIP_CHECK(hipGetLastError());
+        OCTA_HIP_CHECK(hipEventRecord(S->ev[1], stream));
+        int idle = 0;
+        bool failed = false;
+        while (true) {
+            bool any = false;
+            for (int s = 0; s < B; s++) {
+                const int t = __atomic_load_n(M.req_ticket + s, __ATOMIC_ACQUIRE);
+                if (t == seen[s]) continue;
+                any = true;
+                int n = __atomic_load_n(M.req_n + s, __ATOMIC_RELAXED);
+                if (n > REQ_PER_SAMPLE) n = REQ_PER_SAMPLE;
+                if (n > 0) {
+                    auto t0 = std::chrono::steady_clock::now();
+                    bif(n, reinterpret_cast<const octa_bif_request *>(M.reqs + (size_t)s * REQ_PER_SAMPLE),
+                        M.results + (size_t)s * REQ_PER_SAMPLE * 6, user);
+                    S->ms_host_bif += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    S->n_bif_req += n;
+                }
+                __atomic_store_n(M.resp_ticket + s, t, __ATOMIC_RELEASE);
+                seen[s] = t;
+            }
+            if (any) { idle = 0; continue; }
+            if ((++idle & 63) == 0) {
+                hipError_t q = hipEventQuery(S->ev[1]);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) { octa::set_error("octa_sim_run: kernel failed: %s", hipGetErrorString(q)); failed = true; break; }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > 600.0) {
+                    octa::set_error("octa_sim_run: simulation kernel did not finish within 600 s"); failed = true; break;
+                }
+                if (idle > 4096) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+        }
+        if (failed) return -1;
+        float ms = 0;
+        OCTA_HIP_CHECK(hipEventSynchronize(S->ev[1]));
+        OCTA_HIP_CHECK(hipEventElapsedTime(&ms, S->ev[0], S->ev[1]));
+        S->ms_b = ms; S->n_b = 1;
+    } else
     for (int it = 0; it <= C.n_iter; it++) {
         float ms = 0;
         OCTA_HIP_CHECK(hipEventRecord(S->ev[0], stream));

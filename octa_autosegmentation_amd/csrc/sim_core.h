@@ -133,8 +133,7 @@ struct SimArrays {
     unsigned *pairs;     // [PCAP]
     unsigned long long *set_hash;  // [SETCAP]
     int *set_key;        // [SETCAP]
-    int *grid_start;     // [GRID_MAX*GRID_MAX + 1] cell offsets of the current uniform grid
-    int *grid_items;     // [NCAP] point ids sorted by cell
+    double *grid_pts;    // [GRID_N*3] coordinates of the current uniform grid's points, in cell order
     int *tmp_int;        // [OCAP + 2*NCANDCAP] general scratch
     double *tmp_dbl;     // [OCAP*3] general scratch (stable compaction staging)
     SampleScalars *sc;
@@ -333,6 +332,7 @@ struct PySetView {
     int *key;
     int mask, fill, used;
     int *err;
+    int cap;  // slots available in hash[] / key[]; the upper half is the resize staging area
 };
 OCTA_HD inline void pyset_init(PySetView &s) {
     for (int i = 0; i < 8; i++) s.key[i] = -1;
@@ -352,13 +352,13 @@ OCTA_HD inline void pyset_insert_clean(unsigned long long *h, int *k, int mask, 
         i = (i * 5 + 1 + perturb) & (unsigned long long)mask;
     }
 }
-// resize into the upper half of the scratch arrays, then move down (SETCAP bounds the table)
+// resize into the upper half of the scratch arrays, then move down (cap bounds the table)
 OCTA_HD inline void pyset_resize(PySetView &s, int minused) {
     int newsize = 8;
     while (newsize <= minused) newsize <<= 1;
-    if (newsize > SETCAP / 2) { atomic_or_int(s.err, ERR_SET_CAP); return; }
-    unsigned long long *nh = s.hash + SETCAP / 2;
-    int *nk = s.key + SETCAP / 2;
+    if (newsize > s.cap / 2) { atomic_or_int(s.err, ERR_SET_CAP); return; }
+    unsigned long long *nh = s.hash + s.cap / 2;
+    int *nk = s.key + s.cap / 2;
     for (int i = 0; i < newsize; i++) nk[i] = -1;
     for (int i = 0; i <= s.mask; i++)
         if (s.key[i] >= 0) pyset_insert_clean(nh, nk, newsize - 1, s.key[i], s.hash[i]);
@@ -807,14 +807,18 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
 
 // ------------------------------------------------------------------ uniform grid (LDS-binned counting sort)
 // Points are binned on (x, y) with a cell edge >= the query radius, so a radius query visits the
-// 3x3 cell neighbourhood. Cell offsets are built in LDS (histogram -> scan -> scatter) and kept in
-// HBM/L2 for the queries. Item order inside a cell is not defined; every consumer is order-free
-// (existence tests, arg-min with an explicit id tie-break, pair lists that are sorted afterwards).
+// 3x3 cell neighbourhood. Cell offsets and the id list stay in LDS (histogram -> scan -> scatter); the
+// coordinates are written to HBM scratch IN CELL ORDER, so a query reads three contiguous runs (one per
+// cell row) with independent loads instead of chasing start -> item -> point. Item order inside a cell
+// is not defined; every consumer is order-free (existence tests, arg-min with an explicit id tie-break,
+// pair lists that are sorted afterwards). The grid is valid until the next use of the LDS user area.
+constexpr int GRID_N = NCAP > OCAP ? NCAP : OCAP;  // points per grid
 struct Grid {
     int nx, ny;
     double x0, y0, inv;
-    const int *start;
-    const int *items;
+    const int *cell_end;           // LDS [nx*ny]: end offset of each cell (its start is the end of the previous cell)
+    const unsigned short *items;   // LDS [n]: point ids in cell order
+    const double *spts;            // HBM [n][3]: coordinates in cell order
 };
 OCTA_HD inline int grid_clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 OCTA_HD inline int grid_cx(const Grid &G, double x) { return grid_clampi((int)floor((x - G.x0) * G.inv), G.nx - 1); }
@@ -829,9 +833,12 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
     if (nc < 1) nc = 1;
     if (nc > GRID_MAX) nc = GRID_MAX;
     G.nx = G.ny = nc; G.x0 = G.y0 = -0.1; G.inv = 1.0 / cell;
-    G.start = A.grid_start; G.items = A.grid_items;
     const int ncell = nc * nc;
     int *hist = reinterpret_cast<int *>(b.user());  // [ncell + 1]
+    unsigned short *items = reinterpret_cast<unsigned short *>(b.user() + (size_t)(GRID_MAX * GRID_MAX + 1) * 4);  // [GRID_N]
+    static_assert((size_t)(GRID_MAX * GRID_MAX + 1) * 4 + (size_t)GRID_N * 2 + 2048 <= (size_t)SIM_LDS_BYTES, "grid LDS layout");
+    G.cell_end = hist; G.items = items; G.spts = A.grid_pts;
+    if (n > GRID_N) n = GRID_N;
     b.sync();
     for (int c = b.tid; c <= ncell; c += b.nth) hist[c] = 0;
     b.sync();
@@ -849,23 +856,29 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
         int ex;
         blk_scan(b, local, &ex);
         int run = ex;
-        for (int c = c0; c < c1; c++) { int v = hist[c]; hist[c] = run; A.grid_start[c] = run; run += v; }
+        for (int c = c0; c < c1; c++) { int v = hist[c]; hist[c] = run; run += v; }
     }
     b.sync();
     for (int i = b.tid; i < n; i += b.nth) {
         int id = ids ? ids[i] : i;
-        const double *p = pts + 3 * id;
-        int pos = atomic_add_int(&hist[grid_cy(G, p[1]) * nc + grid_cx(G, p[0])], 1);
-        A.grid_items[pos] = id;
+        const V3 p = ld3(pts + 3 * id);
+        int pos = atomic_add_int(&hist[grid_cy(G, p.y) * nc + grid_cx(G, p.x)], 1);  // hist[c] ends as the END of cell c
+        items[pos] = (unsigned short)id;
+        st3(A.grid_pts + 3 * pos, p);
     }
     b.sync();
     return G;
 }
-#define OCTA_GRID_FOR(G, px, py, radius, ITEM)                                                   \
-    for (int _cy = grid_cy(G, (py) - (radius)), _cy1 = grid_cy(G, (py) + (radius)); _cy <= _cy1; _cy++)   \
-        for (int _cx = grid_cx(G, (px) - (radius)), _cx1 = grid_cx(G, (px) + (radius)); _cx <= _cx1; _cx++) \
-            for (int _k = (G).start[_cy * (G).nx + _cx], _k1 = (G).start[_cy * (G).nx + _cx + 1]; _k < _k1; _k++) \
-                for (int ITEM = (G).items[_k], _once = 1; _once; _once = 0)
+// visits every point of the cells overlapping [px-radius, px+radius] x [py-radius, py+radius]:
+// ITEM = point id, PT = its coordinates (V3)
+#define OCTA_GRID_FOR(G, px, py, radius, ITEM, PT)                                                              \
+    for (int _cy = grid_cy(G, (py) - (radius)), _cy1 = grid_cy(G, (py) + (radius)),                               \
+             _cx0 = grid_cx(G, (px) - (radius)), _cx1 = grid_cx(G, (px) + (radius)); _cy <= _cy1; _cy++)          \
+        for (int _c0 = _cy * (G).nx + _cx0, _k = _c0 ? (G).cell_end[_c0 - 1] : 0,                                \
+                 _k1 = (G).cell_end[_cy * (G).nx + _cx1]; _k < _k1; _k++)                                         \
+            for (int _once = 1; _once;)                                                                           \
+                for (const V3 PT = ld3((G).spts + 3 * _k); _once;)                                                \
+                    for (const int ITEM = (int)(G).items[_k]; _once; _once = 0)
 
 // ------------------------------------------------------------------ Murray propagation (one thread)
 // dirty list of the ordered pass: inter-node groups that did not sprout under the speculation but whose
@@ -1098,9 +1111,9 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
         for (int vi = b.tid; vi < n_valid; vi += b.nth) {
             V3 c = ld3(cand + 3 * vlist[vi]);
             bool ok = true;
-            OCTA_GRID_FOR(G, c.x, c.y, en, j) {
+            OCTA_GRID_FOR(G, c.x, c.y, en, j, q) {
                 if (ok) {
-                    double d2 = sqdist(ld3(A.npos[0] + 3 * j), c);
+                    double d2 = sqdist(q, c);
                     if (d2 <= en2 && !(sqrt(d2) > oxd[j])) ok = false;
                 }
             }
@@ -1114,8 +1127,9 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
             if (!okf[vi]) continue;
             V3 c = ld3(cand + 3 * vlist[vi]);
             bool ok = true;
-            OCTA_GRID_FOR(G, c.x, c.y, es, j) {
-                if (ok && sqrt(sqdist(ld3(A.oxy + 3 * j), c)) <= es) ok = false;
+            OCTA_GRID_FOR(G, c.x, c.y, es, j, q) {
+                (void)j;
+                if (ok && sqrt(sqdist(q, c)) <= es) ok = false;
             }
             okf[vi] = ok ? 1 : 0;
         }
@@ -1200,13 +1214,12 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
     b.sync();
     {
         Grid G = grid_build(b, A, A.npos[f], A.act_list, n_act, delta);
-        const double *np_ = A.npos[f];
         for (int a = b.tid; a < n_att; a += b.nth) {
             V3 p = ld3(att + 3 * a);
             double bd = INFINITY;
             int best = -1;
-            OCTA_GRID_FOR(G, p.x, p.y, delta, j) {
-                double d2 = sqdist(ld3(np_ + 3 * j), p);
+            OCTA_GRID_FOR(G, p.x, p.y, delta, j, q) {
+                double d2 = sqdist(q, p);
                 if (d2 < bd || (d2 == bd && j < best)) { bd = d2; best = j; }
             }
             int r = (best >= 0 && sqrt(bd) <= delta) ? best : -1;
@@ -1630,8 +1643,8 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
         Grid G = grid_build(b, A, A.npos[0], new_ids, n_new, ek);
         for (int o = b.tid; o < n_oxy; o += b.nth) {
             V3 p = ld3(A.oxy + 3 * o);
-            OCTA_GRID_FOR(G, p.x, p.y, ek, j) {
-                if (sqdist(p, ld3(A.npos[0] + 3 * j)) <= ek2) {
+            OCTA_GRID_FOR(G, p.x, p.y, ek, j, q) {
+                if (sqdist(p, q) <= ek2) {
                     int q = atomic_add_int(&ctl[0], 1);
                     if (q < PCAP) A.pairs[q] = ((unsigned)(j - nb) << 14) | (unsigned)o;
                     A.removed[o] = 1;
@@ -1662,8 +1675,9 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
             if (!A.removed[o]) continue;
             V3 p = ld3(A.oxy + 3 * o);
             bool near = false;
-            OCTA_GRID_FOR(G, p.x, p.y, ek, j) {
-                if (!near && sqrt(sqdist(ld3(A.npos[1] + 3 * j), p)) <= ek) near = true;
+            OCTA_GRID_FOR(G, p.x, p.y, ek, j, q) {
+                (void)j;
+                if (!near && sqrt(sqdist(q, p)) <= ek) near = true;
             }
             A.ven_near[o] = near ? 1 : 0;
             A.hashes[o] = py_hash_tuple3(p);
@@ -1681,10 +1695,62 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
     for (int i = b.tid; i < n_pairs; i += b.nth) A.pairs[i] = keys[i];
     b.sync();
     OCTA_SUBPROF(sc, 13, t0);
-    // 5. CPython set insertion order -> CO2 append order (one thread)
-    if (b.tid == 0) {
+    // 5. CPython set insertion order -> CO2 append order
+    bool set_in_lds = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Usual case (<= LSET_PAIRS hits): the insert stream (sink, hash) is compacted into LDS in parallel, the
+    // open-addressing table lives in LDS too (a table never exceeds 8 x its entries), one thread replays the
+    // insertions, and the occupied slots are read out in slot order by the whole block.
+    constexpr int LSET_PAIRS = 512, LSET_CAP = 8192;
+    if (n_pairs <= LSET_PAIRS && n_pairs <= b.nth) {
+        set_in_lds = true;
+        unsigned long long *t_hash = reinterpret_cast<unsigned long long *>(b.user());        // [LSET_CAP]
+        int *t_key = reinterpret_cast<int *>(t_hash + LSET_CAP);                               // [LSET_CAP]
+        unsigned long long *in_hash = reinterpret_cast<unsigned long long *>(t_key + LSET_CAP);  // [LSET_PAIRS]
+        int *in_key = reinterpret_cast<int *>(in_hash + LSET_PAIRS);                           // [LSET_PAIRS]
+        int o = -1, take = 0;
+        if (b.tid < n_pairs) {
+            o = (int)A.kd_idx[A.pairs[b.tid] & 16383u];
+            take = A.ven_near[o] ? 0 : 1;
+        }
+        int ex;
+        const int n_ins = blk_scan(b, take, &ex);
+        if (take) { in_key[ex] = o; in_hash[ex] = A.hashes[o]; }
+        b.sync();
+        int *ctl2 = b.coll() + 100;
+        if (b.tid == 0) {
+            PySetView S;
+            S.hash = t_hash; S.key = t_key; S.err = &sc->err; S.cap = LSET_CAP;
+            pyset_init(S);
+            for (int i = 0; i < n_ins; i++) pyset_add(S, in_key[i], in_hash[i]);
+            ctl2[1] = S.mask;
+        }
+        b.sync();
+        const int mask = ctl2[1];
+        const int n_co2_0 = sc->n_co2;
+        int base = 0;
+        for (int e0 = 0; e0 <= mask; e0 += b.nth) {
+            const int e = e0 + b.tid;
+            const int k = (e <= mask) ? t_key[e] : -1;
+            int ex2;
+            const int tot = blk_scan(b, k >= 0 ? 1 : 0, &ex2);
+            if (k >= 0) {
+                const int dst = n_co2_0 + base + ex2;
+                if (dst < CCAP) { A.co2[3 * dst] = A.oxy[3 * k]; A.co2[3 * dst + 1] = A.oxy[3 * k + 1]; A.co2[3 * dst + 2] = A.oxy[3 * k + 2]; }
+            }
+            base += tot;
+        }
+        b.sync();
+        if (b.tid == 0) {
+            int n_co2 = n_co2_0 + base;
+            if (n_co2 > CCAP) { sc->err |= ERR_CO2_CAP; n_co2 = CCAP; }
+            sc->n_co2 = n_co2;
+        }
+    }
+#endif
+    if (!set_in_lds && b.tid == 0) {
         PySetView S;
-        S.hash = A.set_hash; S.key = A.set_key; S.err = &sc->err;
+        S.hash = A.set_hash; S.key = A.set_key; S.err = &sc->err; S.cap = SETCAP;
         pyset_init(S);
         for (int i = 0; i < n_pairs; i++) {
             int o = (int)A.kd_idx[A.pairs[i] & 16383u];
@@ -1725,8 +1791,9 @@ OCTA_HD inline void phase_satisfy_ven(const Blk &b, const SimArrays &A, const It
         for (int o = b.tid; o < n_co2; o += b.nth) {
             V3 p = ld3(A.co2 + 3 * o);
             bool hit = false;
-            OCTA_GRID_FOR(G, p.x, p.y, ek, j) {
-                if (!hit && sqdist(p, ld3(A.npos[1] + 3 * j)) <= ek2) hit = true;
+            OCTA_GRID_FOR(G, p.x, p.y, ek, j, q) {
+                (void)j;
+                if (!hit && sqdist(p, q) <= ek2) hit = true;
             }
             A.removed[o] = hit ? 1 : 0;
         }

@@ -52,7 +52,7 @@ long octa_simcore_set_order(const double *tuples, const int *ids, int n_ins, int
     std::vector<int> k(SETCAP);
     int err = 0;
     PySetView S;
-    S.hash = h.data(); S.key = k.data(); S.err = &err;
+    S.hash = h.data(); S.key = k.data(); S.err = &err; S.cap = (int)k.size();
     pyset_init(S);
     for (int i = 0; i < n_ins; i++) pyset_add(S, ids[i], py_hash_tuple3(v3(tuples[3 * ids[i]], tuples[3 * ids[i] + 1], tuples[3 * ids[i] + 2])));
     long c = 0;
@@ -98,8 +98,8 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
             add_node(A, f, ld3(&S.pos[f][6 * t + 3]), C.r, root, 4.0);
         }
     std::vector<double> oxy((size_t)OCAP * 3), co2((size_t)CCAP * 3), cand((size_t)NCANDCAP * 3), tmp_dbl((size_t)OCAP * 3);
-    std::vector<int> grid_start(GRID_MAX * GRID_MAX + 1), grid_items(NCAP);
-    A.grid_start = grid_start.data(); A.grid_items = grid_items.data();
+    std::vector<double> grid_pts((size_t)GRID_N * 3);
+    A.grid_pts = grid_pts.data();
     std::vector<int> nn(OCAP), first_att(NCAP), act_list(NCAP), gnode(GCAP), gstart(GCAP), gcount(GCAP), set_key(SETCAP), tmp_int(OCAP + 2 * NCANDCAP);
     std::vector<unsigned> sorted(SORTCAP), pairs(PCAP);
     std::vector<Rec> rec(GCAP);

@@ -16,7 +16,7 @@ for rep in range(2):
     torch.cuda.synchronize(); dt = time.time() - t
     print(f"sim B={B} I={i1}+{i2}: {dt:.3f} s -> {B/dt:.1f} samples/s; edges/sample {np.diff(res.edge_off).mean():.0f}; "
           f"stats err={res.stats[:,0].max()} draws~{res.stats[:,1].mean():.0f} murray~{res.stats[:,2].mean():.0f} bif~{res.stats[:,3].mean():.1f} respec~{res.stats[:,4].mean():.0f}")
-    names = ["sample", "assign_art", "pre_art", "seq_art", "satisfy_art", "-", "assign_ven", "pre_ven", "seq_ven", "satisfy_ven"]
+    names = ["sample", "assign_art", "pre_art", "seq_art", "satisfy_art", "host_wait", "assign_ven", "pre_ven", "seq_ven", "satisfy_ven"]
     prof = res.stats[:, 8:18].mean(axis=0) / 1e5  # ms
     sub = res.stats[:, 18:24].mean(axis=0) / 1e5
     print("  candidates=%.0f | satisfy_art: kd=%.0f pairs+ven=%.0f sort=%.0f set=%.0f compact=%.0f" % tuple(sub))
