@@ -1,4 +1,5 @@
 """ctypes binding of liboctahip.so (include/octa_hip.h). Fails loudly when the library is missing."""
+import contextlib
 import ctypes
 import os
 import threading
@@ -76,10 +77,45 @@ def check(rc, what):
         raise OctaHipError(f"{what} failed (rc={rc}): {msg}")
 
 
-def ctx(device_index=None):
-    """Context (grow-only device scratch) for one GPU, one per calling THREAD: an octa_ctx must not be used from
-    two threads at once (include/octa_hip.h), and pipelines keep several steps in flight from a thread pool."""
+_tls = threading.local()
+
+
+def new_ctx(device_index=None):
+    """A private context (own grow-only scratch); the owner frees it with free_ctx()."""
     import torch
+    if not torch.cuda.is_available():
+        raise OctaHipError("no ROCm GPU visible to torch; the HIP path cannot run (no CPU fallback)")
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    out = c_void_p()
+    check(lib().octa_ctx_create(int(device_index), ctypes.byref(out)), "octa_ctx_create")
+    return out
+
+
+def free_ctx(h):
+    if h is not None:
+        lib().octa_ctx_destroy(h)
+
+
+@contextlib.contextmanager
+def use_ctx(h):
+    """Route every ctx() lookup of the calling thread to `h` (a pipeline slot keeps its own scratch, whichever
+    pool thread happens to run it)."""
+    prev = getattr(_tls, "ctx", None)
+    _tls.ctx = h
+    try:
+        yield h
+    finally:
+        _tls.ctx = prev
+
+
+def ctx(device_index=None):
+    """Context (grow-only device scratch) for one GPU, one per calling THREAD unless use_ctx() is active: an
+    octa_ctx must not be used from two threads at once (include/octa_hip.h), and pipelines keep several steps in
+    flight from a thread pool."""
+    import torch
+    if getattr(_tls, "ctx", None) is not None:
+        return _tls.ctx
     if not torch.cuda.is_available():
         raise OctaHipError("no ROCm GPU visible to torch; the HIP path cannot run (no CPU fallback)")
     if device_index is None:

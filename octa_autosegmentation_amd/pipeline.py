@@ -12,7 +12,7 @@ Mirrors what the reference produces with
 """
 import numpy as np
 
-from . import graph_io
+from . import _native, graph_io
 from .vessel_graph_generation import greenhouse, tree2img
 
 
@@ -23,6 +23,7 @@ class TripleGenerator:
         self.batch = int(batch)
         self.device = torch.device("cuda", torch.cuda.current_device() if device_index is None else device_index)
         self.sim = greenhouse.BatchSimulator(config, batch, self.device.index)
+        self._ctx = _native.new_ctx(self.device.index)   # this slot's rasteriser scratch
         g, o = config["Greenhouse"], config.get("output", {})
         shape = np.array([g["SimulationSpace"][k] for k in ("no_voxel_x", "no_voxel_y", "no_voxel_z")])
         vol = [int(d) for d in shape * o.get("image_scale_factor", 304)]          # generate_vessel_graph.py:43
@@ -32,11 +33,19 @@ class TripleGenerator:
 
     def close(self):
         self.sim.close()
+        if self._ctx is not None:
+            _native.free_ctx(self._ctx)
+            self._ctx = None
 
     def generate(self, seeds, want_label=True):
         """Returns dict(result=SimulationResult, image=uint8 CUDA [B,H,W], label=uint8 CUDA {0,255} [B,1216,1216])."""
         import torch
         res = self.sim.run(seeds)
+        with _native.use_ctx(self._ctx):
+            return self._render(res, want_label)
+
+    def _render(self, res, want_label):
+        import torch
         B = self.batch
         off, n_art = res.edge_off, res.n_art
         d_edges = torch.from_numpy(res.edges).to(self.device, non_blocking=True)

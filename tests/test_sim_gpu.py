@@ -91,3 +91,17 @@ def test_device_kd_order_matches_scipy(hip_lib_built):
         out = np.zeros(n, np.int32)
         _native.check(L.octa_sim_kat_kd_order(ctx, pts.ctypes.data, n, None, out.ctypes.data), "octa_sim_kat_kd_order")
         assert (out == cKDTree(pts).indices).all(), n
+
+
+def test_lockstep_and_persistent_forms_agree(gh, golden, monkeypatch):
+    """The persistent kernel (default) and the two-launches-per-iteration form run the same phases."""
+    from octa_autosegmentation_amd import graph_io
+    cfg = _cfg(golden, 12, 9)
+    seeds = np.arange(6) + 40
+    a = gh.simulate_batch(cfg, seeds)
+    monkeypatch.setenv("OCTA_SIM_LOCKSTEP", "1")
+    b = gh.simulate_batch(cfg, seeds)
+    monkeypatch.delenv("OCTA_SIM_LOCKSTEP")
+    assert a.timing["launches_a"] == 0 and b.timing["launches_a"] > 0
+    assert (a.edge_off == b.edge_off).all()
+    assert a.edges.tobytes() == b.edges.tobytes()
