@@ -29,6 +29,25 @@ ALGO_BYTES_PER_SAMPLE = 84e6       # point traffic of one full-l
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def pmc_traffic_per_launch(kernel_name):
+    """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 counter passes
+    (profiles/r01_bench_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this
+    bench, values in KB). Correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 128-B requests as 64 B on
+    gfx950, so it is doubled; WRITE_SIZE is taken as reported. None if the file or the kernel is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+    kb = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if kernel_name in r["kernel"]:
+                kb[r["counter"]] = float(r["avg_KB_per_launch"])
+    if "FETCH_SIZE" not in kb or "WRITE_SIZE" not in kb:
+        return None
+    return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+
+
 def load_config():
     import yaml
     g = np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
@@ -205,7 +224,9 @@ def main():
                                    f"I=100+150, N=2000) + tree2img rasterise 304x304 image and 1216x1216 label",
                        "batch_per_gpu": B, "steps_in_flight": n_fly, "parallelism": f"sample-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(dom_name),
+                         "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_bench_pmc_summary.csv)",
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
                          "note": note},
             "kernel_ms_per_step": {"sim_iter_a": ka / args.steps, dom_name if la == 0 else "sim_iter_b": kb / args.steps,

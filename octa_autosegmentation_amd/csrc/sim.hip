@@ -533,23 +533,31 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
         std::vector<int> Ns(S->iters.size() + 1, 0);
         for (size_t i = 0; i < S->iters.size(); i++) Ns[i] = S->iters[i].N;
         OCTA_HIP_CHECK(hipMemcpyAsync(P.n_per_iter, Ns.data(), sizeof(int) * Ns.size(), hipMemcpyHostToDevice, stream));
-        // stump nodes: root (kappa 4, no parent) + one child per tree
-        std::vector<double> rad((size_t)n0, C.r), kap((size_t)n0, 4.0);
-        std::vector<int> par(n0), c0(n0), c1(n0, -1);
-        std::vector<unsigned char> nch(n0), act(n0, 1);
-        for (int i = 0; i < n0; i++) { par[i] = (i & 1) ? i - 1 : -1; c0[i] = (i & 1) ? -1 : i + 1; nch[i] = (i & 1) ? 0 : 1; }
+        // stump nodes: root (kappa 4, no parent) + one child per tree; one strided copy per array puts the
+        // n0 leading entries of every sample's slice in place
+        std::vector<double> rad((size_t)B * n0, C.r), kap((size_t)B * n0, 4.0);
+        std::vector<int> par((size_t)B * n0), c0((size_t)B * n0), c1((size_t)B * n0, -1);
+        std::vector<unsigned char> nch((size_t)B * n0), act((size_t)B * n0, 1);
+        for (size_t k = 0; k < (size_t)B * n0; k++) {
+            const int i = (int)(k % n0);
+            par[k] = (i & 1) ? i - 1 : -1; c0[k] = (i & 1) ? -1 : i + 1; nch[k] = (i & 1) ? 0 : 1;
+        }
+        std::vector<double> pos_f((size_t)B * n0 * 3);
+        auto put = [&](void *dst, size_t elem, const void *src, size_t per_sample_cap, size_t count) -> hipError_t {
+            return hipMemcpy2DAsync(dst, per_sample_cap * elem, src, count * elem, count * elem, (size_t)B, hipMemcpyHostToDevice, stream);
+        };
         for (int f = 0; f < 2; f++) {
             OCTA_HIP_CHECK(hipMemsetAsync(P.nact[f], 0, (size_t)B * NCAP, stream));
-            for (int s = 0; s < B; s++) {
-                OCTA_HIP_CHECK(hipMemcpyAsync(P.npos[f] + (size_t)s * NCAP * 3, &npos[((size_t)s * 2 + f) * n0 * 3], sizeof(double) * n0 * 3, hipMemcpyHostToDevice, stream));
-                OCTA_HIP_CHECK(hipMemcpyAsync(P.nrad[f] + (size_t)s * NCAP, rad.data(), sizeof(double) * n0, hipMemcpyHostToDevice, stream));
-                OCTA_HIP_CHECK(hipMemcpyAsync(P.nkap[f] + (size_t)s * NCAP, kap.data(), sizeof(double) * n0, hipMemcpyHostToDevice, stream));
-                OCTA_HIP_CHECK(hipMemcpyAsync(P.npar[f] + (size_t)s * NCAP, par.data(), sizeof(int) * n0, hipMemcpyHostToDevice, stream));
-                OCTA_HIP_CHECK(hipMemcpyAsync(P.nch0[f] + (size_t)s * NCAP, c0.data(), sizeof(int) * n0, hipMemcpyHostToDevice, stream));
-                OCTA_HIP_CHECK(hipMemcpyAsync(P.nch1[f] + (size_t)s * NCAP, c1.data(), sizeof(int) * n0, hipMemcpyHostToDevice, stream));
-                OCTA_HIP_CHECK(hipMemcpyAsync(P.nnch[f] + (size_t)s * NCAP, nch.data(), n0, hipMemcpyHostToDevice, stream));
-                OCTA_HIP_CHECK(hipMemcpyAsync(P.nact[f] + (size_t)s * NCAP, act.data(), n0, hipMemcpyHostToDevice, stream));
-            }
+            for (int s = 0; s < B; s++) memcpy(&pos_f[(size_t)s * n0 * 3], &npos[((size_t)s * 2 + f) * n0 * 3], sizeof(double) * n0 * 3);
+            OCTA_HIP_CHECK(put(P.npos[f], sizeof(double), pos_f.data(), (size_t)NCAP * 3, (size_t)n0 * 3));
+            OCTA_HIP_CHECK(hipStreamSynchronize(stream));  // pos_f is reused for the second forest
+            OCTA_HIP_CHECK(put(P.nrad[f], sizeof(double), rad.data(), NCAP, n0));
+            OCTA_HIP_CHECK(put(P.nkap[f], sizeof(double), kap.data(), NCAP, n0));
+            OCTA_HIP_CHECK(put(P.npar[f], sizeof(int), par.data(), NCAP, n0));
+            OCTA_HIP_CHECK(put(P.nch0[f], sizeof(int), c0.data(), NCAP, n0));
+            OCTA_HIP_CHECK(put(P.nch1[f], sizeof(int), c1.data(), NCAP, n0));
+            OCTA_HIP_CHECK(put(P.nnch[f], 1, nch.data(), NCAP, n0));
+            OCTA_HIP_CHECK(put(P.nact[f], 1, act.data(), NCAP, n0));
         }
         OCTA_HIP_CHECK(hipMemsetAsync(P.req_count, 0, sizeof(int) * 4, stream));
         OCTA_HIP_CHECK(hipMemsetAsync(P.child_group, 0, sizeof(int) * (size_t)B * NCAP, stream));

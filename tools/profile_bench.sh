@@ -1,0 +1,40 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
+#   1. --kernel-trace --stats of the default bench command        -> gpurun_out/r02_bench_kernel_stats.csv
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, one counter per pass -> gpurun_out/r02_bench_pmc_summary.csv
+# (counter passes never combined with tracing: see the task's profiling rules)
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+TAG=${1:-r02}
+OUT=gpurun_out
+mkdir -p $OUT
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py > $OUT/${TAG}_bench_stdout.log 2>&1
+find $OUT/prof_kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
+grep '"metric"' $OUT/${TAG}_bench_stdout.log | tail -1 > $OUT/${TAG}_bench_line.json
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-train > $OUT/${TAG}_pmc_$C.log 2>&1
+done
+python - "$OUT" "$TAG" <<'PY'
+import csv, glob, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+rows = []
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(f"{out}/prof_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != c:
+                continue
+            k = r["Kernel_Name"].replace(",", ";")[:90]
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+    for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        rows.append((c, k, n, round(v, 1), round(v / max(n, 1), 1)))
+with open(f"{out}/{tag}_bench_pmc_summary.csv", "w") as f:
+    f.write("counter,kernel,launches,sum_KB,avg_KB_per_launch\n")
+    for r in rows:
+        f.write('%s,"%s",%d,%s,%s\n' % r)
+print("pmc rows:", len(rows))
+PY
+head -12 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-200
+head -8 $OUT/${TAG}_bench_pmc_summary.csv
+cut -c1-300 $OUT/${TAG}_bench_line.json
