@@ -40,6 +40,7 @@ constexpr int WG = 1024;        // threads per render workgroup
 constexpr int EPT = 4;          // edges tested per thread per scan round
 constexpr int LIST_CAP = 1024;  // edges per chunk
 constexpr int SLOT_CAP = 5120;  // int4 side slots per chunk (80 KiB)
+constexpr int ITEM_CAP = 256;   // (side, scanline) work items of one edge inside one wave's block
 
 // ---- kernel 1: per-edge record ---------------------------------------------------------------
 
@@ -56,12 +57,124 @@ raster_meta_kernel(const double *__restrict__ edges, const unsigned char *__rest
     bbox[i] = b;
 }
 
-// ---- kernel 2: render ------------------------------------------------------------------------
+// ---- kernels 2-4: side offsets (exclusive scan of nv + EXTRA_SLOTS) and tessellation, once per edge ----
+
+constexpr int SCAN_EPT = 4;                    // elements per thread
+constexpr int SCAN_BLK = 1024 * SCAN_EPT;      // elements per scan block
+
+__device__ __forceinline__ int edge_slots(const EdgeMeta &m) { return m.nv > 0 ? m.nv + EXTRA_SLOTS : 0; }
+
+__global__ void __launch_bounds__(1024)
+raster_scan_block_kernel(const EdgeMeta *__restrict__ meta, long n_total, int *__restrict__ off, int *__restrict__ block_sums) {
+    __shared__ int s_w[17];
+    const long base = (long)blockIdx.x * SCAN_BLK + (long)threadIdx.x * SCAN_EPT;
+    int v[SCAN_EPT], sum = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_EPT; q++) {
+        v[q] = (base + q < n_total) ? edge_slots(meta[base + q]) : 0;
+        sum += v[q];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int u = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += u;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = 0; k < 16; k++) { int t = s_w[k]; s_w[k] = run; run += t; }
+        s_w[16] = run;
+    }
+    __syncthreads();
+    int run = s_w[wv] + inc - sum;
+#pragma unroll
+    for (int q = 0; q < SCAN_EPT; q++) {
+        if (base + q < n_total) off[base + q] = run;
+        run += v[q];
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[16];
+}
+
+// exclusive scan of the block sums by one workgroup; total (int64) -> total_out[0]; > INT_MAX sets err
+__global__ void __launch_bounds__(1024)
+raster_scan_sums_kernel(int *__restrict__ block_sums, int nb, long *__restrict__ total_out, int *__restrict__ err_flag) {
+    __shared__ long s_w[17];
+    __shared__ long s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < nb; c0 += 1024) {
+        const int i = c0 + (int)threadIdx.x;
+        const long v = i < nb ? (long)block_sums[i] : 0;
+        long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            long u = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += u;
+        }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long run = s_carry;
+            for (int k = 0; k < 16; k++) { long t = s_w[k]; s_w[k] = run; run += t; }
+            s_w[16] = run;
+        }
+        __syncthreads();
+        const long ex = s_w[wv] + inc - v;
+        if (i < nb) {
+            if (ex > 0x7fffffffL) atomicExch(err_flag, 3);
+            block_sums[i] = (int)ex;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = s_w[16];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total_out[0] = s_carry;
+}
+
+// one thread per edge: the stroke polygon's sides, clipped and converted to 24.8 fixed point, into the edge's
+// nv + EXTRA_SLOTS slots (side k in slot k, extra clip pieces behind them, unused slots zero)
+__global__ void __launch_bounds__(256)
+raster_tess_kernel(const EdgeMeta *__restrict__ meta, const int *__restrict__ off, const int *__restrict__ block_sums,
+                   long n_total, int W, int H, int4 *__restrict__ sides, int *__restrict__ err_flag) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    const EdgeMeta m = meta[i];
+    if (m.nv <= 0) return;
+    int4 *out = sides + ((long)off[i] + (long)block_sums[i / SCAN_BLK]);
+    const int nv = m.nv;
+    for (int k = nv; k < nv + EXTRA_SLOTS; k++) out[k] = make_int4(0, 0, 0, 0);
+    const double ddx = m.x1 - m.x0, ddy = m.y1 - m.y0;
+    const double len = sqrt(ddx * ddx + ddy * ddy);
+    double fx, fy;
+    stroke_vertex(m, len, 0, &fx, &fy);
+    double ax = fx, ay = fy;
+    int extra = 0;
+    for (int v = 1; v <= nv; v++) {
+        double bx = fx, by = fy;
+        if (v < nv) stroke_vertex(m, len, v, &bx, &by);
+        SideSink sink;
+        sink.n = 0;
+        clip_side(sink, (double)W, (double)H, ax, ay, bx, by);
+        out[v - 1] = sink.n > 0 ? sink.piece[0] : make_int4(0, 0, 0, 0);
+        for (int q = 1; q < sink.n; q++) {
+            if (extra < EXTRA_SLOTS) out[nv + extra++] = sink.piece[q];
+            else atomicExch(err_flag, 2);
+        }
+        ax = bx; ay = by;
+    }
+}
+
+// ---- kernel 5: render ------------------------------------------------------------------------
 
 struct ListEntry {
     int edge;       // edge index inside the graph
     int slot_off;   // first LDS slot
     int nv;         // polygon sides (primary slots)
+    int side_off;   // first slot of the edge in the global side array
     BBox16 bb;
     float ax, ay, vx, vy;  // segment start and direction (pixels), for the conservative miss test
     float inv_len2, reach; // 1/|v|^2 and half width + margin
@@ -97,11 +210,12 @@ __device__ __forceinline__ void block_scan2(int a, int b, int *sh /*[2*16+2]*/, 
 
 __global__ void __launch_bounds__(WG)
 raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict__ bbox,
-                     const long *__restrict__ edge_off, int W, int H, int tiles_x, int tiles_y,
+                     const long *__restrict__ edge_off, const int4 *__restrict__ sides, const int *__restrict__ side_off,
+                     const int *__restrict__ side_block_sums, int W, int H, int tiles_x, int tiles_y,
                      unsigned char *__restrict__ out, int *__restrict__ err_flag) {
     __shared__ int4 s_slots[SLOT_CAP];
     __shared__ ListEntry s_list[LIST_CAP];
-    __shared__ int s_extra[LIST_CAP];
+    __shared__ unsigned short s_owner[(WG / 64) * ITEM_CAP];
     __shared__ int s_scan[34];
     __shared__ int s_ctl[4];  // 0: first overflow edge, 1: list_n, 2: slots_n
 
@@ -164,6 +278,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                         le.slot_off = sp;
                         le.nv = cnt[q] - EXTRA_SLOTS;
                         le.bb = bb[q];
+                        le.side_off = side_off[e_begin + e0 + q] + side_block_sums[(e_begin + e0 + q) / SCAN_BLK];
                         {
                             const EdgeMeta &em = gm[e0 + q];
                             float vx = (float)(em.x1 - em.x0), vy = (float)(em.y1 - em.y0);
@@ -173,7 +288,6 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                             le.reach = (float)em.w + 0.25f;
                         }
                         s_list[pos] = le;
-                        s_extra[pos] = 0;
                     } else {
                         atomicMin(&s_ctl[0], e0 + q);
                     }
@@ -211,51 +325,32 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 2), (unsigned long long)(_t - _tp)); _tp = _t; }
         if (list_n == 0) continue;
 
-        // ---- phase 2: tessellate + clip the stroke polygons into LDS side slots
-        for (int i = threadIdx.x; i < slots_n; i += WG) s_slots[i] = make_int4(0, 0, 0, 0);
-        __syncthreads();
-        {
-            // total primary work items = sum nv; map item -> (entry, side) by binary search on slot_off
-            for (int item = threadIdx.x; item < slots_n; item += WG) {
-                int lo = 0, hi = list_n - 1;
-                while (lo < hi) {
-                    int mid = (lo + hi + 1) >> 1;
-                    if (s_list[mid].slot_off <= item) lo = mid; else hi = mid - 1;
-                }
-                const ListEntry le = s_list[lo];
-                int sidx = item - le.slot_off;
-                if (sidx >= le.nv) continue;
-                const EdgeMeta m = gm[le.edge];
-                double ddx = m.x1 - m.x0, ddy = m.y1 - m.y0;
-                double len = sqrt(ddx * ddx + ddy * ddy);
-                double ax, ay, bx, by;
-                stroke_vertex(m, len, sidx, &ax, &ay);
-                stroke_vertex(m, len, (sidx + 1 == le.nv) ? 0 : sidx + 1, &bx, &by);
-                SideSink sink;
-                sink.n = 0;
-                clip_side(sink, (double)W, (double)H, ax, ay, bx, by);
-                int4 *slots = s_slots + le.slot_off;
-                for (int q = 0; q < sink.n; q++) {
-                    if (q == 0) {
-                        slots[sidx] = sink.piece[0];
-                    } else {
-                        int k = atomicAdd(&s_extra[lo], 1);
-                        if (k < EXTRA_SLOTS) slots[le.nv + k]= sink.piece[q];
-                        else atomicExch(err_flag, 2);
-                    }
-                }
+        // ---- phase 2: copy the tessellated sides of the listed edges into LDS (16 B per lane, coalesced per edge)
+        for (int item = threadIdx.x; item < slots_n; item += WG) {
+            int lo = 0, hi = list_n - 1;
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (s_list[mid].slot_off <= item) lo = mid; else hi = mid - 1;
             }
+            s_slots[item] = sides[(long)s_list[lo].side_off + (item - s_list[lo].slot_off)];
         }
         __syncthreads();
 
         if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 4), (unsigned long long)(_t - _tp)); _tp = _t; }
-        // ---- phase 3: ordered fold of the edges over this wave's 16x16 block
+        // ---- phase 3: ordered fold of the edges over this wave's 16x16 block.
+        // Per edge the work items are (polygon side, scanline) pairs: lane = side counts the rows of its side
+        // inside the block, a wave prefix sum lays the items out, lane = item computes the scanline piece
+        // ONCE (the two 64-bit floor divisions of Agg's outer DDA), per-row ballots tell every pixel lane
+        // which items lie in its row, and it adds their cells with the cheap inner divisions. Integer sums,
+        // so the order of the items is irrelevant; very wide strokes fall back to the side loop.
+        unsigned short *w_owner = s_owner + wv * ITEM_CAP;
+        const int myrow = lane / (16 / NPX);
         for (int i = 0; i < list_n; i++) {
             const ListEntry le = s_list[i];
             // wave-uniform reject
             if (le.bb.x1 < bx0 || le.bb.x0 > bx0 + 15 || le.bb.y1 < by0 || le.bb.y0 > by0 + BLK_H - 1) continue;
-            if (prow < le.bb.y0 || prow > le.bb.y1 || pcol + NPX - 1 < le.bb.x0 || pcol > le.bb.x1) continue;
-            {
+            bool touch = !(prow < le.bb.y0 || prow > le.bb.y1 || pcol + NPX - 1 < le.bb.x0 || pcol > le.bb.x1);
+            if (touch) {
                 // the NPX x 1 pixel span of this lane cannot be touched if its centre is farther from the
                 // segment than half width + half diagonal of the span + slack for the fp32 test,
                 // the 1/256 vertex rounding and the snap of axis-aligned paths (already in ax..vy)
@@ -264,25 +359,82 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                 t = fminf(fmaxf(t, 0.f), 1.f);
                 float ex = cx - t * le.vx, ey = cy - t * le.vy;
                 float lim = le.reach + 0.5f * sqrtf((float)(NPX * NPX + 1)) + 0.01f;
-                if (ex * ex + ey * ey > lim * lim) continue;
+                if (ex * ex + ey * ey > lim * lim) touch = false;
             }
+            if (!__any(touch)) continue;
             int C[NPX], A[NPX];
 #pragma unroll
             for (int q = 0; q < NPX; q++) { C[q] = 0; A[q] = 0; }
             const int ns = le.nv + EXTRA_SLOTS;
             const int4 *sl = s_slots + le.slot_off;
-            for (int k = 0; k < ns; k++) {
-                int4 s = sl[k];
-                if (s.y == s.w) continue;
-                side_eval<NPX>(s, prow, pcol, C, A);
-            }
+            bool done = false;
+            if (ns <= 64) {
+                int r0 = 0, nr = 0;
+                if (lane < ns) {
+                    const int4 sd = sl[lane];
+                    if (sd.y != sd.w) {
+                        const int ey1 = sd.y >> 8, ey2 = sd.w >> 8;
+                        int lo = ey1 < ey2 ? ey1 : ey2, hi = ey1 < ey2 ? ey2 : ey1;
+                        const int xmin = (sd.x < sd.z ? sd.x : sd.z) >> 8;  // pieces right of the block add nothing
+                        lo = lo > by0 ? lo : by0;
+                        hi = hi < by0 + BLK_H - 1 ? hi : by0 + BLK_H - 1;
+                        if (hi >= lo && xmin <= bx0 + 15) { r0 = lo - by0; nr = hi - lo + 1; }
+                    }
+                }
+                int inc = nr;
 #pragma unroll
-            for (int q = 0; q < NPX; q++) {
-                int v = (C[q] << 9) - A[q];
-                int c = v >> 9;
-                if (c < 0) c = -c;
-                if (c > 255) c = 255;
-                pix[q] = blend_white(pix[q], (unsigned)c);
+                for (int d = 1; d < 64; d <<= 1) {
+                    int u = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc += u;
+                }
+                const int total = __shfl(inc, 63, 64);
+                if (total <= ITEM_CAP) {
+                    done = true;
+                    const int ex0 = inc - nr;
+                    for (int t = 0; t < nr; t++) w_owner[ex0 + t] = (unsigned short)((lane << 8) | (r0 + t));
+                    __builtin_amdgcn_wave_barrier();
+                    for (int base = 0; base < total; base += 64) {
+                        int hx1 = 0, hy1 = 0, hx2 = 0, hy2 = 0, irow = -1;
+                        if (base + lane < total) {
+                            const unsigned ow = w_owner[base + lane];
+                            const int r = (int)(ow & 255u);
+                            if (side_row_piece(sl[ow >> 8], by0 + r, hx1, hy1, hx2, hy2)) irow = r;
+                        }
+                        unsigned long long mine = 0;
+#pragma unroll
+                        for (int r = 0; r < BLK_H; r++) {
+                            const unsigned long long bm = __ballot(irow == r);
+                            if (myrow == r) mine = bm;
+                        }
+                        if (!touch) mine = 0;
+                        while (__any(mine != 0)) {
+                            const int j = mine ? (int)__ffsll((long long)mine) - 1 : 0;
+                            const int a = __shfl(hx1, j, 64), bq = __shfl(hy1, j, 64), c = __shfl(hx2, j, 64), d = __shfl(hy2, j, 64);
+                            if (mine) {
+                                hline_eval<NPX>(a, bq, c, d, pcol, C, A);
+                                mine &= mine - 1ull;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (!done && touch) {
+                for (int k = 0; k < ns; k++) {
+                    int4 s = sl[k];
+                    if (s.y == s.w) continue;
+                    side_eval<NPX>(s, prow, pcol, C, A);
+                }
+            }
+            if (touch) {
+#pragma unroll
+                for (int q = 0; q < NPX; q++) {
+                    int v = (C[q] << 9) - A[q];
+                    int c = v >> 9;
+                    if (c < 0) c = -c;
+                    if (c > 255) c = 255;
+                    pix[q] = blend_white(pix[q], (unsigned)c);
+                }
             }
         }
         __syncthreads();
@@ -444,16 +596,34 @@ extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, co
     if (ctx->r_counters.reserve(sizeof(long) * 8)) return -1;
     OCTA_HIP_CHECK(hipMemcpyAsync(ctx->r_edge_off.p, h_edge_off, sizeof(long) * (B + 1), hipMemcpyHostToDevice, stream));
     OCTA_HIP_CHECK(hipMemsetAsync(ctx->r_counters.p, 0, sizeof(long) * 8, stream));
+    const int nb = (int)((n_total + SCAN_BLK - 1) / SCAN_BLK);
+    if (ctx->r_tile_count.reserve(sizeof(int) * (size_t)(n_total + 1))) return -1;   // per-edge side offsets (block-local)
+    if (ctx->r_seg_total.reserve(sizeof(int) * (size_t)(nb + 1))) return -1;          // scan block sums -> bases
+    long total_sides = 0;
     if (n_total > 0) {
         dim3 g((unsigned)((n_total + 255) / 256));
         hipLaunchKernelGGL(raster_meta_kernel, g, dim3(256), 0, stream, d_edges, d_keep, n_total, W, H, ax_x, ax_y,
                            min_radius, max_radius, ctx->r_edge_meta.as<EdgeMeta>(), ctx->r_ucount.as<BBox16>());
+        hipLaunchKernelGGL(raster_scan_block_kernel, dim3((unsigned)nb), dim3(1024), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(),
+                           n_total, ctx->r_tile_count.as<int>(), ctx->r_seg_total.as<int>());
+        hipLaunchKernelGGL(raster_scan_sums_kernel, dim3(1), dim3(1024), 0, stream, ctx->r_seg_total.as<int>(), nb,
+                           ctx->r_counters.as<long>() + 4, ctx->r_counters.as<int>());
+        OCTA_HIP_CHECK(hipGetLastError());
+        // the side array is sized from the scan total: one 8-byte read-back per call on this stream
+        OCTA_HIP_CHECK(hipMemcpyAsync(&total_sides, ctx->r_counters.as<long>() + 4, sizeof(long), hipMemcpyDeviceToHost, stream));
+        OCTA_HIP_CHECK(hipStreamSynchronize(stream));
+        if (total_sides > 0x7fffffffL) { octa::set_error("octa_rasterize_2d: %ld polygon sides exceed the 32-bit offset range", total_sides); return -2; }
+        if (ctx->r_sides.reserve(sizeof(int4) * (size_t)(total_sides + 1))) return -1;
+        hipLaunchKernelGGL(raster_tess_kernel, g, dim3(256), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(), ctx->r_tile_count.as<int>(),
+                           ctx->r_seg_total.as<int>(), n_total, W, H, ctx->r_sides.as<int4>(), ctx->r_counters.as<int>());
+    } else {
+        if (ctx->r_sides.reserve(sizeof(int4))) return -1;
     }
     const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST_Y - 1) / ST_Y;
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)B);
     hipLaunchKernelGGL(raster_render_kernel, grid, dim3(WG), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(),
-                       ctx->r_ucount.as<BBox16>(), ctx->r_edge_off.as<long>(), W, H, tiles_x, tiles_y, d_out,
-                       ctx->r_counters.as<int>());
+                       ctx->r_ucount.as<BBox16>(), ctx->r_edge_off.as<long>(), ctx->r_sides.as<int4>(), ctx->r_tile_count.as<int>(),
+                       ctx->r_seg_total.as<int>(), W, H, tiles_x, tiles_y, d_out, ctx->r_counters.as<int>());
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }

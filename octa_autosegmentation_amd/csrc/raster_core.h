@@ -304,6 +304,16 @@ OCTA_HD inline void hline_eval(int hx1, int hy1, int hx2, int hy2, int px0, int 
     const int ex1 = hx1 >> 8, ex2 = hx2 >> 8;
     const int fx1 = hx1 & 255, fx2 = hx2 & 255;
     const int dy = hy2 - hy1;
+    if (ex1 == ex2) {
+        // the piece stays inside one cell (most sides of a round cap): no boundary crossing, no division
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const int px = px0 + q;
+            if (px >= ex1) C[q] += dy;
+            if (px == ex1) A[q] += (fx1 + fx2) * dy;
+        }
+        return;
+    }
     int Y[NP + 1];
     if (hx2 >= hx1) {
         // cells ex1 .. ex2 left to right; boundary xb lies between cells xb-1 and xb
@@ -352,20 +362,20 @@ OCTA_HD inline void hline_eval(int hx1, int hy1, int hx2, int hy2, int px0, int 
     }
 }
 
-// One polygon side (24.8 fixed point) for scanline py and NP adjacent pixels.
-template <int NP>
-OCTA_HD inline void side_eval(int4 s, int py, int px0, int (&C)[NP], int (&A)[NP]) {
+// The piece of one polygon side (24.8 fixed point) that lies in scanline py, in Agg's render_hline terms:
+// from (hx1, hy1) to (hx2, hy2) with hy in [0, 256]. Returns false if the side does not touch the scanline
+// or the piece has no vertical extent (it then contributes nothing).
+OCTA_HD inline bool side_row_piece(int4 s, int py, int &hx1, int &hy1, int &hx2, int &hy2) {
     const int x1 = s.x, y1 = s.y, x2 = s.z, y2 = s.w;
     const int ey1 = y1 >> 8, ey2 = y2 >> 8;
     const int lo = ey1 < ey2 ? ey1 : ey2, hi = ey1 < ey2 ? ey2 : ey1;
-    if (py < lo || py > hi) return;
+    if (py < lo || py > hi) return false;
     const int fy1 = y1 & 255, fy2 = y2 & 255;
     if (ey1 == ey2) {
-        hline_eval<NP>(x1, fy1, x2, fy2, px0, C, A);
-        return;
+        hx1 = x1; hy1 = fy1; hx2 = x2; hy2 = fy2;
+        return hy1 != hy2;
     }
     const long dx = (long)x2 - (long)x1;
-    int hx1, hy1, hx2, hy2;
     if (y2 > y1) {
         const long dy = (long)y2 - (long)y1;
         const int K = ey2 - ey1, k = py - ey1;
@@ -381,7 +391,14 @@ OCTA_HD inline void side_eval(int4 s, int py, int px0, int (&C)[NP], int (&A)[NP
         hx2 = (k == K) ? x2 : x1 + floordiv_prod(fy1 + 256 * k, dx, dy);
         hy2 = (k == K) ? fy2 : 0;
     }
-    hline_eval<NP>(hx1, hy1, hx2, hy2, px0, C, A);
+    return hy1 != hy2;
+}
+
+// One polygon side for scanline py and NP adjacent pixels.
+template <int NP>
+OCTA_HD inline void side_eval(int4 s, int py, int px0, int (&C)[NP], int (&A)[NP]) {
+    int hx1, hy1, hx2, hy2;
+    if (side_row_piece(s, py, hx1, hy1, hx2, hy2)) hline_eval<NP>(hx1, hy1, hx2, hy2, px0, C, A);
 }
 
 // matplotlib fixed_blender_rgba_plain: white with coverage alpha over an opaque grey p
