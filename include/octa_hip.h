@@ -120,6 +120,19 @@ int octa_instnorm_lrelu_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, co
                             const float *d_mean, const float *d_rstd, void *d_dx, float *d_dw, float *d_db, int B, int C,
                             int64_t hw, int dtype, float slope, void *stream);
 
+/* ---- 3x3 convolution on the matrix cores, NHWC bf16 (fp32 accumulate) --------------------
+ * Replaces the bias-free 3x3 convolutions of DynUNet's UnetBasicBlock / UnetUpBlock (MONAI, imported at
+ * models/networks.py:6; configs/config_ves_seg-S.yml:6-13: filters [32,64,128,256,512], strides [1,2,2,2,1])
+ * in models/base_model_abc.py:152-167 (octa_conv2d_{fwd,dgrad}).
+ * d_x: [N][H][W][Cin] bf16, d_w: [9][Cout][Cin] bf16 (tap = 3*r + s major, Cin fastest), d_y: [N][Ho][Wo][Cout]
+ * bf16; padding 1; stride 1 or 2. in_dilation 2 reads d_x through a virtual zero insertion (x[i/2] at even
+ * virtual positions, 0 elsewhere; virtual size 2H x 2W): with flipped + transposed weights that is the
+ * data gradient of a stride-2 layer, with in_dilation 1 that of a stride-1 layer.
+ * Ho = (H*in_dilation - 1) / stride + 1 (likewise Wo). Cin and Cout must be multiples of 32.
+ */
+int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin,
+                          int Cout, int stride, int in_dilation, void *stream);
+
 /* ---- N1-N4: space-colonisation vessel-graph simulator --------------------
  * Replaces, for B independent samples advanced in lock-step on the GPU:
  *   vessel_graph_generation/greenhouse.py:57-137 (Greenhouse.develop_forest) with
