@@ -133,6 +133,13 @@ int octa_instnorm_lrelu_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, co
 int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin,
                           int Cout, int stride, int in_dilation, void *stream);
 
+/* Weight gradient of the stride-1 layer above: d_dw [9][Cout][Cin] float32 (overwritten) =
+ * sum over pixels of d_dy[N][H][W][Cout] (bf16) x d_x[N][H][W][Cin] (bf16) shifted by the tap (SURVEY.md 8b:
+ * octa_conv2d_wgrad). fp32 accumulation; partial sums of the persistent workgroups meet in fp32 atomics, so the
+ * last bits depend on the arrival order. */
+int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin,
+                            int Cout, void *stream);
+
 /* ---- N1-N4: space-colonisation vessel-graph simulator --------------------
  * Replaces, for B independent samples advanced in lock-step on the GPU:
  *   vessel_graph_generation/greenhouse.py:57-137 (Greenhouse.develop_forest) with

@@ -42,6 +42,7 @@ SIGNATURES = {
     "octa_sim_timing": (c_int, [c_void_p, c_void_p]),
     "octa_sim_fields": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, ctypes.c_int64, c_void_p]),
     "octa_conv3x3_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "octa_conv3x3_nhwc_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_sim_kat_kd_order": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]),
 }
 

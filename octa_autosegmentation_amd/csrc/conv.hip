@@ -165,3 +165,137 @@ extern "C" int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void 
     return wide ? launch_conv<64, 2>(X, Wt, Y, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream)
                 : launch_conv<32, 2>(X, Wt, Y, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream);
 }
+
+// ---- weight gradient (stride 1) ----------------------------------------------------------------------------------
+// dW[tap][co][ci] = sum over pixels p of dY[p][co] * X[p + tap - (1,1)][ci]: a GEMM whose contraction index is
+// the PIXEL, while NHWC memory is contiguous in the channel. The tiles are therefore transposed on their way
+// into LDS (16-byte global loads of 8 channels, eight 2-byte LDS stores each), so that an MFMA operand -- 8
+// consecutive pixels of one channel -- is one aligned ds_read_b128; the +-1 pixel shift of the taps s = 0, 2
+// is a funnel shift of five dwords in registers. One workgroup = 4 waves works on COB x CIB channels: every
+// wave owns one 32 x 32 (co, ci) pair and all nine taps (144 accumulator registers) over a share of the tile's
+// rows; workgroups are persistent over the pixel tiles and add their fp32 partial sums to dW with atomics once.
+namespace {
+
+constexpr int WG_ROWP = TW * 2 * TH;   // bytes per channel row of the transposed dY tile (256 pixels)
+constexpr int HALO_W = 40;             // halo row pitch in pixels (34 used; 80 B keeps rows 16-byte aligned)
+constexpr int WG_XROW = (TH + 2) * HALO_W * 2;  // bytes per channel row of the transposed X tile
+
+template <int COB, int CIB>
+__global__ void __launch_bounds__(CONV_THREADS)
+conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ dY, float *__restrict__ dW,
+                          int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y) {
+    constexpr int PAIRS = (COB / 32) * (CIB / 32);
+    constexpr int KSPLIT = 4 / PAIRS;            // waves sharing one (co, ci) pair split the tile rows
+    constexpr int ROWS_PER_WAVE = TH / KSPLIT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *s_dy = smem;                       // [COB][256 px] bf16
+    unsigned char *s_x = smem + COB * WG_ROWP;        // [CIB][TH+2][HALO_W] bf16
+    const int co0 = (blockIdx.y / (Cin / CIB)) * COB, ci0 = (blockIdx.y % (Cin / CIB)) * CIB;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pair = wv % PAIRS, kpart = wv / PAIRS;
+    const int cob = (pair % (COB / 32)) * 32, cib = (pair / (COB / 32)) * 32;
+    const int m = lane & 31, kg = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[t][k] = 0.f;
+    const int n_tiles = tiles_x * tiles_y * N;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int n = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
+        const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
+        __syncthreads();
+        // dY tile, transposed: 8 channels of one pixel per load
+        for (int i = threadIdx.x; i < TH * TW * (COB / 8); i += CONV_THREADS) {
+            const int p = i / (COB / 8), q = i % (COB / 8);
+            const int y = ty0 + p / TW, x = tx0 + p % TW;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (y < H && x < W) v = *reinterpret_cast<const uint4 *>(dY + (((size_t)n * H + y) * W + x) * Cout + co0 + q * 8);
+            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                *reinterpret_cast<unsigned short *>(s_dy + (q * 8 + j) * WG_ROWP + p * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+        }
+        // X halo tile, transposed
+        for (int i = threadIdx.x; i < (TH + 2) * (TW + 2) * (CIB / 8); i += CONV_THREADS) {
+            const int p = i / (CIB / 8), q = i % (CIB / 8);
+            const int hy = p / (TW + 2), hx = p % (TW + 2);
+            const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (y >= 0 && y < H && x >= 0 && x < W) v = *reinterpret_cast<const uint4 *>(X + (((size_t)n * H + y) * W + x) * Cin + ci0 + q * 8);
+            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                *reinterpret_cast<unsigned short *>(s_x + (q * 8 + j) * WG_XROW + (hy * HALO_W + hx) * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+        }
+        __syncthreads();
+        // contraction over this wave's rows: K-steps of 16 consecutive pixels of one tile row
+#pragma unroll 1
+        for (int rr = 0; rr < ROWS_PER_WAVE; rr++) {
+            const int y = kpart * ROWS_PER_WAVE + rr;
+#pragma unroll
+            for (int xs = 0; xs < TW; xs += 16) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_dy + (cob + m) * WG_ROWP + (y * TW + xs + kg * 8) * 2);
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    // halo columns xs + kg*8 + s .. +7 of halo row y + r: aligned 8-pixel group + the next dword
+                    const unsigned char *row = s_x + (cib + m) * WG_XROW + ((y + r) * HALO_W + xs + kg * 8) * 2;
+                    const uint4 d = *reinterpret_cast<const uint4 *>(row);
+                    const unsigned e = *reinterpret_cast<const unsigned *>(row + 16);
+                    union { uint4 u; bf16x8 v; } b0, b1, b2;
+                    b0.u = d;
+                    b1.u = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
+                                      __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
+                    b2.u = make_uint4(d.y, d.z, d.w, e);
+                    acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0.v, acc[3 * r + 0], 0, 0, 0);
+                    acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1.v, acc[3 * r + 1], 0, 0, 0);
+                    acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2.v, acc[3 * r + 2], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D[row = co][col = ci]: row = (k&3) + 8*(k>>2) + 4*kg, col = m
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int co = co0 + cob + (k & 3) + 8 * (k >> 2) + 4 * kg;
+            atomicAdd(dW + ((size_t)t * Cout + co) * Cin + ci0 + cib + m, acc[t][k]);
+        }
+}
+
+template <int COB, int CIB>
+int launch_wgrad(const unsigned short *X, const unsigned short *dY, float *dW, int N, int H, int W, int Cin, int Cout, int num_cus,
+                 hipStream_t stream) {
+    const size_t lds = (size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int blocks = (Cout / COB) * (Cin / CIB);
+    int per_block = (2 * num_cus + blocks - 1) / blocks;
+    const int n_tiles = tiles_x * tiles_y * N;
+    if (per_block > n_tiles) per_block = n_tiles;
+    if (per_block < 1) per_block = 1;
+    auto kern = conv3x3_nhwc_wgrad_kernel<COB, CIB>;
+    OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, dY, dW, N, H, W, Cin, Cout,
+                       tiles_x, tiles_y);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin,
+                                       int Cout, void *stream_) {
+    if (!ctx || !d_x || !d_dy || !d_dw) { octa::set_error("octa_conv3x3_nhwc_wgrad: null pointer"); return -2; }
+    if (N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_nhwc_wgrad: bad shape"); return -2; }
+    if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_wgrad: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 9 * (size_t)Cout * Cin, stream));
+    const unsigned short *X = static_cast<const unsigned short *>(d_x), *dY = static_cast<const unsigned short *>(d_dy);
+    const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0;
+    if (co64 && ci64) return launch_wgrad<64, 64>(X, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
+    if (co64) return launch_wgrad<64, 32>(X, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
+    if (ci64) return launch_wgrad<32, 64>(X, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
+    return launch_wgrad<32, 32>(X, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
+}

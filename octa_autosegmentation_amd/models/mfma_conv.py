@@ -37,3 +37,17 @@ def conv3x3_nhwc(x, wt, stride=1, in_dilation=1):
                                              int(stride), int(in_dilation), _native.current_stream_ptr())
     _native.check(rc, "octa_conv3x3_nhwc_fwd")
     return y
+
+
+def conv3x3_nhwc_wgrad(x, dy):
+    """x [N,H,W,Cin] bf16, dy [N,H,W,Cout] bf16 (stride-1 layer) -> dW as a torch conv weight gradient
+    [Cout, Cin, 3, 3] float32."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and dy.dtype == torch.bfloat16 and dy.is_contiguous()
+    n, h, w, cin = x.shape
+    assert dy.shape[:3] == x.shape[:3]
+    cout = dy.shape[3]
+    dw = torch.empty((9, cout, cin), dtype=torch.float32, device=x.device)
+    rc = _native.lib().octa_conv3x3_nhwc_wgrad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
+                                               ctypes.c_void_p(dw.data_ptr()), n, h, w, cin, cout, _native.current_stream_ptr())
+    _native.check(rc, "octa_conv3x3_nhwc_wgrad")
+    return dw.view(3, 3, cout, cin).permute(2, 3, 0, 1)

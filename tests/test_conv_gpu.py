@@ -55,3 +55,22 @@ def test_data_gradient_matches_torch(hip_lib_built, n, h, w, cin, cout, stride):
     got = mfma_conv.conv3x3_nhwc(dy_nhwc, mfma_conv.pack_weight_dgrad(wt), stride=1, in_dilation=stride)
     assert got.shape == want.shape
     _check(got, want)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(1, 16, 32, 32, 32), (2, 24, 40, 64, 64), (1, 37, 45, 64, 32), (2, 19, 70, 32, 64), (1, 8, 32, 128, 128)])
+def test_weight_gradient_matches_torch(hip_lib_built, n, h, w, cin, cout):
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.models import mfma_conv
+    g = torch.Generator(device="cuda").manual_seed(3 * h + cin)
+    x = torch.randn(n, cin, h, w, device="cuda", generator=g).to(torch.bfloat16)
+    wt = (torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (3.0 * cin ** 0.5)).float().requires_grad_(True)
+    y = F.conv2d(x.float(), wt, stride=1, padding=1)
+    dy = torch.randn(y.shape, device="cuda", generator=g).to(torch.bfloat16)
+    y.backward(dy.float())
+    got = mfma_conv.conv3x3_nhwc_wgrad(x.permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous())
+    want = wt.grad
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item()
+    assert err <= scale * 1e-4 + 1e-5, (err, scale)   # fp32 accumulation on exact bf16 products: order only
