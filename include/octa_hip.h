@@ -120,6 +120,14 @@ int octa_instnorm_lrelu_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, co
                             const float *d_mean, const float *d_rstd, void *d_dx, float *d_dw, float *d_db, int B, int C,
                             int64_t hw, int dtype, float slope, void *stream);
 
+/* Channels-last variants for the MFMA convolution path: activations [B][HW][C] bfloat16, C a multiple of 8
+ * (<= 512); same arithmetic and the same float32 statistics / affine gradients as the two functions above. */
+int octa_instnorm_lrelu_nhwc_fwd(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b, float *d_mean,
+                                 float *d_rstd, int B, int C, int64_t hw, float slope, float eps, void *stream);
+int octa_instnorm_lrelu_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, const float *d_w, const float *d_b,
+                                 const float *d_mean, const float *d_rstd, void *d_dx, float *d_dw, float *d_db, int B, int C,
+                                 int64_t hw, float slope, void *stream);
+
 /* ---- 3x3 convolution on the matrix cores, NHWC bf16 (fp32 accumulate) --------------------
  * Replaces the bias-free 3x3 convolutions of DynUNet's UnetBasicBlock / UnetUpBlock (MONAI, imported at
  * models/networks.py:6; configs/config_ves_seg-S.yml:6-13: filters [32,64,128,256,512], strides [1,2,2,2,1])
@@ -139,6 +147,13 @@ int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void 
  * last bits depend on the arrival order. */
 int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin,
                             int Cout, void *stream);
+
+/* 1x1 convolution head with ONE output channel and bias (DynUNet's UnetOutBlock, 32 -> 1; networks.py:6 / MONAI):
+ * y[p] = bias + sum_c x[p][c] w[c] over NHWC bf16 pixels (y bf16 [npix]); backward: dx[p][c] = dy[p] w[c] (bf16),
+ * dw[c] = sum_p x[p][c] dy[p], db = sum_p dy[p] (float32, overwritten). HBM-bound streaming kernels. */
+int octa_head1_nhwc_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, float bias, int64_t npix, int C, void *d_y, void *stream);
+int octa_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, const float *d_w, int64_t npix, int C, void *d_dx,
+                        float *d_dw, float *d_db, void *stream);
 
 /* ---- N1-N4: space-colonisation vessel-graph simulator --------------------
  * Replaces, for B independent samples advanced in lock-step on the GPU:

@@ -299,3 +299,104 @@ extern "C" int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const voi
     if (ci64) return launch_wgrad<32, 64>(X, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
     return launch_wgrad<32, 32>(X, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
 }
+
+// ---- 1x1 head with one output channel (UnetOutBlock, 32 -> 1 with bias): HBM-bound streaming kernels ----------
+namespace {
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// y[p] = b + sum_c x[p][c] w[c];  C multiple of 8, <= 256. One thread per pixel group of 16 bytes x (C/8).
+__global__ void __launch_bounds__(256)
+head1_fwd_kernel(const unsigned short *__restrict__ x, const float *__restrict__ w, float bias, long npix, int C,
+                 unsigned short *__restrict__ y) {
+    __shared__ float s_w[256];
+    for (int c = threadIdx.x; c < C; c += 256) s_w[c] = w[c];
+    __syncthreads();
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        float acc = bias;
+        const uint4 *px = reinterpret_cast<const uint4 *>(x + p * C);
+        for (int g = 0; g < C / 8; g++) {
+            const uint4 v = px[g];
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                acc += __uint_as_float(u[k] << 16) * s_w[g * 8 + 2 * k];
+                acc += __uint_as_float(u[k] & 0xffff0000u) * s_w[g * 8 + 2 * k + 1];
+            }
+        }
+        y[p] = f2bf(acc);
+    }
+}
+
+// dx[p][c] = dy[p] w[c];  dw[c] += sum_p x[p][c] dy[p];  db += sum_p dy[p]
+__global__ void __launch_bounds__(256)
+head1_bwd_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, const float *__restrict__ w, long npix,
+                 int C, unsigned short *__restrict__ dx, float *__restrict__ dw, float *__restrict__ db) {
+    __shared__ float s_w[256];
+    __shared__ float s_acc[257];
+    for (int c = threadIdx.x; c < C; c += 256) { s_w[c] = w[c]; s_acc[c] = 0.f; }
+    if (threadIdx.x == 0) s_acc[256] = 0.f;
+    __syncthreads();
+    // thread = (pixel lane, 8-channel group): consecutive threads cover one pixel's channels (coalesced)
+    const int groups = C / 8, cg = threadIdx.x % groups, pl = threadIdx.x / groups, npl = 256 / groups;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = 0.f;
+    float sdy = 0.f;
+    if (pl < npl) {
+        for (long p = (long)blockIdx.x * npl + pl; p < npix; p += (long)gridDim.x * npl) {
+            const float d = bf2f(dy[p]);
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + p * C + cg * 8);
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+            unsigned o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                a[2 * k] += __uint_as_float(u[k] << 16) * d;
+                a[2 * k + 1] += __uint_as_float(u[k] & 0xffff0000u) * d;
+                o[k] = (unsigned)f2bf(d * s_w[cg * 8 + 2 * k]) | ((unsigned)f2bf(d * s_w[cg * 8 + 2 * k + 1]) << 16);
+            }
+            *reinterpret_cast<uint4 *>(dx + p * C + cg * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+            if (cg == 0) sdy += d;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) atomicAdd(&s_acc[cg * 8 + k], a[k]);
+        if (cg == 0) atomicAdd(&s_acc[256], sdy);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&dw[c], s_acc[c]);
+    if (threadIdx.x == 0) atomicAdd(db, s_acc[256]);
+}
+
+}  // namespace
+
+extern "C" int octa_head1_nhwc_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, float bias, int64_t npix, int C, void *d_y,
+                                   void *stream_) {
+    if (!ctx || !d_x || !d_w || !d_y || npix <= 0 || C <= 0 || C % 8 || C > 256) { octa::set_error("octa_head1_nhwc_fwd: bad arguments (C must be a multiple of 8, <= 256)"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    long blocks = (npix + 255) / 256;
+    if (blocks > 16L * ctx->num_cus) blocks = 16L * ctx->num_cus;
+    hipLaunchKernelGGL(head1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const unsigned short *>(d_x), d_w, bias,
+                       (long)npix, C, static_cast<unsigned short *>(d_y));
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, const float *d_w, int64_t npix, int C, void *d_dx,
+                                   float *d_dw, float *d_db, void *stream_) {
+    if (!ctx || !d_x || !d_dy || !d_w || !d_dx || !d_dw || !d_db || npix <= 0 || C <= 0 || C % 8 || C > 256 || 256 % (C / 8)) {
+        octa::set_error("octa_head1_nhwc_bwd: bad arguments (C must be a multiple of 8 dividing 2048, <= 256)");
+        return -2;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
+    OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float), stream));
+    const int npl = 256 / (C / 8);
+    long blocks = (npix + npl - 1) / npl;
+    if (blocks > 8L * ctx->num_cus) blocks = 8L * ctx->num_cus;
+    hipLaunchKernelGGL(head1_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const unsigned short *>(d_x),
+                       static_cast<const unsigned short *>(d_dy), d_w, (long)npix, C, static_cast<unsigned short *>(d_dx), d_dw, d_db);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}

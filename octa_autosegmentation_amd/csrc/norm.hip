@@ -264,3 +264,220 @@ extern "C" int octa_instnorm_lrelu_bwd(octa_ctx *ctx, const void *d_x, const voi
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---- NHWC (channels-last) bf16 variants, for the MFMA convolution path (csrc/conv.hip) ------------------------
+// Activations [B][HW][C] bf16, C a multiple of 8. A thread owns 8 consecutive channels (one 16-byte access) of a
+// strided set of pixels; per-channel partial sums meet in LDS, then one double atomicAdd per channel and block
+// into sums[b][c][2]. The apply kernels read the finished sums, derive scale / shift per channel into LDS and
+// stream the image. Same arithmetic as the NCHW kernels above.
+namespace {
+
+constexpr int NHWC_MAXC = 512;
+
+__device__ __forceinline__ void nhwc_geometry(int C, int &cg, int &pl, int &npl) {
+    const int groups = C / 8;
+    cg = threadIdx.x % groups;
+    pl = threadIdx.x / groups;
+    npl = NT / groups;
+}
+
+// mode 0: (sum x, sum x^2); mode 1: (sum g, sum g*xhat) with g = dy * lrelu'(pre)
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+in_nhwc_stats(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, const float *__restrict__ w,
+              const float *__restrict__ bias, const float *__restrict__ mean, const float *__restrict__ rstd, long hw, int C,
+              int splits, float slope, double *__restrict__ sums) {
+    __shared__ float s_red[2 * NT * 8];
+    const int b = blockIdx.y, s = blockIdx.x;
+    int cg, pl, npl;
+    nhwc_geometry(C, cg, pl, npl);
+    const bool active = pl < npl && cg < C / 8;   // NT need not be a multiple of C/8
+    const long per = (hw + splits - 1) / splits;
+    const long p0 = (long)s * per, p1 = p0 + per < hw ? p0 + per : hw;
+    float a[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { a[k] = 0.f; q[k] = 0.f; }
+    float mu[8], rs[8], wc[8], bc[8];
+    if (MODE == 1 && active) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = cg * 8 + k;
+            mu[k] = mean[(long)b * C + c]; rs[k] = rstd[(long)b * C + c]; wc[k] = w ? w[c] : 1.f; bc[k] = bias ? bias[c] : 0.f;
+        }
+    }
+    if (active) {
+        const unsigned short *px = x + ((long)b * hw) * C + cg * 8;
+        const unsigned short *pd = MODE == 1 ? dy + ((long)b * hw) * C + cg * 8 : nullptr;
+        for (long p = p0 + pl; p < p1; p += npl) {
+            float v[8];
+            Vec<unsigned short>::load(px + p * C, v);
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) { a[k] += v[k]; q[k] += v[k] * v[k]; }
+            } else {
+                float d[8];
+                Vec<unsigned short>::load(pd + p * C, d);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float xh = (v[k] - mu[k]) * rs[k];
+                    const float g = (xh * wc[k] + bc[k]) > 0.f ? d[k] : d[k] * slope;
+                    a[k] += g; q[k] += g * xh;
+                }
+            }
+        }
+    }
+    // fold the pixel lanes of every channel group
+#pragma unroll
+    for (int k = 0; k < 8; k++) { s_red[(threadIdx.x * 8 + k) * 2] = a[k]; s_red[(threadIdx.x * 8 + k) * 2 + 1] = q[k]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+        const int g = c / 8, k = c % 8, groups = C / 8;
+        double sa = 0, sq = 0;
+        for (int l = 0; l < npl; l++) {
+            const int t = l * groups + g;
+            sa += s_red[(t * 8 + k) * 2]; sq += s_red[(t * 8 + k) * 2 + 1];
+        }
+        atomicAdd(&sums[((long)b * C + c) * 2], sa);
+        atomicAdd(&sums[((long)b * C + c) * 2 + 1], sq);
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+in_nhwc_fwd_apply(const unsigned short *__restrict__ x, unsigned short *__restrict__ y, const float *__restrict__ w,
+                  const float *__restrict__ bias, long hw, int C, int splits, const double *__restrict__ sums, float slope, float eps,
+                  float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+    __shared__ float s_g[NHWC_MAXC], s_sh[NHWC_MAXC];
+    const int b = blockIdx.y, s = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += NT) {
+        const double sa = sums[((long)b * C + c) * 2], sq = sums[((long)b * C + c) * 2 + 1];
+        const double mean_d = sa / (double)hw;
+        double var = sq / (double)hw - mean_d * mean_d;
+        if (var < 0) var = 0;
+        const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (s == 0) { mean_out[(long)b * C + c] = mean; rstd_out[(long)b * C + c] = rstd; }
+        const float g = w ? w[c] * rstd : rstd;
+        s_g[c] = g; s_sh[c] = (bias ? bias[c] : 0.f) - mean * g;
+    }
+    __syncthreads();
+    int cg, pl, npl;
+    nhwc_geometry(C, cg, pl, npl);
+    if (pl >= npl) return;
+    const long per = (hw + splits - 1) / splits;
+    const long p0 = (long)s * per, p1 = p0 + per < hw ? p0 + per : hw;
+    float g[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { g[k] = s_g[cg * 8 + k]; sh[k] = s_sh[cg * 8 + k]; }
+    const unsigned short *px = x + ((long)b * hw) * C + cg * 8;
+    unsigned short *py = y + ((long)b * hw) * C + cg * 8;
+    for (long p = p0 + pl; p < p1; p += npl) {
+        float v[8];
+        Vec<unsigned short>::load(px + p * C, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const float z = v[k] * g[k] + sh[k]; v[k] = z > 0.f ? z : z * slope; }
+        Vec<unsigned short>::store(py + p * C, v);
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+in_nhwc_bwd_apply(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, unsigned short *__restrict__ dx,
+                  const float *__restrict__ w, const float *__restrict__ bias, const float *__restrict__ mean,
+                  const float *__restrict__ rstd, long hw, int C, int splits, float slope, const double *__restrict__ sums,
+                  float *__restrict__ dw, float *__restrict__ db) {
+    __shared__ float s_mg[NHWC_MAXC], s_mgx[NHWC_MAXC];
+    const int b = blockIdx.y, s = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += NT) {
+        const double sa = sums[((long)b * C + c) * 2], sq = sums[((long)b * C + c) * 2 + 1];
+        if (s == 0) {
+            if (db) atomicAdd(&db[c], (float)sa);
+            if (dw) atomicAdd(&dw[c], (float)sq);
+        }
+        s_mg[c] = (float)(sa / (double)hw); s_mgx[c] = (float)(sq / (double)hw);
+    }
+    __syncthreads();
+    int cg, pl, npl;
+    nhwc_geometry(C, cg, pl, npl);
+    if (pl >= npl) return;
+    const long per = (hw + splits - 1) / splits;
+    const long p0 = (long)s * per, p1 = p0 + per < hw ? p0 + per : hw;
+    float mu[8], rs[8], wc[8], bc[8], mg[8], mgx[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int c = cg * 8 + k;
+        mu[k] = mean[(long)b * C + c]; rs[k] = rstd[(long)b * C + c]; wc[k] = w ? w[c] : 1.f; bc[k] = bias ? bias[c] : 0.f;
+        mg[k] = s_mg[c]; mgx[k] = s_mgx[c];
+    }
+    const unsigned short *px = x + ((long)b * hw) * C + cg * 8, *pd = dy + ((long)b * hw) * C + cg * 8;
+    unsigned short *po = dx + ((long)b * hw) * C + cg * 8;
+    for (long p = p0 + pl; p < p1; p += npl) {
+        float v[8], d[8];
+        Vec<unsigned short>::load(px + p * C, v);
+        Vec<unsigned short>::load(pd + p * C, d);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float xh = (v[k] - mu[k]) * rs[k];
+            const float g = (xh * wc[k] + bc[k]) > 0.f ? d[k] : d[k] * slope;
+            v[k] = wc[k] * rs[k] * (g - mg[k] - xh * mgx[k]);
+        }
+        Vec<unsigned short>::store(po + p * C, v);
+    }
+}
+
+int nhwc_splits(const octa_ctx *ctx, int B, long hw) {
+    long s = (4L * ctx->num_cus + B - 1) / B;
+    const long by_size = hw / 512 > 0 ? hw / 512 : 1;
+    if (s > by_size) s = by_size;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return (int)s;
+}
+
+int nhwc_check(const char *who, int B, int C, int64_t hw) {
+    if (B <= 0 || hw <= 0 || C <= 0 || C % 8 || C > NHWC_MAXC || NT % (C / 8) != 0 && C / 8 > NT) { octa::set_error("%s: C must be a multiple of 8, <= %d (got B=%d C=%d)", who, NHWC_MAXC, B, C); return -2; }
+    if (B > 65535) { octa::set_error("%s: B > 65535", who); return -2; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int octa_instnorm_lrelu_nhwc_fwd(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b,
+                                            float *d_mean, float *d_rstd, int B, int C, int64_t hw, float slope, float eps,
+                                            void *stream_) {
+    if (!ctx || !d_x || !d_y || !d_mean || !d_rstd) { octa::set_error("octa_instnorm_lrelu_nhwc_fwd: null pointer"); return -2; }
+    if (nhwc_check("octa_instnorm_lrelu_nhwc_fwd", B, C, hw)) return -2;
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->r_tile_total.reserve(sizeof(double) * 2 * (size_t)B * C)) return -1;
+    double *sums = ctx->r_tile_total.as<double>();
+    OCTA_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, stream));
+    const int splits = nhwc_splits(ctx, B, hw);
+    dim3 grid((unsigned)splits, (unsigned)B);
+    const unsigned short *x = static_cast<const unsigned short *>(d_x);
+    hipLaunchKernelGGL(in_nhwc_stats<0>, grid, dim3(NT), 0, stream, x, (const unsigned short *)nullptr, d_w, d_b, (const float *)nullptr,
+                       (const float *)nullptr, (long)hw, C, splits, slope, sums);
+    hipLaunchKernelGGL(in_nhwc_fwd_apply, grid, dim3(NT), 0, stream, x, static_cast<unsigned short *>(d_y), d_w, d_b, (long)hw, C, splits,
+                       sums, slope, eps, d_mean, d_rstd);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_instnorm_lrelu_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, const float *d_w, const float *d_b,
+                                            const float *d_mean, const float *d_rstd, void *d_dx, float *d_dw, float *d_db, int B,
+                                            int C, int64_t hw, float slope, void *stream_) {
+    if (!ctx || !d_x || !d_dy || !d_dx || !d_mean || !d_rstd) { octa::set_error("octa_instnorm_lrelu_nhwc_bwd: null pointer"); return -2; }
+    if (nhwc_check("octa_instnorm_lrelu_nhwc_bwd", B, C, hw)) return -2;
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->r_tile_total.reserve(sizeof(double) * 2 * (size_t)B * C)) return -1;
+    double *sums = ctx->r_tile_total.as<double>();
+    OCTA_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, stream));
+    if (d_dw) OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
+    if (d_db) OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float) * C, stream));
+    const int splits = nhwc_splits(ctx, B, hw);
+    dim3 grid((unsigned)splits, (unsigned)B);
+    const unsigned short *x = static_cast<const unsigned short *>(d_x), *dy = static_cast<const unsigned short *>(d_dy);
+    hipLaunchKernelGGL(in_nhwc_stats<1>, grid, dim3(NT), 0, stream, x, dy, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, sums);
+    hipLaunchKernelGGL(in_nhwc_bwd_apply, grid, dim3(NT), 0, stream, x, dy, static_cast<unsigned short *>(d_dx), d_w, d_b, d_mean, d_rstd,
+                       (long)hw, C, splits, slope, sums, d_dw, d_db);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}

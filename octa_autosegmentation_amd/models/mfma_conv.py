@@ -51,3 +51,165 @@ def conv3x3_nhwc_wgrad(x, dy):
                                                ctypes.c_void_p(dw.data_ptr()), n, h, w, cin, cout, _native.current_stream_ptr())
     _native.check(rc, "octa_conv3x3_nhwc_wgrad")
     return dw.view(3, 3, cout, cin).permute(2, 3, 0, 1)
+
+
+# ---- autograd bindings ---------------------------------------------------------------------------------------------
+
+def _pad_channels(x, mult=32):
+    c = x.shape[-1]
+    if c % mult == 0:
+        return x
+    out = x.new_zeros(x.shape[:-1] + ((c + mult - 1) // mult * mult,))
+    out[..., :c] = x
+    return out
+
+
+class _Conv3x3NHWC(torch.autograd.Function):
+    """y = conv3x3(x, weight), padding 1, stride 1 or 2. x [N,H,W,Cin] bf16 (Cin padded to 32 internally),
+    weight [Cout,Cin,3,3] (any float dtype; master copy), y [N,Ho,Wo,Cout] bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride):
+        cin = weight.shape[1]
+        xp = _pad_channels(x.contiguous())
+        wp = weight
+        if xp.shape[-1] != cin:
+            wp = weight.new_zeros((weight.shape[0], xp.shape[-1], 3, 3))
+            wp[:, :cin] = weight
+        y = conv3x3_nhwc(xp, pack_weight(wp), stride=stride)
+        ctx.save_for_backward(xp, weight)
+        ctx.stride, ctx.cin = int(stride), cin
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        cin, st = ctx.cin, ctx.stride
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            assert xp.shape[-1] == cin, "data gradient of a channel-padded input is not needed by the U-Net"
+            if st == 2:
+                assert xp.shape[1] % 2 == 0 and xp.shape[2] % 2 == 0, "stride-2 layers need even input sizes"
+            dx = conv3x3_nhwc(dy, pack_weight_dgrad(weight), stride=1, in_dilation=st)
+        if ctx.needs_input_grad[1]:
+            if st == 1:
+                dw = conv3x3_nhwc_wgrad(xp, dy)[:, :cin].to(weight.dtype)
+            else:
+                # stride 2: x[2p + r - 1] lives in the odd plane (shift -1) for r = 0, in the even plane for r = 1 and in
+                # the odd plane (shift 0) for r = 2, so the nine taps are stride-1 taps of the four parity planes
+                dw9 = torch.empty((3, 3) + (weight.shape[0], xp.shape[-1]), dtype=torch.float32, device=xp.device)
+                taps = {1: ((0, 0), (1, 2)), 0: ((1, 1),)}   # plane parity -> ((stride-1 tap, stride-2 tap), ...)
+                for pa in (0, 1):
+                    for pb in (0, 1):
+                        g = conv3x3_nhwc_wgrad(xp[:, pa::2, pb::2, :].contiguous(), dy)   # [Cout, Cin, 3, 3]
+                        for i, r in taps[pa]:
+                            for j, s_ in taps[pb]:
+                                dw9[r, s_] = g[:, :, i, j]
+                dw = dw9.permute(2, 3, 0, 1)[:, :cin].to(weight.dtype)
+        return dx, dw, None
+
+
+def conv3x3(x, weight, stride=1):
+    return _Conv3x3NHWC.apply(x, weight, stride)
+
+
+class _InstNormLReLUNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope, eps):
+        x = x.contiguous()
+        assert x.dtype == torch.bfloat16 and x.dim() == 4
+        B, C = x.shape[0], x.shape[3]
+        hw = x.shape[1] * x.shape[2]
+        y = torch.empty_like(x)
+        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        w = weight.float().contiguous() if weight is not None else None
+        b = bias.float().contiguous() if bias is not None else None
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        rc = _native.lib().octa_instnorm_lrelu_nhwc_fwd(_native.ctx(x.device.index), p(x), p(y), p(w), p(b), p(mean), p(rstd), B, C, hw,
+                                                        float(slope), float(eps), _native.current_stream_ptr())
+        _native.check(rc, "octa_instnorm_lrelu_nhwc_fwd")
+        ctx.save_for_backward(x, w, b, mean, rstd)
+        ctx.slope, ctx.has_w, ctx.has_b = float(slope), weight is not None, bias is not None
+        ctx.w_dtype = weight.dtype if weight is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        B, C = x.shape[0], x.shape[3]
+        hw = x.shape[1] * x.shape[2]
+        dx = torch.empty_like(x)
+        dw = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_w else None
+        db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_b else None
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        rc = _native.lib().octa_instnorm_lrelu_nhwc_bwd(_native.ctx(x.device.index), p(x), p(dy), p(w), p(b), p(mean), p(rstd), p(dx), p(dw),
+                                                        p(db), B, C, hw, ctx.slope, _native.current_stream_ptr())
+        _native.check(rc, "octa_instnorm_lrelu_nhwc_bwd")
+        return dx, (dw.to(ctx.w_dtype) if dw is not None else None), (db.to(ctx.w_dtype) if db is not None else None), None, None
+
+
+def instance_norm_leaky_relu_nhwc(x, weight, bias, negative_slope=0.01, eps=1e-5):
+    return _InstNormLReLUNHWC.apply(x, weight, bias, negative_slope, eps)
+
+
+def conv_transpose_kxk_nhwc(x, weight, k):
+    """ConvTranspose2d with kernel == stride == k (no padding, no bias) on NHWC bf16: every input pixel owns a
+    disjoint k x k output patch, so it is one GEMM [N*H*W, Cin] x [Cin, k*k*Cout] (hipBLASLt through torch) plus a
+    pixel shuffle. weight: the torch parameter [Cin, Cout, k, k]."""
+    n, h, w, cin = x.shape
+    cout = weight.shape[1]
+    wm = weight.permute(0, 2, 3, 1).reshape(cin, k * k * cout).to(torch.bfloat16)
+    y = torch.matmul(x.reshape(n * h * w, cin), wm)
+    if k == 1:
+        return y.view(n, h, w, cout)
+    return y.view(n, h, w, k, k, cout).permute(0, 1, 3, 2, 4, 5).reshape(n, h * k, w * k, cout)
+
+
+class _Head1NHWC(torch.autograd.Function):
+    """1x1 convolution to ONE channel with bias on the streaming HIP kernels (csrc/conv.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        wv = weight.reshape(-1).float().contiguous()
+        y = torch.empty((n, h, w, 1), dtype=torch.bfloat16, device=x.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        rc = _native.lib().octa_head1_nhwc_fwd(_native.ctx(x.device.index), p(x), p(wv), float(bias.item()) if bias is not None else 0.0,
+                                               n * h * w, c, p(y), _native.current_stream_ptr())
+        _native.check(rc, "octa_head1_nhwc_fwd")
+        ctx.save_for_backward(x, wv)
+        ctx.w_shape, ctx.w_dtype, ctx.has_bias = weight.shape, weight.dtype, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wv = ctx.saved_tensors
+        dy = dy.contiguous().to(torch.bfloat16)
+        n, h, w, c = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.empty(c, dtype=torch.float32, device=x.device)
+        db = torch.empty(1, dtype=torch.float32, device=x.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        rc = _native.lib().octa_head1_nhwc_bwd(_native.ctx(x.device.index), p(x), p(dy), p(wv), n * h * w, c, p(dx), p(dw), p(db),
+                                               _native.current_stream_ptr())
+        _native.check(rc, "octa_head1_nhwc_bwd")
+        return dx, dw.view(ctx.w_shape).to(ctx.w_dtype), (db.to(ctx.w_dtype) if ctx.has_bias else None)
+
+
+def conv1x1_bias_nhwc(x, weight, bias):
+    """1x1 convolution head: weight [Cout, Cin, 1, 1], bias [Cout] -> [N,H,W,Cout] bf16."""
+    if weight.shape[0] == 1 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 256 and 256 % (x.shape[-1] // 8) == 0:
+        return _Head1NHWC.apply(x, weight, bias)
+    n, h, w, cin = x.shape
+    y = torch.matmul(x.reshape(n * h * w, cin), weight.reshape(weight.shape[0], cin).t().to(torch.bfloat16))
+    if bias is not None:
+        y = y + bias.to(torch.bfloat16)
+    return y.view(n, h, w, weight.shape[0])

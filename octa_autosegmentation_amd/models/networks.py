@@ -22,6 +22,9 @@ import torch.nn as nn
 USE_FUSED_NORM = True
 # transposed convolutions with kernel == stride as GEMM + pixel shuffle (same parameters, same result)
 FAST_CONVT = False  # measured slower than MIOpen at 1216^2 (65 vs 53 ms per step): kept for experiments only
+# CUDA inputs run channels-last in bf16 through the hand-written MFMA convolution (csrc/conv.hip) and the NHWC
+# norm kernels; False = torch/MIOpen modules (the fp32 reference path of the parity tests)
+USE_MFMA_CONV = True
 
 
 class _Conv(nn.Module):
@@ -140,7 +143,50 @@ class DynUNet(nn.Module):
         for k in [k for k in state_dict if k.startswith(prefix + "skip_layers.")]:
             del state_dict[k]
 
+    # ---- channels-last bf16 path on the hand-written kernels (same parameters, same state dict) ----
+    @staticmethod
+    def _basic_block_nhwc(blk, x):
+        from . import mfma_conv as mc
+        c1, c2 = blk.conv1.conv, blk.conv2.conv
+        x = mc.conv3x3(x, c1.weight, c1.stride[0])
+        x = mc.instance_norm_leaky_relu_nhwc(x, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps)
+        x = mc.conv3x3(x, c2.weight, 1)
+        return mc.instance_norm_leaky_relu_nhwc(x, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps)
+
+    def _mfma_path_ok(self, x):
+        if not (USE_MFMA_CONV and x.is_cuda and x.dim() == 4):
+            return False
+        blocks = [self.input_block, *self.downsamples, self.bottleneck, *[u.conv_block for u in self.upsamples]]
+        for b in blocks:
+            for c in (b.conv1.conv, b.conv2.conv):
+                if c.kernel_size != (3, 3) or c.stride[0] not in (1, 2) or c.out_channels % 32 or c.bias is not None:
+                    return False
+        for u in self.upsamples:
+            t = u.transp_conv.conv
+            if t.kernel_size != t.stride or t.kernel_size[0] not in (1, 2) or t.bias is not None:
+                return False
+        down = 1
+        for d in self.downsamples:
+            down *= d.conv1.conv.stride[0]
+        return x.shape[2] % down == 0 and x.shape[3] % down == 0
+
+    def _forward_nhwc(self, x):
+        from . import mfma_conv as mc
+        y = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+        skips = [self._basic_block_nhwc(self.input_block, y)]
+        for d in self.downsamples:
+            skips.append(self._basic_block_nhwc(d, skips[-1]))
+        y = self._basic_block_nhwc(self.bottleneck, skips[-1])
+        for u, s in zip(self.upsamples, skips[::-1]):
+            t = u.transp_conv.conv
+            y = mc.conv_transpose_kxk_nhwc(y, t.weight, t.kernel_size[0])
+            y = self._basic_block_nhwc(u.conv_block, torch.cat((y, s), dim=-1))
+        o = self.output_block.conv.conv
+        return mc.conv1x1_bias_nhwc(y, o.weight, o.bias).permute(0, 3, 1, 2)
+
     def forward(self, x):
+        if self._mfma_path_ok(x):
+            return self._forward_nhwc(x)
         skips = [self.input_block(x)]
         for d in self.downsamples:
             skips.append(d(skips[-1]))

@@ -19,10 +19,16 @@ for hw, cin, cout, st in shapes:
     wt = mfma_conv.pack_weight(w)
     xn = x.permute(0, 3, 1, 2).contiguous()
     t_m = timeit(lambda: mfma_conv.conv3x3_nhwc(x, wt, stride=st))
+    ho_ = (hw - 1) // st + 1
+    dy = torch.randn(B, ho_, ho_, cout, device="cuda").to(torch.bfloat16)
+    wd = mfma_conv.pack_weight_dgrad(w)
+    t_d = timeit(lambda: mfma_conv.conv3x3_nhwc(dy, wd, stride=1, in_dilation=st))
+    t_w = timeit(lambda: mfma_conv.conv3x3_nhwc_wgrad(x, dy)) if st == 1 else float("nan")
     t_t = timeit(lambda: F.conv2d(xn, w, stride=st, padding=1))
     ho = (hw - 1) // st + 1
     fl = 2.0 * 9 * cin * cout * ho * ho * B
     by = 2.0 * B * (hw * hw * cin + ho * ho * cout)
     tot_m += t_m; tot_t += t_t
+    print(f"   dgrad {t_d*1e3:7.3f} ms {2.0*9*cin*cout*ho_*ho_*B/t_d/1e12:6.1f} TF/s | wgrad {t_w*1e3:7.3f} ms {2.0*9*cin*cout*ho_*ho_*B/t_w/1e12:6.1f} TF/s")
     print(f"{hw:5d}^2 {cin:3d}->{cout:3d} s{st}: mfma {t_m*1e3:7.3f} ms {fl/t_m/1e12:6.1f} TF/s {by/t_m/1e9:6.0f} GB/s | torch/MIOpen NCHW {t_t*1e3:7.3f} ms {fl/t_t/1e12:6.1f} TF/s")
 print(f"sum: mfma {tot_m*1e3:.2f} ms, torch {tot_t*1e3:.2f} ms")
