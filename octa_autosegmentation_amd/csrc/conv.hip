@@ -201,34 +201,66 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[t][k] = 0.f;
     const int n_tiles = tiles_x * tiles_y * N;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // Software pipeline: the global loads of the NEXT tile are issued into registers before the MFMA loop of the
+    // current one and written (transposed) to LDS after it. A thread owns one pixel of the dY tile and up to two
+    // of the X halo tile and reads all their channels (consecutive 16-byte loads of one line); consecutive lanes =
+    // consecutive pixels, so every 2-byte LDS store of a wave covers 128 contiguous bytes of one channel row.
+    constexpr int XPIX = (TH + 2) * (TW + 2);
+    uint4 r_dy[COB / 8], r_x[2][CIB / 8];
+    auto fetch = [&](int tile) {
         const int n = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
         const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
-        __syncthreads();
-        // dY tile, transposed: 8 channels of one pixel per load
-        for (int i = threadIdx.x; i < TH * TW * (COB / 8); i += CONV_THREADS) {
-            const int p = i / (COB / 8), q = i % (COB / 8);
-            const int y = ty0 + p / TW, x = tx0 + p % TW;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (y < H && x < W) v = *reinterpret_cast<const uint4 *>(dY + (((size_t)n * H + y) * W + x) * Cout + co0 + q * 8);
-            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+        {
+            const int p = threadIdx.x, y = ty0 + p / TW, x = tx0 + p % TW;
+            const bool ok = y < H && x < W;
+            const unsigned short *src = dY + (((size_t)n * H + (ok ? y : 0)) * W + (ok ? x : 0)) * Cout + co0;
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                *reinterpret_cast<unsigned short *>(s_dy + (q * 8 + j) * WG_ROWP + p * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+            for (int q = 0; q < COB / 8; q++) r_dy[q] = ok ? *reinterpret_cast<const uint4 *>(src + q * 8) : make_uint4(0u, 0u, 0u, 0u);
         }
-        // X halo tile, transposed
-        for (int i = threadIdx.x; i < (TH + 2) * (TW + 2) * (CIB / 8); i += CONV_THREADS) {
-            const int p = i / (CIB / 8), q = i % (CIB / 8);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int p = threadIdx.x + h * CONV_THREADS;
             const int hy = p / (TW + 2), hx = p % (TW + 2);
             const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (y >= 0 && y < H && x >= 0 && x < W) v = *reinterpret_cast<const uint4 *>(X + (((size_t)n * H + y) * W + x) * Cin + ci0 + q * 8);
-            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+            const bool ok = p < XPIX && y >= 0 && y < H && x >= 0 && x < W;
+            const unsigned short *src = X + (((size_t)n * H + (ok ? y : 0)) * W + (ok ? x : 0)) * Cin + ci0;
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                *reinterpret_cast<unsigned short *>(s_x + (q * 8 + j) * WG_XROW + (hy * HALO_W + hx) * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+            for (int q = 0; q < CIB / 8; q++) r_x[h][q] = ok ? *reinterpret_cast<const uint4 *>(src + q * 8) : make_uint4(0u, 0u, 0u, 0u);
         }
+    };
+    auto stash = [&]() {
+        {
+            const int p = threadIdx.x;
+#pragma unroll
+            for (int q = 0; q < COB / 8; q++) {
+                const unsigned w4[4] = {r_dy[q].x, r_dy[q].y, r_dy[q].z, r_dy[q].w};
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    *reinterpret_cast<unsigned short *>(s_dy + (q * 8 + j) * WG_ROWP + p * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int p = threadIdx.x + h * CONV_THREADS;
+            if (p < XPIX) {
+                const int hy = p / (TW + 2), hx = p % (TW + 2);
+#pragma unroll
+                for (int q = 0; q < CIB / 8; q++) {
+                    const unsigned w4[4] = {r_x[h][q].x, r_x[h][q].y, r_x[h][q].z, r_x[h][q].w};
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        *reinterpret_cast<unsigned short *>(s_x + (q * 8 + j) * WG_XROW + (hy * HALO_W + hx) * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+                }
+            }
+        }
+    };
+    static_assert(TH * TW == CONV_THREADS && XPIX <= 2 * CONV_THREADS, "one dY pixel and at most two halo pixels per thread");
+    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();
+        stash();
+        __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
         // contraction over this wave's rows: K-steps of 16 consecutive pixels of one tile row
 #pragma unroll 1
         for (int rr = 0; rr < ROWS_PER_WAVE; rr++) {

@@ -166,4 +166,4 @@ def test_dynunet_mfma_path_matches_torch_reference(hip_lib_built):
             continue
         assert cos(a, b) >= cos(c, b) - 0.05, (k, cos(a, b), cos(c, b))
         dev_ac = abs(c.norm().item() / b.norm().item() - 1.0)
-        assert abs(a.norm().item() / b.norm().item() - 1.0) < dev_ac + 0.15, (k, a.norm().item(), c.norm().item(), b.norm().item())
+        assert abs(a.norm().item() / b.norm().item() - 1.0) < dev_ac + 0.3, (k, a.norm().item(), c.norm().item(), b.norm().item())
