@@ -141,6 +141,13 @@ int octa_instnorm_lrelu_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_d
 int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin,
                           int Cout, int stride, int in_dilation, void *stream);
 
+/* Same, with a VIRTUAL channel concatenation of two inputs (channels [0, C1) from d_x [.. C1], the rest from d_x2
+ * [.. Cin - C1]; d_x2 NULL = single input) and a split output (channels [0, CY1) to d_y, the rest to d_y2; d_y2
+ * NULL = single output): the decoder's torch.cat((up, skip), 1) of MONAI's UnetUpBlock and its backward slicing
+ * never materialise. C1 and CY1 multiples of 32. */
+int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2, int CY1,
+                           int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, void *stream);
+
 /* Weight gradient of the stride-1 layer above: d_dw [9][Cout][Cin] float32 (overwritten) =
  * sum over pixels of d_dy[N][H][W][Cout] (bf16) x d_x[N][H][W][Cin] (bf16) shifted by the tap (SURVEY.md 8b:
  * octa_conv2d_wgrad). fp32 accumulation; partial sums of the persistent workgroups meet in fp32 atomics, so the
@@ -154,6 +161,9 @@ int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, fl
 int octa_head1_nhwc_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, float bias, int64_t npix, int C, void *d_y, void *stream);
 int octa_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, const float *d_w, int64_t npix, int C, void *d_dx,
                         float *d_dw, float *d_db, void *stream);
+
+int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H, int W,
+                             int Cin, int Cout, void *stream);   /* wgrad with the virtual input concatenation of _fwd2 */
 
 /* ---- N1-N4: space-colonisation vessel-graph simulator --------------------
  * Replaces, for B independent samples advanced in lock-step on the GPU:

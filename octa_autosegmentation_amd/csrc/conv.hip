@@ -46,7 +46,8 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 // Xv(yy, xx) = X[yy/dil][xx/dil] if 0 <= yy < H*dil, 0 <= xx < W*dil and yy, xx multiples of dil, else 0.
 template <int BN, int ST>
 __global__ void __launch_bounds__(CONV_THREADS)
-conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y,
+conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
+                    const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
                     int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;  // halo tile
     constexpr int NB = BN / 32;
@@ -69,6 +70,9 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
     const int m = lane & 31, kg = lane >> 5;
     for (int c0 = 0; c0 < Cin; c0 += KC) {
         __syncthreads();
+        // virtual concatenation: channels [0, C1) come from X, [C1, Cin) from X2 (C1 is a multiple of KC)
+        const unsigned short *Xs = c0 < C1 ? X : X2;
+        const int cs = c0 < C1 ? C1 : Cin - C1, cb = c0 < C1 ? c0 : c0 - C1;
         // stage the input slice: 16-byte pieces (8 channels), 4 per pixel
         for (int i = threadIdx.x; i < IH * IW * 4; i += CONV_THREADS) {
             const int p = i >> 2, q = i & 3;
@@ -78,7 +82,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
             if (ok && dil == 2) ok = !((yy | xx) & 1);
             if (ok) {
                 const int sy = dil == 2 ? yy >> 1 : yy, sx = dil == 2 ? xx >> 1 : xx;
-                v = *reinterpret_cast<const uint4 *>(X + (((size_t)n * H + sy) * W + sx) * Cin + c0 + q * 8);
+                v = *reinterpret_cast<const uint4 *>(Xs + (((size_t)n * H + sy) * W + sx) * cs + cb + q * 8);
             }
             *reinterpret_cast<uint4 *>(s_in + p * PITCH + q * 16) = v;
         }
@@ -112,7 +116,10 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
                             acc[rr][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b[nb], acc[rr][nb], 0, 0, 0);
                 }
     }
-    // epilogue: D[row = pixel x][col = output channel]; row = (k&3) + 8*(k>>2) + 4*(lane>>5), col = lane&31
+    // epilogue: D[row = pixel x][col = output channel]; row = (k&3) + 8*(k>>2) + 4*(lane>>5), col = lane&31.
+    // Split output: channels [0, CY1) go to Y, the rest to Y2 (a BN block never straddles CY1).
+    unsigned short *Yo = co0 < CY1 ? Y : Y2;
+    const int ys = co0 < CY1 ? CY1 : Cout - CY1, yb = co0 < CY1 ? co0 : co0 - CY1;
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int oy = ty0 + 2 * wv + rr;
@@ -122,29 +129,29 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int ox = tx0 + (k & 3) + 8 * (k >> 2) + 4 * kg;
-                if (ox < Wo) Y[(((size_t)n * Ho + oy) * Wo + ox) * Cout + co0 + nb * 32 + m] = f2bf(acc[rr][nb][k]);
+                if (ox < Wo) Yo[(((size_t)n * Ho + oy) * Wo + ox) * ys + yb + nb * 32 + m] = f2bf(acc[rr][nb][k]);
             }
     }
 }
 
 template <int BN, int ST>
-int launch_conv(const unsigned short *X, const unsigned short *Wt, unsigned short *Y, int N, int H, int W, int Cin, int Ho, int Wo,
-                int Cout, int dil, hipStream_t stream) {
+int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
+                int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, hipStream_t stream) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;
     const size_t lds = (size_t)IH * IW * PITCH + (size_t)9 * BN * PITCH;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
     auto kern = conv3x3_nhwc_kernel<BN, ST>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
-    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, Wt, Y, H, W, Cin, Ho, Wo, Cout, dil, tiles_x);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-extern "C" int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin,
-                                     int Cout, int stride, int in_dilation, void *stream_) {
+extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+                                      int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, void *stream_) {
     if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv3x3_nhwc_fwd: null pointer"); return -2; }
     if (N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: bad shape"); return -2; }
     if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
@@ -153,17 +160,26 @@ extern "C" int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void 
         return -2;
     }
     if (N > 65535) { octa::set_error("octa_conv3x3_nhwc_fwd: N > 65535"); return -2; }
+    if (!d_x2) C1 = Cin;
+    if (!d_y2) CY1 = Cout;
+    if (C1 <= 0 || C1 > Cin || C1 % 32 || CY1 <= 0 || CY1 > Cout || CY1 % 32) { octa::set_error("octa_conv3x3_nhwc_fwd: channel splits must be multiples of 32 inside the channel range"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     const int Hv = H * in_dilation, Wv = W * in_dilation;
     const int Ho = (Hv + 2 - 3) / stride + 1, Wo = (Wv + 2 - 3) / stride + 1;
-    const unsigned short *X = static_cast<const unsigned short *>(d_x), *Wt = static_cast<const unsigned short *>(d_w);
-    unsigned short *Y = static_cast<unsigned short *>(d_y);
-    const bool wide = (Cout % 64 == 0);
-    if (stride == 1) return wide ? launch_conv<64, 1>(X, Wt, Y, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream)
-                                 : launch_conv<32, 1>(X, Wt, Y, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream);
-    return wide ? launch_conv<64, 2>(X, Wt, Y, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream)
-                : launch_conv<32, 2>(X, Wt, Y, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream);
+    const unsigned short *X = static_cast<const unsigned short *>(d_x), *X2 = static_cast<const unsigned short *>(d_x2);
+    const unsigned short *Wt = static_cast<const unsigned short *>(d_w);
+    unsigned short *Y = static_cast<unsigned short *>(d_y), *Y2 = static_cast<unsigned short *>(d_y2);
+    const bool wide = (Cout % 64 == 0) && (CY1 % 64 == 0);   // a 64-channel block must not straddle the output split
+    if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream)
+                                 : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream);
+    return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream)
+                : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream);
+}
+
+extern "C" int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin,
+                                     int Cout, int stride, int in_dilation, void *stream_) {
+    return octa_conv3x3_nhwc_fwd2(ctx, d_x, nullptr, Cin, d_w, d_y, nullptr, Cout, N, H, W, Cin, Cout, stride, in_dilation, stream_);
 }
 
 // ---- weight gradient (stride 1) ----------------------------------------------------------------------------------
@@ -182,7 +198,8 @@ constexpr int WG_XROW = (TH + 2) * HALO_W * 2;  // bytes per channel row of the 
 
 template <int COB, int CIB>
 __global__ void __launch_bounds__(CONV_THREADS)
-conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ dY, float *__restrict__ dW,
+conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
+                          const unsigned short *__restrict__ dY, float *__restrict__ dW,
                           int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y) {
     constexpr int PAIRS = (COB / 32) * (CIB / 32);
     constexpr int KSPLIT = 4 / PAIRS;            // waves sharing one (co, ci) pair split the tile rows
@@ -191,6 +208,9 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     unsigned char *s_dy = smem;                       // [COB][256 px] bf16
     unsigned char *s_x = smem + COB * WG_ROWP;        // [CIB][TH+2][HALO_W] bf16
     const int co0 = (blockIdx.y / (Cin / CIB)) * COB, ci0 = (blockIdx.y % (Cin / CIB)) * CIB;
+    // virtual concatenation of the input: a CIB block lies entirely in X (channels < C1) or in X2
+    const unsigned short *Xs = ci0 < C1 ? X : X2;
+    const int xcs = ci0 < C1 ? C1 : Cin - C1, xcb = ci0 < C1 ? ci0 : ci0 - C1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int pair = wv % PAIRS, kpart = wv / PAIRS;
     const int cob = (pair % (COB / 32)) * 32, cib = (pair / (COB / 32)) * 32;
@@ -223,7 +243,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
             const int hy = p / (TW + 2), hx = p % (TW + 2);
             const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
             const bool ok = p < XPIX && y >= 0 && y < H && x >= 0 && x < W;
-            const unsigned short *src = X + (((size_t)n * H + (ok ? y : 0)) * W + (ok ? x : 0)) * Cin + ci0;
+            const unsigned short *src = Xs + (((size_t)n * H + (ok ? y : 0)) * W + (ok ? x : 0)) * xcs + xcb;
 #pragma unroll
             for (int q = 0; q < CIB / 8; q++) r_x[h][q] = ok ? *reinterpret_cast<const uint4 *>(src + q * 8) : make_uint4(0u, 0u, 0u, 0u);
         }
@@ -297,8 +317,8 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
 }
 
 template <int COB, int CIB>
-int launch_wgrad(const unsigned short *X, const unsigned short *dY, float *dW, int N, int H, int W, int Cin, int Cout, int num_cus,
-                 hipStream_t stream) {
+int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
+                 int Cout, int num_cus, hipStream_t stream) {
     const size_t lds = (size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int blocks = (Cout / COB) * (Cin / CIB);
@@ -308,28 +328,36 @@ int launch_wgrad(const unsigned short *X, const unsigned short *dY, float *dW, i
     if (per_block < 1) per_block = 1;
     auto kern = conv3x3_nhwc_wgrad_kernel<COB, CIB>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, dY, dW, N, H, W, Cin, Cout,
-                       tiles_x, tiles_y);
+    hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Cin,
+                       Cout, tiles_x, tiles_y);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-extern "C" int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin,
-                                       int Cout, void *stream_) {
+extern "C" int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
+                                        int W, int Cin, int Cout, void *stream_) {
     if (!ctx || !d_x || !d_dy || !d_dw) { octa::set_error("octa_conv3x3_nhwc_wgrad: null pointer"); return -2; }
     if (N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_nhwc_wgrad: bad shape"); return -2; }
     if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_wgrad: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
+    if (!d_x2) C1 = Cin;
+    if (C1 <= 0 || C1 > Cin || C1 % 32) { octa::set_error("octa_conv3x3_nhwc_wgrad: the input split must be a multiple of 32 inside the channel range"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 9 * (size_t)Cout * Cin, stream));
-    const unsigned short *X = static_cast<const unsigned short *>(d_x), *dY = static_cast<const unsigned short *>(d_dy);
-    const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0;
-    if (co64 && ci64) return launch_wgrad<64, 64>(X, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
-    if (co64) return launch_wgrad<64, 32>(X, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
-    if (ci64) return launch_wgrad<32, 64>(X, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
-    return launch_wgrad<32, 32>(X, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
+    const unsigned short *X = static_cast<const unsigned short *>(d_x), *X2 = static_cast<const unsigned short *>(d_x2);
+    const unsigned short *dY = static_cast<const unsigned short *>(d_dy);
+    const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0 && C1 % 64 == 0;   // a 64-channel block must not straddle the split
+    if (co64 && ci64) return launch_wgrad<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
+    if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
+    if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
+    return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
+}
+
+extern "C" int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin,
+                                       int Cout, void *stream_) {
+    return octa_conv3x3_nhwc_wgrad2(ctx, d_x, nullptr, Cin, d_dy, d_dw, N, H, W, Cin, Cout, stream_);
 }
 
 // ---- 1x1 head with one output channel (UnetOutBlock, 32 -> 1 with bias): HBM-bound streaming kernels ----------

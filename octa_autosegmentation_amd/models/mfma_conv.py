@@ -116,6 +116,57 @@ def conv3x3(x, weight, stride=1):
     return _Conv3x3NHWC.apply(x, weight, stride)
 
 
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _Conv3x3CatNHWC(torch.autograd.Function):
+    """y = conv3x3(cat(x1, x2, channel axis), weight), stride 1, without materialising the concatenation: the
+    kernels read the two tensors as one virtual input and the data gradient is written straight into two tensors
+    (MONAI UnetUpBlock: conv_block(torch.cat((transp_conv(x), skip), 1)))."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight):
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        n, h, w, c1 = x1.shape
+        c2 = x2.shape[3]
+        cout = weight.shape[0]
+        assert x2.shape[:3] == x1.shape[:3] and weight.shape[1] == c1 + c2 and c1 % 32 == 0 and c2 % 32 == 0
+        y = torch.empty((n, h, w, cout), dtype=torch.bfloat16, device=x1.device)
+        wt = pack_weight(weight)
+        rc = _native.lib().octa_conv3x3_nhwc_fwd2(_native.ctx(x1.device.index), _p(x1), _p(x2), c1, _p(wt), _p(y), None, cout, n, h, w, c1 + c2,
+                                                  cout, 1, 1, _native.current_stream_ptr())
+        _native.check(rc, "octa_conv3x3_nhwc_fwd2")
+        ctx.save_for_backward(x1, x2, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        n, h, w, c1 = x1.shape
+        c2, cout = x2.shape[3], weight.shape[0]
+        lib, hctx, st = _native.lib(), _native.ctx(x1.device.index), _native.current_stream_ptr()
+        dx1 = dx2 = dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+            wd = pack_weight_dgrad(weight)
+            rc = lib.octa_conv3x3_nhwc_fwd2(hctx, _p(dy), None, cout, _p(wd), _p(dx1), _p(dx2), c1, n, h, w, cout, c1 + c2, 1, 1, st)
+            _native.check(rc, "octa_conv3x3_nhwc_fwd2 (data gradient)")
+        if ctx.needs_input_grad[2]:
+            dwf = torch.empty((9, cout, c1 + c2), dtype=torch.float32, device=x1.device)
+            rc = lib.octa_conv3x3_nhwc_wgrad2(hctx, _p(x1), _p(x2), c1, _p(dy), _p(dwf), n, h, w, c1 + c2, cout, st)
+            _native.check(rc, "octa_conv3x3_nhwc_wgrad2")
+            dw = dwf.view(3, 3, cout, c1 + c2).permute(2, 3, 0, 1).to(weight.dtype)
+        return dx1, dx2, dw
+
+
+def conv3x3_cat(x1, x2, weight):
+    return _Conv3x3CatNHWC.apply(x1, x2, weight)
+
+
 class _InstNormLReLUNHWC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, slope, eps):

@@ -145,10 +145,15 @@ class DynUNet(nn.Module):
 
     # ---- channels-last bf16 path on the hand-written kernels (same parameters, same state dict) ----
     @staticmethod
-    def _basic_block_nhwc(blk, x):
+    def _basic_block_nhwc(blk, x, skip=None):
         from . import mfma_conv as mc
         c1, c2 = blk.conv1.conv, blk.conv2.conv
-        x = mc.conv3x3(x, c1.weight, c1.stride[0])
+        if skip is not None and x.shape[-1] % 32 == 0 and skip.shape[-1] % 32 == 0 and c1.stride[0] == 1:
+            x = mc.conv3x3_cat(x, skip, c1.weight)       # conv over the virtual concatenation (x, skip)
+        else:
+            if skip is not None:
+                x = torch.cat((x, skip), dim=-1)
+            x = mc.conv3x3(x, c1.weight, c1.stride[0])
         x = mc.instance_norm_leaky_relu_nhwc(x, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps)
         x = mc.conv3x3(x, c2.weight, 1)
         return mc.instance_norm_leaky_relu_nhwc(x, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps)
@@ -180,7 +185,7 @@ class DynUNet(nn.Module):
         for u, s in zip(self.upsamples, skips[::-1]):
             t = u.transp_conv.conv
             y = mc.conv_transpose_kxk_nhwc(y, t.weight, t.kernel_size[0])
-            y = self._basic_block_nhwc(u.conv_block, torch.cat((y, s), dim=-1))
+            y = self._basic_block_nhwc(u.conv_block, y, s)
         o = self.output_block.conv.conv
         return mc.conv1x1_bias_nhwc(y, o.weight, o.bias).permute(0, 3, 1, 2)
 

@@ -102,6 +102,29 @@ def test_autograd_function_gradients(hip_lib_built, stride, cin, cout, h, w):
         _check(xm.grad, xr.grad.permute(0, 2, 3, 1))
 
 
+@pytest.mark.parametrize("c1,c2,cout", [(32, 32, 32), (64, 64, 64), (128, 64, 96)])
+def test_virtual_concat_conv(hip_lib_built, c1, c2, cout):
+    """conv over cat(x1, x2) without the cat: forward, both data gradients, weight gradient vs torch autograd."""
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.models import mfma_conv
+    g = torch.Generator(device="cuda").manual_seed(c1 + cout)
+    x1 = torch.randn(2, 19, 40, c1, device="cuda", generator=g).to(torch.bfloat16)
+    x2 = torch.randn(2, 19, 40, c2, device="cuda", generator=g).to(torch.bfloat16)
+    wt = (torch.randn(cout, c1 + c2, 3, 3, device="cuda", generator=g) / (3.0 * (c1 + c2) ** 0.5)).to(torch.bfloat16).float()
+    x1r, x2r, wr = x1.float().requires_grad_(True), x2.float().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv2d(torch.cat((x1r, x2r), -1).permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1)
+    dy = torch.randn(yr.shape, device="cuda", generator=g).to(torch.bfloat16)
+    yr.backward(dy.float())
+    x1m, x2m, wm = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ym = mfma_conv.conv3x3_cat(x1m, x2m, wm)
+    ym.backward(dy)
+    _check(ym.detach(), yr.detach())
+    _check(x1m.grad, x1r.grad)
+    _check(x2m.grad, x2r.grad)
+    assert (wm.grad - wr.grad).abs().max().item() <= wr.grad.abs().max().item() * 1e-3 + 1e-5
+
+
 def test_head_kernels(hip_lib_built):
     import torch
     from octa_autosegmentation_amd.models import mfma_conv
