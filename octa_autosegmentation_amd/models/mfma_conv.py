@@ -98,17 +98,7 @@ class _Conv3x3NHWC(torch.autograd.Function):
             if st == 1:
                 dw = conv3x3_nhwc_wgrad(xp, dy)[:, :cin].to(weight.dtype)
             else:
-                # stride 2: x[2p + r - 1] lives in the odd plane (shift -1) for r = 0, in the even plane for r = 1 and in
-                # the odd plane (shift 0) for r = 2, so the nine taps are stride-1 taps of the four parity planes
-                dw9 = torch.empty((3, 3) + (weight.shape[0], xp.shape[-1]), dtype=torch.float32, device=xp.device)
-                taps = {1: ((0, 0), (1, 2)), 0: ((1, 1),)}   # plane parity -> ((stride-1 tap, stride-2 tap), ...)
-                for pa in (0, 1):
-                    for pb in (0, 1):
-                        g = conv3x3_nhwc_wgrad(xp[:, pa::2, pb::2, :].contiguous(), dy)   # [Cout, Cin, 3, 3]
-                        for i, r in taps[pa]:
-                            for j, s_ in taps[pb]:
-                                dw9[r, s_] = g[:, :, i, j]
-                dw = dw9.permute(2, 3, 0, 1)[:, :cin].to(weight.dtype)
+                dw = _s2_wgrad(xp, dy)[:, :cin].to(weight.dtype)
         return dx, dw, None
 
 
@@ -210,7 +200,60 @@ def instance_norm_leaky_relu_nhwc(x, weight, bias, negative_slope=0.01, eps=1e-5
     return _InstNormLReLUNHWC.apply(x, weight, bias, negative_slope, eps)
 
 
+def _s2_wgrad(x_big, dy_small):
+    """Weight gradient [Cout, Cin, 3, 3] (float32) of a stride-2, padding-1 3x3 conv with input x_big [N,2H,2W,Cin] and
+    output gradient dy_small [N,H,W,Cout]: the nine taps are stride-1 taps of the four parity planes of the input."""
+    cout, cin = dy_small.shape[-1], x_big.shape[-1]
+    dw9 = torch.empty((3, 3, cout, cin), dtype=torch.float32, device=x_big.device)
+    taps = {1: ((0, 0), (1, 2)), 0: ((1, 1),)}   # plane parity -> ((stride-1 tap, stride-2 tap), ...)
+    for pa in (0, 1):
+        for pb in (0, 1):
+            g = conv3x3_nhwc_wgrad(x_big[:, pa::2, pb::2, :].contiguous(), dy_small)
+            for i, r in taps[pa]:
+                for j, s_ in taps[pb]:
+                    dw9[r, s_] = g[:, :, i, j]
+    return dw9.permute(2, 3, 0, 1)
+
+
+class _ConvT2x2NHWC(torch.autograd.Function):
+    """ConvTranspose2d(kernel 2, stride 2, no bias) as the ADJOINT of a stride-2 3x3 convolution whose taps r, s = 0
+    are zero: forward = that convolution's data-gradient kernel (virtual zero insertion), backward = its forward
+    kernel (stride 2) and its weight gradient -- all on the MFMA kernels, no GEMM + pixel-shuffle round trip."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        cin, cout = weight.shape[0], weight.shape[1]
+        wc = weight.new_zeros((cin, cout, 3, 3))
+        wc[:, :, 1:, 1:] = weight
+        y = conv3x3_nhwc(x, pack_weight_dgrad(wc), stride=1, in_dilation=2)
+        ctx.save_for_backward(x, wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wc = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = conv3x3_nhwc(dy, pack_weight(wc), stride=2)
+        if ctx.needs_input_grad[1]:
+            dw = _s2_wgrad(dy, x)[:, :, 1:, 1:].to(wc.dtype)
+        return dx, dw
+
+
 def conv_transpose_kxk_nhwc(x, weight, k):
+    if k == 2 and x.shape[-1] % 32 == 0 and weight.shape[1] % 32 == 0 and USE_MFMA_CONVT:
+        return _ConvT2x2NHWC.apply(x, weight)
+    return _conv_transpose_kxk_gemm(x, weight, k)
+
+
+USE_MFMA_CONVT = True
+
+
+def _conv_transpose_kxk_gemm(x, weight, k):
     """ConvTranspose2d with kernel == stride == k (no padding, no bias) on NHWC bf16: every input pixel owns a
     disjoint k x k output patch, so it is one GEMM [N*H*W, Cin] x [Cin, k*k*Cout] (hipBLASLt through torch) plus a
     pixel shuffle. weight: the torch parameter [Cin, Cout, k, k]."""

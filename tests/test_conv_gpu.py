@@ -125,6 +125,28 @@ def test_virtual_concat_conv(hip_lib_built, c1, c2, cout):
     assert (wm.grad - wr.grad).abs().max().item() <= wr.grad.abs().max().item() * 1e-3 + 1e-5
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 32), (128, 64)])
+def test_transposed_conv_2x2(hip_lib_built, cin, cout):
+    """ConvTranspose2d(k=2, s=2) through the adjoint-of-stride-2-conv formulation vs torch."""
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.models import mfma_conv
+    g = torch.Generator(device="cuda").manual_seed(cin)
+    x = torch.randn(2, 12, 20, cin, device="cuda", generator=g).to(torch.bfloat16)
+    wt = (torch.randn(cin, cout, 2, 2, device="cuda", generator=g) / cin ** 0.5).to(torch.bfloat16).float()
+    xr, wr = x.float().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr.permute(0, 3, 1, 2), wr, stride=2).permute(0, 2, 3, 1)
+    dy = torch.randn(yr.shape, device="cuda", generator=g).to(torch.bfloat16)
+    yr.backward(dy.float())
+    xm, wm = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ym = mfma_conv.conv_transpose_kxk_nhwc(xm, wm, 2)
+    assert ym.shape == yr.shape
+    ym.backward(dy)
+    _check(ym.detach(), yr.detach())
+    _check(xm.grad, xr.grad)
+    assert (wm.grad - wr.grad).abs().max().item() <= wr.grad.abs().max().item() * 1e-3 + 1e-5
+
+
 def test_head_kernels(hip_lib_built):
     import torch
     from octa_autosegmentation_amd.models import mfma_conv
