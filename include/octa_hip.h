@@ -144,9 +144,11 @@ int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void 
 /* Same, with a VIRTUAL channel concatenation of two inputs (channels [0, C1) from d_x [.. C1], the rest from d_x2
  * [.. Cin - C1]; d_x2 NULL = single input) and a split output (channels [0, CY1) to d_y, the rest to d_y2; d_y2
  * NULL = single output): the decoder's torch.cat((up, skip), 1) of MONAI's UnetUpBlock and its backward slicing
- * never materialise. C1 and CY1 multiples of 32. */
+ * never materialise. C1 and CY1 multiples of 32.
+ * tap_mask: bit 3*r+s set = tap (r, s) is evaluated; taps whose weights are structurally zero (the 2x2 transposed
+ * convolution written as the adjoint of a stride-2 3x3 layer uses 4 of 9) are skipped. 0x1ff = all. */
 int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2, int CY1,
-                           int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, void *stream);
+                           int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask, void *stream);
 
 /* Weight gradient of the stride-1 layer above: d_dw [9][Cout][Cin] float32 (overwritten) =
  * sum over pixels of d_dy[N][H][W][Cout] (bf16) x d_x[N][H][W][Cin] (bf16) shifted by the tap (SURVEY.md 8b:
@@ -163,7 +165,9 @@ int octa_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, const 
                         float *d_dw, float *d_db, void *stream);
 
 int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H, int W,
-                             int Cin, int Cout, void *stream);   /* wgrad with the virtual input concatenation of _fwd2 */
+                             int Cin, int Cout, int tap_mask, void *stream);   /* wgrad with the virtual input concatenation and
+                                                                                  the tap mask of _fwd2 (unmasked taps of d_dw
+                                                                                  are left zero) */
 
 /* ---- N1-N4: space-colonisation vessel-graph simulator --------------------
  * Replaces, for B independent samples advanced in lock-step on the GPU:

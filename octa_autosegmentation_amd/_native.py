@@ -45,8 +45,8 @@ SIGNATURES = {
     "octa_instnorm_lrelu_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, ctypes.c_float, c_void_p]),
     "octa_head1_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_int64, c_int, c_void_p, c_void_p]),
     "octa_head1_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "octa_conv3x3_nhwc_fwd2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "octa_conv3x3_nhwc_wgrad2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "octa_conv3x3_nhwc_fwd2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "octa_conv3x3_nhwc_wgrad2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_conv3x3_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_conv3x3_nhwc_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_sim_kat_kd_order": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]),

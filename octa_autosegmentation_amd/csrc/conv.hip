@@ -48,7 +48,7 @@ template <int BN, int ST>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                     const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
-                    int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x) {
+                    int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, int tap_mask) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;  // halo tile
     constexpr int NB = BN / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -97,7 +97,8 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int s = 0; s < 3; s++)
+            for (int s = 0; s < 3; s++) {
+                if (!((tap_mask >> (3 * r + s)) & 1)) continue;   // taps whose weights are structurally zero
 #pragma unroll
                 for (int ks = 0; ks < KC / 16; ks++) {
                     bf16x8 a[2], b[NB];
@@ -115,6 +116,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
                         for (int nb = 0; nb < NB; nb++)
                             acc[rr][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b[nb], acc[rr][nb], 0, 0, 0);
                 }
+            }
     }
     // epilogue: D[row = pixel x][col = output channel]; row = (k&3) + 8*(k>>2) + 4*(lane>>5), col = lane&31.
     // Split output: channels [0, CY1) go to Y, the rest to Y2 (a BN block never straddles CY1).
@@ -136,14 +138,14 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
 
 template <int BN, int ST>
 int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
-                int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, hipStream_t stream) {
+                int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tap_mask, hipStream_t stream) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;
     const size_t lds = (size_t)IH * IW * PITCH + (size_t)9 * BN * PITCH;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
     auto kern = conv3x3_nhwc_kernel<BN, ST>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
-    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, tap_mask);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -151,7 +153,8 @@ int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const
 }  // namespace
 
 extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
-                                      int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, void *stream_) {
+                                      int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
+                                      void *stream_) {
     if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv3x3_nhwc_fwd: null pointer"); return -2; }
     if (N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: bad shape"); return -2; }
     if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
@@ -162,6 +165,8 @@ extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void
     if (N > 65535) { octa::set_error("octa_conv3x3_nhwc_fwd: N > 65535"); return -2; }
     if (!d_x2) C1 = Cin;
     if (!d_y2) CY1 = Cout;
+    tap_mask &= 0x1ff;
+    if (tap_mask == 0) { octa::set_error("octa_conv3x3_nhwc_fwd: empty tap mask"); return -2; }
     if (C1 <= 0 || C1 > Cin || C1 % 32 || CY1 <= 0 || CY1 > Cout || CY1 % 32) { octa::set_error("octa_conv3x3_nhwc_fwd: channel splits must be multiples of 32 inside the channel range"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
@@ -171,15 +176,15 @@ extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void
     const unsigned short *Wt = static_cast<const unsigned short *>(d_w);
     unsigned short *Y = static_cast<unsigned short *>(d_y), *Y2 = static_cast<unsigned short *>(d_y2);
     const bool wide = (Cout % 64 == 0) && (CY1 % 64 == 0);   // a 64-channel block must not straddle the output split
-    if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream)
-                                 : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream);
-    return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream)
-                : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, stream);
+    if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, stream)
+                                 : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, stream);
+    return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, stream)
+                : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, stream);
 }
 
 extern "C" int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin,
                                      int Cout, int stride, int in_dilation, void *stream_) {
-    return octa_conv3x3_nhwc_fwd2(ctx, d_x, nullptr, Cin, d_w, d_y, nullptr, Cout, N, H, W, Cin, Cout, stride, in_dilation, stream_);
+    return octa_conv3x3_nhwc_fwd2(ctx, d_x, nullptr, Cin, d_w, d_y, nullptr, Cout, N, H, W, Cin, Cout, stride, in_dilation, 0x1ff, stream_);
 }
 
 // ---- weight gradient (stride 1) ----------------------------------------------------------------------------------
@@ -200,7 +205,7 @@ template <int COB, int CIB>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                           const unsigned short *__restrict__ dY, float *__restrict__ dW,
-                          int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y) {
+                          int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask) {
     constexpr int PAIRS = (COB / 32) * (CIB / 32);
     constexpr int KSPLIT = 4 / PAIRS;            // waves sharing one (co, ci) pair split the tile rows
     constexpr int ROWS_PER_WAVE = TH / KSPLIT;
@@ -290,6 +295,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
                 const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_dy + (cob + m) * WG_ROWP + (y * TW + xs + kg * 8) * 2);
 #pragma unroll
                 for (int r = 0; r < 3; r++) {
+                    if (!((tap_mask >> (3 * r)) & 7)) continue;   // no tap of this kernel row is wanted
                     // halo columns xs + kg*8 + s .. +7 of halo row y + r: aligned 8-pixel group + the next dword
                     const unsigned char *row = s_x + (cib + m) * WG_XROW + ((y + r) * HALO_W + xs + kg * 8) * 2;
                     const uint4 d = *reinterpret_cast<const uint4 *>(row);
@@ -299,26 +305,28 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
                     b1.u = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
                                       __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
                     b2.u = make_uint4(d.y, d.z, d.w, e);
-                    acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0.v, acc[3 * r + 0], 0, 0, 0);
-                    acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1.v, acc[3 * r + 1], 0, 0, 0);
-                    acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2.v, acc[3 * r + 2], 0, 0, 0);
+                    if ((tap_mask >> (3 * r)) & 1) acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0.v, acc[3 * r + 0], 0, 0, 0);
+                    if ((tap_mask >> (3 * r + 1)) & 1) acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1.v, acc[3 * r + 1], 0, 0, 0);
+                    if ((tap_mask >> (3 * r + 2)) & 1) acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2.v, acc[3 * r + 2], 0, 0, 0);
                 }
             }
         }
     }
     // D[row = co][col = ci]: row = (k&3) + 8*(k>>2) + 4*kg, col = m
 #pragma unroll
-    for (int t = 0; t < 9; t++)
+    for (int t = 0; t < 9; t++) {
+        if (!((tap_mask >> t) & 1)) continue;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int co = co0 + cob + (k & 3) + 8 * (k >> 2) + 4 * kg;
             atomicAdd(dW + ((size_t)t * Cout + co) * Cin + ci0 + cib + m, acc[t][k]);
         }
+    }
 }
 
 template <int COB, int CIB>
 int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
-                 int Cout, int num_cus, hipStream_t stream) {
+                 int Cout, int num_cus, int tap_mask, hipStream_t stream) {
     const size_t lds = (size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int blocks = (Cout / COB) * (Cin / CIB);
@@ -329,7 +337,7 @@ int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, cons
     auto kern = conv3x3_nhwc_wgrad_kernel<COB, CIB>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Cin,
-                       Cout, tiles_x, tiles_y);
+                       Cout, tiles_x, tiles_y, tap_mask);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -337,8 +345,10 @@ int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, cons
 }  // namespace
 
 extern "C" int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
-                                        int W, int Cin, int Cout, void *stream_) {
+                                        int W, int Cin, int Cout, int tap_mask, void *stream_) {
     if (!ctx || !d_x || !d_dy || !d_dw) { octa::set_error("octa_conv3x3_nhwc_wgrad: null pointer"); return -2; }
+    tap_mask &= 0x1ff;
+    if (tap_mask == 0) { octa::set_error("octa_conv3x3_nhwc_wgrad: empty tap mask"); return -2; }
     if (N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_nhwc_wgrad: bad shape"); return -2; }
     if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_wgrad: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
     if (!d_x2) C1 = Cin;
@@ -349,15 +359,15 @@ extern "C" int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const vo
     const unsigned short *X = static_cast<const unsigned short *>(d_x), *X2 = static_cast<const unsigned short *>(d_x2);
     const unsigned short *dY = static_cast<const unsigned short *>(d_dy);
     const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0 && C1 % 64 == 0;   // a 64-channel block must not straddle the split
-    if (co64 && ci64) return launch_wgrad<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
-    if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
-    if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
-    return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, stream);
+    if (co64 && ci64) return launch_wgrad<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, stream);
+    if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, stream);
+    if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, stream);
+    return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, stream);
 }
 
 extern "C" int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin,
                                        int Cout, void *stream_) {
-    return octa_conv3x3_nhwc_wgrad2(ctx, d_x, nullptr, Cin, d_dy, d_dw, N, H, W, Cin, Cout, stream_);
+    return octa_conv3x3_nhwc_wgrad2(ctx, d_x, nullptr, Cin, d_dy, d_dw, N, H, W, Cin, Cout, 0x1ff, stream_);
 }
 
 // ---- 1x1 head with one output channel (UnetOutBlock, 32 -> 1 with bias): HBM-bound streaming kernels ----------

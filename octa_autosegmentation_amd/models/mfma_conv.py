@@ -23,8 +23,9 @@ def pack_weight_dgrad(w):
     return w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, ci, co).to(torch.bfloat16).contiguous()
 
 
-def conv3x3_nhwc(x, wt, stride=1, in_dilation=1):
-    """x [N,H,W,Cin] bf16, wt [9,Cout,Cin] bf16 -> [N,Ho,Wo,Cout] bf16 (padding 1)."""
+def conv3x3_nhwc(x, wt, stride=1, in_dilation=1, tap_mask=0x1ff):
+    """x [N,H,W,Cin] bf16, wt [9,Cout,Cin] bf16 -> [N,Ho,Wo,Cout] bf16 (padding 1). tap_mask bit 3r+s = evaluate tap
+    (r, s) of wt (as packed); cleared taps must have zero weights."""
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
     assert wt.dtype == torch.bfloat16 and wt.is_contiguous() and wt.shape[0] == 9 and wt.shape[2] == x.shape[3]
     n, h, w, cin = x.shape
@@ -32,24 +33,25 @@ def conv3x3_nhwc(x, wt, stride=1, in_dilation=1):
     ho = (h * in_dilation - 1) // stride + 1
     wo = (w * in_dilation - 1) // stride + 1
     y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
-    rc = _native.lib().octa_conv3x3_nhwc_fwd(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()),
-                                             ctypes.c_void_p(wt.data_ptr()), ctypes.c_void_p(y.data_ptr()), n, h, w, cin, cout,
-                                             int(stride), int(in_dilation), _native.current_stream_ptr())
-    _native.check(rc, "octa_conv3x3_nhwc_fwd")
+    rc = _native.lib().octa_conv3x3_nhwc_fwd2(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), None, cin,
+                                              ctypes.c_void_p(wt.data_ptr()), ctypes.c_void_p(y.data_ptr()), None, cout, n, h, w, cin, cout,
+                                              int(stride), int(in_dilation), int(tap_mask), _native.current_stream_ptr())
+    _native.check(rc, "octa_conv3x3_nhwc_fwd2")
     return y
 
 
-def conv3x3_nhwc_wgrad(x, dy):
+def conv3x3_nhwc_wgrad(x, dy, tap_mask=0x1ff):
     """x [N,H,W,Cin] bf16, dy [N,H,W,Cout] bf16 (stride-1 layer) -> dW as a torch conv weight gradient
-    [Cout, Cin, 3, 3] float32."""
+    [Cout, Cin, 3, 3] float32 (taps cleared in tap_mask come back as zero)."""
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and dy.dtype == torch.bfloat16 and dy.is_contiguous()
     n, h, w, cin = x.shape
     assert dy.shape[:3] == x.shape[:3]
     cout = dy.shape[3]
     dw = torch.empty((9, cout, cin), dtype=torch.float32, device=x.device)
-    rc = _native.lib().octa_conv3x3_nhwc_wgrad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
-                                               ctypes.c_void_p(dw.data_ptr()), n, h, w, cin, cout, _native.current_stream_ptr())
-    _native.check(rc, "octa_conv3x3_nhwc_wgrad")
+    rc = _native.lib().octa_conv3x3_nhwc_wgrad2(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), None, cin,
+                                                ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(dw.data_ptr()), n, h, w, cin, cout, int(tap_mask),
+                                                _native.current_stream_ptr())
+    _native.check(rc, "octa_conv3x3_nhwc_wgrad2")
     return dw.view(3, 3, cout, cin).permute(2, 3, 0, 1)
 
 
@@ -125,7 +127,7 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
         y = torch.empty((n, h, w, cout), dtype=torch.bfloat16, device=x1.device)
         wt = pack_weight(weight)
         rc = _native.lib().octa_conv3x3_nhwc_fwd2(_native.ctx(x1.device.index), _p(x1), _p(x2), c1, _p(wt), _p(y), None, cout, n, h, w, c1 + c2,
-                                                  cout, 1, 1, _native.current_stream_ptr())
+                                                  cout, 1, 1, 0x1ff, _native.current_stream_ptr())
         _native.check(rc, "octa_conv3x3_nhwc_fwd2")
         ctx.save_for_backward(x1, x2, weight)
         return y
@@ -143,11 +145,11 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
             wd = pack_weight_dgrad(weight)
-            rc = lib.octa_conv3x3_nhwc_fwd2(hctx, _p(dy), None, cout, _p(wd), _p(dx1), _p(dx2), c1, n, h, w, cout, c1 + c2, 1, 1, st)
+            rc = lib.octa_conv3x3_nhwc_fwd2(hctx, _p(dy), None, cout, _p(wd), _p(dx1), _p(dx2), c1, n, h, w, cout, c1 + c2, 1, 1, 0x1ff, st)
             _native.check(rc, "octa_conv3x3_nhwc_fwd2 (data gradient)")
         if ctx.needs_input_grad[2]:
             dwf = torch.empty((9, cout, c1 + c2), dtype=torch.float32, device=x1.device)
-            rc = lib.octa_conv3x3_nhwc_wgrad2(hctx, _p(x1), _p(x2), c1, _p(dy), _p(dwf), n, h, w, c1 + c2, cout, st)
+            rc = lib.octa_conv3x3_nhwc_wgrad2(hctx, _p(x1), _p(x2), c1, _p(dy), _p(dwf), n, h, w, c1 + c2, cout, 0x1ff, st)
             _native.check(rc, "octa_conv3x3_nhwc_wgrad2")
             dw = dwf.view(3, 3, cout, c1 + c2).permute(2, 3, 0, 1).to(weight.dtype)
         return dx1, dx2, dw
@@ -200,18 +202,24 @@ def instance_norm_leaky_relu_nhwc(x, weight, bias, negative_slope=0.01, eps=1e-5
     return _InstNormLReLUNHWC.apply(x, weight, bias, negative_slope, eps)
 
 
-def _s2_wgrad(x_big, dy_small):
+def _s2_wgrad(x_big, dy_small, taps2=((0, 1, 2), (0, 1, 2))):
     """Weight gradient [Cout, Cin, 3, 3] (float32) of a stride-2, padding-1 3x3 conv with input x_big [N,2H,2W,Cin] and
     output gradient dy_small [N,H,W,Cout]: the nine taps are stride-1 taps of the four parity planes of the input."""
     cout, cin = dy_small.shape[-1], x_big.shape[-1]
     dw9 = torch.empty((3, 3, cout, cin), dtype=torch.float32, device=x_big.device)
     taps = {1: ((0, 0), (1, 2)), 0: ((1, 1),)}   # plane parity -> ((stride-1 tap, stride-2 tap), ...)
+    dw9.zero_()
     for pa in (0, 1):
         for pb in (0, 1):
-            g = conv3x3_nhwc_wgrad(x_big[:, pa::2, pb::2, :].contiguous(), dy_small)
-            for i, r in taps[pa]:
-                for j, s_ in taps[pb]:
-                    dw9[r, s_] = g[:, :, i, j]
+            want = [(i, r, j, s_) for i, r in taps[pa] if r in taps2[0] for j, s_ in taps[pb] if s_ in taps2[1]]
+            if not want:
+                continue
+            mask = 0
+            for i, r, j, s_ in want:
+                mask |= 1 << (3 * i + j)
+            g = conv3x3_nhwc_wgrad(x_big[:, pa::2, pb::2, :].contiguous(), dy_small, tap_mask=mask)
+            for i, r, j, s_ in want:
+                dw9[r, s_] = g[:, :, i, j]
     return dw9.permute(2, 3, 0, 1)
 
 
@@ -226,7 +234,8 @@ class _ConvT2x2NHWC(torch.autograd.Function):
         cin, cout = weight.shape[0], weight.shape[1]
         wc = weight.new_zeros((cin, cout, 3, 3))
         wc[:, :, 1:, 1:] = weight
-        y = conv3x3_nhwc(x, pack_weight_dgrad(wc), stride=1, in_dilation=2)
+        # wc has taps r, s in {1, 2}; flipped for the data-gradient form they sit at r, s in {0, 1}
+        y = conv3x3_nhwc(x, pack_weight_dgrad(wc), stride=1, in_dilation=2, tap_mask=0b000011011)
         ctx.save_for_backward(x, wc)
         return y
 
@@ -238,9 +247,9 @@ class _ConvT2x2NHWC(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = conv3x3_nhwc(dy, pack_weight(wc), stride=2)
+            dx = conv3x3_nhwc(dy, pack_weight(wc), stride=2, tap_mask=0b110110000)
         if ctx.needs_input_grad[1]:
-            dw = _s2_wgrad(dy, x)[:, :, 1:, 1:].to(wc.dtype)
+            dw = _s2_wgrad(dy, x, taps2=((1, 2), (1, 2)))[:, :, 1:, 1:].to(wc.dtype)
         return dx, dw
 
 
