@@ -197,9 +197,10 @@ extern "C" int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void 
 // rows; workgroups are persistent over the pixel tiles and add their fp32 partial sums to dW with atomics once.
 namespace {
 
-constexpr int WG_ROWP = TW * 2 * TH;   // bytes per channel row of the transposed dY tile (256 pixels)
+constexpr int WTH = 4;                 // tile rows of the weight-gradient kernel (4 x 32 = 128 pixels per tile)
+constexpr int WG_ROWP = TW * 2 * WTH;  // bytes per channel row of the transposed dY tile
 constexpr int HALO_W = 40;             // halo row pitch in pixels (34 used; 80 B keeps rows 16-byte aligned)
-constexpr int WG_XROW = (TH + 2) * HALO_W * 2;  // bytes per channel row of the transposed X tile
+constexpr int WG_XROW = (WTH + 2) * HALO_W * 2;  // bytes per channel row of the transposed X tile
 
 template <int COB, int CIB>
 __global__ void __launch_bounds__(CONV_THREADS)
@@ -208,10 +209,13 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
                           int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask) {
     constexpr int PAIRS = (COB / 32) * (CIB / 32);
     constexpr int KSPLIT = 4 / PAIRS;            // waves sharing one (co, ci) pair split the tile rows
-    constexpr int ROWS_PER_WAVE = TH / KSPLIT;
+    constexpr int ROWS_PER_WAVE = WTH / KSPLIT;
+    constexpr int SLOTS = ROWS_PER_WAVE * (TW / 16);   // MFMA groups of the compute loop = places to tuck LDS stores
+    constexpr int DYPIX = WTH * TW, XPIX = (WTH + 2) * (TW + 2);
+    constexpr int DY_ITEMS = DYPIX * (COB / 8), X_ITEMS = XPIX * (CIB / 8);   // 16-byte pieces per tile
+    constexpr int DY_PT = (DY_ITEMS + CONV_THREADS - 1) / CONV_THREADS, X_PT = (X_ITEMS + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int BUF = COB * WG_ROWP + CIB * WG_XROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *s_dy = smem;                       // [COB][256 px] bf16
-    unsigned char *s_x = smem + COB * WG_ROWP;        // [CIB][TH+2][HALO_W] bf16
     const int co0 = (blockIdx.y / (Cin / CIB)) * COB, ci0 = (blockIdx.y % (Cin / CIB)) * CIB;
     // virtual concatenation of the input: a CIB block lies entirely in X (channels < C1) or in X2
     const unsigned short *Xs = ci0 < C1 ? X : X2;
@@ -226,91 +230,95 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[t][k] = 0.f;
     const int n_tiles = tiles_x * tiles_y * N;
-    // Software pipeline: the global loads of the NEXT tile are issued into registers before the MFMA loop of the
-    // current one and written (transposed) to LDS after it. A thread owns one pixel of the dY tile and up to two
-    // of the X halo tile and reads all their channels (consecutive 16-byte loads of one line); consecutive lanes =
-    // consecutive pixels, so every 2-byte LDS store of a wave covers 128 contiguous bytes of one channel row.
-    constexpr int XPIX = (TH + 2) * (TW + 2);
-    uint4 r_dy[COB / 8], r_x[2][CIB / 8];
+    // Pipeline over the tiles of this workgroup: tile t is contracted out of LDS buffer t&1 while the registers
+    // holding tile t+1 (loaded from HBM during tile t-1) are written, transposed, into the other buffer BETWEEN the
+    // MFMA groups -- LDS stores issue in the shadow of the matrix pipe -- and the loads of tile t+2 are issued.
+    // Item i of a tile: pixel i % NPIX, 8-channel group i / NPIX, so consecutive lanes hold consecutive pixels and
+    // every 2-byte LDS store of a wave covers contiguous bytes of one channel row (no bank conflicts).
+    uint4 r_dy[DY_PT], r_x[X_PT];
     auto fetch = [&](int tile) {
         const int n = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
-        const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
-        {
-            const int p = threadIdx.x, y = ty0 + p / TW, x = tx0 + p % TW;
-            const bool ok = y < H && x < W;
-            const unsigned short *src = dY + (((size_t)n * H + (ok ? y : 0)) * W + (ok ? x : 0)) * Cout + co0;
+        const int ty0 = (tt / tiles_x) * WTH, tx0 = (tt % tiles_x) * TW;
 #pragma unroll
-            for (int q = 0; q < COB / 8; q++) r_dy[q] = ok ? *reinterpret_cast<const uint4 *>(src + q * 8) : make_uint4(0u, 0u, 0u, 0u);
+        for (int k = 0; k < DY_PT; k++) {
+            const int i = threadIdx.x + k * CONV_THREADS, p = i % DYPIX, q = i / DYPIX;
+            const int y = ty0 + p / TW, x = tx0 + p % TW;
+            const bool ok = i < DY_ITEMS && y < H && x < W;
+            r_dy[k] = ok ? *reinterpret_cast<const uint4 *>(dY + (((size_t)n * H + y) * W + x) * Cout + co0 + q * 8) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int p = threadIdx.x + h * CONV_THREADS;
+        for (int k = 0; k < X_PT; k++) {
+            const int i = threadIdx.x + k * CONV_THREADS, p = i % XPIX, q = i / XPIX;
+            const int y = ty0 - 1 + p / (TW + 2), x = tx0 - 1 + p % (TW + 2);
+            const bool ok = i < X_ITEMS && y >= 0 && y < H && x >= 0 && x < W;
+            r_x[k] = ok ? *reinterpret_cast<const uint4 *>(Xs + (((size_t)n * H + y) * W + x) * xcs + xcb + q * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stash_dy = [&](unsigned char *buf, int k) {
+        const int i = threadIdx.x + k * CONV_THREADS, p = i % DYPIX, q = i / DYPIX;
+        if (i < DY_ITEMS) {
+            const unsigned w4[4] = {r_dy[k].x, r_dy[k].y, r_dy[k].z, r_dy[k].w};
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                *reinterpret_cast<unsigned short *>(buf + (q * 8 + j) * WG_ROWP + p * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+        }
+    };
+    auto stash_x = [&](unsigned char *buf, int k) {
+        const int i = threadIdx.x + k * CONV_THREADS, p = i % XPIX, q = i / XPIX;
+        if (i < X_ITEMS) {
             const int hy = p / (TW + 2), hx = p % (TW + 2);
-            const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-            const bool ok = p < XPIX && y >= 0 && y < H && x >= 0 && x < W;
-            const unsigned short *src = Xs + (((size_t)n * H + (ok ? y : 0)) * W + (ok ? x : 0)) * xcs + xcb;
+            const unsigned w4[4] = {r_x[k].x, r_x[k].y, r_x[k].z, r_x[k].w};
 #pragma unroll
-            for (int q = 0; q < CIB / 8; q++) r_x[h][q] = ok ? *reinterpret_cast<const uint4 *>(src + q * 8) : make_uint4(0u, 0u, 0u, 0u);
+            for (int j = 0; j < 8; j++)
+                *reinterpret_cast<unsigned short *>(buf + COB * WG_ROWP + (q * 8 + j) * WG_XROW + (hy * HALO_W + hx) * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
         }
     };
-    auto stash = [&]() {
-        {
-            const int p = threadIdx.x;
+    int tile = blockIdx.x;
+    if (tile < n_tiles) {
+        fetch(tile);
 #pragma unroll
-            for (int q = 0; q < COB / 8; q++) {
-                const unsigned w4[4] = {r_dy[q].x, r_dy[q].y, r_dy[q].z, r_dy[q].w};
+        for (int k = 0; k < DY_PT; k++) stash_dy(smem, k);
 #pragma unroll
-                for (int j = 0; j < 8; j++)
-                    *reinterpret_cast<unsigned short *>(s_dy + (q * 8 + j) * WG_ROWP + p * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int p = threadIdx.x + h * CONV_THREADS;
-            if (p < XPIX) {
-                const int hy = p / (TW + 2), hx = p % (TW + 2);
-#pragma unroll
-                for (int q = 0; q < CIB / 8; q++) {
-                    const unsigned w4[4] = {r_x[h][q].x, r_x[h][q].y, r_x[h][q].z, r_x[h][q].w};
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        *reinterpret_cast<unsigned short *>(s_x + (q * 8 + j) * WG_XROW + (hy * HALO_W + hx) * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
-                }
-            }
-        }
-    };
-    static_assert(TH * TW == CONV_THREADS && XPIX <= 2 * CONV_THREADS, "one dY pixel and at most two halo pixels per thread");
-    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        __syncthreads();
-        stash();
-        __syncthreads();
+        for (int k = 0; k < X_PT; k++) stash_x(smem, k);
         if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
-        // contraction over this wave's rows: K-steps of 16 consecutive pixels of one tile row
-#pragma unroll 1
-        for (int rr = 0; rr < ROWS_PER_WAVE; rr++) {
-            const int y = kpart * ROWS_PER_WAVE + rr;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const unsigned char *s_dy = smem + cur * BUF, *s_x = s_dy + COB * WG_ROWP;
+        unsigned char *nxt = smem + (cur ^ 1) * BUF;
+        const bool have_next = tile + (int)gridDim.x < n_tiles;
 #pragma unroll
-            for (int xs = 0; xs < TW; xs += 16) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_dy + (cob + m) * WG_ROWP + (y * TW + xs + kg * 8) * 2);
+        for (int slot = 0; slot < SLOTS; slot++) {
+            const int y = kpart * ROWS_PER_WAVE + slot / (TW / 16), xs = (slot % (TW / 16)) * 16;
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_dy + (cob + m) * WG_ROWP + (y * TW + xs + kg * 8) * 2);
 #pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    if (!((tap_mask >> (3 * r)) & 7)) continue;   // no tap of this kernel row is wanted
-                    // halo columns xs + kg*8 + s .. +7 of halo row y + r: aligned 8-pixel group + the next dword
-                    const unsigned char *row = s_x + (cib + m) * WG_XROW + ((y + r) * HALO_W + xs + kg * 8) * 2;
-                    const uint4 d = *reinterpret_cast<const uint4 *>(row);
-                    const unsigned e = *reinterpret_cast<const unsigned *>(row + 16);
-                    union { uint4 u; bf16x8 v; } b0, b1, b2;
-                    b0.u = d;
-                    b1.u = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
-                                      __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
-                    b2.u = make_uint4(d.y, d.z, d.w, e);
-                    if ((tap_mask >> (3 * r)) & 1) acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0.v, acc[3 * r + 0], 0, 0, 0);
-                    if ((tap_mask >> (3 * r + 1)) & 1) acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1.v, acc[3 * r + 1], 0, 0, 0);
-                    if ((tap_mask >> (3 * r + 2)) & 1) acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2.v, acc[3 * r + 2], 0, 0, 0);
-                }
+            for (int r = 0; r < 3; r++) {
+                if (!((tap_mask >> (3 * r)) & 7)) continue;   // no tap of this kernel row is wanted
+                // halo columns xs + kg*8 + s .. +7 of halo row y + r: aligned 8-pixel group + the next dword
+                const unsigned char *row = s_x + (cib + m) * WG_XROW + ((y + r) * HALO_W + xs + kg * 8) * 2;
+                const uint4 d = *reinterpret_cast<const uint4 *>(row);
+                const unsigned e = *reinterpret_cast<const unsigned *>(row + 16);
+                union { uint4 u; bf16x8 v; } b0, b1, b2;
+                b0.u = d;
+                b1.u = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
+                                  __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
+                b2.u = make_uint4(d.y, d.z, d.w, e);
+                if ((tap_mask >> (3 * r)) & 1) acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0.v, acc[3 * r + 0], 0, 0, 0);
+                if ((tap_mask >> (3 * r + 1)) & 1) acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1.v, acc[3 * r + 1], 0, 0, 0);
+                if ((tap_mask >> (3 * r + 2)) & 1) acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2.v, acc[3 * r + 2], 0, 0, 0);
+            }
+            // a share of the next tile's transposed stores, tucked behind this MFMA group
+            if (have_next) {
+#pragma unroll
+                for (int k = slot; k < DY_PT; k += SLOTS) stash_dy(nxt, k);
+#pragma unroll
+                for (int k = slot; k < X_PT; k += SLOTS) stash_x(nxt, k);
             }
         }
+        if (tile + 2 * (int)gridDim.x < n_tiles) fetch(tile + 2 * gridDim.x);
+        __syncthreads();
+        cur ^= 1;
     }
     // D[row = co][col = ci]: row = (k&3) + 8*(k>>2) + 4*kg, col = m
 #pragma unroll
@@ -327,8 +335,8 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
 template <int COB, int CIB>
 int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
                  int Cout, int num_cus, int tap_mask, hipStream_t stream) {
-    const size_t lds = (size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const size_t lds = 2 * ((size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW);   // double buffered
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + WTH - 1) / WTH;
     const int blocks = (Cout / COB) * (Cin / CIB);
     int per_block = (2 * num_cus + blocks - 1) / blocks;
     const int n_tiles = tiles_x * tiles_y * N;
