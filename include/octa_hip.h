@@ -150,6 +150,14 @@ int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void 
 int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2, int CY1,
                            int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask, void *stream);
 
+/* Same, with a scattered output: result pixel (y, x) is stored at (y * out_scale + out_off_y, x * out_scale +
+ * out_off_x) of a d_y image out_scale (1 or 2) times larger. With out_scale 2, one call per parity class and the
+ * taps / weights of that class, a stride-2 data gradient or a 2x2 transposed convolution runs without any
+ * multiplication by inserted zeros. */
+int octa_conv3x3_nhwc_fwd3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2, int CY1,
+                           int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask, int out_scale,
+                           int out_off_y, int out_off_x, void *stream);
+
 /* Weight gradient of the stride-1 layer above: d_dw [9][Cout][Cin] float32 (overwritten) =
  * sum over pixels of d_dy[N][H][W][Cout] (bf16) x d_x[N][H][W][Cin] (bf16) shifted by the tap (SURVEY.md 8b:
  * octa_conv2d_wgrad). fp32 accumulation; partial sums of the persistent workgroups meet in fp32 atomics, so the

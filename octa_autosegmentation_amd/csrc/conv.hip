@@ -48,7 +48,7 @@ template <int BN, int ST>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                     const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
-                    int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, int tap_mask) {
+                    int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, int tap_mask, int osc, int ooy, int oox) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;  // halo tile
     constexpr int NB = BN / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -90,6 +90,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
         for (int i = threadIdx.x; i < 9 * BN * 4; i += CONV_THREADS) {
             const int row = i >> 2, q = i & 3;
             const int tap = row / BN, co = row % BN;
+            if (!((tap_mask >> tap) & 1)) continue;   // unused taps are neither staged nor multiplied
             const uint4 v = *reinterpret_cast<const uint4 *>(Wt + ((size_t)tap * Cout + co0 + co) * Cin + c0 + q * 8);
             *reinterpret_cast<uint4 *>(s_w + row * PITCH + q * 16) = v;
         }
@@ -120,8 +121,11 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
     }
     // epilogue: D[row = pixel x][col = output channel]; row = (k&3) + 8*(k>>2) + 4*(lane>>5), col = lane&31.
     // Split output: channels [0, CY1) go to Y, the rest to Y2 (a BN block never straddles CY1).
+    // Scattered output: result pixel (oy, ox) is stored at (oy * osc + ooy, ox * osc + oox) of an image osc times
+    // larger (osc = 2: one parity class of a zero-insertion-free stride-2 data gradient / 2x2 transposed convolution).
     unsigned short *Yo = co0 < CY1 ? Y : Y2;
     const int ys = co0 < CY1 ? CY1 : Cout - CY1, yb = co0 < CY1 ? co0 : co0 - CY1;
+    const int HoF = Ho * osc, WoF = Wo * osc;
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int oy = ty0 + 2 * wv + rr;
@@ -131,30 +135,31 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int ox = tx0 + (k & 3) + 8 * (k >> 2) + 4 * kg;
-                if (ox < Wo) Yo[(((size_t)n * Ho + oy) * Wo + ox) * ys + yb + nb * 32 + m] = f2bf(acc[rr][nb][k]);
+                if (ox < Wo) Yo[(((size_t)n * HoF + oy * osc + ooy) * WoF + ox * osc + oox) * ys + yb + nb * 32 + m] = f2bf(acc[rr][nb][k]);
             }
     }
 }
 
 template <int BN, int ST>
 int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
-                int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tap_mask, hipStream_t stream) {
+                int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tap_mask, int osc, int ooy, int oox,
+                hipStream_t stream) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;
     const size_t lds = (size_t)IH * IW * PITCH + (size_t)9 * BN * PITCH;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
     auto kern = conv3x3_nhwc_kernel<BN, ST>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
-    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, tap_mask);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, tap_mask, osc, ooy, oox);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+extern "C" int octa_conv3x3_nhwc_fwd3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
                                       int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
-                                      void *stream_) {
+                                      int out_scale, int out_off_y, int out_off_x, void *stream_) {
     if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv3x3_nhwc_fwd: null pointer"); return -2; }
     if (N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: bad shape"); return -2; }
     if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
@@ -167,6 +172,10 @@ extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void
     if (!d_y2) CY1 = Cout;
     tap_mask &= 0x1ff;
     if (tap_mask == 0) { octa::set_error("octa_conv3x3_nhwc_fwd: empty tap mask"); return -2; }
+    if (out_scale < 1 || out_scale > 2 || out_off_y < 0 || out_off_y >= out_scale || out_off_x < 0 || out_off_x >= out_scale) {
+        octa::set_error("octa_conv3x3_nhwc_fwd: output scatter must be scale 1 or 2 with offsets below the scale");
+        return -2;
+    }
     if (C1 <= 0 || C1 > Cin || C1 % 32 || CY1 <= 0 || CY1 > Cout || CY1 % 32) { octa::set_error("octa_conv3x3_nhwc_fwd: channel splits must be multiples of 32 inside the channel range"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
@@ -176,10 +185,16 @@ extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void
     const unsigned short *Wt = static_cast<const unsigned short *>(d_w);
     unsigned short *Y = static_cast<unsigned short *>(d_y), *Y2 = static_cast<unsigned short *>(d_y2);
     const bool wide = (Cout % 64 == 0) && (CY1 % 64 == 0);   // a 64-channel block must not straddle the output split
-    if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, stream)
-                                 : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, stream);
-    return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, stream)
-                : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, stream);
+    if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, stream)
+                                 : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, stream);
+    return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, stream)
+                : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, stream);
+}
+
+extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+                                      int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
+                                      void *stream_) {
+    return octa_conv3x3_nhwc_fwd3(ctx, d_x, d_x2, C1, d_w, d_y, d_y2, CY1, N, H, W, Cin, Cout, stride, in_dilation, tap_mask, 1, 0, 0, stream_);
 }
 
 extern "C" int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin,

@@ -147,6 +147,25 @@ def test_transposed_conv_2x2(hip_lib_built, cin, cout):
     assert (wm.grad - wr.grad).abs().max().item() <= wr.grad.abs().max().item() * 1e-3 + 1e-5
 
 
+def test_parity_scatter_forms(hip_lib_built):
+    """The zero-insertion-free forms (one scattered launch per output parity) agree with torch too."""
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.models import mfma_conv
+    g = torch.Generator(device="cuda").manual_seed(9)
+    w = (torch.randn(64, 32, 3, 3, device="cuda", generator=g) / 17.0).to(torch.bfloat16).float()
+    x = torch.randn(1, 32, 24, 40, device="cuda", generator=g).to(torch.bfloat16).float().requires_grad_(True)
+    y = F.conv2d(x, w, stride=2, padding=1)
+    dy = torch.randn(y.shape, device="cuda", generator=g).to(torch.bfloat16)
+    y.backward(dy.float())
+    got = mfma_conv.conv3x3_s2_dgrad(dy.permute(0, 2, 3, 1).contiguous(), w)
+    _check(got, x.grad.permute(0, 2, 3, 1))
+    wt = (torch.randn(64, 32, 2, 2, device="cuda", generator=g) / 8.0).to(torch.bfloat16).float()
+    xt = torch.randn(2, 10, 18, 64, device="cuda", generator=g).to(torch.bfloat16)
+    want = F.conv_transpose2d(xt.float().permute(0, 3, 1, 2), wt, stride=2).permute(0, 2, 3, 1)
+    _check(mfma_conv.conv_transpose_2x2_fwd(xt, wt), want)
+
+
 def test_head_kernels(hip_lib_built):
     import torch
     from octa_autosegmentation_amd.models import mfma_conv
