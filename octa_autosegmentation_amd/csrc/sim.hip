@@ -28,6 +28,7 @@ namespace {
 constexpr int SIM_THREADS = 512;
 constexpr size_t SIM_LDS = SIM_LDS_BYTES;
 static_assert(2048 + (size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES <= SIM_LDS && SIM_LDS <= 160 * 1024, "LDS budget");
+static_assert((624 + 1248) * 4 <= SEQ_SIDE_LDS, "the Mersenne-Twister state and queue of the candidate stream fit the side-job LDS");
 static_assert(SIM_THREADS == 64 * KD_WAVES, "kd mailboxes are sized for KD_WAVES waves");
 constexpr int REQ_CAP = 8192;
 
@@ -51,6 +52,7 @@ struct BatchPtrs {
     unsigned long long *set_hash;
     int *set_key, *tmp_int;
     double *grid_pts;
+    unsigned *cand_idx;          // [B][NCANDCAP] voxel picks of the overlapped candidate stream
     double *tmp_dbl;
     SampleScalars *sc;
     IterParams *iters;
@@ -163,10 +165,9 @@ struct WaveMt {
 
 // executed by wave 0 of the sample's workgroup; lds: 624 + 1248 + N words
 __device__ void gen_candidates_wave(unsigned *g_state /*[625]*/, const unsigned short *valid, unsigned K, int N, double *out,
-                                    unsigned *lds, int lane) {
+                                    unsigned *lds, unsigned *idx /* [N] scratch, LDS or HBM */, int lane) {
     WaveMt g;
     g.st = lds; g.ob = lds + 624; g.lane = lane;
-    unsigned *idx = lds + 624 + 1248;
     for (int i = lane; i < 624; i += 64) g.st[i] = g_state[i];
     int sidx = (int)g_state[624];
     __builtin_amdgcn_wave_barrier();
@@ -246,7 +247,8 @@ sim_iter_a_kernel(BatchPtrs B, int it, int finish_prev) {
         long _t0 = (long)wall_clock64();
         if (threadIdx.x < 64)
             gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], P.N,
-                                B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()), (int)threadIdx.x);
+                                B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()),
+                                reinterpret_cast<unsigned *>(b.user()) + 624 + 1248, (int)threadIdx.x);
         __syncthreads();
         if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
     }
@@ -332,11 +334,12 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
         }
         if (it >= n_iter) break;
         const IterParams P = B.iters[it];
-        {
+        if (it == 0) {   // later iterations get their candidates from the side job of the previous ordered arterial pass
             long _t0 = (long)wall_clock64();
             if (threadIdx.x < 64)
                 gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], P.N,
-                                    B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()), (int)threadIdx.x);
+                                    B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()),
+                                    reinterpret_cast<unsigned *>(b.user()) + 624 + 1248, (int)threadIdx.x);
             __syncthreads();
             if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
         }
@@ -347,7 +350,20 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
         OCTA_PROF(2, phase_pre(b, A, B.C, P, 0, A.oxy, reqs, req_n, REQ_PER_SAMPLE, s));
         mail_roundtrip(b, A, M, s, *req_n, 2 * it + 1);
         if (uniform_err(b, A)) break;
-        OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, results));
+        {
+            // the candidate stream of the NEXT iteration (numpy MT19937, one wave) runs beside the ordered arterial pass:
+            // it only depends on the generator state, and the candidate buffer is free once phase_sample has consumed it
+            const int n_next = it + 1 < n_iter ? B.iters[it + 1].N : 0;
+            auto next_candidates = [&](unsigned char *lds) {
+                if (n_next <= 0) return;
+                const long _t0 = (long)wall_clock64();
+                gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], n_next,
+                                    B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(lds),
+                                    B.cand_idx + (size_t)s * NCANDCAP, (int)(threadIdx.x & 63));
+                if ((threadIdx.x & 63) == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
+            };
+            OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, results, next_candidates));
+        }
         OCTA_PROF(4, phase_satisfy_art(b, A, P));
         OCTA_PROF(6, phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven));
         if (b.tid == 0) *req_n = 0;
@@ -440,7 +456,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     rc |= dev_alloc(S, &P.kd_idx, nb * OCAP); rc |= dev_alloc(S, &P.kd_rank, nb * OCAP);
     rc |= dev_alloc(S, &P.removed, nb * OCAP); rc |= dev_alloc(S, &P.ven_near, nb * OCAP); rc |= dev_alloc(S, &P.hashes, nb * OCAP);
     rc |= dev_alloc(S, &P.pairs, nb * PCAP); rc |= dev_alloc(S, &P.set_hash, nb * SETCAP); rc |= dev_alloc(S, &P.set_key, nb * SETCAP);
-    rc |= dev_alloc(S, &P.grid_pts, nb * GRID_N * 3);
+    rc |= dev_alloc(S, &P.grid_pts, nb * GRID_N * 3); rc |= dev_alloc(S, &P.cand_idx, nb * NCANDCAP);
     rc |= dev_alloc(S, &P.tmp_int, nb * (OCAP + 2 * NCANDCAP)); rc |= dev_alloc(S, &P.tmp_dbl, nb * OCAP * 3);
     rc |= dev_alloc(S, &P.sc, nb); rc |= dev_alloc(S, &P.iters, S->iters.size() + 1);
     rc |= dev_alloc(S, &P.reqs, (size_t)2 * REQ_CAP); rc |= dev_alloc(S, &P.req_count, 4); rc |= dev_alloc(S, &P.bif_results, (size_t)2 * REQ_CAP * 6);

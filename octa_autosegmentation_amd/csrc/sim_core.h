@@ -31,7 +31,7 @@
 
 namespace octa_simk {
 
-constexpr int NCAP = 15360;    // nodes per forest (radii f64 + parent u16 of one forest fit the LDS in the ordered pass)
+constexpr int NCAP = 14336;    // nodes per forest (radii f64 + parent u16 of one forest + a 7.5 KiB side-job area fit the LDS in the ordered pass)
 constexpr int OCAP = 13312;    // live O2 sinks (LDS-resident kd keys bound this)
 constexpr int CCAP = 8192;     // live CO2 sources
 constexpr int GCAP = 8192;     // nodes with attractors per growth pass
@@ -1465,8 +1465,14 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
 // Only the groups that grow under the speculation are visited, plus the (rare) inter-nodes whose child
 // radius an earlier node of this pass changed (dirty list fed by murray_to_root); this visits exactly the
 // groups for which the reference's sequential loop does anything.
+struct NoSideJob { OCTA_HD void operator()(unsigned char *) const {} };
+constexpr int SEQ_SIDE_LDS = 7680;   // bytes of LDS handed to the side job of the ordered pass
+
+// side: work that does not depend on the ordered pass, run by the SECOND wave while the first one is busy with it
+// (device only; e.g. the candidate stream of the next iteration). It gets SEQ_SIDE_LDS bytes of LDS.
+template <class Side = NoSideJob>
 OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
-                              const double *att, const double *bif_results /* [req][6] */) {
+                              const double *att, const double *bif_results /* [req][6] */, Side side = Side()) {
     SampleScalars *sc = A.sc;
     // LDS for the duration of the pass: radii (NCAP f64) and parents (NCAP u16) of this forest, the pow tables
     SeqLds L;
@@ -1474,9 +1480,10 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     L.par = reinterpret_cast<unsigned short *>(b.user() + (size_t)NCAP * 8);
     double *ltab = reinterpret_cast<double *>(b.user() + (size_t)NCAP * 10);
     uint64_t *etab = reinterpret_cast<uint64_t *>(ltab + 384);
-    static_assert((size_t)NCAP * 10 + 384 * 8 + 256 * 8 + 2048 + 2048 <= (size_t)SIM_LDS_BYTES, "ordered-pass LDS layout");
+    static_assert((size_t)NCAP * 10 + 384 * 8 + 256 * 8 + 2048 + SEQ_SIDE_LDS + 2048 <= (size_t)SIM_LDS_BYTES, "ordered-pass LDS layout");
     L.log_tab = ltab; L.exp_tab = etab;
     L.stage = reinterpret_cast<unsigned char *>(etab + 256);
+    unsigned char *side_lds = L.stage + 2048;
     const int n_before = sc->n_nodes[f];
     for (int i = b.tid; i < n_before; i += b.nth) {
         L.rad[i] = A.nrad[f][i];
@@ -1588,6 +1595,13 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
         sc->respec += respec;
         if (b.tid == 0) { sc->kdprof[7] += t_acc[0]; (void)t_acc[1]; (void)t_acc[2]; }
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    else if (b.tid < 128) {
+        side(side_lds);
+    }
+#else
+    (void)side; (void)side_lds;
+#endif
 #undef SEQT
     b.sync();
     // radii changed by Murray go back to HBM (new nodes were written through)
