@@ -161,6 +161,10 @@ class DynUNet(nn.Module):
     def _mfma_path_ok(self, x):
         if not (USE_MFMA_CONV and x.is_cuda and x.dim() == 4):
             return False
+        # bf16 arithmetic only where the caller asked for it (bf16 input or bf16 autocast, as the trainers do);
+        # fp32 inputs keep the fp32 modules (logits within 1e-4 of the CPU reference)
+        if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)):
+            return False
         blocks = [self.input_block, *self.downsamples, self.bottleneck, *[u.conv_block for u in self.upsamples]]
         for b in blocks:
             for c in (b.conv1.conv, b.conv2.conv):

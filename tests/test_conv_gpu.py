@@ -207,7 +207,7 @@ def test_dynunet_mfma_path_matches_torch_reference(hip_lib_built):
         networks.USE_MFMA_CONV, networks.USE_FUSED_NORM = mfma, mfma
         try:
             net.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast or mfma):   # the MFMA path is the bf16 path
                 out = net(x)
             loss = torch.nn.functional.binary_cross_entropy_with_logits(out.float(), tgt)
             loss.backward()
