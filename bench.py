@@ -135,6 +135,7 @@ def main():
 
     from concurrent.futures import ThreadPoolExecutor
     from octa_autosegmentation_amd import pipeline
+    from octa_autosegmentation_amd.utils import sharding
     cfg = load_config()
     B = args.batch
     n_fly = max(1, args.inflight)
@@ -145,7 +146,7 @@ def main():
 
     def step(i):
         slot = i % n_fly
-        seeds = (np.arange(B, dtype=np.int64) + 100000 * rank + 1000 * i + 7).astype(np.uint32)
+        seeds = sharding.rank_seeds(rank, i, B)
         torch.cuda.set_device(dev)
         with torch.cuda.stream(streams[slot]):
             out = gens[slot].generate(seeds)
@@ -195,10 +196,7 @@ def main():
         torch.cuda.empty_cache()
         train_info = unet_train_bench(dev, args.train_batch, dist, world)
 
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.max_over_ranks(dt, dist, dev)
 
     if rank == 0:
         value = world * B * args.steps / dt

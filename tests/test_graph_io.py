@@ -66,3 +66,32 @@ def test_batched_bifurcation_service_is_bitwise_the_reference_formula():
         p1, p2 = gh.bifurcation_children(recs[i, 1:4].copy(), recs[i, 7:7 + 3 * n].reshape(n, 3).copy(),
                                          float(recs[i, 4]), float(recs[i, 5]), float(recs[i, 6]))
         assert (fast[i, 0:3] == p1).all() and (fast[i, 3:6] == p2).all(), i
+
+
+def _shard_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    from octa_autosegmentation_amd.utils import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seeds = [sharding.rank_seeds(rank, step, 128) for step in range(3)]
+    t = sharding.max_over_ranks(1.0 + rank, dist)          # what bench.py does with its wall time
+    dist.barrier()
+    np.save(out + f".{rank}.npy", np.concatenate(seeds))
+    if rank == 0:
+        np.save(out + ".t.npy", np.array([t]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sample_sharding_is_disjoint_and_time_is_max(tmp_path):
+    """bench.py's N > 1 path without a GPU: two gloo ranks take disjoint seeds (no data-path collective) and agree on
+    the MAX of their step times."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "shard")
+    mp.spawn(_shard_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = np.load(out + ".0.npy"), np.load(out + ".1.npy")
+    assert len(set(a.tolist())) == len(a) == 384 and len(set(b.tolist())) == 384
+    assert not set(a.tolist()) & set(b.tolist())
+    assert float(np.load(out + ".t.npy")[0]) == 2.0
