@@ -128,6 +128,14 @@ int octa_instnorm_lrelu_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_d
                                  const float *d_mean, const float *d_rstd, void *d_dx, float *d_dw, float *d_db, int B, int C,
                                  int64_t hw, float slope, void *stream);
 
+/* Statistics only (for the normalise-on-load convolutions below): mean / rstd and the per-(image, channel) scale =
+ * w * rstd and shift = b - mean * scale (float32 [B*C] each). octa_scale_shift_lrelu_nhwc materialises
+ * y = lrelu(x * scale + shift) where a consumer needs the tensor itself. */
+int octa_instnorm_nhwc_stats(octa_ctx *ctx, const void *d_x, const float *d_w, const float *d_b, float *d_mean, float *d_rstd,
+                             float *d_scale, float *d_shift, int B, int C, int64_t hw, float eps, void *stream);
+int octa_scale_shift_lrelu_nhwc(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_scale, const float *d_shift, int B, int C,
+                                int64_t hw, float slope, void *stream);
+
 /* ---- 3x3 convolution on the matrix cores, NHWC bf16 (fp32 accumulate) --------------------
  * Replaces the bias-free 3x3 convolutions of DynUNet's UnetBasicBlock / UnetUpBlock (MONAI, imported at
  * models/networks.py:6; configs/config_ves_seg-S.yml:6-13: filters [32,64,128,256,512], strides [1,2,2,2,1])
@@ -157,6 +165,19 @@ int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void *d_x2, int
 int octa_conv3x3_nhwc_fwd3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2, int CY1,
                            int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask, int out_scale,
                            int out_off_y, int out_off_x, void *stream);
+
+/* Same, with NORMALISE-ON-LOAD: if d_scale1 / d_shift1 (float32 [N][C1]) are given, input 1 is the raw output of an
+ * earlier convolution and is read as lrelu(x * scale + shift) -- InstanceNorm(affine) + LeakyReLU(slope) per image
+ * and channel, rounded to bf16 exactly as the materialised tensor would be; likewise d_scale2 / d_shift2
+ * ([N][Cin - C1]) for input 2. Padding stays zero. The normalised activations of MONAI's UnetBasicBlock then never
+ * go to HBM. */
+int octa_conv3x3_nhwc_fwd4(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2, int CY1,
+                           int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask, int out_scale,
+                           int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1, const float *d_scale2,
+                           const float *d_shift2, float slope, void *stream);
+int octa_conv3x3_nhwc_wgrad3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H, int W,
+                             int Cin, int Cout, int tap_mask, const float *d_scale1, const float *d_shift1, const float *d_scale2,
+                             const float *d_shift2, float slope, void *stream);
 
 /* Weight gradient of the stride-1 layer above: d_dw [9][Cout][Cin] float32 (overwritten) =
  * sum over pixels of d_dy[N][H][W][Cout] (bf16) x d_x[N][H][W][Cin] (bf16) shifted by the tap (SURVEY.md 8b:

@@ -48,12 +48,15 @@ template <int BN, int ST>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                     const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
-                    int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, int tap_mask, int osc, int ooy, int oox) {
+                    int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, int tap_mask, int osc, int ooy, int oox,
+                    const float *__restrict__ sc1, const float *__restrict__ sh1, const float *__restrict__ sc2,
+                    const float *__restrict__ sh2, float slope) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;  // halo tile
     constexpr int NB = BN / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *s_in = smem;                          // [IH][IW] pixels x PITCH
     unsigned char *s_w = smem + IH * IW * PITCH;         // [9][BN] rows x PITCH
+    float *s_ss = reinterpret_cast<float *>(s_w + 9 * BN * PITCH);  // [2][KC] scale / shift of the current input slice
     const int tile = blockIdx.x, n = blockIdx.z, co0 = blockIdx.y * BN;
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -73,6 +76,16 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
         // virtual concatenation: channels [0, C1) come from X, [C1, Cin) from X2 (C1 is a multiple of KC)
         const unsigned short *Xs = c0 < C1 ? X : X2;
         const int cs = c0 < C1 ? C1 : Cin - C1, cb = c0 < C1 ? c0 : c0 - C1;
+        // Normalise-on-load: an input that is the RAW output of an earlier convolution is turned into
+        // lrelu(x * scale + shift) (InstanceNorm affine + LeakyReLU, per image and channel) while it is staged, rounded
+        // to bf16 exactly like the materialised tensor would have been; padding stays zero.
+        const float *scp = c0 < C1 ? sc1 : sc2, *shp = c0 < C1 ? sh1 : sh2;
+        const bool xform = scp != nullptr;
+        if (xform) {
+            if (threadIdx.x < KC) s_ss[threadIdx.x] = scp[(size_t)n * cs + cb + threadIdx.x];
+            else if (threadIdx.x < 2 * KC) s_ss[threadIdx.x] = shp[(size_t)n * cs + cb + threadIdx.x - KC];
+            __syncthreads();
+        }
         // stage the input slice: 16-byte pieces (8 channels), 4 per pixel
         for (int i = threadIdx.x; i < IH * IW * 4; i += CONV_THREADS) {
             const int p = i >> 2, q = i & 3;
@@ -83,6 +96,18 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
             if (ok) {
                 const int sy = dil == 2 ? yy >> 1 : yy, sx = dil == 2 ? xx >> 1 : xx;
                 v = *reinterpret_cast<const uint4 *>(Xs + (((size_t)n * H + sy) * W + sx) * cs + cb + q * 8);
+                if (xform) {
+                    unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float z0 = __uint_as_float(u[k] << 16) * s_ss[q * 8 + 2 * k] + s_ss[KC + q * 8 + 2 * k];
+                        float z1 = __uint_as_float(u[k] & 0xffff0000u) * s_ss[q * 8 + 2 * k + 1] + s_ss[KC + q * 8 + 2 * k + 1];
+                        z0 = z0 > 0.f ? z0 : z0 * slope;
+                        z1 = z1 > 0.f ? z1 : z1 * slope;
+                        u[k] = (unsigned)f2bf(z0) | ((unsigned)f2bf(z1) << 16);
+                    }
+                    v = make_uint4(u[0], u[1], u[2], u[3]);
+                }
             }
             *reinterpret_cast<uint4 *>(s_in + p * PITCH + q * 16) = v;
         }
@@ -143,23 +168,25 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
 template <int BN, int ST>
 int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
                 int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tap_mask, int osc, int ooy, int oox,
-                hipStream_t stream) {
+                const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope, hipStream_t stream) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;
-    const size_t lds = (size_t)IH * IW * PITCH + (size_t)9 * BN * PITCH;
+    const size_t lds = (size_t)IH * IW * PITCH + (size_t)9 * BN * PITCH + 2 * KC * sizeof(float);
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
     auto kern = conv3x3_nhwc_kernel<BN, ST>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
-    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, tap_mask, osc, ooy, oox);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, tap_mask, osc, ooy, oox,
+                       sc1, sh1, sc2, sh2, slope);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-extern "C" int octa_conv3x3_nhwc_fwd3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+extern "C" int octa_conv3x3_nhwc_fwd4(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
                                       int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
-                                      int out_scale, int out_off_y, int out_off_x, void *stream_) {
+                                      int out_scale, int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1,
+                                      const float *d_scale2, const float *d_shift2, float slope, void *stream_) {
     if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv3x3_nhwc_fwd: null pointer"); return -2; }
     if (N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: bad shape"); return -2; }
     if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
@@ -176,6 +203,7 @@ extern "C" int octa_conv3x3_nhwc_fwd3(octa_ctx *ctx, const void *d_x, const void
         octa::set_error("octa_conv3x3_nhwc_fwd: output scatter must be scale 1 or 2 with offsets below the scale");
         return -2;
     }
+    if ((d_scale1 == nullptr) != (d_shift1 == nullptr) || (d_scale2 == nullptr) != (d_shift2 == nullptr)) { octa::set_error("octa_conv3x3_nhwc_fwd: scale and shift come in pairs"); return -2; }
     if (C1 <= 0 || C1 > Cin || C1 % 32 || CY1 <= 0 || CY1 > Cout || CY1 % 32) { octa::set_error("octa_conv3x3_nhwc_fwd: channel splits must be multiples of 32 inside the channel range"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
@@ -185,10 +213,17 @@ extern "C" int octa_conv3x3_nhwc_fwd3(octa_ctx *ctx, const void *d_x, const void
     const unsigned short *Wt = static_cast<const unsigned short *>(d_w);
     unsigned short *Y = static_cast<unsigned short *>(d_y), *Y2 = static_cast<unsigned short *>(d_y2);
     const bool wide = (Cout % 64 == 0) && (CY1 % 64 == 0);   // a 64-channel block must not straddle the output split
-    if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, stream)
-                                 : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, stream);
-    return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, stream)
-                : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, stream);
+    if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream)
+                                 : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+    return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream)
+                : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+}
+
+extern "C" int octa_conv3x3_nhwc_fwd3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+                                      int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
+                                      int out_scale, int out_off_y, int out_off_x, void *stream_) {
+    return octa_conv3x3_nhwc_fwd4(ctx, d_x, d_x2, C1, d_w, d_y, d_y2, CY1, N, H, W, Cin, Cout, stride, in_dilation, tap_mask, out_scale, out_off_y,
+                                  out_off_x, nullptr, nullptr, nullptr, nullptr, 0.f, stream_);
 }
 
 extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
@@ -221,7 +256,9 @@ template <int COB, int CIB>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                           const unsigned short *__restrict__ dY, float *__restrict__ dW,
-                          int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask) {
+                          int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask,
+                          const float *__restrict__ sc1, const float *__restrict__ sh1, const float *__restrict__ sc2,
+                          const float *__restrict__ sh2, float slope) {
     constexpr int PAIRS = (COB / 32) * (CIB / 32);
     constexpr int KSPLIT = 4 / PAIRS;            // waves sharing one (co, ci) pair split the tile rows
     constexpr int ROWS_PER_WAVE = WTH / KSPLIT;
@@ -235,6 +272,9 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     // virtual concatenation of the input: a CIB block lies entirely in X (channels < C1) or in X2
     const unsigned short *Xs = ci0 < C1 ? X : X2;
     const int xcs = ci0 < C1 ? C1 : Cin - C1, xcb = ci0 < C1 ? ci0 : ci0 - C1;
+    // normalise-on-load of the layer input (see the forward kernel): per image and channel scale / shift
+    const float *scp = ci0 < C1 ? sc1 : sc2, *shp = ci0 < C1 ? sh1 : sh2;
+    const bool xform = scp != nullptr;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int pair = wv % PAIRS, kpart = wv / PAIRS;
     const int cob = (pair % (COB / 32)) * 32, cib = (pair / (COB / 32)) * 32;
@@ -266,7 +306,23 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
             const int i = threadIdx.x + k * CONV_THREADS, p = i % XPIX, q = i / XPIX;
             const int y = ty0 - 1 + p / (TW + 2), x = tx0 - 1 + p % (TW + 2);
             const bool ok = i < X_ITEMS && y >= 0 && y < H && x >= 0 && x < W;
-            r_x[k] = ok ? *reinterpret_cast<const uint4 *>(Xs + (((size_t)n * H + y) * W + x) * xcs + xcb + q * 8) : make_uint4(0u, 0u, 0u, 0u);
+            uint4 v = ok ? *reinterpret_cast<const uint4 *>(Xs + (((size_t)n * H + y) * W + x) * xcs + xcb + q * 8) : make_uint4(0u, 0u, 0u, 0u);
+            if (xform && ok) {
+                const float4 s0 = *reinterpret_cast<const float4 *>(scp + (size_t)n * xcs + xcb + q * 8), s1 = *reinterpret_cast<const float4 *>(scp + (size_t)n * xcs + xcb + q * 8 + 4);
+                const float4 h0 = *reinterpret_cast<const float4 *>(shp + (size_t)n * xcs + xcb + q * 8), h1 = *reinterpret_cast<const float4 *>(shp + (size_t)n * xcs + xcb + q * 8 + 4);
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float z0 = __uint_as_float(u[j] << 16) * sc[2 * j] + sh[2 * j];
+                    float z1 = __uint_as_float(u[j] & 0xffff0000u) * sc[2 * j + 1] + sh[2 * j + 1];
+                    z0 = z0 > 0.f ? z0 : z0 * slope;
+                    z1 = z1 > 0.f ? z1 : z1 * slope;
+                    u[j] = (unsigned)f2bf(z0) | ((unsigned)f2bf(z1) << 16);
+                }
+                v = make_uint4(u[0], u[1], u[2], u[3]);
+            }
+            r_x[k] = v;
         }
     };
     auto stash_dy = [&](unsigned char *buf, int k) {
@@ -349,7 +405,8 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
 
 template <int COB, int CIB>
 int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
-                 int Cout, int num_cus, int tap_mask, hipStream_t stream) {
+                 int Cout, int num_cus, int tap_mask, const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope,
+                 hipStream_t stream) {
     const size_t lds = 2 * ((size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW);   // double buffered
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + WTH - 1) / WTH;
     const int blocks = (Cout / COB) * (Cin / CIB);
@@ -360,15 +417,16 @@ int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, cons
     auto kern = conv3x3_nhwc_wgrad_kernel<COB, CIB>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Cin,
-                       Cout, tiles_x, tiles_y, tap_mask);
+                       Cout, tiles_x, tiles_y, tap_mask, sc1, sh1, sc2, sh2, slope);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-extern "C" int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
-                                        int W, int Cin, int Cout, int tap_mask, void *stream_) {
+extern "C" int octa_conv3x3_nhwc_wgrad3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
+                                        int W, int Cin, int Cout, int tap_mask, const float *d_scale1, const float *d_shift1,
+                                        const float *d_scale2, const float *d_shift2, float slope, void *stream_) {
     if (!ctx || !d_x || !d_dy || !d_dw) { octa::set_error("octa_conv3x3_nhwc_wgrad: null pointer"); return -2; }
     tap_mask &= 0x1ff;
     if (tap_mask == 0) { octa::set_error("octa_conv3x3_nhwc_wgrad: empty tap mask"); return -2; }
@@ -382,10 +440,15 @@ extern "C" int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const vo
     const unsigned short *X = static_cast<const unsigned short *>(d_x), *X2 = static_cast<const unsigned short *>(d_x2);
     const unsigned short *dY = static_cast<const unsigned short *>(d_dy);
     const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0 && C1 % 64 == 0;   // a 64-channel block must not straddle the split
-    if (co64 && ci64) return launch_wgrad<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, stream);
-    if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, stream);
-    if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, stream);
-    return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, stream);
+    if (co64 && ci64) return launch_wgrad<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+    if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+    if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+    return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+}
+
+extern "C" int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
+                                        int W, int Cin, int Cout, int tap_mask, void *stream_) {
+    return octa_conv3x3_nhwc_wgrad3(ctx, d_x, d_x2, C1, d_dy, d_dw, N, H, W, Cin, Cout, tap_mask, nullptr, nullptr, nullptr, nullptr, 0.f, stream_);
 }
 
 extern "C" int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin,

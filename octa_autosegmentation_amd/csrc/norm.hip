@@ -535,3 +535,79 @@ extern "C" int octa_instnorm_lrelu_nhwc_bwd(octa_ctx *ctx, const void *d_x, cons
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---- statistics only + lazy application (normalise-on-load path of csrc/conv.hip) ---------------------------------
+namespace {
+
+__global__ void __launch_bounds__(NT)
+in_nhwc_finalize(const double *__restrict__ sums, const float *__restrict__ w, const float *__restrict__ bias, long hw, int C, long total,
+                 float eps, float *__restrict__ mean_out, float *__restrict__ rstd_out, float *__restrict__ scale, float *__restrict__ shift) {
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const double mean_d = sums[2 * i] / (double)hw;
+    double var = sums[2 * i + 1] / (double)hw - mean_d * mean_d;
+    if (var < 0) var = 0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out[i] = mean; rstd_out[i] = rstd;
+    const float g = w ? w[c] * rstd : rstd;
+    scale[i] = g;
+    shift[i] = (bias ? bias[c] : 0.f) - mean * g;
+}
+
+__global__ void __launch_bounds__(NT)
+scale_shift_lrelu_nhwc(const unsigned short *__restrict__ x, unsigned short *__restrict__ y, const float *__restrict__ scale,
+                       const float *__restrict__ shift, long hw, int C, int splits, float slope) {
+    const int b = blockIdx.y, s = blockIdx.x;
+    int cg, pl, npl;
+    nhwc_geometry(C, cg, pl, npl);
+    if (pl >= npl) return;
+    const long per = (hw + splits - 1) / splits;
+    const long p0 = (long)s * per, p1 = p0 + per < hw ? p0 + per : hw;
+    float g[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { g[k] = scale[(long)b * C + cg * 8 + k]; sh[k] = shift[(long)b * C + cg * 8 + k]; }
+    const unsigned short *px = x + ((long)b * hw) * C + cg * 8;
+    unsigned short *py = y + ((long)b * hw) * C + cg * 8;
+    for (long p = p0 + pl; p < p1; p += npl) {
+        float v[8];
+        Vec<unsigned short>::load(px + p * C, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const float z = v[k] * g[k] + sh[k]; v[k] = z > 0.f ? z : z * slope; }
+        Vec<unsigned short>::store(py + p * C, v);
+    }
+}
+
+}  // namespace
+
+extern "C" int octa_instnorm_nhwc_stats(octa_ctx *ctx, const void *d_x, const float *d_w, const float *d_b, float *d_mean, float *d_rstd,
+                                        float *d_scale, float *d_shift, int B, int C, int64_t hw, float eps, void *stream_) {
+    if (!ctx || !d_x || !d_mean || !d_rstd || !d_scale || !d_shift) { octa::set_error("octa_instnorm_nhwc_stats: null pointer"); return -2; }
+    if (nhwc_check("octa_instnorm_nhwc_stats", B, C, hw)) return -2;
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->r_tile_total.reserve(sizeof(double) * 2 * (size_t)B * C)) return -1;
+    double *sums = ctx->r_tile_total.as<double>();
+    OCTA_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, stream));
+    const int splits = nhwc_splits(ctx, B, hw);
+    hipLaunchKernelGGL(in_nhwc_stats<0>, dim3((unsigned)splits, (unsigned)B), dim3(NT), 0, stream, static_cast<const unsigned short *>(d_x),
+                       (const unsigned short *)nullptr, d_w, d_b, (const float *)nullptr, (const float *)nullptr, (long)hw, C, splits, 0.f, sums);
+    const long total = (long)B * C;
+    hipLaunchKernelGGL(in_nhwc_finalize, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, stream, sums, d_w, d_b, (long)hw, C, total, eps,
+                       d_mean, d_rstd, d_scale, d_shift);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_scale_shift_lrelu_nhwc(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_scale, const float *d_shift, int B, int C,
+                                           int64_t hw, float slope, void *stream_) {
+    if (!ctx || !d_x || !d_y || !d_scale || !d_shift) { octa::set_error("octa_scale_shift_lrelu_nhwc: null pointer"); return -2; }
+    if (nhwc_check("octa_scale_shift_lrelu_nhwc", B, C, hw)) return -2;
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const int splits = nhwc_splits(ctx, B, hw);
+    hipLaunchKernelGGL(scale_shift_lrelu_nhwc, dim3((unsigned)splits, (unsigned)B), dim3(NT), 0, stream, static_cast<const unsigned short *>(d_x),
+                       static_cast<unsigned short *>(d_y), d_scale, d_shift, (long)hw, C, splits, slope);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -390,3 +390,126 @@ def conv1x1_bias_nhwc(x, weight, bias):
     if bias is not None:
         y = y + bias.to(torch.bfloat16)
     return y.view(n, h, w, weight.shape[0])
+
+
+# ---- normalise-on-load path: the normalised activations never go to HBM ---------------------------------------------
+# A "lazy" activation is a triple (t, scale, shift): t aliases the RAW output of a convolution, and every consumer reads
+# it as lrelu(t * scale + shift). For autograd t IS the normalised activation: the convolutions return dL/d(normalised)
+# for it, contributions of several consumers are summed by autograd, and _LazyNorm.backward turns the sum into the
+# gradient of the raw tensor with the usual InstanceNorm+LeakyReLU backward kernels.
+
+LRELU_SLOPE = 0.01
+
+
+class _LazyNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope, eps):
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[3]
+        hw = x.shape[1] * x.shape[2]
+        f32 = dict(dtype=torch.float32, device=x.device)
+        mean, rstd, scale, shift = (torch.empty(B * C, **f32) for _ in range(4))
+        w = weight.float().contiguous() if weight is not None else None
+        b = bias.float().contiguous() if bias is not None else None
+        rc = _native.lib().octa_instnorm_nhwc_stats(_native.ctx(x.device.index), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(scale), _p(shift),
+                                                    B, C, hw, float(eps), _native.current_stream_ptr())
+        _native.check(rc, "octa_instnorm_nhwc_stats")
+        ctx.save_for_backward(x, w, b, mean, rstd)
+        ctx.slope, ctx.has_w, ctx.has_b = float(slope), weight is not None, bias is not None
+        ctx.w_dtype = weight.dtype if weight is not None else None
+        y = x.view(x.shape)          # same storage: consumers apply scale / shift / LeakyReLU while loading
+        ctx.mark_non_differentiable(scale, shift)
+        return y, scale, shift
+
+    @staticmethod
+    def backward(ctx, dy, _ds, _dh):
+        return _InstNormLReLUNHWC.backward(ctx, dy)
+
+
+def lazy_norm(x, weight, bias, negative_slope=LRELU_SLOPE, eps=1e-5):
+    """-> (t, scale, shift): see the section comment."""
+    return _LazyNorm.apply(x, weight, bias, negative_slope, eps)
+
+
+class _Materialise(torch.autograd.Function):
+    """y = lrelu(t * scale + shift) as a real tensor, for the consumers that are not normalise-on-load kernels."""
+
+    @staticmethod
+    def forward(ctx, t, scale, shift, slope):
+        t = t.contiguous()
+        y = torch.empty_like(t)
+        B, C = t.shape[0], t.shape[3]
+        rc = _native.lib().octa_scale_shift_lrelu_nhwc(_native.ctx(t.device.index), _p(t), _p(y), _p(scale), _p(shift), B, C,
+                                                       t.shape[1] * t.shape[2], float(slope), _native.current_stream_ptr())
+        _native.check(rc, "octa_scale_shift_lrelu_nhwc")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None, None      # t stands for the normalised activation in the graph
+
+
+def materialise(lazy, slope=LRELU_SLOPE):
+    t, sc, sh = lazy
+    return t if sc is None else _Materialise.apply(t, sc, sh, slope)
+
+
+class _ConvLazy(torch.autograd.Function):
+    """conv3x3 over one or two (virtually concatenated) lazy inputs, stride 1 or 2 (stride 2: single input)."""
+
+    @staticmethod
+    def forward(ctx, x1, sc1, sh1, x2, sc2, sh2, weight, stride, slope):
+        x1 = x1.contiguous()
+        n, h, w, c1 = x1.shape
+        c2 = 0
+        if x2 is not None:
+            x2 = x2.contiguous()
+            c2 = x2.shape[3]
+        cin, cout = c1 + c2, weight.shape[0]
+        assert weight.shape[1] == cin and c1 % 32 == 0 and c2 % 32 == 0 and cout % 32 == 0
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x1.device)
+        wt = pack_weight(weight)
+        rc = _native.lib().octa_conv3x3_nhwc_fwd4(_native.ctx(x1.device.index), _p(x1), _p(x2), c1, _p(wt), _p(y), None, cout, n, h, w, cin, cout,
+                                                  int(stride), 1, 0x1ff, 1, 0, 0, _p(sc1), _p(sh1), _p(sc2), _p(sh2), float(slope),
+                                                  _native.current_stream_ptr())
+        _native.check(rc, "octa_conv3x3_nhwc_fwd4")
+        ctx.save_for_backward(x1, sc1, sh1, x2, sc2, sh2, weight)
+        ctx.stride, ctx.slope = int(stride), float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, sc1, sh1, x2, sc2, sh2, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        n, h, w, c1 = x1.shape
+        c2 = x2.shape[3] if x2 is not None else 0
+        cin, cout, st = c1 + c2, weight.shape[0], ctx.stride
+        lib, hctx, stream = _native.lib(), _native.ctx(x1.device.index), _native.current_stream_ptr()
+        dx1 = dx2 = dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
+            dx1 = torch.empty_like(x1)
+            dx2 = torch.empty_like(x2) if x2 is not None else None
+            wd = pack_weight_dgrad(weight)
+            rc = lib.octa_conv3x3_nhwc_fwd4(hctx, _p(dy), None, cout, _p(wd), _p(dx1), _p(dx2), c1, n, dy.shape[1], dy.shape[2], cout, cin, 1, st,
+                                            0x1ff, 1, 0, 0, None, None, None, None, 0.0, stream)
+            _native.check(rc, "octa_conv3x3_nhwc_fwd4 (data gradient)")
+        if ctx.needs_input_grad[6]:
+            if st == 1:
+                dwf = torch.empty((9, cout, cin), dtype=torch.float32, device=x1.device)
+                rc = lib.octa_conv3x3_nhwc_wgrad3(hctx, _p(x1), _p(x2), c1, _p(dy), _p(dwf), n, h, w, cin, cout, 0x1ff, _p(sc1), _p(sh1), _p(sc2),
+                                                  _p(sh2), ctx.slope, stream)
+                _native.check(rc, "octa_conv3x3_nhwc_wgrad3")
+                dw = dwf.view(3, 3, cout, cin).permute(2, 3, 0, 1).to(weight.dtype)
+            else:
+                xm = x1 if sc1 is None else _Materialise.apply(x1, sc1, sh1, ctx.slope)   # parity planes need the tensor itself
+                dw = _s2_wgrad(xm, dy).to(weight.dtype)
+        return dx1, None, None, dx2, None, None, dw, None, None
+
+
+def conv3x3_lazy(a, weight, stride=1, b=None, slope=LRELU_SLOPE):
+    """a, b: lazy activations (t, scale, shift) (scale None = plain tensor); b is virtually concatenated after a."""
+    t2, s2, h2 = b if b is not None else (None, None, None)
+    return _ConvLazy.apply(a[0], a[1], a[2], t2, s2, h2, weight, stride, slope)

@@ -25,6 +25,10 @@ FAST_CONVT = False  # measured slower than MIOpen at 1216^2 (65 vs 53 ms per ste
 # CUDA inputs run channels-last in bf16 through the hand-written MFMA convolution (csrc/conv.hip) and the NHWC
 # norm kernels; False = torch/MIOpen modules (the fp32 reference path of the parity tests)
 USE_MFMA_CONV = True
+# normalise-on-load (the normalised activations never go to HBM: models/mfma_conv.py) is implemented and tested but
+# measured SLOWER on MI355X (37.5 vs 31.9 ms per step): every output-channel block of a layer re-stages and
+# re-normalises the same input tile, which costs more VALU work than the two HBM passes it saves
+USE_LAZY_NORM = False
 
 
 class _Conv(nn.Module):
@@ -146,17 +150,33 @@ class DynUNet(nn.Module):
     # ---- channels-last bf16 path on the hand-written kernels (same parameters, same state dict) ----
     @staticmethod
     def _basic_block_nhwc(blk, x, skip=None):
+        """x, skip and the result are lazy activations (tensor, scale, shift) -- the normalised tensors are applied by the
+        consuming kernels while loading (mfma_conv.py, normalise-on-load), or plain tensors with scale None."""
         from . import mfma_conv as mc
         c1, c2 = blk.conv1.conv, blk.conv2.conv
-        if skip is not None and x.shape[-1] % 32 == 0 and skip.shape[-1] % 32 == 0 and c1.stride[0] == 1:
-            x = mc.conv3x3_cat(x, skip, c1.weight)       # conv over the virtual concatenation (x, skip)
-        else:
+        st = c1.stride[0]
+        if not USE_LAZY_NORM:
+            xt, sk = x[0], (skip[0] if skip is not None else None)
+            if sk is not None and xt.shape[-1] % 32 == 0 and sk.shape[-1] % 32 == 0 and st == 1:
+                y = mc.conv3x3_cat(xt, sk, c1.weight)       # conv over the virtual concatenation (x, skip)
+            else:
+                if sk is not None:
+                    xt = torch.cat((xt, sk), dim=-1)
+                y = mc.conv3x3(xt, c1.weight, st)
+            y = mc.instance_norm_leaky_relu_nhwc(y, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps)
+            y = mc.conv3x3(y, c2.weight, 1)
+            return (mc.instance_norm_leaky_relu_nhwc(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps), None, None)
+        if x[0].shape[-1] % 32 != 0 or (skip is not None and (skip[0].shape[-1] % 32 != 0 or st != 1)):
+            # channel-padded first layer (or an odd split): through the single-input binding on a real tensor
+            xt = mc.materialise(x)
             if skip is not None:
-                x = torch.cat((x, skip), dim=-1)
-            x = mc.conv3x3(x, c1.weight, c1.stride[0])
-        x = mc.instance_norm_leaky_relu_nhwc(x, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps)
-        x = mc.conv3x3(x, c2.weight, 1)
-        return mc.instance_norm_leaky_relu_nhwc(x, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps)
+                xt = torch.cat((xt, mc.materialise(skip)), dim=-1)
+            y = mc.conv3x3(xt, c1.weight, st)
+        else:
+            y = mc.conv3x3_lazy(x, c1.weight, st, skip, blk.lrelu.negative_slope)
+        y = mc.lazy_norm(y, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps)
+        y = mc.conv3x3_lazy(y, c2.weight, 1, None, blk.lrelu.negative_slope)
+        return mc.lazy_norm(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps)
 
     def _mfma_path_ok(self, x):
         if not (USE_MFMA_CONV and x.is_cuda and x.dim() == 4):
@@ -181,17 +201,17 @@ class DynUNet(nn.Module):
 
     def _forward_nhwc(self, x):
         from . import mfma_conv as mc
-        y = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+        y = (x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), None, None)
         skips = [self._basic_block_nhwc(self.input_block, y)]
         for d in self.downsamples:
             skips.append(self._basic_block_nhwc(d, skips[-1]))
         y = self._basic_block_nhwc(self.bottleneck, skips[-1])
         for u, s in zip(self.upsamples, skips[::-1]):
             t = u.transp_conv.conv
-            y = mc.conv_transpose_kxk_nhwc(y, t.weight, t.kernel_size[0])
-            y = self._basic_block_nhwc(u.conv_block, y, s)
+            up = mc.conv_transpose_kxk_nhwc(mc.materialise(y), t.weight, t.kernel_size[0])
+            y = self._basic_block_nhwc(u.conv_block, (up, None, None), s)
         o = self.output_block.conv.conv
-        return mc.conv1x1_bias_nhwc(y, o.weight, o.bias).permute(0, 3, 1, 2)
+        return mc.conv1x1_bias_nhwc(mc.materialise(y), o.weight, o.bias).permute(0, 3, 1, 2)
 
     def forward(self, x):
         if self._mfma_path_ok(x):

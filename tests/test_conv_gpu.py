@@ -166,6 +166,47 @@ def test_parity_scatter_forms(hip_lib_built):
     _check(mfma_conv.conv_transpose_2x2_fwd(xt, wt), want)
 
 
+def test_normalise_on_load_equals_materialised(hip_lib_built):
+    """conv3x3_lazy (InstanceNorm + LeakyReLU applied while the kernels load their input) is BIT-identical to the
+    materialised route in the forward pass and in all gradients; whole network with networks.USE_LAZY_NORM too."""
+    import torch
+    from octa_autosegmentation_amd.models import mfma_conv as mc, networks
+    g = torch.Generator(device="cuda").manual_seed(21)
+    raw = torch.randn(2, 20, 36, 64, device="cuda", generator=g).to(torch.bfloat16)
+    skip = torch.randn(2, 20, 36, 32, device="cuda", generator=g).to(torch.bfloat16)
+    gam, bet = torch.rand(64, device="cuda", generator=g) + 0.5, torch.randn(64, device="cuda", generator=g) * 0.1
+    w = (torch.randn(64, 96, 3, 3, device="cuda", generator=g) / 29.0)
+    dy = torch.randn(2, 20, 36, 64, device="cuda", generator=g).to(torch.bfloat16)
+    outs = []
+    for lazy in (False, True):
+        r, gm, bt, wt, sk = raw.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True), \
+            w.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+        if lazy:
+            y = mc.conv3x3_lazy(mc.lazy_norm(r, gm, bt), wt, 1, (sk, None, None))
+        else:
+            y = mc.conv3x3_cat(mc.instance_norm_leaky_relu_nhwc(r, gm, bt), sk, wt)
+        y.backward(dy)
+        outs.append((y.detach(), r.grad, sk.grad, gm.grad, bt.grad, wt.grad))
+    for a_, b_ in zip(*outs):
+        if a_.dtype == torch.bfloat16:
+            assert torch.equal(a_, b_)
+        else:
+            assert (a_ - b_).abs().max().item() <= a_.abs().max().item() * 1e-3   # fp32 atomics: arrival order only
+    torch.manual_seed(5)
+    net = networks.DynUNet(2, 1, 1, [3, 3, 3, 3, 3], [1, 2, 2, 2, 1], [1, 2, 2, 2, 1]).cuda()
+    networks.init_weights(net, "kaiming")
+    x = torch.rand(1, 1, 32, 64, device="cuda")
+    res = []
+    for lazy in (False, True):
+        networks.USE_LAZY_NORM = lazy
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+                res.append(net(x).float())
+        finally:
+            networks.USE_LAZY_NORM = False
+    assert torch.equal(res[0], res[1])
+
+
 def test_head_kernels(hip_lib_built):
     import torch
     from octa_autosegmentation_amd.models import mfma_conv
