@@ -179,6 +179,18 @@ int octa_conv3x3_nhwc_wgrad3(octa_ctx *ctx, const void *d_x, const void *d_x2, i
                              int Cin, int Cout, int tap_mask, const float *d_scale1, const float *d_shift1, const float *d_scale2,
                              const float *d_shift2, float slope, void *stream);
 
+/* Same, and the statistics of the InstanceNorm that follows come for free: d_stat_partials (float32
+ * [N][octa_conv_stat_tiles(Ho, Wo)][Cout][2], may be NULL) receives per output tile and channel the sum and the sum of
+ * squares of the bf16-rounded results; octa_instnorm_lrelu_nhwc_fwd_p folds them instead of re-reading the tensor. */
+int octa_conv_stat_tiles(int Ho, int Wo);
+int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2, int CY1,
+                           int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask, int out_scale,
+                           int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1, const float *d_scale2,
+                           const float *d_shift2, float slope, float *d_stat_partials, void *stream);
+int octa_instnorm_lrelu_nhwc_fwd_p(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b, float *d_mean,
+                                   float *d_rstd, int B, int C, int64_t hw, float slope, float eps, const float *d_partials, int tiles,
+                                   void *stream);
+
 /* Weight gradient of the stride-1 layer above: d_dw [9][Cout][Cin] float32 (overwritten) =
  * sum over pixels of d_dy[N][H][W][Cout] (bf16) x d_x[N][H][W][Cin] (bf16) shifted by the tap (SURVEY.md 8b:
  * octa_conv2d_wgrad). fp32 accumulation; partial sums of the persistent workgroups meet in fp32 atomics, so the

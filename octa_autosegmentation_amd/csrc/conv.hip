@@ -50,7 +50,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
                     const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
                     int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, int tap_mask, int osc, int ooy, int oox,
                     const float *__restrict__ sc1, const float *__restrict__ sh1, const float *__restrict__ sc2,
-                    const float *__restrict__ sh2, float slope) {
+                    const float *__restrict__ sh2, float slope, float *__restrict__ part) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;  // halo tile
     constexpr int NB = BN / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -163,12 +163,48 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
                 if (ox < Wo) Yo[(((size_t)n * HoF + oy * osc + ooy) * WoF + ox * osc + oox) * ys + yb + nb * 32 + m] = f2bf(acc[rr][nb][k]);
             }
     }
+    // InstanceNorm statistics of the layer that follows, for free: per tile and output channel the sum and the sum of
+    // squares of the bf16-ROUNDED results (what the norm kernels would read back) -> part[n][tile][Cout][2]
+    if (part) {
+        float s1[NB], s2[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) { s1[nb] = 0.f; s2[nb] = 0.f; }
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int oy = ty0 + 2 * wv + rr;
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int ox = tx0 + (k & 3) + 8 * (k >> 2) + 4 * kg;
+                    if (oy < Ho && ox < Wo) {
+                        const float v = __uint_as_float((unsigned)f2bf(acc[rr][nb][k]) << 16);
+                        s1[nb] += v; s2[nb] += v * v;
+                    }
+                }
+        }
+        float *s_red = reinterpret_cast<float *>(smem);   // [4 waves][BN][2]; the operand tiles are dead now
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            const float a1 = s1[nb] + __shfl_xor(s1[nb], 32, 64), a2 = s2[nb] + __shfl_xor(s2[nb], 32, 64);
+            if (kg == 0) { s_red[(wv * BN + nb * 32 + m) * 2] = a1; s_red[(wv * BN + nb * 32 + m) * 2 + 1] = a2; }
+        }
+        __syncthreads();
+        if (threadIdx.x < BN) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) { a1 += s_red[(w4 * BN + threadIdx.x) * 2]; a2 += s_red[(w4 * BN + threadIdx.x) * 2 + 1]; }
+            float *dst = part + (((size_t)n * gridDim.x + tile) * Cout + co0 + threadIdx.x) * 2;
+            dst[0] = a1; dst[1] = a2;
+        }
+    }
 }
 
 template <int BN, int ST>
 int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
                 int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tap_mask, int osc, int ooy, int oox,
-                const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope, hipStream_t stream) {
+                const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope, float *part, hipStream_t stream) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;
     const size_t lds = (size_t)IH * IW * PITCH + (size_t)9 * BN * PITCH + 2 * KC * sizeof(float);
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
@@ -176,17 +212,19 @@ int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
     hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, tap_mask, osc, ooy, oox,
-                       sc1, sh1, sc2, sh2, slope);
+                       sc1, sh1, sc2, sh2, slope, part);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-extern "C" int octa_conv3x3_nhwc_fwd4(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+extern "C" int octa_conv_stat_tiles(int Ho, int Wo) { return ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH); }
+
+extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
                                       int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
                                       int out_scale, int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1,
-                                      const float *d_scale2, const float *d_shift2, float slope, void *stream_) {
+                                      const float *d_scale2, const float *d_shift2, float slope, float *d_stat_partials, void *stream_) {
     if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv3x3_nhwc_fwd: null pointer"); return -2; }
     if (N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: bad shape"); return -2; }
     if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
@@ -203,6 +241,7 @@ extern "C" int octa_conv3x3_nhwc_fwd4(octa_ctx *ctx, const void *d_x, const void
         octa::set_error("octa_conv3x3_nhwc_fwd: output scatter must be scale 1 or 2 with offsets below the scale");
         return -2;
     }
+    if (d_stat_partials && (out_scale != 1 || d_y2)) { octa::set_error("octa_conv3x3_nhwc_fwd: statistics need a plain single output"); return -2; }
     if ((d_scale1 == nullptr) != (d_shift1 == nullptr) || (d_scale2 == nullptr) != (d_shift2 == nullptr)) { octa::set_error("octa_conv3x3_nhwc_fwd: scale and shift come in pairs"); return -2; }
     if (C1 <= 0 || C1 > Cin || C1 % 32 || CY1 <= 0 || CY1 > Cout || CY1 % 32) { octa::set_error("octa_conv3x3_nhwc_fwd: channel splits must be multiples of 32 inside the channel range"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
@@ -213,10 +252,18 @@ extern "C" int octa_conv3x3_nhwc_fwd4(octa_ctx *ctx, const void *d_x, const void
     const unsigned short *Wt = static_cast<const unsigned short *>(d_w);
     unsigned short *Y = static_cast<unsigned short *>(d_y), *Y2 = static_cast<unsigned short *>(d_y2);
     const bool wide = (Cout % 64 == 0) && (CY1 % 64 == 0);   // a 64-channel block must not straddle the output split
-    if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream)
-                                 : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
-    return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream)
-                : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+    if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream)
+                                 : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream);
+    return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream)
+                : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream);
+}
+
+extern "C" int octa_conv3x3_nhwc_fwd4(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+                                      int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
+                                      int out_scale, int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1,
+                                      const float *d_scale2, const float *d_shift2, float slope, void *stream_) {
+    return octa_conv3x3_nhwc_fwd5(ctx, d_x, d_x2, C1, d_w, d_y, d_y2, CY1, N, H, W, Cin, Cout, stride, in_dilation, tap_mask, out_scale, out_off_y,
+                                  out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, nullptr, stream_);
 }
 
 extern "C" int octa_conv3x3_nhwc_fwd3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,

@@ -611,3 +611,44 @@ extern "C" int octa_scale_shift_lrelu_nhwc(octa_ctx *ctx, const void *d_x, void 
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---- forward with the statistics already accumulated by the producing convolution (csrc/conv.hip, _fwd5) ----------
+namespace {
+
+// partials [B][tiles][C][2] float -> sums [B][C][2] double. Block = 8 tile lanes x 32 channels.
+__global__ void __launch_bounds__(NT)
+in_nhwc_fold_partials(const float *__restrict__ part, int tiles, int C, double *__restrict__ sums) {
+    __shared__ double s_red[NT * 2];
+    const int b = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), tl = threadIdx.x >> 5;
+    double a = 0, q = 0;
+    if (c < C)
+        for (int t = tl; t < tiles; t += NT / 32) {
+            const float2 v = *reinterpret_cast<const float2 *>(part + (((size_t)b * tiles + t) * C + c) * 2);
+            a += v.x; q += v.y;
+        }
+    s_red[threadIdx.x * 2] = a; s_red[threadIdx.x * 2 + 1] = q;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        for (int k = 1; k < NT / 32; k++) { a += s_red[(k * 32 + threadIdx.x) * 2]; q += s_red[(k * 32 + threadIdx.x) * 2 + 1]; }
+        sums[((size_t)b * C + c) * 2] = a; sums[((size_t)b * C + c) * 2 + 1] = q;
+    }
+}
+
+}  // namespace
+
+extern "C" int octa_instnorm_lrelu_nhwc_fwd_p(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b, float *d_mean,
+                                              float *d_rstd, int B, int C, int64_t hw, float slope, float eps, const float *d_partials,
+                                              int tiles, void *stream_) {
+    if (!ctx || !d_x || !d_y || !d_mean || !d_rstd || !d_partials || tiles <= 0) { octa::set_error("octa_instnorm_lrelu_nhwc_fwd_p: bad arguments"); return -2; }
+    if (nhwc_check("octa_instnorm_lrelu_nhwc_fwd_p", B, C, hw)) return -2;
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->r_tile_total.reserve(sizeof(double) * 2 * (size_t)B * C)) return -1;
+    double *sums = ctx->r_tile_total.as<double>();
+    hipLaunchKernelGGL(in_nhwc_fold_partials, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(NT), 0, stream, d_partials, tiles, C, sums);
+    const int splits = nhwc_splits(ctx, B, hw);
+    hipLaunchKernelGGL(in_nhwc_fwd_apply, dim3((unsigned)splits, (unsigned)B), dim3(NT), 0, stream, static_cast<const unsigned short *>(d_x),
+                       static_cast<unsigned short *>(d_y), d_w, d_b, (long)hw, C, splits, sums, slope, eps, d_mean, d_rstd);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}

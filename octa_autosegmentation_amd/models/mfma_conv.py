@@ -55,6 +55,25 @@ def conv3x3_nhwc_wgrad(x, dy, tap_mask=0x1ff):
     return dw.view(3, 3, cout, cin).permute(2, 3, 0, 1)
 
 
+def _conv_fwd_stats(x1, x2, wt, stride, want_stats):
+    """Forward launch over one or two inputs (virtual concatenation); optionally also the per-tile InstanceNorm
+    statistics of the result (float32 [N][tiles][Cout][2]) accumulated in the kernel's epilogue."""
+    n, h, w, c1 = x1.shape
+    c2 = x2.shape[3] if x2 is not None else 0
+    cout = wt.shape[1]
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x1.device)
+    part = None
+    if want_stats:
+        tiles = _native.lib().octa_conv_stat_tiles(ho, wo)
+        part = torch.empty((n, tiles, cout, 2), dtype=torch.float32, device=x1.device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    rc = _native.lib().octa_conv3x3_nhwc_fwd5(_native.ctx(x1.device.index), p(x1), p(x2), c1, p(wt), p(y), None, cout, n, h, w, c1 + c2, cout,
+                                              int(stride), 1, 0x1ff, 1, 0, 0, None, None, None, None, 0.0, p(part), _native.current_stream_ptr())
+    _native.check(rc, "octa_conv3x3_nhwc_fwd5")
+    return y, part
+
+
 # ---- zero-insertion-free stride-2 data gradient / 2x2 transposed convolution: one scattered launch per parity class
 
 # dX[2h+a] receives dY[h + off] * W[r] for (r, off) in: a = 0 -> (1, 0); a = 1 -> (2, 0), (0, +1). The kernel's tap kr reads
@@ -139,20 +158,23 @@ class _Conv3x3NHWC(torch.autograd.Function):
     weight [Cout,Cin,3,3] (any float dtype; master copy), y [N,Ho,Wo,Cout] bf16."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride):
+    def forward(ctx, x, weight, stride, want_stats=False):
         cin = weight.shape[1]
         xp = _pad_channels(x.contiguous())
         wp = weight
         if xp.shape[-1] != cin:
             wp = weight.new_zeros((weight.shape[0], xp.shape[-1], 3, 3))
             wp[:, :cin] = weight
-        y = conv3x3_nhwc(xp, pack_weight(wp), stride=stride)
+        y, part = _conv_fwd_stats(xp, None, pack_weight(wp), stride, want_stats)
         ctx.save_for_backward(xp, weight)
         ctx.stride, ctx.cin = int(stride), cin
+        if want_stats:
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpart=None):
         xp, weight = ctx.saved_tensors
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
@@ -172,11 +194,12 @@ class _Conv3x3NHWC(torch.autograd.Function):
                 dw = conv3x3_nhwc_wgrad(xp, dy)[:, :cin].to(weight.dtype)
             else:
                 dw = _s2_wgrad(xp, dy)[:, :cin].to(weight.dtype)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def conv3x3(x, weight, stride=1):
-    return _Conv3x3NHWC.apply(x, weight, stride)
+def conv3x3(x, weight, stride=1, want_stats=False):
+    """want_stats: also return the per-tile statistics for instance_norm_leaky_relu_nhwc(..., partials=)."""
+    return _Conv3x3NHWC.apply(x, weight, stride, want_stats)
 
 
 def _p(t):
@@ -189,22 +212,19 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
     (MONAI UnetUpBlock: conv_block(torch.cat((transp_conv(x), skip), 1)))."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight):
+    def forward(ctx, x1, x2, weight, want_stats=False):
         x1, x2 = x1.contiguous(), x2.contiguous()
-        n, h, w, c1 = x1.shape
-        c2 = x2.shape[3]
-        cout = weight.shape[0]
+        c1, c2 = x1.shape[3], x2.shape[3]
         assert x2.shape[:3] == x1.shape[:3] and weight.shape[1] == c1 + c2 and c1 % 32 == 0 and c2 % 32 == 0
-        y = torch.empty((n, h, w, cout), dtype=torch.bfloat16, device=x1.device)
-        wt = pack_weight(weight)
-        rc = _native.lib().octa_conv3x3_nhwc_fwd2(_native.ctx(x1.device.index), _p(x1), _p(x2), c1, _p(wt), _p(y), None, cout, n, h, w, c1 + c2,
-                                                  cout, 1, 1, 0x1ff, _native.current_stream_ptr())
-        _native.check(rc, "octa_conv3x3_nhwc_fwd2")
+        y, part = _conv_fwd_stats(x1, x2, pack_weight(weight), 1, want_stats)
         ctx.save_for_backward(x1, x2, weight)
+        if want_stats:
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpart=None):
         x1, x2, weight = ctx.saved_tensors
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
@@ -223,16 +243,16 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
             rc = lib.octa_conv3x3_nhwc_wgrad2(hctx, _p(x1), _p(x2), c1, _p(dy), _p(dwf), n, h, w, c1 + c2, cout, 0x1ff, st)
             _native.check(rc, "octa_conv3x3_nhwc_wgrad2")
             dw = dwf.view(3, 3, cout, c1 + c2).permute(2, 3, 0, 1).to(weight.dtype)
-        return dx1, dx2, dw
+        return dx1, dx2, dw, None
 
 
-def conv3x3_cat(x1, x2, weight):
-    return _Conv3x3CatNHWC.apply(x1, x2, weight)
+def conv3x3_cat(x1, x2, weight, want_stats=False):
+    return _Conv3x3CatNHWC.apply(x1, x2, weight, want_stats)
 
 
 class _InstNormLReLUNHWC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, slope, eps):
+    def forward(ctx, x, weight, bias, slope, eps, partials=None):
         x = x.contiguous()
         assert x.dtype == torch.bfloat16 and x.dim() == 4
         B, C = x.shape[0], x.shape[3]
@@ -243,8 +263,13 @@ class _InstNormLReLUNHWC(torch.autograd.Function):
         w = weight.float().contiguous() if weight is not None else None
         b = bias.float().contiguous() if bias is not None else None
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-        rc = _native.lib().octa_instnorm_lrelu_nhwc_fwd(_native.ctx(x.device.index), p(x), p(y), p(w), p(b), p(mean), p(rstd), B, C, hw,
-                                                        float(slope), float(eps), _native.current_stream_ptr())
+        if partials is not None:
+            rc = _native.lib().octa_instnorm_lrelu_nhwc_fwd_p(_native.ctx(x.device.index), p(x), p(y), p(w), p(b), p(mean), p(rstd), B, C, hw,
+                                                              float(slope), float(eps), p(partials), int(partials.shape[1]),
+                                                              _native.current_stream_ptr())
+        else:
+            rc = _native.lib().octa_instnorm_lrelu_nhwc_fwd(_native.ctx(x.device.index), p(x), p(y), p(w), p(b), p(mean), p(rstd), B, C, hw,
+                                                            float(slope), float(eps), _native.current_stream_ptr())
         _native.check(rc, "octa_instnorm_lrelu_nhwc_fwd")
         ctx.save_for_backward(x, w, b, mean, rstd)
         ctx.slope, ctx.has_w, ctx.has_b = float(slope), weight is not None, bias is not None
@@ -266,11 +291,12 @@ class _InstNormLReLUNHWC(torch.autograd.Function):
         rc = _native.lib().octa_instnorm_lrelu_nhwc_bwd(_native.ctx(x.device.index), p(x), p(dy), p(w), p(b), p(mean), p(rstd), p(dx), p(dw),
                                                         p(db), B, C, hw, ctx.slope, _native.current_stream_ptr())
         _native.check(rc, "octa_instnorm_lrelu_nhwc_bwd")
-        return dx, (dw.to(ctx.w_dtype) if dw is not None else None), (db.to(ctx.w_dtype) if db is not None else None), None, None
+        return dx, (dw.to(ctx.w_dtype) if dw is not None else None), (db.to(ctx.w_dtype) if db is not None else None), None, None, None
 
 
-def instance_norm_leaky_relu_nhwc(x, weight, bias, negative_slope=0.01, eps=1e-5):
-    return _InstNormLReLUNHWC.apply(x, weight, bias, negative_slope, eps)
+def instance_norm_leaky_relu_nhwc(x, weight, bias, negative_slope=0.01, eps=1e-5, partials=None):
+    """partials: per-tile statistics produced by the convolution that wrote x (conv3x3(..., want_stats=True))."""
+    return _InstNormLReLUNHWC.apply(x, weight, bias, negative_slope, eps, partials)
 
 
 def _s2_wgrad(x_big, dy_small, taps2=((0, 1, 2), (0, 1, 2))):
@@ -423,7 +449,7 @@ class _LazyNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _ds, _dh):
-        return _InstNormLReLUNHWC.backward(ctx, dy)
+        return _InstNormLReLUNHWC.backward(ctx, dy)[:5]
 
 
 def lazy_norm(x, weight, bias, negative_slope=LRELU_SLOPE, eps=1e-5):

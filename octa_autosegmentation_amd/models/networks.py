@@ -29,6 +29,10 @@ USE_MFMA_CONV = True
 # measured SLOWER on MI355X (37.5 vs 31.9 ms per step): every output-channel block of a layer re-stages and
 # re-normalises the same input tile, which costs more VALU work than the two HBM passes it saves
 USE_LAZY_NORM = False
+# InstanceNorm statistics accumulated in the convolution epilogue (conv.hip _fwd5) instead of a statistics pass:
+# implemented and tested, measured slower too (33.6 vs 32.1 ms: the MFMA kernels are the critical resource, the
+# statistics pass they would save is a cheap HBM-bound stream)
+USE_EPILOGUE_STATS = False
 
 
 class _Conv(nn.Module):
@@ -158,14 +162,16 @@ class DynUNet(nn.Module):
         if not USE_LAZY_NORM:
             xt, sk = x[0], (skip[0] if skip is not None else None)
             if sk is not None and xt.shape[-1] % 32 == 0 and sk.shape[-1] % 32 == 0 and st == 1:
-                y = mc.conv3x3_cat(xt, sk, c1.weight)       # conv over the virtual concatenation (x, skip)
+                y = mc.conv3x3_cat(xt, sk, c1.weight, USE_EPILOGUE_STATS)       # conv over the virtual concatenation (x, skip)
             else:
                 if sk is not None:
                     xt = torch.cat((xt, sk), dim=-1)
-                y = mc.conv3x3(xt, c1.weight, st)
-            y = mc.instance_norm_leaky_relu_nhwc(y, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps)
-            y = mc.conv3x3(y, c2.weight, 1)
-            return (mc.instance_norm_leaky_relu_nhwc(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps), None, None)
+                y = mc.conv3x3(xt, c1.weight, st, USE_EPILOGUE_STATS)
+            y, part = y if USE_EPILOGUE_STATS else (y, None)
+            y = mc.instance_norm_leaky_relu_nhwc(y, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps, part)
+            y = mc.conv3x3(y, c2.weight, 1, USE_EPILOGUE_STATS)
+            y, part = y if USE_EPILOGUE_STATS else (y, None)
+            return (mc.instance_norm_leaky_relu_nhwc(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps, part), None, None)
         if x[0].shape[-1] % 32 != 0 or (skip is not None and (skip[0].shape[-1] % 32 != 0 or st != 1)):
             # channel-padded first layer (or an odd split): through the single-input binding on a real tensor
             xt = mc.materialise(x)
