@@ -44,7 +44,9 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 // X: [N][H][W][Cin] (bf16 bits), Wt: [9][Cout][Cin], Y: [N][Ho][Wo][Cout].
 // out(y, x) = sum_{r,s,ci} Xv(y*st + r - 1, x*st + s - 1, ci) * Wt[3r+s][co][ci], where the virtual input is
 // Xv(yy, xx) = X[yy/dil][xx/dil] if 0 <= yy < H*dil, 0 <= xx < W*dil and yy, xx multiples of dil, else 0.
-template <int BN, int ST>
+// EXTRA = false compiles the plain kernel; true adds normalise-on-load and the statistics epilogue (both measured
+// slower in the U-Net step, kept for experiments -- as a template flag they cost the plain kernel nothing).
+template <int BN, int ST, bool EXTRA, bool MASKED>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                     const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
@@ -80,7 +82,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
         // lrelu(x * scale + shift) (InstanceNorm affine + LeakyReLU, per image and channel) while it is staged, rounded
         // to bf16 exactly like the materialised tensor would have been; padding stays zero.
         const float *scp = c0 < C1 ? sc1 : sc2, *shp = c0 < C1 ? sh1 : sh2;
-        const bool xform = scp != nullptr;
+        const bool xform = EXTRA && scp != nullptr;
         if (xform) {
             if (threadIdx.x < KC) s_ss[threadIdx.x] = scp[(size_t)n * cs + cb + threadIdx.x];
             else if (threadIdx.x < 2 * KC) s_ss[threadIdx.x] = shp[(size_t)n * cs + cb + threadIdx.x - KC];
@@ -115,7 +117,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
         for (int i = threadIdx.x; i < 9 * BN * 4; i += CONV_THREADS) {
             const int row = i >> 2, q = i & 3;
             const int tap = row / BN, co = row % BN;
-            if (!((tap_mask >> tap) & 1)) continue;   // unused taps are neither staged nor multiplied
+            if (MASKED && !((tap_mask >> tap) & 1)) continue;   // unused taps are neither staged nor multiplied
             const uint4 v = *reinterpret_cast<const uint4 *>(Wt + ((size_t)tap * Cout + co0 + co) * Cin + c0 + q * 8);
             *reinterpret_cast<uint4 *>(s_w + row * PITCH + q * 16) = v;
         }
@@ -124,7 +126,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
         for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int s = 0; s < 3; s++) {
-                if (!((tap_mask >> (3 * r + s)) & 1)) continue;   // taps whose weights are structurally zero
+                if (MASKED && !((tap_mask >> (3 * r + s)) & 1)) continue;   // taps whose weights are structurally zero
 #pragma unroll
                 for (int ks = 0; ks < KC / 16; ks++) {
                     bf16x8 a[2], b[NB];
@@ -150,6 +152,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
     // larger (osc = 2: one parity class of a zero-insertion-free stride-2 data gradient / 2x2 transposed convolution).
     unsigned short *Yo = co0 < CY1 ? Y : Y2;
     const int ys = co0 < CY1 ? CY1 : Cout - CY1, yb = co0 < CY1 ? co0 : co0 - CY1;
+    if (!EXTRA) { osc = 1; ooy = 0; oox = 0; }   // the scattered store is compiled into the EXTRA variant only
     const int HoF = Ho * osc, WoF = Wo * osc;
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
@@ -165,7 +168,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
     }
     // InstanceNorm statistics of the layer that follows, for free: per tile and output channel the sum and the sum of
     // squares of the bf16-ROUNDED results (what the norm kernels would read back) -> part[n][tile][Cout][2]
-    if (part) {
+    if (EXTRA && part) {
         float s1[NB], s2[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) { s1[nb] = 0.f; s2[nb] = 0.f; }
@@ -201,20 +204,34 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
     }
 }
 
-template <int BN, int ST>
-int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
+template <int BN, int ST, bool EXTRA, bool MASKED>
+int launch_conv_impl(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
                 int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tap_mask, int osc, int ooy, int oox,
                 const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope, float *part, hipStream_t stream) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;
     const size_t lds = (size_t)IH * IW * PITCH + (size_t)9 * BN * PITCH + 2 * KC * sizeof(float);
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    auto kern = conv3x3_nhwc_kernel<BN, ST>;
+    auto kern = conv3x3_nhwc_kernel<BN, ST, EXTRA, MASKED>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
     hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, tap_mask, osc, ooy, oox,
                        sc1, sh1, sc2, sh2, slope, part);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+template <int BN, int ST>
+int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
+                int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tap_mask, int osc, int ooy, int oox,
+                const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope, float *part, hipStream_t stream) {
+    if (sc1 || sc2 || part || osc != 1)
+        return launch_conv_impl<BN, ST, true, true>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, dil, tap_mask, osc, ooy, oox, sc1, sh1, sc2,
+                                                    sh2, slope, part, stream);
+    if (tap_mask != 0x1ff)
+        return launch_conv_impl<BN, ST, false, true>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, dil, tap_mask, 1, 0, 0, nullptr, nullptr,
+                                                     nullptr, nullptr, 0.f, nullptr, stream);
+    return launch_conv_impl<BN, ST, false, false>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, dil, tap_mask, 1, 0, 0, nullptr, nullptr,
+                                                  nullptr, nullptr, 0.f, nullptr, stream);
 }
 
 }  // namespace
@@ -299,7 +316,7 @@ constexpr int WG_ROWP = TW * 2 * WTH;  // bytes per channel row of the transpose
 constexpr int HALO_W = 40;             // halo row pitch in pixels (34 used; 80 B keeps rows 16-byte aligned)
 constexpr int WG_XROW = (WTH + 2) * HALO_W * 2;  // bytes per channel row of the transposed X tile
 
-template <int COB, int CIB>
+template <int COB, int CIB, bool MASKED>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                           const unsigned short *__restrict__ dY, float *__restrict__ dW,
@@ -412,7 +429,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_dy + (cob + m) * WG_ROWP + (y * TW + xs + kg * 8) * 2);
 #pragma unroll
             for (int r = 0; r < 3; r++) {
-                if (!((tap_mask >> (3 * r)) & 7)) continue;   // no tap of this kernel row is wanted
+                if (MASKED && !((tap_mask >> (3 * r)) & 7)) continue;   // no tap of this kernel row is wanted
                 // halo columns xs + kg*8 + s .. +7 of halo row y + r: aligned 8-pixel group + the next dword
                 const unsigned char *row = s_x + (cib + m) * WG_XROW + ((y + r) * HALO_W + xs + kg * 8) * 2;
                 const uint4 d = *reinterpret_cast<const uint4 *>(row);
@@ -422,9 +439,9 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
                 b1.u = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
                                   __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
                 b2.u = make_uint4(d.y, d.z, d.w, e);
-                if ((tap_mask >> (3 * r)) & 1) acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0.v, acc[3 * r + 0], 0, 0, 0);
-                if ((tap_mask >> (3 * r + 1)) & 1) acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1.v, acc[3 * r + 1], 0, 0, 0);
-                if ((tap_mask >> (3 * r + 2)) & 1) acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2.v, acc[3 * r + 2], 0, 0, 0);
+                if (!MASKED || ((tap_mask >> (3 * r)) & 1)) acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0.v, acc[3 * r + 0], 0, 0, 0);
+                if (!MASKED || ((tap_mask >> (3 * r + 1)) & 1)) acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1.v, acc[3 * r + 1], 0, 0, 0);
+                if (!MASKED || ((tap_mask >> (3 * r + 2)) & 1)) acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2.v, acc[3 * r + 2], 0, 0, 0);
             }
             // a share of the next tile's transposed stores, tucked behind this MFMA group
             if (have_next) {
@@ -441,7 +458,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     // D[row = co][col = ci]: row = (k&3) + 8*(k>>2) + 4*kg, col = m
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-        if (!((tap_mask >> t) & 1)) continue;
+        if (MASKED && !((tap_mask >> t) & 1)) continue;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int co = co0 + cob + (k & 3) + 8 * (k >> 2) + 4 * kg;
@@ -450,8 +467,8 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     }
 }
 
-template <int COB, int CIB>
-int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
+template <int COB, int CIB, bool MASKED>
+int launch_wgrad_impl(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
                  int Cout, int num_cus, int tap_mask, const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope,
                  hipStream_t stream) {
     const size_t lds = 2 * ((size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW);   // double buffered
@@ -461,12 +478,20 @@ int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, cons
     const int n_tiles = tiles_x * tiles_y * N;
     if (per_block > n_tiles) per_block = n_tiles;
     if (per_block < 1) per_block = 1;
-    auto kern = conv3x3_nhwc_wgrad_kernel<COB, CIB>;
+    auto kern = conv3x3_nhwc_wgrad_kernel<COB, CIB, MASKED>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Cin,
                        Cout, tiles_x, tiles_y, tap_mask, sc1, sh1, sc2, sh2, slope);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+template <int COB, int CIB>
+int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
+                 int Cout, int num_cus, int tap_mask, const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope,
+                 hipStream_t stream) {
+    if (tap_mask != 0x1ff) return launch_wgrad_impl<COB, CIB, true>(X, X2, C1, dY, dW, N, H, W, Cin, Cout, num_cus, tap_mask, sc1, sh1, sc2, sh2, slope, stream);
+    return launch_wgrad_impl<COB, CIB, false>(X, X2, C1, dY, dW, N, H, W, Cin, Cout, num_cus, tap_mask, sc1, sh1, sc2, sh2, slope, stream);
 }
 
 }  // namespace
