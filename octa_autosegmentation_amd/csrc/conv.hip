@@ -154,6 +154,31 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
     const int ys = co0 < CY1 ? CY1 : Cout - CY1, yb = co0 < CY1 ? co0 : co0 - CY1;
     if (!EXTRA) { osc = 1; ooy = 0; oox = 0; }   // the scattered store is compiled into the EXTRA variant only
     const int HoF = Ho * osc, WoF = Wo * osc;
+    if (!EXTRA) {
+        // Coalesced store: the tile goes through LDS ([pixel][BN channels], 16-byte padded rows) so that consecutive
+        // threads write consecutive 16-byte pieces -- whole 64/128-byte pixel rows, whole tile rows back to back --
+        // instead of 2-byte elements 64 bytes apart.
+        constexpr int OP = BN * 2 + 16;                 // bytes per pixel row in LDS
+        unsigned char *s_out = smem;                    // [TH*TW] rows; the operand tiles are dead now
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int px = (k & 3) + 8 * (k >> 2) + 4 * kg;
+                    *reinterpret_cast<unsigned short *>(s_out + ((2 * wv + rr) * TW + px) * OP + (nb * 32 + m) * 2) = f2bf(acc[rr][nb][k]);
+                }
+        __syncthreads();
+        constexpr int PIECES = BN / 8;                  // 16-byte pieces per pixel
+        for (int i = threadIdx.x; i < TH * TW * PIECES; i += CONV_THREADS) {
+            const int p = i / PIECES, q = i % PIECES;
+            const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+            if (oy < Ho && ox < Wo)
+                *reinterpret_cast<uint4 *>(Yo + (((size_t)n * Ho + oy) * Wo + ox) * ys + yb + q * 8) = *reinterpret_cast<const uint4 *>(s_out + p * OP + q * 16);
+        }
+    } else {
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int oy = ty0 + 2 * wv + rr;
@@ -165,6 +190,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
                 const int ox = tx0 + (k & 3) + 8 * (k >> 2) + 4 * kg;
                 if (ox < Wo) Yo[(((size_t)n * HoF + oy * osc + ooy) * WoF + ox * osc + oox) * ys + yb + nb * 32 + m] = f2bf(acc[rr][nb][k]);
             }
+    }
     }
     // InstanceNorm statistics of the layer that follows, for free: per tile and output channel the sum and the sum of
     // squares of the bf16-ROUNDED results (what the norm kernels would read back) -> part[n][tile][Cout][2]
