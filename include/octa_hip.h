@@ -191,6 +191,13 @@ int octa_instnorm_lrelu_nhwc_fwd_p(octa_ctx *ctx, const void *d_x, void *d_y, co
                                    float *d_rstd, int B, int C, int64_t hw, float slope, float eps, const float *d_partials, int tiles,
                                    void *stream);
 
+/* Weight gradient with a stride: stride 2 = d_x is the [N][H][W][Cin] input of a stride-2 layer (H, W even), d_dy its
+ * [N][H/2][W/2][Cout] output gradient; tap_mask as above (the 2x2 transposed convolution, written as the adjoint of a
+ * stride-2 layer, asks for 4 of the 9 taps). */
+int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H, int W,
+                             int Cin, int Cout, int stride, int tap_mask, const float *d_scale1, const float *d_shift1,
+                             const float *d_scale2, const float *d_shift2, float slope, void *stream);
+
 /* Weight gradient of the stride-1 layer above: d_dw [9][Cout][Cin] float32 (overwritten) =
  * sum over pixels of d_dy[N][H][W][Cout] (bf16) x d_x[N][H][W][Cin] (bf16) shifted by the tap (SURVEY.md 8b:
  * octa_conv2d_wgrad). fp32 accumulation; partial sums of the persistent workgroups meet in fp32 atomics, so the

@@ -340,20 +340,26 @@ namespace {
 constexpr int WTH = 4;                 // tile rows of the weight-gradient kernel (4 x 32 = 128 pixels per tile)
 constexpr int WG_ROWP = TW * 2 * WTH;  // bytes per channel row of the transposed dY tile
 constexpr int HALO_W = 40;             // halo row pitch in pixels (34 used; 80 B keeps rows 16-byte aligned)
-constexpr int WG_XROW = (WTH + 2) * HALO_W * 2;  // bytes per channel row of the transposed X tile
 
-template <int COB, int CIB, bool MASKED>
+// ST = 2: weight gradient of a stride-2 layer. dY has Ho x Wo pixels, the input 2Ho x 2Wo; tap (r, s) pairs output
+// pixel (y, x) with input pixel (2y + r - 1, 2x + s - 1). The transposed X tile keeps its ODD and EVEN halo columns in
+// two planes per row, so the eight input pixels of a K-group are contiguous again: tap s = 0 reads the odd plane, s = 1
+// the even plane, s = 2 the odd plane one element further (funnel shift).
+template <int COB, int CIB, bool MASKED, int ST>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                           const unsigned short *__restrict__ dY, float *__restrict__ dW,
-                          int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask,
+                          int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask,
                           const float *__restrict__ sc1, const float *__restrict__ sh1, const float *__restrict__ sc2,
                           const float *__restrict__ sh2, float slope) {
     constexpr int PAIRS = (COB / 32) * (CIB / 32);
     constexpr int KSPLIT = 4 / PAIRS;            // waves sharing one (co, ci) pair split the tile rows
     constexpr int ROWS_PER_WAVE = WTH / KSPLIT;
     constexpr int SLOTS = ROWS_PER_WAVE * (TW / 16);   // MFMA groups of the compute loop = places to tuck LDS stores
-    constexpr int DYPIX = WTH * TW, XPIX = (WTH + 2) * (TW + 2);
+    constexpr int XROWS = ST == 1 ? WTH + 2 : 2 * WTH + 1, XCOLS = ST == 1 ? TW + 2 : 2 * TW + 1;
+    constexpr int XRP = ST == 1 ? HALO_W * 2 : 2 * HALO_W * 2;      // bytes per halo row (two column-parity planes for ST = 2)
+    constexpr int WG_XROW = XROWS * XRP;                             // bytes per channel row of the transposed X tile
+    constexpr int DYPIX = WTH * TW, XPIX = XROWS * XCOLS;
     constexpr int DY_ITEMS = DYPIX * (COB / 8), X_ITEMS = XPIX * (CIB / 8);   // 16-byte pieces per tile
     constexpr int DY_PT = (DY_ITEMS + CONV_THREADS - 1) / CONV_THREADS, X_PT = (X_ITEMS + CONV_THREADS - 1) / CONV_THREADS;
     constexpr int BUF = COB * WG_ROWP + CIB * WG_XROW;
@@ -388,13 +394,13 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
         for (int k = 0; k < DY_PT; k++) {
             const int i = threadIdx.x + k * CONV_THREADS, p = i % DYPIX, q = i / DYPIX;
             const int y = ty0 + p / TW, x = tx0 + p % TW;
-            const bool ok = i < DY_ITEMS && y < H && x < W;
-            r_dy[k] = ok ? *reinterpret_cast<const uint4 *>(dY + (((size_t)n * H + y) * W + x) * Cout + co0 + q * 8) : make_uint4(0u, 0u, 0u, 0u);
+            const bool ok = i < DY_ITEMS && y < Ho && x < Wo;
+            r_dy[k] = ok ? *reinterpret_cast<const uint4 *>(dY + (((size_t)n * Ho + y) * Wo + x) * Cout + co0 + q * 8) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int k = 0; k < X_PT; k++) {
             const int i = threadIdx.x + k * CONV_THREADS, p = i % XPIX, q = i / XPIX;
-            const int y = ty0 - 1 + p / (TW + 2), x = tx0 - 1 + p % (TW + 2);
+            const int y = ty0 * ST - 1 + p / XCOLS, x = tx0 * ST - 1 + p % XCOLS;
             const bool ok = i < X_ITEMS && y >= 0 && y < H && x >= 0 && x < W;
             uint4 v = ok ? *reinterpret_cast<const uint4 *>(Xs + (((size_t)n * H + y) * W + x) * xcs + xcb + q * 8) : make_uint4(0u, 0u, 0u, 0u);
             if (xform && ok) {
@@ -427,11 +433,13 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     auto stash_x = [&](unsigned char *buf, int k) {
         const int i = threadIdx.x + k * CONV_THREADS, p = i % XPIX, q = i / XPIX;
         if (i < X_ITEMS) {
-            const int hy = p / (TW + 2), hx = p % (TW + 2);
+            const int hy = p / XCOLS, hx = p % XCOLS;
+            // ST = 2: halo column hx is input column 2*tx0 - 1 + hx: even hx -> odd plane (0), odd hx -> even plane (1)
+            const int off = ST == 1 ? hy * XRP + hx * 2 : hy * XRP + (hx & 1) * (HALO_W * 2) + (hx >> 1) * 2;
             const unsigned w4[4] = {r_x[k].x, r_x[k].y, r_x[k].z, r_x[k].w};
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                *reinterpret_cast<unsigned short *>(buf + COB * WG_ROWP + (q * 8 + j) * WG_XROW + (hy * HALO_W + hx) * 2) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+                *reinterpret_cast<unsigned short *>(buf + COB * WG_ROWP + (q * 8 + j) * WG_XROW + off) = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
         }
     };
     int tile = blockIdx.x;
@@ -456,15 +464,26 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 if (MASKED && !((tap_mask >> (3 * r)) & 7)) continue;   // no tap of this kernel row is wanted
-                // halo columns xs + kg*8 + s .. +7 of halo row y + r: aligned 8-pixel group + the next dword
-                const unsigned char *row = s_x + (cib + m) * WG_XROW + ((y + r) * HALO_W + xs + kg * 8) * 2;
-                const uint4 d = *reinterpret_cast<const uint4 *>(row);
-                const unsigned e = *reinterpret_cast<const unsigned *>(row + 16);
                 union { uint4 u; bf16x8 v; } b0, b1, b2;
-                b0.u = d;
-                b1.u = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
-                                  __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
-                b2.u = make_uint4(d.y, d.z, d.w, e);
+                if (ST == 1) {
+                    // halo columns xs + kg*8 + s .. +7 of halo row y + r: aligned 8-pixel group + the next dword
+                    const unsigned char *row = s_x + (cib + m) * WG_XROW + (y + r) * XRP + (xs + kg * 8) * 2;
+                    const uint4 d = *reinterpret_cast<const uint4 *>(row);
+                    const unsigned e = *reinterpret_cast<const unsigned *>(row + 16);
+                    b0.u = d;
+                    b1.u = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
+                                      __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
+                    b2.u = make_uint4(d.y, d.z, d.w, e);
+                } else {
+                    // input row 2y + r of the halo; s = 0: odd plane at xs.., s = 1: even plane at xs.., s = 2: odd plane at xs+1..
+                    const unsigned char *row = s_x + (cib + m) * WG_XROW + (2 * y + r) * XRP + (xs + kg * 8) * 2;
+                    const uint4 d = *reinterpret_cast<const uint4 *>(row);
+                    const unsigned e = *reinterpret_cast<const unsigned *>(row + 16);
+                    b0.u = d;
+                    b1.u = *reinterpret_cast<const uint4 *>(row + HALO_W * 2);
+                    b2.u = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
+                                      __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
+                }
                 if (!MASKED || ((tap_mask >> (3 * r)) & 1)) acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0.v, acc[3 * r + 0], 0, 0, 0);
                 if (!MASKED || ((tap_mask >> (3 * r + 1)) & 1)) acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1.v, acc[3 * r + 1], 0, 0, 0);
                 if (!MASKED || ((tap_mask >> (3 * r + 2)) & 1)) acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2.v, acc[3 * r + 2], 0, 0, 0);
@@ -493,37 +512,40 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     }
 }
 
-template <int COB, int CIB, bool MASKED>
+template <int COB, int CIB, bool MASKED, int ST>
 int launch_wgrad_impl(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
                  int Cout, int num_cus, int tap_mask, const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope,
                  hipStream_t stream) {
+    constexpr int XROWS = ST == 1 ? WTH + 2 : 2 * WTH + 1;
+    constexpr int WG_XROW = XROWS * (ST == 1 ? HALO_W * 2 : 2 * HALO_W * 2);
     const size_t lds = 2 * ((size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW);   // double buffered
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + WTH - 1) / WTH;
+    const int Ho = H / ST, Wo = W / ST;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + WTH - 1) / WTH;
     const int blocks = (Cout / COB) * (Cin / CIB);
     int per_block = (2 * num_cus + blocks - 1) / blocks;
     const int n_tiles = tiles_x * tiles_y * N;
     if (per_block > n_tiles) per_block = n_tiles;
     if (per_block < 1) per_block = 1;
-    auto kern = conv3x3_nhwc_wgrad_kernel<COB, CIB, MASKED>;
+    auto kern = conv3x3_nhwc_wgrad_kernel<COB, CIB, MASKED, ST>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Cin,
+    hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Ho, Wo, Cin,
                        Cout, tiles_x, tiles_y, tap_mask, sc1, sh1, sc2, sh2, slope);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-template <int COB, int CIB>
+template <int COB, int CIB, int ST = 1>
 int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
                  int Cout, int num_cus, int tap_mask, const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope,
                  hipStream_t stream) {
-    if (tap_mask != 0x1ff) return launch_wgrad_impl<COB, CIB, true>(X, X2, C1, dY, dW, N, H, W, Cin, Cout, num_cus, tap_mask, sc1, sh1, sc2, sh2, slope, stream);
-    return launch_wgrad_impl<COB, CIB, false>(X, X2, C1, dY, dW, N, H, W, Cin, Cout, num_cus, tap_mask, sc1, sh1, sc2, sh2, slope, stream);
+    if (tap_mask != 0x1ff) return launch_wgrad_impl<COB, CIB, true, ST>(X, X2, C1, dY, dW, N, H, W, Cin, Cout, num_cus, tap_mask, sc1, sh1, sc2, sh2, slope, stream);
+    return launch_wgrad_impl<COB, CIB, false, ST>(X, X2, C1, dY, dW, N, H, W, Cin, Cout, num_cus, tap_mask, sc1, sh1, sc2, sh2, slope, stream);
 }
 
 }  // namespace
 
-extern "C" int octa_conv3x3_nhwc_wgrad3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
-                                        int W, int Cin, int Cout, int tap_mask, const float *d_scale1, const float *d_shift1,
+extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
+                                        int W, int Cin, int Cout, int stride, int tap_mask, const float *d_scale1, const float *d_shift1,
                                         const float *d_scale2, const float *d_shift2, float slope, void *stream_) {
     if (!ctx || !d_x || !d_dy || !d_dw) { octa::set_error("octa_conv3x3_nhwc_wgrad: null pointer"); return -2; }
     tap_mask &= 0x1ff;
@@ -538,10 +560,23 @@ extern "C" int octa_conv3x3_nhwc_wgrad3(octa_ctx *ctx, const void *d_x, const vo
     const unsigned short *X = static_cast<const unsigned short *>(d_x), *X2 = static_cast<const unsigned short *>(d_x2);
     const unsigned short *dY = static_cast<const unsigned short *>(d_dy);
     const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0 && C1 % 64 == 0;   // a 64-channel block must not straddle the split
+    if (stride == 2) {
+        if (H % 2 || W % 2) { octa::set_error("octa_conv3x3_nhwc_wgrad: stride-2 layers need even input sizes"); return -2; }
+        // two column-parity planes per halo row: 32 input channels per workgroup keep the double buffer inside the LDS
+        if (co64) return launch_wgrad<64, 32, 2>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+        return launch_wgrad<32, 32, 2>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+    }
+    if (stride != 1) { octa::set_error("octa_conv3x3_nhwc_wgrad: stride must be 1 or 2"); return -2; }
     if (co64 && ci64) return launch_wgrad<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
     if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
     if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
     return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+}
+
+extern "C" int octa_conv3x3_nhwc_wgrad3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
+                                        int W, int Cin, int Cout, int tap_mask, const float *d_scale1, const float *d_shift1,
+                                        const float *d_scale2, const float *d_shift2, float slope, void *stream_) {
+    return octa_conv3x3_nhwc_wgrad4(ctx, d_x, d_x2, C1, d_dy, d_dw, N, H, W, Cin, Cout, 1, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream_);
 }
 
 extern "C" int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,

@@ -301,23 +301,20 @@ def instance_norm_leaky_relu_nhwc(x, weight, bias, negative_slope=0.01, eps=1e-5
 
 def _s2_wgrad(x_big, dy_small, taps2=((0, 1, 2), (0, 1, 2))):
     """Weight gradient [Cout, Cin, 3, 3] (float32) of a stride-2, padding-1 3x3 conv with input x_big [N,2H,2W,Cin] and
-    output gradient dy_small [N,H,W,Cout]: the nine taps are stride-1 taps of the four parity planes of the input."""
-    cout, cin = dy_small.shape[-1], x_big.shape[-1]
-    dw9 = torch.empty((3, 3, cout, cin), dtype=torch.float32, device=x_big.device)
-    taps = {1: ((0, 0), (1, 2)), 0: ((1, 1),)}   # plane parity -> ((stride-1 tap, stride-2 tap), ...)
-    dw9.zero_()
-    for pa in (0, 1):
-        for pb in (0, 1):
-            want = [(i, r, j, s_) for i, r in taps[pa] if r in taps2[0] for j, s_ in taps[pb] if s_ in taps2[1]]
-            if not want:
-                continue
-            mask = 0
-            for i, r, j, s_ in want:
-                mask |= 1 << (3 * i + j)
-            g = conv3x3_nhwc_wgrad(x_big[:, pa::2, pb::2, :].contiguous(), dy_small, tap_mask=mask)
-            for i, r, j, s_ in want:
-                dw9[r, s_] = g[:, :, i, j]
-    return dw9.permute(2, 3, 0, 1)
+    output gradient dy_small [N,H,W,Cout]; taps2 = the (r, s) taps that are wanted (others come back zero)."""
+    x_big, dy_small = x_big.contiguous(), dy_small.contiguous()
+    n, h, w, cin = x_big.shape
+    cout = dy_small.shape[-1]
+    mask = 0
+    for r in taps2[0]:
+        for s_ in taps2[1]:
+            mask |= 1 << (3 * r + s_)
+    dw = torch.empty((9, cout, cin), dtype=torch.float32, device=x_big.device)
+    rc = _native.lib().octa_conv3x3_nhwc_wgrad4(_native.ctx(x_big.device.index), ctypes.c_void_p(x_big.data_ptr()), None, cin,
+                                                ctypes.c_void_p(dy_small.data_ptr()), ctypes.c_void_p(dw.data_ptr()), n, h, w, cin, cout, 2, mask,
+                                                None, None, None, None, 0.0, _native.current_stream_ptr())
+    _native.check(rc, "octa_conv3x3_nhwc_wgrad4")
+    return dw.view(3, 3, cout, cin).permute(2, 3, 0, 1)
 
 
 class _ConvT2x2NHWC(torch.autograd.Function):
