@@ -522,7 +522,7 @@ int launch_wgrad_impl(const unsigned short *X, const unsigned short *X2, int C1,
     const int Ho = H / ST, Wo = W / ST;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + WTH - 1) / WTH;
     const int blocks = (Cout / COB) * (Cin / CIB);
-    int per_block = (2 * num_cus + blocks - 1) / blocks;
+    int per_block = (num_cus + blocks - 1) / blocks;   // one resident workgroup per CU (LDS): one round, fewer atomics
     const int n_tiles = tiles_x * tiles_y * N;
     if (per_block > n_tiles) per_block = n_tiles;
     if (per_block < 1) per_block = 1;
