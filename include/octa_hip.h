@@ -217,6 +217,21 @@ int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, i
                                                                                   the tap mask of _fwd2 (unmasked taps of d_dw
                                                                                   are left zero) */
 
+/* ---- GPU data-augmentation chain between rasteriser and network --------------------
+ * Replaces the MONAI CPU transforms of configs/config_ves_seg-S.yml:42-102 (registry data/data_transforms.py:587-611)
+ * for a batch resident in HBM.
+ * octa_resize_bilinear: ScaleIntensityd + Resized(mode bilinear): in [B][h][w] (in_dtype 0 = uint8, 1 = float32) ->
+ *   float32 [B][H][W] with torch's upsample_bilinear2d arithmetic (align_corners False); every source value is mapped
+ *   v * d_mul[b] + d_add[b] first (NULL = identity) -- ScaleIntensity's per-image min/max map.
+ * octa_flip_rot90_rotate: RandFlipd (both axes, d_flip[b] != 0) -> RandRotate90d (d_rot_k[b] quarter turns, torch.rot90) ->
+ *   RandRotated (d_angle[b] radians, bilinear, zeros padding, affine_grid + grid_sample arithmetic with align_corners
+ *   False) -> optional AsDiscreted (v >= threshold ? 1 : 0) on square float32 images [B][N][N]; out must not alias in.
+ */
+int octa_resize_bilinear(octa_ctx *ctx, const void *d_in, int in_dtype, int B, int h, int w, float *d_out, int H, int W,
+                         const float *d_mul, const float *d_add, void *stream);
+int octa_flip_rot90_rotate(octa_ctx *ctx, const float *d_in, float *d_out, int B, int N, const float *d_angle, const int *d_rot_k,
+                           const int *d_flip, float threshold, int use_threshold, void *stream);
+
 /* ---- N1-N4: space-colonisation vessel-graph simulator --------------------
  * Replaces, for B independent samples advanced in lock-step on the GPU:
  *   vessel_graph_generation/greenhouse.py:57-137 (Greenhouse.develop_forest) with

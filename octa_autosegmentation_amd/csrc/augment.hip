@@ -1,0 +1,111 @@
+// augment.hip -- the GPU data-augmentation chain between the rasteriser and the network.
+//
+// Replaces, for a whole batch resident in HBM, the MONAI CPU transforms of the training configs
+// (configs/config_ves_seg-S.yml:42-102, built by data/data_transforms.py:587-611 get_data_augmentations):
+//   ScaleIntensityd(0, 1) -> Resized(1216, 1216, bilinear) -> RandFlipd -> RandRotate90d -> RandRotated(+-10 deg,
+//   bilinear, zeros) -> AsDiscreted(label, 0.1) -> CastToTyped.
+// Two streaming kernels (HBM-bound; algorithmic bytes = one read of the source + one write of the result):
+//   resize_bilinear_kernel : uint8 / float32 [B][h][w] -> float32 [B][H][W], torch's upsample_bilinear2d arithmetic
+//                            (align_corners = False), with the per-image affine intensity map of ScaleIntensity folded in;
+//   rotate_kernel          : float32 [B][H][W] -> float32 [B][H][W]: rotation by a per-image angle about the image centre
+//                            (F.affine_grid + F.grid_sample, bilinear, zeros padding, align_corners = False arithmetic),
+//                            the exact index permutations of the preceding flip / rot90 folded into the tap addresses,
+//                            optional threshold (AsDiscrete) on the way out.
+// MONAI itself is not in the image (parity with it is unpinned); the kernels are pinned against the torch
+// ops MONAI delegates to (tests/test_augment_gpu.py).
+
+#include "common.h"
+
+namespace {
+
+template <class T> __device__ __forceinline__ float ldf(const T *p);
+template <> __device__ __forceinline__ float ldf<unsigned char>(const unsigned char *p) { return (float)*p; }
+template <> __device__ __forceinline__ float ldf<float>(const float *p) { return *p; }
+
+// torch area_pixel_compute_source_index(scale, dst, align_corners = false, cubic = false)
+__device__ __forceinline__ float src_index(float scale, int dst) {
+    const float s = scale * ((float)dst + 0.5f) - 0.5f;
+    return s < 0.f ? 0.f : s;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+resize_bilinear_kernel(const T *__restrict__ in, int h, int w, float *__restrict__ out, int H, int W, const float *__restrict__ mul,
+                       const float *__restrict__ add) {
+    const int b = blockIdx.z, Y = blockIdx.y, X = blockIdx.x * 256 + threadIdx.x;
+    if (X >= W) return;
+    const float rh = (float)h / (float)H, rw = (float)w / (float)W;
+    const float h1r = src_index(rh, Y), w1r = src_index(rw, X);
+    const int h1 = (int)h1r, w1 = (int)w1r;
+    const int h1p = h1 < h - 1 ? 1 : 0, w1p = w1 < w - 1 ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l, w1l = w1r - (float)w1, w0l = 1.f - w1l;
+    const T *p = in + ((size_t)b * h + h1) * w + w1;
+    const float m = mul ? mul[b] : 1.f, a = add ? add[b] : 0.f;
+    const float p00 = ldf(p) * m + a, p01 = ldf(p + w1p) * m + a, p10 = ldf(p + (size_t)h1p * w) * m + a, p11 = ldf(p + (size_t)h1p * w + w1p) * m + a;
+    out[((size_t)b * H + Y) * W + X] = h0l * (w0l * p00 + w1l * p01) + h1l * (w0l * p10 + w1l * p11);
+}
+
+// One tap of the rotated image's source: (iy, ix) indexes the image AFTER flip and rot90; map it back to the stored one.
+// torch.rot90(x, k, (H, W)) on a square image: k = 1: out[i][j] = in[j][N-1-i]; k = 2: in[N-1-i][N-1-j]; k = 3: in[N-1-j][i].
+__device__ __forceinline__ float tap(const float *img, int N, int iy, int ix, int k, int flip) {
+    if (iy < 0 || iy >= N || ix < 0 || ix >= N) return 0.f;   // zeros padding
+    int y = iy, x = ix;
+    if (k == 1) { y = ix; x = N - 1 - iy; }
+    else if (k == 2) { y = N - 1 - iy; x = N - 1 - ix; }
+    else if (k == 3) { y = N - 1 - ix; x = iy; }
+    if (flip) { y = N - 1 - y; x = N - 1 - x; }
+    return img[(size_t)y * N + x];
+}
+
+// theta = [[c, -s, 0], [s, c, 0]] in grid_sample's normalised coordinates (x first), align_corners = False.
+__global__ void __launch_bounds__(256)
+rotate_kernel(const float *__restrict__ in, float *__restrict__ out, int N, const float *__restrict__ angle, const int *__restrict__ rot_k,
+              const int *__restrict__ flip, float threshold, int use_threshold) {
+    const int b = blockIdx.z, Y = blockIdx.y, X = blockIdx.x * 256 + threadIdx.x;
+    if (X >= N) return;
+    const float c = cosf(angle[b]), s = sinf(angle[b]);
+    // affine_grid base coordinates: (2i + 1) / N - 1
+    const float gx = (2.f * (float)X + 1.f) / (float)N - 1.f, gy = (2.f * (float)Y + 1.f) / (float)N - 1.f;
+    const float sx = c * gx - s * gy, sy = s * gx + c * gy;
+    // grid_sample unnormalise (align_corners = False): ((coord + 1) * N - 1) / 2
+    const float fx = ((sx + 1.f) * (float)N - 1.f) * 0.5f, fy = ((sy + 1.f) * (float)N - 1.f) * 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float tx = fx - x0f, ty = fy - y0f;
+    const float *img = in + (size_t)b * N * N;
+    const int k = rot_k ? rot_k[b] : 0, fl = flip ? flip[b] : 0;
+    // grid_sample's weights: nw = (x1 - x)(y1 - y), ne = (x - x0)(y1 - y), sw = (x1 - x)(y - y0), se = (x - x0)(y - y0)
+    const float nw = (1.f - tx) * (1.f - ty), ne = tx * (1.f - ty), sw = (1.f - tx) * ty, se = tx * ty;
+    float v = tap(img, N, y0, x0, k, fl) * nw;
+    v += tap(img, N, y0, x0 + 1, k, fl) * ne;
+    v += tap(img, N, y0 + 1, x0, k, fl) * sw;
+    v += tap(img, N, y0 + 1, x0 + 1, k, fl) * se;
+    if (use_threshold) v = v >= threshold ? 1.f : 0.f;
+    out[((size_t)b * N + Y) * N + X] = v;
+}
+
+}  // namespace
+
+extern "C" int octa_resize_bilinear(octa_ctx *ctx, const void *d_in, int in_dtype, int B, int h, int w, float *d_out, int H, int W,
+                                    const float *d_mul, const float *d_add, void *stream_) {
+    if (!ctx || !d_in || !d_out || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || B > 65535 || H > 65535) { octa::set_error("octa_resize_bilinear: bad arguments"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)B);
+    if (in_dtype == 0) hipLaunchKernelGGL(resize_bilinear_kernel<unsigned char>, grid, dim3(256), 0, stream, static_cast<const unsigned char *>(d_in), h, w, d_out, H, W, d_mul, d_add);
+    else if (in_dtype == 1) hipLaunchKernelGGL(resize_bilinear_kernel<float>, grid, dim3(256), 0, stream, static_cast<const float *>(d_in), h, w, d_out, H, W, d_mul, d_add);
+    else { octa::set_error("octa_resize_bilinear: in_dtype must be 0 (uint8) or 1 (float32)"); return -2; }
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_flip_rot90_rotate(octa_ctx *ctx, const float *d_in, float *d_out, int B, int N, const float *d_angle, const int *d_rot_k,
+                                      const int *d_flip, float threshold, int use_threshold, void *stream_) {
+    if (!ctx || !d_in || !d_out || !d_angle || B <= 0 || N <= 0 || B > 65535 || N > 65535 || d_in == d_out) { octa::set_error("octa_flip_rot90_rotate: bad arguments"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)N, (unsigned)B);
+    hipLaunchKernelGGL(rotate_kernel, grid, dim3(256), 0, stream, d_in, d_out, N, d_angle, d_rot_k, d_flip, threshold, use_threshold);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}

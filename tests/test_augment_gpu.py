@@ -1,0 +1,79 @@
+"""GPU parity of the augmentation kernels (csrc/augment.hip) against the torch ops MONAI's transforms delegate to:
+F.interpolate(bilinear), torch.flip / torch.rot90, F.affine_grid + F.grid_sample. fp32, tolerance 1e-5 (same formulas,
+fused multiply-adds may differ in the last bits)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_resize_matches_torch_interpolate(hip_lib_built):
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.data import gpu_augment
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randint(0, 256, (3, 76, 76), device="cuda", generator=g, dtype=torch.uint8)
+    got = gpu_augment.resize_bilinear(x, [304, 304])
+    want = F.interpolate(x.float().unsqueeze(1), size=(304, 304), mode="bilinear", align_corners=False).squeeze(1)
+    assert (got - want).abs().max().item() <= 1e-3          # values up to 255
+    xf = torch.rand(2, 50, 70, device="cuda", generator=g)
+    mul, add = torch.tensor([2.0, 0.5], device="cuda"), torch.tensor([-1.0, 3.0], device="cuda")
+    got = gpu_augment.resize_bilinear(xf, [125, 91], mul, add)
+    want = F.interpolate((xf * mul[:, None, None] + add[:, None, None]).unsqueeze(1), size=(125, 91), mode="bilinear", align_corners=False).squeeze(1)
+    assert (got - want).abs().max().item() <= 1e-5
+    same = gpu_augment.resize_bilinear(xf, [50, 70])
+    assert (same - xf).abs().max().item() <= 1e-6           # Resized to the same size is the identity
+
+
+def test_flip_rot90_rotate_matches_torch(hip_lib_built):
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.data import gpu_augment
+    g = torch.Generator(device="cuda").manual_seed(2)
+    B, N = 8, 96
+    x = torch.rand(B, N, N, device="cuda", generator=g)
+    flip = torch.tensor([0, 1, 0, 1, 0, 1, 0, 1], dtype=torch.int32, device="cuda")
+    k = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3], dtype=torch.int32, device="cuda")
+    ang = torch.tensor([0.0, 0.1, -0.17, 0.05, 0.17, -0.03, 0.12, -0.1], device="cuda")
+    got = gpu_augment.flip_rot90_rotate(x, ang, k, flip)
+    for b in range(B):
+        y = x[b]
+        if int(flip[b]):
+            y = torch.flip(y, (0, 1))
+        y = torch.rot90(y, int(k[b]), (0, 1))
+        c, s = float(torch.cos(ang[b])), float(torch.sin(ang[b]))
+        theta = torch.tensor([[[c, -s, 0.0], [s, c, 0.0]]], device="cuda")
+        grid = F.affine_grid(theta, (1, 1, N, N), align_corners=False)
+        want = F.grid_sample(y[None, None], grid, mode="bilinear", padding_mode="zeros", align_corners=False)[0, 0]
+        assert (got[b] - want).abs().max().item() <= 2e-5, b
+    thr = gpu_augment.flip_rot90_rotate(x, ang, k, flip, threshold=0.5)
+    assert set(thr.unique().tolist()) <= {0.0, 1.0}
+    assert ((thr > 0.5) != (got >= 0.5)).float().mean().item() < 1e-4
+
+
+def test_augmentation_chain_from_config(hip_lib_built):
+    """The reference's config list drives the chain; image and label of a sample get the same geometry."""
+    import torch
+    from octa_autosegmentation_amd.data import gpu_augment
+    cfg = [{"name": "LoadGraphAndFilterByRandomRadiusd", "keys": ["image", "label"]},
+           {"name": "ScaleIntensityd", "keys": ["image", "label"], "minv": 0, "maxv": 1},
+           {"name": "EnsureChannelFirstd", "keys": ["image", "label"]},
+           {"name": "Resized", "keys": ["image", "label"], "spatial_size": [128, 128], "mode": "bilinear"},
+           {"name": "RandFlipd", "keys": ["image", "label"], "prob": 0.5, "spatial_axis": [0, 1]},
+           {"name": "RandRotate90d", "keys": ["image", "label"], "prob": 0.75},
+           {"name": "RandRotated", "keys": ["image", "label"], "prob": 1, "range_x": 0.1745, "padding_mode": "zeros"},
+           {"name": "AsDiscreted", "keys": ["label"], "threshold": 0.1},
+           {"name": "CastToTyped", "keys": ["image", "label"], "dtype": "dtype"}]
+    aug = gpu_augment.GpuSegAugmentation(cfg, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    img = torch.randint(0, 256, (6, 32, 32), device="cuda", generator=g, dtype=torch.uint8)
+    lab = (torch.rand(6, 128, 128, device="cuda", generator=g) > 0.7).to(torch.uint8) * 255
+    out = aug(img, lab)
+    assert out["image"].shape == (6, 1, 128, 128) and out["label"].shape == (6, 1, 128, 128)
+    assert out["image"].dtype == torch.float32 and 0.0 <= float(out["image"].min()) and float(out["image"].max()) <= 1.0 + 1e-6
+    assert set(out["label"].unique().tolist()) <= {0.0, 1.0}
+    p = out["params"]
+    assert p["rot_k"].max() <= 3 and np.abs(p["angle"]).max() <= 0.1745 + 1e-6
+    # same seed -> same decisions
+    again = gpu_augment.GpuSegAugmentation(cfg, seed=3)(img, lab)
+    assert torch.equal(again["image"], out["image"]) and torch.equal(again["label"], out["label"])
