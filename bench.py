@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary U-Net training measurement")
     ap.add_argument("--train-batch", type=int, default=4)
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the on-the-fly generation + training measurement")
     args = ap.parse_args()
 
     import torch
@@ -195,6 +196,12 @@ def main():
         gens = []
         torch.cuda.empty_cache()
         train_info = unet_train_bench(dev, args.train_batch, dist, world)
+    # BASELINE.json configs[4]: on-the-fly simulation + rasterisation + GPU augmentation feeding the same training step
+    e2e_info = None
+    if not args.no_train and not args.no_end_to_end:
+        import train_synthetic
+        torch.cuda.empty_cache()
+        e2e_info = train_synthetic.run(steps=60, batch=args.train_batch, gen_batch=128, seed0=500000, log=False)
 
     dt = sharding.max_over_ranks(dt, dist, dev)
 
@@ -233,6 +240,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         line["unet_train"] = train_info
+        line["end_to_end_train"] = e2e_info
         print(json.dumps(line))
     for g_ in gens:
         g_.close()

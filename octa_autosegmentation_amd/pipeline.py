@@ -17,7 +17,7 @@ from .vessel_graph_generation import greenhouse, tree2img
 
 
 class TripleGenerator:
-    def __init__(self, config, batch, device_index=None, label_resolution=(1216, 1216)):
+    def __init__(self, config, batch, device_index=None, label_resolution=(1216, 1216), label_min_radius=0.0):
         import torch
         self.config = config
         self.batch = int(batch)
@@ -30,6 +30,8 @@ class TripleGenerator:
         self.proj_axis = int(o.get("proj_axis", 2))
         self.image_res = [v for i, v in enumerate(vol) if i != self.proj_axis]     # :81-82
         self.label_res = list(label_resolution)
+        # the training configs render the label with min_radius[1] = 0.0033 (configs/config_ves_seg-S.yml:38)
+        self.label_min_radius = float(label_min_radius)
 
     def close(self):
         self.sim.close()
@@ -59,7 +61,7 @@ class TripleGenerator:
         out = dict(result=res, image=image)
         if want_label:
             d_rb = graph_io.edges_as_read_back_device(d_edges)
-            grey = tree2img.rasterize_edges_device(d_rb, off, self.label_res, 2)
+            grey = tree2img.rasterize_edges_device(d_rb, off, self.label_res, 2, min_radius=self.label_min_radius)
             out["label_grey"] = grey
             out["label"] = tree2img.binarize_label_device(grey)
         return out

@@ -91,3 +91,10 @@ def test_three_steps_in_flight_are_independent(hip_lib_built):
                 assert (label[k] == octa_oracle.fs_dither(grey)).all()
     for gen in gens:
         gen.close()
+
+
+def test_on_the_fly_training_runs(hip_lib_built):
+    """train_synthetic.py: generator thread (simulate + rasterise) -> GPU augmentation -> training step, a few steps."""
+    import train_synthetic
+    res = train_synthetic.run(steps=4, batch=2, gen_batch=8, warmup=1, log=False)
+    assert res["value"] > 0 and np.isfinite(res["last_loss"]) and res["n_gpus"] == 1

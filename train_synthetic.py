@@ -1,0 +1,129 @@
+"""On-the-fly training: HIP vessel simulation -> rasterisation -> GPU augmentation -> U-Net step, all on one MI355X.
+
+This is BASELINE.json configs[4] for the segmentation network ("on-the-fly HIP vessel simulation feeding training, overlapped
+gen/compute"): instead of the reference's loader (CSV graphs on disk, `LoadGraphAndFilterByRandomRadiusd` + MONAI transforms in
+CPU workers, configs/config_ves_seg-S.yml:28-102, train.py:29-203) a generator thread keeps simulating seeded samples in
+small batches on its own HIP stream and hands uint8 image / label batches over in HBM; the training thread applies the
+config's augmentation list on the GPU (data/gpu_augment.py) and runs the training step (models/segmentation_trainer.py).
+Multi-GPU: launch with torch.distributed.run -- every rank generates and trains on its own seeds, gradients are
+all-reduced with RCCL (the trainer's flat all-reduce).
+
+  python train_synthetic.py --steps 50 --batch 4 --gen-batch 128
+"""
+import argparse
+import json
+import os
+import queue
+import sys
+import threading
+import time
+
+import numpy as np
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEG_CONFIG = {   # configs/config_ves_seg-S.yml, the parts this script uses
+    "General": {"amp": True, "model": {"name": "DynUNet", "spatial_dims": 2, "in_channels": 1, "out_channels": 1,
+                                       "kernel_size": [3, 3, 3, 3, 3], "strides": [1, 2, 2, 2, 1], "upsample_kernel_size": [1, 2, 2, 2, 1]}},
+    "Train": {"lr": 1e-4, "loss": "DiceBCELoss", "epochs": 30, "epochs_decay": 10, "batch_size": 4,
+              "data_augmentation": [
+                  {"name": "LoadGraphAndFilterByRandomRadiusd", "keys": ["image", "label"], "image_resolutions": [[304, 304], [1216, 1216]],
+                   "min_radius": [0, 0.0033], "max_dropout_prob": 0},
+                  {"name": "ScaleIntensityd", "keys": ["image", "label"], "minv": 0, "maxv": 1},
+                  {"name": "EnsureChannelFirstd", "keys": ["image", "label"], "strict_check": False, "channel_dim": "no_channel"},
+                  {"name": "Resized", "keys": ["image", "label"], "spatial_size": [1216, 1216], "mode": "bilinear"},
+                  {"name": "RandFlipd", "keys": ["image", "label"], "prob": 0.5, "spatial_axis": [0, 1]},
+                  {"name": "RandRotate90d", "keys": ["image", "label"], "prob": 0.75},
+                  {"name": "RandRotated", "keys": ["image", "label"], "prob": 1, "range_x": 0.17453292519943295, "padding_mode": "zeros"},
+                  {"name": "AsDiscreted", "keys": ["label"], "threshold": 0.1},
+                  {"name": "CastToTyped", "keys": ["image", "label"], "dtype": "dtype"}]},
+}
+
+
+def load_sim_config():
+    import yaml
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
+    return yaml.safe_load(str(g["config_yaml"]))
+
+
+def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True):
+    import torch
+    import torch.distributed as dist
+    from octa_autosegmentation_amd import pipeline
+    from octa_autosegmentation_amd.data.gpu_augment import GpuSegAugmentation
+    from octa_autosegmentation_amd.models.segmentation_trainer import SegmentationTrainer
+    from octa_autosegmentation_amd.utils import sharding
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend="nccl", device_id=dev)
+    aug_cfg = SEG_CONFIG["Train"]["data_augmentation"]
+    loader = aug_cfg[0]
+    gen = pipeline.TripleGenerator(load_sim_config(), gen_batch, label_resolution=loader["image_resolutions"][1],
+                                   label_min_radius=loader["min_radius"][1])
+    aug = GpuSegAugmentation(aug_cfg, seed=1234 + rank)
+    trainer = SegmentationTrainer(SEG_CONFIG, dev)
+    q = queue.Queue(maxsize=2)
+    stop = threading.Event()
+    gen_stream = torch.cuda.Stream()
+
+    def produce():
+        torch.cuda.set_device(dev)
+        i = 0
+        with torch.cuda.stream(gen_stream):
+            while not stop.is_set():
+                out = gen.generate(sharding.rank_seeds(rank, i, gen_batch, base=seed0))
+                gen_stream.synchronize()
+                item = (out["image"], out["label_grey"])
+                while not stop.is_set():
+                    try:
+                        q.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        pass
+                i += 1
+
+    th = threading.Thread(target=produce, daemon=True)
+    th.start()
+    images = labels = None
+    pos = 0
+    losses = []
+    t0 = None
+    for step in range(warmup + steps):
+        if step == warmup:
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.time()
+        if images is None or pos + batch > images.shape[0]:
+            images, labels = q.get()
+            pos = 0
+        mb = aug(images[pos:pos + batch].contiguous(), labels[pos:pos + batch].contiguous())
+        pos += batch
+        _, l = trainer.perform_training_step({"image": mb["image"], "label": mb["label"]})
+        losses.append(l[trainer.loss_name])
+    torch.cuda.synchronize()
+    dt = sharding.max_over_ranks(time.time() - t0, dist if world > 1 else None, dev)
+    stop.set()
+    th.join(timeout=30)
+    gen.close()
+    res = {"metric": "end-to-end on-the-fly training imgs/s (simulate + rasterise + augment + DynUNet-S step @1216^2)",
+           "value": world * batch * steps / dt, "unit": "imgs/s", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "batch_per_gpu": batch, "generator_batch": gen_batch, "first_loss": float(losses[0]), "last_loss": float(losses[-1])}
+    if log and rank == 0:
+        print(json.dumps(res))
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--gen-batch", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    run(a.steps, a.batch, a.gen_batch, warmup=a.warmup)
