@@ -232,6 +232,14 @@ int octa_resize_bilinear(octa_ctx *ctx, const void *d_in, int in_dtype, int B, i
 int octa_flip_rot90_rotate(octa_ctx *ctx, const float *d_in, float *d_out, int B, int N, const float *d_angle, const int *d_rot_k,
                            const int *d_flip, float threshold, int use_threshold, void *stream);
 
+/* ---- inference post-processing --------------------
+ * RemoveSmallObjects(min_size) of the configs' post_processing lists (configs/config_ves_seg-S.yml:103-113; MONAI ->
+ * skimage.morphology.remove_small_objects) for a batch of masks in HBM: d_in uint8 [B][H][W] (non-zero = foreground);
+ * every connected component (connectivity 1 = 4-neighbourhood, 2 = 8-neighbourhood) with fewer than min_size pixels is
+ * removed; d_out uint8 [B][H][W] gets on_value on the surviving pixels, 0 elsewhere (may alias d_in). */
+int octa_remove_small_objects(octa_ctx *ctx, const uint8_t *d_in, int B, int H, int W, int min_size, int connectivity,
+                              uint8_t on_value, uint8_t *d_out, void *stream);
+
 /* ---- N1-N4: space-colonisation vessel-graph simulator --------------------
  * Replaces, for B independent samples advanced in lock-step on the GPU:
  *   vessel_graph_generation/greenhouse.py:57-137 (Greenhouse.develop_forest) with
