@@ -232,6 +232,15 @@ int octa_resize_bilinear(octa_ctx *ctx, const void *d_in, int in_dtype, int B, i
 int octa_flip_rot90_rotate(octa_ctx *ctx, const float *d_in, float *d_out, int B, int N, const float *d_angle, const int *d_rot_k,
                            const int *d_flip, float threshold, int use_threshold, void *stream);
 
+/* ---- DiceBCELoss in one pass each way --------------------
+ * utils/losses.py:111-121: (DiceLoss(sigmoid=True) + BCEWithLogitsLoss) / 2 over logits [B][n] (dtype 0 = float32,
+ * 1 = bfloat16) and float32 labels [B][n]. Forward fills d_sums double[B][4] = (sum p*y, sum p, sum y, sum bce), p =
+ * sigmoid(logit); the scalar is dice = mean_b(1 - (2 S_py + nr) / (S_p + S_y + dr)), bce = sum_b S_bce / (B n), loss =
+ * (dice + bce) / 2. Backward writes dloss/dlogits (same dtype as the logits) scaled by d_grad_out[0]. */
+int octa_dice_bce_fwd(octa_ctx *ctx, const void *d_logits, int dtype, const float *d_y, int B, int64_t n, double *d_sums, void *stream);
+int octa_dice_bce_bwd(octa_ctx *ctx, const void *d_logits, int dtype, const float *d_y, int B, int64_t n, const double *d_sums,
+                      const float *d_grad_out, float smooth_nr, float smooth_dr, void *d_dlogits, void *stream);
+
 /* ---- inference post-processing --------------------
  * RemoveSmallObjects(min_size) of the configs' post_processing lists (configs/config_ves_seg-S.yml:103-113; MONAI ->
  * skimage.morphology.remove_small_objects) for a batch of masks in HBM: d_in uint8 [B][H][W] (non-zero = foreground);

@@ -55,3 +55,28 @@ def test_fused_instnorm_lrelu_matches_torch(dtype):
         assert torch.allclose(gx.double(), x2.grad, atol=tol, rtol=tol), (shape, float((gx.double() - x2.grad).abs().max()))
         assert torch.allclose(gw.double(), w2.grad, atol=tol * 50, rtol=tol), float((gw.double() - w2.grad).abs().max())
         assert torch.allclose(gb.double(), b2.grad, atol=tol * 50, rtol=tol)
+
+
+def test_fused_dice_bce_matches_torch():
+    """csrc/loss.hip against the torch composition of the same loss (fp32): value to 1e-6, gradient to 1e-6 relative."""
+    from octa_autosegmentation_amd.models import losses
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = (torch.randn(3, 1, 157, 201, device="cuda", generator=g) * 3).requires_grad_(True)
+    y = (torch.rand(3, 1, 157, 201, device="cuda", generator=g) > 0.8).float()
+    loss = losses.DiceBCELoss(True)
+    losses.USE_FUSED_LOSS = False
+    try:
+        ref = loss(x, y)
+        ref.backward()
+        gref = x.grad.clone()
+    finally:
+        losses.USE_FUSED_LOSS = True
+    x.grad = None
+    got = loss(x, y)
+    got.backward()
+    assert abs(float(got) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert (x.grad - gref).abs().max().item() <= 1e-6 * gref.abs().max().item() + 1e-12
+    xb = x.detach().to(torch.bfloat16).requires_grad_(True)      # bf16 logits straight from the network
+    gb = loss(xb, y)
+    gb.backward()
+    assert abs(float(gb) - float(loss(xb.detach().float(), y))) <= 1e-5 and xb.grad.dtype == torch.bfloat16
