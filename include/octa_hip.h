@@ -232,6 +232,12 @@ int octa_resize_bilinear(octa_ctx *ctx, const void *d_in, int in_dtype, int B, i
 int octa_flip_rot90_rotate(octa_ctx *ctx, const float *d_in, float *d_out, int B, int N, const float *d_angle, const int *d_rot_k,
                            const int *d_flip, float threshold, int use_threshold, void *stream);
 
+/* First layer of the U-Net (UnetBasicBlock.conv1 of the input block: ONE input channel -> Cout in {8, 16, 32, 64}, 3x3,
+ * padding 1, stride 1): d_x [N][H][W] bf16, d_w float32 [Cout][9] (tap = 3r + s), d_y [N][H][W][Cout] bf16; the weight
+ * gradient d_dw float32 [Cout][9] (overwritten). Streaming kernels: 9 multiply-adds per output are not matrix-core work. */
+int octa_conv3x3_c1_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, void *d_y, int N, int H, int W, int Cout, void *stream);
+int octa_conv3x3_c1_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cout, void *stream);
+
 /* ---- DiceBCELoss in one pass each way --------------------
  * utils/losses.py:111-121: (DiceLoss(sigmoid=True) + BCEWithLogitsLoss) / 2 over logits [B][n] (dtype 0 = float32,
  * 1 = bfloat16) and float32 labels [B][n]. Forward fills d_sums double[B][4] = (sum p*y, sum p, sum y, sum bce), p =

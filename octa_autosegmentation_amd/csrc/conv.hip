@@ -689,3 +689,119 @@ extern "C" int octa_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---- first layer: ONE input channel (the grey image) -> Cout channels, 3x3, padding 1, stride 1 ------------------------
+// 9 multiply-adds per output value: not matrix-core work. A thread owns 8 output channels of one pixel (one 16-byte store);
+// forward and weight gradient are single streaming passes over the Cout-channel tensor (HBM-bound), instead of padding the
+// image to 32 zero channels for the MFMA kernels.
+namespace {
+
+__device__ __forceinline__ float bfu(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+__global__ void __launch_bounds__(256)
+conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restrict__ Wf /* [Cout][9] */, unsigned short *__restrict__ Y,
+                      int N, int H, int W, int Cout) {
+    extern __shared__ float s_wf[];   // [Cout][9]
+    for (int i = threadIdx.x; i < Cout * 9; i += 256) s_wf[i] = Wf[i];
+    __syncthreads();
+    const int groups = Cout / 8, gshift = 31 - __clz(groups);   // groups is a power of two: no integer divisions per item
+    for (int row = blockIdx.x; row < N * H; row += gridDim.x)
+    for (int j = threadIdx.x; j < W * groups; j += 256) {
+        const int q = j & (groups - 1), x = j >> gshift, y = row % H;
+        const long n = row / H, p = (long)row * W + x;
+        float in[9];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                const int yy = y + r - 1, xx = x + s - 1;
+                in[3 * r + s] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
+            }
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; t++) { a0 += in[t] * s_wf[(q * 8 + 2 * k) * 9 + t]; a1 += in[t] * s_wf[(q * 8 + 2 * k + 1) * 9 + t]; }
+            o[k] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+        }
+        *reinterpret_cast<uint4 *>(Y + p * Cout + q * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+conv3x3_c1_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ dY, float *__restrict__ dW /* [Cout][9] */,
+                        int N, int H, int W, int Cout) {
+    extern __shared__ float s_acc[];  // [Cout][9]
+    for (int i = threadIdx.x; i < Cout * 9; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    const int groups = Cout / 8, gshift = 31 - __clz(groups);
+    float acc[8][9];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) acc[k][t] = 0.f;
+    // 256 is a multiple of `groups`, so a thread keeps its channel group q for the whole loop
+    const int q = threadIdx.x & (groups - 1);
+    for (int row = blockIdx.x; row < N * H; row += gridDim.x)
+    for (int j = threadIdx.x; j < W * groups; j += 256) {
+        const int x = j >> gshift, y = row % H;
+        const long n = row / H, p = (long)row * W + x;
+        const uint4 v = *reinterpret_cast<const uint4 *>(dY + p * Cout + q * 8);
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+        float d[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { d[2 * k] = __uint_as_float(u[k] << 16); d[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                const int yy = y + r - 1, xx = x + s - 1;
+                const float in = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc[k][3 * r + s] += d[k] * in;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            float a = acc[k][t];
+            // lanes with the same channel group: lane % groups (groups divides 64 for Cout in {8, 16, 32, 64})
+            for (int dlt = groups; dlt < 64; dlt <<= 1) a += __shfl_xor(a, dlt, 64);
+            if ((int)(threadIdx.x & 63) < groups) atomicAdd(&s_acc[(q * 8 + k) * 9 + t], a);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cout * 9; i += 256) atomicAdd(&dW[i], s_acc[i]);
+}
+
+}  // namespace
+
+extern "C" int octa_conv3x3_c1_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, void *d_y, int N, int H, int W, int Cout, void *stream_) {
+    if (!ctx || !d_x || !d_w || !d_y || N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_c1_fwd: bad arguments"); return -2; }
+    if (Cout != 8 && Cout != 16 && Cout != 32 && Cout != 64) { octa::set_error("octa_conv3x3_c1_fwd: Cout must be 8, 16, 32 or 64"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    long blocks = (long)N * H;
+    if (blocks > 32L * ctx->num_cus) blocks = 32L * ctx->num_cus;
+    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * Cout * 9, stream, static_cast<const unsigned short *>(d_x),
+                       d_w, static_cast<unsigned short *>(d_y), N, H, W, Cout);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_conv3x3_c1_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cout, void *stream_) {
+    if (!ctx || !d_x || !d_dy || !d_dw || N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_c1_wgrad: bad arguments"); return -2; }
+    if (Cout != 8 && Cout != 16 && Cout != 32 && Cout != 64) { octa::set_error("octa_conv3x3_c1_wgrad: Cout must be 8, 16, 32 or 64"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * Cout * 9, stream));
+    const int groups = Cout / 8;
+    long blocks = 8L * ctx->num_cus;
+    if (blocks > (long)N * H) blocks = (long)N * H;
+    (void)groups;   // gridDim.x * 256 is a multiple of `groups` for any block count (256 % groups == 0)
+    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * Cout * 9, stream, static_cast<const unsigned short *>(d_x),
+                       static_cast<const unsigned short *>(d_dy), d_dw, N, H, W, Cout);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -197,7 +197,42 @@ class _Conv3x3NHWC(torch.autograd.Function):
         return dx, dw, None, None
 
 
+class _Conv3x3C1(torch.autograd.Function):
+    """First layer: one input channel (no data gradient: the input is the image)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        n, h, w, _ = x.shape
+        cout = weight.shape[0]
+        wf = weight.reshape(cout, 9).float().contiguous()
+        y = torch.empty((n, h, w, cout), dtype=torch.bfloat16, device=x.device)
+        rc = _native.lib().octa_conv3x3_c1_fwd(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wf.data_ptr()),
+                                               ctypes.c_void_p(y.data_ptr()), n, h, w, cout, _native.current_stream_ptr())
+        _native.check(rc, "octa_conv3x3_c1_fwd")
+        ctx.save_for_backward(x)
+        ctx.w_shape, ctx.w_dtype = weight.shape, weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        n, h, w, _ = x.shape
+        cout = dy.shape[3]
+        dw = torch.empty((cout, 9), dtype=torch.float32, device=x.device)
+        rc = _native.lib().octa_conv3x3_c1_wgrad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
+                                                 ctypes.c_void_p(dw.data_ptr()), n, h, w, cout, _native.current_stream_ptr())
+        _native.check(rc, "octa_conv3x3_c1_wgrad")
+        return None, dw.view(ctx.w_shape).to(ctx.w_dtype)
+
+
 def conv3x3(x, weight, stride=1, want_stats=False):
+    if (x.shape[-1] == 1 and weight.shape[1] == 1 and stride == 1 and not want_stats and weight.shape[0] in (8, 16, 32, 64)
+            and not x.requires_grad):
+        return _Conv3x3C1.apply(x, weight)
     """want_stats: also return the per-tile statistics for instance_norm_leaky_relu_nhwc(..., partials=)."""
     return _Conv3x3NHWC.apply(x, weight, stride, want_stats)
 
