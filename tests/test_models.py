@@ -149,3 +149,32 @@ def test_convt_as_gemm_matches_conv_transpose():
         y2 = m(x); y2.sum().backward()
         networks.FAST_CONVT = True
         assert torch.allclose(y, y2, atol=1e-5) and torch.allclose(g1, x.grad, atol=1e-5) and torch.allclose(gw1, m.conv.weight.grad, atol=1e-4)
+
+
+def test_checkpoint_files_round_trip_and_metrics_csv(tmp_path):
+    """File names, dict keys and resume order of the reference's trainer."""
+    from octa_autosegmentation_amd.models.segmentation_trainer import SegmentationTrainer
+    from octa_autosegmentation_amd.utils import checkpoints
+    torch.manual_seed(0)
+    a = SegmentationTrainer(CFG, "cpu", channels_last=False)
+    x = torch.rand(1, 1, 32, 32); y = (torch.rand(1, 1, 32, 32) > 0.5).float()
+    a.perform_training_step({"image": x, "label": y})
+    d = str(tmp_path)
+    files = checkpoints.save_epoch(d, a, 9, CFG, save_interval=10, save_best=True)
+    names = sorted(os.listdir(os.path.join(d, "checkpoints")))
+    assert names == sorted(f"{p}_{n}_model.pth" for p in ("latest", "10", "best") for n in ("optimizer", "model"))
+    ck = torch.load(files[-1], weights_only=False)
+    assert set(ck) == {"epoch", "model", "optimizer", "config"} and ck["epoch"] == 10 and ck["optimizer"] is None
+    assert any(k.startswith("skip_layers.") for k in ck["model"])            # MONAI's aliased keys are present
+    torch.manual_seed(1)
+    b = SegmentationTrainer(CFG, "cpu", channels_last=False)
+    assert checkpoints.load_checkpoint(b, os.path.join(d, "checkpoints", "latest_model.pth")) == 10
+    for (k, v), (_, w) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert torch.equal(v, w), k
+    assert b.optimizer.state_dict()["state"][0]["step"] == a.optimizer.state_dict()["state"][0]["step"]
+    log = checkpoints.MetricsLog(d, CFG)
+    log.append(0, {"loss": {"train_loss": 0.5, "val_loss": 0.6}, "metric": {"val_DSC": 0.7}})
+    log.append(1, {"loss": {"train_loss": 0.4, "val_loss": 0.5}, "metric": {"val_DSC": 0.8}})
+    rows = open(os.path.join(d, "metrics.csv")).read().splitlines()
+    assert rows[0] == "epoch,train_loss,val_loss,val_DSC" and rows[2] == "1,0.4,0.5,0.8"
+    assert os.path.exists(os.path.join(d, "config.yml"))
