@@ -182,13 +182,18 @@ class _Conv3x3NHWC(torch.autograd.Function):
         cin, st = ctx.cin, ctx.stride
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            assert xp.shape[-1] == cin, "data gradient of a channel-padded input is not needed by the U-Net"
             if st == 2:
                 assert xp.shape[1] % 2 == 0 and xp.shape[2] % 2 == 0, "stride-2 layers need even input sizes"
+            wd = weight
+            if xp.shape[-1] != cin:   # channel-padded input (the GAN trains the generator THROUGH the segmentor's first layer)
+                wd = weight.new_zeros((weight.shape[0], xp.shape[-1], 3, 3))
+                wd[:, :cin] = weight
             if st == 2 and USE_PARITY_SCATTER:
-                dx = conv3x3_s2_dgrad(dy, weight)
+                dx = conv3x3_s2_dgrad(dy, wd)
             else:
-                dx = conv3x3_nhwc(dy, pack_weight_dgrad(weight), stride=1, in_dilation=st)
+                dx = conv3x3_nhwc(dy, pack_weight_dgrad(wd), stride=1, in_dilation=st)
+            if xp.shape[-1] != cin:
+                dx = dx[..., :cin].contiguous()
         if ctx.needs_input_grad[1]:
             if st == 1:
                 dw = conv3x3_nhwc_wgrad(xp, dy)[:, :cin].to(weight.dtype)

@@ -80,3 +80,23 @@ def test_fused_dice_bce_matches_torch():
     gb = loss(xb, y)
     gb.backward()
     assert abs(float(gb) - float(loss(xb.detach().float(), y))) <= 1e-5 and xb.grad.dtype == torch.bfloat16
+
+
+def test_gan_seg_step_on_gpu_trains_generator_through_mfma_segmentor():
+    """configs[3]: the GAN-seg step under bf16 autocast; the generator's gradient flows through the segmentor's first
+    (channel-padded) layer on the MFMA path."""
+    from tests.test_models import CFG
+    from octa_autosegmentation_amd.models.gan_seg_trainer import GanSegTrainer
+    cfg = {"General": {"amp": True, "model": {"name": "GanSegModel", "model_g": {"name": "resnetGenerator9"},
+                                                "model_d": {"name": "patchGAN70x70"},
+                                                "model_s": dict(CFG["General"]["model"]), "upshape": (128, 128)}},
+           "Train": {"lr": 2e-4, "loss_dg": "LSGANLoss", "loss_s": "DiceBCELoss"}}
+    torch.manual_seed(0)
+    tr = GanSegTrainer(cfg, "cuda")
+    batch = {"real_A": torch.rand(2, 1, 64, 64), "real_B": torch.rand(2, 1, 64, 64), "real_A_seg": (torch.rand(2, 1, 128, 128) > 0.7).float()}
+    g0 = [p.detach().clone() for p in tr.generator.parameters()][0]
+    for _ in range(2):
+        out, losses = tr.perform_training_step(batch)
+    assert all(torch.isfinite(v) for v in losses.values())
+    assert not torch.equal(g0, [p for p in tr.generator.parameters()][0])
+    assert out["prediction"].shape == (1, 1, 128, 128)
