@@ -328,8 +328,50 @@ class ResnetGenerator(nn.Module):
         m += [nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, 7), nn.Sigmoid()]
         self.model = nn.Sequential(*m)
 
+    # ---- residual blocks channels-last in bf16 on the MFMA convolution (csrc/conv.hip) --------------------------------
+    # ReflectionPad2d(1) + Conv2d(3, padding 0) = the zero-padded kernel on the reflect-padded tensor, cropped by one pixel.
+    # The convolution bias is followed by InstanceNorm WITHOUT affine, which subtracts it again: it is not added here (its
+    # gradient is identically zero in the reference too).
+    _pad_idx = {}
+
+    @classmethod
+    def _reflect_pad1(cls, x):
+        n, h, w, c = x.shape
+        key = (h, w, str(x.device))
+        if key not in cls._pad_idx:
+            ih = torch.tensor([1, *range(h), h - 2], device=x.device)
+            iw = torch.tensor([1, *range(w), w - 2], device=x.device)
+            cls._pad_idx[key] = (ih, iw)
+        ih, iw = cls._pad_idx[key]
+        return x.index_select(1, ih).index_select(2, iw)
+
+    @classmethod
+    def _resblock_nhwc(cls, blk, x):
+        from . import mfma_conv as mc
+        c1, n1, c2, n2 = blk.conv_block[1], blk.conv_block[2], blk.conv_block[5], blk.conv_block[6]
+        h = mc.conv3x3(cls._reflect_pad1(x), c1.weight, 1)[:, 1:-1, 1:-1, :]
+        h = mc.instance_norm_leaky_relu_nhwc(h, None, None, 0.0, n1.eps)          # InstanceNorm + ReLU
+        h = mc.conv3x3(cls._reflect_pad1(h), c2.weight, 1)[:, 1:-1, 1:-1, :]
+        h = mc.instance_norm_leaky_relu_nhwc(h, None, None, 1.0, n2.eps)          # InstanceNorm, no activation
+        return x + h
+
     def forward(self, x):
-        return self.model(x)
+        use_mfma = (USE_MFMA_CONV and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+        if not use_mfma:
+            return self.model(x)
+        mods = list(self.model)
+        i = 0
+        while i < len(mods):
+            if isinstance(mods[i], ResnetBlock) and mods[i].conv_block[1].in_channels % 32 == 0:
+                y = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+                while i < len(mods) and isinstance(mods[i], ResnetBlock):
+                    y = self._resblock_nhwc(mods[i], y)
+                    i += 1
+                x = y.permute(0, 3, 1, 2).contiguous()
+            else:
+                x = mods[i](x)
+                i += 1
+        return x
 
 
 class NLayerDiscriminator(nn.Module):

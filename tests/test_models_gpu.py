@@ -100,3 +100,28 @@ def test_gan_seg_step_on_gpu_trains_generator_through_mfma_segmentor():
     assert all(torch.isfinite(v) for v in losses.values())
     assert not torch.equal(g0, [p for p in tr.generator.parameters()][0])
     assert out["prediction"].shape == (1, 1, 128, 128)
+
+
+def test_resnet_generator_mfma_blocks_match_torch_autocast():
+    """ResNet-9 generator: residual blocks on the MFMA path vs the torch modules, both under bf16 autocast."""
+    from octa_autosegmentation_amd.models import networks
+    torch.manual_seed(2)
+    g = networks.resnetGenerator9().cuda()
+    networks.init_weights(g, "kaiming", nonlinearity="relu")
+    x = torch.rand(2, 1, 64, 64, device="cuda")
+    outs, grads = [], []
+    for mfma in (False, True):
+        networks.USE_MFMA_CONV = mfma
+        try:
+            g.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = g(x)
+            y.float().mean().backward()
+            outs.append(y.float().detach())
+            grads.append(g.model[1].weight.grad.float().clone())     # stem weight: gradient through all nine blocks
+        finally:
+            networks.USE_MFMA_CONV = True
+    ref32 = None
+    assert (outs[0] - outs[1]).abs().max().item() < 0.06              # sigmoid outputs in [0, 1], bf16 through 9 blocks
+    cos = torch.dot(grads[0].flatten(), grads[1].flatten()) / (grads[0].norm() * grads[1].norm())
+    assert cos.item() > 0.9
