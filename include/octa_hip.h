@@ -247,6 +247,24 @@ int octa_dice_bce_fwd(octa_ctx *ctx, const void *d_logits, int dtype, const floa
 int octa_dice_bce_bwd(octa_ctx *ctx, const void *d_logits, int dtype, const float *d_y, int B, int64_t n, const double *d_sums,
                       const float *d_grad_out, float smooth_nr, float smooth_dr, void *d_dlogits, void *stream);
 
+/* ---- anti-aliased resampling and reflection pad of the GAN networks ----
+ * Replace models/networks.py:244-262 (Upsample: ReplicationPad2d(1) + depth-wise conv_transpose2d with the
+ * [1 3 3 1]^2/64*4 filter, stride 2, crop), :264-289 (Downsample: ReflectionPad2d(1) + depth-wise conv2d with the
+ * [1 2 1]^2/16 filter, stride 2) and the nn.ReflectionPad2d(pad) of ResnetBlock / ResnetGenerator (:366-368, :404-421),
+ * each as one streaming kernel per direction. Tensors are planes [B][H][W][C], C innermost: an NCHW tensor is passed as
+ * B*C planes with C = 1, an NHWC tensor as it is. dtype 0 = float32, 1 = bfloat16 (fp32 arithmetic, one rounding).
+ * H, W, C always describe the UNPADDED / LARGER-INPUT side named below; _bwd takes the gradient of the forward's
+ * output in d_in and writes the gradient of the forward's input to d_out (gather form, deterministic).
+ *   reflect_pad : [B][H][W][C] -> [B][H+2pad][W+2pad][C], 1 <= pad < min(H, W)
+ *   blur_down   : [B][H][W][C] -> [B][(H-1)/2+1][(W-1)/2+1][C]
+ *   blur_up     : [B][H][W][C] -> [B][2H][2W][C] */
+int octa_reflect_pad_fwd(octa_ctx *ctx, const void *d_in, void *d_out, int dtype, int B, int H, int W, int C, int pad, void *stream);
+int octa_reflect_pad_bwd(octa_ctx *ctx, const void *d_in, void *d_out, int dtype, int B, int H, int W, int C, int pad, void *stream);
+int octa_blur_down_fwd(octa_ctx *ctx, const void *d_in, void *d_out, int dtype, int B, int H, int W, int C, void *stream);
+int octa_blur_down_bwd(octa_ctx *ctx, const void *d_in, void *d_out, int dtype, int B, int H, int W, int C, void *stream);
+int octa_blur_up_fwd(octa_ctx *ctx, const void *d_in, void *d_out, int dtype, int B, int H, int W, int C, void *stream);
+int octa_blur_up_bwd(octa_ctx *ctx, const void *d_in, void *d_out, int dtype, int B, int H, int W, int C, void *stream);
+
 /* ---- inference post-processing --------------------
  * RemoveSmallObjects(min_size) of the configs' post_processing lists (configs/config_ves_seg-S.yml:103-113; MONAI ->
  * skimage.morphology.remove_small_objects) for a batch of masks in HBM: d_in uint8 [B][H][W] (non-zero = foreground);

@@ -16,6 +16,8 @@ from typing import Sequence
 import torch
 import torch.nn as nn
 
+from . import resample
+
 
 # CUDA tensors go through the fused HIP InstanceNorm+LeakyReLU kernels (csrc/norm.hip); set to False to run the
 # plain torch modules (used by the parity tests as the reference).
@@ -189,7 +191,7 @@ class DynUNet(nn.Module):
             return False
         # bf16 arithmetic only where the caller asked for it (bf16 input or bf16 autocast, as the trainers do);
         # fp32 inputs keep the fp32 modules (logits within 1e-4 of the CPU reference)
-        if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)):
+        if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)):
             return False
         blocks = [self.input_block, *self.downsamples, self.bottleneck, *[u.conv_block for u in self.upsamples]]
         for b in blocks:
@@ -275,10 +277,13 @@ class Downsample(nn.Module):
         super().__init__()
         lo, hi = int((filt_size - 1) / 2), int(-(-(filt_size - 1) // 2))
         self.pad = nn.ReflectionPad2d([lo, hi, lo, hi])
-        self.stride, self.channels = stride, channels
+        self.stride, self.channels, self.filt_size = stride, channels, filt_size
         self.register_buffer("filt", _blur_kernel(filt_size)[None, None].repeat(channels, 1, 1, 1))
 
-    def forward(self, x):
+    def forward(self, x, layout="nchw"):
+        if x.is_cuda and self.filt_size == 3 and self.stride == 2:
+            return resample.blur_down(x, layout)        # one streaming HIP kernel per direction (csrc/blur.hip)
+        assert layout == "nchw"
         return nn.functional.conv2d(self.pad(x), self.filt, stride=self.stride, groups=x.shape[1])
 
 
@@ -289,22 +294,35 @@ class Upsample(nn.Module):
         super().__init__()
         self.odd = filt_size % 2 == 1
         self.pad_size = int((filt_size - 1) / 2)
-        self.stride = stride
+        self.stride, self.filt_size = stride, filt_size
         self.pad = nn.ReplicationPad2d([1, 1, 1, 1])
         self.register_buffer("filt", (_blur_kernel(filt_size) * stride ** 2)[None, None].repeat(channels, 1, 1, 1))
 
-    def forward(self, x):
+    def forward(self, x, layout="nchw"):
+        if x.is_cuda and self.filt_size == 4 and self.stride == 2:
+            return resample.blur_up(x, layout)
+        assert layout == "nchw"
         y = nn.functional.conv_transpose2d(self.pad(x), self.filt, stride=self.stride, padding=1 + self.pad_size,
                                            groups=x.shape[1])[:, :, 1:, 1:]
         return y if self.odd else y[:, :, :-1, :-1]
+
+
+class ReflectionPad2d(nn.ReflectionPad2d):
+    """nn.ReflectionPad2d whose GPU path is the gather kernels of csrc/blur.hip (torch's backward scatters with atomics)."""
+
+    def forward(self, x):
+        p = self.padding
+        if x.is_cuda and x.dim() == 4 and p[0] == p[1] == p[2] == p[3]:
+            return resample.reflect_pad(x, p[0])
+        return super().forward(x)
 
 
 class ResnetBlock(nn.Module):
     def __init__(self, dim, use_bias=True):
         super().__init__()
         inorm = lambda: nn.InstanceNorm2d(dim, affine=False, track_running_stats=False)
-        self.conv_block = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3, bias=use_bias), inorm(), nn.ReLU(True),
-                                        nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3, bias=use_bias), inorm())
+        self.conv_block = nn.Sequential(ReflectionPad2d(1), nn.Conv2d(dim, dim, 3, bias=use_bias), inorm(), nn.ReLU(True),
+                                        ReflectionPad2d(1), nn.Conv2d(dim, dim, 3, bias=use_bias), inorm())
 
     def forward(self, x):
         return x + self.conv_block(x)
@@ -317,7 +335,7 @@ class ResnetGenerator(nn.Module):
     def __init__(self, input_nc=1, output_nc=1, ngf=64, n_blocks=9):
         super().__init__()
         inorm = lambda c: nn.InstanceNorm2d(c, affine=False, track_running_stats=False)
-        m = [nn.ReflectionPad2d(3), nn.Conv2d(input_nc, ngf, 7, bias=True), inorm(ngf), nn.ReLU(True)]
+        m = [ReflectionPad2d(3), nn.Conv2d(input_nc, ngf, 7, bias=True), inorm(ngf), nn.ReLU(True)]
         for i in range(2):
             c = ngf * 2 ** i
             m += [nn.Conv2d(c, 2 * c, 3, padding=1, bias=True), inorm(2 * c), nn.ReLU(True), Downsample(2 * c)]
@@ -325,53 +343,62 @@ class ResnetGenerator(nn.Module):
         for i in range(2):
             c = ngf * 2 ** (2 - i)
             m += [Upsample(c), nn.Conv2d(c, c // 2, 3, padding=1, bias=True), inorm(c // 2), nn.ReLU(True)]
-        m += [nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, 7), nn.Sigmoid()]
+        m += [ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, 7), nn.Sigmoid()]
         self.model = nn.Sequential(*m)
 
-    # ---- residual blocks channels-last in bf16 on the MFMA convolution (csrc/conv.hip) --------------------------------
+    # ---- all 3x3 layers channels-last in bf16 on the MFMA convolution (csrc/conv.hip) ----------------------------------
     # ReflectionPad2d(1) + Conv2d(3, padding 0) = the zero-padded kernel on the reflect-padded tensor, cropped by one pixel.
-    # The convolution bias is followed by InstanceNorm WITHOUT affine, which subtracts it again: it is not added here (its
-    # gradient is identically zero in the reference too).
-    _pad_idx = {}
-
-    @classmethod
-    def _reflect_pad1(cls, x):
-        n, h, w, c = x.shape
-        key = (h, w, str(x.device))
-        if key not in cls._pad_idx:
-            ih = torch.tensor([1, *range(h), h - 2], device=x.device)
-            iw = torch.tensor([1, *range(w), w - 2], device=x.device)
-            cls._pad_idx[key] = (ih, iw)
-        ih, iw = cls._pad_idx[key]
-        return x.index_select(1, ih).index_select(2, iw)
-
-    @classmethod
-    def _resblock_nhwc(cls, blk, x):
+    # Every 3x3 convolution is followed by InstanceNorm WITHOUT affine, which subtracts the convolution bias again: it is
+    # not added here (its gradient is identically zero in the reference too).
+    @staticmethod
+    def _resblock_nhwc(blk, x):
         from . import mfma_conv as mc
         c1, n1, c2, n2 = blk.conv_block[1], blk.conv_block[2], blk.conv_block[5], blk.conv_block[6]
-        h = mc.conv3x3(cls._reflect_pad1(x), c1.weight, 1)[:, 1:-1, 1:-1, :]
+        h = mc.conv3x3(resample.reflect_pad(x, 1, "nhwc"), c1.weight, 1)[:, 1:-1, 1:-1, :]
         h = mc.instance_norm_leaky_relu_nhwc(h, None, None, 0.0, n1.eps)          # InstanceNorm + ReLU
-        h = mc.conv3x3(cls._reflect_pad1(h), c2.weight, 1)[:, 1:-1, 1:-1, :]
+        h = mc.conv3x3(resample.reflect_pad(h, 1, "nhwc"), c2.weight, 1)[:, 1:-1, 1:-1, :]
         h = mc.instance_norm_leaky_relu_nhwc(h, None, None, 1.0, n2.eps)          # InstanceNorm, no activation
         return x + h
 
+    @staticmethod
+    def _is_conv_norm_relu(mods, i):
+        """Conv2d(3x3, padding 1, stride 1) -> InstanceNorm2d(affine=False) -> ReLU with MFMA-sized channel counts."""
+        if i + 2 >= len(mods):
+            return False
+        c, n, r = mods[i], mods[i + 1], mods[i + 2]
+        return (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride == (1, 1) and c.groups == 1
+                and c.in_channels % 32 == 0 and c.out_channels % 32 == 0 and isinstance(n, nn.InstanceNorm2d) and not n.affine
+                and isinstance(r, nn.ReLU))
+
     def forward(self, x):
-        use_mfma = (USE_MFMA_CONV and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+        use_mfma = (USE_MFMA_CONV and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
         if not use_mfma:
             return self.model(x)
+        from . import mfma_conv as mc
         mods = list(self.model)
+        nhwc = False                                     # layout of x between layers
         i = 0
         while i < len(mods):
-            if isinstance(mods[i], ResnetBlock) and mods[i].conv_block[1].in_channels % 32 == 0:
-                y = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
-                while i < len(mods) and isinstance(mods[i], ResnetBlock):
-                    y = self._resblock_nhwc(mods[i], y)
-                    i += 1
-                x = y.permute(0, 3, 1, 2).contiguous()
-            else:
-                x = mods[i](x)
+            m = mods[i]
+            on_path = (self._is_conv_norm_relu(mods, i) or (isinstance(m, ResnetBlock) and m.conv_block[1].in_channels % 32 == 0)
+                       or (nhwc and isinstance(m, (Downsample, Upsample))))
+            if on_path and not nhwc:
+                x, nhwc = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), True
+            elif not on_path and nhwc:
+                x, nhwc = x.permute(0, 3, 1, 2).contiguous(), False
+            if not on_path:
+                x = m(x)
                 i += 1
-        return x
+            elif isinstance(m, ResnetBlock):
+                x = self._resblock_nhwc(m, x)
+                i += 1
+            elif isinstance(m, (Downsample, Upsample)):
+                x = m(x, "nhwc")
+                i += 1
+            else:
+                x = mc.instance_norm_leaky_relu_nhwc(mc.conv3x3(x, m.weight, 1), None, None, 0.0, mods[i + 1].eps)
+                i += 3
+        return x.permute(0, 3, 1, 2).contiguous() if nhwc else x
 
 
 class NLayerDiscriminator(nn.Module):
