@@ -1,0 +1,87 @@
+"""The GAN networks of models/networks.py (ResNet-9 generator, 70x70 PatchGAN, blur down/up-sampling) against outputs
+of the REFERENCE's models/networks.py recorded in tests/golden/networks_golden.npz (tools/make_golden_networks.py,
+SURVEY.md 8c G5): same state_dict keys and shapes, and, with the same closed-form weights and inputs, the same outputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from octa_autosegmentation_amd.models import networks
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "networks_golden.npz"))
+
+
+def fill(shape, k):        # tools/make_golden_networks.py: fill
+    n = int(np.prod(shape))
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+    v = np.sin(np.arange(n, dtype=np.float64) * (0.37 + 0.011 * k) + 0.5 * k) / np.sqrt(max(fan_in, 1))
+    return torch.from_numpy(v.astype(np.float32)).reshape(shape)
+
+
+def image(shape, k):       # tools/make_golden_networks.py: image
+    n = int(np.prod(shape))
+    v = 0.5 + 0.5 * np.sin(np.arange(n, dtype=np.float64) * 0.0137 * (k + 1) + np.arange(n, dtype=np.float64) ** 2 * 1e-7)
+    return torch.from_numpy(v.astype(np.float32)).reshape(shape)
+
+
+def build(name):
+    net = {"G": networks.resnetGenerator9, "D": networks.patchGAN70x70}[name]().eval()
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(G[f"{name}_keys"]), "state_dict keys differ from the reference's"
+    assert [",".join(map(str, t.shape)) for t in sd.values()] == list(G[f"{name}_shapes"])
+    for k, (key, t) in enumerate(sd.items()):
+        if not key.endswith("filt"):
+            sd[key] = fill(tuple(t.shape), k)
+    net.load_state_dict(sd)
+    return net
+
+
+def check(name, net, size, device, tol):
+    with torch.no_grad():
+        y = net.to(device)(image((1, 1, size, size), 1 if name == "G" else 2).to(device)).double().cpu().numpy()
+    if size == 64:
+        want = G[f"{name}_out_64"]
+        assert y.shape == want.shape
+        assert np.abs(y - want).max() <= tol
+    else:
+        assert np.abs(y[0, 0, :24, :24] - G[f"{name}_crop_304"]).max() <= tol
+        assert np.abs(y[0, 0, -24:, -24:] - G[f"{name}_crop2_304"]).max() <= tol
+    s = G[f"{name}_sum_{size}"]
+    assert abs(y.sum() - s[0]) <= tol * y.size and abs(np.abs(y).sum() - s[1]) <= tol * y.size
+
+
+@pytest.mark.parametrize("name", ["G", "D"])
+def test_cpu_networks_match_reference_outputs(name):
+    net = build(name)
+    check(name, net, 64, "cpu", 2e-5)
+
+
+def test_cpu_generator_matches_reference_at_304():
+    check("G", build("G"), 304, "cpu", 2e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 16, 16), (1, 4, 15, 13)])
+def test_cpu_blur_layers_match_reference(shape):
+    x, tag = image(shape, 3), f"{shape[2]}x{shape[3]}"
+    assert np.abs(networks.Downsample(4)(x).numpy() - G[f"down_{tag}"]).max() <= 1e-6
+    assert np.abs(networks.Upsample(4)(x).numpy() - G[f"up_{tag}"]).max() <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 4, 16, 16), (1, 4, 15, 13)])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_hip_blur_kernels_match_reference(shape, layout):
+    from octa_autosegmentation_amd.models import resample
+    x, tag = image(shape, 3).cuda(), f"{shape[2]}x{shape[3]}"
+    xin = x.permute(0, 2, 3, 1).contiguous() if layout == "nhwc" else x
+    back = (lambda t: t.permute(0, 3, 1, 2)) if layout == "nhwc" else (lambda t: t)
+    assert np.abs(back(resample.blur_down(xin, layout)).cpu().numpy() - G[f"down_{tag}"]).max() <= 1e-6
+    assert np.abs(back(resample.blur_up(xin, layout)).cpu().numpy() - G[f"up_{tag}"]).max() <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,size", [("G", 64), ("G", 304), ("D", 64), ("D", 304)])
+def test_gpu_fp32_networks_match_reference_outputs(name, size):
+    """fp32 on the GPU: pad / blur layers on the HIP kernels, convolutions in fp32 (logits within 1e-4, BASELINE.json)."""
+    check(name, build(name), size, "cuda", 1e-4)
