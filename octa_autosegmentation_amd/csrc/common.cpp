@@ -46,6 +46,7 @@ extern "C" void octa_ctx_destroy(octa_ctx *ctx) {
     ctx->r_tile_total.release();
     ctx->r_tile_list.release();
     ctx->r_counters.release();
+    ctx->zero_page.release();
     delete ctx;
 }
 

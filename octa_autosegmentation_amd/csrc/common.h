@@ -73,6 +73,7 @@ struct octa_ctx {
     octa::DevBuf r_tile_total;  // int64 [B]
     octa::DevBuf r_tile_list;   // int32 [sum tile counts]
     octa::DevBuf r_counters;    // int64 [8] misc device counters
+    octa::DevBuf zero_page;     // 256 zero bytes: source of the padding pixels of the DMA-staged convolution (conv.hip)
     size_t scratch_bytes() const {
         return r_edge_off.cap + r_ucount.cap + r_seg_total.cap + r_sides.cap + r_edge_meta.cap + r_tile_count.cap +
                r_tile_fill.cap + r_tile_total.cap + r_tile_list.cap + r_counters.cap;

@@ -23,6 +23,7 @@
 // input + output activations once (bf16) + weights.
 
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -246,6 +247,157 @@ int launch_conv_impl(const unsigned short *X, const unsigned short *X2, int C1, 
     return 0;
 }
 
+// ---- stride-1 kernel with asynchronous global -> LDS staging (global_load_lds, 16 bytes per lane) -------------------------
+// Same tile, same MFMA schedule and same epilogue as conv3x3_nhwc_kernel<BN, 1, false, false>, but the operand slices
+// never pass through VGPRs: every wave issues global_load_lds_dwordx4 for the NEXT slice into the other LDS buffer, then
+// multiplies the current one, so the HBM/L2 latency of a slice hides under the 72 (BN = 64) MFMAs of the previous slice
+// and the ds_write_b128 pass (~79 B/clk/CU) disappears. One barrier per slice.
+// The DMA writes LDS lane-linearly (wave-uniform base + lane * 16), so the LDS image is an unpadded array of 16-byte
+// pieces [row][PP] (row = halo pixel or weight row, PP = KCV / 8 pieces) and the bank spread comes from an XOR swizzle
+// applied to BOTH the source address and the read: piece q of row p lives in slot p * PP + (q ^ swz(p)), swz(p) =
+// (p >> 2) & 3 for PP = 4: the 16 rows of one ds_read_b128 lane group then cover all 64 banks once.
+// Out-of-image halo pixels (padding, the zero rows of a virtual zero insertion) are fetched from a 16-byte zero page.
+template <int PP> __device__ __forceinline__ int glds_swz(int p) { return PP == 4 ? (p >> 2) & 3 : (p >> 3) & 1; }
+
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int BN, int KCV>
+__global__ void __launch_bounds__(CONV_THREADS)
+conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
+                         const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
+                         int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, const unsigned short *__restrict__ zero16) {
+    constexpr int IH = TH + 2, IW = TW + 2;
+    constexpr int PP = KCV / 8, NB = BN / 32;
+    constexpr int IN_INSTR = (IH * IW * PP + 63) / 64, W_INSTR = 9 * BN * PP / 64;
+    constexpr int IN_BYTES = IN_INSTR * 1024, BUF = IN_BYTES + W_INSTR * 1024;
+    constexpr int IN_PW = (IN_INSTR + 3) / 4, W_PW = (W_INSTR + 3) / 4;   // wave-instructions per wave and slice
+    static_assert((9 * BN * PP) % 64 == 0, "weight slice must be whole wave-instructions");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tile = blockIdx.x, n = blockIdx.z, co0 = blockIdx.y * BN;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Hv = H * dil, Wv = W * dil;
+    const int iy0 = ty0 - 1, ix0 = tx0 - 1;
+    const int m = lane & 31, kg = lane >> 5;
+
+    // per-lane sources of this wave's DMA slots (the same pixels / weight rows for every channel slice)
+    int in_src[IN_PW], w_src[W_PW];
+#pragma unroll
+    for (int i = 0; i < IN_PW; i++) {
+        const int slot = (wv + 4 * i) * 64 + lane, p = slot / PP, q = (slot % PP) ^ glds_swz<PP>(p);
+        const int yy = iy0 + p / IW, xx = ix0 + p % IW;
+        bool ok = p < IH * IW && yy >= 0 && yy < Hv && xx >= 0 && xx < Wv;
+        if (ok && dil == 2) ok = !((yy | xx) & 1);
+        const int sy = dil == 2 ? yy >> 1 : yy, sx = dil == 2 ? xx >> 1 : xx;
+        in_src[i] = ok ? ((sy * W + sx) << 2) | q : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < W_PW; i++) {
+        const int slot = (wv + 4 * i) * 64 + lane, rw = slot / PP, q = (slot % PP) ^ glds_swz<PP>(rw);
+        w_src[i] = ((rw / BN) * Cout + co0 + rw % BN) * Cin + q * 8;
+    }
+    auto issue = [&](int c0, unsigned char *buf) {
+        const unsigned short *Xs = c0 < C1 ? X : X2;
+        const int cs = c0 < C1 ? C1 : Cin - C1, cb = c0 < C1 ? c0 : c0 - C1;
+        const unsigned short *img = Xs + (size_t)n * H * W * cs + cb;
+#pragma unroll
+        for (int i = 0; i < IN_PW; i++) {
+            const int j = wv + 4 * i;
+            if (j < IN_INSTR) {
+                const unsigned short *src = in_src[i] < 0 ? zero16 : img + (size_t)(in_src[i] >> 2) * cs + (in_src[i] & 3) * 8;
+                glds16(src, buf + j * 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W_PW; i++) {
+            const int j = wv + 4 * i;
+            if (j < W_INSTR) glds16(Wt + w_src[i] + c0, buf + IN_BYTES + j * 1024);
+        }
+    };
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+
+    const int nsl = Cin / KCV;
+    issue(0, smem);
+    for (int k = 0; k < nsl; k++) {
+        __syncthreads();   // slice k has landed (every wave drained its own DMA queue first); buffer (k+1)&1 is free again
+        if (k + 1 < nsl) issue((k + 1) * KCV, smem + ((k + 1) & 1) * BUF);
+        const unsigned char *s_in = smem + (k & 1) * BUF, *s_w = s_in + IN_BYTES;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int s = 0; s < 3; s++)
+#pragma unroll
+                for (int ks = 0; ks < KCV / 16; ks++) {
+                    const int qa = ks * 2 + kg;
+                    bf16x8 a[2], b[NB];
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++) {
+                        const int p = (2 * wv + rr + r) * IW + m + s;
+                        a[rr] = *reinterpret_cast<const bf16x8 *>(s_in + (p * PP + (qa ^ glds_swz<PP>(p))) * 16);
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        const int rw = (3 * r + s) * BN + nb * 32 + m;
+                        b[nb] = *reinterpret_cast<const bf16x8 *>(s_w + (rw * PP + (qa ^ glds_swz<PP>(rw))) * 16);
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++)
+                            acc[rr][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b[nb], acc[rr][nb], 0, 0, 0);
+                }
+    }
+    // epilogue of the plain kernel: tile through LDS, 16-byte coalesced NHWC stores
+    unsigned short *Yo = co0 < CY1 ? Y : Y2;
+    const int ys = co0 < CY1 ? CY1 : Cout - CY1, yb = co0 < CY1 ? co0 : co0 - CY1;
+    constexpr int OP = BN * 2 + 16;
+    unsigned char *s_out = smem;
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int px = (k & 3) + 8 * (k >> 2) + 4 * kg;
+                *reinterpret_cast<unsigned short *>(s_out + ((2 * wv + rr) * TW + px) * OP + (nb * 32 + m) * 2) = f2bf(acc[rr][nb][k]);
+            }
+    __syncthreads();
+    constexpr int PIECES = BN / 8;
+    for (int i = threadIdx.x; i < TH * TW * PIECES; i += CONV_THREADS) {
+        const int p = i / PIECES, q = i % PIECES;
+        const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+        if (oy < Ho && ox < Wo)
+            *reinterpret_cast<uint4 *>(Yo + (((size_t)n * Ho + oy) * Wo + ox) * ys + yb + q * 8) = *reinterpret_cast<const uint4 *>(s_out + p * OP + q * 16);
+    }
+}
+
+template <int BN, int KCV>
+int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
+                     int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, hipStream_t stream) {
+    constexpr int IH = TH + 2, IW = TW + 2, PP = KCV / 8;
+    constexpr int BUF = ((IH * IW * PP + 63) / 64 + 9 * BN * PP / 64) * 1024;
+    constexpr int OUT = TH * TW * (BN * 2 + 16);
+    const size_t lds = 2 * BUF > OUT ? 2 * BUF : OUT;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    auto kern = conv3x3_nhwc_glds_kernel<BN, KCV>;
+    OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <int BN, int ST>
 int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
                 int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tap_mask, int osc, int ooy, int oox,
@@ -295,6 +447,20 @@ extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void
     const unsigned short *Wt = static_cast<const unsigned short *>(d_w);
     unsigned short *Y = static_cast<unsigned short *>(d_y), *Y2 = static_cast<unsigned short *>(d_y2);
     const bool wide = (Cout % 64 == 0) && (CY1 % 64 == 0);   // a 64-channel block must not straddle the output split
+    // plain stride-1 layers: the DMA-staged kernel (OCTA_CONV_GLDS=0 selects the register-staged one, =16 (default) / =32 the slice depth)
+    static const int glds_mode = [] { const char *e = getenv("OCTA_CONV_GLDS"); return e ? atoi(e) : 16; }();
+    if (glds_mode && stride == 1 && tap_mask == 0x1ff && out_scale == 1 && !d_scale1 && !d_scale2 && !d_stat_partials) {
+        if (!ctx->zero_page.p) {
+            if (ctx->zero_page.reserve(256)) return -1;
+            OCTA_HIP_CHECK(hipMemset(ctx->zero_page.p, 0, ctx->zero_page.cap));
+        }
+        const unsigned short *z = ctx->zero_page.as<unsigned short>();
+        if (glds_mode == 16)
+            return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, stream)
+                        : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, stream);
+        return wide ? launch_conv_glds<64, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, stream)
+                    : launch_conv_glds<32, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, stream);
+    }
     if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream)
                                  : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream);
     return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream)
@@ -338,7 +504,11 @@ extern "C" int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void 
 namespace {
 
 constexpr int WTH = 4;                 // tile rows of the weight-gradient kernel (4 x 32 = 128 pixels per tile)
-constexpr int WG_ROWP = TW * 2 * WTH;  // bytes per channel row of the transposed dY tile
+// LDS row pitches of the transposed tiles are padded to 16 (mod 256) bytes: the 16 lanes of a ds_read_b128 group read
+// the same pixel group of 16 DIFFERENT channel rows, so the pitch must walk the 64 banks four at a time (a 256-byte
+// pitch would put all 16 rows on the same four banks: a 16-way conflict on every operand read).
+constexpr int wg_pad_pitch(int bytes) { return ((bytes - 16 + 255) / 256) * 256 + 16; }
+constexpr int WG_ROWP = wg_pad_pitch(TW * 2 * WTH);  // bytes per channel row of the transposed dY tile
 constexpr int HALO_W = 40;             // halo row pitch in pixels (34 used; 80 B keeps rows 16-byte aligned)
 
 // ST = 2: weight gradient of a stride-2 layer. dY has Ho x Wo pixels, the input 2Ho x 2Wo; tap (r, s) pairs output
@@ -358,7 +528,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     constexpr int SLOTS = ROWS_PER_WAVE * (TW / 16);   // MFMA groups of the compute loop = places to tuck LDS stores
     constexpr int XROWS = ST == 1 ? WTH + 2 : 2 * WTH + 1, XCOLS = ST == 1 ? TW + 2 : 2 * TW + 1;
     constexpr int XRP = ST == 1 ? HALO_W * 2 : 2 * HALO_W * 2;      // bytes per halo row (two column-parity planes for ST = 2)
-    constexpr int WG_XROW = XROWS * XRP;                             // bytes per channel row of the transposed X tile
+    constexpr int WG_XROW = wg_pad_pitch(XROWS * XRP);               // bytes per channel row of the transposed X tile
     constexpr int DYPIX = WTH * TW, XPIX = XROWS * XCOLS;
     constexpr int DY_ITEMS = DYPIX * (COB / 8), X_ITEMS = XPIX * (CIB / 8);   // 16-byte pieces per tile
     constexpr int DY_PT = (DY_ITEMS + CONV_THREADS - 1) / CONV_THREADS, X_PT = (X_ITEMS + CONV_THREADS - 1) / CONV_THREADS;
@@ -517,7 +687,7 @@ int launch_wgrad_impl(const unsigned short *X, const unsigned short *X2, int C1,
                  int Cout, int num_cus, int tap_mask, const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope,
                  hipStream_t stream) {
     constexpr int XROWS = ST == 1 ? WTH + 2 : 2 * WTH + 1;
-    constexpr int WG_XROW = XROWS * (ST == 1 ? HALO_W * 2 : 2 * HALO_W * 2);
+    constexpr int WG_XROW = wg_pad_pitch(XROWS * (ST == 1 ? HALO_W * 2 : 2 * HALO_W * 2));
     const size_t lds = 2 * ((size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW);   // double buffered
     const int Ho = H / ST, Wo = W / ST;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + WTH - 1) / WTH;

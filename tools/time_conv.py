@@ -23,8 +23,8 @@ for hw, cin, cout, st in shapes:
     dy = torch.randn(B, ho_, ho_, cout, device="cuda").to(torch.bfloat16)
     wd = mfma_conv.pack_weight_dgrad(w)
     t_d = timeit(lambda: mfma_conv.conv3x3_nhwc(dy, wd, stride=1, in_dilation=st))
-    t_w = timeit(lambda: mfma_conv.conv3x3_nhwc_wgrad(x, dy)) if st == 1 else float("nan")
-    t_t = timeit(lambda: F.conv2d(xn, w, stride=st, padding=1))
+    t_w = timeit(lambda: mfma_conv.conv3x3_nhwc_wgrad(x, dy)) if st == 1 and not os.environ.get("OCTA_SKIP_WGRAD") else float("nan")
+    t_t = timeit(lambda: F.conv2d(xn, w, stride=st, padding=1)) if not os.environ.get("OCTA_SKIP_TORCH") else float("nan")
     ho = (hw - 1) // st + 1
     fl = 2.0 * 9 * cin * cout * ho * ho * B
     by = 2.0 * B * (hw * hw * cin + ho * ho * cout)
