@@ -627,36 +627,48 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
         const unsigned char *s_dy = smem + cur * BUF, *s_x = s_dy + COB * WG_ROWP;
         unsigned char *nxt = smem + (cur ^ 1) * BUF;
         const bool have_next = tile + (int)gridDim.x < n_tiles;
-#pragma unroll
-        for (int slot = 0; slot < SLOTS; slot++) {
+        // Operands of MFMA group `slot`: the dY fragment and, per kernel row, the aligned 8-pixel group of the halo row plus
+        // the dword (ST = 1) / the other parity plane (ST = 2) the shifted taps need. They are read one group AHEAD, before
+        // the MFMAs of the current group and before its share of the transposed stores (which the compiler must assume to
+        // alias), so the LDS latency hides under nine MFMAs even with one wave per SIMD.
+        struct Ops { bf16x8 a; uint4 d[3]; unsigned e[3]; uint4 f[3]; };
+        // the dword behind the 16-byte group is fetched through an offset the compiler cannot see: it would otherwise fuse the
+        // 20 contiguous bytes into ds_read_b96 + ds_read2_b32 (12 LDS cycles) instead of ds_read_b128 + ds_read_b32 (6)
+        int e_off = 16;
+        asm volatile("" : "+v"(e_off));
+        auto load_ops = [&](int slot, Ops &o) {
             const int y = kpart * ROWS_PER_WAVE + slot / (TW / 16), xs = (slot % (TW / 16)) * 16;
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(s_dy + (cob + m) * WG_ROWP + (y * TW + xs + kg * 8) * 2);
+            o.a = *reinterpret_cast<const bf16x8 *>(s_dy + (cob + m) * WG_ROWP + (y * TW + xs + kg * 8) * 2);
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 if (MASKED && !((tap_mask >> (3 * r)) & 7)) continue;   // no tap of this kernel row is wanted
+                // ST = 1: halo columns xs + kg*8 + s .. +7 of halo row y + r. ST = 2: input row 2y + r; s = 0: odd plane at
+                // xs.., s = 1: even plane at xs.., s = 2: odd plane at xs+1..
+                const unsigned char *row = s_x + (cib + m) * WG_XROW + (ST * y + r) * XRP + (xs + kg * 8) * 2;
+                o.d[r] = *reinterpret_cast<const uint4 *>(row);
+                o.e[r] = *reinterpret_cast<const unsigned *>(row + e_off);
+                if (ST == 2) o.f[r] = *reinterpret_cast<const uint4 *>(row + HALO_W * 2);
+            }
+        };
+        Ops ops[2];
+        load_ops(0, ops[0]);
+#pragma unroll
+        for (int slot = 0; slot < SLOTS; slot++) {
+            if (slot + 1 < SLOTS) load_ops(slot + 1, ops[(slot + 1) & 1]);
+            const Ops &o = ops[slot & 1];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                if (MASKED && !((tap_mask >> (3 * r)) & 7)) continue;
                 union { uint4 u; bf16x8 v; } b0, b1, b2;
-                if (ST == 1) {
-                    // halo columns xs + kg*8 + s .. +7 of halo row y + r: aligned 8-pixel group + the next dword
-                    const unsigned char *row = s_x + (cib + m) * WG_XROW + (y + r) * XRP + (xs + kg * 8) * 2;
-                    const uint4 d = *reinterpret_cast<const uint4 *>(row);
-                    const unsigned e = *reinterpret_cast<const unsigned *>(row + 16);
-                    b0.u = d;
-                    b1.u = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
-                                      __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
-                    b2.u = make_uint4(d.y, d.z, d.w, e);
-                } else {
-                    // input row 2y + r of the halo; s = 0: odd plane at xs.., s = 1: even plane at xs.., s = 2: odd plane at xs+1..
-                    const unsigned char *row = s_x + (cib + m) * WG_XROW + (2 * y + r) * XRP + (xs + kg * 8) * 2;
-                    const uint4 d = *reinterpret_cast<const uint4 *>(row);
-                    const unsigned e = *reinterpret_cast<const unsigned *>(row + 16);
-                    b0.u = d;
-                    b1.u = *reinterpret_cast<const uint4 *>(row + HALO_W * 2);
-                    b2.u = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
-                                      __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
-                }
-                if (!MASKED || ((tap_mask >> (3 * r)) & 1)) acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0.v, acc[3 * r + 0], 0, 0, 0);
-                if (!MASKED || ((tap_mask >> (3 * r + 1)) & 1)) acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1.v, acc[3 * r + 1], 0, 0, 0);
-                if (!MASKED || ((tap_mask >> (3 * r + 2)) & 1)) acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2.v, acc[3 * r + 2], 0, 0, 0);
+                const uint4 d = o.d[r];
+                const uint4 sh = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
+                                            __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(o.e[r], d.w, 16));
+                b0.u = d;
+                if (ST == 1) { b1.u = sh; b2.u = make_uint4(d.y, d.z, d.w, o.e[r]); }
+                else { b1.u = o.f[r]; b2.u = sh; }
+                if (!MASKED || ((tap_mask >> (3 * r)) & 1)) acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b0.v, acc[3 * r + 0], 0, 0, 0);
+                if (!MASKED || ((tap_mask >> (3 * r + 1)) & 1)) acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b1.v, acc[3 * r + 1], 0, 0, 0);
+                if (!MASKED || ((tap_mask >> (3 * r + 2)) & 1)) acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b2.v, acc[3 * r + 2], 0, 0, 0);
             }
             // a share of the next tile's transposed stores, tucked behind this MFMA group
             if (have_next) {
