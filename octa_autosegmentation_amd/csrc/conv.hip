@@ -35,6 +35,15 @@ constexpr int KC = 32;             // input channels per LDS slice
 constexpr int PITCH = 80;          // bytes per pixel / per weight row in LDS (64 B of data + 16 B pad)
 constexpr int CONV_THREADS = 256;
 
+// 256 zero bytes in HBM: the source of padding pixels for loads that must not be branched around
+const unsigned short *zero_page(octa_ctx *ctx) {
+    if (!ctx->zero_page.p) {
+        if (ctx->zero_page.reserve(256)) return nullptr;
+        if (hipMemset(ctx->zero_page.p, 0, ctx->zero_page.cap) != hipSuccess) { octa::set_error("conv: zero page memset failed"); ctx->zero_page.release(); return nullptr; }
+    }
+    return ctx->zero_page.as<unsigned short>();
+}
+
 __device__ __forceinline__ unsigned short f2bf(float f) {
     unsigned u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
@@ -450,11 +459,8 @@ extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void
     // plain stride-1 layers: the DMA-staged kernel (OCTA_CONV_GLDS=0 selects the register-staged one, =16 (default) / =32 the slice depth)
     static const int glds_mode = [] { const char *e = getenv("OCTA_CONV_GLDS"); return e ? atoi(e) : 16; }();
     if (glds_mode && stride == 1 && tap_mask == 0x1ff && out_scale == 1 && !d_scale1 && !d_scale2 && !d_stat_partials) {
-        if (!ctx->zero_page.p) {
-            if (ctx->zero_page.reserve(256)) return -1;
-            OCTA_HIP_CHECK(hipMemset(ctx->zero_page.p, 0, ctx->zero_page.cap));
-        }
-        const unsigned short *z = ctx->zero_page.as<unsigned short>();
+        const unsigned short *z = zero_page(ctx);
+        if (!z) return -1;
         if (glds_mode == 16)
             return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, stream)
                         : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, stream);
@@ -515,13 +521,13 @@ constexpr int HALO_W = 40;             // halo row pitch in pixels (34 used; 80 
 // pixel (y, x) with input pixel (2y + r - 1, 2x + s - 1). The transposed X tile keeps its ODD and EVEN halo columns in
 // two planes per row, so the eight input pixels of a K-group are contiguous again: tap s = 0 reads the odd plane, s = 1
 // the even plane, s = 2 the odd plane one element further (funnel shift).
-template <int COB, int CIB, bool MASKED, int ST>
+template <int COB, int CIB, bool MASKED, int ST, bool XFORM>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                           const unsigned short *__restrict__ dY, float *__restrict__ dW,
                           int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask,
                           const float *__restrict__ sc1, const float *__restrict__ sh1, const float *__restrict__ sc2,
-                          const float *__restrict__ sh2, float slope) {
+                          const float *__restrict__ sh2, float slope, const unsigned short *__restrict__ zero16) {
     constexpr int PAIRS = (COB / 32) * (CIB / 32);
     constexpr int KSPLIT = 4 / PAIRS;            // waves sharing one (co, ci) pair split the tile rows
     constexpr int ROWS_PER_WAVE = WTH / KSPLIT;
@@ -540,7 +546,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     const int xcs = ci0 < C1 ? C1 : Cin - C1, xcb = ci0 < C1 ? ci0 : ci0 - C1;
     // normalise-on-load of the layer input (see the forward kernel): per image and channel scale / shift
     const float *scp = ci0 < C1 ? sc1 : sc2, *shp = ci0 < C1 ? sh1 : sh2;
-    const bool xform = scp != nullptr;
+    const bool xform = XFORM && scp != nullptr;   // compiled into the XFORM variant only (measured slower in the U-Net step)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int pair = wv % PAIRS, kpart = wv / PAIRS;
     const int cob = (pair % (COB / 32)) * 32, cib = (pair / (COB / 32)) * 32;
@@ -557,39 +563,48 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     // Item i of a tile: pixel i % NPIX, 8-channel group i / NPIX, so consecutive lanes hold consecutive pixels and
     // every 2-byte LDS store of a wave covers contiguous bytes of one channel row (no bank conflicts).
     uint4 r_dy[DY_PT], r_x[X_PT];
-    auto fetch = [&](int tile) {
+    struct TilePos { int n, ty0, tx0; };
+    auto tile_pos = [&](int tile) {
         const int n = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
-        const int ty0 = (tt / tiles_x) * WTH, tx0 = (tt % tiles_x) * TW;
+        return TilePos{n, (tt / tiles_x) * WTH, (tt % tiles_x) * TW};
+    };
+    auto fetch_dy = [&](const TilePos &tp, int k) {
+        const int i = threadIdx.x + k * CONV_THREADS, p = i % DYPIX, q = i / DYPIX;
+        const int y = tp.ty0 + p / TW, x = tp.tx0 + p % TW;
+        const bool ok = i < DY_ITEMS && y < Ho && x < Wo;
+        // the load itself is unconditional (padding comes from a zero page): a branch around it would make the number of
+        // loads in flight path-dependent and the compiler would then wait for ALL of them (vmcnt(0)) at every use
+        r_dy[k] = *reinterpret_cast<const uint4 *>(ok ? dY + (((size_t)tp.n * Ho + y) * Wo + x) * Cout + co0 + q * 8 : zero16);
+    };
+    auto fetch_x = [&](const TilePos &tp, int k) {
+        const int n = tp.n;
+        const int i = threadIdx.x + k * CONV_THREADS, p = i % XPIX, q = i / XPIX;
+        const int y = tp.ty0 * ST - 1 + p / XCOLS, x = tp.tx0 * ST - 1 + p % XCOLS;
+        const bool ok = i < X_ITEMS && y >= 0 && y < H && x >= 0 && x < W;
+        uint4 v = *reinterpret_cast<const uint4 *>(ok ? Xs + (((size_t)n * H + y) * W + x) * xcs + xcb + q * 8 : zero16);
+        if (XFORM && xform && ok) {
+            const float4 s0 = *reinterpret_cast<const float4 *>(scp + (size_t)n * xcs + xcb + q * 8), s1 = *reinterpret_cast<const float4 *>(scp + (size_t)n * xcs + xcb + q * 8 + 4);
+            const float4 h0 = *reinterpret_cast<const float4 *>(shp + (size_t)n * xcs + xcb + q * 8), h1 = *reinterpret_cast<const float4 *>(shp + (size_t)n * xcs + xcb + q * 8 + 4);
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            unsigned u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int k = 0; k < DY_PT; k++) {
-            const int i = threadIdx.x + k * CONV_THREADS, p = i % DYPIX, q = i / DYPIX;
-            const int y = ty0 + p / TW, x = tx0 + p % TW;
-            const bool ok = i < DY_ITEMS && y < Ho && x < Wo;
-            r_dy[k] = ok ? *reinterpret_cast<const uint4 *>(dY + (((size_t)n * Ho + y) * Wo + x) * Cout + co0 + q * 8) : make_uint4(0u, 0u, 0u, 0u);
-        }
-#pragma unroll
-        for (int k = 0; k < X_PT; k++) {
-            const int i = threadIdx.x + k * CONV_THREADS, p = i % XPIX, q = i / XPIX;
-            const int y = ty0 * ST - 1 + p / XCOLS, x = tx0 * ST - 1 + p % XCOLS;
-            const bool ok = i < X_ITEMS && y >= 0 && y < H && x >= 0 && x < W;
-            uint4 v = ok ? *reinterpret_cast<const uint4 *>(Xs + (((size_t)n * H + y) * W + x) * xcs + xcb + q * 8) : make_uint4(0u, 0u, 0u, 0u);
-            if (xform && ok) {
-                const float4 s0 = *reinterpret_cast<const float4 *>(scp + (size_t)n * xcs + xcb + q * 8), s1 = *reinterpret_cast<const float4 *>(scp + (size_t)n * xcs + xcb + q * 8 + 4);
-                const float4 h0 = *reinterpret_cast<const float4 *>(shp + (size_t)n * xcs + xcb + q * 8), h1 = *reinterpret_cast<const float4 *>(shp + (size_t)n * xcs + xcb + q * 8 + 4);
-                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-                unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float z0 = __uint_as_float(u[j] << 16) * sc[2 * j] + sh[2 * j];
-                    float z1 = __uint_as_float(u[j] & 0xffff0000u) * sc[2 * j + 1] + sh[2 * j + 1];
-                    z0 = z0 > 0.f ? z0 : z0 * slope;
-                    z1 = z1 > 0.f ? z1 : z1 * slope;
-                    u[j] = (unsigned)f2bf(z0) | ((unsigned)f2bf(z1) << 16);
-                }
-                v = make_uint4(u[0], u[1], u[2], u[3]);
+            for (int j = 0; j < 4; j++) {
+                float z0 = __uint_as_float(u[j] << 16) * sc[2 * j] + sh[2 * j];
+                float z1 = __uint_as_float(u[j] & 0xffff0000u) * sc[2 * j + 1] + sh[2 * j + 1];
+                z0 = z0 > 0.f ? z0 : z0 * slope;
+                z1 = z1 > 0.f ? z1 : z1 * slope;
+                u[j] = (unsigned)f2bf(z0) | ((unsigned)f2bf(z1) << 16);
             }
-            r_x[k] = v;
+            v = make_uint4(u[0], u[1], u[2], u[3]);
         }
+        r_x[k] = v;
+    };
+    auto fetch = [&](int tile) {
+        const TilePos tp = tile_pos(tile);
+#pragma unroll
+        for (int k = 0; k < DY_PT; k++) fetch_dy(tp, k);
+#pragma unroll
+        for (int k = 0; k < X_PT; k++) fetch_x(tp, k);
     };
     auto stash_dy = [&](unsigned char *buf, int k) {
         const int i = threadIdx.x + k * CONV_THREADS, p = i % DYPIX, q = i / DYPIX;
@@ -619,14 +634,23 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
         for (int k = 0; k < DY_PT; k++) stash_dy(smem, k);
 #pragma unroll
         for (int k = 0; k < X_PT; k++) stash_x(smem, k);
-        if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
+        // staging registers <- tile after this one, issued in the order the loop below re-issues them (slot by slot), so
+        // that the in-order load counter is the same on the loop's entry edge and on its back edge
+        const TilePos tp1 = tile_pos(tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile);
+#pragma unroll
+        for (int slot = 0; slot < SLOTS; slot++) {
+#pragma unroll
+            for (int k = slot; k < DY_PT; k += SLOTS) fetch_dy(tp1, k);
+#pragma unroll
+            for (int k = slot; k < X_PT; k += SLOTS) fetch_x(tp1, k);
+        }
     }
     __syncthreads();
     int cur = 0;
     for (; tile < n_tiles; tile += gridDim.x) {
         const unsigned char *s_dy = smem + cur * BUF, *s_x = s_dy + COB * WG_ROWP;
         unsigned char *nxt = smem + (cur ^ 1) * BUF;
-        const bool have_next = tile + (int)gridDim.x < n_tiles;
+        const TilePos tp2 = tile_pos(tile + 2 * (int)gridDim.x < n_tiles ? tile + 2 * (int)gridDim.x : tile);
         // Operands of MFMA group `slot`: the dY fragment and, per kernel row, the aligned 8-pixel group of the halo row plus
         // the dword (ST = 1) / the other parity plane (ST = 2) the shifted taps need. They are read one group AHEAD, before
         // the MFMAs of the current group and before its share of the transposed stores (which the compiler must assume to
@@ -670,15 +694,16 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
                 if (!MASKED || ((tap_mask >> (3 * r + 1)) & 1)) acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b1.v, acc[3 * r + 1], 0, 0, 0);
                 if (!MASKED || ((tap_mask >> (3 * r + 2)) & 1)) acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b2.v, acc[3 * r + 2], 0, 0, 0);
             }
-            // a share of the next tile's transposed stores, tucked behind this MFMA group
-            if (have_next) {
+            // a share of the next tile's transposed stores, tucked behind this MFMA group; every staging register is
+            // refilled with its piece of the tile after next as soon as it has been stored, so each load has a whole tile
+            // of MFMAs to land before its turn comes round again
+            // (unconditional: on the last tiles the stores fill a buffer nobody reads and the loads re-read a valid tile --
+            // branch-free code keeps the compiler's count of loads in flight exact, so it waits with vmcnt(N), not vmcnt(0))
 #pragma unroll
-                for (int k = slot; k < DY_PT; k += SLOTS) stash_dy(nxt, k);
+            for (int k = slot; k < DY_PT; k += SLOTS) { stash_dy(nxt, k); fetch_dy(tp2, k); }
 #pragma unroll
-                for (int k = slot; k < X_PT; k += SLOTS) stash_x(nxt, k);
-            }
+            for (int k = slot; k < X_PT; k += SLOTS) { stash_x(nxt, k); fetch_x(tp2, k); }
         }
-        if (tile + 2 * (int)gridDim.x < n_tiles) fetch(tile + 2 * gridDim.x);
         __syncthreads();
         cur ^= 1;
     }
@@ -697,7 +722,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
 template <int COB, int CIB, bool MASKED, int ST>
 int launch_wgrad_impl(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
                  int Cout, int num_cus, int tap_mask, const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope,
-                 hipStream_t stream) {
+                 const unsigned short *zero16, hipStream_t stream) {
     constexpr int XROWS = ST == 1 ? WTH + 2 : 2 * WTH + 1;
     constexpr int WG_XROW = wg_pad_pitch(XROWS * (ST == 1 ? HALO_W * 2 : 2 * HALO_W * 2));
     const size_t lds = 2 * ((size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW);   // double buffered
@@ -708,10 +733,10 @@ int launch_wgrad_impl(const unsigned short *X, const unsigned short *X2, int C1,
     const int n_tiles = tiles_x * tiles_y * N;
     if (per_block > n_tiles) per_block = n_tiles;
     if (per_block < 1) per_block = 1;
-    auto kern = conv3x3_nhwc_wgrad_kernel<COB, CIB, MASKED, ST>;
+    auto kern = (sc1 || sc2) ? conv3x3_nhwc_wgrad_kernel<COB, CIB, MASKED, ST, true> : conv3x3_nhwc_wgrad_kernel<COB, CIB, MASKED, ST, false>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Ho, Wo, Cin,
-                       Cout, tiles_x, tiles_y, tap_mask, sc1, sh1, sc2, sh2, slope);
+                       Cout, tiles_x, tiles_y, tap_mask, sc1, sh1, sc2, sh2, slope, zero16);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -719,9 +744,9 @@ int launch_wgrad_impl(const unsigned short *X, const unsigned short *X2, int C1,
 template <int COB, int CIB, int ST = 1>
 int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
                  int Cout, int num_cus, int tap_mask, const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope,
-                 hipStream_t stream) {
-    if (tap_mask != 0x1ff) return launch_wgrad_impl<COB, CIB, true, ST>(X, X2, C1, dY, dW, N, H, W, Cin, Cout, num_cus, tap_mask, sc1, sh1, sc2, sh2, slope, stream);
-    return launch_wgrad_impl<COB, CIB, false, ST>(X, X2, C1, dY, dW, N, H, W, Cin, Cout, num_cus, tap_mask, sc1, sh1, sc2, sh2, slope, stream);
+                 const unsigned short *zero16, hipStream_t stream) {
+    if (tap_mask != 0x1ff) return launch_wgrad_impl<COB, CIB, true, ST>(X, X2, C1, dY, dW, N, H, W, Cin, Cout, num_cus, tap_mask, sc1, sh1, sc2, sh2, slope, zero16, stream);
+    return launch_wgrad_impl<COB, CIB, false, ST>(X, X2, C1, dY, dW, N, H, W, Cin, Cout, num_cus, tap_mask, sc1, sh1, sc2, sh2, slope, zero16, stream);
 }
 
 }  // namespace
@@ -741,18 +766,20 @@ extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const vo
     OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 9 * (size_t)Cout * Cin, stream));
     const unsigned short *X = static_cast<const unsigned short *>(d_x), *X2 = static_cast<const unsigned short *>(d_x2);
     const unsigned short *dY = static_cast<const unsigned short *>(d_dy);
+    const unsigned short *z = zero_page(ctx);
+    if (!z) return -1;
     const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0 && C1 % 64 == 0;   // a 64-channel block must not straddle the split
     if (stride == 2) {
         if (H % 2 || W % 2) { octa::set_error("octa_conv3x3_nhwc_wgrad: stride-2 layers need even input sizes"); return -2; }
         // two column-parity planes per halo row: 32 input channels per workgroup keep the double buffer inside the LDS
-        if (co64) return launch_wgrad<64, 32, 2>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
-        return launch_wgrad<32, 32, 2>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+        if (co64) return launch_wgrad<64, 32, 2>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
+        return launch_wgrad<32, 32, 2>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     }
     if (stride != 1) { octa::set_error("octa_conv3x3_nhwc_wgrad: stride must be 1 or 2"); return -2; }
-    if (co64 && ci64) return launch_wgrad<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
-    if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
-    if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
-    return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream);
+    if (co64 && ci64) return launch_wgrad<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
+    if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
+    if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
+    return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
 }
 
 extern "C" int octa_conv3x3_nhwc_wgrad3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
