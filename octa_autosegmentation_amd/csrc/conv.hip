@@ -273,11 +273,12 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned char *lds_wave
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, int KCV>
+template <int BN, int KCV, bool STATS, bool MASKED>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                          const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
-                         int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, const unsigned short *__restrict__ zero16) {
+                         int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, const unsigned short *__restrict__ zero16,
+                         float *__restrict__ part, int tap_mask) {
     constexpr int IH = TH + 2, IW = TW + 2;
     constexpr int PP = KCV / 8, NB = BN / 32;
     constexpr int IN_INSTR = (IH * IW * PP + 63) / 64, W_INSTR = 9 * BN * PP / 64;
@@ -323,7 +324,8 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
 #pragma unroll
         for (int i = 0; i < W_PW; i++) {
             const int j = wv + 4 * i;
-            if (j < W_INSTR) glds16(Wt + w_src[i] + c0, buf + IN_BYTES + j * 1024);
+            // (a wave-instruction of weights covers 64 / PP rows of ONE tap, BN being a multiple of that: masked taps are not fetched)
+            if (j < W_INSTR && (!MASKED || ((tap_mask >> (j * (64 / PP) / BN)) & 1))) glds16(Wt + w_src[i] + c0, buf + IN_BYTES + j * 1024);
         }
     };
 
@@ -347,6 +349,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
             for (int s = 0; s < 3; s++)
 #pragma unroll
                 for (int ks = 0; ks < KCV / 16; ks++) {
+                    if (MASKED && !((tap_mask >> (3 * r + s)) & 1)) continue;   // taps whose weights are structurally zero
                     const int qa = ks * 2 + kg;
                     bf16x8 a[2], b[NB];
 #pragma unroll
@@ -389,20 +392,55 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
         if (oy < Ho && ox < Wo)
             *reinterpret_cast<uint4 *>(Yo + (((size_t)n * Ho + oy) * Wo + ox) * ys + yb + q * 8) = *reinterpret_cast<const uint4 *>(s_out + p * OP + q * 16);
     }
+    // InstanceNorm statistics of the layer that follows: per tile and output channel the sum and the sum of squares of the
+    // bf16-ROUNDED results (what a statistics pass would read back) -> part[n][tile][Cout][2]; saves that pass over Y.
+    if (STATS) {
+        float s1[NB], s2[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) { s1[nb] = 0.f; s2[nb] = 0.f; }
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int oy = ty0 + 2 * wv + rr;
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int ox = tx0 + (k & 3) + 8 * (k >> 2) + 4 * kg;
+                    const float v = (oy < Ho && ox < Wo) ? __uint_as_float((unsigned)f2bf(acc[rr][nb][k]) << 16) : 0.f;
+                    s1[nb] += v; s2[nb] += v * v;
+                }
+        }
+        float *s_red = reinterpret_cast<float *>(smem);   // [4 waves][BN][2]
+        __syncthreads();                                  // the output tile has been read out of LDS
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            const float a1 = s1[nb] + __shfl_xor(s1[nb], 32, 64), a2 = s2[nb] + __shfl_xor(s2[nb], 32, 64);
+            if (kg == 0) { s_red[(wv * BN + nb * 32 + m) * 2] = a1; s_red[(wv * BN + nb * 32 + m) * 2 + 1] = a2; }
+        }
+        __syncthreads();
+        if (threadIdx.x < BN) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) { a1 += s_red[(w4 * BN + threadIdx.x) * 2]; a2 += s_red[(w4 * BN + threadIdx.x) * 2 + 1]; }
+            float *dst = part + (((size_t)n * gridDim.x + tile) * Cout + co0 + threadIdx.x) * 2;
+            dst[0] = a1; dst[1] = a2;
+        }
+    }
 }
 
 template <int BN, int KCV>
 int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
-                     int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, hipStream_t stream) {
+                     int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, float *part, int tap_mask, hipStream_t stream) {
     constexpr int IH = TH + 2, IW = TW + 2, PP = KCV / 8;
     constexpr int BUF = ((IH * IW * PP + 63) / 64 + 9 * BN * PP / 64) * 1024;
     constexpr int OUT = TH * TW * (BN * 2 + 16);
     const size_t lds = 2 * BUF > OUT ? 2 * BUF : OUT;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    auto kern = conv3x3_nhwc_glds_kernel<BN, KCV>;
+    auto kern = part ? conv3x3_nhwc_glds_kernel<BN, KCV, true, true>
+                     : (tap_mask != 0x1ff ? conv3x3_nhwc_glds_kernel<BN, KCV, false, true> : conv3x3_nhwc_glds_kernel<BN, KCV, false, false>);
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
-    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -458,14 +496,14 @@ extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void
     const bool wide = (Cout % 64 == 0) && (CY1 % 64 == 0);   // a 64-channel block must not straddle the output split
     // plain stride-1 layers: the DMA-staged kernel (OCTA_CONV_GLDS=0 selects the register-staged one, =16 (default) / =32 the slice depth)
     static const int glds_mode = [] { const char *e = getenv("OCTA_CONV_GLDS"); return e ? atoi(e) : 16; }();
-    if (glds_mode && stride == 1 && tap_mask == 0x1ff && out_scale == 1 && !d_scale1 && !d_scale2 && !d_stat_partials) {
+    if (glds_mode && stride == 1 && out_scale == 1 && !d_scale1 && !d_scale2) {
         const unsigned short *z = zero_page(ctx);
         if (!z) return -1;
         if (glds_mode == 16)
-            return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, stream)
-                        : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, stream);
-        return wide ? launch_conv_glds<64, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, stream)
-                    : launch_conv_glds<32, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, stream);
+            return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, stream)
+                        : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, stream);
+        return wide ? launch_conv_glds<64, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, stream)
+                    : launch_conv_glds<32, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, stream);
     }
     if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream)
                                  : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream);
@@ -521,8 +559,12 @@ constexpr int HALO_W = 40;             // halo row pitch in pixels (34 used; 80 
 // pixel (y, x) with input pixel (2y + r - 1, 2x + s - 1). The transposed X tile keeps its ODD and EVEN halo columns in
 // two planes per row, so the eight input pixels of a K-group are contiguous again: tap s = 0 reads the odd plane, s = 1
 // the even plane, s = 2 the odd plane one element further (funnel shift).
+// Workgroups per CU: the 32 x 32-channel stride-1 tile (the 1216^2 level: HBM / latency-bound, 18 MFMAs per wave and tile)
+// is compiled for two resident workgroups -- twice the loads in flight; the larger tiles need the whole register file.
+template <int COB, int CIB, int ST> constexpr int wgrad_wgs_per_cu() { return COB == 32 && CIB == 32 && ST == 1 ? 2 : 1; }
+
 template <int COB, int CIB, bool MASKED, int ST, bool XFORM>
-__global__ void __launch_bounds__(CONV_THREADS)
+__global__ void __launch_bounds__(CONV_THREADS, (wgrad_wgs_per_cu<COB, CIB, ST>()))
 conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                           const unsigned short *__restrict__ dY, float *__restrict__ dW,
                           int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask,
@@ -729,7 +771,7 @@ int launch_wgrad_impl(const unsigned short *X, const unsigned short *X2, int C1,
     const int Ho = H / ST, Wo = W / ST;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + WTH - 1) / WTH;
     const int blocks = (Cout / COB) * (Cin / CIB);
-    int per_block = (num_cus + blocks - 1) / blocks;   // one resident workgroup per CU (LDS): one round, fewer atomics
+    int per_block = (num_cus * wgrad_wgs_per_cu<COB, CIB, ST>() + blocks - 1) / blocks;   // one round of resident workgroups: fewer atomics
     const int n_tiles = tiles_x * tiles_y * N;
     if (per_block > n_tiles) per_block = n_tiles;
     if (per_block < 1) per_block = 1;
@@ -910,13 +952,17 @@ __device__ __forceinline__ float bfu(unsigned short h) { return __uint_as_float(
 __global__ void __launch_bounds__(256)
 conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restrict__ Wf /* [Cout][9] */, unsigned short *__restrict__ Y,
                       int N, int H, int W, int Cout) {
-    extern __shared__ float s_wf[];   // [Cout][9]
-    for (int i = threadIdx.x; i < Cout * 9; i += 256) s_wf[i] = Wf[i];
-    __syncthreads();
     const int groups = Cout / 8, gshift = 31 - __clz(groups);   // groups is a power of two: no integer divisions per item
+    // 256 is a multiple of `groups`: a thread keeps its channel group q, hence its 72 weights, in registers for the whole loop
+    const int q = threadIdx.x & (groups - 1);
+    float wr[8][9];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) wr[k][t] = Wf[(q * 8 + k) * 9 + t];
     for (int row = blockIdx.x; row < N * H; row += gridDim.x)
     for (int j = threadIdx.x; j < W * groups; j += 256) {
-        const int q = j & (groups - 1), x = j >> gshift, y = row % H;
+        const int x = j >> gshift, y = row % H;
         const long n = row / H, p = (long)row * W + x;
         float in[9];
 #pragma unroll
@@ -931,7 +977,7 @@ conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restr
         for (int k = 0; k < 4; k++) {
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int t = 0; t < 9; t++) { a0 += in[t] * s_wf[(q * 8 + 2 * k) * 9 + t]; a1 += in[t] * s_wf[(q * 8 + 2 * k + 1) * 9 + t]; }
+            for (int t = 0; t < 9; t++) { a0 += in[t] * wr[2 * k][t]; a1 += in[t] * wr[2 * k + 1][t]; }
             o[k] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
         }
         *reinterpret_cast<uint4 *>(Y + p * Cout + q * 8) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -952,24 +998,36 @@ conv3x3_c1_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned sho
         for (int t = 0; t < 9; t++) acc[k][t] = 0.f;
     // 256 is a multiple of `groups`, so a thread keeps its channel group q for the whole loop
     const int q = threadIdx.x & (groups - 1);
-    for (int row = blockIdx.x; row < N * H; row += gridDim.x)
-    for (int j = threadIdx.x; j < W * groups; j += 256) {
-        const int x = j >> gshift, y = row % H;
-        const long n = row / H, p = (long)row * W + x;
-        const uint4 v = *reinterpret_cast<const uint4 *>(dY + p * Cout + q * 8);
-        const unsigned u[4] = {v.x, v.y, v.z, v.w};
-        float d[8];
+    const int items = W * groups;
+    for (int row = blockIdx.x; row < N * H; row += gridDim.x) {
+        const int y = row % H;
+        const long n = row / H;
+        // two 16-byte pieces of dY per trip, both loads issued before either is used (the kernel is latency-bound otherwise)
+        for (int j = threadIdx.x; j < items; j += 512) {
+            const int x0 = j >> gshift, j1 = j + 256, x1 = j1 >> gshift;
+            const bool has1 = j1 < items;
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(dY + ((long)row * W + x0) * Cout + q * 8);
+            const uint4 v1 = *reinterpret_cast<const uint4 *>(dY + ((long)row * W + (has1 ? x1 : x0)) * Cout + q * 8);
 #pragma unroll
-        for (int k = 0; k < 4; k++) { d[2 * k] = __uint_as_float(u[k] << 16); d[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+            for (int h = 0; h < 2; h++) {
+                if (h == 1 && !has1) break;
+                const int x = h ? x1 : x0;
+                const uint4 v = h ? v1 : v0;
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                float d[8];
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+                for (int k = 0; k < 4; k++) { d[2 * k] = __uint_as_float(u[k] << 16); d[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
-                const int yy = y + r - 1, xx = x + s - 1;
-                const float in = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
+                for (int r = 0; r < 3; r++)
 #pragma unroll
-                for (int k = 0; k < 8; k++) acc[k][3 * r + s] += d[k] * in;
+                    for (int s = 0; s < 3; s++) {
+                        const int yy = y + r - 1, xx = x + s - 1;
+                        const float in = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) acc[k][3 * r + s] += d[k] * in;
+                    }
             }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 8; k++)
@@ -993,7 +1051,7 @@ extern "C" int octa_conv3x3_c1_fwd(octa_ctx *ctx, const void *d_x, const float *
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     long blocks = (long)N * H;
     if (blocks > 32L * ctx->num_cus) blocks = 32L * ctx->num_cus;
-    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * Cout * 9, stream, static_cast<const unsigned short *>(d_x),
+    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const unsigned short *>(d_x),
                        d_w, static_cast<unsigned short *>(d_y), N, H, W, Cout);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
