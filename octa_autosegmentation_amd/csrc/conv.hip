@@ -952,17 +952,13 @@ __device__ __forceinline__ float bfu(unsigned short h) { return __uint_as_float(
 __global__ void __launch_bounds__(256)
 conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restrict__ Wf /* [Cout][9] */, unsigned short *__restrict__ Y,
                       int N, int H, int W, int Cout) {
+    extern __shared__ float s_wf[];   // [Cout][9] (weights in registers were measured slower: 97 VGPRs, fewer waves in flight)
+    for (int i = threadIdx.x; i < Cout * 9; i += 256) s_wf[i] = Wf[i];
+    __syncthreads();
     const int groups = Cout / 8, gshift = 31 - __clz(groups);   // groups is a power of two: no integer divisions per item
-    // 256 is a multiple of `groups`: a thread keeps its channel group q, hence its 72 weights, in registers for the whole loop
-    const int q = threadIdx.x & (groups - 1);
-    float wr[8][9];
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-#pragma unroll
-        for (int t = 0; t < 9; t++) wr[k][t] = Wf[(q * 8 + k) * 9 + t];
     for (int row = blockIdx.x; row < N * H; row += gridDim.x)
     for (int j = threadIdx.x; j < W * groups; j += 256) {
-        const int x = j >> gshift, y = row % H;
+        const int q = j & (groups - 1), x = j >> gshift, y = row % H;
         const long n = row / H, p = (long)row * W + x;
         float in[9];
 #pragma unroll
@@ -977,7 +973,7 @@ conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restr
         for (int k = 0; k < 4; k++) {
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int t = 0; t < 9; t++) { a0 += in[t] * wr[2 * k][t]; a1 += in[t] * wr[2 * k + 1][t]; }
+            for (int t = 0; t < 9; t++) { a0 += in[t] * s_wf[(q * 8 + 2 * k) * 9 + t]; a1 += in[t] * s_wf[(q * 8 + 2 * k + 1) * 9 + t]; }
             o[k] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
         }
         *reinterpret_cast<uint4 *>(Y + p * Cout + q * 8) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -1051,7 +1047,7 @@ extern "C" int octa_conv3x3_c1_fwd(octa_ctx *ctx, const void *d_x, const float *
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     long blocks = (long)N * H;
     if (blocks > 32L * ctx->num_cus) blocks = 32L * ctx->num_cus;
-    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const unsigned short *>(d_x),
+    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * Cout * 9, stream, static_cast<const unsigned short *>(d_x),
                        d_w, static_cast<unsigned short *>(d_y), N, H, W, Cout);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;

@@ -10,6 +10,7 @@
 // the 128-plane top level; kernel 1 leaves per-split partial sums, kernel 2 folds them (a few floats) and
 // streams the plane with 16-byte accesses.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -286,9 +287,9 @@ template <int MODE>
 __global__ void __launch_bounds__(NT)
 in_nhwc_stats(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, const float *__restrict__ w,
               const float *__restrict__ bias, const float *__restrict__ mean, const float *__restrict__ rstd, long hw, int C,
-              int splits, float slope, double *__restrict__ sums) {
+              int splits, float slope, double *__restrict__ sums, int b0) {
     __shared__ float s_red[2 * NT * 8];
-    const int b = blockIdx.y, s = blockIdx.x;
+    const int b = blockIdx.y + b0, s = blockIdx.x;
     int cg, pl, npl;
     nhwc_geometry(C, cg, pl, npl);
     const bool active = pl < npl && cg < C / 8;   // NT need not be a multiple of C/8
@@ -371,9 +372,9 @@ in_nhwc_stats(const unsigned short *__restrict__ x, const unsigned short *__rest
 __global__ void __launch_bounds__(NT)
 in_nhwc_fwd_apply(const unsigned short *__restrict__ x, unsigned short *__restrict__ y, const float *__restrict__ w,
                   const float *__restrict__ bias, long hw, int C, int splits, const double *__restrict__ sums, float slope, float eps,
-                  float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+                  float *__restrict__ mean_out, float *__restrict__ rstd_out, int b0) {
     __shared__ float s_g[NHWC_MAXC], s_sh[NHWC_MAXC];
-    const int b = blockIdx.y, s = blockIdx.x;
+    const int b = blockIdx.y + b0, s = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += NT) {
         const double sa = sums[((long)b * C + c) * 2], sq = sums[((long)b * C + c) * 2 + 1];
         const double mean_d = sa / (double)hw;
@@ -420,9 +421,9 @@ __global__ void __launch_bounds__(NT)
 in_nhwc_bwd_apply(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, unsigned short *__restrict__ dx,
                   const float *__restrict__ w, const float *__restrict__ bias, const float *__restrict__ mean,
                   const float *__restrict__ rstd, long hw, int C, int splits, float slope, const double *__restrict__ sums,
-                  float *__restrict__ dw, float *__restrict__ db) {
+                  float *__restrict__ dw, float *__restrict__ db, int b0) {
     __shared__ float s_mg[NHWC_MAXC], s_mgx[NHWC_MAXC];
-    const int b = blockIdx.y, s = blockIdx.x;
+    const int b = blockIdx.y + b0, s = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += NT) {
         const double sa = sums[((long)b * C + c) * 2], sq = sums[((long)b * C + c) * 2 + 1];
         if (s == 0) {
@@ -485,6 +486,17 @@ int nhwc_splits(const octa_ctx *ctx, int B, long hw) {
     return (int)s;
 }
 
+// Images per launch group of the two-pass norm kernels: as many as fit OCTA_NORM_CACHE_MB together (at least one). Default 0 =
+// the whole batch in one launch: image-by-image launches (application pass served from the 256 MB Infinity Cache) were
+// measured SLOWER on MI355X (U-Net step 22.0 ms at 192 MB, 23.6 ms at 96 MB vs 21.2 ms) -- short launches, longer tails.
+int nhwc_group(int B, size_t bytes_per_image) {
+    static const size_t budget = [] { const char *e = getenv("OCTA_NORM_CACHE_MB"); return (size_t)(e ? atol(e) : 0) << 20; }();
+    if (budget == 0) return B;
+    size_t g = budget / (bytes_per_image ? bytes_per_image : 1);
+    if (g < 1) g = 1;
+    return g > (size_t)B ? B : (int)g;
+}
+
 int nhwc_check(const char *who, int B, int C, int64_t hw) {
     if (B <= 0 || hw <= 0 || C <= 0 || C % 8 || C > NHWC_MAXC || NT % (C / 8) != 0 && C / 8 > NT) { octa::set_error("%s: C must be a multiple of 8, <= %d (got B=%d C=%d)", who, NHWC_MAXC, B, C); return -2; }
     if (B > 65535) { octa::set_error("%s: B > 65535", who); return -2; }
@@ -503,13 +515,18 @@ extern "C" int octa_instnorm_lrelu_nhwc_fwd(octa_ctx *ctx, const void *d_x, void
     if (ctx->r_tile_total.reserve(sizeof(double) * 2 * (size_t)B * C)) return -1;
     double *sums = ctx->r_tile_total.as<double>();
     OCTA_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, stream));
-    const int splits = nhwc_splits(ctx, B, hw);
-    dim3 grid((unsigned)splits, (unsigned)B);
+    // optional image groups (nhwc_group): statistics and application of one group back to back
+    const int group = nhwc_group(B, (size_t)hw * C * 2);
+    const int splits = nhwc_splits(ctx, group, hw);
+    dim3 grid((unsigned)splits, (unsigned)group);
     const unsigned short *x = static_cast<const unsigned short *>(d_x);
-    hipLaunchKernelGGL(in_nhwc_stats<0>, grid, dim3(NT), 0, stream, x, (const unsigned short *)nullptr, d_w, d_b, (const float *)nullptr,
-                       (const float *)nullptr, (long)hw, C, splits, slope, sums);
-    hipLaunchKernelGGL(in_nhwc_fwd_apply, grid, dim3(NT), 0, stream, x, static_cast<unsigned short *>(d_y), d_w, d_b, (long)hw, C, splits,
-                       sums, slope, eps, d_mean, d_rstd);
+    for (int b0 = 0; b0 < B; b0 += group) {
+        if (b0 + group > B) grid.y = (unsigned)(B - b0);
+        hipLaunchKernelGGL(in_nhwc_stats<0>, grid, dim3(NT), 0, stream, x, (const unsigned short *)nullptr, d_w, d_b, (const float *)nullptr,
+                           (const float *)nullptr, (long)hw, C, splits, slope, sums, b0);
+        hipLaunchKernelGGL(in_nhwc_fwd_apply, grid, dim3(NT), 0, stream, x, static_cast<unsigned short *>(d_y), d_w, d_b, (long)hw, C, splits,
+                           sums, slope, eps, d_mean, d_rstd, b0);
+    }
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -526,12 +543,16 @@ extern "C" int octa_instnorm_lrelu_nhwc_bwd(octa_ctx *ctx, const void *d_x, cons
     OCTA_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, stream));
     if (d_dw) OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
     if (d_db) OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float) * C, stream));
-    const int splits = nhwc_splits(ctx, B, hw);
-    dim3 grid((unsigned)splits, (unsigned)B);
+    const int group = nhwc_group(B, (size_t)hw * C * 2 * 2);   // two tensors (x, dy) are read twice
+    const int splits = nhwc_splits(ctx, group, hw);
+    dim3 grid((unsigned)splits, (unsigned)group);
     const unsigned short *x = static_cast<const unsigned short *>(d_x), *dy = static_cast<const unsigned short *>(d_dy);
-    hipLaunchKernelGGL(in_nhwc_stats<1>, grid, dim3(NT), 0, stream, x, dy, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, sums);
-    hipLaunchKernelGGL(in_nhwc_bwd_apply, grid, dim3(NT), 0, stream, x, dy, static_cast<unsigned short *>(d_dx), d_w, d_b, d_mean, d_rstd,
-                       (long)hw, C, splits, slope, sums, d_dw, d_db);
+    for (int b0 = 0; b0 < B; b0 += group) {
+        if (b0 + group > B) grid.y = (unsigned)(B - b0);
+        hipLaunchKernelGGL(in_nhwc_stats<1>, grid, dim3(NT), 0, stream, x, dy, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, sums, b0);
+        hipLaunchKernelGGL(in_nhwc_bwd_apply, grid, dim3(NT), 0, stream, x, dy, static_cast<unsigned short *>(d_dx), d_w, d_b, d_mean, d_rstd,
+                           (long)hw, C, splits, slope, sums, d_dw, d_db, b0);
+    }
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -591,7 +612,7 @@ extern "C" int octa_instnorm_nhwc_stats(octa_ctx *ctx, const void *d_x, const fl
     OCTA_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, stream));
     const int splits = nhwc_splits(ctx, B, hw);
     hipLaunchKernelGGL(in_nhwc_stats<0>, dim3((unsigned)splits, (unsigned)B), dim3(NT), 0, stream, static_cast<const unsigned short *>(d_x),
-                       (const unsigned short *)nullptr, d_w, d_b, (const float *)nullptr, (const float *)nullptr, (long)hw, C, splits, 0.f, sums);
+                       (const unsigned short *)nullptr, d_w, d_b, (const float *)nullptr, (const float *)nullptr, (long)hw, C, splits, 0.f, sums, 0);
     const long total = (long)B * C;
     hipLaunchKernelGGL(in_nhwc_finalize, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, stream, sums, d_w, d_b, (long)hw, C, total, eps,
                        d_mean, d_rstd, d_scale, d_shift);
@@ -648,7 +669,7 @@ extern "C" int octa_instnorm_lrelu_nhwc_fwd_p(octa_ctx *ctx, const void *d_x, vo
     hipLaunchKernelGGL(in_nhwc_fold_partials, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(NT), 0, stream, d_partials, tiles, C, sums);
     const int splits = nhwc_splits(ctx, B, hw);
     hipLaunchKernelGGL(in_nhwc_fwd_apply, dim3((unsigned)splits, (unsigned)B), dim3(NT), 0, stream, static_cast<const unsigned short *>(d_x),
-                       static_cast<unsigned short *>(d_y), d_w, d_b, (long)hw, C, splits, sums, slope, eps, d_mean, d_rstd);
+                       static_cast<unsigned short *>(d_y), d_w, d_b, (long)hw, C, splits, sums, slope, eps, d_mean, d_rstd, 0);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
