@@ -273,15 +273,21 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned char *lds_wave
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, int KCV, bool STATS, bool MASKED>
+// ST = 2 (stride-2 layers): the halo is (2*TH+1) x (2*TW+1) pixels and a wave's 32 output columns read every OTHER halo
+// column, so the LDS image keeps the even and the odd halo columns of a row in two planes ([row][parity][33 pixels]):
+// the 32 lanes of a tap then read 32 CONSECUTIVE LDS pixels again and the swizzle stays conflict-free. One workgroup
+// per CU (2 x 54 KB of LDS), the loads of the next slice still overlap the MFMAs of the current one.
+template <int BN, int KCV, bool STATS, bool MASKED, int ST>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                          const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
                          int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, const unsigned short *__restrict__ zero16,
                          float *__restrict__ part, int tap_mask) {
-    constexpr int IH = TH + 2, IW = TW + 2;
+    constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;
+    constexpr int PW = (IW + ST - 1) / ST;                 // pixels per LDS plane row (ST = 2: 33 even / 32 odd columns)
+    constexpr int LPIX = IH * ST * PW;                      // pixels of the LDS image
     constexpr int PP = KCV / 8, NB = BN / 32;
-    constexpr int IN_INSTR = (IH * IW * PP + 63) / 64, W_INSTR = 9 * BN * PP / 64;
+    constexpr int IN_INSTR = (LPIX * PP + 63) / 64, W_INSTR = 9 * BN * PP / 64;
     constexpr int IN_BYTES = IN_INSTR * 1024, BUF = IN_BYTES + W_INSTR * 1024;
     constexpr int IN_PW = (IN_INSTR + 3) / 4, W_PW = (W_INSTR + 3) / 4;   // wave-instructions per wave and slice
     static_assert((9 * BN * PP) % 64 == 0, "weight slice must be whole wave-instructions");
@@ -290,7 +296,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Hv = H * dil, Wv = W * dil;
-    const int iy0 = ty0 - 1, ix0 = tx0 - 1;
+    const int iy0 = ty0 * ST - 1, ix0 = tx0 * ST - 1;
     const int m = lane & 31, kg = lane >> 5;
 
     // per-lane sources of this wave's DMA slots (the same pixels / weight rows for every channel slice)
@@ -298,8 +304,10 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
 #pragma unroll
     for (int i = 0; i < IN_PW; i++) {
         const int slot = (wv + 4 * i) * 64 + lane, p = slot / PP, q = (slot % PP) ^ glds_swz<PP>(p);
-        const int yy = iy0 + p / IW, xx = ix0 + p % IW;
-        bool ok = p < IH * IW && yy >= 0 && yy < Hv && xx >= 0 && xx < Wv;
+        // LDS pixel p = (halo row * ST + column parity) * PW + column / ST
+        const int prow = p / PW, hy = prow / ST, hx = (p % PW) * ST + prow % ST;
+        const int yy = iy0 + hy, xx = ix0 + hx;
+        bool ok = p < LPIX && hx < IW && yy >= 0 && yy < Hv && xx >= 0 && xx < Wv;
         if (ok && dil == 2) ok = !((yy | xx) & 1);
         const int sy = dil == 2 ? yy >> 1 : yy, sx = dil == 2 ? xx >> 1 : xx;
         in_src[i] = ok ? ((sy * W + sx) << 2) | q : -1;
@@ -354,7 +362,8 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
                     bf16x8 a[2], b[NB];
 #pragma unroll
                     for (int rr = 0; rr < 2; rr++) {
-                        const int p = (2 * wv + rr + r) * IW + m + s;
+                        const int hy = (2 * wv + rr) * ST + r;                       // halo row; halo column = m * ST + s
+                        const int p = (hy * ST + (ST == 2 ? (s & 1) : 0)) * PW + m + (ST == 2 ? (s >> 1) : s);
                         a[rr] = *reinterpret_cast<const bf16x8 *>(s_in + (p * PP + (qa ^ glds_swz<PP>(p))) * 16);
                     }
 #pragma unroll
@@ -428,16 +437,16 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
     }
 }
 
-template <int BN, int KCV>
+template <int BN, int KCV, int ST = 1>
 int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
                      int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, float *part, int tap_mask, hipStream_t stream) {
-    constexpr int IH = TH + 2, IW = TW + 2, PP = KCV / 8;
-    constexpr int BUF = ((IH * IW * PP + 63) / 64 + 9 * BN * PP / 64) * 1024;
+    constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3, PP = KCV / 8;
+    constexpr int BUF = ((IH * ST * ((IW + ST - 1) / ST) * PP + 63) / 64 + 9 * BN * PP / 64) * 1024;
     constexpr int OUT = TH * TW * (BN * 2 + 16);
     const size_t lds = 2 * BUF > OUT ? 2 * BUF : OUT;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    auto kern = part ? conv3x3_nhwc_glds_kernel<BN, KCV, true, true>
-                     : (tap_mask != 0x1ff ? conv3x3_nhwc_glds_kernel<BN, KCV, false, true> : conv3x3_nhwc_glds_kernel<BN, KCV, false, false>);
+    auto kern = part ? conv3x3_nhwc_glds_kernel<BN, KCV, true, true, ST>
+                     : (tap_mask != 0x1ff ? conv3x3_nhwc_glds_kernel<BN, KCV, false, true, ST> : conv3x3_nhwc_glds_kernel<BN, KCV, false, false, ST>);
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
     hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask);
@@ -496,9 +505,12 @@ extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void
     const bool wide = (Cout % 64 == 0) && (CY1 % 64 == 0);   // a 64-channel block must not straddle the output split
     // plain stride-1 layers: the DMA-staged kernel (OCTA_CONV_GLDS=0 selects the register-staged one, =16 (default) / =32 the slice depth)
     static const int glds_mode = [] { const char *e = getenv("OCTA_CONV_GLDS"); return e ? atoi(e) : 16; }();
-    if (glds_mode && stride == 1 && out_scale == 1 && !d_scale1 && !d_scale2) {
+    if (glds_mode && out_scale == 1 && !d_scale1 && !d_scale2) {
         const unsigned short *z = zero_page(ctx);
         if (!z) return -1;
+        if (stride == 2)
+            return wide ? launch_conv_glds<64, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, stream)
+                        : launch_conv_glds<32, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, stream);
         if (glds_mode == 16)
             return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, stream)
                         : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, stream);

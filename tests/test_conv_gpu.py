@@ -206,7 +206,10 @@ def test_normalise_on_load_equals_materialised(hip_lib_built):
                 res.append(net(x).float())
         finally:
             networks.USE_LAZY_NORM = False
-    assert (res[0] - res[1]).abs().max().item() <= 0.02 * max(res[0].abs().max().item(), 1.0)
+    # 20 bf16 layers with instance norms over as few as 32 pixels: a last-bit difference per layer (different slice depth of
+    # the two kernels) grows to a few percent of the logit range; a wrong scale / shift would be off by O(1)
+    assert (res[0] - res[1]).abs().max().item() <= 0.05 * max(res[0].abs().max().item(), 1.0)
+    assert (res[0] - res[1]).abs().mean().item() <= 0.01 * max(res[0].abs().max().item(), 1.0)
 
 
 def test_head_kernels(hip_lib_built):
