@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                          const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
                          int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, const unsigned short *__restrict__ zero16,
-                         float *__restrict__ part, int tap_mask) {
+                         float *__restrict__ part, int tap_mask, int osc, int ooy, int oox) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;
     constexpr int PW = (IW + ST - 1) / ST;                 // pixels per LDS plane row (ST = 2: 33 even / 32 odd columns)
     constexpr int LPIX = IH * ST * PW;                      // pixels of the LDS image
@@ -378,6 +378,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
                             acc[rr][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b[nb], acc[rr][nb], 0, 0, 0);
                 }
     }
+    if (!MASKED) { osc = 1; ooy = 0; oox = 0; }   // the scattered store is compiled into the masked variant only (its only user)
     // epilogue of the plain kernel: tile through LDS, 16-byte coalesced NHWC stores
     unsigned short *Yo = co0 < CY1 ? Y : Y2;
     const int ys = co0 < CY1 ? CY1 : Cout - CY1, yb = co0 < CY1 ? co0 : co0 - CY1;
@@ -398,8 +399,11 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
     for (int i = threadIdx.x; i < TH * TW * PIECES; i += CONV_THREADS) {
         const int p = i / PIECES, q = i % PIECES;
         const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+        // scattered output (osc = 2): result pixel (oy, ox) lands at (oy * 2 + ooy, ox * 2 + oox) of an image twice as large --
+        // one parity class of a zero-insertion-free stride-2 data gradient / 2x2 transposed convolution
         if (oy < Ho && ox < Wo)
-            *reinterpret_cast<uint4 *>(Yo + (((size_t)n * Ho + oy) * Wo + ox) * ys + yb + q * 8) = *reinterpret_cast<const uint4 *>(s_out + p * OP + q * 16);
+            *reinterpret_cast<uint4 *>(Yo + (((size_t)n * Ho * osc + oy * osc + ooy) * (Wo * osc) + ox * osc + oox) * ys + yb + q * 8) =
+                *reinterpret_cast<const uint4 *>(s_out + p * OP + q * 16);
     }
     // InstanceNorm statistics of the layer that follows: per tile and output channel the sum and the sum of squares of the
     // bf16-ROUNDED results (what a statistics pass would read back) -> part[n][tile][Cout][2]; saves that pass over Y.
@@ -439,17 +443,18 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
 
 template <int BN, int KCV, int ST = 1>
 int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
-                     int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, float *part, int tap_mask, hipStream_t stream) {
+                     int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, float *part, int tap_mask,
+                     int osc, int ooy, int oox, hipStream_t stream) {
     constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3, PP = KCV / 8;
     constexpr int BUF = ((IH * ST * ((IW + ST - 1) / ST) * PP + 63) / 64 + 9 * BN * PP / 64) * 1024;
     constexpr int OUT = TH * TW * (BN * 2 + 16);
     const size_t lds = 2 * BUF > OUT ? 2 * BUF : OUT;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
     auto kern = part ? conv3x3_nhwc_glds_kernel<BN, KCV, true, true, ST>
-                     : (tap_mask != 0x1ff ? conv3x3_nhwc_glds_kernel<BN, KCV, false, true, ST> : conv3x3_nhwc_glds_kernel<BN, KCV, false, false, ST>);
+                     : (tap_mask != 0x1ff || osc != 1 ? conv3x3_nhwc_glds_kernel<BN, KCV, false, true, ST> : conv3x3_nhwc_glds_kernel<BN, KCV, false, false, ST>);
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
-    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask, osc, ooy, oox);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -505,17 +510,17 @@ extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void
     const bool wide = (Cout % 64 == 0) && (CY1 % 64 == 0);   // a 64-channel block must not straddle the output split
     // plain stride-1 layers: the DMA-staged kernel (OCTA_CONV_GLDS=0 selects the register-staged one, =16 (default) / =32 the slice depth)
     static const int glds_mode = [] { const char *e = getenv("OCTA_CONV_GLDS"); return e ? atoi(e) : 16; }();
-    if (glds_mode && out_scale == 1 && !d_scale1 && !d_scale2) {
+    if (glds_mode && !d_scale1 && !d_scale2) {
         const unsigned short *z = zero_page(ctx);
         if (!z) return -1;
         if (stride == 2)
-            return wide ? launch_conv_glds<64, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, stream)
-                        : launch_conv_glds<32, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, stream);
+            return wide ? launch_conv_glds<64, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream)
+                        : launch_conv_glds<32, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream);
         if (glds_mode == 16)
-            return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, stream)
-                        : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, stream);
-        return wide ? launch_conv_glds<64, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, stream)
-                    : launch_conv_glds<32, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, stream);
+            return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream)
+                        : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream);
+        return wide ? launch_conv_glds<64, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream)
+                    : launch_conv_glds<32, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream);
     }
     if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream)
                                  : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream);

@@ -136,10 +136,12 @@ def conv_transpose_2x2_fwd(x, weight):
     return y
 
 
-# Measured on MI355X (B=4, 1216^2 U-Net step): the four scattered launches are no faster than one launch over the
-# zero-inserted input (32.6 vs 32.1 ms per step: stride-2 stores and four passes over the input cost what the skipped
-# multiplications save), so the virtual-zero-insertion form stays the default.
-USE_PARITY_SCATTER = False
+# Measured on MI355X (B=4, 1216^2 U-Net step), twice: with the register-staged kernels (32.6 vs 32.1 ms) and again with the
+# DMA-staged ones (stride-2 data gradient 22.0 vs 21.8 ms, transposed convolution 22.15 vs 21.8 ms in the same session): the
+# four scattered launches are no faster than one launch over the zero-inserted input -- four passes over the input, four
+# weight repacks and 64/128-byte scattered stores cost what the skipped multiplications save. The zero-insertion form stays.
+USE_PARITY_SCATTER = False          # stride-2 data gradient as four parity classes
+USE_PARITY_SCATTER_CONVT = False    # 2x2 transposed convolution forward as four 1x1 parity classes
 
 
 # ---- autograd bindings ---------------------------------------------------------------------------------------------
@@ -368,7 +370,7 @@ class _ConvT2x2NHWC(torch.autograd.Function):
         cin, cout = weight.shape[0], weight.shape[1]
         wc = weight.new_zeros((cin, cout, 3, 3))
         wc[:, :, 1:, 1:] = weight
-        if USE_PARITY_SCATTER:
+        if USE_PARITY_SCATTER_CONVT:
             y = conv_transpose_2x2_fwd(x, weight)
         else:
             # wc has taps r, s in {1, 2}; flipped for the data-gradient form they sit at r, s in {0, 1}
