@@ -1000,9 +1000,10 @@ conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restr
 __global__ void __launch_bounds__(256)
 conv3x3_c1_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ dY, float *__restrict__ dW /* [Cout][9] */,
                         int N, int H, int W, int Cout) {
-    extern __shared__ float s_acc[];  // [Cout][9]
+    extern __shared__ float s_mem[];
+    float *s_acc = s_mem;                 // [Cout][9]
+    float *s_x = s_mem + Cout * 9;        // [3][W + 2]: image rows y-1, y, y+1 with zero borders (the nine taps of every item)
     for (int i = threadIdx.x; i < Cout * 9; i += 256) s_acc[i] = 0.f;
-    __syncthreads();
     const int groups = Cout / 8, gshift = 31 - __clz(groups);
     float acc[8][9];
 #pragma unroll
@@ -1011,11 +1012,17 @@ conv3x3_c1_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned sho
         for (int t = 0; t < 9; t++) acc[k][t] = 0.f;
     // 256 is a multiple of `groups`, so a thread keeps its channel group q for the whole loop
     const int q = threadIdx.x & (groups - 1);
-    const int items = W * groups;
+    const int items = W * groups, WP = W + 2;
     for (int row = blockIdx.x; row < N * H; row += gridDim.x) {
         const int y = row % H;
         const long n = row / H;
-        // two 16-byte pieces of dY per trip, both loads issued before either is used (the kernel is latency-bound otherwise)
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * WP; i += 256) {
+            const int r = i / WP, xx = i % WP - 1, yy = y + r - 1;
+            s_x[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
+        }
+        __syncthreads();
+        // two 16-byte pieces of dY per trip, both loads issued before either is used
         for (int j = threadIdx.x; j < items; j += 512) {
             const int x0 = j >> gshift, j1 = j + 256, x1 = j1 >> gshift;
             const bool has1 = j1 < items;
@@ -1034,8 +1041,7 @@ conv3x3_c1_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned sho
                 for (int r = 0; r < 3; r++)
 #pragma unroll
                     for (int s = 0; s < 3; s++) {
-                        const int yy = y + r - 1, xx = x + s - 1;
-                        const float in = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
+                        const float in = s_x[r * WP + x + s];
 #pragma unroll
                         for (int k = 0; k < 8; k++) acc[k][3 * r + s] += d[k] * in;
                     }
@@ -1080,7 +1086,8 @@ extern "C" int octa_conv3x3_c1_wgrad(octa_ctx *ctx, const void *d_x, const void 
     long blocks = 8L * ctx->num_cus;
     if (blocks > (long)N * H) blocks = (long)N * H;
     (void)groups;   // gridDim.x * 256 is a multiple of `groups` for any block count (256 % groups == 0)
-    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * Cout * 9, stream, static_cast<const unsigned short *>(d_x),
+    if (W > 8192) { octa::set_error("octa_conv3x3_c1_wgrad: W > 8192"); return -2; }
+    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * (Cout * 9 + 3 * (W + 2)), stream, static_cast<const unsigned short *>(d_x),
                        static_cast<const unsigned short *>(d_dy), d_dw, N, H, W, Cout);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
