@@ -450,7 +450,7 @@ int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, 
     constexpr int OUT = TH * TW * (BN * 2 + 16);
     const size_t lds = 2 * BUF > OUT ? 2 * BUF : OUT;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    auto kern = part ? conv3x3_nhwc_glds_kernel<BN, KCV, true, true, ST>
+    auto kern = part ? (tap_mask != 0x1ff || osc != 1 ? conv3x3_nhwc_glds_kernel<BN, KCV, true, true, ST> : conv3x3_nhwc_glds_kernel<BN, KCV, true, false, ST>)
                      : (tap_mask != 0x1ff || osc != 1 ? conv3x3_nhwc_glds_kernel<BN, KCV, false, true, ST> : conv3x3_nhwc_glds_kernel<BN, KCV, false, false, ST>);
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);

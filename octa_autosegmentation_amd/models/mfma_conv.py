@@ -237,9 +237,10 @@ class _Conv3x3C1(torch.autograd.Function):
 
 
 def conv3x3(x, weight, stride=1, want_stats=False):
-    if (x.shape[-1] == 1 and weight.shape[1] == 1 and stride == 1 and not want_stats and weight.shape[0] in (8, 16, 32, 64)
+    if (x.shape[-1] == 1 and weight.shape[1] == 1 and stride == 1 and weight.shape[0] in (8, 16, 32, 64)
             and not x.requires_grad):
-        return _Conv3x3C1.apply(x, weight)
+        y = _Conv3x3C1.apply(x, weight)              # streaming first-layer kernels: no statistics epilogue (None = the
+        return (y, None) if want_stats else y        # norm runs its own statistics pass)
     """want_stats: also return the per-tile statistics for instance_norm_leaky_relu_nhwc(..., partials=)."""
     return _Conv3x3NHWC.apply(x, weight, stride, want_stats)
 

@@ -34,7 +34,8 @@ USE_LAZY_NORM = False
 # InstanceNorm statistics accumulated in the convolution epilogue (conv.hip _fwd5) instead of a statistics pass:
 # implemented and tested, measured slower too (33.6 vs 32.1 ms: the MFMA kernels are the critical resource, the
 # statistics pass they would save is a cheap HBM-bound stream)
-USE_EPILOGUE_STATS = False
+import os as _os
+USE_EPILOGUE_STATS = _os.environ.get('OCTA_EPI_STATS', '0') == '1'
 
 
 class _Conv(nn.Module):
