@@ -205,6 +205,13 @@ int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const void *d_x2, i
 int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin,
                             int Cout, void *stream);
 
+/* 4x4 convolution, stride 1, zero padding `pad`, on the same DMA-staged MFMA kernel (KS = 4 instantiation): the inner
+ * layers of the 70x70 PatchGAN (models/networks.py:445-500 NLayerDiscriminator: Conv2d(ndf*m, ndf*2m, 4, 1, 1)).
+ * d_x [N][H][W][Cin] bf16, d_w [16][Cout][Cin] bf16 (tap 4r+s), d_y [N][H+2pad-3][W+2pad-3][Cout] bf16; Cin, Cout
+ * multiples of 32. Data gradient = the same entry point on dy with flipped + transposed weights and pad' = 3 - pad. */
+int octa_conv4x4_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int pad,
+                          void *stream);
+
 /* 1x1 convolution head with ONE output channel and bias (DynUNet's UnetOutBlock, 32 -> 1; networks.py:6 / MONAI):
  * y[p] = bias + sum_c x[p][c] w[c] over NHWC bf16 pixels (y bf16 [npix]); backward: dx[p][c] = dy[p] w[c] (bf16),
  * dw[c] = sum_p x[p][c] dy[p], db = sum_p dy[p] (float32, overwritten). HBM-bound streaming kernels. */

@@ -277,26 +277,26 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned char *lds_wave
 // column, so the LDS image keeps the even and the odd halo columns of a row in two planes ([row][parity][33 pixels]):
 // the 32 lanes of a tap then read 32 CONSECUTIVE LDS pixels again and the swizzle stays conflict-free. One workgroup
 // per CU (2 x 54 KB of LDS), the loads of the next slice still overlap the MFMAs of the current one.
-template <int BN, int KCV, bool STATS, bool MASKED, int ST>
+template <int BN, int KCV, bool STATS, bool MASKED, int ST, int KS>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                          const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
                          int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, const unsigned short *__restrict__ zero16,
-                         float *__restrict__ part, int tap_mask, int osc, int ooy, int oox) {
-    constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3;
+                         float *__restrict__ part, int tap_mask, int osc, int ooy, int oox, int pad) {
+    constexpr int IH = (TH - 1) * ST + KS, IW = (TW - 1) * ST + KS;   // KS x KS taps (3: the U-Net / generator layers, 4: the PatchGAN)
     constexpr int PW = (IW + ST - 1) / ST;                 // pixels per LDS plane row (ST = 2: 33 even / 32 odd columns)
     constexpr int LPIX = IH * ST * PW;                      // pixels of the LDS image
     constexpr int PP = KCV / 8, NB = BN / 32;
-    constexpr int IN_INSTR = (LPIX * PP + 63) / 64, W_INSTR = 9 * BN * PP / 64;
+    constexpr int IN_INSTR = (LPIX * PP + 63) / 64, W_INSTR = KS * KS * BN * PP / 64;
     constexpr int IN_BYTES = IN_INSTR * 1024, BUF = IN_BYTES + W_INSTR * 1024;
     constexpr int IN_PW = (IN_INSTR + 3) / 4, W_PW = (W_INSTR + 3) / 4;   // wave-instructions per wave and slice
-    static_assert((9 * BN * PP) % 64 == 0, "weight slice must be whole wave-instructions");
+    static_assert((KS * KS * BN * PP) % 64 == 0, "weight slice must be whole wave-instructions");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tile = blockIdx.x, n = blockIdx.z, co0 = blockIdx.y * BN;
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Hv = H * dil, Wv = W * dil;
-    const int iy0 = ty0 * ST - 1, ix0 = tx0 * ST - 1;
+    const int iy0 = ty0 * ST - pad, ix0 = tx0 * ST - pad;
     const int m = lane & 31, kg = lane >> 5;
 
     // per-lane sources of this wave's DMA slots (the same pixels / weight rows for every channel slice)
@@ -352,12 +352,12 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
         if (k + 1 < nsl) issue((k + 1) * KCV, smem + ((k + 1) & 1) * BUF);
         const unsigned char *s_in = smem + (k & 1) * BUF, *s_w = s_in + IN_BYTES;
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+        for (int r = 0; r < KS; r++)
 #pragma unroll
-            for (int s = 0; s < 3; s++)
+            for (int s = 0; s < KS; s++)
 #pragma unroll
                 for (int ks = 0; ks < KCV / 16; ks++) {
-                    if (MASKED && !((tap_mask >> (3 * r + s)) & 1)) continue;   // taps whose weights are structurally zero
+                    if (MASKED && !((tap_mask >> (KS * r + s)) & 1)) continue;   // taps whose weights are structurally zero
                     const int qa = ks * 2 + kg;
                     bf16x8 a[2], b[NB];
 #pragma unroll
@@ -368,7 +368,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
                     }
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
-                        const int rw = (3 * r + s) * BN + nb * 32 + m;
+                        const int rw = (KS * r + s) * BN + nb * 32 + m;
                         b[nb] = *reinterpret_cast<const bf16x8 *>(s_w + (rw * PP + (qa ^ glds_swz<PP>(rw))) * 16);
                     }
 #pragma unroll
@@ -441,20 +441,23 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
     }
 }
 
-template <int BN, int KCV, int ST = 1>
+template <int BN, int KCV, int ST = 1, int KS = 3>
 int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
                      int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, float *part, int tap_mask,
-                     int osc, int ooy, int oox, hipStream_t stream) {
-    constexpr int IH = (TH - 1) * ST + 3, IW = (TW - 1) * ST + 3, PP = KCV / 8;
-    constexpr int BUF = ((IH * ST * ((IW + ST - 1) / ST) * PP + 63) / 64 + 9 * BN * PP / 64) * 1024;
+                     int osc, int ooy, int oox, hipStream_t stream, int pad = 1) {
+    constexpr int IH = (TH - 1) * ST + KS, IW = (TW - 1) * ST + KS, PP = KCV / 8;
+    constexpr int BUF = ((IH * ST * ((IW + ST - 1) / ST) * PP + 63) / 64 + KS * KS * BN * PP / 64) * 1024;
     constexpr int OUT = TH * TW * (BN * 2 + 16);
     const size_t lds = 2 * BUF > OUT ? 2 * BUF : OUT;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    auto kern = part ? (tap_mask != 0x1ff || osc != 1 ? conv3x3_nhwc_glds_kernel<BN, KCV, true, true, ST> : conv3x3_nhwc_glds_kernel<BN, KCV, true, false, ST>)
-                     : (tap_mask != 0x1ff || osc != 1 ? conv3x3_nhwc_glds_kernel<BN, KCV, false, true, ST> : conv3x3_nhwc_glds_kernel<BN, KCV, false, false, ST>);
+    auto kern = conv3x3_nhwc_glds_kernel<BN, KCV, false, false, ST, KS>;
+    if constexpr (KS == 3) {
+        if (part) kern = tap_mask != 0x1ff || osc != 1 ? conv3x3_nhwc_glds_kernel<BN, KCV, true, true, ST, 3> : conv3x3_nhwc_glds_kernel<BN, KCV, true, false, ST, 3>;
+        else if (tap_mask != 0x1ff || osc != 1) kern = conv3x3_nhwc_glds_kernel<BN, KCV, false, true, ST, 3>;
+    }
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
-    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask, osc, ooy, oox);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask, osc, ooy, oox, pad);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -552,6 +555,23 @@ extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void
 extern "C" int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin,
                                      int Cout, int stride, int in_dilation, void *stream_) {
     return octa_conv3x3_nhwc_fwd2(ctx, d_x, nullptr, Cin, d_w, d_y, nullptr, Cout, N, H, W, Cin, Cout, stride, in_dilation, 0x1ff, stream_);
+}
+
+extern "C" int octa_conv4x4_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int pad,
+                                     void *stream_) {
+    if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv4x4_nhwc_fwd: null pointer"); return -2; }
+    if (N <= 0 || N > 65535 || H <= 0 || W <= 0 || pad < 0 || pad > 3 || H + 2 * pad < 4 || W + 2 * pad < 4) { octa::set_error("octa_conv4x4_nhwc_fwd: bad shape"); return -2; }
+    if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv4x4_nhwc_fwd: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const unsigned short *z = zero_page(ctx);
+    if (!z) return -1;
+    const int Ho = H + 2 * pad - 3, Wo = W + 2 * pad - 3;
+    const unsigned short *X = static_cast<const unsigned short *>(d_x), *Wt = static_cast<const unsigned short *>(d_w);
+    unsigned short *Y = static_cast<unsigned short *>(d_y);
+    if (Cout % 64 == 0)
+        return launch_conv_glds<64, 16, 1, 4>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, nullptr, 0xffff, 1, 0, 0, stream, pad);
+    return launch_conv_glds<32, 16, 1, 4>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, nullptr, 0xffff, 1, 0, 0, stream, pad);
 }
 
 // ---- weight gradient (stride 1) ----------------------------------------------------------------------------------

@@ -579,3 +579,51 @@ def conv3x3_lazy(a, weight, stride=1, b=None, slope=LRELU_SLOPE):
     """a, b: lazy activations (t, scale, shift) (scale None = plain tensor); b is virtually concatenated after a."""
     t2, s2, h2 = b if b is not None else (None, None, None)
     return _ConvLazy.apply(a[0], a[1], a[2], t2, s2, h2, weight, stride, slope)
+
+
+# ---- 4x4 stride-1 convolution (PatchGAN inner layers) -----------------------------------------------------------------
+
+def conv4x4_nhwc(x, wt, pad):
+    """x [N,H,W,Cin] bf16, wt [16,Cout,Cin] bf16 (tap 4r+s) -> [N,H+2pad-3,W+2pad-3,Cout] bf16 (csrc/conv.hip, KS = 4)."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and wt.dtype == torch.bfloat16 and wt.is_contiguous()
+    n, h, w, cin = x.shape
+    cout = wt.shape[1]
+    y = torch.empty((n, h + 2 * pad - 3, w + 2 * pad - 3, cout), dtype=torch.bfloat16, device=x.device)
+    rc = _native.lib().octa_conv4x4_nhwc_fwd(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wt.data_ptr()),
+                                             ctypes.c_void_p(y.data_ptr()), n, h, w, cin, cout, int(pad), _native.current_stream_ptr())
+    _native.check(rc, "octa_conv4x4_nhwc_fwd")
+    return y
+
+
+class _Conv4x4NHWC(torch.autograd.Function):
+    """Conv2d(Cin, Cout, 4, stride 1, padding 1) without bias on NHWC bf16: forward and data gradient on the MFMA kernel; the
+    weight gradient (16 taps = 256 accumulator registers per wave in the 3x3 kernel's scheme) is MIOpen's, called on
+    channels-last views of the same tensors (no layout copies)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        wt = weight.to(torch.bfloat16).permute(2, 3, 0, 1).reshape(16, weight.shape[0], weight.shape[1]).contiguous()
+        ctx.save_for_backward(x, weight)
+        return conv4x4_nhwc(x, wt, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dx = full correlation of dy with the flipped kernel, channels transposed: padding 3 - 1 = 2
+            wd = weight.to(torch.bfloat16).flip(2, 3).permute(2, 3, 1, 0).reshape(16, weight.shape[1], weight.shape[0]).contiguous()
+            dx = conv4x4_nhwc(dy, wd, 2)
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), weight.to(torch.bfloat16), None,
+                                                     [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].to(weight.dtype)
+        return dx, dw
+
+
+def conv4x4(x, weight):
+    """weight: the torch parameter [Cout, Cin, 4, 4]; stride 1, padding 1, no bias."""
+    return _Conv4x4NHWC.apply(x, weight)

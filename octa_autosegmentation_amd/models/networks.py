@@ -420,8 +420,38 @@ class NLayerDiscriminator(nn.Module):
                 nn.Conv2d(ndf * mult, 1, 4, 1, 1)]
         self.model = nn.Sequential(*seq)
 
+    # ---- inner layers channels-last in bf16: 4x4 convolutions on the MFMA kernel (csrc/conv.hip, KS = 4), InstanceNorm +
+    # LeakyReLU(0.2) and blur-downsampling on the NHWC streaming kernels. A convolution bias in front of an InstanceNorm
+    # without affine is subtracted again by the norm and is not added here (its gradient is zero in the reference too).
+    # The 1 -> ndf stem (+ bias, LeakyReLU) and the ndf*8 -> 1 head are not matrix-core shaped and stay torch's.
     def forward(self, x):
-        return self.model(x)
+        use_mfma = (USE_MFMA_CONV and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
+        if not use_mfma:
+            return self.model(x)
+        from . import mfma_conv as mc
+        mods = list(self.model)
+        nhwc = False
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            fused = (isinstance(m, nn.Conv2d) and m.kernel_size == (4, 4) and m.stride == (1, 1) and m.padding == (1, 1)
+                     and m.in_channels % 32 == 0 and m.out_channels % 32 == 0 and i + 2 < len(mods)
+                     and isinstance(mods[i + 1], nn.InstanceNorm2d) and not mods[i + 1].affine and isinstance(mods[i + 2], nn.LeakyReLU))
+            on_path = fused or (nhwc and isinstance(m, Downsample))
+            if on_path and not nhwc:
+                x, nhwc = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), True
+            elif not on_path and nhwc:
+                x, nhwc = x.permute(0, 3, 1, 2), False          # a channels-last view: torch's convolution takes it as it is
+            if fused:
+                x = mc.instance_norm_leaky_relu_nhwc(mc.conv4x4(x, m.weight), None, None, mods[i + 2].negative_slope, mods[i + 1].eps)
+                i += 3
+            elif on_path:
+                x = m(x, "nhwc")
+                i += 1
+            else:
+                x = m(x)
+                i += 1
+        return x.permute(0, 3, 1, 2).contiguous() if nhwc else x
 
 
 def resnetGenerator9():

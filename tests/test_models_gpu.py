@@ -125,3 +125,55 @@ def test_resnet_generator_mfma_blocks_match_torch_autocast():
     assert (outs[0] - outs[1]).abs().max().item() < 0.06              # sigmoid outputs in [0, 1], bf16 through 9 blocks
     cos = torch.dot(grads[0].flatten(), grads[1].flatten()) / (grads[0].norm() * grads[1].norm())
     assert cos.item() > 0.9
+
+
+def test_conv4x4_mfma_matches_torch():
+    """4x4 stride-1 padding-1 convolution (PatchGAN inner layers) on the MFMA kernel: forward, data gradient, weight gradient
+    against torch fp32 on the same bf16-rounded operands, odd sizes included."""
+    from octa_autosegmentation_amd.models import mfma_conv as mc
+    torch.manual_seed(11)
+    for (n, h, w, cin, cout) in [(2, 19, 37, 32, 64), (1, 75, 75, 128, 256), (2, 8, 8, 64, 32), (1, 151, 151, 64, 128)]:
+        x = torch.randn(n, h, w, cin, device="cuda").to(torch.bfloat16)
+        wgt = (torch.randn(cout, cin, 4, 4, device="cuda") / (4 * cin ** 0.5)).to(torch.bfloat16).float()
+        xa = x.clone().requires_grad_(True)
+        wa = wgt.clone().requires_grad_(True)
+        y = mc.conv4x4(xa, wa)
+        xr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+        wr = wgt.clone().requires_grad_(True)
+        yr = torch.nn.functional.conv2d(xr, wr, padding=1)
+        assert y.shape == (n, h - 1, w - 1, cout)
+        dy = torch.randn_like(yr).to(torch.bfloat16)
+        y.backward(dy.permute(0, 2, 3, 1).contiguous())
+        yr.backward(dy.float())
+        sc = lambda t: max(t.abs().max().item(), 1e-6)
+        assert (y.float().permute(0, 3, 1, 2) - yr).abs().max().item() <= 2 ** -7 * sc(yr)
+        assert (xa.grad.float().permute(0, 3, 1, 2) - xr.grad).abs().max().item() <= 2 ** -7 * sc(xr.grad)
+        assert (wa.grad - wr.grad).abs().max().item() <= 2e-2 * sc(wr.grad)       # MIOpen's bf16 weight-gradient kernel
+
+
+def test_patchgan_mfma_layers_match_torch_autocast():
+    """PatchGAN under bf16 autocast: inner layers on the MFMA / NHWC kernels vs the plain torch modules under the same autocast."""
+    from octa_autosegmentation_amd.models import networks
+    torch.manual_seed(4)
+    net = networks.patchGAN70x70().cuda()
+    networks.init_weights(net, "kaiming") if hasattr(networks, "init_weights") else None
+    x = torch.rand(2, 1, 128, 128, device="cuda")
+    outs, grads = [], []
+    for flag in (True, False):
+        networks.USE_MFMA_CONV = flag
+        try:
+            net.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = net(xi)
+            (y.float() ** 2).mean().backward()
+            outs.append(y.float().detach())
+            grads.append((xi.grad.detach(), {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if p.grad is not None and p.dim() == 4}))
+        finally:
+            networks.USE_MFMA_CONV = True
+    assert outs[0].shape == outs[1].shape == (2, 1, 14, 14)
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+    assert cos(outs[0], outs[1]) > 0.99
+    assert cos(grads[0][0], grads[1][0]) > 0.9
+    assert set(grads[0][1]) == set(grads[1][1])                       # every convolution weight has a gradient on both paths
+    assert min(cos(grads[0][1][k], grads[1][1][k]) for k in grads[1][1]) > 0.9
