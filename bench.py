@@ -201,7 +201,7 @@ def main():
     if not args.no_train and not args.no_end_to_end:
         import train_synthetic
         torch.cuda.empty_cache()
-        e2e_info = train_synthetic.run(steps=60, batch=args.train_batch, gen_batch=128, seed0=500000, log=False)
+        e2e_info = train_synthetic.run(steps=160, batch=args.train_batch, gen_batch=128, seed0=500000, log=False)   # 5 generator batches: past the queue-filling transient
 
     dt = sharding.max_over_ranks(dt, dist, dev)
 
