@@ -277,13 +277,14 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned char *lds_wave
 // column, so the LDS image keeps the even and the odd halo columns of a row in two planes ([row][parity][33 pixels]):
 // the 32 lanes of a tap then read 32 CONSECUTIVE LDS pixels again and the swizzle stays conflict-free. One workgroup
 // per CU (2 x 54 KB of LDS), the loads of the next slice still overlap the MFMAs of the current one.
-template <int BN, int KCV, bool STATS, bool MASKED, int ST, int KS>
-__global__ void __launch_bounds__(CONV_THREADS)
+template <int BN, int KCV, bool STATS, bool MASKED, int ST, int KS, int THT>
+__global__ void __launch_bounds__(CONV_THREADS, (THT == 16 ? 2 : 1))
 conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                          const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
                          int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, const unsigned short *__restrict__ zero16,
                          float *__restrict__ part, int tap_mask, int osc, int ooy, int oox, int pad) {
-    constexpr int IH = (TH - 1) * ST + KS, IW = (TW - 1) * ST + KS;   // KS x KS taps (3: the U-Net / generator layers, 4: the PatchGAN)
+    constexpr int RPW = THT / 4;                           // tile rows per wave (THT = 8: two, THT = 16: four)
+    constexpr int IH = (THT - 1) * ST + KS, IW = (TW - 1) * ST + KS;   // KS x KS taps (3: the U-Net / generator layers, 4: the PatchGAN)
     constexpr int PW = (IW + ST - 1) / ST;                 // pixels per LDS plane row (ST = 2: 33 even / 32 odd columns)
     constexpr int LPIX = IH * ST * PW;                      // pixels of the LDS image
     constexpr int PP = KCV / 8, NB = BN / 32;
@@ -293,7 +294,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
     static_assert((KS * KS * BN * PP) % 64 == 0, "weight slice must be whole wave-instructions");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tile = blockIdx.x, n = blockIdx.z, co0 = blockIdx.y * BN;
-    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+    const int ty0 = (tile / tiles_x) * THT, tx0 = (tile % tiles_x) * TW;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Hv = H * dil, Wv = W * dil;
     const int iy0 = ty0 * ST - pad, ix0 = tx0 * ST - pad;
@@ -337,9 +338,9 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
         }
     };
 
-    f32x16 acc[2][NB];
+    f32x16 acc[RPW][NB];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < RPW; a++)
 #pragma unroll
         for (int b = 0; b < NB; b++)
 #pragma unroll
@@ -359,10 +360,10 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
                 for (int ks = 0; ks < KCV / 16; ks++) {
                     if (MASKED && !((tap_mask >> (KS * r + s)) & 1)) continue;   // taps whose weights are structurally zero
                     const int qa = ks * 2 + kg;
-                    bf16x8 a[2], b[NB];
+                    bf16x8 a[RPW], b[NB];
 #pragma unroll
-                    for (int rr = 0; rr < 2; rr++) {
-                        const int hy = (2 * wv + rr) * ST + r;                       // halo row; halo column = m * ST + s
+                    for (int rr = 0; rr < RPW; rr++) {
+                        const int hy = (RPW * wv + rr) * ST + r;                       // halo row; halo column = m * ST + s
                         const int p = (hy * ST + (ST == 2 ? (s & 1) : 0)) * PW + m + (ST == 2 ? (s >> 1) : s);
                         a[rr] = *reinterpret_cast<const bf16x8 *>(s_in + (p * PP + (qa ^ glds_swz<PP>(p))) * 16);
                     }
@@ -372,7 +373,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
                         b[nb] = *reinterpret_cast<const bf16x8 *>(s_w + (rw * PP + (qa ^ glds_swz<PP>(rw))) * 16);
                     }
 #pragma unroll
-                    for (int rr = 0; rr < 2; rr++)
+                    for (int rr = 0; rr < RPW; rr++)
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++)
                             acc[rr][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b[nb], acc[rr][nb], 0, 0, 0);
@@ -386,17 +387,17 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
     unsigned char *s_out = smem;
     __syncthreads();
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++)
+    for (int rr = 0; rr < RPW; rr++)
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int px = (k & 3) + 8 * (k >> 2) + 4 * kg;
-                *reinterpret_cast<unsigned short *>(s_out + ((2 * wv + rr) * TW + px) * OP + (nb * 32 + m) * 2) = f2bf(acc[rr][nb][k]);
+                *reinterpret_cast<unsigned short *>(s_out + ((RPW * wv + rr) * TW + px) * OP + (nb * 32 + m) * 2) = f2bf(acc[rr][nb][k]);
             }
     __syncthreads();
     constexpr int PIECES = BN / 8;
-    for (int i = threadIdx.x; i < TH * TW * PIECES; i += CONV_THREADS) {
+    for (int i = threadIdx.x; i < THT * TW * PIECES; i += CONV_THREADS) {
         const int p = i / PIECES, q = i % PIECES;
         const int oy = ty0 + p / TW, ox = tx0 + p % TW;
         // scattered output (osc = 2): result pixel (oy, ox) lands at (oy * 2 + ooy, ox * 2 + oox) of an image twice as large --
@@ -412,8 +413,8 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) { s1[nb] = 0.f; s2[nb] = 0.f; }
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int oy = ty0 + 2 * wv + rr;
+        for (int rr = 0; rr < RPW; rr++) {
+            const int oy = ty0 + RPW * wv + rr;
 #pragma unroll
             for (int nb = 0; nb < NB; nb++)
 #pragma unroll
@@ -441,19 +442,19 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
     }
 }
 
-template <int BN, int KCV, int ST = 1, int KS = 3>
+template <int BN, int KCV, int ST = 1, int KS = 3, int THT = TH>
 int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
                      int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, float *part, int tap_mask,
                      int osc, int ooy, int oox, hipStream_t stream, int pad = 1) {
-    constexpr int IH = (TH - 1) * ST + KS, IW = (TW - 1) * ST + KS, PP = KCV / 8;
+    constexpr int IH = (THT - 1) * ST + KS, IW = (TW - 1) * ST + KS, PP = KCV / 8;
     constexpr int BUF = ((IH * ST * ((IW + ST - 1) / ST) * PP + 63) / 64 + KS * KS * BN * PP / 64) * 1024;
-    constexpr int OUT = TH * TW * (BN * 2 + 16);
+    constexpr int OUT = THT * TW * (BN * 2 + 16);
     const size_t lds = 2 * BUF > OUT ? 2 * BUF : OUT;
-    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    auto kern = conv3x3_nhwc_glds_kernel<BN, KCV, false, false, ST, KS>;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + THT - 1) / THT;
+    auto kern = conv3x3_nhwc_glds_kernel<BN, KCV, false, false, ST, KS, THT>;
     if constexpr (KS == 3) {
-        if (part) kern = tap_mask != 0x1ff || osc != 1 ? conv3x3_nhwc_glds_kernel<BN, KCV, true, true, ST, 3> : conv3x3_nhwc_glds_kernel<BN, KCV, true, false, ST, 3>;
-        else if (tap_mask != 0x1ff || osc != 1) kern = conv3x3_nhwc_glds_kernel<BN, KCV, false, true, ST, 3>;
+        if (part) kern = tap_mask != 0x1ff || osc != 1 ? conv3x3_nhwc_glds_kernel<BN, KCV, true, true, ST, 3, THT> : conv3x3_nhwc_glds_kernel<BN, KCV, true, false, ST, 3, THT>;
+        else if (tap_mask != 0x1ff || osc != 1) kern = conv3x3_nhwc_glds_kernel<BN, KCV, false, true, ST, 3, THT>;
     }
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
@@ -519,6 +520,12 @@ extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void
         if (stride == 2)
             return wide ? launch_conv_glds<64, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream)
                         : launch_conv_glds<32, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream);
+        // 16-row tiles (a wave owns four tile rows: 6 operand reads per 8 MFMAs instead of 4 per 4, 72 MFMAs per barrier) from
+        // 200 output rows up: 8-14 % faster on the 304^2 / 608^2 layers (256->128 at 304^2: 1.0 PFLOP/s), no gain at 152^2
+        // (half as many workgroups: tail effects) and on the HBM-bound 1216^2 layers. OCTA_CONV_TALL=0 disables.
+        static const int tall = [] { const char *e = getenv("OCTA_CONV_TALL"); return e ? atoi(e) : 200; }();
+        if (glds_mode == 16 && tall && wide && stride == 1 && tap_mask == 0x1ff && out_scale == 1 && !d_stat_partials && Ho >= tall)
+            return launch_conv_glds<64, 16, 1, 3, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, nullptr, tap_mask, 1, 0, 0, stream);
         if (glds_mode == 16)
             return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream)
                         : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream);

@@ -25,6 +25,7 @@ def _check(got, want):
 @pytest.mark.parametrize("n,h,w,cin,cout,stride", [
     (2, 40, 70, 32, 32, 1), (1, 16, 64, 64, 64, 1), (1, 37, 45, 64, 32, 1), (2, 24, 40, 128, 64, 1),
     (1, 48, 80, 32, 64, 2), (1, 38, 66, 64, 128, 2), (1, 8, 32, 256, 256, 1),
+    (1, 213, 37, 32, 64, 1), (2, 200, 64, 64, 128, 1),     # >= 200 output rows: the 16-row-tile variant of the DMA-staged kernel
 ])
 def test_forward_matches_torch(hip_lib_built, n, h, w, cin, cout, stride):
     import torch
@@ -39,7 +40,8 @@ def test_forward_matches_torch(hip_lib_built, n, h, w, cin, cout, stride):
     _check(got, want)
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout,stride", [(1, 24, 40, 32, 64, 1), (2, 16, 32, 64, 32, 1), (1, 48, 64, 32, 64, 2), (1, 20, 36, 64, 64, 2)])
+@pytest.mark.parametrize("n,h,w,cin,cout,stride", [(1, 24, 40, 32, 64, 1), (2, 16, 32, 64, 32, 1), (1, 48, 64, 32, 64, 2), (1, 20, 36, 64, 64, 2),
+                                                   (1, 207, 40, 64, 64, 1), (1, 104, 36, 64, 64, 2)])
 def test_data_gradient_matches_torch(hip_lib_built, n, h, w, cin, cout, stride):
     import torch
     import torch.nn.functional as F
