@@ -211,6 +211,10 @@ int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, fl
  * multiples of 32. Data gradient = the same entry point on dy with flipped + transposed weights and pad' = 3 - pad. */
 int octa_conv4x4_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int pad,
                           void *stream);
+/* Weight gradient of that layer with padding 1: d_dw [16][Cout][Cin] float32 (overwritten) from d_x [N][H][W][Cin] and
+ * d_dy [N][H-1][W-1][Cout] (bf16); the KS = 4 instantiation of the 3x3 weight-gradient kernel (16 accumulator tiles per wave). */
+int octa_conv4x4_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin, int Cout,
+                            void *stream);
 
 /* 1x1 convolution head with ONE output channel and bias (DynUNet's UnetOutBlock, 32 -> 1; networks.py:6 / MONAI):
  * y[p] = bias + sum_c x[p][c] w[c] over NHWC bf16 pixels (y bf16 [npix]); backward: dx[p][c] = dy[p] w[c] (bf16),

@@ -605,10 +605,10 @@ constexpr int HALO_W = 40;             // halo row pitch in pixels (34 used; 80 
 // the even plane, s = 2 the odd plane one element further (funnel shift).
 // Workgroups per CU: the 32 x 32-channel stride-1 tile (the 1216^2 level: HBM / latency-bound, 18 MFMAs per wave and tile)
 // is compiled for two resident workgroups -- twice the loads in flight; the larger tiles need the whole register file.
-template <int COB, int CIB, int ST> constexpr int wgrad_wgs_per_cu() { return COB == 32 && CIB == 32 && ST == 1 ? 2 : 1; }
+template <int COB, int CIB, int ST, int KS = 3> constexpr int wgrad_wgs_per_cu() { return COB == 32 && CIB == 32 && ST == 1 && KS == 3 ? 2 : 1; }
 
-template <int COB, int CIB, bool MASKED, int ST, bool XFORM>
-__global__ void __launch_bounds__(CONV_THREADS, (wgrad_wgs_per_cu<COB, CIB, ST>()))
+template <int COB, int CIB, bool MASKED, int ST, bool XFORM, int KS>
+__global__ void __launch_bounds__(CONV_THREADS, (wgrad_wgs_per_cu<COB, CIB, ST, KS>()))
 conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                           const unsigned short *__restrict__ dY, float *__restrict__ dW,
                           int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask,
@@ -618,7 +618,8 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     constexpr int KSPLIT = 4 / PAIRS;            // waves sharing one (co, ci) pair split the tile rows
     constexpr int ROWS_PER_WAVE = WTH / KSPLIT;
     constexpr int SLOTS = ROWS_PER_WAVE * (TW / 16);   // MFMA groups of the compute loop = places to tuck LDS stores
-    constexpr int XROWS = ST == 1 ? WTH + 2 : 2 * WTH + 1, XCOLS = ST == 1 ? TW + 2 : 2 * TW + 1;
+    constexpr int XROWS = ST == 1 ? WTH + KS - 1 : 2 * WTH + 1, XCOLS = ST == 1 ? TW + KS - 1 : 2 * TW + 1;   // KS x KS taps (4: the PatchGAN, stride 1 only)
+    static_assert(KS == 3 || (KS == 4 && ST == 1 && !MASKED && !XFORM), "4x4 taps: plain stride-1 variant only");
     constexpr int XRP = ST == 1 ? HALO_W * 2 : 2 * HALO_W * 2;      // bytes per halo row (two column-parity planes for ST = 2)
     constexpr int WG_XROW = wg_pad_pitch(XROWS * XRP);               // bytes per channel row of the transposed X tile
     constexpr int DYPIX = WTH * TW, XPIX = XROWS * XCOLS;
@@ -637,9 +638,9 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     const int pair = wv % PAIRS, kpart = wv / PAIRS;
     const int cob = (pair % (COB / 32)) * 32, cib = (pair / (COB / 32)) * 32;
     const int m = lane & 31, kg = lane >> 5;
-    f32x16 acc[9];
+    f32x16 acc[KS * KS];
 #pragma unroll
-    for (int t = 0; t < 9; t++)
+    for (int t = 0; t < KS * KS; t++)
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[t][k] = 0.f;
     const int n_tiles = tiles_x * tiles_y * N;
@@ -741,7 +742,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
         // the dword (ST = 1) / the other parity plane (ST = 2) the shifted taps need. They are read one group AHEAD, before
         // the MFMAs of the current group and before its share of the transposed stores (which the compiler must assume to
         // alias), so the LDS latency hides under nine MFMAs even with one wave per SIMD.
-        struct Ops { bf16x8 a; uint4 d[3]; unsigned e[3]; uint4 f[3]; };
+        struct Ops { bf16x8 a; uint4 d[KS]; unsigned e[KS]; unsigned e2[KS]; uint4 f[KS]; };
         // the dword behind the 16-byte group is fetched through an offset the compiler cannot see: it would otherwise fuse the
         // 20 contiguous bytes into ds_read_b96 + ds_read2_b32 (12 LDS cycles) instead of ds_read_b128 + ds_read_b32 (6)
         int e_off = 16;
@@ -750,13 +751,14 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
             const int y = kpart * ROWS_PER_WAVE + slot / (TW / 16), xs = (slot % (TW / 16)) * 16;
             o.a = *reinterpret_cast<const bf16x8 *>(s_dy + (cob + m) * WG_ROWP + (y * TW + xs + kg * 8) * 2);
 #pragma unroll
-            for (int r = 0; r < 3; r++) {
+            for (int r = 0; r < KS; r++) {
                 if (MASKED && !((tap_mask >> (3 * r)) & 7)) continue;   // no tap of this kernel row is wanted
                 // ST = 1: halo columns xs + kg*8 + s .. +7 of halo row y + r. ST = 2: input row 2y + r; s = 0: odd plane at
                 // xs.., s = 1: even plane at xs.., s = 2: odd plane at xs+1..
                 const unsigned char *row = s_x + (cib + m) * WG_XROW + (ST * y + r) * XRP + (xs + kg * 8) * 2;
                 o.d[r] = *reinterpret_cast<const uint4 *>(row);
                 o.e[r] = *reinterpret_cast<const unsigned *>(row + e_off);
+                if (KS == 4) o.e2[r] = *reinterpret_cast<const unsigned *>(row + e_off + 4);   // pixels +10, +11 for the shift by three
                 if (ST == 2) o.f[r] = *reinterpret_cast<const uint4 *>(row + HALO_W * 2);
             }
         };
@@ -767,7 +769,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
             if (slot + 1 < SLOTS) load_ops(slot + 1, ops[(slot + 1) & 1]);
             const Ops &o = ops[slot & 1];
 #pragma unroll
-            for (int r = 0; r < 3; r++) {
+            for (int r = 0; r < KS; r++) {
                 if (MASKED && !((tap_mask >> (3 * r)) & 7)) continue;
                 union { uint4 u; bf16x8 v; } b0, b1, b2;
                 const uint4 d = o.d[r];
@@ -776,9 +778,15 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
                 b0.u = d;
                 if (ST == 1) { b1.u = sh; b2.u = make_uint4(d.y, d.z, d.w, o.e[r]); }
                 else { b1.u = o.f[r]; b2.u = sh; }
-                if (!MASKED || ((tap_mask >> (3 * r)) & 1)) acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b0.v, acc[3 * r + 0], 0, 0, 0);
-                if (!MASKED || ((tap_mask >> (3 * r + 1)) & 1)) acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b1.v, acc[3 * r + 1], 0, 0, 0);
-                if (!MASKED || ((tap_mask >> (3 * r + 2)) & 1)) acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b2.v, acc[3 * r + 2], 0, 0, 0);
+                if (!MASKED || ((tap_mask >> (3 * r)) & 1)) acc[KS * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b0.v, acc[KS * r + 0], 0, 0, 0);
+                if (!MASKED || ((tap_mask >> (3 * r + 1)) & 1)) acc[KS * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b1.v, acc[KS * r + 1], 0, 0, 0);
+                if (!MASKED || ((tap_mask >> (3 * r + 2)) & 1)) acc[KS * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b2.v, acc[KS * r + 2], 0, 0, 0);
+                if (KS == 4) {   // shift by three pixels: the funnel shift of the group that starts one dword further
+                    union { uint4 u; bf16x8 v; } b3;
+                    b3.u = make_uint4(__builtin_amdgcn_alignbit(d.z, d.y, 16), __builtin_amdgcn_alignbit(d.w, d.z, 16),
+                                      __builtin_amdgcn_alignbit(o.e[r], d.w, 16), __builtin_amdgcn_alignbit(o.e2[r], o.e[r], 16));
+                    acc[KS * r + 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a, b3.v, acc[KS * r + 3], 0, 0, 0);
+                }
             }
             // a share of the next tile's transposed stores, tucked behind this MFMA group; every staging register is
             // refilled with its piece of the tile after next as soon as it has been stored, so each load has a whole tile
@@ -795,7 +803,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     }
     // D[row = co][col = ci]: row = (k&3) + 8*(k>>2) + 4*kg, col = m
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
+    for (int t = 0; t < KS * KS; t++) {
         if (MASKED && !((tap_mask >> t) & 1)) continue;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -805,21 +813,22 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     }
 }
 
-template <int COB, int CIB, bool MASKED, int ST>
+template <int COB, int CIB, bool MASKED, int ST, int KS = 3>
 int launch_wgrad_impl(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
                  int Cout, int num_cus, int tap_mask, const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope,
                  const unsigned short *zero16, hipStream_t stream) {
-    constexpr int XROWS = ST == 1 ? WTH + 2 : 2 * WTH + 1;
+    constexpr int XROWS = ST == 1 ? WTH + KS - 1 : 2 * WTH + 1;
     constexpr int WG_XROW = wg_pad_pitch(XROWS * (ST == 1 ? HALO_W * 2 : 2 * HALO_W * 2));
     const size_t lds = 2 * ((size_t)COB * WG_ROWP + (size_t)CIB * WG_XROW);   // double buffered
-    const int Ho = H / ST, Wo = W / ST;
+    const int Ho = ST == 1 ? H + 3 - KS : H / ST, Wo = ST == 1 ? W + 3 - KS : W / ST;   // padding 1
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + WTH - 1) / WTH;
     const int blocks = (Cout / COB) * (Cin / CIB);
-    int per_block = (num_cus * wgrad_wgs_per_cu<COB, CIB, ST>() + blocks - 1) / blocks;   // one round of resident workgroups: fewer atomics
+    int per_block = (num_cus * wgrad_wgs_per_cu<COB, CIB, ST, KS>() + blocks - 1) / blocks;   // one round of resident workgroups: fewer atomics
     const int n_tiles = tiles_x * tiles_y * N;
     if (per_block > n_tiles) per_block = n_tiles;
     if (per_block < 1) per_block = 1;
-    auto kern = (sc1 || sc2) ? conv3x3_nhwc_wgrad_kernel<COB, CIB, MASKED, ST, true> : conv3x3_nhwc_wgrad_kernel<COB, CIB, MASKED, ST, false>;
+    auto kern = conv3x3_nhwc_wgrad_kernel<COB, CIB, MASKED, ST, false, KS>;
+    if constexpr (KS == 3) { if (sc1 || sc2) kern = conv3x3_nhwc_wgrad_kernel<COB, CIB, MASKED, ST, true, 3>; }
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Ho, Wo, Cin,
                        Cout, tiles_x, tiles_y, tap_mask, sc1, sh1, sc2, sh2, slope, zero16);
@@ -866,6 +875,22 @@ extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const vo
     if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
+}
+
+extern "C" int octa_conv4x4_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin, int Cout,
+                                       void *stream_) {
+    if (!ctx || !d_x || !d_dy || !d_dw) { octa::set_error("octa_conv4x4_nhwc_wgrad: null pointer"); return -2; }
+    if (N <= 0 || H < 2 || W < 2) { octa::set_error("octa_conv4x4_nhwc_wgrad: bad shape"); return -2; }
+    if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv4x4_nhwc_wgrad: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 16 * (size_t)Cout * Cin, stream));
+    const unsigned short *z = zero_page(ctx);
+    if (!z) return -1;
+    const unsigned short *X = static_cast<const unsigned short *>(d_x), *dY = static_cast<const unsigned short *>(d_dy);
+    if (Cout % 64 == 0 && Cin % 64 == 0)
+        return launch_wgrad_impl<64, 64, false, 1, 4>(X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0xffff, nullptr, nullptr, nullptr, nullptr, 0.f, z, stream);
+    return launch_wgrad_impl<32, 32, false, 1, 4>(X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0xffff, nullptr, nullptr, nullptr, nullptr, 0.f, z, stream);
 }
 
 extern "C" int octa_conv3x3_nhwc_wgrad3(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,

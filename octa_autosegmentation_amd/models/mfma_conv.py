@@ -596,9 +596,8 @@ def conv4x4_nhwc(x, wt, pad):
 
 
 class _Conv4x4NHWC(torch.autograd.Function):
-    """Conv2d(Cin, Cout, 4, stride 1, padding 1) without bias on NHWC bf16: forward and data gradient on the MFMA kernel; the
-    weight gradient (16 taps = 256 accumulator registers per wave in the 3x3 kernel's scheme) is MIOpen's, called on
-    channels-last views of the same tensors (no layout copies)."""
+    """Conv2d(Cin, Cout, 4, stride 1, padding 1) without bias on NHWC bf16: forward, data gradient and weight gradient on
+    the K = 4 instantiations of the MFMA kernels (the weight gradient holds 16 accumulator tiles = 256 AGPRs per wave)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -619,8 +618,13 @@ class _Conv4x4NHWC(torch.autograd.Function):
             wd = weight.to(torch.bfloat16).flip(2, 3).permute(2, 3, 1, 0).reshape(16, weight.shape[1], weight.shape[0]).contiguous()
             dx = conv4x4_nhwc(dy, wd, 2)
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), weight.to(torch.bfloat16), None,
-                                                     [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].to(weight.dtype)
+            n, h, w, cin = x.shape
+            cout = dy.shape[3]
+            d = torch.empty((16, cout, cin), dtype=torch.float32, device=x.device)
+            rc = _native.lib().octa_conv4x4_nhwc_wgrad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
+                                                       ctypes.c_void_p(d.data_ptr()), n, h, w, cin, cout, _native.current_stream_ptr())
+            _native.check(rc, "octa_conv4x4_nhwc_wgrad")
+            dw = d.view(4, 4, cout, cin).permute(2, 3, 0, 1).to(weight.dtype)
         return dx, dw
 
 

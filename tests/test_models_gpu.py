@@ -148,7 +148,7 @@ def test_conv4x4_mfma_matches_torch():
         sc = lambda t: max(t.abs().max().item(), 1e-6)
         assert (y.float().permute(0, 3, 1, 2) - yr).abs().max().item() <= 2 ** -7 * sc(yr)
         assert (xa.grad.float().permute(0, 3, 1, 2) - xr.grad).abs().max().item() <= 2 ** -7 * sc(xr.grad)
-        assert (wa.grad - wr.grad).abs().max().item() <= 2e-2 * sc(wr.grad)       # MIOpen's bf16 weight-gradient kernel
+        assert (wa.grad - wr.grad).abs().max().item() <= 1e-3 * sc(wr.grad)       # fp32 accumulation order only
 
 
 def test_patchgan_mfma_layers_match_torch_autocast():
