@@ -222,6 +222,18 @@ int octa_conv4x4_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, fl
 int octa_head1_nhwc_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, float bias, int64_t npix, int C, void *d_y, void *stream);
 int octa_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_dy, const float *d_w, int64_t npix, int C, void *d_dx,
                         float *d_dw, float *d_db, void *stream);
+/* The same forward with the bias read from device memory (d_bias float32[1] or NULL): the training step never reads the
+ * parameter back to the host. */
+int octa_head1_nhwc_fwd_b(octa_ctx *ctx, const void *d_x, const float *d_w, const float *d_bias, int64_t npix, int C, void *d_y, void *stream);
+
+/* Every KxK convolution weight of a network into both layouts the MFMA kernels read, in ONE launch per optimiser step
+ * (the master copies stay float32 torch parameters in the reference's state-dict layout, models/networks.py /
+ * MONAI DynUNet: [Cout][Cin][K][K]). d_table: int64 [L][8] in device memory, one row per layer =
+ * {src pointer, off_fwd, off_dg, A, B, BP, KK, kind}: kind 0 = Conv2d weight float32 [A][B][K][K] (KK = K*K);
+ * kind 1 = ConvTranspose2d(kernel 2, stride 2) weight [A][B][2][2] read as the 3x3 kernel whose taps r = 0 / s = 0 are
+ * zero (KK = 9). Written to d_dst (bf16, element offsets): [KK][A][BP] at off_fwd and, taps reversed, [KK][BP][A] at
+ * off_dg; columns B..BP-1 (channel padding to the kernels' multiple of 32) are zero. */
+int octa_pack_conv_weights(octa_ctx *ctx, const int64_t *d_table, int L, void *d_dst, void *stream);
 
 int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H, int W,
                              int Cin, int Cout, int tap_mask, void *stream);   /* wgrad with the virtual input concatenation and

@@ -44,6 +44,8 @@ SIGNATURES = {
     "octa_instnorm_lrelu_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_float, c_void_p]),
     "octa_instnorm_lrelu_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, ctypes.c_float, c_void_p]),
     "octa_head1_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_int64, c_int, c_void_p, c_void_p]),
+    "octa_head1_nhwc_fwd_b": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_void_p, c_void_p]),
+    "octa_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "octa_head1_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "octa_conv3x3_nhwc_fwd2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_conv3x3_nhwc_fwd3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -103,7 +105,15 @@ def lib():
     return _lib
 
 
+_SYNC_DEBUG = bool(os.environ.get("OCTA_SYNC_DEBUG"))
+
+
 def check(rc, what):
+    if _SYNC_DEBUG and rc == 0:     # development aid: wait for the launch and name it, so that an asynchronous fault has an owner
+        import sys
+        import torch
+        torch.cuda.current_stream().synchronize()
+        print(f"[octa-sync] {threading.current_thread().name} {what} ok", file=sys.stderr, flush=True)
     if rc != 0:
         msg = lib().octa_last_error().decode("utf-8", "replace")
         raise OctaHipError(f"{what} failed (rc={rc}): {msg}")

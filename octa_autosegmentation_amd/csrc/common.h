@@ -74,6 +74,26 @@ struct octa_ctx {
     octa::DevBuf r_tile_list;   // int32 [sum tile counts]
     octa::DevBuf r_counters;    // int64 [8] misc device counters
     octa::DevBuf zero_page;     // 256 zero bytes: source of the padding pixels of the DMA-staged convolution (conv.hip)
+    // ring of pre-zeroed accumulator slots (norm.hip statistics): ONE memset per lap instead of one per launch. Stream-ordered
+    // like every other scratch buffer of the context (one context = one stream at a time).
+    octa::DevBuf zero_ring;
+    size_t zero_ring_pos = 0;
+    // returns `bytes` (multiple of 256 after rounding) of zeros that the caller may dirty; nullptr on failure
+    void *zeroed(size_t bytes, hipStream_t stream) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        const size_t want = bytes * 64 > ((size_t)4 << 20) ? bytes * 64 : ((size_t)4 << 20);
+        if (zero_ring.cap < want) {
+            if (zero_ring.reserve(want)) return nullptr;
+            zero_ring_pos = zero_ring.cap;            // force a clearing lap
+        }
+        if (zero_ring_pos + bytes > zero_ring.cap) {
+            if (hipMemsetAsync(zero_ring.p, 0, zero_ring.cap, stream) != hipSuccess) { octa::set_error("zero ring memset failed"); return nullptr; }
+            zero_ring_pos = 0;
+        }
+        void *r = static_cast<char *>(zero_ring.p) + zero_ring_pos;
+        zero_ring_pos += bytes;
+        return r;
+    }
     size_t scratch_bytes() const {
         return r_edge_off.cap + r_ucount.cap + r_seg_total.cap + r_sides.cap + r_edge_meta.cap + r_tile_count.cap +
                r_tile_fill.cap + r_tile_total.cap + r_tile_list.cap + r_counters.cap;

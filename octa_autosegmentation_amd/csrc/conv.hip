@@ -916,11 +916,12 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 
 // y[p] = b + sum_c x[p][c] w[c];  C multiple of 8, <= 256. One thread per pixel group of 16 bytes x (C/8).
 __global__ void __launch_bounds__(256)
-head1_fwd_kernel(const unsigned short *__restrict__ x, const float *__restrict__ w, float bias, long npix, int C,
-                 unsigned short *__restrict__ y) {
+head1_fwd_kernel(const unsigned short *__restrict__ x, const float *__restrict__ w, float bias, const float *__restrict__ bias_p,
+                 long npix, int C, unsigned short *__restrict__ y) {
     __shared__ float s_w[256];
     for (int c = threadIdx.x; c < C; c += 256) s_w[c] = w[c];
     __syncthreads();
+    if (bias_p) bias += *bias_p;
     for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
         float acc = bias;
         const uint4 *px = reinterpret_cast<const uint4 *>(x + p * C);
@@ -986,7 +987,7 @@ extern "C" int octa_head1_nhwc_fwd(octa_ctx *ctx, const void *d_x, const float *
     long blocks = (npix + 255) / 256;
     if (blocks > 16L * ctx->num_cus) blocks = 16L * ctx->num_cus;
     hipLaunchKernelGGL(head1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const unsigned short *>(d_x), d_w, bias,
-                       (long)npix, C, static_cast<unsigned short *>(d_y));
+                       (const float *)nullptr, (long)npix, C, static_cast<unsigned short *>(d_y));
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1141,6 +1142,74 @@ extern "C" int octa_conv3x3_c1_wgrad(octa_ctx *ctx, const void *d_x, const void 
     if (W > 8192) { octa::set_error("octa_conv3x3_c1_wgrad: W > 8192"); return -2; }
     hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * (Cout * 9 + 3 * (W + 2)), stream, static_cast<const unsigned short *>(d_x),
                        static_cast<const unsigned short *>(d_dy), d_dw, N, H, W, Cout);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- every KxK weight of a network into both MFMA layouts, ONE launch per optimiser step ---------------------------
+// The master weights stay torch parameters (float32 [Cout][Cin][K][K]; MONAI / networks.py state-dict layout); the
+// kernels want bf16 "tap-major" [K*K][Cout][CinP] (forward) and [K*K][CinP][Cout] with the taps reversed (data
+// gradient). Packing layer by layer with torch ops costs ~7 tiny launches per layer and step (flip, permute-copy,
+// cast, zero fill: 0.66 ms of the 20.3 ms U-Net step, profiles/r01_train_mfma_kernel_stats.csv); here a table of
+// descriptors drives one launch. HBM-bound, ~6 B per weight element; nothing to tile.
+namespace {
+
+struct PackDesc {          // one row of the int64 table [L][8]
+    long src;              // const float *: [A][B][K][K], A = Cout, B = Cin (kind 0); kind 1: ConvTranspose2d(k = s = 2)
+                           //   weight [A][B][2][2] read as the 3x3 kernel wc[a][b][r][s] = w[a][b][r-1][s-1] (r, s >= 1)
+    long off_fwd;          // element offset in dst of [KK][A][BP]
+    long off_dg;           // element offset in dst of [KK][BP][A], taps reversed
+    long A, B, BP, KK, kind;
+};
+
+__device__ __forceinline__ float pack_src(const float *w, long a, long b, long B, int t, int KK, int kind) {
+    if (kind == 0) return w[(a * B + b) * KK + t];
+    const int r = t / 3, s = t % 3;                      // kind 1: KK == 9 over a 2x2 source
+    return (r >= 1 && s >= 1) ? w[(a * B + b) * 4 + (r - 1) * 2 + (s - 1)] : 0.f;
+}
+
+__global__ void __launch_bounds__(256)
+pack_weights_kernel(const long *__restrict__ table, unsigned short *__restrict__ dst) {
+    const PackDesc d = *reinterpret_cast<const PackDesc *>(table + 8 * blockIdx.y);
+    const float *w = reinterpret_cast<const float *>(d.src);
+    const long pairs = d.A * d.BP;
+    const int KK = (int)d.KK, kind = (int)d.kind;
+    // forward layout: b fastest -> coalesced bf16 stores per tap, K*K contiguous floats read per thread
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < pairs; e += (long)gridDim.x * 256) {
+        const long a = e / d.BP, b = e % d.BP;
+        for (int t = 0; t < KK; t++)
+            dst[d.off_fwd + (long)t * pairs + e] = b < d.B ? f2bf(pack_src(w, a, b, d.B, t, KK, kind)) : (unsigned short)0;
+    }
+    // data-gradient layout: a fastest (source re-read through L2, stores coalesced), taps reversed
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < pairs; e += (long)gridDim.x * 256) {
+        const long b = e / d.A, a = e % d.A;
+        for (int t = 0; t < KK; t++)
+            dst[d.off_dg + (long)(KK - 1 - t) * pairs + e] = b < d.B ? f2bf(pack_src(w, a, b, d.B, t, KK, kind)) : (unsigned short)0;
+    }
+}
+
+}  // namespace
+
+extern "C" int octa_pack_conv_weights(octa_ctx *ctx, const int64_t *d_table, int L, void *d_dst, void *stream_) {
+    if (!ctx || !d_table || !d_dst || L <= 0 || L > 65535) { octa::set_error("octa_pack_conv_weights: bad arguments"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(64, (unsigned)L), dim3(256), 0, stream, reinterpret_cast<const long *>(d_table),
+                       static_cast<unsigned short *>(d_dst));
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// head forward with the bias read from device memory (no host read-back of the parameter in the training step)
+extern "C" int octa_head1_nhwc_fwd_b(octa_ctx *ctx, const void *d_x, const float *d_w, const float *d_bias, int64_t npix, int C, void *d_y,
+                                     void *stream_) {
+    if (!ctx || !d_x || !d_w || !d_y || npix <= 0 || C <= 0 || C % 8 || C > 256) { octa::set_error("octa_head1_nhwc_fwd_b: bad arguments (C must be a multiple of 8, <= 256)"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    long blocks = (npix + 255) / 256;
+    if (blocks > 16L * ctx->num_cus) blocks = 16L * ctx->num_cus;
+    hipLaunchKernelGGL(head1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const unsigned short *>(d_x), d_w, 0.f, d_bias,
+                       (long)npix, C, static_cast<unsigned short *>(d_y));
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }

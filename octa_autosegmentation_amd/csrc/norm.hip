@@ -253,8 +253,12 @@ extern "C" int octa_instnorm_lrelu_bwd(octa_ctx *ctx, const void *d_x, const voi
     if (ctx->r_tile_total.reserve(sizeof(double) * 2 * planes * splits)) return -1;
     double *partial = ctx->r_tile_total.as<double>();
     dim3 grid((unsigned)splits, (unsigned)planes);
-    if (d_dw) OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
-    if (d_db) OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float) * C, stream));
+    if (d_dw && d_db == d_dw + C) {                                   // allocated back to back by the host side: one fill
+        OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 2 * C, stream));
+    } else {
+        if (d_dw) OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
+        if (d_db) OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float) * C, stream));
+    }
     if (dtype == 0) {
         hipLaunchKernelGGL(in_bwd_stats<float>, grid, dim3(NT), 0, stream, (const float *)d_x, (const float *)d_dy, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, partial);
         hipLaunchKernelGGL(in_bwd_apply<float>, grid, dim3(NT), 0, stream, (const float *)d_x, (const float *)d_dy, (float *)d_dx, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, partial, d_dw, d_db);
@@ -512,9 +516,8 @@ extern "C" int octa_instnorm_lrelu_nhwc_fwd(octa_ctx *ctx, const void *d_x, void
     if (nhwc_check("octa_instnorm_lrelu_nhwc_fwd", B, C, hw)) return -2;
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
-    if (ctx->r_tile_total.reserve(sizeof(double) * 2 * (size_t)B * C)) return -1;
-    double *sums = ctx->r_tile_total.as<double>();
-    OCTA_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, stream));
+    double *sums = static_cast<double *>(ctx->zeroed(sizeof(double) * 2 * (size_t)B * C, stream));   // pre-zeroed ring slot
+    if (!sums) return -1;
     // optional image groups (nhwc_group): statistics and application of one group back to back
     const int group = nhwc_group(B, (size_t)hw * C * 2);
     const int splits = nhwc_splits(ctx, group, hw);
@@ -538,11 +541,14 @@ extern "C" int octa_instnorm_lrelu_nhwc_bwd(octa_ctx *ctx, const void *d_x, cons
     if (nhwc_check("octa_instnorm_lrelu_nhwc_bwd", B, C, hw)) return -2;
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
-    if (ctx->r_tile_total.reserve(sizeof(double) * 2 * (size_t)B * C)) return -1;
-    double *sums = ctx->r_tile_total.as<double>();
-    OCTA_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, stream));
-    if (d_dw) OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
-    if (d_db) OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float) * C, stream));
+    double *sums = static_cast<double *>(ctx->zeroed(sizeof(double) * 2 * (size_t)B * C, stream));   // pre-zeroed ring slot
+    if (!sums) return -1;
+    if (d_dw && d_db == d_dw + C) {                                   // allocated back to back by the host side: one fill
+        OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 2 * C, stream));
+    } else {
+        if (d_dw) OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
+        if (d_db) OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float) * C, stream));
+    }
     const int group = nhwc_group(B, (size_t)hw * C * 2 * 2);   // two tensors (x, dy) are read twice
     const int splits = nhwc_splits(ctx, group, hw);
     dim3 grid((unsigned)splits, (unsigned)group);
@@ -607,9 +613,8 @@ extern "C" int octa_instnorm_nhwc_stats(octa_ctx *ctx, const void *d_x, const fl
     if (nhwc_check("octa_instnorm_nhwc_stats", B, C, hw)) return -2;
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
-    if (ctx->r_tile_total.reserve(sizeof(double) * 2 * (size_t)B * C)) return -1;
-    double *sums = ctx->r_tile_total.as<double>();
-    OCTA_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, stream));
+    double *sums = static_cast<double *>(ctx->zeroed(sizeof(double) * 2 * (size_t)B * C, stream));   // pre-zeroed ring slot
+    if (!sums) return -1;
     const int splits = nhwc_splits(ctx, B, hw);
     hipLaunchKernelGGL(in_nhwc_stats<0>, dim3((unsigned)splits, (unsigned)B), dim3(NT), 0, stream, static_cast<const unsigned short *>(d_x),
                        (const unsigned short *)nullptr, d_w, d_b, (const float *)nullptr, (const float *)nullptr, (long)hw, C, splits, 0.f, sums, 0);

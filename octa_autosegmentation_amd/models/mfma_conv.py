@@ -11,16 +11,123 @@ import torch
 from .. import _native
 
 
-def pack_weight(w):
-    """[Cout, Cin, 3, 3] -> [9, Cout, Cin] bf16."""
-    co, ci = w.shape[0], w.shape[1]
-    return w.permute(2, 3, 0, 1).reshape(9, co, ci).to(torch.bfloat16).contiguous()
+def _pad32(c):
+    return (c + 31) // 32 * 32
 
 
-def pack_weight_dgrad(w):
-    """[Cout, Cin, 3, 3] -> [9, Cin, Cout] bf16 with the taps flipped: conv3x3(dy, this) = dL/dx."""
-    co, ci = w.shape[0], w.shape[1]
-    return w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, ci, co).to(torch.bfloat16).contiguous()
+USE_PACK_PLAN = True
+
+
+class WeightPackPlan:
+    """All KxK convolution weights of a network packed into both kernel layouts by ONE launch per optimiser step
+    (csrc/conv.hip octa_pack_conv_weights) instead of ~7 small torch kernels per layer and step. The plan is
+    refreshed when any parameter's version counter (or storage) changed; `pack_weight*` below look parameters up here
+    and fall back to the torch formulation for tensors that are not registered."""
+
+    def __init__(self, convs, convts=()):
+        """convs: float32 parameters [Cout,Cin,K,K]; convts: ConvTranspose2d(2, 2) parameters [Cin,Cout,2,2]."""
+        self.params = [(w, 0) for w in convs] + [(w, 1) for w in convts]
+        assert all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w, _ in self.params)
+        self.device = self.params[0][0].device
+        off, self.geom = 0, []
+        for w, kind in self.params:
+            a, b = w.shape[0], w.shape[1]
+            kk = 9 if kind == 1 else w.shape[2] * w.shape[3]
+            bp = _pad32(b)
+            n = kk * a * bp
+            self.geom.append((off, off + n, a, b, bp, kk, kind))
+            off += 2 * n
+        self.buf = torch.empty(off, dtype=torch.bfloat16, device=self.device)
+        self.fwd = [self.buf[g[0]:g[0] + g[5] * g[2] * g[4]].view(g[5], g[2], g[4]) for g in self.geom]      # [KK][A][BP]
+        self.dg = [self.buf[g[1]:g[1] + g[5] * g[2] * g[4]].view(g[5], g[4], g[2]) for g in self.geom]       # [KK][BP][A]
+        self.table, self.ptrs, self.versions = None, None, None
+        for i, (w, _) in enumerate(self.params):
+            w._octa_pack = (self, i)          # found again by pack_weight*(w); lives as long as the parameter
+
+    def ensure(self):
+        ptrs = [w.data_ptr() for w, _ in self.params]
+        versions = [w._version for w, _ in self.params]
+        if ptrs != self.ptrs:
+            rows = [[p, g[0], g[1], g[2], g[3], g[4], g[5], g[6]] for p, g in zip(ptrs, self.geom)]
+            self.table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+            self.ptrs, self.versions = ptrs, None
+        if versions != self.versions:
+            rc = _native.lib().octa_pack_conv_weights(_native.ctx(self.device.index), ctypes.c_void_p(self.table.data_ptr()), len(self.params),
+                                                      ctypes.c_void_p(self.buf.data_ptr()), _native.current_stream_ptr())
+            _native.check(rc, "octa_pack_conv_weights")
+            self.versions = versions
+
+    def invalidate(self):
+        """After writes that bypass the version counter (`.data`)."""
+        self.versions = None
+
+
+def plan_for_module(module):
+    """One WeightPackPlan over every MFMA-shaped convolution weight of `module` (3x3 / 4x4 Conv2d, 2x2 ConvTranspose2d),
+    built on first use and cached on the module; None when nothing qualifies (CPU, non-float32 master weights)."""
+    plan = getattr(module, "_octa_pack_plan", None)
+    if plan is not None or not USE_PACK_PLAN:
+        return plan
+    ok = lambda w: w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+    convs = [m.weight for m in module.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size in ((3, 3), (4, 4)) and m.groups == 1
+             and ok(m.weight)]
+    convts = [m.weight for m in module.modules() if isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and m.stride == (2, 2)
+              and m.groups == 1 and ok(m.weight)]
+    if not convs and not convts:
+        return None
+    plan = WeightPackPlan(convs, convts)
+    object.__setattr__(module, "_octa_pack_plan", plan)
+    return plan
+
+
+def _planned(w, kind):
+    if not USE_PACK_PLAN:
+        return None, None
+    ent = getattr(w, "_octa_pack", None)
+    if ent is None or ent[0].params[ent[1]][0] is not w or ent[0].params[ent[1]][1] != kind:
+        return None, None
+    ent[0].ensure()
+    return ent
+
+
+def pack_weight(w, cin_pad=None):
+    """[Cout, Cin, K, K] -> [K*K, Cout, CinP] bf16 (CinP = cin_pad or Cin; padded columns zero)."""
+    co, ci, kk = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+    cp = ci if cin_pad is None else cin_pad
+    plan, i = _planned(w, 0)
+    if plan is not None and plan.geom[i][4] == cp:
+        return plan.fwd[i]
+    if cp != ci:
+        wp = w.new_zeros((co, cp) + tuple(w.shape[2:]))
+        wp[:, :ci] = w
+        w = wp
+    return w.permute(2, 3, 0, 1).reshape(kk, co, cp).to(torch.bfloat16).contiguous()
+
+
+def pack_weight_dgrad(w, cin_pad=None):
+    """[Cout, Cin, K, K] -> [K*K, CinP, Cout] bf16 with the taps flipped: conv(dy, this) = dL/dx."""
+    co, ci, kk = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+    cp = ci if cin_pad is None else cin_pad
+    plan, i = _planned(w, 0)
+    if plan is not None and plan.geom[i][4] == cp:
+        return plan.dg[i]
+    if cp != ci:
+        wp = w.new_zeros((co, cp) + tuple(w.shape[2:]))
+        wp[:, :ci] = w
+        w = wp
+    return w.flip(2, 3).permute(2, 3, 1, 0).reshape(kk, cp, co).to(torch.bfloat16).contiguous()
+
+
+def pack_convt2x2(w):
+    """ConvTranspose2d(2, 2) weight [Cin, Cout, 2, 2] as the 3x3 kernel wc[a][b][r][s] = w[a][b][r-1][s-1] (zero at r = 0 or
+    s = 0), in both layouts: (pack_weight(wc) [9, Cin, Cout], pack_weight_dgrad(wc) [9, Cout, Cin])."""
+    plan, i = _planned(w, 1)
+    if plan is not None and plan.geom[i][4] == w.shape[1]:
+        return plan.fwd[i], plan.dg[i]
+    wc = w.new_zeros((w.shape[0], w.shape[1], 3, 3))
+    wc[:, :, 1:, 1:] = w
+    return (wc.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(torch.bfloat16).contiguous(),
+            wc.flip(2, 3).permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]).to(torch.bfloat16).contiguous())
 
 
 def conv3x3_nhwc(x, wt, stride=1, in_dilation=1, tap_mask=0x1ff):
@@ -163,11 +270,7 @@ class _Conv3x3NHWC(torch.autograd.Function):
     def forward(ctx, x, weight, stride, want_stats=False):
         cin = weight.shape[1]
         xp = _pad_channels(x.contiguous())
-        wp = weight
-        if xp.shape[-1] != cin:
-            wp = weight.new_zeros((weight.shape[0], xp.shape[-1], 3, 3))
-            wp[:, :cin] = weight
-        y, part = _conv_fwd_stats(xp, None, pack_weight(wp), stride, want_stats)
+        y, part = _conv_fwd_stats(xp, None, pack_weight(weight, xp.shape[-1]), stride, want_stats)
         ctx.save_for_backward(xp, weight)
         ctx.stride, ctx.cin = int(stride), cin
         if want_stats:
@@ -186,14 +289,15 @@ class _Conv3x3NHWC(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if st == 2:
                 assert xp.shape[1] % 2 == 0 and xp.shape[2] % 2 == 0, "stride-2 layers need even input sizes"
-            wd = weight
-            if xp.shape[-1] != cin:   # channel-padded input (the GAN trains the generator THROUGH the segmentor's first layer)
-                wd = weight.new_zeros((weight.shape[0], xp.shape[-1], 3, 3))
-                wd[:, :cin] = weight
+            # channel-padded input: the GAN trains the generator THROUGH the segmentor's first layer
             if st == 2 and USE_PARITY_SCATTER:
+                wd = weight
+                if xp.shape[-1] != cin:
+                    wd = weight.new_zeros((weight.shape[0], xp.shape[-1], 3, 3))
+                    wd[:, :cin] = weight
                 dx = conv3x3_s2_dgrad(dy, wd)
             else:
-                dx = conv3x3_nhwc(dy, pack_weight_dgrad(wd), stride=1, in_dilation=st)
+                dx = conv3x3_nhwc(dy, pack_weight_dgrad(weight, xp.shape[-1]), stride=1, in_dilation=st)
             if xp.shape[-1] != cin:
                 dx = dx[..., :cin].contiguous()
         if ctx.needs_input_grad[1]:
@@ -328,8 +432,12 @@ class _InstNormLReLUNHWC(torch.autograd.Function):
         B, C = x.shape[0], x.shape[3]
         hw = x.shape[1] * x.shape[2]
         dx = torch.empty_like(x)
-        dw = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_w else None
-        db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_b else None
+        if ctx.has_w and ctx.has_b:
+            dwb = torch.empty(2 * C, dtype=torch.float32, device=x.device)     # back to back: the C side clears both with one fill
+            dw, db = dwb[:C], dwb[C:]
+        else:
+            dw = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_w else None
+            db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_b else None
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         rc = _native.lib().octa_instnorm_lrelu_nhwc_bwd(_native.ctx(x.device.index), p(x), p(dy), p(w), p(b), p(mean), p(rstd), p(dx), p(dw),
                                                         p(db), B, C, hw, ctx.slope, _native.current_stream_ptr())
@@ -368,28 +476,25 @@ class _ConvT2x2NHWC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         x = x.contiguous()
-        cin, cout = weight.shape[0], weight.shape[1]
-        wc = weight.new_zeros((cin, cout, 3, 3))
-        wc[:, :, 1:, 1:] = weight
         if USE_PARITY_SCATTER_CONVT:
             y = conv_transpose_2x2_fwd(x, weight)
         else:
-            # wc has taps r, s in {1, 2}; flipped for the data-gradient form they sit at r, s in {0, 1}
-            y = conv3x3_nhwc(x, pack_weight_dgrad(wc), stride=1, in_dilation=2, tap_mask=0b000011011)
-        ctx.save_for_backward(x, wc)
+            # the 3x3 form wc has taps r, s in {1, 2}; flipped for the data-gradient form they sit at r, s in {0, 1}
+            y = conv3x3_nhwc(x, pack_convt2x2(weight)[1], stride=1, in_dilation=2, tap_mask=0b000011011)
+        ctx.save_for_backward(x, weight)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wc = ctx.saved_tensors
+        x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = conv3x3_nhwc(dy, pack_weight(wc), stride=2, tap_mask=0b110110000)
+            dx = conv3x3_nhwc(dy, pack_convt2x2(weight)[0], stride=2, tap_mask=0b110110000)
         if ctx.needs_input_grad[1]:
-            dw = _s2_wgrad(dy, x, taps2=((1, 2), (1, 2)))[:, :, 1:, 1:].to(wc.dtype)
+            dw = _s2_wgrad(dy, x, taps2=((1, 2), (1, 2)))[:, :, 1:, 1:].to(weight.dtype)
         return dx, dw
 
 
@@ -425,9 +530,10 @@ class _Head1NHWC(torch.autograd.Function):
         wv = weight.reshape(-1).float().contiguous()
         y = torch.empty((n, h, w, 1), dtype=torch.bfloat16, device=x.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
-        rc = _native.lib().octa_head1_nhwc_fwd(_native.ctx(x.device.index), p(x), p(wv), float(bias.item()) if bias is not None else 0.0,
-                                               n * h * w, c, p(y), _native.current_stream_ptr())
-        _native.check(rc, "octa_head1_nhwc_fwd")
+        bv = bias.float().contiguous() if bias is not None else None      # read on the device: no host round trip in the step
+        rc = _native.lib().octa_head1_nhwc_fwd_b(_native.ctx(x.device.index), p(x), p(wv), p(bv) if bv is not None else None,
+                                                 n * h * w, c, p(y), _native.current_stream_ptr())
+        _native.check(rc, "octa_head1_nhwc_fwd_b")
         ctx.save_for_backward(x, wv)
         ctx.w_shape, ctx.w_dtype, ctx.has_bias = weight.shape, weight.dtype, bias is not None
         return y
@@ -602,9 +708,8 @@ class _Conv4x4NHWC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         x = x.contiguous()
-        wt = weight.to(torch.bfloat16).permute(2, 3, 0, 1).reshape(16, weight.shape[0], weight.shape[1]).contiguous()
         ctx.save_for_backward(x, weight)
-        return conv4x4_nhwc(x, wt, 1)
+        return conv4x4_nhwc(x, pack_weight(weight), 1)
 
     @staticmethod
     def backward(ctx, dy):
@@ -615,8 +720,7 @@ class _Conv4x4NHWC(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             # dx = full correlation of dy with the flipped kernel, channels transposed: padding 3 - 1 = 2
-            wd = weight.to(torch.bfloat16).flip(2, 3).permute(2, 3, 1, 0).reshape(16, weight.shape[1], weight.shape[0]).contiguous()
-            dx = conv4x4_nhwc(dy, wd, 2)
+            dx = conv4x4_nhwc(dy, pack_weight_dgrad(weight), 2)
         if ctx.needs_input_grad[1]:
             n, h, w, cin = x.shape
             cout = dy.shape[3]

@@ -210,6 +210,7 @@ class DynUNet(nn.Module):
 
     def _forward_nhwc(self, x):
         from . import mfma_conv as mc
+        mc.plan_for_module(self)          # all layers' weights packed by one launch per optimiser step
         y = (x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), None, None)
         skips = [self._basic_block_nhwc(self.input_block, y)]
         for d in self.downsamples:
@@ -376,6 +377,7 @@ class ResnetGenerator(nn.Module):
         if not use_mfma:
             return self.model(x)
         from . import mfma_conv as mc
+        mc.plan_for_module(self)
         mods = list(self.model)
         nhwc = False                                     # layout of x between layers
         i = 0
@@ -429,6 +431,7 @@ class NLayerDiscriminator(nn.Module):
         if not use_mfma:
             return self.model(x)
         from . import mfma_conv as mc
+        mc.plan_for_module(self)
         mods = list(self.model)
         nhwc = False
         i = 0

@@ -298,3 +298,40 @@ def test_epilogue_statistics_feed_the_norm(hip_lib_built):
         b = mc.instance_norm_leaky_relu_nhwc(y, gam, bet)
         assert (a.float() - b.float()).abs().max().item() <= 2.0 ** -7 * b.float().abs().max().item()
         assert (a != b).float().mean().item() < 0.01      # a handful of values may round the other way
+
+
+def test_weight_pack_plan_is_bit_exact_and_follows_updates(hip_lib_built):
+    """One-launch packing of all KxK weights (octa_pack_conv_weights) against the torch formulation of the same layouts:
+    3x3 with a channel-padded input, 4x4, the 2x2 transposed convolution; bf16 bits identical; refreshed after an in-place
+    optimiser-style update."""
+    import torch
+    from octa_autosegmentation_amd.models import mfma_conv as mc
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda *s: torch.nn.Parameter(torch.randn(*s, device="cuda", generator=g))
+    w3, w3p, w4, wt = mk(64, 32, 3, 3), mk(32, 1, 3, 3), mk(128, 64, 4, 4), mk(64, 32, 2, 2)
+    plan = mc.WeightPackPlan([w3, w3p, w4], [wt])
+
+    def ref():
+        mc.USE_PACK_PLAN = False
+        try:
+            return [mc.pack_weight(w3), mc.pack_weight_dgrad(w3), mc.pack_weight(w3p, 32), mc.pack_weight_dgrad(w3p, 32),
+                    mc.pack_weight(w4), mc.pack_weight_dgrad(w4), *mc.pack_convt2x2(wt)]
+        finally:
+            mc.USE_PACK_PLAN = True
+
+    def got():
+        return [mc.pack_weight(w3), mc.pack_weight_dgrad(w3), mc.pack_weight(w3p, 32), mc.pack_weight_dgrad(w3p, 32),
+                mc.pack_weight(w4), mc.pack_weight_dgrad(w4), *mc.pack_convt2x2(wt)]
+
+    for a, b in zip(got(), ref()):
+        assert a.shape == b.shape and a.dtype == torch.bfloat16
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert mc.pack_weight(w3).data_ptr() == plan.fwd[0].data_ptr()          # served from the plan, not recomputed
+    with torch.no_grad():
+        for w in (w3, w3p, w4, wt):
+            w.add_(0.25)
+    for a, b in zip(got(), ref()):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    # an unregistered tensor takes the torch formulation
+    other = torch.randn(32, 32, 3, 3, device="cuda")
+    assert mc.pack_weight(other).shape == (9, 32, 32)

@@ -42,13 +42,27 @@ SEG_CONFIG = {   # configs/config_ves_seg-S.yml, the parts this script uses
 }
 
 
+GAN_CONFIG = {   # configs/config_gan_ves_seg.yml, the parts this script uses
+    "General": {"amp": True, "model": {"name": "GanSegModel", "model_g": {"name": "resnetGenerator9"}, "model_d": {"name": "patchGAN70x70"},
+                                       "model_s": SEG_CONFIG["General"]["model"], "upshape": (1216, 1216),
+                                       "compute_identity": False, "compute_identity_seg": True}},
+    "Train": {"lr": 2e-4, "loss_dg": "LSGANLoss", "loss_s": "DiceBCELoss", "batch_size": 4,
+              "data_augmentation": [   # the entries applied to real_A / real_A_seg after the graph loader (same draws for both keys)
+                  {"name": "ScaleIntensityd", "keys": ["real_A", "real_A_seg"], "minv": 0, "maxv": 1},
+                  {"name": "RandFlipd", "keys": ["real_A", "real_A_seg"], "prob": 0.5, "spatial_axis": [0, 1]},
+                  {"name": "RandRotate90d", "keys": ["real_A", "real_A_seg"], "prob": 0.75},
+                  {"name": "RandRotated", "keys": ["real_A", "real_A_seg"], "prob": 1, "range_x": 0.17453292519943295, "padding_mode": "zeros"},
+                  {"name": "AsDiscreted", "keys": ["real_A_seg"], "threshold": 0.1}]},
+}
+
+
 def load_sim_config():
     import yaml
     g = np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
     return yaml.safe_load(str(g["config_yaml"]))
 
 
-def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True):
+def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
     import torch
     import torch.distributed as dist
     from octa_autosegmentation_amd import pipeline
@@ -61,12 +75,22 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True):
     dev = torch.device("cuda", torch.cuda.current_device())
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend="nccl", device_id=dev)
-    aug_cfg = SEG_CONFIG["Train"]["data_augmentation"]
-    loader = aug_cfg[0]
-    gen = pipeline.TripleGenerator(load_sim_config(), gen_batch, label_resolution=loader["image_resolutions"][1],
-                                   label_min_radius=loader["min_radius"][1])
+    if gan:
+        # BASELINE configs[4] proper: the on-the-fly stream feeds the joint GAN contrast-adaptation + segmentation step
+        # (configs/config_gan_ves_seg.yml; graph loader with min_radius [0, 0]). real_B (real OCTA scans) and the background
+        # tiles are not in the repository: uniform-noise stand-ins of the same shape (data = synthetic, as everywhere here).
+        from octa_autosegmentation_amd.models.gan_seg_trainer import GanSegTrainer
+        aug_cfg = GAN_CONFIG["Train"]["data_augmentation"]
+        gen = pipeline.TripleGenerator(load_sim_config(), gen_batch, label_resolution=[1216, 1216], label_min_radius=0)
+        trainer = GanSegTrainer(GAN_CONFIG, dev)
+    else:
+        aug_cfg = SEG_CONFIG["Train"]["data_augmentation"]
+        loader = aug_cfg[0]
+        gen = pipeline.TripleGenerator(load_sim_config(), gen_batch, label_resolution=loader["image_resolutions"][1],
+                                       label_min_radius=loader["min_radius"][1])
+        trainer = SegmentationTrainer(SEG_CONFIG, dev)
     aug = GpuSegAugmentation(aug_cfg, seed=1234 + rank)
-    trainer = SegmentationTrainer(SEG_CONFIG, dev)
+    noise = torch.Generator(device=dev).manual_seed(99 + rank)
     q = queue.Queue(maxsize=2)
     stop = threading.Event()
     gen_stream = torch.cuda.Stream()
@@ -78,6 +102,8 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True):
             while not stop.is_set():
                 out = gen.generate(sharding.rank_seeds(rank, i, gen_batch, base=seed0))
                 gen_stream.synchronize()
+                if os.environ.get("OCTA_E2E_DEBUG"):
+                    print(f"   generator batch {i} done t={time.time():.2f}", file=sys.stderr, flush=True)
                 item = (out["image"], out["label_grey"])
                 while not stop.is_set():
                     try:
@@ -102,16 +128,28 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True):
         if images is None or pos + batch > images.shape[0]:
             images, labels = q.get()
             pos = 0
+        if os.environ.get("OCTA_E2E_DEBUG"):
+            torch.cuda.synchronize()
+            print(f"step {step} t={time.time():.2f} pos={pos}", file=sys.stderr, flush=True)
         mb = aug(images[pos:pos + batch].contiguous(), labels[pos:pos + batch].contiguous())
         pos += batch
-        _, l = trainer.perform_training_step({"image": mb["image"], "label": mb["label"]})
-        losses.append(l[trainer.loss_name])
+        if gan:
+            a = mb["image"]
+            bg = torch.rand(a.shape, device=dev, generator=noise) * torch.rand(a.shape, device=dev, generator=noise)
+            real_a = torch.maximum(a, bg)                      # AddRandomBackgroundNoised (data_transforms.py:506-516)
+            real_b = torch.rand(a.shape, device=dev, generator=noise)
+            _, l = trainer.perform_training_step({"real_A": real_a, "real_B": real_b, "real_A_seg": mb["label"]})
+            losses.append(l["S"])
+        else:
+            _, l = trainer.perform_training_step({"image": mb["image"], "label": mb["label"]})
+            losses.append(l[trainer.loss_name])
     torch.cuda.synchronize()
     dt = sharding.max_over_ranks(time.time() - t0, dist if world > 1 else None, dev)
     stop.set()
     th.join(timeout=30)
     gen.close()
-    res = {"metric": "end-to-end on-the-fly training imgs/s (simulate + rasterise + augment + DynUNet-S step @1216^2)",
+    res = {"metric": ("end-to-end on-the-fly GAN-seg training imgs/s (simulate + rasterise + augment + G/D @304^2 + DynUNet-S @1216^2 step)" if gan else
+                      "end-to-end on-the-fly training imgs/s (simulate + rasterise + augment + DynUNet-S step @1216^2)"),
            "value": world * batch * steps / dt, "unit": "imgs/s", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3,
            "batch_per_gpu": batch, "generator_batch": gen_batch, "first_loss": float(losses[0]), "last_loss": float(losses[-1])}
     if log and rank == 0:
@@ -125,5 +163,6 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--gen-batch", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gan", action="store_true", help="feed the GAN-seg trainer (configs[4]) instead of the segmentation trainer")
     a = ap.parse_args()
-    run(a.steps, a.batch, a.gen_batch, warmup=a.warmup)
+    run(a.steps, a.batch, a.gen_batch, warmup=a.warmup, gan=a.gan)
