@@ -31,7 +31,10 @@ struct DevBuf {
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
         if (p) {
-            hipError_t e = hipFree(p);
+            // kernels launched a moment ago may still read the old buffer (on any stream of this context's owner): wait
+            // for the device explicitly instead of relying on hipFree's implicit synchronisation
+            hipError_t e = hipDeviceSynchronize();
+            e = hipFree(p);
             (void)e;
             p = nullptr;
             cap = 0;

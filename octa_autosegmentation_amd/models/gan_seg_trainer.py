@@ -5,6 +5,17 @@ bilinearly upsampled fake / identity images, pseudo-labels from thresholding S(r
 bf16 autocast; with torch.distributed initialised each optimiser's gradients are averaged with one flat
 RCCL all-reduce (D after its backward; G and S together after theirs)."""
 import itertools
+import os
+
+# The four layers of G and D that are not matrix-core shaped (7x7 stem / head of the generator, 4x4 stem / head of the
+# PatchGAN) stay torch convolutions. With the GEMM solvers off (segmentation_trainer.py sets MIOPEN_DEBUG_CONV_GEMM=0 for
+# its fp32 reference path) MIOpen's immediate mode answers the PatchGAN head's data gradient (512 -> 1 channels, NHWC bf16)
+# with its asm implicit-GEMM NHWC kernel WITHOUT the 11 MB workspace that kernel needs ("workspace required: 11214848,
+# provided ptr: 0") and the kernel faults a few steps later (rocgdb: igemm_bwd_gtcx35_nhwc_bf16_... memory violation in the
+# on-the-fly GAN-seg loop). That solver is switched off here, before MIOpen reads its environment.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "0")    # same "provided ptr: 0" warning for this one
 
 import torch
 import torch.distributed as dist

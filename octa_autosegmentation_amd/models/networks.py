@@ -444,7 +444,9 @@ class NLayerDiscriminator(nn.Module):
             if on_path and not nhwc:
                 x, nhwc = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), True
             elif not on_path and nhwc:
-                x, nhwc = x.permute(0, 3, 1, 2), False          # a channels-last view: torch's convolution takes it as it is
+                # NCHW copy (37x37x512: nothing): a channels-last VIEW sends torch to MIOpen's NHWC asm solvers, whose data-gradient
+                # kernel runs without its workspace in immediate mode and faults (gan_seg_trainer.py)
+                x, nhwc = x.permute(0, 3, 1, 2).contiguous(), False
             if fused:
                 x = mc.instance_norm_leaky_relu_nhwc(mc.conv4x4(x, m.weight), None, None, mods[i + 2].negative_slope, mods[i + 1].eps)
                 i += 3

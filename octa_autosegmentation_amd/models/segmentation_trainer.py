@@ -14,6 +14,8 @@ os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 # step in profiles/r01_train_kernel_stats.csv); without the GEMM solvers it picks its implicit-GEMM kernels
 # (53 -> 41 ms per step at B=4, 1216x1216).
 os.environ.setdefault("MIOPEN_DEBUG_CONV_GEMM", "0")
+# ... and its asm NHWC data-gradient kernel is launched without the workspace it asks for (faults; see gan_seg_trainer.py)
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
 
 import torch
 import torch.distributed as dist

@@ -75,6 +75,9 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
     dev = torch.device("cuda", torch.cuda.current_device())
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend="nccl", device_id=dev)
+    if os.environ.get("OCTA_E2E_TORCH"):                                   # development aid: torch modules instead of the MFMA path
+        from octa_autosegmentation_amd.models import networks as _nw
+        _nw.USE_MFMA_CONV = False
     if gan:
         # BASELINE configs[4] proper: the on-the-fly stream feeds the joint GAN contrast-adaptation + segmentation step
         # (configs/config_gan_ves_seg.yml; graph loader with min_radius [0, 0]). real_B (real OCTA scans) and the background
@@ -99,8 +102,11 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
         torch.cuda.set_device(dev)
         i = 0
         with torch.cuda.stream(gen_stream):
+            limit = int(os.environ.get("OCTA_E2E_GEN_LIMIT", "0"))          # development aid: stop generating after N batches
+            out = None
             while not stop.is_set():
-                out = gen.generate(sharding.rank_seeds(rank, i, gen_batch, base=seed0))
+                if not limit or i < limit:
+                    out = gen.generate(sharding.rank_seeds(rank, i, gen_batch, base=seed0))
                 gen_stream.synchronize()
                 if os.environ.get("OCTA_E2E_DEBUG"):
                     print(f"   generator batch {i} done t={time.time():.2f}", file=sys.stderr, flush=True)
