@@ -1022,7 +1022,10 @@ __device__ __forceinline__ float bfu(unsigned short h) { return __uint_as_float(
 __global__ void __launch_bounds__(256)
 conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restrict__ Wf /* [Cout][9] */, unsigned short *__restrict__ Y,
                       int N, int H, int W, int Cout) {
-    extern __shared__ float s_wf[];   // [Cout][9] (weights in registers were measured slower: 97 VGPRs, fewer waves in flight)
+    // VALU-bound (333 vector instructions per 8-channel item: bounds checks, 64-bit addresses, bf16 rounding around 72 FMAs).
+    // Tap-major weights read as 16-byte LDS pieces were measured SLOWER (0.217 vs 0.179 ms at 4 x 1216^2 x 32): the LDS was not
+    // the limiter; weights in registers were slower too (97 VGPRs, fewer waves in flight).
+    extern __shared__ float s_wf[];   // [Cout][9]
     for (int i = threadIdx.x; i < Cout * 9; i += 256) s_wf[i] = Wf[i];
     __syncthreads();
     const int groups = Cout / 8, gshift = 31 - __clz(groups);   // groups is a power of two: no integer divisions per item
@@ -1050,12 +1053,14 @@ conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restr
     }
 }
 
+constexpr int C1_ROWS = 4;   // output rows per staging step of the weight gradient
+
 __global__ void __launch_bounds__(256)
 conv3x3_c1_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ dY, float *__restrict__ dW /* [Cout][9] */,
                         int N, int H, int W, int Cout) {
     extern __shared__ float s_mem[];
     float *s_acc = s_mem;                 // [Cout][9]
-    float *s_x = s_mem + Cout * 9;        // [3][W + 2]: image rows y-1, y, y+1 with zero borders (the nine taps of every item)
+    float *s_x = s_mem + Cout * 9;        // [C1_ROWS + 2][W + 2]: image rows y0-1 .. y0+C1_ROWS with zero borders
     for (int i = threadIdx.x; i < Cout * 9; i += 256) s_acc[i] = 0.f;
     const int groups = Cout / 8, gshift = 31 - __clz(groups);
     float acc[8][9];
@@ -1066,38 +1071,48 @@ conv3x3_c1_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned sho
     // 256 is a multiple of `groups`, so a thread keeps its channel group q for the whole loop
     const int q = threadIdx.x & (groups - 1);
     const int items = W * groups, WP = W + 2;
-    for (int row = blockIdx.x; row < N * H; row += gridDim.x) {
-        const int y = row % H;
-        const long n = row / H;
+    const int HG = (H + C1_ROWS - 1) / C1_ROWS;       // row groups per image: one barrier pair and one staging pass per C1_ROWS rows
+    for (int grp = blockIdx.x; grp < N * HG; grp += gridDim.x) {
+        const int y0 = (grp % HG) * C1_ROWS;
+        const long n = grp / HG;
+        const int rows = H - y0 < C1_ROWS ? H - y0 : C1_ROWS;
         __syncthreads();
-        for (int i = threadIdx.x; i < 3 * WP; i += 256) {
-            const int r = i / WP, xx = i % WP - 1, yy = y + r - 1;
-            s_x[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
+        for (int r = 0; r < rows + 2; r++) {
+            const int yy = y0 + r - 1;
+            const bool in_y = yy >= 0 && yy < H;
+            for (int i = threadIdx.x; i < WP; i += 256) {
+                const int xx = i - 1;
+                s_x[r * WP + i] = (in_y && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
+            }
         }
         __syncthreads();
-        // two 16-byte pieces of dY per trip, both loads issued before either is used
-        for (int j = threadIdx.x; j < items; j += 512) {
-            const int x0 = j >> gshift, j1 = j + 256, x1 = j1 >> gshift;
-            const bool has1 = j1 < items;
-            const uint4 v0 = *reinterpret_cast<const uint4 *>(dY + ((long)row * W + x0) * Cout + q * 8);
-            const uint4 v1 = *reinterpret_cast<const uint4 *>(dY + ((long)row * W + (has1 ? x1 : x0)) * Cout + q * 8);
+        for (int rr = 0; rr < rows; rr++) {
+            const long row = n * H + y0 + rr;
+            const float *sx = s_x + rr * WP;
+            // two 16-byte pieces of dY per trip, both loads issued before either is used
+            for (int j = threadIdx.x; j < items; j += 512) {
+                const int x0 = j >> gshift, j1 = j + 256, x1 = j1 >> gshift;
+                const bool has1 = j1 < items;
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(dY + (row * W + x0) * Cout + q * 8);
+                const uint4 v1 = *reinterpret_cast<const uint4 *>(dY + (row * W + (has1 ? x1 : x0)) * Cout + q * 8);
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if (h == 1 && !has1) break;
-                const int x = h ? x1 : x0;
-                const uint4 v = h ? v1 : v0;
-                const unsigned u[4] = {v.x, v.y, v.z, v.w};
-                float d[8];
+                for (int h = 0; h < 2; h++) {
+                    if (h == 1 && !has1) break;
+                    const int x = h ? x1 : x0;
+                    const uint4 v = h ? v1 : v0;
+                    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                    float d[8];
 #pragma unroll
-                for (int k = 0; k < 4; k++) { d[2 * k] = __uint_as_float(u[k] << 16); d[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+                    for (int k = 0; k < 4; k++) { d[2 * k] = __uint_as_float(u[k] << 16); d[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
 #pragma unroll
-                for (int r = 0; r < 3; r++)
+                    for (int r = 0; r < 3; r++)
 #pragma unroll
-                    for (int s = 0; s < 3; s++) {
-                        const float in = s_x[r * WP + x + s];
+                        for (int s = 0; s < 3; s++) {
+                            const float in = sx[r * WP + x + s];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) acc[k][3 * r + s] += d[k] * in;
-                    }
+                            for (int k = 0; k < 8; k++) acc[k][3 * r + s] += d[k] * in;
+                        }
+                }
             }
         }
     }
@@ -1137,10 +1152,11 @@ extern "C" int octa_conv3x3_c1_wgrad(octa_ctx *ctx, const void *d_x, const void 
     OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * Cout * 9, stream));
     const int groups = Cout / 8;
     long blocks = 8L * ctx->num_cus;
-    if (blocks > (long)N * H) blocks = (long)N * H;
+    const long row_groups = (long)N * ((H + C1_ROWS - 1) / C1_ROWS);
+    if (blocks > row_groups) blocks = row_groups;
     (void)groups;   // gridDim.x * 256 is a multiple of `groups` for any block count (256 % groups == 0)
-    if (W > 8192) { octa::set_error("octa_conv3x3_c1_wgrad: W > 8192"); return -2; }
-    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * (Cout * 9 + 3 * (W + 2)), stream, static_cast<const unsigned short *>(d_x),
+    if (W > 4096) { octa::set_error("octa_conv3x3_c1_wgrad: W > 4096"); return -2; }
+    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * (Cout * 9 + (C1_ROWS + 2) * (W + 2)), stream, static_cast<const unsigned short *>(d_x),
                        static_cast<const unsigned short *>(d_dy), d_dw, N, H, W, Cout);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;

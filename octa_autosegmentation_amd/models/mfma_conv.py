@@ -498,9 +498,46 @@ class _ConvT2x2NHWC(torch.autograd.Function):
         return dx, dw
 
 
+class _ConvT1x1NHWC(torch.autograd.Function):
+    """ConvTranspose2d(kernel 1, stride 1, no bias) = a 1x1 convolution with the transposed weight. Forward and data gradient
+    are plain GEMMs (hipBLASLt through torch: 470-580 TFLOP/s on 512 -> 256 at 152^2); the WEIGHT gradient is a [Cin x Cout]
+    product over K = N*H*W = 92 416 pixels, which hipBLASLt runs as 16 workgroups without split-K (0.30 ms, 81 TFLOP/s,
+    profiles/r01_train_mfma_kernel_stats.csv) -- it goes to the MFMA weight-gradient kernel with only the centre tap unmasked
+    (persistent workgroups over pixel blocks, fp32 atomics), as the 3x3 layers do."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        n, h, w, cin = x.shape
+        cout = weight.shape[1]
+        wm = weight.reshape(cin, cout).to(torch.bfloat16)
+        ctx.save_for_backward(x, wm)
+        ctx.w_shape, ctx.w_dtype = weight.shape, weight.dtype
+        return torch.matmul(x.reshape(n * h * w, cin), wm).view(n, h, w, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wm = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        n, h, w, cin = x.shape
+        cout = dy.shape[3]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(dy.reshape(n * h * w, cout), wm.t()).view(n, h, w, cin)
+        if ctx.needs_input_grad[1]:
+            # as a convolution weight [Cout_conv = cout][Cin_conv = cin][3][3] with only tap (1, 1): dW[co][ci] = sum_p dy[p][co] x[p][ci]
+            dwc = conv3x3_nhwc_wgrad(x, dy, tap_mask=1 << 4)[:, :, 1, 1]
+            dw = dwc.t().reshape(ctx.w_shape).to(ctx.w_dtype)
+        return dx, dw
+
+
 def conv_transpose_kxk_nhwc(x, weight, k):
     if k == 2 and x.shape[-1] % 32 == 0 and weight.shape[1] % 32 == 0 and USE_MFMA_CONVT:
         return _ConvT2x2NHWC.apply(x, weight)
+    if k == 1 and x.shape[-1] % 32 == 0 and weight.shape[1] % 32 == 0 and USE_MFMA_CONVT:
+        return _ConvT1x1NHWC.apply(x, weight)
     return _conv_transpose_kxk_gemm(x, weight, k)
 
 

@@ -335,3 +335,26 @@ def test_weight_pack_plan_is_bit_exact_and_follows_updates(hip_lib_built):
     # an unregistered tensor takes the torch formulation
     other = torch.randn(32, 32, 3, 3, device="cuda")
     assert mc.pack_weight(other).shape == (9, 32, 32)
+
+
+def test_transposed_conv_1x1_weight_gradient_on_the_mfma_kernel(hip_lib_built):
+    """ConvTranspose2d(k=1, s=1): GEMM forward / data gradient, weight gradient through the tap-masked MFMA kernel."""
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.models import mfma_conv
+    cin, cout = 128, 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(2, 19, 23, cin, device="cuda", generator=g).to(torch.bfloat16)
+    wt = (torch.randn(cin, cout, 1, 1, device="cuda", generator=g) / cin ** 0.5).to(torch.bfloat16).float()
+    xr, wr = x.float().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr.permute(0, 3, 1, 2), wr, stride=1).permute(0, 2, 3, 1)
+    dy = torch.randn(yr.shape, device="cuda", generator=g).to(torch.bfloat16)
+    yr.backward(dy.float())
+    xm, wm = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ym = mfma_conv.conv_transpose_kxk_nhwc(xm, wm, 1)
+    assert ym.shape == yr.shape
+    ym.backward(dy)
+    _check(ym.detach(), yr.detach())
+    _check(xm.grad, xr.grad)
+    assert wm.grad.shape == wr.grad.shape
+    assert (wm.grad - wr.grad).abs().max().item() <= wr.grad.abs().max().item() * 1e-3 + 1e-5
