@@ -197,11 +197,14 @@ def main():
         torch.cuda.empty_cache()
         train_info = unet_train_bench(dev, args.train_batch, dist, world)
     # BASELINE.json configs[4]: on-the-fly simulation + rasterisation + GPU augmentation feeding the same training step
-    e2e_info = None
+    e2e_info = e2e_gan_info = None
     if not args.no_train and not args.no_end_to_end:
         import train_synthetic
         torch.cuda.empty_cache()
         e2e_info = train_synthetic.run(steps=160, batch=args.train_batch, gen_batch=128, seed0=500000, log=False)   # 5 generator batches: past the queue-filling transient
+        # configs[4] proper: the same stream feeding the joint GAN contrast-adaptation + segmentation step (G, D at 304^2, S at 1216^2)
+        torch.cuda.empty_cache()
+        e2e_gan_info = train_synthetic.run(steps=64, batch=args.train_batch, gen_batch=128, seed0=600000, log=False, gan=True)
 
     dt = sharding.max_over_ranks(dt, dist, dev)
 
@@ -241,6 +244,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg)
         line["unet_train"] = train_info
         line["end_to_end_train"] = e2e_info
+        line["end_to_end_gan_seg_train"] = e2e_gan_info
         print(json.dumps(line))
     for g_ in gens:
         g_.close()

@@ -145,7 +145,7 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
             real_a = torch.maximum(a, bg)                      # AddRandomBackgroundNoised (data_transforms.py:506-516)
             real_b = torch.rand(a.shape, device=dev, generator=noise)
             _, l = trainer.perform_training_step({"real_A": real_a, "real_B": real_b, "real_A_seg": mb["label"]})
-            losses.append(l["S"])
+            losses.append(l["S"].detach())
         else:
             _, l = trainer.perform_training_step({"image": mb["image"], "label": mb["label"]})
             losses.append(l[trainer.loss_name])
