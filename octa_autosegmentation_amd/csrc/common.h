@@ -62,6 +62,19 @@ struct DevBuf {
 
 }  // namespace octa
 
+#if defined(__HIPCC__)
+// fp32 -> bf16, round to nearest even, on gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; the integer formulation costs
+// five per value, which shows in the VALU-bound epilogues and streaming kernels). Bit-identical to it for every non-NaN input.
+__device__ __forceinline__ unsigned octa_pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float octa_f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 octa_bf2;
+    const octa_f2 v = {lo, hi};
+    const octa_bf2 r = __builtin_convertvector(v, octa_bf2);
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ unsigned short octa_f2bf(float f) { return (unsigned short)(octa_pack_bf16x2(f, 0.f) & 0xffffu); }
+#endif
+
 struct octa_ctx {
     int device = 0;
     int num_cus = 256;

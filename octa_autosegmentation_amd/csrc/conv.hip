@@ -44,12 +44,7 @@ const unsigned short *zero_page(octa_ctx *ctx) {
     return ctx->zero_page.as<unsigned short>();
 }
 
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f2bf(float f) { return octa_f2bf(f); }
 
 // X: [N][H][W][Cin] (bf16 bits), Wt: [9][Cout][Cin], Y: [N][Ho][Wo][Cout].
 // out(y, x) = sum_{r,s,ci} Xv(y*st + r - 1, x*st + s - 1, ci) * Wt[3r+s][co][ci], where the virtual input is
@@ -116,7 +111,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
                         float z1 = __uint_as_float(u[k] & 0xffff0000u) * s_ss[q * 8 + 2 * k + 1] + s_ss[KC + q * 8 + 2 * k + 1];
                         z0 = z0 > 0.f ? z0 : z0 * slope;
                         z1 = z1 > 0.f ? z1 : z1 * slope;
-                        u[k] = (unsigned)f2bf(z0) | ((unsigned)f2bf(z1) << 16);
+                        u[k] = octa_pack_bf16x2(z0, z1);
                     }
                     v = make_uint4(u[0], u[1], u[2], u[3]);
                 }
@@ -680,7 +675,7 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
                 float z1 = __uint_as_float(u[j] & 0xffff0000u) * sc[2 * j + 1] + sh[2 * j + 1];
                 z0 = z0 > 0.f ? z0 : z0 * slope;
                 z1 = z1 > 0.f ? z1 : z1 * slope;
-                u[j] = (unsigned)f2bf(z0) | ((unsigned)f2bf(z1) << 16);
+                u[j] = octa_pack_bf16x2(z0, z1);
             }
             v = make_uint4(u[0], u[1], u[2], u[3]);
         }
@@ -963,7 +958,7 @@ head1_bwd_kernel(const unsigned short *__restrict__ x, const unsigned short *__r
             for (int k = 0; k < 4; k++) {
                 a[2 * k] += __uint_as_float(u[k] << 16) * d;
                 a[2 * k + 1] += __uint_as_float(u[k] & 0xffff0000u) * d;
-                o[k] = (unsigned)f2bf(d * s_w[cg * 8 + 2 * k]) | ((unsigned)f2bf(d * s_w[cg * 8 + 2 * k + 1]) << 16);
+                o[k] = octa_pack_bf16x2(d * s_w[cg * 8 + 2 * k], d * s_w[cg * 8 + 2 * k + 1]);
             }
             *reinterpret_cast<uint4 *>(dx + p * C + cg * 8) = make_uint4(o[0], o[1], o[2], o[3]);
             if (cg == 0) sdy += d;
@@ -1047,7 +1042,7 @@ conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restr
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int t = 0; t < 9; t++) { a0 += in[t] * s_wf[(q * 8 + 2 * k) * 9 + t]; a1 += in[t] * s_wf[(q * 8 + 2 * k + 1) * 9 + t]; }
-            o[k] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+            o[k] = octa_pack_bf16x2(a0, a1);
         }
         *reinterpret_cast<uint4 *>(Y + p * Cout + q * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }

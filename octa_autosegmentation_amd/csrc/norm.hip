@@ -27,12 +27,7 @@ template <> struct Vec<float> {
 template <> struct Vec<unsigned short> {  // bf16 bits
     static constexpr int N = 8;
     __device__ static float up(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-    __device__ static unsigned short down(float f) {  // round to nearest even, NaN preserved
-        unsigned u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (unsigned short)(u >> 16);
-    }
+    __device__ static unsigned short down(float f) { return octa_f2bf(f); }  // round to nearest even (v_cvt_pk_bf16_f32)
     __device__ static void load(const unsigned short *p, float (&v)[8]) {
         uint4 t = *reinterpret_cast<const uint4 *>(p);
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
@@ -42,7 +37,7 @@ template <> struct Vec<unsigned short> {  // bf16 bits
     __device__ static void store(unsigned short *p, const float (&v)[8]) {
         unsigned w[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) w[k] = (unsigned)down(v[2 * k]) | ((unsigned)down(v[2 * k + 1]) << 16);
+        for (int k = 0; k < 4; k++) w[k] = octa_pack_bf16x2(v[2 * k], v[2 * k + 1]);
         *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
     __device__ static float ld1(const unsigned short *p) { return up(*p); }
