@@ -187,6 +187,15 @@ int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void *d_x2, int
                            int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask, int out_scale,
                            int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1, const float *d_scale2,
                            const float *d_shift2, float slope, float *d_stat_partials, void *stream);
+/* _fwd5 plus a residual: d_residual (NULL = none) has the shape of d_y and is ADDED to the bf16-rounded result (fp32 add, rounded
+ * again: what a separate bf16 tensor addition would store). Used by the data gradient of a layer whose input has a second
+ * consumer -- the skip connections of the U-Net (MONAI DynUNet, models/networks.py:6): the decoder's gradient of the skip tensor is
+ * ready first and rides along in the epilogue of the encoder's data-gradient launch instead of a separate addition pass. Plain single
+ * output only (no scatter, split, statistics or normalise-on-load). */
+int octa_conv3x3_nhwc_fwd6(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2, int CY1,
+                           int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask, int out_scale,
+                           int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1, const float *d_scale2,
+                           const float *d_shift2, float slope, float *d_stat_partials, const void *d_residual, void *stream);
 int octa_instnorm_lrelu_nhwc_fwd_p(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b, float *d_mean,
                                    float *d_rstd, int B, int C, int64_t hw, float slope, float eps, const float *d_partials, int tiles,
                                    void *stream);

@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(CONV_THREADS, (THT == 16 ? 2 : 1))
 conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                          const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
                          int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, const unsigned short *__restrict__ zero16,
-                         float *__restrict__ part, int tap_mask, int osc, int ooy, int oox, int pad) {
+                         float *__restrict__ part, int tap_mask, int osc, int ooy, int oox, int pad, const unsigned short *__restrict__ R) {
     constexpr int RPW = THT / 4;                           // tile rows per wave (THT = 8: two, THT = 16: four)
     constexpr int IH = (THT - 1) * ST + KS, IW = (TW - 1) * ST + KS;   // KS x KS taps (3: the U-Net / generator layers, 4: the PatchGAN)
     constexpr int PW = (IW + ST - 1) / ST;                 // pixels per LDS plane row (ST = 2: 33 even / 32 odd columns)
@@ -397,9 +397,23 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
         const int oy = ty0 + p / TW, ox = tx0 + p % TW;
         // scattered output (osc = 2): result pixel (oy, ox) lands at (oy * 2 + ooy, ox * 2 + oox) of an image twice as large --
         // one parity class of a zero-insertion-free stride-2 data gradient / 2x2 transposed convolution
-        if (oy < Ho && ox < Wo)
-            *reinterpret_cast<uint4 *>(Yo + (((size_t)n * Ho * osc + oy * osc + ooy) * (Wo * osc) + ox * osc + oox) * ys + yb + q * 8) =
-                *reinterpret_cast<const uint4 *>(s_out + p * OP + q * 16);
+        if (oy < Ho && ox < Wo) {
+            const size_t off = (((size_t)n * Ho * osc + oy * osc + ooy) * (Wo * osc) + ox * osc + oox) * ys + yb + q * 8;
+            uint4 v = *reinterpret_cast<const uint4 *>(s_out + p * OP + q * 16);
+            if (R) {
+                // residual: the other gradient of a tensor with two consumers (a U-Net skip connection), added to the bf16-rounded
+                // result in fp32 and rounded again -- bit for bit what a separate bf16 tensor addition would store
+                const uint4 r = *reinterpret_cast<const uint4 *>(R + off);
+                unsigned a[4] = {v.x, v.y, v.z, v.w};
+                const unsigned b[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    a[k] = octa_pack_bf16x2(__uint_as_float(a[k] << 16) + __uint_as_float(b[k] << 16),
+                                            __uint_as_float(a[k] & 0xffff0000u) + __uint_as_float(b[k] & 0xffff0000u));
+                v = make_uint4(a[0], a[1], a[2], a[3]);
+            }
+            *reinterpret_cast<uint4 *>(Yo + off) = v;
+        }
     }
     // InstanceNorm statistics of the layer that follows: per tile and output channel the sum and the sum of squares of the
     // bf16-ROUNDED results (what a statistics pass would read back) -> part[n][tile][Cout][2]; saves that pass over Y.
@@ -440,7 +454,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
 template <int BN, int KCV, int ST = 1, int KS = 3, int THT = TH>
 int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
                      int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, float *part, int tap_mask,
-                     int osc, int ooy, int oox, hipStream_t stream, int pad = 1) {
+                     int osc, int ooy, int oox, hipStream_t stream, int pad = 1, const unsigned short *R = nullptr) {
     constexpr int IH = (THT - 1) * ST + KS, IW = (TW - 1) * ST + KS, PP = KCV / 8;
     constexpr int BUF = ((IH * ST * ((IW + ST - 1) / ST) * PP + 63) / 64 + KS * KS * BN * PP / 64) * 1024;
     constexpr int OUT = THT * TW * (BN * 2 + 16);
@@ -453,7 +467,7 @@ int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, 
     }
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
-    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask, osc, ooy, oox, pad);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask, osc, ooy, oox, pad, R);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -476,10 +490,11 @@ int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const
 
 extern "C" int octa_conv_stat_tiles(int Ho, int Wo) { return ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH); }
 
-extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+extern "C" int octa_conv3x3_nhwc_fwd6(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
                                       int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
                                       int out_scale, int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1,
-                                      const float *d_scale2, const float *d_shift2, float slope, float *d_stat_partials, void *stream_) {
+                                      const float *d_scale2, const float *d_shift2, float slope, float *d_stat_partials,
+                                      const void *d_residual, void *stream_) {
     if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv3x3_nhwc_fwd: null pointer"); return -2; }
     if (N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: bad shape"); return -2; }
     if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
@@ -497,6 +512,11 @@ extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void
         return -2;
     }
     if (d_stat_partials && (out_scale != 1 || d_y2)) { octa::set_error("octa_conv3x3_nhwc_fwd: statistics need a plain single output"); return -2; }
+    const unsigned short *Rz = static_cast<const unsigned short *>(d_residual);
+    if (Rz && (out_scale != 1 || d_y2 || d_scale1 || d_scale2 || d_stat_partials || d_residual == d_y)) {
+        octa::set_error("octa_conv3x3_nhwc_fwd: the residual needs a plain single output on the DMA-staged kernel");
+        return -2;
+    }
     if ((d_scale1 == nullptr) != (d_shift1 == nullptr) || (d_scale2 == nullptr) != (d_shift2 == nullptr)) { octa::set_error("octa_conv3x3_nhwc_fwd: scale and shift come in pairs"); return -2; }
     if (C1 <= 0 || C1 > Cin || C1 % 32 || CY1 <= 0 || CY1 > Cout || CY1 % 32) { octa::set_error("octa_conv3x3_nhwc_fwd: channel splits must be multiples of 32 inside the channel range"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
@@ -513,24 +533,33 @@ extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void
         const unsigned short *z = zero_page(ctx);
         if (!z) return -1;
         if (stride == 2)
-            return wide ? launch_conv_glds<64, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream)
-                        : launch_conv_glds<32, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream);
+            return wide ? launch_conv_glds<64, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz)
+                        : launch_conv_glds<32, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz);
         // 16-row tiles (a wave owns four tile rows: 6 operand reads per 8 MFMAs instead of 4 per 4, 72 MFMAs per barrier) from
         // 200 output rows up: 8-14 % faster on the 304^2 / 608^2 layers (256->128 at 304^2: 1.0 PFLOP/s), no gain at 152^2
         // (half as many workgroups: tail effects) and on the HBM-bound 1216^2 layers. OCTA_CONV_TALL=0 disables.
         static const int tall = [] { const char *e = getenv("OCTA_CONV_TALL"); return e ? atoi(e) : 200; }();
         if (glds_mode == 16 && tall && wide && stride == 1 && tap_mask == 0x1ff && out_scale == 1 && !d_stat_partials && Ho >= tall)
-            return launch_conv_glds<64, 16, 1, 3, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, nullptr, tap_mask, 1, 0, 0, stream);
+            return launch_conv_glds<64, 16, 1, 3, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, nullptr, tap_mask, 1, 0, 0, stream, 1, Rz);
         if (glds_mode == 16)
-            return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream)
-                        : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream);
-        return wide ? launch_conv_glds<64, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream)
-                    : launch_conv_glds<32, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream);
+            return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz)
+                        : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz);
+        return wide ? launch_conv_glds<64, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz)
+                    : launch_conv_glds<32, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz);
     }
+    if (Rz) { octa::set_error("octa_conv3x3_nhwc_fwd: the residual is implemented in the DMA-staged kernel only (OCTA_CONV_GLDS=0 is set)"); return -2; }
     if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream)
                                  : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream);
     return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream)
                 : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream);
+}
+
+extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+                                      int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
+                                      int out_scale, int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1,
+                                      const float *d_scale2, const float *d_shift2, float slope, float *d_stat_partials, void *stream_) {
+    return octa_conv3x3_nhwc_fwd6(ctx, d_x, d_x2, C1, d_w, d_y, d_y2, CY1, N, H, W, Cin, Cout, stride, in_dilation, tap_mask, out_scale, out_off_y,
+                                  out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, nullptr, stream_);
 }
 
 extern "C" int octa_conv3x3_nhwc_fwd4(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,

@@ -5,6 +5,7 @@ Layouts: activations [N, H, W, C] contiguous bfloat16; weights "tap-major" [9, C
 DynUNet naming) into the forward layout and into the layout whose forward pass IS the data gradient.
 """
 import ctypes
+import os
 
 import torch
 
@@ -130,9 +131,10 @@ def pack_convt2x2(w):
             wc.flip(2, 3).permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]).to(torch.bfloat16).contiguous())
 
 
-def conv3x3_nhwc(x, wt, stride=1, in_dilation=1, tap_mask=0x1ff):
+def conv3x3_nhwc(x, wt, stride=1, in_dilation=1, tap_mask=0x1ff, residual=None):
     """x [N,H,W,Cin] bf16, wt [9,Cout,Cin] bf16 -> [N,Ho,Wo,Cout] bf16 (padding 1). tap_mask bit 3r+s = evaluate tap
-    (r, s) of wt (as packed); cleared taps must have zero weights."""
+    (r, s) of wt (as packed); cleared taps must have zero weights. residual (shape of the result, bf16) is added in the
+    kernel's epilogue (octa_conv3x3_nhwc_fwd6)."""
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
     assert wt.dtype == torch.bfloat16 and wt.is_contiguous() and wt.shape[0] == 9 and wt.shape[2] == x.shape[3]
     n, h, w, cin = x.shape
@@ -140,6 +142,14 @@ def conv3x3_nhwc(x, wt, stride=1, in_dilation=1, tap_mask=0x1ff):
     ho = (h * in_dilation - 1) // stride + 1
     wo = (w * in_dilation - 1) // stride + 1
     y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        assert residual.shape == y.shape and residual.dtype == torch.bfloat16 and residual.is_contiguous()
+        rc = _native.lib().octa_conv3x3_nhwc_fwd6(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), None, cin,
+                                                  ctypes.c_void_p(wt.data_ptr()), ctypes.c_void_p(y.data_ptr()), None, cout, n, h, w, cin, cout,
+                                                  int(stride), int(in_dilation), int(tap_mask), 1, 0, 0, None, None, None, None, 0.0, None,
+                                                  ctypes.c_void_p(residual.data_ptr()), _native.current_stream_ptr())
+        _native.check(rc, "octa_conv3x3_nhwc_fwd6")
+        return y
     rc = _native.lib().octa_conv3x3_nhwc_fwd2(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), None, cin,
                                               ctypes.c_void_p(wt.data_ptr()), ctypes.c_void_p(y.data_ptr()), None, cout, n, h, w, cin, cout,
                                               int(stride), int(in_dilation), int(tap_mask), _native.current_stream_ptr())
@@ -262,13 +272,33 @@ def _pad_channels(x, mult=32):
     return out
 
 
+USE_SKIP_GRAD_FUSION = os.environ.get("OCTA_SKIP_FUSION", "1") != "0"     # A/B switch (development aid)
+
+
+class SkipGradMailbox:
+    """A tensor with two consumers in the U-Net (a skip connection: the next encoder block and the decoder's concatenation)
+    receives two gradients that autograd would add in a separate pass over the tensor (`add<bf16>`: 0.32 ms of the step for the
+    four skips). The decoder's gradient is always computed first (everything the encoder block feeds lies between them), so the
+    decoder's backward POSTS its gradient here and reports None to autograd, and the encoder convolution's backward adds it in the
+    epilogue of its data-gradient launch. One mailbox per skip tensor and forward pass (models/networks.py builds them)."""
+    __slots__ = ("pending", "armed")
+
+    def __init__(self):
+        self.pending = None
+        self.armed = False       # set by the encoder convolution's forward when its backward will collect the posting
+
+
 class _Conv3x3NHWC(torch.autograd.Function):
     """y = conv3x3(x, weight), padding 1, stride 1 or 2. x [N,H,W,Cin] bf16 (Cin padded to 32 internally),
     weight [Cout,Cin,3,3] (any float dtype; master copy), y [N,Ho,Wo,Cout] bf16."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, want_stats=False):
+    def forward(ctx, x, weight, stride, want_stats=False, mailbox=None):
         cin = weight.shape[1]
+        ctx.mailbox = None
+        if mailbox is not None and USE_SKIP_GRAD_FUSION and x.requires_grad and x.shape[-1] % 32 == 0 and not (int(stride) == 2 and USE_PARITY_SCATTER):
+            ctx.mailbox = mailbox
+            mailbox.armed = True
         xp = _pad_channels(x.contiguous())
         y, part = _conv_fwd_stats(xp, None, pack_weight(weight, xp.shape[-1]), stride, want_stats)
         ctx.save_for_backward(xp, weight)
@@ -297,15 +327,20 @@ class _Conv3x3NHWC(torch.autograd.Function):
                     wd[:, :cin] = weight
                 dx = conv3x3_s2_dgrad(dy, wd)
             else:
-                dx = conv3x3_nhwc(dy, pack_weight_dgrad(weight, xp.shape[-1]), stride=1, in_dilation=st)
+                res = None
+                if ctx.mailbox is not None:
+                    res, ctx.mailbox.pending = ctx.mailbox.pending, None       # the decoder's gradient of the same tensor, if posted
+                dx = conv3x3_nhwc(dy, pack_weight_dgrad(weight, xp.shape[-1]), stride=1, in_dilation=st, residual=res)
             if xp.shape[-1] != cin:
                 dx = dx[..., :cin].contiguous()
+        elif ctx.mailbox is not None and ctx.mailbox.pending is not None:
+            raise RuntimeError("skip gradient posted but the encoder convolution computes no input gradient")
         if ctx.needs_input_grad[1]:
             if st == 1:
                 dw = conv3x3_nhwc_wgrad(xp, dy)[:, :cin].to(weight.dtype)
             else:
                 dw = _s2_wgrad(xp, dy)[:, :cin].to(weight.dtype)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class _Conv3x3C1(torch.autograd.Function):
@@ -340,13 +375,13 @@ class _Conv3x3C1(torch.autograd.Function):
         return None, dw.view(ctx.w_shape).to(ctx.w_dtype)
 
 
-def conv3x3(x, weight, stride=1, want_stats=False):
+def conv3x3(x, weight, stride=1, want_stats=False, mailbox=None):
     if (x.shape[-1] == 1 and weight.shape[1] == 1 and stride == 1 and weight.shape[0] in (8, 16, 32, 64)
             and not x.requires_grad):
         y = _Conv3x3C1.apply(x, weight)              # streaming first-layer kernels: no statistics epilogue (None = the
         return (y, None) if want_stats else y        # norm runs its own statistics pass)
     """want_stats: also return the per-tile statistics for instance_norm_leaky_relu_nhwc(..., partials=)."""
-    return _Conv3x3NHWC.apply(x, weight, stride, want_stats)
+    return _Conv3x3NHWC.apply(x, weight, stride, want_stats, mailbox)
 
 
 def _p(t):
@@ -359,7 +394,8 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
     (MONAI UnetUpBlock: conv_block(torch.cat((transp_conv(x), skip), 1)))."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, want_stats=False):
+    def forward(ctx, x1, x2, weight, want_stats=False, mailbox=None):
+        ctx.mailbox = mailbox if (mailbox is not None and mailbox.armed) else None
         x1, x2 = x1.contiguous(), x2.contiguous()
         c1, c2 = x1.shape[3], x2.shape[3]
         assert x2.shape[:3] == x1.shape[:3] and weight.shape[1] == c1 + c2 and c1 % 32 == 0 and c2 % 32 == 0
@@ -390,11 +426,14 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
             rc = lib.octa_conv3x3_nhwc_wgrad2(hctx, _p(x1), _p(x2), c1, _p(dy), _p(dwf), n, h, w, c1 + c2, cout, 0x1ff, st)
             _native.check(rc, "octa_conv3x3_nhwc_wgrad2")
             dw = dwf.view(3, 3, cout, c1 + c2).permute(2, 3, 0, 1).to(weight.dtype)
-        return dx1, dx2, dw, None
+        if ctx.mailbox is not None and dx2 is not None and ctx.needs_input_grad[1]:
+            assert ctx.mailbox.pending is None
+            ctx.mailbox.pending, dx2 = dx2, None          # collected by the encoder convolution's data-gradient epilogue
+        return dx1, dx2, dw, None, None
 
 
-def conv3x3_cat(x1, x2, weight, want_stats=False):
-    return _Conv3x3CatNHWC.apply(x1, x2, weight, want_stats)
+def conv3x3_cat(x1, x2, weight, want_stats=False, mailbox=None):
+    return _Conv3x3CatNHWC.apply(x1, x2, weight, want_stats, mailbox)
 
 
 class _InstNormLReLUNHWC(torch.autograd.Function):

@@ -156,7 +156,7 @@ class DynUNet(nn.Module):
 
     # ---- channels-last bf16 path on the hand-written kernels (same parameters, same state dict) ----
     @staticmethod
-    def _basic_block_nhwc(blk, x, skip=None):
+    def _basic_block_nhwc(blk, x, skip=None, mb_recv=None, mb_send=None):
         """x, skip and the result are lazy activations (tensor, scale, shift) -- the normalised tensors are applied by the
         consuming kernels while loading (mfma_conv.py, normalise-on-load), or plain tensors with scale None."""
         from . import mfma_conv as mc
@@ -165,11 +165,12 @@ class DynUNet(nn.Module):
         if not USE_LAZY_NORM:
             xt, sk = x[0], (skip[0] if skip is not None else None)
             if sk is not None and xt.shape[-1] % 32 == 0 and sk.shape[-1] % 32 == 0 and st == 1:
-                y = mc.conv3x3_cat(xt, sk, c1.weight, USE_EPILOGUE_STATS)       # conv over the virtual concatenation (x, skip)
+                # conv over the virtual concatenation (x, skip); mb_send: the skip's gradient rides in the encoder's data-gradient launch
+                y = mc.conv3x3_cat(xt, sk, c1.weight, USE_EPILOGUE_STATS, mb_send)
             else:
                 if sk is not None:
                     xt = torch.cat((xt, sk), dim=-1)
-                y = mc.conv3x3(xt, c1.weight, st, USE_EPILOGUE_STATS)
+                y = mc.conv3x3(xt, c1.weight, st, USE_EPILOGUE_STATS, mb_recv if sk is None else None)
             y, part = y if USE_EPILOGUE_STATS else (y, None)
             y = mc.instance_norm_leaky_relu_nhwc(y, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps, part)
             y = mc.conv3x3(y, c2.weight, 1, USE_EPILOGUE_STATS)
@@ -213,13 +214,15 @@ class DynUNet(nn.Module):
         mc.plan_for_module(self)          # all layers' weights packed by one launch per optimiser step
         y = (x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), None, None)
         skips = [self._basic_block_nhwc(self.input_block, y)]
+        boxes = [mc.SkipGradMailbox()]                       # one per skip tensor: decoder gradient -> encoder data-gradient epilogue
         for d in self.downsamples:
-            skips.append(self._basic_block_nhwc(d, skips[-1]))
-        y = self._basic_block_nhwc(self.bottleneck, skips[-1])
-        for u, s in zip(self.upsamples, skips[::-1]):
+            skips.append(self._basic_block_nhwc(d, skips[-1], mb_recv=boxes[-1]))
+            boxes.append(mc.SkipGradMailbox())
+        y = self._basic_block_nhwc(self.bottleneck, skips[-1], mb_recv=boxes[-1])
+        for u, s, box in zip(self.upsamples, skips[::-1], boxes[::-1]):
             t = u.transp_conv.conv
             up = mc.conv_transpose_kxk_nhwc(mc.materialise(y), t.weight, t.kernel_size[0])
-            y = self._basic_block_nhwc(u.conv_block, (up, None, None), s)
+            y = self._basic_block_nhwc(u.conv_block, (up, None, None), s, mb_send=box)
         o = self.output_block.conv.conv
         return mc.conv1x1_bias_nhwc(mc.materialise(y), o.weight, o.bias).permute(0, 3, 1, 2)
 

@@ -358,3 +358,46 @@ def test_transposed_conv_1x1_weight_gradient_on_the_mfma_kernel(hip_lib_built):
     _check(xm.grad, xr.grad)
     assert wm.grad.shape == wr.grad.shape
     assert (wm.grad - wr.grad).abs().max().item() <= wr.grad.abs().max().item() * 1e-3 + 1e-5
+
+
+@pytest.mark.parametrize("stride_of_layer", [1, 2])
+def test_residual_epilogue_equals_separate_bf16_addition(hip_lib_built, stride_of_layer):
+    """octa_conv3x3_nhwc_fwd6: result + residual in the epilogue is bit for bit conv -> bf16, then a bf16 tensor addition
+    (the data gradient of a stride-1 / stride-2 layer is the dilation-1 / dilation-2 launch)."""
+    import torch
+    from octa_autosegmentation_amd.models import mfma_conv
+    g = torch.Generator(device="cuda").manual_seed(77 + stride_of_layer)
+    cin, cout, n, h, w = 64, 32, 2, 21, 35
+    dy = torch.randn(n, h, w, cin, device="cuda", generator=g).to(torch.bfloat16)
+    wt = (torch.randn(cin, cout, 3, 3, device="cuda", generator=g) / (3.0 * cin ** 0.5)).to(torch.bfloat16)
+    wd = mfma_conv.pack_weight_dgrad(wt)          # [9, cout, cin]: conv(dy, wd) has `cout` channels
+    plain = mfma_conv.conv3x3_nhwc(dy, wd, stride=1, in_dilation=stride_of_layer)
+    res = torch.randn(plain.shape, device="cuda", generator=g).to(torch.bfloat16)
+    fused = mfma_conv.conv3x3_nhwc(dy, wd, stride=1, in_dilation=stride_of_layer, residual=res)
+    assert torch.equal(fused.view(torch.int16), (plain + res).view(torch.int16))
+
+
+def test_skip_gradient_fusion_leaves_the_gradients_unchanged(hip_lib_built):
+    """DynUNet-S step with the decoder's skip gradients riding in the encoder's data-gradient epilogue vs autograd's own
+    additions: every parameter gradient identical up to the fp32 atomics' arrival order of the weight-gradient kernels."""
+    import torch
+    from octa_autosegmentation_amd.models import mfma_conv
+    from octa_autosegmentation_amd.models.networks import DynUNet, init_weights
+    torch.manual_seed(3)
+    net = DynUNet(spatial_dims=2, in_channels=1, out_channels=1, kernel_size=[3, 3, 3, 3, 3], strides=[1, 2, 2, 2, 1],
+                  upsample_kernel_size=[1, 2, 2, 2, 1]).cuda()
+    init_weights(net, "kaiming")
+    x = torch.rand(2, 1, 64, 96, device="cuda")
+    grads = []
+    for fused in (True, False):
+        mfma_conv.USE_SKIP_GRAD_FUSION = fused
+        try:
+            net.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = net(x)
+            out.float().square().mean().backward()
+            grads.append([p.grad.clone() for p in net.parameters()])
+        finally:
+            mfma_conv.USE_SKIP_GRAD_FUSION = True
+    for a, b in zip(*grads):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-6 + 1e-4 * b.abs().max().item())
