@@ -541,8 +541,8 @@ class _ConvT1x1NHWC(torch.autograd.Function):
     """ConvTranspose2d(kernel 1, stride 1, no bias) = a 1x1 convolution with the transposed weight. Forward and data gradient
     are plain GEMMs (hipBLASLt through torch: 470-580 TFLOP/s on 512 -> 256 at 152^2); the WEIGHT gradient is a [Cin x Cout]
     product over K = N*H*W = 92 416 pixels, which hipBLASLt runs as 16 workgroups without split-K (0.30 ms, 81 TFLOP/s,
-    profiles/r01_train_mfma_kernel_stats.csv) -- it goes to the MFMA weight-gradient kernel with only the centre tap unmasked
-    (persistent workgroups over pixel blocks, fp32 atomics), as the 3x3 layers do."""
+    profiles/r01_train_mfma_kernel_stats.csv) -- it is split by hand into 32 batched products with fp32 results (0.055 ms incl.
+    the sum); pixel counts that do not split go to the MFMA weight-gradient kernel with only the centre tap unmasked (0.27 ms)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -566,9 +566,17 @@ class _ConvT1x1NHWC(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.matmul(dy.reshape(n * h * w, cout), wm.t()).view(n, h, w, cin)
         if ctx.needs_input_grad[1]:
-            # as a convolution weight [Cout_conv = cout][Cin_conv = cin][3][3] with only tap (1, 1): dW[co][ci] = sum_p dy[p][co] x[p][ci]
-            dwc = conv3x3_nhwc_wgrad(x, dy, tap_mask=1 << 4)[:, :, 1, 1]
-            dw = dwc.t().reshape(ctx.w_shape).to(ctx.w_dtype)
+            m = n * h * w
+            split = next((s_ for s_ in (32, 16, 8, 4) if m % s_ == 0 and m // s_ >= 512), 0)
+            if split:
+                # split-K by hand: S independent [Cin x m/S] x [m/S x Cout] products with fp32 results (hipBLASLt batched GEMM,
+                # S x 8 workgroups instead of 16), summed in fp32: 0.055 ms against 0.30 (one GEMM) / 0.27 (tap-masked MFMA kernel)
+                dw = torch.bmm(x.reshape(split, m // split, cin).transpose(1, 2), dy.reshape(split, m // split, cout),
+                               out_dtype=torch.float32).sum(0)
+            else:
+                # as a convolution weight [Cout_conv = cout][Cin_conv = cin][3][3] with only tap (1, 1): dW[co][ci] = sum_p dy[p][co] x[p][ci]
+                dw = conv3x3_nhwc_wgrad(x, dy, tap_mask=1 << 4)[:, :, 1, 1].t()
+            dw = dw.reshape(ctx.w_shape).to(ctx.w_dtype)
         return dx, dw
 
 

@@ -337,14 +337,16 @@ def test_weight_pack_plan_is_bit_exact_and_follows_updates(hip_lib_built):
     assert mc.pack_weight(other).shape == (9, 32, 32)
 
 
-def test_transposed_conv_1x1_weight_gradient_on_the_mfma_kernel(hip_lib_built):
-    """ConvTranspose2d(k=1, s=1): GEMM forward / data gradient, weight gradient through the tap-masked MFMA kernel."""
+@pytest.mark.parametrize("hw", [(19, 23), (64, 96)])
+def test_transposed_conv_1x1_weight_gradient_on_the_mfma_kernel(hip_lib_built, hw):
+    """ConvTranspose2d(k=1, s=1): GEMM forward / data gradient; weight gradient as a hand-split batched GEMM with fp32 results
+    (pixel counts divisible by the split: 64 x 96) or through the tap-masked MFMA kernel (19 x 23)."""
     import torch
     import torch.nn.functional as F
     from octa_autosegmentation_amd.models import mfma_conv
     cin, cout = 128, 64
     g = torch.Generator(device="cuda").manual_seed(11)
-    x = torch.randn(2, 19, 23, cin, device="cuda", generator=g).to(torch.bfloat16)
+    x = torch.randn(2, hw[0], hw[1], cin, device="cuda", generator=g).to(torch.bfloat16)
     wt = (torch.randn(cin, cout, 1, 1, device="cuda", generator=g) / cin ** 0.5).to(torch.bfloat16).float()
     xr, wr = x.float().requires_grad_(True), wt.clone().requires_grad_(True)
     yr = F.conv_transpose2d(xr.permute(0, 3, 1, 2), wr, stride=1).permute(0, 2, 3, 1)
