@@ -98,3 +98,11 @@ def test_on_the_fly_training_runs(hip_lib_built):
     import train_synthetic
     res = train_synthetic.run(steps=4, batch=2, gen_batch=8, warmup=1, log=False)
     assert res["value"] > 0 and np.isfinite(res["last_loss"]) and res["n_gpus"] == 1
+
+
+def test_on_the_fly_gan_seg_training_runs(hip_lib_built):
+    """train_synthetic.py --gan (BASELINE configs[4]): the same stream feeding the joint GAN + segmentation step. 20 steps: the
+    MIOpen solver fault this loop exposed (models/gan_seg_trainer.py) needed about twelve steps to show."""
+    import train_synthetic
+    res = train_synthetic.run(steps=20, batch=2, gen_batch=16, warmup=1, log=False, gan=True)
+    assert res["value"] > 0 and np.isfinite(res["first_loss"]) and np.isfinite(res["last_loss"]) and res["n_gpus"] == 1
