@@ -196,6 +196,18 @@ int octa_conv3x3_nhwc_fwd6(octa_ctx *ctx, const void *d_x, const void *d_x2, int
                            int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask, int out_scale,
                            int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1, const float *d_scale2,
                            const float *d_shift2, float slope, float *d_stat_partials, const void *d_residual, void *stream);
+/* InstanceNorm(affine) + LeakyReLU + 1x1 convolution to ONE channel with bias, fused: the last norm of DynUNet's decoder followed
+ * by UnetOutBlock (MONAI, imported at models/networks.py:6; 32 -> 1 channels at 1216^2). d_x [B][hw][C] bf16 (the raw output of the last
+ * 3x3 convolution), d_w / d_b the norm's affine parameters (NULL = none), d_head_w float32[C], d_head_b float32[1] or NULL ->
+ * d_logits bf16 [B][hw]; mean / rstd [B*C] are kept for backward. The normalised tensor and its gradient never reach HBM: backward
+ * rebuilds dL/dy[p][c] = dlogit[p] * head_w[c] from d_dlogits (bf16 [B][hw]) and writes d_dx (bf16), d_dw / d_db (float32[C], may be
+ * NULL), d_dhead_w (float32[C]) and d_dhead_b (float32[1] or NULL), all overwritten. C in {8, 16, 32, 64, 128, 256}. */
+int octa_instnorm_lrelu_head1_nhwc_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, const float *d_b, const float *d_head_w,
+                                       const float *d_head_b, float *d_mean, float *d_rstd, void *d_logits, int B, int C, int64_t hw,
+                                       float slope, float eps, void *stream);
+int octa_instnorm_lrelu_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_dlogits, const float *d_w, const float *d_b,
+                                       const float *d_head_w, const float *d_mean, const float *d_rstd, void *d_dx, float *d_dw, float *d_db,
+                                       float *d_dhead_w, float *d_dhead_b, int B, int C, int64_t hw, float slope, void *stream);
 int octa_instnorm_lrelu_nhwc_fwd_p(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b, float *d_mean,
                                    float *d_rstd, int B, int C, int64_t hw, float slope, float eps, const float *d_partials, int tiles,
                                    void *stream);

@@ -673,3 +673,265 @@ extern "C" int octa_instnorm_lrelu_nhwc_fwd_p(octa_ctx *ctx, const void *d_x, vo
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---- last layer of the U-Net fused: InstanceNorm(affine) + LeakyReLU + 1x1 convolution to ONE channel ---------------
+// DynUNet's last UnetBasicBlock norm followed by UnetOutBlock (MONAI, models/networks.py:6; 32 -> 1 at 1216^2). Unfused, the
+// normalised tensor y (378 MB at B = 4) is written by the norm, read by the head, its gradient is written by the head's backward
+// and read twice by the norm's backward. Here y and dL/dy never exist in HBM: the head's dot product runs on the values the
+// apply pass has in registers, and backward rebuilds dL/dy[p][c] = dlogit[p] * head_w[c] from the one-channel logit gradient.
+// HBM traffic per step: forward x twice + logits (instead of x twice, y twice); backward x twice + dx once (instead of
+// x twice, dy three times, y once, dx once). Same thread layout as the kernels above: the C/8 channel groups of a pixel sit in
+// adjacent lanes, so the dot product closes with C/8 - 1 lane exchanges.
+namespace {
+
+__global__ void __launch_bounds__(NT)
+in_nhwc_head_fwd(const unsigned short *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, long hw, int C, int splits,
+                 const double *__restrict__ sums, float slope, float eps, float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                 const float *__restrict__ headw, const float *__restrict__ headb, unsigned short *__restrict__ logits) {
+    __shared__ float s_g[NHWC_MAXC], s_sh[NHWC_MAXC];
+    const int b = blockIdx.y, s = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += NT) {
+        const double sa = sums[((long)b * C + c) * 2], sq = sums[((long)b * C + c) * 2 + 1];
+        const double mean_d = sa / (double)hw;
+        double var = sq / (double)hw - mean_d * mean_d;
+        if (var < 0) var = 0;
+        const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (s == 0) { mean_out[(long)b * C + c] = mean; rstd_out[(long)b * C + c] = rstd; }
+        const float g = w ? w[c] * rstd : rstd;
+        s_g[c] = g; s_sh[c] = (bias ? bias[c] : 0.f) - mean * g;
+    }
+    __syncthreads();
+    int cg, pl, npl;
+    nhwc_geometry(C, cg, pl, npl);                 // host guarantees NT % (C / 8) == 0 and C / 8 a power of two <= 64
+    const int groups = C / 8;
+    const long per = (hw + splits - 1) / splits;
+    const long p0 = (long)s * per, p1 = p0 + per < hw ? p0 + per : hw;
+    float g[8], sh[8], hv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { g[k] = s_g[cg * 8 + k]; sh[k] = s_sh[cg * 8 + k]; hv[k] = headw[cg * 8 + k]; }
+    const float hb = headb ? *headb : 0.f;
+    const unsigned short *px = x + ((long)b * hw) * C + cg * 8;
+    unsigned short *pl_out = logits + (long)b * hw;
+    long p = p0 + pl;
+    for (; p + 3L * npl < p1; p += 4L * npl) {
+        float v[4][8], dot[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) Vec<unsigned short>::load(px + (p + (long)u * npl) * C, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            dot[u] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float z = v[u][k] * g[k] + sh[k]; dot[u] += (z > 0.f ? z : z * slope) * hv[k]; }
+            for (int d = 1; d < groups; d <<= 1) dot[u] += __shfl_xor(dot[u], d, 64);
+            if (cg == 0) pl_out[p + (long)u * npl] = octa_f2bf(dot[u] + hb);
+        }
+    }
+    for (; p < p1; p += npl) {
+        float v[8], dot = 0.f;
+        Vec<unsigned short>::load(px + p * C, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const float z = v[k] * g[k] + sh[k]; dot += (z > 0.f ? z : z * slope) * hv[k]; }
+        for (int d = 1; d < groups; d <<= 1) dot += __shfl_xor(dot, d, 64);
+        if (cg == 0) pl_out[p] = octa_f2bf(dot + hb);
+    }
+}
+
+// sums[b][c] = (sum g, sum g * xhat) with g = dlogit * head_w[c] * lrelu'(pre); hsums[c] += sum y * dlogit (head weight gradient),
+// hsums[C] += sum dlogit (head bias gradient)
+__global__ void __launch_bounds__(NT)
+in_nhwc_head_bwd_stats(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dl, const float *__restrict__ w,
+                       const float *__restrict__ bias, const float *__restrict__ mean, const float *__restrict__ rstd, long hw, int C, int splits,
+                       float slope, const float *__restrict__ headw, double *__restrict__ sums, double *__restrict__ hsums) {
+    __shared__ float s_red[2 * NT * 8];
+    const int b = blockIdx.y, s = blockIdx.x;
+    int cg, pl, npl;
+    nhwc_geometry(C, cg, pl, npl);
+    const long per = (hw + splits - 1) / splits;
+    const long p0 = (long)s * per, p1 = p0 + per < hw ? p0 + per : hw;
+    float a[8], q[8], t[8], sdl = 0.f, mu[8], rs[8], wc[8], bc[8], hv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int c = cg * 8 + k;
+        a[k] = 0.f; q[k] = 0.f; t[k] = 0.f;
+        mu[k] = mean[(long)b * C + c]; rs[k] = rstd[(long)b * C + c]; wc[k] = w ? w[c] : 1.f; bc[k] = bias ? bias[c] : 0.f; hv[k] = headw[c];
+    }
+    const unsigned short *px = x + ((long)b * hw) * C + cg * 8;
+    const unsigned short *pd = dl + (long)b * hw;
+    long p = p0 + pl;
+    for (; p + (long)npl < p1; p += 2L * npl) {
+        float v[2][8], d[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) { Vec<unsigned short>::load(px + (p + (long)u * npl) * C, v[u]); d[u] = Vec<unsigned short>::up(pd[p + (long)u * npl]); }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float xh = (v[u][k] - mu[k]) * rs[k], z = xh * wc[k] + bc[k];
+                const float dy = d[u] * hv[k];
+                const float gk = z > 0.f ? dy : dy * slope;
+                a[k] += gk; q[k] += gk * xh; t[k] += (z > 0.f ? z : z * slope) * d[u];
+            }
+            sdl += d[u];
+        }
+    }
+    for (; p < p1; p += npl) {
+        float v[8];
+        Vec<unsigned short>::load(px + p * C, v);
+        const float d = Vec<unsigned short>::up(pd[p]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float xh = (v[k] - mu[k]) * rs[k], z = xh * wc[k] + bc[k];
+            const float dy = d * hv[k];
+            const float gk = z > 0.f ? dy : dy * slope;
+            a[k] += gk; q[k] += gk * xh; t[k] += (z > 0.f ? z : z * slope) * d;
+        }
+        sdl += d;
+    }
+    const int groups = C / 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { s_red[(threadIdx.x * 8 + k) * 2] = a[k]; s_red[(threadIdx.x * 8 + k) * 2 + 1] = q[k]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+        const int g = c / 8, k = c % 8;
+        double sa = 0, sq = 0;
+        for (int l = 0; l < npl; l++) { const int tt = l * groups + g; sa += s_red[(tt * 8 + k) * 2]; sq += s_red[(tt * 8 + k) * 2 + 1]; }
+        atomicAdd(&sums[((long)b * C + c) * 2], sa);
+        atomicAdd(&sums[((long)b * C + c) * 2 + 1], sq);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; k++) { s_red[(threadIdx.x * 8 + k) * 2] = t[k]; s_red[(threadIdx.x * 8 + k) * 2 + 1] = (k == 0 && cg == 0) ? sdl : 0.f; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+        const int g = c / 8, k = c % 8;
+        double st = 0;
+        for (int l = 0; l < npl; l++) { const int tt = l * groups + g; st += s_red[(tt * 8 + k) * 2]; }
+        atomicAdd(&hsums[c], st);
+    }
+    if (threadIdx.x == 0) {
+        double sd = 0;
+        for (int l = 0; l < npl; l++) sd += s_red[((l * groups) * 8) * 2 + 1];
+        atomicAdd(&hsums[C], sd);
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+in_nhwc_head_bwd_apply(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dl, unsigned short *__restrict__ dx,
+                       const float *__restrict__ w, const float *__restrict__ bias, const float *__restrict__ mean, const float *__restrict__ rstd,
+                       long hw, int C, int splits, float slope, const float *__restrict__ headw, const double *__restrict__ sums,
+                       const double *__restrict__ hsums, float *__restrict__ dw, float *__restrict__ db, float *__restrict__ dheadw,
+                       float *__restrict__ dheadb) {
+    __shared__ float s_mg[NHWC_MAXC], s_mgx[NHWC_MAXC];
+    const int b = blockIdx.y, s = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += NT) {
+        const double sa = sums[((long)b * C + c) * 2], sq = sums[((long)b * C + c) * 2 + 1];
+        if (s == 0) {
+            if (db) atomicAdd(&db[c], (float)sa);
+            if (dw) atomicAdd(&dw[c], (float)sq);
+            if (b == 0) dheadw[c] = (float)hsums[c];
+        }
+        s_mg[c] = (float)(sa / (double)hw); s_mgx[c] = (float)(sq / (double)hw);
+    }
+    if (s == 0 && b == 0 && threadIdx.x == 0 && dheadb) *dheadb = (float)hsums[C];
+    __syncthreads();
+    int cg, pl, npl;
+    nhwc_geometry(C, cg, pl, npl);
+    const long per = (hw + splits - 1) / splits;
+    const long p0 = (long)s * per, p1 = p0 + per < hw ? p0 + per : hw;
+    float mu[8], rs[8], wc[8], bc[8], mg[8], mgx[8], hv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int c = cg * 8 + k;
+        mu[k] = mean[(long)b * C + c]; rs[k] = rstd[(long)b * C + c]; wc[k] = w ? w[c] : 1.f; bc[k] = bias ? bias[c] : 0.f;
+        mg[k] = s_mg[c]; mgx[k] = s_mgx[c]; hv[k] = headw[c];
+    }
+    const unsigned short *px = x + ((long)b * hw) * C + cg * 8;
+    const unsigned short *pd = dl + (long)b * hw;
+    unsigned short *po = dx + ((long)b * hw) * C + cg * 8;
+    long p = p0 + pl;
+    for (; p + 3L * npl < p1; p += 4L * npl) {
+        float v[4][8], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { Vec<unsigned short>::load(px + (p + (long)u * npl) * C, v[u]); d[u] = Vec<unsigned short>::up(pd[p + (long)u * npl]); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float xh = (v[u][k] - mu[k]) * rs[k];
+                const float dy = d[u] * hv[k];
+                const float gk = (xh * wc[k] + bc[k]) > 0.f ? dy : dy * slope;
+                v[u][k] = wc[k] * rs[k] * (gk - mg[k] - xh * mgx[k]);
+            }
+            Vec<unsigned short>::store(po + (p + (long)u * npl) * C, v[u]);
+        }
+    }
+    for (; p < p1; p += npl) {
+        float v[8];
+        Vec<unsigned short>::load(px + p * C, v);
+        const float d = Vec<unsigned short>::up(pd[p]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float xh = (v[k] - mu[k]) * rs[k];
+            const float dy = d * hv[k];
+            const float gk = (xh * wc[k] + bc[k]) > 0.f ? dy : dy * slope;
+            v[k] = wc[k] * rs[k] * (gk - mg[k] - xh * mgx[k]);
+        }
+        Vec<unsigned short>::store(po + p * C, v);
+    }
+}
+
+int head_check(const char *who, int B, int C, int64_t hw) {
+    if (nhwc_check(who, B, C, hw)) return -2;
+    const int groups = C / 8;
+    if (C > 256 || (groups & (groups - 1)) || NT % groups) { octa::set_error("%s: C must be 8, 16, 32, 64, 128 or 256 (got %d)", who, C); return -2; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int octa_instnorm_lrelu_head1_nhwc_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, const float *d_b, const float *d_head_w,
+                                                  const float *d_head_b, float *d_mean, float *d_rstd, void *d_logits, int B, int C, int64_t hw,
+                                                  float slope, float eps, void *stream_) {
+    if (!ctx || !d_x || !d_head_w || !d_mean || !d_rstd || !d_logits) { octa::set_error("octa_instnorm_lrelu_head1_nhwc_fwd: null pointer"); return -2; }
+    if (head_check("octa_instnorm_lrelu_head1_nhwc_fwd", B, C, hw)) return -2;
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    double *sums = static_cast<double *>(ctx->zeroed(sizeof(double) * 2 * (size_t)B * C, stream));
+    if (!sums) return -1;
+    const int splits = nhwc_splits(ctx, B, hw);
+    const dim3 grid((unsigned)splits, (unsigned)B);
+    const unsigned short *x = static_cast<const unsigned short *>(d_x);
+    hipLaunchKernelGGL(in_nhwc_stats<0>, grid, dim3(NT), 0, stream, x, (const unsigned short *)nullptr, d_w, d_b, (const float *)nullptr,
+                       (const float *)nullptr, (long)hw, C, splits, slope, sums, 0);
+    hipLaunchKernelGGL(in_nhwc_head_fwd, grid, dim3(NT), 0, stream, x, d_w, d_b, (long)hw, C, splits, sums, slope, eps, d_mean, d_rstd, d_head_w,
+                       d_head_b, static_cast<unsigned short *>(d_logits));
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_instnorm_lrelu_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_dlogits, const float *d_w, const float *d_b,
+                                                  const float *d_head_w, const float *d_mean, const float *d_rstd, void *d_dx, float *d_dw,
+                                                  float *d_db, float *d_dhead_w, float *d_dhead_b, int B, int C, int64_t hw, float slope,
+                                                  void *stream_) {
+    if (!ctx || !d_x || !d_dlogits || !d_head_w || !d_mean || !d_rstd || !d_dx || !d_dhead_w) { octa::set_error("octa_instnorm_lrelu_head1_nhwc_bwd: null pointer"); return -2; }
+    if (head_check("octa_instnorm_lrelu_head1_nhwc_bwd", B, C, hw)) return -2;
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    double *sums = static_cast<double *>(ctx->zeroed(sizeof(double) * (2 * (size_t)B * C + C + 1), stream));
+    if (!sums) return -1;
+    double *hsums = sums + 2 * (size_t)B * C;
+    if (d_dw && d_db == d_dw + C) {
+        OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 2 * C, stream));
+    } else {
+        if (d_dw) OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
+        if (d_db) OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float) * C, stream));
+    }
+    const int splits = nhwc_splits(ctx, B, hw);
+    const dim3 grid((unsigned)splits, (unsigned)B);
+    const unsigned short *x = static_cast<const unsigned short *>(d_x), *dl = static_cast<const unsigned short *>(d_dlogits);
+    hipLaunchKernelGGL(in_nhwc_head_bwd_stats, grid, dim3(NT), 0, stream, x, dl, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, d_head_w, sums, hsums);
+    hipLaunchKernelGGL(in_nhwc_head_bwd_apply, grid, dim3(NT), 0, stream, x, dl, static_cast<unsigned short *>(d_dx), d_w, d_b, d_mean, d_rstd,
+                       (long)hw, C, splits, slope, d_head_w, sums, hsums, d_dw, d_db, d_dhead_w, d_dhead_b);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}

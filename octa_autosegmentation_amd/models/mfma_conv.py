@@ -637,6 +637,64 @@ class _Head1NHWC(torch.autograd.Function):
         return dx, dw.view(ctx.w_shape).to(ctx.w_dtype), (db.to(ctx.w_dtype) if ctx.has_bias else None)
 
 
+class _InstNormLReLUHead1NHWC(torch.autograd.Function):
+    """InstanceNorm(affine) + LeakyReLU + 1x1 convolution to one channel (+ bias) in one pair of passes each way
+    (csrc/norm.hip octa_instnorm_lrelu_head1_nhwc_*): the normalised tensor and its gradient never reach HBM."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, eps, head_w, head_b):
+        x = x.contiguous()
+        assert x.dtype == torch.bfloat16 and x.dim() == 4
+        B, H, W, C = x.shape
+        f32 = dict(dtype=torch.float32, device=x.device)
+        g = gamma.float().contiguous() if gamma is not None else None
+        bt = beta.float().contiguous() if beta is not None else None
+        hw_ = head_w.reshape(-1).float().contiguous()
+        hb = head_b.float().contiguous() if head_b is not None else None
+        mean, rstd = torch.empty(B * C, **f32), torch.empty(B * C, **f32)
+        logits = torch.empty((B, H, W, 1), dtype=torch.bfloat16, device=x.device)
+        rc = _native.lib().octa_instnorm_lrelu_head1_nhwc_fwd(_native.ctx(x.device.index), _p(x), _p(g), _p(bt), _p(hw_), _p(hb), _p(mean), _p(rstd),
+                                                              _p(logits), B, C, H * W, float(slope), float(eps), _native.current_stream_ptr())
+        _native.check(rc, "octa_instnorm_lrelu_head1_nhwc_fwd")
+        ctx.save_for_backward(x, g, bt, hw_, mean, rstd)
+        ctx.slope = float(slope)
+        ctx.meta = (gamma is not None, beta is not None, head_b is not None, head_w.shape, head_w.dtype,
+                    gamma.dtype if gamma is not None else None)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, g, bt, hw_, mean, rstd = ctx.saved_tensors
+        has_g, has_b, has_hb, hw_shape, hw_dtype, g_dtype = ctx.meta
+        dl = dl.contiguous()
+        if dl.dtype != torch.bfloat16:
+            dl = dl.to(torch.bfloat16)
+        B, H, W, C = x.shape
+        f32 = dict(dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2 * C, **f32)                   # back to back: one fill clears both
+        dg, db = dgb[:C], dgb[C:]
+        dhw, dhb = torch.empty(C, **f32), torch.empty(1, **f32)
+        rc = _native.lib().octa_instnorm_lrelu_head1_nhwc_bwd(_native.ctx(x.device.index), _p(x), _p(dl), _p(g), _p(bt), _p(hw_), _p(mean), _p(rstd),
+                                                              _p(dx), _p(dg), _p(db), _p(dhw), _p(dhb), B, C, H * W, ctx.slope,
+                                                              _native.current_stream_ptr())
+        _native.check(rc, "octa_instnorm_lrelu_head1_nhwc_bwd")
+        return (dx, dg.to(g_dtype) if has_g else None, db.to(g_dtype) if has_b else None, None, None,
+                dhw.view(hw_shape).to(hw_dtype), dhb.to(hw_dtype) if has_hb else None)
+
+
+USE_FUSED_NORM_HEAD = os.environ.get("OCTA_FUSED_HEAD", "1") != "0"     # A/B switch (development aid)
+
+
+def norm_lrelu_head1_ok(c, head_weight):
+    return USE_FUSED_NORM_HEAD and head_weight.shape[0] == 1 and head_weight.shape[1] == c and c in (8, 16, 32, 64, 128, 256)
+
+
+def instance_norm_leaky_relu_head1_nhwc(x, gamma, beta, negative_slope, eps, head_weight, head_bias):
+    """x [N,H,W,C] bf16 (raw convolution output) -> logits [N,H,W,1] bf16 = head(lrelu(instance_norm(x)))."""
+    return _InstNormLReLUHead1NHWC.apply(x, gamma, beta, negative_slope, eps, head_weight, head_bias)
+
+
 def conv1x1_bias_nhwc(x, weight, bias):
     """1x1 convolution head: weight [Cout, Cin, 1, 1], bias [Cout] -> [N,H,W,Cout] bf16."""
     if weight.shape[0] == 1 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 256 and 256 % (x.shape[-1] // 8) == 0:

@@ -156,7 +156,7 @@ class DynUNet(nn.Module):
 
     # ---- channels-last bf16 path on the hand-written kernels (same parameters, same state dict) ----
     @staticmethod
-    def _basic_block_nhwc(blk, x, skip=None, mb_recv=None, mb_send=None):
+    def _basic_block_nhwc(blk, x, skip=None, mb_recv=None, mb_send=None, head=None):
         """x, skip and the result are lazy activations (tensor, scale, shift) -- the normalised tensors are applied by the
         consuming kernels while loading (mfma_conv.py, normalise-on-load), or plain tensors with scale None."""
         from . import mfma_conv as mc
@@ -175,7 +175,14 @@ class DynUNet(nn.Module):
             y = mc.instance_norm_leaky_relu_nhwc(y, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps, part)
             y = mc.conv3x3(y, c2.weight, 1, USE_EPILOGUE_STATS)
             y, part = y if USE_EPILOGUE_STATS else (y, None)
-            return (mc.instance_norm_leaky_relu_nhwc(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps, part), None, None)
+            if head is not None and part is None and mc.norm_lrelu_head1_ok(y.shape[-1], head.weight):
+                # last block: norm + activation + the 1x1 output convolution in one pair of passes, nothing normalised goes to HBM
+                return mc.instance_norm_leaky_relu_head1_nhwc(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps,
+                                                              head.weight, head.bias)
+            y = mc.instance_norm_leaky_relu_nhwc(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps, part)
+            if head is not None:
+                return mc.conv1x1_bias_nhwc(y, head.weight, head.bias)
+            return (y, None, None)
         if x[0].shape[-1] % 32 != 0 or (skip is not None and (skip[0].shape[-1] % 32 != 0 or st != 1)):
             # channel-padded first layer (or an odd split): through the single-input binding on a real tensor
             xt = mc.materialise(x)
@@ -219,12 +226,15 @@ class DynUNet(nn.Module):
             skips.append(self._basic_block_nhwc(d, skips[-1], mb_recv=boxes[-1]))
             boxes.append(mc.SkipGradMailbox())
         y = self._basic_block_nhwc(self.bottleneck, skips[-1], mb_recv=boxes[-1])
-        for u, s, box in zip(self.upsamples, skips[::-1], boxes[::-1]):
+        o = self.output_block.conv.conv
+        last = len(self.upsamples) - 1
+        for i, (u, s, box) in enumerate(zip(self.upsamples, skips[::-1], boxes[::-1])):
             t = u.transp_conv.conv
             up = mc.conv_transpose_kxk_nhwc(mc.materialise(y), t.weight, t.kernel_size[0])
-            y = self._basic_block_nhwc(u.conv_block, (up, None, None), s, mb_send=box)
-        o = self.output_block.conv.conv
-        return mc.conv1x1_bias_nhwc(mc.materialise(y), o.weight, o.bias).permute(0, 3, 1, 2)
+            y = self._basic_block_nhwc(u.conv_block, (up, None, None), s, mb_send=box, head=o if (i == last and not USE_LAZY_NORM) else None)
+        if USE_LAZY_NORM:
+            y = mc.conv1x1_bias_nhwc(mc.materialise(y), o.weight, o.bias)
+        return y.permute(0, 3, 1, 2)
 
     def forward(self, x):
         if self._mfma_path_ok(x):

@@ -403,3 +403,42 @@ def test_skip_gradient_fusion_leaves_the_gradients_unchanged(hip_lib_built):
             mfma_conv.USE_SKIP_GRAD_FUSION = True
     for a, b in zip(*grads):
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-6 + 1e-4 * b.abs().max().item())
+
+
+@pytest.mark.parametrize("c,h,w", [(32, 37, 53), (64, 16, 24)])
+def test_fused_norm_head_matches_torch_fp64(hip_lib_built, c, h, w):
+    """InstanceNorm(affine) + LeakyReLU + 1x1 head to one channel in one pair of passes (csrc/norm.hip) against the plain torch
+    float64 formulation (MIOpen's fp32 instance-norm backward is itself off by 1e-2 on odd plane sizes) on the same bf16 input: logits within one bf16 rounding, gradients within 2^-7 of their scale (the fused
+    route rounds LESS than the unfused one: the normalised tensor and its gradient are never rounded to bf16)."""
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.models import mfma_conv
+    g = torch.Generator(device="cuda").manual_seed(c + h)
+    n = 2
+    x = (torch.randn(n, h, w, c, device="cuda", generator=g) * 1.7 + 0.3).to(torch.bfloat16)
+    gamma = torch.rand(c, device="cuda", generator=g) + 0.5
+    beta = torch.randn(c, device="cuda", generator=g) * 0.2
+    hw_ = torch.randn(1, c, 1, 1, device="cuda", generator=g) / c ** 0.5
+    hb = torch.randn(1, device="cuda", generator=g)
+    dl = torch.randn(n, h, w, 1, device="cuda", generator=g).to(torch.bfloat16)
+    # reference
+    xr, gr, br, wr, hbr = (t.clone().double().requires_grad_(True) for t in (x, gamma, beta, hw_, hb))
+    y = F.leaky_relu(F.instance_norm(xr.permute(0, 3, 1, 2), weight=gr, bias=br, eps=1e-5), 0.01)
+    lr = (y.permute(0, 2, 3, 1) @ wr.reshape(-1, 1) + hbr)
+    lr.backward(dl.double())
+    # fused
+    xm, gm, bm, wm, hbm = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), \
+        hw_.clone().requires_grad_(True), hb.clone().requires_grad_(True)
+    lm = mfma_conv.instance_norm_leaky_relu_head1_nhwc(xm, gm, bm, 0.01, 1e-5, wm, hbm)
+    assert lm.shape == lr.shape and lm.dtype == torch.bfloat16
+    lm.backward(dl)
+    _check(lm.detach(), lr.detach().float())
+
+    def close(a, b, rel):
+        assert a.shape == b.shape
+        assert (a.float() - b.float()).abs().max().item() <= b.abs().max().item() * rel + 1e-6, ((a.float() - b.float()).abs().max().item(), b.abs().max().item())
+    close(xm.grad, xr.grad, 2.0 ** -7)
+    close(gm.grad, gr.grad, 2e-3)
+    close(bm.grad, br.grad, 2e-3)
+    close(wm.grad, wr.grad, 2e-3)
+    close(hbm.grad, hbr.grad, 2e-3)
