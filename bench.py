@@ -103,8 +103,9 @@ def unet_train_bench(dev, batch, dist, world, steps=10, warmup=3):
             "batch_per_gpu": batch, "ms_per_step": dt / steps * 1e3, "tflops": 2.0 * ips,
             "frac_of_bf16_dense_peak": 2.0 * ips / 2500.0,
             "implementation": "channels-last bf16 on hand-written HIP kernels: MFMA 3x3 conv forward / data gradient / weight "
-                              "gradient (csrc/conv.hip), NHWC InstanceNorm+LeakyReLU (csrc/norm.hip), streaming 1x1 head; "
-                              "hipBLASLt only for the 2x2 up-sampling GEMMs; flat RCCL gradient all-reduce"}
+                              "gradient (csrc/conv.hip; skip-connection gradients in the data-gradient epilogue), NHWC InstanceNorm+LeakyReLU "
+                              "(csrc/norm.hip; the last one fused with the 1x1 output convolution), one-launch weight packing; hipBLASLt "
+                              "only for the 1x1 transposed convolution at the bottleneck; flat RCCL gradient all-reduce"}
 
 
 def main():
