@@ -23,7 +23,9 @@ class WeightPackPlan:
     """All KxK convolution weights of a network packed into both kernel layouts by ONE launch per optimiser step
     (csrc/conv.hip octa_pack_conv_weights) instead of ~7 small torch kernels per layer and step. The plan is
     refreshed when any parameter's version counter (or storage) changed; `pack_weight*` below look parameters up here
-    and fall back to the torch formulation for tensors that are not registered."""
+    and fall back to the torch formulation for tensors that are not registered. Optimisers, `load_state_dict` and every
+    in-place op on the parameter move the counter; writes through `parameter.data` do NOT -- call `invalidate()` after those
+    (`networks.init_weights` does)."""
 
     def __init__(self, convs, convts=()):
         """convs: float32 parameters [Cout,Cin,K,K]; convts: ConvTranspose2d(2, 2) parameters [Cin,Cout,2,2]."""

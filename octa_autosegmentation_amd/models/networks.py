@@ -267,6 +267,12 @@ def init_weights(net: nn.Module, init_type='normal', init_gain=0.02, debug=False
             nn.init.normal_(m.weight.data, 1.0, init_gain)
             nn.init.constant_(m.bias.data, 0.0)
     net.apply(init_func)
+    # writes through `.data` do not move the parameters' version counters: packed copies of the weights (mfma_conv.WeightPackPlan)
+    # of this network or of any sub-network that already ran must be rebuilt
+    for m in net.modules():
+        plan = getattr(m, "_octa_pack_plan", None)
+        if plan is not None:
+            plan.invalidate()
 
 
 # ---------------------------------------------------------------------------------------------------

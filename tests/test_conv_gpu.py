@@ -442,3 +442,23 @@ def test_fused_norm_head_matches_torch_fp64(hip_lib_built, c, h, w):
     close(bm.grad, br.grad, 2e-3)
     close(wm.grad, wr.grad, 2e-3)
     close(hbm.grad, hbr.grad, 2e-3)
+
+
+def test_pack_plan_survives_data_writes_through_init_weights(hip_lib_built):
+    """`.data` writes (init_weights) after a forward pass do not move version counters: the plan is invalidated explicitly."""
+    import torch
+    from octa_autosegmentation_amd.models.networks import DynUNet, init_weights
+    torch.manual_seed(1)
+    net = DynUNet(spatial_dims=2, in_channels=1, out_channels=1, kernel_size=[3, 3, 3], strides=[1, 2, 2], upsample_kernel_size=[2, 2]).cuda()
+    x = torch.rand(1, 1, 32, 32, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        a = net(x).float()
+        init_weights(net, "kaiming")                 # new weights through .data
+        b = net(x).float()
+        net2_out = None
+    ref = DynUNet(spatial_dims=2, in_channels=1, out_channels=1, kernel_size=[3, 3, 3], strides=[1, 2, 2], upsample_kernel_size=[2, 2]).cuda()
+    ref.load_state_dict(net.state_dict())
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        c = ref(x).float()
+    assert not torch.equal(a, b)
+    assert torch.equal(b, c)
