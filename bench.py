@@ -73,7 +73,7 @@ def cpu_baseline(cfg, budget_s=30.0):
             "sample": f"{n} full-length samples (I=100+150, N=2000) incl. 304x304 image + 1216x1216 label, oracle/ C++ on one core"}
 
 
-def unet_train_bench(dev, batch, dist, world, steps=10, warmup=3):
+def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4):
     import torch
     from octa_autosegmentation_amd.models.segmentation_trainer import SegmentationTrainer
     cfg = {"General": {"amp": True, "model": {"name": "DynUNet", "spatial_dims": 2, "in_channels": 1, "out_channels": 1,
