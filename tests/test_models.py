@@ -178,3 +178,35 @@ def test_checkpoint_files_round_trip_and_metrics_csv(tmp_path):
     rows = open(os.path.join(d, "metrics.csv")).read().splitlines()
     assert rows[0] == "epoch,train_loss,val_loss,val_DSC" and rows[2] == "1,0.4,0.5,0.8"
     assert os.path.exists(os.path.join(d, "config.yml"))
+
+
+def _gan_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    from octa_autosegmentation_amd.models.gan_seg_trainer import GanSegTrainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = {"General": {"amp": False, "model": {"name": "GanSegModel", "model_g": {"name": "resnetGenerator9"},
+                                                 "model_d": {"name": "patchGAN70x70"},
+                                                 "model_s": dict(CFG["General"]["model"]), "upshape": (64, 64)}},
+           "Train": {"lr": 2e-4, "loss_dg": "LSGANLoss", "loss_s": "DiceBCELoss"}}
+    torch.manual_seed(200 + rank)                      # different init and different data per rank
+    tr = GanSegTrainer(cfg, "cpu")
+    batch = {"real_A": torch.rand(1, 1, 32, 32), "real_B": torch.rand(1, 1, 32, 32), "real_A_seg": (torch.rand(1, 1, 64, 64) > 0.7).float()}
+    tr.perform_training_step(batch)
+    state = {f"{n}.{k}": v.clone() for n, m in (("g", tr.generator), ("d", tr.discriminator), ("s", tr.segmentor))
+             for k, v in m.state_dict().items() if "skip_layers" not in k}
+    torch.save(state, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gan_seg_step_keeps_the_replicas_identical(tmp_path):
+    """GAN-seg trainer under torch.distributed (gloo, 2 ranks, different data and different seeds per rank): rank 0's parameters are
+    broadcast at construction and every optimiser sees the rank-averaged gradients, so G, D and S are identical on both ranks after
+    the step (the path bench.py --gpus N and train_synthetic.py --gan run over RCCL)."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_gan_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(str(tmp_path / "rank0.pt")), torch.load(str(tmp_path / "rank1.pt"))
+    assert a.keys() == b.keys() and len(a) > 100
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
