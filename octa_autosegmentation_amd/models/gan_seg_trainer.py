@@ -94,10 +94,17 @@ class GanSegTrainer:
         with ac():
             self.discriminator.requires_grad_(False)
             pred_fake_B = self.discriminator(fake_B)
-            real_B_seg = self.segmentor(self._up(real_B))
-            idt_B_seg = self.segmentor(self._up(idt_B)) if self.compute_identity_seg else None
-            fake_B_seg = self.segmentor(self._up(fake_B))
-            pseudo = (real_B_seg.detach() > 0.5).float()
+            with torch.no_grad():                      # only its thresholded, detached output is used (gan_seg_model.py: pseudo-labels)
+                real_B_seg = self.segmentor(self._up(real_B))
+            if self.compute_identity_seg:
+                # S(idt_B) and S(fake_B) as ONE pass over the concatenated batch: InstanceNorm is per sample, so every logit and every
+                # gradient is what the reference's two passes give (fp32 summation order of the weight gradients aside), with half
+                # the launches, one weight-gradient pass and no second gradient accumulation
+                both = self.segmentor(torch.cat((self._up(idt_B), self._up(fake_B)), dim=0))
+                idt_B_seg, fake_B_seg = both[:idt_B.shape[0]], both[idt_B.shape[0]:]
+            else:
+                idt_B_seg, fake_B_seg = None, self.segmentor(self._up(fake_B))
+            pseudo = (real_B_seg > 0.5).float()
             loss_G = self.dg_loss(pred_fake_B.float(), True)
             loss_G_idt = self.l1(idt_B.float(), real_B.float()) if self.compute_identity else torch.zeros((), device=self.device)
             loss_G = loss_G + loss_G_idt
