@@ -79,11 +79,17 @@ class GanSegTrainer:
         # ---- D step
         self.optimizer_D.zero_grad(set_to_none=True)
         with ac():
-            fake_B = self.generator(real_A)
-            idt_B = self.generator(real_B) if (self.compute_identity or self.compute_identity_seg) else None
+            # G(real_A) and G(real_B), D(fake_B) and D(real_B): one pass each over the concatenated batch (both networks normalise per
+            # sample, so the halves are what the reference's separate calls give; the 76x76 residual stages are launch-bound at B = 4)
+            if self.compute_identity or self.compute_identity_seg:
+                g_both = self.generator(torch.cat((real_A, real_B), dim=0))
+                fake_B, idt_B = g_both[:real_A.shape[0]], g_both[real_A.shape[0]:]
+            else:
+                fake_B, idt_B = self.generator(real_A), None
             self.discriminator.requires_grad_(True)
-            loss_D_fake = self.dg_loss(self.discriminator(fake_B.detach()).float(), False)
-            loss_D_real = self.dg_loss(self.discriminator(real_B).float(), True)
+            d_both = self.discriminator(torch.cat((fake_B.detach(), real_B), dim=0)).float()
+            loss_D_fake = self.dg_loss(d_both[:fake_B.shape[0]], False)
+            loss_D_real = self.dg_loss(d_both[fake_B.shape[0]:], True)
             loss_D = 0.5 * (loss_D_fake + loss_D_real)
         loss_D.backward()
         _flat_allreduce(list(self.discriminator.parameters()))
