@@ -420,14 +420,25 @@ __global__ void __launch_bounds__(NT)
 in_nhwc_bwd_apply(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, unsigned short *__restrict__ dx,
                   const float *__restrict__ w, const float *__restrict__ bias, const float *__restrict__ mean,
                   const float *__restrict__ rstd, long hw, int C, int splits, float slope, const double *__restrict__ sums,
-                  float *__restrict__ dw, float *__restrict__ db, int b0) {
+                  float *__restrict__ dw, float *__restrict__ db, int b0, int Bsum) {
     __shared__ float s_mg[NHWC_MAXC], s_mgx[NHWC_MAXC];
     const int b = blockIdx.y + b0, s = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += NT) {
         const double sa = sums[((long)b * C + c) * 2], sq = sums[((long)b * C + c) * 2 + 1];
         if (s == 0) {
-            if (db) atomicAdd(&db[c], (float)sa);
-            if (dw) atomicAdd(&dw[c], (float)sq);
+            if (Bsum > 0) {
+                // whole batch in this launch: ONE workgroup folds the per-image sums and stores the affine gradients -- no cleared
+                // output, no atomics (17 fills per U-Net step), and a fixed summation order
+                if (b == 0) {
+                    double ta = 0, tq = 0;
+                    for (int bb = 0; bb < Bsum; bb++) { ta += sums[((long)bb * C + c) * 2]; tq += sums[((long)bb * C + c) * 2 + 1]; }
+                    if (db) db[c] = (float)ta;
+                    if (dw) dw[c] = (float)tq;
+                }
+            } else {
+                if (db) atomicAdd(&db[c], (float)sa);
+                if (dw) atomicAdd(&dw[c], (float)sq);
+            }
         }
         s_mg[c] = (float)(sa / (double)hw); s_mgx[c] = (float)(sq / (double)hw);
     }
@@ -538,13 +549,16 @@ extern "C" int octa_instnorm_lrelu_nhwc_bwd(octa_ctx *ctx, const void *d_x, cons
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     double *sums = static_cast<double *>(ctx->zeroed(sizeof(double) * 2 * (size_t)B * C, stream));   // pre-zeroed ring slot
     if (!sums) return -1;
-    if (d_dw && d_db == d_dw + C) {                                   // allocated back to back by the host side: one fill
-        OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 2 * C, stream));
-    } else {
-        if (d_dw) OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
-        if (d_db) OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float) * C, stream));
-    }
     const int group = nhwc_group(B, (size_t)hw * C * 2 * 2);   // two tensors (x, dy) are read twice
+    const int bsum = group == B ? B : 0;                         // one launch covers the batch: gradients are stored, not accumulated
+    if (!bsum) {
+        if (d_dw && d_db == d_dw + C) {                               // allocated back to back by the host side: one fill
+            OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 2 * C, stream));
+        } else {
+            if (d_dw) OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * C, stream));
+            if (d_db) OCTA_HIP_CHECK(hipMemsetAsync(d_db, 0, sizeof(float) * C, stream));
+        }
+    }
     const int splits = nhwc_splits(ctx, group, hw);
     dim3 grid((unsigned)splits, (unsigned)group);
     const unsigned short *x = static_cast<const unsigned short *>(d_x), *dy = static_cast<const unsigned short *>(d_dy);
@@ -552,7 +566,7 @@ extern "C" int octa_instnorm_lrelu_nhwc_bwd(octa_ctx *ctx, const void *d_x, cons
         if (b0 + group > B) grid.y = (unsigned)(B - b0);
         hipLaunchKernelGGL(in_nhwc_stats<1>, grid, dim3(NT), 0, stream, x, dy, d_w, d_b, d_mean, d_rstd, (long)hw, C, splits, slope, sums, b0);
         hipLaunchKernelGGL(in_nhwc_bwd_apply, grid, dim3(NT), 0, stream, x, dy, static_cast<unsigned short *>(d_dx), d_w, d_b, d_mean, d_rstd,
-                           (long)hw, C, splits, slope, sums, d_dw, d_db, b0);
+                           (long)hw, C, splits, slope, sums, d_dw, d_db, b0, bsum);
     }
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
