@@ -370,7 +370,8 @@ int octa_bif_native_counts(int64_t *h_out2);
 int octa_sim_create(octa_ctx *ctx, const octa_sim_config *cfg, int B, octa_sim **out);
 void octa_sim_destroy(octa_sim *sim);
 
-/* Run all iterations for B samples. Synchronous (the bifurcation service needs the host). */
+/* Run all iterations for B samples. Synchronous (the bifurcation service needs the host). Returns 0, -1 (runtime
+ * failure), -2 (bad arguments) or -3 (a sample set error bits: capacity, or 0x800 = the host did not answer in time). */
 int octa_sim_run(octa_sim *sim, const uint32_t *h_np_seeds, const uint64_t *h_py_seeds, octa_bif_fn bif, void *user,
                  void *stream);
 
@@ -392,6 +393,15 @@ int octa_sim_stats(octa_sim *sim, int64_t *h_stats);
  * of the iteration loop, [5] host ms spent in the bifurcation callback, [6] requests served,
  * [7] bytes of HBM held by the simulator. */
 int octa_sim_timing(octa_sim *sim, double *h_out8);
+
+/* Host-side record of the mailbox service of the last octa_sim_run (persistent form), h_out4: [0] tickets served,
+ * [1] longest absence of the service thread from the mailbox (ms), [2] longest hipEventQuery call (ms; only measured
+ * with OCTA_SIM_LEGACY_EVENT_POLL=1, the round-1 exit condition kept for diagnosis), [3] times that query reported the
+ * launch complete while workgroups were still running. Environment read by octa_sim_create:
+ * OCTA_SIM_MAIL_TIMEOUT_MS (device-side bound on one wait for the host, default 30000; error bit 0x800),
+ * OCTA_SIM_TEST_HOST_STALL_MS (test hook: the service thread sleeps once while a ticket is pending),
+ * OCTA_SIM_SPIN_SCANS (idle scans before the service thread sleeps between scans; 4096, 256 when WORLD_SIZE > 1). */
+int octa_sim_service_stats(octa_sim *sim, double *h_out4);
 
 /* Final O2 / CO2 fields of one sample (host buffers, capacity in points); returns counts. */
 int octa_sim_fields(octa_sim *sim, int sample, double *h_oxy, int64_t cap_oxy, int64_t *n_oxy, double *h_co2,

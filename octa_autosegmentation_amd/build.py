@@ -27,15 +27,43 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _stale(obj, src, hdr_time):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return os.path.getmtime(src) > t or hdr_time > t
+
+
 def build(force=False, verbose=False):
+    """One object per source (compiled in parallel, only the stale ones), then one link."""
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc_path()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = hipcc_path()
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    common = ["common.h", os.path.join("..", "..", "include", "octa_hip.h")]
+    own = {"raster.hip": ["raster_core.h"], "sim.hip": ["sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h"]}
+    mt = lambda hs: max(os.path.getmtime(os.path.join(CSRC, h)) for h in hs)
+    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl")]
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + ".o")
+        if force or _stale(obj, src, mt(common + own.get(s, []))):
+            jobs.append([hipcc] + cflags + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        for res in ex.map(run, jobs):
+            if res.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + res.stdout)
+    res = run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + [os.path.join(objdir, s + ".o") for s in SOURCES] + ["-ldl"])
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
+        raise RuntimeError("hipcc (link) failed:\n" + res.stdout)
     return LIB
 
 

@@ -281,9 +281,10 @@ struct HostMail {
     int *req_n;          // pinned host [B]                     device -> host
     int *req_ticket;     // pinned host [B]                     device -> host (2*it+1: arterial pass, 2*it+2: venous)
     int *resp_ticket;    // pinned host [B]                     host -> device
+    int *done;           // pinned host [1]                     device -> host: workgroups that have left the kernel
+    long timeout_ticks;  // device-side bound on one wait for the host (100 MHz wall clock)
 };
 constexpr int REQ_PER_SAMPLE = 32;
-constexpr long MAIL_TIMEOUT_TICKS = 30L * 100000000L;  // 30 s of the 100 MHz wall clock
 constexpr int ERR_HOST_TIMEOUT = 2048;
 
 __device__ inline void mail_roundtrip(const Blk &b, const SimArrays &A, const HostMail &M, int s, int n_req, int ticket) {
@@ -296,7 +297,7 @@ __device__ inline void mail_roundtrip(const Blk &b, const SimArrays &A, const Ho
         const long t0 = (long)wall_clock64();
         while (__hip_atomic_load(M.resp_ticket + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ticket) {
             __builtin_amdgcn_s_sleep(64);
-            if ((long)wall_clock64() - t0 > MAIL_TIMEOUT_TICKS) { atomicOr(&A.sc->err, ERR_HOST_TIMEOUT); break; }
+            if ((long)wall_clock64() - t0 > M.timeout_ticks) { atomicOr(&A.sc->err, ERR_HOST_TIMEOUT); break; }
         }
         A.sc->prof[5] += (long)wall_clock64() - t0;
         __threadfence_system();
@@ -371,6 +372,13 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
         OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, reqs, req_n, REQ_PER_SAMPLE, s));
         mail_roundtrip(b, A, M, s, *req_n, 2 * it + 2);
     }
+    // the host leaves its service loop when every workgroup has signed off HERE, not on a HIP event: it must not enter
+    // the HIP runtime while workgroups may still be waiting for it (see octa_sim_run)
+    b.sync();
+    if (b.tid == 0) {
+        __threadfence_system();
+        __hip_atomic_fetch_add(M.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace
@@ -386,8 +394,14 @@ struct octa_sim {
     BifRequest *h_reqs = nullptr;   // pinned [2*REQ_CAP]
     double *h_results = nullptr;    // pinned [2*REQ_CAP*6]
     int *h_req_count = nullptr;     // pinned [2]
-    HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr};  // pinned mailbox of the persistent form
+    HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};  // pinned mailbox of the persistent form
     bool lockstep = false;          // OCTA_SIM_LOCKSTEP=1: two launches per iteration (the round-1 form)
+    double mail_timeout_ms = 30000; // OCTA_SIM_MAIL_TIMEOUT_MS: device-side bound on one wait for the host
+    int test_stall_ms = 0;          // OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once with a ticket pending
+    bool legacy_event_poll = false; // OCTA_SIM_LEGACY_EVENT_POLL=1 (diagnosis): also poll hipEventQuery as round 1 did, timed
+    long spin_scans = 4096;         // idle mailbox scans before the service thread starts sleeping 20 us between scans
+    double diag_max_gap_ms = 0, diag_max_query_ms = 0;
+    long diag_tickets = 0, diag_early_event = 0;
     bool ran = false;
     // host copies for export
     std::vector<SampleScalars> h_sc;
@@ -472,11 +486,17 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
         const unsigned fl = hipHostMallocCoherent | hipHostMallocMapped;
         hipError_t e1 = hipHostMalloc((void **)&S->mail.reqs, sizeof(BifRequest) * nb * REQ_PER_SAMPLE, fl);
         hipError_t e2 = hipHostMalloc((void **)&S->mail.results, sizeof(double) * nb * REQ_PER_SAMPLE * 6, fl);
-        hipError_t e3 = hipHostMalloc((void **)&S->mail.req_n, sizeof(int) * nb * 3, fl);
+        hipError_t e3 = hipHostMalloc((void **)&S->mail.req_n, sizeof(int) * (nb * 3 + 16), fl);
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { octa::set_error("octa_sim_create: hipHostMalloc (mailbox) failed"); rc = -1; }
-        else { S->mail.req_ticket = S->mail.req_n + nb; S->mail.resp_ticket = S->mail.req_n + 2 * nb; }
+        else { S->mail.req_ticket = S->mail.req_n + nb; S->mail.resp_ticket = S->mail.req_n + 2 * nb; S->mail.done = S->mail.req_n + 3 * nb; }
         const char *ls = getenv("OCTA_SIM_LOCKSTEP");
         S->lockstep = ls && ls[0] == '1';
+        if (const char *e = getenv("OCTA_SIM_MAIL_TIMEOUT_MS")) { double v = atof(e); if (v >= 1.0) S->mail_timeout_ms = v; }
+        if (const char *e = getenv("OCTA_SIM_TEST_HOST_STALL_MS")) S->test_stall_ms = atoi(e);
+        if (const char *e = getenv("OCTA_SIM_LEGACY_EVENT_POLL")) S->legacy_event_poll = e[0] == '1';
+        // several ranks per host (one service thread per step in flight and rank): give the cores back sooner
+        if (const char *e = getenv("WORLD_SIZE")) { if (atoi(e) > 1) S->spin_scans = 256; }
+        if (const char *e = getenv("OCTA_SIM_SPIN_SCANS")) S->spin_scans = atol(e);
     }
     if (!rc) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIM_LDS);
@@ -600,43 +620,76 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
     S->ms_a = S->ms_b = S->ms_total = S->ms_host_bif = 0; S->n_a = S->n_b = S->n_bif_req = 0;
     auto wall0 = std::chrono::steady_clock::now();
     if (!S->lockstep) {
-        // ---- persistent form: one launch, the host answers mailbox tickets until the kernel has finished
+        // ---- persistent form: one launch, the host answers mailbox tickets until every workgroup has signed off.
+        // Between the launch and that moment this thread makes NO call into the HIP runtime. Round 1 polled
+        // hipEventQuery(ev[1]) here: its first call on a pending event enqueues a notification marker under the stream's
+        // submission lock, and a device-wide wait issued by ANOTHER thread in that window (torch.cuda.synchronize(), the
+        // hipDeviceSynchronize of a growing scratch buffer, hipFree) holds that lock while it waits for this very kernel --
+        // the kernel waits for this thread, this thread for the lock: workgroups ran into their 30 s mailbox timeout
+        // (error bit 0x800). The exit condition is now a counter in the pinned block that the kernel itself increments.
         HostMail &M = S->mail;
-        for (int s = 0; s < 3 * B; s++) M.req_n[s] = 0;
+        for (int s = 0; s < 3 * B + 1; s++) M.req_n[s] = 0;
+        M.timeout_ticks = (long)(S->mail_timeout_ms * 1e5);
         std::vector<int> seen(B, 0);
         OCTA_HIP_CHECK(hipEventRecord(S->ev[0], stream));
         hipLaunchKernelGGL(sim_persistent_kernel, dim3((unsigned)B), dim3(SIM_THREADS), SIM_LDS, stream, P, M);
         OCTA_HIP_CHECK(hipGetLastError());
         OCTA_HIP_CHECK(hipEventRecord(S->ev[1], stream));
-        int idle = 0;
+        using clk = std::chrono::steady_clock;
+        long idle = 0;
         bool failed = false;
+        bool stalled_once = false;
+        auto last_progress = clk::now(), last_scan = last_progress;
+        int last_done = 0;
+        S->diag_max_gap_ms = 0; S->diag_tickets = 0; S->diag_max_query_ms = 0; S->diag_early_event = 0;
         while (true) {
             bool any = false;
             for (int s = 0; s < B; s++) {
                 const int t = __atomic_load_n(M.req_ticket + s, __ATOMIC_ACQUIRE);
                 if (t == seen[s]) continue;
                 any = true;
+                if (S->test_stall_ms > 0 && !stalled_once) {   // test hook: the host goes away once, with a ticket pending
+                    stalled_once = true;
+                    std::this_thread::sleep_for(std::chrono::milliseconds(S->test_stall_ms));
+                }
                 int n = __atomic_load_n(M.req_n + s, __ATOMIC_RELAXED);
                 if (n > REQ_PER_SAMPLE) n = REQ_PER_SAMPLE;
                 if (n > 0) {
-                    auto t0 = std::chrono::steady_clock::now();
+                    auto t0 = clk::now();
                     bif(n, reinterpret_cast<const octa_bif_request *>(M.reqs + (size_t)s * REQ_PER_SAMPLE),
                         M.results + (size_t)s * REQ_PER_SAMPLE * 6, user);
-                    S->ms_host_bif += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    S->ms_host_bif += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
                     S->n_bif_req += n;
                 }
                 __atomic_store_n(M.resp_ticket + s, t, __ATOMIC_RELEASE);
                 seen[s] = t;
+                S->diag_tickets++;
             }
-            if (any) { idle = 0; continue; }
+            const int done = __atomic_load_n(M.done, __ATOMIC_ACQUIRE);
+            if (done >= B) break;
+            if (any || done != last_done) { idle = 0; last_done = done; last_progress = last_scan = clk::now(); continue; }
             if ((++idle & 63) == 0) {
-                hipError_t q = hipEventQuery(S->ev[1]);
-                if (q == hipSuccess) break;
-                if (q != hipErrorNotReady) { octa::set_error("octa_sim_run: kernel failed: %s", hipGetErrorString(q)); failed = true; break; }
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > 600.0) {
-                    octa::set_error("octa_sim_run: simulation kernel did not finish within 600 s"); failed = true; break;
+                const auto now = clk::now();
+                const double gap = std::chrono::duration<double, std::milli>(now - last_scan).count();
+                if (gap > S->diag_max_gap_ms) S->diag_max_gap_ms = gap;   // how long this thread was away from the mailbox
+                last_scan = now;
+                if (S->legacy_event_poll) {   // diagnosis only (OCTA_SIM_LEGACY_EVENT_POLL=1): the round-1 exit condition, timed
+                    hipError_t q = hipEventQuery(S->ev[1]);
+                    const double qms = std::chrono::duration<double, std::milli>(clk::now() - now).count();
+                    if (qms > S->diag_max_query_ms) S->diag_max_query_ms = qms;
+                    if (q == hipSuccess && __atomic_load_n(M.done, __ATOMIC_ACQUIRE) < B) S->diag_early_event++;
+                    last_scan = clk::now();
                 }
-                if (idle > 4096) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                // no ticket and no workgroup finished for 20 s: the kernel is gone (fault) or wedged. Only now ask the runtime.
+                if (std::chrono::duration<double>(now - last_progress).count() > 20.0 + S->mail_timeout_ms * 1e-3) {
+                    hipError_t q = hipEventQuery(S->ev[1]);
+                    octa::set_error("octa_sim_run: no mailbox ticket and no finished sample for %.0f s (%d of %d workgroups signed off, "
+                                    "%ld tickets served, stream status: %s)", std::chrono::duration<double>(now - last_progress).count(),
+                                    done, B, S->diag_tickets, q == hipSuccess ? "complete" : hipGetErrorString(q));
+                    failed = true;
+                    break;
+                }
+                if (idle > S->spin_scans) std::this_thread::sleep_for(std::chrono::microseconds(20));
             }
         }
         if (failed) return -1;
@@ -674,7 +727,17 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
     OCTA_HIP_CHECK(hipStreamSynchronize(stream));
     S->ran = true;
     for (int s = 0; s < B; s++)
-        if (S->h_sc[s].err) { octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x", s, S->h_sc[s].err); return -3; }
+        if (S->h_sc[s].err) {
+            if ((S->h_sc[s].err & ERR_HOST_TIMEOUT) && !S->lockstep)
+                octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x: a workgroup waited more than %.0f ms for the host's "
+                                "mailbox answer (request ticket %d, answered %d, %ld tickets served this run, longest absence of the service thread "
+                                "%.1f ms, longest hipEventQuery %.1f ms, early event completions %ld)", s, S->h_sc[s].err, S->mail_timeout_ms,
+                                S->mail.req_ticket[s], S->mail.resp_ticket[s], S->diag_tickets, S->diag_max_gap_ms, S->diag_max_query_ms,
+                                S->diag_early_event);
+            else
+                octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x", s, S->h_sc[s].err);
+            return -3;
+        }
     return 0;
 }
 
@@ -783,6 +846,12 @@ extern "C" int octa_sim_kat_kd_order(octa_ctx *ctx, const double *h_pts, int64_t
     OCTA_HIP_CHECK(hipMemcpy(h.data(), d_idx, sizeof(unsigned short) * n, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; i++) h_indices[i] = (int32_t)h[i];
     (void)hipFree(d_pts); (void)hipFree(d_idx); if (d_need) (void)hipFree(d_need);
+    return 0;
+}
+
+extern "C" int octa_sim_service_stats(octa_sim *S, double *h_out4) {
+    if (!S || !S->ran || !h_out4) { octa::set_error("octa_sim_service_stats: run the simulation first"); return -2; }
+    h_out4[0] = (double)S->diag_tickets; h_out4[1] = S->diag_max_gap_ms; h_out4[2] = S->diag_max_query_ms; h_out4[3] = (double)S->diag_early_event;
     return 0;
 }
 
