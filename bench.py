@@ -1,7 +1,7 @@
 """bench.py -- headline benchmark: synthetic OCTA triples per second on MI355X.
 
 A step = one pass of the hot path over one batch of seeded samples with the reference's own
-generator config (docker/vessel_graph_gen_docker_config.yml, embedded in tests/golden/sim_golden.npz):
+generator config (docker/vessel_graph_gen_docker_config.yml):
 space-colonisation simulation of B vessel graphs (HIP), 304x304 arterial/venous rasterisation and
 max-combine, 1216x1216 label rasterisation + Floyd-Steinberg binarisation. Outputs stay in memory
 (edge arrays on the host, images/labels in HBM); writing CSV/PNG files is not part of the step.
@@ -49,9 +49,8 @@ def pmc_traffic_per_launch(kernel_name):
 
 
 def load_config():
-    import yaml
-    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
-    return yaml.safe_load(str(g["config_yaml"]))
+    from octa_autosegmentation_amd.utils import configs
+    return configs.load_generator_config()
 
 
 def cpu_baseline(cfg, budget_s=30.0):

@@ -1,0 +1,119 @@
+"""GPU: liveness of the device<->host mailbox of the persistent simulator kernel (leaf-bifurcation service).
+
+Round 1's driver run lost a generator thread to error bit 0x800 (a workgroup waited 30 s for the host). Root cause: the
+service loop polled hipEventQuery, whose first call on a pending event enqueues a notification marker under the stream's
+submission lock; a device-wide wait from another thread (torch.cuda.synchronize, a growing scratch buffer's
+hipDeviceSynchronize, hipFree) holds that lock while it waits for the very kernel that waits for the service loop.
+These tests pin the fix (octa_sim_run leaves on a device-written sign-off counter and never enters the HIP runtime while
+workgroups may wait for it) and that a host that does go away is an ERROR, not a warning.
+"""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(i1, i2):
+    from octa_autosegmentation_amd.utils import configs
+    cfg = configs.load_generator_config()
+    cfg["Greenhouse"]["modes"][0]["I"] = i1
+    cfg["Greenhouse"]["modes"][1]["I"] = i2
+    return cfg
+
+
+def test_host_stall_is_fatal(hip_lib_built, monkeypatch):
+    """A service thread that disappears for 1 s with a ticket pending, against a 300 ms device-side bound: octa_sim_run
+    must fail with the timeout bit and say what the host side saw."""
+    from octa_autosegmentation_amd import _native
+    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
+    monkeypatch.setenv("OCTA_SIM_MAIL_TIMEOUT_MS", "300")
+    monkeypatch.setenv("OCTA_SIM_TEST_HOST_STALL_MS", "1000")
+    sim = greenhouse.BatchSimulator(_cfg(100, 20), 4)
+    try:
+        with pytest.raises(_native.OctaHipError) as ei:
+            sim.run([0, 1, 2, 3])
+        msg = str(ei.value)
+        assert "rc=-3" in msg and "0x800" in msg and "waited more than 300 ms" in msg and "longest absence" in msg, msg
+    finally:
+        sim.close()
+    # the same simulator configuration without the stall is fine (and the environment hook is per simulator object)
+    monkeypatch.delenv("OCTA_SIM_TEST_HOST_STALL_MS")
+    sim = greenhouse.BatchSimulator(_cfg(100, 20), 4)
+    try:
+        res = sim.run([0, 1, 2, 3])
+        assert int(res.stats[:, 0].max()) == 0 and res.service["tickets"] > 0
+    finally:
+        sim.close()
+
+
+def test_producer_failure_reaches_the_consumer(hip_lib_built, monkeypatch):
+    """train_synthetic.run: a generator thread that dies must fail the training loop (the reference swallows worker
+    exceptions, generate_vessel_graph.py:127-129; round 1 trained on with a dead producer)."""
+    import train_synthetic
+    monkeypatch.setenv("OCTA_SIM_MAIL_TIMEOUT_MS", "300")
+    monkeypatch.setenv("OCTA_SIM_TEST_HOST_STALL_MS", "1000")
+    with pytest.raises(RuntimeError, match="generator thread failed") as ei:
+        train_synthetic.run(steps=4, batch=2, gen_batch=8, warmup=1, log=False)
+    assert "0x800" in str(ei.value.__cause__)
+
+
+@pytest.mark.parametrize("repeat", range(3))
+def test_device_wide_waits_from_another_thread_do_not_starve_the_mailbox(hip_lib_built, repeat):
+    """The round-1 failure window, forced: while two generator threads run simulations back to back, the main thread keeps
+    issuing device-wide waits, allocations and frees. With a 5 s device-side bound a single lost ticket fails the run."""
+    import torch
+    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
+    os.environ["OCTA_SIM_MAIL_TIMEOUT_MS"] = "5000"
+    try:
+        sims = [greenhouse.BatchSimulator(_cfg(60, 30), 16) for _ in range(2)]
+    finally:
+        del os.environ["OCTA_SIM_MAIL_TIMEOUT_MS"]
+    streams = [torch.cuda.Stream() for _ in sims]
+    dev = torch.cuda.current_device()
+    errors, tickets, stop = [], [0, 0], threading.Event()
+
+    def work(slot):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[slot]):
+                for rep in range(6):
+                    res = sims[slot].run(np.arange(16) + 1000 * slot + 16 * rep + 7919 * repeat)
+                    assert int(res.stats[:, 0].max()) == 0
+                    tickets[slot] += res.service["tickets"]
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(len(sims))]
+    for t in ths:
+        t.start()
+    n_sync = 0
+    x = torch.zeros(1 << 20, device="cuda")
+    while any(t.is_alive() for t in ths):
+        torch.cuda.synchronize()                       # hipDeviceSynchronize: waits for the persistent kernels too
+        y = torch.empty(3 << 20, device="cuda"); y.fill_(1.0)
+        del y
+        torch.cuda.empty_cache()                       # hipFree: implicit device-wide wait
+        x += 1
+        float(x[0])                                    # blocking copy on the null stream
+        n_sync += 1
+        time.sleep(0.0005)
+    for t in ths:
+        t.join()
+    for s in sims:
+        s.close()
+    assert not errors, errors
+    assert min(tickets) > 0 and n_sync > 3
+
+
+@pytest.mark.parametrize("repeat", range(3))
+def test_soak_gan_seg_training_with_generator_running(hip_lib_built, repeat):
+    """200 joint GAN + segmentation steps with the generator thread simulating beside them (BASELINE configs[4]): the loop
+    of round 1's failure, long enough for the scratch buffers, MIOpen's solver choices and the allocator to go through
+    their device-wide waits many times. Any lost generator batch raises inside run()."""
+    import train_synthetic
+    res = train_synthetic.run(steps=200, batch=2, gen_batch=32, warmup=2, log=False, gan=True, seed0=70000 + 1000 * repeat)
+    assert res["value"] > 0 and np.isfinite(res["first_loss"]) and np.isfinite(res["last_loss"]) and res["n_gpus"] == 1

@@ -1,0 +1,65 @@
+"""Root-cause record for error bit 0x800 (round 1): run simulations with the round-1 exit condition re-enabled
+(OCTA_SIM_LEGACY_EVENT_POLL=1 adds a timed hipEventQuery to the service loop) while the main thread issues device-wide
+waits, and print how long the longest hipEventQuery took. A call that takes as long as the kernel has left (or the
+device-side bound) is the service thread blocked on the stream's submission lock.
+
+  python tools/repro_mailbox_deadlock.py [--legacy 1] [--reps 8]
+"""
+import argparse
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--legacy", type=int, default=1)
+ap.add_argument("--reps", type=int, default=8)
+ap.add_argument("--timeout-ms", type=int, default=4000)
+a = ap.parse_args()
+os.environ["OCTA_SIM_LEGACY_EVENT_POLL"] = str(a.legacy)
+os.environ["OCTA_SIM_MAIL_TIMEOUT_MS"] = str(a.timeout_ms)
+
+import torch
+from octa_autosegmentation_amd.utils import configs
+from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
+
+cfg = configs.load_generator_config()
+cfg["Greenhouse"]["modes"][0]["I"] = 60
+cfg["Greenhouse"]["modes"][1]["I"] = 30
+sims = [greenhouse.BatchSimulator(cfg, 16) for _ in range(2)]
+streams = [torch.cuda.Stream() for _ in sims]
+dev = torch.cuda.current_device()
+log = []
+
+
+def work(slot):
+    torch.cuda.set_device(dev)
+    with torch.cuda.stream(streams[slot]):
+        for rep in range(a.reps):
+            t0 = time.time()
+            try:
+                res = sims[slot].run(np.arange(16) + 1000 * slot + 16 * rep)
+                log.append((slot, rep, time.time() - t0, "ok", res.service))
+            except Exception as e:  # noqa: BLE001
+                log.append((slot, rep, time.time() - t0, "FAILED: " + str(e)[-400:], None))
+
+
+ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+for t in ths:
+    t.start()
+n = 0
+while any(t.is_alive() for t in ths):
+    torch.cuda.synchronize()
+    y = torch.empty(3 << 20, device="cuda"); y.fill_(1.0); del y
+    torch.cuda.empty_cache()
+    n += 1
+for t in ths:
+    t.join()
+for row in sorted(log):
+    print(row)
+print("device-wide waits issued by the main thread:", n)

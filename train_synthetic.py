@@ -57,9 +57,8 @@ GAN_CONFIG = {   # configs/config_gan_ves_seg.yml, the parts this script uses
 
 
 def load_sim_config():
-    import yaml
-    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
-    return yaml.safe_load(str(g["config_yaml"]))
+    from octa_autosegmentation_amd.utils import configs
+    return configs.load_generator_config()
 
 
 def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
@@ -97,63 +96,91 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
     q = queue.Queue(maxsize=2)
     stop = threading.Event()
     gen_stream = torch.cuda.Stream()
+    failure = []                                                            # the producer's exception, re-raised by the consumer
 
     def produce():
-        torch.cuda.set_device(dev)
-        i = 0
-        with torch.cuda.stream(gen_stream):
-            limit = int(os.environ.get("OCTA_E2E_GEN_LIMIT", "0"))          # development aid: stop generating after N batches
-            out = None
-            while not stop.is_set():
-                if not limit or i < limit:
-                    out = gen.generate(sharding.rank_seeds(rank, i, gen_batch, base=seed0))
-                gen_stream.synchronize()
-                if os.environ.get("OCTA_E2E_DEBUG"):
-                    print(f"   generator batch {i} done t={time.time():.2f}", file=sys.stderr, flush=True)
-                item = (out["image"], out["label_grey"])
+        try:
+            torch.cuda.set_device(dev)
+            i = 0
+            with torch.cuda.stream(gen_stream):
+                limit = int(os.environ.get("OCTA_E2E_GEN_LIMIT", "0"))      # development aid: stop generating after N batches
+                out = None
                 while not stop.is_set():
-                    try:
-                        q.put(item, timeout=0.1)
-                        break
-                    except queue.Full:
-                        pass
-                i += 1
+                    if not limit or i < limit:
+                        out = gen.generate(sharding.rank_seeds(rank, i, gen_batch, base=seed0))
+                    ready = torch.cuda.Event()
+                    ready.record(gen_stream)
+                    if os.environ.get("OCTA_E2E_DEBUG"):
+                        gen_stream.synchronize()
+                        print(f"   generator batch {i} done t={time.time():.2f}", file=sys.stderr, flush=True)
+                    item = (out["image"], out["label_grey"], ready)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            pass
+                    i += 1
+        except BaseException as e:                                          # noqa: BLE001 -- handed to the consumer, which re-raises
+            failure.append(e)
 
-    th = threading.Thread(target=produce, daemon=True)
+    def next_batch():
+        """Blocks for the producer's next batch; a dead producer is an error here, not a silent stall (the reference swallows
+        worker exceptions, generate_vessel_graph.py:127-129; SURVEY section 5 asks the build to surface them)."""
+        while True:
+            if failure:
+                raise RuntimeError("the generator thread failed") from failure[0]
+            try:
+                return q.get(timeout=0.2)
+            except queue.Empty:
+                if not th.is_alive() and not failure:
+                    raise RuntimeError("the generator thread ended without handing over a batch")
+
+    th = threading.Thread(target=produce, name="octa-generator")
     th.start()
     images = labels = None
     pos = 0
     losses = []
     t0 = None
-    for step in range(warmup + steps):
-        if step == warmup:
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            t0 = time.time()
-        if images is None or pos + batch > images.shape[0]:
-            images, labels = q.get()
-            pos = 0
-        if os.environ.get("OCTA_E2E_DEBUG"):
-            torch.cuda.synchronize()
-            print(f"step {step} t={time.time():.2f} pos={pos}", file=sys.stderr, flush=True)
-        mb = aug(images[pos:pos + batch].contiguous(), labels[pos:pos + batch].contiguous())
-        pos += batch
-        if gan:
-            a = mb["image"]
-            bg = torch.rand(a.shape, device=dev, generator=noise) * torch.rand(a.shape, device=dev, generator=noise)
-            real_a = torch.maximum(a, bg)                      # AddRandomBackgroundNoised (data_transforms.py:506-516)
-            real_b = torch.rand(a.shape, device=dev, generator=noise)
-            _, l = trainer.perform_training_step({"real_A": real_a, "real_B": real_b, "real_A_seg": mb["label"]})
-            losses.append(l["S"].detach())
-        else:
-            _, l = trainer.perform_training_step({"image": mb["image"], "label": mb["label"]})
-            losses.append(l[trainer.loss_name])
-    torch.cuda.synchronize()
-    dt = sharding.max_over_ranks(time.time() - t0, dist if world > 1 else None, dev)
-    stop.set()
-    th.join(timeout=30)
-    gen.close()
+    try:
+        for step in range(warmup + steps):
+            if step == warmup:
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t0 = time.time()
+            if images is None or pos + batch > images.shape[0]:
+                images, labels, ready = next_batch()
+                # the batch was written on the generator's stream and its blocks belong to that stream's pool: order the
+                # training stream after the writes, and keep the allocator from recycling the blocks under queued readers
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ready)
+                images.record_stream(cur)
+                labels.record_stream(cur)
+                pos = 0
+            if os.environ.get("OCTA_E2E_DEBUG"):
+                torch.cuda.synchronize()
+                print(f"step {step} t={time.time():.2f} pos={pos}", file=sys.stderr, flush=True)
+            mb = aug(images[pos:pos + batch].contiguous(), labels[pos:pos + batch].contiguous())
+            pos += batch
+            if gan:
+                a = mb["image"]
+                bg = torch.rand(a.shape, device=dev, generator=noise) * torch.rand(a.shape, device=dev, generator=noise)
+                real_a = torch.maximum(a, bg)                      # AddRandomBackgroundNoised (data_transforms.py:506-516)
+                real_b = torch.rand(a.shape, device=dev, generator=noise)
+                _, l = trainer.perform_training_step({"real_A": real_a, "real_B": real_b, "real_A_seg": mb["label"]})
+                losses.append(l["S"].detach())
+            else:
+                _, l = trainer.perform_training_step({"image": mb["image"], "label": mb["label"]})
+                losses.append(l[trainer.loss_name].detach() if hasattr(l[trainer.loss_name], "detach") else l[trainer.loss_name])
+        torch.cuda.synchronize()
+        dt = sharding.max_over_ranks(time.time() - t0, dist if world > 1 else None, dev)
+    finally:
+        stop.set()
+        th.join()
+        gen.close()
+    if failure:                                                             # e.g. the batch being generated when the loop ended
+        raise RuntimeError("the generator thread failed") from failure[0]
     res = {"metric": ("end-to-end on-the-fly GAN-seg training imgs/s (simulate + rasterise + augment + G/D @304^2 + DynUNet-S @1216^2 step)" if gan else
                       "end-to-end on-the-fly training imgs/s (simulate + rasterise + augment + DynUNet-S step @1216^2)"),
            "value": world * batch * steps / dt, "unit": "imgs/s", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3,
