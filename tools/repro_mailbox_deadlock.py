@@ -20,6 +20,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--legacy", type=int, default=1)
 ap.add_argument("--reps", type=int, default=8)
 ap.add_argument("--timeout-ms", type=int, default=4000)
+ap.add_argument("--iters", type=str, default="60,30", help="iterations of the two growth modes (short kernels = many launches)")
+ap.add_argument("--pure-sync", type=int, default=1, help="main thread spins on torch.cuda.synchronize() only")
 a = ap.parse_args()
 os.environ["OCTA_SIM_LEGACY_EVENT_POLL"] = str(a.legacy)
 os.environ["OCTA_SIM_MAIL_TIMEOUT_MS"] = str(a.timeout_ms)
@@ -29,8 +31,7 @@ from octa_autosegmentation_amd.utils import configs
 from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
 
 cfg = configs.load_generator_config()
-cfg["Greenhouse"]["modes"][0]["I"] = 60
-cfg["Greenhouse"]["modes"][1]["I"] = 30
+cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = (int(v) for v in a.iters.split(","))
 sims = [greenhouse.BatchSimulator(cfg, 16) for _ in range(2)]
 streams = [torch.cuda.Stream() for _ in sims]
 dev = torch.cuda.current_device()
@@ -55,11 +56,18 @@ for t in ths:
 n = 0
 while any(t.is_alive() for t in ths):
     torch.cuda.synchronize()
-    y = torch.empty(3 << 20, device="cuda"); y.fill_(1.0); del y
-    torch.cuda.empty_cache()
+    if not a.pure_sync:
+        y = torch.empty(3 << 20, device="cuda"); y.fill_(1.0); del y
+        torch.cuda.empty_cache()
     n += 1
 for t in ths:
     t.join()
-for row in sorted(log):
+ok = [r for r in log if r[3] == "ok"]
+for row in sorted(log)[:6] + [r for r in sorted(log) if r[3] != "ok"][:6]:
     print(row)
+print("runs:", len(log), "failed:", len(log) - len(ok))
+if ok:
+    print("longest hipEventQuery over all runs (ms):", max(r[4]["max_event_query_ms"] for r in ok),
+          " longest absence of the service thread (ms):", max(r[4]["max_absence_ms"] for r in ok),
+          " median run (s):", sorted(r[2] for r in ok)[len(ok) // 2])
 print("device-wide waits issued by the main thread:", n)
