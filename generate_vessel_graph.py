@@ -5,7 +5,10 @@ same outputs per sample under `<output.directory>/<YYYYmmdd_HHMMSS>_<uuid4>/`: `
 (`node1,node2,radius`), `art_ven_img_gray.png` (+ `art_ven_img_gray.npy` for save_3D_volumes: npy), written
 from GPU results: all samples are simulated in lock-step batches by the HIP simulator and rasterised by the HIP
 rasteriser. Additive flags: `--seed S` (sample k uses random.seed(S+k); np.random.seed(S+k); the reference never
-seeds), `--batch B` (samples per GPU batch, default 128), `--device N`.
+seeds), `--batch B` (samples per GPU batch, default 128), `--device N`, `--labels` (also write `<name>_label.png`, the
+1216x1216 binarised label visualize_vessel_graphs.py --binarize would render from the CSV: complete triples in one pass).
+CSV text and PNG files are formatted / encoded natively by a pool of host threads (`--threads`) while the GPU simulates
+the next batch.
 """
 import argparse
 import os
@@ -23,7 +26,8 @@ def main(argv=None):
     parser.add_argument('--config_file', type=str, required=True)
     parser.add_argument('--num_samples', type=int, default=1)
     parser.add_argument('--debug', action="store_true")
-    parser.add_argument('--threads', type=int, default=-1, help="accepted for compatibility; samples run on the GPU")
+    parser.add_argument('--threads', type=int, default=-1, help="host threads that format and write the files (samples run on the GPU)")
+    parser.add_argument('--labels', action="store_true", help="also write <name>_label.png (1216x1216, binarised)")
     parser.add_argument('--seed', type=int, default=None)
     parser.add_argument('--batch', type=int, default=128)
     parser.add_argument('--device', type=int, default=0)
@@ -45,37 +49,46 @@ def main(argv=None):
         raise NotImplementedError("nifti output needs nibabel, which is not part of the MI355X image; use 'npy'")
 
     import torch
+    from octa_autosegmentation_amd.output_files import SampleFileWriter
     torch.cuda.set_device(args.device)
     seed0 = args.seed if args.seed is not None else random.SystemRandom().randrange(0, 2 ** 31 - args.num_samples - 1)
+    writer = SampleFileWriter(args.threads if args.threads > 0 else None)
     done = 0
-    while done < args.num_samples:
-        B = min(args.batch, args.num_samples - done)
-        gen = pipeline.TripleGenerator(config, B)
-        seeds = np.arange(seed0 + done, seed0 + done + B, dtype=np.int64).astype(np.uint32)
-        out = gen.generate(seeds, want_label=False)
-        res = out["result"]
-        images = out["image"].cpu().numpy()
-        for k in range(B):
-            out_dir = os.path.join(os.path.abspath(out_cfg['directory']), datetime.now().strftime('%Y%m%d_%H%M%S') + "_" + str(uuid4()))
-            os.makedirs(out_dir, exist_ok=True)
-            with open(os.path.join(out_dir, 'config.yml'), 'w') as f:
-                yaml.dump(config, f)
-            edges = res.sample_edges(k)
-            if out_cfg.get('save_trees', True):
-                graph_io.write_csv(edges, os.path.join(out_dir, os.path.basename(out_dir) + '.csv'))
-            if out_cfg.get("save_3D_volumes"):
-                shape = np.array([config['Greenhouse']['SimulationSpace'][a] for a in ("no_voxel_x", "no_voxel_y", "no_voxel_z")])
-                vol_dim = [int(d) for d in shape * out_cfg['image_scale_factor']]
-                d_edges = torch.from_numpy(np.ascontiguousarray(edges)).cuda()
-                na = int(res.n_art[k])
-                vols = tree2img.voxelize_edges_device(d_edges, np.array([0, na, len(edges)]), vol_dim)
-                vol = torch.maximum(vols[0], vols[1]).cpu().numpy().astype(np.uint8)
-                np.save(f'{out_dir}/art_ven_img_gray.npy', vol)
-            if out_cfg.get("save_2D_image", True):
-                tree2img.save_2d_img(images[k], out_dir, "art_ven_img_gray")
-        gen.close()
-        done += B
-        print(f"generated {done}/{args.num_samples} vessel graphs")
+    gen = None
+    try:
+        while done < args.num_samples:
+            B = min(args.batch, args.num_samples - done)
+            if gen is None or gen.batch != B:
+                if gen is not None:
+                    gen.close()
+                gen = pipeline.TripleGenerator(config, B)
+            seeds = np.arange(seed0 + done, seed0 + done + B, dtype=np.int64).astype(np.uint32)
+            out = gen.generate(seeds, want_label=args.labels)
+            res = out["result"]
+            images = out["image"].cpu().numpy()
+            labels = out["label"].cpu().numpy() if args.labels else None
+            writer.wait()                                  # the previous batch's files (written while this one was simulated)
+            for k in range(B):
+                out_dir = os.path.join(os.path.abspath(out_cfg['directory']), datetime.now().strftime('%Y%m%d_%H%M%S') + "_" + str(uuid4()))
+                name = os.path.basename(out_dir)
+                edges = res.sample_edges(k)
+                vol = None
+                if out_cfg.get("save_3D_volumes"):
+                    shape = np.array([config['Greenhouse']['SimulationSpace'][a] for a in ("no_voxel_x", "no_voxel_y", "no_voxel_z")])
+                    vol_dim = [int(d) for d in shape * out_cfg['image_scale_factor']]
+                    d_edges = torch.from_numpy(np.ascontiguousarray(edges)).cuda()
+                    na = int(res.n_art[k])
+                    vols = tree2img.voxelize_edges_device(d_edges, np.array([0, na, len(edges)]), vol_dim)
+                    vol = torch.maximum(vols[0], vols[1]).cpu().numpy().astype(np.uint8)
+                writer.submit(out_dir, name, edges=edges if out_cfg.get('save_trees', True) else None,
+                              image=images[k] if out_cfg.get("save_2D_image", True) else None,
+                              label_bits=labels[k] if labels is not None else None, config=config, volume=vol)
+            done += B
+            print(f"generated {done}/{args.num_samples} vessel graphs")
+    finally:
+        writer.close()                                     # a failed write raises here (the reference drops worker exceptions)
+        if gen is not None:
+            gen.close()
 
 
 if __name__ == '__main__':

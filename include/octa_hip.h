@@ -93,6 +93,26 @@ int octa_voxel_padded_dims(const int *dims3, int *padded3);
 int octa_voxelize_3d(octa_ctx *ctx, int B, const double *d_edges, const int64_t *h_edge_off, const uint8_t *d_keep,
                      const int *dims3, double min_radius, double max_radius, int ignore_z, uint16_t *d_out, void *stream);
 
+/* ---- graph CSV and PNG files (host; csrc/fileio.cpp) ----------------------------
+ * The reference's on-disk formats, byte for byte where text is the contract:
+ *   `node1,node2,radius` rows of generate_vessel_graph.py:59-66 / forest.py:196-207 -- positions as str(np.ndarray)
+ *   (numpy default print options), radius as repr(float), "\r\n" row ends (csv.writer default dialect).
+ * octa_csv_format_edges: h_edges [n][7] (node xyz, parent xyz, radius) -> text in `out` (capacity `cap` >=
+ *   octa_csv_bytes_bound(n)); returns the byte count. octa_csv_write_file does the same into a file.
+ * octa_csv_parse_edges: the read-back of visualize_vessel_graphs.py:71-75 + the "Legacy" string branch of
+ *   tree2img.py:73-76 (split on blanks, float()) -> h_out [rows][7]; returns the row count (octa_csv_count_rows sizes it).
+ * octa_png_write_gray8 / octa_png_write_bits: tree2img.py:282-292 (uint8 "L" image) and
+ *   visualize_vessel_graphs.py:99 (mode "1" label: one byte per pixel in, non-zero = white); `level` = zlib level
+ *   (-1: fastest sensible). Pixels decode identically to Pillow's files; compressed bytes are not part of the contract.
+ * All return < 0 on error (octa_last_error()). */
+int64_t octa_csv_bytes_bound(int64_t n_edges);
+int64_t octa_csv_format_edges(const double *h_edges, int64_t n_edges, char *out, int64_t cap);
+int octa_csv_write_file(const char *path, const double *h_edges, int64_t n_edges);
+int64_t octa_csv_count_rows(const char *text, int64_t len);
+int64_t octa_csv_parse_edges(const char *text, int64_t len, double *h_out, int64_t cap_rows);
+int octa_png_write_gray8(const char *path, const uint8_t *h_pixels, int width, int height, int level);
+int octa_png_write_bits(const char *path, const uint8_t *h_pixels, int width, int height, int level);
+
 /* ---- CSV round trip of node positions ------------------------------------
  * Replaces the text round trip str(np.ndarray) -> float() of generate_vessel_graph.py:59-66 +
  * tree2img.py:73-76 for a whole edge array on the device: d_out[n][7] receives the positions exactly as

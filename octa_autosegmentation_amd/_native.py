@@ -33,6 +33,13 @@ SIGNATURES = {
     "octa_bif_native_counts": (c_int, [c_void_p]),
     "octa_instnorm_lrelu_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, ctypes.c_int64, c_int, ctypes.c_float, ctypes.c_float, c_void_p]),
     "octa_instnorm_lrelu_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, ctypes.c_int64, c_int, ctypes.c_float, c_void_p]),
+    "octa_csv_bytes_bound": (ctypes.c_int64, [ctypes.c_int64]),
+    "octa_csv_format_edges": (ctypes.c_int64, [c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64]),
+    "octa_csv_write_file": (c_int, [ctypes.c_char_p, c_void_p, ctypes.c_int64]),
+    "octa_csv_count_rows": (ctypes.c_int64, [c_void_p, ctypes.c_int64]),
+    "octa_csv_parse_edges": (ctypes.c_int64, [c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64]),
+    "octa_png_write_gray8": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int]),
+    "octa_png_write_bits": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int]),
     "octa_sim_create": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
     "octa_sim_destroy": (None, [c_void_p]),
     "octa_sim_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

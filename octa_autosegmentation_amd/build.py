@@ -7,9 +7,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liboctahip.so")
-SOURCES = ["common.cpp", "bif_native.cpp", "raster.hip", "sim.hip", "voxel.hip", "graphio.hip", "norm.hip", "conv.hip", "augment.hip", "postproc.hip", "loss.hip", "blur.hip"]
+SOURCES = ["common.cpp", "bif_native.cpp", "fileio.cpp", "raster.hip", "sim.hip", "voxel.hip", "graphio.hip", "norm.hip", "conv.hip", "augment.hip", "postproc.hip", "loss.hip", "blur.hip"]
 HEADERS = ["common.h", "raster_core.h", "sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h", os.path.join("..", "..", "include", "octa_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-ldl"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-ldl", "-lz"]
 
 
 def hipcc_path():
@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
     common = ["common.h", os.path.join("..", "..", "include", "octa_hip.h")]
     own = {"raster.hip": ["raster_core.h"], "sim.hip": ["sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h"]}
     mt = lambda hs: max(os.path.getmtime(os.path.join(CSRC, h)) for h in hs)
-    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl")]
+    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl", "-lz")]
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + ".o")
@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
         for res in ex.map(run, jobs):
             if res.returncode != 0:
                 raise RuntimeError("hipcc failed:\n" + res.stdout)
-    res = run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + [os.path.join(objdir, s + ".o") for s in SOURCES] + ["-ldl"])
+    res = run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + [os.path.join(objdir, s + ".o") for s in SOURCES] + ["-ldl", "-lz"])
     if res.returncode != 0:
         raise RuntimeError("hipcc (link) failed:\n" + res.stdout)
     return LIB

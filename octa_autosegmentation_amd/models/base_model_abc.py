@@ -1,0 +1,219 @@
+"""Shared behaviour of every trainable model behind ModelInterface (reference models/base_model_abc.py:13-171), for one
+process per GPU:
+
+* optimisers: one Adam per entry of `optimizer_mapping` (lr from the config, betas (0.5, 0.999) unless overridden,
+  `Train.weight_decay`), LambdaLR constant then linear to zero over `Train.epochs_decay` -- one scheduler per optimiser
+  (the reference attaches every scheduler to the LAST optimiser, base_model_abc.py:63-64 uses the stale loop variable;
+  with one optimiser, i.e. the segmentation configs, the two are identical);
+* initialisation: He-normal through `init_weights` ('relu' gain for resnet generators, 'leaky_relu' otherwise) or, with
+  `args.start_epoch > 0`, resume from `<save_dir>/checkpoints/<epoch>_<net>_model.pth` + `<epoch>_<optimizer>_model.pth`
+  (what train.py writes; the reference reads `<epoch>_<optimizer>.pth`, which its own train.py never creates -- both names
+  are accepted here);
+* inference phases: only the network named by `General.inference` is loaded (`model`, `segmentor`/`S`, `generator`/`G`,
+  legacy `<epoch>_model.pth`);
+* training step: bf16 autocast (no loss scaling: the GradScaler argument is accepted and left alone, bf16 has fp32's
+  exponent range), backward, ONE all-reduce per optimiser over a flat fp32 gradient arena, optimiser step.
+
+Gradient arena (world size > 1, or OCTA_GRAD_ARENA=1): every parameter's `.grad` is a view into one contiguous fp32 buffer per
+optimiser. autograd accumulates into the views in place, "zero_grad" is one fill, the data-parallel exchange is one
+RCCL all-reduce on the buffer itself -- no per-parameter copies in or out (round 1 copied ~70 tensors each way per step).
+"""
+import itertools
+import os
+from abc import ABC, abstractmethod
+from typing import Any, Callable, Dict, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from ..utils.enums import Phase
+from .model_interface_abc import ModelInterface, Output
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class GradArena:
+    """One flat fp32 buffer holding the gradients of a parameter list as views."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.attach()
+
+    def attach(self):
+        off = 0
+        for p in self.params:
+            assert p.dtype == torch.float32, "master parameters are fp32"
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+        for p in self.params:                         # someone (e.g. zero_grad(set_to_none=True)) dropped a view: re-attach all
+            if p.grad is None or p.grad.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
+                self.attach()
+                break
+
+    def all_reduce_mean(self):
+        if _dist_on():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+
+def load_checkpoint_file(path, device):
+    """torch.load of a reference-format checkpoint dict {'epoch','model','optimizer','config'} (utils/visualizer.py:225-238);
+    the dict carries the whole config (plain python containers), hence weights_only=False."""
+    return torch.load(path, map_location=device, weights_only=False)
+
+
+class BaseModelABC(nn.Module, ModelInterface, ABC):
+    def __init__(self, optimizer_mapping=None, optimizer_configs: Dict[str, dict] = None, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.optimizer_mapping: Dict[str, list] = optimizer_mapping or {"optimizer": []}
+        self.optimizer_configs = optimizer_configs or dict()
+        self.lr_schedulers = []
+        self._arenas: Dict[str, GradArena] = {}
+        self.amp = True
+
+    # ---- construction -------------------------------------------------------------------------------------------
+    def _nets_of(self, net_names):
+        return [self] if len(net_names) == 0 else [getattr(self, n) for n in net_names]
+
+    def initialize_model_and_optimizer(self, init_mini_batch: dict, init_weights: Callable, config: dict, args, scaler,
+                                       phase=Phase.TRAIN):
+        nets = [getattr(self, n, None) for names in self.optimizer_mapping.values() for n in names]
+        if not any(isinstance(n, nn.Module) for n in nets):
+            print(f"Skipping initialization for {list(self.optimizer_mapping.values())}")
+            return
+        device = torch.device(config["General"].get("device") or "cpu")
+        self.amp = bool(config["General"].get("amp")) and device.type == "cuda"
+        epoch_tag = getattr(args, "epoch", "latest")
+        model_path = os.path.join(config["Output"]["save_dir"], "checkpoints", f"{epoch_tag}_model.pth")
+        if phase == Phase.TRAIN:
+            tr = config[Phase.TRAIN]
+            for optim_name, net_names in self.optimizer_mapping.items():
+                params = itertools.chain(*[n.parameters() for n in self._nets_of(net_names)])
+                setattr(self, optim_name, torch.optim.Adam(params, **{"lr": tr["lr"], "betas": (0.5, 0.999),
+                                                                      "weight_decay": tr.get("weight_decay", 0),
+                                                                      **self.optimizer_configs.get(optim_name, {})}))
+            max_epochs, decay = tr["epochs"], tr.get("epochs_decay", 0)
+
+            def schedule(step: int):
+                return 1 if step < (max_epochs - decay) else (max_epochs - step) * (1 / max(1, decay))
+
+            self.lr_schedulers = [torch.optim.lr_scheduler.LambdaLR(getattr(self, name), schedule) for name in self.optimizer_mapping]
+            if getattr(args, "start_epoch", 0) > 0:
+                self._resume(model_path, device)
+            else:
+                for net_name in [n for names in self.optimizer_mapping.values() for n in names]:
+                    m: nn.Module = getattr(self, net_name)
+                    activation = "relu" if "resnet" in m._get_name().lower() else "leaky_relu"
+                    init_weights(m, init_type="kaiming", nonlinearity=activation)
+                    print(f"Initialized {net_name} network weights using He initialization ({activation}).")
+            if _dist_on():                                     # replicas start from rank 0's weights
+                for p in self.parameters():
+                    dist.broadcast(p.data, src=0)
+                self._after_weight_surgery()
+            # single process: gradients are handed over by autograd without an accumulation pass (grad = None before backward);
+            # data-parallel: they accumulate into the arena views, which IS the all-reduce bucket
+            if _dist_on() or os.environ.get("OCTA_GRAD_ARENA") == "1":
+                self._arenas = {name: GradArena(itertools.chain(*[n.parameters() for n in self._nets_of(net_names)]))
+                                for name, net_names in self.optimizer_mapping.items()}
+        else:
+            prefix = config["General"].get("inference")
+            prefix = prefix + "_" if prefix else "model_"
+            checkpoint_path = model_path.replace("model.pth", f"{prefix}model.pth")
+            if not os.path.exists(checkpoint_path):
+                checkpoint_path = checkpoint_path.replace("model_", "")          # legacy `<epoch>_model.pth`
+            checkpoint = load_checkpoint_file(checkpoint_path, device)
+            which = config["General"].get("inference") or "model"
+            which = {"S": "segmentor", "G": "generator"}.get(which, which)
+            config["General"]["inference"] = which
+            assert hasattr(self, which), f"Inference mode {which} not implemented."
+            getattr(self, which).load_state_dict(checkpoint["model"])
+            self._after_weight_surgery()
+            print(f"Loaded network weights {which} from epoch {checkpoint['epoch']}.")
+
+    def _resume(self, model_path, device):
+        for optimizer_name, net_names in self.optimizer_mapping.items():
+            checkpoint = None
+            if len(net_names) == 0:
+                checkpoint = load_checkpoint_file(model_path, device)
+                self.load_state_dict(checkpoint["model"])
+            for net_name in net_names:
+                checkpoint = load_checkpoint_file(model_path.replace("model.pth", f"{net_name}_model.pth"), device)
+                getattr(self, net_name).load_state_dict(checkpoint["model"])
+            optimizer: torch.optim.Optimizer = getattr(self, optimizer_name)
+            if checkpoint.get("optimizer") is not None:
+                optimizer.load_state_dict(checkpoint["optimizer"])
+            else:
+                for cand in (model_path.replace("model.pth", f"{optimizer_name}.pth"), model_path.replace("model.pth", f"{optimizer_name}_model.pth")):
+                    if os.path.exists(cand):
+                        optimizer.load_state_dict(load_checkpoint_file(cand, device)["optimizer"])
+                        break
+                else:
+                    raise FileNotFoundError(f"no optimizer state for {optimizer_name} next to {model_path}")
+            print(f"Loaded all network weights from epoch {checkpoint['epoch']}.")
+        self._after_weight_surgery()
+
+    def _after_weight_surgery(self):
+        """Weights were written through .data / load_state_dict: packed bf16 copies of the MFMA path are stale."""
+        from . import mfma_conv
+        mfma_conv.invalidate_all_pack_plans(self)
+
+    # ---- the step ------------------------------------------------------------------------------------------------
+    def autocast(self):
+        dev = next(self.parameters()).device
+        return torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=self.amp and dev.type == "cuda")
+
+    def zero_grads(self, optimizer_name):
+        if optimizer_name in self._arenas:
+            self._arenas[optimizer_name].zero()
+        else:
+            getattr(self, optimizer_name).zero_grad(set_to_none=True)
+
+    def exchange_gradients(self, *optimizer_names):
+        """Data-parallel mean of the gradients of the named optimisers: one all-reduce per arena."""
+        for name in optimizer_names:
+            if name in self._arenas:
+                self._arenas[name].all_reduce_mean()
+
+    @abstractmethod
+    def inference(self, mini_batch: Dict[str, Any], post_transformations: Dict[str, Callable], device: torch.device = "cpu",
+                  phase: Phase = Phase.TEST) -> Tuple[Output, Dict[str, torch.Tensor]]:
+        raise NotImplementedError()
+
+    @abstractmethod
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError()
+
+    def perform_training_step(self, mini_batch: Dict[str, Any], scaler, post_transformations: Dict[str, Callable],
+                              device: torch.device = "cpu") -> Tuple[Output, Dict[str, float]]:
+        self.zero_grads("optimizer")
+        with self.autocast():
+            outputs, losses = self.inference(mini_batch, post_transformations, device, phase=Phase.TRAIN)
+            loss = sum(list(losses.values()))
+        loss.backward()
+        self.exchange_gradients("optimizer")
+        self.optimizer.step()
+        return outputs, LossValues(losses)
+
+    def compute_metric(self, outputs: Output, metrics) -> None:
+        metrics(y_pred=outputs["prediction"], y=outputs["label"])
+
+
+class LossValues(dict):
+    """Losses of a training step. The reference returns python floats (`v.item()` per loss: one device sync each,
+    base_model_abc.py:166); here the values stay device tensors until someone reads them -- `float(v)`, `v.item()`,
+    arithmetic and formatting all work on 0-dim tensors -- so a step queues no sync of its own. `as_floats()` gives
+    the reference's dict in one transfer."""
+
+    def as_floats(self):
+        keys = list(self.keys())
+        vals = torch.stack([torch.as_tensor(self[k]).detach().float().reshape(()) for k in keys]).cpu().tolist()
+        return dict(zip(keys, vals))

@@ -51,6 +51,11 @@ class WeightPackPlan:
         ptrs = [w.data_ptr() for w, _ in self.params]
         versions = [w._version for w, _ in self.params]
         if ptrs != self.ptrs:
+            # storage moved (.to(), .bfloat16(), memory_format change ...): the packing kernel reads contiguous fp32 [A][B][K][K]
+            for w, _ in self.params:
+                if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+                    raise RuntimeError("MFMA weight packing needs contiguous float32 master weights on the GPU; got "
+                                       f"{w.dtype}, contiguous={w.is_contiguous()}, device={w.device} (convert activations, not parameters)")
             rows = [[p, g[0], g[1], g[2], g[3], g[4], g[5], g[6]] for p, g in zip(ptrs, self.geom)]
             self.table = torch.tensor(rows, dtype=torch.int64).to(self.device)
             self.ptrs, self.versions = ptrs, None
@@ -63,6 +68,15 @@ class WeightPackPlan:
     def invalidate(self):
         """After writes that bypass the version counter (`.data`)."""
         self.versions = None
+
+
+def invalidate_all_pack_plans(module):
+    """Every cached WeightPackPlan below `module` repacks on its next use: call after writes that do not move the
+    parameters' version counters (`.data` writes: dist.broadcast(p.data), EMA, checkpoint surgery)."""
+    for m in module.modules():
+        plan = getattr(m, "_octa_pack_plan", None)
+        if plan is not None:
+            plan.invalidate()
 
 
 def plan_for_module(module):

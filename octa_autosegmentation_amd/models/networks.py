@@ -486,4 +486,8 @@ def patchGAN70x70():
     return NLayerDiscriminator(1, ndf=64, n_layers=3)
 
 
-MODEL_DICT = {"DynUNet": DynUNet, "resnetGenerator9": resnetGenerator9, "patchGAN70x70": patchGAN70x70}
+from .gan_seg_model import GanSegModel  # noqa: E402  (it receives MODEL_DICT through its constructor, like the reference's)
+
+# reference models/networks.py:1009-1026 restricted to the hot path: the segmentation network, the contrast-adaptation
+# generator / discriminator and the joint model; the paper's other GAN baselines are out of scope
+MODEL_DICT = {"DynUNet": DynUNet, "resnetGenerator9": resnetGenerator9, "patchGAN70x70": patchGAN70x70, "GanSegModel": GanSegModel}

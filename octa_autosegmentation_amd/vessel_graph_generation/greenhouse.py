@@ -296,11 +296,6 @@ def simulate_batch(config, seeds, device_index=None):
 
 
 def edges_to_csv_text(edges):
-    """CSV bytes exactly as generate_vessel_graph.py:59-66 writes them (numpy array str() for the
-    positions, float repr for the radius, csv.writer default dialect)."""
-    buf = io.StringIO(newline="")
-    w = csv.writer(buf)
-    w.writerow(["node1", "node2", "radius"])
-    for e in edges:
-        w.writerow([np.array(e[0:3]), np.array(e[3:6]), float(e[6])])
-    return buf.getvalue()
+    """CSV text exactly as generate_vessel_graph.py:59-66 writes it (graph_io: native formatter)."""
+    from .. import graph_io
+    return graph_io.edges_to_csv_text(edges)

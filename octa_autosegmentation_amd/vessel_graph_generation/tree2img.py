@@ -168,6 +168,16 @@ def maximum_u8_device(a, b):
 
 
 def save_2d_img(img: np.ndarray, out_dir: str, name: str):
-    """tree2img.py:282-292."""
-    from PIL import Image
-    Image.fromarray(img.astype(np.uint8)).save(f'{out_dir}/{name}.png')
+    """tree2img.py:282-292: `<out_dir>/<name>.png`, 8-bit grey, written by the native PNG encoder (csrc/fileio.cpp;
+    the pixels decode identically to Pillow's file)."""
+    a = np.ascontiguousarray(img.astype(np.uint8))
+    if a.ndim != 2:
+        raise ValueError("save_2d_img expects a 2-D image")
+    _native.check(_native.lib().octa_png_write_gray8(f'{out_dir}/{name}.png'.encode(), a.ctypes.data, a.shape[1], a.shape[0], -1),
+                  "octa_png_write_gray8")
+
+
+def save_label_png(bits: np.ndarray, path: str):
+    """visualize_vessel_graphs.py:99: a mode "1" PNG (non-zero = white) from a binarised label."""
+    a = np.ascontiguousarray(bits.astype(np.uint8))
+    _native.check(_native.lib().octa_png_write_bits(str(path).encode(), a.ctypes.data, a.shape[1], a.shape[0], -1), "octa_png_write_bits")

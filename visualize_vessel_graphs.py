@@ -9,7 +9,6 @@ import re
 from glob import glob
 
 import numpy as np
-from PIL import Image
 
 
 def _natural_key(s):
@@ -45,9 +44,37 @@ def main(argv=None):
 
     import csv
     import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from octa_autosegmentation_amd import graph_io
+    from octa_autosegmentation_amd.output_files import SampleFileWriter, default_threads
     from octa_autosegmentation_amd.vessel_graph_generation import tree2img
     files = sorted(glob(os.path.join(args.source_dir, "**", "*.csv"), recursive=True), key=_natural_key)[:args.num_samples]
     assert len(files) > 0, f"Your provided source directory {args.source_dir} does not contain any csv files."
+    n_threads = args.threads if args.threads > 0 else default_threads()
+    if args.save_2d and not args.save_3d and args.max_dropout_prob == 0:
+        # the common case (labels / images without dropout): whole chunks of graphs go through the native CSV reader (host
+        # threads), ONE rasteriser launch sequence and the native PNG encoder. The reference draws one `random()` per edge even
+        # at dropout 0 (tree2img.py:62,78); nothing else reads that stream in this script, so the draws are not replayed.
+        writer = SampleFileWriter(n_threads)
+        chunk = 32 if max(img_res) > 512 else 128
+        with ThreadPoolExecutor(n_threads) as readers:
+            for c0 in range(0, len(files), chunk):
+                part = files[c0:c0 + chunk]
+                edges = list(readers.map(graph_io.read_csv_native, part))
+                off = np.concatenate(([0], np.cumsum([len(e) for e in edges]))).astype(np.int64)
+                d_edges = torch.from_numpy(np.concatenate(edges, axis=0)).cuda()
+                img = tree2img.rasterize_edges_device(d_edges, off, img_res, args.mip_axis, min_radius=0.0, max_radius=1.0)
+                out = (tree2img.binarize_label_device(img) if args.binarize else img).cpu().numpy()
+                writer.wait()
+                for path, a in zip(part, out):
+                    name = os.path.basename(path)[:-4]
+                    if args.binarize:
+                        writer.pending.append(writer.pool.submit(tree2img.save_label_png, a, os.path.join(args.out_dir, name + "_label.png")))
+                    else:
+                        writer.pending.append(writer.pool.submit(tree2img.save_2d_img, a, args.out_dir, name))
+        writer.close()
+        print(f"rendered {len(files)} vessel graphs")
+        return
     for path in files:
         name = os.path.basename(path)[:-4]
         with open(path, newline='') as fh:
@@ -66,9 +93,9 @@ def main(argv=None):
             if args.binarize:
                 d = torch.from_numpy(img.astype(np.uint8)[None]).cuda()
                 bits = tree2img.binarize_label_device(d)[0].cpu().numpy()
-                Image.fromarray(bits > 0).save(os.path.join(args.out_dir, name + "_label.png"))
+                tree2img.save_label_png(bits, os.path.join(args.out_dir, name + "_label.png"))
             else:
-                Image.fromarray(img.astype(np.uint8)).save(os.path.join(args.out_dir, name + ".png"))
+                tree2img.save_2d_img(img, args.out_dir, name)
             if args.max_dropout_prob > 0:
                 with open(os.path.join(args.out_dir, name + "_blackdict.pkl"), 'wb') as f:
                     pickle.dump(black_dict, f)
