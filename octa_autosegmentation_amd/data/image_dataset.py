@@ -1,0 +1,168 @@
+"""Datasets and loaders of the entry points (reference data/image_dataset.py:19-81), without MONAI / torch DataLoader
+workers: `get_dataset(config, phase)` builds the file lists exactly as the reference does (recursive glob, natural sort,
+optional split files, the shorter lists repeated to the longest) and returns a DeviceLoader whose samples are transformed ON
+THE GPU (data/data_transforms.py) and collated into device-resident mini-batches -- the reference's loader workers
+spend 0.6 s per sample on the CPU (CSV parse + two matplotlib renders), which would cap training at a few images per
+second whatever the convolutions do."""
+import os
+import queue
+import re
+import threading
+from glob import glob
+from math import ceil
+
+import numpy as np
+import torch
+
+from ..utils.enums import Phase, Task
+from .data_transforms import Compose, get_data_augmentations
+from .unalignedZipDataset import UnalignedZipDataset
+
+
+def natsorted(paths):
+    """Natural sort (the reference uses natsort.natsorted): digit runs compare as integers."""
+    return sorted(paths, key=lambda s: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", s)])
+
+
+def _get_transformation(config, phase: str, dtype=torch.float32) -> Compose:
+    return Compose(get_data_augmentations(config[phase]["data_augmentation"], config["General"].get("seed", 42), dtype))
+
+
+def get_post_transformation(config: dict, phase: str) -> dict:
+    """`post_processing` of a phase -> {output name: Compose}, applied to predictions / labels before metrics and files."""
+    post = dict()
+    for k, v in config[phase]["post_processing"].items():
+        try:
+            post[k] = Compose(get_data_augmentations(v, seed=config["General"].get("seed", 42)))
+        except Exception as e:
+            print("Error: Your provided data augmentations for prediction are invalid.\n")
+            raise e
+    return post
+
+
+class ListDataset:
+    def __init__(self, items, transform):
+        self.items, self.transform = items, transform
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.transform(self.items[i])
+
+
+def collate(samples):
+    out = {}
+    for k in samples[0]:
+        vals = [s[k] for s in samples]
+        out[k] = torch.stack(vals) if torch.is_tensor(vals[0]) else vals
+    return out
+
+
+class DeviceLoader:
+    """Iterable over collated, device-resident mini-batches. shuffle: a fresh torch.randperm per epoch (the global CPU
+    generator, seeded by train.py like the reference's set_determinism). num_workers > 0: ONE producer thread prepares
+    the next batches on its own HIP stream while the current one trains (hand-over through an event + record_stream);
+    num_workers == 0: batches are prepared inline."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, num_workers=0, prefetch=2):
+        self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
+        self.num_workers, self.prefetch = int(num_workers), prefetch
+        self.shard = (0, 1)          # (rank, world): data-parallel ranks take every world-th batch of the SAME permutation
+
+    def __len__(self):
+        return ceil(ceil(len(self.dataset) / self.batch_size) / self.shard[1])
+
+    def _batches(self):
+        n = len(self.dataset)
+        order = torch.randperm(n).tolist() if self.shuffle else list(range(n))     # all ranks share the seed, hence the order
+        rank, world = self.shard
+        starts = list(range(0, n, self.batch_size))
+        if world > 1:                                                              # same number of steps on every rank
+            starts = (starts + starts[: (-len(starts)) % world])[rank::world]
+        for i in starts:
+            yield collate([self.dataset[j] for j in order[i:i + self.batch_size]])
+
+    def __iter__(self):
+        if self.num_workers <= 0 or not torch.cuda.is_available():
+            yield from self._batches()
+            return
+        q = queue.Queue(maxsize=self.prefetch)
+        dev = torch.cuda.current_device()
+        stream = torch.cuda.Stream()
+        stop = threading.Event()
+        END = object()
+
+        def produce():
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(stream):
+                    for b in self._batches():
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                        while not stop.is_set():
+                            try:
+                                q.put((b, ev), timeout=0.1)
+                                break
+                            except queue.Full:
+                                pass
+                        if stop.is_set():
+                            return
+                q.put(END)
+            except BaseException as e:  # noqa: BLE001 -- re-raised by the consumer
+                q.put(e)
+
+        th = threading.Thread(target=produce, name="octa-loader")
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is END:
+                    break
+                if isinstance(item, BaseException):
+                    raise RuntimeError("the loader thread failed") from item
+                b, ev = item
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                for v in b.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
+                yield b
+        finally:
+            stop.set()
+            th.join()
+
+
+def get_dataset(config: dict, phase: str, batch_size=None, num_workers=None) -> DeviceLoader:
+    task = config["General"]["task"]
+    amp_train = phase == Phase.TRAIN and bool(config["General"].get("amp"))
+    # the reference hands fp16 tensors to its fp16 autocast (image_dataset.py:46); the MI355X path computes in bf16
+    transform = _get_transformation(config, phase, dtype=torch.bfloat16 if amp_train else torch.float32)
+    data = dict()
+    for key, val in config[phase]["data"].items():
+        paths = natsorted(glob(val["files"], recursive=True))
+        assert len(paths) > 0, f"Error: Your provided file path {val['files']} for {key} does not match any files!"
+        if "split" in val:
+            assert os.path.isfile(val["split"]), f"Error: Your provided split file path {val['split']} for {key} does not exist."
+            with open(val["split"], "r") as f:
+                indices = [int(line.rstrip()) for line in f.readlines()]
+            assert max(indices) < len(paths), (f"Error: Your provided split file for {key} does not seem to match your dataset! The index "
+                                               f"{max(indices)} was requested but the dataset only contains {len(paths)} files.")
+            paths = np.array(paths)[indices].tolist()
+            assert len(paths) > 0, "Error: Your provided split file does not reference any file!"
+        data[key] = paths
+        data[key + "_path"] = paths
+
+    def zipped():
+        max_length = max(len(v) for v in data.values())
+        cols = {k: np.resize(np.array(v), max_length).tolist() for k, v in data.items()}
+        return ListDataset([dict(zip(cols, t)) for t in zip(*cols.values())], transform)
+
+    if task == Task.VESSEL_SEGMENTATION:
+        data_set = zipped()
+    elif task == Task.GAN_VESSEL_SEGMENTATION:
+        data_set = zipped() if phase == Phase.VALIDATION else UnalignedZipDataset(data, transform, phase)
+    else:
+        raise NotImplementedError(f"task {task} is outside the MI355X hot path")
+    return DeviceLoader(data_set, batch_size=batch_size or config[phase].get("batch_size") or 1, shuffle=phase != Phase.TEST,
+                        num_workers=1 if num_workers is None else num_workers)

@@ -1,0 +1,148 @@
+"""Training / validation metrics of the entry points (reference utils/metrics.py:165-196 MetricsManager): DSC and IoU in
+the training phase; the validation phase adds AUC, ACC, Recall, Precision and -- when scikit-image is importable -- clDice
+(skeletonisation is skimage's; it is not in the MI355X image, so the column is simply absent there). Every score is computed
+on the device the tensors live on and read back as ONE scalar per metric and sample; the reference moves whole 1216x1216
+maps to numpy for each of them. These are logging quantities, not a kernel target (metrics are out of
+scope as kernels)."""
+import math
+
+import torch
+
+from .enums import Phase
+
+
+class Metric:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.scores = []
+
+    def aggregate(self) -> torch.Tensor:
+        vals = [s for s in self.scores if not math.isnan(s)]
+        return torch.tensor(sum(vals) / len(vals) if vals else float("nan"))
+
+
+def _flat_bool(t):
+    return t.detach().reshape(-1) != 0
+
+
+class MacroDiceMetric(Metric):
+    """Per layer 2 |gt & pred| / (|gt| + |pred|) for class 1, NaN (skipped) for an empty ground truth (metrics.py:95-123)."""
+
+    def __call__(self, y_pred, y):
+        for p_i, y_i in zip(y_pred, y):
+            for layer in range(len(p_i)):
+                gt, pr = y_i[layer].detach().float(), p_i[layer].detach().float()
+                if float(gt.sum()) == 0:
+                    self.scores.append(float("nan"))
+                    continue
+                inter = ((gt == 1) & (pr == 1)).sum()
+                self.scores.append(float(2.0 * inter / (gt.sum() + pr.sum())))
+
+    def aggregate(self):
+        return super().aggregate() if self.scores else torch.tensor(0)
+
+
+class MeanIoU(Metric):
+    """MONAI MeanIoU(include_background=True, reduction='mean') on binarised maps: per channel |p & y| / |p | y|; channels with
+    an empty ground truth are NaN and ignored (MONAI's ignore_empty default)."""
+
+    def __call__(self, y_pred, y):
+        for p_i, y_i in zip(y_pred, y):
+            for c in range(len(p_i)):
+                p, g = _flat_bool(p_i[c]), _flat_bool(y_i[c])
+                if not bool(g.any()):
+                    self.scores.append(float("nan"))
+                    continue
+                self.scores.append(float((p & g).sum() / (p | g).sum()))
+
+
+class _Confusion(Metric):
+    def counts(self, p_i, y_i):
+        p, g = _flat_bool(p_i), _flat_bool(y_i)
+        tp, tn = (p & g).sum(), (~p & ~g).sum()
+        fp, fn = (p & ~g).sum(), (~p & g).sum()
+        return [float(v) for v in (tp, tn, fp, fn)]
+
+
+class AccuracyMetric(_Confusion):
+    def __call__(self, y_pred, y):
+        for p_i, y_i in zip(y_pred, y):
+            tp, tn, fp, fn = self.counts(p_i, y_i)
+            self.scores.append((tp + tn) / (tp + tn + fp + fn))
+
+
+class Recall(_Confusion):
+    def __call__(self, y_pred, y):
+        for p_i, y_i in zip(y_pred, y):
+            tp, tn, fp, fn = self.counts(p_i, y_i)
+            self.scores.append(tp / (tp + fn) if tp + fn else float("nan"))
+
+
+class Precision(_Confusion):
+    def __call__(self, y_pred, y):
+        for p_i, y_i in zip(y_pred, y):
+            tp, tn, fp, fn = self.counts(p_i, y_i)
+            self.scores.append(tp / (tp + fp) if tp + fp else float("nan"))
+
+
+class AUCMetric(Metric):
+    """ROC AUC of the flattened map (monai.metrics.compute_roc_auc): rank statistic with average ranks for ties."""
+
+    def __call__(self, y_pred, y):
+        for p_i, y_i in zip(y_pred, y):
+            s, g = p_i.detach().reshape(-1).double(), _flat_bool(y_i)
+            n_pos, n_neg = int(g.sum()), int((~g).sum())
+            if n_pos == 0 or n_neg == 0:
+                self.scores.append(float("nan"))
+                continue
+            vals, inv, cnt = torch.unique(s, sorted=True, return_inverse=True, return_counts=True)
+            hi = torch.cumsum(cnt, 0).double()
+            avg_rank = hi - (cnt.double() - 1) / 2          # average 1-based rank of each distinct score
+            r_pos = avg_rank[inv][g].sum()
+            self.scores.append(float((r_pos - n_pos * (n_pos + 1) / 2) / (n_pos * n_neg)))
+
+
+class ClDiceMetric(Metric):
+    def __call__(self, y_pred, y):
+        from skimage.morphology import skeletonize
+        import numpy as np
+        for p_i, y_i in zip(y_pred, y):
+            for layer in range(len(p_i)):
+                v_p, v_l = p_i[layer].detach().cpu().numpy(), y_i[layer].detach().cpu().numpy()
+                cl = lambda v, s: np.sum(v * s) / np.sum(s)
+                tprec, tsens = cl(v_p, skeletonize(v_l)), cl(v_l, skeletonize(v_p))
+                self.scores.append(float(2 * tprec * tsens / (tprec + tsens)))
+
+
+def _have_skimage():
+    try:
+        import skimage.morphology  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
+class MetricsManager:
+    def __init__(self, phase: Phase = Phase.TRAIN):
+        self.metrics = {"DSC": MacroDiceMetric(), "IoU": MeanIoU()}
+        if phase != Phase.TRAIN:
+            if _have_skimage():
+                self.metrics["ClDice"] = ClDiceMetric()
+            self.metrics.update({"AUC": AUCMetric(), "ACC": AccuracyMetric(), "Recall": Recall(), "Precision": Precision()})
+        self.comp = "DSC"
+
+    def __call__(self, y_pred, y):
+        for v in self.metrics.values():
+            v(y_pred=y_pred, y=y)
+
+    def aggregate_and_reset(self, prefix: str = ""):
+        d = dict()
+        for k, v in self.metrics.items():
+            d[f"{prefix}_{k}"] = v.aggregate().item()
+            v.reset()
+        return d
+
+    def get_comp_metric(self, prefix: str):
+        return f"{prefix}_{self.comp}"

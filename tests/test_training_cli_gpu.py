@@ -1,0 +1,163 @@
+"""GPU: the reference's entry points end to end on MI355X with the reference's own config files -- generate_vessel_graph.py ->
+train.py (configs/config_ves_seg-S.yml, then configs/config_gan_ves_seg.yml) -> test.py -> validate.py -- plus the graph loader
+transform (a16) against the general rasterize_forest path."""
+import glob
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def graphs(tmp_path_factory, hip_lib_built):
+    """Eight short seeded samples written by the generator CLI: graph CSV + 304x304 image + 1216x1216 label each."""
+    import generate_vessel_graph
+    from octa_autosegmentation_amd.utils import configs
+    cfg = configs.load_generator_config()
+    out = tmp_path_factory.mktemp("graphs")
+    modes = [dict(cfg["Greenhouse"]["modes"][0], I=30), dict(cfg["Greenhouse"]["modes"][1], I=20)]
+    generate_vessel_graph.main(["--config_file", configs.GENERATOR_CONFIG, "--num_samples", "8", "--seed", "100", "--labels",
+                                "--output.directory", str(out), "--Greenhouse.modes", yaml.safe_dump(modes, default_flow_style=True).strip()])
+    dirs = sorted(glob.glob(str(out / "*")))
+    assert len(dirs) == 8
+    return str(out), dirs
+
+
+def test_generator_cli_writes_complete_triples(graphs):
+    from PIL import Image
+    from octa_autosegmentation_amd import graph_io
+    from oracle import octa_oracle
+    out, dirs = graphs
+    for d in dirs[:2]:
+        name = os.path.basename(d)
+        e = graph_io.read_csv(os.path.join(d, name + ".csv"))
+        assert (graph_io.read_csv_native(os.path.join(d, name + ".csv")) == e).all()
+        label = Image.open(os.path.join(d, name + "_label.png"))
+        assert label.mode == "1" and label.size == (1216, 1216)
+        want = octa_oracle.fs_dither(octa_oracle.rasterize(e, [1216, 1216]))          # the label IS the raster of the file's text
+        assert (np.array(label.convert("L")) == want).all()
+        img = np.array(Image.open(os.path.join(d, "art_ven_img_gray.png")))
+        assert img.shape == (304, 304) and img.dtype == np.uint8 and img.max() > 0
+
+
+def test_graph_loader_transform_fast_path_equals_reference_path(graphs):
+    """a16: LoadGraphAndFilterByRandomRadiusd on a CSV file -- the native-reader / device-window fast path gives the tensors and
+    consumes the `random` stream exactly like the general path (csv.DictReader + rasterize_forest with string positions, the
+    reference's data_transforms.py:369-387), incl. the shared blackdict of the second key; and both equal the oracle."""
+    import torch
+    from octa_autosegmentation_amd import graph_io
+    from octa_autosegmentation_amd.data import data_transforms as T
+    from octa_autosegmentation_amd.vessel_graph_generation.tree2img import rasterize_forest
+    from oracle import octa_oracle
+    import csv
+    out, dirs = graphs
+    path = glob.glob(os.path.join(dirs[0], "*.csv"))[0]
+    t = T.LoadGraphAndFilterByRandomRadiusd(["image", "label"], image_resolutions=[[304, 304], [1216, 1216]], min_radius=[0, 0.0033], max_dropout_prob=0)
+    random.seed(7)
+    got = t({"image": path, "label": path})
+    after_fast = random.random()
+    random.seed(7)
+    with open(path, newline="") as f:
+        forest = list(csv.DictReader(f))
+    img, bd = rasterize_forest(forest, [304, 304], 2, min_radius=0, max_dropout_prob=0, blackdict=None)
+    lab, bd = rasterize_forest(forest, [1216, 1216], 2, min_radius=0.0033, max_dropout_prob=0, blackdict=bd)
+    after_ref = random.random()
+    assert after_fast == after_ref
+    assert got["image"].is_cuda and got["image"].dtype == torch.float32 and tuple(got["label"].shape) == (1216, 1216)
+    assert (got["image"].cpu().numpy() == img).all() and (got["label"].cpu().numpy() == lab).all()
+    e = graph_io.read_csv(path)
+    assert (lab == octa_oracle.rasterize(e[e[:, 6] >= 0.0033], [1216, 1216])).all()
+    # with dropout the transform goes through the general path: same blackdict for both keys
+    t2 = T.LoadGraphAndFilterByRandomRadiusd(["image", "label"], image_resolutions=[[304, 304], [1216, 1216]], min_radius=[0, 0], max_dropout_prob=0.9)
+    random.seed(11)
+    d2 = t2({"image": path, "label": path})
+    random.seed(11)
+    img2, bd2 = rasterize_forest(forest, [304, 304], 2, min_radius=0, max_dropout_prob=0.9, blackdict=None)
+    lab2, _ = rasterize_forest(forest, [1216, 1216], 2, min_radius=0, max_dropout_prob=0.9, blackdict=bd2)
+    assert (d2["image"].cpu().numpy() == img2).all() and (d2["label"].cpu().numpy() == lab2).all()
+
+
+def _pngs(graph_dirs, root):
+    """Validation / test / real_B / background stand-ins: the generated 304x304 images and 1216x1216 labels as flat PNG folders."""
+    from PIL import Image
+    for sub in ("images", "labels", "background"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    rng = np.random.default_rng(0)
+    for i, d in enumerate(graph_dirs):
+        name = os.path.basename(d)
+        Image.open(os.path.join(d, "art_ven_img_gray.png")).save(os.path.join(root, "images", f"{i}.png"))
+        Image.open(os.path.join(d, name + "_label.png")).convert("L").save(os.path.join(root, "labels", f"{i}.png"))
+        Image.fromarray(rng.integers(0, 80, (304, 304)).astype(np.uint8)).save(os.path.join(root, "background", f"{i}.png"))
+
+
+def test_train_test_validate_with_the_reference_segmentation_config(graphs, tmp_path):
+    """BASELINE configs[2] plumbing: train.py --config_file configs/config_ves_seg-S.yml (one epoch on the eight graphs), then
+    test.py and validate.py on its checkpoints. Only paths and the epoch count are overridden."""
+    import torch
+    from PIL import Image
+    import test as test_cli
+    import train as train_cli
+    import validate as validate_cli
+    out, dirs = graphs
+    data = str(tmp_path / "png")
+    _pngs(dirs, data)
+    res = str(tmp_path / "results")
+    csvs = os.path.join(out, "**", "*.csv")
+    ov = ["--Train.data.image.files", csvs, "--Train.data.label.files", csvs, "--Train.epochs", "1", "--Train.epochs_decay", "0",
+          "--Validation.data.image", yaml.safe_dump({"files": os.path.join(data, "images", "*.png")}, default_flow_style=True).strip(),
+          "--Validation.data.label", yaml.safe_dump({"files": os.path.join(data, "labels", "*.png")}, default_flow_style=True).strip(),
+          "--Test.data.image", yaml.safe_dump({"files": os.path.join(data, "images", "*.png")}, default_flow_style=True).strip(),
+          "--Output.save_dir", res, "--General.seed", "3"]
+    run = train_cli.main(["--config_file", os.path.join(ROOT, "configs", "config_ves_seg-S.yml")] + ov)
+    rows = open(os.path.join(run, "metrics.csv")).read().splitlines()
+    assert rows[0].startswith("epoch,train_DiceBCELoss,val_DiceBCELoss,Train_DSC,Train_IoU,Validation_DSC,Validation_IoU") and len(rows) == 2
+    vals = dict(zip(rows[0].split(","), (float(v) for v in rows[1].split(","))))
+    assert np.isfinite(list(vals.values())).all() and 0 < vals["train_DiceBCELoss"] < 2
+    names = set(os.listdir(os.path.join(run, "checkpoints")))
+    assert {"latest_model_model.pth", "latest_optimizer_model.pth", "best_model_model.pth", "best_optimizer_model.pth"} <= names
+    ck = torch.load(os.path.join(run, "checkpoints", "best_model_model.pth"), weights_only=False)
+    assert ck["epoch"] == 1 and "input_block.conv1.conv.weight" in ck["model"] and any(k.startswith("skip_layers.") for k in ck["model"])
+    run_cfg = os.path.join(run, "config.yml")
+    written = test_cli.main(["--config_file", run_cfg, "--epoch", "best", "--num_samples", "3"])
+    assert len(written) == 3
+    pred = np.array(Image.open(written[0]))
+    assert pred.shape == (1216, 1216) and set(np.unique(pred)) <= {0, 255}
+    # RemoveSmallObjects(160) ran: no 4-connected component below 160 pixels survives in the written file
+    from scipy import ndimage
+    lab, n = ndimage.label(pred > 0)
+    assert n == 0 or np.bincount(lab.ravel())[1:].min() >= 160
+    metrics = validate_cli.main(["--config_file", run_cfg, "--epoch", "best"])
+    assert {"Validation_DSC", "Validation_IoU", "Validation_AUC", "Validation_ACC", "Validation_Recall", "Validation_Precision"} <= set(metrics)
+    assert all(np.isfinite(v) for v in metrics.values())
+
+
+def test_train_with_the_reference_gan_seg_config(graphs, tmp_path):
+    """BASELINE configs[3] plumbing: train.py --config_file configs/config_gan_ves_seg.yml for one epoch (GanSegModel through
+    define_model, UnalignedZipDataset pairing, dropout 0.02 in the graph loader, three optimisers' checkpoints)."""
+    import torch
+    import train as train_cli
+    out, dirs = graphs
+    data = str(tmp_path / "png")
+    _pngs(dirs, data)
+    res = str(tmp_path / "results")
+    csvs = os.path.join(out, "**", "*.csv")
+    f = lambda p: yaml.safe_dump({"files": p}, default_flow_style=True).strip()
+    ov = ["--Train.data.real_A", f(csvs), "--Train.data.real_A_seg", f(csvs), "--Train.data.real_B", f(os.path.join(data, "images", "*.png")),
+          "--Train.data.background", f(os.path.join(data, "background", "*.png")), "--Train.epochs", "1", "--Train.batch_size", "2",
+          "--Output.save_dir", res, "--General.seed", "4"]
+    run = train_cli.main(["--config_file", os.path.join(ROOT, "configs", "config_gan_ves_seg.yml")] + ov)
+    rows = open(os.path.join(run, "metrics.csv")).read().splitlines()
+    assert rows[0] == "epoch,train_S,train_D_fake,train_D_real,train_G,train_G_idt,train_S_idt,Train_DSC,Train_IoU" and len(rows) == 2
+    assert np.isfinite([float(v) for v in rows[1].split(",")]).all()
+    names = set(os.listdir(os.path.join(run, "checkpoints")))
+    assert {f"latest_{n}_model.pth" for n in ("generator", "discriminator", "segmentor", "optimizer_G", "optimizer_D", "optimizer_S")} <= names
+    ck = torch.load(os.path.join(run, "checkpoints", "latest_optimizer_S_model.pth"), weights_only=False)
+    assert ck["optimizer"]["param_groups"][0]["betas"] == (0.9, 0.999) and ck["epoch"] == 1
