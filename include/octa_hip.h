@@ -414,8 +414,8 @@ int octa_sim_stats(octa_sim *sim, int64_t *h_stats);
  * [7] bytes of HBM held by the simulator. */
 int octa_sim_timing(octa_sim *sim, double *h_out8);
 
-/* Host-side record of the mailbox service of the last octa_sim_run (persistent form), h_out4: [0] tickets served,
- * [1] longest absence of the service thread from the mailbox (ms), [2] longest hipEventQuery call (ms; only measured
+/* Host-side record of the mailbox service of the last octa_sim_run (persistent form), h_out4 (FIVE doubles): [0] tickets served,
+ * [1] longest single pass of the service loop (ms: how long the thread was away from the mailbox), [4] longest bifurcation callback (ms), [2] longest hipEventQuery call (ms; only measured
  * with OCTA_SIM_LEGACY_EVENT_POLL=1, the round-1 exit condition kept for diagnosis), [3] times that query reported the
  * launch complete while workgroups were still running. Environment read by octa_sim_create:
  * OCTA_SIM_MAIL_TIMEOUT_MS (device-side bound on one wait for the host, default 30000; error bit 0x800),

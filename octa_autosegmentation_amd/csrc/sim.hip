@@ -400,7 +400,7 @@ struct octa_sim {
     int test_stall_ms = 0;          // OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once with a ticket pending
     bool legacy_event_poll = false; // OCTA_SIM_LEGACY_EVENT_POLL=1 (diagnosis): also poll hipEventQuery as round 1 did, timed
     long spin_scans = 4096;         // idle mailbox scans before the service thread starts sleeping 20 us between scans
-    double diag_max_gap_ms = 0, diag_max_query_ms = 0;
+    double diag_max_gap_ms = 0, diag_max_query_ms = 0, diag_max_bif_ms = 0;
     long diag_tickets = 0, diag_early_event = 0;
     bool ran = false;
     // host copies for export
@@ -641,8 +641,15 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
         bool stalled_once = false;
         auto last_progress = clk::now(), last_scan = last_progress;
         int last_done = 0;
-        S->diag_max_gap_ms = 0; S->diag_tickets = 0; S->diag_max_query_ms = 0; S->diag_early_event = 0;
+        S->diag_max_gap_ms = 0; S->diag_tickets = 0; S->diag_max_query_ms = 0; S->diag_early_event = 0; S->diag_max_bif_ms = 0;
+        auto iter_start = clk::now();
         while (true) {
+            {   // longest single pass of this loop, whatever it was spent in (callback, descheduling, ...)
+                const auto t = clk::now();
+                const double it_ms = std::chrono::duration<double, std::milli>(t - iter_start).count();
+                if (it_ms > S->diag_max_gap_ms) S->diag_max_gap_ms = it_ms;
+                iter_start = t;
+            }
             bool any = false;
             for (int s = 0; s < B; s++) {
                 const int t = __atomic_load_n(M.req_ticket + s, __ATOMIC_ACQUIRE);
@@ -658,7 +665,9 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
                     auto t0 = clk::now();
                     bif(n, reinterpret_cast<const octa_bif_request *>(M.reqs + (size_t)s * REQ_PER_SAMPLE),
                         M.results + (size_t)s * REQ_PER_SAMPLE * 6, user);
-                    S->ms_host_bif += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+                    const double bms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+                    S->ms_host_bif += bms;
+                    if (bms > S->diag_max_bif_ms) S->diag_max_bif_ms = bms;
                     S->n_bif_req += n;
                 }
                 __atomic_store_n(M.resp_ticket + s, t, __ATOMIC_RELEASE);
@@ -670,8 +679,6 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
             if (any || done != last_done) { idle = 0; last_done = done; last_progress = last_scan = clk::now(); continue; }
             if ((++idle & 63) == 0) {
                 const auto now = clk::now();
-                const double gap = std::chrono::duration<double, std::milli>(now - last_scan).count();
-                if (gap > S->diag_max_gap_ms) S->diag_max_gap_ms = gap;   // how long this thread was away from the mailbox
                 last_scan = now;
                 if (S->legacy_event_poll) {   // diagnosis only (OCTA_SIM_LEGACY_EVENT_POLL=1): the round-1 exit condition, timed
                     hipError_t q = hipEventQuery(S->ev[1]);
@@ -731,9 +738,9 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
             if ((S->h_sc[s].err & ERR_HOST_TIMEOUT) && !S->lockstep)
                 octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x: a workgroup waited more than %.0f ms for the host's "
                                 "mailbox answer (request ticket %d, answered %d, %ld tickets served this run, longest absence of the service thread "
-                                "%.1f ms, longest hipEventQuery %.1f ms, early event completions %ld)", s, S->h_sc[s].err, S->mail_timeout_ms,
-                                S->mail.req_ticket[s], S->mail.resp_ticket[s], S->diag_tickets, S->diag_max_gap_ms, S->diag_max_query_ms,
-                                S->diag_early_event);
+                                "%.1f ms, longest bifurcation callback %.1f ms, longest hipEventQuery %.1f ms, early event completions %ld)", s, S->h_sc[s].err,
+                                S->mail_timeout_ms, S->mail.req_ticket[s], S->mail.resp_ticket[s], S->diag_tickets, S->diag_max_gap_ms,
+                                S->diag_max_bif_ms, S->diag_max_query_ms, S->diag_early_event);
             else
                 octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x", s, S->h_sc[s].err);
             return -3;
@@ -852,6 +859,7 @@ extern "C" int octa_sim_kat_kd_order(octa_ctx *ctx, const double *h_pts, int64_t
 extern "C" int octa_sim_service_stats(octa_sim *S, double *h_out4) {
     if (!S || !S->ran || !h_out4) { octa::set_error("octa_sim_service_stats: run the simulation first"); return -2; }
     h_out4[0] = (double)S->diag_tickets; h_out4[1] = S->diag_max_gap_ms; h_out4[2] = S->diag_max_query_ms; h_out4[3] = (double)S->diag_early_event;
+    h_out4[4] = S->diag_max_bif_ms;
     return 0;
 }
 

@@ -210,3 +210,43 @@ def test_two_rank_gan_seg_step_keeps_the_replicas_identical(tmp_path):
     assert a.keys() == b.keys() and len(a) > 100
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("tag,idt", [("idt0", False), ("idt1", True)])
+def test_gan_seg_update_matches_the_reference_fixture(tag, idt):
+    """a21: two consecutive joint G / D / S updates against tests/golden/ganseg_golden.npz, recorded from the reference's own
+    GanSegModel.perform_training_step (tools/make_golden_ganseg.py). Losses of step 1 depend only on the forward composition,
+    those of step 2 on all three optimiser updates (Adam, betas (0.5, 0.999) for G and D, (0.9, 0.999) for S); the gradient norms and
+    parameter checksums pin the backward paths (D frozen in the G+S pass, detached fake_B in the D pass, detached pseudo-labels)."""
+    import sys
+    from argparse import Namespace
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from tools.make_golden_ganseg import S_CFG, TRAIN, batch, checksums, formula_weights, grad_norms
+    from octa_autosegmentation_amd.models.model import define_model
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ganseg_golden.npz"))
+    config = {"General": {"device": "cpu", "amp": False, "model": {"name": "GanSegModel", "model_g": {"name": "resnetGenerator9"},
+                                                                    "model_d": {"name": "patchGAN70x70"}, "model_s": dict(S_CFG),
+                                                                    "compute_identity": idt, "compute_identity_seg": True, "upshape": (64, 64)}},
+              "Train": dict(TRAIN), "Output": {"save_dir": "/tmp"}}
+    from copy import deepcopy
+    from octa_autosegmentation_amd.utils.enums import Phase
+    torch.manual_seed(0)
+    model = define_model(deepcopy(config), Phase.TRAIN)
+    model.initialize_model_and_optimizer(None, networks.init_weights, config, Namespace(start_epoch=0, epoch="latest"), None, Phase.TRAIN)
+    for salt, name in ((0, "generator"), (100, "discriminator"), (200, "segmentor")):
+        formula_weights(getattr(model, name), salt)
+    model.train()
+    ident = {"prediction": lambda t: t, "label": lambda t: t}
+    keys = ("S", "D_fake", "D_real", "G", "G_idt", "S_idt")
+    for step in range(2):
+        _, l = model.perform_training_step(batch(), None, ident, "cpu")
+        got = np.array([float(l[k]) for k in keys])
+        # step 0: the forward composition alone (fp32 summation order); step 1: after one Adam step of all three optimisers, where
+        # first-step updates are lr * sign(g) and parameters with rounding-noise gradients move either way
+        assert np.allclose(got, g[f"{tag}_losses"][step], rtol=2e-5 if step == 0 else 1e-3, atol=1e-6), (step, got, g[f"{tag}_losses"][step])
+    assert np.allclose(grad_norms(model), g[f"{tag}_grad_norms"], rtol=2e-3), (grad_norms(model), g[f"{tag}_grad_norms"])
+    # parameter checksums after two Adam steps: parameters whose gradient is rounding noise take +-lr steps of either sign, so the
+    # sums agree to a small absolute slack only (the step-2 losses above are the sharp pin of the three updates)
+    assert np.allclose(checksums(model), g[f"{tag}_param_sums"], rtol=1e-6, atol=0.1), (checksums(model), g[f"{tag}_param_sums"])
+    # and a sign error would not pass: the generator's adversarial term enters loss_GS with a plus sign
+    assert g[f"{tag}_losses"][0][3] > 1.0

@@ -69,5 +69,10 @@ print("runs:", len(log), "failed:", len(log) - len(ok))
 if ok:
     print("longest hipEventQuery over all runs (ms):", max(r[4]["max_event_query_ms"] for r in ok),
           " longest absence of the service thread (ms):", max(r[4]["max_absence_ms"] for r in ok),
+          " longest callback (ms):", max(r[4]["max_callback_ms"] for r in ok),
           " median run (s):", sorted(r[2] for r in ok)[len(ok) // 2])
 print("device-wide waits issued by the main thread:", n)
+from octa_autosegmentation_amd import _native
+cnt = np.zeros(2, np.int64)
+_native.lib().octa_bif_native_counts(cnt.ctypes.data)
+print("bifurcation requests served natively / through the numpy callback:", cnt.tolist())
