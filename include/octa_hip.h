@@ -416,7 +416,7 @@ int octa_sim_timing(octa_sim *sim, double *h_out8);
 
 /* Host-side record of the mailbox service of the last octa_sim_run (persistent form), h_out4 (FIVE doubles): [0] tickets served,
  * [1] longest single pass of the service loop (ms: how long the thread was away from the mailbox), [4] longest bifurcation callback (ms), [2] longest hipEventQuery call (ms; only measured
- * with OCTA_SIM_LEGACY_EVENT_POLL=1, the round-1 exit condition kept for diagnosis), [3] times that query reported the
+ * with OCTA_SIM_ROUND1_MAILBOX=1, which re-enables round 1's ticket publication and exit condition to reproduce its defect), [3] times that query reported the
  * launch complete while workgroups were still running. Environment read by octa_sim_create:
  * OCTA_SIM_MAIL_TIMEOUT_MS (device-side bound on one wait for the host, default 30000; error bit 0x800),
  * OCTA_SIM_TEST_HOST_STALL_MS (test hook: the service thread sleeps once while a ticket is pending),

@@ -283,21 +283,47 @@ struct HostMail {
     int *resp_ticket;    // pinned host [B]                     host -> device
     int *done;           // pinned host [1]                     device -> host: workgroups that have left the kernel
     long timeout_ticks;  // device-side bound on one wait for the host (100 MHz wall clock)
+    int round1_publish;  // OCTA_SIM_ROUND1_MAILBOX=1 (reproduction of the round-1 defect only): publish tickets with a plain release store
 };
 constexpr int REQ_PER_SAMPLE = 32;
 constexpr int ERR_HOST_TIMEOUT = 2048;
 
-__device__ inline void mail_roundtrip(const Blk &b, const SimArrays &A, const HostMail &M, int s, int n_req, int ticket) {
+// One request / answer round trip with the host service thread (octa_sim_run). Publication rule, learnt the hard way:
+// round 1 published the ticket with a system-scope RELEASE STORE and then only polled. A release fence orders what comes
+// BEFORE the store; the stored word itself may stay in the XCD's L2 until some later write-back. It usually left within
+// microseconds because another workgroup of the same XCD ran a system-scope fence (buffer_wbl2 writes back every dirty line of
+// that L2) -- and stayed for as long as the poll lasted when no neighbour did: the host, scanning all the time, saw the ticket
+// only when the device-side deadline fired and the workgroup moved on (error bit 0x800; measured with the diagnostics below:
+// "began waiting at 7 ms ... host answered 4008 ms after the launch ... read answer 0 at its deadline"). Now the ticket is
+// published with an atomic EXCHANGE -- a read-modify-write at system scope executes at the memory, it cannot linger in a cache --
+// followed by a system fence, and the poll loop repeats the fence now and then.
+__device__ inline void mail_roundtrip(const Blk &b, const SimArrays &A, const HostMail &M, int s, int n_req, int ticket, long t_kernel) {
     if (n_req == 0) return;  // block-uniform
     if (b.tid == 0) {
         if (n_req > REQ_PER_SAMPLE) { atomicOr(&A.sc->err, ERR_REQ_CAP); n_req = REQ_PER_SAMPLE; }
-        __threadfence_system();
+        __threadfence_system();      // the request records (written by the whole block before the barrier) reach host memory
         __hip_atomic_store(M.req_n + s, n_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(M.req_ticket + s, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (M.round1_publish) __hip_atomic_store(M.req_ticket + s, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // repro only
+        else {
+            __hip_atomic_exchange(M.req_ticket + s, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+        }
         const long t0 = (long)wall_clock64();
+        long polls = 0;
         while (__hip_atomic_load(M.resp_ticket + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ticket) {
             __builtin_amdgcn_s_sleep(64);
-            if ((long)wall_clock64() - t0 > M.timeout_ticks) { atomicOr(&A.sc->err, ERR_HOST_TIMEOUT); break; }
+            polls++;
+            if (!M.round1_publish && (polls & 255) == 0) __threadfence_system();
+            if ((long)wall_clock64() - t0 > M.timeout_ticks) {
+                atomicOr(&A.sc->err, ERR_HOST_TIMEOUT);
+                // what the device saw when it gave up (the host's error report prints these)
+                A.sc->prof[11] = __hip_atomic_load(M.resp_ticket + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                A.sc->prof[12] = t0 - t_kernel;
+                A.sc->prof[13] = ticket;
+                A.sc->prof[14] = polls;
+                A.sc->prof[15] = __hip_atomic_fetch_or(M.resp_ticket + s, 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);   // the same word through an atomic RMW
+                break;
+            }
         }
         A.sc->prof[5] += (long)wall_clock64() - t0;
         __threadfence_system();
@@ -326,6 +352,7 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
     BifRequest *reqs = M.reqs + (size_t)s * REQ_PER_SAMPLE;
     const double *results = M.results + (size_t)s * REQ_PER_SAMPLE * 6;
     const int n_iter = B.C.n_iter;
+    const long t_kernel = (long)wall_clock64();
     for (int it = 0; it <= n_iter; it++) {
         if (uniform_err(b, A)) break;
         if (it > 0) {
@@ -349,7 +376,7 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
         if (b.tid == 0) *req_n = 0;
         b.sync();
         OCTA_PROF(2, phase_pre(b, A, B.C, P, 0, A.oxy, reqs, req_n, REQ_PER_SAMPLE, s));
-        mail_roundtrip(b, A, M, s, *req_n, 2 * it + 1);
+        mail_roundtrip(b, A, M, s, *req_n, 2 * it + 1, t_kernel);
         if (uniform_err(b, A)) break;
         {
             // the candidate stream of the NEXT iteration (numpy MT19937, one wave) runs beside the ordered arterial pass:
@@ -370,7 +397,7 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
         if (b.tid == 0) *req_n = 0;
         b.sync();
         OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, reqs, req_n, REQ_PER_SAMPLE, s));
-        mail_roundtrip(b, A, M, s, *req_n, 2 * it + 2);
+        mail_roundtrip(b, A, M, s, *req_n, 2 * it + 2, t_kernel);
     }
     // the host leaves its service loop when every workgroup has signed off HERE, not on a HIP event: it must not enter
     // the HIP runtime while workgroups may still be waiting for it (see octa_sim_run)
@@ -394,14 +421,15 @@ struct octa_sim {
     BifRequest *h_reqs = nullptr;   // pinned [2*REQ_CAP]
     double *h_results = nullptr;    // pinned [2*REQ_CAP*6]
     int *h_req_count = nullptr;     // pinned [2]
-    HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};  // pinned mailbox of the persistent form
+    HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};  // pinned mailbox of the persistent form
     bool lockstep = false;          // OCTA_SIM_LOCKSTEP=1: two launches per iteration (the round-1 form)
     double mail_timeout_ms = 30000; // OCTA_SIM_MAIL_TIMEOUT_MS: device-side bound on one wait for the host
     int test_stall_ms = 0;          // OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once with a ticket pending
-    bool legacy_event_poll = false; // OCTA_SIM_LEGACY_EVENT_POLL=1 (diagnosis): also poll hipEventQuery as round 1 did, timed
+    bool legacy_event_poll = false; // OCTA_SIM_ROUND1_MAILBOX=1 (reproduction only): round 1's ticket publication (plain release store) and its timed hipEventQuery poll
     long spin_scans = 4096;         // idle mailbox scans before the service thread starts sleeping 20 us between scans
     double diag_max_gap_ms = 0, diag_max_query_ms = 0, diag_max_bif_ms = 0;
     long diag_tickets = 0, diag_early_event = 0;
+    std::vector<double> diag_answer_ms;
     bool ran = false;
     // host copies for export
     std::vector<SampleScalars> h_sc;
@@ -493,7 +521,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
         S->lockstep = ls && ls[0] == '1';
         if (const char *e = getenv("OCTA_SIM_MAIL_TIMEOUT_MS")) { double v = atof(e); if (v >= 1.0) S->mail_timeout_ms = v; }
         if (const char *e = getenv("OCTA_SIM_TEST_HOST_STALL_MS")) S->test_stall_ms = atoi(e);
-        if (const char *e = getenv("OCTA_SIM_LEGACY_EVENT_POLL")) S->legacy_event_poll = e[0] == '1';
+        if (const char *e = getenv("OCTA_SIM_ROUND1_MAILBOX")) S->legacy_event_poll = e[0] == '1';
         // several ranks per host (one service thread per step in flight and rank): give the cores back sooner
         if (const char *e = getenv("WORLD_SIZE")) { if (atoi(e) > 1) S->spin_scans = 256; }
         if (const char *e = getenv("OCTA_SIM_SPIN_SCANS")) S->spin_scans = atol(e);
@@ -620,17 +648,18 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
     S->ms_a = S->ms_b = S->ms_total = S->ms_host_bif = 0; S->n_a = S->n_b = S->n_bif_req = 0;
     auto wall0 = std::chrono::steady_clock::now();
     if (!S->lockstep) {
-        // ---- persistent form: one launch, the host answers mailbox tickets until every workgroup has signed off.
-        // Between the launch and that moment this thread makes NO call into the HIP runtime. Round 1 polled
-        // hipEventQuery(ev[1]) here: its first call on a pending event enqueues a notification marker under the stream's
-        // submission lock, and a device-wide wait issued by ANOTHER thread in that window (torch.cuda.synchronize(), the
-        // hipDeviceSynchronize of a growing scratch buffer, hipFree) holds that lock while it waits for this very kernel --
-        // the kernel waits for this thread, this thread for the lock: workgroups ran into their 30 s mailbox timeout
-        // (error bit 0x800). The exit condition is now a counter in the pinned block that the kernel itself increments.
+        // ---- persistent form: one launch, the host answers mailbox tickets until every workgroup has signed off (a counter in
+        // the pinned block that the kernel increments with a system-scope atomic). Between the launch and that moment this thread
+        // stays out of the HIP runtime: its only job is the mailbox, and runtime calls can take locks that device-wide waits of
+        // other threads hold for as long as this very kernel runs. (Round 1 polled hipEventQuery here; that was not the cause of
+        // the 0x800 time-outs -- see mail_roundtrip -- but it is one less way for this loop to stall.)
         HostMail &M = S->mail;
         for (int s = 0; s < 3 * B + 1; s++) M.req_n[s] = 0;
         M.timeout_ticks = (long)(S->mail_timeout_ms * 1e5);
+        M.round1_publish = S->legacy_event_poll ? 1 : 0;
         std::vector<int> seen(B, 0);
+        S->diag_answer_ms.assign(B, 0.0);
+        const auto t_launch = std::chrono::steady_clock::now();
         OCTA_HIP_CHECK(hipEventRecord(S->ev[0], stream));
         hipLaunchKernelGGL(sim_persistent_kernel, dim3((unsigned)B), dim3(SIM_THREADS), SIM_LDS, stream, P, M);
         OCTA_HIP_CHECK(hipGetLastError());
@@ -673,6 +702,7 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
                 __atomic_store_n(M.resp_ticket + s, t, __ATOMIC_RELEASE);
                 seen[s] = t;
                 S->diag_tickets++;
+                S->diag_answer_ms[s] = std::chrono::duration<double, std::milli>(clk::now() - t_launch).count();
             }
             const int done = __atomic_load_n(M.done, __ATOMIC_ACQUIRE);
             if (done >= B) break;
@@ -680,7 +710,7 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
             if ((++idle & 63) == 0) {
                 const auto now = clk::now();
                 last_scan = now;
-                if (S->legacy_event_poll) {   // diagnosis only (OCTA_SIM_LEGACY_EVENT_POLL=1): the round-1 exit condition, timed
+                if (S->legacy_event_poll) {   // reproduction only (OCTA_SIM_ROUND1_MAILBOX=1): the round-1 exit condition, timed
                     hipError_t q = hipEventQuery(S->ev[1]);
                     const double qms = std::chrono::duration<double, std::milli>(clk::now() - now).count();
                     if (qms > S->diag_max_query_ms) S->diag_max_query_ms = qms;
@@ -738,9 +768,12 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
             if ((S->h_sc[s].err & ERR_HOST_TIMEOUT) && !S->lockstep)
                 octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x: a workgroup waited more than %.0f ms for the host's "
                                 "mailbox answer (request ticket %d, answered %d, %ld tickets served this run, longest absence of the service thread "
-                                "%.1f ms, longest bifurcation callback %.1f ms, longest hipEventQuery %.1f ms, early event completions %ld)", s, S->h_sc[s].err,
+                                "%.1f ms, longest bifurcation callback %.1f ms, longest hipEventQuery %.1f ms, early event completions %ld; the host answered this "
+                                "sample's last ticket %.1f ms after the launch; the workgroup began waiting for ticket %ld at %.1f ms, polled %ld times and "
+                                "at its deadline read answer %ld by load, %ld by atomic)", s, S->h_sc[s].err,
                                 S->mail_timeout_ms, S->mail.req_ticket[s], S->mail.resp_ticket[s], S->diag_tickets, S->diag_max_gap_ms,
-                                S->diag_max_bif_ms, S->diag_max_query_ms, S->diag_early_event);
+                                S->diag_max_bif_ms, S->diag_max_query_ms, S->diag_early_event, S->diag_answer_ms[s], S->h_sc[s].prof[13],
+                                S->h_sc[s].prof[12] * 1e-5, S->h_sc[s].prof[14], S->h_sc[s].prof[11], S->h_sc[s].prof[15]);
             else
                 octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x", s, S->h_sc[s].err);
             return -3;

@@ -1,11 +1,13 @@
 """GPU: liveness of the device<->host mailbox of the persistent simulator kernel (leaf-bifurcation service).
 
-Round 1's driver run lost a generator thread to error bit 0x800 (a workgroup waited 30 s for the host). Root cause: the
-service loop polled hipEventQuery, whose first call on a pending event enqueues a notification marker under the stream's
-submission lock; a device-wide wait from another thread (torch.cuda.synchronize, a growing scratch buffer's
-hipDeviceSynchronize, hipFree) holds that lock while it waits for the very kernel that waits for the service loop.
-These tests pin the fix (octa_sim_run leaves on a device-written sign-off counter and never enters the HIP runtime while
-workgroups may wait for it) and that a host that does go away is an ERROR, not a warning.
+Round 1's driver run lost a generator thread to error bit 0x800 (a workgroup waited 30 s for the host). Root cause, measured
+with tools/repro_mailbox_deadlock.py (profiles/r02_mailbox_repro.log): the workgroup published its ticket with a system-scope
+release STORE and then only polled; the stored word could stay in the XCD's L2 until some later write-back (usually a
+neighbouring workgroup's system fence, microseconds later -- or nobody's), so the host, scanning continuously, never saw
+the request. The ticket is now published with an atomic exchange (executes at the memory) + a system fence, the poll loop
+repeats the fence, and octa_sim_run leaves on a device-written sign-off counter without entering the HIP runtime while
+workgroups may wait for it. These tests pin that the protocol survives device-wide waits, allocations and frees from
+other threads and long training loops beside it, and that a host that really goes away is an ERROR, not a warning.
 """
 import os
 import threading
@@ -63,8 +65,9 @@ def test_producer_failure_reaches_the_consumer(hip_lib_built, monkeypatch):
 
 @pytest.mark.parametrize("repeat", range(3))
 def test_device_wide_waits_from_another_thread_do_not_starve_the_mailbox(hip_lib_built, repeat):
-    """The round-1 failure window, forced: while two generator threads run simulations back to back, the main thread keeps
-    issuing device-wide waits, allocations and frees. With a 5 s device-side bound a single lost ticket fails the run."""
+    """Two generator threads run simulations back to back (few workgroups per XCD: the constellation in which a lingering ticket
+    word had no neighbour to flush it) while the main thread keeps issuing device-wide waits, allocations and frees. With a 5 s
+    device-side bound a single lost ticket fails the run."""
     import torch
     from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
     os.environ["OCTA_SIM_MAIL_TIMEOUT_MS"] = "5000"

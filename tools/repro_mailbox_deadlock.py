@@ -1,9 +1,12 @@
-"""Root-cause record for error bit 0x800 (round 1): run simulations with the round-1 exit condition re-enabled
-(OCTA_SIM_LEGACY_EVENT_POLL=1 adds a timed hipEventQuery to the service loop) while the main thread issues device-wide
-waits, and print how long the longest hipEventQuery took. A call that takes as long as the kernel has left (or the
-device-side bound) is the service thread blocked on the stream's submission lock.
+"""Root-cause record for error bit 0x800 (round 1: "a workgroup waited 30 s for the host"). Runs many short simulations
+from two threads while the main thread hammers device-wide waits; `--legacy 1` (OCTA_SIM_ROUND1_MAILBOX=1) re-enables round
+1's mailbox -- tickets published with a plain system-scope release store, hipEventQuery polled by the service thread -- and the
+failure reproduces a few times in 600 runs, with the library's diagnostics showing what happened: the workgroup began waiting a few
+milliseconds into the launch, the host (scanning all the time, longest pass < 0.1 ms) saw and answered the ticket only when
+the device-side deadline fired, i.e. the ticket word sat in the GPU's L2 until a later write-back. `--legacy 0` is the
+shipped protocol (atomic exchange + fence): 0 failures. Results: profiles/r02_mailbox_repro.log.
 
-  python tools/repro_mailbox_deadlock.py [--legacy 1] [--reps 8]
+  python tools/repro_mailbox_deadlock.py [--legacy 1] [--reps 300] [--iters 12,6]
 """
 import argparse
 import os
@@ -23,7 +26,7 @@ ap.add_argument("--timeout-ms", type=int, default=4000)
 ap.add_argument("--iters", type=str, default="60,30", help="iterations of the two growth modes (short kernels = many launches)")
 ap.add_argument("--pure-sync", type=int, default=1, help="main thread spins on torch.cuda.synchronize() only")
 a = ap.parse_args()
-os.environ["OCTA_SIM_LEGACY_EVENT_POLL"] = str(a.legacy)
+os.environ["OCTA_SIM_ROUND1_MAILBOX"] = str(a.legacy)
 os.environ["OCTA_SIM_MAIL_TIMEOUT_MS"] = str(a.timeout_ms)
 
 import torch
