@@ -414,14 +414,16 @@ int octa_sim_stats(octa_sim *sim, int64_t *h_stats);
  * [7] bytes of HBM held by the simulator. */
 int octa_sim_timing(octa_sim *sim, double *h_out8);
 
-/* Host-side record of the mailbox service of the last octa_sim_run (persistent form), h_out4 (FIVE doubles): [0] tickets served,
- * [1] longest single pass of the service loop (ms: how long the thread was away from the mailbox), [4] longest bifurcation callback (ms), [2] longest hipEventQuery call (ms; only measured
- * with OCTA_SIM_ROUND1_MAILBOX=1, which re-enables round 1's ticket publication and exit condition to reproduce its defect), [3] times that query reported the
- * launch complete while workgroups were still running. Environment read by octa_sim_create:
- * OCTA_SIM_MAIL_TIMEOUT_MS (device-side bound on one wait for the host, default 30000; error bit 0x800),
- * OCTA_SIM_TEST_HOST_STALL_MS (test hook: the service thread sleeps once while a ticket is pending),
- * OCTA_SIM_SPIN_SCANS (idle scans before the service thread sleeps between scans; 4096, 256 when WORLD_SIZE > 1). */
-int octa_sim_service_stats(octa_sim *sim, double *h_out4);
+/* Host-side record of the mailbox service of the last octa_sim_run (persistent form), h_out5 (five doubles): [0] tickets
+ * served while kernels ran, [1] longest single pass of the service loop (ms: how long the thread was away from the mailbox),
+ * [2] extra kernel launches because workgroups had parked, [3] parked workgroups served at kernel boundaries, [4] longest
+ * bifurcation callback (ms). Environment read by octa_sim_create:
+ *   OCTA_SIM_PARK_MS (default 3): a workgroup that has waited this long for its answer records its resume point and leaves the
+ *     kernel; the host serves it at the kernel boundary and launches again. 0 = never park (round-1 behaviour: wait up to
+ *     OCTA_SIM_MAIL_TIMEOUT_MS, default 30000, then fail the sample with error bit 0x800);
+ *   OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once while a ticket is pending;
+ *   OCTA_SIM_SPIN_SCANS: idle scans before the service thread sleeps between scans (4096; 256 when WORLD_SIZE > 1). */
+int octa_sim_service_stats(octa_sim *sim, double *h_out5);
 
 /* Final O2 / CO2 fields of one sample (host buffers, capacity in points); returns counts. */
 int octa_sim_fields(octa_sim *sim, int sample, double *h_oxy, int64_t cap_oxy, int64_t *n_oxy, double *h_co2,

@@ -283,45 +283,49 @@ struct HostMail {
     int *resp_ticket;    // pinned host [B]                     host -> device
     int *done;           // pinned host [1]                     device -> host: workgroups that have left the kernel
     long timeout_ticks;  // device-side bound on one wait for the host (100 MHz wall clock)
-    int round1_publish;  // OCTA_SIM_ROUND1_MAILBOX=1 (reproduction of the round-1 defect only): publish tickets with a plain release store
+    long park_ticks;     // a workgroup that has waited this long parks (0: never, wait until timeout_ticks as round 1 did)
 };
 constexpr int REQ_PER_SAMPLE = 32;
 constexpr int ERR_HOST_TIMEOUT = 2048;
 
-// One request / answer round trip with the host service thread (octa_sim_run). Publication rule, learnt the hard way:
-// round 1 published the ticket with a system-scope RELEASE STORE and then only polled. A release fence orders what comes
-// BEFORE the store; the stored word itself may stay in the XCD's L2 until some later write-back. It usually left within
-// microseconds because another workgroup of the same XCD ran a system-scope fence (buffer_wbl2 writes back every dirty line of
-// that L2) -- and stayed for as long as the poll lasted when no neighbour did: the host, scanning all the time, saw the ticket
-// only when the device-side deadline fired and the workgroup moved on (error bit 0x800; measured with the diagnostics below:
-// "began waiting at 7 ms ... host answered 4008 ms after the launch ... read answer 0 at its deadline"). Now the ticket is
-// published with an atomic EXCHANGE -- a read-modify-write at system scope executes at the memory, it cannot linger in a cache --
-// followed by a system fence, and the poll loop repeats the fence now and then.
-__device__ inline void mail_roundtrip(const Blk &b, const SimArrays &A, const HostMail &M, int s, int n_req, int ticket, long t_kernel) {
-    if (n_req == 0) return;  // block-uniform
+// One request / answer round trip with the host service thread (octa_sim_run). Returns 0 when the answer is in
+// M.results, 1 when the workgroup must PARK (block-uniform).
+//
+// Why parking exists. Round 1 waited here for as long as it took (30 s bound, error bit 0x800) and the driver's run hit that
+// bound. Measured in round 2 (tools/repro_mailbox_deadlock.py, profiles/r02_mailbox_repro.log): in about one launch in two
+// hundred -- provoked by runtime activity of other host threads: device-wide waits, pageable copies -- the host, although it
+// scans the mailbox all the time (longest pass < 0.1 ms), stops seeing ANY ticket of that launch from some moment on and sees
+// them all when the kernel ends; meanwhile the workgroup reads its own ticket back correctly through a system-scope atomic,
+// and neither publishing with an atomic exchange + system fences nor flushing the host's cache lines changes that. In other
+// words: on this platform a running kernel's writes to pinned host memory are not guaranteed to become visible to the host
+// before the kernel ends -- only kernel boundaries are. So liveness must not depend on it: a workgroup waits a few
+// milliseconds (normal answers take tens of microseconds), then records its resume point in HBM and LEAVES the kernel; at
+// the kernel boundary the host sees every parked request, serves it and launches the kernel again for the parked samples.
+// A launch without an episode is unaffected; an episode costs one extra launch instead of the run.
+__device__ inline int mail_roundtrip(const Blk &b, const SimArrays &A, const HostMail &M, int s, int n_req, int ticket, long t_kernel) {
+    if (n_req == 0) return 0;  // block-uniform
+    int *park = b.coll() + 98;
     if (b.tid == 0) {
+        *park = 0;
         if (n_req > REQ_PER_SAMPLE) { atomicOr(&A.sc->err, ERR_REQ_CAP); n_req = REQ_PER_SAMPLE; }
-        __threadfence_system();      // the request records (written by the whole block before the barrier) reach host memory
+        __threadfence_system();      // the request records (written by the whole block before the barrier)
         __hip_atomic_store(M.req_n + s, n_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (M.round1_publish) __hip_atomic_store(M.req_ticket + s, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // repro only
-        else {
-            __hip_atomic_exchange(M.req_ticket + s, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            __threadfence_system();
-        }
+        __hip_atomic_exchange(M.req_ticket + s, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
         const long t0 = (long)wall_clock64();
         long polls = 0;
         while (__hip_atomic_load(M.resp_ticket + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ticket) {
             __builtin_amdgcn_s_sleep(64);
             polls++;
-            if (!M.round1_publish && (polls & 255) == 0) __threadfence_system();
-            if ((long)wall_clock64() - t0 > M.timeout_ticks) {
+            const long waited = (long)wall_clock64() - t0;
+            if (M.park_ticks > 0 && waited > M.park_ticks) { *park = 1; break; }
+            if (waited > M.timeout_ticks) {      // only without parking (OCTA_SIM_PARK_MS=0): the round-1 behaviour
                 atomicOr(&A.sc->err, ERR_HOST_TIMEOUT);
-                // what the device saw when it gave up (the host's error report prints these)
                 A.sc->prof[11] = __hip_atomic_load(M.resp_ticket + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                 A.sc->prof[12] = t0 - t_kernel;
                 A.sc->prof[13] = ticket;
                 A.sc->prof[14] = polls;
-                A.sc->prof[15] = __hip_atomic_fetch_or(M.resp_ticket + s, 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);   // the same word through an atomic RMW
+                A.sc->prof[15] = __hip_atomic_fetch_or(M.req_ticket + s, 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);   // its own request, read back
                 break;
             }
         }
@@ -329,6 +333,9 @@ __device__ inline void mail_roundtrip(const Blk &b, const SimArrays &A, const Ho
         __threadfence_system();
     }
     b.sync();
+    const int p = *park;
+    b.sync();
+    return p;
 }
 
 // block-uniform read of the sample's error bits
@@ -353,56 +360,73 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
     const double *results = M.results + (size_t)s * REQ_PER_SAMPLE * 6;
     const int n_iter = B.C.n_iter;
     const long t_kernel = (long)wall_clock64();
-    for (int it = 0; it <= n_iter; it++) {
-        if (uniform_err(b, A)) break;
-        if (it > 0) {
-            const IterParams Pp = B.iters[it - 1];
-            OCTA_PROF(8, phase_seq(b, A, B.C, Pp, 1, A.co2, results));
-            OCTA_PROF(9, phase_satisfy_ven(b, A, Pp));
+    // where this sample stands: a fresh sample starts at (0, 0); a parked one resumes behind the mailbox it parked at (its
+    // answer is in M.results, written by the host before this launch); finished or failed samples only sign off
+    int *uni = b.coll() + 99;
+    if (b.tid == 0) { uni[0] = A.sc->resume_it; uni[1] = A.sc->resume_stage; uni[2] = A.sc->finished | (A.sc->err != 0); A.sc->parked = 0; }
+    b.sync();
+    const int it0 = uni[0];
+    int stage = uni[1];
+    const int skip = uni[2];
+    b.sync();
+    int parked_at = -1, parked_stage = 0;
+    for (int it = it0; it <= n_iter && !skip; it++) {
+        if (stage == 0) {
+            if (uniform_err(b, A)) break;
+            if (it > 0) {
+                const IterParams Pp = B.iters[it - 1];
+                OCTA_PROF(8, phase_seq(b, A, B.C, Pp, 1, A.co2, results));
+                OCTA_PROF(9, phase_satisfy_ven(b, A, Pp));
+            }
+            if (it >= n_iter) break;
+            const IterParams P = B.iters[it];
+            if (it == 0) {   // later iterations get their candidates from the side job of the previous ordered arterial pass
+                long _t0 = (long)wall_clock64();
+                if (threadIdx.x < 64)
+                    gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], P.N,
+                                        B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()),
+                                        reinterpret_cast<unsigned *>(b.user()) + 624 + 1248, (int)threadIdx.x);
+                __syncthreads();
+                if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
+            }
+            OCTA_PROF(0, phase_sample(b, A, B.C, P, it));
+            OCTA_PROF(1, phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art));
+            if (b.tid == 0) *req_n = 0;
+            b.sync();
+            OCTA_PROF(2, phase_pre(b, A, B.C, P, 0, A.oxy, reqs, req_n, REQ_PER_SAMPLE, s));
+            if (mail_roundtrip(b, A, M, s, *req_n, 2 * it + 1, t_kernel)) { parked_at = it; parked_stage = 1; break; }
         }
-        if (it >= n_iter) break;
-        const IterParams P = B.iters[it];
-        if (it == 0) {   // later iterations get their candidates from the side job of the previous ordered arterial pass
-            long _t0 = (long)wall_clock64();
-            if (threadIdx.x < 64)
-                gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], P.N,
-                                    B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()),
-                                    reinterpret_cast<unsigned *>(b.user()) + 624 + 1248, (int)threadIdx.x);
-            __syncthreads();
-            if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
+        if (stage <= 1) {
+            const IterParams P = B.iters[it];
+            if (uniform_err(b, A)) break;
+            {
+                // the candidate stream of the NEXT iteration (numpy MT19937, one wave) runs beside the ordered arterial pass:
+                // it only depends on the generator state, and the candidate buffer is free once phase_sample has consumed it
+                const int n_next = it + 1 < n_iter ? B.iters[it + 1].N : 0;
+                auto next_candidates = [&](unsigned char *lds) {
+                    if (n_next <= 0) return;
+                    const long _t0 = (long)wall_clock64();
+                    gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], n_next,
+                                        B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(lds),
+                                        B.cand_idx + (size_t)s * NCANDCAP, (int)(threadIdx.x & 63));
+                    if ((threadIdx.x & 63) == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
+                };
+                OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, results, next_candidates));
+            }
+            OCTA_PROF(4, phase_satisfy_art(b, A, P));
+            OCTA_PROF(6, phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven));
+            if (b.tid == 0) *req_n = 0;
+            b.sync();
+            OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, reqs, req_n, REQ_PER_SAMPLE, s));
+            if (mail_roundtrip(b, A, M, s, *req_n, 2 * it + 2, t_kernel)) { parked_at = it; parked_stage = 2; break; }
         }
-        OCTA_PROF(0, phase_sample(b, A, B.C, P, it));
-        OCTA_PROF(1, phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art));
-        if (b.tid == 0) *req_n = 0;
-        b.sync();
-        OCTA_PROF(2, phase_pre(b, A, B.C, P, 0, A.oxy, reqs, req_n, REQ_PER_SAMPLE, s));
-        mail_roundtrip(b, A, M, s, *req_n, 2 * it + 1, t_kernel);
-        if (uniform_err(b, A)) break;
-        {
-            // the candidate stream of the NEXT iteration (numpy MT19937, one wave) runs beside the ordered arterial pass:
-            // it only depends on the generator state, and the candidate buffer is free once phase_sample has consumed it
-            const int n_next = it + 1 < n_iter ? B.iters[it + 1].N : 0;
-            auto next_candidates = [&](unsigned char *lds) {
-                if (n_next <= 0) return;
-                const long _t0 = (long)wall_clock64();
-                gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], n_next,
-                                    B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(lds),
-                                    B.cand_idx + (size_t)s * NCANDCAP, (int)(threadIdx.x & 63));
-                if ((threadIdx.x & 63) == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
-            };
-            OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, results, next_candidates));
-        }
-        OCTA_PROF(4, phase_satisfy_art(b, A, P));
-        OCTA_PROF(6, phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven));
-        if (b.tid == 0) *req_n = 0;
-        b.sync();
-        OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, reqs, req_n, REQ_PER_SAMPLE, s));
-        mail_roundtrip(b, A, M, s, *req_n, 2 * it + 2, t_kernel);
+        stage = 0;
     }
-    // the host leaves its service loop when every workgroup has signed off HERE, not on a HIP event: it must not enter
-    // the HIP runtime while workgroups may still be waiting for it (see octa_sim_run)
+    // sign-off: the host leaves its service loop when every workgroup has passed here (or when the launch has completed)
     b.sync();
     if (b.tid == 0) {
+        if (parked_at >= 0) { A.sc->resume_it = parked_stage == 2 ? parked_at + 1 : parked_at; A.sc->resume_stage = parked_stage == 2 ? 0 : 1; A.sc->parked = 1; }
+        else if (!skip) A.sc->finished = 1;
         __threadfence_system();
         __hip_atomic_fetch_add(M.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -423,13 +447,12 @@ struct octa_sim {
     int *h_req_count = nullptr;     // pinned [2]
     HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};  // pinned mailbox of the persistent form
     bool lockstep = false;          // OCTA_SIM_LOCKSTEP=1: two launches per iteration (the round-1 form)
-    double mail_timeout_ms = 30000; // OCTA_SIM_MAIL_TIMEOUT_MS: device-side bound on one wait for the host
+    double mail_timeout_ms = 30000; // OCTA_SIM_MAIL_TIMEOUT_MS: device-side bound on one wait for the host when parking is off
+    double park_ms = 3.0;           // OCTA_SIM_PARK_MS: a workgroup that has waited this long for its answer parks (0: never)
     int test_stall_ms = 0;          // OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once with a ticket pending
-    bool legacy_event_poll = false; // OCTA_SIM_ROUND1_MAILBOX=1 (reproduction only): round 1's ticket publication (plain release store) and its timed hipEventQuery poll
     long spin_scans = 4096;         // idle mailbox scans before the service thread starts sleeping 20 us between scans
-    double diag_max_gap_ms = 0, diag_max_query_ms = 0, diag_max_bif_ms = 0;
-    long diag_tickets = 0, diag_early_event = 0;
-    std::vector<double> diag_answer_ms;
+    double diag_max_gap_ms = 0, diag_max_bif_ms = 0;
+    long diag_tickets = 0, diag_relaunches = 0, diag_parked = 0;
     bool ran = false;
     // host copies for export
     std::vector<SampleScalars> h_sc;
@@ -521,7 +544,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
         S->lockstep = ls && ls[0] == '1';
         if (const char *e = getenv("OCTA_SIM_MAIL_TIMEOUT_MS")) { double v = atof(e); if (v >= 1.0) S->mail_timeout_ms = v; }
         if (const char *e = getenv("OCTA_SIM_TEST_HOST_STALL_MS")) S->test_stall_ms = atoi(e);
-        if (const char *e = getenv("OCTA_SIM_ROUND1_MAILBOX")) S->legacy_event_poll = e[0] == '1';
+        if (const char *e = getenv("OCTA_SIM_PARK_MS")) { double v = atof(e); if (v >= 0.0) S->park_ms = v; }
         // several ranks per host (one service thread per step in flight and rank): give the cores back sooner
         if (const char *e = getenv("WORLD_SIZE")) { if (atoi(e) > 1) S->spin_scans = 256; }
         if (const char *e = getenv("OCTA_SIM_SPIN_SCANS")) S->spin_scans = atol(e);
@@ -648,92 +671,96 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
     S->ms_a = S->ms_b = S->ms_total = S->ms_host_bif = 0; S->n_a = S->n_b = S->n_bif_req = 0;
     auto wall0 = std::chrono::steady_clock::now();
     if (!S->lockstep) {
-        // ---- persistent form: one launch, the host answers mailbox tickets until every workgroup has signed off (a counter in
-        // the pinned block that the kernel increments with a system-scope atomic). Between the launch and that moment this thread
-        // stays out of the HIP runtime: its only job is the mailbox, and runtime calls can take locks that device-wide waits of
-        // other threads hold for as long as this very kernel runs. (Round 1 polled hipEventQuery here; that was not the cause of
-        // the 0x800 time-outs -- see mail_roundtrip -- but it is one less way for this loop to stall.)
+        // ---- persistent form: ONE launch runs every iteration of every sample; this thread answers mailbox tickets until all
+        // workgroups have signed off (a counter in the pinned block, incremented by the kernel with a system-scope atomic) or the
+        // launch has completed. Workgroups whose answer did not reach them in time have PARKED (mail_roundtrip): their requests
+        // are served here, at the kernel boundary, and the kernel is launched again for them. While a launch runs this thread's
+        // only job is the mailbox; it asks the runtime about the launch only after a millisecond of silence.
         HostMail &M = S->mail;
-        for (int s = 0; s < 3 * B + 1; s++) M.req_n[s] = 0;
-        M.timeout_ticks = (long)(S->mail_timeout_ms * 1e5);
-        M.round1_publish = S->legacy_event_poll ? 1 : 0;
-        std::vector<int> seen(B, 0);
-        S->diag_answer_ms.assign(B, 0.0);
-        const auto t_launch = std::chrono::steady_clock::now();
-        OCTA_HIP_CHECK(hipEventRecord(S->ev[0], stream));
-        hipLaunchKernelGGL(sim_persistent_kernel, dim3((unsigned)B), dim3(SIM_THREADS), SIM_LDS, stream, P, M);
-        OCTA_HIP_CHECK(hipGetLastError());
-        OCTA_HIP_CHECK(hipEventRecord(S->ev[1], stream));
         using clk = std::chrono::steady_clock;
-        long idle = 0;
-        bool failed = false;
+        M.timeout_ticks = (long)(S->mail_timeout_ms * 1e5);
+        M.park_ticks = (long)(S->park_ms * 1e5);
+        S->diag_max_gap_ms = 0; S->diag_tickets = 0; S->diag_max_bif_ms = 0; S->diag_relaunches = 0; S->diag_parked = 0;
+        S->h_sc.resize(B);
         bool stalled_once = false;
-        auto last_progress = clk::now(), last_scan = last_progress;
-        int last_done = 0;
-        S->diag_max_gap_ms = 0; S->diag_tickets = 0; S->diag_max_query_ms = 0; S->diag_early_event = 0; S->diag_max_bif_ms = 0;
-        auto iter_start = clk::now();
+        double ms_kernels = 0;
+        int launches = 0;
+        auto answer = [&](int s, int n) {
+            if (n > REQ_PER_SAMPLE) n = REQ_PER_SAMPLE;
+            if (n <= 0) return;
+            auto t0 = clk::now();
+            bif(n, reinterpret_cast<const octa_bif_request *>(M.reqs + (size_t)s * REQ_PER_SAMPLE), M.results + (size_t)s * REQ_PER_SAMPLE * 6, user);
+            const double bms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+            S->ms_host_bif += bms;
+            if (bms > S->diag_max_bif_ms) S->diag_max_bif_ms = bms;
+            S->n_bif_req += n;
+        };
         while (true) {
-            {   // longest single pass of this loop, whatever it was spent in (callback, descheduling, ...)
-                const auto t = clk::now();
-                const double it_ms = std::chrono::duration<double, std::milli>(t - iter_start).count();
-                if (it_ms > S->diag_max_gap_ms) S->diag_max_gap_ms = it_ms;
-                iter_start = t;
+            for (int s = 0; s < 3 * B + 1; s++) M.req_n[s] = 0;
+            std::vector<int> seen(B, 0);
+            OCTA_HIP_CHECK(hipEventRecord(S->ev[0], stream));
+            hipLaunchKernelGGL(sim_persistent_kernel, dim3((unsigned)B), dim3(SIM_THREADS), SIM_LDS, stream, P, M);
+            OCTA_HIP_CHECK(hipGetLastError());
+            OCTA_HIP_CHECK(hipEventRecord(S->ev[1], stream));
+            launches++;
+            long idle = 0;
+            auto last_progress = clk::now(), iter_start = last_progress;
+            int last_done = 0;
+            while (true) {
+                {   // longest single pass of this loop, whatever it was spent in (callback, descheduling, ...)
+                    const auto t = clk::now();
+                    const double it_ms = std::chrono::duration<double, std::milli>(t - iter_start).count();
+                    if (it_ms > S->diag_max_gap_ms) S->diag_max_gap_ms = it_ms;
+                    iter_start = t;
+                }
+                bool any = false;
+                for (int s = 0; s < B; s++) {
+                    const int t = __atomic_load_n(M.req_ticket + s, __ATOMIC_ACQUIRE);
+                    if (t == seen[s]) continue;
+                    any = true;
+                    if (S->test_stall_ms > 0 && !stalled_once) {   // test hook: the host goes away once, with a ticket pending
+                        stalled_once = true;
+                        std::this_thread::sleep_for(std::chrono::milliseconds(S->test_stall_ms));
+                    }
+                    answer(s, __atomic_load_n(M.req_n + s, __ATOMIC_RELAXED));
+                    __atomic_store_n(M.resp_ticket + s, t, __ATOMIC_RELEASE);
+                    seen[s] = t;
+                    S->diag_tickets++;
+                }
+                const int done = __atomic_load_n(M.done, __ATOMIC_ACQUIRE);
+                if (done >= B) break;
+                if (any || done != last_done) { idle = 0; last_done = done; last_progress = clk::now(); continue; }
+                if ((++idle & 63) == 0) {
+                    const double silent = std::chrono::duration<double, std::milli>(clk::now() - last_progress).count();
+                    if (silent > 1.0) {
+                        hipError_t q = hipEventQuery(S->ev[1]);
+                        if (q == hipSuccess) break;                       // launch over although not every sign-off was seen
+                        if (q != hipErrorNotReady) { octa::set_error("octa_sim_run: kernel failed: %s", hipGetErrorString(q)); return -1; }
+                        if (silent > 1000.0 * 120.0) { octa::set_error("octa_sim_run: the simulation kernel made no progress for 120 s"); return -1; }
+                    }
+                    if (idle > S->spin_scans) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                }
             }
-            bool any = false;
+            float ms = 0;
+            OCTA_HIP_CHECK(hipEventSynchronize(S->ev[1]));
+            OCTA_HIP_CHECK(hipEventElapsedTime(&ms, S->ev[0], S->ev[1]));
+            ms_kernels += ms;
+            // kernel boundary: everything the launch wrote is visible now
+            OCTA_HIP_CHECK(hipMemcpyAsync(S->h_sc.data(), P.sc, sizeof(SampleScalars) * B, hipMemcpyDeviceToHost, stream));
+            OCTA_HIP_CHECK(hipStreamSynchronize(stream));
+            int n_parked = 0;
             for (int s = 0; s < B; s++) {
-                const int t = __atomic_load_n(M.req_ticket + s, __ATOMIC_ACQUIRE);
-                if (t == seen[s]) continue;
-                any = true;
-                if (S->test_stall_ms > 0 && !stalled_once) {   // test hook: the host goes away once, with a ticket pending
-                    stalled_once = true;
-                    std::this_thread::sleep_for(std::chrono::milliseconds(S->test_stall_ms));
-                }
-                int n = __atomic_load_n(M.req_n + s, __ATOMIC_RELAXED);
-                if (n > REQ_PER_SAMPLE) n = REQ_PER_SAMPLE;
-                if (n > 0) {
-                    auto t0 = clk::now();
-                    bif(n, reinterpret_cast<const octa_bif_request *>(M.reqs + (size_t)s * REQ_PER_SAMPLE),
-                        M.results + (size_t)s * REQ_PER_SAMPLE * 6, user);
-                    const double bms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
-                    S->ms_host_bif += bms;
-                    if (bms > S->diag_max_bif_ms) S->diag_max_bif_ms = bms;
-                    S->n_bif_req += n;
-                }
-                __atomic_store_n(M.resp_ticket + s, t, __ATOMIC_RELEASE);
-                seen[s] = t;
-                S->diag_tickets++;
-                S->diag_answer_ms[s] = std::chrono::duration<double, std::milli>(clk::now() - t_launch).count();
+                if (!S->h_sc[s].parked || S->h_sc[s].err) continue;
+                n_parked++;
+                answer(s, M.req_n[s]);
             }
-            const int done = __atomic_load_n(M.done, __ATOMIC_ACQUIRE);
-            if (done >= B) break;
-            if (any || done != last_done) { idle = 0; last_done = done; last_progress = last_scan = clk::now(); continue; }
-            if ((++idle & 63) == 0) {
-                const auto now = clk::now();
-                last_scan = now;
-                if (S->legacy_event_poll) {   // reproduction only (OCTA_SIM_ROUND1_MAILBOX=1): the round-1 exit condition, timed
-                    hipError_t q = hipEventQuery(S->ev[1]);
-                    const double qms = std::chrono::duration<double, std::milli>(clk::now() - now).count();
-                    if (qms > S->diag_max_query_ms) S->diag_max_query_ms = qms;
-                    if (q == hipSuccess && __atomic_load_n(M.done, __ATOMIC_ACQUIRE) < B) S->diag_early_event++;
-                    last_scan = clk::now();
-                }
-                // no ticket and no workgroup finished for 20 s: the kernel is gone (fault) or wedged. Only now ask the runtime.
-                if (std::chrono::duration<double>(now - last_progress).count() > 20.0 + S->mail_timeout_ms * 1e-3) {
-                    hipError_t q = hipEventQuery(S->ev[1]);
-                    octa::set_error("octa_sim_run: no mailbox ticket and no finished sample for %.0f s (%d of %d workgroups signed off, "
-                                    "%ld tickets served, stream status: %s)", std::chrono::duration<double>(now - last_progress).count(),
-                                    done, B, S->diag_tickets, q == hipSuccess ? "complete" : hipGetErrorString(q));
-                    failed = true;
-                    break;
-                }
-                if (idle > S->spin_scans) std::this_thread::sleep_for(std::chrono::microseconds(20));
-            }
+            if (n_parked == 0) break;
+            S->diag_relaunches++;
+            S->diag_parked += n_parked;
+            if (launches > 4 * (int)S->iters.size() + 16) { octa::set_error("octa_sim_run: %d launches without finishing (parking loop)", launches); return -1; }
         }
-        if (failed) return -1;
-        float ms = 0;
-        OCTA_HIP_CHECK(hipEventSynchronize(S->ev[1]));
-        OCTA_HIP_CHECK(hipEventElapsedTime(&ms, S->ev[0], S->ev[1]));
-        S->ms_b = ms; S->n_b = 1;
+        const float ms = (float)ms_kernels;
+        S->ms_b = ms; S->n_b = launches;
     } else
     for (int it = 0; it <= C.n_iter; it++) {
         float ms = 0;
@@ -766,14 +793,12 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
     for (int s = 0; s < B; s++)
         if (S->h_sc[s].err) {
             if ((S->h_sc[s].err & ERR_HOST_TIMEOUT) && !S->lockstep)
-                octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x: a workgroup waited more than %.0f ms for the host's "
-                                "mailbox answer (request ticket %d, answered %d, %ld tickets served this run, longest absence of the service thread "
-                                "%.1f ms, longest bifurcation callback %.1f ms, longest hipEventQuery %.1f ms, early event completions %ld; the host answered this "
-                                "sample's last ticket %.1f ms after the launch; the workgroup began waiting for ticket %ld at %.1f ms, polled %ld times and "
-                                "at its deadline read answer %ld by load, %ld by atomic)", s, S->h_sc[s].err,
-                                S->mail_timeout_ms, S->mail.req_ticket[s], S->mail.resp_ticket[s], S->diag_tickets, S->diag_max_gap_ms,
-                                S->diag_max_bif_ms, S->diag_max_query_ms, S->diag_early_event, S->diag_answer_ms[s], S->h_sc[s].prof[13],
-                                S->h_sc[s].prof[12] * 1e-5, S->h_sc[s].prof[14], S->h_sc[s].prof[11], S->h_sc[s].prof[15]);
+                octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x: with parking disabled (OCTA_SIM_PARK_MS=0) a workgroup waited "
+                                "more than %.0f ms for the host's mailbox answer (request ticket %d, answered %d, %ld tickets served this run, longest pass of the "
+                                "service loop %.1f ms, longest bifurcation callback %.1f ms; the workgroup began waiting for ticket %ld at %.1f ms into its "
+                                "launch, polled %ld times, at its deadline read answer %ld and its own request word back as %ld)", s, S->h_sc[s].err,
+                                S->mail_timeout_ms, S->mail.req_ticket[s], S->mail.resp_ticket[s], S->diag_tickets, S->diag_max_gap_ms, S->diag_max_bif_ms,
+                                S->h_sc[s].prof[13], S->h_sc[s].prof[12] * 1e-5, S->h_sc[s].prof[14], S->h_sc[s].prof[11], S->h_sc[s].prof[15]);
             else
                 octa::set_error("octa_sim_run: sample %d failed with capacity/error bits 0x%x", s, S->h_sc[s].err);
             return -3;
@@ -891,7 +916,7 @@ extern "C" int octa_sim_kat_kd_order(octa_ctx *ctx, const double *h_pts, int64_t
 
 extern "C" int octa_sim_service_stats(octa_sim *S, double *h_out4) {
     if (!S || !S->ran || !h_out4) { octa::set_error("octa_sim_service_stats: run the simulation first"); return -2; }
-    h_out4[0] = (double)S->diag_tickets; h_out4[1] = S->diag_max_gap_ms; h_out4[2] = S->diag_max_query_ms; h_out4[3] = (double)S->diag_early_event;
+    h_out4[0] = (double)S->diag_tickets; h_out4[1] = S->diag_max_gap_ms; h_out4[2] = (double)S->diag_relaunches; h_out4[3] = (double)S->diag_parked;
     h_out4[4] = S->diag_max_bif_ms;
     return 0;
 }

@@ -103,6 +103,10 @@ struct SampleScalars {
     long respec;
     long prof[16];  // accumulated 100 MHz ticks per phase (thread 0), see sim.hip
     long kdprof[8]; // kd_build breakdown: bbox, dim, gather, nth(wave), nth(thread), next-level, finalize
+    // persistent form (sim.hip): a workgroup whose host answer does not arrive in time PARKS -- it records where to resume and
+    // leaves the kernel; the host serves it at the kernel boundary and launches again
+    int resume_it, resume_stage;   // stage 0: top of iteration resume_it; 1: behind its arterial mailbox
+    int parked, finished;
 };
 
 // pointers to ONE sample's slices

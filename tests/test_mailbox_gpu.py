@@ -1,13 +1,13 @@
 """GPU: liveness of the device<->host mailbox of the persistent simulator kernel (leaf-bifurcation service).
 
-Round 1's driver run lost a generator thread to error bit 0x800 (a workgroup waited 30 s for the host). Root cause, measured
-with tools/repro_mailbox_deadlock.py (profiles/r02_mailbox_repro.log): the workgroup published its ticket with a system-scope
-release STORE and then only polled; the stored word could stay in the XCD's L2 until some later write-back (usually a
-neighbouring workgroup's system fence, microseconds later -- or nobody's), so the host, scanning continuously, never saw
-the request. The ticket is now published with an atomic exchange (executes at the memory) + a system fence, the poll loop
-repeats the fence, and octa_sim_run leaves on a device-written sign-off counter without entering the HIP runtime while
-workgroups may wait for it. These tests pin that the protocol survives device-wide waits, allocations and frees from
-other threads and long training loops beside it, and that a host that really goes away is an ERROR, not a warning.
+Round 1's driver run lost a generator thread to error bit 0x800 (a workgroup waited 30 s for the host). Measured in round 2
+(tools/repro_mailbox_deadlock.py, profiles/r02_mailbox_repro.log): about one launch in two hundred, provoked by runtime
+activity of other host threads, the host stops seeing the launch's tickets until the kernel ends although it scans the mailbox
+continuously and the workgroup reads its own ticket back correctly -- a running kernel's writes to pinned host memory are not
+guaranteed to reach the host before the kernel ends. The protocol therefore no longer depends on it: a workgroup that has
+waited 3 ms PARKS (records its resume point, leaves the kernel), the host serves parked requests at the kernel boundary and
+launches again. These tests pin that results stay bit-identical through parking, that the loops around the simulator survive
+device-wide waits, allocations and frees from other threads, and that failures of the generator thread are errors, not warnings.
 """
 import os
 import threading
@@ -27,35 +27,57 @@ def _cfg(i1, i2):
     return cfg
 
 
-def test_host_stall_is_fatal(hip_lib_built, monkeypatch):
-    """A service thread that disappears for 1 s with a ticket pending, against a 300 ms device-side bound: octa_sim_run
-    must fail with the timeout bit and say what the host side saw."""
-    from octa_autosegmentation_amd import _native
+def test_host_stall_is_absorbed_by_parking_and_fatal_without_it(hip_lib_built, monkeypatch):
+    """A service thread that disappears for 1 s with a ticket pending. Default protocol: the waiting workgroups park after 3 ms,
+    the launch ends, the host (back from its absence) serves them at the kernel boundary and launches again -- the CSV rows are
+    the ones of an undisturbed run. With parking off (round 1) and a 300 ms device-side bound the run must fail loudly."""
+    from octa_autosegmentation_amd import _native, graph_io
     from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
-    monkeypatch.setenv("OCTA_SIM_MAIL_TIMEOUT_MS", "300")
+    want = greenhouse.simulate_batch(_cfg(40, 20), [0, 1, 2, 3])
+    assert want.service["relaunches"] == 0 or want.service["parked"] > 0
     monkeypatch.setenv("OCTA_SIM_TEST_HOST_STALL_MS", "1000")
-    sim = greenhouse.BatchSimulator(_cfg(100, 20), 4)
+    sim = greenhouse.BatchSimulator(_cfg(40, 20), 4)
+    try:
+        res = sim.run([0, 1, 2, 3])
+        assert res.service["relaunches"] >= 1 and res.service["parked"] >= 1 and int(res.stats[:, 0].max()) == 0
+        for k in range(4):
+            assert graph_io.edges_to_csv_bytes(res.sample_edges(k)) == graph_io.edges_to_csv_bytes(want.sample_edges(k))
+    finally:
+        sim.close()
+    monkeypatch.setenv("OCTA_SIM_PARK_MS", "0")
+    monkeypatch.setenv("OCTA_SIM_MAIL_TIMEOUT_MS", "300")
+    sim = greenhouse.BatchSimulator(_cfg(40, 20), 4)
     try:
         with pytest.raises(_native.OctaHipError) as ei:
             sim.run([0, 1, 2, 3])
         msg = str(ei.value)
-        assert "rc=-3" in msg and "0x800" in msg and "waited more than 300 ms" in msg and "longest absence" in msg, msg
+        assert "rc=-3" in msg and "0x800" in msg and "waited more than 300 ms" in msg and "longest pass of the service loop" in msg, msg
     finally:
         sim.close()
-    # the same simulator configuration without the stall is fine (and the environment hook is per simulator object)
-    monkeypatch.delenv("OCTA_SIM_TEST_HOST_STALL_MS")
-    sim = greenhouse.BatchSimulator(_cfg(100, 20), 4)
-    try:
-        res = sim.run([0, 1, 2, 3])
-        assert int(res.stats[:, 0].max()) == 0 and res.service["tickets"] > 0
-    finally:
-        sim.close()
+
+
+def test_every_workgroup_parking_at_every_ticket_changes_nothing(hip_lib_built, monkeypatch):
+    """OCTA_SIM_PARK_MS tiny: practically every mailbox round trip parks, so the run is a long chain of launches resumed at both
+    resume points of every iteration -- and still gives the reference's bytes (tests/golden: CSV written by the reference)."""
+    import yaml
+    from octa_autosegmentation_amd import graph_io
+    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_golden.npz"))
+    cfg = yaml.safe_load(str(g["config_yaml"]))
+    cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = 30, 20
+    monkeypatch.setenv("OCTA_SIM_PARK_MS", "0.0005")
+    monkeypatch.setenv("OCTA_SIM_TEST_HOST_STALL_MS", "5")
+    res = greenhouse.simulate_batch(cfg, [0, 1, 2, 3])
+    assert res.service["relaunches"] >= 5, res.service
+    for k in range(4):
+        assert graph_io.edges_to_csv_bytes(res.sample_edges(k)) == g[f"run_s{k}_30_20_csv"].tobytes(), k
 
 
 def test_producer_failure_reaches_the_consumer(hip_lib_built, monkeypatch):
     """train_synthetic.run: a generator thread that dies must fail the training loop (the reference swallows worker
     exceptions, generate_vessel_graph.py:127-129; round 1 trained on with a dead producer)."""
     import train_synthetic
+    monkeypatch.setenv("OCTA_SIM_PARK_MS", "0")
     monkeypatch.setenv("OCTA_SIM_MAIL_TIMEOUT_MS", "300")
     monkeypatch.setenv("OCTA_SIM_TEST_HOST_STALL_MS", "1000")
     with pytest.raises(RuntimeError, match="generator thread failed") as ei:
@@ -65,9 +87,8 @@ def test_producer_failure_reaches_the_consumer(hip_lib_built, monkeypatch):
 
 @pytest.mark.parametrize("repeat", range(3))
 def test_device_wide_waits_from_another_thread_do_not_starve_the_mailbox(hip_lib_built, repeat):
-    """Two generator threads run simulations back to back (few workgroups per XCD: the constellation in which a lingering ticket
-    word had no neighbour to flush it) while the main thread keeps issuing device-wide waits, allocations and frees. With a 5 s
-    device-side bound a single lost ticket fails the run."""
+    """Two generator threads run simulations back to back while the main thread keeps issuing device-wide waits, allocations and
+    frees -- the activity that provokes the visibility episodes. Every run must succeed (episodes are absorbed by parking)."""
     import torch
     from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
     os.environ["OCTA_SIM_MAIL_TIMEOUT_MS"] = "5000"
