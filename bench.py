@@ -1,20 +1,24 @@
 """bench.py -- headline benchmark: synthetic OCTA triples per second on MI355X.
 
-A step = one pass of the hot path over one batch of seeded samples with the reference's own
-generator config (docker/vessel_graph_gen_docker_config.yml):
-space-colonisation simulation of B vessel graphs (HIP), 304x304 arterial/venous rasterisation and
-max-combine, 1216x1216 label rasterisation + Floyd-Steinberg binarisation. Outputs stay in memory
-(edge arrays on the host, images/labels in HBM); writing CSV/PNG files is not part of the step.
-Workload = BASELINE.json configs[1] (128-sample batch, rasterise to 1216x1216).
+A step = one pass of the hot path over one batch of seeded samples with the reference's own generator config
+(docker/vessel_graph_gen_docker_config.yml): space-colonisation simulation of B vessel graphs (HIP), 304x304
+arterial/venous rasterisation and max-combine, 1216x1216 label rasterisation + Floyd-Steinberg binarisation.
+Workload = BASELINE.json configs[1] (128-sample batch, rasterise to 1216x1216). `value` counts triples complete in memory
+(edge arrays on the host, images / labels in HBM); the `files` leg of the same run writes the reference's per-sample
+files (graph CSV + image PNG + label PNG) for one batch and reports on-disk triples per second.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
-Multi-GPU (driver-launched with torch.distributed.run): samples are independent, every rank
-generates its own batch with its own seeds; no data-path collective (weak scaling).
+Multi-GPU (driver-launched with torch.distributed.run): samples are independent, every rank generates its own batch with
+its own seeds; no data-path collective (weak scaling).
+
+Every number quoted in DESIGN.md section 5 is a field of the JSON line this prints (or of profiles/).
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,26 +30,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_SAMPLE = 84e6       # point traffic of one full-length sample (all iterations)
+RASTER_BYTES_1216 = 2.2e6          # edges * 56 B + 1216 * 1216 B per label image
+RASTER_BYTES_304 = 0.82e6
+UNET_TFLOP_PER_IMAGE = 2.0         # forward 0.666 TFLOP x 3
+UNET_MIN_HBM_GB_PER_IMAGE = 6.0    # activations written once / read once, norm + activation fused
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16
+N_CUS = 256
+PMC_SUMMARY = os.path.join("profiles", "r02_bench_pmc_summary.csv")
 
 
 def pmc_traffic_per_launch(kernel_name):
-    """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 counter passes
-    (profiles/r01_bench_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this
-    bench, values in KB). Correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 128-B requests as 64 B on
-    gfx950, so it is doubled; WRITE_SIZE is taken as reported. None if the file or the kernel is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.csv")
-    if not os.path.exists(path):
-        return None
-    import csv
-    kb = {}
-    with open(path) as f:
-        for r in csv.DictReader(f):
-            if kernel_name in r["kernel"]:
-                kb[r["counter"]] = float(r["avg_KB_per_launch"])
-    if "FETCH_SIZE" not in kb or "WRITE_SIZE" not in kb:
-        return None
-    return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+    """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 counter passes (PMC_SUMMARY: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc passes of this bench by tools/profile_bench.sh, values in KB). Correction per
+    MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 128-B requests as 64 B on gfx950, so it is doubled; WRITE_SIZE is taken as
+    reported. None if the file or the kernel is missing."""
+    for cand in (PMC_SUMMARY, os.path.join("profiles", "r01_bench_pmc_summary.csv")):
+        path = os.path.join(ROOT, cand)
+        if not os.path.exists(path):
+            continue
+        import csv
+        kb = {}
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if kernel_name in r["kernel"]:
+                    kb[r["counter"]] = float(r["avg_KB_per_launch"])
+        if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
+            return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, cand
+    return None, None
 
 
 def load_config():
@@ -53,23 +65,55 @@ def load_config():
     return configs.load_generator_config()
 
 
-def cpu_baseline(cfg, budget_s=30.0):
-    """The oracle (CPU restatement of the reference) on host cores: full-length samples, one core."""
+def _oracle_sample(args):
+    cfg, seed = args
     from oracle import octa_oracle, sim_oracle
     from octa_autosegmentation_amd import graph_io
+    e, info = sim_oracle.simulate(cfg, seed)
+    na = info["n_art_edges"]
+    np.maximum(octa_oracle.rasterize(e[:na], [304, 304]), octa_oracle.rasterize(e[na:], [304, 304]))
+    octa_oracle.fs_dither(octa_oracle.rasterize(graph_io.edges_as_read_back(e), [1216, 1216]))
+    return len(e)
+
+
+def cpu_baseline(cfg):
+    """The oracle (CPU restatement of the reference, oracle/) on the GPU box's host cores: ONE full-length sample per core on
+    all cores at once (the reference's own parallelism: one sample per pool worker, generate_vessel_graph.py:112-129), and the
+    single-core figure. Bounded: one wave of samples (about 5-10 s) + one more sample."""
+    from multiprocessing import get_context
+    cores = os.cpu_count() or 1
+    workers = min(cores, 64)
     t0 = time.time()
-    n = 0
-    while True:
-        e, info = sim_oracle.simulate(cfg, 900 + n)
-        na = info["n_art_edges"]
-        np.maximum(octa_oracle.rasterize(e[:na], [304, 304]), octa_oracle.rasterize(e[na:], [304, 304]))
-        octa_oracle.fs_dither(octa_oracle.rasterize(graph_io.edges_as_read_back(e), [1216, 1216]))
-        n += 1
-        if time.time() - t0 > budget_s * 0.6 or n >= 3:
-            break
+    _oracle_sample((cfg, 900))
+    single = 1.0 / (time.time() - t0)
+    t0 = time.time()
+    with get_context("spawn").Pool(workers) as pool:
+        pool.map(_oracle_sample, [(cfg, 901 + k) for k in range(workers)])
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"{n} full-length samples (I=100+150, N=2000) incl. 304x304 image + 1216x1216 label, oracle/ C++ on one core"}
+    return {"value": workers / dt, "unit": "samples/s", "cores": workers, "kind": "port", "host_cores_visible": cores,
+            "single_core_value": single,
+            "sample": f"{workers} full-length samples (I=100+150, N=2000) incl. 304x304 image + 1216x1216 label, one per core on {workers} cores "
+                      f"at once (pool start-up included), oracle/ C++; single core: one sample"}
+
+
+def cpu_unet_step():
+    """plain torch DynUNet-S fp32 training step on the host CPU, B = 1 at 1x1216x1216."""
+    import torch
+    from octa_autosegmentation_amd.models import networks
+    torch.manual_seed(0)
+    net = networks.DynUNet()
+    networks.init_weights(net, "kaiming")
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    x, y = torch.rand(1, 1, 1216, 1216), (torch.rand(1, 1, 1216, 1216) > 0.8).float()
+    from octa_autosegmentation_amd.models.losses import DiceBCELoss
+    loss_f = DiceBCELoss(True)
+    t0 = time.time()
+    opt.zero_grad()
+    loss_f(net(x), y).backward()
+    opt.step()
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "plain torch fp32 on the CPU device",
+            "sample": "one DynUNet-S training step, B=1, 1x1216x1216 (no warm-up: includes first-call overheads)"}
 
 
 def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4):
@@ -98,13 +142,54 @@ def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ips = world * batch * steps / dt
+    per_gpu = ips / world
     return {"metric": "DynUNet-S training imgs/s @1x1216x1216", "value": ips, "unit": "imgs/s", "dtype": "bf16",
-            "batch_per_gpu": batch, "ms_per_step": dt / steps * 1e3, "tflops": 2.0 * ips,
-            "frac_of_bf16_dense_peak": 2.0 * ips / 2500.0,
+            "batch_per_gpu": batch, "ms_per_step": dt / steps * 1e3, "tflops": UNET_TFLOP_PER_IMAGE * ips,
+            "roofline": {"mfma": {"achieved": UNET_TFLOP_PER_IMAGE * per_gpu, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": UNET_TFLOP_PER_IMAGE * per_gpu / MFMA_BF16_PEAK_TFLOPS},
+                         "hbm": {"achieved": UNET_MIN_HBM_GB_PER_IMAGE * per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": UNET_MIN_HBM_GB_PER_IMAGE * per_gpu / HBM_PEAK_GBS,
+                                 "note": "algorithmic minimum traffic (6 GB per training image with norm + activation fused), not measured traffic"},
+                         "binding": "mfma"},
+            "parity": "bf16 activations: logits / gradients within bf16's error budget of an fp32 run on the same bf16-rounded weights "
+                      "(tests/test_fullsize_gpu.py); north_star's 1e-4 holds for the fp32 path (tests/test_models_gpu.py); DynUNet / DiceLoss are "
+                      "restated from MONAI's documentation (MONAI absent: parity with MONAI itself unpinned)",
             "implementation": "channels-last bf16 on hand-written HIP kernels: MFMA 3x3 conv forward / data gradient / weight "
                               "gradient (csrc/conv.hip; skip-connection gradients in the data-gradient epilogue), NHWC InstanceNorm+LeakyReLU "
                               "(csrc/norm.hip; the last one fused with the 1x1 output convolution), one-launch weight packing; hipBLASLt "
                               "only for the 1x1 transposed convolution at the bottleneck; flat RCCL gradient all-reduce"}
+
+
+def files_leg(gen, stream, seeds, threads=None):
+    """One batch through generate -> native CSV / PNG writers: the reference's per-sample files (generate_vessel_graph.py:43-86 +
+    visualize_vessel_graphs.py:95-101) on disk. Returns on-disk triples per second, generation included."""
+    import torch
+    from octa_autosegmentation_amd.output_files import SampleFileWriter, default_threads
+    out_root = tempfile.mkdtemp(prefix="octa_bench_files_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    writer = SampleFileWriter(threads)
+    try:
+        torch.cuda.synchronize()
+        t0 = time.time()
+        with torch.cuda.stream(stream):
+            out = gen.generate(seeds)
+            images = out["image"].cpu().numpy()
+            labels = out["label"].cpu().numpy()
+        t_gen = time.time() - t0
+        res = out["result"]
+        for k in range(len(seeds)):
+            name = f"sample_{int(seeds[k])}"
+            writer.submit(os.path.join(out_root, name), name, edges=res.sample_edges(k), image=images[k], label_bits=labels[k])
+        writer.wait()
+        dt = time.time() - t0
+        nbytes = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(out_root) for f in fs)
+        return {"metric": "complete on-disk triples/s (graph CSV + 304x304 image PNG + 1216x1216 label PNG per sample)", "value": len(seeds) / dt,
+                "unit": "samples/s", "samples": len(seeds), "seconds": dt, "generate_seconds": t_gen, "write_seconds": dt - t_gen,
+                "writer_threads": threads or default_threads(), "bytes_written": nbytes, "where": out_root.rsplit("/", 1)[0],
+                "note": "one batch, nothing overlapped: simulate + rasterise on the GPU, then native CSV formatting (byte-identical to numpy's "
+                        "str(ndarray) / repr(float), tests/test_fileio.py) and PNG encoding on host threads"}
+    finally:
+        writer.close()
+        shutil.rmtree(out_root, ignore_errors=True)
 
 
 def main():
@@ -118,6 +203,7 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the secondary U-Net training measurement")
     ap.add_argument("--train-batch", type=int, default=4)
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the on-the-fly generation + training measurement")
+    ap.add_argument("--no-files", action="store_true", help="skip the on-disk triples leg")
     args = ap.parse_args()
 
     import torch
@@ -181,19 +267,51 @@ def main():
     ka = kb = 0.0
     la = lb = 0
     bif_ms = 0.0
+    relaunches = 0
+    per_sample_ticks = []
     for out in outs:
-        tm = out["result"].timing
+        r = out["result"]
+        tm = r.timing
         ka += tm["kernel_a_ms"]; kb += tm["kernel_b_ms"]; la += tm["launches_a"]; lb += tm["launches_b"]
         bif_ms += tm["host_bif_ms"]
-        assert int(out["result"].stats[:, 0].max()) == 0, "simulator reported error bits"
-    out = outs[-1]
+        relaunches += r.service["relaunches"]
+        assert int(r.stats[:, 0].max()) == 0, "simulator reported error bits"
+        per_sample_ticks.append(r.stats[:, 8:24].sum(axis=1))
+    # device milliseconds one sample spends in its phases (100 MHz timers of thread 0; mailbox waits included)
+    sample_ms = float(np.concatenate(per_sample_ticks).mean()) * 1e-5
+
+    # ---- rasteriser alone (other slots idle): HIP events on the stream the kernels go to
+    raster = None
+    if rank == 0:
+        gens[0].time_render = True
+        best = None
+        for rep in range(3):
+            with torch.cuda.stream(streams[0]):
+                o = gens[0].generate(sharding.rank_seeds(rank, 900 + rep, B))
+                streams[0].synchronize()
+            ms = pipeline.TripleGenerator.render_ms(o)
+            best = ms if best is None else {k: min(best[k], ms[k]) for k in ms}
+        gens[0].time_render = False
+        lab, img = best["label_raster_ms"], best["image_raster_ms"]
+        raster = {"kernel": "octa_rasterize_2d launch sequence (raster_meta / scan / tess / render)", "bound": "hbm",
+                  "label_1216": {"ms_per_batch": lab, "achieved": RASTER_BYTES_1216 * B / (lab * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": RASTER_BYTES_1216 * B / (lab * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                  "image_304_x2": {"ms_per_batch": img, "achieved": RASTER_BYTES_304 * 2 * B / (img * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": RASTER_BYTES_304 * 2 * B / (img * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                  "read_back_ms": best["read_back_ms"], "dither_ms": best["dither_ms"],
+                  "note": "HBM-bound on paper (2.2 MB per label), ALU-bound in the per-pixel coverage fold in practice (DESIGN.md 4.2)"}
+
+    files_info = None
+    if rank == 0 and not args.no_files:
+        files_info = files_leg(gens[0], streams[0], sharding.rank_seeds(rank, 950, B))
+
     # secondary metric of BASELINE.json: DynUNet-S training images/s at 1x1216x1216, bf16, on the MFMA convolution
     # path; reported so the gap to the 200 imgs/s target is tracked, it is NOT part of `value`.
     train_info = None
+    for g_ in gens:
+        g_.close()
+    gens = []
     if not args.no_train:
-        for g_ in gens:
-            g_.close()
-        gens = []
         torch.cuda.empty_cache()
         train_info = unet_train_bench(dev, args.train_batch, dist, world)
     # BASELINE.json configs[4]: on-the-fly simulation + rasterisation + GPU augmentation feeding the same training step
@@ -210,19 +328,23 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / dt
+        per_gpu = value / world
         # dominant kernel: the persistent simulator kernel (one launch per batch runs all iterations of every
         # sample; OCTA_SIM_LOCKSTEP=1 selects the two-launches-per-iteration form, then launch A or B)
         if la == 0:
             dom_ms, dom_n, dom_name = kb, lb, "sim_persistent_kernel"
             bytes_per_launch = ALGO_BYTES_PER_SAMPLE * B
             note = ("one launch = 250 dependent growth iterations of 128 independent samples, one workgroup each; "
-                    "dependency/latency-bound (ordered passes, pow chains), not HBM-bound; see DESIGN.md")
+                    "dependency/latency-bound (ordered passes, pow chains), not HBM-bound: see serial_depth")
         else:
             dom_ms, dom_n, dom_name = (kb, lb, "sim_iter_b_kernel") if kb >= ka else (ka, la, "sim_iter_a_kernel")
             n_iter = max(lb // max(args.steps, 1), 1)
             bytes_per_launch = ALGO_BYTES_PER_SAMPLE / (2.0 * n_iter) * B
-            note = "lock-step form: 250 dependent iterations x 2 launches; latency-bound, see DESIGN.md"
-        achieved = bytes_per_launch / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9
+            note = "lock-step form: 250 dependent iterations x 2 launches; latency-bound, see serial_depth"
+        launch_ms = dom_ms / max(dom_n, 1)
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic_per_launch(dom_name)
+        bound_samples_s = N_CUS / (sample_ms * 1e-3)
         line = {
             "metric": "synthetic OCTA samples/sec (graph + 304x304 image + 1216x1216 label triples)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -231,23 +353,34 @@ def main():
             "config": {"workload": f"configs[1]: {B}-sample vessel-graph batch (docker/vessel_graph_gen_docker_config.yml, "
                                    f"I=100+150, N=2000) + tree2img rasterise 304x304 image and 1216x1216 label",
                        "batch_per_gpu": B, "steps_in_flight": n_fly, "parallelism": f"sample-sharded x{world}, no collective"},
+            "parity": "graph CSV text and label / image pixels bit-exact with the reference (radii: identical doubles; node positions: identical "
+                      "as printed with 8 decimals, the doubles may differ from the oracle's in the last bits: numpy's AVX-512 arccos vs glibc's)",
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(dom_name),
-                         "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_bench_pmc_summary.csv)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, {traffic_src})",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
-                         "note": note},
-            "kernel_ms_per_step": {"sim_iter_a": ka / args.steps, dom_name if la == 0 else "sim_iter_b": kb / args.steps,
-                                   "host_bifurcation_callback": bif_ms / args.steps},
+                         "avg_launch_ms": launch_ms, "launches": dom_n, "note": note,
+                         "serial_depth": {"per_sample_device_ms": sample_ms, "cus": N_CUS, "one_workgroup_per_cu": True,
+                                          "bound_samples_per_s": bound_samples_s, "frac_of_bound": per_gpu / bound_samples_s,
+                                          "note": "a sample occupies one CU (160 KiB of LDS) for per_sample_device_ms: CUs / that time is what the "
+                                                  "simulator could reach with the GPU to itself; this, not HBM, is the binding limit"},
+                         "rasteriser": raster},
+            "kernel_ms_per_launch": {dom_name: launch_ms, "launches_per_step": dom_n / max(args.steps, 1),
+                                     "cu_occupancy_weighted_ms_per_step": launch_ms * (dom_n / max(args.steps, 1)) * min(B, N_CUS) / N_CUS,
+                                     "note": f"{n_fly} launches of {B} workgroups overlap on {N_CUS} CUs, so a launch outlasts ms_per_step; the weighted "
+                                             "figure is the launch duration times the share of the CUs it holds"},
+            "host_bifurcation_callback_ms_per_step": bif_ms / args.steps,
+            "mailbox_relaunches": relaunches,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
+            if not args.no_train:
+                line["cpu_baseline"]["unet_train_step"] = cpu_unet_step()
+        line["files"] = files_info
         line["unet_train"] = train_info
         line["end_to_end_train"] = e2e_info
         line["end_to_end_gan_seg_train"] = e2e_gan_info
         print(json.dumps(line))
-    for g_ in gens:
-        g_.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -291,6 +291,17 @@ int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, i
  *   RandRotated (d_angle[b] radians, bilinear, zeros padding, affine_grid + grid_sample arithmetic with align_corners
  *   False) -> optional AsDiscreted (v >= threshold ? 1 : 0) on square float32 images [B][N][N]; out must not alias in.
  */
+/* Noise model of the GAN configs, on batches in HBM (reference data/data_transforms.py):
+ * octa_background_noise: AddRandomBackgroundNoised (:498-516): max(img, noise * u) over n float32 pixels, u = the float64 factors of
+ *   numpy's uniform stream; the product is formed in float64 like the reference's promoted tensor; d_out_f64 / d_out_f32 (either may be
+ *   NULL) receive the float64 result and its float32 cast.
+ * octa_speckle_brightness: SpeckleBrightnesd (:25-42): per image a 9x9 control grid (d_grid9 [B][81], values in [0.5, 1)) is bilinearly
+ *   upsampled (torch arithmetic, align_corners False), R = C - u (1 - C) with d_u [B][H][W], out = img * R, divided by its maximum, then
+ *   shifted by its minimum. d_minmax: int32 [B][2] scratch. */
+int octa_background_noise(octa_ctx *ctx, const float *d_img, const float *d_noise, const double *d_u, int64_t n, double *d_out_f64,
+                          float *d_out_f32, void *stream);
+int octa_speckle_brightness(octa_ctx *ctx, const float *d_img, const float *d_grid9, const float *d_u, int B, int H, int W, float *d_out,
+                            int *d_minmax, void *stream);
 int octa_resize_bilinear(octa_ctx *ctx, const void *d_in, int in_dtype, int B, int h, int w, float *d_out, int H, int W,
                          const float *d_mul, const float *d_add, void *stream);
 int octa_flip_rot90_rotate(octa_ctx *ctx, const float *d_in, float *d_out, int B, int N, const float *d_angle, const int *d_rot_k,

@@ -84,7 +84,101 @@ rotate_kernel(const float *__restrict__ in, float *__restrict__ out, int N, cons
     out[((size_t)b * N + Y) * N + X] = v;
 }
 
+// ---- noise model of the GAN configs (reference data/data_transforms.py:25-42 SpeckleBrightnesd, :498-516 AddRandomBackgroundNoised) ----
+// Both are streaming, HBM-bound maps over [B][H][W] float32 images; the random numbers are the reference's own streams (numpy's
+// global uniform stream for the background factor, torch's CPU generator for the speckle grid), drawn on the host and passed in.
+
+// out = max(img, noise * u): the product is formed in float64 as torch's type promotion does in the reference (float32 tensor
+// times float64 numpy array), then compared with the float32 image; out_f64 receives the reference's float64 result, out_f32 its
+// CastToTyped(float32) -- either may be NULL.
+__global__ void __launch_bounds__(256)
+background_noise_kernel(const float *__restrict__ img, const float *__restrict__ noise, const double *__restrict__ u, long n, double *__restrict__ out_f64,
+                        float *__restrict__ out_f32) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double a = (double)img[i], b = (double)noise[i] * u[i];
+    const double m = (a >= b || a != a) ? a : b;                 // torch.maximum propagates NaN of either operand; b is finite here
+    if (out_f64) out_f64[i] = m;
+    if (out_f32) out_f32[i] = (float)m;
+}
+
+// torch's upsample_bilinear2d of the 9x9 control grid c (align_corners = False) at pixel (Y, X) of an H x W image
+__device__ __forceinline__ float speckle_grid(const float *c, int H, int W, int Y, int X) {
+    const float rh = 9.f / (float)H, rw = 9.f / (float)W;
+    const float h1r = src_index(rh, Y), w1r = src_index(rw, X);
+    const int h1 = (int)h1r, w1 = (int)w1r;
+    const int h1p = h1 < 8 ? 1 : 0, w1p = w1 < 8 ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l, w1l = w1r - (float)w1, w0l = 1.f - w1l;
+    const float *p = c + h1 * 9 + w1;
+    return h0l * (w0l * p[0] + w1l * p[w1p]) + h1l * (w0l * p[h1p * 9] + w1l * p[h1p * 9 + w1p]);
+}
+
+// pass 1: v = img * (C - u (1 - C)); per-image max and min of v through order-preserving integer atomics
+__device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void __launch_bounds__(256)
+speckle_pass1_kernel(const float *__restrict__ img, const float *__restrict__ grid9, const float *__restrict__ u, int H, int W, float *__restrict__ v_out,
+                     int *__restrict__ minmax) {
+    const int b = blockIdx.z, Y = blockIdx.y, X = blockIdx.x * 256 + threadIdx.x;
+    __shared__ int smx, smn;
+    if (threadIdx.x == 0) { smx = f2ord(-INFINITY); smn = f2ord(INFINITY); }
+    __syncthreads();
+    if (X < W) {
+        const size_t i = ((size_t)b * H + Y) * W + X;
+        const float C = speckle_grid(grid9 + (size_t)b * 81, H, W, Y, X);
+        const float R = C - u[i] * (1.f - C);
+        const float v = img[i] * R;
+        v_out[i] = v;
+        atomicMax(&smx, f2ord(v));
+        atomicMin(&smn, f2ord(v));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicMax(minmax + 2 * b, smx); atomicMin(minmax + 2 * b + 1, smn); }
+}
+
+// pass 2: img /= img.max(); img -= img.min()   (min of the quotients = quotient of the min: division by a positive constant is monotone)
+__global__ void __launch_bounds__(256)
+speckle_pass2_kernel(float *__restrict__ v, long per_image, const int *__restrict__ minmax) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_image) return;
+    const float mx = ord2f(minmax[2 * b]), mn = ord2f(minmax[2 * b + 1]);
+    float *p = v + (size_t)b * per_image + i;
+    *p = *p / mx - mn / mx;
+}
+
+__global__ void speckle_init_kernel(int *minmax, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < B) { minmax[2 * b] = f2ord(-INFINITY); minmax[2 * b + 1] = f2ord(INFINITY); }
+}
+
 }  // namespace
+
+extern "C" int octa_background_noise(octa_ctx *ctx, const float *d_img, const float *d_noise, const double *d_u, int64_t n, double *d_out_f64,
+                                     float *d_out_f32, void *stream_) {
+    if (!ctx || !d_img || !d_noise || !d_u || n <= 0 || (!d_out_f64 && !d_out_f32)) { octa::set_error("octa_background_noise: bad arguments"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(background_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_img, d_noise, d_u, (long)n, d_out_f64, d_out_f32);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_speckle_brightness(octa_ctx *ctx, const float *d_img, const float *d_grid9, const float *d_u, int B, int H, int W, float *d_out,
+                                       int *d_minmax, void *stream_) {
+    if (!ctx || !d_img || !d_grid9 || !d_u || !d_out || !d_minmax || B <= 0 || H <= 0 || W <= 0 || B > 65535 || H > 65535) {
+        octa::set_error("octa_speckle_brightness: bad arguments"); return -2;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(speckle_init_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, d_minmax, B);
+    hipLaunchKernelGGL(speckle_pass1_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0, stream, d_img, d_grid9, d_u, H, W, d_out, d_minmax);
+    const long per = (long)H * W;
+    hipLaunchKernelGGL(speckle_pass2_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream, d_out, per, d_minmax);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 extern "C" int octa_resize_bilinear(octa_ctx *ctx, const void *d_in, int in_dtype, int B, int h, int w, float *d_out, int H, int W,
                                     const float *d_mul, const float *d_add, void *stream_) {

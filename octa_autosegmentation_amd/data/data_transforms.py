@@ -154,6 +154,11 @@ class SpeckleBrightnesd(MapTransform):
         for key in self.present(data):
             img = data[key]
             c = torch.rand((1, 1, 9, 9)) * 0.5 + 0.5
+            if img.is_cuda and img.dim() == 3 and img.shape[0] == 1:
+                from .gpu_augment import speckle_brightness             # csrc/augment.hip: two streaming passes, same draws
+                u = torch.rand((1,) + tuple(img.shape[-2:]))
+                data[key] = speckle_brightness(img.float(), c.reshape(1, 9, 9).to(img.device), u.to(img.device)).to(img.dtype)
+                continue
             C = torch.nn.functional.interpolate(c, size=img.shape[-2:], mode="bilinear").squeeze(0)
             R = C - (torch.rand_like(C) * (1 - C))
             img = img * R.to(img.device)
@@ -178,7 +183,11 @@ class AddRandomBackgroundNoised(MapTransform):
                 img = data[key]
                 noise = data["background"].to(img.device) if "background" in data else torch.rand(img.shape).to(img.device)
                 speckle = torch.from_numpy(np.random.uniform(0, 1, tuple(img.shape))).to(img.device)
-                data[key] = torch.maximum(img, noise * speckle)          # float64 product, as torch promotes in the reference
+                if img.is_cuda and img.dtype == torch.float32 and noise.dtype == torch.float32 and noise.shape == img.shape:
+                    from .gpu_augment import background_noise           # csrc/augment.hip
+                    data[key] = background_noise(img, noise, speckle)
+                else:
+                    data[key] = torch.maximum(img, noise * speckle)      # float64 product, as torch promotes in the reference
         if self.delete_background and "background" in data:
             del data["background"]
         return data

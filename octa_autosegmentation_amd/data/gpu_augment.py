@@ -46,6 +46,30 @@ def flip_rot90_rotate(x, angle, rot_k=None, flip=None, threshold=None):
     return out
 
 
+def background_noise(img, noise, u, out_dtype=torch.float64):
+    """AddRandomBackgroundNoised on device tensors of equal shape: img / noise float32, u float64 (numpy's uniform factors).
+    Returns max(img, noise * u) as float64 (the reference's promoted dtype) or float32."""
+    assert img.is_cuda and img.shape == noise.shape == u.shape and u.dtype == torch.float64
+    img, noise, u = img.contiguous().float(), noise.contiguous().float(), u.contiguous()
+    out = torch.empty(img.shape, dtype=out_dtype, device=img.device)
+    o64, o32 = (_p(out), None) if out_dtype == torch.float64 else (None, _p(out))
+    rc = _native.lib().octa_background_noise(_native.ctx(img.device.index), _p(img), _p(noise), _p(u), img.numel(), o64, o32, _native.current_stream_ptr())
+    _native.check(rc, "octa_background_noise")
+    return out
+
+
+def speckle_brightness(img, grid9, u):
+    """SpeckleBrightnesd on a device batch: img float32 [B,H,W], grid9 float32 [B,9,9] (control values in [0.5, 1)), u float32 [B,H,W]."""
+    assert img.is_cuda and img.dim() == 3 and grid9.shape == (img.shape[0], 9, 9) and u.shape == img.shape
+    img, grid9, u = img.contiguous().float(), grid9.contiguous().float(), u.contiguous().float()
+    out = torch.empty_like(img)
+    mm = torch.empty((img.shape[0], 2), dtype=torch.int32, device=img.device)
+    rc = _native.lib().octa_speckle_brightness(_native.ctx(img.device.index), _p(img), _p(grid9), _p(u), img.shape[0], img.shape[1], img.shape[2],
+                                               _p(out), _p(mm), _native.current_stream_ptr())
+    _native.check(rc, "octa_speckle_brightness")
+    return out
+
+
 class GpuSegAugmentation:
     """Batched replacement of the `data_augmentation` list of a segmentation config (the entries after the graph loader)."""
 

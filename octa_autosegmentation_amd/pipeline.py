@@ -32,6 +32,7 @@ class TripleGenerator:
         self.label_res = list(label_resolution)
         # the training configs render the label with min_radius[1] = 0.0033 (configs/config_ves_seg-S.yml:38)
         self.label_min_radius = float(label_min_radius)
+        self.time_render = False
 
     def close(self):
         self.sim.close()
@@ -50,7 +51,10 @@ class TripleGenerator:
         import torch
         B = self.batch
         off, n_art = res.edge_off, res.n_art
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.time_render else None
+        mark = (lambda i: ev[i].record()) if ev else (lambda i: None)       # on the current stream = the stream the kernels go to
         d_edges = torch.from_numpy(res.edges).to(self.device, non_blocking=True)
+        mark(0)
         # 2B graphs: arterial_k, venous_k interleaved -> max of the pairs (np.maximum(art_mat, ven_mat))
         split = np.empty(2 * B + 1, np.int64)
         split[0::2] = off
@@ -58,10 +62,27 @@ class TripleGenerator:
         pair = tree2img.rasterize_edges_device(d_edges, split, self.image_res, self.proj_axis)
         pair = pair.view(B, 2, pair.shape[1], pair.shape[2])
         image = tree2img.maximum_u8_device(pair[:, 0].contiguous(), pair[:, 1].contiguous())
+        mark(1)
         out = dict(result=res, image=image)
         if want_label:
             d_rb = graph_io.edges_as_read_back_device(d_edges)
+            mark(2)
             grey = tree2img.rasterize_edges_device(d_rb, off, self.label_res, 2, min_radius=self.label_min_radius)
+            mark(3)
             out["label_grey"] = grey
             out["label"] = tree2img.binarize_label_device(grey)
+            mark(4)
+        if ev:
+            # read with render_ms() after the stream has been synchronised
+            out["render_events"] = ev if want_label else ev[:2]
         return out
+
+    @staticmethod
+    def render_ms(out):
+        """GPU milliseconds of the render stages of a finished generate() (time_render=True): image rasterisation (2B graphs at
+        the image resolution + max), CSV read-back emulation, label rasterisation, dither."""
+        ev = out.get("render_events")
+        if not ev:
+            return None
+        names = ["image_raster_ms", "read_back_ms", "label_raster_ms", "dither_ms"]
+        return {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names) if i + 1 < len(ev)}

@@ -77,3 +77,38 @@ def test_augmentation_chain_from_config(hip_lib_built):
     # same seed -> same decisions
     again = gpu_augment.GpuSegAugmentation(cfg, seed=3)(img, lab)
     assert torch.equal(again["image"], out["image"]) and torch.equal(again["label"], out["label"])
+
+
+def test_noise_kernels_match_the_reference_fixture(hip_lib_built):
+    """a17 on the device: the HIP kernels behind SpeckleBrightnesd / AddRandomBackgroundNoised (csrc/augment.hip) against the outputs of
+    the reference's own classes (tests/golden/noise_golden.npz, tools/make_golden_noise.py) with the same generator seeds. The
+    background blend is exact (one float64 product, one comparison); the speckle map differs from torch's CPU arithmetic by fused
+    multiply-adds only (1e-6 of values in [0, 1])."""
+    import os
+    import torch
+    from octa_autosegmentation_amd.data import data_transforms as T
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "noise_golden.npz"))
+    for k in range(2):
+        img = torch.from_numpy(g[f"speckle_{k}_in"]).cuda()
+        torch.manual_seed(100 + k)
+        out = T.SpeckleBrightnesd(["image"])({"image": img.clone()})["image"]
+        assert out.is_cuda and out.dtype == torch.float32
+        assert (out.cpu() - torch.from_numpy(g[f"speckle_{k}_out"])).abs().max().item() <= 1e-6
+        np.random.seed(200 + k)
+        d = T.AddRandomBackgroundNoised(["image"])({"image": img.clone(), "background": torch.from_numpy(g[f"bg_{k}_noise"]).cuda()})
+        assert d["image"].is_cuda and d["image"].dtype == torch.float64 and torch.equal(d["image"].cpu(), torch.from_numpy(g[f"bg_{k}_out"]))
+    # batched entry points
+    from octa_autosegmentation_amd.data import gpu_augment
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(3, 64, 80, device="cuda", generator=gen)
+    c9 = torch.rand(3, 9, 9, device="cuda", generator=gen) * 0.5 + 0.5
+    u = torch.rand(3, 64, 80, device="cuda", generator=gen)
+    got = gpu_augment.speckle_brightness(x, c9, u)
+    C = torch.nn.functional.interpolate(c9[:, None], size=(64, 80), mode="bilinear")[:, 0]
+    v = x * (C - u * (1 - C))
+    want = v / v.amax(dim=(1, 2), keepdim=True)
+    want = want - want.amin(dim=(1, 2), keepdim=True)
+    assert (got - want).abs().max().item() <= 2e-6
+    u64 = torch.rand(3, 64, 80, device="cuda", generator=gen, dtype=torch.float64)
+    assert torch.equal(gpu_augment.background_noise(x, u, u64), torch.maximum(x.double(), u.double() * u64))
+    assert torch.equal(gpu_augment.background_noise(x, u, u64, torch.float32), torch.maximum(x.double(), u.double() * u64).float())

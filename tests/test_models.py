@@ -113,28 +113,29 @@ def test_gan_seg_training_step_runs_on_cpu():
     assert out["prediction"].shape == (1, 1, 64, 64)
 
 
-def test_noise_transforms_follow_reference_formulas():
-    import numpy as np
+def test_noise_transforms_match_the_reference_fixture():
+    """a17: SpeckleBrightnesd and AddRandomBackgroundNoised against tests/golden/noise_golden.npz -- outputs of the reference's own
+    classes (tools/make_golden_noise.py) -- with the same generator seeds: CPU tensors, bit for bit (same torch / numpy draws, same
+    arithmetic, the float64 promotion of the background product included)."""
     from octa_autosegmentation_amd.data import data_transforms as T
-    img = torch.rand(1, 40, 40)
-    torch.manual_seed(3)
-    out = T.SpeckleBrightnesd(["image"])({"image": img})["image"]
-    torch.manual_seed(3)
-    c = torch.rand((1, 1, 9, 9)) * 0.5 + 0.5
-    C = torch.nn.functional.interpolate(c, size=(40, 40), mode="bilinear").squeeze(0)
-    R = C - (torch.rand_like(C) * (1 - C))
-    want = img * R; want = want / want.max(); want = want - want.min()
-    assert torch.equal(out, want)
-    bg = torch.rand(1, 40, 40)
-    np.random.seed(5)
-    o2 = T.AddRandomBackgroundNoised(["image"])({"image": img, "background": bg})
-    np.random.seed(5)
-    assert "background" not in o2
-    assert torch.allclose(o2["image"], torch.maximum(img, bg * torch.from_numpy(np.random.uniform(0, 1, (1, 40, 40))).float()))
-    g = networks.resnetGenerator9()
-    o3 = T.ImageToImageTranslationd(keys=["image"], model=g, device="cpu")({"image": img})["image"]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "noise_golden.npz"))
+    for k in range(2):
+        img = torch.from_numpy(g[f"speckle_{k}_in"])
+        torch.manual_seed(100 + k)
+        out = T.SpeckleBrightnesd(["image"])({"image": img.clone()})["image"]
+        assert out.dtype == torch.float32 and torch.equal(out, torch.from_numpy(g[f"speckle_{k}_out"]))
+        np.random.seed(200 + k)
+        d = T.AddRandomBackgroundNoised(["image"])({"image": img.clone(), "background": torch.from_numpy(g[f"bg_{k}_noise"])})
+        assert "background" not in d and d["image"].dtype == torch.float64 and torch.equal(d["image"], torch.from_numpy(g[f"bg_{k}_out"]))
+        np.random.seed(300 + k); torch.manual_seed(300 + k)
+        d = T.AddRandomBackgroundNoised(["image"])({"image": img.clone()})
+        assert torch.equal(d["image"], torch.from_numpy(g[f"bg_{k}_out_nobg"]))
+    keep = T.AddRandomBackgroundNoised(["image"], delete_background=False)({"image": img.clone(), "background": img.clone()})
+    assert "background" in keep
+    gnet = networks.resnetGenerator9()
+    o3 = T.ImageToImageTranslationd(keys=["image"], model=gnet, device="cpu")({"image": img})["image"]
     with torch.no_grad():
-        assert torch.equal(o3, g.eval()(img.unsqueeze(0)).squeeze(0))
+        assert torch.equal(o3, gnet.eval()(img.unsqueeze(0)).squeeze(0))
 
 
 def test_convt_as_gemm_matches_conv_transpose():
