@@ -375,6 +375,12 @@ typedef struct {
     int n_modes;
     /* per mode: I, N, eps_n, eps_s, eps_k, delta_art, delta_ven, gamma_art, gamma_ven, phi, omega, kappa, delta_sigma */
     double modes[8][13];
+    /* Forest.type: 0 = 'stumps' (roots on the lateral walls, forest.py:68-181), 1 = 'nerve' (all roots inside the optic-nerve disc,
+     * forest.py:38-66); Greenhouse nerve_center / nerve_radius as in the YAML (divided by param_scale inside). The disc is also cut
+     * out of the sink-sampling mask when it lies inside the field of view (simulation_space.py:48-50). */
+    int forest_type;
+    double nerve_center[2];
+    double nerve_radius;
 } octa_sim_config;
 
 #define OCTA_BIF_MAX_ATTS 256

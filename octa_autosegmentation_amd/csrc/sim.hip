@@ -494,12 +494,14 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     cfg.sx = c->size[0]; cfg.sy = c->size[1]; cfg.sz = c->size[2]; cfg.n_trees = c->n_trees;
     int nw = 0;
     for (int w = 0; w < 4; w++) { cfg.walls[w] = c->walls[w]; nw += c->walls[w] ? 1 : 0; }
+    cfg.forest_type = c->forest_type; cfg.nc0 = c->nerve_center[0]; cfg.nc1 = c->nerve_center[1]; cfg.nr = c->nerve_radius;
+    if (cfg.forest_type != 0 && cfg.forest_type != 1) { octa::set_error("octa_sim_create: forest_type must be 0 (stumps) or 1 (nerve)"); delete S; return -2; }
     for (int m = 0; m < c->n_modes; m++) {
         const double *q = c->modes[m];
         cfg.modes.push_back(ModeCfg{(int)q[0], (int)q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11], q[12]});
         if ((int)q[1] > NCANDCAP || (int)q[1] < 0) { octa::set_error("octa_sim_create: N=%d exceeds %d", (int)q[1], NCANDCAP); delete S; return -2; }
     }
-    if (nw == 0 || cfg.n_trees < 1 || 2 * cfg.n_trees > NCAP) { octa::set_error("octa_sim_create: bad forest config"); delete S; return -2; }
+    if ((nw == 0 && cfg.forest_type == 0) || cfg.n_trees < 1 || 2 * cfg.n_trees > NCAP) { octa::set_error("octa_sim_create: bad forest config"); delete S; return -2; }
     if (std::ceil(cfg.sx * 76) > 76 || std::ceil(cfg.sy * 76) > 76) { octa::set_error("octa_sim_create: simulation space larger than the unit square"); delete S; return -2; }
     S->iters = build_iter_table(cfg, &S->C);
     BatchPtrs &P = S->P;

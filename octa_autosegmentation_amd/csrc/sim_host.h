@@ -132,6 +132,8 @@ struct SimConfig {
     int n_trees;
     int walls[4];
     std::vector<ModeCfg> modes;
+    int forest_type = 0;               // 0 stumps, 1 nerve
+    double nc0 = 1e30, nc1 = 1e30, nr = 0;   // nerve_center / nerve_radius as configured (before the division by param_scale)
 };
 
 // values live DURING each iteration (the reference loads a mode's raw values and only divides by
@@ -189,15 +191,38 @@ inline void init_sample(const SimConfig &cfg, uint32_t np_seed, uint64_t py_seed
     const int GS = 76;
     const int gy = (int)std::ceil(cfg.sx * GS), gx = (int)std::ceil(cfg.sy * GS);
     const double fcx = cfg.fc0 * GS, fcy = cfg.fc1 * GS, fr = S->faz_radius * GS * 0.5;
+    // optic-nerve disc: cut out of the mask only when it lies inside the field of view (simulation_space.py:48-50:
+    // `all(nerve_center - nerve_radius <= 1)` on the values already divided by param_scale)
+    const double nerve_c0 = cfg.nc0 / ps, nerve_c1 = cfg.nc1 / ps, nerve_r = cfg.nr / ps;
+    const bool disc = (nerve_c0 - nerve_r <= 1.0) && (nerve_c1 - nerve_r <= 1.0);
+    const double ncx = nerve_c0 * GS, ncy = nerve_c1 * GS, nrr = nerve_r * GS;
     S->valid.clear();
     for (int i = 0; i < gy; i++)
-        for (int j = 0; j < gx; j++)
-            if ((j - fcx) * (j - fcx) + (i - fcy) * (i - fcy) > fr * fr) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); }
+        for (int j = 0; j < gx; j++) {
+            bool ok = (j - fcx) * (j - fcx) + (i - fcy) * (i - fcy) > fr * fr;
+            if (ok && disc) ok = (j - ncx) * (j - ncx) + (i - ncy) * (i - ncy) > nrr * nrr;
+            if (ok) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); }
+        }
     std::vector<int> walls;
     for (int w = 0; w < 4; w++) if (cfg.walls[w]) walls.push_back(w);
     for (int f = 0; f < 2; f++) {
         S->pos[f].clear();
-        for (int t = 0; t < cfg.n_trees; t++) {
+        for (int t = 0; t < cfg.n_trees && cfg.forest_type == 1; t++) {
+            // Forest._initialize_tree_stumps_from_nerve (forest.py:38-66): five draws of Python's random() per tree
+            const double alpha = 2 * M_PI * py.next_double();
+            const double rr = nerve_r * std::sqrt(py.next_double());
+            double p[3], dir[3];
+            p[0] = rr * std::cos(alpha) + nerve_c1;
+            p[1] = rr * std::sin(alpha) + nerve_c0;
+            p[2] = py.next_double() * cfg.sz;
+            dir[0] = py.next_double() - 0.5;
+            dir[1] = py.next_double() - 0.5;
+            dir[2] = 0.0;
+            const double nrm = std::sqrt(std::fma(dir[2], dir[2], std::fma(dir[1], dir[1], dir[0] * dir[0])));
+            for (int c = 0; c < 3; c++) S->pos[f].push_back(p[c]);
+            for (int c = 0; c < 3; c++) S->pos[f].push_back(p[c] + dir[c] / nrm * d0);
+        }
+        for (int t = 0; t < cfg.n_trees && cfg.forest_type == 0; t++) {
             int wall = walls[py_randbelow(py, (uint32_t)walls.size())];
             double p[3], dir[3];
             if (wall == 0 || wall == 1) {

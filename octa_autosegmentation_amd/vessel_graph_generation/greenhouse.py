@@ -24,7 +24,8 @@ class SimConfigStruct(ctypes.Structure):
                 ("faz_radius_mean", ctypes.c_double), ("faz_radius_std", ctypes.c_double),
                 ("rotation_radius", ctypes.c_double), ("faz_center", ctypes.c_double * 2),
                 ("size", ctypes.c_double * 3), ("n_trees", ctypes.c_int), ("walls", ctypes.c_int * 4),
-                ("n_modes", ctypes.c_int), ("modes", (ctypes.c_double * 13) * 8)]
+                ("n_modes", ctypes.c_int), ("modes", (ctypes.c_double * 13) * 8),
+                ("forest_type", ctypes.c_int), ("nerve_center", ctypes.c_double * 2), ("nerve_radius", ctypes.c_double)]
 
 
 REQ_DTYPE = np.dtype([("sample", np.int32), ("n", np.int32), ("pos", np.float64, 3), ("r", np.float64),
@@ -35,13 +36,10 @@ BIF_FN = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ct
 def config_to_struct(config):
     """Generator YAML dict (Greenhouse / Forest sections, docker/vessel_graph_gen_docker_config.yml) -> C struct."""
     g, f = config["Greenhouse"], config["Forest"]
-    if f["type"] != "stumps":
-        raise NotImplementedError("only Forest.type == 'stumps' runs on the GPU path (forest.py:68-181)")
+    if f["type"] not in ("stumps", "nerve"):
+        raise NotImplementedError(f"The Forest initialization type '{f['type']}' is not implemented. Try 'stumps' or 'nerve' instead.")
     if g["SimulationSpace"].get("oxygen_sample_geometry_path") is not None:
-        raise NotImplementedError("fixed-geometry simulation spaces are not on the GPU path yet")
-    nc, nr = np.array(g["nerve_center"]) / g["param_scale"], np.array(g["nerve_radius"]) / g["param_scale"]
-    if all(nc - nr <= 1):
-        raise NotImplementedError("a nerve disc inside the field of view is not on the GPU path yet")
+        raise NotImplementedError("fixed-geometry simulation spaces (oxygen_sample_geometry_path) are not on the GPU path yet")
     walls = f["source_walls"]
     if walls.get("z0") or walls.get("z1"):
         raise NotImplementedError("z source walls are not on the GPU path yet")
@@ -57,6 +55,9 @@ def config_to_struct(config):
     p.n_trees = f["N_trees"]
     for i, k in enumerate(("x0", "x1", "y0", "y1")):
         p.walls[i] = 1 if walls.get(k) else 0
+    p.forest_type = 1 if f["type"] == "nerve" else 0
+    p.nerve_center[0], p.nerve_center[1] = g["nerve_center"]
+    p.nerve_radius = g["nerve_radius"]
     if len(g["modes"]) > 8:
         raise NotImplementedError("at most 8 modes")
     p.n_modes = len(g["modes"])

@@ -368,6 +368,8 @@ struct octa_sim_params {
     int walls[4];  // x0, x1, y0, y1 enabled
     int n_modes;
     double modes[8][13];  // I, N, eps_n, eps_s, eps_k, delta_art, delta_ven, gamma_art, gamma_ven, phi, omega, kappa, delta_sigma
+    int forest_type;      // 0 'stumps' (forest.py:68-181), 1 'nerve' (forest.py:38-66)
+    double nerve_center[2], nerve_radius;   // as configured (greenhouse.py:28-29 divides them by param_scale)
 };
 
 struct octa_sim_result {
@@ -406,10 +408,17 @@ int octa_oracle_simulate(const octa_sim_params *P, uint32_t np_seed, uint64_t py
     const double sx = P->size[0], sy = P->size[1], sz = P->size[2];
     const int gy = (int)std::ceil(sx * GS), gx = (int)std::ceil(sy * GS);
     const double fcx = fc0 * GS, fcy = fc1 * GS, fr = FAZ_radius * GS * 0.5;
+    // greenhouse.py:28-29, simulation_space.py:48-50: the optic-nerve disc leaves the mask when it is inside the field of view
+    const double nerve_c0 = P->nerve_center[0] / ps, nerve_c1 = P->nerve_center[1] / ps, nerve_r = P->nerve_radius / ps;
+    const bool disc = (nerve_c0 - nerve_r <= 1.0) && (nerve_c1 - nerve_r <= 1.0);
+    const double ncx = nerve_c0 * GS, ncy = nerve_c1 * GS, nrr = nerve_r * GS;
     std::vector<std::array<int, 2>> valid;
     for (int i = 0; i < gy; i++)
-        for (int j = 0; j < gx; j++)
-            if ((j - fcx) * (j - fcx) + (i - fcy) * (i - fcy) > fr * fr) valid.push_back({i, j});
+        for (int j = 0; j < gx; j++) {
+            bool ok = (j - fcx) * (j - fcx) + (i - fcy) * (i - fcy) > fr * fr;
+            if (ok && disc) ok = (j - ncx) * (j - ncx) + (i - ncy) * (i - ncy) > nrr * nrr;
+            if (ok) valid.push_back({i, j});
+        }
     const uint32_t K = (uint32_t)valid.size();
 
     // ---- modes; first mode loaded in __init__ (unscaled values are live during iteration 0)
@@ -434,9 +443,23 @@ int octa_oracle_simulate(const octa_sim_params *P, uint32_t np_seed, uint64_t py
     Forest forest[2];
     std::vector<int> walls;
     for (int w = 0; w < 4; w++) if (P->walls[w]) walls.push_back(w);
-    if (walls.empty()) return -3;
+    if (walls.empty() && P->forest_type == 0) return -3;
     for (int f = 0; f < 2; f++) {
-        for (int t = 0; t < P->n_trees; t++) {
+        for (int t = 0; t < P->n_trees && P->forest_type == 1; t++) {   // forest.py:38-66
+            const double alpha = 2 * M_PI * py.random();
+            const double rr = nerve_r * std::sqrt(py.random());
+            const double x = rr * std::cos(alpha) + nerve_c1;
+            const double y = rr * std::sin(alpha) + nerve_c0;
+            const double z = py.random() * sz;
+            V3 pos = {x, y, z};
+            const double a = py.random() - 0.5, b = py.random() - 0.5;
+            V3 dir = {a, b, 0.0};
+            dir = mul(divs(dir, norm3(dir)), d);
+            int root = forest[f].add(pos, r, -1, 4.0);
+            forest[f].roots.push_back(root);
+            forest[f].add(add(pos, dir), r, root, 4.0);
+        }
+        for (int t = 0; t < P->n_trees && P->forest_type == 0; t++) {
             int wall = walls[py.randbelow((uint32_t)walls.size())];
             V3 pos, dir;
             const double d0 = d;

@@ -23,7 +23,8 @@ class SimParams(ctypes.Structure):
                 ("faz_radius_mean", ctypes.c_double), ("faz_radius_std", ctypes.c_double),
                 ("rotation_radius", ctypes.c_double), ("faz_center", ctypes.c_double * 2),
                 ("size", ctypes.c_double * 3), ("n_trees", ctypes.c_int), ("walls", ctypes.c_int * 4),
-                ("n_modes", ctypes.c_int), ("modes", (ctypes.c_double * 13) * 8)]
+                ("n_modes", ctypes.c_int), ("modes", (ctypes.c_double * 13) * 8),
+                ("forest_type", ctypes.c_int), ("nerve_center", ctypes.c_double * 2), ("nerve_radius", ctypes.c_double)]
 
 
 class SimResult(ctypes.Structure):
@@ -100,8 +101,8 @@ def lib():
 def params_from_config(config):
     """config = the full generator YAML dict (keys Greenhouse / Forest / output)."""
     g, f = config["Greenhouse"], config["Forest"]
-    if f["type"] != "stumps":
-        raise NotImplementedError("oracle covers Forest.type == 'stumps' (forest.py:68-181)")
+    if f["type"] not in ("stumps", "nerve"):
+        raise NotImplementedError("oracle covers Forest.type 'stumps' (forest.py:68-181) and 'nerve' (forest.py:38-66)")
     if g["SimulationSpace"].get("oxygen_sample_geometry_path") is not None:
         raise NotImplementedError("oracle covers the analytic FAZ geometry (simulation_space.py:36-54)")
     p = SimParams()
@@ -111,9 +112,9 @@ def params_from_config(config):
     p.faz_center[0], p.faz_center[1] = g["FAZ_center"]
     s = g["SimulationSpace"]
     p.size[0], p.size[1], p.size[2] = s["no_voxel_x"], s["no_voxel_y"], s["no_voxel_z"]
-    nc, nr = np.array(g["nerve_center"]) / g["param_scale"], np.array(g["nerve_radius"]) / g["param_scale"]
-    if all(nc - nr <= 1):
-        raise NotImplementedError("oracle does not cover a nerve disc inside the field of view")
+    p.forest_type = 1 if f["type"] == "nerve" else 0
+    p.nerve_center[0], p.nerve_center[1] = g["nerve_center"]
+    p.nerve_radius = g["nerve_radius"]
     p.n_trees = f["N_trees"]
     walls = f["source_walls"]
     if walls.get("z0") or walls.get("z1"):

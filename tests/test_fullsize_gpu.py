@@ -33,9 +33,11 @@ def test_every_dynunet_layer_shape_at_batch_4(hip_lib_built, cin, cout, hw, stri
     x = torch.randn(B, hw, hw, cin, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (3.0 * cin ** 0.5)).to(torch.bfloat16).float()
     xr, wr = x.float().permute(0, 3, 1, 2).requires_grad_(True), w.clone().requires_grad_(True)
-    yr = F.conv2d(xr, wr, stride=stride, padding=1)
-    dy = torch.randn(yr.shape, device="cuda", generator=g).to(torch.bfloat16)
-    yr.backward(dy.float())
+    # reference = torch's native im2col + GEMM convolution (MIOpen off: on a fresh box it would JIT-compile three kernels per shape)
+    with torch.backends.cudnn.flags(enabled=False):
+        yr = F.conv2d(xr, wr, stride=stride, padding=1)
+        dy = torch.randn(yr.shape, device="cuda", generator=g).to(torch.bfloat16)
+        yr.backward(dy.float())
     xm, wm = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     ym = mfma_conv.conv3x3(xm, wm, stride)
     assert tuple(ym.shape) == (B, hw // stride, hw // stride, cout)
@@ -57,9 +59,10 @@ def test_bottleneck_1x1_transposed_conv_and_2x2_upsampling_at_full_size(hip_lib_
         x = torch.randn(4, hw, hw, cin, device="cuda", generator=g).to(torch.bfloat16)
         wt = (torch.randn(cin, cout, k, k, device="cuda", generator=g) / (k * cin ** 0.5)).to(torch.bfloat16).float()
         xr, wr = x.float().requires_grad_(True), wt.clone().requires_grad_(True)
-        yr = F.conv_transpose2d(xr.permute(0, 3, 1, 2), wr, stride=k).permute(0, 2, 3, 1)
-        dy = torch.randn(yr.shape, device="cuda", generator=g).to(torch.bfloat16)
-        yr.backward(dy.float())
+        with torch.backends.cudnn.flags(enabled=False):
+            yr = F.conv_transpose2d(xr.permute(0, 3, 1, 2), wr, stride=k).permute(0, 2, 3, 1)
+            dy = torch.randn(yr.shape, device="cuda", generator=g).to(torch.bfloat16)
+            yr.backward(dy.float())
         xm, wm = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
         ym = mfma_conv.conv_transpose_kxk_nhwc(xm, wm, k)
         ym.backward(dy)

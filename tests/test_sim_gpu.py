@@ -44,6 +44,30 @@ def test_short_runs_match_reference_csv(gh, golden):
     sim.close()
 
 
+def test_nerve_forest_runs_match_reference_csv(gh, golden):
+    """f4: optic-nerve forests + nerve disc (forest.py:38-66, simulation_space.py:48-50) on the GPU, N = 8000 candidates per
+    iteration, 16 + 16 trees: CSV text and the O2 / CO2 fields identical to the reference's; a run that outgrows the per-sample
+    capacities (the notebook's full 400 + 500 iterations would) fails loudly with capacity bits instead of truncating."""
+    names = [str(n) for n in golden["names"] if str(n).startswith("nerve_")]
+    assert len(names) >= 3
+    for name in names:
+        seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])
+        cfg = yaml.safe_load(str(golden["nerve_config_yaml"]))
+        cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = i1, i2
+        sim = gh.BatchSimulator(cfg, 1)
+        res = sim.run([seed])
+        assert res.n_art[0] == int(golden[name + "_n_art"])
+        assert gh.edges_to_csv_text(res.sample_edges(0)).encode() == golden[name + "_csv"].tobytes(), name
+        oxy, co2 = sim.fields(0)
+        assert (oxy == golden[name + "_oxy"]).all() and (co2 == golden[name + "_co2"]).all()
+        sim.close()
+    from octa_autosegmentation_amd import _native
+    cfg = yaml.safe_load(str(golden["nerve_config_yaml"]))
+    cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = 400, 500
+    with pytest.raises(_native.OctaHipError, match="capacity"):
+        gh.simulate_batch(cfg, [0])
+
+
 def test_mode_edge_cases(gh, golden):
     for name in ("run_s0_10_5", "run_s5_10_5", "run_s11_20_0", "run_s4_0_12"):
         seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])

@@ -40,6 +40,23 @@ def test_short_runs_csv_bit_exact(golden):
         assert (info["oxy"] == golden[name + "_oxy"]).all() and (info["co2"] == golden[name + "_co2"]).all()
 
 
+def test_nerve_forest_runs_csv_bit_exact(golden):
+    """f4: Forest.type 'nerve' (forest.py:38-66) with the optic-nerve disc cut out of the sampling mask (simulation_space.py:48-50) in
+    the 12x12 mm^2 geometry of the reference's notebook: fixtures recorded from the reference itself."""
+    names = [str(n) for n in golden["names"] if str(n).startswith("nerve_")]
+    assert len(names) >= 3
+    for name in names:
+        seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])
+        cfg = yaml.safe_load(str(golden["nerve_config_yaml"]))
+        cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = i1, i2
+        edges, info = sim_oracle.simulate(cfg, seed, return_fields=True)
+        assert info["faz_radius"] == float(golden[name + "_faz"])
+        assert (info["trace"] == golden[name + "_trace"]).all(), name
+        assert info["n_art_edges"] == int(golden[name + "_n_art"])
+        assert sim_oracle.edges_to_csv_text(edges).encode() == golden[name + "_csv"].tobytes(), name
+        assert (info["oxy"] == golden[name + "_oxy"]).all() and (info["co2"] == golden[name + "_co2"]).all()
+
+
 def test_full_length_run_sha(golden):
     names = [str(n) for n in golden["names"] if str(n).startswith("full_")]
     if not names:

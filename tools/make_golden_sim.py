@@ -87,6 +87,35 @@ def main():
             g[name + "_oxy"] = r["oxy"]
             g[name + "_co2"] = r["co2"]
         print(name, "rows", r["csv"].count("\n") - 1, "oxy", len(r["oxy"]), "co2", len(r["co2"]))
+    # f4: optic-nerve forests (forest.py:38-66) with the nerve disc inside the field of view (simulation_space.py:48-50): the
+    # notebook's 12x12 mm^2 geometry (example_custom_vessel_simulation.ipynb:138-156: param_scale 12, 16 trees, N = 8000, thinner z),
+    # short runs
+    nerve = copy.deepcopy(base)
+    nerve["Greenhouse"]["param_scale"] = 12
+    nerve["Forest"]["type"] = "nerve"
+    nerve["Forest"]["N_trees"] = 16
+    nerve["Greenhouse"]["SimulationSpace"]["no_voxel_z"] = 0.0033
+    nerve["Greenhouse"]["d"] = 0.15
+    for m in nerve["Greenhouse"]["modes"]:
+        m["N"] = 8000
+        m["delta_sigma"] = 0.002222
+    g["nerve_config_yaml"] = np.array(yaml.safe_dump(nerve))
+    for seed, i1, i2 in [(0, 12, 6), (3, 12, 6), (8, 20, 0)]:
+        cfg = copy.deepcopy(nerve)
+        cfg["Greenhouse"]["modes"][0]["I"] = i1
+        cfg["Greenhouse"]["modes"][1]["I"] = i2
+        r = run_reference(cfg, seed)
+        name = f"nerve_s{seed}_{i1}_{i2}"
+        names.append(name)
+        g[name + "_seed_I"] = np.array([seed, i1, i2])
+        g[name + "_trace"] = r["trace"]
+        g[name + "_faz"] = np.array(r["faz"])
+        g[name + "_n_art"] = np.array(r["n_art"])
+        g[name + "_next"] = np.array([r["next_py"], r["next_np"]])
+        g[name + "_csv"] = np.frombuffer(r["csv"].encode(), dtype=np.uint8)
+        g[name + "_oxy"] = r["oxy"]
+        g[name + "_co2"] = r["co2"]
+        print(name, "rows", r["csv"].count("\n") - 1, "oxy", len(r["oxy"]), "co2", len(r["co2"]))
     for k, v in keep_old.items():
         g.setdefault(k, v)
         if k.endswith("_seed_I"):
