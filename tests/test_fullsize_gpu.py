@@ -118,9 +118,11 @@ def test_whole_network_at_1216_against_fp32_on_the_same_bf16_weights(hip_lib_bui
         networks.USE_MFMA_CONV, networks.USE_FUSED_NORM = mfma, mfma
         try:
             net.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            # the torch reference modules run torch's native kernels (MIOpen off: on a fresh box its JIT compilation of every fp32 and
+            # bf16 layer shape takes four minutes); the MFMA path does not touch MIOpen either way
+            with torch.backends.cudnn.flags(enabled=False), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
                 out = net(x)
-            torch.nn.functional.binary_cross_entropy_with_logits(out.float(), tgt).backward()
+                torch.nn.functional.binary_cross_entropy_with_logits(out.float(), tgt).backward()
             return out.float().detach(), {k: p.grad.float().clone() for k, p in net.named_parameters() if p.grad is not None}
         finally:
             networks.USE_MFMA_CONV, networks.USE_FUSED_NORM = old
@@ -131,14 +133,14 @@ def test_whole_network_at_1216_against_fp32_on_the_same_bf16_weights(hip_lib_bui
     rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-30)).item()
     e_got, e_ac = rel(got_out, ref_out), rel(ac_out, ref_out)
     assert e_got <= max(1.5 * e_ac, 0.02), (e_got, e_ac)
-    worst = (0.0, "")
+    worst = (0.0, "", 0.0)
     for k, b in ref_g.items():
         if b.norm().item() < 1e-12 or k not in got_g:
             continue
         r_got, r_ac = rel(got_g[k], b), rel(ac_g[k], b)
-        worst = max(worst, (r_got, k))
+        worst = max(worst, (r_got, k, r_ac))
         assert r_got <= max(2.0 * r_ac, 0.05) + 0.1, (k, r_got, r_ac)
-    print(f"logits: rel. error {e_got:.4f} (torch autocast {e_ac:.4f}); worst gradient tensor {worst[1]}: {worst[0]:.4f}")
+    print(f"logits: rel. error {e_got:.4f} (torch autocast {e_ac:.4f}); worst gradient tensor {worst[1]}: {worst[0]:.4f} (torch autocast {worst[2]:.4f})")
 
 
 def _oracle_one(args):
