@@ -210,7 +210,8 @@ class ImageToImageTranslationd(MapTransform):
             if model_path is not None:
                 ckpt = load_checkpoint_file(model_path, "cpu")
                 model.load_state_dict(ckpt["model"])
-                print(f"Loaded network weights from epoch {ckpt['epoch']}.")
+                import sys
+                print(f"Loaded network weights from epoch {ckpt['epoch']}.", file=sys.stderr)
         self.device = torch.device(device) if device is not None else default_device()
         self.model = model.to(self.device).eval()
 

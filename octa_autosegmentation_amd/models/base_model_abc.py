@@ -20,6 +20,7 @@ RCCL all-reduce on the buffer itself -- no per-parameter copies in or out (round
 """
 import itertools
 import os
+import sys
 from abc import ABC, abstractmethod
 from typing import Any, Callable, Dict, Tuple
 
@@ -29,6 +30,11 @@ from torch import nn
 
 from ..utils.enums import Phase
 from .model_interface_abc import ModelInterface, Output
+
+
+def _log(msg):
+    """Progress notes go to stderr: stdout belongs to the entry points' results (bench.py prints exactly one JSON line)."""
+    print(msg, file=sys.stderr)
 
 
 def _dist_on():
@@ -88,7 +94,7 @@ class BaseModelABC(nn.Module, ModelInterface, ABC):
                                        phase=Phase.TRAIN):
         nets = [getattr(self, n, None) for names in self.optimizer_mapping.values() for n in names]
         if not any(isinstance(n, nn.Module) for n in nets):
-            print(f"Skipping initialization for {list(self.optimizer_mapping.values())}")
+            _log(f"Skipping initialization for {list(self.optimizer_mapping.values())}")
             return
         device = torch.device(config["General"].get("device") or "cpu")
         self.amp = bool(config["General"].get("amp")) and device.type == "cuda"
@@ -114,7 +120,7 @@ class BaseModelABC(nn.Module, ModelInterface, ABC):
                     m: nn.Module = getattr(self, net_name)
                     activation = "relu" if "resnet" in m._get_name().lower() else "leaky_relu"
                     init_weights(m, init_type="kaiming", nonlinearity=activation)
-                    print(f"Initialized {net_name} network weights using He initialization ({activation}).")
+                    _log(f"Initialized {net_name} network weights using He initialization ({activation}).")
             if _dist_on():                                     # replicas start from rank 0's weights
                 for p in self.parameters():
                     dist.broadcast(p.data, src=0)
@@ -137,7 +143,7 @@ class BaseModelABC(nn.Module, ModelInterface, ABC):
             assert hasattr(self, which), f"Inference mode {which} not implemented."
             getattr(self, which).load_state_dict(checkpoint["model"])
             self._after_weight_surgery()
-            print(f"Loaded network weights {which} from epoch {checkpoint['epoch']}.")
+            _log(f"Loaded network weights {which} from epoch {checkpoint['epoch']}.")
 
     def _resume(self, model_path, device):
         for optimizer_name, net_names in self.optimizer_mapping.items():
@@ -158,7 +164,7 @@ class BaseModelABC(nn.Module, ModelInterface, ABC):
                         break
                 else:
                     raise FileNotFoundError(f"no optimizer state for {optimizer_name} next to {model_path}")
-            print(f"Loaded all network weights from epoch {checkpoint['epoch']}.")
+            _log(f"Loaded all network weights from epoch {checkpoint['epoch']}.")
         self._after_weight_surgery()
 
     def _after_weight_surgery(self):
