@@ -275,9 +275,9 @@ def main():
         bif_ms += tm["host_bif_ms"]
         relaunches += r.service["relaunches"]
         assert int(r.stats[:, 0].max()) == 0, "simulator reported error bits"
-    # device milliseconds one sample spends in its phases (100 MHz timers of thread 0, mailbox waits included; slot 10 -- the
-    # candidate stream -- runs BESIDE the ordered arterial pass and is not added) while n_fly launches share the GPU
-    phase_ms = lambda st: float((st[:, 8:24].sum(axis=1) - st[:, 18]).mean()) * 1e-5
+    # device milliseconds one sample spends in its ten phases (100 MHz timers of thread 0: octa_sim_stats slots 0-9, mailbox waits
+    # included; slots 10-15 are sub-timers of those phases) while n_fly launches share the GPU
+    phase_ms = lambda st: float(st[:, 8:18].sum(axis=1).mean()) * 1e-5
     sample_ms_loaded = float(np.mean([phase_ms(o["result"].stats) for o in outs]))
 
     # ---- rasteriser alone (other slots idle): HIP events on the stream the kernels go to

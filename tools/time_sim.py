@@ -3,8 +3,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, yaml
 from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
-g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "sim_golden.npz"))
-cfg = yaml.safe_load(str(g["config_yaml"]))
+from octa_autosegmentation_amd.utils import configs
+cfg = configs.load_generator_config()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 i1 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 i2 = int(sys.argv[3]) if len(sys.argv) > 3 else 150
