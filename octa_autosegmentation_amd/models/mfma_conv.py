@@ -288,7 +288,9 @@ def _pad_channels(x, mult=32):
     return out
 
 
-USE_SKIP_GRAD_FUSION = os.environ.get("OCTA_SKIP_FUSION", "1") != "0"     # A/B switch (development aid)
+# A/B switch (development aid). The residual epilogue exists in the DMA-staged kernel only: with OCTA_CONV_GLDS=0 (the
+# register-staged kernel) the mailbox is never armed and autograd adds the two skip gradients itself.
+USE_SKIP_GRAD_FUSION = os.environ.get("OCTA_SKIP_FUSION", "1") != "0" and os.environ.get("OCTA_CONV_GLDS", "16") != "0"
 
 
 class SkipGradMailbox:

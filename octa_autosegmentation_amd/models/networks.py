@@ -214,6 +214,7 @@ class DynUNet(nn.Module):
         down = 1
         for d in self.downsamples:
             down *= d.conv1.conv.stride[0]
+        down *= self.bottleneck.conv1.conv.stride[0]      # a strided bottleneck halves the map once more: odd sizes take the torch path
         return x.shape[2] % down == 0 and x.shape[3] % down == 0
 
     def _forward_nhwc(self, x):
