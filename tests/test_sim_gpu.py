@@ -87,7 +87,9 @@ def test_batch_vs_oracle_radii_bit_exact(gh, golden):
         assert g.shape == e.shape
         assert (g[:, 6] == e[:, 6]).all()
         assert gh.edges_to_csv_text(g) == sim_oracle.edges_to_csv_text(e)
-        assert res.stats[k, 1] == info["py_random_draws"] and res.stats[k, 2] == info["murray_steps"]
+        # same random.uniform draws; the device batches Murray walks (a node several walks of a pass pass through is recomputed once),
+        # so it never takes MORE pow-pair steps than the reference's walk-per-node propagation
+        assert res.stats[k, 1] == info["py_random_draws"] and 0 < res.stats[k, 2] <= info["murray_steps"]
 
 
 def test_full_length_run_sha(gh, golden):

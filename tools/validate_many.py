@@ -16,8 +16,8 @@ def oracle_one(args):
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-    g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "sim_golden.npz"))
-    cfg = yaml.safe_load(str(g["config_yaml"]))
+    from octa_autosegmentation_amd.utils import configs
+    cfg = configs.load_generator_config()
     seeds = list(range(s0, s0 + N))
     t = time.time()
     with Pool(min(N, os.cpu_count() or 1, 64)) as p:
