@@ -52,8 +52,7 @@ constexpr int SIM_LDS_BYTES = 160 * 1024;  // dynamic LDS of the simulator kerne
 constexpr int GRID_MAX = 128;   // uniform-grid cells per axis (x, y); the thin z extent is not binned
 
 enum ErrBits { ERR_NODE_CAP = 1, ERR_OXY_CAP = 2, ERR_CO2_CAP = 4, ERR_GROUP_CAP = 8, ERR_PAIR_CAP = 16, ERR_SET_CAP = 32,
-               ERR_PY_CAP = 64, ERR_KEPT_CAP = 128, ERR_REQ_CAP = 256, ERR_ACC_CAP = 512, ERR_MISSING_BIF = 1024,
-               ERR_MURRAY_BATCH = 4096 /* 2048 = ERR_HOST_TIMEOUT (sim.hip) */ };
+               ERR_PY_CAP = 64, ERR_KEPT_CAP = 128, ERR_REQ_CAP = 256, ERR_ACC_CAP = 512, ERR_MISSING_BIF = 1024 };
 
 struct IterParams {
     int t, first_mode, N, pad;
@@ -943,10 +942,7 @@ __device__ inline double readlane_f64(double v, int j /* wave-uniform */) {
 // chain -- two pow evaluations per node, operands fetched with readlane -- is executed uniformly; (4) the lanes
 // store the new radii. Floating-point addition is commutative, so "on-path power + other power" is
 // bit-identical to the reference's c0-then-c1 order.
-// `until` (default -1): the walk ends BEFORE this node (batched flushes: a later walk of the batch recomputes it and everything
-// above it); *early (optional) is set when the walk ended because a radius did not change.
-__device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L,
-                                      int until = -1, bool *early = nullptr) {
+__device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L) {
     if (id < 0) return 0;
     const int lane = (int)(threadIdx.x & 63);
     double *rad = L.rad;
@@ -955,9 +951,7 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
     double rp_prev = 0, k_last = 0, inv_k = 0;
     while (true) {
         int cur = first, nn = 0, mine = -1;
-        bool hit_until = false;
         for (; nn < 64; nn++) {
-            if (cur == until) { hit_until = true; break; }
             const int p = walk_parent(L, cur);
             if (p < 0) break;
             if (lane == nn) mine = cur;
@@ -999,7 +993,7 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
             }
             const double rp = octa_gpow::gpow_t(s, inv_k, L.log_tab, L.exp_tab);
             steps++;
-            if (old_j == rp) { stop = true; if (early) *early = true; break; }
+            if (old_j == rp) { stop = true; break; }
             if (lane == j) my_rp = rp;
             done = j + 1;
             rp_prev = rp;
@@ -1013,104 +1007,10 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
         }
         if (lane < done) rad[mine] = my_rp;
         __builtin_amdgcn_wave_barrier();
-        if (stop || nn < 64 || hit_until) break;
+        if (stop || nn < 64) break;
         below = __shfl(mine, 63, 64);
         first = cur;
     }
-    return steps;
-}
-
-// ---- batched Murray propagation of the ordered pass ---------------------------------------------------------------------
-// The reference walks to the root after EVERY sprout / bifurcation (arterial_tree.py:174-184): ~11 walks of ~23 nodes per pass,
-// 133 k dependent pow pairs per sample, and the upper ancestors are recomputed by every one of them. Only two things observe
-// the intermediate radii: the walks themselves and the ordered pass when it reads an inter-node's child radius. So a walk is
-// DEFERRED: its root path is marked stale (and its dirty-list insertions are made at once, as the reference's walk would make
-// them); pending walks are flushed when the pass is about to read a stale radius, when the list is full and at the end of the
-// pass. A flush runs the pending walks in their order, but walk i ends right below the first node that a LATER pending walk
-// passes too: that walk recomputes the node and everything above from the children's then-final radii, which is the value the
-// reference's last walk leaves there. One pending walk = the reference's walk, early stop included. With several, an early
-// stop ("radius unchanged") would break the hand-over; it cannot happen for these walks (their start node has just gained a
-// child, and a sum never absorbs a power three orders of magnitude below it) -- if it ever did, the sample fails loudly
-// (ERR_MURRAY_BATCH) instead of drifting.
-struct MurrayBatch {
-    unsigned *stale;        // [NCAP / 32] LDS: node lies on the root path of a pending walk
-    unsigned *mark;         // [NCAP / 32] LDS: scratch of the flush
-    unsigned short *pend;   // [CAP] LDS: start nodes of the pending walks, in order
-    int n;
-    static constexpr int CAP = 64;
-};
-__device__ inline bool murray_is_stale(const MurrayBatch &M, int id) { return (M.stale[id >> 5] >> (id & 31)) & 1u; }
-
-// all 64 lanes call it with identical arguments
-__device__ inline void murray_defer(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L, MurrayBatch &M) {
-    const int lane = (int)(threadIdx.x & 63);
-    int first = id;
-    while (true) {
-        int cur = first, nn = 0, mine = -1;
-        for (; nn < 64; nn++) {
-            const int p = walk_parent(L, cur);
-            if (p < 0) break;                       // the root is never updated
-            if (lane == nn) mine = cur;
-            cur = p;
-        }
-        if (nn == 0) break;
-        int v_cg = 0;
-        if (lane < nn) {
-            v_cg = A.child_group[mine];
-            atomicOr(&M.stale[mine >> 5], 1u << (mine & 31));
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (D) {
-            for (int jj = 0; jj < nn; jj++) {
-                const int cg = __builtin_amdgcn_readlane(v_cg, __builtin_amdgcn_readfirstlane(jj));
-                if ((cg >> 14) == pass_tag && !((cg >> 13) & 1)) {
-                    const int g2 = cg & 8191;
-                    if (g2 > cur_g) dirty_insert(*D, g2);
-                }
-            }
-        }
-        if (nn < 64) break;
-        first = cur;
-    }
-    M.pend[M.n] = (unsigned short)id;
-    M.n++;
-}
-
-// all 64 lanes call it with identical arguments; returns the pow-pair steps executed
-__device__ inline long murray_flush(const SimArrays &A, int f, const SeqLds &L, MurrayBatch &M, int *err) {
-    const int lane = (int)(threadIdx.x & 63);
-    long steps = 0;
-    const int n = M.n;
-    if (n == 0) return 0;
-    if (n == 1) {
-        steps = murray_to_root(A, f, (int)M.pend[0], 0, 0, nullptr, L);
-    } else {
-        // where each walk hands over: processed last to first, a walk marks its path until it meets a node a later one marked
-        int until_reg = -1;                         // lane i keeps the hand-over node of walk i
-        for (int i = n - 1; i >= 0; i--) {
-            int cur = (int)M.pend[i], u = -1;
-            while (true) {
-                const int p = walk_parent(L, cur);
-                if (p < 0) break;
-                if ((M.mark[cur >> 5] >> (cur & 31)) & 1u) { u = cur; break; }
-                if (lane == 0) M.mark[cur >> 5] |= 1u << (cur & 31);
-                __builtin_amdgcn_wave_barrier();
-                cur = p;
-            }
-            if (lane == i) until_reg = u;
-        }
-        for (int i = 0; i < n; i++) {
-            const int until = __builtin_amdgcn_readlane(until_reg, __builtin_amdgcn_readfirstlane(i));
-            if (until == (int)M.pend[i]) continue;   // a later walk starts below or at this node and covers it entirely
-            bool early = false;
-            steps += murray_to_root(A, f, (int)M.pend[i], 0, 0, nullptr, L, until, &early);
-            if (early) *err |= ERR_MURRAY_BATCH;
-        }
-        for (int w = lane; w < NCAP / 32; w += 64) M.mark[w] = 0u;
-    }
-    for (int w = lane; w < NCAP / 32; w += 64) M.stale[w] = 0u;
-    __builtin_amdgcn_wave_barrier();
-    M.n = 0;
     return steps;
 }
 #else
@@ -1588,13 +1488,6 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     L.log_tab = ltab; L.exp_tab = etab;
     L.stage = reinterpret_cast<unsigned char *>(etab + 256);
     unsigned char *side_lds = L.stage + 2048;
-    // batched Murray propagation: stale bits + pending starts in the 2 KiB stage area, mark bits behind the side job's LDS
-    static_assert(NCAP / 8 + 2 * 64 <= 2048, "stale bits + pending list fit the stage area");
-    static_assert((size_t)NCAP * 10 + 384 * 8 + 256 * 8 + 2048 + SEQ_SIDE_LDS + NCAP / 8 + 2048 <= (size_t)SIM_LDS_BYTES, "mark bits fit behind the side-job area");
-    unsigned *mb_stale = reinterpret_cast<unsigned *>(L.stage);
-    unsigned short *mb_pend = reinterpret_cast<unsigned short *>(L.stage + NCAP / 8);
-    unsigned *mb_mark = reinterpret_cast<unsigned *>(side_lds + SEQ_SIDE_LDS);
-    for (int i = b.tid; i < NCAP / 32; i += b.nth) { mb_stale[i] = 0u; mb_mark[i] = 0u; }
     const int n_before = sc->n_nodes[f];
     for (int i = b.tid; i < n_before; i += b.nth) {
         L.rad[i] = A.nrad[f][i];
@@ -1619,17 +1512,6 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
         const int tag = sc->pass_tag[f];
         DirtyList D;
         D.v = b.coll() + 128; D.n = 0; D.cap = 256; D.overflow = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-        MurrayBatch MB = {mb_stale, mb_mark, mb_pend, 0};
-#define OCTA_MURRAY(id_, g_) do { murray_defer(A, f, (id_), (g_), tag, &D, L, MB); if (MB.n == MurrayBatch::CAP) steps += murray_flush(A, f, L, MB, &err); } while (0)
-#define OCTA_MURRAY_SYNC(node_) do { if (MB.n && murray_is_stale(MB, (node_))) steps += murray_flush(A, f, L, MB, &err); } while (0)
-#define OCTA_MURRAY_END() do { steps += murray_flush(A, f, L, MB, &err); } while (0)
-#else
-        (void)mb_stale; (void)mb_mark; (void)mb_pend;
-#define OCTA_MURRAY(id_, g_) do { steps += murray_to_root(A, f, (id_), (g_), tag, &D, L); } while (0)
-#define OCTA_MURRAY_SYNC(node_) do { } while (0)
-#define OCTA_MURRAY_END() do { } while (0)
-#endif
         // scalars of the sample stay in registers during the pass
         int n_nodes = n_before, py_pos = sc->py_pos, err = 0;
         const int py_cap = sc->py_cap;
@@ -1684,14 +1566,13 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                     const double *o = bif_results + 6 * (size_t)R.req;
                     seq_add_node(A, f, n_nodes, v3(o[0], o[1], o[2]), C.r, id, 0, P.kappa, L);
                     seq_add_node(A, f, n_nodes, v3(o[3], o[4], o[5]), C.r, id, 1, P.kappa, L);
-                    SEQT(0, OCTA_MURRAY(id, g));
+                    SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L));
                     A.nact[f][id] = 0;
                     n_bif++;
                 } else {
                     seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 0, P.kappa, L);
                 }
             } else {
-                SEQT(0, OCTA_MURRAY_SYNC((int)R.child));      // the child's radius is about to be read: pending walks through it first
                 if (L.rad[R.child] != R.r1_used) {
                     SEQT(1, eval_inter(G, g, R));
                     respec++;
@@ -1703,15 +1584,11 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 u_next = py_pos < py_cap ? A.py_u[py_pos] : 0.0;
                 if (R.thr <= u && !R.ang_gt90) continue;
                 seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 1, P.kappa, L);
-                SEQT(0, OCTA_MURRAY(id, g));
+                SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L));
                 A.nact[f][id] = 0;
             }
             if (D.overflow && !scan_all) { scan_all = true; D.n = 0; }
         }
-        SEQT(0, OCTA_MURRAY_END());
-#undef OCTA_MURRAY
-#undef OCTA_MURRAY_SYNC
-#undef OCTA_MURRAY_END
         sc->new_begin[f] = n_before;
         sc->new_end[f] = n_nodes;
         sc->n_nodes[f] = n_nodes;
