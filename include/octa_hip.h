@@ -381,6 +381,13 @@ typedef struct {
     int forest_type;
     double nerve_center[2];
     double nerve_radius;
+    /* SimulationSpace.oxygen_sample_geometry_path (simulation_space.py:29-34,70-76): the loaded .npy mask, one byte per voxel in C
+     * order [76][76][1] (non-zero = sinks may be sampled there), or NULL for the analytic FAZ mask. With a geometry the space's
+     * extent is the mask's shape / 76 (size[] is ignored), candidate sinks are never rejected, and the stumps' wall positions come
+     * from a random valid voxel of the wall's face (face 0 for all four walls: `shape[axis] - 1` of the normalised shape,
+     * simulation_space.py:71). The bytes are copied by octa_sim_create. */
+    const uint8_t *geometry;
+    int geometry_shape[3];
 } octa_sim_config;
 
 #define OCTA_BIF_MAX_ATTS 256

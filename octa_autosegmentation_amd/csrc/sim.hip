@@ -495,6 +495,16 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     int nw = 0;
     for (int w = 0; w < 4; w++) { cfg.walls[w] = c->walls[w]; nw += c->walls[w] ? 1 : 0; }
     cfg.forest_type = c->forest_type; cfg.nc0 = c->nerve_center[0]; cfg.nc1 = c->nerve_center[1]; cfg.nr = c->nerve_radius;
+    if (c->geometry) {   // simulation_space.py:29-34
+        if (c->geometry_shape[0] != 76 || c->geometry_shape[1] != 76 || c->geometry_shape[2] != 1) {
+            octa::set_error("octa_sim_create: the sampling geometry must be a [76][76][1] mask (got [%d][%d][%d])", c->geometry_shape[0],
+                            c->geometry_shape[1], c->geometry_shape[2]);
+            delete S; return -2;
+        }
+        cfg.geometry.assign(c->geometry, c->geometry + 76 * 76);
+        cfg.sx = 1.0; cfg.sy = 1.0; cfg.sz = 1.0 / 76.0;       // shape = geometry.shape / max(geometry.shape)
+        if (cfg.forest_type != 0) { octa::set_error("octa_sim_create: a sampling geometry with nerve forests is not supported"); delete S; return -2; }
+    }
     if (cfg.forest_type != 0 && cfg.forest_type != 1) { octa::set_error("octa_sim_create: forest_type must be 0 (stumps) or 1 (nerve)"); delete S; return -2; }
     for (int m = 0; m < c->n_modes; m++) {
         const double *q = c->modes[m];

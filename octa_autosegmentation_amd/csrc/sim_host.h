@@ -132,6 +132,7 @@ struct SimConfig {
     int n_trees;
     int walls[4];
     std::vector<ModeCfg> modes;
+    std::vector<unsigned char> geometry;   // fixed geometry [76][76] (z extent 1), empty = analytic mask
     int forest_type = 0;               // 0 stumps, 1 nerve
     double nc0 = 1e30, nc1 = 1e30, nr = 0;   // nerve_center / nerve_radius as configured (before the division by param_scale)
 };
@@ -197,6 +198,15 @@ inline void init_sample(const SimConfig &cfg, uint32_t np_seed, uint64_t py_seed
     const bool disc = (nerve_c0 - nerve_r <= 1.0) && (nerve_c1 - nerve_r <= 1.0);
     const double ncx = nerve_c0 * GS, ncy = nerve_c1 * GS, nrr = nerve_r * GS;
     S->valid.clear();
+    const bool fixed = !cfg.geometry.empty();      // simulation_space.py:29-34: the mask comes from the geometry file
+    std::vector<int> face_x, face_y;               // valid voxels of face 0 along axis 0 (index j) and axis 1 (index i)
+    if (fixed) {
+        for (int i = 0; i < GS; i++)
+            for (int j = 0; j < GS; j++)
+                if (cfg.geometry[(size_t)i * GS + j]) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); }
+        for (int j = 0; j < GS; j++) if (cfg.geometry[j]) face_x.push_back(j);
+        for (int i = 0; i < GS; i++) if (cfg.geometry[(size_t)i * GS]) face_y.push_back(i);
+    } else
     for (int i = 0; i < gy; i++)
         for (int j = 0; j < gx; j++) {
             bool ok = (j - fcx) * (j - fcx) + (i - fcy) * (i - fcy) > fr * fr;
@@ -225,14 +235,24 @@ inline void init_sample(const SimConfig &cfg, uint32_t np_seed, uint64_t py_seed
         for (int t = 0; t < cfg.n_trees && cfg.forest_type == 0; t++) {
             int wall = walls[py_randbelow(py, (uint32_t)walls.size())];
             double p[3], dir[3];
+            // fixed geometry (simulation_space.py:70-76): random.choice over the wall face's valid voxels, then the voxel + three
+            // numpy uniforms (the one along the wall axis is drawn and dropped)
+            double fa = 0, fb = 0;
+            if (fixed) {
+                const std::vector<int> &face = (wall == 0 || wall == 1) ? face_x : face_y;
+                const int v = face.empty() ? 0 : face[py_randbelow(py, (uint32_t)face.size())];
+                const double u0 = np.next_double(), u1 = np.next_double(), u2 = np.next_double();
+                if (wall == 0 || wall == 1) { fa = (v + u1) / GS; fb = (0 + u2) / GS; }
+                else { fa = (v + u0) / GS; fb = (0 + u2) / GS; }
+            }
             if (wall == 0 || wall == 1) {
-                double y = np_uniform(np, 0, cfg.sy), z = np_uniform(np, 0, cfg.sz);
+                double y = fixed ? fa : np_uniform(np, 0, cfg.sy), z = fixed ? fb : np_uniform(np, 0, cfg.sz);
                 p[0] = wall == 0 ? 0.0 : cfg.sx - 1e-6; p[1] = y; p[2] = z;
                 dir[0] = wall == 0 ? np_uniform(np, 0.1, 1) : np_uniform(np, -1, -0.1);
                 dir[1] = np_uniform(np, y - d0 > 0 ? -1 : 0, y + d0 < cfg.sy ? 1 : 0);
                 dir[2] = np_uniform(np, z - d0 > 0 ? -1 : 0, z + d0 < cfg.sz ? 1 : 0);
             } else {
-                double x = np_uniform(np, 0, cfg.sx), z = np_uniform(np, 0, cfg.sz);
+                double x = fixed ? fa : np_uniform(np, 0, cfg.sx), z = fixed ? fb : np_uniform(np, 0, cfg.sz);
                 p[0] = x; p[1] = wall == 2 ? 0.0 : cfg.sy - 1e-6; p[2] = z;
                 dir[0] = np_uniform(np, x - d0 > 0 ? -1 : 0, x + d0 < cfg.sx ? 1 : 0);
                 dir[1] = wall == 2 ? np_uniform(np, 0.1, 1) : np_uniform(np, -1, -0.1);

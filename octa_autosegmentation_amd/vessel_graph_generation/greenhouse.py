@@ -25,7 +25,8 @@ class SimConfigStruct(ctypes.Structure):
                 ("rotation_radius", ctypes.c_double), ("faz_center", ctypes.c_double * 2),
                 ("size", ctypes.c_double * 3), ("n_trees", ctypes.c_int), ("walls", ctypes.c_int * 4),
                 ("n_modes", ctypes.c_int), ("modes", (ctypes.c_double * 13) * 8),
-                ("forest_type", ctypes.c_int), ("nerve_center", ctypes.c_double * 2), ("nerve_radius", ctypes.c_double)]
+                ("forest_type", ctypes.c_int), ("nerve_center", ctypes.c_double * 2), ("nerve_radius", ctypes.c_double),
+                ("geometry", ctypes.c_void_p), ("geometry_shape", ctypes.c_int * 3)]
 
 
 REQ_DTYPE = np.dtype([("sample", np.int32), ("n", np.int32), ("pos", np.float64, 3), ("r", np.float64),
@@ -38,8 +39,6 @@ def config_to_struct(config):
     g, f = config["Greenhouse"], config["Forest"]
     if f["type"] not in ("stumps", "nerve"):
         raise NotImplementedError(f"The Forest initialization type '{f['type']}' is not implemented. Try 'stumps' or 'nerve' instead.")
-    if g["SimulationSpace"].get("oxygen_sample_geometry_path") is not None:
-        raise NotImplementedError("fixed-geometry simulation spaces (oxygen_sample_geometry_path) are not on the GPU path yet")
     walls = f["source_walls"]
     if walls.get("z0") or walls.get("z1"):
         raise NotImplementedError("z source walls are not on the GPU path yet")
@@ -55,6 +54,16 @@ def config_to_struct(config):
     p.n_trees = f["N_trees"]
     for i, k in enumerate(("x0", "x1", "y0", "y1")):
         p.walls[i] = 1 if walls.get(k) else 0
+    geo_path = g["SimulationSpace"].get("oxygen_sample_geometry_path")
+    if geo_path is not None:     # simulation_space.py:29-34: the sink-sampling mask (and the space's extent) come from a .npy file
+        geo = np.ascontiguousarray(np.load(geo_path) != 0, dtype=np.uint8)
+        if geo.shape != (76, 76, 1):
+            raise NotImplementedError(f"sampling geometries other than [76, 76, 1] masks are not on the GPU path (got {geo.shape})")
+        if f["type"] != "stumps":
+            raise NotImplementedError("a sampling geometry with nerve forests is not on the GPU path")
+        p._geometry_keepalive = geo          # the struct only carries the pointer
+        p.geometry = geo.ctypes.data
+        p.geometry_shape[0], p.geometry_shape[1], p.geometry_shape[2] = geo.shape
     p.forest_type = 1 if f["type"] == "nerve" else 0
     p.nerve_center[0], p.nerve_center[1] = g["nerve_center"]
     p.nerve_radius = g["nerve_radius"]

@@ -370,6 +370,8 @@ struct octa_sim_params {
     double modes[8][13];  // I, N, eps_n, eps_s, eps_k, delta_art, delta_ven, gamma_art, gamma_ven, phi, omega, kappa, delta_sigma
     int forest_type;      // 0 'stumps' (forest.py:68-181), 1 'nerve' (forest.py:38-66)
     double nerve_center[2], nerve_radius;   // as configured (greenhouse.py:28-29 divides them by param_scale)
+    const unsigned char *geometry;          // oxygen_sample_geometry_path mask [76][76][1] or NULL (simulation_space.py:29-34)
+    int geometry_shape[3];
 };
 
 struct octa_sim_result {
@@ -405,7 +407,10 @@ int octa_oracle_simulate(const octa_sim_params *P, uint32_t np_seed, uint64_t py
     const double fc0 = P->faz_center[0], fc1 = P->faz_center[1];
     // ---- SimulationSpace.__init__ (simulation_space.py:36-54), no nerve disc for the docker config
     const int GS = 76;
-    const double sx = P->size[0], sy = P->size[1], sz = P->size[2];
+    const bool fixed = P->geometry != nullptr;
+    if (fixed && (P->geometry_shape[0] != GS || P->geometry_shape[1] != GS || P->geometry_shape[2] != 1)) return -4;
+    // fixed geometry: shape = geometry.shape / max(geometry.shape) (simulation_space.py:31-33)
+    const double sx = fixed ? 1.0 : P->size[0], sy = fixed ? 1.0 : P->size[1], sz = fixed ? 1.0 / GS : P->size[2];
     const int gy = (int)std::ceil(sx * GS), gx = (int)std::ceil(sy * GS);
     const double fcx = fc0 * GS, fcy = fc1 * GS, fr = FAZ_radius * GS * 0.5;
     // greenhouse.py:28-29, simulation_space.py:48-50: the optic-nerve disc leaves the mask when it is inside the field of view
@@ -413,6 +418,14 @@ int octa_oracle_simulate(const octa_sim_params *P, uint32_t np_seed, uint64_t py
     const bool disc = (nerve_c0 - nerve_r <= 1.0) && (nerve_c1 - nerve_r <= 1.0);
     const double ncx = nerve_c0 * GS, ncy = nerve_c1 * GS, nrr = nerve_r * GS;
     std::vector<std::array<int, 2>> valid;
+    std::vector<int> face_x, face_y;   // simulation_space.py:70-76: valid voxels of face 0 along axis 0 / axis 1
+    if (fixed) {
+        for (int i = 0; i < GS; i++)
+            for (int j = 0; j < GS; j++)
+                if (P->geometry[(size_t)i * GS + j]) valid.push_back({i, j});
+        for (int j = 0; j < GS; j++) if (P->geometry[j]) face_x.push_back(j);
+        for (int i = 0; i < GS; i++) if (P->geometry[(size_t)i * GS]) face_y.push_back(i);
+    } else
     for (int i = 0; i < gy; i++)
         for (int j = 0; j < gx; j++) {
             bool ok = (j - fcx) * (j - fcx) + (i - fcy) * (i - fcy) > fr * fr;
@@ -463,15 +476,24 @@ int octa_oracle_simulate(const octa_sim_params *P, uint32_t np_seed, uint64_t py
             int wall = walls[py.randbelow((uint32_t)walls.size())];
             V3 pos, dir;
             const double d0 = d;
+            double fa = 0, fb = 0;
+            if (fixed) {   // get_random_valid_position: random.choice over the face's valid voxels + np.random.uniform(0, 1, 3)
+                const std::vector<int> &face = (wall == 0 || wall == 1) ? face_x : face_y;
+                if (face.empty()) return -3;
+                const int v = face[py.randbelow((uint32_t)face.size())];
+                const double u0 = np.uniform(0, 1), u1 = np.uniform(0, 1), u2 = np.uniform(0, 1);
+                if (wall == 0 || wall == 1) { fa = (v + u1) / GS; fb = (0 + u2) / GS; }
+                else { fa = (v + u0) / GS; fb = (0 + u2) / GS; }
+            }
             if (wall == 0 || wall == 1) {
-                double y = np.uniform(0, sy), z = np.uniform(0, sz);
+                double y = fixed ? fa : np.uniform(0, sy), z = fixed ? fb : np.uniform(0, sz);
                 pos = {wall == 0 ? 0.0 : sx - 1e-6, y, z};
                 double a = wall == 0 ? np.uniform(0.1, 1) : np.uniform(-1, -0.1);
                 double b = np.uniform(y - d0 > 0 ? -1 : 0, y + d0 < sy ? 1 : 0);
                 double c = np.uniform(z - d0 > 0 ? -1 : 0, z + d0 < sz ? 1 : 0);
                 dir = {a, b, c};
             } else {
-                double x = np.uniform(0, sx), z = np.uniform(0, sz);
+                double x = fixed ? fa : np.uniform(0, sx), z = fixed ? fb : np.uniform(0, sz);
                 pos = {x, wall == 2 ? 0.0 : sy - 1e-6, z};
                 double a = np.uniform(x - d0 > 0 ? -1 : 0, x + d0 < sx ? 1 : 0);
                 double b = wall == 2 ? np.uniform(0.1, 1) : np.uniform(-1, -0.1);

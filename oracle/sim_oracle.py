@@ -24,7 +24,8 @@ class SimParams(ctypes.Structure):
                 ("rotation_radius", ctypes.c_double), ("faz_center", ctypes.c_double * 2),
                 ("size", ctypes.c_double * 3), ("n_trees", ctypes.c_int), ("walls", ctypes.c_int * 4),
                 ("n_modes", ctypes.c_int), ("modes", (ctypes.c_double * 13) * 8),
-                ("forest_type", ctypes.c_int), ("nerve_center", ctypes.c_double * 2), ("nerve_radius", ctypes.c_double)]
+                ("forest_type", ctypes.c_int), ("nerve_center", ctypes.c_double * 2), ("nerve_radius", ctypes.c_double),
+                ("geometry", ctypes.c_void_p), ("geometry_shape", ctypes.c_int * 3)]
 
 
 class SimResult(ctypes.Structure):
@@ -103,9 +104,13 @@ def params_from_config(config):
     g, f = config["Greenhouse"], config["Forest"]
     if f["type"] not in ("stumps", "nerve"):
         raise NotImplementedError("oracle covers Forest.type 'stumps' (forest.py:68-181) and 'nerve' (forest.py:38-66)")
-    if g["SimulationSpace"].get("oxygen_sample_geometry_path") is not None:
-        raise NotImplementedError("oracle covers the analytic FAZ geometry (simulation_space.py:36-54)")
     p = SimParams()
+    geo_path = g["SimulationSpace"].get("oxygen_sample_geometry_path")
+    if geo_path is not None:      # simulation_space.py:29-34 ([76, 76, 1] masks)
+        geo = np.ascontiguousarray(np.load(geo_path) != 0, dtype=np.uint8)
+        p._geometry_keepalive = geo
+        p.geometry = geo.ctypes.data
+        p.geometry_shape[0], p.geometry_shape[1], p.geometry_shape[2] = geo.shape
     p.param_scale, p.d, p.r = g["param_scale"], g["d"], g["r"]
     p.faz_radius_mean, p.faz_radius_std = g["FAZ_radius_bound"]
     p.rotation_radius = g["rotation_radius"]

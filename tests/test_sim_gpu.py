@@ -68,6 +68,28 @@ def test_nerve_forest_runs_match_reference_csv(gh, golden):
         gh.simulate_batch(cfg, [0])
 
 
+def test_fixed_geometry_runs_match_reference_csv(gh, golden, tmp_path):
+    """f4: fixed sampling geometry (`oxygen_sample_geometry_path`, simulation_space.py:29-34, 70-76) on the GPU: CSV text and fields
+    identical to the reference's runs with its shipped mask; other mask shapes are rejected loudly."""
+    path = str(tmp_path / "geometry.npy")
+    np.save(path, golden["geometry_mask"])
+    for name in [str(n) for n in golden["names"] if str(n).startswith("geom_")]:
+        seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])
+        cfg = _cfg(golden, i1, i2)
+        cfg["Greenhouse"]["SimulationSpace"]["oxygen_sample_geometry_path"] = path
+        sim = gh.BatchSimulator(cfg, 1)
+        res = sim.run([seed])
+        assert gh.edges_to_csv_text(res.sample_edges(0)).encode() == golden[name + "_csv"].tobytes(), name
+        oxy, co2 = sim.fields(0)
+        assert (oxy == golden[name + "_oxy"]).all() and (co2 == golden[name + "_co2"]).all()
+        sim.close()
+    bad = str(tmp_path / "bad.npy")
+    np.save(bad, np.ones((32, 32, 4), bool))
+    cfg["Greenhouse"]["SimulationSpace"]["oxygen_sample_geometry_path"] = bad
+    with pytest.raises(NotImplementedError):
+        gh.BatchSimulator(cfg, 1)
+
+
 def test_mode_edge_cases(gh, golden):
     for name in ("run_s0_10_5", "run_s5_10_5", "run_s11_20_0", "run_s4_0_12"):
         seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])

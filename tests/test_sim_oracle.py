@@ -57,6 +57,28 @@ def test_nerve_forest_runs_csv_bit_exact(golden):
         assert (info["oxy"] == golden[name + "_oxy"]).all() and (info["co2"] == golden[name + "_co2"]).all()
 
 
+def _geom_cfg(golden, tmp_path, i1, i2):
+    path = str(tmp_path / "geometry.npy")
+    np.save(path, golden["geometry_mask"])
+    cfg = _cfg(golden, i1, i2)
+    cfg["Greenhouse"]["SimulationSpace"]["oxygen_sample_geometry_path"] = path
+    return cfg
+
+
+def test_fixed_geometry_runs_csv_bit_exact(golden, tmp_path):
+    """f4: `oxygen_sample_geometry_path` (simulation_space.py:29-34, 70-76) with the mask the reference ships: the space's extent
+    comes from the mask, stumps start at a random valid voxel of their wall's face, no candidate is rejected."""
+    names = [str(n) for n in golden["names"] if str(n).startswith("geom_")]
+    assert len(names) >= 2
+    for name in names:
+        seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])
+        edges, info = sim_oracle.simulate(_geom_cfg(golden, tmp_path, i1, i2), seed, return_fields=True)
+        assert info["faz_radius"] == float(golden[name + "_faz"])
+        assert (info["trace"] == golden[name + "_trace"]).all(), name
+        assert sim_oracle.edges_to_csv_text(edges).encode() == golden[name + "_csv"].tobytes(), name
+        assert (info["oxy"] == golden[name + "_oxy"]).all() and (info["co2"] == golden[name + "_co2"]).all()
+
+
 def test_full_length_run_sha(golden):
     names = [str(n) for n in golden["names"] if str(n).startswith("full_")]
     if not names:

@@ -116,6 +116,26 @@ def main():
         g[name + "_oxy"] = r["oxy"]
         g[name + "_co2"] = r["co2"]
         print(name, "rows", r["csv"].count("\n") - 1, "oxy", len(r["oxy"]), "co2", len(r["co2"]))
+    # f4: fixed sampling geometry (simulation_space.py:29-34, 70-76) with the mask the reference ships
+    # (vessel_graph_generation/geometries/slab_oxy_sample_3mm.npy, [76, 76, 1]); the mask itself is stored as data
+    geo_path = "/root/reference/vessel_graph_generation/geometries/slab_oxy_sample_3mm.npy"
+    g["geometry_mask"] = np.load(geo_path)
+    for seed, i1, i2 in [(0, 30, 20), (6, 10, 5)]:
+        cfg = copy.deepcopy(base)
+        cfg["Greenhouse"]["SimulationSpace"]["oxygen_sample_geometry_path"] = geo_path
+        cfg["Greenhouse"]["modes"][0]["I"] = i1
+        cfg["Greenhouse"]["modes"][1]["I"] = i2
+        r = run_reference(cfg, seed)
+        name = f"geom_s{seed}_{i1}_{i2}"
+        names.append(name)
+        g[name + "_seed_I"] = np.array([seed, i1, i2])
+        g[name + "_trace"] = r["trace"]
+        g[name + "_faz"] = np.array(r["faz"])
+        g[name + "_n_art"] = np.array(r["n_art"])
+        g[name + "_csv"] = np.frombuffer(r["csv"].encode(), dtype=np.uint8)
+        g[name + "_oxy"] = r["oxy"]
+        g[name + "_co2"] = r["co2"]
+        print(name, "rows", r["csv"].count("\n") - 1, "oxy", len(r["oxy"]), "co2", len(r["co2"]))
     for k, v in keep_old.items():
         g.setdefault(k, v)
         if k.endswith("_seed_I"):
