@@ -461,6 +461,10 @@ struct octa_sim {
     double ms_a = 0, ms_b = 0, ms_total = 0, ms_host_bif = 0;
     long n_a = 0, n_b = 0, n_bif_req = 0;
     size_t bytes = 0;
+    // pinned staging + stream of octa_sim_export_edges
+    void *export_stage = nullptr;
+    size_t export_cap = 0;
+    hipStream_t export_stream = nullptr;
 };
 
 namespace {
@@ -587,6 +591,8 @@ extern "C" void octa_sim_destroy(octa_sim *S) {
     if (S->mail.results) e = hipHostFree(S->mail.results);
     if (S->mail.req_n) e = hipHostFree(S->mail.req_n);
     for (int k = 0; k < 3; k++) if (S->ev[k]) e = hipEventDestroy(S->ev[k]);
+    if (S->export_stage) e = hipHostFree(S->export_stage);
+    if (S->export_stream) e = hipStreamDestroy(S->export_stream);
     (void)e;
     delete S;
 }
@@ -834,29 +840,56 @@ extern "C" int octa_sim_export_edges(octa_sim *S, double *h_edges) {
     if (!S || !S->ran || !h_edges) { octa::set_error("octa_sim_export_edges: run the simulation first"); return -2; }
     OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
     const BatchPtrs &P = S->P;
-    std::vector<double> pos[2], rad[2];
-    std::vector<int> par[2], c0[2], c1[2];
-    std::vector<unsigned char> nch[2];
-    long off = 0;
-    for (int s = 0; s < S->B; s++) {
+    const int B = S->B;
+    // Twelve strided copies (one per node array and forest: B rows of the longest forest's node count, pitch = the per-sample
+    // capacity) into pinned staging + ONE wait, instead of a synchronous hipMemcpy per sample, forest and array (1 536 round
+    // trips per 128-sample batch in round 1).
+    int nmax[2] = {0, 0};
+    for (int s = 0; s < B; s++) for (int f = 0; f < 2; f++) nmax[f] = S->h_sc[s].n_nodes[f] > nmax[f] ? S->h_sc[s].n_nodes[f] : nmax[f];
+    size_t need = 0;
+    for (int f = 0; f < 2; f++) need += (size_t)B * nmax[f] * (24 + 8 + 4 + 4 + 4 + 1) + 64 * 6;
+    if (S->export_cap < need) {
+        if (S->export_stage) { hipError_t e = hipHostFree(S->export_stage); (void)e; S->export_stage = nullptr; S->export_cap = 0; }
+        OCTA_HIP_CHECK(hipHostMalloc(&S->export_stage, need + need / 4));
+        S->export_cap = need + need / 4;
+    }
+    hipStream_t stream = S->export_stream;
+    if (!stream) { OCTA_HIP_CHECK(hipStreamCreateWithFlags(&S->export_stream, hipStreamNonBlocking)); stream = S->export_stream; }
+    char *base = static_cast<char *>(S->export_stage);
+    double *pos[2], *rad[2];
+    int *par[2], *c0[2], *c1[2];
+    unsigned char *nch[2];
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = base + off; off += (bytes + 63) & ~(size_t)63; return p; };
+    for (int f = 0; f < 2; f++) {
+        const size_t n = (size_t)nmax[f];
+        pos[f] = reinterpret_cast<double *>(take((size_t)B * n * 24)); rad[f] = reinterpret_cast<double *>(take((size_t)B * n * 8));
+        par[f] = reinterpret_cast<int *>(take((size_t)B * n * 4)); c0[f] = reinterpret_cast<int *>(take((size_t)B * n * 4));
+        c1[f] = reinterpret_cast<int *>(take((size_t)B * n * 4)); nch[f] = reinterpret_cast<unsigned char *>(take((size_t)B * n));
+        if (n == 0) continue;
+        auto get = [&](void *dst, const void *src, size_t elem, size_t cap_elems) -> hipError_t {
+            return hipMemcpy2DAsync(dst, n * elem, src, cap_elems * elem, n * elem, (size_t)B, hipMemcpyDeviceToHost, stream);
+        };
+        OCTA_HIP_CHECK(get(pos[f], P.npos[f], 24, NCAP)); OCTA_HIP_CHECK(get(rad[f], P.nrad[f], 8, NCAP));
+        OCTA_HIP_CHECK(get(par[f], P.npar[f], 4, NCAP)); OCTA_HIP_CHECK(get(c0[f], P.nch0[f], 4, NCAP));
+        OCTA_HIP_CHECK(get(c1[f], P.nch1[f], 4, NCAP)); OCTA_HIP_CHECK(get(nch[f], P.nnch[f], 1, NCAP));
+    }
+    OCTA_HIP_CHECK(hipStreamSynchronize(stream));
+    long total = 0;
+    for (int s = 0; s < B; s++) {
         const SampleScalars &sc = S->h_sc[s];
+        const double *cp[2], *cr[2];
+        const int *cpar[2], *cc0[2], *cc1[2];
+        const unsigned char *cn[2];
         for (int f = 0; f < 2; f++) {
-            int n = sc.n_nodes[f];
-            pos[f].resize((size_t)n * 3); rad[f].resize(n); par[f].resize(n); c0[f].resize(n); c1[f].resize(n); nch[f].resize(n);
-            OCTA_HIP_CHECK(hipMemcpy(pos[f].data(), P.npos[f] + (size_t)s * NCAP * 3, sizeof(double) * n * 3, hipMemcpyDeviceToHost));
-            OCTA_HIP_CHECK(hipMemcpy(rad[f].data(), P.nrad[f] + (size_t)s * NCAP, sizeof(double) * n, hipMemcpyDeviceToHost));
-            OCTA_HIP_CHECK(hipMemcpy(par[f].data(), P.npar[f] + (size_t)s * NCAP, sizeof(int) * n, hipMemcpyDeviceToHost));
-            OCTA_HIP_CHECK(hipMemcpy(c0[f].data(), P.nch0[f] + (size_t)s * NCAP, sizeof(int) * n, hipMemcpyDeviceToHost));
-            OCTA_HIP_CHECK(hipMemcpy(c1[f].data(), P.nch1[f] + (size_t)s * NCAP, sizeof(int) * n, hipMemcpyDeviceToHost));
-            OCTA_HIP_CHECK(hipMemcpy(nch[f].data(), P.nnch[f] + (size_t)s * NCAP, n, hipMemcpyDeviceToHost));
+            const size_t n = (size_t)nmax[f];
+            cp[f] = pos[f] + (size_t)s * n * 3; cr[f] = rad[f] + (size_t)s * n; cpar[f] = par[f] + (size_t)s * n;
+            cc0[f] = c0[f] + (size_t)s * n; cc1[f] = c1[f] + (size_t)s * n; cn[f] = nch[f] + (size_t)s * n;
         }
-        const double *cp[2] = {pos[0].data(), pos[1].data()}, *cr[2] = {rad[0].data(), rad[1].data()};
-        const int *cpar[2] = {par[0].data(), par[1].data()}, *cc0[2] = {c0[0].data(), c0[1].data()}, *cc1[2] = {c1[0].data(), c1[1].data()};
-        const unsigned char *cn[2] = {nch[0].data(), nch[1].data()};
         long n_art = 0;
-        long ne = export_edges(cp, cr, cpar, cc0, cc1, cn, sc.n_nodes, S->cfg.n_trees, h_edges + 7 * off, 1L << 40, &n_art);
+        long ne = export_edges(cp, cr, cpar, cc0, cc1, cn, sc.n_nodes, S->cfg.n_trees, h_edges + 7 * total, 1L << 40, &n_art);
         if (ne < 0) { octa::set_error("octa_sim_export_edges: export failed"); return -1; }
-        off += ne;
+        total += ne;
     }
     return 0;
 }
