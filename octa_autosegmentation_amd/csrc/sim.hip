@@ -63,6 +63,8 @@ struct BatchPtrs {
     unsigned short *valid;       // [B][76*76*2]
     unsigned *valid_count;       // [B]
     int *n_per_iter;             // [n_iter]
+    int *next_sample;            // [1] work queue of the persistent kernel
+    int n_samples;
     SimConst C;
 };
 
@@ -349,12 +351,9 @@ __device__ inline int uniform_err(const Blk &b, const SimArrays &A) {
     return e;
 }
 
-__global__ void __launch_bounds__(SIM_THREADS)
-sim_persistent_kernel(BatchPtrs B, HostMail M) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int s = blockIdx.x;
+// every iteration of ONE sample (or what is left of them after a park), by one workgroup
+__device__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s, const Blk &b) {
     SimArrays A = sample_arrays(B, s);
-    Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
     int *req_n = b.coll() + 96;
     BifRequest *reqs = M.reqs + (size_t)s * REQ_PER_SAMPLE;
     const double *results = M.results + (size_t)s * REQ_PER_SAMPLE * 6;
@@ -422,13 +421,34 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
         }
         stage = 0;
     }
-    // sign-off: the host leaves its service loop when every workgroup has passed here (or when the launch has completed)
+    // sign-off: the host leaves its service loop when every SAMPLE has passed here (or when the launch has completed)
     b.sync();
     if (b.tid == 0) {
         if (parked_at >= 0) { A.sc->resume_it = parked_stage == 2 ? parked_at + 1 : parked_at; A.sc->resume_stage = parked_stage == 2 ? 0 : 1; A.sc->parked = 1; }
         else if (!skip) A.sc->finished = 1;
         __threadfence_system();
         __hip_atomic_fetch_add(M.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    b.sync();
+}
+
+// Work-queue form: the launch has at most one workgroup per CU (160 KiB of LDS each); a workgroup takes the next sample of the
+// batch from a device counter, runs all of its iterations, and comes back for another. Samples differ by +-10 % in run time
+// and workgroups that park leave early: with one workgroup PER SAMPLE the CUs waited for the hardware dispatcher to place the
+// next launch's workgroups (measured: 76 % of the CU time used with 2-12 launches in flight, whatever their size); resident
+// workgroups that refill themselves only leave the CU idle at the very end of a launch.
+__global__ void __launch_bounds__(SIM_THREADS)
+sim_persistent_kernel(BatchPtrs B, HostMail M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
+    int *next = b.coll() + 104;
+    while (true) {
+        if (b.tid == 0) *next = atomicAdd(B.next_sample, 1);
+        b.sync();
+        const int s = *next;
+        b.sync();
+        if (s >= B.n_samples) break;
+        run_sample(B, M, s, b);
     }
 }
 
@@ -449,6 +469,7 @@ struct octa_sim {
     bool lockstep = false;          // OCTA_SIM_LOCKSTEP=1: two launches per iteration (the round-1 form)
     double mail_timeout_ms = 30000; // OCTA_SIM_MAIL_TIMEOUT_MS: device-side bound on one wait for the host when parking is off
     double park_ms = 3.0;           // OCTA_SIM_PARK_MS: a workgroup that has waited this long for its answer parks (0: never)
+    int grid_cap = 256;             // workgroups per launch of the persistent kernel (one per CU; OCTA_SIM_GRID overrides)
     int test_stall_ms = 0;          // OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once with a ticket pending
     long spin_scans = 4096;         // idle mailbox scans before the service thread starts sleeping 20 us between scans
     double diag_max_gap_ms = 0, diag_max_bif_ms = 0;
@@ -543,6 +564,8 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     rc |= dev_alloc(S, &P.reqs, (size_t)2 * REQ_CAP); rc |= dev_alloc(S, &P.req_count, 4); rc |= dev_alloc(S, &P.bif_results, (size_t)2 * REQ_CAP * 6);
     rc |= dev_alloc(S, &P.mt_state, nb * 625); rc |= dev_alloc(S, &P.valid, nb * 76 * 76 * 2); rc |= dev_alloc(S, &P.valid_count, nb);
     rc |= dev_alloc(S, &P.n_per_iter, S->iters.size() + 1);  // kept for diagnostics
+    rc |= dev_alloc(S, &P.next_sample, 4);
+    P.n_samples = B;
     if (!rc) {
         hipError_t e1 = hipHostMalloc((void **)&S->h_reqs, sizeof(BifRequest) * 2 * REQ_CAP);
         hipError_t e2 = hipHostMalloc((void **)&S->h_results, sizeof(double) * 2 * REQ_CAP * 6);
@@ -561,6 +584,8 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
         if (const char *e = getenv("OCTA_SIM_MAIL_TIMEOUT_MS")) { double v = atof(e); if (v >= 1.0) S->mail_timeout_ms = v; }
         if (const char *e = getenv("OCTA_SIM_TEST_HOST_STALL_MS")) S->test_stall_ms = atoi(e);
         if (const char *e = getenv("OCTA_SIM_PARK_MS")) { double v = atof(e); if (v >= 0.0) S->park_ms = v; }
+        S->grid_cap = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        if (const char *e = getenv("OCTA_SIM_GRID")) { int v = atoi(e); if (v >= 1) S->grid_cap = v; }
         // several ranks per host (one service thread per step in flight and rank): give the cores back sooner
         if (const char *e = getenv("WORLD_SIZE")) { if (atoi(e) > 1) S->spin_scans = 256; }
         if (const char *e = getenv("OCTA_SIM_SPIN_SCANS")) S->spin_scans = atol(e);
@@ -716,8 +741,10 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
         while (true) {
             for (int s = 0; s < 3 * B + 1; s++) M.req_n[s] = 0;
             std::vector<int> seen(B, 0);
+            OCTA_HIP_CHECK(hipMemsetAsync(P.next_sample, 0, sizeof(int), stream));
             OCTA_HIP_CHECK(hipEventRecord(S->ev[0], stream));
-            hipLaunchKernelGGL(sim_persistent_kernel, dim3((unsigned)B), dim3(SIM_THREADS), SIM_LDS, stream, P, M);
+            const int grid = B < S->grid_cap ? B : S->grid_cap;
+            hipLaunchKernelGGL(sim_persistent_kernel, dim3((unsigned)grid), dim3(SIM_THREADS), SIM_LDS, stream, P, M);
             OCTA_HIP_CHECK(hipGetLastError());
             OCTA_HIP_CHECK(hipEventRecord(S->ev[1], stream));
             launches++;
