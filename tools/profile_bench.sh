@@ -12,7 +12,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt
 find $OUT/prof_kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
 grep '"metric"' $OUT/${TAG}_bench_stdout.log | tail -1 > $OUT/${TAG}_bench_line.json
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-train --no-files > $OUT/${TAG}_pmc_$C.log 2>&1
+  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 2 --warmup 1 --inflight 1 --group 1 --no-cpu-baseline --no-train --no-files > $OUT/${TAG}_pmc_$C.log 2>&1
 done
 python - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, collections
