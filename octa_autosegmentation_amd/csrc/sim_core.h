@@ -33,7 +33,8 @@ namespace octa_simk {
 
 constexpr int NCAP = 14336;    // nodes per forest (radii f64 + parent u16 of one forest + a 7.5 KiB side-job area fit the LDS in the ordered pass)
 constexpr int OCAP = 13312;    // live O2 sinks (LDS-resident kd keys bound this)
-constexpr int CCAP = 8192;     // live CO2 sources
+constexpr int CCAP = OCAP;     // live CO2 sources (8192 until a full-length seed -- 953121 -- peaked at 8353; every scratch array the CO2 list
+                               // passes through is sized for OCAP points)
 constexpr int GCAP = 8192;     // nodes with attractors per growth pass
 constexpr int SORTCAP = 16384; // keys per block sort
 constexpr int PCAP = 16384;    // (new node, sink) hit pairs per iteration

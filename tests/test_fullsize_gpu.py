@@ -159,7 +159,7 @@ def test_128_sample_full_length_batch_against_the_oracle(hip_lib_built):
     from octa_autosegmentation_amd.utils import configs
     from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
     cfg = configs.load_generator_config()
-    seeds = list(range(31000, 31128))
+    seeds = list(range(31000, 31127)) + [953121]      # the last one peaks at 8353 live CO2 sources (above round 1's capacity of 8192)
     picks = [0, 17, 38, 59, 64, 90, 111, 127]
     with get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:
         fut = pool.map_async(_oracle_one, [(cfg, seeds[k]) for k in picks])
