@@ -110,6 +110,9 @@ int64_t octa_csv_format_edges(const double *h_edges, int64_t n_edges, char *out,
 int octa_csv_write_file(const char *path, const double *h_edges, int64_t n_edges);
 int64_t octa_csv_count_rows(const char *text, int64_t len);
 int64_t octa_csv_parse_edges(const char *text, int64_t len, double *h_out, int64_t cap_rows);
+/* random.random() called n_draws times, on the state random.getstate() reports (uint32 [625]: 624 words + position): the draws of
+ * the reference's per-edge dropout test (tree2img.py:62,78) replayed without a Python loop. */
+int octa_py_random_advance(uint32_t *state625, int64_t n_draws);
 int octa_png_write_gray8(const char *path, const uint8_t *h_pixels, int width, int height, int level);
 int octa_png_write_bits(const char *path, const uint8_t *h_pixels, int width, int height, int level);
 

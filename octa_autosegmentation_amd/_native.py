@@ -38,6 +38,7 @@ SIGNATURES = {
     "octa_csv_write_file": (c_int, [ctypes.c_char_p, c_void_p, ctypes.c_int64]),
     "octa_csv_count_rows": (ctypes.c_int64, [c_void_p, ctypes.c_int64]),
     "octa_csv_parse_edges": (ctypes.c_int64, [c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64]),
+    "octa_py_random_advance": (c_int, [c_void_p, ctypes.c_int64]),
     "octa_png_write_gray8": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int]),
     "octa_png_write_bits": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int]),
     "octa_background_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),

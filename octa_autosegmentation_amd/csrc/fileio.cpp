@@ -331,6 +331,31 @@ extern "C" int64_t octa_csv_count_rows(const char *text, int64_t len) {
     return n > 0 ? n - 1 : 0;   // minus the header
 }
 
+// CPython's random.random() consumed n times: the MT19937 state as random.getstate() reports it (624 words + position) advanced
+// by 2 n outputs -- for replaying the draws of the reference's per-edge dropout test (tree2img.py:62,78) without a Python loop.
+extern "C" int octa_py_random_advance(uint32_t *state625, int64_t n_draws) {
+    if (!state625 || n_draws < 0) { octa::set_error("octa_py_random_advance: bad arguments"); return -2; }
+    uint32_t *mt = state625;
+    int64_t left = 2 * n_draws;
+    uint32_t pos = mt[624];
+    if (pos > 624) { octa::set_error("octa_py_random_advance: corrupt state"); return -2; }
+    while (left > 0) {
+        if (pos >= 624) {
+            int kk;
+            for (kk = 0; kk < 624 - 397; kk++) { uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            for (; kk < 623; kk++) { uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+            mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            pos = 0;
+        }
+        const int64_t take = left < (int64_t)(624 - pos) ? left : (int64_t)(624 - pos);
+        pos += (uint32_t)take;
+        left -= take;
+    }
+    mt[624] = pos;
+    return 0;
+}
+
 extern "C" int octa_png_write_gray8(const char *path, const uint8_t *h_pixels, int width, int height, int level) {
     if (!path || !h_pixels || width <= 0 || height <= 0) { octa::set_error("octa_png_write_gray8: bad arguments"); return -2; }
     std::vector<unsigned char> png;
