@@ -100,19 +100,25 @@ class GpuSegAugmentation:
                 self.threshold = float(d["threshold"])
             else:
                 raise NotImplementedError(f"transform {name} is not part of the GPU augmentation chain")
-        self.R = np.random.RandomState(seed)
+        # one generator PER random transform, all seeded alike -- what get_data_augmentations does with MONAI's Randomizable objects
+        # (data_transforms.py:606-607) and what data/data_transforms.py's RandFlipd / RandRotate90d / RandRotated do: the fused chain
+        # and the generic per-sample transforms take the same decisions for the same seed (tests/test_training_cli_gpu.py)
+        self.R_flip, self.R_rot90, self.R_rot = (np.random.RandomState(seed) for _ in range(3))
 
     def draw(self, batch):
-        """Per-sample (flip, k, angle) in MONAI's draw order."""
+        """Per-sample (flip, k, angle), every transform drawing from its own stream in the order its `randomize` draws."""
         flip = np.zeros(batch, np.int32)
         k = np.zeros(batch, np.int32)
         ang = np.zeros(batch, np.float32)
         for b in range(batch):
-            flip[b] = self.R.rand() < self.flip_p
-            if self.R.rand() < self.rot90_p:
-                k[b] = self.R.randint(3) + 1
-            if self.R.rand() < self.rot_p:
-                ang[b] = self.R.uniform(-self.rot_range, self.rot_range)
+            flip[b] = self.R_flip.rand() < self.flip_p
+            kk = self.R_rot90.randint(3) + 1
+            if self.R_rot90.rand() < self.rot90_p:
+                k[b] = kk
+            if self.R_rot.rand() < self.rot_p:
+                ang[b] = self.R_rot.uniform(low=-self.rot_range, high=self.rot_range)
+                self.R_rot.uniform(low=0.0, high=0.0)
+                self.R_rot.uniform(low=0.0, high=0.0)
         return flip, k, ang
 
     def _scale_map(self, x):

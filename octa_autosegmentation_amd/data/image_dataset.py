@@ -51,6 +51,57 @@ class ListDataset:
         return self.transform(self.items[i])
 
 
+class FusedGraphSegBatches:
+    """Batch-level form of the segmentation configs' training chain (configs/config_ves_seg-S.yml:28-102) for the common case --
+    graph loader without dropout, then ScaleIntensityd, EnsureChannelFirstd, Resized (bilinear), RandFlipd (both axes), RandRotate90d,
+    RandRotated (zeros padding), AsDiscreted on the label, CastToTyped: a whole mini-batch is rendered by two rasteriser launch
+    sequences (image and label resolution) and augmented by two streaming kernels per tensor (data/gpu_augment.py) instead of a
+    dozen small torch ops per sample and key. Takes the decisions of the generic per-sample transforms for the same seed."""
+
+    NAMES = ["LoadGraphAndFilterByRandomRadiusd", "ScaleIntensityd", "EnsureChannelFirstd", "Resized", "RandFlipd", "RandRotate90d",
+             "RandRotated", "AsDiscreted", "CastToTyped"]
+
+    @staticmethod
+    def applies(aug_config):
+        if [d.get("name") for d in aug_config] != FusedGraphSegBatches.NAMES or not torch.cuda.is_available():
+            return False
+        load, scale, _, resize, flip, rot90, rot, disc, cast = aug_config
+        both = lambda d: list(d.get("keys", [])) == ["image", "label"]
+        size = resize.get("spatial_size", [0, 1])
+        return (both(load) and both(scale) and both(resize) and both(flip) and both(rot90) and both(rot) and both(cast)
+                and list(disc.get("keys", [])) == ["label"] and load.get("max_dropout_prob", 0) == 0 and resize.get("mode") == "bilinear"
+                and size[0] == size[1] and sorted(flip.get("spatial_axis", [])) == [0, 1] and rot.get("padding_mode") == "zeros"
+                and not rot.get("range_y") and not rot.get("range_z") and cast.get("dtype") == "dtype" and rot90.get("max_k", 3) == 3)
+
+    def __init__(self, aug_config, seed, dtype):
+        from .gpu_augment import GpuSegAugmentation
+        self.load = aug_config[0]
+        self.aug = GpuSegAugmentation(aug_config, seed=seed)
+        self.dtype = dtype
+
+    def __call__(self, items):
+        """items: list of {image: csv path, label: csv path, *_path}. -> collated batch dict on the device."""
+        from ..vessel_graph_generation import tree2img
+        from .data_transforms import advance_python_random, load_graph_cached
+        out = {k: [it[k] for it in items] for k in items[0] if k.endswith("_path")}
+        rendered = {}
+        for i, key in enumerate(("image", "label")):
+            graphs = [load_graph_cached(it[key]) for it in items]
+            lo = float(self.load["min_radius"][i])
+            off = np.concatenate(([0], np.cumsum([len(e) for e, _ in graphs]))).astype(np.int64)
+            d_edges = torch.cat([d for _, d in graphs], dim=0) if len(graphs) > 1 else graphs[0][1]
+            rendered[key] = tree2img.rasterize_edges_device(d_edges, off, self.load["image_resolutions"][i], self.load.get("MIP_axis", 2),
+                                                            min_radius=lo, max_radius=1.0)
+        for it in items:                   # random() draws of tree2img.py:62,78 in the loader's order: sample by sample, image then label
+            for i, key in enumerate(("image", "label")):
+                e, _ = load_graph_cached(it[key])
+                lo = float(self.load["min_radius"][i])
+                advance_python_random(int(np.count_nonzero((e[:, 6] >= lo) & (e[:, 6] <= 1.0))) + (1 if i == 0 else 0))
+        mb = self.aug(rendered["image"], rendered["label"])
+        out["image"], out["label"] = mb["image"].to(self.dtype), mb["label"].to(self.dtype)
+        return out
+
+
 def collate(samples):
     out = {}
     for k in samples[0]:
@@ -69,6 +120,7 @@ class DeviceLoader:
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
         self.num_workers, self.prefetch = int(num_workers), prefetch
         self.shard = (0, 1)          # (rank, world): data-parallel ranks take every world-th batch of the SAME permutation
+        self.fused = None            # batch-level transform chain (FusedGraphSegBatches) replacing the per-sample one
 
     def __len__(self):
         return ceil(ceil(len(self.dataset) / self.batch_size) / self.shard[1])
@@ -81,7 +133,10 @@ class DeviceLoader:
         if world > 1:                                                              # same number of steps on every rank
             starts = (starts + starts[: (-len(starts)) % world])[rank::world]
         for i in starts:
-            yield collate([self.dataset[j] for j in order[i:i + self.batch_size]])
+            if self.fused is not None:
+                yield self.fused([self.dataset.items[j] for j in order[i:i + self.batch_size]])
+            else:
+                yield collate([self.dataset[j] for j in order[i:i + self.batch_size]])
 
     def __iter__(self):
         if self.num_workers <= 0 or not torch.cuda.is_available():
@@ -164,5 +219,11 @@ def get_dataset(config: dict, phase: str, batch_size=None, num_workers=None) -> 
         data_set = zipped() if phase == Phase.VALIDATION else UnalignedZipDataset(data, transform, phase)
     else:
         raise NotImplementedError(f"task {task} is outside the MI355X hot path")
-    return DeviceLoader(data_set, batch_size=batch_size or config[phase].get("batch_size") or 1, shuffle=phase != Phase.TEST,
-                        num_workers=1 if num_workers is None else num_workers)
+    loader = DeviceLoader(data_set, batch_size=batch_size or config[phase].get("batch_size") or 1, shuffle=phase != Phase.TEST,
+                          num_workers=1 if num_workers is None else num_workers)
+    aug_config = config[phase]["data_augmentation"]
+    if (isinstance(data_set, ListDataset) and FusedGraphSegBatches.applies(aug_config) and not config["General"].get("generic_loader")
+            and all("blackdict" not in it for it in data_set.items)):
+        loader.fused = FusedGraphSegBatches(aug_config, config["General"].get("seed", 42),
+                                            torch.bfloat16 if amp_train else torch.float32)
+    return loader

@@ -85,6 +85,35 @@ def test_graph_loader_transform_fast_path_equals_reference_path(graphs):
     assert (d2["image"].cpu().numpy() == img2).all() and (d2["label"].cpu().numpy() == lab2).all()
 
 
+def test_fused_batch_loader_equals_the_per_sample_transform_chain(graphs):
+    """configs/config_ves_seg-S.yml's training chain: the batch-level loader (two rasteriser launch sequences + two augmentation
+    kernels per tensor and mini-batch) against the generic per-sample transforms of the registry, same seed, same shuffled order:
+    same random decisions, images within fp32 rounding, labels equal except pixels within rounding of the 0.1 threshold; the
+    global `random` stream ends in the same state."""
+    import torch
+    from octa_autosegmentation_amd.data.image_dataset import get_dataset
+    out, dirs = graphs
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "config_ves_seg-S.yml")))
+    csvs = os.path.join(out, "**", "*.csv")
+    cfg["Train"]["data"] = {"image": {"files": csvs}, "label": {"files": csvs}}
+    cfg["General"].update(amp=False, seed=11)
+    got = {}
+    for generic in (False, True):
+        cfg["General"]["generic_loader"] = generic
+        torch.manual_seed(5); random.seed(5)
+        loader = get_dataset(cfg, "Train", num_workers=0)
+        assert (loader.fused is None) == generic and len(loader) == 2
+        got[generic] = (list(loader), random.random())
+    (fused, r_f), (plain, r_p) = got[False], got[True]
+    assert r_f == r_p
+    for a, b in zip(fused, plain):
+        assert a["image_path"] == b["image_path"] and a["label_path"] == b["label_path"]
+        assert a["image"].shape == b["image"].shape == (4, 1, 1216, 1216) and a["image"].dtype == b["image"].dtype == torch.float32
+        assert (a["image"] - b["image"]).abs().max().item() <= 5e-5
+        assert (a["label"] != b["label"]).float().mean().item() < 1e-4 and set(a["label"].unique().tolist()) <= {0.0, 1.0}
+        assert 0.01 < a["label"].mean().item() < 0.5
+
+
 def _pngs(graph_dirs, root):
     """Validation / test / real_B / background stand-ins: the generated 304x304 images and 1216x1216 labels as flat PNG folders."""
     from PIL import Image
