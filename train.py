@@ -11,6 +11,7 @@ epoch's batches, gradients are averaged with one RCCL all-reduce per optimiser a
 import argparse
 import datetime
 import os
+import sys
 import time
 from copy import deepcopy
 from random import randint
@@ -20,6 +21,7 @@ import torch
 import yaml
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+LAST_RUN = {}        # filled by train(): per-epoch images per second of the last run in this process (read by bench.py)
 
 
 def set_determinism(seed):
@@ -82,7 +84,7 @@ def train(args: argparse.Namespace, config: dict):
         post_transformations_val = get_post_transformation(config, Phase.VALIDATION)
     else:
         val_loader = None
-        print("No validation config. Skipping validation steps.")
+        print("No validation config. Skipping validation steps.", file=sys.stderr)
 
     model = define_model(deepcopy(config), phase=Phase.TRAIN)
     model.initialize_model_and_optimizer(None, init_weights, config, args, scaler, phase=Phase.TRAIN)
@@ -95,6 +97,8 @@ def train(args: argparse.Namespace, config: dict):
         best_metric, best_metric_epoch = -1, -1
 
     total_start = time.time()
+    LAST_RUN.clear()
+    LAST_RUN["imgs_per_s"] = []
     for epoch in range(args.start_epoch, max_epochs):
         t_epoch = time.time()
         epoch_metrics = {"loss": dict()}
@@ -116,8 +120,9 @@ def train(args: argparse.Namespace, config: dict):
         epoch_metrics["loss"] = {f"train_{k}": v / step for k, v in zip(losses.keys(), sums)}
         epoch_metrics["metric"] = metrics.aggregate_and_reset(prefix=Phase.TRAIN)
         main_loss = list(losses.keys())[0]
+        LAST_RUN["imgs_per_s"].append(n_img / (time.time() - t_epoch))
         print(f"epoch {epoch + 1}/{max_epochs}: train {main_loss} {epoch_metrics['loss']['train_' + main_loss]:.4f}, "
-              f"{n_img / (time.time() - t_epoch):.1f} imgs/s", flush=True)
+              f"{LAST_RUN['imgs_per_s'][-1]:.1f} imgs/s", file=sys.stderr, flush=True)
         train_sample_path = val_sample_path = None
         if rank == 0 and (args.save_latest or (epoch + 1) % save_interval == 0):
             train_sample_path = model.plot_sample(visualizer, mini_batch, outputs, suffix="train_latest")
@@ -167,9 +172,9 @@ def train(args: argparse.Namespace, config: dict):
         if dist is not None:
             dist.barrier()
 
-    print(f"Finished training after {str(datetime.timedelta(seconds=time.time() - total_start))}.")
+    print(f"Finished training after {str(datetime.timedelta(seconds=time.time() - total_start))}.", file=sys.stderr)
     if best_metric_epoch > -1:
-        print(f"Best metric: {best_metric} at epoch: {best_metric_epoch}.")
+        print(f"Best metric: {best_metric} at epoch: {best_metric_epoch}.", file=sys.stderr)
     return config["Output"]["save_dir"]
 
 
