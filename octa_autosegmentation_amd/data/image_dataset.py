@@ -92,11 +92,13 @@ class FusedGraphSegBatches:
             d_edges = torch.cat([d for _, d in graphs], dim=0) if len(graphs) > 1 else graphs[0][1]
             rendered[key] = tree2img.rasterize_edges_device(d_edges, off, self.load["image_resolutions"][i], self.load.get("MIP_axis", 2),
                                                             min_radius=lo, max_radius=1.0)
-        for it in items:                   # random() draws of tree2img.py:62,78 in the loader's order: sample by sample, image then label
+        draws = 0                          # random() draws of tree2img.py:62,78 over the mini-batch: per sample one for the dropout probability
+        for it in items:                   # (first key) and one per in-range edge of either key; only their total moves the stream
             for i, key in enumerate(("image", "label")):
                 e, _ = load_graph_cached(it[key])
                 lo = float(self.load["min_radius"][i])
-                advance_python_random(int(np.count_nonzero((e[:, 6] >= lo) & (e[:, 6] <= 1.0))) + (1 if i == 0 else 0))
+                draws += int(np.count_nonzero((e[:, 6] >= lo) & (e[:, 6] <= 1.0))) + (1 if i == 0 else 0)
+        advance_python_random(draws)
         mb = self.aug(rendered["image"], rendered["label"])
         out["image"], out["label"] = mb["image"].to(self.dtype), mb["label"].to(self.dtype)
         return out
