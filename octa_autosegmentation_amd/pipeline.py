@@ -17,7 +17,11 @@ from .vessel_graph_generation import greenhouse, tree2img
 
 
 class TripleGenerator:
-    def __init__(self, config, batch, device_index=None, label_resolution=(1216, 1216), label_min_radius=0.0):
+    def __init__(self, config, batch, device_index=None, label_resolution=(1216, 1216), label_min_radius=0.0, image_mode="cli",
+                 image_min_radius=0.0):
+        """image_mode "cli": arterial and venous edges rendered separately and max-combined, as generate_vessel_graph.py:79-86 writes
+        art_ven_img_gray.png; "loader": ONE render of the whole edge list read back from the CSV text with `image_min_radius`, as the
+        training loader's LoadGraphAndFilterByRandomRadiusd does (data_transforms.py:376-386) -- what a network trained by train.py sees."""
         import torch
         self.config = config
         self.batch = int(batch)
@@ -32,6 +36,8 @@ class TripleGenerator:
         self.label_res = list(label_resolution)
         # the training configs render the label with min_radius[1] = 0.0033 (configs/config_ves_seg-S.yml:38)
         self.label_min_radius = float(label_min_radius)
+        assert image_mode in ("cli", "loader")
+        self.image_mode, self.image_min_radius = image_mode, float(image_min_radius)
         self.time_render = False
 
     def close(self):
@@ -55,17 +61,23 @@ class TripleGenerator:
         mark = (lambda i: ev[i].record()) if ev else (lambda i: None)       # on the current stream = the stream the kernels go to
         d_edges = torch.from_numpy(res.edges).to(self.device, non_blocking=True)
         mark(0)
-        # 2B graphs: arterial_k, venous_k interleaved -> max of the pairs (np.maximum(art_mat, ven_mat))
-        split = np.empty(2 * B + 1, np.int64)
-        split[0::2] = off
-        split[1::2] = off[:-1] + n_art
-        pair = tree2img.rasterize_edges_device(d_edges, split, self.image_res, self.proj_axis)
-        pair = pair.view(B, 2, pair.shape[1], pair.shape[2])
-        image = tree2img.maximum_u8_device(pair[:, 0].contiguous(), pair[:, 1].contiguous())
+        d_rb = None
+        if self.image_mode == "cli":
+            # 2B graphs: arterial_k, venous_k interleaved -> max of the pairs (np.maximum(art_mat, ven_mat))
+            split = np.empty(2 * B + 1, np.int64)
+            split[0::2] = off
+            split[1::2] = off[:-1] + n_art
+            pair = tree2img.rasterize_edges_device(d_edges, split, self.image_res, self.proj_axis)
+            pair = pair.view(B, 2, pair.shape[1], pair.shape[2])
+            image = tree2img.maximum_u8_device(pair[:, 0].contiguous(), pair[:, 1].contiguous())
+        else:
+            d_rb = graph_io.edges_as_read_back_device(d_edges)
+            image = tree2img.rasterize_edges_device(d_rb, off, self.image_res, self.proj_axis, min_radius=self.image_min_radius)
         mark(1)
         out = dict(result=res, image=image)
         if want_label:
-            d_rb = graph_io.edges_as_read_back_device(d_edges)
+            if d_rb is None:
+                d_rb = graph_io.edges_as_read_back_device(d_edges)
             mark(2)
             grey = tree2img.rasterize_edges_device(d_rb, off, self.label_res, 2, min_radius=self.label_min_radius)
             mark(3)

@@ -34,6 +34,26 @@ def test_triples_match_oracle(hip_lib_built):
     gen.close()
 
 
+def test_loader_image_mode_is_one_render_of_the_read_back_graph(hip_lib_built):
+    """image_mode="loader" (the on-the-fly training loops): the image is what LoadGraphAndFilterByRandomRadiusd renders from the CSV file
+    (data_transforms.py:376-386) -- ONE rasterisation of all edges as read back from the text, radius window included -- not the
+    max of separate arterial / venous renders the generator CLI writes."""
+    import torch
+    from octa_autosegmentation_amd import graph_io, pipeline
+    from octa_autosegmentation_amd.utils import configs
+    from oracle import octa_oracle
+    cfg = configs.load_generator_config()
+    cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = 30, 20
+    gen = pipeline.TripleGenerator(cfg, 2, label_min_radius=0.0033, image_mode="loader", image_min_radius=0.001)
+    out = gen.generate([4, 5])
+    torch.cuda.synchronize()
+    for k in range(2):
+        e = graph_io.edges_as_read_back(out["result"].sample_edges(k))
+        assert (out["image"][k].cpu().numpy() == octa_oracle.rasterize(e[e[:, 6] >= 0.001], [304, 304])).all()
+        assert (out["label_grey"][k].cpu().numpy() == octa_oracle.rasterize(e[e[:, 6] >= 0.0033], [1216, 1216])).all()
+    gen.close()
+
+
 def test_device_read_back_matches_host_emulation(hip_lib_built):
     import torch
     from octa_autosegmentation_amd import graph_io

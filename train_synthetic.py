@@ -83,13 +83,13 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
         # tiles are not in the repository: uniform-noise stand-ins of the same shape (data = synthetic, as everywhere here).
         from octa_autosegmentation_amd.models.gan_seg_trainer import GanSegTrainer
         aug_cfg = GAN_CONFIG["Train"]["data_augmentation"]
-        gen = pipeline.TripleGenerator(load_sim_config(), gen_batch, label_resolution=[1216, 1216], label_min_radius=0)
+        gen = pipeline.TripleGenerator(load_sim_config(), gen_batch, label_resolution=[1216, 1216], label_min_radius=0, image_mode="loader")
         trainer = GanSegTrainer(GAN_CONFIG, dev)
     else:
         aug_cfg = SEG_CONFIG["Train"]["data_augmentation"]
         loader = aug_cfg[0]
         gen = pipeline.TripleGenerator(load_sim_config(), gen_batch, label_resolution=loader["image_resolutions"][1],
-                                       label_min_radius=loader["min_radius"][1])
+                                       label_min_radius=loader["min_radius"][1], image_mode="loader", image_min_radius=loader["min_radius"][0])
         trainer = SegmentationTrainer(SEG_CONFIG, dev)
     aug = GpuSegAugmentation(aug_cfg, seed=1234 + rank)
     noise = torch.Generator(device=dev).manual_seed(99 + rank)
