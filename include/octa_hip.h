@@ -422,6 +422,16 @@ void octa_sim_destroy(octa_sim *sim);
 int octa_sim_run(octa_sim *sim, const uint32_t *h_np_seeds, const uint64_t *h_py_seeds, octa_bif_fn bif, void *user,
                  void *stream);
 
+/* The same run for samples whose random generators stand where a CALLER's do -- the object API of the reference (Greenhouse(...),
+ * Forest(...) x 2, develop_forest(), generate_vessel_graph.py:24-39) draws the FAZ radius and the stump nodes from the global numpy /
+ * CPython generators in its constructors; the adapters do the same in Python and hand over: h_faz_radius [B]; h_stumps
+ * [B][2 forests][2 * N_trees][3] (root, stump child per tree; arterial forest first); the generators' MT19937 states afterwards,
+ * [B][625] each (624 words + position, as np.random.get_state() / random.getstate() report them). octa_sim_np_state returns numpy's
+ * state after the run (CPython's then stands octa_sim_stats' `random.uniform draws` column of random.random() draws further). */
+int octa_sim_run_states(octa_sim *sim, const double *h_faz_radius, const double *h_stumps, const uint32_t *h_np_states,
+                        const uint32_t *h_py_states, octa_bif_fn bif, void *user, void *stream);
+int octa_sim_np_state(octa_sim *sim, int sample, uint32_t *h_state625);
+
 /* After octa_sim_run: per-sample edge offsets (h_edge_off[B+1]) and arterial edge counts (h_n_art[B]). */
 int octa_sim_edge_offsets(octa_sim *sim, int64_t *h_edge_off, int64_t *h_n_art);
 

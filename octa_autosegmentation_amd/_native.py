@@ -2,7 +2,10 @@
 import contextlib
 import ctypes
 import os
+import random as _random
 import threading
+
+import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboctahip.so")
@@ -46,6 +49,8 @@ SIGNATURES = {
     "octa_sim_create": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
     "octa_sim_destroy": (None, [c_void_p]),
     "octa_sim_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "octa_sim_run_states": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "octa_sim_np_state": (c_int, [c_void_p, c_int, c_void_p]),
     "octa_sim_edge_offsets": (c_int, [c_void_p, c_void_p, c_void_p]),
     "octa_sim_export_edges": (c_int, [c_void_p, c_void_p]),
     "octa_sim_stats": (c_int, [c_void_p, c_void_p]),
@@ -191,3 +196,17 @@ def ctx(device_index=None):
 def current_stream_ptr():
     import torch
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def advance_python_random(n):
+    """`random.random()` n times, natively (same final state of the global generator as the Python loop)."""
+    if n <= 0:
+        return
+    if n < 64:
+        for _ in range(n):
+            _random.random()
+        return
+    ver, state, gauss = _random.getstate()
+    arr = np.array(state, dtype=np.uint32)
+    check(lib().octa_py_random_advance(arr.ctypes.data, int(n)), "octa_py_random_advance")
+    _random.setstate((ver, tuple(arr.tolist()), gauss))

@@ -622,9 +622,53 @@ extern "C" void octa_sim_destroy(octa_sim *S) {
     delete S;
 }
 
+namespace {
+// what differs between the entry points: how sample s gets its FAZ radius, stump nodes and generator states
+struct SampleSource {
+    const uint32_t *np_seeds = nullptr;
+    const uint64_t *py_seeds = nullptr;
+    const double *faz = nullptr, *stumps = nullptr;        // [B], [B][2][2 * n_trees][3]
+    const uint32_t *np_states = nullptr, *py_states = nullptr;   // [B][625] each: 624 words + position
+    void fill(const SimConfig &cfg, int s, SampleInit *I) const {
+        if (np_seeds) { init_sample(cfg, np_seeds[s], py_seeds[s], I); return; }
+        Mt19937 np, py;
+        memcpy(np.mt, np_states + (size_t)s * 625, 624 * 4); np.idx = (int)np_states[(size_t)s * 625 + 624];
+        memcpy(py.mt, py_states + (size_t)s * 625, 624 * 4); py.idx = (int)py_states[(size_t)s * 625 + 624];
+        const size_t n = (size_t)2 * cfg.n_trees * 3;
+        init_sample_given(cfg, faz[s], stumps + (size_t)s * 2 * n, stumps + (size_t)s * 2 * n + n, np, py, I);
+    }
+};
+int sim_run_impl(octa_sim *S, const SampleSource &src, octa_bif_fn bif, void *user, void *stream_);
+}  // namespace
+
 extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint64_t *h_py_seeds, octa_bif_fn bif, void *user,
                             void *stream_) {
     if (!S || !h_np_seeds || !h_py_seeds || !bif) { octa::set_error("octa_sim_run: bad arguments"); return -2; }
+    SampleSource src;
+    src.np_seeds = h_np_seeds; src.py_seeds = h_py_seeds;
+    return sim_run_impl(S, src, bif, user, stream_);
+}
+
+extern "C" int octa_sim_run_states(octa_sim *S, const double *h_faz_radius, const double *h_stumps, const uint32_t *h_np_states,
+                                   const uint32_t *h_py_states, octa_bif_fn bif, void *user, void *stream_) {
+    if (!S || !h_faz_radius || !h_stumps || !h_np_states || !h_py_states || !bif) { octa::set_error("octa_sim_run_states: bad arguments"); return -2; }
+    for (int s = 0; s < S->B; s++)
+        if (h_np_states[(size_t)s * 625 + 624] > 624 || h_py_states[(size_t)s * 625 + 624] > 624) { octa::set_error("octa_sim_run_states: corrupt generator state"); return -2; }
+    SampleSource src;
+    src.faz = h_faz_radius; src.stumps = h_stumps; src.np_states = h_np_states; src.py_states = h_py_states;
+    return sim_run_impl(S, src, bif, user, stream_);
+}
+
+// numpy's generator of sample `sample` after the run: 624 words + position (the candidate stream is its only consumer)
+extern "C" int octa_sim_np_state(octa_sim *S, int sample, uint32_t *h_state625) {
+    if (!S || !S->ran || !h_state625 || sample < 0 || sample >= S->B) { octa::set_error("octa_sim_np_state: bad arguments"); return -2; }
+    OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
+    OCTA_HIP_CHECK(hipMemcpy(h_state625, S->P.mt_state + (size_t)sample * 625, 625 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+namespace {
+int sim_run_impl(octa_sim *S, const SampleSource &src, octa_bif_fn bif, void *user, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
     const int B = S->B;
@@ -641,7 +685,7 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
         std::vector<double> npos((size_t)B * 2 * n0 * 3);
         SampleInit I;
         for (int s = 0; s < B; s++) {
-            init_sample(S->cfg, h_np_seeds[s], h_py_seeds[s], &I);
+            src.fill(S->cfg, s, &I);
             memset(&sc[s], 0, sizeof(SampleScalars));
             sc[s].faz_radius = I.faz_radius;
             sc[s].py_cap = PYCAP;
@@ -850,6 +894,7 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
         }
     return 0;
 }
+}  // namespace
 
 extern "C" int octa_sim_edge_offsets(octa_sim *S, int64_t *h_edge_off, int64_t *h_n_art) {
     if (!S || !S->ran || !h_edge_off) { octa::set_error("octa_sim_edge_offsets: run the simulation first"); return -2; }

@@ -181,6 +181,52 @@ struct SampleInit {
     int n_nodes[2];
 };
 
+// sink-sampling mask of one sample (simulation_space.py:36-54) and, for a fixed geometry, the valid voxels of the wall faces
+inline void init_mask(const SimConfig &cfg, double faz_radius, SampleInit *S, std::vector<int> *face_x, std::vector<int> *face_y) {
+    const double ps = cfg.param_scale;
+    const int GS = 76;
+    const int gy = (int)std::ceil(cfg.sx * GS), gx = (int)std::ceil(cfg.sy * GS);
+    const double fcx = cfg.fc0 * GS, fcy = cfg.fc1 * GS, fr = faz_radius * GS * 0.5;
+    // optic-nerve disc: cut out of the mask only when it lies inside the field of view (simulation_space.py:48-50:
+    // `all(nerve_center - nerve_radius <= 1)` on the values already divided by param_scale)
+    const double nerve_c0 = cfg.nc0 / ps, nerve_c1 = cfg.nc1 / ps, nerve_r = cfg.nr / ps;
+    const bool disc = (nerve_c0 - nerve_r <= 1.0) && (nerve_c1 - nerve_r <= 1.0);
+    const double ncx = nerve_c0 * GS, ncy = nerve_c1 * GS, nrr = nerve_r * GS;
+    S->valid.clear();
+    face_x->clear(); face_y->clear();
+    if (!cfg.geometry.empty()) {      // simulation_space.py:29-34: the mask comes from the geometry file
+        for (int i = 0; i < GS; i++)
+            for (int j = 0; j < GS; j++)
+                if (cfg.geometry[(size_t)i * GS + j]) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); }
+        for (int j = 0; j < GS; j++) if (cfg.geometry[j]) face_x->push_back(j);
+        for (int i = 0; i < GS; i++) if (cfg.geometry[(size_t)i * GS]) face_y->push_back(i);
+        return;
+    }
+    for (int i = 0; i < gy; i++)
+        for (int j = 0; j < gx; j++) {
+            bool ok = (j - fcx) * (j - fcx) + (i - fcy) * (i - fcy) > fr * fr;
+            if (ok && disc) ok = (j - ncx) * (j - ncx) + (i - ncy) * (i - ncy) > nrr * nrr;
+            if (ok) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); }
+        }
+}
+
+// a sample whose generators stand where the caller's do: FAZ radius and stump nodes already drawn (the Greenhouse / Forest
+// adapters draw them from the global numpy / CPython generators exactly as the reference's constructors do), `np` / `py` = the
+// generators' states afterwards
+inline void init_sample_given(const SimConfig &cfg, double faz_radius, const double *pos_art, const double *pos_ven, const Mt19937 &np,
+                              Mt19937 py, SampleInit *S) {
+    std::vector<int> fx, fy;
+    S->np_state = np;
+    S->faz_radius = faz_radius;
+    init_mask(cfg, faz_radius, S, &fx, &fy);
+    const size_t n = (size_t)2 * cfg.n_trees * 3;
+    S->pos[0].assign(pos_art, pos_art + n);
+    S->pos[1].assign(pos_ven, pos_ven + n);
+    S->n_nodes[0] = S->n_nodes[1] = 2 * cfg.n_trees;
+    S->py_u.resize(PYCAP);
+    for (int i = 0; i < PYCAP; i++) S->py_u[i] = py.next_double();
+}
+
 inline void init_sample(const SimConfig &cfg, uint32_t np_seed, uint64_t py_seed_v, SampleInit *S) {
     Mt19937 &np = S->np_state;
     Mt19937 py;
@@ -190,29 +236,10 @@ inline void init_sample(const SimConfig &cfg, uint32_t np_seed, uint64_t py_seed
     const double d0 = cfg.d / ps;
     S->faz_radius = np_normal_first(np, cfg.faz_mean / ps, cfg.faz_std / ps);
     const int GS = 76;
-    const int gy = (int)std::ceil(cfg.sx * GS), gx = (int)std::ceil(cfg.sy * GS);
-    const double fcx = cfg.fc0 * GS, fcy = cfg.fc1 * GS, fr = S->faz_radius * GS * 0.5;
-    // optic-nerve disc: cut out of the mask only when it lies inside the field of view (simulation_space.py:48-50:
-    // `all(nerve_center - nerve_radius <= 1)` on the values already divided by param_scale)
     const double nerve_c0 = cfg.nc0 / ps, nerve_c1 = cfg.nc1 / ps, nerve_r = cfg.nr / ps;
-    const bool disc = (nerve_c0 - nerve_r <= 1.0) && (nerve_c1 - nerve_r <= 1.0);
-    const double ncx = nerve_c0 * GS, ncy = nerve_c1 * GS, nrr = nerve_r * GS;
-    S->valid.clear();
-    const bool fixed = !cfg.geometry.empty();      // simulation_space.py:29-34: the mask comes from the geometry file
+    const bool fixed = !cfg.geometry.empty();
     std::vector<int> face_x, face_y;               // valid voxels of face 0 along axis 0 (index j) and axis 1 (index i)
-    if (fixed) {
-        for (int i = 0; i < GS; i++)
-            for (int j = 0; j < GS; j++)
-                if (cfg.geometry[(size_t)i * GS + j]) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); }
-        for (int j = 0; j < GS; j++) if (cfg.geometry[j]) face_x.push_back(j);
-        for (int i = 0; i < GS; i++) if (cfg.geometry[(size_t)i * GS]) face_y.push_back(i);
-    } else
-    for (int i = 0; i < gy; i++)
-        for (int j = 0; j < gx; j++) {
-            bool ok = (j - fcx) * (j - fcx) + (i - fcy) * (i - fcy) > fr * fr;
-            if (ok && disc) ok = (j - ncx) * (j - ncx) + (i - ncy) * (i - ncy) > nrr * nrr;
-            if (ok) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); }
-        }
+    init_mask(cfg, S->faz_radius, S, &face_x, &face_y);
     std::vector<int> walls;
     for (int w = 0; w < 4; w++) if (cfg.walls[w]) walls.push_back(w);
     for (int f = 0; f < 2; f++) {

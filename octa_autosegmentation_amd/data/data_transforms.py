@@ -19,6 +19,7 @@ import random as _py_random
 import numpy as np
 import torch
 
+from .._native import advance_python_random
 from ..vessel_graph_generation import tree2img
 from ..vessel_graph_generation.tree2img import rasterize_forest
 
@@ -42,21 +43,6 @@ def load_graph_cached(path):
             _GRAPH_CACHE.pop(next(iter(_GRAPH_CACHE)))
         _GRAPH_CACHE[key] = hit
     return hit
-
-
-def advance_python_random(n):
-    """`random.random()` n times, natively (same final state of the global generator as the Python loop)."""
-    if n <= 0:
-        return
-    if n < 64:
-        for _ in range(n):
-            _py_random.random()
-        return
-    from .. import _native
-    ver, state, gauss = _py_random.getstate()
-    arr = np.array(state, dtype=np.uint32)
-    _native.check(_native.lib().octa_py_random_advance(arr.ctypes.data, int(n)), "octa_py_random_advance")
-    _py_random.setstate((ver, tuple(arr.tolist()), gauss))
 
 
 def _as_keys(keys):

@@ -272,6 +272,9 @@ class BatchSimulator:
         py = np.ascontiguousarray(seeds if py_seeds is None else py_seeds, dtype=np.uint64)
         rc = self._lib.octa_sim_run(self._h, seeds.ctypes.data, py.ctypes.data, self._bif_fn, None, _native.current_stream_ptr())
         _native.check(rc, "octa_sim_run")
+        return self._collect()
+
+    def _collect(self):
         off = np.zeros(self.batch + 1, np.int64)
         n_art = np.zeros(self.batch, np.int64)
         _native.check(self._lib.octa_sim_edge_offsets(self._h, off.ctypes.data, n_art.ctypes.data), "octa_sim_edge_offsets")
@@ -297,6 +300,28 @@ class BatchSimulator:
         return oxy[: no.value].copy(), co2[: nc.value].copy()
 
 
+    def run_from_states(self, faz_radius, stumps, np_states, py_states):
+        """One run for samples whose generators stand where a caller's do (octa_sim_run_states): faz_radius [B], stumps
+        [B][2][2 N_trees][3], np_states / py_states [B][625] uint32."""
+        faz = np.ascontiguousarray(faz_radius, dtype=np.float64)
+        st = np.ascontiguousarray(stumps, dtype=np.float64)
+        nps = np.ascontiguousarray(np_states, dtype=np.uint32)
+        pys = np.ascontiguousarray(py_states, dtype=np.uint32)
+        if faz.shape != (self.batch,) or st.shape != (self.batch, 2, 2 * self._cfg.n_trees, 3) or nps.shape != (self.batch, 625) \
+                or pys.shape != (self.batch, 625):
+            raise ValueError("run_from_states: array shapes do not match the batch / the forest configuration")
+        rc = self._lib.octa_sim_run_states(self._h, faz.ctypes.data, st.ctypes.data, nps.ctypes.data, pys.ctypes.data, self._bif_fn, None,
+                                           _native.current_stream_ptr())
+        _native.check(rc, "octa_sim_run_states")
+        return self._collect()
+
+    def np_state(self, k):
+        """numpy's MT19937 state of sample k after the run: 624 words + position."""
+        out = np.zeros(625, np.uint32)
+        _native.check(self._lib.octa_sim_np_state(self._h, int(k), out.ctypes.data), "octa_sim_np_state")
+        return out
+
+
 def simulate_batch(config, seeds, device_index=None):
     sim = BatchSimulator(config, len(seeds), device_index)
     try:
@@ -309,3 +334,72 @@ def edges_to_csv_text(edges):
     """CSV text exactly as generate_vessel_graph.py:59-66 writes it (graph_io: native formatter)."""
     from .. import graph_io
     return graph_io.edges_to_csv_text(edges)
+
+
+class Greenhouse:
+    """The reference's object API (vessel_graph_generation/greenhouse.py:15-75; use: generate_vessel_graph.py:24-39):
+
+        greenhouse = Greenhouse(config['Greenhouse'])
+        art = Forest(config['Forest'], greenhouse.d, greenhouse.r, greenhouse.simspace, nerve_center=..., nerve_radius=...)
+        ven = Forest(..., arterial=False, ...)
+        greenhouse.set_forests(art, ven); greenhouse.develop_forest()
+
+    The constructors consume the GLOBAL numpy / CPython generators exactly as the reference's do (FAZ radius, stump nodes);
+    develop_forest() hands the generators' current states to the device, grows both forests there (one sample), loads the trees back
+    into the Forest objects and leaves both global generators where the reference leaves them. For throughput use BatchSimulator
+    (B samples per launch); this class is the one-sample drop-in."""
+
+    def __init__(self, config):
+        from .simulation_space import SimulationSpace
+        self.config = config
+        self.modes = config["modes"]
+        self.sigma_t = 1
+        self.param_scale = config["param_scale"]
+        self.d = config["d"] / self.param_scale
+        self.r = config["r"] / self.param_scale
+        self.FAZ_radius = np.random.normal(config["FAZ_radius_bound"][0] / self.param_scale, config["FAZ_radius_bound"][1] / self.param_scale)
+        self.rotation_radius = config["rotation_radius"] / self.param_scale
+        self.FAZ_center = config["FAZ_center"]
+        self.nerve_center = np.array(config["nerve_center"]) / self.param_scale
+        self.nerve_radius = np.array(config["nerve_radius"]) / self.param_scale
+        self.simspace = SimulationSpace(config["SimulationSpace"], self.FAZ_center, self.FAZ_radius, nerve_center=self.nerve_center,
+                                        nerve_radius=self.nerve_radius)
+        self.arterial_forest = self.venous_forest = None
+        self.init_params_from_config(self.modes[0])
+
+    def init_params_from_config(self, config):
+        for key in MODE_KEYS:
+            setattr(self, key, config[key])
+        self.sigma_t = 1
+
+    def set_forests(self, arterialForest, venousForest=None):
+        self.arterial_forest = arterialForest
+        self.venous_forest = venousForest
+
+    def develop_forest(self):
+        import random
+        if self.arterial_forest is None or self.venous_forest is None:
+            raise NotImplementedError("the GPU simulator grows the arterial and the venous forest together: set_forests(arterial, venous)")
+        config = {"Greenhouse": self.config, "Forest": self.arterial_forest.config}
+        kind, key, pos, has_gauss, _ = np.random.get_state()
+        if kind != "MT19937":
+            raise RuntimeError("numpy's global generator is not MT19937")
+        ver, py_state, gauss_next = random.getstate()
+        stumps = np.stack([self.arterial_forest._stump_array(), self.venous_forest._stump_array()])[None]
+        sim = BatchSimulator(config, 1)
+        try:
+            res = sim.run_from_states([self.FAZ_radius], stumps, np.append(np.asarray(key, np.uint32), np.uint32(pos))[None],
+                                      np.asarray(py_state, np.uint32)[None])
+            after = sim.np_state(0)
+            self.oxys, self.co2s = sim.fields(0)
+        finally:
+            sim.close()
+        self.result = res
+        art, ven = res.arterial_venous(0)
+        kappa = self.modes[-1]["kappa"]
+        self.arterial_forest._load_rows(art, kappa)
+        self.venous_forest._load_rows(ven, kappa)
+        # the generators continue where the reference's stand after its loop: numpy's stream was consumed on the device, CPython's by
+        # `random.uniform draws` draws of random.random() (the cached second normal of FAZ_radius' np.random.normal stays cached)
+        np.random.set_state((kind, after[:624], int(after[624]), has_gauss, _))
+        _native.advance_python_random(int(res.stats[0, 1]))
