@@ -445,6 +445,11 @@ int octa_sim_export_edges(octa_sim *sim, double *h_edges);
  * 4 O2->CO2, 6 assign-ven, 7 speculate-ven, 8 ordered-ven, 9 CO2 removal), then 8 timers of the kd-order build. */
 int octa_sim_stats(octa_sim *sim, int64_t *h_stats);
 
+/* When each sample held a CU (persistent form): h_spans[B][2] = the GPU's 100 MHz wall clock when a workgroup first took the sample
+ * and when it last left it. The clock is common to all launches on the device, so spans of concurrent launches can be laid over
+ * each other: sum of spans / (CUs x window) = the share of CU time the simulator used (bench.py's cu_time_used). */
+int octa_sim_spans(octa_sim *sim, int64_t *h_spans);
+
 /* Timing of the last octa_sim_run, h_out8: [0] sum of launch-A kernel durations (ms, HIP events on
  * the launch stream), [1] launches A, [2] sum of launch-B durations (ms), [3] launches B, [4] wall ms
  * of the iteration loop, [5] host ms spent in the bifurcation callback, [6] requests served,

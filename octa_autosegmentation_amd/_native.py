@@ -51,6 +51,7 @@ SIGNATURES = {
     "octa_sim_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "octa_sim_run_states": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "octa_sim_np_state": (c_int, [c_void_p, c_int, c_void_p]),
+    "octa_sim_spans": (c_int, [c_void_p, c_void_p]),
     "octa_sim_edge_offsets": (c_int, [c_void_p, c_void_p, c_void_p]),
     "octa_sim_export_edges": (c_int, [c_void_p, c_void_p]),
     "octa_sim_stats": (c_int, [c_void_p, c_void_p]),

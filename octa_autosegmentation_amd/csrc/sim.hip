@@ -362,7 +362,10 @@ __device__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s, c
     // where this sample stands: a fresh sample starts at (0, 0); a parked one resumes behind the mailbox it parked at (its
     // answer is in M.results, written by the host before this launch); finished or failed samples only sign off
     int *uni = b.coll() + 99;
-    if (b.tid == 0) { uni[0] = A.sc->resume_it; uni[1] = A.sc->resume_stage; uni[2] = A.sc->finished | (A.sc->err != 0); A.sc->parked = 0; }
+    if (b.tid == 0) {
+        uni[0] = A.sc->resume_it; uni[1] = A.sc->resume_stage; uni[2] = A.sc->finished | (A.sc->err != 0); A.sc->parked = 0;
+        if (A.sc->t_begin == 0) A.sc->t_begin = t_kernel;
+    }
     b.sync();
     const int it0 = uni[0];
     int stage = uni[1];
@@ -426,6 +429,7 @@ __device__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s, c
     if (b.tid == 0) {
         if (parked_at >= 0) { A.sc->resume_it = parked_stage == 2 ? parked_at + 1 : parked_at; A.sc->resume_stage = parked_stage == 2 ? 0 : 1; A.sc->parked = 1; }
         else if (!skip) A.sc->finished = 1;
+        if (!skip) A.sc->t_end = (long)wall_clock64();
         __threadfence_system();
         __hip_atomic_fetch_add(M.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1035,6 +1039,12 @@ extern "C" int octa_sim_service_stats(octa_sim *S, double *h_out4) {
     if (!S || !S->ran || !h_out4) { octa::set_error("octa_sim_service_stats: run the simulation first"); return -2; }
     h_out4[0] = (double)S->diag_tickets; h_out4[1] = S->diag_max_gap_ms; h_out4[2] = (double)S->diag_relaunches; h_out4[3] = (double)S->diag_parked;
     h_out4[4] = S->diag_max_bif_ms;
+    return 0;
+}
+
+extern "C" int octa_sim_spans(octa_sim *S, int64_t *h_spans) {
+    if (!S || !S->ran || !h_spans) { octa::set_error("octa_sim_spans: run the simulation first"); return -2; }
+    for (int s = 0; s < S->B; s++) { h_spans[2 * s] = S->h_sc[s].t_begin; h_spans[2 * s + 1] = S->h_sc[s].t_end; }
     return 0;
 }
 

@@ -100,6 +100,8 @@ struct SampleScalars {
     int pass_tag[2];
     int pass_counter;
     long murray_steps;
+    long flush_rounds;     // rounds of the deferred Murray evaluation (sum over passes)
+    long murray_deferred;  // radii recomputed by it (the rest of murray_steps are eager steps)
     long n_bif;
     long respec;
     long prof[16];  // accumulated 100 MHz ticks per phase (thread 0), see sim.hip
@@ -108,6 +110,7 @@ struct SampleScalars {
     // leaves the kernel; the host serves it at the kernel boundary and launches again
     int resume_it, resume_stage;   // stage 0: top of iteration resume_it; 1: behind its arterial mailbox
     int parked, finished;
+    long t_begin, t_end;           // 100 MHz wall clock when a workgroup first took the sample / last left it
 };
 
 // pointers to ONE sample's slices
@@ -206,6 +209,13 @@ OCTA_HD inline void atomic_or_int(int *p, int v) {
     atomicOr(p, v);
 #else
     *p |= v;
+#endif
+}
+OCTA_HD inline void atomic_and_int(int *p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAnd(p, v);
+#else
+    *p &= v;
 #endif
 }
 
@@ -909,8 +919,9 @@ struct SeqLds {
     unsigned short *par;       // [NCAP] parent id, 0xffff = none
     const double *log_tab;     // glibc pow tables (gpow.h)
     const uint64_t *exp_tab;
-    unsigned char *stage;      // 2 KiB of per-chunk operands of the wave-form Murray walk
+    int *deferred;             // [NCAP / 32] bitmap: radius to be recomputed when the pass ends (2 KiB)
 };
+OCTA_HD inline bool deferred_get(const SeqLds &L, int id) { return ((unsigned)L.deferred[id >> 5] >> (id & 31)) & 1u; }
 struct WalkRec { int nch, c0, c1, cg; double k; };
 OCTA_HD inline WalkRec walk_load(const SimArrays &A, int f, int id, bool want_cg) {
     WalkRec r;
@@ -926,107 +937,159 @@ OCTA_HD inline int walk_parent(const SeqLds &L, int id) {
     return p == 0xffffu ? -1 : (int)p;
 }
 
-// Murray's law from node id up to the root (arterial_tree.py:174-184). Radii and the parent chain are read
-// from LDS; the topology records of the next four ancestors are always in flight from HBM/L2, so a step
-// costs its three pow evaluations (tables in LDS) and not a memory round trip.
-// Murray's law from node id up to the root (arterial_tree.py:174-184): every node on the way gets
-// (r_c0^k + r_c1^k)^(1/k) until a radius does not change or the root (never updated) is reached.
+// Murray's law from node id towards the root (arterial_tree.py:174-184): the reference recomputes (r_c0^k + r_c1^k)^(1/k) for
+// every node on the way, one walk per sprouting node, until a radius does not change or the root (never updated) is reached.
+// A radius is READ during the pass only as "the child radius of an inter-node whose turn is still to come" (eval_inter; those
+// children carry this pass's tag in child_group). So a walk is split:
+//   * eager part -- from `id` up to the highest node on the path whose tag names a group still to be visited: computed now, in
+//     the reference's order and with its early exit; everything at or below a pending node therefore always holds exact radii;
+//   * deferred part -- the nodes above: only marked (bitmap in LDS, list in HBM) up to the first node an earlier walk of this
+//     pass already marked. Their radii are pure functions of their children's, so recomputing each marked node ONCE when the
+//     pass ends (murray_flush, children before parents, all ready nodes of the workgroup in parallel) leaves the radii the
+//     walks would have left -- the reference's early exit cannot trigger above a sprouting node (each ancestor's k-th-power sum
+//     grows by at least one leaf's share, orders of magnitude above an ulp), and if it could, an unchanged child gives its
+//     parent the value it already holds.
+// Radii and the parent chain are read from LDS; topology records come from HBM/L2 lane-parallel, one round trip per 64 ancestors.
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ inline double readlane_f64(double v, int j /* wave-uniform */) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
     return __hiloint2double(hi, lo);
 }
-// Wave form; all 64 lanes call it with identical arguments. Per chunk of 64 ancestors: (1) the chain is
-// followed through the LDS parent array, lane j keeps the j-th node; (2) lane-parallel, every lane fetches
-// its node's topology from HBM/L2 (one round trip for the whole chunk) and raises the children that are
-// NOT on the path (their radii cannot change during this walk) to the node's kappa; (3) the sequential
-// chain -- two pow evaluations per node, operands fetched with readlane -- is executed uniformly; (4) the lanes
-// store the new radii. Floating-point addition is commutative, so "on-path power + other power" is
-// bit-identical to the reference's c0-then-c1 order.
-__device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L) {
+// any pending tag on the path from `start` up to the first deferred node / the root (paths longer than one chunk only)
+__device__ inline bool murray_pending_above(const SimArrays &A, int start, int cur_g, int pass_tag, const SeqLds &L) {
+    const int lane = (int)(threadIdx.x & 63);
+    int cur = start;
+    while (true) {
+        int nn = 0, mine = -1;
+        bool ended = false;
+        for (; nn < 64; nn++) {
+            const int p = walk_parent(L, cur);
+            if (p < 0 || deferred_get(L, cur)) { ended = true; break; }
+            if (lane == nn) mine = cur;
+            cur = p;
+        }
+        const int cg = lane < nn ? A.child_group[mine] : 0;
+        if (__ballot(lane < nn && (cg >> 14) == pass_tag && (cg & 8191) > cur_g)) return true;
+        if (ended) return false;
+    }
+}
+// Wave form; all 64 lanes call it with identical arguments. Per chunk of 64 ancestors: (1) the chain is followed through the LDS
+// parent array, lane j keeps the j-th node; (2) lane-parallel, every lane fetches its node's topology and tag from HBM/L2 and the
+// eager length is voted; the eager lanes raise the children that are NOT on the path to the node's kappa; (3) the sequential
+// chain -- two pow evaluations per node, operands fetched with readlane -- is executed uniformly; (4) the lanes store the new radii
+// / mark the deferred nodes. Floating-point addition is commutative, so "on-path power + other power" is bit-identical to the
+// reference's c0-then-c1 order. Returns the eager steps; n_def counts the nodes appended to the deferred list (A.act_list).
+__device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L, int &n_def) {
     if (id < 0) return 0;
     const int lane = (int)(threadIdx.x & 63);
     double *rad = L.rad;
     long steps = 0;
     int first = id, below = -1;  // first node of the chunk and its on-path child (-1 at the start of the walk)
     double rp_prev = 0, k_last = 0, inv_k = 0;
+    bool defer_rest = false;     // an earlier chunk ended its eager part: nothing pending above
     while (true) {
         int cur = first, nn = 0, mine = -1;
+        bool ended = false;
         for (; nn < 64; nn++) {
             const int p = walk_parent(L, cur);
-            if (p < 0) break;
+            if (p < 0 || deferred_get(L, cur)) { ended = true; break; }
             if (lane == nn) mine = cur;
             cur = p;
         }
         if (nn == 0) break;
-        int onpath = __shfl_up(mine, 1, 64);
-        if (lane == 0) onpath = below;
-        double v_k = 0, v_pw = 0, v_old = 0;  // lane j: kappa, sum of the off-path child powers, radius before the walk
-        int v_cg = 0, v_nch = 0;
-        if (lane < nn) {
-            const WalkRec r = walk_load(A, f, mine, D != nullptr);
-            double pw = 0;
-            if (onpath < 0) {
-                if (r.nch >= 1) {
-                    pw = octa_gpow::gpow_t(rad[r.c0], r.k, L.log_tab, L.exp_tab);
-                    if (r.nch >= 2) pw = pw + octa_gpow::gpow_t(rad[r.c1], r.k, L.log_tab, L.exp_tab);
-                }
-            } else if (r.nch >= 2) {
-                pw = octa_gpow::gpow_t(rad[r.c0 == onpath ? r.c1 : r.c0], r.k, L.log_tab, L.exp_tab);
-            }
-            v_k = r.k; v_pw = pw; v_old = rad[mine]; v_cg = r.cg; v_nch = r.nch;
+        int eager_n = 0;
+        WalkRec r;
+        r.nch = 0; r.c0 = r.c1 = -1; r.cg = 0; r.k = 0;
+        if (!defer_rest) {
+            if (lane < nn) r = walk_load(A, f, mine, true);
+            const unsigned long long pend = __ballot(lane < nn && (r.cg >> 14) == pass_tag && (r.cg & 8191) > cur_g);
+            if (!ended && murray_pending_above(A, cur, cur_g, pass_tag, L)) eager_n = nn;
+            else eager_n = pend ? 64 - __builtin_clzll(pend) : 0;
         }
-        int done = 0;
         bool stop = false;
-        double my_rp = 0;
-        for (int jj = 0; jj < nn; jj++) {
-            const int j = __builtin_amdgcn_readfirstlane(jj);
-            const int nch = __builtin_amdgcn_readlane(v_nch, j);
-            if (nch == 0) { stop = true; break; }
-            const double k = readlane_f64(v_k, j), pw_j = readlane_f64(v_pw, j), old_j = readlane_f64(v_old, j);
-            if (k != k_last) { k_last = k; inv_k = 1.0 / k; }
-            double s;
-            if (j == 0 && below < 0) {
-                s = pw_j;
-            } else {
-                s = octa_gpow::gpow_t(rp_prev, k, L.log_tab, L.exp_tab);
-                if (nch >= 2) s = s + pw_j;
+        if (eager_n > 0) {
+            int onpath = __shfl_up(mine, 1, 64);
+            if (lane == 0) onpath = below;
+            double v_pw = 0, v_old = 0;  // lane j: sum of the off-path child powers, radius before the walk
+            if (lane < eager_n) {
+                double pw = 0;
+                if (onpath < 0) {
+                    if (r.nch >= 1) {
+                        pw = octa_gpow::gpow_t(rad[r.c0], r.k, L.log_tab, L.exp_tab);
+                        if (r.nch >= 2) pw = pw + octa_gpow::gpow_t(rad[r.c1], r.k, L.log_tab, L.exp_tab);
+                    }
+                } else if (r.nch >= 2) {
+                    pw = octa_gpow::gpow_t(rad[r.c0 == onpath ? r.c1 : r.c0], r.k, L.log_tab, L.exp_tab);
+                }
+                v_pw = pw; v_old = rad[mine];
             }
-            const double rp = octa_gpow::gpow_t(s, inv_k, L.log_tab, L.exp_tab);
-            steps++;
-            if (old_j == rp) { stop = true; break; }
-            if (lane == j) my_rp = rp;
-            done = j + 1;
-            rp_prev = rp;
-            if (D) {
-                const int cg = __builtin_amdgcn_readlane(v_cg, j);
-                if ((cg >> 14) == pass_tag && !((cg >> 13) & 1)) {
+            int done = 0;
+            double my_rp = 0;
+            for (int jj = 0; jj < eager_n; jj++) {
+                const int j = __builtin_amdgcn_readfirstlane(jj);
+                const int nch = __builtin_amdgcn_readlane(r.nch, j);
+                if (nch == 0) { stop = true; break; }
+                const double k = readlane_f64(r.k, j), pw_j = readlane_f64(v_pw, j), old_j = readlane_f64(v_old, j);
+                if (k != k_last) { k_last = k; inv_k = 1.0 / k; }
+                double s;
+                if (j == 0 && below < 0) {
+                    s = pw_j;
+                } else {
+                    s = octa_gpow::gpow_t(rp_prev, k, L.log_tab, L.exp_tab);
+                    if (nch >= 2) s = s + pw_j;
+                }
+                const double rp = octa_gpow::gpow_t(s, inv_k, L.log_tab, L.exp_tab);
+                steps++;
+                if (old_j == rp) { stop = true; break; }
+                if (lane == j) my_rp = rp;
+                done = j + 1;
+                rp_prev = rp;
+                const int cg = __builtin_amdgcn_readlane(r.cg, j);
+                if (D && (cg >> 14) == pass_tag && !((cg >> 13) & 1)) {
                     int g2 = cg & 8191;
                     if (g2 > cur_g) dirty_insert(*D, g2);
                 }
             }
+            if (lane < done) rad[mine] = my_rp;
         }
-        if (lane < done) rad[mine] = my_rp;
+        if (stop) break;          // the reference's walk ends here: nothing above changes
+        if (eager_n < nn) {
+            if (lane >= eager_n && lane < nn) {
+                atomic_or_int(&L.deferred[mine >> 5], (int)(1u << (mine & 31)));
+                A.act_list[n_def + lane - eager_n] = mine;
+            }
+            n_def += nn - eager_n;
+            defer_rest = true;
+        }
         __builtin_amdgcn_wave_barrier();
-        if (stop || nn < 64) break;
+        if (ended) break;
         below = __shfl(mine, 63, 64);
         first = cur;
     }
     return steps;
 }
 #else
-OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L) {
+OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L, int &n_def) {
     long steps = 0;
     double *rad = L.rad;
-    while (id >= 0) {
+    int path_len = 0, eager_n = 0;
+    for (int cur = id; cur >= 0; path_len++) {
+        const int par = walk_parent(L, cur);
+        if (par < 0 || deferred_get(L, cur)) break;
+        const int cg = A.child_group[cur];
+        if ((cg >> 14) == pass_tag && (cg & 8191) > cur_g) eager_n = path_len + 1;
+        cur = par;
+    }
+    int k = 0;
+    for (; k < eager_n; k++) {
         const int par = walk_parent(L, id);
-        const WalkRec r = walk_load(A, f, id, D != nullptr);
-        if (par < 0 || r.nch == 0) break;
+        const WalkRec r = walk_load(A, f, id, true);
+        if (r.nch == 0) return steps;
         double s = octa_gpow::gpow_t(rad[r.c0], r.k, L.log_tab, L.exp_tab);
         if (r.nch >= 2) s = s + octa_gpow::gpow_t(rad[r.c1], r.k, L.log_tab, L.exp_tab);
         double rp = octa_gpow::gpow_t(s, 1.0 / r.k, L.log_tab, L.exp_tab);
         steps++;
-        if (rad[id] == rp) break;
+        if (rad[id] == rp) return steps;
         rad[id] = rp;
         if (D && (r.cg >> 14) == pass_tag && !((r.cg >> 13) & 1)) {
             int g2 = r.cg & 8191;
@@ -1034,9 +1097,99 @@ OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g,
         }
         id = par;
     }
+    for (; k < path_len; k++) {
+        atomic_or_int(&L.deferred[id >> 5], (int)(1u << (id & 31)));
+        A.act_list[n_def++] = id;
+        id = walk_parent(L, id);
+    }
     return steps;
 }
 #endif
+
+// The deferred radii of one pass (A.act_list[0..n_def), bitmap L.deferred), children before parents: in every round each thread
+// looks at its marked nodes, adds the k-th power of every child that is final by now and, once both are in, writes the node's
+// radius; the bits are cleared between two syncs, so a round only sees children finished in earlier rounds. Rounds = height of
+// the marked forest. Up to MURRAY_EPT nodes per thread keep their operands in registers; a longer list re-reads them per round.
+#ifndef OCTA_MURRAY_EPT
+#define OCTA_MURRAY_EPT 4
+#endif
+constexpr int MURRAY_EPT = OCTA_MURRAY_EPT;
+OCTA_HD inline int murray_flush(const Blk &b, const SimArrays &A, int f, const SeqLds &L, int n_def) {
+    if (n_def <= 0) return 0;
+    int *ctl = b.coll() + 90;
+    if (b.tid == 0) ctl[0] = 0;
+    double *rad = L.rad;
+    int rounds = 0;
+    if (n_def <= MURRAY_EPT * b.nth) {
+        int node[MURRAY_EPT], c0[MURRAY_EPT], c1[MURRAY_EPT];
+        double kk[MURRAY_EPT], acc[MURRAY_EPT];
+        int pend[MURRAY_EPT];     // 1: c0 not added yet, 2: c1 not added yet, 4: radius not written yet, 8: written in this round
+                                  // (int on purpose: as an unsigned char array this state was miscomputed by hipcc 7.2 -O3 on gfx950)
+        for (int e = 0; e < MURRAY_EPT; e++) {
+            const int idx = b.tid + e * b.nth;
+            pend[e] = 0; node[e] = 0; c0[e] = c1[e] = 0; kk[e] = 1; acc[e] = 0;
+            if (idx < n_def) {
+                node[e] = A.act_list[idx];
+                const WalkRec r = walk_load(A, f, node[e], false);
+                c0[e] = r.c0; c1[e] = r.c1; kk[e] = r.k;
+                pend[e] = 4 | (r.nch >= 1 ? 1 : 0) | (r.nch >= 2 ? 2 : 0);
+            }
+        }
+        b.sync();
+        while (true) {
+            rounds++;
+            int fin = 0;
+            for (int e = 0; e < MURRAY_EPT; e++) {
+                if (!(pend[e] & 4)) continue;
+                if ((pend[e] & 1) && !deferred_get(L, c0[e])) { acc[e] = acc[e] + octa_gpow::gpow_t(rad[c0[e]], kk[e], L.log_tab, L.exp_tab); pend[e] &= ~1; }
+                if ((pend[e] & 2) && !deferred_get(L, c1[e])) { acc[e] = acc[e] + octa_gpow::gpow_t(rad[c1[e]], kk[e], L.log_tab, L.exp_tab); pend[e] &= ~2; }
+                if (!(pend[e] & 3)) {
+                    rad[node[e]] = octa_gpow::gpow_t(acc[e], 1.0 / kk[e], L.log_tab, L.exp_tab);
+                    pend[e] = 8;
+                    fin++;
+                }
+            }
+            b.sync();
+            for (int e = 0; e < MURRAY_EPT; e++)
+                if (pend[e] == 8) { atomic_and_int(&L.deferred[node[e] >> 5], (int)~(1u << (node[e] & 31))); pend[e] = 0; }
+            if (fin) atomic_add_int(&ctl[0], fin);
+            b.sync();
+            if (ctl[0] >= n_def) break;
+        }
+    } else {
+        b.sync();
+        while (true) {
+            rounds++;
+            int fin = 0;
+            for (int idx = b.tid; idx < n_def; idx += b.nth) {
+                const int id = A.act_list[idx];
+                if (id < 0 || !deferred_get(L, id)) continue;
+                const WalkRec r = walk_load(A, f, id, false);
+                if ((r.nch >= 1 && deferred_get(L, r.c0)) || (r.nch >= 2 && deferred_get(L, r.c1))) continue;
+                double s = 0;
+                if (r.nch >= 1) s = octa_gpow::gpow_t(rad[r.c0], r.k, L.log_tab, L.exp_tab);
+                if (r.nch >= 2) s = s + octa_gpow::gpow_t(rad[r.c1], r.k, L.log_tab, L.exp_tab);
+                rad[id] = octa_gpow::gpow_t(s, 1.0 / r.k, L.log_tab, L.exp_tab);
+                A.act_list[idx] = -1 - id;      // finished in this round: bit cleared after the sync
+                fin++;
+            }
+            b.sync();
+            for (int idx = b.tid; idx < n_def; idx += b.nth) {
+                const int v = A.act_list[idx];
+                if (v < 0 && v != (int)0x80000000) {
+                    const int id = -1 - v;
+                    atomic_and_int(&L.deferred[id >> 5], (int)~(1u << (id & 31)));
+                    A.act_list[idx] = (int)0x80000000;
+                }
+            }
+            if (fin) atomic_add_int(&ctl[0], fin);
+            b.sync();
+            if (ctl[0] >= n_def) break;
+        }
+    }
+    b.sync();
+    return rounds;
+}
 
 // node creation of the ordered pass: the counter, the parent's child count and the LDS mirrors are kept by
 // the caller (parent_nch = children the parent has before this call)
@@ -1470,6 +1623,11 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
 // Only the groups that grow under the speculation are visited, plus the (rare) inter-nodes whose child
 // radius an earlier node of this pass changed (dirty list fed by murray_to_root); this visits exactly the
 // groups for which the reference's sequential loop does anything.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OCTA_FLUSH_T0() ((long)wall_clock64())
+#else
+#define OCTA_FLUSH_T0() 0L
+#endif
 struct NoSideJob { OCTA_HD void operator()(unsigned char *) const {} };
 constexpr int SEQ_SIDE_LDS = 7680;   // bytes of LDS handed to the side job of the ordered pass
 
@@ -1487,8 +1645,9 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     uint64_t *etab = reinterpret_cast<uint64_t *>(ltab + 384);
     static_assert((size_t)NCAP * 10 + 384 * 8 + 256 * 8 + 2048 + SEQ_SIDE_LDS + 2048 <= (size_t)SIM_LDS_BYTES, "ordered-pass LDS layout");
     L.log_tab = ltab; L.exp_tab = etab;
-    L.stage = reinterpret_cast<unsigned char *>(etab + 256);
-    unsigned char *side_lds = L.stage + 2048;
+    L.deferred = reinterpret_cast<int *>(etab + 256);
+    static_assert(NCAP / 8 <= 2048, "deferred bitmap");
+    unsigned char *side_lds = reinterpret_cast<unsigned char *>(L.deferred) + 2048;
     const int n_before = sc->n_nodes[f];
     for (int i = b.tid; i < n_before; i += b.nth) {
         L.rad[i] = A.nrad[f][i];
@@ -1497,6 +1656,8 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     }
     for (int i = b.tid; i < 384; i += b.nth) ltab[i] = octa_gpow::LOG_TAB[i];
     for (int i = b.tid; i < 256; i += b.nth) etab[i] = octa_gpow::EXP_TAB[i];
+    for (int i = b.tid; i < 512; i += b.nth) L.deferred[i] = 0;
+    if (b.tid == 0) b.coll()[91] = 0;
     b.sync();
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SEQT(slot, stmt) do { long _t0 = (long)wall_clock64(); stmt; t_acc[slot] += (long)wall_clock64() - _t0; } while (0)
@@ -1517,6 +1678,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
         int n_nodes = n_before, py_pos = sc->py_pos, err = 0;
         const int py_cap = sc->py_cap;
         long steps = 0, n_bif = 0, respec = 0;
+        int n_def = 0;           // nodes on the deferred list (A.act_list) of this pass
         double u_next = py_pos < py_cap ? A.py_u[py_pos] : 0.0;
         // the next record of the grow list is always in flight
         const int INF = 0x7fffffff;
@@ -1567,7 +1729,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                     const double *o = bif_results + 6 * (size_t)R.req;
                     seq_add_node(A, f, n_nodes, v3(o[0], o[1], o[2]), C.r, id, 0, P.kappa, L);
                     seq_add_node(A, f, n_nodes, v3(o[3], o[4], o[5]), C.r, id, 1, P.kappa, L);
-                    SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L));
+                    SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def));
                     A.nact[f][id] = 0;
                     n_bif++;
                 } else {
@@ -1585,7 +1747,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 u_next = py_pos < py_cap ? A.py_u[py_pos] : 0.0;
                 if (R.thr <= u && !R.ang_gt90) continue;
                 seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 1, P.kappa, L);
-                SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L));
+                SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def));
                 A.nact[f][id] = 0;
             }
             if (D.overflow && !scan_all) { scan_all = true; D.n = 0; }
@@ -1594,11 +1756,15 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
         sc->new_end[f] = n_nodes;
         sc->n_nodes[f] = n_nodes;
         sc->py_pos = py_pos;
-        if (err) sc->err |= err;
-        sc->murray_steps += steps;
-        sc->n_bif += n_bif;
-        sc->respec += respec;
-        if (b.tid == 0) { sc->kdprof[7] += t_acc[0]; (void)t_acc[1]; (void)t_acc[2]; }
+        if (b.tid == 0) {        // one lane: the read-modify-write statistics must not be repeated by the other 63
+            if (err) sc->err |= err;
+            sc->murray_steps += steps + n_def;
+            sc->murray_deferred += n_def;
+            b.coll()[91] = n_def;
+            sc->n_bif += n_bif;
+            sc->respec += respec;
+            sc->kdprof[7] += t_acc[0]; (void)t_acc[1]; (void)t_acc[2];
+        }
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     else if (b.tid < 128) {
@@ -1609,6 +1775,11 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
 #endif
 #undef SEQT
     b.sync();
+    {
+        long t0 = OCTA_FLUSH_T0();
+        const int rounds = murray_flush(b, A, f, L, b.coll()[91]);
+        if (b.tid == 0) { sc->kdprof[7] += OCTA_FLUSH_T0() - t0; sc->flush_rounds += rounds; }
+    }
     // radii changed by Murray go back to HBM (new nodes were written through)
     for (int i = b.tid; i < n_before; i += b.nth) A.nrad[f][i] = L.rad[i];
     b.sync();

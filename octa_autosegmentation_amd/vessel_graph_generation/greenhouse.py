@@ -287,6 +287,8 @@ class BatchSimulator:
         svc = np.zeros(5)
         _native.check(self._lib.octa_sim_service_stats(self._h, svc.ctypes.data), "octa_sim_service_stats")
         res = SimulationResult(edges, off, n_art, stats)
+        res.spans = np.zeros((self.batch, 2), np.int64)      # 100 MHz device clock: first taken / last left by a workgroup
+        _native.check(self._lib.octa_sim_spans(self._h, res.spans.ctypes.data), "octa_sim_spans")
         res.service = dict(tickets=int(svc[0]), max_absence_ms=svc[1], relaunches=int(svc[2]), parked=int(svc[3]), max_callback_ms=svc[4])
         res.timing = dict(kernel_a_ms=timing[0], launches_a=int(timing[1]), kernel_b_ms=timing[2], launches_b=int(timing[3]),
                           loop_wall_ms=timing[4], host_bif_ms=timing[5], bif_requests=int(timing[6]), hbm_bytes=int(timing[7]))

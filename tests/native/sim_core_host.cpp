@@ -153,6 +153,7 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     long n_art = 0;
     long ne = export_edges(cp, cr, cpar, c0, c1, cn, sc.n_nodes, cfg.n_trees, edges_out, max_edges, &n_art);
     info_out[0] = ne; info_out[1] = n_art; info_out[2] = sc.err; info_out[3] = sc.py_pos; info_out[4] = sc.murray_steps;
+    if (getenv("OCTA_SIMCORE_VERBOSE")) fprintf(stderr, "murray: steps %ld deferred %ld flush rounds %ld\n", sc.murray_steps, sc.murray_deferred, sc.flush_rounds);
     info_out[5] = sc.n_bif; info_out[6] = sc.respec; info_out[7] = C.n_iter;
     return sc.err ? -10 : 0;
 }
