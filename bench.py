@@ -316,6 +316,17 @@ def main():
     # included; slots 10-15 are sub-timers of those phases) while n_fly launches share the GPU
     phase_ms = lambda st: float(st[:, 8:18].sum(axis=1).mean()) * 1e-5
     sample_ms_loaded = float(np.mean([phase_ms(o["result"].stats) for o in outs]))
+    # share of the CU time the simulator's workgroups held during the timed steps: per-sample spans on the device's common 100 MHz
+    # clock (octa_sim_spans), clipped to a window inside the steady state (between the quartiles of the first-taken / last-left times)
+    sp = np.concatenate([o["result"].spans for o in outs]).astype(np.float64) / 1e8
+    w0, w1 = np.percentile(sp[:, 0], 25), np.percentile(sp[:, 1], 75)
+    cu_time = None
+    if w1 > w0:
+        held = float(np.clip(np.minimum(sp[:, 1], w1) - np.maximum(sp[:, 0], w0), 0, None).sum())
+        cu_time = {"simulator_share": held / (N_CUS * (w1 - w0)), "span_ms_per_sample": float((sp[:, 1] - sp[:, 0]).mean() * 1e3),
+                   "window_s": float(w1 - w0),
+                   "note": "CU-seconds held by simulator workgroups / (CUs x window), one workgroup per CU; the remainder is the rasteriser's "
+                           "kernels (they need the same CUs) and dispatch gaps"}
 
     # ---- rasteriser alone (other slots idle): HIP events on the stream the kernels go to
     raster = None
@@ -424,6 +435,7 @@ def main():
                                      "cu_occupancy_weighted_ms_per_step": launch_ms * (dom_n / max(args.steps, 1)) / n_fly,
                                      "note": f"a launch covers {G} steps and {n_fly} launches of up to {N_CUS} workgroups share the {N_CUS} CUs, so a launch "
                                              "outlasts ms_per_step; the weighted figure is the launch duration per step divided by the launches in flight"},
+            "cu_time": cu_time,
             "host_bifurcation_callback_ms_per_step": bif_ms / args.steps,
             "mailbox_relaunches": relaunches,
         }

@@ -325,6 +325,26 @@ int octa_dice_bce_fwd(octa_ctx *ctx, const void *d_logits, int dtype, const floa
 int octa_dice_bce_bwd(octa_ctx *ctx, const void *d_logits, int dtype, const float *d_y, int B, int64_t n, const double *d_sums,
                       const float *d_grad_out, float smooth_nr, float smooth_dr, void *d_dlogits, void *stream);
 
+/* ---- convolutions with ONE channel on one side: the GAN networks' stems and heads ----
+ * Replace nn.Conv2d(1, 64, 7) / nn.Conv2d(64, 1, 7) of ResnetGenerator (models/networks.py:360-368, behind ReflectionPad2d(3)) and
+ * nn.Conv2d(1, 64, 4, 1, 1) / nn.Conv2d(512, 1, 4, 1, 1) of NLayerDiscriminator (:433-442) -- forward, data gradient and weight
+ * gradient -- which the reference leaves to the vendor library (im2col + GEMM + col2im). Stride 1, zero padding `pad`, K = 4 or 7,
+ * C (the wide side) a multiple of 64. s / squeeze-out: bf16 [N][H][W]; a / expand-out: bf16 [N][H][W][C]; w, g: float32 [C][K*K]
+ * (Conv2d.weight of either shape, contiguous); bias float32 or NULL. With t = ky*K + kx, tf = flip ? K*K-1-t : t:
+ *   expand : out[n][y][x][c] = lrelu_slope(bias[c] + sum_t s[n][y+ky-pad][x+kx-pad] * w[c][tf]),  out extent Hs + 2 pad - K + 1
+ *   squeeze: out[n][y][x]    = bias[0] + sum_t sum_c a[n][y+ky-pad][x+kx-pad][c] * w[c][tf]
+ *   wgrad  : g[c][tf]        = sum_{n,y,x} a[n][y][x][c] * s[n][y+ky-pad][x+kx-pad] (zero outside s);  asum[c] = sum a (or NULL)
+ * so that for y = conv(x, w, pad):  1 -> C layer: forward = expand(x), dx = squeeze(dy, flip, K-1-pad), dw = wgrad(a = dy, s = x, pad);
+ * C -> 1 layer: forward = squeeze(x), dx = expand(dy, flip, K-1-pad), dw = wgrad(a = x, s = dy, flip, K-1-pad).
+ * wgrad needs octa_thinconv_wgrad_scratch_floats(N, Ha, C, K) floats of device scratch (per-block partial sums: deterministic). */
+int octa_thinconv_expand(octa_ctx *ctx, const void *d_s, const void *d_w, const void *d_bias, void *d_out, int N, int Hs, int Ws, int C, int K,
+                         int pad, int flip, float slope, void *stream);
+int octa_thinconv_squeeze(octa_ctx *ctx, const void *d_a, const void *d_w, const void *d_bias, void *d_out, int N, int Ha, int Wa, int C, int K,
+                          int pad, int flip, void *stream);
+long long octa_thinconv_wgrad_scratch_floats(int N, int Ha, int C, int K);
+int octa_thinconv_wgrad(octa_ctx *ctx, const void *d_a, const void *d_s, void *d_scratch, void *d_g, void *d_asum, int N, int Ha, int Wa, int Hs,
+                        int Ws, int C, int K, int pad, int flip, void *stream);
+
 /* ---- anti-aliased resampling and reflection pad of the GAN networks ----
  * Replace models/networks.py:244-262 (Upsample: ReplicationPad2d(1) + depth-wise conv_transpose2d with the
  * [1 3 3 1]^2/64*4 filter, stride 2, crop), :264-289 (Downsample: ReflectionPad2d(1) + depth-wise conv2d with the

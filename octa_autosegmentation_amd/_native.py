@@ -51,6 +51,10 @@ SIGNATURES = {
     "octa_sim_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "octa_sim_run_states": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "octa_sim_np_state": (c_int, [c_void_p, c_int, c_void_p]),
+    "octa_thinconv_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p]),
+    "octa_thinconv_squeeze": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "octa_thinconv_wgrad_scratch_floats": (ctypes.c_longlong, [c_int, c_int, c_int, c_int]),
+    "octa_thinconv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_sim_spans": (c_int, [c_void_p, c_void_p]),
     "octa_sim_edge_offsets": (c_int, [c_void_p, c_void_p, c_void_p]),
     "octa_sim_export_edges": (c_int, [c_void_p, c_void_p]),

@@ -401,8 +401,25 @@ class ResnetGenerator(nn.Module):
         mods = list(self.model)
         nhwc = False                                     # layout of x between layers
         i = 0
+        from . import thin_conv as tc
         while i < len(mods):
             m = mods[i]
+            # 7x7 stem (1 -> ngf, behind ReflectionPad2d, in front of InstanceNorm + ReLU) and head (ngf -> 1, + Sigmoid): streaming
+            # kernels (csrc/thin_conv.hip); the stem's bias is subtracted again by the norm, like every 3x3 layer's
+            if (not nhwc and i + 3 < len(mods) and isinstance(m, ReflectionPad2d) and isinstance(mods[i + 1], nn.Conv2d) and mods[i + 1].in_channels == 1
+                    and mods[i + 1].padding == (0, 0) and tc.supported(mods[i + 1]) and isinstance(mods[i + 2], nn.InstanceNorm2d)
+                    and not mods[i + 2].affine and isinstance(mods[i + 3], nn.ReLU) and x.shape[1] == 1):
+                xp = resample.reflect_pad(x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), m.padding[0], "nhwc")[..., 0]
+                x = mc.instance_norm_leaky_relu_nhwc(tc._ConvFrom1.apply(xp, mods[i + 1].weight, None, 0, 1.0), None, None, 0.0, mods[i + 2].eps)
+                nhwc = True
+                i += 4
+                continue
+            if (nhwc and i + 1 < len(mods) and isinstance(m, ReflectionPad2d) and isinstance(mods[i + 1], nn.Conv2d) and mods[i + 1].out_channels == 1
+                    and mods[i + 1].padding == (0, 0) and tc.supported(mods[i + 1])):
+                x = tc.conv_to_1(resample.reflect_pad(x, m.padding[0], "nhwc"), mods[i + 1])[:, None]      # [N, 1, H, W]
+                nhwc = False
+                i += 2
+                continue
             on_path = (self._is_conv_norm_relu(mods, i) or (isinstance(m, ResnetBlock) and m.conv_block[1].in_channels % 32 == 0)
                        or (nhwc and isinstance(m, (Downsample, Upsample))))
             if on_path and not nhwc:
@@ -445,12 +462,13 @@ class NLayerDiscriminator(nn.Module):
     # ---- inner layers channels-last in bf16: 4x4 convolutions on the MFMA kernel (csrc/conv.hip, KS = 4), InstanceNorm +
     # LeakyReLU(0.2) and blur-downsampling on the NHWC streaming kernels. A convolution bias in front of an InstanceNorm
     # without affine is subtracted again by the norm and is not added here (its gradient is zero in the reference too).
-    # The 1 -> ndf stem (+ bias, LeakyReLU) and the ndf*8 -> 1 head are not matrix-core shaped and stay torch's.
+    # The 1 -> ndf stem (+ bias, LeakyReLU) and the ndf*8 -> 1 head are not matrix-core shaped: streaming kernels (csrc/thin_conv.hip).
     def forward(self, x):
         use_mfma = (USE_MFMA_CONV and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
         if not use_mfma:
             return self.model(x)
         from . import mfma_conv as mc
+        from . import thin_conv as tc
         mc.plan_for_module(self)
         mods = list(self.model)
         nhwc = False
@@ -460,6 +478,17 @@ class NLayerDiscriminator(nn.Module):
             fused = (isinstance(m, nn.Conv2d) and m.kernel_size == (4, 4) and m.stride == (1, 1) and m.padding == (1, 1)
                      and m.in_channels % 32 == 0 and m.out_channels % 32 == 0 and i + 2 < len(mods)
                      and isinstance(mods[i + 1], nn.InstanceNorm2d) and not mods[i + 1].affine and isinstance(mods[i + 2], nn.LeakyReLU))
+            if (not nhwc and isinstance(m, nn.Conv2d) and m.in_channels == 1 and tc.supported(m) and i + 1 < len(mods)
+                    and isinstance(mods[i + 1], nn.LeakyReLU) and x.shape[1] == 1):
+                x = tc.conv_from_1(x[:, 0], m, mods[i + 1].negative_slope)          # stem: bias + LeakyReLU fused (csrc/thin_conv.hip)
+                nhwc = True
+                i += 2
+                continue
+            if nhwc and isinstance(m, nn.Conv2d) and m.out_channels == 1 and tc.supported(m):
+                x = tc.conv_to_1(x, m)[:, None]                                     # head: [N, 1, Ho, Wo]
+                nhwc = False
+                i += 1
+                continue
             on_path = fused or (nhwc and isinstance(m, Downsample))
             if on_path and not nhwc:
                 x, nhwc = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), True
