@@ -379,10 +379,10 @@ def main():
     if not args.no_train and not args.no_end_to_end:
         import train_synthetic
         torch.cuda.empty_cache()
-        e2e_info = train_synthetic.run(steps=160, batch=args.train_batch, gen_batch=128, seed0=500000, log=False)   # 5 generator batches: past the queue-filling transient
+        e2e_info = train_synthetic.run(steps=160, batch=args.train_batch, gen_batch=128, seed0=500000, log=False, warmup=32)   # warm-up = one generator batch (the queue-filling transient), then 5 batches timed
         # configs[4] proper: the same stream feeding the joint GAN contrast-adaptation + segmentation step (G, D at 304^2, S at 1216^2)
         torch.cuda.empty_cache()
-        e2e_gan_info = train_synthetic.run(steps=64, batch=args.train_batch, gen_batch=128, seed0=600000, log=False, gan=True)
+        e2e_gan_info = train_synthetic.run(steps=64, batch=args.train_batch, gen_batch=128, seed0=600000, log=False, gan=True, warmup=32)
 
     dt = sharding.max_over_ranks(dt, dist, dev)
 

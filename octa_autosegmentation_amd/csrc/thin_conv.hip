@@ -33,176 +33,221 @@ __device__ __forceinline__ bf16_t f2bf(float v) {   // round to nearest even (to
 }
 
 constexpr int TC_THREADS = 256;
-constexpr int EXPAND_SEGS = 8;   // row segments one expand block walks with the weights resident in LDS
+constexpr int WG_ROWS = 2;       // rows of `a` one wgrad block folds into its partial sums
+
+// All three kernels put the 64 channels of a chunk on the 64 lanes of a wave and walk along an image row, so that every access
+// to the wide tensor is one coalesced 128-byte line per pixel and the one-channel operand is wave-uniform (LDS broadcast). The
+// K x K window slides in registers: the pixel loop is unrolled K times and column (u + kx) % K of the window is a compile-time
+// register, so a step costs K loads (one per window row), not K*K.
+
+// weights of the chunk, [64][KK] in global memory (contiguous) -> registers of lane c, through LDS so that the global read is coalesced
+template <int KK>
+__device__ __forceinline__ void load_weights(const float *__restrict__ w, int c0, int flip, float *wl /* LDS [64][KK + 1] */, float (&wr)[KK]) {
+    for (int i = threadIdx.x; i < 64 * KK; i += blockDim.x) wl[(i / KK) * (KK + 1) + i % KK] = w[(size_t)c0 * KK + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < KK; t++) wr[t] = wl[lane * (KK + 1) + (flip ? KK - 1 - t : t)];
+}
 
 // ---- expand: 1 -> C -----------------------------------------------------------------------------------------------------
-// A thread owns one output pixel x 8 channels (one 16-byte store); a block of 256 threads = 256 / (C / 8) consecutive pixels
-// of a row per segment. LDS: weights [K*K][C] fp32 (tap-major: the 8 channels of a thread are contiguous), the K x (pixels + K - 1)
-// window of s as fp32.
+// block = one output row x one 64-channel chunk; its 4 waves take a quarter of the row each. LDS: the K rows of s the output row
+// meets (fp32, zero outside) + the weight staging area.
 template <int K>
 __global__ void __launch_bounds__(TC_THREADS)
 thin_expand_kernel(const bf16_t *__restrict__ s, const float *__restrict__ w, const float *__restrict__ bias, bf16_t *__restrict__ out,
                    int N, int Hs, int Ws, int Ho, int Wo, int C, int pad, int flip, float slope) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KK = K * K;
-    float *wl = reinterpret_cast<float *>(smem);                 // [KK][C]
-    const int g8 = C >> 3, ppw = TC_THREADS / g8;                // channel groups, pixels per segment
-    float *win = wl + KK * C;                                    // [K][ppw + K - 1]
-    const int wrow = ppw + K - 1;
-    for (int i = threadIdx.x; i < KK * C; i += TC_THREADS) {
-        const int c = i % C, t = i / C;
-        wl[i] = w[(size_t)c * KK + (flip ? KK - 1 - t : t)];
+    float *wl = reinterpret_cast<float *>(smem);                 // [64][KK + 1]
+    float *srow = wl + 64 * (KK + 1);                            // [K][Wo + K - 1]
+    const int wrow = Wo + K - 1;
+    const int c0 = blockIdx.y * 64, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int oy = blockIdx.x % Ho, n = blockIdx.x / Ho;
+    float wr[KK];
+    load_weights<KK>(w, c0, flip, wl, wr);
+    for (int i = threadIdx.x; i < K * wrow; i += TC_THREADS) {
+        const int ky = i / wrow, j = i % wrow;
+        const int iy = oy + ky - pad, ix = j - pad;
+        srow[i] = (iy >= 0 && iy < Hs && ix >= 0 && ix < Ws) ? bf2f(s[((size_t)n * Hs + iy) * Ws + ix]) : 0.f;
     }
-    const int g = threadIdx.x % g8, p = threadIdx.x / g8;
-    float b[8];
+    __syncthreads();
+    const float b = bias ? bias[c0 + lane] : 0.f;
+    const int per = (Wo + 3) / 4;
+    const int x0 = wave * per, x1 = (x0 + per < Wo) ? x0 + per : Wo;
+    if (x0 >= x1) return;
+    float win[K][K];                                             // win[ky][col]: column (x + kx) lives in register (x - x0 + kx) % K
 #pragma unroll
-    for (int j = 0; j < 8; j++) b[j] = bias ? bias[8 * g + j] : 0.f;
-    const int segs_per_row = (Wo + ppw - 1) / ppw;
-    const long long n_seg = (long long)N * Ho * segs_per_row;
-    for (int k = 0; k < EXPAND_SEGS; k++) {
-        const long long seg = (long long)blockIdx.x * EXPAND_SEGS + k;
-        if (seg >= n_seg) break;
-        const int sx = (int)(seg % segs_per_row), oy = (int)((seg / segs_per_row) % Ho), n = (int)(seg / ((long long)segs_per_row * Ho));
-        const int ox0 = sx * ppw;
-        __syncthreads();                                         // weights staged / previous window consumed
-        for (int i = threadIdx.x; i < K * wrow; i += TC_THREADS) {
-            const int ky = i / wrow, j = i % wrow;
-            const int iy = oy + ky - pad, ix = ox0 + j - pad;
-            win[i] = (iy >= 0 && iy < Hs && ix >= 0 && ix < Ws) ? bf2f(s[((size_t)n * Hs + iy) * Ws + ix]) : 0.f;
-        }
-        __syncthreads();
-        const int ox = ox0 + p;
-        if (ox >= Wo) continue;
-        float acc[8];
+    for (int ky = 0; ky < K; ky++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = b[j];
+        for (int kx = 0; kx < K - 1; kx++) win[ky][kx] = srow[ky * wrow + x0 + kx];
+    bf16_t *orow = out + (((size_t)n * Ho + oy) * Wo) * C + c0 + lane;
+    for (int xb = x0; xb < x1; xb += K) {
 #pragma unroll
-        for (int ky = 0; ky < K; ky++)
+        for (int u = 0; u < K; u++) {
+            const int x = xb + u;
+            if (x < x1) {
 #pragma unroll
-            for (int kx = 0; kx < K; kx++) {
-                const float sv = win[ky * wrow + p + kx];
-                const float4 w0 = *reinterpret_cast<const float4 *>(wl + (ky * K + kx) * C + 8 * g);
-                const float4 w1 = *reinterpret_cast<const float4 *>(wl + (ky * K + kx) * C + 8 * g + 4);
-                acc[0] += sv * w0.x; acc[1] += sv * w0.y; acc[2] += sv * w0.z; acc[3] += sv * w0.w;
-                acc[4] += sv * w1.x; acc[5] += sv * w1.y; acc[6] += sv * w1.z; acc[7] += sv * w1.w;
+                for (int ky = 0; ky < K; ky++) win[ky][(u + K - 1) % K] = srow[ky * wrow + x + K - 1];
+                float acc = b;
+#pragma unroll
+                for (int ky = 0; ky < K; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < K; kx++) acc = __builtin_fmaf(win[ky][(u + kx) % K], wr[ky * K + kx], acc);
+                acc = acc > 0.f ? acc : acc * slope;
+                orow[(size_t)x * C] = f2bf(acc);
             }
-        union { bf16_t h[8]; uint4 v; } o;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { float v = acc[j]; v = v > 0.f ? v : v * slope; o.h[j] = f2bf(v); }
-        *reinterpret_cast<uint4 *>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + 8 * g) = o.v;
+        }
     }
 }
 
 // ---- squeeze: C -> 1 ----------------------------------------------------------------------------------------------------
-// A wave owns P consecutive output pixels of a row, lane = channel of the current 64-channel chunk with its K*K weights in
-// registers: every input pixel of the K x (P + K - 1) window is loaded once (one coalesced 128-byte load) and feeds the up to K
-// outputs it belongs to; the P sums are reduced over the lanes at the end.
+// block = one output row; the weights of ALL chunks sit in LDS ([C][KK + 1]). A wave takes groups of P consecutive output pixels:
+// per 64-channel chunk it loads the K x (P + K - 1) window of the wide tensor -- every load independent of the others, coordinates
+// clamped and masked instead of branched on -- and each loaded pixel feeds the up to K outputs it belongs to; the P sums are reduced
+// over the lanes at the end of the group.
 template <int K, int P>
 __global__ void __launch_bounds__(TC_THREADS)
 thin_squeeze_kernel(const bf16_t *__restrict__ a, const float *__restrict__ w, const float *__restrict__ bias, bf16_t *__restrict__ out,
                     int N, int Ha, int Wa, int Ho, int Wo, int C, int pad, int flip) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KK = K * K;
-    const int lane = threadIdx.x & 63;
-    const int groups_per_row = (Wo + P - 1) / P;
-    const long long grp = (long long)blockIdx.x * (TC_THREADS / 64) + (threadIdx.x >> 6);
-    if (grp >= (long long)N * Ho * groups_per_row) return;
-    const int gx = (int)(grp % groups_per_row), oy = (int)((grp / groups_per_row) % Ho), n = (int)(grp / ((long long)groups_per_row * Ho));
-    const int ox0 = gx * P;
-    float acc[P];
-#pragma unroll
-    for (int o = 0; o < P; o++) acc[o] = 0.f;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        float wr[KK];
-#pragma unroll
-        for (int t = 0; t < KK; t++) wr[t] = w[(size_t)(c0 + lane) * KK + (flip ? KK - 1 - t : t)];
-#pragma unroll
-        for (int ky = 0; ky < K; ky++) {
-            const int iy = oy + ky - pad;
-            if (iy < 0 || iy >= Ha) continue;
-            const bf16_t *row = a + (((size_t)n * Ha + iy) * Wa) * C + c0 + lane;
-#pragma unroll
-            for (int j = 0; j < P + K - 1; j++) {
-                const int ix = ox0 + j - pad;
-                const float xv = (ix >= 0 && ix < Wa) ? bf2f(row[(size_t)ix * C]) : 0.f;
-#pragma unroll
-                for (int kx = 0; kx < K; kx++) {
-                    const int o = j - kx;
-                    if (o >= 0 && o < P) acc[o] += xv * wr[ky * K + kx];
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < P; o++) {
-        float v = acc[o];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-        acc[o] = v;
-    }
+    float *wl = reinterpret_cast<float *>(smem);                 // [C][KK + 1]
+    for (int i = threadIdx.x; i < C * KK; i += TC_THREADS) wl[(i / KK) * (KK + 1) + i % KK] = w[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int oy = blockIdx.x % Ho, n = blockIdx.x / Ho;
     const float b = bias ? bias[0] : 0.f;
+    const int groups = (Wo + P - 1) / P;
+    for (int g = wave; g < groups; g += TC_THREADS / 64) {
+        const int ox0 = g * P;
+        // columns of the window: clamped index + 0/1 factor (wave-uniform), so that no load depends on a branch or a select mask
+        int ixc[P + K - 1];
+        float mcol[P + K - 1];
 #pragma unroll
-    for (int o = 0; o < P; o++)
-        if (lane == o && ox0 + o < Wo) out[((size_t)n * Ho + oy) * Wo + ox0 + o] = f2bf(acc[o] + b);
+        for (int j = 0; j < P + K - 1; j++) {
+            const int ix = ox0 + j - pad;
+            const bool ok = ix >= 0 && ix < Wa;
+            ixc[j] = ok ? ix : 0;
+            mcol[j] = ok ? 1.f : 0.f;
+        }
+        float acc[P];
+#pragma unroll
+        for (int o = 0; o < P; o++) acc[o] = 0.f;
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            float wr[KK];
+#pragma unroll
+            for (int t = 0; t < KK; t++) wr[t] = wl[(c0 + lane) * (KK + 1) + (flip ? KK - 1 - t : t)];
+            float xv[K][P + K - 1];
+#pragma unroll
+            for (int ky = 0; ky < K; ky++) {
+                const int iy = oy + ky - pad;
+                const bool rowok = iy >= 0 && iy < Ha;
+                const bf16_t *row = a + (((size_t)n * Ha + (rowok ? iy : 0)) * Wa) * C + c0 + lane;
+                if (!rowok) {                                       // the row lies in the zero padding: its weights do not count
+#pragma unroll
+                    for (int kx = 0; kx < K; kx++) wr[ky * K + kx] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < P + K - 1; j++) xv[ky][j] = bf2f(row[(size_t)ixc[j] * C]) * mcol[j];
+            }
+#pragma unroll
+            for (int ky = 0; ky < K; ky++)
+#pragma unroll
+                for (int j = 0; j < P + K - 1; j++)
+#pragma unroll
+                    for (int kx = 0; kx < K; kx++) {
+                        const int o = j - kx;
+                        if (o >= 0 && o < P) acc[o] = __builtin_fmaf(xv[ky][j], wr[ky * K + kx], acc[o]);
+                    }
+        }
+#pragma unroll
+        for (int o = 0; o < P; o++) {
+            float v = acc[o];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            acc[o] = v;
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int o = 0; o < P; o++) mine = lane == o ? acc[o] : mine;
+        if (lane < P && ox0 + lane < Wo) out[((size_t)n * Ho + oy) * Wo + ox0 + lane] = f2bf(mine + b);
+    }
 }
 
 // ---- wgrad --------------------------------------------------------------------------------------------------------------
-// g[c][t] = sum a[n][y][x][c] * s[n][y+ky-pad][x+kx-pad]. Block = (rows of a) x (64-channel chunk); thread = channel x every
-// fourth tap (accumulators in registers). The K rows of s a row of a meets are staged in LDS as fp32 (zero outside). Per-block
-// partial sums go to `partial` [gridDim.x][C][K*K (+1: the plain sum of a, the bias gradient of the 1 -> C layer)].
-constexpr int WG_ROWS = 2;
+// g[c][t] = sum a[n][y][x][c] * s[n][y+ky-pad][x+kx-pad]. block = WG_ROWS rows of a x one 64-channel chunk, K waves: wave ky
+// owns window row ky (K accumulators per lane), its window of s slides along the row (one LDS broadcast per pixel); the values of
+// a are fetched 2K pixels at a time (independent loads, index clamped and masked). Per-block partial sums go to `partial`
+// [gridDim.x][C][K*K (+1: the plain sum of a, the bias gradient of the 1 -> C layer)].
 template <int K>
-__global__ void __launch_bounds__(TC_THREADS)
+__global__ void __launch_bounds__(K * 64)
 thin_wgrad_kernel(const bf16_t *__restrict__ a, const bf16_t *__restrict__ s, float *__restrict__ partial,
                   int N, int Ha, int Wa, int Hs, int Ws, int C, int pad, int flip) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int KK = K * K, NT = (KK + 3) / 4;
-    float *srow = reinterpret_cast<float *>(smem);               // [K][Wa + K - 1]
-    const int wrow = Wa + K - 1;
-    const int c = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    constexpr int KK = K * K, U = 2 * K;
+    float *srow = reinterpret_cast<float *>(smem);               // [K][Wa + K - 1 + U]: U zero columns of slack behind each row
+    const int wrow = Wa + K - 1 + U;
+    const int c = threadIdx.x & 63, ky = threadIdx.x >> 6;
     const int c0 = blockIdx.y * 64;
-    float acc[NT], asum = 0.f;
-    int off[NT];
+    float acc[K], asum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-        acc[j] = 0.f;
-        const int t = tq + 4 * j;
-        off[j] = t < KK ? (t / K) * wrow + (t % K) : 0;
-    }
+    for (int kx = 0; kx < K; kx++) acc[kx] = 0.f;
     for (int r = 0; r < WG_ROWS; r++) {
         const long long rowid = (long long)blockIdx.x * WG_ROWS + r;
         if (rowid >= (long long)N * Ha) break;
         const int n = (int)(rowid / Ha), qy = (int)(rowid % Ha);
         __syncthreads();
-        for (int i = threadIdx.x; i < K * wrow; i += TC_THREADS) {
-            const int ky = i / wrow, j = i % wrow;
-            const int iy = qy + ky - pad, ix = j - pad;
+        for (int i = threadIdx.x; i < K * wrow; i += K * 64) {
+            const int wy = i / wrow, j = i % wrow;
+            const int iy = qy + wy - pad, ix = j - pad;
             srow[i] = (iy >= 0 && iy < Hs && ix >= 0 && ix < Ws) ? bf2f(s[((size_t)n * Hs + iy) * Ws + ix]) : 0.f;
         }
         __syncthreads();
         const bf16_t *arow = a + (((size_t)n * Ha + qy) * Wa) * C + c0 + c;
-#pragma unroll 4
-        for (int qx = 0; qx < Wa; qx++) {
-            const float av = bf2f(arow[(size_t)qx * C]);
-            asum += av;
+        const float *sr = srow + ky * wrow;
+        float sw[K];
 #pragma unroll
-            for (int j = 0; j < NT; j++) acc[j] += av * srow[off[j] + qx];
+        for (int kx = 0; kx < K - 1; kx++) sw[kx] = sr[kx];
+        for (int xb = 0; xb < Wa; xb += U) {
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int qx = xb + u;
+                const float v = bf2f(arow[(size_t)(qx < Wa ? qx : Wa - 1) * C]);
+                av[u] = qx < Wa ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                sw[(u + K - 1) % K] = sr[xb + u + K - 1];
+                asum += av[u];
+#pragma unroll
+                for (int kx = 0; kx < K; kx++) acc[kx] = __builtin_fmaf(av[u], sw[(u + kx) % K], acc[kx]);
+            }
         }
     }
     float *dst = partial + ((size_t)blockIdx.x * C + c0 + c) * (KK + 1);
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-        const int t = tq + 4 * j;
-        if (t < KK) dst[flip ? KK - 1 - t : t] = acc[j];
+    for (int kx = 0; kx < K; kx++) {
+        const int t = ky * K + kx;
+        dst[flip ? KK - 1 - t : t] = acc[kx];
     }
-    if (tq == 0) dst[KK] = asum;
+    if (ky == 0) dst[KK] = asum;
 }
 
+// sum of the per-block partials: a block takes 64 consecutive outputs x 4 slices of the partial list
 __global__ void __launch_bounds__(TC_THREADS)
 thin_wgrad_reduce_kernel(const float *__restrict__ partial, int n_blocks, int C, int KK, float *__restrict__ g, float *__restrict__ asum) {
-    const int i = blockIdx.x * TC_THREADS + threadIdx.x;        // over C * (KK + 1)
-    if (i >= C * (KK + 1)) return;
+    __shared__ float part[4][64];
+    const int total = C * (KK + 1);
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     float v = 0.f;
-    for (int b = 0; b < n_blocks; b++) v += partial[(size_t)b * C * (KK + 1) + i];
+    if (i < total)
+        for (int b = slice; b < n_blocks; b += 4) v += partial[(size_t)b * total + i];
+    part[slice][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (slice != 0 || i >= total) return;
+    v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
     const int c = i / (KK + 1), t = i % (KK + 1);
     if (t < KK) g[(size_t)c * KK + t] = v;
     else if (asum) asum[c] = v;
@@ -226,14 +271,11 @@ extern "C" int octa_thinconv_expand(octa_ctx *ctx, const void *d_s, const void *
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
     const int Ho = Hs + 2 * pad - K + 1, Wo = Ws + 2 * pad - K + 1;
-    const int g8 = C / 8, ppw = TC_THREADS / g8;
-    if (ppw < 1 || TC_THREADS % g8) { octa::set_error("octa_thinconv_expand: C / 8 must divide %d", TC_THREADS); return -2; }
-    const long long n_seg = (long long)N * Ho * ((Wo + ppw - 1) / ppw);
-    const unsigned grid = (unsigned)((n_seg + EXPAND_SEGS - 1) / EXPAND_SEGS);
-    const size_t lds = ((size_t)K * K * C + (size_t)K * (ppw + K - 1)) * sizeof(float);
-    if (lds > 64 * 1024) { octa::set_error("octa_thinconv_expand: %d x %d weights of %d channels do not fit the LDS", K, K, C); return -2; }
-    if (K == 7) hipLaunchKernelGGL(thin_expand_kernel<7>, dim3(grid), dim3(TC_THREADS), lds, stream, (const bf16_t *)d_s, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Hs, Ws, Ho, Wo, C, pad, flip, slope);
-    else hipLaunchKernelGGL(thin_expand_kernel<4>, dim3(grid), dim3(TC_THREADS), lds, stream, (const bf16_t *)d_s, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Hs, Ws, Ho, Wo, C, pad, flip, slope);
+    const size_t lds = ((size_t)64 * (K * K + 1) + (size_t)K * (Wo + K - 1)) * sizeof(float);
+    if (lds > 64 * 1024) { octa::set_error("octa_thinconv_expand: rows of %d pixels do not fit the LDS window", Wo); return -2; }
+    const dim3 grid((unsigned)((long long)N * Ho), (unsigned)(C / 64));
+    if (K == 7) hipLaunchKernelGGL(thin_expand_kernel<7>, grid, dim3(TC_THREADS), lds, stream, (const bf16_t *)d_s, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Hs, Ws, Ho, Wo, C, pad, flip, slope);
+    else hipLaunchKernelGGL(thin_expand_kernel<4>, grid, dim3(TC_THREADS), lds, stream, (const bf16_t *)d_s, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Hs, Ws, Ho, Wo, C, pad, flip, slope);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -245,11 +287,11 @@ extern "C" int octa_thinconv_squeeze(octa_ctx *ctx, const void *d_a, const void 
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
     const int Ho = Ha + 2 * pad - K + 1, Wo = Wa + 2 * pad - K + 1;
-    constexpr int P = 8;
-    const long long groups = (long long)N * Ho * ((Wo + P - 1) / P);
-    const unsigned grid = (unsigned)((groups + TC_THREADS / 64 - 1) / (TC_THREADS / 64));
-    if (K == 7) hipLaunchKernelGGL((thin_squeeze_kernel<7, P>), dim3(grid), dim3(TC_THREADS), 0, stream, (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho, Wo, C, pad, flip);
-    else hipLaunchKernelGGL((thin_squeeze_kernel<4, P>), dim3(grid), dim3(TC_THREADS), 0, stream, (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho, Wo, C, pad, flip);
+    const unsigned grid = (unsigned)((long long)N * Ho);
+    const size_t lds = (size_t)C * (K * K + 1) * sizeof(float);
+    if (lds > 64 * 1024) { octa::set_error("octa_thinconv_squeeze: %d x %d weights of %d channels do not fit the LDS", K, K, C); return -2; }
+    if (K == 7) hipLaunchKernelGGL((thin_squeeze_kernel<7, 8>), dim3(grid), dim3(TC_THREADS), lds, stream, (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho, Wo, C, pad, flip);
+    else hipLaunchKernelGGL((thin_squeeze_kernel<4, 8>), dim3(grid), dim3(TC_THREADS), lds, stream, (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho, Wo, C, pad, flip);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -263,16 +305,17 @@ extern "C" long long octa_thinconv_wgrad_scratch_floats(int N, int Ha, int C, in
 extern "C" int octa_thinconv_wgrad(octa_ctx *ctx, const void *d_a, const void *d_s, void *d_scratch, void *d_g, void *d_asum, int N, int Ha, int Wa,
                                    int Hs, int Ws, int C, int K, int pad, int flip, void *stream_) {
     if (!ctx || !d_a || !d_s || !d_scratch || !d_g) { octa::set_error("octa_thinconv_wgrad: null argument"); return -2; }
-    if (!shape_ok("octa_thinconv_wgrad", N, Ha, Wa, C, K, pad) || Hs <= 0 || Ws <= 0) { if (Hs <= 0 || Ws <= 0) octa::set_error("octa_thinconv_wgrad: bad s extent"); return -2; }
+    if (!shape_ok("octa_thinconv_wgrad", N, Ha, Wa, C, K, pad)) return -2;
+    if (Hs <= 0 || Ws <= 0) { octa::set_error("octa_thinconv_wgrad: bad s extent"); return -2; }
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
     const unsigned blocks = (unsigned)(((long long)N * Ha + WG_ROWS - 1) / WG_ROWS);
-    const size_t lds = (size_t)K * (Wa + K - 1) * sizeof(float);
+    const size_t lds = (size_t)K * (Wa + K - 1 + 2 * K) * sizeof(float);
     if (lds > 60 * 1024) { octa::set_error("octa_thinconv_wgrad: rows of %d pixels do not fit the LDS window", Wa); return -2; }
-    if (K == 7) hipLaunchKernelGGL(thin_wgrad_kernel<7>, dim3(blocks, C / 64), dim3(TC_THREADS), lds, stream, (const bf16_t *)d_a, (const bf16_t *)d_s, (float *)d_scratch, N, Ha, Wa, Hs, Ws, C, pad, flip);
-    else hipLaunchKernelGGL(thin_wgrad_kernel<4>, dim3(blocks, C / 64), dim3(TC_THREADS), lds, stream, (const bf16_t *)d_a, (const bf16_t *)d_s, (float *)d_scratch, N, Ha, Wa, Hs, Ws, C, pad, flip);
+    if (K == 7) hipLaunchKernelGGL(thin_wgrad_kernel<7>, dim3(blocks, C / 64), dim3(7 * 64), lds, stream, (const bf16_t *)d_a, (const bf16_t *)d_s, (float *)d_scratch, N, Ha, Wa, Hs, Ws, C, pad, flip);
+    else hipLaunchKernelGGL(thin_wgrad_kernel<4>, dim3(blocks, C / 64), dim3(4 * 64), lds, stream, (const bf16_t *)d_a, (const bf16_t *)d_s, (float *)d_scratch, N, Ha, Wa, Hs, Ws, C, pad, flip);
     const int total = C * (K * K + 1);
-    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((total + TC_THREADS - 1) / TC_THREADS), dim3(TC_THREADS), 0, stream, (const float *)d_scratch, (int)blocks, C, K * K, (float *)d_g, (float *)d_asum);
+    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(TC_THREADS), 0, stream, (const float *)d_scratch, (int)blocks, C, K * K, (float *)d_g, (float *)d_asum);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
