@@ -1314,16 +1314,23 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     if (b.tid < 64) {
         const int lane = b.tid;
         int acc_n = 0;
-        for (int q = 0; q < n_pass; q++) {
-            V3 c = ld3(cand + 3 * plist[q]);
-            bool conflict = false;
-            for (int j = lane; j < acc_n; j += 64)
-                if (!(rownorm(sub(c, ld3(acc + 3 * j))) > es)) conflict = true;
-            if (!__any(conflict)) {
-                if (acc_n < ACCCAP) { if (lane == 0) st3(acc + 3 * acc_n, c); }
-                else if (lane == 0) atomic_or_int(&sc->err, ERR_ACC_CAP);
-                acc_n++;
-                __builtin_amdgcn_wave_barrier();
+        for (int q0 = 0; q0 < n_pass; q0 += 64) {
+            // the next 64 candidates, one per lane: two memory round trips per 64 candidates instead of two per candidate
+            V3 mine = v3(0, 0, 0);
+            if (q0 + lane < n_pass) mine = ld3(cand + 3 * plist[q0 + lane]);
+            const int cnt = n_pass - q0 < 64 ? n_pass - q0 : 64;
+            for (int jj = 0; jj < cnt; jj++) {
+                const int jl = __builtin_amdgcn_readfirstlane(jj);
+                const V3 c = v3(readlane_f64(mine.x, jl), readlane_f64(mine.y, jl), readlane_f64(mine.z, jl));
+                bool conflict = false;
+                for (int j = lane; j < acc_n; j += 64)
+                    if (!(rownorm(sub(c, ld3(acc + 3 * j))) > es)) conflict = true;
+                if (!__any(conflict)) {
+                    if (acc_n < ACCCAP) { if (lane == 0) st3(acc + 3 * acc_n, c); }
+                    else if (lane == 0) atomic_or_int(&sc->err, ERR_ACC_CAP);
+                    acc_n++;
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
         if (lane == 0) ctl[0] = acc_n < ACCCAP ? acc_n : ACCCAP;
@@ -1623,6 +1630,73 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
 // Only the groups that grow under the speculation are visited, plus the (rare) inter-nodes whose child
 // radius an earlier node of this pass changed (dirty list fed by murray_to_root); this visits exactly the
 // groups for which the reference's sequential loop does anything.
+// The ordered pass consumes two streams whose order is known when it starts: the records of the groups that grow (A.glist /
+// A.rec, read-only during the pass) and the pre-generated random.uniform draws. One wave runs the pass, so both are fetched 64
+// entries at a time, one per lane (two memory round trips per 64 visits instead of one dependent round trip per visit), and
+// handed out with v_readlane. Host build: plain loads.
+struct GrowWindow {
+    const SimArrays *A;
+    int n_grow, base, g_mine;
+    Rec mine;                  // record of group g_mine (typed loads and typed lane reads: no aliasing through int*)
+    OCTA_HD inline void init(const SimArrays *A_, int n) { A = A_; n_grow = n; base = -64; g_mine = 0x7fffffff; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __device__ inline void refill(int from) {
+        base = from;
+        const int k = from + (int)(threadIdx.x & 63);
+        g_mine = 0x7fffffff;
+        if (k < n_grow) {
+            g_mine = A->glist[k];
+            mine = A->rec[g_mine];
+        }
+    }
+    __device__ inline int group(int gi) {
+        if (gi >= n_grow) return 0x7fffffff;
+        if (gi >= base + 64) refill(gi);
+        return __builtin_amdgcn_readlane(g_mine, __builtin_amdgcn_readfirstlane(gi - base));
+    }
+    static __device__ inline double lane_f64(double v, int j) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
+    }
+    __device__ inline Rec record(int gi) const {     // after group(gi)
+        const int j = __builtin_amdgcn_readfirstlane(gi - base);
+        Rec R;
+        R.newpos[0] = lane_f64(mine.newpos[0], j); R.newpos[1] = lane_f64(mine.newpos[1], j); R.newpos[2] = lane_f64(mine.newpos[2], j);
+        R.thr = lane_f64(mine.thr, j);
+        R.r1_used = lane_f64(mine.r1_used, j);
+        R.node = __builtin_amdgcn_readlane(mine.node, j);
+        R.req = __builtin_amdgcn_readlane(mine.req, j);
+        const int flags = __builtin_amdgcn_readlane((int)mine.type | ((int)mine.draw << 8) | ((int)mine.ang_gt90 << 16) | ((int)mine.grow << 24), j);
+        R.type = (unsigned char)(flags & 255); R.draw = (unsigned char)((flags >> 8) & 255);
+        R.ang_gt90 = (unsigned char)((flags >> 16) & 255); R.grow = (unsigned char)((flags >> 24) & 255);
+        R.child = (unsigned short)__builtin_amdgcn_readlane((int)mine.child, j);
+        R.pad[0] = R.pad[1] = 0;
+        return R;
+    }
+#else
+    inline int group(int gi) { return gi < n_grow ? A->glist[gi] : 0x7fffffff; }
+    inline Rec record(int gi) const { return A->rec[A->glist[gi]]; }
+#endif
+};
+struct UniformWindow {
+    const double *u;
+    int cap, base;
+    double mine;
+    OCTA_HD inline void init(const double *u_, int cap_) { u = u_; cap = cap_; base = -64; mine = 0; }
+    OCTA_HD inline double at(int pos) {            // pos < cap
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (pos >= base + 64 || pos < base) {
+            base = pos;
+            const int k = pos + (int)(threadIdx.x & 63);
+            mine = k < cap ? u[k] : 0.0;
+        }
+        const int j = __builtin_amdgcn_readfirstlane(pos - base);
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), j), __builtin_amdgcn_readlane(__double2loint(mine), j));
+#else
+        return u[pos];
+#endif
+    }
+};
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OCTA_FLUSH_T0() ((long)wall_clock64())
 #else
@@ -1679,14 +1753,12 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
         const int py_cap = sc->py_cap;
         long steps = 0, n_bif = 0, respec = 0;
         int n_def = 0;           // nodes on the deferred list (A.act_list) of this pass
-        double u_next = py_pos < py_cap ? A.py_u[py_pos] : 0.0;
-        // the next record of the grow list is always in flight
+        UniformWindow U;
+        U.init(A.py_u, py_cap);
+        GrowWindow W;
+        W.init(&A, n_grow);
         const int INF = 0x7fffffff;
         int gi = 0;
-        int g1 = n_grow > 0 ? A.glist[0] : INF;
-        int g1n = n_grow > 1 ? A.glist[1] : INF;
-        Rec R1;
-        if (g1 != INF) R1 = A.rec[g1];
         int last_g = -1;
         bool scan_all = false;  // fallback when the dirty list overflows: visit every remaining group
         while (true) {
@@ -1697,16 +1769,14 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 if (g >= ng) break;
                 R = A.rec[g];
             } else {
+                const int g1 = W.group(gi);
                 int g2 = D.n > 0 ? D.v[0] : INF;
                 g = g1 < g2 ? g1 : g2;
                 if (g == INF) break;
                 if (g == g2) { for (int k = 1; k < D.n; k++) D.v[k - 1] = D.v[k]; D.n--; }
                 if (g == g1) {
-                    R = R1;
+                    R = W.record(gi);
                     gi++;
-                    g1 = g1n;
-                    g1n = gi + 1 < n_grow ? A.glist[gi + 1] : INF;
-                    if (g1 != INF) R1 = A.rec[g1];
                 } else {
                     R = A.rec[g];
                 }
@@ -1719,9 +1789,8 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 bool bif = false;
                 if (R.draw) {
                     if (py_pos >= py_cap) { err |= ERR_PY_CAP; break; }
-                    double u = u_next;
+                    const double u = U.at(py_pos);
                     py_pos++;
-                    u_next = py_pos < py_cap ? A.py_u[py_pos] : 0.0;
                     bif = (R.thr > u) && R.ang_gt90;
                 }
                 if (bif) {
@@ -1742,9 +1811,8 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 }
                 if (!R.grow) continue;
                 if (py_pos >= py_cap) { err |= ERR_PY_CAP; break; }
-                double u = u_next;
+                const double u = U.at(py_pos);
                 py_pos++;
-                u_next = py_pos < py_cap ? A.py_u[py_pos] : 0.0;
                 if (R.thr <= u && !R.ang_gt90) continue;
                 seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 1, P.kappa, L);
                 SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def));
