@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r02}
 OUT=gpurun_out
 mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py > $OUT/${TAG}_bench_stdout.log 2>&1
+timeout 2400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py > $OUT/${TAG}_bench_stdout.log 2>&1
 find $OUT/prof_kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
 grep '"metric"' $OUT/${TAG}_bench_stdout.log | tail -1 > $OUT/${TAG}_bench_line.json
 for C in FETCH_SIZE WRITE_SIZE; do
