@@ -30,6 +30,7 @@ def main(argv=None):
     parser.add_argument('--labels', action="store_true", help="also write <name>_label.png (1216x1216, binarised)")
     parser.add_argument('--seed', type=int, default=None)
     parser.add_argument('--batch', type=int, default=128)
+    parser.add_argument('--inflight', type=int, default=4, help="batches simulated concurrently (one generator thread, HIP stream and simulator state each)")
     parser.add_argument('--device', type=int, default=0)
     args, unknown = parser.parse_known_args(argv)
     if args.debug:
@@ -53,42 +54,94 @@ def main(argv=None):
     torch.cuda.set_device(args.device)
     seed0 = args.seed if args.seed is not None else random.SystemRandom().randrange(0, 2 ** 31 - args.num_samples - 1)
     writer = SampleFileWriter(args.threads if args.threads > 0 else None)
+    # Batches are independent: `--inflight` generator threads (own simulator state, rasteriser scratch and HIP stream each) keep
+    # that many launches of the persistent kernel on the GPU while this thread hands finished batches to the file writers -- the
+    # reference's process pool over samples (generate_vessel_graph.py:112-129) with the roles of CPU and GPU exchanged.
+    import queue
+    import threading
+    plan = []
     done = 0
-    gen = None
+    while done < args.num_samples:
+        B = min(args.batch, args.num_samples - done)
+        plan.append((done, B))
+        done += B
+    n_fly = max(1, min(args.inflight, len(plan)))
+    todo = queue.Queue()
+    for item in plan:
+        todo.put(item)
+    finished = queue.Queue(maxsize=2)                     # bounds the host memory held by batches waiting for the writers
+    failure = []
+    stop = threading.Event()
+    dev = torch.cuda.current_device()
+
+    def generate_batches():
+        gens = {}
+        try:
+            torch.cuda.set_device(dev)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                while not stop.is_set():
+                    try:
+                        start, B = todo.get_nowait()
+                    except queue.Empty:
+                        break
+                    if B not in gens:
+                        gens[B] = pipeline.TripleGenerator(config, B)
+                    seeds = np.arange(seed0 + start, seed0 + start + B, dtype=np.int64).astype(np.uint32)
+                    out = gens[B].generate(seeds, want_label=args.labels)
+                    res = out["result"]
+                    images = out["image"].cpu().numpy()
+                    labels = out["label"].cpu().numpy() if args.labels else None
+                    vols = None
+                    if out_cfg.get("save_3D_volumes"):
+                        shape = np.array([config['Greenhouse']['SimulationSpace'][a] for a in ("no_voxel_x", "no_voxel_y", "no_voxel_z")])
+                        vol_dim = [int(d) for d in shape * out_cfg['image_scale_factor']]
+                        vols = []
+                        for k in range(B):
+                            d_edges = torch.from_numpy(np.ascontiguousarray(res.sample_edges(k))).cuda()
+                            na = int(res.n_art[k])
+                            v = tree2img.voxelize_edges_device(d_edges, np.array([0, na, len(d_edges)]), vol_dim)
+                            vols.append(torch.maximum(v[0], v[1]).cpu().numpy().astype(np.uint8))
+                    finished.put((B, res, images, labels, vols))
+        except BaseException as e:                            # noqa: BLE001 -- re-raised by the main thread
+            failure.append(e)
+            stop.set()
+        finally:
+            for g in gens.values():
+                g.close()
+            finished.put(None)
+
+    threads = [threading.Thread(target=generate_batches, name=f"octa-generator-{i}") for i in range(n_fly)]
+    for t in threads:
+        t.start()
+    done = 0
+    alive = n_fly
     try:
-        while done < args.num_samples:
-            B = min(args.batch, args.num_samples - done)
-            if gen is None or gen.batch != B:
-                if gen is not None:
-                    gen.close()
-                gen = pipeline.TripleGenerator(config, B)
-            seeds = np.arange(seed0 + done, seed0 + done + B, dtype=np.int64).astype(np.uint32)
-            out = gen.generate(seeds, want_label=args.labels)
-            res = out["result"]
-            images = out["image"].cpu().numpy()
-            labels = out["label"].cpu().numpy() if args.labels else None
-            writer.wait()                                  # the previous batch's files (written while this one was simulated)
+        while alive:
+            item = finished.get()
+            if item is None:
+                alive -= 1
+                continue
+            B, res, images, labels, vols = item
+            writer.wait()                                  # the previous batch's files (written while the next ones were simulated)
             for k in range(B):
                 out_dir = os.path.join(os.path.abspath(out_cfg['directory']), datetime.now().strftime('%Y%m%d_%H%M%S') + "_" + str(uuid4()))
                 name = os.path.basename(out_dir)
-                edges = res.sample_edges(k)
-                vol = None
-                if out_cfg.get("save_3D_volumes"):
-                    shape = np.array([config['Greenhouse']['SimulationSpace'][a] for a in ("no_voxel_x", "no_voxel_y", "no_voxel_z")])
-                    vol_dim = [int(d) for d in shape * out_cfg['image_scale_factor']]
-                    d_edges = torch.from_numpy(np.ascontiguousarray(edges)).cuda()
-                    na = int(res.n_art[k])
-                    vols = tree2img.voxelize_edges_device(d_edges, np.array([0, na, len(edges)]), vol_dim)
-                    vol = torch.maximum(vols[0], vols[1]).cpu().numpy().astype(np.uint8)
-                writer.submit(out_dir, name, edges=edges if out_cfg.get('save_trees', True) else None,
+                writer.submit(out_dir, name, edges=res.sample_edges(k) if out_cfg.get('save_trees', True) else None,
                               image=images[k] if out_cfg.get("save_2D_image", True) else None,
-                              label_bits=labels[k] if labels is not None else None, config=config, volume=vol)
+                              label_bits=labels[k] if labels is not None else None, config=config, volume=vols[k] if vols is not None else None)
             done += B
             print(f"generated {done}/{args.num_samples} vessel graphs")
     finally:
+        stop.set()                                         # after a failure here or in a generator: let the other threads run out
+        while alive:
+            if finished.get() is None:
+                alive -= 1
+        for t in threads:
+            t.join()
         writer.close()                                     # a failed write raises here (the reference drops worker exceptions)
-        if gen is not None:
-            gen.close()
+    if failure:
+        raise RuntimeError("a generator thread failed") from failure[0]
 
 
 if __name__ == '__main__':

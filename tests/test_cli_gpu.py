@@ -44,3 +44,36 @@ def test_generate_and_visualize_cli(tmp_path, hip_lib_built):
         got = np.array(Image.open(str(vis / (name + "_label.png"))).convert("L"))
         assert Image.open(str(vis / (name + "_label.png"))).mode == "1"
         assert (got == want).all()
+
+
+def test_generate_cli_keeps_batches_in_flight(tmp_path, hip_lib_built):
+    """--inflight: ten samples in batches of four (4 + 4 + 2) from three generator threads, labels included: every sample's files
+    arrive, and the CSV texts are the oracle's for seeds 0..9 whatever the order the batches finish in."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import generate_vessel_graph
+    from PIL import Image
+    from octa_autosegmentation_amd import graph_io
+    from oracle import octa_oracle, sim_oracle
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
+    cfg = yaml.safe_load(str(g["config_yaml"]))
+    cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = 10, 5
+    cfg_path = tmp_path / "cfg.yml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    out_dir = tmp_path / "graphs"
+    generate_vessel_graph.main(["--config_file", str(cfg_path), "--num_samples", "10", "--batch", "4", "--inflight", "3", "--seed", "0", "--labels",
+                                "--output.directory", str(out_dir)])
+    dirs = sorted(glob.glob(str(out_dir / "*")))
+    assert len(dirs) == 10
+    want = {}
+    for seed in range(10):
+        e, _ = sim_oracle.simulate(cfg, seed)
+        want[sim_oracle.edges_to_csv_text(e)] = e
+    for d in dirs:
+        name = os.path.basename(d)
+        text = open(os.path.join(d, name + ".csv"), newline="").read()
+        assert text in want
+        e = want.pop(text)
+        label = np.array(Image.open(os.path.join(d, name + "_label.png")).convert("L"))
+        assert (label == octa_oracle.fs_dither(octa_oracle.rasterize(graph_io.edges_as_read_back(e), [1216, 1216]))).all()
+    assert not want
