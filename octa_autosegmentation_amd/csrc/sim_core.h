@@ -857,9 +857,20 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
     b.sync();
     for (int c = b.tid; c <= ncell; c += b.nth) hist[c] = 0;
     b.sync();
-    for (int i = b.tid; i < n; i += b.nth) {
-        const double *p = pts + 3 * (ids ? ids[i] : i);
-        atomic_add_int(&hist[grid_cy(G, p[1]) * nc + grid_cx(G, p[0])], 1);
+    // both passes fetch four points per thread and round: the loads (id, then coordinates) of the four are independent
+    constexpr int GB = 4;
+    for (int i0 = b.tid; i0 < n; i0 += GB * b.nth) {
+        double px[GB], py[GB];
+#pragma unroll
+        for (int k = 0; k < GB; k++) {
+            const int i = i0 + k * b.nth;
+            const int ic = i < n ? i : n - 1;
+            const double *p = pts + 3 * (ids ? ids[ic] : ic);
+            px[k] = p[0]; py[k] = p[1];
+        }
+#pragma unroll
+        for (int k = 0; k < GB; k++)
+            if (i0 + k * b.nth < n) atomic_add_int(&hist[grid_cy(G, py[k]) * nc + grid_cx(G, px[k])], 1);
     }
     b.sync();
     {   // exclusive scan over the cells: contiguous chunk per thread + ONE block scan
@@ -874,12 +885,23 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
         for (int c = c0; c < c1; c++) { int v = hist[c]; hist[c] = run; run += v; }
     }
     b.sync();
-    for (int i = b.tid; i < n; i += b.nth) {
-        int id = ids ? ids[i] : i;
-        const V3 p = ld3(pts + 3 * id);
-        int pos = atomic_add_int(&hist[grid_cy(G, p.y) * nc + grid_cx(G, p.x)], 1);  // hist[c] ends as the END of cell c
-        items[pos] = (unsigned short)id;
-        st3(A.grid_pts + 3 * pos, p);
+    for (int i0 = b.tid; i0 < n; i0 += GB * b.nth) {
+        V3 p[GB];
+        int id[GB];
+#pragma unroll
+        for (int k = 0; k < GB; k++) {
+            const int i = i0 + k * b.nth;
+            const int ic = i < n ? i : n - 1;
+            id[k] = ids ? ids[ic] : ic;
+            p[k] = ld3(pts + 3 * id[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < GB; k++)
+            if (i0 + k * b.nth < n) {
+                int pos = atomic_add_int(&hist[grid_cy(G, p[k].y) * nc + grid_cx(G, p[k].x)], 1);  // hist[c] ends as the END of cell c
+                items[pos] = (unsigned short)id[k];
+                st3(A.grid_pts + 3 * pos, p[k]);
+            }
     }
     b.sync();
     return G;
