@@ -46,8 +46,6 @@ def main(argv=None):
     out_cfg = config['output']
     assert out_cfg.get('save_3D_volumes') in [None, 'npy', 'nifti'], \
         f"Your provided option {out_cfg.get('save_3D_volumes')} for 'save_3D_volumes' does not exist. Choose one of 'null', 'npy' or 'nifti'."
-    if out_cfg.get('save_3D_volumes') == 'nifti':
-        raise NotImplementedError("nifti output needs nibabel, which is not part of the MI355X image; use 'npy'")
 
     import torch
     from octa_autosegmentation_amd.output_files import SampleFileWriter
@@ -129,7 +127,8 @@ def main(argv=None):
                 name = os.path.basename(out_dir)
                 writer.submit(out_dir, name, edges=res.sample_edges(k) if out_cfg.get('save_trees', True) else None,
                               image=images[k] if out_cfg.get("save_2D_image", True) else None,
-                              label_bits=labels[k] if labels is not None else None, config=config, volume=vols[k] if vols is not None else None)
+                              label_bits=labels[k] if labels is not None else None, config=config, volume=vols[k] if vols is not None else None,
+                              volume_format=out_cfg.get("save_3D_volumes") or "npy")
             done += B
             print(f"generated {done}/{args.num_samples} vessel graphs")
     finally:

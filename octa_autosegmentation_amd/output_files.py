@@ -22,7 +22,7 @@ class SampleFileWriter:
         self.pool = ThreadPoolExecutor(max_workers=threads or default_threads())
         self.pending = []
 
-    def submit(self, out_dir, name, edges=None, image=None, label_bits=None, config=None, volume=None):
+    def submit(self, out_dir, name, edges=None, image=None, label_bits=None, config=None, volume=None, volume_format="npy"):
         """Queue one sample's files. edges float64 [n,7]; image uint8 [H,W]; label_bits uint8 [H,W] (non-zero = white)."""
         os.makedirs(out_dir, exist_ok=True)
         if config is not None:
@@ -36,7 +36,10 @@ class SampleFileWriter:
         if label_bits is not None:
             self.pending.append(self.pool.submit(tree2img.save_label_png, label_bits, os.path.join(out_dir, name + "_label.png")))
         if volume is not None:
-            self.pending.append(self.pool.submit(np.save, os.path.join(out_dir, "art_ven_img_gray.npy"), volume))
+            if volume_format == "nifti":
+                self.pending.append(self.pool.submit(write_nifti_u8, os.path.join(out_dir, "art_ven_img_gray.nii.gz"), volume))
+            else:
+                self.pending.append(self.pool.submit(np.save, os.path.join(out_dir, "art_ven_img_gray.npy"), volume))
 
     def wait(self):
         """Block until everything queued so far is on disk; a failed write raises here."""
@@ -47,3 +50,36 @@ class SampleFileWriter:
     def close(self):
         self.wait()
         self.pool.shutdown()
+
+
+def write_nifti_u8(path, volume):
+    """`nib.save(nib.Nifti1Image(volume, np.eye(4)), path)` (generate_vessel_graph.py:75-77) for a uint8 volume without nibabel (not in
+    the MI355X image): a single-file NIfTI-1 (`n+1`), 348-byte header + 4 empty extension bytes, voxels in Fortran order, gzip when
+    the name ends in .gz. Identity sform (code 2, "aligned"), qform code 0, unit voxel sizes, no intensity scaling -- what nibabel
+    derives from an identity affine. Written from the NIfTI-1 specification; nibabel is absent, so byte identity with its files is
+    unpinned (readers compare header fields, not bytes)."""
+    import gzip
+    import struct
+    vol = np.asarray(volume)
+    if vol.dtype != np.uint8 or vol.ndim != 3:
+        raise ValueError("write_nifti_u8 expects a 3-D uint8 volume")
+    hdr = bytearray(348)
+    struct.pack_into("<i", hdr, 0, 348)                                   # sizeof_hdr
+    hdr[38] = ord("r")                                                    # regular
+    struct.pack_into("<8h", hdr, 40, 3, vol.shape[0], vol.shape[1], vol.shape[2], 1, 1, 1, 1)   # dim
+    struct.pack_into("<hh", hdr, 70, 2, 8)                                # datatype = DT_UINT8, bitpix
+    struct.pack_into("<8f", hdr, 76, 1, 1, 1, 1, 1, 1, 1, 1)              # pixdim (qfac = 1)
+    struct.pack_into("<f", hdr, 108, 352.0)                               # vox_offset
+    struct.pack_into("<ff", hdr, 112, float("nan"), float("nan"))         # scl_slope / scl_inter: not set
+    struct.pack_into("<hh", hdr, 252, 0, 2)                               # qform_code = unknown, sform_code = aligned
+    struct.pack_into("<4f", hdr, 280, 1, 0, 0, 0)                         # srow_x
+    struct.pack_into("<4f", hdr, 296, 0, 1, 0, 0)                         # srow_y
+    struct.pack_into("<4f", hdr, 312, 0, 0, 1, 0)                         # srow_z
+    hdr[344:348] = b"n+1\0"
+    payload = bytes(hdr) + b"\0\0\0\0" + vol.tobytes(order="F")
+    if str(path).endswith(".gz"):
+        with open(path, "wb") as raw, gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as f:
+            f.write(payload)
+    else:
+        with open(path, "wb") as f:
+            f.write(payload)

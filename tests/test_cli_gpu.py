@@ -62,7 +62,7 @@ def test_generate_cli_keeps_batches_in_flight(tmp_path, hip_lib_built):
     cfg_path.write_text(yaml.safe_dump(cfg))
     out_dir = tmp_path / "graphs"
     generate_vessel_graph.main(["--config_file", str(cfg_path), "--num_samples", "10", "--batch", "4", "--inflight", "3", "--seed", "0", "--labels",
-                                "--output.directory", str(out_dir)])
+                                "--output.directory", str(out_dir), "--output.save_3D_volumes", "nifti"])
     dirs = sorted(glob.glob(str(out_dir / "*")))
     assert len(dirs) == 10
     want = {}
@@ -76,4 +76,10 @@ def test_generate_cli_keeps_batches_in_flight(tmp_path, hip_lib_built):
         e = want.pop(text)
         label = np.array(Image.open(os.path.join(d, name + "_label.png")).convert("L"))
         assert (label == octa_oracle.fs_dither(octa_oracle.rasterize(graph_io.edges_as_read_back(e), [1216, 1216]))).all()
+        import gzip
+        import struct
+        raw = gzip.open(os.path.join(d, "art_ven_img_gray.nii.gz"), "rb").read()          # save_3D_volumes: nifti (generate_vessel_graph.py:75-77)
+        dims = struct.unpack_from("<8h", raw, 40)
+        # 304 x 304 x (3 + the voxeliser's padding of the thin axis, tree2img.py: the same volume `npy` output stores)
+        assert dims[0] == 3 and dims[1:3] == (304, 304) and dims[3] >= 3 and len(raw) == 352 + dims[1] * dims[2] * dims[3]
     assert not want

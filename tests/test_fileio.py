@@ -90,3 +90,26 @@ def test_png_files_decode_like_pillows(tmp_path, hip_lib_built):
         ref = str(tmp_path / f"r{h}.png")
         Image.fromarray(bits > 0).save(ref)               # what visualize_vessel_graphs.py:99 writes
         assert (np.array(Image.open(ref).convert("L")) == np.array(back.convert("L"))).all()
+
+
+def test_nifti_writer_header_and_voxels(tmp_path):
+    """generate_vessel_graph.py:75-77 (`save_3D_volumes: nifti`) without nibabel: the file read back by the NIfTI-1 layout -- header
+    fields a reader checks, Fortran-ordered voxels behind vox_offset."""
+    import gzip
+    import struct
+    from octa_autosegmentation_amd.output_files import write_nifti_u8
+    rng = np.random.default_rng(4)
+    vol = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    path = tmp_path / "art_ven_img_gray.nii.gz"
+    write_nifti_u8(str(path), vol)
+    raw = gzip.open(path, "rb").read()
+    assert struct.unpack_from("<i", raw, 0)[0] == 348 and raw[344:348] == b"n+1\0"
+    assert struct.unpack_from("<8h", raw, 40) == (3, 7, 5, 3, 1, 1, 1, 1)
+    assert struct.unpack_from("<hh", raw, 70) == (2, 8) and struct.unpack_from("<f", raw, 108)[0] == 352.0
+    assert struct.unpack_from("<hh", raw, 252) == (0, 2)
+    assert struct.unpack_from("<12f", raw, 280) == (1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0)
+    assert len(raw) == 352 + vol.size
+    back = np.frombuffer(raw, np.uint8, vol.size, 352).reshape(vol.shape, order="F")
+    assert (back == vol).all()
+    with pytest.raises(ValueError):
+        write_nifti_u8(str(tmp_path / "x.nii"), vol.astype(np.float32))
