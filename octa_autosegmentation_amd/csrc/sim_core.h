@@ -1875,22 +1875,47 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     b.sync();
 }
 
-// stable removal of flagged points from an ordered list (element_mesh.py:196-211 delete_all)
+// stable removal of flagged points from an ordered list (element_mesh.py:196-211 delete_all), IN PLACE: a point only moves towards
+// the front, so the list is rewritten tile by tile -- a tile = the contiguous chunks of a group of threads; its kept points are
+// packed into LDS (each thread at its scanned offset), then copied to their final place with coalesced stores. One read of the
+// list, one write of the kept points that moved; no staging copy in HBM. `stage` is unused (kept for the callers' signature).
+constexpr int COMPACT_TILE = 6144;     // points per LDS tile (144 KiB of the user area)
 OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsigned char *removed, double *stage) {
-    int n_keep = 0;
-    {
-        const int chunk = (n + b.nth - 1) / b.nth;
-        const int i0 = b.tid * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
-        int local = 0;
-        for (int i = i0; i < i1; i++) local += removed[i] ? 0 : 1;
-        int ex;
-        n_keep = blk_scan(b, local, &ex);
-        int w = ex;
-        for (int i = i0; i < i1; i++)
-            if (!removed[i]) { stage[3 * w] = pts[3 * i]; stage[3 * w + 1] = pts[3 * i + 1]; stage[3 * w + 2] = pts[3 * i + 2]; w++; }
+    (void)stage;
+    if (b.nth == 1) {                                                 // host build: one thread, a forward copy is in place already
+        int w = 0;
+        for (int i = 0; i < n; i++)
+            if (!removed[i]) { if (w != i) { pts[3 * w] = pts[3 * i]; pts[3 * w + 1] = pts[3 * i + 1]; pts[3 * w + 2] = pts[3 * i + 2]; } w++; }
+        return w;
     }
-    b.sync();
-    for (int j = b.tid; j < n_keep * 3; j += b.nth) pts[j] = stage[j];
+    double *tile = reinterpret_cast<double *>(b.user());
+    static_assert((size_t)COMPACT_TILE * 24 + 2048 <= (size_t)SIM_LDS_BYTES, "compaction tile");
+    const int chunk = (n + b.nth - 1) / b.nth;
+    const int i0 = b.tid * chunk < n ? b.tid * chunk : n, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+    int local = 0;
+    for (int i = i0; i < i1; i++) local += removed[i] ? 0 : 1;
+    int ex;
+    const int n_keep = blk_scan(b, local, &ex);
+    if (n_keep == n) return n_keep;                                   // nothing removed (uniform)
+    const int group = chunk > 0 ? (COMPACT_TILE / chunk > 0 ? COMPACT_TILE / chunk : 1) : b.nth;   // threads per tile
+    int *ctl = b.coll() + 106;                                        // [0] first destination of the tile, [1] its end
+    for (int t0 = 0; t0 < b.nth; t0 += group) {
+        const int t1 = t0 + group < b.nth ? t0 + group : b.nth;
+        b.sync();
+        if (b.tid == t0) ctl[0] = ex;
+        if (b.tid == t1 - 1) ctl[1] = ex + local;
+        b.sync();
+        const int base = ctl[0], kept = ctl[1] - ctl[0];
+        if (b.tid >= t0 && b.tid < t1) {
+            int w = ex - base;
+            for (int i = i0; i < i1; i++)
+                if (!removed[i]) { tile[3 * w] = pts[3 * i]; tile[3 * w + 1] = pts[3 * i + 1]; tile[3 * w + 2] = pts[3 * i + 2]; w++; }
+        }
+        b.sync();
+        // the tile's first source index is t0 * chunk: points in front of the first removal keep their place (base == source)
+        if (base != (t0 * chunk < n ? t0 * chunk : n) || kept != ((t1 * chunk < n ? t1 * chunk : n) - (t0 * chunk < n ? t0 * chunk : n)))
+            for (int j = b.tid; j < kept * 3; j += b.nth) pts[(size_t)3 * base + j] = tile[j];
+    }
     b.sync();
     return n_keep;
 }
