@@ -8,8 +8,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r02}
 OUT=gpurun_out
 mkdir -p $OUT
-timeout 2400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py > $OUT/${TAG}_bench_stdout.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_stdout.log 2>&1
 find $OUT/prof_kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
+rm -rf $OUT/prof_kt   # the raw trace is large; only the summary is kept
 grep '"metric"' $OUT/${TAG}_bench_stdout.log | tail -1 > $OUT/${TAG}_bench_line.json
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 2 --warmup 1 --inflight 1 --group 1 --no-cpu-baseline --no-train --no-files > $OUT/${TAG}_pmc_$C.log 2>&1
