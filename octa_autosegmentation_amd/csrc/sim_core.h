@@ -341,14 +341,24 @@ OCTA_HD inline unsigned long long py_hash_tuple3(V3 t) {
     return acc;
 }
 
-// CPython 3.10 set (add only): table arrays in global scratch, run by ONE thread
+// CPython 3.10 set (add only): table arrays in LDS or global scratch. Run by ONE thread (lane 0, nl 1) or by the nl = 64 lanes of
+// a wave that all execute the same insertions (same addresses, same values) and share the bulk loops of a resize -- clearing the
+// new table, scanning the old one for its entries, moving the new table down -- which dominate the replay for a few hundred keys.
 struct PySetView {
     unsigned long long *hash;
     int *key;
     int mask, fill, used;
     int *err;
     int cap;  // slots available in hash[] / key[]; the upper half is the resize staging area
+    int lane = 0, nl = 1;
 };
+OCTA_HD inline void pyset_team_sync(const PySetView &s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (s.nl > 1) __builtin_amdgcn_wave_barrier();
+#else
+    (void)s;
+#endif
+}
 OCTA_HD inline void pyset_init(PySetView &s) {
     for (int i = 0; i < 8; i++) s.key[i] = -1;
     s.mask = 7; s.fill = 0; s.used = 0;
@@ -374,10 +384,25 @@ OCTA_HD inline void pyset_resize(PySetView &s, int minused) {
     if (newsize > s.cap / 2) { atomic_or_int(s.err, ERR_SET_CAP); return; }
     unsigned long long *nh = s.hash + s.cap / 2;
     int *nk = s.key + s.cap / 2;
-    for (int i = 0; i < newsize; i++) nk[i] = -1;
-    for (int i = 0; i <= s.mask; i++)
-        if (s.key[i] >= 0) pyset_insert_clean(nh, nk, newsize - 1, s.key[i], s.hash[i]);
-    for (int i = 0; i < newsize; i++) { s.key[i] = nk[i]; s.hash[i] = nh[i]; }
+    for (int i = s.lane; i < newsize; i += s.nl) nk[i] = -1;
+    pyset_team_sync(s);
+    for (int base = 0; base <= s.mask; base += s.nl) {          // entries of the old table in slot order
+        const int slot = base + s.lane;
+        const bool used = slot <= s.mask && s.key[slot] >= 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned long long m = s.nl > 1 ? __ballot(used) : (used ? 1ull : 0ull);
+        while (m) {
+            const int j = (int)__ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            pyset_insert_clean(nh, nk, newsize - 1, s.key[base + j], s.hash[base + j]);
+        }
+#else
+        if (used) pyset_insert_clean(nh, nk, newsize - 1, s.key[slot], s.hash[slot]);
+#endif
+    }
+    pyset_team_sync(s);
+    for (int i = s.lane; i < newsize; i += s.nl) { s.key[i] = nk[i]; s.hash[i] = nh[i]; }
+    pyset_team_sync(s);
     s.mask = newsize - 1;
     s.fill = s.used;
 }
@@ -2023,12 +2048,13 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
         if (take) { in_key[ex] = o; in_hash[ex] = A.hashes[o]; }
         b.sync();
         int *ctl2 = b.coll() + 100;
-        if (b.tid == 0) {
+        if (b.tid < 64) {                       // the first wave replays the insertions, its lanes share the resizes' bulk loops
             PySetView S;
             S.hash = t_hash; S.key = t_key; S.err = &sc->err; S.cap = LSET_CAP;
+            S.lane = b.tid; S.nl = b.nth >= 64 ? 64 : 1;
             pyset_init(S);
             for (int i = 0; i < n_ins; i++) pyset_add(S, in_key[i], in_hash[i]);
-            ctl2[1] = S.mask;
+            if (b.tid == 0) ctl2[1] = S.mask;
         }
         b.sync();
         const int mask = ctl2[1];
