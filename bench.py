@@ -435,9 +435,9 @@ def main():
             "config": {"workload": f"configs[1]: {B}-sample vessel-graph batch (docker/vessel_graph_gen_docker_config.yml, "
                                    f"I=100+150, N=2000) + tree2img rasterise 304x304 image and 1216x1216 label",
                        "batch_per_gpu": B, "steps_per_launch": G, "launches_in_flight": n_fly, "parallelism": f"sample-sharded x{world}, no collective"},
-            "parity": "graph CSV text and label / image pixels bit-exact with the reference on its fixtures (radii: identical doubles; node "
-                      "positions: identical as printed, the doubles differ from the oracle's in the last bits -- device acos / cos / sin vs glibc's "
-                      "-- which changed ONE printed digit of one coordinate in 4352 further full-length seeds, profiles/r02_validate_final.log)",
+            "parity": "graph CSV text and label / image pixels bit-exact with the reference on its fixtures; edge lists identical to the "
+                      "oracle's in EVERY double (radii: glibc pow restated; node positions: glibc acos / sin / cos restated, "
+                      "csrc/glibc_trig.h) on the validated full-length seeds (profiles/r02_validate_final.log)",
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, {traffic_src})",

@@ -28,6 +28,7 @@
 #include <cstring>
 #include <algorithm>
 #include "gpow.h"
+#include "glibc_trig.h"
 
 namespace octa_simk {
 
@@ -1514,6 +1515,10 @@ struct GrowCtx {
     const double *rad;  // radii of forest f: HBM array, or the LDS copy during the ordered pass
 };
 
+// acos / cos / sin whose results reach a node position: glibc's, bit for bit (glibc_trig.h), inside the restated domain
+OCTA_HD inline double pos_acos(double c) { return (c > 0.0 && c <= 1.0) ? octa_gtrig::gacos(c) : acos(c); }
+OCTA_HD inline double pos_cos(double x) { return (x >= 0.0 && x < 2.4) ? octa_gtrig::gcos(x) : cos(x); }
+OCTA_HD inline double pos_sin(double x) { return (x >= 0.0 && x < 2.4) ? octa_gtrig::gsin(x) : sin(x); }
 // inter-node sprouting (greenhouse.py:259-306) for group g with the CURRENT child radius
 OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     const SimArrays &A = *G.A;
@@ -1529,7 +1534,8 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     double rp = gpow(gpow(r1, kappa) + gpow(r2, kappa), 1 / kappa);
     double rp4 = gpow(rp, 4.0), rp2 = gpow(rp, 2.0);
     double phi1 = acos((rp4 + gpow(r1, 4.0) - gpow(r2, 4.0)) / (2 * rp2 * gpow(r1, 2.0))) * rad2deg();
-    double phi2 = acos((rp4 + gpow(r2, 4.0) - gpow(r1, 4.0)) / (2 * rp2 * gpow(r2, 2.0))) * rad2deg();
+    // phi_2 and the rotation built from it reach the node position (phi_1 only enters angle windows): glibc's values (glibc_trig.h)
+    double phi2 = pos_acos((rp4 + gpow(r2, 4.0) - gpow(r1, 4.0)) / (2 * rp2 * gpow(r2, 2.0))) * rad2deg();
     V3 dist_seg = sub(ld3(A.npos[f] + 3 * ch), pos);
     V3 prox_seg = sub(pos, ld3(A.npos[f] + 3 * A.npar[f][id]));
     double nd = norm3(dist_seg), npx = norm3(prox_seg);
@@ -1557,7 +1563,7 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     R.ang_gt90 = angle2(vc0, vc1, avg.x, avg.y) > 90 ? 1 : 0;
     V3 k = unit(cr);
     double th = phi2 * deg2rad();
-    double ct = cos(th), st = sin(th);
+    double ct = pos_cos(th), st = pos_sin(th);
     V3 kxd = cross(k, dv);
     V3 vrot = add(add(mul(dv, ct), mul(kxd, st)), mul(mul(k, dot3_blas(k, dv)), 1 - ct));
     V3 gg = add(mul(unit(vrot), omega), mul(unit(avg), 1 - omega));

@@ -3,6 +3,7 @@
 // std::nth_element / CPython-set / glibc-pow restatements and the host-side init can be compared
 // with the oracle without a GPU. Never used by the product path.
 #include <cstdio>
+#include "../../octa_autosegmentation_amd/csrc/glibc_trig.h"
 #include <cstdlib>
 #include <vector>
 #include "../../octa_autosegmentation_amd/csrc/sim_host.h"
@@ -156,6 +157,15 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     if (getenv("OCTA_SIMCORE_VERBOSE")) fprintf(stderr, "murray: steps %ld deferred %ld flush rounds %ld\n", sc.murray_steps, sc.murray_deferred, sc.flush_rounds);
     info_out[5] = sc.n_bif; info_out[6] = sc.respec; info_out[7] = C.n_iter;
     return sc.err ? -10 : 0;
+}
+
+// glibc restatements of csrc/glibc_trig.h: out[3 i] = gsin(x[i]), out[3 i + 1] = gcos(x[i]), out[3 i + 2] = gacos(c[i])
+void octa_simcore_gtrig(const double *x, const double *c, int n, double *out) {
+    for (int i = 0; i < n; i++) {
+        out[3 * i] = octa_gtrig::gsin(x[i]);
+        out[3 * i + 1] = octa_gtrig::gcos(x[i]);
+        out[3 * i + 2] = octa_gtrig::gacos(c[i]);
+    }
 }
 
 }  // extern "C"

@@ -173,6 +173,7 @@ def test_128_sample_full_length_batch_against_the_oracle(hip_lib_built):
         assert gpu.shape == e.shape and int(res.n_art[k]) == na, seed
         assert graph_io.edges_to_csv_bytes(gpu) == graph_io.edges_to_csv_bytes(e), seed
         assert (gpu[:, 6] == e[:, 6]).all(), seed
+        assert (gpu == e).all(), (seed, int((gpu != e).sum()))         # every double: radii and node positions
 
 
 def test_voxel_volume_at_1216x1216x16_against_the_oracle(hip_lib_built):

@@ -18,12 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def core():
     src = os.path.join(ROOT, "tests", "native", "sim_core_host.cpp")
     so = os.path.join(ROOT, "tests", "native", "libsimcorehost.so")
-    deps = [src] + [os.path.join(ROOT, "octa_autosegmentation_amd", "csrc", f) for f in ("sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h")]
+    deps = [src] + [os.path.join(ROOT, "octa_autosegmentation_amd", "csrc", f) for f in ("sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h", "glibc_trig.h", "glibc_trig_tables.h")]
     if not os.path.exists(so) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(so):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
     l = ctypes.CDLL(so)
     l.octa_simcore_gpow_check.restype = ctypes.c_long
     l.octa_simcore_gpow_check.argtypes = [ctypes.c_long, ctypes.c_ulonglong]
+    l.octa_simcore_gtrig.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     l.octa_simcore_kd_indices.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     l.octa_simcore_set_order.restype = ctypes.c_long
     l.octa_simcore_set_order.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -85,3 +86,22 @@ def test_phases_reproduce_reference_csv(core, golden):
         assert (trace[: info[7]] == golden[name + "_trace"]).all(), name
         text = sim_oracle.edges_to_csv_text(edges[: info[0]])
         assert text.encode() == golden[name + "_csv"].tobytes(), name
+        # on the host (glibc's acos / cos / sin) the phase code equals the oracle in EVERY double, not only as printed
+        e_or, _ = sim_oracle.simulate(cfg, seed)
+        assert e_or.shape == (info[0], 7) and (e_or == edges[: info[0]]).all(), name
+
+
+def test_gtrig_is_glibc_sin_cos_acos(core):
+    """csrc/glibc_trig.h (the acos / sin / cos that reach node positions) against this image's libm, every branch: sin / cos on
+    [0, 2.4), acos on (0, 1] incl. arguments next to 1 and next to 0 and the interval knots."""
+    import math
+    rng = np.random.default_rng(7)
+    n = 600000
+    x = np.ascontiguousarray(np.concatenate([rng.uniform(0, 2.4, n - 6), [0.0, 1e-9, 0.126, 0.855469, math.pi / 2, 2.39]]))
+    c = np.ascontiguousarray(np.concatenate([rng.uniform(0, 1, n // 2), 1 - 10 ** rng.uniform(-16, -1, n // 4), 10 ** rng.uniform(-18, 0, n // 4 - 6),
+                                             [1.0, 0.125, 0.25, 0.5, 0.75, 0.96875]]))
+    out = np.zeros((n, 3))
+    core.octa_simcore_gtrig(x.ctypes.data, c.ctypes.data, n, out.ctypes.data)
+    assert (out[:, 0] == np.array([math.sin(v) for v in x])).all()
+    assert (out[:, 1] == np.array([math.cos(v) for v in x])).all()
+    assert (out[:, 2] == np.array([math.acos(v) for v in c])).all()

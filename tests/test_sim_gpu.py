@@ -98,7 +98,8 @@ def test_mode_edge_cases(gh, golden):
 
 
 def test_batch_vs_oracle_radii_bit_exact(gh, golden):
-    """A ragged batch of other seeds vs the CPU oracle: radii bit-exact, positions equal as text."""
+    """A ragged batch of other seeds vs the CPU oracle: EVERY double identical -- radii (glibc pow restated, csrc/gpow.h) and node
+    positions (glibc acos / sin / cos restated, csrc/glibc_trig.h) -- hence identical text."""
     from oracle import sim_oracle
     cfg = _cfg(golden, 12, 8)
     seeds = [21, 22, 23, 24, 25, 26]
@@ -108,6 +109,7 @@ def test_batch_vs_oracle_radii_bit_exact(gh, golden):
         g = res.sample_edges(k)
         assert g.shape == e.shape
         assert (g[:, 6] == e[:, 6]).all()
+        assert (g == e).all(), int((g != e).sum())
         assert gh.edges_to_csv_text(g) == sim_oracle.edges_to_csv_text(e)
         # same random.uniform draws; the device batches Murray walks (a node several walks of a pass pass through is recomputed once),
         # so it never takes MORE pow-pair steps than the reference's walk-per-node propagation
