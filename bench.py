@@ -36,7 +36,7 @@ UNET_TFLOP_PER_IMAGE = 2.0         # forward 0.666 TFLOP x 3
 UNET_MIN_HBM_GB_PER_IMAGE = 6.0    # activations written once / read once, norm + activation fused
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16
-N_CUS = 256
+N_CUS = 256          # MI355X; main() replaces it by the device's own count
 PMC_SUMMARY = os.path.join("profiles", "r02_bench_pmc_summary.csv")
 
 
@@ -271,6 +271,8 @@ def main():
         # and its barrier live on this rank's GPU.
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
     dev = torch.device("cuda", torch.cuda.current_device())
+    global N_CUS
+    N_CUS = int(torch.cuda.get_device_properties(dev).multi_processor_count)
 
     from concurrent.futures import ThreadPoolExecutor
     from octa_autosegmentation_amd import pipeline

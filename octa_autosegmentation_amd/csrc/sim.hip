@@ -472,7 +472,9 @@ struct octa_sim {
     HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};  // pinned mailbox of the persistent form
     bool lockstep = false;          // OCTA_SIM_LOCKSTEP=1: two launches per iteration (the round-1 form)
     double mail_timeout_ms = 30000; // OCTA_SIM_MAIL_TIMEOUT_MS: device-side bound on one wait for the host when parking is off
-    double park_ms = 3.0;           // OCTA_SIM_PARK_MS: a workgroup that has waited this long for its answer parks (0: never)
+    double park_ms = 20.0;          // OCTA_SIM_PARK_MS: a workgroup that has waited this long for its answer parks (0: never). Normal answers
+                                    // take tens of microseconds; 3 ms (until the end of round 2) also parked workgroups whenever a busy host
+                                    // descheduled the service thread for a few milliseconds, and a park costs a drain + relaunch
     int grid_cap = 256;             // workgroups per launch of the persistent kernel (one per CU; OCTA_SIM_GRID overrides)
     int test_stall_ms = 0;          // OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once with a ticket pending
     long spin_scans = 4096;         // idle mailbox scans before the service thread starts sleeping 20 us between scans

@@ -5,7 +5,7 @@ Round 1's driver run lost a generator thread to error bit 0x800 (a workgroup wai
 activity of other host threads, the host stops seeing the launch's tickets until the kernel ends although it scans the mailbox
 continuously and the workgroup reads its own ticket back correctly -- a running kernel's writes to pinned host memory are not
 guaranteed to reach the host before the kernel ends. The protocol therefore no longer depends on it: a workgroup that has
-waited 3 ms PARKS (records its resume point, leaves the kernel), the host serves parked requests at the kernel boundary and
+waited 20 ms (OCTA_SIM_PARK_MS) PARKS (records its resume point, leaves the kernel), the host serves parked requests at the kernel boundary and
 launches again. These tests pin that results stay bit-identical through parking, that the loops around the simulator survive
 device-wide waits, allocations and frees from other threads, and that failures of the generator thread are errors, not warnings.
 """
@@ -28,7 +28,7 @@ def _cfg(i1, i2):
 
 
 def test_host_stall_is_absorbed_by_parking_and_fatal_without_it(hip_lib_built, monkeypatch):
-    """A service thread that disappears for 1 s with a ticket pending. Default protocol: the waiting workgroups park after 3 ms,
+    """A service thread that disappears for 1 s with a ticket pending. Default protocol: the waiting workgroups park after 20 ms,
     the launch ends, the host (back from its absence) serves them at the kernel boundary and launches again -- the CSV rows are
     the ones of an undisturbed run. With parking off (round 1) and a 300 ms device-side bound the run must fail loudly."""
     from octa_autosegmentation_amd import _native, graph_io
