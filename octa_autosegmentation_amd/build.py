@@ -8,7 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liboctahip.so")
 SOURCES = ["common.cpp", "bif_native.cpp", "fileio.cpp", "raster.hip", "sim.hip", "voxel.hip", "graphio.hip", "norm.hip", "conv.hip", "augment.hip", "postproc.hip", "loss.hip", "blur.hip", "thin_conv.hip"]
-HEADERS = ["common.h", "raster_core.h", "sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h", os.path.join("..", "..", "include", "octa_hip.h")]
+HEADERS = ["common.h", "raster_core.h", "sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h", "glibc_trig.h", "glibc_trig_tables.h",
+           os.path.join("..", "..", "include", "octa_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-ldl", "-lz"]
 
 
@@ -43,7 +44,7 @@ def build(force=False, verbose=False):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     common = ["common.h", os.path.join("..", "..", "include", "octa_hip.h")]
-    own = {"raster.hip": ["raster_core.h"], "sim.hip": ["sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h"]}
+    own = {"raster.hip": ["raster_core.h"], "sim.hip": ["sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h", "glibc_trig.h", "glibc_trig_tables.h"]}
     mt = lambda hs: max(os.path.getmtime(os.path.join(CSRC, h)) for h in hs)
     cflags = [f for f in FLAGS if f not in ("-shared", "-ldl", "-lz")]
     jobs = []
