@@ -1168,6 +1168,49 @@ OCTA_HD inline int murray_flush(const Blk &b, const SimArrays &A, int f, const S
     if (b.tid == 0) ctl[0] = 0;
     double *rad = L.rad;
     int rounds = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (n_def <= MURRAY_EPT * 64) {
+        // the usual case (about 135 marked nodes per pass): ONE wave runs the rounds -- its LDS accesses are ordered, so the two block
+        // barriers per round are not needed and the finished count is a ballot
+        if (b.tid < 64) {
+            int node[MURRAY_EPT], c0[MURRAY_EPT], c1[MURRAY_EPT];
+            double kk[MURRAY_EPT], acc[MURRAY_EPT];
+            int pend[MURRAY_EPT];
+            for (int e = 0; e < MURRAY_EPT; e++) {
+                const int idx = b.tid + e * 64;
+                pend[e] = 0; node[e] = 0; c0[e] = c1[e] = 0; kk[e] = 1; acc[e] = 0;
+                if (idx < n_def) {
+                    node[e] = A.act_list[idx];
+                    const WalkRec r = walk_load(A, f, node[e], false);
+                    c0[e] = r.c0; c1[e] = r.c1; kk[e] = r.k;
+                    pend[e] = 4 | (r.nch >= 1 ? 1 : 0) | (r.nch >= 2 ? 2 : 0);
+                }
+            }
+            int done = 0;
+            while (done < n_def) {
+                rounds++;
+                for (int e = 0; e < MURRAY_EPT; e++) {
+                    if (!(pend[e] & 4)) continue;
+                    if ((pend[e] & 1) && !deferred_get(L, c0[e])) { acc[e] = acc[e] + octa_gpow::gpow_t(rad[c0[e]], kk[e], L.log_tab, L.exp_tab); pend[e] &= ~1; }
+                    if ((pend[e] & 2) && !deferred_get(L, c1[e])) { acc[e] = acc[e] + octa_gpow::gpow_t(rad[c1[e]], kk[e], L.log_tab, L.exp_tab); pend[e] &= ~2; }
+                    if (!(pend[e] & 3)) {
+                        rad[node[e]] = octa_gpow::gpow_t(acc[e], 1.0 / kk[e], L.log_tab, L.exp_tab);
+                        pend[e] = 8;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int e = 0; e < MURRAY_EPT; e++) {
+                    const bool fin = pend[e] == 8;
+                    if (fin) { atomic_and_int(&L.deferred[node[e] >> 5], (int)~(1u << (node[e] & 31))); pend[e] = 0; }
+                    done += (int)__popcll(__ballot(fin));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        b.sync();
+        return rounds;
+    }
+#endif
     if (n_def <= MURRAY_EPT * b.nth) {
         int node[MURRAY_EPT], c0[MURRAY_EPT], c1[MURRAY_EPT];
         double kk[MURRAY_EPT], acc[MURRAY_EPT];
@@ -1513,6 +1556,7 @@ struct GrowCtx {
     const double *att;
     double gamma;
     const double *rad;  // radii of forest f: HBM array, or the LDS copy during the ordered pass
+    bool wave_coop = false;   // the caller is a whole wave executing uniformly (ordered pass): attractor loops are shared by its lanes
 };
 
 // acos / cos / sin whose results reach a node position: glibc's, bit for bit (glibc_trig.h), inside the restated domain
@@ -1543,6 +1587,33 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     V3 avg = v3(0, 0, 0);
     int kept = 0;
     const int s = A.gstart[g], cnt = A.gcount[g];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (G.wave_coop) {
+        // re-speculation inside the ordered pass: the 64 lanes take one attractor each (angles, unit vector), the kept unit vectors
+        // are then summed in attractor order with lane reads -- the same operations in the same order as the loop below
+        const int lane = (int)(threadIdx.x & 63);
+        for (int k0 = 0; k0 < cnt; k0 += 64) {
+            const int k = k0 + lane;
+            bool keep = false;
+            V3 u = v3(0, 0, 0);
+            if (k < cnt) {
+                const int a = (int)(A.sorted[s + k] & 16383u);
+                const V3 w = sub(ld3(G.att + 3 * a), pos);
+                const double ad = angle_uv(dist_seg, nd, w), ap = angle_uv(prox_seg, npx, w);
+                keep = lo <= ad && ad <= hi && ap <= pl;
+                if (keep) u = unit(w);
+            }
+            unsigned long long m = __ballot(keep);
+            while (m) {
+                const int j = (int)__ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                const V3 uj = v3(readlane_f64(u.x, j), readlane_f64(u.y, j), readlane_f64(u.z, j));
+                avg = kept == 0 ? uj : add(avg, uj);
+                kept++;
+            }
+        }
+    } else
+#endif
     for (int k = 0; k < cnt; k++) {
         int a = (int)(A.sorted[s + k] & 16383u);
         V3 w = sub(ld3(G.att + 3 * a), pos);
@@ -1796,6 +1867,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     // only differ inside murray_to_root. One thread alone on the host build.
     if (b.tid < (b.nth >= 64 ? 64 : 1)) {
         GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, L.rad};
+        G.wave_coop = b.nth >= 64;
         const int ng = sc->n_groups[f];
         const int n_grow = sc->n_grow[f];
         const int tag = sc->pass_tag[f];

@@ -41,5 +41,8 @@ if __name__ == "__main__":
         bad_rad += int(not (gpu[:, 6] == e[:, 6]).all())
         bad_bits += int(not (gpu == e).all())
         n_diff += int((gpu != e).sum()); n_vals += gpu.size
+        if not (gpu == e).all():
+            rows = np.nonzero((gpu != e).any(axis=1))[0]
+            print("seed", seed, "differing doubles", int((gpu != e).sum()), "first rows", rows[:4], "first diff", (gpu[rows[0]] - e[rows[0]]))
     print(f"RESULT: {N} full-length samples: CSV text mismatches {bad_text}, radius-bit mismatches {bad_rad}, "
           f"samples whose position doubles differ in the last bits (same text) {bad_bits}; differing doubles {n_diff} of {n_vals}")
