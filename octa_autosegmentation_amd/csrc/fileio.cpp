@@ -16,7 +16,7 @@
 //     shortest, closest digit string), exponent form iff the decimal exponent is < -4 or >= 16, ".0" appended to integers.
 //     Checked against numpy / CPython themselves on millions of vectors in tests/test_fileio.py.
 //   * reading it back: the "Legacy" string branch of tree2img.py:73-76 / data_transforms.py:369-375 (split on blanks, float())
-//     with strtod, which is what float() calls.
+//     with std::from_chars (correctly rounded like float(); locale-independent).
 //   * PNG: 8-bit grey (art_ven_img_gray.png, tree2img.py:282-292) and 1-bit (label PNGs, visualize_vessel_graphs.py:99) through
 //     zlib's deflate; readers decode them to the pixels PIL writes (PNG is lossless; the compressed bytes are not part of the
 //     contract).
@@ -280,7 +280,7 @@ extern "C" int octa_csv_write_file(const char *path, const double *h_edges, int6
     return write_file(path, buf.data(), (size_t)len);
 }
 
-// Rows of "[a b c],[d e f],r": every number with strtod (what float() uses); blanks, brackets and commas separate.
+// Rows of "[a b c],[d e f],r": every number with std::from_chars (float()'s value); blanks, brackets and commas separate.
 extern "C" int64_t octa_csv_parse_edges(const char *text, int64_t len, double *h_out, int64_t cap_rows) {
     if (!text || len < 0 || (!h_out && cap_rows > 0)) { octa::set_error("octa_csv_parse_edges: bad arguments"); return -2; }
     const char *p = text, *end = text + len;
@@ -303,8 +303,13 @@ extern "C" int64_t octa_csv_parse_edges(const char *text, int64_t len, double *h
             while (*c && got < 7) {
                 while (*c == ' ' || *c == '[' || *c == ']' || *c == ',' || *c == '\r' || *c == '"') c++;
                 if (!*c) break;
-                char *q = nullptr;
-                const double v = strtod(c, &q);
+                // std::from_chars: correctly rounded like float(), independent of the process locale (strtod honours LC_NUMERIC and
+                // takes hex floats); a leading '+' is float()'s, not from_chars'
+                const char *b = (*c == '+' && c[1] != '-' && c[1] != '+') ? c + 1 : c;
+                double v = 0.0;
+                const auto fc = std::from_chars(b, line.data() + line.size(), v, std::chars_format::general);
+                char *q = (fc.ec == std::errc() || fc.ec == std::errc::result_out_of_range) ? const_cast<char *>(fc.ptr) : c;
+                if (fc.ec == std::errc::result_out_of_range) v = strtod(b, nullptr);      // +-inf / 0 / subnormal exactly as float() gives
                 if (q == c) { octa::set_error("octa_csv_parse_edges: row %lld: cannot parse '%.24s'", (long long)rows, c); return -3; }
                 o[got++] = v;
                 c = q;

@@ -89,6 +89,32 @@ class Compose:
             data = t(data)
         return data
 
+    def batchable(self):
+        """True when the chain holds a transform with a mini-batch form (`batch_apply`: the frozen generator of
+        ImageToImageTranslationd) and may be cut there without changing any random decision: the transforms in front of the cut
+        draw from python's `random` and numpy's global stream, those behind it from torch's generator and their own
+        RandomStates, so "all prefixes, one batched call, all suffixes" consumes every stream in the per-sample order."""
+        cut = [i for i, t in enumerate(self.transforms) if hasattr(t, "batch_apply")]
+        if len(cut) != 1:
+            return False
+        return not any(getattr(t, "draws_from_torch", lambda: False)() for t in self.transforms[:cut[0]])
+
+    def call_batch(self, items):
+        """[sample dict] -> [sample dict]: the chain applied to a mini-batch, the `batch_apply` transform once for all samples."""
+        cut = next(i for i, t in enumerate(self.transforms) if hasattr(t, "batch_apply"))
+        samples = []
+        for data in items:
+            for t in self.transforms[:cut]:
+                data = t(data)
+            samples.append(data)
+        samples = self.transforms[cut].batch_apply(samples)
+        out = []
+        for data in samples:
+            for t in self.transforms[cut + 1:]:
+                data = t(data)
+            out.append(data)
+        return out
+
 
 # ---- the reference's own transforms ---------------------------------------------------------------------------------
 
@@ -196,6 +222,8 @@ class AddRandomBackgroundNoised(MapTransform):
         for key in self.keys:
             if key in data:
                 img = data[key]
+                # (torch.rand stands in for a missing tile: this transform then shares torch's stream with SpeckleBrightnesd and
+                # must not be reordered against it -- image_dataset.ListDataset.get_batch checks for the key)
                 noise = data["background"].to(img.device) if "background" in data else torch.rand(img.shape).to(img.device)
                 speckle = torch.from_numpy(np.random.uniform(0, 1, tuple(img.shape))).to(img.device)
                 if img.is_cuda and img.dtype == torch.float32 and noise.dtype == torch.float32 and noise.shape == img.shape:
@@ -214,7 +242,7 @@ class ImageToImageTranslationd(MapTransform):
     are loaded from `model_path` (checkpoint dict with key 'model')."""
 
     def __init__(self, model_path=None, keys=("image",), model_config: dict = None, allow_missing_keys: bool = False,
-                 model=None, device=None) -> None:
+                 model=None, device=None, amp=None) -> None:
         super().__init__(keys, allow_missing_keys)
         from ..models.base_model_abc import load_checkpoint_file
         from ..models.networks import MODEL_DICT
@@ -228,15 +256,39 @@ class ImageToImageTranslationd(MapTransform):
                 import sys
                 print(f"Loaded network weights from epoch {ckpt['epoch']}.", file=sys.stderr)
         self.device = torch.device(device) if device is not None else default_device()
-        self.model = model.to(self.device).eval()
+        self.model = model.to(self.device).eval().requires_grad_(False)
+        # bf16 autocast on the GPU: the generator's 3x3 stages run the MFMA convolution kernels and its stems the thin-conv
+        # kernels (models/networks.py), as in the GAN-seg training step; `amp: false` keeps the fp32 torch modules
+        self.amp = (self.device.type == "cuda") if amp is None else (bool(amp) and self.device.type == "cuda")
+
+    def _translate(self, x):
+        with torch.no_grad(), torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.amp):
+            return self.model(x.float().to(self.device)).float()
 
     def __call__(self, data):
         data = dict(data)
         for key in self.present(data):
-            with torch.no_grad():
-                img = data[key]
-                data[key] = self.model(img.float().unsqueeze(0).to(self.device)).squeeze(0)
+            data[key] = self._translate(data[key].unsqueeze(0)).squeeze(0)
         return data
+
+    def batch_apply(self, samples):
+        """The same transform on a list of samples with ONE generator pass per key over the stacked mini-batch (InstanceNorm is
+        per sample, so each image gets what its own pass would give)."""
+        samples = [dict(d) for d in samples]
+        for key in self.keys:
+            have = [d for d in samples if key in d]
+            if len(have) != len(samples) and not self.allow_missing_keys:
+                raise KeyError(f"ImageToImageTranslationd: key {key!r} is missing from a sample")
+            if not have:
+                continue
+            if len({tuple(d[key].shape) for d in have}) == 1:
+                y = self._translate(torch.stack([d[key] for d in have]))
+                for i, d in enumerate(have):
+                    d[key] = y[i]
+            else:
+                for d in have:
+                    d[key] = self._translate(d[key].unsqueeze(0)).squeeze(0)
+        return samples
 
 
 # ---- MONAI transforms named by the configs (restated; see the module docstring) ------------------------------------------------

@@ -50,6 +50,15 @@ class ListDataset:
     def __getitem__(self, i):
         return self.transform(self.items[i])
 
+    def get_batch(self, indices):
+        """Samples `indices`, transformed; chains with a mini-batch form (the frozen generator of configs/config_ves_seg-S_GAN.yml)
+        run it once per mini-batch (data_transforms.Compose.call_batch) -- same random decisions as sample-by-sample."""
+        items = [self.items[j] for j in indices]
+        t = self.transform
+        if len(items) > 1 and getattr(t, "batchable", lambda: False)() and all("background" in it for it in items):
+            return t.call_batch(items)
+        return [t(it) for it in items]
+
 
 class FusedGraphSegBatches:
     """Batch-level form of the segmentation configs' training chain (configs/config_ves_seg-S.yml:28-102) for the common case --
@@ -123,13 +132,24 @@ class DeviceLoader:
         self.num_workers, self.prefetch = int(num_workers), prefetch
         self.shard = (0, 1)          # (rank, world): data-parallel ranks take every world-th batch of the SAME permutation
         self.fused = None            # batch-level transform chain (FusedGraphSegBatches) replacing the per-sample one
+        self.perm_generator = None   # data-parallel runs: the permutation's own generator (same on every rank); else torch's global one
+
+    def reseed_augmentations(self, seed):
+        """Give the random transforms of this loader their own streams (data-parallel ranks: seed + rank, so rank r's k-th batch
+        does not get the flips / rotations of every other rank's k-th batch; only the batch permutation is shared)."""
+        from .data_transforms import Randomizable
+        for t in getattr(getattr(self.dataset, "transform", None), "transforms", []):
+            if isinstance(t, Randomizable):
+                t.set_random_state(seed=seed)
+        if self.fused is not None:
+            self.fused.aug.R_flip, self.fused.aug.R_rot90, self.fused.aug.R_rot = (np.random.RandomState(seed) for _ in range(3))
 
     def __len__(self):
         return ceil(ceil(len(self.dataset) / self.batch_size) / self.shard[1])
 
     def _batches(self):
         n = len(self.dataset)
-        order = torch.randperm(n).tolist() if self.shuffle else list(range(n))     # all ranks share the seed, hence the order
+        order = torch.randperm(n, generator=self.perm_generator).tolist() if self.shuffle else list(range(n))     # all ranks share this stream, hence the order
         rank, world = self.shard
         starts = list(range(0, n, self.batch_size))
         if world > 1:                                                              # same number of steps on every rank
@@ -138,7 +158,8 @@ class DeviceLoader:
             if self.fused is not None:
                 yield self.fused([self.dataset.items[j] for j in order[i:i + self.batch_size]])
             else:
-                yield collate([self.dataset[j] for j in order[i:i + self.batch_size]])
+                idx = order[i:i + self.batch_size]
+                yield collate(self.dataset.get_batch(idx) if hasattr(self.dataset, "get_batch") else [self.dataset[j] for j in idx])
 
     def __iter__(self):
         if self.num_workers <= 0 or not torch.cuda.is_available():

@@ -65,10 +65,21 @@ class GradArena:
                 self.attach()
                 break
 
+    def check_views(self):
+        """Every parameter's gradient must still BE its arena view when the exchange starts: a `.grad` autograd replaced (instead
+        of accumulating in place) would leave zeros in the buffer and the all-reduce would silently send them."""
+        base = self.flat.untyped_storage().data_ptr()
+        for p in self.params:
+            if p.grad is None or p.grad.untyped_storage().data_ptr() != base:
+                raise RuntimeError("GradArena: a parameter's .grad no longer aliases the flat gradient buffer "
+                                   f"(shape {tuple(p.shape)}); its gradient would be lost in the all-reduce")
+
     def all_reduce_mean(self):
-        if _dist_on():
+        self.check_views()
+        if dist.is_available() and dist.is_initialized():      # also at world size 1 (OCTA_GRAD_ARENA=1): same code path, RCCL on the buffer
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+            if dist.get_world_size() > 1:
+                self.flat.div_(dist.get_world_size())
 
 
 def load_checkpoint_file(path, device):
@@ -131,11 +142,17 @@ class BaseModelABC(nn.Module, ModelInterface, ABC):
                 self._arenas = {name: GradArena(itertools.chain(*[n.parameters() for n in self._nets_of(net_names)]))
                                 for name, net_names in self.optimizer_mapping.items()}
         else:
-            prefix = config["General"].get("inference")
-            prefix = prefix + "_" if prefix else "model_"
-            checkpoint_path = model_path.replace("model.pth", f"{prefix}model.pth")
-            if not os.path.exists(checkpoint_path):
-                checkpoint_path = checkpoint_path.replace("model_", "")          # legacy `<epoch>_model.pth`
+            # `General.inference` names the network: `model`, `segmentor` / `generator`, or the aliases `S` / `G` the GAN-seg
+            # config ships. train.py writes `<epoch>_<network>_model.pth` (utils/visualizer.py:225-238), so the alias is resolved
+            # BEFORE the path is built (the reference builds `<epoch>_G_model.pth`, which its own trainer never writes); the alias
+            # spelling and the legacy `<epoch>_model.pth` are still accepted.
+            alias = config["General"].get("inference")
+            net = {"S": "segmentor", "G": "generator"}.get(alias, alias)
+            cands = [model_path.replace("model.pth", f"{n}_model.pth") for n in dict.fromkeys((net, alias)) if n]
+            cands += [model_path.replace("model.pth", "model_model.pth"), model_path]
+            checkpoint_path = next((c for c in cands if os.path.exists(c)), None)
+            if checkpoint_path is None:
+                raise FileNotFoundError(f"no checkpoint for inference={alias!r}; looked for {cands}")
             checkpoint = load_checkpoint_file(checkpoint_path, device)
             which = config["General"].get("inference") or "model"
             which = {"S": "segmentor", "G": "generator"}.get(which, which)

@@ -34,9 +34,9 @@ class GanSegModel(BaseModelABC):
         self.generator: nn.Module = None
         self.discriminator: nn.Module = None
         model_g, model_d, model_s = dict(model_g), dict(model_d), dict(model_s)
-        if phase == Phase.TRAIN or inference == "S":
+        if phase == Phase.TRAIN or inference in ("S", "segmentor"):
             self.segmentor = MODEL_DICT[model_s.pop("name")](**model_s)
-        if phase == Phase.TRAIN or inference == "G":
+        if phase == Phase.TRAIN or inference in ("G", "generator"):
             self.generator = MODEL_DICT[model_g.pop("name")](**model_g)
         if phase == Phase.TRAIN:
             self.discriminator = MODEL_DICT[model_d.pop("name")](**model_d)

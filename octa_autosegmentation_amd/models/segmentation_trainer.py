@@ -9,10 +9,6 @@ from copy import deepcopy
 # MIOpen's exhaustive find mode benchmarks every solver (incl. naive reference kernels) on first use:
 # minutes per process on a fresh box. The fast heuristic mode starts in seconds (set before torch loads MIOpen).
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
-# In FAST mode MIOpen answers the backward-data convolutions of the fp32 reference modules with GEMM + Col2Im2dU; without the GEMM
-# solvers it picks its implicit-GEMM kernels (53 -> 41 ms per step at B=4, 1216x1216 on the torch path).
-os.environ.setdefault("MIOPEN_DEBUG_CONV_GEMM", "0")
-
 import torch
 
 from ..utils.enums import Phase

@@ -12,19 +12,36 @@ from .enums import Phase
 
 
 class Metric:
+    """Scores are kept as 0-dim tensors ON THE DEVICE of the maps (NaN = "skip this sample", e.g. empty ground truth) and meet in
+    one stacked nanmean when the epoch ends: a training step queues no host read of its own (the reference reads every score of
+    every sample back as a python float)."""
+
     def __init__(self):
         self.reset()
 
     def reset(self):
         self.scores = []
 
+    def add(self, value):
+        self.scores.append(value if torch.is_tensor(value) else torch.tensor(float(value)))
+
     def aggregate(self) -> torch.Tensor:
-        vals = [s for s in self.scores if not math.isnan(s)]
-        return torch.tensor(sum(vals) / len(vals) if vals else float("nan"))
+        if not self.scores:
+            return torch.tensor(float("nan"))
+        dev = next((s.device for s in self.scores if s.is_cuda), torch.device("cpu"))
+        v = torch.stack([s.detach().to(dev, torch.float64).reshape(()) for s in self.scores])
+        ok = ~torch.isnan(v)
+        n = ok.sum()
+        mean = torch.where(ok, v, torch.zeros_like(v)).sum() / n.clamp(min=1)
+        return torch.where(n > 0, mean, torch.full_like(mean, float("nan"))).float().cpu()
 
 
 def _flat_bool(t):
     return t.detach().reshape(-1) != 0
+
+
+def _nan_unless(cond, value):
+    return torch.where(cond, value, torch.full_like(value, float("nan")))
 
 
 class MacroDiceMetric(Metric):
@@ -34,11 +51,9 @@ class MacroDiceMetric(Metric):
         for p_i, y_i in zip(y_pred, y):
             for layer in range(len(p_i)):
                 gt, pr = y_i[layer].detach().float(), p_i[layer].detach().float()
-                if float(gt.sum()) == 0:
-                    self.scores.append(float("nan"))
-                    continue
+                gsum = gt.sum()
                 inter = ((gt == 1) & (pr == 1)).sum()
-                self.scores.append(float(2.0 * inter / (gt.sum() + pr.sum())))
+                self.add(_nan_unless(gsum != 0, 2.0 * inter / (gsum + pr.sum())))
 
     def aggregate(self):
         return super().aggregate() if self.scores else torch.tensor(0)
@@ -52,39 +67,37 @@ class MeanIoU(Metric):
         for p_i, y_i in zip(y_pred, y):
             for c in range(len(p_i)):
                 p, g = _flat_bool(p_i[c]), _flat_bool(y_i[c])
-                if not bool(g.any()):
-                    self.scores.append(float("nan"))
-                    continue
-                self.scores.append(float((p & g).sum() / (p | g).sum()))
+                self.add(_nan_unless(g.any(), (p & g).sum().double() / (p | g).sum().clamp(min=1).double()))
 
 
 class _Confusion(Metric):
     def counts(self, p_i, y_i):
+        """(tp, tn, fp, fn) as float64 0-dim tensors on the maps' device."""
         p, g = _flat_bool(p_i), _flat_bool(y_i)
-        tp, tn = (p & g).sum(), (~p & ~g).sum()
-        fp, fn = (p & ~g).sum(), (~p & g).sum()
-        return [float(v) for v in (tp, tn, fp, fn)]
+        tp, pp, gp = (p & g).sum().double(), p.sum().double(), g.sum().double()
+        n = float(p.numel())
+        return tp, n - pp - gp + tp, pp - tp, gp - tp
 
 
 class AccuracyMetric(_Confusion):
     def __call__(self, y_pred, y):
         for p_i, y_i in zip(y_pred, y):
             tp, tn, fp, fn = self.counts(p_i, y_i)
-            self.scores.append((tp + tn) / (tp + tn + fp + fn))
+            self.add((tp + tn) / (tp + tn + fp + fn))
 
 
 class Recall(_Confusion):
     def __call__(self, y_pred, y):
         for p_i, y_i in zip(y_pred, y):
             tp, tn, fp, fn = self.counts(p_i, y_i)
-            self.scores.append(tp / (tp + fn) if tp + fn else float("nan"))
+            self.add(_nan_unless(tp + fn > 0, tp / (tp + fn).clamp(min=1)))
 
 
 class Precision(_Confusion):
     def __call__(self, y_pred, y):
         for p_i, y_i in zip(y_pred, y):
             tp, tn, fp, fn = self.counts(p_i, y_i)
-            self.scores.append(tp / (tp + fp) if tp + fp else float("nan"))
+            self.add(_nan_unless(tp + fp > 0, tp / (tp + fp).clamp(min=1)))
 
 
 class AUCMetric(Metric):
@@ -93,15 +106,14 @@ class AUCMetric(Metric):
     def __call__(self, y_pred, y):
         for p_i, y_i in zip(y_pred, y):
             s, g = p_i.detach().reshape(-1).double(), _flat_bool(y_i)
-            n_pos, n_neg = int(g.sum()), int((~g).sum())
-            if n_pos == 0 or n_neg == 0:
-                self.scores.append(float("nan"))
-                continue
+            n_pos = g.sum().double()
+            n_neg = float(g.numel()) - n_pos
             vals, inv, cnt = torch.unique(s, sorted=True, return_inverse=True, return_counts=True)
             hi = torch.cumsum(cnt, 0).double()
             avg_rank = hi - (cnt.double() - 1) / 2          # average 1-based rank of each distinct score
-            r_pos = avg_rank[inv][g].sum()
-            self.scores.append(float((r_pos - n_pos * (n_pos + 1) / 2) / (n_pos * n_neg)))
+            r_pos = (avg_rank[inv] * g.double()).sum()
+            auc = (r_pos - n_pos * (n_pos + 1) / 2) / (n_pos * n_neg).clamp(min=1)
+            self.add(_nan_unless((n_pos > 0) & (n_neg > 0), auc))
 
 
 class ClDiceMetric(Metric):
@@ -113,7 +125,7 @@ class ClDiceMetric(Metric):
                 v_p, v_l = p_i[layer].detach().cpu().numpy(), y_i[layer].detach().cpu().numpy()
                 cl = lambda v, s: np.sum(v * s) / np.sum(s)
                 tprec, tsens = cl(v_p, skeletonize(v_l)), cl(v_l, skeletonize(v_p))
-                self.scores.append(float(2 * tprec * tsens / (tprec + tsens)))
+                self.add(float(2 * tprec * tsens / (tprec + tsens)))
 
 
 def _have_skimage():

@@ -1,5 +1,6 @@
 """CPU: CSV text format helpers and the arithmetic emulation of numpy's position printing."""
 import numpy as np
+import pytest
 import yaml
 
 from octa_autosegmentation_amd import graph_io
@@ -95,3 +96,11 @@ def test_two_rank_sample_sharding_is_disjoint_and_time_is_max(tmp_path):
     assert len(set(a.tolist())) == len(a) == 384 and len(set(b.tolist())) == 384
     assert not set(a.tolist()) & set(b.tolist())
     assert float(np.load(out + ".t.npy")[0]) == 2.0
+    # ranks own disjoint 2^26-seed ranges: rank 0 at step 150 no longer meets rank 1 at step 50 (round 2: 100000 * rank + 1000 * step),
+    # and leaving the range fails instead of wrapping
+    from octa_autosegmentation_amd.utils import sharding
+    far = set(sharding.rank_seeds(0, 150, 128).tolist())
+    assert not far & set(sharding.rank_seeds(1, 50, 128).tolist()) and not far & set(sharding.rank_seeds(1, 0, 128).tolist())
+    assert sharding.rank_seeds(7, 500000, 128).max() < sharding.rank_seeds(8, 0, 128).min()
+    with pytest.raises(OverflowError):
+        sharding.rank_seeds(0, 2 ** 26 // 128, 128)

@@ -213,41 +213,98 @@ def test_two_rank_gan_seg_step_keeps_the_replicas_identical(tmp_path):
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("tag,idt", [("idt0", False), ("idt1", True)])
-def test_gan_seg_update_matches_the_reference_fixture(tag, idt):
-    """a21: two consecutive joint G / D / S updates against tests/golden/ganseg_golden.npz, recorded from the reference's own
-    GanSegModel.perform_training_step (tools/make_golden_ganseg.py). Losses of step 1 depend only on the forward composition,
-    those of step 2 on all three optimiser updates (Adam, betas (0.5, 0.999) for G and D, (0.9, 0.999) for S); the gradient norms and
-    parameter checksums pin the backward paths (D frozen in the G+S pass, detached fake_B in the D pass, detached pseudo-labels)."""
+def run_gan_seg_fixture(tag, idt, device="cpu", amp=False, arena=False):
+    """Two consecutive joint G / D / S updates of this repository's GanSegModel on the closed-form weights and inputs of
+    tools/make_golden_ganseg.py; returns (losses [2, 6], gradient norms [3], parameter checksums [3, 2], the fixture)."""
     import sys
     from argparse import Namespace
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
     from tools.make_golden_ganseg import S_CFG, TRAIN, batch, checksums, formula_weights, grad_norms
     from octa_autosegmentation_amd.models.model import define_model
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ganseg_golden.npz"))
-    config = {"General": {"device": "cpu", "amp": False, "model": {"name": "GanSegModel", "model_g": {"name": "resnetGenerator9"},
-                                                                    "model_d": {"name": "patchGAN70x70"}, "model_s": dict(S_CFG),
-                                                                    "compute_identity": idt, "compute_identity_seg": True, "upshape": (64, 64)}},
+    config = {"General": {"device": device, "amp": amp, "model": {"name": "GanSegModel", "model_g": {"name": "resnetGenerator9"},
+                                                                   "model_d": {"name": "patchGAN70x70"}, "model_s": dict(S_CFG),
+                                                                   "compute_identity": idt, "compute_identity_seg": True, "upshape": (64, 64)}},
               "Train": dict(TRAIN), "Output": {"save_dir": "/tmp"}}
     from copy import deepcopy
     from octa_autosegmentation_amd.utils.enums import Phase
     torch.manual_seed(0)
-    model = define_model(deepcopy(config), Phase.TRAIN)
-    model.initialize_model_and_optimizer(None, networks.init_weights, config, Namespace(start_epoch=0, epoch="latest"), None, Phase.TRAIN)
+    old = os.environ.get("OCTA_GRAD_ARENA")
+    if arena:
+        os.environ["OCTA_GRAD_ARENA"] = "1"
+    try:
+        model = define_model(deepcopy(config), Phase.TRAIN)
+        model.initialize_model_and_optimizer(None, networks.init_weights, config, Namespace(start_epoch=0, epoch="latest"), None, Phase.TRAIN)
+    finally:
+        if arena:
+            os.environ.pop("OCTA_GRAD_ARENA") if old is None else os.environ.__setitem__("OCTA_GRAD_ARENA", old)
+    assert bool(model._arenas) == arena
     for salt, name in ((0, "generator"), (100, "discriminator"), (200, "segmentor")):
         formula_weights(getattr(model, name), salt)
+    model._after_weight_surgery()
     model.train()
     ident = {"prediction": lambda t: t, "label": lambda t: t}
     keys = ("S", "D_fake", "D_real", "G", "G_idt", "S_idt")
+    losses = []
     for step in range(2):
-        _, l = model.perform_training_step(batch(), None, ident, "cpu")
-        got = np.array([float(l[k]) for k in keys])
-        # step 0: the forward composition alone (fp32 summation order); step 1: after one Adam step of all three optimisers, where
-        # first-step updates are lr * sign(g) and parameters with rounding-noise gradients move either way
-        assert np.allclose(got, g[f"{tag}_losses"][step], rtol=2e-5 if step == 0 else 1e-3, atol=1e-6), (step, got, g[f"{tag}_losses"][step])
-    assert np.allclose(grad_norms(model), g[f"{tag}_grad_norms"], rtol=2e-3), (grad_norms(model), g[f"{tag}_grad_norms"])
+        _, l = model.perform_training_step(batch(), None, ident, device)
+        losses.append([float(l[k]) for k in keys])
+    return np.array(losses), grad_norms(model), checksums(model), g
+
+
+@pytest.mark.parametrize("tag,idt", [("idt0", False), ("idt1", True)])
+def test_gan_seg_update_matches_the_reference_fixture(tag, idt):
+    """a21: two consecutive joint G / D / S updates against tests/golden/ganseg_golden.npz, recorded from the reference's own
+    GanSegModel.perform_training_step (tools/make_golden_ganseg.py). Losses of step 1 depend only on the forward composition,
+    those of step 2 on all three optimiser updates (Adam, betas (0.5, 0.999) for G and D, (0.9, 0.999) for S); the gradient norms and
+    parameter checksums pin the backward paths (D frozen in the G+S pass, detached fake_B in the D pass, detached pseudo-labels).
+    The same fixture runs on the GPU in fp32 and through the bf16 / MFMA path in tests/test_models_gpu.py."""
+    losses, gnorm, sums, g = run_gan_seg_fixture(tag, idt)
+    # step 0: the forward composition alone (fp32 summation order); step 1: after one Adam step of all three optimisers, where
+    # first-step updates are lr * sign(g) and parameters with rounding-noise gradients move either way
+    for step in range(2):
+        assert np.allclose(losses[step], g[f"{tag}_losses"][step], rtol=2e-5 if step == 0 else 1e-3, atol=1e-6), (step, losses[step], g[f"{tag}_losses"][step])
+    assert np.allclose(gnorm, g[f"{tag}_grad_norms"], rtol=2e-3), (gnorm, g[f"{tag}_grad_norms"])
     # parameter checksums after two Adam steps: parameters whose gradient is rounding noise take +-lr steps of either sign, so the
     # sums agree to a small absolute slack only (the step-2 losses above are the sharp pin of the three updates)
-    assert np.allclose(checksums(model), g[f"{tag}_param_sums"], rtol=1e-6, atol=0.5), (checksums(model), g[f"{tag}_param_sums"])
+    assert np.allclose(sums, g[f"{tag}_param_sums"], rtol=1e-6, atol=0.5), (sums, g[f"{tag}_param_sums"])
     # and a sign error would not pass: the generator's adversarial term enters loss_GS with a plus sign
     assert g[f"{tag}_losses"][0][3] > 1.0
+
+
+def test_batched_translation_chain_takes_the_per_sample_decisions():
+    """configs/config_ves_seg-S_GAN.yml's loader chain cut at the frozen generator (Compose.call_batch): prefixes, ONE generator pass
+    over the mini-batch, suffixes -- same tensors and same stream positions as sample by sample (reference data_transforms.py:327-356
+    runs the generator once per sample inside the loader workers)."""
+    import random
+    from octa_autosegmentation_amd.data import data_transforms as T
+    from octa_autosegmentation_amd.data.image_dataset import ListDataset
+    torch.manual_seed(3)
+    gnet = networks.resnetGenerator9()
+    networks.init_weights(gnet, "kaiming", nonlinearity="relu")
+    aug = [{"name": "AddRandomBackgroundNoised", "keys": ["image"], "delete_background": False},
+           {"name": "ImageToImageTranslationd", "keys": ["image"], "model": gnet, "device": "cpu"},
+           {"name": "SpeckleBrightnesd", "keys": ["image"]},
+           {"name": "RandFlipd", "keys": ["image", "label"], "prob": 0.5, "spatial_axis": [0, 1]},
+           {"name": "RandRotate90d", "keys": ["image", "label"], "prob": 0.75}]
+    items = [{"image": torch.rand(1, 32, 32), "label": torch.rand(1, 32, 32), "background": torch.rand(1, 32, 32)} for _ in range(3)]
+    got = {}
+    for batched in (True, False):
+        ds = ListDataset(items, T.Compose(T.get_data_augmentations(aug, seed=5)))
+        assert ds.transform.batchable()
+        random.seed(1); np.random.seed(1); torch.manual_seed(1)
+        out = ds.get_batch([0, 1, 2]) if batched else [ds[i] for i in range(3)]
+        got[batched] = (out, random.random(), np.random.random_sample(), float(torch.rand(())))
+    assert got[True][1:] == got[False][1:]
+    for a, b in zip(got[True][0], got[False][0]):
+        assert torch.allclose(a["image"], b["image"], atol=1e-6) and torch.equal(a["label"], b["label"])
+    # without a background tile the noise stand-in draws from torch's stream, which the speckle transform behind the cut shares:
+    # such mini-batches stay sample by sample
+    bare = [{k: v for k, v in it.items() if k != "background"} for it in items]
+    nob = ListDataset(bare, T.Compose(T.get_data_augmentations(aug, seed=5)))
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    out = nob.get_batch([0, 1, 2])
+    nob = ListDataset(bare, T.Compose(T.get_data_augmentations(aug, seed=5)))
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    ref = [nob[i] for i in range(3)]
+    assert all(torch.equal(a["image"], b["image"]) for a, b in zip(out, ref))

@@ -1,5 +1,6 @@
 """GPU: DynUNet forward parity (fp32, same weights) between cuda and cpu within the 1e-4 of north_star,
 and one bf16 training step."""
+import numpy as np
 import pytest
 import torch
 
@@ -177,3 +178,97 @@ def test_patchgan_mfma_layers_match_torch_autocast():
     assert cos(grads[0][0], grads[1][0]) > 0.9
     assert set(grads[0][1]) == set(grads[1][1])                       # every convolution weight has a gradient on both paths
     assert min(cos(grads[0][1][k], grads[1][1][k]) for k in grads[1][1]) > 0.9
+
+
+# ---- a21 on the device (round 3): the reference-made fixture of the joint G / D / S update on cuda --------------------------------
+
+def _report(tag, what, got, want):
+    rel = np.abs(np.asarray(got) - np.asarray(want)) / np.maximum(np.abs(np.asarray(want)), 1e-12)
+    print(f"[ganseg {tag}] {what}: max rel dev {rel.max():.3e}", flush=True)
+    return rel
+
+
+
+@pytest.mark.parametrize("tag,idt", [("idt0", False), ("idt1", True)])
+def test_gan_seg_fixture_on_cuda_fp32(tag, idt):
+    """tests/golden/ganseg_golden.npz (two perform_training_steps of the reference's own GanSegModel, tools/make_golden_ganseg.py;
+    reference models/gan_seg_model.py:116-173) with `device: cuda, amp: False`: the HIP pad / blur / InstanceNorm kernels and the
+    fp32 convolutions. Tolerances: step-1 losses 5e-4 relative (fp32 summation order through ~60 layers; the CPU test holds 2e-5),
+    step-2 losses 3e-3 (first Adam steps are lr * sign(g)), gradient norms 5e-3."""
+    from tests.test_models import run_gan_seg_fixture
+    losses, gnorm, sums, g = run_gan_seg_fixture(tag, idt, device="cuda", amp=False)
+    r0 = _report(tag, "fp32 step-1 losses", losses[0], g[f"{tag}_losses"][0])
+    r1 = _report(tag, "fp32 step-2 losses", losses[1], g[f"{tag}_losses"][1])
+    rg = _report(tag, "fp32 grad norms", gnorm, g[f"{tag}_grad_norms"])
+    assert np.allclose(losses[0], g[f"{tag}_losses"][0], rtol=5e-4, atol=1e-6), (losses[0], g[f"{tag}_losses"][0])
+    assert np.allclose(losses[1], g[f"{tag}_losses"][1], rtol=3e-3, atol=1e-6), (losses[1], g[f"{tag}_losses"][1])
+    assert np.allclose(gnorm, g[f"{tag}_grad_norms"], rtol=5e-3), (gnorm, g[f"{tag}_grad_norms"])
+    assert np.allclose(sums, g[f"{tag}_param_sums"], rtol=1e-6, atol=0.5)
+
+
+@pytest.mark.parametrize("tag,idt", [("idt0", False), ("idt1", True)])
+def test_gan_seg_fixture_on_cuda_bf16_mfma(tag, idt):
+    """The same fixture through the PRODUCT path of the GAN-seg step: `amp: True` -- bf16 autocast, generator / PatchGAN / DynUNet
+    on the MFMA convolution, thin-conv, NHWC InstanceNorm and fused loss kernels, passes batched over concatenated mini-batches.
+    bf16 budget (8 mantissa bits, ~25 layers deep, 32x32 inputs): step-1 losses within 3 % (+0.01 absolute), step-2 losses within
+    6 %, gradient norms within 15 %; a sign or detach error moves these by factors (D_fake <-> D_real swap: 2x; missing detach of
+    fake_B in the D pass: the generator's gradient norm doubles)."""
+    from tests.test_models import run_gan_seg_fixture
+    losses, gnorm, sums, g = run_gan_seg_fixture(tag, idt, device="cuda", amp=True)
+    _report(tag, "bf16 step-1 losses", losses[0], g[f"{tag}_losses"][0])
+    _report(tag, "bf16 step-2 losses", losses[1], g[f"{tag}_losses"][1])
+    _report(tag, "bf16 grad norms", gnorm, g[f"{tag}_grad_norms"])
+    assert np.allclose(losses[0], g[f"{tag}_losses"][0], rtol=3e-2, atol=1e-2), (losses[0], g[f"{tag}_losses"][0])
+    assert np.allclose(losses[1], g[f"{tag}_losses"][1], rtol=6e-2, atol=1e-2), (losses[1], g[f"{tag}_losses"][1])
+    assert np.allclose(gnorm, g[f"{tag}_grad_norms"], rtol=0.15), (gnorm, g[f"{tag}_grad_norms"])
+    assert np.allclose(sums, g[f"{tag}_param_sums"], rtol=1e-4, atol=1.0)
+
+
+@pytest.fixture(scope="module")
+def one_rank_rccl():
+    """A one-rank `nccl` (= RCCL) process group in this process: device-memory all-reduce and communicator set-up are real."""
+    import os
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_grad_arena_and_rccl_on_device_equal_the_plain_step(one_rank_rccl):
+    """(e) on the GPU: OCTA_GRAD_ARENA=1 makes every parameter's .grad a view into one flat fp32 buffer per optimiser, the MFMA
+    autograd functions accumulate into the views, the exchange is ONE RCCL all-reduce on that buffer (one rank: sum = identity).
+    Both trainers give the arena-less step's numbers: the GAN-seg fixture (three optimisers, bf16 / MFMA) and the U-Net step."""
+    from tests.test_models import CFG, run_gan_seg_fixture
+    plain = run_gan_seg_fixture("idt1", True, device="cuda", amp=True)
+    arena = run_gan_seg_fixture("idt1", True, device="cuda", amp=True, arena=True)
+    # fp32 atomics in the weight-gradient kernels make bf16 steps reproducible to rounding only
+    assert np.allclose(plain[0], arena[0], rtol=2e-3, atol=1e-4), (plain[0], arena[0])
+    assert np.allclose(plain[1], arena[1], rtol=2e-2), (plain[1], arena[1])
+    import os
+    from octa_autosegmentation_amd.models.segmentation_trainer import SegmentationTrainer
+    x = torch.rand(2, 1, 128, 128, device="cuda")
+    y = (x > 0.7).float()
+    traj = {}
+    for use in (False, True):
+        if use:
+            os.environ["OCTA_GRAD_ARENA"] = "1"
+        try:
+            torch.manual_seed(1)
+            tr = SegmentationTrainer(CFG, "cuda")
+        finally:
+            os.environ.pop("OCTA_GRAD_ARENA", None)
+        assert bool(tr.impl._arenas) == use
+        vals = []
+        for _ in range(6):
+            _, l = tr.perform_training_step({"image": x, "label": y})
+            vals.append(float(l["DiceBCELoss"]))
+        if use:
+            a = tr.impl._arenas["optimizer"]
+            a.check_views()
+            assert a.flat.is_cuda and a.flat.numel() == 7_368_769 and float(a.flat.abs().sum()) > 0
+        traj[use] = np.array(vals)
+    assert np.allclose(traj[False], traj[True], rtol=5e-3), traj

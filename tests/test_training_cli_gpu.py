@@ -168,21 +168,29 @@ def test_train_test_validate_with_the_reference_segmentation_config(graphs, tmp_
     assert all(np.isfinite(v) for v in metrics.values())
 
 
-def test_train_with_the_reference_gan_seg_config(graphs, tmp_path):
-    """BASELINE configs[3] plumbing: train.py --config_file configs/config_gan_ves_seg.yml for one epoch (GanSegModel through
-    define_model, UnalignedZipDataset pairing, dropout 0.02 in the graph loader, three optimisers' checkpoints)."""
-    import torch
+@pytest.fixture(scope="module")
+def gan_run(graphs, tmp_path_factory):
+    """One epoch of train.py --config_file configs/config_gan_ves_seg.yml on the eight graphs (shared by the tests below)."""
     import train as train_cli
     out, dirs = graphs
-    data = str(tmp_path / "png")
+    tmp = tmp_path_factory.mktemp("ganrun")
+    data = str(tmp / "png")
     _pngs(dirs, data)
-    res = str(tmp_path / "results")
+    res = str(tmp / "results")
     csvs = os.path.join(out, "**", "*.csv")
     f = lambda p: yaml.safe_dump({"files": p}, default_flow_style=True).strip()
     ov = ["--Train.data.real_A", f(csvs), "--Train.data.real_A_seg", f(csvs), "--Train.data.real_B", f(os.path.join(data, "images", "*.png")),
           "--Train.data.background", f(os.path.join(data, "background", "*.png")), "--Train.epochs", "1", "--Train.batch_size", "2",
           "--Output.save_dir", res, "--General.seed", "4"]
     run = train_cli.main(["--config_file", os.path.join(ROOT, "configs", "config_gan_ves_seg.yml")] + ov)
+    return run, data, csvs
+
+
+def test_train_with_the_reference_gan_seg_config(gan_run):
+    """BASELINE configs[3] plumbing: train.py --config_file configs/config_gan_ves_seg.yml for one epoch (GanSegModel through
+    define_model, UnalignedZipDataset pairing, dropout 0.02 in the graph loader, three optimisers' checkpoints)."""
+    import torch
+    run, data, csvs = gan_run
     rows = open(os.path.join(run, "metrics.csv")).read().splitlines()
     assert rows[0] == "epoch,train_S,train_D_fake,train_D_real,train_G,train_G_idt,train_S_idt,Train_DSC,Train_IoU" and len(rows) == 2
     assert np.isfinite([float(v) for v in rows[1].split(",")]).all()
@@ -190,3 +198,115 @@ def test_train_with_the_reference_gan_seg_config(graphs, tmp_path):
     assert {f"latest_{n}_model.pth" for n in ("generator", "discriminator", "segmentor", "optimizer_G", "optimizer_D", "optimizer_S")} <= names
     ck = torch.load(os.path.join(run, "checkpoints", "latest_optimizer_S_model.pth"), weights_only=False)
     assert ck["optimizer"]["param_groups"][0]["betas"] == (0.9, 0.999) and ck["epoch"] == 1
+
+
+def test_gan_checkpoints_load_in_test_cli_as_G_and_S(gan_run, tmp_path):
+    """train.py writes `<tag>_generator_model.pth` / `<tag>_segmentor_model.pth`; test.py with `General.inference: G` (what
+    configs/config_gan_ves_seg.yml ships) and `S` must find them (the reference builds `<tag>_G_model.pth`, which its own trainer
+    never writes). G: translated 304x304 images; S: 1216x1216 segmentations of real scans, RemoveSmallObjects applied."""
+    from PIL import Image
+    import test as test_cli
+    run, data, csvs = gan_run
+    f = lambda p: yaml.safe_dump({"files": p}, default_flow_style=True).strip()
+    cfg = os.path.join(run, "config.yml")
+    w = test_cli.main(["--config_file", cfg, "--epoch", "latest", "--num_samples", "2", "--General.inference", "G",
+                       "--Test.data", yaml.safe_dump({"real_A": {"files": csvs}, "background": {"files": os.path.join(data, "background", "*.png")}},
+                                                     default_flow_style=True).strip(),
+                       "--Test.save_dir", str(tmp_path / "G")])
+    assert len(w) == 2 and all(os.path.basename(x).startswith("generator_") for x in w)
+    assert np.array(Image.open(w[0])).shape == (304, 304)
+    w = test_cli.main(["--config_file", cfg, "--epoch", "latest", "--num_samples", "2", "--General.inference", "S",
+                       "--Test.data", yaml.safe_dump({"real_B": {"files": os.path.join(data, "images", "*.png")}}, default_flow_style=True).strip(),
+                       "--Test.save_dir", str(tmp_path / "S")])
+    assert len(w) == 2 and all(os.path.basename(x).startswith("segmentor_") for x in w)
+    seg = np.array(Image.open(w[0]))
+    assert seg.shape == (1216, 1216) and set(np.unique(seg)) <= {0, 255}
+
+
+def test_translation_transform_from_a_checkpoint_file_runs_the_mfma_generator(gan_run):
+    """a17 ImageToImageTranslationd (reference data/data_transforms.py:327-356) from a checkpoint FILE on the GPU: the frozen
+    resnetGenerator9 under bf16 autocast -- MFMA 3x3 stages, thin-conv stems -- one pass per mini-batch, against the CPU fp32 module
+    with the same weights. Budget: sigmoid outputs in [0, 1] through 9 residual blocks in bf16: max 0.06, mean 0.01; the batched pass
+    equals the per-sample passes to bf16 rounding of identical arithmetic (InstanceNorm is per sample)."""
+    import torch
+    from octa_autosegmentation_amd.data import data_transforms as T
+    from octa_autosegmentation_amd.models import networks
+    from octa_autosegmentation_amd.models.base_model_abc import load_checkpoint_file
+    run, data, csvs = gan_run
+    path = os.path.join(run, "checkpoints", "latest_generator_model.pth")
+    t = T.ImageToImageTranslationd(model_path=path, keys=["image"])
+    assert t.amp and next(t.model.parameters()).is_cuda and not any(p.requires_grad for p in t.model.parameters())
+    g = torch.Generator().manual_seed(0)
+    imgs = [torch.rand(1, 304, 304, generator=g).cuda() for _ in range(4)]
+    from octa_autosegmentation_amd.models import mfma_conv
+    calls, orig = [], mfma_conv.conv3x3
+    mfma_conv.conv3x3 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        batched = t.batch_apply([{"image": im} for im in imgs])
+    finally:
+        mfma_conv.conv3x3 = orig
+    assert len(calls) >= 20          # 2 down + 18 residual + 2 up 3x3 stages went through the MFMA convolution, once for the mini-batch
+    single = [t({"image": im})["image"] for im in imgs]
+    cpu = networks.resnetGenerator9()
+    cpu.load_state_dict(load_checkpoint_file(path, "cpu")["model"])
+    cpu.eval()
+    with torch.no_grad():
+        ref = cpu(torch.stack([im.cpu() for im in imgs]))
+    for i in range(4):
+        b, s1 = batched[i]["image"], single[i]
+        assert b.shape == (1, 304, 304) and b.dtype == torch.float32
+        assert (b - s1).abs().max().item() <= 1e-2, (b - s1).abs().max().item()
+        d = (b.cpu() - ref[i]).abs()
+        print(f"[i2i] sample {i}: max {d.max().item():.4f} mean {d.mean().item():.5f}", flush=True)
+        assert d.max().item() <= 0.06 and d.mean().item() <= 0.01
+    t32 = T.ImageToImageTranslationd(model_path=path, keys=["image"], amp=False)         # fp32 modules on the GPU
+    d32 = (t32.batch_apply([{"image": im} for im in imgs])[0]["image"].cpu() - ref[0]).abs().max().item()
+    assert d32 <= 2e-3, d32
+
+
+def test_train_with_the_reference_s_gan_config(graphs, gan_run, tmp_path):
+    """BASELINE configs[3] AS NAMED: train.py --config_file configs/config_ves_seg-S_GAN.yml for one epoch -- background blend ->
+    frozen generator from the checkpoint the GAN run above wrote -> resize -> speckle -> flips / rotations -> DynUNet-S step. Only
+    paths, the epoch count and the generator checkpoint path are overridden. The loader's batched generator pass is checked against
+    the per-sample chain on the same seed."""
+    import torch
+    import train as train_cli
+    from octa_autosegmentation_amd.data.image_dataset import get_dataset
+    out, dirs = graphs
+    run, data, csvs = gan_run
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "config_ves_seg-S_GAN.yml")))
+    aug = cfg["Train"]["data_augmentation"]
+    i2i = [a for a in aug if a["name"] == "ImageToImageTranslationd"]
+    assert len(i2i) == 1
+    i2i[0]["model_path"] = os.path.join(run, "checkpoints", "latest_generator_model.pth")
+    f = lambda p: yaml.safe_dump({"files": p}, default_flow_style=True).strip()
+    res = str(tmp_path / "results")
+    ov = ["--Train.data.image", f(csvs), "--Train.data.label", f(csvs), "--Train.data.background", f(os.path.join(data, "background", "*.png")),
+          "--Train.data_augmentation", yaml.safe_dump(aug, default_flow_style=True, width=100000).strip(),
+          "--Train.epochs", "1", "--Train.epochs_decay", "0",
+          "--Validation.data.image", f(os.path.join(data, "images", "*.png")), "--Validation.data.label", f(os.path.join(data, "labels", "*.png")),
+          "--Output.save_dir", res, "--General.seed", "5"]
+    run2 = train_cli.main(["--config_file", os.path.join(ROOT, "configs", "config_ves_seg-S_GAN.yml")] + ov)
+    rows = open(os.path.join(run2, "metrics.csv")).read().splitlines()
+    assert rows[0].startswith("epoch,train_DiceBCELoss,val_DiceBCELoss,Train_DSC") and len(rows) == 2
+    vals = [float(v) for v in rows[1].split(",")]
+    assert np.isfinite(vals).all() and 0 < vals[1] < 2
+    assert "latest_model_model.pth" in os.listdir(os.path.join(run2, "checkpoints"))
+    # the loader itself: batched generator pass == per-sample chain (same seeds, same permutation)
+    cfg["Train"]["data"] = {"image": {"files": csvs}, "label": {"files": csvs}, "background": {"files": os.path.join(data, "background", "*.png")}}
+    cfg["General"].update(seed=9)
+    got = {}
+    for batched in (True, False):
+        torch.manual_seed(6); random.seed(6); np.random.seed(6)
+        loader = get_dataset(cfg, "Train", num_workers=0)
+        assert loader.fused is None and loader.dataset.transform.batchable()
+        if not batched:
+            loader.dataset.get_batch = lambda idx, ds=loader.dataset: [ds[j] for j in idx]
+        got[batched] = (list(loader), random.random(), float(np.random.random_sample()), float(torch.rand(())))
+    assert got[True][1:] == got[False][1:]
+    for a, b in zip(got[True][0], got[False][0]):
+        assert a["image_path"] == b["image_path"]
+        assert a["image"].shape == (4, 1, 1216, 1216) and a["image"].dtype == torch.bfloat16 and a["label"].shape == (4, 1, 1216, 1216)
+        assert (a["image"].float() - b["image"].float()).abs().max().item() <= 2e-2
+        assert torch.equal(a["label"], b["label"]) and set(a["label"].unique().tolist()) <= {0.0, 1.0}
+        assert 0.0 <= a["image"].float().min().item() and a["image"].float().max().item() <= 1.0 + 1e-2

@@ -79,6 +79,14 @@ def train(args: argparse.Namespace, config: dict):
 
     train_loader = get_dataset(config, Phase.TRAIN, num_workers=args.num_workers)
     train_loader.shard = (rank, world)
+    if world > 1:
+        # only the batch permutation is shared between ranks (its own generator, same seed everywhere); python's, numpy's and torch's
+        # global streams and every random transform continue from seed + rank, so ranks draw different flips, rotations, real_B /
+        # background picks and noise for their k-th batch
+        seed = int(config["General"].get("seed", 42))
+        train_loader.perm_generator = torch.Generator().manual_seed(seed)
+        set_determinism(seed + rank)
+        train_loader.reseed_augmentations(seed + rank)
     post_transformations_train = get_post_transformation(config, Phase.TRAIN)
     if Phase.VALIDATION in config:
         val_loader = get_dataset(config, Phase.VALIDATION, num_workers=args.num_workers)
