@@ -44,9 +44,8 @@ def main(argv=None):
 
     test_loader = get_dataset(config, Phase.TEST, num_workers=args.num_workers)
     post_transformations_test = get_post_transformation(config, Phase.TEST)
-    first = test_loader.dataset.items[0] if hasattr(test_loader.dataset, "items") else None
-    keys = list(first.keys()) if first is not None else list(config[Phase.TEST]["data"].keys())
-    input_key = [k for k in keys if not k.endswith("_path")][0]
+    input_key = None          # first non-path key of the TRANSFORMED mini-batch, as in the reference (test.py:63-65): keys a transform
+                              # deletes (`background`) do not count
 
     model = define_model(config, phase=Phase.TEST)
     model.initialize_model_and_optimizer(None, init_weights, config, args, scaler, phase=Phase.TEST)
@@ -56,6 +55,8 @@ def main(argv=None):
         for num_sample, test_mini_batch in enumerate(test_loader):
             if num_sample >= args.num_samples:
                 break
+            if input_key is None:
+                input_key = [k for k in test_mini_batch.keys() if not k.endswith("_path")][0]
             test_mini_batch["image"] = test_mini_batch.pop(input_key)
             with model.autocast():
                 outputs, _ = model.inference(test_mini_batch, post_transformations_test, device=device, phase=Phase.TEST)

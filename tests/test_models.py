@@ -219,7 +219,7 @@ def run_gan_seg_fixture(tag, idt, device="cpu", amp=False, arena=False):
     import sys
     from argparse import Namespace
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-    from tools.make_golden_ganseg import S_CFG, TRAIN, batch, checksums, formula_weights, grad_norms
+    from tools.make_golden_ganseg import S_CFG, TRAIN, WEIGHTS, batch, checksums, grad_norms
     from octa_autosegmentation_amd.models.model import define_model
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ganseg_golden.npz"))
     config = {"General": {"device": device, "amp": amp, "model": {"name": "GanSegModel", "model_g": {"name": "resnetGenerator9"},
@@ -240,31 +240,35 @@ def run_gan_seg_fixture(tag, idt, device="cpu", amp=False, arena=False):
             os.environ.pop("OCTA_GRAD_ARENA") if old is None else os.environ.__setitem__("OCTA_GRAD_ARENA", old)
     assert bool(model._arenas) == arena
     for salt, name in ((0, "generator"), (100, "discriminator"), (200, "segmentor")):
-        formula_weights(getattr(model, name), salt)
+        WEIGHTS["he_" if tag.startswith("he_") else ""](getattr(model, name), salt)
     model._after_weight_surgery()
     model.train()
     ident = {"prediction": lambda t: t, "label": lambda t: t}
     keys = ("S", "D_fake", "D_real", "G", "G_idt", "S_idt")
-    losses = []
+    losses, norms = [], []
     for step in range(2):
         _, l = model.perform_training_step(batch(), None, ident, device)
         losses.append([float(l[k]) for k in keys])
-    return np.array(losses), grad_norms(model), checksums(model), g
+        norms.append(grad_norms(model))
+    return np.array(losses), np.array(norms), checksums(model), g
 
 
-@pytest.mark.parametrize("tag,idt", [("idt0", False), ("idt1", True)])
+@pytest.mark.parametrize("tag,idt", [("idt0", False), ("idt1", True), ("he_idt0", False), ("he_idt1", True)])
 def test_gan_seg_update_matches_the_reference_fixture(tag, idt):
     """a21: two consecutive joint G / D / S updates against tests/golden/ganseg_golden.npz, recorded from the reference's own
     GanSegModel.perform_training_step (tools/make_golden_ganseg.py). Losses of step 1 depend only on the forward composition,
     those of step 2 on all three optimiser updates (Adam, betas (0.5, 0.999) for G and D, (0.9, 0.999) for S); the gradient norms and
     parameter checksums pin the backward paths (D frozen in the G+S pass, detached fake_B in the D pass, detached pseudo-labels).
-    The same fixture runs on the GPU in fp32 and through the bf16 / MFMA path in tests/test_models_gpu.py."""
+    `idt*`: parameters from the `fill` ramp; `he_idt*` (round 3): well-conditioned He-scaled parameters from numpy's legacy generator
+    (tools/make_golden_ganseg.he_weights) -- the variant that also runs on the GPU in fp32 and through the bf16 / MFMA path
+    (tests/test_models_gpu.py); with the ramp some InstanceNorm inputs are nearly constant, the generator's gradient norm is 1e6 and
+    a different summation order alone moves step-2 losses by tens of percent."""
     losses, gnorm, sums, g = run_gan_seg_fixture(tag, idt)
     # step 0: the forward composition alone (fp32 summation order); step 1: after one Adam step of all three optimisers, where
     # first-step updates are lr * sign(g) and parameters with rounding-noise gradients move either way
     for step in range(2):
         assert np.allclose(losses[step], g[f"{tag}_losses"][step], rtol=2e-5 if step == 0 else 1e-3, atol=1e-6), (step, losses[step], g[f"{tag}_losses"][step])
-    assert np.allclose(gnorm, g[f"{tag}_grad_norms"], rtol=2e-3), (gnorm, g[f"{tag}_grad_norms"])
+    assert np.allclose(gnorm, g[f"{tag}_grad_norms_steps"], rtol=2e-3), (gnorm, g[f"{tag}_grad_norms_steps"])
     # parameter checksums after two Adam steps: parameters whose gradient is rounding noise take +-lr steps of either sign, so the
     # sums agree to a small absolute slack only (the step-2 losses above are the sharp pin of the three updates)
     assert np.allclose(sums, g[f"{tag}_param_sums"], rtol=1e-6, atol=0.5), (sums, g[f"{tag}_param_sums"])

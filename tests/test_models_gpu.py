@@ -189,39 +189,46 @@ def _report(tag, what, got, want):
 
 
 
-@pytest.mark.parametrize("tag,idt", [("idt0", False), ("idt1", True)])
+@pytest.mark.parametrize("tag,idt", [("he_idt0", False), ("he_idt1", True)])
 def test_gan_seg_fixture_on_cuda_fp32(tag, idt):
     """tests/golden/ganseg_golden.npz (two perform_training_steps of the reference's own GanSegModel, tools/make_golden_ganseg.py;
-    reference models/gan_seg_model.py:116-173) with `device: cuda, amp: False`: the HIP pad / blur / InstanceNorm kernels and the
-    fp32 convolutions. Tolerances: step-1 losses 5e-4 relative (fp32 summation order through ~60 layers; the CPU test holds 2e-5),
-    step-2 losses 3e-3 (first Adam steps are lr * sign(g)), gradient norms 5e-3."""
+    reference models/gan_seg_model.py:116-173; the well-conditioned `he_` parameters) with `device: cuda, amp: False`: the HIP pad /
+    blur / InstanceNorm kernels and fp32 convolutions. Tolerances (measured on MI355X: 1.4e-5 / 3.2e-4 / 1e-4 / 6.7e-3): step-1 losses
+    1e-4 relative, step-1 gradient norms 1e-3 (one backward pass, no update behind it), step-2 losses 2e-3 and step-2 gradient norms
+    2e-2 (the first Adam step is lr * sign(g): parameters with rounding-noise gradients move either way)."""
     from tests.test_models import run_gan_seg_fixture
     losses, gnorm, sums, g = run_gan_seg_fixture(tag, idt, device="cuda", amp=False)
-    r0 = _report(tag, "fp32 step-1 losses", losses[0], g[f"{tag}_losses"][0])
-    r1 = _report(tag, "fp32 step-2 losses", losses[1], g[f"{tag}_losses"][1])
-    rg = _report(tag, "fp32 grad norms", gnorm, g[f"{tag}_grad_norms"])
-    assert np.allclose(losses[0], g[f"{tag}_losses"][0], rtol=5e-4, atol=1e-6), (losses[0], g[f"{tag}_losses"][0])
-    assert np.allclose(losses[1], g[f"{tag}_losses"][1], rtol=3e-3, atol=1e-6), (losses[1], g[f"{tag}_losses"][1])
-    assert np.allclose(gnorm, g[f"{tag}_grad_norms"], rtol=5e-3), (gnorm, g[f"{tag}_grad_norms"])
-    assert np.allclose(sums, g[f"{tag}_param_sums"], rtol=1e-6, atol=0.5)
+    _report(tag, "fp32 step-1 losses", losses[0], g[f"{tag}_losses"][0])
+    _report(tag, "fp32 step-2 losses", losses[1], g[f"{tag}_losses"][1])
+    _report(tag, "fp32 step-1 grad norms", gnorm[0], g[f"{tag}_grad_norms_steps"][0])
+    _report(tag, "fp32 step-2 grad norms", gnorm[1], g[f"{tag}_grad_norms_steps"][1])
+    assert np.allclose(losses[0], g[f"{tag}_losses"][0], rtol=1e-4, atol=1e-6), (losses[0], g[f"{tag}_losses"][0])
+    assert np.allclose(gnorm[0], g[f"{tag}_grad_norms_steps"][0], rtol=1e-3), (gnorm[0], g[f"{tag}_grad_norms_steps"][0])
+    assert np.allclose(losses[1], g[f"{tag}_losses"][1], rtol=2e-3, atol=1e-6), (losses[1], g[f"{tag}_losses"][1])
+    assert np.allclose(gnorm[1], g[f"{tag}_grad_norms_steps"][1], rtol=2e-2), (gnorm[1], g[f"{tag}_grad_norms_steps"][1])
+    assert np.allclose(sums[:, 1], g[f"{tag}_param_sums"][:, 1], rtol=1e-5), (sums, g[f"{tag}_param_sums"])
 
 
-@pytest.mark.parametrize("tag,idt", [("idt0", False), ("idt1", True)])
+@pytest.mark.parametrize("tag,idt", [("he_idt0", False), ("he_idt1", True)])
 def test_gan_seg_fixture_on_cuda_bf16_mfma(tag, idt):
     """The same fixture through the PRODUCT path of the GAN-seg step: `amp: True` -- bf16 autocast, generator / PatchGAN / DynUNet
     on the MFMA convolution, thin-conv, NHWC InstanceNorm and fused loss kernels, passes batched over concatenated mini-batches.
-    bf16 budget (8 mantissa bits, ~25 layers deep, 32x32 inputs): step-1 losses within 3 % (+0.01 absolute), step-2 losses within
-    6 %, gradient norms within 15 %; a sign or detach error moves these by factors (D_fake <-> D_real swap: 2x; missing detach of
-    fake_B in the D pass: the generator's gradient norm doubles)."""
+    bf16 budget (8 mantissa bits, ~25 layers deep, 32x32 inputs; measured on MI355X: step-1 losses 0.9 %, step-1 gradient norms
+    0.1 - 4.3 %, step-2 losses 12 %): step-1 losses within 3 %, step-1 gradient norms of G / D / S within 8 % -- the pin of the
+    backward composition: a missing detach of fake_B in the D pass adds D's gradient to G's (norm x1.4), a D that is not frozen in
+    the G+S pass doubles D's, attached pseudo-labels change S's by tens of percent; step-2 quantities (behind a sign-like first Adam
+    step of every parameter) within 20 %."""
     from tests.test_models import run_gan_seg_fixture
     losses, gnorm, sums, g = run_gan_seg_fixture(tag, idt, device="cuda", amp=True)
     _report(tag, "bf16 step-1 losses", losses[0], g[f"{tag}_losses"][0])
     _report(tag, "bf16 step-2 losses", losses[1], g[f"{tag}_losses"][1])
-    _report(tag, "bf16 grad norms", gnorm, g[f"{tag}_grad_norms"])
-    assert np.allclose(losses[0], g[f"{tag}_losses"][0], rtol=3e-2, atol=1e-2), (losses[0], g[f"{tag}_losses"][0])
-    assert np.allclose(losses[1], g[f"{tag}_losses"][1], rtol=6e-2, atol=1e-2), (losses[1], g[f"{tag}_losses"][1])
-    assert np.allclose(gnorm, g[f"{tag}_grad_norms"], rtol=0.15), (gnorm, g[f"{tag}_grad_norms"])
-    assert np.allclose(sums, g[f"{tag}_param_sums"], rtol=1e-4, atol=1.0)
+    _report(tag, "bf16 step-1 grad norms", gnorm[0], g[f"{tag}_grad_norms_steps"][0])
+    _report(tag, "bf16 step-2 grad norms", gnorm[1], g[f"{tag}_grad_norms_steps"][1])
+    assert np.allclose(losses[0], g[f"{tag}_losses"][0], rtol=3e-2, atol=1e-3), (losses[0], g[f"{tag}_losses"][0])
+    assert np.allclose(gnorm[0], g[f"{tag}_grad_norms_steps"][0], rtol=8e-2), (gnorm[0], g[f"{tag}_grad_norms_steps"][0])
+    assert np.allclose(losses[1], g[f"{tag}_losses"][1], rtol=0.2, atol=1e-3), (losses[1], g[f"{tag}_losses"][1])
+    assert np.allclose(gnorm[1], g[f"{tag}_grad_norms_steps"][1], rtol=0.2), (gnorm[1], g[f"{tag}_grad_norms_steps"][1])
+    assert np.allclose(sums[:, 1], g[f"{tag}_param_sums"][:, 1], rtol=1e-4), (sums, g[f"{tag}_param_sums"])
 
 
 @pytest.fixture(scope="module")
@@ -243,8 +250,8 @@ def test_grad_arena_and_rccl_on_device_equal_the_plain_step(one_rank_rccl):
     autograd functions accumulate into the views, the exchange is ONE RCCL all-reduce on that buffer (one rank: sum = identity).
     Both trainers give the arena-less step's numbers: the GAN-seg fixture (three optimisers, bf16 / MFMA) and the U-Net step."""
     from tests.test_models import CFG, run_gan_seg_fixture
-    plain = run_gan_seg_fixture("idt1", True, device="cuda", amp=True)
-    arena = run_gan_seg_fixture("idt1", True, device="cuda", amp=True, arena=True)
+    plain = run_gan_seg_fixture("he_idt1", True, device="cuda", amp=True)
+    arena = run_gan_seg_fixture("he_idt1", True, device="cuda", amp=True, arena=True)
     # fp32 atomics in the weight-gradient kernels make bf16 steps reproducible to rounding only
     assert np.allclose(plain[0], arena[0], rtol=2e-3, atol=1e-4), (plain[0], arena[0])
     assert np.allclose(plain[1], arena[1], rtol=2e-2), (plain[1], arena[1])

@@ -128,6 +128,22 @@ def test_full_length_run_sha(gh, golden):
         assert hashlib.sha256(text.encode()).hexdigest() == str(golden[n + "_csv_sha256"]), n
 
 
+def test_wide_reference_pin_64_full_length_seeds(gh, golden):
+    """tests/golden/sim_wide_golden.npz (tools/make_golden_sim_wide.py): the imported reference run on 64 full-length seeds (1000..1063,
+    shipped docker config, I = 100 + 150) -- SHA-256 of its CSV text, row counts and per-iteration traces. One GPU batch of all 64
+    must print every file byte for byte."""
+    wide = np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_wide_golden.npz"))
+    seeds = [int(v) for v in wide["seeds"]]
+    assert len(seeds) >= 64
+    res = gh.simulate_batch(_cfg(golden, 100, 150), seeds)
+    bad = []
+    for k, seed in enumerate(seeds):
+        text = gh.edges_to_csv_text(res.sample_edges(k))
+        if text.count("\n") - 1 != int(wide["rows"][k]) or hashlib.sha256(text.encode()).hexdigest() != str(wide["csv_sha256"][k]):
+            bad.append(seed)
+    assert not bad, f"CSV text differs from the reference's for seeds {bad}"
+
+
 def test_device_kd_order_matches_scipy(hip_lib_built):
     """The team-parallel introselect on the device must give scipy's tree.indices (no ties in the data)."""
     from scipy.spatial import cKDTree

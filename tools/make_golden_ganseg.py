@@ -42,6 +42,30 @@ def formula_weights(net, salt):
     net.load_state_dict(sd)
 
 
+def he_weights(net, salt):
+    """Well-conditioned closed-form parameters (round 3): per tensor (state_dict order, index k) numpy's legacy
+    RandomState(7000 + salt + k) -- a fixed algorithm, so the test rebuilds the same values on any machine; conv weights
+    N(0, 2 / fan_in) (He), InstanceNorm scales 1 + 0.1 N(0, 1), biases 0.01 N(0, 1). The `fill` ramp above makes some
+    InstanceNorm inputs nearly constant (gradient norms of 1e6 in the generator), which amplifies summation-order differences
+    between devices by orders of magnitude; these parameters do not."""
+    sd = net.state_dict()
+    for k, (name, t) in enumerate(sd.items()):
+        if name.endswith("filt") or name.startswith("skip_layers"):
+            continue
+        r = np.random.RandomState(7000 + salt + k).standard_normal(tuple(t.shape))
+        if t.dim() > 1:
+            v = r * np.sqrt(2.0 / max(int(np.prod(t.shape[1:])), 1))
+        elif name.endswith("bias"):
+            v = 0.01 * r
+        else:
+            v = 1.0 + 0.1 * r
+        sd[name] = torch.from_numpy(v.astype(np.float32))
+    net.load_state_dict(sd)
+
+
+WEIGHTS = {"": formula_weights, "he_": he_weights}
+
+
 def batch():
     real_A = image((2, 1, 32, 32), 4)
     real_B = image((2, 1, 32, 32), 5).flip(-1)
@@ -66,11 +90,12 @@ def run(model, steps=2):
     from torch.amp import GradScaler
     scaler = GradScaler("cpu", enabled=False)
     ident = {"prediction": lambda t: t, "label": lambda t: t}
-    losses = []
+    losses, norms = [], []
     for _ in range(steps):
         _, l = model.perform_training_step(batch(), scaler, ident, "cpu")
         losses.append([float(l[k]) for k in ("S", "D_fake", "D_real", "G", "G_idt", "S_idt")])
-    return np.array(losses), grad_norms(model), checksums(model)
+        norms.append(grad_norms(model))
+    return np.array(losses), np.array(norms), checksums(model)
 
 
 def main():
@@ -105,17 +130,20 @@ def main():
     from utils.enums import Phase
     MODEL_DICT = {"resnetGenerator9": ref_nets.resnetGenerator9, "patchGAN70x70": ref_nets.patchGAN70x70, "DynUNet": DynUNet}
     out = {}
-    for tag, idt in (("idt0", False), ("idt1", True)):
+    for tag, idt in (("idt0", False), ("idt1", True), ("he_idt0", False), ("he_idt1", True)):
+        set_weights = WEIGHTS["he_" if tag.startswith("he_") else ""]
         torch.manual_seed(0)
         model = ref_gs.GanSegModel(MODEL_DICT, {"name": "resnetGenerator9"}, {"name": "patchGAN70x70"}, dict(S_CFG), compute_identity=idt,
                                    compute_identity_seg=True, phase=Phase.TRAIN, upshape=(64, 64))
         config = {"General": {"device": "cpu", "amp": False}, "Train": dict(TRAIN), "Output": {"save_dir": "/tmp"}}
         model.initialize_model_and_optimizer(None, ref_nets.init_weights, config, argparse.Namespace(start_epoch=0, epoch="latest"), None, Phase.TRAIN)
         for salt, name in ((0, "generator"), (100, "discriminator"), (200, "segmentor")):
-            formula_weights(getattr(model, name), salt)
+            set_weights(getattr(model, name), salt)
         model.train()
         losses, gnorm, sums = run(model)
-        out[f"{tag}_losses"], out[f"{tag}_grad_norms"], out[f"{tag}_param_sums"] = losses, gnorm, sums
+        # `_grad_norms`: after the second step (round 2's entry); `_grad_norms_steps`: after each step -- the first row is a pure
+        # backward pass (no optimiser update behind it), the sharp pin of detach / sign errors on reduced-precision paths
+        out[f"{tag}_losses"], out[f"{tag}_grad_norms"], out[f"{tag}_grad_norms_steps"], out[f"{tag}_param_sums"] = losses, gnorm[-1], gnorm, sums
         print(tag, losses, gnorm, sums, sep="\n")
     np.savez_compressed(OUT, **out)
     print("wrote", OUT)
