@@ -45,8 +45,8 @@ constexpr int MAXKEPT = 256;   // attractors shipped with one bifurcation reques
 constexpr int NCANDCAP = 8192; // candidates per iteration
 constexpr int TILE = 1024;     // points per LDS tile in brute-force queries
 constexpr int ACCCAP = 2048;   // accepted sinks per iteration
-constexpr int KD_RANGES = 896;  // ranges per kd level (> OCAP / 17)
-constexpr int KD_MAILBOX_OFF = OCAP * 10 + KD_RANGES * (4 * 2 + 4);  // LDS offset (after user()) of the swap mailbox
+constexpr int KD_RANGES = 784;  // ranges per kd level (> OCAP / 17: a range that is split further holds at least 17 points)
+constexpr int KD_MAILBOX_OFF = OCAP * 4 + ((KD_RANGES * 9 + 15) / 16) * 16;   // LDS offset (after user()) of the swap mailbox / box table
 constexpr int KD_TEAM_MIN = 192;   // ranges at least this long get a whole wave, shorter ones 16 lanes
 constexpr int KD_WAVES = 8;                                    // waves per workgroup
 constexpr int KD_MAILBOX_BYTES = (OCAP / 2 + 64) * 2;          // one u16 slot per possible swap: ranges are disjoint
@@ -431,71 +431,106 @@ OCTA_HD inline void pyset_add(PySetView &s, int key, unsigned long long hash) {
 
 // ------------------------------------------------------------------ libstdc++ std::nth_element restated
 // Elements are (key, idx) pairs ordered by (key, idx) -- scipy's index_compare for one split dimension.
+// LDS form (round 3): ONE 32-bit word per element, q << 14 | idx. idx names the point (OCAP <= 2^14); q is the split-dimension
+// coordinate quantised to 18 bits over its range's [min, max] -- a monotone map (rounding of x - min, of the product with the
+// scale and the truncation are all monotone), so two words whose q differ compare exactly like the coordinates; words with the
+// same q (about n / 2^18 of the comparisons) are decided on the doubles themselves, fetched from the point list. Every
+// comparison has the exact (key, idx) outcome with 4 B instead of 10 B of LDS per element, and a swap moves one word.
+constexpr int KD_IDX_BITS = 14;
+constexpr unsigned KD_IDX_MASK = (1u << KD_IDX_BITS) - 1u;
+constexpr unsigned KD_QMAX = (1u << (32 - KD_IDX_BITS)) - 1u;
+static_assert(OCAP <= (1 << KD_IDX_BITS), "kd index bits");
 struct KdPair {
-    double *key;
-    unsigned short *idx;
+    unsigned *kv;        // packed elements (LDS on the device)
+    const double *pts;   // [n][3] coordinates
+    int d;               // split dimension of the range being partitioned
 };
-OCTA_HD inline bool kd_less(const KdPair &a, int i, int j) {
-    double x = a.key[i], y = a.key[j];
-    if (x == y) return a.idx[i] < a.idx[j];
-    return x < y;
+OCTA_HD inline bool kd_less_w(const KdPair &a, unsigned x, unsigned y) {
+    if ((x ^ y) >> KD_IDX_BITS) return x < y;
+    const unsigned xi = x & KD_IDX_MASK, yi = y & KD_IDX_MASK;
+    const double fx = a.pts[3 * xi + a.d], fy = a.pts[3 * yi + a.d];
+    if (fx == fy) return xi < yi;
+    return fx < fy;
 }
-OCTA_HD inline bool kd_less_vi(double xv, unsigned short xi, const KdPair &a, int j) {
-    double y = a.key[j];
-    if (xv == y) return xi < a.idx[j];
-    return xv < y;
+OCTA_HD inline bool kd_less(const KdPair &a, int i, int j) { return kd_less_w(a, a.kv[i], a.kv[j]); }
+OCTA_HD inline void kd_swap(const KdPair &a, int i, int j) { unsigned t = a.kv[i]; a.kv[i] = a.kv[j]; a.kv[j] = t; }
+OCTA_HD inline unsigned kd_quant(double x, double mn, double scale) {
+    const double t = (x - mn) * scale;
+    unsigned q = t > 0.0 ? (unsigned)t : 0u;
+    return q > KD_QMAX ? KD_QMAX : q;
 }
-OCTA_HD inline bool kd_less_iv(const KdPair &a, int i, double yv, unsigned short yi) {
-    double x = a.key[i];
-    if (x == yv) return a.idx[i] < yi;
-    return x < yv;
-}
-OCTA_HD inline void kd_swap(const KdPair &a, int i, int j) {
-    double t = a.key[i]; a.key[i] = a.key[j]; a.key[j] = t;
-    unsigned short u = a.idx[i]; a.idx[i] = a.idx[j]; a.idx[j] = u;
-}
-OCTA_HD inline void kd_push_heap(const KdPair &a, int first, int hole, int top, double vv, unsigned short vi) {
+OCTA_HD inline void kd_push_heap(const KdPair &a, int first, int hole, int top, unsigned v) {
     int parent = (hole - 1) / 2;
-    while (hole > top && kd_less_iv(a, first + parent, vv, vi)) {
-        a.key[first + hole] = a.key[first + parent]; a.idx[first + hole] = a.idx[first + parent];
+    while (hole > top && kd_less_w(a, a.kv[first + parent], v)) {
+        a.kv[first + hole] = a.kv[first + parent];
         hole = parent;
         parent = (hole - 1) / 2;
     }
-    a.key[first + hole] = vv; a.idx[first + hole] = vi;
+    a.kv[first + hole] = v;
 }
-OCTA_HD inline void kd_adjust_heap(const KdPair &a, int first, int hole, int len, double vv, unsigned short vi) {
+OCTA_HD inline void kd_adjust_heap(const KdPair &a, int first, int hole, int len, unsigned v) {
     const int top = hole;
     int second = hole;
     while (second < (len - 1) / 2) {
         second = 2 * (second + 1);
         if (kd_less(a, first + second, first + (second - 1))) second--;
-        a.key[first + hole] = a.key[first + second]; a.idx[first + hole] = a.idx[first + second];
+        a.kv[first + hole] = a.kv[first + second];
         hole = second;
     }
     if ((len & 1) == 0 && second == (len - 2) / 2) {
         second = 2 * (second + 1);
-        a.key[first + hole] = a.key[first + (second - 1)]; a.idx[first + hole] = a.idx[first + (second - 1)];
+        a.kv[first + hole] = a.kv[first + (second - 1)];
         hole = second - 1;
     }
-    kd_push_heap(a, first, hole, top, vv, vi);
+    kd_push_heap(a, first, hole, top, v);
 }
 OCTA_HD inline void kd_heap_select(const KdPair &a, int first, int middle, int last) {
     int len = middle - first;
     if (len >= 2) {
         int parent = (len - 2) / 2;
         while (true) {
-            double vv = a.key[first + parent]; unsigned short vi = a.idx[first + parent];
-            kd_adjust_heap(a, first, parent, len, vv, vi);
+            unsigned v = a.kv[first + parent];
+            kd_adjust_heap(a, first, parent, len, v);
             if (parent == 0) break;
             parent--;
         }
     }
     for (int i = middle; i < last; ++i)
         if (kd_less(a, i, first)) {
-            double vv = a.key[i]; unsigned short vi = a.idx[i];
-            a.key[i] = a.key[first]; a.idx[i] = a.idx[first];
-            kd_adjust_heap(a, first, 0, middle - first, vv, vi);
+            unsigned v = a.kv[i];
+            a.kv[i] = a.kv[first];
+            kd_adjust_heap(a, first, 0, middle - first, v);
         }
+}
+// __insertion_sort of [first, last)
+OCTA_HD inline void kd_insertion_sort(const KdPair &a, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i < last; ++i) {
+        const unsigned v = a.kv[i];
+        if (kd_less_w(a, v, a.kv[first])) {
+            for (int k = i; k > first; --k) a.kv[k] = a.kv[k - 1];
+            a.kv[first] = v;
+        } else {
+            int lastp = i, next = i - 1;
+            while (kd_less_w(a, v, a.kv[next])) {
+                a.kv[lastp] = a.kv[next];
+                lastp = next; --next;
+            }
+            a.kv[lastp] = v;
+        }
+    }
+}
+// __move_median_to_first(first, first + 1, mid, last - 1)
+OCTA_HD inline void kd_median_to_first(const KdPair &a, int first, int last) {
+    const int mid = first + (last - first) / 2;
+    const int A = first + 1, B = mid, C = last - 1;
+    if (kd_less(a, A, B)) {
+        if (kd_less(a, B, C)) kd_swap(a, first, B);
+        else if (kd_less(a, A, C)) kd_swap(a, first, C);
+        else kd_swap(a, first, A);
+    } else if (kd_less(a, A, C)) kd_swap(a, first, A);
+    else if (kd_less(a, B, C)) kd_swap(a, first, C);
+    else kd_swap(a, first, B);
 }
 OCTA_HD inline void kd_nth_element(const KdPair &a, int first, int nth, int last) {
     if (first == last || nth == last) return;
@@ -509,16 +544,7 @@ OCTA_HD inline void kd_nth_element(const KdPair &a, int first, int nth, int last
             return;
         }
         --depth;
-        // __unguarded_partition_pivot
-        int mid = first + (last - first) / 2;
-        int A = first + 1, B = mid, C = last - 1;
-        if (kd_less(a, A, B)) {
-            if (kd_less(a, B, C)) kd_swap(a, first, B);
-            else if (kd_less(a, A, C)) kd_swap(a, first, C);
-            else kd_swap(a, first, A);
-        } else if (kd_less(a, A, C)) kd_swap(a, first, A);
-        else if (kd_less(a, B, C)) kd_swap(a, first, C);
-        else kd_swap(a, first, B);
+        kd_median_to_first(a, first, last);   // __unguarded_partition_pivot
         int lo = first + 1, hi = last;
         while (true) {
             while (kd_less(a, lo, first)) ++lo;
@@ -531,22 +557,7 @@ OCTA_HD inline void kd_nth_element(const KdPair &a, int first, int nth, int last
         int cut = lo;
         if (cut <= nth) first = cut; else last = cut;
     }
-    // __insertion_sort
-    if (first == last) return;
-    for (int i = first + 1; i != last; ++i) {
-        double vv = a.key[i]; unsigned short vi = a.idx[i];
-        if (kd_less(a, i, first)) {
-            for (int k = i; k > first; --k) { a.key[k] = a.key[k - 1]; a.idx[k] = a.idx[k - 1]; }
-            a.key[first] = vv; a.idx[first] = vi;
-        } else {
-            int lastp = i, next = i - 1;
-            while (kd_less_vi(vv, vi, a, next)) {
-                a.key[lastp] = a.key[next]; a.idx[lastp] = a.idx[next];
-                lastp = next; --next;
-            }
-            a.key[lastp] = vv; a.idx[lastp] = vi;
-        }
-    }
+    kd_insertion_sort(a, first, last);
 }
 
 
@@ -576,20 +587,9 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
             return;
         }
         --depth;
-        if (tl == 0) {
-            int mid = first + (last - first) / 2;
-            int A = first + 1, B = mid, C = last - 1;
-            if (kd_less(a, A, B)) {
-                if (kd_less(a, B, C)) kd_swap(a, first, B);
-                else if (kd_less(a, A, C)) kd_swap(a, first, C);
-                else kd_swap(a, first, A);
-            } else if (kd_less(a, A, C)) kd_swap(a, first, A);
-            else if (kd_less(a, B, C)) kd_swap(a, first, C);
-            else kd_swap(a, first, B);
-        }
+        if (tl == 0) kd_median_to_first(a, first, last);
         __builtin_amdgcn_wave_barrier();
-        const double pv = a.key[first];
-        const unsigned short pi = a.idx[first];
+        const unsigned pk = a.kv[first];
         const int base = first + 1, m = last - base;
         const int c = ((m + TW - 1) / TW) | 1;  // odd chunk length: lanes hit distinct LDS banks
         int p0 = base + tl * c;
@@ -604,8 +604,12 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
             lim = lim > 64 ? 64 : lim;
             unsigned long long bits = 0;
 #pragma unroll 4
-            for (int i = 0; i < lim; i++)
-                if (kd_less_iv(a, q0 + i, pv, pi)) bits |= 1ull << i;
+            for (int i = 0; i < lim; i++) {
+                const unsigned x = a.kv[q0 + i];
+                bool lt = x < pk;
+                if (!((x ^ pk) >> KD_IDX_BITS)) lt = kd_less_w(a, x, pk);     // same bucket as the pivot: exact (rare)
+                if (lt) bits |= 1ull << i;
+            }
             ms[w] = bits;
             nS += __popcll(bits);
         }
@@ -655,31 +659,75 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
         __builtin_amdgcn_wave_barrier();
         if (cut <= nth) first = cut; else last = cut;
     }
-    if (tl == 0) {
-        for (int i = first + 1; i < last; ++i) {
-            double vv = a.key[i]; unsigned short vi = a.idx[i];
-            if (kd_less(a, i, first)) {
-                for (int k = i; k > first; --k) { a.key[k] = a.key[k - 1]; a.idx[k] = a.idx[k - 1]; }
-                a.key[first] = vv; a.idx[first] = vi;
-            } else {
-                int lastp = i, next = i - 1;
-                while (kd_less_vi(vv, vi, a, next)) {
-                    a.key[lastp] = a.key[next]; a.idx[lastp] = a.idx[next];
-                    lastp = next; --next;
-                }
-                a.key[lastp] = vv; a.idx[lastp] = vi;
-            }
-        }
-    }
+    if (tl == 0) kd_insertion_sort(a, first, last);
     __builtin_amdgcn_wave_barrier();
 }
 #endif
+
+// Per-range bounding boxes as SINGLE-precision outer bounds (max rounded up, min rounded down; 24 B per range in LDS, folded with
+// 32-bit LDS atomics on order-preserving encodings). They only have to answer "which dimension has the largest spread" (scipy: the
+// first one, strict >): with s_hi = max_up - min_dn >= spread >= s_lo = s_hi - the two roundings, dimension k is the answer when
+// s_lo[k] > s_hi[j] for both others; a range whose intervals overlap (two spreads equal to 1e-7 relative: about once per thousand
+// builds) is measured exactly by its thread. The quantisation of the keys needs no exact bounds at all (kd_quant is monotone for any
+// offset / scale; values outside clamp).
+OCTA_HD inline unsigned f32_sortable(float v) {
+    unsigned u;
+    memcpy(&u, &v, 4);
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+OCTA_HD inline float f32_unsortable(unsigned e) {
+    unsigned u = (e >> 31) ? (e & 0x7fffffffu) : ~e;
+    float v;
+    memcpy(&v, &u, 4);
+    return v;
+}
+OCTA_HD inline float f32_round_up(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2float_ru(x);
+#else
+    float f = (float)x;
+    return (double)f < x ? nextafterf(f, INFINITY) : f;
+#endif
+}
+OCTA_HD inline float f32_round_down(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2float_rd(x);
+#else
+    float f = (float)x;
+    return (double)f > x ? nextafterf(f, -INFINITY) : f;
+#endif
+}
+OCTA_HD inline double f32_ulp(float v) {   // spacing of single-precision numbers at |v| (>= the rounding error of one directed conversion)
+    const float a = fabsf(v);
+    return (double)nextafterf(a, INFINITY) - (double)a;
+}
+OCTA_HD inline void atomic_max_u32(unsigned *p, unsigned v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax(p, v);
+#else
+    if (v > *p) *p = v;
+#endif
+}
+OCTA_HD inline void atomic_min_u32(unsigned *p, unsigned v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
 
 // scipy cKDTree build order (leafsize 16, compact, median): fills kd_idx (tree.indices) and kd_rank.
 // Level-synchronous: range boundaries depend only on n; a range that became a leaf is marked done.
 // `need` (optional) flags the points whose rank will be read: a range without any such point is not
 // partitioned further (its internal order is never observed), which prunes most of the deep levels.
-// LDS: key double[OCAP] + idx u16[OCAP] + per-level range table.
+// LDS (78 KiB, kd_lds_layout below): packed elements u32[OCAP], per-level range tables, and the swap mailbox, whose area (plus the
+// tail) hosts the box table while no partition is running.
+constexpr int KD_TAB_OFF = OCAP * 4;                        // rs, re, rs2, re2 (u16 each), rd (s8) per range
+constexpr int KD_BOX_BYTES = KD_RANGES * 24;
+static_assert(KD_RANGES >= OCAP / 17 + 1, "ranges per level");
+static_assert(KD_MAILBOX_OFF % 16 == 0 && KD_MAILBOX_OFF >= KD_TAB_OFF + KD_RANGES * 9, "kd tables overlap the mailbox");
+static_assert(KD_BOX_BYTES >= KD_MAILBOX_BYTES, "the box table covers the mailbox");
+static_assert(2048 + KD_MAILBOX_OFF + KD_BOX_BYTES <= SIM_LDS_BYTES, "kd LDS layout");
 OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned short *out_idx, unsigned short *out_rank,
                               long *kdprof = nullptr, const unsigned char *need = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -688,26 +736,23 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
 #else
 #define KDP(slot) do { } while (0)
 #endif
-    double *key = reinterpret_cast<double *>(b.user());
-    unsigned short *idx = reinterpret_cast<unsigned short *>(b.user() + (size_t)OCAP * 8);
-    unsigned short *tab = reinterpret_cast<unsigned short *>(b.user() + (size_t)OCAP * 10);  // 4 u16 tables + 1 int table
-    unsigned short *rs = tab, *re = tab + KD_RANGES;                     // range start / end
+    unsigned *kv = reinterpret_cast<unsigned *>(b.user());
+    unsigned short *tab = reinterpret_cast<unsigned short *>(b.user() + KD_TAB_OFF);
+    unsigned short *rs = tab, *re = tab + KD_RANGES;                        // range start / end
     unsigned short *rs2 = tab + 2 * KD_RANGES, *re2 = tab + 3 * KD_RANGES;  // next level
-    int *rd = reinterpret_cast<int *>(tab + 4 * KD_RANGES);              // split dim (-1 = leaf / not needed)
-    for (int i = b.tid; i < n; i += b.nth) idx[i] = (unsigned short)i;
+    signed char *rd = reinterpret_cast<signed char *>(tab + 4 * KD_RANGES); // bbox pass: 1 = holds a needed point; then split dim (-1 = leaf / not needed)
+    unsigned *bbf = reinterpret_cast<unsigned *>(b.user() + KD_MAILBOX_OFF); // [nr][6]: max xyz (rounded up), min xyz (rounded down)
+    for (int i = b.tid; i < n; i += b.nth) kv[i] = (unsigned)i;
     if (b.tid == 0) { rs[0] = 0; re[0] = (unsigned short)n; }
     b.sync();
     int nr = (n > 16) ? 1 : 0;  // a range of <= leafsize points is a leaf: left in input order
-    KdPair kp = {key, idx};
     while (nr > 0) {
-        // 1. bounding box per range, element-parallel: every thread walks a contiguous chunk of the index
-        //    array (ranges are sorted, disjoint slices of it), gathers the three coordinates and folds
-        //    them into a per-range min/max table with LDS 64-bit atomics on order-preserving encodings.
-        //    The key array is free at this point and hosts the table.
-        unsigned long long *bb = reinterpret_cast<unsigned long long *>(key);  // [nr][6]: max xyz, min xyz
+        // 1. bounding box per range, element-parallel: every thread walks a contiguous chunk of the element
+        //    array (ranges are sorted, disjoint slices of it), gathers the three coordinates, keeps exact
+        //    running extrema and folds their single-precision outer bounds into the per-range table.
         for (int q = b.tid; q < nr; q += b.nth) {
-            for (int k = 0; k < 3; k++) { bb[6 * q + k] = 0ull; bb[6 * q + 3 + k] = ~0ull; }
-            rd[q] = 0;  // counts the needed points of the range during the bbox pass
+            for (int k = 0; k < 3; k++) { bbf[6 * q + k] = 0u; bbf[6 * q + 3 + k] = ~0u; }
+            rd[q] = 0;
         }
         b.sync();
         {
@@ -719,45 +764,62 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 while (lo_ < hi_) { int mid = (lo_ + hi_ + 1) >> 1; if (rs[mid] <= i0) lo_ = mid; else hi_ = mid - 1; }
                 q = lo_;
             }
-            bool have = false;
-            int hits = 0;
-            unsigned long long mx[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+            bool have = false, hit = false;
+            double mx[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
             for (int i = i0; i < i1; i++) {
                 while (q + 1 < nr && rs[q + 1] <= i) {
-                    if (have) { for (int k = 0; k < 3; k++) { atomic_max_u64(&bb[6 * q + k], mx[k]); atomic_min_u64(&bb[6 * q + 3 + k], mn[k]); } have = false; }
-                    if (hits) { atomic_add_int(&rd[q], hits); hits = 0; }
+                    if (have) { for (int k = 0; k < 3; k++) { atomic_max_u32(&bbf[6 * q + k], f32_sortable(f32_round_up(mx[k]))); atomic_min_u32(&bbf[6 * q + 3 + k], f32_sortable(f32_round_down(mn[k]))); } have = false; }
+                    if (hit) { rd[q] = 1; hit = false; }
                     q++;
                 }
                 if (i < rs[q] || i >= re[q]) continue;  // element of a finished leaf
-                if (!need || need[idx[i]]) hits++;
-                const double *p = pts + 3 * (int)idx[i];
+                const int id = (int)(kv[i] & KD_IDX_MASK);
+                if (!need || need[id]) hit = true;
+                const double *p = pts + 3 * id;
                 for (int k = 0; k < 3; k++) {
-                    unsigned long long e = dbl_sortable(p[k]);
+                    const double e = p[k];
                     if (!have) { mx[k] = mn[k] = e; }
                     else { mx[k] = mx[k] > e ? mx[k] : e; mn[k] = mn[k] < e ? mn[k] : e; }
                 }
                 have = true;
             }
-            if (have) for (int k = 0; k < 3; k++) { atomic_max_u64(&bb[6 * q + k], mx[k]); atomic_min_u64(&bb[6 * q + 3 + k], mn[k]); }
-            if (hits) atomic_add_int(&rd[q], hits);
+            if (have) for (int k = 0; k < 3; k++) { atomic_max_u32(&bbf[6 * q + k], f32_sortable(f32_round_up(mx[k]))); atomic_min_u32(&bbf[6 * q + 3 + k], f32_sortable(f32_round_down(mn[k]))); }
+            if (hit) rd[q] = 1;
         }
         b.sync();
         KDP(0);
+        // split dimension = the first one with the largest spread
         for (int q = b.tid; q < nr; q += b.nth) {
-            int d = 0;
-            double size = 0;
-            double mxd = 0, mnd = 0;
+            if (rd[q] == 0) { rd[q] = -1; continue; }     // no needed point below this range
+            double shi[3], slo[3];
             for (int k = 0; k < 3; k++) {
-                double hi_ = dbl_unsortable(bb[6 * q + k]), lo_ = dbl_unsortable(bb[6 * q + 3 + k]);
-                if (hi_ - lo_ > size) { d = k; size = hi_ - lo_; }
-                if (k == 0) { mxd = hi_; mnd = lo_; }
+                const float up = f32_unsortable(bbf[6 * q + k]), dn = f32_unsortable(bbf[6 * q + 3 + k]);
+                shi[k] = (double)up - (double)dn;
+                slo[k] = shi[k] - 2.0 * (f32_ulp(up) + f32_ulp(dn));
             }
-            mxd = dbl_unsortable(bb[6 * q + d]); mnd = dbl_unsortable(bb[6 * q + 3 + d]);
-            rd[q] = (mxd == mnd || rd[q] == 0) ? -1 : d;
+            int d = 0;
+            if (shi[1] > shi[d]) d = 1;
+            if (shi[2] > shi[d]) d = 2;
+            bool sure = true;
+            for (int k = 0; k < 3; k++) if (k != d && !(slo[d] > shi[k])) sure = false;
+            if (sure) { rd[q] = (signed char)d; continue; }
+            // overlapping intervals (or a degenerate box): the exact extrema of the range decide, as scipy's do
+            double hi3[3] = {0, 0, 0}, lo3[3] = {0, 0, 0};
+            for (int i = rs[q]; i < re[q]; i++) {
+                const double *p = pts + 3 * (int)(kv[i] & KD_IDX_MASK);
+                for (int k = 0; k < 3; k++) {
+                    if (i == rs[q]) { hi3[k] = lo3[k] = p[k]; }
+                    else { hi3[k] = hi3[k] > p[k] ? hi3[k] : p[k]; lo3[k] = lo3[k] < p[k] ? lo3[k] : p[k]; }
+                }
+            }
+            d = 0;
+            double size = 0;
+            for (int k = 0; k < 3; k++) if (hi3[k] - lo3[k] > size) { d = k; size = hi3[k] - lo3[k]; }
+            rd[q] = (hi3[d] == lo3[d]) ? (signed char)-1 : (signed char)d;
         }
         b.sync();
         KDP(1);
-        // 2. gather the split-dimension keys, element-parallel with the same chunking
+        // 2. quantised split-dimension keys, element-parallel with the same chunking
         {
             const int chunk = (n + b.nth - 1) / b.nth;
             const int i0 = b.tid * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
@@ -767,14 +829,26 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 while (lo_ < hi_) { int mid = (lo_ + hi_ + 1) >> 1; if (rs[mid] <= i0) lo_ = mid; else hi_ = mid - 1; }
                 q = lo_;
             }
+            int qc = -1, d = -1;
+            double mnd = 0, scale = 0;
             for (int i = i0; i < i1; i++) {
                 while (q + 1 < nr && rs[q + 1] <= i) q++;
                 if (i < rs[q] || i >= re[q]) continue;
-                int d = rd[q];
-                if (d >= 0) key[i] = pts[3 * (int)idx[i] + d];
+                if (q != qc) {
+                    qc = q; d = rd[q];
+                    if (d >= 0) {
+                        mnd = (double)f32_unsortable(bbf[6 * q + 3 + d]);
+                        const double w = (double)f32_unsortable(bbf[6 * q + d]) - mnd;
+                        scale = w > 0.0 ? (double)KD_QMAX / w : 0.0;
+                    }
+                }
+                if (d >= 0) {
+                    const unsigned id = kv[i] & KD_IDX_MASK;
+                    kv[i] = (kd_quant(pts[3 * id + d], mnd, scale) << KD_IDX_BITS) | id;
+                }
             }
         }
-        b.sync();
+        b.sync();    // the box table is dead from here on: its area is the mailbox of the partitions
         KDP(2);
         // 3. nth_element per range: long ranges by one wave each, short ranges by a quarter wave each
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -785,6 +859,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 int d = rd[q];
                 int s = rs[q], e = re[q];
                 if (d < 0 || e - s < KD_TEAM_MIN) continue;
+                const KdPair kp = {kv, pts, d};
                 if (e - s > 4000) kd_nth_element_team<64, 4>(kp, s, s + (e - s) / 2, e, true, mb);
                 else kd_nth_element_team<64, 1>(kp, s, s + (e - s) / 2, e, true, mb);
             }
@@ -797,11 +872,12 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
             for (int q0 = 0; q0 < nr; q0 += nteam) {
                 int q = q0 + team;
                 bool live = q < nr;
-                int s = 0, e = 0;
+                int s = 0, e = 0, d = 0;
                 if (live) {
-                    s = rs[q]; e = re[q];
-                    live = rd[q] >= 0 && e - s < KD_TEAM_MIN;
+                    s = rs[q]; e = re[q]; d = rd[q];
+                    live = d >= 0 && e - s < KD_TEAM_MIN;
                 }
+                const KdPair kp = {kv, pts, d < 0 ? 0 : d};
                 kd_nth_element_team<16, 1>(kp, s, s + (e - s) / 2, e, live, mb);
             }
         }
@@ -810,6 +886,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
             int d = rd[q];
             if (d < 0) continue;
             int s = rs[q], e = re[q];
+            const KdPair kp = {kv, pts, d};
             kd_nth_element(kp, s, s + (e - s) / 2, e);
         }
 #endif
@@ -839,7 +916,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
         b.sync();
         KDP(5);
     }
-    for (int i = b.tid; i < n; i += b.nth) { out_idx[i] = idx[i]; out_rank[idx[i]] = (unsigned short)i; }
+    for (int i = b.tid; i < n; i += b.nth) { const unsigned short id = (unsigned short)(kv[i] & KD_IDX_MASK); out_idx[i] = id; out_rank[id] = (unsigned short)i; }
     b.sync();
     KDP(6);
 #undef KDP

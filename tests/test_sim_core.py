@@ -52,6 +52,17 @@ def test_nth_element_restatement_matches_scipy(core):
         out = np.zeros(n, np.uint16)
         core.octa_simcore_kd_indices(pts.ctypes.data, n, out.ctypes.data)
         assert (out == cKDTree(pts).indices).all(), n
+    # round 3: the LDS elements are 32-bit words (18-bit quantised key << 14 | index); coordinates that share a quantisation bucket
+    # are compared on the doubles themselves. Clustered data -- distinct doubles 1e-10 to 1e-6 apart around a handful of
+    # centres -- sends most comparisons of the deep levels down that path
+    for n, k in ((300, 3), (5000, 7), (13312, 40)):
+        centres = rng.uniform(0.1, 0.9, (k, 3))
+        pts = centres[rng.integers(0, k, n)] + rng.uniform(-1, 1, (n, 3)) * 10.0 ** rng.uniform(-10, -6, (n, 1))
+        pts = np.ascontiguousarray(pts * np.array([1, 1, 0.0131]))
+        assert len(np.unique(pts[:, 0])) == n and len(np.unique(pts[:, 1])) == n
+        out = np.zeros(n, np.uint16)
+        core.octa_simcore_kd_indices(pts.ctypes.data, n, out.ctypes.data)
+        assert (out == cKDTree(pts).indices).all(), (n, k)
 
 
 def test_set_emulation_matches_cpython(core):

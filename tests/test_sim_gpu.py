@@ -157,6 +157,15 @@ def test_device_kd_order_matches_scipy(hip_lib_built):
         out = np.zeros(n, np.int32)
         _native.check(L.octa_sim_kat_kd_order(ctx, pts.ctypes.data, n, None, out.ctypes.data), "octa_sim_kat_kd_order")
         assert (out == cKDTree(pts).indices).all(), n
+    # clustered coordinates: most deep-level comparisons fall into one quantisation bucket of the packed LDS elements and are
+    # decided on the doubles fetched from the point list (sim_core.h kd_less_w)
+    for n, k in ((300, 3), (5000, 7), (13312, 40)):
+        centres = rng.uniform(0.1, 0.9, (k, 3))
+        pts = centres[rng.integers(0, k, n)] + rng.uniform(-1, 1, (n, 3)) * 10.0 ** rng.uniform(-10, -6, (n, 1))
+        pts = np.ascontiguousarray(pts * np.array([1, 1, 0.0131]))
+        out = np.zeros(n, np.int32)
+        _native.check(L.octa_sim_kat_kd_order(ctx, pts.ctypes.data, n, None, out.ctypes.data), "octa_sim_kat_kd_order")
+        assert (out == cKDTree(pts).indices).all(), (n, k)
 
 
 def test_lockstep_and_persistent_forms_agree(gh, golden, monkeypatch):
