@@ -275,7 +275,7 @@ def main():
     N_CUS = int(torch.cuda.get_device_properties(dev).multi_processor_count)
 
     from concurrent.futures import ThreadPoolExecutor
-    from octa_autosegmentation_amd import pipeline
+    from octa_autosegmentation_amd import _native, pipeline
     from octa_autosegmentation_amd.utils import sharding
     cfg = load_config()
     B = args.batch
@@ -428,7 +428,11 @@ def main():
         if traffic is not None:
             # the counter passes run `--inflight 1 --group 1` (one 128-sample launch at a time): scale to this run's samples per launch
             traffic = traffic * (args.steps * B / max(dom_n, 1)) / 128.0
-        bound_samples_s = N_CUS / (sample_ms * 1e-3)
+        geo = np.zeros(4, np.int32)
+        _native.check(_native.lib().octa_sim_geometry(N_CUS, geo.ctypes.data), "octa_sim_geometry")
+        wg_per_cu = int(geo[1])
+        # every CU holds wg_per_cu samples at a time; with all of them resident a sample takes sample_ms_loaded
+        bound_samples_s = N_CUS * wg_per_cu / (sample_ms_loaded * 1e-3)
         line = {
             "metric": "synthetic OCTA samples/sec (graph + 304x304 image + 1216x1216 label triples)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -446,12 +450,14 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": launch_ms, "launches": dom_n, "note": note,
                          "serial_depth": {"per_sample_device_ms": sample_ms, "per_sample_device_ms_with_4_launches_in_flight": sample_ms_loaded,
-                                          "solo_launch_ms": solo_launch_ms, "cus": N_CUS, "one_workgroup_per_cu": True,
+                                          "solo_launch_ms": solo_launch_ms, "cus": N_CUS, "workgroups_per_cu": wg_per_cu,
+                                          "threads_per_workgroup": int(geo[0]), "lds_bytes_per_workgroup": int(geo[2]),
                                           "bound_samples_per_s": bound_samples_s, "frac_of_bound": per_gpu / bound_samples_s,
-                                          "note": "a sample occupies one CU (160 KiB of LDS) for per_sample_device_ms (mean over the samples of ONE "
-                                                  "launch that has the GPU to itself; the slowest sample sets the launch time): CUs / that time is what "
-                                                  "the simulator could reach alone on the GPU; this dependency chain, not HBM, is the binding limit. With "
-                                                  "four launches in flight every sample runs slower (shared L2 / HBM / clocks)"},
+                                          "note": f"a sample occupies one of the {wg_per_cu} workgroup slots of a CU ({int(geo[2]) // 1024} KiB of LDS, "
+                                                  f"{int(geo[0])} threads at 256 registers) for per_sample_device_ms when its launch has the GPU to itself "
+                                                  "(one sample per CU) and for ..._with_4_launches_in_flight when every slot is taken (the co-resident "
+                                                  "sample shares the CU's issue slots, LDS and L1); CUs x slots / that time is what the simulator could "
+                                                  "reach alone on the GPU; this dependency chain, not HBM, is the binding limit"},
                          "rasteriser": raster},
             "kernel_ms_per_launch": {dom_name: launch_ms, "launches_per_step": dom_n / max(args.steps, 1),
                                      "cu_occupancy_weighted_ms_per_step": launch_ms * (dom_n / max(args.steps, 1)) / n_fly,

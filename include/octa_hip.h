@@ -487,6 +487,12 @@ int octa_sim_timing(octa_sim *sim, double *h_out8);
  *   OCTA_SIM_SPIN_SCANS: idle scans before the service thread sleeps between scans (4096; 256 when WORLD_SIZE > 1). */
 int octa_sim_service_stats(octa_sim *sim, double *h_out5);
 
+/* Launch geometry of the simulator kernels (build-time constants), h_out4 (four ints): [0] threads per workgroup, [1] workgroups
+ * (= samples) resident per CU, [2] bytes of LDS per workgroup, [3] workgroups per launch of the persistent kernel on a device
+ * with `num_cus` compute units (pass 0 for the 256 of an MI355X). One workgroup advances one sample at a time
+ * (greenhouse.py:57-137 runs one sample per worker process). */
+int octa_sim_geometry(int num_cus, int *h_out4);
+
 /* Final O2 / CO2 fields of one sample (host buffers, capacity in points); returns counts. */
 int octa_sim_fields(octa_sim *sim, int sample, double *h_oxy, int64_t cap_oxy, int64_t *n_oxy, double *h_co2,
                     int64_t cap_co2, int64_t *n_co2);

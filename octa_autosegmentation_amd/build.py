@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
     common = ["common.h", os.path.join("..", "..", "include", "octa_hip.h")]
     own = {"raster.hip": ["raster_core.h"], "sim.hip": ["sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h", "glibc_trig.h", "glibc_trig_tables.h"]}
     mt = lambda hs: max(os.path.getmtime(os.path.join(CSRC, h)) for h in hs)
-    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl", "-lz")]
+    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl", "-lz")] + os.environ.get("OCTA_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + ".o")

@@ -25,9 +25,10 @@ using namespace octa_simk;
 
 namespace {
 
-constexpr int SIM_THREADS = 512;
+constexpr int SIM_THREADS = SIM_THREADS_PER_WG;   // 256: 4 waves, one per SIMD -- at 256 VGPRs per lane two such workgroups fill a CU's register files
+constexpr int SIM_WG_PER_CU = 2;       // 2 x 80 KiB of LDS: while one sample is in a single-wave ordered pass the other's parallel phases use the CU
 constexpr size_t SIM_LDS = SIM_LDS_BYTES;
-static_assert(2048 + (size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES <= SIM_LDS && SIM_LDS <= 160 * 1024, "LDS budget");
+static_assert(2048 + (size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES <= SIM_LDS && SIM_WG_PER_CU * SIM_LDS <= 160 * 1024, "LDS budget");
 static_assert((624 + 1248) * 4 <= SEQ_SIDE_LDS, "the Mersenne-Twister state and queue of the candidate stream fit the side-job LDS");
 static_assert(SIM_THREADS == 64 * KD_WAVES, "kd mailboxes are sized for KD_WAVES waves");
 constexpr int REQ_CAP = 8192;
@@ -436,12 +437,12 @@ __device__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s, c
     b.sync();
 }
 
-// Work-queue form: the launch has at most one workgroup per CU (160 KiB of LDS each); a workgroup takes the next sample of the
+// Work-queue form: the launch has at most SIM_WG_PER_CU workgroups per CU (80 KiB of LDS each); a workgroup takes the next sample of the
 // batch from a device counter, runs all of its iterations, and comes back for another. Samples differ by +-10 % in run time
 // and workgroups that park leave early: with one workgroup PER SAMPLE the CUs waited for the hardware dispatcher to place the
 // next launch's workgroups (measured: 76 % of the CU time used with 2-12 launches in flight, whatever their size); resident
 // workgroups that refill themselves only leave the CU idle at the very end of a launch.
-__global__ void __launch_bounds__(SIM_THREADS)
+__global__ void __launch_bounds__(SIM_THREADS, SIM_WG_PER_CU * SIM_THREADS / 256)      // HIP's second argument = waves per SIMD: 2 at 256 threads (<= 256 registers per lane)
 sim_persistent_kernel(BatchPtrs B, HostMail M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
@@ -475,7 +476,7 @@ struct octa_sim {
     double park_ms = 20.0;          // OCTA_SIM_PARK_MS: a workgroup that has waited this long for its answer parks (0: never). Normal answers
                                     // take tens of microseconds; 3 ms (until the end of round 2) also parked workgroups whenever a busy host
                                     // descheduled the service thread for a few milliseconds, and a park costs a drain + relaunch
-    int grid_cap = 256;             // workgroups per launch of the persistent kernel (one per CU; OCTA_SIM_GRID overrides)
+    int grid_cap = 512;             // workgroups per launch of the persistent kernel (SIM_WG_PER_CU per CU; OCTA_SIM_GRID overrides)
     int test_stall_ms = 0;          // OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once with a ticket pending
     long spin_scans = 4096;         // idle mailbox scans before the service thread starts sleeping 20 us between scans
     double diag_max_gap_ms = 0, diag_max_bif_ms = 0;
@@ -590,7 +591,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
         if (const char *e = getenv("OCTA_SIM_MAIL_TIMEOUT_MS")) { double v = atof(e); if (v >= 1.0) S->mail_timeout_ms = v; }
         if (const char *e = getenv("OCTA_SIM_TEST_HOST_STALL_MS")) S->test_stall_ms = atoi(e);
         if (const char *e = getenv("OCTA_SIM_PARK_MS")) { double v = atof(e); if (v >= 0.0) S->park_ms = v; }
-        S->grid_cap = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        S->grid_cap = SIM_WG_PER_CU * (ctx->num_cus > 0 ? ctx->num_cus : 256);
         if (const char *e = getenv("OCTA_SIM_GRID")) { int v = atoi(e); if (v >= 1) S->grid_cap = v; }
         // several ranks per host (one service thread per step in flight and rank): give the cores back sooner
         if (const char *e = getenv("WORLD_SIZE")) { if (atoi(e) > 1) S->spin_scans = 256; }
@@ -1041,6 +1042,12 @@ extern "C" int octa_sim_service_stats(octa_sim *S, double *h_out4) {
     if (!S || !S->ran || !h_out4) { octa::set_error("octa_sim_service_stats: run the simulation first"); return -2; }
     h_out4[0] = (double)S->diag_tickets; h_out4[1] = S->diag_max_gap_ms; h_out4[2] = (double)S->diag_relaunches; h_out4[3] = (double)S->diag_parked;
     h_out4[4] = S->diag_max_bif_ms;
+    return 0;
+}
+
+extern "C" int octa_sim_geometry(int num_cus, int *h_out4) {
+    if (!h_out4) { octa::set_error("octa_sim_geometry: null output"); return -2; }
+    h_out4[0] = SIM_THREADS; h_out4[1] = SIM_WG_PER_CU; h_out4[2] = (int)SIM_LDS; h_out4[3] = SIM_WG_PER_CU * (num_cus > 0 ? num_cus : 256);
     return 0;
 }
 

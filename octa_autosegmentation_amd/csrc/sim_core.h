@@ -48,10 +48,14 @@ constexpr int ACCCAP = 2048;   // accepted sinks per iteration
 constexpr int KD_RANGES = 784;  // ranges per kd level (> OCAP / 17: a range that is split further holds at least 17 points)
 constexpr int KD_MAILBOX_OFF = OCAP * 4 + ((KD_RANGES * 9 + 15) / 16) * 16;   // LDS offset (after user()) of the swap mailbox / box table
 constexpr int KD_TEAM_MIN = 192;   // ranges at least this long get a whole wave, shorter ones 16 lanes
-constexpr int KD_WAVES = 8;                                    // waves per workgroup
+#ifndef OCTA_SIM_THREADS
+#define OCTA_SIM_THREADS 256
+#endif
+constexpr int SIM_THREADS_PER_WG = OCTA_SIM_THREADS;           // threads per simulator workgroup (build-time choice, see sim.hip)
+constexpr int KD_WAVES = SIM_THREADS_PER_WG / 64;              // waves per workgroup
 constexpr int KD_MAILBOX_BYTES = (OCAP / 2 + 64) * 2;          // one u16 slot per possible swap: ranges are disjoint
-constexpr int SIM_LDS_BYTES = 160 * 1024;  // dynamic LDS of the simulator kernels (one workgroup per CU)
-constexpr int GRID_MAX = 128;   // uniform-grid cells per axis (x, y); the thin z extent is not binned
+constexpr int SIM_LDS_BYTES = 80 * 1024;   // dynamic LDS of the simulator kernels: half a CU's 160 KiB, so TWO workgroups (two samples) share a CU
+constexpr int GRID_MAX = 112;   // uniform-grid cells per axis (x, y); the thin z extent is not binned (cell ends int[112^2 + 1] + ids u16[GRID_N] = 77 KiB)
 
 enum ErrBits { ERR_NODE_CAP = 1, ERR_OXY_CAP = 2, ERR_CO2_CAP = 4, ERR_GROUP_CAP = 8, ERR_PAIR_CAP = 16, ERR_SET_CAP = 32,
                ERR_PY_CAP = 64, ERR_KEPT_CAP = 128, ERR_REQ_CAP = 256, ERR_ACC_CAP = 512, ERR_MISSING_BIF = 1024 };
@@ -1040,12 +1044,15 @@ OCTA_HD inline void dirty_insert(DirtyList &D, int g) {
 
 // State of the ordered pass that lives in LDS / registers instead of HBM.
 struct SeqLds {
-    double *rad;               // [NCAP] radii of the forest
-    unsigned short *par;       // [NCAP] parent id, 0xffff = none
-    const double *log_tab;     // glibc pow tables (gpow.h)
+    double *rad;               // [NCAP] radii of the forest: the HBM array itself (L2-resident during the pass; round 2 kept an LDS copy)
+    unsigned short *par;       // [NCAP] parent id, 0xffff = none (LDS)
+    const double *log_tab;     // glibc pow tables (gpow.h) (LDS)
     const uint64_t *exp_tab;
-    int *deferred;             // [NCAP / 32] bitmap: radius to be recomputed when the pass ends (2 KiB)
+    int *deferred;             // [NCAP / 32] bitmap: radius to be recomputed when the pass ends (2 KiB, LDS)
+    int *changed;              // [GCAP / 32] bitmap over this pass's groups: a walk rewrote the radius of the group's child (1 KiB, LDS)
 };
+OCTA_HD inline bool changed_get(const SeqLds &L, int g) { return ((unsigned)L.changed[g >> 5] >> (g & 31)) & 1u; }
+OCTA_HD inline void changed_set(const SeqLds &L, int g) { L.changed[g >> 5] |= (int)(1u << (g & 31)); }   // the ordered pass's wave only, all lanes alike
 OCTA_HD inline bool deferred_get(const SeqLds &L, int id) { return ((unsigned)L.deferred[id >> 5] >> (id & 31)) & 1u; }
 struct WalkRec { int nch, c0, c1, cg; double k; };
 OCTA_HD inline WalkRec walk_load(const SimArrays &A, int f, int id, bool want_cg) {
@@ -1170,9 +1177,12 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
                 done = j + 1;
                 rp_prev = rp;
                 const int cg = __builtin_amdgcn_readlane(r.cg, j);
-                if (D && (cg >> 14) == pass_tag && !((cg >> 13) & 1)) {
-                    int g2 = cg & 8191;
-                    if (g2 > cur_g) dirty_insert(*D, g2);
+                if ((cg >> 14) == pass_tag) {
+                    const int g2 = cg & 8191;
+                    if (g2 > cur_g) {
+                        changed_set(L, g2);
+                        if (D && !((cg >> 13) & 1)) dirty_insert(*D, g2);
+                    }
                 }
             }
             if (lane < done) rad[mine] = my_rp;
@@ -1216,9 +1226,12 @@ OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g,
         steps++;
         if (rad[id] == rp) return steps;
         rad[id] = rp;
-        if (D && (r.cg >> 14) == pass_tag && !((r.cg >> 13) & 1)) {
-            int g2 = r.cg & 8191;
-            if (g2 > cur_g) dirty_insert(*D, g2);
+        if ((r.cg >> 14) == pass_tag) {
+            const int g2 = r.cg & 8191;
+            if (g2 > cur_g) {
+                changed_set(L, g2);
+                if (D && !((r.cg >> 13) & 1)) dirty_insert(*D, g2);
+            }
         }
         id = par;
     }
@@ -1367,8 +1380,7 @@ OCTA_HD inline int seq_add_node(const SimArrays &A, int f, int &n_nodes, V3 p, d
     if (id >= NCAP) { atomic_or_int(&A.sc->err, ERR_NODE_CAP); return -1; }
     n_nodes = id + 1;
     st3(A.npos[f] + 3 * id, p);
-    A.nrad[f][id] = r; A.nkap[f][id] = kappa; A.npar[f][id] = parent;
-    L.rad[id] = r;
+    A.nrad[f][id] = r; A.nkap[f][id] = kappa; A.npar[f][id] = parent;   // L.rad IS A.nrad[f]
     L.par[id] = (unsigned short)parent;
     A.nch0[f][id] = -1; A.nch1[f][id] = -1; A.nnch[f][id] = 0; A.nact[f][id] = 1;
     if (parent_nch == 0) A.nch0[f][parent] = id; else if (parent_nch == 1) A.nch1[f][parent] = id;
@@ -1912,26 +1924,30 @@ template <class Side = NoSideJob>
 OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
                               const double *att, const double *bif_results /* [req][6] */, Side side = Side()) {
     SampleScalars *sc = A.sc;
-    // LDS for the duration of the pass: radii (NCAP f64) and parents (NCAP u16) of this forest, the pow tables
+    // LDS for the duration of the pass (44 KiB): parents (NCAP u16) of this forest, the pow tables, two bitmaps, the side job's area.
+    // The radii stay where they are, in HBM / L2 (round 3; an LDS copy of NCAP doubles alone is 112 KiB): the pass's wave reads a
+    // radius only inside a Murray walk (lane-parallel, one more round trip per 64 ancestors) and when an inter-node is re-speculated;
+    // "has this group's child radius changed since the speculation" is answered by the `changed` bitmap the walks keep.
     SeqLds L;
-    L.rad = reinterpret_cast<double *>(b.user());
-    L.par = reinterpret_cast<unsigned short *>(b.user() + (size_t)NCAP * 8);
-    double *ltab = reinterpret_cast<double *>(b.user() + (size_t)NCAP * 10);
+    L.rad = A.nrad[f];
+    L.par = reinterpret_cast<unsigned short *>(b.user());
+    double *ltab = reinterpret_cast<double *>(b.user() + (size_t)NCAP * 2);
     uint64_t *etab = reinterpret_cast<uint64_t *>(ltab + 384);
-    static_assert((size_t)NCAP * 10 + 384 * 8 + 256 * 8 + 2048 + SEQ_SIDE_LDS + 2048 <= (size_t)SIM_LDS_BYTES, "ordered-pass LDS layout");
+    static_assert((size_t)NCAP * 2 + 384 * 8 + 256 * 8 + 2048 + 1024 + SEQ_SIDE_LDS + 2048 <= (size_t)SIM_LDS_BYTES, "ordered-pass LDS layout");
     L.log_tab = ltab; L.exp_tab = etab;
     L.deferred = reinterpret_cast<int *>(etab + 256);
     static_assert(NCAP / 8 <= 2048, "deferred bitmap");
-    unsigned char *side_lds = reinterpret_cast<unsigned char *>(L.deferred) + 2048;
+    L.changed = L.deferred + 512;
+    static_assert(GCAP / 8 <= 1024, "changed bitmap");
+    unsigned char *side_lds = reinterpret_cast<unsigned char *>(L.changed) + 1024;
     const int n_before = sc->n_nodes[f];
     for (int i = b.tid; i < n_before; i += b.nth) {
-        L.rad[i] = A.nrad[f][i];
         int p = A.npar[f][i];
         L.par[i] = p < 0 ? (unsigned short)0xffffu : (unsigned short)p;
     }
     for (int i = b.tid; i < 384; i += b.nth) ltab[i] = octa_gpow::LOG_TAB[i];
     for (int i = b.tid; i < 256; i += b.nth) etab[i] = octa_gpow::EXP_TAB[i];
-    for (int i = b.tid; i < 512; i += b.nth) L.deferred[i] = 0;
+    for (int i = b.tid; i < 512 + 256; i += b.nth) L.deferred[i] = 0;      // both bitmaps
     if (b.tid == 0) b.coll()[91] = 0;
     b.sync();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2007,7 +2023,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                     seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 0, P.kappa, L);
                 }
             } else {
-                if (L.rad[R.child] != R.r1_used) {
+                if (changed_get(L, g)) {      // a walk of this pass rewrote the child's radius (every rewrite changes it: the walk stops at old == new)
                     SEQT(1, eval_inter(G, g, R));
                     respec++;
                 }
@@ -2050,8 +2066,6 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
         const int rounds = murray_flush(b, A, f, L, b.coll()[91]);
         if (b.tid == 0) { sc->kdprof[7] += OCTA_FLUSH_T0() - t0; sc->flush_rounds += rounds; }
     }
-    // radii changed by Murray go back to HBM (new nodes were written through)
-    for (int i = b.tid; i < n_before; i += b.nth) A.nrad[f][i] = L.rad[i];
     b.sync();
 }
 
@@ -2059,7 +2073,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
 // the front, so the list is rewritten tile by tile -- a tile = the contiguous chunks of a group of threads; its kept points are
 // packed into LDS (each thread at its scanned offset), then copied to their final place with coalesced stores. One read of the
 // list, one write of the kept points that moved; no staging copy in HBM. `stage` is unused (kept for the callers' signature).
-constexpr int COMPACT_TILE = 6144;     // points per LDS tile (144 KiB of the user area)
+constexpr int COMPACT_TILE = 3072;     // points per LDS tile (72 KiB of the user area)
 OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsigned char *removed, double *stage) {
     (void)stage;
     if (b.nth == 1) {                                                 // host build: one thread, a forward copy is in place already
@@ -2186,21 +2200,26 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
     // Usual case (<= LSET_PAIRS hits): the insert stream (sink, hash) is compacted into LDS in parallel, the
     // open-addressing table lives in LDS too (a table never exceeds 8 x its entries), one thread replays the
     // insertions, and the occupied slots are read out in slot order by the whole block.
-    constexpr int LSET_PAIRS = 512, LSET_CAP = 8192;
-    if (n_pairs <= LSET_PAIRS && n_pairs <= b.nth) {
+    constexpr int LSET_PAIRS = 512, LSET_CAP = 4096;     // <= 512 keys: the table never exceeds 2048 slots (+ as many for the resize staging)
+    if (n_pairs <= LSET_PAIRS) {
         set_in_lds = true;
         unsigned long long *t_hash = reinterpret_cast<unsigned long long *>(b.user());        // [LSET_CAP]
         int *t_key = reinterpret_cast<int *>(t_hash + LSET_CAP);                               // [LSET_CAP]
         unsigned long long *in_hash = reinterpret_cast<unsigned long long *>(t_key + LSET_CAP);  // [LSET_PAIRS]
         int *in_key = reinterpret_cast<int *>(in_hash + LSET_PAIRS);                           // [LSET_PAIRS]
-        int o = -1, take = 0;
-        if (b.tid < n_pairs) {
-            o = (int)A.kd_idx[A.pairs[b.tid] & 16383u];
-            take = A.ven_near[o] ? 0 : 1;
+        int n_ins = 0;
+        for (int p0 = 0; p0 < n_pairs; p0 += b.nth) {          // ordered compaction of the insert stream, b.nth pairs per round
+            const int i = p0 + b.tid;
+            int o = -1, take = 0;
+            if (i < n_pairs) {
+                o = (int)A.kd_idx[A.pairs[i] & 16383u];
+                take = A.ven_near[o] ? 0 : 1;
+            }
+            int ex;
+            const int tot = blk_scan(b, take, &ex);
+            if (take) { in_key[n_ins + ex] = o; in_hash[n_ins + ex] = A.hashes[o]; }
+            n_ins += tot;
         }
-        int ex;
-        const int n_ins = blk_scan(b, take, &ex);
-        if (take) { in_key[ex] = o; in_hash[ex] = A.hashes[o]; }
         b.sync();
         int *ctl2 = b.coll() + 100;
         if (b.tid < 64) {                       // the first wave replays the insertions, its lanes share the resizes' bulk loops
