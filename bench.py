@@ -60,6 +60,57 @@ def pmc_traffic_per_launch(kernel_name):
     return None, None
 
 
+def pmc_child(batch):
+    """Hidden mode (`bench.py --pmc-child`): one warm-up and one measured 128-sample launch of the simulator with the GPU to itself;
+    run under `rocprofv3 --pmc <counter>` by pmc_traffic_live()."""
+    import torch
+    from octa_autosegmentation_amd.utils import sharding
+    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
+    torch.cuda.set_device(0)
+    sim = greenhouse.BatchSimulator(load_config(), batch)
+    for i in range(2):
+        res = sim.run(sharding.rank_seeds(0, 800 + i, batch))
+        assert int(res.stats[:, 0].max()) == 0
+    sim.close()
+
+
+def pmc_traffic_live(kernel_name, batch):
+    """HBM-side bytes per launch of `kernel_name`, measured IN THIS RUN when rocprofv3 is on PATH: one separate counter pass per
+    counter (FETCH_SIZE, WRITE_SIZE; --pmc alone, no tracing -- MI355X_MICROARCH.md's recipe) over `bench.py --pmc-child` (two
+    launches of one `batch`-sample batch). Same correction as the file-based figure: 2 x FETCH_SIZE + WRITE_SIZE, counters in KB.
+    Returns (bytes per launch, description) or (None, reason)."""
+    import csv
+    import glob
+    import subprocess
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    kb = {}
+    tmp = tempfile.mkdtemp(prefix="octa_pmc_", dir="/tmp")
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, c)
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([exe, "--pmc", c, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+                                "--batch", str(batch)], cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {c} failed (rc {r.returncode}): {r.stdout[-300:]}"
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == c and kernel_name in row.get("Kernel_Name", ""):
+                        tot += float(row["Counter_Value"]); n += 1
+            if n == 0:
+                return None, f"no {c} rows for {kernel_name}"
+            kb[c] = tot / n
+        return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
+                                                                      f"2 launches of {batch} samples each, GPU otherwise idle)")
+    except Exception as e:  # noqa: BLE001 -- the counters are a report, never a reason to lose the bench line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def load_config():
     from octa_autosegmentation_amd.utils import configs
     return configs.load_generator_config()
@@ -81,8 +132,16 @@ def cpu_baseline(cfg):
     all cores at once (the reference's own parallelism: one sample per pool worker, generate_vessel_graph.py:112-129), and the
     single-core figure. Bounded: one wave of samples (about 5-10 s) + one more sample."""
     from multiprocessing import get_context
-    cores = os.cpu_count() or 1
-    workers = min(cores, 64)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # one worker per visible core (BASELINE.md section 3), bounded only by memory: a spawned worker (numpy + the oracle's tables and
+    # buffers) is budgeted at 1 GiB of MemAvailable so that a small box is not driven out of memory
+    avail_gb = cores
+    try:
+        with open("/proc/meminfo") as f:
+            avail_gb = next(int(line.split()[1]) for line in f if line.startswith("MemAvailable")) // (1024 * 1024)
+    except Exception:  # noqa: BLE001
+        pass
+    workers = max(1, min(cores, int(avail_gb * 0.8)))
     t0 = time.time()
     _oracle_sample((cfg, 900))
     single = 1.0 / (time.time() - t0)
@@ -107,13 +166,23 @@ def cpu_unet_step():
     x, y = torch.rand(1, 1, 1216, 1216), (torch.rand(1, 1, 1216, 1216) > 0.8).float()
     from octa_autosegmentation_amd.models.losses import DiceBCELoss
     loss_f = DiceBCELoss(True)
+    def step():
+        opt.zero_grad()
+        loss_f(net(x), y).backward()
+        opt.step()
+
     t0 = time.time()
-    opt.zero_grad()
-    loss_f(net(x), y).backward()
-    opt.step()
-    dt = time.time() - t0
+    step()                                   # warm-up: first-call overheads (thread pools, oneDNN primitive creation)
+    cold = time.time() - t0
+    times = []
+    for _ in range(2):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    dt = sum(times) / len(times)
     return {"value": 1.0 / dt, "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "plain torch fp32 on the CPU device",
-            "sample": "one DynUNet-S training step, B=1, 1x1216x1216 (no warm-up: includes first-call overheads)"}
+            "cold_first_step_s": cold, "step_s": times,
+            "sample": "DynUNet-S training steps, B=1, 1x1216x1216: one warm-up step, then the mean of two timed steps"}
 
 
 def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4):
@@ -252,11 +321,16 @@ def main():
     ap.add_argument("--group", type=int, default=1, help="steps (batches) simulated by one launch of the persistent kernel (measured: 4 steps per "
                     "launch with 3 launches in flight gains 3.5 %% at --steps 20 and loses as much at --steps 8; one step per launch is the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 counter passes (roofline.traffic then comes from the committed file)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-train", action="store_true", help="skip the secondary U-Net training measurement")
     ap.add_argument("--train-batch", type=int, default=4)
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the on-the-fly generation + training measurement")
     ap.add_argument("--no-files", action="store_true", help="skip the on-disk triples leg")
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child(args.batch)
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -424,10 +498,19 @@ def main():
             note = "lock-step form: 250 dependent iterations x 2 launches; latency-bound, see serial_depth"
         launch_ms = dom_ms / max(dom_n, 1)
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic_per_launch(dom_name)
-        if traffic is not None:
-            # the counter passes run `--inflight 1 --group 1` (one 128-sample launch at a time): scale to this run's samples per launch
-            traffic = traffic * (args.steps * B / max(dom_n, 1)) / 128.0
+        traffic = None
+        if world == 1 and not args.no_pmc and la == 0:
+            traffic, traffic_src = pmc_traffic_live(dom_name, B)          # per launch of B samples
+            if traffic is not None:
+                traffic = traffic * (args.steps * B / max(dom_n, 1)) / B
+            else:
+                print(f"[bench] live counter passes unavailable ({traffic_src}); using the committed summary", file=sys.stderr)
+        if traffic is None:
+            traffic, traffic_src = pmc_traffic_per_launch(dom_name)
+            if traffic is not None:
+                # the committed counter passes ran `--inflight 1 --group 1` (one 128-sample launch at a time): scale to this run's samples per launch
+                traffic = traffic * (args.steps * B / max(dom_n, 1)) / 128.0
+                traffic_src = f"NOT measured in this run: committed file {traffic_src}"
         geo = np.zeros(4, np.int32)
         _native.check(_native.lib().octa_sim_geometry(N_CUS, geo.ctypes.data), "octa_sim_geometry")
         wg_per_cu = int(geo[1])
@@ -446,7 +529,7 @@ def main():
                       "csrc/glibc_trig.h) on the validated full-length seeds (profiles/r02_validate_final.log)",
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, {traffic_src})",
+                         "traffic_unit": f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE; {traffic_src})",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": launch_ms, "launches": dom_n, "note": note,
                          "serial_depth": {"per_sample_device_ms": sample_ms, "per_sample_device_ms_with_4_launches_in_flight": sample_ms_loaded,
