@@ -280,7 +280,7 @@ def files_leg(gen, stream, seeds, threads=None):
         shutil.rmtree(out_root, ignore_errors=True)
 
 
-def train_cli_leg(n_graphs=64, epochs=4):
+def train_cli_leg(n_graphs=128, epochs=4):
     """BASELINE configs[2] through the reference's entry point: `train.py --config_file configs/config_ves_seg-S.yml` on freshly
     generated full-length graphs (the reference's 500 provided pairs are not on the GPU box): graph CSV -> loader (parse, two
     rasterisations per sample, augmentation) -> DynUNet-S step at 1216^2. Reports the last epoch's images per second."""

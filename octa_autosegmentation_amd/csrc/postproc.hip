@@ -72,14 +72,21 @@ cc_merge_kernel(int *__restrict__ L, int H, int W, int B, int conn8) {
 
 __global__ void __launch_bounds__(256)
 cc_count_kernel(const int *__restrict__ L, int *__restrict__ root, int *__restrict__ cnt, long n_total) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_total) return;
+    const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = i0 < n_total ? i0 : n_total - 1;      // every lane stays for the ballots; the tail lanes hold no pixel
     int r = -1;
-    if (L[i] >= 0) {
-        r = cc_root(L, (int)i);
-        atomicAdd(&cnt[r], 1);
+    if (i0 < n_total && L[i] >= 0) r = cc_root(L, (int)i);
+    if (i0 < n_total) root[i] = r;
+    // members are counted per wave and root: the lanes that share the first pending lane's root add their number with ONE atomic
+    // (a vessel mask is a few large components: one atomic per pixel serialised ~0.6 M adds on a handful of addresses, 1 ms at 1216^2)
+    unsigned long long pending = __ballot(r >= 0);
+    while (pending) {
+        const int leader = (int)__ffsll((long long)pending) - 1;
+        const int r0 = __shfl(r, leader, 64);
+        const unsigned long long same = __ballot(r == r0) & pending;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&cnt[r0], (int)__popcll(same));
+        pending &= ~same;
     }
-    root[i] = r;
 }
 
 __global__ void __launch_bounds__(256)

@@ -87,20 +87,42 @@ class FusedGraphSegBatches:
         self.load = aug_config[0]
         self.aug = GpuSegAugmentation(aug_config, seed=seed)
         self.dtype = dtype
+        # Without dropout the raster of a graph file at a given resolution / radius window is the same in every epoch: it is rendered
+        # once and kept in HBM (uint8: 0.09 MB per 304^2 image + 1.48 MB per 1216^2 label = 0.8 GB for the reference's 500 training
+        # pairs, of 288 GB) -- from the second epoch on a mini-batch costs the augmentation kernels only. OCTA_RASTER_CACHE_GB bounds
+        # it (default 16; 0 disables). The reference re-renders every sample with matplotlib in every epoch (0.6 s per sample).
+        self.cache = {}
+        self.cache_bytes = 0
+        self.cache_cap = int(float(os.environ.get("OCTA_RASTER_CACHE_GB", "16")) * (1 << 30))
+
+    def _render(self, items, i, key):
+        """uint8 [B, h, w]: rasters of the mini-batch's graphs for key i, from the cache or from ONE launch sequence over the misses."""
+        from ..vessel_graph_generation import tree2img
+        from .data_transforms import load_graph_cached
+        res, lo = self.load["image_resolutions"][i], float(self.load["min_radius"][i])
+        graphs = [load_graph_cached(it[key]) for it in items]
+        keys = [(it[key], len(e), int(res[0]), int(res[1]), lo, int(self.load.get("MIP_axis", 2))) for it, (e, _) in zip(items, graphs)]
+        miss = [j for j, k in enumerate(keys) if k not in self.cache]
+        fresh = {}
+        if miss:
+            off = np.concatenate(([0], np.cumsum([len(graphs[j][0]) for j in miss]))).astype(np.int64)
+            d_edges = torch.cat([graphs[j][1] for j in miss], dim=0) if len(miss) > 1 else graphs[miss[0]][1]
+            imgs = tree2img.rasterize_edges_device(d_edges, off, res, self.load.get("MIP_axis", 2), min_radius=lo, max_radius=1.0)
+            for n, j in enumerate(miss):
+                fresh[j] = imgs[n]
+                nbytes = imgs[n].numel()
+                if self.cache_bytes + nbytes <= self.cache_cap:
+                    self.cache[keys[j]] = imgs[n].clone()      # own storage: the batch tensor is freed with the mini-batch
+                    self.cache_bytes += nbytes
+            if len(miss) == len(items):
+                return imgs
+        return torch.stack([fresh[j] if j in fresh else self.cache[k] for j, k in enumerate(keys)])
 
     def __call__(self, items):
         """items: list of {image: csv path, label: csv path, *_path}. -> collated batch dict on the device."""
-        from ..vessel_graph_generation import tree2img
         from .data_transforms import advance_python_random, load_graph_cached
         out = {k: [it[k] for it in items] for k in items[0] if k.endswith("_path")}
-        rendered = {}
-        for i, key in enumerate(("image", "label")):
-            graphs = [load_graph_cached(it[key]) for it in items]
-            lo = float(self.load["min_radius"][i])
-            off = np.concatenate(([0], np.cumsum([len(e) for e, _ in graphs]))).astype(np.int64)
-            d_edges = torch.cat([d for _, d in graphs], dim=0) if len(graphs) > 1 else graphs[0][1]
-            rendered[key] = tree2img.rasterize_edges_device(d_edges, off, self.load["image_resolutions"][i], self.load.get("MIP_axis", 2),
-                                                            min_radius=lo, max_radius=1.0)
+        rendered = {key: self._render(items, i, key) for i, key in enumerate(("image", "label"))}
         draws = 0                          # random() draws of tree2img.py:62,78 over the mini-batch: per sample one for the dropout probability
         for it in items:                   # (first key) and one per in-range edge of either key; only their total moves the stream
             for i, key in enumerate(("image", "label")):
@@ -161,43 +183,75 @@ class DeviceLoader:
                 idx = order[i:i + self.batch_size]
                 yield collate(self.dataset.get_batch(idx) if hasattr(self.dataset, "get_batch") else [self.dataset[j] for j in idx])
 
-    def __iter__(self):
-        if self.num_workers <= 0 or not torch.cuda.is_available():
-            yield from self._batches()
-            return
-        q = queue.Queue(maxsize=self.prefetch)
+    _END = object()
+
+    def _start_producer(self):
+        """ONE producer thread for the life of the loader: it prepares epoch after epoch on its own HIP stream, at most `prefetch`
+        mini-batches ahead, so the first batches of the next epoch are ready while the training loop still drains the current one
+        and does its end-of-epoch work (the reference's DataLoader restarts its workers' prefetch at every epoch). Every random
+        decision of the loader is taken in this thread, in the same order as an inline loader would take it."""
+        self._q = queue.Queue(maxsize=self.prefetch)
+        self._stop = threading.Event()
         dev = torch.cuda.current_device()
         stream = torch.cuda.Stream()
-        stop = threading.Event()
-        END = object()
+        q, stop = self._q, self._stop
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
                 torch.cuda.set_device(dev)
                 with torch.cuda.stream(stream):
-                    for b in self._batches():
-                        ev = torch.cuda.Event()
-                        ev.record(stream)
-                        while not stop.is_set():
-                            try:
-                                q.put((b, ev), timeout=0.1)
-                                break
-                            except queue.Full:
-                                pass
-                        if stop.is_set():
+                    while not stop.is_set():
+                        for b in self._batches():
+                            ev = torch.cuda.Event()
+                            ev.record(stream)
+                            if not put((b, ev)):
+                                return
+                        if not put(DeviceLoader._END):
                             return
-                q.put(END)
             except BaseException as e:  # noqa: BLE001 -- re-raised by the consumer
-                q.put(e)
+                put(e)
 
-        th = threading.Thread(target=produce, name="octa-loader")
-        th.start()
+        self._thread = threading.Thread(target=produce, name="octa-loader", daemon=True)
+        self._thread.start()
+
+    def close(self):
+        """Stop the producer thread (idempotent). Mini-batches it prepared ahead are dropped."""
+        th = getattr(self, "_thread", None)
+        if th is not None:
+            self._stop.set()
+            th.join()
+            self._thread = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __iter__(self):
+        if self.num_workers <= 0 or not torch.cuda.is_available():
+            yield from self._batches()
+            return
+        if getattr(self, "_thread", None) is None:
+            self._start_producer()
+        complete = False
         try:
             while True:
-                item = q.get()
-                if item is END:
+                item = self._q.get()
+                if item is DeviceLoader._END:
+                    complete = True
                     break
                 if isinstance(item, BaseException):
+                    self._thread = None
                     raise RuntimeError("the loader thread failed") from item
                 b, ev = item
                 cur = torch.cuda.current_stream()
@@ -207,8 +261,8 @@ class DeviceLoader:
                         v.record_stream(cur)
                 yield b
         finally:
-            stop.set()
-            th.join()
+            if not complete:          # the consumer left mid-epoch (break / exception): the next __iter__ must start a fresh epoch
+                self.close()
 
 
 def get_dataset(config: dict, phase: str, batch_size=None, num_workers=None) -> DeviceLoader:
@@ -244,6 +298,9 @@ def get_dataset(config: dict, phase: str, batch_size=None, num_workers=None) -> 
         raise NotImplementedError(f"task {task} is outside the MI355X hot path")
     loader = DeviceLoader(data_set, batch_size=batch_size or config[phase].get("batch_size") or 1, shuffle=phase != Phase.TEST,
                           num_workers=1 if num_workers is None else num_workers)
+    # the permutation stream is the loader's own (seeded from General.seed and the phase): loaders prepare batches from their own
+    # threads, ahead of the training loop, and must not race for torch's global generator
+    loader.perm_generator = torch.Generator().manual_seed(int(config["General"].get("seed", 42)) + {"Train": 0, "Validation": 1, "Test": 2}.get(getattr(phase, "value", phase), 3))
     aug_config = config[phase]["data_augmentation"]
     if (isinstance(data_set, ListDataset) and FusedGraphSegBatches.applies(aug_config) and not config["General"].get("generic_loader")
             and all("blackdict" not in it for it in data_set.items)):

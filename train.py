@@ -181,6 +181,9 @@ def train(args: argparse.Namespace, config: dict):
         if dist is not None:
             dist.barrier()
 
+    train_loader.close()
+    if val_loader is not None:
+        val_loader.close()
     print(f"Finished training after {str(datetime.timedelta(seconds=time.time() - total_start))}.", file=sys.stderr)
     if best_metric_epoch > -1:
         print(f"Best metric: {best_metric} at epoch: {best_metric_epoch}.", file=sys.stderr)
