@@ -249,6 +249,16 @@ int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const void *d_x2, i
 int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin,
                             int Cout, void *stream);
 
+/* Single-precision convolution on the matrix cores (v_mfma_f32_32x32x2_f32: fp32 operands, fp32 accumulation), NCHW: the
+ * convolutions of the reference's paths that run WITHOUT mixed precision -- test.py:79 / validate.py call model.inference outside
+ * torch.cuda.amp.autocast -- i.e. torch.nn.Conv2d / ConvTranspose2d of models/networks.py (DynUNet 3x3 stride 1 / 2, 1x1 head with
+ * bias, 2x2 stride-2 and 1x1 transposed convolutions) evaluated in fp32.
+ * d_x [N][Cin][H][W], d_wp the weights packed [Cin][K*K][cout_w] (output channel innermost, cout_w >= Cout), d_bias [Cout] or NULL,
+ * d_y [N][Cout][Ho*osc][Wo*osc]: osc = 1 dense output; osc = 2 writes only the pixels (2 oy + ooy, 2 ox + oox) -- one of the four
+ * 1x1 products of a 2x2 stride-2 transposed convolution. K / stride in {1/1, 3/1, 3/2}; zero padding `pad`. */
+int octa_conv2d_f32_nchw(octa_ctx *ctx, const float *d_x, const float *d_wp, const float *d_bias, float *d_y, int N, int Cin, int H, int W,
+                         int Cout, int cout_w, int K, int stride, int pad, int Ho, int Wo, int osc, int ooy, int oox, void *stream);
+
 /* 4x4 convolution, stride 1, zero padding `pad`, on the same DMA-staged MFMA kernel (KS = 4 instantiation): the inner
  * layers of the 70x70 PatchGAN (models/networks.py:445-500 NLayerDiscriminator: Conv2d(ndf*m, ndf*2m, 4, 1, 1)).
  * d_x [N][H][W][Cin] bf16, d_w [16][Cout][Cin] bf16 (tap 4r+s), d_y [N][H+2pad-3][W+2pad-3][Cout] bf16; Cin, Cout

@@ -1,0 +1,150 @@
+// conv_f32.hip -- single-precision convolution on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: fp32 operands, fp32
+// accumulation -- no bf16 / xf32 rounding anywhere), NCHW, for the paths of the reference that run WITHOUT mixed precision:
+//   * test.py:79 and validate.py (model.inference outside torch.cuda.amp.autocast): every convolution of DynUNet
+//     (models/networks.py:6 -> MONAI DynUNet: 3x3 stride 1 / 2, 2x2 stride-2 and 1x1 transposed, 1x1 head with bias);
+//   * `General.amp: false` forward passes that need no gradient.
+// north_star asks for segmentation logits within 1e-4 of the reference's fp32 CPU path: with exact fp32 products and fp32 sums the
+// only difference left is the summation order (tests/test_conv_f32_gpu.py: 1x1x1216x1216 DynUNet logits against the CPU modules).
+//
+// Implicit GEMM, D[co][pixel] += W[co][ci, tap] * X[ci][pixel + tap]: a 256-thread workgroup owns 32 * MB output channels x an
+// 8 x 32 output-pixel tile; a wave owns two tile rows (two 32-pixel N-blocks) x MB M-blocks. Per slice of KC = 8 input channels
+// the halo tile [KC][IH][IW] and the weight slice [KC][K*K][32 * MB] are staged in LDS (zero-filled outside the image / beyond Cin /
+// beyond Cout); an MFMA consumes two input channels of one tap: lane l supplies W[co = l % 32][ci + l / 32] and
+// X[ci + l / 32][pixel l % 32] (one ds_read_b32 each, conflict-free: consecutive lanes read consecutive words). The accumulator
+// fragment holds, per register, 32 consecutive pixels of one output channel, so the NCHW stores are 128-byte rows straight from
+// registers. A 2x2 stride-2 transposed convolution is four 1x1 launches with a scattered store (osc = 2: one output parity each).
+//
+// Roofline: MFMA-bound on paper (dense fp32 matrix peak 157 TFLOP/s, MI355X_MICROARCH.md); algorithmic HBM bytes = input + output
+// activations once (fp32) + weights. Measured figures: DESIGN.md section 4.2c'.
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int F_TH = 8, F_TW = 32, F_KC = 8, F_THREADS = 256;
+
+// X: [N][Cin][H][W]; Wp: [Cin][K*K][CoutW] (packed by the caller: output channel innermost); Y: [N][CoutY][Ho*osc][Wo*osc] written at
+// (oy * osc + ooy, ox * osc + oox). out(co, oy, ox) = bias[co] + sum_{ci, r, s} X(ci, oy * S + r - pad, ox * S + s - pad) * Wp[ci][r * K + s][co].
+template <int K, int S, int MB>
+__global__ void __launch_bounds__(F_THREADS)
+conv_f32_kernel(const float *__restrict__ X, const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ Y,
+                int Cin, int H, int W, int Cout, int CoutW, int Ho, int Wo, int pad, int tiles_x, int osc, int ooy, int oox) {
+    constexpr int IH = (F_TH - 1) * S + K, IW = (F_TW - 1) * S + K;
+    constexpr int IWP = IW | 1;                          // odd row pitch: the two half-waves (channels ci, ci + 1) start on different banks
+    constexpr int BM = 32 * MB, KK = K * K;
+    constexpr int IN_FLOATS = F_KC * IH * IWP, W_FLOATS = F_KC * KK * BM;
+    __shared__ float s_in[IN_FLOATS];
+    __shared__ float s_w[W_FLOATS];
+    const int tile = blockIdx.x, n = blockIdx.z, co0 = blockIdx.y * BM;
+    const int ty0 = (tile / tiles_x) * F_TH, tx0 = (tile % tiles_x) * F_TW;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = lane & 31, kg = lane >> 5;
+    const int iy0 = ty0 * S - pad, ix0 = tx0 * S - pad;
+    const float *img = X + (size_t)n * Cin * H * W;
+
+    f32x16 acc[2][MB];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < MB; b++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+
+    for (int c0 = 0; c0 < Cin; c0 += F_KC) {
+        __syncthreads();                                  // the previous slice has been consumed
+        for (int i = threadIdx.x; i < F_KC * IH * IW; i += F_THREADS) {
+            const int c = i / (IH * IW), rem = i % (IH * IW), hy = rem / IW, hx = rem % IW;
+            const int ci = c0 + c, yy = iy0 + hy, xx = ix0 + hx;
+            float v = 0.f;
+            if (ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[((size_t)ci * H + yy) * W + xx];
+            s_in[(c * IH + hy) * IWP + hx] = v;
+        }
+        for (int i = threadIdx.x; i < W_FLOATS; i += F_THREADS) {
+            const int c = i / (KK * BM), rem = i % (KK * BM), t = rem / BM, mm = rem % BM;
+            const int ci = c0 + c, co = co0 + mm;
+            s_w[i] = (ci < Cin && co < Cout) ? Wp[((size_t)ci * KK + t) * CoutW + co] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cp = 0; cp < F_KC; cp += 2) {
+            const int c = cp + kg;                        // this lane's input channel of the pair
+#pragma unroll
+            for (int r = 0; r < K; r++)
+#pragma unroll
+                for (int s = 0; s < K; s++) {
+                    float a[MB], b[2];
+#pragma unroll
+                    for (int mb = 0; mb < MB; mb++) a[mb] = s_w[(c * KK + r * K + s) * BM + mb * 32 + m];
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++) b[rr] = s_in[(c * IH + (2 * wv + rr) * S + r) * IWP + m * S + s];
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                        for (int mb = 0; mb < MB; mb++)
+                            acc[rr][mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[rr], acc[rr][mb], 0, 0, 0);
+                }
+        }
+    }
+    // D[co][pixel]: register k of lane (m, kg) holds output channel (k & 3) + 8 * (k >> 2) + 4 * kg of the M-block, pixel column m
+    const int Hy = Ho * osc, Wy = Wo * osc;
+    const int ox = tx0 + m;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int oy = ty0 + 2 * wv + rr;
+        if (oy >= Ho || ox >= Wo) continue;
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int co = co0 + mb * 32 + (k & 3) + 8 * (k >> 2) + 4 * kg;
+                if (co < Cout) {
+                    const float v = acc[rr][mb][k] + (bias ? bias[co] : 0.f);
+                    Y[(((size_t)n * Cout + co) * Hy + (oy * osc + ooy)) * Wy + ox * osc + oox] = v;
+                }
+            }
+    }
+}
+
+template <int K, int S, int MB>
+int launch_f32(const float *X, const float *Wp, const float *bias, float *Y, int N, int Cin, int H, int W, int Cout, int CoutW, int Ho, int Wo, int pad,
+               int osc, int ooy, int oox, hipStream_t stream) {
+    const int tiles_x = (Wo + F_TW - 1) / F_TW, tiles_y = (Ho + F_TH - 1) / F_TH;
+    dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((Cout + 32 * MB - 1) / (32 * MB)), (unsigned)N);
+    hipLaunchKernelGGL((conv_f32_kernel<K, S, MB>), grid, dim3(F_THREADS), 0, stream, X, Wp, bias, Y, Cin, H, W, Cout, CoutW, Ho, Wo, pad, tiles_x, osc, ooy, oox);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// Single-precision convolution, NCHW (see the file header). d_wp: weights packed as [Cin][K*K][cout_w] with cout_w >= Cout (a
+// view of a larger packed tensor may be passed: rows are cout_w apart); d_bias: [Cout] or NULL. K / stride in {1/1, 3/1, 3/2}.
+// The output tensor is [N][Cout][Ho * osc][Wo * osc]; osc = 1 writes it densely, osc = 2 writes the pixels of
+// parity (ooy, oox) only (one of the four 1x1 products of a 2x2 stride-2 transposed convolution).
+extern "C" int octa_conv2d_f32_nchw(octa_ctx *ctx, const float *d_x, const float *d_wp, const float *d_bias, float *d_y, int N, int Cin, int H, int W,
+                                    int Cout, int cout_w, int K, int stride, int pad, int Ho, int Wo, int osc, int ooy, int oox, void *stream_) {
+    if (!ctx || !d_x || !d_wp || !d_y || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cout_w < Cout || Ho <= 0 || Wo <= 0 || pad < 0) {
+        octa::set_error("octa_conv2d_f32_nchw: bad arguments");
+        return -2;
+    }
+    if ((osc != 1 && osc != 2) || ooy < 0 || ooy >= osc || oox < 0 || oox >= osc) { octa::set_error("octa_conv2d_f32_nchw: bad output scatter"); return -2; }
+    if ((long)(Ho - 1) * stride + K - pad > (long)H + pad || (long)(Wo - 1) * stride + K - pad > (long)W + pad) {
+        octa::set_error("octa_conv2d_f32_nchw: output size %dx%d reads beyond the padded input", Ho, Wo);
+        return -2;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const bool wide = Cout > 32;
+#define OCTA_F32_CASE(KK_, SS_)                                                                                                              \
+    if (K == KK_ && stride == SS_)                                                                                                           \
+        return wide ? launch_f32<KK_, SS_, 2>(d_x, d_wp, d_bias, d_y, N, Cin, H, W, Cout, cout_w, Ho, Wo, pad, osc, ooy, oox, stream)       \
+                    : launch_f32<KK_, SS_, 1>(d_x, d_wp, d_bias, d_y, N, Cin, H, W, Cout, cout_w, Ho, Wo, pad, osc, ooy, oox, stream);
+    OCTA_F32_CASE(1, 1)
+    OCTA_F32_CASE(3, 1)
+    OCTA_F32_CASE(3, 2)
+#undef OCTA_F32_CASE
+    octa::set_error("octa_conv2d_f32_nchw: kernel size %d with stride %d is not instantiated (1/1, 3/1, 3/2)", K, stride);
+    return -2;
+}

@@ -77,6 +77,8 @@ def invalidate_all_pack_plans(module):
         plan = getattr(m, "_octa_pack_plan", None)
         if plan is not None:
             plan.invalidate()
+    from . import conv_f32
+    conv_f32.invalidate_packs()
 
 
 def plan_for_module(module):

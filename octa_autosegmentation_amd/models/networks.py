@@ -27,6 +27,7 @@ FAST_CONVT = False  # measured slower than MIOpen at 1216^2 (65 vs 53 ms per ste
 # CUDA inputs run channels-last in bf16 through the hand-written MFMA convolution (csrc/conv.hip) and the NHWC
 # norm kernels; False = torch/MIOpen modules (the fp32 reference path of the parity tests)
 USE_MFMA_CONV = True
+USE_F32_MFMA = True      # fp32 forward passes that record no gradient run csrc/conv_f32.hip (exact-fp32 MFMA) instead of the vendor library
 # normalise-on-load (the normalised activations never go to HBM: models/mfma_conv.py) is implemented and tested but
 # measured SLOWER on MI355X (37.5 vs 31.9 ms per step): every output-channel block of a layer re-stages and
 # re-normalises the same input tile, which costs more VALU work than the two HBM passes it saves
@@ -52,6 +53,11 @@ class _Conv(nn.Module):
 
     def forward(self, x):
         c = self.conv
+        if USE_F32_MFMA and x.is_cuda and x.dtype == torch.float32:
+            # fp32 without gradients (test.py / validate.py, as the reference runs them: no autocast): exact-fp32 MFMA convolution
+            from . import conv_f32
+            if conv_f32.applies(c, x):
+                return conv_f32.forward(c, x)
         if (FAST_CONVT and isinstance(c, nn.ConvTranspose2d) and c.kernel_size == c.stride and c.kernel_size[0] == c.kernel_size[1]
                 and c.padding == (0, 0) and c.output_padding == (0, 0) and c.bias is None and c.groups == 1):
             # kernel == stride: every input pixel owns a disjoint k x k output patch, so the transposed conv is one

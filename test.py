@@ -50,6 +50,11 @@ def main(argv=None):
     model = define_model(config, phase=Phase.TEST)
     model.initialize_model_and_optimizer(None, init_weights, config, args, scaler, phase=Phase.TEST)
     model.eval()
+    # The reference's test.py evaluates in fp32 (no autocast, test.py:79). Segmentation networks do so here too: every DynUNet
+    # convolution runs the exact-fp32 MFMA kernel (csrc/conv_f32.hip; logits within 1e-4 of the CPU path, tests/test_conv_f32_gpu.py).
+    # The contrast-adaptation generator (`General.inference: G`) keeps bf16 autocast: its layers run on the bf16 MFMA kernels.
+    import contextlib
+    precision = model.autocast if config["General"].get("inference") in ("G", "generator") else contextlib.nullcontext
     written = []
     with torch.no_grad():
         for num_sample, test_mini_batch in enumerate(test_loader):
@@ -58,7 +63,7 @@ def main(argv=None):
             if input_key is None:
                 input_key = [k for k in test_mini_batch.keys() if not k.endswith("_path")][0]
             test_mini_batch["image"] = test_mini_batch.pop(input_key)
-            with model.autocast():
+            with precision():
                 outputs, _ = model.inference(test_mini_batch, post_transformations_test, device=device, phase=Phase.TEST)
             inference_mode = config["General"].get("inference") or "pred"
             image_name: str = test_mini_batch[f"{input_key}_path"][0].split("/")[-1]

@@ -40,8 +40,8 @@ def main(argv=None):
     model.eval()
     with torch.no_grad():
         for val_mini_batch in val_loader:
-            with model.autocast():
-                outputs, losses = model.inference(val_mini_batch, post_transformations_val, device=device, phase=Phase.VALIDATION)
+            # fp32 like the reference's validate.py (no autocast): DynUNet's convolutions on the exact-fp32 MFMA kernel (csrc/conv_f32.hip)
+            outputs, losses = model.inference(val_mini_batch, post_transformations_val, device=device, phase=Phase.VALIDATION)
             model.compute_metric(outputs, metrics)
     result = {k: float(str(round(v, 3))) for k, v in metrics.aggregate_and_reset(Phase.VALIDATION).items()}
     print(f"Metrics: {result}")
