@@ -369,6 +369,7 @@ def main():
         with torch.cuda.stream(streams[slot]):
             out = gens[nsteps][slot].generate(seeds)
             streams[slot].synchronize()
+        out["wall"]["t_done"] = time.time()
         return out
 
     pool = ThreadPoolExecutor(max_workers=n_fly)
@@ -396,6 +397,17 @@ def main():
     outs = run_steps(args.warmup, args.steps)
     barrier()
     dt = time.time() - t0
+    # where a slot's time goes (host clock, mean over the timed launches): simulator call (host init + kernel + download + BFS export),
+    # render enqueue, wait for the render kernels; `kernel` is the device time of the persistent kernel inside the simulator call
+    slot_cycle = None
+    if outs and "wall" in outs[0]:
+        w = [o["wall"] for o in outs]
+        slot_cycle = {"sim_call_ms": 1e3 * float(np.mean([x["sim_run_s"] for x in w])),
+                      "kernel_ms": float(np.mean([o["result"].timing["kernel_b_ms"] for o in outs])),
+                      "render_enqueue_ms": 1e3 * float(np.mean([x["render_enqueue_s"] for x in w])),
+                      "render_wait_ms": 1e3 * float(np.mean([x["t_done"] - x["t_start"] - x["sim_run_s"] - x["render_enqueue_s"] for x in w])),
+                      "launch_to_done_ms": 1e3 * float(np.mean([x["t_done"] - x["t_start"] for x in w]))}
+        print(f"[bench] slot cycle: {slot_cycle}", file=sys.stderr)
     ka = kb = 0.0
     la = lb = 0
     bif_ms = 0.0
@@ -418,10 +430,12 @@ def main():
     cu_time = None
     if w1 > w0:
         held = float(np.clip(np.minimum(sp[:, 1], w1) - np.maximum(sp[:, 0], w0), 0, None).sum())
-        cu_time = {"simulator_share": held / (N_CUS * (w1 - w0)), "span_ms_per_sample": float((sp[:, 1] - sp[:, 0]).mean() * 1e3),
+        geo_ = np.zeros(4, np.int32)
+        _native.check(_native.lib().octa_sim_geometry(N_CUS, geo_.ctypes.data), "octa_sim_geometry")
+        cu_time = {"simulator_share": held / (N_CUS * int(geo_[1]) * (w1 - w0)), "workgroup_slots": N_CUS * int(geo_[1]), "span_ms_per_sample": float((sp[:, 1] - sp[:, 0]).mean() * 1e3),
                    "window_s": float(w1 - w0),
-                   "note": "CU-seconds held by simulator workgroups / (CUs x window), one workgroup per CU; the remainder is the rasteriser's "
-                           "kernels (they need the same CUs) and dispatch gaps"}
+                   "note": "slot-seconds held by simulator workgroups / (CUs x workgroup slots per CU x window); the remainder is the rasteriser's "
+                           "kernels (they need CUs free of simulator workgroups) and dispatch gaps"}
 
     # ---- rasteriser alone (other slots idle): HIP events on the stream the kernels go to
     raster = None
@@ -547,6 +561,7 @@ def main():
                                      "note": f"a launch covers {G} steps and {n_fly} launches of up to {N_CUS} workgroups share the {N_CUS} CUs, so a launch "
                                              "outlasts ms_per_step; the weighted figure is the launch duration per step divided by the launches in flight"},
             "cu_time": cu_time,
+            "slot_cycle": slot_cycle,
             "host_bifurcation_callback_ms_per_step": bif_ms / args.steps,
             "mailbox_relaunches": relaunches,
         }

@@ -469,6 +469,12 @@ int octa_sim_edge_offsets(octa_sim *sim, int64_t *h_edge_off, int64_t *h_n_art);
  * tree -- the CSV row order of generate_vessel_graph.py:59-66. h_edges: host buffer. */
 int octa_sim_export_edges(octa_sim *sim, double *h_edges);
 
+/* The same edge list written on the DEVICE (round 3): d_edges [edge_off[B]][7] float64 in HBM, filled by one workgroup per
+ * (sample, forest) that walks the trees level by level (children in parent order, child 0 before child 1 -- anytree's level
+ * order, generate_vessel_graph.py:43-66) on `stream`. The rows equal octa_sim_export_edges' bit for bit; the list can go straight
+ * to octa_rasterize_2d without crossing PCIe. */
+int octa_sim_export_edges_device(octa_sim *sim, double *d_edges, void *stream);
+
 /* Per-sample statistics, h_stats[B][32] int64: error bits, random.uniform draws, Murray steps,
  * bifurcations, re-speculated inter-nodes, arterial nodes, venous nodes, FAZ radius bits, then 16
  * per-phase device timers (100 MHz ticks: 0 sample, 1 assign-art, 2 speculate-art, 3 ordered-art,

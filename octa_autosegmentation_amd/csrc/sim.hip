@@ -41,6 +41,7 @@ struct BatchPtrs {
     int *npar[2], *nch0[2], *nch1[2];
     unsigned char *nnch[2], *nact[2];
     double *oxy, *co2, *cand, *py_u;
+    unsigned *py_state;   // [B][625] CPython generator states behind the stump draws (input of py_uniform_kernel)
     int *nn, *first_att, *act_list;
     unsigned *sorted;
     int *gnode, *gstart, *gcount;
@@ -223,6 +224,34 @@ __device__ void gen_candidates_wave(unsigned *g_state /*[625]*/, const unsigned 
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < 624; i += 64) g_state[i] = g.st[i];
     if (lane == 0) g_state[624] = (unsigned)(624 - (g.avail - g.cur));
+}
+
+// CPython's random.uniform(0, 1) stream of every sample (greenhouse.py:191,289 draw from it in node order): PYCAP doubles per sample
+// from the generator state the host left behind the stump draws, one wave per sample (round 2 drew 4.2 M doubles per 128-sample batch
+// on the host and copied 34 MB). random.random() = (a >> 5, b >> 6) of two consecutive outputs, as numpy's next_double.
+__global__ void __launch_bounds__(64)
+py_uniform_kernel(const unsigned *__restrict__ py_state /* [B][625] */, double *__restrict__ py_u /* [B][cap] */, int cap) {
+    __shared__ unsigned lds[624 + 1248];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const unsigned *g_state = py_state + (size_t)s * 625;
+    double *out = py_u + (size_t)s * cap;
+    WaveMt g;
+    g.st = lds; g.ob = lds + 624; g.lane = lane;
+    for (int i = lane; i < 624; i += 64) g.st[i] = g_state[i];
+    const int sidx = (int)g_state[624];
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 624 - sidx; i += 64) g.ob[i] = WaveMt::temper(g.st[sidx + i]);
+    g.cur = 0; g.avail = 624 - sidx;
+    __builtin_amdgcn_wave_barrier();
+    for (int j0 = 0; j0 < cap; j0 += 64) {
+        const int m = cap - j0 < 64 ? cap - j0 : 64;
+        g.ensure(2 * m);
+        if (lane < m) {
+            const unsigned a = g.ob[g.cur + 2 * lane] >> 5, bb = g.ob[g.cur + 2 * lane + 1] >> 6;
+            out[j0 + lane] = (a * 67108864.0 + bb) / 9007199254740992.0;
+        }
+        g.cur += 2 * m;
+    }
 }
 
 // ---- iteration kernels
@@ -457,6 +486,59 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
     }
 }
 
+// Edge list of every sample ON THE DEVICE (round 3), in the reference's CSV row order (generate_vessel_graph.py:43-66: per forest,
+// per tree, anytree's level order with the root excluded; rows = node xyz, parent xyz, radius). One workgroup per (sample, forest)
+// walks its trees level by level: the next level = the children of the current one in parent order (child 0 before child 1), placed
+// by an exclusive scan of the child counts; a level's rows are written in parallel. The frontiers (u16 ids) live in LDS. The host
+// BFS of sim_host.h: export_edges produces the same rows (octa_sim_export_edges keeps it as the cross-check and for callers that
+// want the list on the host); here the list never leaves HBM on its way to the rasteriser.
+__global__ void __launch_bounds__(256)
+sim_export_kernel(BatchPtrs B, const long *__restrict__ edge_off, int n_trees, double *__restrict__ edges) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x, f = blockIdx.y;
+    SimArrays A = sample_arrays(B, s);
+    Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
+    unsigned short *cur = reinterpret_cast<unsigned short *>(b.user());
+    unsigned short *nxt = cur + NCAP;
+    const int n_art_rows = A.sc->n_nodes[0] - n_trees;
+    long row = edge_off[s] + (f ? n_art_rows : 0);
+    const double *pos = A.npos[f], *rad = A.nrad[f];
+    const int *par = A.npar[f], *c0 = A.nch0[f], *c1 = A.nch1[f];
+    const unsigned char *nch = A.nnch[f];
+    for (int t = 0; t < n_trees; t++) {
+        b.sync();
+        if (b.tid == 0) cur[0] = (unsigned short)(2 * t);
+        b.sync();
+        int n_cur = 1;
+        while (n_cur > 0) {
+            int base = 0;
+            for (int i0 = 0; i0 < n_cur; i0 += b.nth) {
+                const int i = i0 + b.tid;
+                int id = -1, nc = 0;
+                if (i < n_cur) { id = cur[i]; nc = nch[id]; if (nc > 2) nc = 2; }
+                int ex;
+                const int tot = blk_scan(b, nc, &ex);
+                if (nc >= 1 && base + ex < NCAP) nxt[base + ex] = (unsigned short)c0[id];
+                if (nc >= 2 && base + ex + 1 < NCAP) nxt[base + ex + 1] = (unsigned short)c1[id];
+                base += tot;
+            }
+            b.sync();
+            const int n_next = base < NCAP ? base : NCAP;
+            for (int j = b.tid; j < n_next; j += b.nth) {
+                const int v = nxt[j], p = par[v];
+                double *e = edges + 7 * (row + j);
+                e[0] = pos[3 * v]; e[1] = pos[3 * v + 1]; e[2] = pos[3 * v + 2];
+                e[3] = pos[3 * p]; e[4] = pos[3 * p + 1]; e[5] = pos[3 * p + 2];
+                e[6] = rad[v];
+            }
+            row += n_next;
+            unsigned short *tmp = cur; cur = nxt; nxt = tmp;
+            n_cur = n_next;
+            b.sync();
+        }
+    }
+}
+
 }  // namespace
 
 struct octa_sim {
@@ -467,6 +549,7 @@ struct octa_sim {
     std::vector<IterParams> iters;
     BatchPtrs P;
     std::vector<void *> allocs;
+    long *d_edge_off = nullptr;     // [B + 1] row offsets for the device-side edge export
     BifRequest *h_reqs = nullptr;   // pinned [2*REQ_CAP]
     double *h_results = nullptr;    // pinned [2*REQ_CAP*6]
     int *h_req_count = nullptr;     // pinned [2]
@@ -557,7 +640,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
         rc |= dev_alloc(S, &P.nnch[f], nb * NCAP); rc |= dev_alloc(S, &P.nact[f], nb * NCAP);
     }
     rc |= dev_alloc(S, &P.oxy, nb * OCAP * 3); rc |= dev_alloc(S, &P.co2, nb * CCAP * 3);
-    rc |= dev_alloc(S, &P.cand, nb * NCANDCAP * 3); rc |= dev_alloc(S, &P.py_u, nb * PYCAP);
+    rc |= dev_alloc(S, &P.cand, nb * NCANDCAP * 3); rc |= dev_alloc(S, &P.py_u, nb * PYCAP); rc |= dev_alloc(S, &P.py_state, nb * 625);
     rc |= dev_alloc(S, &P.nn, nb * OCAP); rc |= dev_alloc(S, &P.first_att, nb * NCAP); rc |= dev_alloc(S, &P.act_list, nb * NCAP);
     rc |= dev_alloc(S, &P.sorted, nb * SORTCAP); rc |= dev_alloc(S, &P.gnode, nb * GCAP); rc |= dev_alloc(S, &P.gstart, nb * GCAP);
     rc |= dev_alloc(S, &P.gcount, nb * GCAP); rc |= dev_alloc(S, &P.rec, nb * GCAP);
@@ -625,6 +708,7 @@ extern "C" void octa_sim_destroy(octa_sim *S) {
     for (int k = 0; k < 3; k++) if (S->ev[k]) e = hipEventDestroy(S->ev[k]);
     if (S->export_stage) e = hipHostFree(S->export_stage);
     if (S->export_stream) e = hipStreamDestroy(S->export_stream);
+    if (S->d_edge_off) e = hipFree(S->d_edge_off);
     (void)e;
     delete S;
 }
@@ -687,10 +771,11 @@ int sim_run_impl(octa_sim *S, const SampleSource &src, octa_bif_fn bif, void *us
         std::vector<unsigned> mt((size_t)B * 625);
         std::vector<unsigned short> valid((size_t)B * 76 * 76 * 2, 0);
         std::vector<unsigned> vcount(B);
-        std::vector<double> py_u((size_t)B * PYCAP);
+        std::vector<unsigned> py_mt((size_t)B * 625);
         const int n0 = 2 * S->cfg.n_trees;
         std::vector<double> npos((size_t)B * 2 * n0 * 3);
         SampleInit I;
+        I.want_py_u = false;             // the uniforms are drawn on the device from the generator state (py_uniform_kernel)
         for (int s = 0; s < B; s++) {
             src.fill(S->cfg, s, &I);
             memset(&sc[s], 0, sizeof(SampleScalars));
@@ -702,14 +787,17 @@ int sim_run_impl(octa_sim *S, const SampleSource &src, octa_bif_fn bif, void *us
             vcount[s] = (unsigned)(I.valid.size() / 2);
             if (vcount[s] == 0) { octa::set_error("octa_sim_run: sample %d has no valid voxel", s); return -2; }
             memcpy(&valid[(size_t)s * 76 * 76 * 2], I.valid.data(), I.valid.size() * 2);
-            memcpy(&py_u[(size_t)s * PYCAP], I.py_u.data(), sizeof(double) * PYCAP);
+            memcpy(&py_mt[(size_t)s * 625], I.py_state.mt, 624 * 4);
+            py_mt[(size_t)s * 625 + 624] = (unsigned)I.py_state.idx;
             for (int f = 0; f < 2; f++) memcpy(&npos[((size_t)s * 2 + f) * n0 * 3], I.pos[f].data(), sizeof(double) * n0 * 3);
         }
         OCTA_HIP_CHECK(hipMemcpyAsync(P.sc, sc.data(), sizeof(SampleScalars) * B, hipMemcpyHostToDevice, stream));
         OCTA_HIP_CHECK(hipMemcpyAsync(P.mt_state, mt.data(), mt.size() * 4, hipMemcpyHostToDevice, stream));
         OCTA_HIP_CHECK(hipMemcpyAsync(P.valid, valid.data(), valid.size() * 2, hipMemcpyHostToDevice, stream));
         OCTA_HIP_CHECK(hipMemcpyAsync(P.valid_count, vcount.data(), vcount.size() * 4, hipMemcpyHostToDevice, stream));
-        OCTA_HIP_CHECK(hipMemcpyAsync(P.py_u, py_u.data(), py_u.size() * 8, hipMemcpyHostToDevice, stream));
+        OCTA_HIP_CHECK(hipMemcpyAsync(P.py_state, py_mt.data(), py_mt.size() * 4, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(py_uniform_kernel, dim3((unsigned)B), dim3(64), 0, stream, P.py_state, P.py_u, PYCAP);
+        OCTA_HIP_CHECK(hipGetLastError());
         OCTA_HIP_CHECK(hipMemcpyAsync(P.iters, S->iters.data(), sizeof(IterParams) * S->iters.size(), hipMemcpyHostToDevice, stream));
         std::vector<int> Ns(S->iters.size() + 1, 0);
         for (size_t i = 0; i < S->iters.size(); i++) Ns[i] = S->iters[i].N;
@@ -970,6 +1058,22 @@ extern "C" int octa_sim_export_edges(octa_sim *S, double *h_edges) {
         if (ne < 0) { octa::set_error("octa_sim_export_edges: export failed"); return -1; }
         total += ne;
     }
+    return 0;
+}
+
+extern "C" int octa_sim_export_edges_device(octa_sim *S, double *d_edges, void *stream_) {
+    if (!S || !S->ran || !d_edges) { octa::set_error("octa_sim_export_edges_device: run the simulation first"); return -2; }
+    OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const int B = S->B;
+    std::vector<long> off(B + 1, 0);
+    for (int s = 0; s < B; s++) off[s + 1] = off[s] + (S->h_sc[s].n_nodes[0] - S->cfg.n_trees) + (S->h_sc[s].n_nodes[1] - S->cfg.n_trees);
+    if (!S->d_edge_off) OCTA_HIP_CHECK(hipMalloc(&S->d_edge_off, sizeof(long) * (B + 1)));
+    OCTA_HIP_CHECK(hipMemcpyAsync(S->d_edge_off, off.data(), sizeof(long) * (B + 1), hipMemcpyHostToDevice, stream));
+    OCTA_HIP_CHECK(hipStreamSynchronize(stream));     // `off` is a local; the copy is a few hundred bytes
+    const size_t lds = 2048 + (size_t)NCAP * 2 * 2;
+    hipLaunchKernelGGL(sim_export_kernel, dim3((unsigned)B, 2), dim3(256), lds, stream, S->P, S->d_edge_off, S->cfg.n_trees, d_edges);
+    OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
 

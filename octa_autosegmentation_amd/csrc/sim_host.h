@@ -175,7 +175,9 @@ struct SampleInit {
     double faz_radius;
     std::vector<unsigned short> valid;   // [K][2] (i, j)
     Mt19937 np_state;                     // numpy stream after the forest stumps
-    std::vector<double> py_u;             // PYCAP pre-drawn random.uniform(0,1) values after the stumps
+    std::vector<double> py_u;             // PYCAP pre-drawn random.uniform(0,1) values after the stumps (host builds / tests only)
+    Mt19937 py_state;                     // CPython's generator after the stumps: the device draws the uniforms itself (sim.hip)
+    bool want_py_u = true;                // false: leave py_u empty (4.2 M draws per 128-sample batch that the device makes faster)
     // stump nodes per forest: root, child per tree
     std::vector<double> pos[2];           // xyz
     int n_nodes[2];
@@ -223,8 +225,11 @@ inline void init_sample_given(const SimConfig &cfg, double faz_radius, const dou
     S->pos[0].assign(pos_art, pos_art + n);
     S->pos[1].assign(pos_ven, pos_ven + n);
     S->n_nodes[0] = S->n_nodes[1] = 2 * cfg.n_trees;
-    S->py_u.resize(PYCAP);
-    for (int i = 0; i < PYCAP; i++) S->py_u[i] = py.next_double();
+    S->py_state = py;
+    if (S->want_py_u) {
+        S->py_u.resize(PYCAP);
+        for (int i = 0; i < PYCAP; i++) S->py_u[i] = py.next_double();
+    }
 }
 
 inline void init_sample(const SimConfig &cfg, uint32_t np_seed, uint64_t py_seed_v, SampleInit *S) {
@@ -291,8 +296,11 @@ inline void init_sample(const SimConfig &cfg, uint32_t np_seed, uint64_t py_seed
         }
         S->n_nodes[f] = 2 * cfg.n_trees;
     }
-    S->py_u.resize(PYCAP);
-    for (int i = 0; i < PYCAP; i++) S->py_u[i] = py.next_double();
+    S->py_state = py;
+    if (S->want_py_u) {
+        S->py_u.resize(PYCAP);
+        for (int i = 0; i < PYCAP; i++) S->py_u[i] = py.next_double();
+    }
 }
 
 // BFS per tree, root excluded: rows (node xyz, parent xyz, radius); arterial then venous

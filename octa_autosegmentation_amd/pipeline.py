@@ -48,10 +48,14 @@ class TripleGenerator:
 
     def generate(self, seeds, want_label=True):
         """Returns dict(result=SimulationResult, image=uint8 CUDA [B,H,W], label=uint8 CUDA {0,255} [B,1216,1216])."""
-        import torch
+        import time
+        t0 = time.time()
         res = self.sim.run(seeds)
+        t1 = time.time()
         with _native.use_ctx(self._ctx):
-            return self._render(res, want_label)
+            out = self._render(res, want_label)
+        out["wall"] = {"t_start": t0, "sim_run_s": t1 - t0, "render_enqueue_s": time.time() - t1}     # host-side stamps (bench.py's slot accounting)
+        return out
 
     def _render(self, res, want_label):
         import torch
@@ -59,7 +63,8 @@ class TripleGenerator:
         off, n_art = res.edge_off, res.n_art
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.time_render else None
         mark = (lambda i: ev[i].record()) if ev else (lambda i: None)       # on the current stream = the stream the kernels go to
-        d_edges = torch.from_numpy(res.edges).to(self.device, non_blocking=True)
+        # the simulator exported the edge list on the device (round 3): no host BFS, no PCIe round trip of ~93 MB per 128 samples
+        d_edges = res.d_edges if res.d_edges is not None else torch.from_numpy(res.edges).to(self.device, non_blocking=True)
         mark(0)
         d_rb = None
         if self.image_mode == "cli":

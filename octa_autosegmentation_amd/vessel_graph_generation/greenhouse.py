@@ -8,6 +8,7 @@ geometry (np.mean / np.cov / np.linalg.eig, greenhouse.py:205-233), served to th
 """
 import csv
 import ctypes
+import os
 import io
 
 import numpy as np
@@ -225,8 +226,17 @@ def _enable_native_bifurcation_service(config):
 class SimulationResult:
     """Edges of B samples in the reference's CSV row order plus per-sample statistics."""
 
-    def __init__(self, edges, edge_off, n_art, stats):
-        self.edges, self.edge_off, self.n_art, self.stats = edges, edge_off, n_art, stats
+    def __init__(self, edges, edge_off, n_art, stats, d_edges=None):
+        """edges: float64 [n, 7] on the host, or None when the list was exported on the device (`d_edges`, a CUDA tensor): the host
+        copy is then fetched on first use of `.edges`."""
+        self._edges, self.d_edges = edges, d_edges
+        self.edge_off, self.n_art, self.stats = edge_off, n_art, stats
+
+    @property
+    def edges(self):
+        if self._edges is None:
+            self._edges = self.d_edges.cpu().numpy()
+        return self._edges
 
     def __len__(self):
         return len(self.edge_off) - 1
@@ -248,6 +258,9 @@ class BatchSimulator:
         self._cfg = config_to_struct(config)
         self._bif_fn = _enable_native_bifurcation_service(config)
         self.batch = int(batch)
+        import torch
+        self.device_index = torch.cuda.current_device() if device_index is None else int(device_index)
+        self.device_export = os.environ.get("OCTA_SIM_HOST_EXPORT") != "1"       # 1: the round-2 path (download the node arrays, BFS on the host)
         h = ctypes.c_void_p()
         _native.check(self._lib.octa_sim_create(self._ctx, ctypes.byref(self._cfg), self.batch, ctypes.byref(h)),
                       "octa_sim_create")
@@ -278,15 +291,24 @@ class BatchSimulator:
         off = np.zeros(self.batch + 1, np.int64)
         n_art = np.zeros(self.batch, np.int64)
         _native.check(self._lib.octa_sim_edge_offsets(self._h, off.ctypes.data, n_art.ctypes.data), "octa_sim_edge_offsets")
-        edges = np.zeros((int(off[-1]), 7))
-        _native.check(self._lib.octa_sim_export_edges(self._h, edges.ctypes.data), "octa_sim_export_edges")
+        edges = d_edges = None
+        if self.device_export:
+            # the edge list is written by a kernel on the stream of the run and stays in HBM (the rasteriser reads it there); the host
+            # copy is made when somebody asks for `.edges`
+            import torch
+            d_edges = torch.empty((int(off[-1]), 7), dtype=torch.float64, device=torch.device("cuda", self.device_index))
+            _native.check(self._lib.octa_sim_export_edges_device(self._h, ctypes.c_void_p(d_edges.data_ptr()), _native.current_stream_ptr()),
+                          "octa_sim_export_edges_device")
+        else:
+            edges = np.zeros((int(off[-1]), 7))
+            _native.check(self._lib.octa_sim_export_edges(self._h, edges.ctypes.data), "octa_sim_export_edges")
         stats = np.zeros((self.batch, 32), np.int64)
         _native.check(self._lib.octa_sim_stats(self._h, stats.ctypes.data), "octa_sim_stats")
         timing = np.zeros(8)
         _native.check(self._lib.octa_sim_timing(self._h, timing.ctypes.data), "octa_sim_timing")
         svc = np.zeros(5)
         _native.check(self._lib.octa_sim_service_stats(self._h, svc.ctypes.data), "octa_sim_service_stats")
-        res = SimulationResult(edges, off, n_art, stats)
+        res = SimulationResult(edges, off, n_art, stats, d_edges)
         res.spans = np.zeros((self.batch, 2), np.int64)      # 100 MHz device clock: first taken / last left by a workgroup
         _native.check(self._lib.octa_sim_spans(self._h, res.spans.ctypes.data), "octa_sim_spans")
         res.service = dict(tickets=int(svc[0]), max_absence_ms=svc[1], relaunches=int(svc[2]), parked=int(svc[3]), max_callback_ms=svc[4])

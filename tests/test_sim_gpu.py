@@ -144,6 +144,22 @@ def test_wide_reference_pin_64_full_length_seeds(gh, golden):
     assert not bad, f"CSV text differs from the reference's for seeds {bad}"
 
 
+def test_device_edge_export_equals_the_host_bfs(gh, golden, monkeypatch):
+    """The edge list written on the device (level-order walk per tree, sim.hip: sim_export_kernel) equals the host BFS over the
+    downloaded node arrays (sim_host.h: export_edges) byte for byte, for a ragged batch; the device list is a CUDA tensor and the
+    host copy is made on first use."""
+    cfg = _cfg(golden, 14, 9)
+    seeds = np.arange(7) + 300
+    a = gh.simulate_batch(cfg, seeds)
+    assert a.d_edges is not None and a.d_edges.is_cuda and a._edges is None
+    monkeypatch.setenv("OCTA_SIM_HOST_EXPORT", "1")
+    b = gh.simulate_batch(cfg, seeds)
+    monkeypatch.delenv("OCTA_SIM_HOST_EXPORT")
+    assert b.d_edges is None
+    assert (a.edge_off == b.edge_off).all() and (a.n_art == b.n_art).all()
+    assert a.edges.shape == b.edges.shape and a.edges.tobytes() == b.edges.tobytes()
+
+
 def test_device_kd_order_matches_scipy(hip_lib_built):
     """The team-parallel introselect on the device must give scipy's tree.indices (no ties in the data)."""
     from scipy.spatial import cKDTree
