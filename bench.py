@@ -133,15 +133,10 @@ def cpu_baseline(cfg):
     single-core figure. Bounded: one wave of samples (about 5-10 s) + one more sample."""
     from multiprocessing import get_context
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # one worker per visible core (BASELINE.md section 3), bounded only by memory: a spawned worker (numpy + the oracle's tables and
-    # buffers) is budgeted at 1 GiB of MemAvailable so that a small box is not driven out of memory
-    avail_gb = cores
-    try:
-        with open("/proc/meminfo") as f:
-            avail_gb = next(int(line.split()[1]) for line in f if line.startswith("MemAvailable")) // (1024 * 1024)
-    except Exception:  # noqa: BLE001
-        pass
-    workers = max(1, min(cores, int(avail_gb * 0.8)))
+    # 64 workers, not one per visible core: measured on the 256-thread host of the GPU box (round 3), 256 workers give 1.1 samples/s
+    # against 2.2 with 64 -- the restatement's brute-force neighbour queries are memory-bound and the wave of 256 takes 230 s, far
+    # beyond the bounded 10-30 s sample this leg is allowed; `host_cores_visible` reports what the box has
+    workers = min(cores, 64)
     t0 = time.time()
     _oracle_sample((cfg, 900))
     single = 1.0 / (time.time() - t0)
@@ -175,14 +170,14 @@ def cpu_unet_step():
     step()                                   # warm-up: first-call overheads (thread pools, oneDNN primitive creation)
     cold = time.time() - t0
     times = []
-    for _ in range(2):
+    for _ in range(1):                        # one timed step (13 s on the 128-core host): the leg stays within its 30 s
         t0 = time.time()
         step()
         times.append(time.time() - t0)
     dt = sum(times) / len(times)
     return {"value": 1.0 / dt, "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "plain torch fp32 on the CPU device",
             "cold_first_step_s": cold, "step_s": times,
-            "sample": "DynUNet-S training steps, B=1, 1x1216x1216: one warm-up step, then the mean of two timed steps"}
+            "sample": "DynUNet-S training steps, B=1, 1x1216x1216: one warm-up step, then one timed step"}
 
 
 def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4):
@@ -488,7 +483,10 @@ def main():
     if not args.no_train and not args.no_end_to_end:
         import train_synthetic
         torch.cuda.empty_cache()
-        e2e_info = train_synthetic.run(steps=160, batch=args.train_batch, gen_batch=128, seed0=500000, log=False, warmup=32)   # warm-up = one generator batch (the queue-filling transient), then 5 batches timed
+        # generator batches of 256 samples (round 3: a sample holds half a CU, so 256 workgroups = the CU time 128 held before; with 128
+        # the single generator launch in flight produced fewer samples per second than the training step consumes): warm-up = one
+        # generator batch (the queue-filling transient), then three batches timed
+        e2e_info = train_synthetic.run(steps=192, batch=args.train_batch, gen_batch=256, seed0=500000, log=False, warmup=64)
         # configs[4] proper: the same stream feeding the joint GAN contrast-adaptation + segmentation step (G, D at 304^2, S at 1216^2)
         torch.cuda.empty_cache()
         e2e_gan_info = train_synthetic.run(steps=64, batch=args.train_batch, gen_batch=128, seed0=600000, log=False, gan=True, warmup=32)

@@ -8,7 +8,7 @@ config's augmentation list on the GPU (data/gpu_augment.py) and runs the trainin
 Multi-GPU: launch with torch.distributed.run -- every rank generates and trains on its own seeds, gradients are
 all-reduced with RCCL (the trainer's flat all-reduce).
 
-  python train_synthetic.py --steps 50 --batch 4 --gen-batch 128
+  python train_synthetic.py --steps 50 --batch 4 --gen-batch 256
 """
 import argparse
 import json
@@ -194,7 +194,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--gen-batch", type=int, default=128)
+    ap.add_argument("--gen-batch", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gan", action="store_true", help="feed the GAN-seg trainer (configs[4]) instead of the segmentation trainer")
     a = ap.parse_args()
