@@ -298,7 +298,7 @@ sim_iter_b_kernel(BatchPtrs B, int it) {
     if (A.sc->err) return;
     const IterParams P = B.iters[it];
     OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, B.bif_results));
-    OCTA_PROF(4, phase_satisfy_art(b, A, P));
+    OCTA_PROF(4, phase_satisfy_art(b, A, B.C, P));
     OCTA_PROF(6, phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven));
     OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, B.reqs + REQ_CAP, B.req_count + 1, REQ_CAP, s));
 }
@@ -445,7 +445,7 @@ __device__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s, c
                 };
                 OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, results, next_candidates));
             }
-            OCTA_PROF(4, phase_satisfy_art(b, A, P));
+            OCTA_PROF(4, phase_satisfy_art(b, A, B.C, P));
             OCTA_PROF(6, phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven));
             if (b.tid == 0) *req_n = 0;
             b.sync();
@@ -1111,10 +1111,10 @@ extern "C" int octa_sim_fields(octa_sim *S, int sample, double *h_oxy, int64_t c
 
 namespace {
 __global__ void __launch_bounds__(SIM_THREADS)
-sim_kat_kd_kernel(const double *pts, int n, const unsigned char *need, unsigned short *out_idx, unsigned short *out_rank) {
+sim_kat_kd_kernel(const double *pts, int n, const unsigned char *need, unsigned short *out_idx, unsigned short *out_rank, float *xy, double zlo, double zhi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
-    kd_build(b, pts, n, out_idx, out_rank, nullptr, need);
+    kd_build(b, pts, n, out_idx, out_rank, xy, zlo, zhi, nullptr, need);
 }
 }  // namespace
 
@@ -1125,6 +1125,10 @@ extern "C" int octa_sim_kat_kd_order(octa_ctx *ctx, const double *h_pts, int64_t
     double *d_pts = nullptr;
     unsigned char *d_need = nullptr;
     unsigned short *d_idx = nullptr;
+    float *d_xy = nullptr;
+    double zlo = h_pts[2], zhi = h_pts[2];
+    for (int64_t i = 1; i < n; i++) { zlo = h_pts[3 * i + 2] < zlo ? h_pts[3 * i + 2] : zlo; zhi = h_pts[3 * i + 2] > zhi ? h_pts[3 * i + 2] : zhi; }
+    OCTA_HIP_CHECK(hipMalloc(&d_xy, sizeof(float) * 2 * n));
     OCTA_HIP_CHECK(hipMalloc(&d_pts, sizeof(double) * 3 * n));
     OCTA_HIP_CHECK(hipMalloc(&d_idx, sizeof(unsigned short) * 2 * n));
     OCTA_HIP_CHECK(hipMemcpy(d_pts, h_pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
@@ -1133,12 +1137,12 @@ extern "C" int octa_sim_kat_kd_order(octa_ctx *ctx, const double *h_pts, int64_t
         OCTA_HIP_CHECK(hipMemcpy(d_need, h_need, n, hipMemcpyHostToDevice));
     }
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(sim_kat_kd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIM_LDS));
-    hipLaunchKernelGGL(sim_kat_kd_kernel, dim3(1), dim3(SIM_THREADS), SIM_LDS, 0, d_pts, (int)n, d_need, d_idx, d_idx + n);
+    hipLaunchKernelGGL(sim_kat_kd_kernel, dim3(1), dim3(SIM_THREADS), SIM_LDS, 0, d_pts, (int)n, d_need, d_idx, d_idx + n, d_xy, zlo, zhi);
     OCTA_HIP_CHECK(hipGetLastError());
     std::vector<unsigned short> h(n);
     OCTA_HIP_CHECK(hipMemcpy(h.data(), d_idx, sizeof(unsigned short) * n, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; i++) h_indices[i] = (int32_t)h[i];
-    (void)hipFree(d_pts); (void)hipFree(d_idx); if (d_need) (void)hipFree(d_need);
+    (void)hipFree(d_pts); (void)hipFree(d_idx); (void)hipFree(d_xy); if (d_need) (void)hipFree(d_need);
     return 0;
 }
 

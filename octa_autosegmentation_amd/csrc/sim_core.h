@@ -732,8 +732,12 @@ static_assert(KD_RANGES >= OCAP / 17 + 1, "ranges per level");
 static_assert(KD_MAILBOX_OFF % 16 == 0 && KD_MAILBOX_OFF >= KD_TAB_OFF + KD_RANGES * 9, "kd tables overlap the mailbox");
 static_assert(KD_BOX_BYTES >= KD_MAILBOX_BYTES, "the box table covers the mailbox");
 static_assert(2048 + KD_MAILBOX_OFF + KD_BOX_BYTES <= SIM_LDS_BYTES, "kd LDS layout");
+// xy: [n][2] floats of global scratch -- the x and y coordinates rounded to single precision, written here and read by the box and
+// key passes of every level (8 B instead of 24 + 8 B of gathered doubles per element and level: the gathers were the kernel's
+// largest HBM/L2 read stream); zlo / zhi: bounds of every point's z (the slab is thin: z wins the "largest spread" only for ranges
+// whose x and y boxes are thinner than the slab, and those are measured exactly).
 OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned short *out_idx, unsigned short *out_rank,
-                              long *kdprof = nullptr, const unsigned char *need = nullptr) {
+                              float *xy, double zlo, double zhi, long *kdprof = nullptr, const unsigned char *need = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KDP(slot) do { if (kdprof && b.tid == 0) { long _t = (long)wall_clock64(); kdprof[slot] += _t - _kt; _kt = _t; } } while (0)
     long _kt = (long)wall_clock64();
@@ -746,8 +750,12 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
     unsigned short *rs2 = tab + 2 * KD_RANGES, *re2 = tab + 3 * KD_RANGES;  // next level
     signed char *rd = reinterpret_cast<signed char *>(tab + 4 * KD_RANGES); // bbox pass: 1 = holds a needed point; then split dim (-1 = leaf / not needed)
     unsigned *bbf = reinterpret_cast<unsigned *>(b.user() + KD_MAILBOX_OFF); // [nr][6]: max xyz (rounded up), min xyz (rounded down)
-    for (int i = b.tid; i < n; i += b.nth) kv[i] = (unsigned)i;
+    for (int i = b.tid; i < n; i += b.nth) {
+        kv[i] = (unsigned)i;
+        xy[2 * i] = (float)pts[3 * i]; xy[2 * i + 1] = (float)pts[3 * i + 1];      // round to nearest: x lies within one float spacing of it
+    }
     if (b.tid == 0) { rs[0] = 0; re[0] = (unsigned short)n; }
+    const float z_up = f32_round_up(zhi), z_dn = f32_round_down(zlo);
     b.sync();
     int nr = (n > 16) ? 1 : 0;  // a range of <= leafsize points is a leaf: left in input order
     while (nr > 0) {
@@ -755,7 +763,8 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
         //    array (ranges are sorted, disjoint slices of it), gathers the three coordinates, keeps exact
         //    running extrema and folds their single-precision outer bounds into the per-range table.
         for (int q = b.tid; q < nr; q += b.nth) {
-            for (int k = 0; k < 3; k++) { bbf[6 * q + k] = 0u; bbf[6 * q + 3 + k] = ~0u; }
+            for (int k = 0; k < 2; k++) { bbf[6 * q + k] = 0u; bbf[6 * q + 3 + k] = ~0u; }
+            bbf[6 * q + 2] = f32_sortable(z_up); bbf[6 * q + 5] = f32_sortable(z_dn);      // z: the slab's bounds for every range
             rd[q] = 0;
         }
         b.sync();
@@ -769,25 +778,32 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 q = lo_;
             }
             bool have = false, hit = false;
-            double mx[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+            float mx[2] = {0, 0}, mn[2] = {0, 0};
+            // the extrema of the ROUNDED coordinates, widened by one float spacing each way, bound the true extrema
+            auto flush = [&](int qq) {
+                for (int k = 0; k < 2; k++) {
+                    atomic_max_u32(&bbf[6 * qq + k], f32_sortable(nextafterf(mx[k], INFINITY)));
+                    atomic_min_u32(&bbf[6 * qq + 3 + k], f32_sortable(nextafterf(mn[k], -INFINITY)));
+                }
+            };
             for (int i = i0; i < i1; i++) {
                 while (q + 1 < nr && rs[q + 1] <= i) {
-                    if (have) { for (int k = 0; k < 3; k++) { atomic_max_u32(&bbf[6 * q + k], f32_sortable(f32_round_up(mx[k]))); atomic_min_u32(&bbf[6 * q + 3 + k], f32_sortable(f32_round_down(mn[k]))); } have = false; }
+                    if (have) { flush(q); have = false; }
                     if (hit) { rd[q] = 1; hit = false; }
                     q++;
                 }
                 if (i < rs[q] || i >= re[q]) continue;  // element of a finished leaf
                 const int id = (int)(kv[i] & KD_IDX_MASK);
                 if (!need || need[id]) hit = true;
-                const double *p = pts + 3 * id;
-                for (int k = 0; k < 3; k++) {
-                    const double e = p[k];
-                    if (!have) { mx[k] = mn[k] = e; }
-                    else { mx[k] = mx[k] > e ? mx[k] : e; mn[k] = mn[k] < e ? mn[k] : e; }
+                const float ex = xy[2 * id], ey = xy[2 * id + 1];
+                if (!have) { mx[0] = mn[0] = ex; mx[1] = mn[1] = ey; }
+                else {
+                    mx[0] = mx[0] > ex ? mx[0] : ex; mn[0] = mn[0] < ex ? mn[0] : ex;
+                    mx[1] = mx[1] > ey ? mx[1] : ey; mn[1] = mn[1] < ey ? mn[1] : ey;
                 }
                 have = true;
             }
-            if (have) for (int k = 0; k < 3; k++) { atomic_max_u32(&bbf[6 * q + k], f32_sortable(f32_round_up(mx[k]))); atomic_min_u32(&bbf[6 * q + 3 + k], f32_sortable(f32_round_down(mn[k]))); }
+            if (have) flush(q);
             if (hit) rd[q] = 1;
         }
         b.sync();
@@ -801,6 +817,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 shi[k] = (double)up - (double)dn;
                 slo[k] = shi[k] - 2.0 * (f32_ulp(up) + f32_ulp(dn));
             }
+            slo[2] = 0.0;      // z: the table holds the slab's bounds, not the range's -- an upper bound of the spread only
             int d = 0;
             if (shi[1] > shi[d]) d = 1;
             if (shi[2] > shi[d]) d = 2;
@@ -848,7 +865,9 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 }
                 if (d >= 0) {
                     const unsigned id = kv[i] & KD_IDX_MASK;
-                    kv[i] = (kd_quant(pts[3 * id + d], mnd, scale) << KD_IDX_BITS) | id;
+                    // x / y: the rounded coordinate (rounding is monotone, so the key still is); z: the double itself
+                    const double cv = d < 2 ? (double)xy[2 * id + d] : pts[3 * id + 2];
+                    kv[i] = (kd_quant(cv, mnd, scale) << KD_IDX_BITS) | id;
                 }
             }
         }
@@ -2127,7 +2146,8 @@ OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsign
 #endif
 
 // ------------------------------------------------------------------ phase: satisfied O2 sinks -> CO2
-OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const IterParams &P) {
+OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P) {
+    const double zext = C.sz;      // every sink passed is_valid_position: 0 <= z < size_z
     SampleScalars *sc = A.sc;
     const int nb = sc->new_begin[0], ne = sc->new_end[0];
     const int n_new = ne - nb, n_oxy = sc->n_oxy;
@@ -2163,7 +2183,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const It
     b.sync();
     if (n_pairs == 0) return;  // nothing satisfied: no conversion, no deletion (uniform across the block)
     // 2. cKDTree order of the O2 list, only as deep as the hit sinks need it; pairs get kd ranks
-    kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank, sc->kdprof, A.removed);
+    kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank, reinterpret_cast<float *>(A.hashes) /* free until step 3 */, 0.0, zext, sc->kdprof, A.removed);
     for (int i = b.tid; i < n_pairs; i += b.nth) {
         unsigned pr = A.pairs[i];
         A.pairs[i] = (pr & ~16383u) | (unsigned)A.kd_rank[pr & 16383u];

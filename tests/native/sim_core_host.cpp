@@ -45,7 +45,10 @@ void octa_simcore_kd_indices(const double *pts, int n, unsigned short *out_idx) 
     std::vector<unsigned char> smem((size_t)SIM_LDS_BYTES + 64);
     Blk b = {0, 1, smem.data()};
     std::vector<unsigned short> rank(n);
-    kd_build(b, pts, n, out_idx, rank.data());
+    std::vector<float> xy((size_t)2 * n + 2);
+    double zlo = n ? pts[2] : 0, zhi = zlo;
+    for (int i = 1; i < n; i++) { zlo = std::min(zlo, pts[3 * i + 2]); zhi = std::max(zhi, pts[3 * i + 2]); }
+    kd_build(b, pts, n, out_idx, rank.data(), xy.data(), zlo, zhi);
 }
 
 long octa_simcore_set_order(const double *tuples, const int *ids, int n_ins, int *out) {
@@ -137,7 +140,7 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
         phase_pre(b, A, C, P, 0, A.oxy, reqs.data(), &req_count, REQ_CAP, 0);
         serve(req_count);
         phase_seq(b, A, C, P, 0, A.oxy, results.data());
-        phase_satisfy_art(b, A, P);
+        phase_satisfy_art(b, A, C, P);
         req_count = 0;
         phase_assign(b, A, 1, A.co2, sc.n_co2, P.delta_ven);
         phase_pre(b, A, C, P, 1, A.co2, reqs.data(), &req_count, REQ_CAP, 0);
