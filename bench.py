@@ -37,7 +37,7 @@ UNET_MIN_HBM_GB_PER_IMAGE = 6.0    # activations written once / 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16
 N_CUS = 256          # MI355X; main() replaces it by the device's own count
-PMC_SUMMARY = os.path.join("profiles", "r02_bench_pmc_summary.csv")
+PMC_SUMMARY = os.path.join("profiles", "r03_bench_pmc_summary.csv")
 
 
 def pmc_traffic_per_launch(kernel_name):
@@ -45,7 +45,7 @@ def pmc_traffic_per_launch(kernel_name):
     WRITE_SIZE collected in separate --pmc passes of this bench by tools/profile_bench.sh, values in KB). Correction per
     MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 128-B requests as 64 B on gfx950, so it is doubled; WRITE_SIZE is taken as
     reported. None if the file or the kernel is missing."""
-    for cand in (PMC_SUMMARY, os.path.join("profiles", "r01_bench_pmc_summary.csv")):
+    for cand in (PMC_SUMMARY, os.path.join("profiles", "r02_bench_pmc_summary.csv")):
         path = os.path.join(ROOT, cand)
         if not os.path.exists(path):
             continue
@@ -501,7 +501,7 @@ def main():
         if la == 0:
             dom_ms, dom_n, dom_name = kb, lb, "sim_persistent_kernel"
             bytes_per_launch = ALGO_BYTES_PER_SAMPLE * B * args.steps / max(lb, 1)
-            note = (f"one launch = 250 dependent growth iterations of {G} x {B} independent samples (work queue, at most one workgroup per CU); "
+            note = (f"one launch = 250 dependent growth iterations of {G} x {B} independent samples (work queue, two workgroups = two samples per CU); "
                     "dependency/latency-bound (ordered passes, pow chains), not HBM-bound: see serial_depth")
         else:
             dom_ms, dom_n, dom_name = (kb, lb, "sim_iter_b_kernel") if kb >= ka else (ka, la, "sim_iter_a_kernel")
@@ -536,9 +536,13 @@ def main():
             "config": {"workload": f"configs[1]: {B}-sample vessel-graph batch (docker/vessel_graph_gen_docker_config.yml, "
                                    f"I=100+150, N=2000) + tree2img rasterise 304x304 image and 1216x1216 label",
                        "batch_per_gpu": B, "steps_per_launch": G, "launches_in_flight": n_fly, "parallelism": f"sample-sharded x{world}, no collective"},
-            "parity": "graph CSV text and label / image pixels bit-exact with the reference on its fixtures; edge lists identical to the "
-                      "oracle's in EVERY double (radii: glibc pow restated; node positions: glibc acos / sin / cos restated, "
-                      "csrc/glibc_trig.h) on the validated full-length seeds (profiles/r02_validate_final.log)",
+            "parity": "graph CSV text bit-exact with the REFERENCE (imported and run in the build container) on 8 short + 2 full-length fixture "
+                      "runs and on 64 further full-length seeds (tests/golden/sim_wide_golden.npz: SHA-256 of the CSV text of seeds 1000-1063; the "
+                      "GPU reproduces all 64, tests/test_sim_gpu.py); label / image pixels bit-exact on the reference's fixtures. The oracle follows "
+                      "glibc's acos, numpy on the AVX-512 build host its own SIMD arccos: the oracle's edge lists differ from the reference's in 0-241 "
+                      "of ~92 000 doubles per full-length sample (last bit), never in a printed digit on those 64 + 10 runs; GPU and oracle agree in "
+                      "EVERY double (radii: glibc pow restated; node positions: glibc acos / sin / cos restated, csrc/glibc_trig.h) on the validated "
+                      "full-length seeds (profiles/r02_validate_final.log, profiles/r03_validate.log)",
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE; {traffic_src})",

@@ -475,6 +475,11 @@ int octa_sim_export_edges(octa_sim *sim, double *h_edges);
  * to octa_rasterize_2d without crossing PCIe. */
 int octa_sim_export_edges_device(octa_sim *sim, double *d_edges, void *stream);
 
+/* Per-iteration statistics of the last run, h_trace int32 [B][n_iter][4]: arterial nodes, O2 sinks, venous nodes, CO2 sources at the
+ * end of every iteration -- Greenhouse.art_nodes_per_step / oxys_per_step / ven_nodes_per_step / co2_per_step without their initial
+ * entry (greenhouse.py:129-134). Rows of samples that stopped on an error are undefined from the failing iteration on. */
+int octa_sim_trace(octa_sim *sim, int32_t *h_trace);
+
 /* Per-sample statistics, h_stats[B][32] int64: error bits, random.uniform draws, Murray steps,
  * bifurcations, re-speculated inter-nodes, arterial nodes, venous nodes, FAZ radius bits, then 16
  * per-phase device timers (100 MHz ticks: 0 sample, 1 assign-art, 2 speculate-art, 3 ordered-art,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "octa_sim_edge_offsets": (c_int, [c_void_p, c_void_p, c_void_p]),
     "octa_sim_export_edges": (c_int, [c_void_p, c_void_p]),
     "octa_sim_export_edges_device": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "octa_sim_trace": (c_int, [c_void_p, c_void_p]),
     "octa_sim_stats": (c_int, [c_void_p, c_void_p]),
     "octa_sim_timing": (c_int, [c_void_p, c_void_p]),
     "octa_sim_service_stats": (c_int, [c_void_p, c_void_p]),

@@ -66,6 +66,7 @@ struct BatchPtrs {
     unsigned *valid_count;       // [B]
     int *n_per_iter;             // [n_iter]
     int *next_sample;            // [1] work queue of the persistent kernel
+    int *trace;                  // [B][n_iter][4] arterial nodes, O2 sinks, venous nodes, CO2 sources at the end of every iteration (greenhouse.py:129-134)
     int n_samples;
     SimConst C;
 };
@@ -272,6 +273,10 @@ sim_iter_a_kernel(BatchPtrs B, int it, int finish_prev) {
         const IterParams Pp = B.iters[it - 1];
         OCTA_PROF(8, phase_seq(b, A, B.C, Pp, 1, A.co2, B.bif_results));
         OCTA_PROF(9, phase_satisfy_ven(b, A, Pp));
+        if (threadIdx.x == 0) {
+            int *tr = B.trace + ((size_t)s * B.C.n_iter + (it - 1)) * 4;
+            tr[0] = A.sc->n_nodes[0]; tr[1] = A.sc->n_oxy; tr[2] = A.sc->n_nodes[1]; tr[3] = A.sc->n_co2;
+        }
     }
     if (it >= B.C.n_iter) return;
     const IterParams P = B.iters[it];
@@ -409,6 +414,10 @@ __device__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s, c
                 const IterParams Pp = B.iters[it - 1];
                 OCTA_PROF(8, phase_seq(b, A, B.C, Pp, 1, A.co2, results));
                 OCTA_PROF(9, phase_satisfy_ven(b, A, Pp));
+                if (b.tid == 0) {      // iteration it - 1 is complete: the reference's per-step statistics
+                    int *tr = B.trace + ((size_t)s * n_iter + (it - 1)) * 4;
+                    tr[0] = A.sc->n_nodes[0]; tr[1] = A.sc->n_oxy; tr[2] = A.sc->n_nodes[1]; tr[3] = A.sc->n_co2;
+                }
             }
             if (it >= n_iter) break;
             const IterParams P = B.iters[it];
@@ -655,6 +664,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     rc |= dev_alloc(S, &P.mt_state, nb * 625); rc |= dev_alloc(S, &P.valid, nb * 76 * 76 * 2); rc |= dev_alloc(S, &P.valid_count, nb);
     rc |= dev_alloc(S, &P.n_per_iter, S->iters.size() + 1);  // kept for diagnostics
     rc |= dev_alloc(S, &P.next_sample, 4);
+    rc |= dev_alloc(S, &P.trace, nb * (S->iters.size() + 1) * 4);
     P.n_samples = B;
     if (!rc) {
         hipError_t e1 = hipHostMalloc((void **)&S->h_reqs, sizeof(BifRequest) * 2 * REQ_CAP);
@@ -1074,6 +1084,13 @@ extern "C" int octa_sim_export_edges_device(octa_sim *S, double *d_edges, void *
     const size_t lds = 2048 + (size_t)NCAP * 2 * 2;
     hipLaunchKernelGGL(sim_export_kernel, dim3((unsigned)B, 2), dim3(256), lds, stream, S->P, S->d_edge_off, S->cfg.n_trees, d_edges);
     OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_sim_trace(octa_sim *S, int32_t *h_trace) {
+    if (!S || !S->ran || !h_trace) { octa::set_error("octa_sim_trace: run the simulation first"); return -2; }
+    OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
+    OCTA_HIP_CHECK(hipMemcpy(h_trace, S->P.trace, sizeof(int32_t) * (size_t)S->B * S->iters.size() * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -256,6 +256,7 @@ class BatchSimulator:
         self._lib = _native.lib()
         self._ctx = _native.ctx(device_index)
         self._cfg = config_to_struct(config)
+        self._config = config
         self._bif_fn = _enable_native_bifurcation_service(config)
         self.batch = int(batch)
         import torch
@@ -315,6 +316,15 @@ class BatchSimulator:
         res.timing = dict(kernel_a_ms=timing[0], launches_a=int(timing[1]), kernel_b_ms=timing[2], launches_b=int(timing[3]),
                           loop_wall_ms=timing[4], host_bif_ms=timing[5], bif_requests=int(timing[6]), hbm_bytes=int(timing[7]))
         return res
+
+    def trace(self):
+        """int32 [B, n_iter, 4]: arterial nodes, O2 sinks, venous nodes, CO2 sources at the end of every iteration of the last run
+        (the reference's per-step statistics, greenhouse.py:129-134)."""
+        n_iter = sum(int(m["I"]) for m in self._config["Greenhouse"]["modes"] if int(m["I"]) > 0)
+        out = np.zeros((self.batch, n_iter, 4), np.int32)
+        if n_iter:
+            _native.check(self._lib.octa_sim_trace(self._h, out.ctypes.data), "octa_sim_trace")
+        return out
 
     def fields(self, k):
         oxy, co2 = np.zeros((16384, 3)), np.zeros((16384, 3))
@@ -416,9 +426,18 @@ class Greenhouse:
                                       np.asarray(py_state, np.uint32)[None])
             after = sim.np_state(0)
             self.oxys, self.co2s = sim.fields(0)
+            tr = sim.trace()[0]
+            wall = float(res.timing["loop_wall_ms"]) * 1e-3
         finally:
             sim.close()
         self.result = res
+        # the reference's per-step statistics (greenhouse.py:72-76, 128-134): lists that start with 0 and gain one entry per iteration;
+        # the device records no per-iteration clock, so the run's wall time is spread evenly over time_per_step
+        self.art_nodes_per_step = [0] + [int(v) for v in tr[:, 0]]
+        self.oxys_per_step = [0] + [int(v) for v in tr[:, 1]]
+        self.ven_nodes_per_step = [0] + [int(v) for v in tr[:, 2]]
+        self.co2_per_step = [0] + [int(v) for v in tr[:, 3]]
+        self.time_per_step = [wall / max(len(tr), 1)] * len(tr)
         art, ven = res.arterial_venous(0)
         kappa = self.modes[-1]["kappa"]
         self.arterial_forest._load_rows(art, kappa)
@@ -427,3 +446,34 @@ class Greenhouse:
         # `random.uniform draws` draws of random.random() (the cached second normal of FAZ_radius' np.random.normal stays cached)
         np.random.set_state((kind, after[:624], int(after[624]), has_gauss, _))
         _native.advance_python_random(int(res.stats[0, 1]))
+
+    def save_stats(self, out_dir: str):
+        """The four PNG plots of the reference's Greenhouse.save_stats (greenhouse.py:401-441: final O2 / CO2 sink distributions,
+        runtime per iteration, growth over time) from the device run's fields and per-iteration statistics. Needs matplotlib (a
+        plotting dependency of the reference, not of the hot path)."""
+        import time
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        os.makedirs(out_dir, exist_ok=True)
+        for pts, style, title, name in ((self.oxys, "r.", "Final Oxygen Sink Distribution", "oxy_distribution"),
+                                        (self.co2s, "b.", "Final CO\u2082 Sink Distribution", "co2_distribution")):
+            plt.figure(figsize=(6, 6))
+            if len(pts) > 0:
+                plt.plot(pts[:, 1], 1 - pts[:, 0], style)
+            plt.xlim(0, 1); plt.ylim(0, 1)
+            plt.title(title)
+            plt.savefig(f"{out_dir}/{name}.png", bbox_inches="tight")
+            plt.close()
+        plt.figure(figsize=(6, 6))
+        plt.plot(self.time_per_step)
+        plt.title(f"Runtime Per Iteration (Total={time.strftime('%H:%M:%S', time.gmtime(sum(self.time_per_step)))})")
+        plt.xlabel("Iterations"); plt.ylabel("Seconds")
+        plt.savefig(f"{out_dir}/time_per_step.png", bbox_inches="tight")
+        plt.close()
+        plt.figure(figsize=(6, 6))
+        plt.plot(self.art_nodes_per_step); plt.plot(self.oxys_per_step); plt.plot(self.ven_nodes_per_step); plt.plot(self.co2_per_step)
+        plt.legend(["Arterial Nodes", "Oxygen Sinks", "Venous Nodes", "CO\u2082 Sources"])
+        plt.title("Growth Over Time"); plt.xlabel("Iterations"); plt.ylabel("Amount")
+        plt.savefig(f"{out_dir}/growth_over_time.png", bbox_inches="tight")
+        plt.close()

@@ -91,3 +91,10 @@ def test_develop_forest_equals_reference_run(name, tmp_path, hip_lib_built):
         assert [random.random(), float(np.random.random_sample())] == list(g[name + "_next"])
     leaf = [n for n in ven.get_nodes() if n.is_leaf][0]
     assert leaf.proximal_num_segments >= 1 and leaf.get_proximal_radius() == leaf.radius
+    # the reference's per-step statistics and its save_stats plots (greenhouse.py:72-76, 128-134, 401-441)
+    tr = g[name + "_trace"]
+    assert greenhouse.art_nodes_per_step == [0] + tr[:, 0].tolist() and greenhouse.oxys_per_step == [0] + tr[:, 1].tolist()
+    assert greenhouse.ven_nodes_per_step == [0] + tr[:, 2].tolist() and greenhouse.co2_per_step == [0] + tr[:, 3].tolist()
+    assert len(greenhouse.time_per_step) == len(tr)
+    greenhouse.save_stats(str(tmp_path / "stats"))
+    assert sorted(os.listdir(tmp_path / "stats")) == ["co2_distribution.png", "growth_over_time.png", "oxy_distribution.png", "time_per_step.png"]

@@ -41,6 +41,8 @@ def test_short_runs_match_reference_csv(gh, golden):
         oxy, co2 = sim.fields(k)
         assert (oxy == golden[name + "_oxy"]).all() and (co2 == golden[name + "_co2"]).all()
         assert res.stats[k, 0] == 0
+        # the reference's per-iteration statistics (nodes / sinks after every iteration), recorded on the device (round 3)
+        assert (sim.trace()[k] == golden[name + "_trace"]).all(), name
     sim.close()
 
 
@@ -60,6 +62,7 @@ def test_nerve_forest_runs_match_reference_csv(gh, golden):
         assert gh.edges_to_csv_text(res.sample_edges(0)).encode() == golden[name + "_csv"].tobytes(), name
         oxy, co2 = sim.fields(0)
         assert (oxy == golden[name + "_oxy"]).all() and (co2 == golden[name + "_co2"]).all()
+        assert (sim.trace()[0] == golden[name + "_trace"]).all(), name
         sim.close()
     from octa_autosegmentation_amd import _native
     cfg = yaml.safe_load(str(golden["nerve_config_yaml"]))

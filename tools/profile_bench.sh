@@ -1,19 +1,19 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
-#   1. --kernel-trace --stats of the default bench command        -> gpurun_out/r02_bench_kernel_stats.csv
-#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, one counter per pass -> gpurun_out/r02_bench_pmc_summary.csv
+#   1. --kernel-trace --stats of the default bench command        -> gpurun_out/r03_bench_kernel_stats.csv
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, one counter per pass -> gpurun_out/r03_bench_pmc_summary.csv
 # (counter passes never combined with tracing: see the task's profiling rules)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out
 mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_stdout.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py --no-cpu-baseline --no-pmc > $OUT/${TAG}_bench_stdout.log 2>&1
 find $OUT/prof_kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
 rm -rf $OUT/prof_kt   # the raw trace is large; only the summary is kept
 grep '"metric"' $OUT/${TAG}_bench_stdout.log | tail -1 > $OUT/${TAG}_bench_line.json
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 2 --warmup 1 --inflight 1 --group 1 --no-cpu-baseline --no-train --no-files > $OUT/${TAG}_pmc_$C.log 2>&1
+  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 2 --warmup 1 --inflight 1 --group 1 --no-cpu-baseline --no-train --no-files --no-pmc > $OUT/${TAG}_pmc_$C.log 2>&1
 done
 python - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, collections
