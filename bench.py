@@ -312,9 +312,10 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--inflight", type=int, default=4, help="launches in flight per GPU (each on its own HIP stream)")
-    ap.add_argument("--group", type=int, default=1, help="steps (batches) simulated by one launch of the persistent kernel (measured: 4 steps per "
-                    "launch with 3 launches in flight gains 3.5 %% at --steps 20 and loses as much at --steps 8; one step per launch is the default)")
+    ap.add_argument("--inflight", type=int, default=1, help="launches in flight per GPU (each on its own HIP stream)")
+    ap.add_argument("--group", type=int, default=4, help="steps (128-sample batches) simulated by ONE launch of the persistent kernel. Round 3: a "
+                    "launch of 4 x 128 samples fills the GPU's 512 workgroup slots (two samples per CU) and the rasteriser then has the whole GPU; "
+                    "measured on one box: group / inflight 4/1 681, 4/2 644, 2/2 620, 1/4 616, 2/3 567 samples/s (rounds 1-2: 1 step per launch, 4 in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 counter passes (roofline.traffic then comes from the committed file)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -436,21 +437,20 @@ def main():
     raster = None
     sample_ms, solo_launch_ms = sample_ms_loaded, None
     if rank == 0:
-        g0 = gens[G][0]
+        g0 = pipeline.TripleGenerator(cfg, B)                            # ONE 128-sample batch: every sample alone on its CU
         g0.time_render = True
         best = None
         solo = []
         for rep in range(3):
             with torch.cuda.stream(streams[0]):
-                o = g0.generate(np.concatenate([sharding.rank_seeds(rank, 900 + G * rep + k, B) for k in range(G)]))
+                o = g0.generate(sharding.rank_seeds(rank, 900 + rep, B))
                 streams[0].synchronize()
             ms = pipeline.TripleGenerator.render_ms(o)
             best = ms if best is None else {k: min(best[k], ms[k]) for k in ms}
             solo.append((phase_ms(o["result"].stats), o["result"].timing["kernel_b_ms"]))
         sample_ms = float(np.mean([a for a, _ in solo]))            # one launch with the GPU to itself
         solo_launch_ms = float(np.mean([b for _, b in solo]))
-        g0.time_render = False
-        best = {k: v / G for k, v in best.items()}                       # per 128-sample batch
+        g0.close()
         lab, img = best["label_raster_ms"], best["image_raster_ms"]
         raster = {"kernel": "octa_rasterize_2d launch sequence (raster_meta / scan / tess / render)", "bound": "hbm",
                   "label_1216": {"ms_per_batch": lab, "achieved": RASTER_BYTES_1216 * B / (lab * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -462,7 +462,9 @@ def main():
 
     files_info = None
     if rank == 0 and not args.no_files:
-        files_info = files_leg(gens[G][0], streams[0], np.concatenate([sharding.rank_seeds(rank, 950 + k, B) for k in range(G)]))
+        gf = pipeline.TripleGenerator(cfg, B)
+        files_info = files_leg(gf, streams[0], sharding.rank_seeds(rank, 950, B))
+        gf.close()
 
     # secondary metric of BASELINE.json: DynUNet-S training images/s at 1x1216x1216, bf16, on the MFMA convolution
     # path; reported so the gap to the 200 imgs/s target is tracked, it is NOT part of `value`.
@@ -512,10 +514,9 @@ def main():
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         traffic = None
         if world == 1 and not args.no_pmc and la == 0:
-            traffic, traffic_src = pmc_traffic_live(dom_name, B)          # per launch of B samples
-            if traffic is not None:
-                traffic = traffic * (args.steps * B / max(dom_n, 1)) / B
-            else:
+            per_launch = max(1, args.steps * B // max(dom_n, 1))            # samples one launch of this run simulates
+            traffic, traffic_src = pmc_traffic_live(dom_name, per_launch)
+            if traffic is None:
                 print(f"[bench] live counter passes unavailable ({traffic_src}); using the committed summary", file=sys.stderr)
         if traffic is None:
             traffic, traffic_src = pmc_traffic_per_launch(dom_name)
@@ -548,13 +549,13 @@ def main():
                          "traffic_unit": f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE; {traffic_src})",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": launch_ms, "launches": dom_n, "note": note,
-                         "serial_depth": {"per_sample_device_ms": sample_ms, "per_sample_device_ms_with_4_launches_in_flight": sample_ms_loaded,
+                         "serial_depth": {"per_sample_device_ms": sample_ms, "per_sample_device_ms_all_slots_taken": sample_ms_loaded,
                                           "solo_launch_ms": solo_launch_ms, "cus": N_CUS, "workgroups_per_cu": wg_per_cu,
                                           "threads_per_workgroup": int(geo[0]), "lds_bytes_per_workgroup": int(geo[2]),
                                           "bound_samples_per_s": bound_samples_s, "frac_of_bound": per_gpu / bound_samples_s,
                                           "note": f"a sample occupies one of the {wg_per_cu} workgroup slots of a CU ({int(geo[2]) // 1024} KiB of LDS, "
                                                   f"{int(geo[0])} threads at 256 registers) for per_sample_device_ms when its launch has the GPU to itself "
-                                                  "(one sample per CU) and for ..._with_4_launches_in_flight when every slot is taken (the co-resident "
+                                                  "(one sample per CU: the solo leg runs 128 samples) and for ..._all_slots_taken in the timed launches (the co-resident "
                                                   "sample shares the CU's issue slots, LDS and L1); CUs x slots / that time is what the simulator could "
                                                   "reach alone on the GPU; this dependency chain, not HBM, is the binding limit"},
                          "rasteriser": raster},
