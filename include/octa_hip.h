@@ -514,6 +514,11 @@ int octa_sim_service_stats(octa_sim *sim, double *h_out5);
  * (greenhouse.py:57-137 runs one sample per worker process). */
 int octa_sim_geometry(int num_cus, int *h_out4);
 
+/* 1 when the simulator was bound to the wide-field build (32-bit indices, 64-bit kd elements, per-sample tables in HBM instead of
+ * LDS: the reference's 12 x 12 mm^2 notebook configuration, example_custom_vessel_simulation.ipynb:138-156), 0 for the default build.
+ * Chosen by octa_sim_create from the configuration; OCTA_SIM_BUILD=large / default overrides. */
+int octa_sim_is_large(const octa_sim *sim);
+
 /* Final O2 / CO2 fields of one sample (host buffers, capacity in points); returns counts. */
 int octa_sim_fields(octa_sim *sim, int sample, double *h_oxy, int64_t cap_oxy, int64_t *n_oxy, double *h_co2,
                     int64_t cap_co2, int64_t *n_co2);

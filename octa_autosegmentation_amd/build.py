@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liboctahip.so")
-SOURCES = ["common.cpp", "bif_native.cpp", "fileio.cpp", "raster.hip", "sim.hip", "voxel.hip", "graphio.hip", "norm.hip", "conv.hip", "conv_f32.hip", "augment.hip", "postproc.hip", "loss.hip", "blur.hip", "thin_conv.hip"]
+SOURCES = ["common.cpp", "bif_native.cpp", "fileio.cpp", "sim_api.cpp", "raster.hip", "sim.hip", "sim.hip@large", "voxel.hip", "graphio.hip", "norm.hip", "conv.hip", "conv_f32.hip", "augment.hip", "postproc.hip", "loss.hip", "blur.hip", "thin_conv.hip"]
 HEADERS = ["common.h", "raster_core.h", "sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h", "glibc_trig.h", "glibc_trig_tables.h",
            os.path.join("..", "..", "include", "octa_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-ldl", "-lz"]
@@ -24,7 +24,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s.partition("@")[0]) for s in SOURCES + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -49,9 +49,12 @@ def build(force=False, verbose=False):
     cflags = [f for f in FLAGS if f not in ("-shared", "-ldl", "-lz")] + os.environ.get("OCTA_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
     jobs = []
     for s in SOURCES:
-        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + ".o")
-        if force or _stale(obj, src, mt(common + own.get(s, []))):
-            jobs.append([hipcc] + cflags + ["-c", src, "-o", obj])
+        # "file@variant": the same source compiled again with -DOCTA_SIM_LARGE=1 (the wide-field build of the simulator, csrc/sim_api.cpp)
+        name, _, variant = s.partition("@")
+        src, obj = os.path.join(CSRC, name), os.path.join(objdir, s + ".o")
+        extra = ["-DOCTA_SIM_LARGE=1"] if variant == "large" else []
+        if force or _stale(obj, src, mt(common + own.get(name, []))):
+            jobs.append([hipcc] + cflags + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -21,14 +21,47 @@
 #include <thread>
 #include <cstdlib>
 
-using namespace octa_simk;
+using namespace OCTA_SIMK;
+
+// This file is compiled TWICE (build.py): the default build for the 3 x 3 mm^2 configurations (LDS-resident tables, two samples per
+// CU) and -DOCTA_SIM_LARGE=1 for wide fields of view (sim_core.h). Each build exports its entry points under its own suffix;
+// csrc/sim_api.cpp owns the public octa_sim_* names of include/octa_hip.h and picks the build per simulator (octa_sim_create).
+#if OCTA_SIM_LARGE
+#define OCTA_SIM_T octa_simL_impl
+#define OCTA_SIM_FN(name) octa_simL_##name
+#else
+#define OCTA_SIM_T octa_simS_impl
+#define OCTA_SIM_FN(name) octa_simS_##name
+#endif
+#define octa_sim_create OCTA_SIM_FN(create)
+#define octa_sim_destroy OCTA_SIM_FN(destroy)
+#define octa_sim_run OCTA_SIM_FN(run)
+#define octa_sim_run_states OCTA_SIM_FN(run_states)
+#define octa_sim_np_state OCTA_SIM_FN(np_state)
+#define octa_sim_edge_offsets OCTA_SIM_FN(edge_offsets)
+#define octa_sim_export_edges OCTA_SIM_FN(export_edges)
+#define octa_sim_export_edges_device OCTA_SIM_FN(export_edges_device)
+#define octa_sim_trace OCTA_SIM_FN(trace)
+#define octa_sim_stats OCTA_SIM_FN(stats)
+#define octa_sim_fields OCTA_SIM_FN(fields)
+#define octa_sim_service_stats OCTA_SIM_FN(service_stats)
+#define octa_sim_geometry OCTA_SIM_FN(geometry)
+#define octa_sim_spans OCTA_SIM_FN(spans)
+#define octa_sim_timing OCTA_SIM_FN(timing)
+#define octa_sim_kat_kd_order OCTA_SIM_FN(kat_kd_order)
+struct OCTA_SIM_T;
+extern "C" void octa_sim_destroy(OCTA_SIM_T *S);
 
 namespace {
 
 constexpr int SIM_THREADS = SIM_THREADS_PER_WG;   // 256: 4 waves, one per SIMD -- at 256 VGPRs per lane two such workgroups fill a CU's register files
 constexpr int SIM_WG_PER_CU = 2;       // 2 x 80 KiB of LDS: while one sample is in a single-wave ordered pass the other's parallel phases use the CU
+#if OCTA_SIM_LARGE
+constexpr size_t SIM_LDS = 2048;            // collectives only: the table area of a workgroup is HBM scratch (BatchPtrs::wg_scratch)
+#else
 constexpr size_t SIM_LDS = SIM_LDS_BYTES;
-static_assert(2048 + (size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES <= SIM_LDS && SIM_WG_PER_CU * SIM_LDS <= 160 * 1024, "LDS budget");
+static_assert((size_t)KD_MAILBOX_OFF + KD_MAILBOX_BYTES <= (size_t)SIM_USER_BYTES && SIM_WG_PER_CU * SIM_LDS <= 160 * 1024, "LDS budget");
+#endif
 static_assert((624 + 1248) * 4 <= SEQ_SIDE_LDS, "the Mersenne-Twister state and queue of the candidate stream fit the side-job LDS");
 static_assert(SIM_THREADS == 64 * KD_WAVES, "kd mailboxes are sized for KD_WAVES waves");
 constexpr int REQ_CAP = 8192;
@@ -47,7 +80,7 @@ struct BatchPtrs {
     int *gnode, *gstart, *gcount;
     Rec *rec;
     int *glist, *child_group, *node_group;
-    unsigned short *kd_idx, *kd_rank;
+    idx_t *kd_idx, *kd_rank;
     unsigned char *removed, *ven_near;
     unsigned long long *hashes;
     unsigned *pairs;
@@ -66,6 +99,7 @@ struct BatchPtrs {
     unsigned *valid_count;       // [B]
     int *n_per_iter;             // [n_iter]
     int *next_sample;            // [1] work queue of the persistent kernel
+    unsigned char *wg_scratch;   // large build: [B][SIM_USER_BYTES] table area of the workgroup that runs sample s (Blk::umem); else null
     int *trace;                  // [B][n_iter][4] arterial nodes, O2 sinks, venous nodes, CO2 sources at the end of every iteration (greenhouse.py:129-134)
     int n_samples;
     SimConst C;
@@ -268,6 +302,7 @@ sim_iter_a_kernel(BatchPtrs B, int it, int finish_prev) {
     const int s = blockIdx.x;
     SimArrays A = sample_arrays(B, s);
     Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
+    if (B.wg_scratch) b.umem = B.wg_scratch + (size_t)s * SIM_USER_BYTES;
     if (A.sc->err) return;
     if (finish_prev) {
         const IterParams Pp = B.iters[it - 1];
@@ -300,6 +335,7 @@ sim_iter_b_kernel(BatchPtrs B, int it) {
     const int s = blockIdx.x;
     SimArrays A = sample_arrays(B, s);
     Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
+    if (B.wg_scratch) b.umem = B.wg_scratch + (size_t)s * SIM_USER_BYTES;
     if (A.sc->err) return;
     const IterParams P = B.iters[it];
     OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, B.bif_results));
@@ -322,7 +358,7 @@ struct HostMail {
     long timeout_ticks;  // device-side bound on one wait for the host (100 MHz wall clock)
     long park_ticks;     // a workgroup that has waited this long parks (0: never, wait until timeout_ticks as round 1 did)
 };
-constexpr int REQ_PER_SAMPLE = 32;
+constexpr int REQ_PER_SAMPLE = OCTA_SIM_LARGE ? 256 : 32;    // bifurcation requests of one sample per mailbox round trip (6.2 KB each, pinned host memory)
 constexpr int ERR_HOST_TIMEOUT = 2048;
 
 // One request / answer round trip with the host service thread (octa_sim_run). Returns 0 when the answer is in
@@ -491,7 +527,9 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
         const int s = *next;
         b.sync();
         if (s >= B.n_samples) break;
-        run_sample(B, M, s, b);
+        Blk bs = b;
+        if (B.wg_scratch) bs.umem = B.wg_scratch + (size_t)s * SIM_USER_BYTES;     // large build: this sample's table area in HBM
+        run_sample(B, M, s, bs);
     }
 }
 
@@ -507,8 +545,9 @@ sim_export_kernel(BatchPtrs B, const long *__restrict__ edge_off, int n_trees, d
     const int s = blockIdx.x, f = blockIdx.y;
     SimArrays A = sample_arrays(B, s);
     Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
-    unsigned short *cur = reinterpret_cast<unsigned short *>(b.user());
-    unsigned short *nxt = cur + NCAP;
+    if (B.wg_scratch) b.umem = B.wg_scratch + (size_t)s * SIM_USER_BYTES + (size_t)f * 2 * NCAP * sizeof(idx_t);   // the two forests' frontiers side by side
+    idx_t *cur = reinterpret_cast<idx_t *>(b.user());
+    idx_t *nxt = cur + NCAP;
     const int n_art_rows = A.sc->n_nodes[0] - n_trees;
     long row = edge_off[s] + (f ? n_art_rows : 0);
     const double *pos = A.npos[f], *rad = A.nrad[f];
@@ -516,7 +555,7 @@ sim_export_kernel(BatchPtrs B, const long *__restrict__ edge_off, int n_trees, d
     const unsigned char *nch = A.nnch[f];
     for (int t = 0; t < n_trees; t++) {
         b.sync();
-        if (b.tid == 0) cur[0] = (unsigned short)(2 * t);
+        if (b.tid == 0) cur[0] = (idx_t)(2 * t);
         b.sync();
         int n_cur = 1;
         while (n_cur > 0) {
@@ -527,8 +566,8 @@ sim_export_kernel(BatchPtrs B, const long *__restrict__ edge_off, int n_trees, d
                 if (i < n_cur) { id = cur[i]; nc = nch[id]; if (nc > 2) nc = 2; }
                 int ex;
                 const int tot = blk_scan(b, nc, &ex);
-                if (nc >= 1 && base + ex < NCAP) nxt[base + ex] = (unsigned short)c0[id];
-                if (nc >= 2 && base + ex + 1 < NCAP) nxt[base + ex + 1] = (unsigned short)c1[id];
+                if (nc >= 1 && base + ex < NCAP) nxt[base + ex] = (idx_t)c0[id];
+                if (nc >= 2 && base + ex + 1 < NCAP) nxt[base + ex + 1] = (idx_t)c1[id];
                 base += tot;
             }
             b.sync();
@@ -541,7 +580,7 @@ sim_export_kernel(BatchPtrs B, const long *__restrict__ edge_off, int n_trees, d
                 e[6] = rad[v];
             }
             row += n_next;
-            unsigned short *tmp = cur; cur = nxt; nxt = tmp;
+            idx_t *tmp = cur; cur = nxt; nxt = tmp;
             n_cur = n_next;
             b.sync();
         }
@@ -550,7 +589,7 @@ sim_export_kernel(BatchPtrs B, const long *__restrict__ edge_off, int n_trees, d
 
 }  // namespace
 
-struct octa_sim {
+struct OCTA_SIM_T {
     octa_ctx *ctx = nullptr;
     int B = 0;
     SimConfig cfg;
@@ -590,7 +629,7 @@ struct octa_sim {
 namespace {
 
 template <class T>
-int dev_alloc(octa_sim *S, T **p, size_t count) {
+int dev_alloc(OCTA_SIM_T *S, T **p, size_t count) {
     void *q = nullptr;
     size_t bytes = count * sizeof(T);
     hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
@@ -603,12 +642,12 @@ int dev_alloc(octa_sim *S, T **p, size_t count) {
 
 }  // namespace
 
-extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, octa_sim **out) {
+extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, OCTA_SIM_T **out) {
     if (!ctx || !c || !out || B <= 0) { octa::set_error("octa_sim_create: bad arguments"); return -2; }
     *out = nullptr;
     if (c->n_modes < 1 || c->n_modes > 8) { octa::set_error("octa_sim_create: n_modes must be 1..8"); return -2; }
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
-    octa_sim *S = new (std::nothrow) octa_sim();
+    OCTA_SIM_T *S = new (std::nothrow) OCTA_SIM_T();
     if (!S) { octa::set_error("octa_sim_create: out of host memory"); return -1; }
     S->ctx = ctx;
     S->B = B;
@@ -665,6 +704,10 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     rc |= dev_alloc(S, &P.n_per_iter, S->iters.size() + 1);  // kept for diagnostics
     rc |= dev_alloc(S, &P.next_sample, 4);
     rc |= dev_alloc(S, &P.trace, nb * (S->iters.size() + 1) * 4);
+    P.wg_scratch = nullptr;
+#if OCTA_SIM_LARGE
+    rc |= dev_alloc(S, &P.wg_scratch, nb * (size_t)SIM_USER_BYTES);
+#endif
     P.n_samples = B;
     if (!rc) {
         hipError_t e1 = hipHostMalloc((void **)&S->h_reqs, sizeof(BifRequest) * 2 * REQ_CAP);
@@ -705,7 +748,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, o
     return 0;
 }
 
-extern "C" void octa_sim_destroy(octa_sim *S) {
+extern "C" void octa_sim_destroy(OCTA_SIM_T *S) {
     if (!S) return;
     hipError_t e = hipSetDevice(S->ctx->device);
     for (void *p : S->allocs) e = hipFree(p);
@@ -739,10 +782,10 @@ struct SampleSource {
         init_sample_given(cfg, faz[s], stumps + (size_t)s * 2 * n, stumps + (size_t)s * 2 * n + n, np, py, I);
     }
 };
-int sim_run_impl(octa_sim *S, const SampleSource &src, octa_bif_fn bif, void *user, void *stream_);
+int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *user, void *stream_);
 }  // namespace
 
-extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint64_t *h_py_seeds, octa_bif_fn bif, void *user,
+extern "C" int octa_sim_run(OCTA_SIM_T *S, const uint32_t *h_np_seeds, const uint64_t *h_py_seeds, octa_bif_fn bif, void *user,
                             void *stream_) {
     if (!S || !h_np_seeds || !h_py_seeds || !bif) { octa::set_error("octa_sim_run: bad arguments"); return -2; }
     SampleSource src;
@@ -750,7 +793,7 @@ extern "C" int octa_sim_run(octa_sim *S, const uint32_t *h_np_seeds, const uint6
     return sim_run_impl(S, src, bif, user, stream_);
 }
 
-extern "C" int octa_sim_run_states(octa_sim *S, const double *h_faz_radius, const double *h_stumps, const uint32_t *h_np_states,
+extern "C" int octa_sim_run_states(OCTA_SIM_T *S, const double *h_faz_radius, const double *h_stumps, const uint32_t *h_np_states,
                                    const uint32_t *h_py_states, octa_bif_fn bif, void *user, void *stream_) {
     if (!S || !h_faz_radius || !h_stumps || !h_np_states || !h_py_states || !bif) { octa::set_error("octa_sim_run_states: bad arguments"); return -2; }
     for (int s = 0; s < S->B; s++)
@@ -761,7 +804,7 @@ extern "C" int octa_sim_run_states(octa_sim *S, const double *h_faz_radius, cons
 }
 
 // numpy's generator of sample `sample` after the run: 624 words + position (the candidate stream is its only consumer)
-extern "C" int octa_sim_np_state(octa_sim *S, int sample, uint32_t *h_state625) {
+extern "C" int octa_sim_np_state(OCTA_SIM_T *S, int sample, uint32_t *h_state625) {
     if (!S || !S->ran || !h_state625 || sample < 0 || sample >= S->B) { octa::set_error("octa_sim_np_state: bad arguments"); return -2; }
     OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
     OCTA_HIP_CHECK(hipMemcpy(h_state625, S->P.mt_state + (size_t)sample * 625, 625 * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -769,7 +812,7 @@ extern "C" int octa_sim_np_state(octa_sim *S, int sample, uint32_t *h_state625) 
 }
 
 namespace {
-int sim_run_impl(octa_sim *S, const SampleSource &src, octa_bif_fn bif, void *user, void *stream_) {
+int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *user, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
     const int B = S->B;
@@ -1001,7 +1044,7 @@ int sim_run_impl(octa_sim *S, const SampleSource &src, octa_bif_fn bif, void *us
 }
 }  // namespace
 
-extern "C" int octa_sim_edge_offsets(octa_sim *S, int64_t *h_edge_off, int64_t *h_n_art) {
+extern "C" int octa_sim_edge_offsets(OCTA_SIM_T *S, int64_t *h_edge_off, int64_t *h_n_art) {
     if (!S || !S->ran || !h_edge_off) { octa::set_error("octa_sim_edge_offsets: run the simulation first"); return -2; }
     h_edge_off[0] = 0;
     for (int s = 0; s < S->B; s++) {
@@ -1013,7 +1056,7 @@ extern "C" int octa_sim_edge_offsets(octa_sim *S, int64_t *h_edge_off, int64_t *
     return 0;
 }
 
-extern "C" int octa_sim_export_edges(octa_sim *S, double *h_edges) {
+extern "C" int octa_sim_export_edges(OCTA_SIM_T *S, double *h_edges) {
     if (!S || !S->ran || !h_edges) { octa::set_error("octa_sim_export_edges: run the simulation first"); return -2; }
     OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
     const BatchPtrs &P = S->P;
@@ -1071,7 +1114,7 @@ extern "C" int octa_sim_export_edges(octa_sim *S, double *h_edges) {
     return 0;
 }
 
-extern "C" int octa_sim_export_edges_device(octa_sim *S, double *d_edges, void *stream_) {
+extern "C" int octa_sim_export_edges_device(OCTA_SIM_T *S, double *d_edges, void *stream_) {
     if (!S || !S->ran || !d_edges) { octa::set_error("octa_sim_export_edges_device: run the simulation first"); return -2; }
     OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
@@ -1081,20 +1124,20 @@ extern "C" int octa_sim_export_edges_device(octa_sim *S, double *d_edges, void *
     if (!S->d_edge_off) OCTA_HIP_CHECK(hipMalloc(&S->d_edge_off, sizeof(long) * (B + 1)));
     OCTA_HIP_CHECK(hipMemcpyAsync(S->d_edge_off, off.data(), sizeof(long) * (B + 1), hipMemcpyHostToDevice, stream));
     OCTA_HIP_CHECK(hipStreamSynchronize(stream));     // `off` is a local; the copy is a few hundred bytes
-    const size_t lds = 2048 + (size_t)NCAP * 2 * 2;
+    const size_t lds = OCTA_SIM_LARGE ? 2048 : 2048 + (size_t)NCAP * 2 * sizeof(idx_t);
     hipLaunchKernelGGL(sim_export_kernel, dim3((unsigned)B, 2), dim3(256), lds, stream, S->P, S->d_edge_off, S->cfg.n_trees, d_edges);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-extern "C" int octa_sim_trace(octa_sim *S, int32_t *h_trace) {
+extern "C" int octa_sim_trace(OCTA_SIM_T *S, int32_t *h_trace) {
     if (!S || !S->ran || !h_trace) { octa::set_error("octa_sim_trace: run the simulation first"); return -2; }
     OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
     OCTA_HIP_CHECK(hipMemcpy(h_trace, S->P.trace, sizeof(int32_t) * (size_t)S->B * S->iters.size() * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 
-extern "C" int octa_sim_stats(octa_sim *S, int64_t *h_stats) {
+extern "C" int octa_sim_stats(OCTA_SIM_T *S, int64_t *h_stats) {
     if (!S || !S->ran || !h_stats) { octa::set_error("octa_sim_stats: run the simulation first"); return -2; }
     for (int s = 0; s < S->B; s++) {
         const SampleScalars &sc = S->h_sc[s];
@@ -1108,7 +1151,7 @@ extern "C" int octa_sim_stats(octa_sim *S, int64_t *h_stats) {
     return 0;
 }
 
-extern "C" int octa_sim_fields(octa_sim *S, int sample, double *h_oxy, int64_t cap_oxy, int64_t *n_oxy, double *h_co2,
+extern "C" int octa_sim_fields(OCTA_SIM_T *S, int sample, double *h_oxy, int64_t cap_oxy, int64_t *n_oxy, double *h_co2,
                                int64_t cap_co2, int64_t *n_co2) {
     if (!S || !S->ran || sample < 0 || sample >= S->B) { octa::set_error("octa_sim_fields: bad arguments"); return -2; }
     OCTA_HIP_CHECK(hipSetDevice(S->ctx->device));
@@ -1126,9 +1169,10 @@ extern "C" int octa_sim_fields(octa_sim *S, int sample, double *h_oxy, int64_t c
     return 0;
 }
 
+#if !OCTA_SIM_LARGE
 namespace {
 __global__ void __launch_bounds__(SIM_THREADS)
-sim_kat_kd_kernel(const double *pts, int n, const unsigned char *need, unsigned short *out_idx, unsigned short *out_rank, float *xy, double zlo, double zhi) {
+sim_kat_kd_kernel(const double *pts, int n, const unsigned char *need, idx_t *out_idx, idx_t *out_rank, float *xy, double zlo, double zhi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
     kd_build(b, pts, n, out_idx, out_rank, xy, zlo, zhi, nullptr, need);
@@ -1141,13 +1185,13 @@ extern "C" int octa_sim_kat_kd_order(octa_ctx *ctx, const double *h_pts, int64_t
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     double *d_pts = nullptr;
     unsigned char *d_need = nullptr;
-    unsigned short *d_idx = nullptr;
+    idx_t *d_idx = nullptr;
     float *d_xy = nullptr;
     double zlo = h_pts[2], zhi = h_pts[2];
     for (int64_t i = 1; i < n; i++) { zlo = h_pts[3 * i + 2] < zlo ? h_pts[3 * i + 2] : zlo; zhi = h_pts[3 * i + 2] > zhi ? h_pts[3 * i + 2] : zhi; }
     OCTA_HIP_CHECK(hipMalloc(&d_xy, sizeof(float) * 2 * n));
     OCTA_HIP_CHECK(hipMalloc(&d_pts, sizeof(double) * 3 * n));
-    OCTA_HIP_CHECK(hipMalloc(&d_idx, sizeof(unsigned short) * 2 * n));
+    OCTA_HIP_CHECK(hipMalloc(&d_idx, sizeof(idx_t) * 2 * n));
     OCTA_HIP_CHECK(hipMemcpy(d_pts, h_pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
     if (h_need) {
         OCTA_HIP_CHECK(hipMalloc(&d_need, n));
@@ -1156,14 +1200,16 @@ extern "C" int octa_sim_kat_kd_order(octa_ctx *ctx, const double *h_pts, int64_t
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(sim_kat_kd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIM_LDS));
     hipLaunchKernelGGL(sim_kat_kd_kernel, dim3(1), dim3(SIM_THREADS), SIM_LDS, 0, d_pts, (int)n, d_need, d_idx, d_idx + n, d_xy, zlo, zhi);
     OCTA_HIP_CHECK(hipGetLastError());
-    std::vector<unsigned short> h(n);
-    OCTA_HIP_CHECK(hipMemcpy(h.data(), d_idx, sizeof(unsigned short) * n, hipMemcpyDeviceToHost));
+    std::vector<idx_t> h(n);
+    OCTA_HIP_CHECK(hipMemcpy(h.data(), d_idx, sizeof(idx_t) * n, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; i++) h_indices[i] = (int32_t)h[i];
     (void)hipFree(d_pts); (void)hipFree(d_idx); (void)hipFree(d_xy); if (d_need) (void)hipFree(d_need);
     return 0;
 }
 
-extern "C" int octa_sim_service_stats(octa_sim *S, double *h_out4) {
+#endif
+
+extern "C" int octa_sim_service_stats(OCTA_SIM_T *S, double *h_out4) {
     if (!S || !S->ran || !h_out4) { octa::set_error("octa_sim_service_stats: run the simulation first"); return -2; }
     h_out4[0] = (double)S->diag_tickets; h_out4[1] = S->diag_max_gap_ms; h_out4[2] = (double)S->diag_relaunches; h_out4[3] = (double)S->diag_parked;
     h_out4[4] = S->diag_max_bif_ms;
@@ -1176,13 +1222,13 @@ extern "C" int octa_sim_geometry(int num_cus, int *h_out4) {
     return 0;
 }
 
-extern "C" int octa_sim_spans(octa_sim *S, int64_t *h_spans) {
+extern "C" int octa_sim_spans(OCTA_SIM_T *S, int64_t *h_spans) {
     if (!S || !S->ran || !h_spans) { octa::set_error("octa_sim_spans: run the simulation first"); return -2; }
     for (int s = 0; s < S->B; s++) { h_spans[2 * s] = S->h_sc[s].t_begin; h_spans[2 * s + 1] = S->h_sc[s].t_end; }
     return 0;
 }
 
-extern "C" int octa_sim_timing(octa_sim *S, double *h_out8) {
+extern "C" int octa_sim_timing(OCTA_SIM_T *S, double *h_out8) {
     if (!S || !S->ran || !h_out8) { octa::set_error("octa_sim_timing: run the simulation first"); return -2; }
     h_out8[0] = S->ms_a; h_out8[1] = (double)S->n_a; h_out8[2] = S->ms_b; h_out8[3] = (double)S->n_b;
     h_out8[4] = S->ms_total; h_out8[5] = S->ms_host_bif; h_out8[6] = (double)S->n_bif_req; h_out8[7] = (double)S->bytes;

@@ -30,10 +30,47 @@
 #include "gpow.h"
 #include "glibc_trig.h"
 
-namespace octa_simk {
+// Two builds of this header (round 3): the default one for the 3 x 3 mm^2 configurations -- every per-sample table of a phase fits
+// 78 KiB of LDS, indices are 16-bit, packed words carry 14-bit indices -- and OCTA_SIM_LARGE for wide fields of view (the reference's
+// notebook: 12 x 12 mm^2, N = 8000, 400 + 500 iterations, ~16 x the nodes and sinks): the same phases with 32-bit indices, 18-bit
+// packed indices, 64-bit kd elements, and the "LDS" user area of a workgroup placed in HBM / L2 scratch (Blk::umem). The large build
+// trades speed for capacity; it exists so that the path is COMPLETE for the reference's configurations.
+#ifndef OCTA_SIM_LARGE
+#define OCTA_SIM_LARGE 0
+#endif
+#if OCTA_SIM_LARGE
+#define OCTA_SIMK octa_simk_large
+#else
+#define OCTA_SIMK octa_simk
+#endif
+namespace OCTA_SIMK {
 
-constexpr int NCAP = 14336;    // nodes per forest (radii f64 + parent u16 of one forest + a 7.5 KiB side-job area fit the LDS in the ordered pass)
-constexpr int OCAP = 13312;    // live O2 sinks (LDS-resident kd keys bound this)
+#if OCTA_SIM_LARGE
+typedef unsigned int idx_t;            // point / node / position index of the per-phase tables
+typedef unsigned long long kdw_t;      // kd element: quantised key << IDX_BITS | point index
+constexpr int IDX_BITS = 18;           // index bits of packed words (kd elements, hit pairs, sorted attractor keys)
+constexpr int GROUP_BITS = 17;         // group index bits of child_group tags
+constexpr int NCAP = 1 << 17;          // nodes per forest
+constexpr int OCAP = 1 << 18;          // live O2 sinks
+constexpr int CCAP = OCAP;
+constexpr int GCAP = 1 << 17;          // nodes with attractors per growth pass
+constexpr int SORTCAP = OCAP;          // attractor keys of one assignment
+constexpr int PCAP = 1 << 21;          // (new node, sink) hit pairs per iteration: the FIRST iteration of a mode runs with the mode's raw radii
+                                       // (not yet divided by param_scale, greenhouse.py:84-85), so every new node of that iteration "reaches"
+                                       // a disc of eps_k = 0.0675 of the whole field -- 2 x 10^5 pairs at the notebook's mode switch
+constexpr int SETCAP = 1 << 20;        // slots of the emulated CPython set (a table never exceeds 8 x its entries; half is resize staging)
+constexpr int PYCAP = 1 << 20;         // pre-generated random.uniform draws per sample
+constexpr int ACCCAP = 8192;           // accepted sinks per iteration
+constexpr int GRID_MAX = 448;          // uniform-grid cells per axis
+constexpr int SIM_USER_BYTES = 12 << 20;  // per-workgroup table area (HBM scratch in this build): the largest tenant is the pair sort (4 B x PCAP)
+constexpr int LSET_PAIRS = 1 << 14, LSET_CAP = 1 << 18;   // the "LDS" set replay (wave-parallel resizes) takes every iteration of this build
+#else
+typedef unsigned short idx_t;
+typedef unsigned int kdw_t;
+constexpr int IDX_BITS = 14;
+constexpr int GROUP_BITS = 13;
+constexpr int NCAP = 14336;    // nodes per forest
+constexpr int OCAP = 13312;    // live O2 sinks (the LDS-resident kd elements bound this)
 constexpr int CCAP = OCAP;     // live CO2 sources (8192 until a full-length seed -- 953121 -- peaked at 8353; every scratch array the CO2 list
                                // passes through is sized for OCAP points)
 constexpr int GCAP = 8192;     // nodes with attractors per growth pass
@@ -41,21 +78,28 @@ constexpr int SORTCAP = 16384; // keys per block sort
 constexpr int PCAP = 16384;    // (new node, sink) hit pairs per iteration
 constexpr int SETCAP = 16384;  // slots of the emulated CPython set
 constexpr int PYCAP = 32768;   // pre-generated random.uniform draws per sample
+constexpr int ACCCAP = 2048;   // accepted sinks per iteration
+constexpr int GRID_MAX = 112;   // uniform-grid cells per axis (x, y); the thin z extent is not binned (cell ends int[112^2 + 1] + ids u16[GRID_N] = 77 KiB)
+constexpr int SIM_USER_BYTES = 78 * 1024;   // per-workgroup table area: LDS
+constexpr int LSET_PAIRS = 512, LSET_CAP = 4096;     // <= 512 keys: the table never exceeds 2048 slots (+ as many for the resize staging)
+#endif
+static_assert(OCAP <= (1 << IDX_BITS) && GCAP <= (1 << GROUP_BITS) && NCAP <= (1 << 30), "index widths");
+constexpr unsigned IDX_MASK = (1u << IDX_BITS) - 1u;
+constexpr idx_t IDX_NONE = (idx_t)~(idx_t)0;
 constexpr int MAXKEPT = 256;   // attractors shipped with one bifurcation request
 constexpr int NCANDCAP = 8192; // candidates per iteration
 constexpr int TILE = 1024;     // points per LDS tile in brute-force queries
-constexpr int ACCCAP = 2048;   // accepted sinks per iteration
-constexpr int KD_RANGES = 784;  // ranges per kd level (> OCAP / 17: a range that is split further holds at least 17 points)
-constexpr int KD_MAILBOX_OFF = OCAP * 4 + ((KD_RANGES * 9 + 15) / 16) * 16;   // LDS offset (after user()) of the swap mailbox / box table
+constexpr int KD_RANGES = OCAP / 17 + 1;  // ranges per kd level (a range that is split further holds at least 17 points)
+constexpr int KD_TAB_BYTES_PER_RANGE = 4 * (int)sizeof(idx_t) + 1;   // range start / end of two levels + split dimension
+constexpr int KD_MAILBOX_OFF = OCAP * (int)sizeof(kdw_t) + ((KD_RANGES * KD_TAB_BYTES_PER_RANGE + 15) / 16) * 16;   // offset (after user()) of the swap mailbox / box table
 constexpr int KD_TEAM_MIN = 192;   // ranges at least this long get a whole wave, shorter ones 16 lanes
 #ifndef OCTA_SIM_THREADS
 #define OCTA_SIM_THREADS 256
 #endif
 constexpr int SIM_THREADS_PER_WG = OCTA_SIM_THREADS;           // threads per simulator workgroup (build-time choice, see sim.hip)
 constexpr int KD_WAVES = SIM_THREADS_PER_WG / 64;              // waves per workgroup
-constexpr int KD_MAILBOX_BYTES = (OCAP / 2 + 64) * 2;          // one u16 slot per possible swap: ranges are disjoint
-constexpr int SIM_LDS_BYTES = 80 * 1024;   // dynamic LDS of the simulator kernels: half a CU's 160 KiB, so TWO workgroups (two samples) share a CU
-constexpr int GRID_MAX = 112;   // uniform-grid cells per axis (x, y); the thin z extent is not binned (cell ends int[112^2 + 1] + ids u16[GRID_N] = 77 KiB)
+constexpr int KD_MAILBOX_BYTES = (OCAP / 2 + 64) * (int)sizeof(idx_t);   // one slot per possible swap: ranges are disjoint
+constexpr int SIM_LDS_BYTES = SIM_USER_BYTES + 2048;   // default build: dynamic LDS of the simulator kernels = half a CU's 160 KiB, so TWO workgroups (two samples) share a CU
 
 enum ErrBits { ERR_NODE_CAP = 1, ERR_OXY_CAP = 2, ERR_CO2_CAP = 4, ERR_GROUP_CAP = 8, ERR_PAIR_CAP = 16, ERR_SET_CAP = 32,
                ERR_PY_CAP = 64, ERR_KEPT_CAP = 128, ERR_REQ_CAP = 256, ERR_ACC_CAP = 512, ERR_MISSING_BIF = 1024 };
@@ -81,8 +125,7 @@ struct __attribute__((aligned(8))) Rec {
     unsigned char draw;     // consumes one random.uniform
     unsigned char ang_gt90; // angle(vector_to_center, avg_xy) > 90
     unsigned char grow;     // inter nodes: reaches the draw with the radius used
-    unsigned short child;   // inter nodes: the (only) child
-    unsigned char pad[2];
+    unsigned int child;     // inter nodes: the (only) child
 };
 
 struct __attribute__((aligned(8))) BifRequest {
@@ -139,7 +182,7 @@ struct SimArrays {
     int *glist;          // [GCAP] groups that grow under the speculation, ascending (dict order)
     int *node_group;     // [NCAP] group index of a node during assignment
     int *child_group;    // [NCAP] tag<<14 | grow<<13 | group of the inter-node whose first child this node is
-    unsigned short *kd_idx, *kd_rank;  // [OCAP]
+    idx_t *kd_idx, *kd_rank;  // [OCAP]
     unsigned char *removed;  // [OCAP]
     unsigned char *ven_near; // [OCAP]
     unsigned long long *hashes;  // [OCAP]
@@ -156,13 +199,14 @@ struct SimArrays {
 struct Blk {
     int tid, nth;
     unsigned char *smem;  // LDS (device) or heap (host emulation); first 2 KiB reserved for collectives
+    unsigned char *umem = nullptr;   // the per-phase table area when it is NOT the LDS behind the collectives (large build: HBM scratch)
     OCTA_HD inline void sync() const {
 #if defined(__HIP_DEVICE_COMPILE__)
         __syncthreads();
 #endif
     }
     OCTA_HD inline int *coll() const { return reinterpret_cast<int *>(smem); }
-    OCTA_HD inline unsigned char *user() const { return smem + 2048; }
+    OCTA_HD inline unsigned char *user() const { return umem ? umem : smem + 2048; }
 };
 
 // exclusive scan of one int per thread; returns block total. Contains block syncs.
@@ -440,30 +484,31 @@ OCTA_HD inline void pyset_add(PySetView &s, int key, unsigned long long hash) {
 // scale and the truncation are all monotone), so two words whose q differ compare exactly like the coordinates; words with the
 // same q (about n / 2^18 of the comparisons) are decided on the doubles themselves, fetched from the point list. Every
 // comparison has the exact (key, idx) outcome with 4 B instead of 10 B of LDS per element, and a swap moves one word.
-constexpr int KD_IDX_BITS = 14;
-constexpr unsigned KD_IDX_MASK = (1u << KD_IDX_BITS) - 1u;
-constexpr unsigned KD_QMAX = (1u << (32 - KD_IDX_BITS)) - 1u;
+constexpr int KD_IDX_BITS = IDX_BITS;
+constexpr kdw_t KD_IDX_MASK = ((kdw_t)1 << KD_IDX_BITS) - 1u;
+constexpr kdw_t KD_QMAX = ((kdw_t)1 << (8 * (int)sizeof(kdw_t) - KD_IDX_BITS)) - 1u;     // 18 key bits (default build) / 46 (large build)
 static_assert(OCAP <= (1 << KD_IDX_BITS), "kd index bits");
 struct KdPair {
-    unsigned *kv;        // packed elements (LDS on the device)
+    kdw_t *kv;           // packed elements (LDS on the device)
     const double *pts;   // [n][3] coordinates
     int d;               // split dimension of the range being partitioned
 };
-OCTA_HD inline bool kd_less_w(const KdPair &a, unsigned x, unsigned y) {
+OCTA_HD inline bool kd_less_w(const KdPair &a, kdw_t x, kdw_t y) {
     if ((x ^ y) >> KD_IDX_BITS) return x < y;
-    const unsigned xi = x & KD_IDX_MASK, yi = y & KD_IDX_MASK;
+    const unsigned xi = (unsigned)(x & KD_IDX_MASK), yi = (unsigned)(y & KD_IDX_MASK);
     const double fx = a.pts[3 * xi + a.d], fy = a.pts[3 * yi + a.d];
     if (fx == fy) return xi < yi;
     return fx < fy;
 }
 OCTA_HD inline bool kd_less(const KdPair &a, int i, int j) { return kd_less_w(a, a.kv[i], a.kv[j]); }
-OCTA_HD inline void kd_swap(const KdPair &a, int i, int j) { unsigned t = a.kv[i]; a.kv[i] = a.kv[j]; a.kv[j] = t; }
-OCTA_HD inline unsigned kd_quant(double x, double mn, double scale) {
+OCTA_HD inline void kd_swap(const KdPair &a, int i, int j) { kdw_t t = a.kv[i]; a.kv[i] = a.kv[j]; a.kv[j] = t; }
+OCTA_HD inline kdw_t kd_quant(double x, double mn, double scale) {
     const double t = (x - mn) * scale;
-    unsigned q = t > 0.0 ? (unsigned)t : 0u;
-    return q > KD_QMAX ? KD_QMAX : q;
+    if (!(t > 0.0)) return 0;
+    if (t >= (double)KD_QMAX) return KD_QMAX;
+    return (kdw_t)t;
 }
-OCTA_HD inline void kd_push_heap(const KdPair &a, int first, int hole, int top, unsigned v) {
+OCTA_HD inline void kd_push_heap(const KdPair &a, int first, int hole, int top, kdw_t v) {
     int parent = (hole - 1) / 2;
     while (hole > top && kd_less_w(a, a.kv[first + parent], v)) {
         a.kv[first + hole] = a.kv[first + parent];
@@ -472,7 +517,7 @@ OCTA_HD inline void kd_push_heap(const KdPair &a, int first, int hole, int top, 
     }
     a.kv[first + hole] = v;
 }
-OCTA_HD inline void kd_adjust_heap(const KdPair &a, int first, int hole, int len, unsigned v) {
+OCTA_HD inline void kd_adjust_heap(const KdPair &a, int first, int hole, int len, kdw_t v) {
     const int top = hole;
     int second = hole;
     while (second < (len - 1) / 2) {
@@ -493,7 +538,7 @@ OCTA_HD inline void kd_heap_select(const KdPair &a, int first, int middle, int l
     if (len >= 2) {
         int parent = (len - 2) / 2;
         while (true) {
-            unsigned v = a.kv[first + parent];
+            kdw_t v = a.kv[first + parent];
             kd_adjust_heap(a, first, parent, len, v);
             if (parent == 0) break;
             parent--;
@@ -501,7 +546,7 @@ OCTA_HD inline void kd_heap_select(const KdPair &a, int first, int middle, int l
     }
     for (int i = middle; i < last; ++i)
         if (kd_less(a, i, first)) {
-            unsigned v = a.kv[i];
+            kdw_t v = a.kv[i];
             a.kv[i] = a.kv[first];
             kd_adjust_heap(a, first, 0, middle - first, v);
         }
@@ -510,7 +555,7 @@ OCTA_HD inline void kd_heap_select(const KdPair &a, int first, int middle, int l
 OCTA_HD inline void kd_insertion_sort(const KdPair &a, int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i < last; ++i) {
-        const unsigned v = a.kv[i];
+        const kdw_t v = a.kv[i];
         if (kd_less_w(a, v, a.kv[first])) {
             for (int k = i; k > first; --k) a.kv[k] = a.kv[k - 1];
             a.kv[first] = v;
@@ -577,13 +622,13 @@ OCTA_HD inline void kd_nth_element(const KdPair &a, int first, int nth, int last
 // mb: u16 mailbox; a range [s, e) owns the slots from (s+1)/2 (ranges of one level are disjoint).
 template <int TW, int NW>
 __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, int last, bool live,
-                                           unsigned short *mb) {
+                                           idx_t *mb, int depth_left = -1) {
     const int tl = (int)(threadIdx.x & (TW - 1));
     if (!live || first == last || nth == last) return;
-    unsigned short *box = mb + ((first + 1) >> 1);
+    idx_t *box = mb + ((first + 1) >> 1);
     int n = last - first, lg = 0;
     while ((n >> (lg + 1)) > 0) lg++;
-    int depth = lg * 2;
+    int depth = depth_left >= 0 ? depth_left : lg * 2;     // a range handed over by kd_nth_element_wave_long keeps its introselect budget
     while (last - first > 3) {
         if (depth == 0) {
             if (tl == 0) { kd_heap_select(a, first, nth + 1, last); kd_swap(a, first, nth); }
@@ -593,7 +638,7 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
         --depth;
         if (tl == 0) kd_median_to_first(a, first, last);
         __builtin_amdgcn_wave_barrier();
-        const unsigned pk = a.kv[first];
+        const kdw_t pk = a.kv[first];
         const int base = first + 1, m = last - base;
         const int c = ((m + TW - 1) / TW) | 1;  // odd chunk length: lanes hit distinct LDS banks
         int p0 = base + tl * c;
@@ -609,7 +654,7 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
             unsigned long long bits = 0;
 #pragma unroll 4
             for (int i = 0; i < lim; i++) {
-                const unsigned x = a.kv[q0 + i];
+                const kdw_t x = a.kv[q0 + i];
                 bool lt = x < pk;
                 if (!((x ^ pk) >> KD_IDX_BITS)) lt = kd_less_w(a, x, pk);     // same bucket as the pivot: exact (rare)
                 if (lt) bits |= 1ull << i;
@@ -639,7 +684,7 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
                 while (inv) {
                     int i = (int)__ffsll((long long)inv) - 1;
                     inv &= inv - 1ull;
-                    box[g++] = (unsigned short)(q0 + i);
+                    box[g++] = (idx_t)(q0 + i);
                 }
             }
         }
@@ -665,6 +710,61 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
     }
     if (tl == 0) kd_insertion_sort(a, first, last);
     __builtin_amdgcn_wave_barrier();
+}
+// Ranges too long for the bit masks of kd_nth_element_team (more than 64 lanes x 4 words x 64 elements; only the large build has
+// them): the same Hoare passes by one wave with the comparisons RECOMPUTED in the posting and the swapping sweep instead of
+// remembered; once the active range fits the masks the rest is handed to kd_nth_element_team with the remaining depth budget.
+constexpr int KD_MASK_MAX = 16000;      // 64 lanes x (4 x 64 mask bits) = 16384, minus the rounding of the chunk length up to the next odd number
+__device__ inline void kd_nth_element_wave_long(const KdPair &a, int first, int nth, int last, idx_t *mb) {
+    const int tl = (int)(threadIdx.x & 63);
+    if (first == last || nth == last) return;
+    idx_t *box = mb + ((first + 1) >> 1);
+    int n = last - first, lg = 0;
+    while ((n >> (lg + 1)) > 0) lg++;
+    int depth = lg * 2;
+    while (last - first > KD_MASK_MAX) {
+        if (depth == 0) {
+            if (tl == 0) { kd_heap_select(a, first, nth + 1, last); kd_swap(a, first, nth); }
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
+        --depth;
+        if (tl == 0) kd_median_to_first(a, first, last);
+        __builtin_amdgcn_wave_barrier();
+        const kdw_t pk = a.kv[first];
+        const int base = first + 1, m = last - base;
+        const int c = ((m + 63) / 64) | 1;
+        int p0 = base + tl * c;
+        if (p0 > last) p0 = last;
+        const int p1 = (p0 + c < last) ? p0 + c : last;
+        int nS = 0;
+        for (int i = p0; i < p1; i++) nS += kd_less_w(a, a.kv[i], pk) ? 1 : 0;
+        int inc = nS;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int u = __shfl_up(inc, d, 64);
+            if (tl >= d) inc += u;
+        }
+        const int totS = __shfl(inc, 63, 64);
+        const int preS = inc - nS;
+        const int cut = base + totS;
+        {   // left of the cut: the elements > pivot, ranked from the left
+            int g = (p0 - base) - preS;
+            const int lim = p1 < cut ? p1 : cut;
+            for (int i = p0; i < lim; i++)
+                if (!kd_less_w(a, a.kv[i], pk)) box[g++] = (idx_t)i;
+        }
+        __builtin_amdgcn_wave_barrier();
+        {   // right of the cut: the elements < pivot, ranked from the right, swap with their partners
+            int r = totS - preS - nS;
+            const int lo = p0 > cut ? p0 : cut;
+            for (int i = p1 - 1; i >= lo; i--)
+                if (kd_less_w(a, a.kv[i], pk)) kd_swap(a, i, (int)box[r++]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    kd_nth_element_team<64, 4>(a, first, nth, last, true, mb, depth);
 }
 #endif
 
@@ -726,17 +826,16 @@ OCTA_HD inline void atomic_min_u32(unsigned *p, unsigned v) {
 // partitioned further (its internal order is never observed), which prunes most of the deep levels.
 // LDS (78 KiB, kd_lds_layout below): packed elements u32[OCAP], per-level range tables, and the swap mailbox, whose area (plus the
 // tail) hosts the box table while no partition is running.
-constexpr int KD_TAB_OFF = OCAP * 4;                        // rs, re, rs2, re2 (u16 each), rd (s8) per range
+constexpr int KD_TAB_OFF = OCAP * (int)sizeof(kdw_t);       // rs, re, rs2, re2 (idx_t each), rd (s8) per range
 constexpr int KD_BOX_BYTES = KD_RANGES * 24;
 static_assert(KD_RANGES >= OCAP / 17 + 1, "ranges per level");
-static_assert(KD_MAILBOX_OFF % 16 == 0 && KD_MAILBOX_OFF >= KD_TAB_OFF + KD_RANGES * 9, "kd tables overlap the mailbox");
-static_assert(KD_BOX_BYTES >= KD_MAILBOX_BYTES, "the box table covers the mailbox");
-static_assert(2048 + KD_MAILBOX_OFF + KD_BOX_BYTES <= SIM_LDS_BYTES, "kd LDS layout");
+static_assert(KD_MAILBOX_OFF % 16 == 0 && KD_MAILBOX_OFF >= KD_TAB_OFF + KD_RANGES * KD_TAB_BYTES_PER_RANGE, "kd tables overlap the mailbox");
+static_assert(KD_MAILBOX_OFF + (KD_BOX_BYTES > KD_MAILBOX_BYTES ? KD_BOX_BYTES : KD_MAILBOX_BYTES) <= SIM_USER_BYTES, "kd table layout (box table and mailbox share their area)");
 // xy: [n][2] floats of global scratch -- the x and y coordinates rounded to single precision, written here and read by the box and
 // key passes of every level (8 B instead of 24 + 8 B of gathered doubles per element and level: the gathers were the kernel's
 // largest HBM/L2 read stream); zlo / zhi: bounds of every point's z (the slab is thin: z wins the "largest spread" only for ranges
 // whose x and y boxes are thinner than the slab, and those are measured exactly).
-OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned short *out_idx, unsigned short *out_rank,
+OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_idx, idx_t *out_rank,
                               float *xy, double zlo, double zhi, long *kdprof = nullptr, const unsigned char *need = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KDP(slot) do { if (kdprof && b.tid == 0) { long _t = (long)wall_clock64(); kdprof[slot] += _t - _kt; _kt = _t; } } while (0)
@@ -744,17 +843,17 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
 #else
 #define KDP(slot) do { } while (0)
 #endif
-    unsigned *kv = reinterpret_cast<unsigned *>(b.user());
-    unsigned short *tab = reinterpret_cast<unsigned short *>(b.user() + KD_TAB_OFF);
-    unsigned short *rs = tab, *re = tab + KD_RANGES;                        // range start / end
-    unsigned short *rs2 = tab + 2 * KD_RANGES, *re2 = tab + 3 * KD_RANGES;  // next level
+    kdw_t *kv = reinterpret_cast<kdw_t *>(b.user());
+    idx_t *tab = reinterpret_cast<idx_t *>(b.user() + KD_TAB_OFF);
+    idx_t *rs = tab, *re = tab + KD_RANGES;                        // range start / end
+    idx_t *rs2 = tab + 2 * KD_RANGES, *re2 = tab + 3 * KD_RANGES;  // next level
     signed char *rd = reinterpret_cast<signed char *>(tab + 4 * KD_RANGES); // bbox pass: 1 = holds a needed point; then split dim (-1 = leaf / not needed)
     unsigned *bbf = reinterpret_cast<unsigned *>(b.user() + KD_MAILBOX_OFF); // [nr][6]: max xyz (rounded up), min xyz (rounded down)
     for (int i = b.tid; i < n; i += b.nth) {
-        kv[i] = (unsigned)i;
+        kv[i] = (kdw_t)i;
         xy[2 * i] = (float)pts[3 * i]; xy[2 * i + 1] = (float)pts[3 * i + 1];      // round to nearest: x lies within one float spacing of it
     }
-    if (b.tid == 0) { rs[0] = 0; re[0] = (unsigned short)n; }
+    if (b.tid == 0) { rs[0] = 0; re[0] = (idx_t)n; }
     const float z_up = f32_round_up(zhi), z_dn = f32_round_down(zlo);
     b.sync();
     int nr = (n > 16) ? 1 : 0;  // a range of <= leafsize points is a leaf: left in input order
@@ -864,10 +963,10 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                     }
                 }
                 if (d >= 0) {
-                    const unsigned id = kv[i] & KD_IDX_MASK;
+                    const unsigned id = (unsigned)(kv[i] & KD_IDX_MASK);
                     // x / y: the rounded coordinate (rounding is monotone, so the key still is); z: the double itself
                     const double cv = d < 2 ? (double)xy[2 * id + d] : pts[3 * id + 2];
-                    kv[i] = (kd_quant(cv, mnd, scale) << KD_IDX_BITS) | id;
+                    kv[i] = (kd_quant(cv, mnd, scale) << KD_IDX_BITS) | (kdw_t)id;
                 }
             }
         }
@@ -876,21 +975,22 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
         // 3. nth_element per range: long ranges by one wave each, short ranges by a quarter wave each
 #if defined(__HIP_DEVICE_COMPILE__)
         {
-            unsigned short *mb = reinterpret_cast<unsigned short *>(b.user() + KD_MAILBOX_OFF);
+            idx_t *mb = reinterpret_cast<idx_t *>(b.user() + KD_MAILBOX_OFF);
             const int wv = b.tid >> 6, nw = (b.nth + 63) >> 6;
             for (int q = wv; q < nr; q += nw) {
                 int d = rd[q];
                 int s = rs[q], e = re[q];
                 if (d < 0 || e - s < KD_TEAM_MIN) continue;
                 const KdPair kp = {kv, pts, d};
-                if (e - s > 4000) kd_nth_element_team<64, 4>(kp, s, s + (e - s) / 2, e, true, mb);
+                if (e - s > KD_MASK_MAX) kd_nth_element_wave_long(kp, s, s + (e - s) / 2, e, mb);
+                else if (e - s > 4000) kd_nth_element_team<64, 4>(kp, s, s + (e - s) / 2, e, true, mb);
                 else kd_nth_element_team<64, 1>(kp, s, s + (e - s) / 2, e, true, mb);
             }
         }
         b.sync();
         KDP(3);
         {
-            unsigned short *mb = reinterpret_cast<unsigned short *>(b.user() + KD_MAILBOX_OFF);
+            idx_t *mb = reinterpret_cast<idx_t *>(b.user() + KD_MAILBOX_OFF);
             const int team = b.tid >> 4, nteam = b.nth >> 4;
             for (int q0 = 0; q0 < nr; q0 += nteam) {
                 int q = q0 + team;
@@ -928,18 +1028,18 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, unsigned sh
                 int ex;
                 const int tot = blk_scan(b, c, &ex);
                 int pos = base + ex;
-                if (m - s > 16) { if (pos < KD_RANGES) { rs2[pos] = (unsigned short)s; re2[pos] = (unsigned short)m; } pos++; }
-                if (e - m > 16) { if (pos < KD_RANGES) { rs2[pos] = (unsigned short)m; re2[pos] = (unsigned short)e; } }
+                if (m - s > 16) { if (pos < KD_RANGES) { rs2[pos] = (idx_t)s; re2[pos] = (idx_t)m; } pos++; }
+                if (e - m > 16) { if (pos < KD_RANGES) { rs2[pos] = (idx_t)m; re2[pos] = (idx_t)e; } }
                 base += tot;
             }
             nr = base < KD_RANGES ? base : KD_RANGES;
         }
         b.sync();
-        { unsigned short *t = rs; rs = rs2; rs2 = t; t = re; re = re2; re2 = t; }
+        { idx_t *t = rs; rs = rs2; rs2 = t; t = re; re = re2; re2 = t; }
         b.sync();
         KDP(5);
     }
-    for (int i = b.tid; i < n; i += b.nth) { const unsigned short id = (unsigned short)(kv[i] & KD_IDX_MASK); out_idx[i] = id; out_rank[id] = (unsigned short)i; }
+    for (int i = b.tid; i < n; i += b.nth) { const idx_t id = (idx_t)(kv[i] & KD_IDX_MASK); out_idx[i] = id; out_rank[id] = (idx_t)i; }
     b.sync();
     KDP(6);
 #undef KDP
@@ -958,7 +1058,7 @@ struct Grid {
     int nx, ny;
     double x0, y0, inv;
     const int *cell_end;           // LDS [nx*ny]: end offset of each cell (its start is the end of the previous cell)
-    const unsigned short *items;   // LDS [n]: point ids in cell order
+    const idx_t *items;   // LDS [n]: point ids in cell order
     const double *spts;            // HBM [n][3]: coordinates in cell order
 };
 OCTA_HD inline int grid_clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
@@ -976,8 +1076,8 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
     G.nx = G.ny = nc; G.x0 = G.y0 = -0.1; G.inv = 1.0 / cell;
     const int ncell = nc * nc;
     int *hist = reinterpret_cast<int *>(b.user());  // [ncell + 1]
-    unsigned short *items = reinterpret_cast<unsigned short *>(b.user() + (size_t)(GRID_MAX * GRID_MAX + 1) * 4);  // [GRID_N]
-    static_assert((size_t)(GRID_MAX * GRID_MAX + 1) * 4 + (size_t)GRID_N * 2 + 2048 <= (size_t)SIM_LDS_BYTES, "grid LDS layout");
+    idx_t *items = reinterpret_cast<idx_t *>(b.user() + (size_t)(GRID_MAX * GRID_MAX + 1) * 4);  // [GRID_N]
+    static_assert((size_t)(GRID_MAX * GRID_MAX + 1) * 4 + (size_t)GRID_N * sizeof(idx_t) <= (size_t)SIM_USER_BYTES, "grid table layout");
     G.cell_end = hist; G.items = items; G.spts = A.grid_pts;
     if (n > GRID_N) n = GRID_N;
     b.sync();
@@ -1025,7 +1125,7 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
         for (int k = 0; k < GB; k++)
             if (i0 + k * b.nth < n) {
                 int pos = atomic_add_int(&hist[grid_cy(G, p[k].y) * nc + grid_cx(G, p[k].x)], 1);  // hist[c] ends as the END of cell c
-                items[pos] = (unsigned short)id[k];
+                items[pos] = (idx_t)id[k];
                 st3(A.grid_pts + 3 * pos, p[k]);
             }
     }
@@ -1064,7 +1164,7 @@ OCTA_HD inline void dirty_insert(DirtyList &D, int g) {
 // State of the ordered pass that lives in LDS / registers instead of HBM.
 struct SeqLds {
     double *rad;               // [NCAP] radii of the forest: the HBM array itself (L2-resident during the pass; round 2 kept an LDS copy)
-    unsigned short *par;       // [NCAP] parent id, 0xffff = none (LDS)
+    idx_t *par;       // [NCAP] parent id, 0xffff = none (LDS)
     const double *log_tab;     // glibc pow tables (gpow.h) (LDS)
     const uint64_t *exp_tab;
     int *deferred;             // [NCAP / 32] bitmap: radius to be recomputed when the pass ends (2 KiB, LDS)
@@ -1084,8 +1184,8 @@ OCTA_HD inline WalkRec walk_load(const SimArrays &A, int f, int id, bool want_cg
 }
 OCTA_HD inline int walk_parent(const SeqLds &L, int id) {
     if (id < 0) return -1;
-    unsigned short p = L.par[id];
-    return p == 0xffffu ? -1 : (int)p;
+    idx_t p = L.par[id];
+    return p == IDX_NONE ? -1 : (int)p;
 }
 
 // Murray's law from node id towards the root (arterial_tree.py:174-184): the reference recomputes (r_c0^k + r_c1^k)^(1/k) for
@@ -1120,7 +1220,7 @@ __device__ inline bool murray_pending_above(const SimArrays &A, int start, int c
             cur = p;
         }
         const int cg = lane < nn ? A.child_group[mine] : 0;
-        if (__ballot(lane < nn && (cg >> 14) == pass_tag && (cg & 8191) > cur_g)) return true;
+        if (__ballot(lane < nn && (cg >> (GROUP_BITS + 1)) == pass_tag && (cg & ((1 << GROUP_BITS) - 1)) > cur_g)) return true;
         if (ended) return false;
     }
 }
@@ -1153,7 +1253,7 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
         r.nch = 0; r.c0 = r.c1 = -1; r.cg = 0; r.k = 0;
         if (!defer_rest) {
             if (lane < nn) r = walk_load(A, f, mine, true);
-            const unsigned long long pend = __ballot(lane < nn && (r.cg >> 14) == pass_tag && (r.cg & 8191) > cur_g);
+            const unsigned long long pend = __ballot(lane < nn && (r.cg >> (GROUP_BITS + 1)) == pass_tag && (r.cg & ((1 << GROUP_BITS) - 1)) > cur_g);
             if (!ended && murray_pending_above(A, cur, cur_g, pass_tag, L)) eager_n = nn;
             else eager_n = pend ? 64 - __builtin_clzll(pend) : 0;
         }
@@ -1196,11 +1296,11 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
                 done = j + 1;
                 rp_prev = rp;
                 const int cg = __builtin_amdgcn_readlane(r.cg, j);
-                if ((cg >> 14) == pass_tag) {
-                    const int g2 = cg & 8191;
+                if ((cg >> (GROUP_BITS + 1)) == pass_tag) {
+                    const int g2 = cg & ((1 << GROUP_BITS) - 1);
                     if (g2 > cur_g) {
                         changed_set(L, g2);
-                        if (D && !((cg >> 13) & 1)) dirty_insert(*D, g2);
+                        if (D && !((cg >> GROUP_BITS) & 1)) dirty_insert(*D, g2);
                     }
                 }
             }
@@ -1231,7 +1331,7 @@ OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g,
         const int par = walk_parent(L, cur);
         if (par < 0 || deferred_get(L, cur)) break;
         const int cg = A.child_group[cur];
-        if ((cg >> 14) == pass_tag && (cg & 8191) > cur_g) eager_n = path_len + 1;
+        if ((cg >> (GROUP_BITS + 1)) == pass_tag && (cg & ((1 << GROUP_BITS) - 1)) > cur_g) eager_n = path_len + 1;
         cur = par;
     }
     int k = 0;
@@ -1245,11 +1345,11 @@ OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g,
         steps++;
         if (rad[id] == rp) return steps;
         rad[id] = rp;
-        if ((r.cg >> 14) == pass_tag) {
-            const int g2 = r.cg & 8191;
+        if ((r.cg >> (GROUP_BITS + 1)) == pass_tag) {
+            const int g2 = r.cg & ((1 << GROUP_BITS) - 1);
             if (g2 > cur_g) {
                 changed_set(L, g2);
-                if (D && !((r.cg >> 13) & 1)) dirty_insert(*D, g2);
+                if (D && !((r.cg >> GROUP_BITS) & 1)) dirty_insert(*D, g2);
             }
         }
         id = par;
@@ -1400,7 +1500,7 @@ OCTA_HD inline int seq_add_node(const SimArrays &A, int f, int &n_nodes, V3 p, d
     n_nodes = id + 1;
     st3(A.npos[f] + 3 * id, p);
     A.nrad[f][id] = r; A.nkap[f][id] = kappa; A.npar[f][id] = parent;   // L.rad IS A.nrad[f]
-    L.par[id] = (unsigned short)parent;
+    L.par[id] = (idx_t)parent;
     A.nch0[f][id] = -1; A.nch1[f][id] = -1; A.nnch[f][id] = 0; A.nact[f][id] = 1;
     if (parent_nch == 0) A.nch0[f][parent] = id; else if (parent_nch == 1) A.nch1[f][parent] = id;
     A.nnch[f][parent] = (unsigned char)(parent_nch + 1);
@@ -1685,7 +1785,7 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     const int ch = A.nch0[f][id];
     const double r1 = G.rad[ch], r2 = r;
     R.r1_used = r1;
-    R.child = (unsigned short)ch;
+    R.child = (idx_t)ch;
     using octa_gpow::gpow;
     double rp = gpow(gpow(r1, kappa) + gpow(r2, kappa), 1 / kappa);
     double rp4 = gpow(rp, 4.0), rp2 = gpow(rp, 2.0);
@@ -1709,7 +1809,7 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
             bool keep = false;
             V3 u = v3(0, 0, 0);
             if (k < cnt) {
-                const int a = (int)(A.sorted[s + k] & 16383u);
+                const int a = (int)(A.sorted[s + k] & IDX_MASK);
                 const V3 w = sub(ld3(G.att + 3 * a), pos);
                 const double ad = angle_uv(dist_seg, nd, w), ap = angle_uv(prox_seg, npx, w);
                 keep = lo <= ad && ad <= hi && ap <= pl;
@@ -1727,7 +1827,7 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     } else
 #endif
     for (int k = 0; k < cnt; k++) {
-        int a = (int)(A.sorted[s + k] & 16383u);
+        int a = (int)(A.sorted[s + k] & IDX_MASK);
         V3 w = sub(ld3(G.att + 3 * a), pos);
         double ad = angle_uv(dist_seg, nd, w), ap = angle_uv(prox_seg, npx, w);
         if (lo <= ad && ad <= hi && ap <= pl) {
@@ -1768,7 +1868,7 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
     double sum = 0;
     const int s = A.gstart[g], cnt = A.gcount[g];
     for (int k = 0; k < cnt; k++) {
-        int a = (int)(A.sorted[s + k] & 16383u);
+        int a = (int)(A.sorted[s + k] & IDX_MASK);
         V3 w = sub(ld3(G.att + 3 * a), pos);
         double an = angle_uv(v, nv, w);
         if (an <= lim) {
@@ -1781,7 +1881,7 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
     if (kept == 0) return;
     double mean = sum / (double)kept, var = 0;
     for (int k = 0; k < cnt; k++) {
-        int a = (int)(A.sorted[s + k] & 16383u);
+        int a = (int)(A.sorted[s + k] & IDX_MASK);
         double an = angle_uv(v, nv, sub(ld3(G.att + 3 * a), pos));
         if (an <= lim) var += (an - mean) * (an - mean);
     }
@@ -1801,7 +1901,7 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
                 Q.r = r; Q.kappa = kappa; Q.d = d;
                 int w = 0;
                 for (int k = 0; k < cnt; k++) {
-                    int a = (int)(A.sorted[s + k] & 16383u);
+                    int a = (int)(A.sorted[s + k] & IDX_MASK);
                     V3 p = ld3(G.att + 3 * a);
                     if (angle_uv(v, nv, sub(p, pos)) <= lim) { st3(Q.atts + 3 * w, p); w++; }
                 }
@@ -1851,7 +1951,7 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
             else { R.type = 0; R.node = id; R.req = -1; }
             A.rec[g] = R;
             grows = (R.type == 1) || (R.type == 3 && R.grow);
-            if (R.type == 3) A.child_group[A.nch0[f][id]] = (tag << 14) | ((int)R.grow << 13) | g;
+            if (R.type == 3) A.child_group[A.nch0[f][id]] = (tag << (GROUP_BITS + 1)) | ((int)R.grow << GROUP_BITS) | g;
         }
         int ex;
         int tot = blk_scan(b, grows, &ex);
@@ -1904,8 +2004,7 @@ struct GrowWindow {
         const int flags = __builtin_amdgcn_readlane((int)mine.type | ((int)mine.draw << 8) | ((int)mine.ang_gt90 << 16) | ((int)mine.grow << 24), j);
         R.type = (unsigned char)(flags & 255); R.draw = (unsigned char)((flags >> 8) & 255);
         R.ang_gt90 = (unsigned char)((flags >> 16) & 255); R.grow = (unsigned char)((flags >> 24) & 255);
-        R.child = (unsigned short)__builtin_amdgcn_readlane((int)mine.child, j);
-        R.pad[0] = R.pad[1] = 0;
+        R.child = (unsigned)__builtin_amdgcn_readlane((int)mine.child, j);
         return R;
     }
 #else
@@ -1953,24 +2052,23 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     // "has this group's child radius changed since the speculation" is answered by the `changed` bitmap the walks keep.
     SeqLds L;
     L.rad = A.nrad[f];
-    L.par = reinterpret_cast<unsigned short *>(b.user());
-    double *ltab = reinterpret_cast<double *>(b.user() + (size_t)NCAP * 2);
+    constexpr int DEF_WORDS = (NCAP + 31) / 32, CHG_WORDS = (GCAP + 31) / 32;     // the two bitmaps
+    L.par = reinterpret_cast<idx_t *>(b.user());
+    double *ltab = reinterpret_cast<double *>(b.user() + (((size_t)NCAP * sizeof(idx_t) + 15) & ~(size_t)15));
     uint64_t *etab = reinterpret_cast<uint64_t *>(ltab + 384);
-    static_assert((size_t)NCAP * 2 + 384 * 8 + 256 * 8 + 2048 + 1024 + SEQ_SIDE_LDS + 2048 <= (size_t)SIM_LDS_BYTES, "ordered-pass LDS layout");
+    static_assert((size_t)NCAP * sizeof(idx_t) + 16 + 384 * 8 + 256 * 8 + (DEF_WORDS + CHG_WORDS) * 4 + SEQ_SIDE_LDS <= (size_t)SIM_USER_BYTES, "ordered-pass table layout");
     L.log_tab = ltab; L.exp_tab = etab;
     L.deferred = reinterpret_cast<int *>(etab + 256);
-    static_assert(NCAP / 8 <= 2048, "deferred bitmap");
-    L.changed = L.deferred + 512;
-    static_assert(GCAP / 8 <= 1024, "changed bitmap");
-    unsigned char *side_lds = reinterpret_cast<unsigned char *>(L.changed) + 1024;
+    L.changed = L.deferred + DEF_WORDS;
+    unsigned char *side_lds = reinterpret_cast<unsigned char *>(L.changed + CHG_WORDS);
     const int n_before = sc->n_nodes[f];
     for (int i = b.tid; i < n_before; i += b.nth) {
         int p = A.npar[f][i];
-        L.par[i] = p < 0 ? (unsigned short)0xffffu : (unsigned short)p;
+        L.par[i] = p < 0 ? IDX_NONE : (idx_t)p;
     }
     for (int i = b.tid; i < 384; i += b.nth) ltab[i] = octa_gpow::LOG_TAB[i];
     for (int i = b.tid; i < 256; i += b.nth) etab[i] = octa_gpow::EXP_TAB[i];
-    for (int i = b.tid; i < 512 + 256; i += b.nth) L.deferred[i] = 0;      // both bitmaps
+    for (int i = b.tid; i < DEF_WORDS + CHG_WORDS; i += b.nth) L.deferred[i] = 0;      // both bitmaps
     if (b.tid == 0) b.coll()[91] = 0;
     b.sync();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2106,7 +2204,7 @@ OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsign
         return w;
     }
     double *tile = reinterpret_cast<double *>(b.user());
-    static_assert((size_t)COMPACT_TILE * 24 + 2048 <= (size_t)SIM_LDS_BYTES, "compaction tile");
+    static_assert((size_t)COMPACT_TILE * 24 <= (size_t)SIM_USER_BYTES, "compaction tile");
     const int chunk = (n + b.nth - 1) / b.nth;
     const int i0 = b.tid * chunk < n ? b.tid * chunk : n, i1 = (i0 + chunk < n) ? i0 + chunk : n;
     int local = 0;
@@ -2169,7 +2267,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
             OCTA_GRID_FOR(G, p.x, p.y, ek, j, q) {
                 if (sqdist(p, q) <= ek2) {
                     int q = atomic_add_int(&ctl[0], 1);
-                    if (q < PCAP) A.pairs[q] = ((unsigned)(j - nb) << 14) | (unsigned)o;
+                    if (q < PCAP) A.pairs[q] = ((unsigned)(j - nb) << IDX_BITS) | (unsigned)o;
                     A.removed[o] = 1;
                 }
             }
@@ -2179,14 +2277,14 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     OCTA_SUBPROF(sc, 12, t0);
     int n_pairs = ctl[0];
     if (n_pairs > PCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_PAIR_CAP); n_pairs = PCAP; }
-    if (n_new > (1 << 18)) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_PAIR_CAP); }
+    if (n_new > (1 << (32 - IDX_BITS))) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_PAIR_CAP); }
     b.sync();
     if (n_pairs == 0) return;  // nothing satisfied: no conversion, no deletion (uniform across the block)
     // 2. cKDTree order of the O2 list, only as deep as the hit sinks need it; pairs get kd ranks
     kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank, reinterpret_cast<float *>(A.hashes) /* free until step 3 */, 0.0, zext, sc->kdprof, A.removed);
     for (int i = b.tid; i < n_pairs; i += b.nth) {
         unsigned pr = A.pairs[i];
-        A.pairs[i] = (pr & ~16383u) | (unsigned)A.kd_rank[pr & 16383u];
+        A.pairs[i] = (pr & ~IDX_MASK) | (unsigned)A.kd_rank[pr & IDX_MASK];
     }
     b.sync();
     OCTA_SUBPROF(sc, 11, t0);
@@ -2247,7 +2345,6 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     // Usual case (<= LSET_PAIRS hits): the insert stream (sink, hash) is compacted into LDS in parallel, the
     // open-addressing table lives in LDS too (a table never exceeds 8 x its entries), one thread replays the
     // insertions, and the occupied slots are read out in slot order by the whole block.
-    constexpr int LSET_PAIRS = 512, LSET_CAP = 4096;     // <= 512 keys: the table never exceeds 2048 slots (+ as many for the resize staging)
     if (n_pairs <= LSET_PAIRS) {
         set_in_lds = true;
         unsigned long long *t_hash = reinterpret_cast<unsigned long long *>(b.user());        // [LSET_CAP]
@@ -2259,7 +2356,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
             const int i = p0 + b.tid;
             int o = -1, take = 0;
             if (i < n_pairs) {
-                o = (int)A.kd_idx[A.pairs[i] & 16383u];
+                o = (int)A.kd_idx[A.pairs[i] & IDX_MASK];
                 take = A.ven_near[o] ? 0 : 1;
             }
             int ex;
@@ -2305,7 +2402,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
         S.hash = A.set_hash; S.key = A.set_key; S.err = &sc->err; S.cap = SETCAP;
         pyset_init(S);
         for (int i = 0; i < n_pairs; i++) {
-            int o = (int)A.kd_idx[A.pairs[i] & 16383u];
+            int o = (int)A.kd_idx[A.pairs[i] & IDX_MASK];
             if (!A.ven_near[o]) pyset_add(S, o, A.hashes[o]);
         }
         int n_co2 = sc->n_co2;
@@ -2356,4 +2453,4 @@ OCTA_HD inline void phase_satisfy_ven(const Blk &b, const SimArrays &A, const It
     b.sync();
 }
 
-}  // namespace octa_simk
+}  // namespace OCTA_SIMK

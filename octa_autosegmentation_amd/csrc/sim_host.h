@@ -15,7 +15,7 @@
 
 #include "sim_core.h"
 
-namespace octa_simk {
+namespace OCTA_SIMK {
 
 struct Mt19937 {
     uint32_t mt[624];
@@ -334,4 +334,4 @@ inline long export_edges(const double *npos[2], const double *nrad[2], const int
     return ne;
 }
 
-}  // namespace octa_simk
+}  // namespace OCTA_SIMK

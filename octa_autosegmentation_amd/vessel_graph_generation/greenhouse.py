@@ -266,6 +266,7 @@ class BatchSimulator:
         _native.check(self._lib.octa_sim_create(self._ctx, ctypes.byref(self._cfg), self.batch, ctypes.byref(h)),
                       "octa_sim_create")
         self._h = h
+        self.is_large = bool(self._lib.octa_sim_is_large(h))      # bound to the wide-field build (csrc/sim_api.cpp)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -327,7 +328,8 @@ class BatchSimulator:
         return out
 
     def fields(self, k):
-        oxy, co2 = np.zeros((16384, 3)), np.zeros((16384, 3))
+        cap = 1 << 18 if self.is_large else 16384
+        oxy, co2 = np.zeros((cap, 3)), np.zeros((cap, 3))
         no, nc = ctypes.c_int64(), ctypes.c_int64()
         _native.check(self._lib.octa_sim_fields(self._h, int(k), oxy.ctypes.data, len(oxy), ctypes.byref(no),
                                                 co2.ctypes.data, len(co2), ctypes.byref(nc)), "octa_sim_fields")

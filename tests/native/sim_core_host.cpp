@@ -8,7 +8,7 @@
 #include <vector>
 #include "../../octa_autosegmentation_amd/csrc/sim_host.h"
 
-using namespace octa_simk;
+using namespace OCTA_SIMK;      // octa_simk, or octa_simk_large when compiled with -DOCTA_SIM_LARGE=1 (the wide-field build)
 
 extern "C" {
 
@@ -18,6 +18,8 @@ struct host_sim_params {
     double param_scale, d, r, faz_mean, faz_std, rotation_radius, fc[2], size[3];
     int n_trees, walls[4], n_modes;
     double modes[8][13];
+    int forest_type;                 // the leading fields of oracle/sim_oracle.py: SimParams (same layout)
+    double nerve_center[2], nerve_radius;
 };
 
 double octa_simcore_gpow(double x, double y) { return octa_gpow::gpow(x, y); }
@@ -41,10 +43,10 @@ long octa_simcore_gpow_check(long n, unsigned long long seed) {
 }
 
 // nth_element restatement vs the real std::nth_element is checked from Python through this hook
-void octa_simcore_kd_indices(const double *pts, int n, unsigned short *out_idx) {
+void octa_simcore_kd_indices(const double *pts, int n, idx_t *out_idx) {
     std::vector<unsigned char> smem((size_t)SIM_LDS_BYTES + 64);
     Blk b = {0, 1, smem.data()};
-    std::vector<unsigned short> rank(n);
+    std::vector<idx_t> rank(n);
     std::vector<float> xy((size_t)2 * n + 2);
     double zlo = n ? pts[2] : 0, zhi = zlo;
     for (int i = 1; i < n; i++) { zlo = std::min(zlo, pts[3 * i + 2]); zhi = std::max(zhi, pts[3 * i + 2]); }
@@ -71,6 +73,7 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     cfg.rotation_radius = hp->rotation_radius; cfg.fc0 = hp->fc[0]; cfg.fc1 = hp->fc[1];
     cfg.sx = hp->size[0]; cfg.sy = hp->size[1]; cfg.sz = hp->size[2]; cfg.n_trees = hp->n_trees;
     for (int w = 0; w < 4; w++) cfg.walls[w] = hp->walls[w];
+    cfg.forest_type = hp->forest_type; cfg.nc0 = hp->nerve_center[0]; cfg.nc1 = hp->nerve_center[1]; cfg.nr = hp->nerve_radius;
     for (int m = 0; m < hp->n_modes; m++) {
         const double *q = hp->modes[m];
         cfg.modes.push_back(ModeCfg{(int)q[0], (int)q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11], q[12]});
@@ -110,7 +113,7 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     std::vector<int> glist(GCAP), child_group(NCAP, 0);
     std::vector<int> node_group(NCAP, 0);
     A.glist = glist.data(); A.child_group = child_group.data(); A.node_group = node_group.data();
-    std::vector<unsigned short> kd_idx(OCAP), kd_rank(OCAP);
+    std::vector<idx_t> kd_idx(OCAP), kd_rank(OCAP);
     std::vector<unsigned char> removed(OCAP), ven_near(OCAP);
     std::vector<unsigned long long> hashes(OCAP), set_hash(SETCAP);
     A.oxy = oxy.data(); A.co2 = co2.data(); A.cand = cand.data(); A.py_u = S.py_u.data();
@@ -122,7 +125,7 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     std::vector<unsigned> idx_scratch(NCANDCAP + 1);
     const uint32_t Kvox = (uint32_t)(S.valid.size() / 2);
 
-    std::vector<unsigned char> smem(160 * 1024);
+    std::vector<unsigned char> smem((size_t)SIM_LDS_BYTES + 64);
     Blk b = {0, 1, smem.data()};
     const int REQ_CAP = 4096;
     std::vector<BifRequest> reqs(REQ_CAP);

@@ -46,7 +46,7 @@ def test_short_runs_match_reference_csv(gh, golden):
     sim.close()
 
 
-def test_nerve_forest_runs_match_reference_csv(gh, golden):
+def test_nerve_forest_runs_match_reference_csv(gh, golden, monkeypatch):
     """f4: optic-nerve forests + nerve disc (forest.py:38-66, simulation_space.py:48-50) on the GPU, N = 8000 candidates per
     iteration, 16 + 16 trees: CSV text and the O2 / CO2 fields identical to the reference's; a run that outgrows the per-sample
     capacities (the notebook's full 400 + 500 iterations would) fails loudly with capacity bits instead of truncating."""
@@ -65,10 +65,44 @@ def test_nerve_forest_runs_match_reference_csv(gh, golden):
         assert (sim.trace()[0] == golden[name + "_trace"]).all(), name
         sim.close()
     from octa_autosegmentation_amd import _native
+    # the notebook's full run (400 + 500 iterations) is bound to the wide-field build (csrc/sim_api.cpp); forced into the default build
+    # it outgrows the per-sample capacities and fails loudly with capacity bits instead of truncating
     cfg = yaml.safe_load(str(golden["nerve_config_yaml"]))
     cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = 400, 500
+    sim = gh.BatchSimulator(cfg, 1)
+    assert sim.is_large
+    sim.close()
+    monkeypatch.setenv("OCTA_SIM_BUILD", "default")
     with pytest.raises(_native.OctaHipError, match="capacity"):
         gh.simulate_batch(cfg, [0])
+    monkeypatch.delenv("OCTA_SIM_BUILD")
+
+
+@pytest.mark.parametrize("name", ["run_s0_30_20", "run_s3_30_20", "run_s11_20_0", "nerve_s0_12_6", "nerve_s8_20_0", "geom_s0_30_20"])
+def test_wide_field_build_reproduces_the_reference_fixtures(gh, golden, monkeypatch, tmp_path, name):
+    """The wide-field build of the simulator (OCTA_SIM_LARGE: 32-bit indices, 64-bit kd elements, per-sample tables in HBM; chosen
+    automatically for configurations like the reference's 12 x 12 mm^2 notebook run) is the same phase code: forced onto the
+    reference-made short fixtures it must give their CSV text, traces and fields bit for bit, like the default build."""
+    monkeypatch.setenv("OCTA_SIM_BUILD", "large")
+    seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])
+    if name.startswith("nerve_"):
+        cfg = yaml.safe_load(str(golden["nerve_config_yaml"]))
+        cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = i1, i2
+    else:
+        cfg = _cfg(golden, i1, i2)
+        if name.startswith("geom_"):
+            path = str(tmp_path / "geometry.npy")
+            np.save(path, golden["geometry_mask"])
+            cfg["Greenhouse"]["SimulationSpace"]["oxygen_sample_geometry_path"] = path
+    sim = gh.BatchSimulator(cfg, 1)
+    assert sim.is_large
+    res = sim.run([seed])
+    assert res.stats[0, 0] == 0
+    assert gh.edges_to_csv_text(res.sample_edges(0)).encode() == golden[name + "_csv"].tobytes(), name
+    assert (sim.trace()[0] == golden[name + "_trace"]).all()
+    oxy, co2 = sim.fields(0)
+    assert (oxy == golden[name + "_oxy"]).all() and (co2 == golden[name + "_co2"]).all()
+    sim.close()
 
 
 def test_fixed_geometry_runs_match_reference_csv(gh, golden, tmp_path):

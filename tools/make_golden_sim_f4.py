@@ -30,25 +30,36 @@ def notebook_config():
     return cfg
 
 
-def main():
+def one(seed):
     import make_golden_sim as mg
     from make_golden_sim_wide import run_reference_once
-    seeds = [int(a) for a in sys.argv[1:]] or [0]
     cfg = notebook_config()
-    out = {"config_yaml": np.array(yaml.safe_dump(cfg)), "seeds": np.array(seeds, dtype=np.int64)}
-    for seed in seeds:
-        t0 = time.time()
-        text, trace, edges = run_reference_once(cfg, seed, mg)
-        dt = time.time() - t0
-        out[f"s{seed}_rows"] = np.array(text.count("\n") - 1)
-        out[f"s{seed}_csv_sha256"] = np.array(hashlib.sha256(text.encode()).hexdigest())
-        out[f"s{seed}_trace"] = trace
-        out[f"s{seed}_peaks"] = trace.max(axis=0)
-        out[f"s{seed}_seconds"] = np.array(dt)
-        out[f"s{seed}_edges_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(edges).tobytes()).hexdigest())
-        print(f"seed {seed}: {out[f's{seed}_rows']} rows, peaks (art, O2, ven, CO2) {trace.max(axis=0).tolist()}, {dt:.0f} s", flush=True)
-        np.savez_compressed(OUT, **out)
-    print("wrote", OUT)
+    t0 = time.time()
+    text, trace, edges = run_reference_once(cfg, seed, mg)
+    dt = time.time() - t0
+    print(f"seed {seed}: {text.count(chr(10)) - 1} rows, peaks (art, O2, ven, CO2) {trace.max(axis=0).tolist()}, {dt:.0f} s", flush=True)
+    return seed, {"rows": np.array(text.count("\n") - 1), "csv_sha256": np.array(hashlib.sha256(text.encode()).hexdigest()), "trace": trace,
+                  "peaks": trace.max(axis=0), "seconds": np.array(dt),
+                  "edges_sha256": np.array(hashlib.sha256(np.ascontiguousarray(edges).tobytes()).hexdigest())}
+
+
+def main():
+    """Seeds given on the command line are ADDED to the existing file (one worker process per seed, at most three at a time)."""
+    from concurrent.futures import ProcessPoolExecutor
+    seeds = [int(a) for a in sys.argv[1:]] or [0]
+    out = {}
+    if os.path.exists(OUT):
+        old = np.load(OUT)
+        out = {k: old[k] for k in old.files}
+    out["config_yaml"] = np.array(yaml.safe_dump(notebook_config()))
+    with ProcessPoolExecutor(max_workers=min(3, len(seeds))) as ex:
+        for seed, d in ex.map(one, seeds):
+            for k, v in d.items():
+                out[f"s{seed}_{k}"] = v
+    have = sorted({int(k[1:].split("_")[0]) for k in out if k.startswith("s") and k[1:2].isdigit() and k.endswith("_rows")})
+    out["seeds"] = np.array(have, dtype=np.int64)
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, "seeds", have)
 
 
 if __name__ == "__main__":
