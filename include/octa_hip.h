@@ -404,7 +404,7 @@ typedef struct {
     double faz_center[2];
     double size[3];                       /* SimulationSpace no_voxel_x/y/z                 */
     int n_trees;                          /* Forest.N_trees                                 */
-    int walls[4];                         /* source_walls x0, x1, y0, y1                    */
+    int walls[4];                         /* source_walls x0, x1, y0, y1 (see n_source_walls) */
     int n_modes;
     /* per mode: I, N, eps_n, eps_s, eps_k, delta_art, delta_ven, gamma_art, gamma_ven, phi, omega, kappa, delta_sigma */
     double modes[8][13];
@@ -415,12 +415,18 @@ typedef struct {
     double nerve_center[2];
     double nerve_radius;
     /* SimulationSpace.oxygen_sample_geometry_path (simulation_space.py:29-34,70-76): the loaded .npy mask, one byte per voxel in C
-     * order [76][76][1] (non-zero = sinks may be sampled there), or NULL for the analytic FAZ mask. With a geometry the space's
-     * extent is the mask's shape / 76 (size[] is ignored), candidate sinks are never rejected, and the stumps' wall positions come
-     * from a random valid voxel of the wall's face (face 0 for all four walls: `shape[axis] - 1` of the normalised shape,
-     * simulation_space.py:71). The bytes are copied by octa_sim_create. */
+     * order [g0][g1][g2] (non-zero = sinks may be sampled there; each dimension 1..65535, at most 2^26 voxels), or NULL for the
+     * analytic FAZ mask. With a geometry the space's extent is the mask's shape / its largest dimension (size[] is ignored), a
+     * candidate sink is (valid voxel + U[0,1)^3) / that dimension, kept when the voxel it maps back to is set, and the stumps' wall
+     * positions come from a random valid voxel of the wall's face (face 0 for every wall: `shape[axis] - 1` of the normalised
+     * shape, simulation_space.py:71). The bytes are copied by octa_sim_create. */
     const uint8_t *geometry;
     int geometry_shape[3];
+    /* n_source_walls > 0: the enabled source walls in the order of the configuration's mapping -- the reference draws the wall of
+     * every tree by position in that list (forest.py:81-91) -- as 0..5 = x0 x1 y0 y1 z0 z1; walls[] is then ignored. The z walls
+     * (forest.py:153-181) need a geometry: without one the reference fails (simulation_space.py:82-87). 0: walls[] in x0..y1 order. */
+    int n_source_walls;
+    int source_walls[6];
 } octa_sim_config;
 
 #define OCTA_BIF_MAX_ATTS 256

@@ -95,7 +95,8 @@ struct BatchPtrs {
     int *req_count;
     double *bif_results;
     unsigned *mt_state;          // [B][625] numpy stream after init (624 words + idx)
-    unsigned short *valid;       // [B][76*76*2]
+    unsigned short *valid;       // [B][valid_stride]: (i, j, k) per valid voxel; valid_stride = 0: one list for all samples (geometry file)
+    size_t valid_stride;
     unsigned *valid_count;       // [B]
     int *n_per_iter;             // [n_iter]
     int *next_sample;            // [1] work queue of the persistent kernel
@@ -204,7 +205,7 @@ struct WaveMt {
 
 // executed by wave 0 of the sample's workgroup; lds: 624 + 1248 + N words
 __device__ void gen_candidates_wave(unsigned *g_state /*[625]*/, const unsigned short *valid, unsigned K, int N, double *out,
-                                    unsigned *lds, unsigned *idx /* [N] scratch, LDS or HBM */, int lane) {
+                                    unsigned *lds, unsigned *idx /* [N] scratch, LDS or HBM */, int lane, double gs) {
     WaveMt g;
     g.st = lds; g.ob = lds + 624; g.lane = lane;
     for (int i = lane; i < 624; i += 64) g.st[i] = g_state[i];
@@ -251,8 +252,8 @@ __device__ void gen_candidates_wave(unsigned *g_state /*[625]*/, const unsigned 
             unsigned a = g.ob[g.cur + 2 * lane] >> 5, bb = g.ob[g.cur + 2 * lane + 1] >> 6;
             double u = (a * 67108864.0 + bb) / 9007199254740992.0;
             int j = j0 + lane, i = j / 3, c = j - 3 * i;
-            double vox = (c == 2) ? 0.0 : (double)valid[2 * idx[i] + c];
-            out[j] = (vox + u) / 76.0;
+            double vox = (double)valid[3 * idx[i] + c];
+            out[j] = (vox + u) / gs;
         }
         g.cur += 2 * m;
     }
@@ -318,9 +319,9 @@ sim_iter_a_kernel(BatchPtrs B, int it, int finish_prev) {
     {
         long _t0 = (long)wall_clock64();
         if (threadIdx.x < 64)
-            gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], P.N,
+            gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * B.valid_stride, B.valid_count[s], P.N,
                                 B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()),
-                                reinterpret_cast<unsigned *>(b.user()) + 624 + 1248, (int)threadIdx.x);
+                                reinterpret_cast<unsigned *>(b.user()) + 624 + 1248, (int)threadIdx.x, B.C.gs);
         __syncthreads();
         if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
     }
@@ -460,9 +461,9 @@ __device__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s, c
             if (it == 0) {   // later iterations get their candidates from the side job of the previous ordered arterial pass
                 long _t0 = (long)wall_clock64();
                 if (threadIdx.x < 64)
-                    gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], P.N,
+                    gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * B.valid_stride, B.valid_count[s], P.N,
                                         B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()),
-                                        reinterpret_cast<unsigned *>(b.user()) + 624 + 1248, (int)threadIdx.x);
+                                        reinterpret_cast<unsigned *>(b.user()) + 624 + 1248, (int)threadIdx.x, B.C.gs);
                 __syncthreads();
                 if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
             }
@@ -483,9 +484,9 @@ __device__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s, c
                 auto next_candidates = [&](unsigned char *lds) {
                     if (n_next <= 0) return;
                     const long _t0 = (long)wall_clock64();
-                    gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * 76 * 76 * 2, B.valid_count[s], n_next,
+                    gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * B.valid_stride, B.valid_count[s], n_next,
                                         B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(lds),
-                                        B.cand_idx + (size_t)s * NCANDCAP, (int)(threadIdx.x & 63));
+                                        B.cand_idx + (size_t)s * NCANDCAP, (int)(threadIdx.x & 63), B.C.gs);
                     if ((threadIdx.x & 63) == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
                 };
                 OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, results, next_candidates));
@@ -597,6 +598,8 @@ struct OCTA_SIM_T {
     std::vector<IterParams> iters;
     BatchPtrs P;
     std::vector<void *> allocs;
+    std::vector<unsigned short> fixed_valid;   // geometry file: the valid voxels (i, j, k), shared by all samples
+    unsigned char *d_mask = nullptr;           // geometry file: the mask in HBM (SimConst::mask)
     long *d_edge_off = nullptr;     // [B + 1] row offsets for the device-side edge export
     BifRequest *h_reqs = nullptr;   // pinned [2*REQ_CAP]
     double *h_results = nullptr;    // pinned [2*REQ_CAP*6]
@@ -657,16 +660,42 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, O
     cfg.sx = c->size[0]; cfg.sy = c->size[1]; cfg.sz = c->size[2]; cfg.n_trees = c->n_trees;
     int nw = 0;
     for (int w = 0; w < 4; w++) { cfg.walls[w] = c->walls[w]; nw += c->walls[w] ? 1 : 0; }
+    if (c->n_source_walls < 0 || c->n_source_walls > 6) { octa::set_error("octa_sim_create: n_source_walls must be 0..6"); delete S; return -2; }
+    if (c->n_source_walls > 0) {
+        nw = cfg.n_wall_list = c->n_source_walls;
+        for (int w = 0; w < nw; w++) {
+            cfg.wall_list[w] = c->source_walls[w];
+            if (cfg.wall_list[w] < 0 || cfg.wall_list[w] > 5) { octa::set_error("octa_sim_create: source_walls[%d] = %d is not a wall (0..5)", w, cfg.wall_list[w]); delete S; return -2; }
+            if (cfg.wall_list[w] >= 4 && !c->geometry && c->forest_type == 0) {   // simulation_space.py:82-87 reads `self.valid_pixels`, which nothing sets
+                octa::set_error("octa_sim_create: the z source walls need a sampling geometry file (the reference fails without one)");
+                delete S; return -2;
+            }
+        }
+    }
     cfg.forest_type = c->forest_type; cfg.nc0 = c->nerve_center[0]; cfg.nc1 = c->nerve_center[1]; cfg.nr = c->nerve_radius;
     if (c->geometry) {   // simulation_space.py:29-34
-        if (c->geometry_shape[0] != 76 || c->geometry_shape[1] != 76 || c->geometry_shape[2] != 1) {
-            octa::set_error("octa_sim_create: the sampling geometry must be a [76][76][1] mask (got [%d][%d][%d])", c->geometry_shape[0],
-                            c->geometry_shape[1], c->geometry_shape[2]);
+        const int *g = c->geometry_shape;
+        if (g[0] < 1 || g[1] < 1 || g[2] < 1 || g[0] > 65535 || g[1] > 65535 || g[2] > 65535 || (size_t)g[0] * g[1] * g[2] > ((size_t)1 << 26)) {
+            octa::set_error("octa_sim_create: sampling geometry [%d][%d][%d]: every dimension must be 1..65535 and the mask at most 2^26 voxels", g[0], g[1], g[2]);
             delete S; return -2;
         }
-        cfg.geometry.assign(c->geometry, c->geometry + 76 * 76);
-        cfg.sx = 1.0; cfg.sy = 1.0; cfg.sz = 1.0 / 76.0;       // shape = geometry.shape / max(geometry.shape)
+        for (int k = 0; k < 3; k++) cfg.gshape[k] = g[k];
+        cfg.geometry.assign(c->geometry, c->geometry + (size_t)g[0] * g[1] * g[2]);
+        const double gs = (double)cfg.gs();
+        cfg.sx = g[0] / gs; cfg.sy = g[1] / gs; cfg.sz = g[2] / gs;       // shape = geometry.shape / max(geometry.shape)
         if (cfg.forest_type != 0) { octa::set_error("octa_sim_create: a sampling geometry with nerve forests is not supported"); delete S; return -2; }
+        // a wall whose face 0 has no valid voxel: the reference's random.choice raises IndexError on the empty list
+        SampleInit probe;
+        std::vector<int> face[3];
+        init_mask(cfg, 0.0, &probe, face);
+        if (probe.valid.empty()) { octa::set_error("octa_sim_create: the sampling geometry has no valid voxel"); delete S; return -2; }
+        S->fixed_valid = probe.valid;
+        for (int w = 0; w < 6; w++) {
+            bool used = false;
+            if (cfg.n_wall_list > 0) { for (int k = 0; k < cfg.n_wall_list; k++) used |= cfg.wall_list[k] == w; }
+            else used = w < 4 && cfg.walls[w];
+            if (used && face[w >> 1].empty()) { octa::set_error("octa_sim_create: source wall %d: face 0 of the sampling geometry along axis %d has no valid voxel", w, w >> 1); delete S; return -2; }
+        }
     }
     if (cfg.forest_type != 0 && cfg.forest_type != 1) { octa::set_error("octa_sim_create: forest_type must be 0 (stumps) or 1 (nerve)"); delete S; return -2; }
     for (int m = 0; m < c->n_modes; m++) {
@@ -700,7 +729,20 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, O
     rc |= dev_alloc(S, &P.tmp_int, nb * (OCAP + 2 * NCANDCAP)); rc |= dev_alloc(S, &P.tmp_dbl, nb * OCAP * 3);
     rc |= dev_alloc(S, &P.sc, nb); rc |= dev_alloc(S, &P.iters, S->iters.size() + 1);
     rc |= dev_alloc(S, &P.reqs, (size_t)2 * REQ_CAP); rc |= dev_alloc(S, &P.req_count, 4); rc |= dev_alloc(S, &P.bif_results, (size_t)2 * REQ_CAP * 6);
-    rc |= dev_alloc(S, &P.mt_state, nb * 625); rc |= dev_alloc(S, &P.valid, nb * 76 * 76 * 2); rc |= dev_alloc(S, &P.valid_count, nb);
+    rc |= dev_alloc(S, &P.mt_state, nb * 625); rc |= dev_alloc(S, &P.valid_count, nb);
+    if (cfg.fixed()) {       // one voxel list and the mask itself, shared by every sample
+        P.valid_stride = 0;
+        rc |= dev_alloc(S, &P.valid, S->fixed_valid.size());
+        rc |= dev_alloc(S, &S->d_mask, cfg.geometry.size());
+        if (!rc) {
+            OCTA_HIP_CHECK(hipMemcpy(P.valid, S->fixed_valid.data(), S->fixed_valid.size() * 2, hipMemcpyHostToDevice));
+            OCTA_HIP_CHECK(hipMemcpy(S->d_mask, cfg.geometry.data(), cfg.geometry.size(), hipMemcpyHostToDevice));
+            P.C.mask = S->d_mask;
+        }
+    } else {
+        P.valid_stride = (size_t)76 * 76 * 3;
+        rc |= dev_alloc(S, &P.valid, nb * P.valid_stride);
+    }
     rc |= dev_alloc(S, &P.n_per_iter, S->iters.size() + 1);  // kept for diagnostics
     rc |= dev_alloc(S, &P.next_sample, 4);
     rc |= dev_alloc(S, &P.trace, nb * (S->iters.size() + 1) * 4);
@@ -822,7 +864,7 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
     {
         std::vector<SampleScalars> sc(B);
         std::vector<unsigned> mt((size_t)B * 625);
-        std::vector<unsigned short> valid((size_t)B * 76 * 76 * 2, 0);
+        std::vector<unsigned short> valid((size_t)B * P.valid_stride, 0);
         std::vector<unsigned> vcount(B);
         std::vector<unsigned> py_mt((size_t)B * 625);
         const int n0 = 2 * S->cfg.n_trees;
@@ -837,16 +879,16 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
             sc[s].n_nodes[0] = sc[s].n_nodes[1] = n0;
             memcpy(&mt[(size_t)s * 625], I.np_state.mt, 624 * 4);
             mt[(size_t)s * 625 + 624] = (unsigned)I.np_state.idx;
-            vcount[s] = (unsigned)(I.valid.size() / 2);
+            vcount[s] = (unsigned)(I.valid.size() / 3);
             if (vcount[s] == 0) { octa::set_error("octa_sim_run: sample %d has no valid voxel", s); return -2; }
-            memcpy(&valid[(size_t)s * 76 * 76 * 2], I.valid.data(), I.valid.size() * 2);
+            if (P.valid_stride) memcpy(&valid[(size_t)s * P.valid_stride], I.valid.data(), I.valid.size() * 2);
             memcpy(&py_mt[(size_t)s * 625], I.py_state.mt, 624 * 4);
             py_mt[(size_t)s * 625 + 624] = (unsigned)I.py_state.idx;
             for (int f = 0; f < 2; f++) memcpy(&npos[((size_t)s * 2 + f) * n0 * 3], I.pos[f].data(), sizeof(double) * n0 * 3);
         }
         OCTA_HIP_CHECK(hipMemcpyAsync(P.sc, sc.data(), sizeof(SampleScalars) * B, hipMemcpyHostToDevice, stream));
         OCTA_HIP_CHECK(hipMemcpyAsync(P.mt_state, mt.data(), mt.size() * 4, hipMemcpyHostToDevice, stream));
-        OCTA_HIP_CHECK(hipMemcpyAsync(P.valid, valid.data(), valid.size() * 2, hipMemcpyHostToDevice, stream));
+        if (P.valid_stride) OCTA_HIP_CHECK(hipMemcpyAsync(P.valid, valid.data(), valid.size() * 2, hipMemcpyHostToDevice, stream));
         OCTA_HIP_CHECK(hipMemcpyAsync(P.valid_count, vcount.data(), vcount.size() * 4, hipMemcpyHostToDevice, stream));
         OCTA_HIP_CHECK(hipMemcpyAsync(P.py_state, py_mt.data(), py_mt.size() * 4, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(py_uniform_kernel, dim3((unsigned)B), dim3(64), 0, stream, P.py_state, P.py_u, PYCAP);

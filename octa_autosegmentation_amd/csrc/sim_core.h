@@ -111,7 +111,11 @@ struct IterParams {
 
 struct SimConst {
     double ps, r, rotation_radius, fc0, fc1, sx, sy, sz;
+    double gs;          // SimulationSpace.geometry_size: 76, or the largest dimension of the geometry file's mask
     int n_iter, n_max;  // iterations, max candidates per iteration (stride of the candidate stream)
+    int fixed;          // a geometry file gives the mask (simulation_space.py:29-34): `mask` [gshape[0]][gshape[1]][gshape[2]] bytes
+    int gshape[3];
+    const unsigned char *mask;
 };
 
 // growth record of one node with attractors (one per group, dict order)
@@ -1531,7 +1535,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     (void)iter;
     const double en = fmax(P.eps_n, P.eps_k), es = P.eps_s;
     const double en2 = en * en;
-    const double GSd = 76.0;
+    const double GSd = C.gs;
     const double fcx = C.fc0 * GSd, fcy = C.fc1 * GSd, fr = sc->faz_radius * GSd * 0.5;
     int *vlist = A.tmp_int;               // valid candidate indices, in order
     int *plist = A.tmp_int + NCANDCAP;    // passing candidate indices, in order
@@ -1544,7 +1548,12 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
         for (int i = i0; i < i1; i++) {
             V3 p = ld3(cand + 3 * i);
             int ok = !(p.x >= C.sx || p.y >= C.sy || p.z >= C.sz || p.x < 0 || p.y < 0 || p.z < 0);
-            if (ok) {
+            if (ok && C.fixed) {
+                // geometry[(pos * geometry_size).astype(np.uint16)] > 0: the candidate came from a valid voxel, but (v + u) / gs * gs may
+                // land one voxel below v
+                const int vi = (int)(unsigned short)(int)(p.x * GSd), vj = (int)(unsigned short)(int)(p.y * GSd), vk = (int)(unsigned short)(int)(p.z * GSd);
+                ok = vi < C.gshape[0] && vj < C.gshape[1] && vk < C.gshape[2] && C.mask[((size_t)vi * C.gshape[1] + vj) * C.gshape[2] + vk] != 0;
+            } else if (ok) {
                 double dd = sqrt((p.x - fcx) * (p.x - fcx) + (p.y - fcy) * (p.y - fcy));
                 ok = dd > fr;
             }

@@ -8,6 +8,7 @@
 //   Forest._initialize_tree_stumps                        forest.py:68-181
 //   edge list order                                       generate_vessel_graph.py:43-56
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -106,19 +107,20 @@ inline uint32_t py_randbelow(Mt19937 &g, uint32_t n) {
 }
 
 // candidate stream of one sample: for every iteration N masked-rejection voxel picks, then N x 3
-// uniforms; candidate = (voxel + u) / 76 (simulation_space.py:57-67,106-110). ONE thread.
-OCTA_HD inline void gen_candidates(Mt19937 &g, const unsigned short *valid /*[K][2]*/, uint32_t K, const int *N_per_iter,
-                                   int n_iter, int n_max, double *out /*[n_iter][n_max][3]*/, unsigned *idx_scratch /*[n_max]*/) {
+// uniforms; candidate = (voxel + u) / geometry_size (simulation_space.py:57-67,106-110). ONE thread.
+OCTA_HD inline void gen_candidates(Mt19937 &g, const unsigned short *valid /*[K][3]*/, uint32_t K, const int *N_per_iter,
+                                   int n_iter, int n_max, double *out /*[n_iter][n_max][3]*/, unsigned *idx_scratch /*[n_max]*/,
+                                   double gs = 76.0) {
     for (int it = 0; it < n_iter; it++) {
         const int N = N_per_iter[it];
         for (int i = 0; i < N; i++) idx_scratch[i] = np_randint(g, K);
         double *o = out + (size_t)it * n_max * 3;
         for (int i = 0; i < N; i++) {
             double u0 = g.next_double(), u1 = g.next_double(), u2 = g.next_double();
-            const unsigned short *v = valid + 2 * idx_scratch[i];
-            o[3 * i] = ((double)v[0] + u0) / 76.0;
-            o[3 * i + 1] = ((double)v[1] + u1) / 76.0;
-            o[3 * i + 2] = (0.0 + u2) / 76.0;
+            const unsigned short *v = valid + 3 * idx_scratch[i];
+            o[3 * i] = ((double)v[0] + u0) / gs;
+            o[3 * i + 1] = ((double)v[1] + u1) / gs;
+            o[3 * i + 2] = ((double)v[2] + u2) / gs;
         }
     }
 }
@@ -132,7 +134,13 @@ struct SimConfig {
     int n_trees;
     int walls[4];
     std::vector<ModeCfg> modes;
-    std::vector<unsigned char> geometry;   // fixed geometry [76][76] (z extent 1), empty = analytic mask
+    std::vector<unsigned char> geometry;   // fixed geometry [gshape[0]][gshape[1]][gshape[2]] (C order), empty = analytic mask
+    int gshape[3] = {76, 76, 1};
+    int n_wall_list = 0;                   // > 0: the enabled source walls in the order of the configuration's mapping (forest.py:81-84),
+    int wall_list[6] = {0, 0, 0, 0, 0, 0}; //      0..5 = x0 x1 y0 y1 z0 z1; 0: walls[] (x0 x1 y0 y1 order)
+    bool fixed() const { return !geometry.empty(); }
+    // SimulationSpace.geometry_size (simulation_space.py:31, 41)
+    int gs() const { return fixed() ? std::max(gshape[0], std::max(gshape[1], gshape[2])) : 76; }
     int forest_type = 0;               // 0 stumps, 1 nerve
     double nc0 = 1e30, nc1 = 1e30, nr = 0;   // nerve_center / nerve_radius as configured (before the division by param_scale)
 };
@@ -168,12 +176,15 @@ inline std::vector<IterParams> build_iter_table(const SimConfig &cfg, SimConst *
     }
     C->ps = ps; C->r = cfg.r / ps; C->rotation_radius = cfg.rotation_radius / ps; C->fc0 = cfg.fc0; C->fc1 = cfg.fc1;
     C->sx = cfg.sx; C->sy = cfg.sy; C->sz = cfg.sz; C->n_iter = (int)tab.size(); C->n_max = n_max;
+    C->gs = (double)cfg.gs(); C->fixed = cfg.fixed() ? 1 : 0;
+    for (int c = 0; c < 3; c++) C->gshape[c] = cfg.fixed() ? cfg.gshape[c] : 0;
+    C->mask = nullptr;
     return tab;
 }
 
 struct SampleInit {
     double faz_radius;
-    std::vector<unsigned short> valid;   // [K][2] (i, j)
+    std::vector<unsigned short> valid;   // [K][3] (i, j, k): np.argwhere(geometry)
     Mt19937 np_state;                     // numpy stream after the forest stumps
     std::vector<double> py_u;             // PYCAP pre-drawn random.uniform(0,1) values after the stumps (host builds / tests only)
     Mt19937 py_state;                     // CPython's generator after the stumps: the device draws the uniforms itself (sim.hip)
@@ -183,8 +194,10 @@ struct SampleInit {
     int n_nodes[2];
 };
 
-// sink-sampling mask of one sample (simulation_space.py:36-54) and, for a fixed geometry, the valid voxels of the wall faces
-inline void init_mask(const SimConfig &cfg, double faz_radius, SampleInit *S, std::vector<int> *face_x, std::vector<int> *face_y) {
+// sink-sampling mask of one sample (simulation_space.py:36-54) and, for a fixed geometry, the valid voxels of the wall faces:
+// face[a] = pairs of the two remaining voxel indices of np.argwhere(np.take(geometry, 0, axis=a)), C order. (Face 0 for the far walls
+// too: `self.shape[along_axis] - 1` of the normalised shape lies in (-1, 0] and np.take truncates it to 0, simulation_space.py:71-72.)
+inline void init_mask(const SimConfig &cfg, double faz_radius, SampleInit *S, std::vector<int> face[3]) {
     const double ps = cfg.param_scale;
     const int GS = 76;
     const int gy = (int)std::ceil(cfg.sx * GS), gx = (int)std::ceil(cfg.sy * GS);
@@ -195,20 +208,24 @@ inline void init_mask(const SimConfig &cfg, double faz_radius, SampleInit *S, st
     const bool disc = (nerve_c0 - nerve_r <= 1.0) && (nerve_c1 - nerve_r <= 1.0);
     const double ncx = nerve_c0 * GS, ncy = nerve_c1 * GS, nrr = nerve_r * GS;
     S->valid.clear();
-    face_x->clear(); face_y->clear();
-    if (!cfg.geometry.empty()) {      // simulation_space.py:29-34: the mask comes from the geometry file
-        for (int i = 0; i < GS; i++)
-            for (int j = 0; j < GS; j++)
-                if (cfg.geometry[(size_t)i * GS + j]) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); }
-        for (int j = 0; j < GS; j++) if (cfg.geometry[j]) face_x->push_back(j);
-        for (int i = 0; i < GS; i++) if (cfg.geometry[(size_t)i * GS]) face_y->push_back(i);
+    for (int a = 0; a < 3; a++) face[a].clear();
+    if (cfg.fixed()) {      // simulation_space.py:29-34: the mask comes from the geometry file
+        const int G0 = cfg.gshape[0], G1 = cfg.gshape[1], G2 = cfg.gshape[2];
+        auto geo = [&](int i, int j, int k) { return cfg.geometry[((size_t)i * G1 + j) * G2 + k] != 0; };
+        for (int i = 0; i < G0; i++)
+            for (int j = 0; j < G1; j++)
+                for (int k = 0; k < G2; k++)
+                    if (geo(i, j, k)) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); S->valid.push_back((unsigned short)k); }
+        for (int j = 0; j < G1; j++) for (int k = 0; k < G2; k++) if (geo(0, j, k)) { face[0].push_back(j); face[0].push_back(k); }
+        for (int i = 0; i < G0; i++) for (int k = 0; k < G2; k++) if (geo(i, 0, k)) { face[1].push_back(i); face[1].push_back(k); }
+        for (int i = 0; i < G0; i++) for (int j = 0; j < G1; j++) if (geo(i, j, 0)) { face[2].push_back(i); face[2].push_back(j); }
         return;
     }
     for (int i = 0; i < gy; i++)
         for (int j = 0; j < gx; j++) {
             bool ok = (j - fcx) * (j - fcx) + (i - fcy) * (i - fcy) > fr * fr;
             if (ok && disc) ok = (j - ncx) * (j - ncx) + (i - ncy) * (i - ncy) > nrr * nrr;
-            if (ok) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); }
+            if (ok) { S->valid.push_back((unsigned short)i); S->valid.push_back((unsigned short)j); S->valid.push_back(0); }
         }
 }
 
@@ -217,10 +234,10 @@ inline void init_mask(const SimConfig &cfg, double faz_radius, SampleInit *S, st
 // generators' states afterwards
 inline void init_sample_given(const SimConfig &cfg, double faz_radius, const double *pos_art, const double *pos_ven, const Mt19937 &np,
                               Mt19937 py, SampleInit *S) {
-    std::vector<int> fx, fy;
+    std::vector<int> face[3];
     S->np_state = np;
     S->faz_radius = faz_radius;
-    init_mask(cfg, faz_radius, S, &fx, &fy);
+    init_mask(cfg, faz_radius, S, face);
     const size_t n = (size_t)2 * cfg.n_trees * 3;
     S->pos[0].assign(pos_art, pos_art + n);
     S->pos[1].assign(pos_ven, pos_ven + n);
@@ -240,13 +257,15 @@ inline void init_sample(const SimConfig &cfg, uint32_t np_seed, uint64_t py_seed
     const double ps = cfg.param_scale;
     const double d0 = cfg.d / ps;
     S->faz_radius = np_normal_first(np, cfg.faz_mean / ps, cfg.faz_std / ps);
-    const int GS = 76;
+    const int GS = cfg.gs();
     const double nerve_c0 = cfg.nc0 / ps, nerve_c1 = cfg.nc1 / ps, nerve_r = cfg.nr / ps;
-    const bool fixed = !cfg.geometry.empty();
-    std::vector<int> face_x, face_y;               // valid voxels of face 0 along axis 0 (index j) and axis 1 (index i)
-    init_mask(cfg, S->faz_radius, S, &face_x, &face_y);
+    const bool fixed = cfg.fixed();
+    std::vector<int> face[3];                      // valid voxels of face 0 along each axis
+    init_mask(cfg, S->faz_radius, S, face);
     std::vector<int> walls;
-    for (int w = 0; w < 4; w++) if (cfg.walls[w]) walls.push_back(w);
+    if (cfg.n_wall_list > 0) walls.assign(cfg.wall_list, cfg.wall_list + cfg.n_wall_list);
+    else
+        for (int w = 0; w < 4; w++) if (cfg.walls[w]) walls.push_back(w);
     for (int f = 0; f < 2; f++) {
         S->pos[f].clear();
         for (int t = 0; t < cfg.n_trees && cfg.forest_type == 1; t++) {
@@ -271,11 +290,12 @@ inline void init_sample(const SimConfig &cfg, uint32_t np_seed, uint64_t py_seed
             // numpy uniforms (the one along the wall axis is drawn and dropped)
             double fa = 0, fb = 0;
             if (fixed) {
-                const std::vector<int> &face = (wall == 0 || wall == 1) ? face_x : face_y;
-                const int v = face.empty() ? 0 : face[py_randbelow(py, (uint32_t)face.size())];
-                const double u0 = np.next_double(), u1 = np.next_double(), u2 = np.next_double();
-                if (wall == 0 || wall == 1) { fa = (v + u1) / GS; fb = (0 + u2) / GS; }
-                else { fa = (v + u0) / GS; fb = (0 + u2) / GS; }
+                const int axis = wall >> 1;
+                const std::vector<int> &fc = face[axis];      // octa_sim_create refuses a wall whose face has no valid voxel
+                const uint32_t pick = py_randbelow(py, (uint32_t)(fc.size() / 2));
+                const double u[3] = {np.next_double(), np.next_double(), np.next_double()};
+                const int ca = axis == 0 ? 1 : 0, cb = axis == 2 ? 1 : 2;   // the coordinates left after `del pos_3d[along_axis]`
+                fa = (fc[2 * pick] + u[ca]) / GS; fb = (fc[2 * pick + 1] + u[cb]) / GS;
             }
             if (wall == 0 || wall == 1) {
                 double y = fixed ? fa : np_uniform(np, 0, cfg.sy), z = fixed ? fb : np_uniform(np, 0, cfg.sz);
@@ -283,12 +303,18 @@ inline void init_sample(const SimConfig &cfg, uint32_t np_seed, uint64_t py_seed
                 dir[0] = wall == 0 ? np_uniform(np, 0.1, 1) : np_uniform(np, -1, -0.1);
                 dir[1] = np_uniform(np, y - d0 > 0 ? -1 : 0, y + d0 < cfg.sy ? 1 : 0);
                 dir[2] = np_uniform(np, z - d0 > 0 ? -1 : 0, z + d0 < cfg.sz ? 1 : 0);
-            } else {
+            } else if (wall == 2 || wall == 3) {
                 double x = fixed ? fa : np_uniform(np, 0, cfg.sx), z = fixed ? fb : np_uniform(np, 0, cfg.sz);
                 p[0] = x; p[1] = wall == 2 ? 0.0 : cfg.sy - 1e-6; p[2] = z;
                 dir[0] = np_uniform(np, x - d0 > 0 ? -1 : 0, x + d0 < cfg.sx ? 1 : 0);
                 dir[1] = wall == 2 ? np_uniform(np, 0.1, 1) : np_uniform(np, -1, -0.1);
                 dir[2] = np_uniform(np, z - d0 > 0 ? -1 : 0, z + d0 < cfg.sz ? 1 : 0);
+            } else {   // z0 / z1 (forest.py:153-181): only with a geometry file (simulation_space.py:82-87 fails without one)
+                const double x = fa, y = fb;
+                p[0] = x; p[1] = y; p[2] = wall == 4 ? 0.0 : cfg.sz - 1e-6;
+                dir[0] = np_uniform(np, x - d0 > 0 ? -1 : 0, x + d0 < cfg.sx ? 1 : 0);
+                dir[1] = np_uniform(np, y - d0 > 0 ? -1 : 0, y + d0 < cfg.sy ? 1 : 0);
+                dir[2] = wall == 4 ? np_uniform(np, 0.1, 1) : np_uniform(np, -1, -0.1);
             }
             double nrm = std::sqrt(std::fma(dir[2], dir[2], std::fma(dir[1], dir[1], dir[0] * dir[0])));
             for (int c = 0; c < 3; c++) S->pos[f].push_back(p[c]);

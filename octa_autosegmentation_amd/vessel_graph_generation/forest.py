@@ -50,17 +50,18 @@ class Forest:
 
         for i in range(1, config["N_trees"] + 1):
             wall = random.choice(walls)
-            if wall not in ("x0", "x1", "y0", "y1"):
-                raise NotImplementedError("z source walls are not on the GPU path")
-            axis, far = "xy".index(wall[0]), wall[1] == "1"
-            a, z = self.sim_space.get_random_valid_position(along_axis=axis, first=not far)
+            axis, far = "xyz".index(wall[0]), wall[1] == "1"
+            a, z = self.sim_space.get_random_valid_position(along_axis=axis, first=not far or axis == 2)   # reference :169: z1 asks for `first` too
             inward = (lambda: np.random.uniform(-1, -0.1)) if far else (lambda: np.random.uniform(0.1, 1))
             if axis == 0:
                 position = np.array([self.size_x - 1e-6 if far else 0, a, z])
                 direction = np.array([inward(), free(a, 1), free(z, 2)])
-            else:
+            elif axis == 1:
                 position = np.array([a, self.size_y - 1e-6 if far else 0, z])
                 direction = np.array([free(a, 0), inward(), free(z, 2)])
+            else:               # reference :153-181 (a = x, z = y here)
+                position = np.array([a, z, self.size_z - 1e-6 if far else 0])
+                direction = np.array([free(a, 0), free(z, 1), inward()])
             direction = direction / np.linalg.norm(direction) * d_0
             tree = ArterialTree(self._name(i), tuple(position), r_0, self.size_x, self.size_y, self.size_z, self)
             tree.add_node(position=tuple(position + direction), radius=r_0, parent=tree.root)

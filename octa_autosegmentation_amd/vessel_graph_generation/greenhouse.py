@@ -27,7 +27,8 @@ class SimConfigStruct(ctypes.Structure):
                 ("size", ctypes.c_double * 3), ("n_trees", ctypes.c_int), ("walls", ctypes.c_int * 4),
                 ("n_modes", ctypes.c_int), ("modes", (ctypes.c_double * 13) * 8),
                 ("forest_type", ctypes.c_int), ("nerve_center", ctypes.c_double * 2), ("nerve_radius", ctypes.c_double),
-                ("geometry", ctypes.c_void_p), ("geometry_shape", ctypes.c_int * 3)]
+                ("geometry", ctypes.c_void_p), ("geometry_shape", ctypes.c_int * 3),
+                ("n_source_walls", ctypes.c_int), ("source_walls", ctypes.c_int * 6)]
 
 
 REQ_DTYPE = np.dtype([("sample", np.int32), ("n", np.int32), ("pos", np.float64, 3), ("r", np.float64),
@@ -41,11 +42,16 @@ def config_to_struct(config):
     if f["type"] not in ("stumps", "nerve"):
         raise NotImplementedError(f"The Forest initialization type '{f['type']}' is not implemented. Try 'stumps' or 'nerve' instead.")
     walls = f["source_walls"]
-    if walls.get("z0") or walls.get("z1"):
-        raise NotImplementedError("z source walls are not on the GPU path yet")
-    if [k for k, v in walls.items() if v] != [k for k in ("x0", "x1", "y0", "y1") if walls.get(k)]:
-        raise NotImplementedError("source_walls must be listed in x0, x1, y0, y1 order")
+    geo_path = g["SimulationSpace"].get("oxygen_sample_geometry_path")
+    wall_names = ("x0", "x1", "y0", "y1", "z0", "z1")
+    enabled = [k for k, v in walls.items() if v]       # forest.py:81-91: the wall is drawn by its position in the mapping
+    if f["type"] == "stumps" and geo_path is None and any(k in ("z0", "z1") for k in enabled):
+        # simulation_space.py:82-87: without a geometry file the z branch reads an attribute nothing sets
+        raise AttributeError("'SimulationSpace' object has no attribute 'valid_pixels'")
     p = SimConfigStruct()
+    p.n_source_walls = len(enabled)
+    for i, k in enumerate(enabled):
+        p.source_walls[i] = wall_names.index(k)
     p.param_scale, p.d, p.r = g["param_scale"], g["d"], g["r"]
     p.faz_radius_mean, p.faz_radius_std = g["FAZ_radius_bound"]
     p.rotation_radius = g["rotation_radius"]
@@ -55,11 +61,10 @@ def config_to_struct(config):
     p.n_trees = f["N_trees"]
     for i, k in enumerate(("x0", "x1", "y0", "y1")):
         p.walls[i] = 1 if walls.get(k) else 0
-    geo_path = g["SimulationSpace"].get("oxygen_sample_geometry_path")
     if geo_path is not None:     # simulation_space.py:29-34: the sink-sampling mask (and the space's extent) come from a .npy file
         geo = np.ascontiguousarray(np.load(geo_path) != 0, dtype=np.uint8)
-        if geo.shape != (76, 76, 1):
-            raise NotImplementedError(f"sampling geometries other than [76, 76, 1] masks are not on the GPU path (got {geo.shape})")
+        if geo.ndim != 3:
+            raise ValueError(f"the sampling geometry must be a 3-D mask (got shape {geo.shape})")
         if f["type"] != "stumps":
             raise NotImplementedError("a sampling geometry with nerve forests is not on the GPU path")
         p._geometry_keepalive = geo          # the struct only carries the pointer

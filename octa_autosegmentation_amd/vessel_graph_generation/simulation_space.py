@@ -53,7 +53,8 @@ class SimulationSpace:
             return np.random.uniform(0, self.size_y), np.random.uniform(0, self.size_z)
         if along_axis == 1:
             return np.random.uniform(0, self.size_x), np.random.uniform(0, self.size_z)
-        raise NotImplementedError("z source walls are not on the GPU path")
+        # reference :82-87: the z branch reads `self.valid_pixels`, which nothing sets -- z walls work with a geometry file only
+        raise AttributeError("'SimulationSpace' object has no attribute 'valid_pixels'")
 
     def is_valid_position(self, pos):
         """Reference :90-99 (the FAZ test compares a unit-cube position with the voxel-scaled centre, as the reference does)."""

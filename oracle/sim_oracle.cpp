@@ -370,8 +370,10 @@ struct octa_sim_params {
     double modes[8][13];  // I, N, eps_n, eps_s, eps_k, delta_art, delta_ven, gamma_art, gamma_ven, phi, omega, kappa, delta_sigma
     int forest_type;      // 0 'stumps' (forest.py:68-181), 1 'nerve' (forest.py:38-66)
     double nerve_center[2], nerve_radius;   // as configured (greenhouse.py:28-29 divides them by param_scale)
-    const unsigned char *geometry;          // oxygen_sample_geometry_path mask [76][76][1] or NULL (simulation_space.py:29-34)
+    const unsigned char *geometry;          // oxygen_sample_geometry_path mask [g0][g1][g2], C order, or NULL (simulation_space.py:29-34)
     int geometry_shape[3];
+    int n_source_walls;                     // > 0: the enabled walls in the order of the YAML mapping (forest.py:81-84), 0..5 = x0 x1 y0 y1 z0 z1
+    int source_walls[6];                    //      (walls[] is then ignored); the z walls need a geometry file (simulation_space.py:82-87)
 };
 
 struct octa_sim_result {
@@ -406,31 +408,37 @@ int octa_oracle_simulate(const octa_sim_params *P, uint32_t np_seed, uint64_t py
     const double rotation_radius = P->rotation_radius / ps;
     const double fc0 = P->faz_center[0], fc1 = P->faz_center[1];
     // ---- SimulationSpace.__init__ (simulation_space.py:36-54), no nerve disc for the docker config
-    const int GS = 76;
     const bool fixed = P->geometry != nullptr;
-    if (fixed && (P->geometry_shape[0] != GS || P->geometry_shape[1] != GS || P->geometry_shape[2] != 1)) return -4;
-    // fixed geometry: shape = geometry.shape / max(geometry.shape) (simulation_space.py:31-33)
-    const double sx = fixed ? 1.0 : P->size[0], sy = fixed ? 1.0 : P->size[1], sz = fixed ? 1.0 / GS : P->size[2];
+    const int G0 = fixed ? P->geometry_shape[0] : 0, G1 = fixed ? P->geometry_shape[1] : 0, G2 = fixed ? P->geometry_shape[2] : 0;
+    if (fixed && (G0 <= 0 || G1 <= 0 || G2 <= 0 || G0 > 65535 || G1 > 65535 || G2 > 65535)) return -4;
+    // fixed geometry: geometry_size = max(geometry.shape), shape = geometry.shape / geometry_size (simulation_space.py:31-33)
+    const int GS = fixed ? std::max(G0, std::max(G1, G2)) : 76;
+    const double sx = fixed ? (double)G0 / GS : P->size[0], sy = fixed ? (double)G1 / GS : P->size[1], sz = fixed ? (double)G2 / GS : P->size[2];
     const int gy = (int)std::ceil(sx * GS), gx = (int)std::ceil(sy * GS);
     const double fcx = fc0 * GS, fcy = fc1 * GS, fr = FAZ_radius * GS * 0.5;
     // greenhouse.py:28-29, simulation_space.py:48-50: the optic-nerve disc leaves the mask when it is inside the field of view
     const double nerve_c0 = P->nerve_center[0] / ps, nerve_c1 = P->nerve_center[1] / ps, nerve_r = P->nerve_radius / ps;
     const bool disc = (nerve_c0 - nerve_r <= 1.0) && (nerve_c1 - nerve_r <= 1.0);
     const double ncx = nerve_c0 * GS, ncy = nerve_c1 * GS, nrr = nerve_r * GS;
-    std::vector<std::array<int, 2>> valid;
-    std::vector<int> face_x, face_y;   // simulation_space.py:70-76: valid voxels of face 0 along axis 0 / axis 1
+    std::vector<std::array<int, 3>> valid;    // np.argwhere(geometry): C order
+    // simulation_space.py:70-76: np.argwhere over face 0 along the wall's axis -- for every wall: `shape[axis] - 1` of the NORMALISED
+    // shape lies in (-1, 0] and np.take truncates it to 0. face[a] = the two remaining voxel indices, C order of the 2-D face.
+    std::vector<std::array<int, 2>> face[3];
+    auto geo = [&](int i, int j, int k) { return P->geometry[((size_t)i * G1 + j) * G2 + k] != 0; };
     if (fixed) {
-        for (int i = 0; i < GS; i++)
-            for (int j = 0; j < GS; j++)
-                if (P->geometry[(size_t)i * GS + j]) valid.push_back({i, j});
-        for (int j = 0; j < GS; j++) if (P->geometry[j]) face_x.push_back(j);
-        for (int i = 0; i < GS; i++) if (P->geometry[(size_t)i * GS]) face_y.push_back(i);
+        for (int i = 0; i < G0; i++)
+            for (int j = 0; j < G1; j++)
+                for (int k = 0; k < G2; k++)
+                    if (geo(i, j, k)) valid.push_back({i, j, k});
+        for (int j = 0; j < G1; j++) for (int k = 0; k < G2; k++) if (geo(0, j, k)) face[0].push_back({j, k});
+        for (int i = 0; i < G0; i++) for (int k = 0; k < G2; k++) if (geo(i, 0, k)) face[1].push_back({i, k});
+        for (int i = 0; i < G0; i++) for (int j = 0; j < G1; j++) if (geo(i, j, 0)) face[2].push_back({i, j});
     } else
     for (int i = 0; i < gy; i++)
         for (int j = 0; j < gx; j++) {
             bool ok = (j - fcx) * (j - fcx) + (i - fcy) * (i - fcy) > fr * fr;
             if (ok && disc) ok = (j - ncx) * (j - ncx) + (i - ncy) * (i - ncy) > nrr * nrr;
-            if (ok) valid.push_back({i, j});
+            if (ok) valid.push_back({i, j, 0});
         }
     const uint32_t K = (uint32_t)valid.size();
 
@@ -455,7 +463,14 @@ int octa_oracle_simulate(const octa_sim_params *P, uint32_t np_seed, uint64_t py
     // ---- Forest stumps (forest.py:68-181), arterial then venous
     Forest forest[2];
     std::vector<int> walls;
-    for (int w = 0; w < 4; w++) if (P->walls[w]) walls.push_back(w);
+    if (P->n_source_walls > 0) {
+        for (int w = 0; w < P->n_source_walls && w < 6; w++) {
+            if (P->source_walls[w] < 0 || P->source_walls[w] > 5) return -3;
+            if (P->source_walls[w] >= 4 && !fixed) return -3;   // simulation_space.py:82-87: AttributeError (`valid_pixels`) in the reference
+            walls.push_back(P->source_walls[w]);
+        }
+    } else
+        for (int w = 0; w < 4; w++) if (P->walls[w]) walls.push_back(w);
     if (walls.empty() && P->forest_type == 0) return -3;
     for (int f = 0; f < 2; f++) {
         for (int t = 0; t < P->n_trees && P->forest_type == 1; t++) {   // forest.py:38-66
@@ -478,12 +493,13 @@ int octa_oracle_simulate(const octa_sim_params *P, uint32_t np_seed, uint64_t py
             const double d0 = d;
             double fa = 0, fb = 0;
             if (fixed) {   // get_random_valid_position: random.choice over the face's valid voxels + np.random.uniform(0, 1, 3)
-                const std::vector<int> &face = (wall == 0 || wall == 1) ? face_x : face_y;
-                if (face.empty()) return -3;
-                const int v = face[py.randbelow((uint32_t)face.size())];
-                const double u0 = np.uniform(0, 1), u1 = np.uniform(0, 1), u2 = np.uniform(0, 1);
-                if (wall == 0 || wall == 1) { fa = (v + u1) / GS; fb = (0 + u2) / GS; }
-                else { fa = (v + u0) / GS; fb = (0 + u2) / GS; }
+                const int axis = wall >> 1;
+                const std::vector<std::array<int, 2>> &fc = face[axis];
+                if (fc.empty()) return -3;
+                const std::array<int, 2> v = fc[py.randbelow((uint32_t)fc.size())];
+                const double u[3] = {np.uniform(0, 1), np.uniform(0, 1), np.uniform(0, 1)};
+                const int ca = axis == 0 ? 1 : 0, cb = axis == 2 ? 1 : 2;   // the coordinates that stay after `del pos_3d[along_axis]`
+                fa = (v[0] + u[ca]) / GS; fb = (v[1] + u[cb]) / GS;
             }
             if (wall == 0 || wall == 1) {
                 double y = fixed ? fa : np.uniform(0, sy), z = fixed ? fb : np.uniform(0, sz);
@@ -492,12 +508,19 @@ int octa_oracle_simulate(const octa_sim_params *P, uint32_t np_seed, uint64_t py
                 double b = np.uniform(y - d0 > 0 ? -1 : 0, y + d0 < sy ? 1 : 0);
                 double c = np.uniform(z - d0 > 0 ? -1 : 0, z + d0 < sz ? 1 : 0);
                 dir = {a, b, c};
-            } else {
+            } else if (wall == 2 || wall == 3) {
                 double x = fixed ? fa : np.uniform(0, sx), z = fixed ? fb : np.uniform(0, sz);
                 pos = {x, wall == 2 ? 0.0 : sy - 1e-6, z};
                 double a = np.uniform(x - d0 > 0 ? -1 : 0, x + d0 < sx ? 1 : 0);
                 double b = wall == 2 ? np.uniform(0.1, 1) : np.uniform(-1, -0.1);
                 double c = np.uniform(z - d0 > 0 ? -1 : 0, z + d0 < sz ? 1 : 0);
+                dir = {a, b, c};
+            } else {       // z0 / z1 (forest.py:153-181), fixed geometry only
+                const double x = fa, y = fb;
+                pos = {x, y, wall == 4 ? 0.0 : sz - 1e-6};
+                double a = np.uniform(x - d0 > 0 ? -1 : 0, x + d0 < sx ? 1 : 0);
+                double b = np.uniform(y - d0 > 0 ? -1 : 0, y + d0 < sy ? 1 : 0);
+                double c = wall == 4 ? np.uniform(0.1, 1) : np.uniform(-1, -0.1);
                 dir = {a, b, c};
             }
             dir = mul(divs(dir, norm3(dir)), d0);
@@ -688,11 +711,16 @@ int octa_oracle_simulate(const octa_sim_params *P, uint32_t np_seed, uint64_t py
                 std::vector<V3> cand;
                 for (int i = 0; i < N; i++) {
                     double u0 = np.uniform(0, 1), u1 = np.uniform(0, 1), u2 = np.uniform(0, 1);
-                    V3 p = {(valid[idx[i]][0] + u0) / GS, (valid[idx[i]][1] + u1) / GS, (0 + u2) / GS};
+                    V3 p = {(valid[idx[i]][0] + u0) / GS, (valid[idx[i]][1] + u1) / GS, (valid[idx[i]][2] + u2) / GS};
                     // simulation_space.py:89-98 (the FAZ test compares unit coordinates with the voxel-unit centre)
                     if (p[0] >= sx || p[1] >= sy || p[2] >= sz || p[0] < 0 || p[1] < 0 || p[2] < 0) continue;
-                    double dd = std::sqrt((p[0] - fcx) * (p[0] - fcx) + (p[1] - fcy) * (p[1] - fcy));
-                    if (!(dd > fr)) continue;
+                    if (fixed) {   // geometry[(pos * geometry_size).astype(np.uint16)] > 0: the product may land one voxel below
+                        const int vi = (int)(uint16_t)(p[0] * GS), vj = (int)(uint16_t)(p[1] * GS), vk = (int)(uint16_t)(p[2] * GS);
+                        if (vi >= G0 || vj >= G1 || vk >= G2 || !geo(vi, vj, vk)) continue;
+                    } else {
+                        double dd = std::sqrt((p[0] - fcx) * (p[0] - fcx) + (p[1] - fcy) * (p[1] - fcy));
+                        if (!(dd > fr)) continue;
+                    }
                     cand.push_back(p);
                 }
                 std::vector<V3> to_add;

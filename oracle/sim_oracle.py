@@ -25,7 +25,8 @@ class SimParams(ctypes.Structure):
                 ("size", ctypes.c_double * 3), ("n_trees", ctypes.c_int), ("walls", ctypes.c_int * 4),
                 ("n_modes", ctypes.c_int), ("modes", (ctypes.c_double * 13) * 8),
                 ("forest_type", ctypes.c_int), ("nerve_center", ctypes.c_double * 2), ("nerve_radius", ctypes.c_double),
-                ("geometry", ctypes.c_void_p), ("geometry_shape", ctypes.c_int * 3)]
+                ("geometry", ctypes.c_void_p), ("geometry_shape", ctypes.c_int * 3),
+                ("n_source_walls", ctypes.c_int), ("source_walls", ctypes.c_int * 6)]
 
 
 class SimResult(ctypes.Structure):
@@ -106,7 +107,7 @@ def params_from_config(config):
         raise NotImplementedError("oracle covers Forest.type 'stumps' (forest.py:68-181) and 'nerve' (forest.py:38-66)")
     p = SimParams()
     geo_path = g["SimulationSpace"].get("oxygen_sample_geometry_path")
-    if geo_path is not None:      # simulation_space.py:29-34 ([76, 76, 1] masks)
+    if geo_path is not None:      # simulation_space.py:29-34
         geo = np.ascontiguousarray(np.load(geo_path) != 0, dtype=np.uint8)
         p._geometry_keepalive = geo
         p.geometry = geo.ctypes.data
@@ -122,12 +123,15 @@ def params_from_config(config):
     p.nerve_radius = g["nerve_radius"]
     p.n_trees = f["N_trees"]
     walls = f["source_walls"]
-    if walls.get("z0") or walls.get("z1"):
-        raise NotImplementedError("z walls are not covered")
-    if list(k for k, v in walls.items() if v) != [k for k in ("x0", "x1", "y0", "y1") if walls.get(k)]:
-        raise NotImplementedError("source_walls must be listed in x0,x1,y0,y1 order")
-    for i, k in enumerate(("x0", "x1", "y0", "y1")):
+    names = ("x0", "x1", "y0", "y1", "z0", "z1")
+    enabled = [k for k, v in walls.items() if v]          # forest.py:81-84: the order of the mapping
+    if (walls.get("z0") or walls.get("z1")) and geo_path is None:
+        raise AttributeError("'SimulationSpace' object has no attribute 'valid_pixels'")   # simulation_space.py:83
+    for i, k in enumerate(names[:4]):
         p.walls[i] = 1 if walls.get(k) else 0
+    p.n_source_walls = len(enabled)
+    for i, k in enumerate(enabled):
+        p.source_walls[i] = names.index(k)
     p.n_modes = len(g["modes"])
     for m, mode in enumerate(g["modes"]):
         for j, key in enumerate(MODE_KEYS):

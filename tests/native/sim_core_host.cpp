@@ -18,8 +18,11 @@ struct host_sim_params {
     double param_scale, d, r, faz_mean, faz_std, rotation_radius, fc[2], size[3];
     int n_trees, walls[4], n_modes;
     double modes[8][13];
-    int forest_type;                 // the leading fields of oracle/sim_oracle.py: SimParams (same layout)
+    int forest_type;                 // oracle/sim_oracle.py: SimParams (same layout)
     double nerve_center[2], nerve_radius;
+    const unsigned char *geometry;   // geometry file's mask or NULL
+    int geometry_shape[3];
+    int n_source_walls, source_walls[6];
 };
 
 double octa_simcore_gpow(double x, double y) { return octa_gpow::gpow(x, y); }
@@ -74,12 +77,22 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     cfg.sx = hp->size[0]; cfg.sy = hp->size[1]; cfg.sz = hp->size[2]; cfg.n_trees = hp->n_trees;
     for (int w = 0; w < 4; w++) cfg.walls[w] = hp->walls[w];
     cfg.forest_type = hp->forest_type; cfg.nc0 = hp->nerve_center[0]; cfg.nc1 = hp->nerve_center[1]; cfg.nr = hp->nerve_radius;
+    cfg.n_wall_list = hp->n_source_walls;
+    for (int w = 0; w < hp->n_source_walls && w < 6; w++) cfg.wall_list[w] = hp->source_walls[w];
+    if (hp->geometry) {
+        const int *g = hp->geometry_shape;
+        for (int k = 0; k < 3; k++) cfg.gshape[k] = g[k];
+        cfg.geometry.assign(hp->geometry, hp->geometry + (size_t)g[0] * g[1] * g[2]);
+        const double gs = (double)cfg.gs();
+        cfg.sx = g[0] / gs; cfg.sy = g[1] / gs; cfg.sz = g[2] / gs;
+    }
     for (int m = 0; m < hp->n_modes; m++) {
         const double *q = hp->modes[m];
         cfg.modes.push_back(ModeCfg{(int)q[0], (int)q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11], q[12]});
     }
     SimConst C;
     std::vector<IterParams> tab = build_iter_table(cfg, &C);
+    C.mask = cfg.fixed() ? cfg.geometry.data() : nullptr;
     SampleInit S;
     init_sample(cfg, np_seed, py_seed_v, &S);
 
@@ -123,7 +136,7 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     A.hashes = hashes.data(); A.pairs = pairs.data(); A.set_hash = set_hash.data(); A.set_key = set_key.data();
     A.tmp_int = tmp_int.data(); A.tmp_dbl = tmp_dbl.data();
     std::vector<unsigned> idx_scratch(NCANDCAP + 1);
-    const uint32_t Kvox = (uint32_t)(S.valid.size() / 2);
+    const uint32_t Kvox = (uint32_t)(S.valid.size() / 3);
 
     std::vector<unsigned char> smem((size_t)SIM_LDS_BYTES + 64);
     Blk b = {0, 1, smem.data()};
@@ -137,7 +150,7 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     for (int it = 0; it < C.n_iter; it++) {
         const IterParams &P = tab[it];
         int req_count = 0;
-        { int Nn = P.N; gen_candidates(S.np_state, S.valid.data(), Kvox, &Nn, 1, Nn, cand.data(), idx_scratch.data()); }
+        { int Nn = P.N; gen_candidates(S.np_state, S.valid.data(), Kvox, &Nn, 1, Nn, cand.data(), idx_scratch.data(), C.gs); }
         phase_sample(b, A, C, P, it);
         phase_assign(b, A, 0, A.oxy, sc.n_oxy, P.delta_art);
         phase_pre(b, A, C, P, 0, A.oxy, reqs.data(), &req_count, REQ_CAP, 0);

@@ -69,6 +69,24 @@ def test_constructors_draw_what_the_reference_draws(name, tmp_path):
         root.get_proximal_node()
 
 
+def test_constructors_on_other_masks_and_z_walls(tmp_path):
+    """Stump draws on masks of other shapes and on the z walls (simulation_space.py:70-76, forest.py:153-181) against the
+    reference-made fixtures; without a geometry file the z walls fail as they do in the reference."""
+    from _sim_cases import mask_cases
+    for name, cfg, seed, g in mask_cases(tmp_path):
+        greenhouse, art, ven = _construct(cfg, seed)
+        assert greenhouse.FAZ_radius == float(g[name + "_faz"])
+        want = [row.rsplit(",", 1)[0] for row in g[name + "_csv"].tobytes().decode().split("\r\n")]
+        at = 0
+        for line in _rows([art, ven]).split("\r\n")[1:-1]:
+            at = want.index(line.rsplit(",", 1)[0], at) + 1
+    gold = np.load(GOLDEN)
+    seed, cfg = _case(gold, "run_s5_10_5", tmp_path)
+    cfg["Forest"]["source_walls"] = {"z0": True}
+    with pytest.raises(AttributeError):
+        _construct(cfg, seed)
+
+
 def test_unknown_forest_type_is_rejected():
     from octa_autosegmentation_amd.vessel_graph_generation.forest import Forest
     with pytest.raises(NotImplementedError):
@@ -84,6 +102,19 @@ def test_develop_forest_equals_reference_run(name, tmp_path, hip_lib_built):
     seed, cfg = _case(g, name, tmp_path)
     greenhouse, art, ven = _construct(cfg, seed)
     greenhouse.develop_forest()
+    _check_developed(g, name, cfg, greenhouse, art, ven, tmp_path)
+
+
+@pytest.mark.gpu
+def test_develop_forest_on_other_masks_and_z_walls(tmp_path, hip_lib_built):
+    from _sim_cases import mask_cases
+    for name, cfg, seed, g in mask_cases(tmp_path):
+        greenhouse, art, ven = _construct(cfg, seed)
+        greenhouse.develop_forest()
+        _check_developed(g, name, cfg, greenhouse, art, ven, tmp_path / name)
+
+
+def _check_developed(g, name, cfg, greenhouse, art, ven, tmp_path):
     assert _rows([art, ven]).encode() == g[name + "_csv"].tobytes()
     assert sum(1 for _ in art.get_nodes()) - cfg["Forest"]["N_trees"] == int(g[name + "_n_art"])
     assert (greenhouse.oxys == g[name + "_oxy"]).all() and (greenhouse.co2s == g[name + "_co2"]).all()

@@ -34,9 +34,50 @@ def core():
     return l
 
 
+def _load_core(so_name, extra_flags):
+    src = os.path.join(ROOT, "tests", "native", "sim_core_host.cpp")
+    so = os.path.join(ROOT, "tests", "native", so_name)
+    deps = [src] + [os.path.join(ROOT, "octa_autosegmentation_amd", "csrc", f) for f in ("sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h", "glibc_trig.h", "glibc_trig_tables.h")]
+    if not os.path.exists(so) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", "-fPIC", "-shared"] + extra_flags + ["-o", so, src])
+    l = ctypes.CDLL(so)
+    l.octa_simcore_host_run.restype = ctypes.c_int
+    l.octa_simcore_host_run.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_ulonglong, sim_oracle.BIF_CB, ctypes.c_void_p,
+                                        ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
+    return l
+
+
+@pytest.fixture(scope="module")
+def core_large():
+    """The same host harness compiled with -DOCTA_SIM_LARGE=1: the wide-field build of the phase code (32-bit indices, 64-bit kd
+    elements, 18-bit packed indices)."""
+    return _load_core("libsimcorehost_large.so", ["-DOCTA_SIM_LARGE=1"])
+
+
 @pytest.fixture(scope="module")
 def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
+
+
+def test_wide_field_build_reproduces_the_notebook_run(core_large):
+    """f4 at full size, on the CPU: the reference's notebook configuration (example_custom_vessel_simulation.ipynb:138-156: 12 x 12 mm^2,
+    optic-nerve forests with 16 trees, N = 8000, 400 + 500 iterations) through the wide-field build of the phase code, one host
+    thread, against tests/golden/sim_f4_golden.npz -- the imported reference's own full-length run (tools/make_golden_sim_f4.py,
+    26 minutes per seed): every one of the 900 trace rows and the SHA-256 of the 73 389-row CSV text. About 10 s."""
+    import hashlib
+    f4 = np.load(os.path.join(ROOT, "tests", "golden", "sim_f4_golden.npz"))
+    cfg = yaml.safe_load(str(f4["config_yaml"]))
+    seed = int(f4["seeds"][0])
+    p = sim_oracle.params_from_config(cfg)
+    n_it = 900
+    cap = 200000
+    edges = np.zeros((cap, 7)); trace = np.zeros((n_it, 4), np.int64); info = np.zeros(8, np.int64)
+    rc = core_large.octa_simcore_host_run(ctypes.addressof(p), seed, seed, sim_oracle._bif_cb, edges.ctypes.data, cap, trace.ctypes.data, info.ctypes.data)
+    assert rc == 0 and info[2] == 0 and info[7] == n_it
+    assert (trace == f4[f"s{seed}_trace"]).all()
+    assert info[0] == int(f4[f"s{seed}_rows"])
+    assert hashlib.sha256(sim_oracle.edges_to_csv_text(edges[: info[0]]).encode()).hexdigest() == str(f4[f"s{seed}_csv_sha256"])
+
 
 
 def test_gpow_is_glibc_pow(core):
@@ -100,6 +141,25 @@ def test_phases_reproduce_reference_csv(core, golden):
         # on the host (glibc's acos / cos / sin) the phase code equals the oracle in EVERY double, not only as printed
         e_or, _ = sim_oracle.simulate(cfg, seed)
         assert e_or.shape == (info[0], 7) and (e_or == edges[: info[0]]).all(), name
+
+
+def test_phases_reproduce_reference_csv_on_other_masks(core, tmp_path):
+    """The device phase code (host build) on the reference-made fixtures for other mask shapes and the z source walls
+    (tests/golden/sim_masks_golden.npz; simulation_space.py:29-34, 70-76, forest.py:153-181)."""
+    from _sim_cases import mask_cases
+    n = 0
+    for name, cfg, seed, g in mask_cases(tmp_path):
+        p = sim_oracle.params_from_config(cfg)
+        edges = np.zeros((40000, 7))
+        trace = np.zeros((len(g[name + "_trace"]) + 1, 4), np.int64)
+        info = np.zeros(8, np.int64)
+        rc = core.octa_simcore_host_run(ctypes.addressof(p), seed, seed, sim_oracle._bif_cb, edges.ctypes.data, 40000,
+                                        trace.ctypes.data, info.ctypes.data)
+        assert rc == 0 and info[2] == 0
+        assert (trace[: info[7]] == g[name + "_trace"]).all(), name
+        assert sim_oracle.edges_to_csv_text(edges[: info[0]]).encode() == g[name + "_csv"].tobytes(), name
+        n += 1
+    assert n >= 4
 
 
 def test_gtrig_is_glibc_sin_cos_acos(core):

@@ -80,6 +80,28 @@ def test_fixed_geometry_runs_csv_bit_exact(golden, tmp_path):
         assert (info["oxy"] == golden[name + "_oxy"]).all() and (info["co2"] == golden[name + "_co2"]).all()
 
 
+def test_other_mask_shapes_and_z_walls_csv_bit_exact(tmp_path):
+    from _sim_cases import mask_cases
+    n = 0
+    for name, cfg, seed, g in mask_cases(tmp_path):
+        edges, info = sim_oracle.simulate(cfg, seed, return_fields=True)
+        assert info["faz_radius"] == float(g[name + "_faz"])
+        assert (info["trace"] == g[name + "_trace"]).all(), name
+        assert info["n_art_edges"] == int(g[name + "_n_art"])
+        assert sim_oracle.edges_to_csv_text(edges).encode() == g[name + "_csv"].tobytes(), name
+        assert (info["oxy"] == g[name + "_oxy"]).all() and (info["co2"] == g[name + "_co2"]).all()
+        n += 1
+    assert n >= 4
+
+
+def test_z_walls_need_a_geometry_file(golden):
+    """simulation_space.py:82-87: without a geometry file the z branch reads `self.valid_pixels`, which does not exist."""
+    cfg = _cfg(golden, 3, 2)
+    cfg["Forest"]["source_walls"]["z0"] = True
+    with pytest.raises(AttributeError):
+        sim_oracle.simulate(cfg, 0)
+
+
 def test_full_length_run_sha(golden):
     names = [str(n) for n in golden["names"] if str(n).startswith("full_")]
     if not names:
