@@ -34,6 +34,9 @@ constexpr int TH = 8, TW = 32;     // output pixels per workgroup tile
 constexpr int KC = 32;             // input channels per LDS slice
 constexpr int PITCH = 80;          // bytes per pixel / per weight row in LDS (64 B of data + 16 B pad)
 constexpr int CONV_THREADS = 256;
+#ifndef OCTA_DMA_PARTS
+#define OCTA_DMA_PARTS 4
+#endif
 
 // 256 zero bytes in HBM: the source of padding pixels for loads that must not be branched around
 const unsigned short *zero_page(octa_ctx *ctx) {
@@ -313,14 +316,17 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
         const int slot = (wv + 4 * i) * 64 + lane, rw = slot / PP, q = (slot % PP) ^ glds_swz<PP>(rw);
         w_src[i] = ((rw / BN) * Cout + co0 + rw % BN) * Cin + q * 8;
     }
-    auto issue = [&](int c0, unsigned char *buf) {
+    // `part` / `nparts`: issue the wave's DMA instructions i with i % nparts == part (all of them for nparts = 1) -- the main loop spreads
+    // them between its MFMA groups, so that their issue (M0 write, address, the VMEM slot: 60-180 cycles each) runs in the matrix
+    // pipe's shadow instead of in front of the slice's first MFMA
+    auto issue = [&](int c0, unsigned char *buf, int part = 0, int nparts = 1) {
         const unsigned short *Xs = c0 < C1 ? X : X2;
         const int cs = c0 < C1 ? C1 : Cin - C1, cb = c0 < C1 ? c0 : c0 - C1;
         const unsigned short *img = Xs + (size_t)n * H * W * cs + cb;
 #pragma unroll
         for (int i = 0; i < IN_PW; i++) {
             const int j = wv + 4 * i;
-            if (j < IN_INSTR) {
+            if (i % nparts == part && j < IN_INSTR) {
                 const unsigned short *src = in_src[i] < 0 ? zero16 : img + (size_t)(in_src[i] >> 2) * cs + (in_src[i] & 3) * 8;
                 glds16(src, buf + j * 1024);
             }
@@ -329,7 +335,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
         for (int i = 0; i < W_PW; i++) {
             const int j = wv + 4 * i;
             // (a wave-instruction of weights covers 64 / PP rows of ONE tap, BN being a multiple of that: masked taps are not fetched)
-            if (j < W_INSTR && (!MASKED || ((tap_mask >> (j * (64 / PP) / BN)) & 1))) glds16(Wt + w_src[i] + c0, buf + IN_BYTES + j * 1024);
+            if ((IN_PW + i) % nparts == part && j < W_INSTR && (!MASKED || ((tap_mask >> (j * (64 / PP) / BN)) & 1))) glds16(Wt + w_src[i] + c0, buf + IN_BYTES + j * 1024);
         }
     };
 
@@ -345,8 +351,94 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
     issue(0, smem);
     for (int k = 0; k < nsl; k++) {
         __syncthreads();   // slice k has landed (every wave drained its own DMA queue first); buffer (k+1)&1 is free again
-        if (k + 1 < nsl) issue((k + 1) * KCV, smem + ((k + 1) & 1) * BUF);
+        constexpr bool SPREAD = !MASKED && ST == 1;           // the DMA of the next slice goes out between this slice's MFMA groups
+        const bool more = k + 1 < nsl;
+        unsigned char *nbuf = smem + ((k + 1) & 1) * BUF;
+        if (!SPREAD && more) issue((k + 1) * KCV, nbuf);
         const unsigned char *s_in = smem + (k & 1) * BUF, *s_w = s_in + IN_BYTES;
+        if constexpr (!MASKED && ST == 1 && RPW == 2) {
+            // column-major tap order: the RPW + KS - 1 halo rows a wave's RPW tile rows touch at tap column s are read ONCE and serve all KS
+            // tap rows (tile row rr at tap row r reads halo row rr + r): RPW + KS - 1 + KS * NB operand reads per KS * RPW * NB MFMAs --
+            // 10 per 12 at RPW = 2, 12 per 24 at RPW = 4. The reads of tap column s + 1 are issued BEFORE the MFMAs of column s (two
+            // operand sets in registers; the compiler's own schedule kept four operands and waited for LDS every 2-4 MFMAs).
+            constexpr int PH = (KCV / 16) * KS, NA = RPW + KS - 1;
+            bf16x8 a[2][NA], b[2][NB];
+            auto load_a = [&](int ph, bf16x8 *ad) {
+                const int ks = ph / KS, sc = ph % KS, qa = ks * 2 + kg;
+#pragma unroll
+                for (int hr = 0; hr < NA; hr++) {
+                    const int p = (RPW * wv + hr) * PW + m + sc;
+                    ad[hr] = *reinterpret_cast<const bf16x8 *>(s_in + (p * PP + (qa ^ glds_swz<PP>(p))) * 16);
+                }
+            };
+            auto load_b = [&](int t, bf16x8 *bd) {           // step t = (phase, tap row r)
+                const int ph = t / KS, r = t % KS, ks = ph / KS, sc = ph % KS, qa = ks * 2 + kg;
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    const int rw = (KS * r + sc) * BN + nb * 32 + m;
+                    bd[nb] = *reinterpret_cast<const bf16x8 *>(s_w + (rw * PP + (qa ^ glds_swz<PP>(rw))) * 16);
+                }
+            };
+            load_a(0, a[0]);
+            load_b(0, b[0]);
+#pragma unroll
+            for (int t = 0; t < PH * KS; t++) {
+                const int ph = t / KS, r = t % KS;
+                if (t + 1 < PH * KS) load_b(t + 1, b[(t + 1) & 1]);
+                if (r == 0 && ph + 1 < PH) load_a(ph + 1, a[(ph + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int NPARTS = OCTA_DMA_PARTS;   // steps of the slice that carry DMA issues: the data must land before the next barrier
+#pragma unroll
+                for (int rr = 0; rr < RPW; rr++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        acc[rr][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ph & 1][rr + r], b[t & 1][nb], acc[rr][nb], 0, 0, 0);
+                        if (rr == 0 && nb == 0 && t < NPARTS) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) issue((k + 1) * KCV, nbuf, t, NPARTS);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (!MASKED && ST == 1) {
+            // 16-row tiles (RPW = 4): the same column-major order without the second operand set -- two sets on top of 128 accumulator
+            // registers spill at two waves per SIMD (measured: 304^2 128->128 0.122 -> 0.144 ms with 6-12 spilled registers)
+#pragma unroll
+            for (int ks = 0; ks < KCV / 16; ks++)
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const int qa = ks * 2 + kg;
+                    bf16x8 a[RPW + KS - 1];
+#pragma unroll
+                    for (int hr = 0; hr < RPW + KS - 1; hr++) {
+                        const int p = (RPW * wv + hr) * PW + m + s;
+                        a[hr] = *reinterpret_cast<const bf16x8 *>(s_in + (p * PP + (qa ^ glds_swz<PP>(p))) * 16);
+                    }
+#pragma unroll
+                    for (int r = 0; r < KS; r++) {
+                        bf16x8 b[NB];
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) {
+                            const int rw = (KS * r + s) * BN + nb * 32 + m;
+                            b[nb] = *reinterpret_cast<const bf16x8 *>(s_w + (rw * PP + (qa ^ glds_swz<PP>(rw))) * 16);
+                        }
+                        constexpr int NPARTS = OCTA_DMA_PARTS;
+                        const int t = (ks * KS + s) * KS + r;
+#pragma unroll
+                        for (int rr = 0; rr < RPW; rr++)
+#pragma unroll
+                            for (int nb = 0; nb < NB; nb++) {
+                                acc[rr][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr + r], b[nb], acc[rr][nb], 0, 0, 0);
+                                if (rr == 0 && nb == 0 && t < NPARTS) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (more) issue((k + 1) * KCV, nbuf, t, NPARTS);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                    }
+                }
+        } else
 #pragma unroll
         for (int r = 0; r < KS; r++)
 #pragma unroll
@@ -441,12 +533,25 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
             if (kg == 0) { s_red[(wv * BN + nb * 32 + m) * 2] = a1; s_red[(wv * BN + nb * 32 + m) * 2 + 1] = a2; }
         }
         __syncthreads();
-        if (threadIdx.x < BN) {
-            float a1 = 0.f, a2 = 0.f;
+        if (THT == 8) {
+            if (threadIdx.x < BN) {
+                float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int w4 = 0; w4 < 4; w4++) { a1 += s_red[(w4 * BN + threadIdx.x) * 2]; a2 += s_red[(w4 * BN + threadIdx.x) * 2 + 1]; }
-            float *dst = part + (((size_t)n * gridDim.x + tile) * Cout + co0 + threadIdx.x) * 2;
-            dst[0] = a1; dst[1] = a2;
+                for (int w4 = 0; w4 < 4; w4++) { a1 += s_red[(w4 * BN + threadIdx.x) * 2]; a2 += s_red[(w4 * BN + threadIdx.x) * 2 + 1]; }
+                float *dst = part + (((size_t)n * gridDim.x + tile) * Cout + co0 + threadIdx.x) * 2;
+                dst[0] = a1; dst[1] = a2;
+            }
+        } else if (threadIdx.x < 2 * BN) {
+            // 16-row tiles: `part` keeps the layout of the 8-row tiling (octa_conv_stat_tiles): waves 0-1 hold the upper half's rows,
+            // waves 2-3 the lower half's, each half is one 8-row tile of that grid
+            const int half = threadIdx.x / BN, c = threadIdx.x % BN;
+            const int ty8 = (tile / tiles_x) * 2 + half, tiles_y8 = (Ho + 7) / 8;
+            if (ty8 < tiles_y8) {
+                const float a1 = s_red[((2 * half) * BN + c) * 2] + s_red[((2 * half + 1) * BN + c) * 2];
+                const float a2 = s_red[((2 * half) * BN + c) * 2 + 1] + s_red[((2 * half + 1) * BN + c) * 2 + 1];
+                float *dst = part + (((size_t)n * tiles_y8 * tiles_x + (size_t)ty8 * tiles_x + tile % tiles_x) * Cout + co0 + c) * 2;
+                dst[0] = a1; dst[1] = a2;
+            }
         }
     }
 }
@@ -539,8 +644,8 @@ extern "C" int octa_conv3x3_nhwc_fwd6(octa_ctx *ctx, const void *d_x, const void
         // 200 output rows up: 8-14 % faster on the 304^2 / 608^2 layers (256->128 at 304^2: 1.0 PFLOP/s), no gain at 152^2
         // (half as many workgroups: tail effects) and on the HBM-bound 1216^2 layers. OCTA_CONV_TALL=0 disables.
         static const int tall = [] { const char *e = getenv("OCTA_CONV_TALL"); return e ? atoi(e) : 200; }();
-        if (glds_mode == 16 && tall && wide && stride == 1 && tap_mask == 0x1ff && out_scale == 1 && !d_stat_partials && Ho >= tall)
-            return launch_conv_glds<64, 16, 1, 3, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, nullptr, tap_mask, 1, 0, 0, stream, 1, Rz);
+        if (glds_mode == 16 && tall && wide && stride == 1 && tap_mask == 0x1ff && out_scale == 1 && Ho >= tall)
+            return launch_conv_glds<64, 16, 1, 3, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, 1, 0, 0, stream, 1, Rz);
         if (glds_mode == 16)
             return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz)
                         : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz);
