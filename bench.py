@@ -275,7 +275,7 @@ def files_leg(gen, stream, seeds, threads=None):
         shutil.rmtree(out_root, ignore_errors=True)
 
 
-def train_cli_leg(n_graphs=128, epochs=4):
+def train_cli_leg(n_graphs=128, epochs=4, extra_args=()):
     """BASELINE configs[2] through the reference's entry point: `train.py --config_file configs/config_ves_seg-S.yml` on freshly
     generated full-length graphs (the reference's 500 provided pairs are not on the GPU box): graph CSV -> loader (parse, two
     rasterisations per sample, augmentation) -> DynUNet-S step at 1216^2. Reports the last epoch's images per second."""
@@ -296,7 +296,7 @@ def train_cli_leg(n_graphs=128, epochs=4):
             yaml.safe_dump(cfg, f)
         csvs = os.path.join(tmp, "graphs", "**", "*.csv")
         train_cli.main(["--config_file", p, "--Train.data.image.files", csvs, "--Train.data.label.files", csvs, "--Train.epochs", str(epochs),
-                        "--Train.epochs_decay", "0", "--General.seed", "3", "--Output.save_dir", os.path.join(tmp, "results")])
+                        "--Train.epochs_decay", "0", "--General.seed", "3", "--Output.save_dir", os.path.join(tmp, "results")] + list(extra_args))
         rates = list(train_cli.LAST_RUN["imgs_per_s"])
         return {"metric": "train.py imgs/s with configs/config_ves_seg-S.yml (graph CSVs -> device-side loader -> DynUNet-S step @1216^2, bf16, B=4)",
                 "value": rates[-1], "unit": "imgs/s", "epochs": epochs, "graphs": n_graphs, "imgs_per_s_per_epoch": rates,

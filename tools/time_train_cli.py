@@ -14,6 +14,6 @@ if __name__ == "__main__":
     dev = torch.device("cuda", 0)
     u = bench.unet_train_bench(dev, 4, None, 1)
     print("bare step", round(u["value"], 1), "imgs/s", round(u["ms_per_step"], 2), "ms", flush=True)
-    c = bench.train_cli_leg(n_graphs=int(sys.argv[2]) if len(sys.argv) > 2 else 64, epochs=epochs)
+    c = bench.train_cli_leg(n_graphs=int(sys.argv[2]) if len(sys.argv) > 2 else 64, epochs=epochs, extra_args=os.environ.get("OCTA_TRAIN_ARGS", "").split())
     print("train.py", [round(v, 1) for v in c["imgs_per_s_per_epoch"]], flush=True)
     print("ratio", round(c["value"] / u["value"], 3))
