@@ -345,10 +345,23 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         // so the order of the items is irrelevant; very wide strokes fall back to the side loop.
         unsigned short *w_owner = s_owner + wv * ITEM_CAP;
         const int myrow = lane / (16 / NPX);
-        for (int i = 0; i < list_n; i++) {
+        // the entries whose bounding box misses this wave's block (most of a super-tile's list) are dropped 64 at a time: lane j tests
+        // entry base + j, the ballot's set bits are visited in order
+        for (int base_i = 0; base_i < list_n; base_i += 64) {
+          unsigned long long cand = 0;
+          {
+            const int j = base_i + lane;
+            bool hit = false;
+            if (j < list_n) {
+                const BBox16 b = s_list[j].bb;
+                hit = !(b.x1 < bx0 || b.x0 > bx0 + 15 || b.y1 < by0 || b.y0 > by0 + BLK_H - 1);
+            }
+            cand = __ballot(hit);
+          }
+          while (cand) {
+            const int i = base_i + (int)__ffsll((long long)cand) - 1;
+            cand &= cand - 1ull;
             const ListEntry le = s_list[i];
-            // wave-uniform reject
-            if (le.bb.x1 < bx0 || le.bb.x0 > bx0 + 15 || le.bb.y1 < by0 || le.bb.y0 > by0 + BLK_H - 1) continue;
             bool touch = !(prow < le.bb.y0 || prow > le.bb.y1 || pcol + NPX - 1 < le.bb.x0 || pcol > le.bb.x1);
             if (touch) {
                 // the NPX x 1 pixel span of this lane cannot be touched if its centre is farther from the
@@ -395,10 +408,11 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                     __builtin_amdgcn_wave_barrier();
                     for (int base = 0; base < total; base += 64) {
                         int hx1 = 0, hy1 = 0, hx2 = 0, hy2 = 0, irow = -1;
+                        HStep hst = {0, 0};
                         if (base + lane < total) {
                             const unsigned ow = w_owner[base + lane];
                             const int r = (int)(ow & 255u);
-                            if (side_row_piece(sl[ow >> 8], by0 + r, hx1, hy1, hx2, hy2)) irow = r;
+                            if (side_row_piece(sl[ow >> 8], by0 + r, hx1, hy1, hx2, hy2)) { irow = r; hst = hline_step(hx1, hy1, hx2, hy2); }
                         }
                         unsigned long long mine = 0;
 #pragma unroll
@@ -410,8 +424,10 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                         while (__any(mine != 0)) {
                             const int j = mine ? (int)__ffsll((long long)mine) - 1 : 0;
                             const int a = __shfl(hx1, j, 64), bq = __shfl(hy1, j, 64), c = __shfl(hx2, j, 64), d = __shfl(hy2, j, 64);
+                            HStep sj;
+                            sj.lift = __shfl(hst.lift, j, 64); sj.rem = __shfl(hst.rem, j, 64);
                             if (mine) {
-                                hline_eval<NPX>(a, bq, c, d, pcol, C, A);
+                                hline_eval<NPX>(a, bq, c, d, sj, pcol, C, A);
                                 mine &= mine - 1ull;
                             }
                         }
@@ -436,6 +452,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                     pix[q] = blend_white(pix[q], (unsigned)c);
                 }
             }
+          }
         }
         __syncthreads();
         if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 6), (unsigned long long)(_t - _tp)); }

@@ -292,14 +292,50 @@ OCTA_HD inline int floordiv_i(int a, int b) {
     if (r >= b) { q++; }
     return q;
 }
-OCTA_HD inline int floordiv_prod(int num, long dx, long dy) { return (int)floordiv_d((long)num * dx, dy); }
+// floor(num * dx / dy), dy > 0, |num * dx| < 2^52: the same estimate + fix-up in double arithmetic -- the product, q * dy and the
+// remainder are integers below 2^53, so fma(-q, dy, num * dx) is exact; replaces the 64-bit integer multiply / subtract / compare
+// sequences of floordiv_d in the per-item code of the render kernel (two of these per scanline piece)
+OCTA_HD inline int floordiv_prod(int num, long dx, long dy) {
+    const double a = (double)num * (double)dx, b = (double)dy;
+    double q = floor(a * rcp_approx(b));
+    double r = fma(-q, b, a);
+    if (r < 0.0) { q -= 1.0; r += b; }
+    if (r < 0.0) { q -= 1.0; r += b; }
+    if (r >= b) { q += 1.0; r -= b; }
+    if (r >= b) { q += 1.0; }
+    return (int)q;
+}
+
+// floor(a / b) and the remainder a - q * b in [0, b), b > 0 (|a|, b < 2^31)
+OCTA_HD inline int floordivmod_i(int a, int b, int &rem) {
+    int q = (int)floor((double)a * rcp_approx((double)b));
+    int r = a - q * b;
+    if (r < 0) { q--; r += b; }
+    if (r >= b) { q++; r -= b; }
+    rem = r;
+    return q;
+}
+
+// The division of a scanline piece that does not depend on the pixel: Agg's DDA step. Crossing one more cell boundary adds
+// 256 * dy to the numerator of y = hy1 + floor((.. + k * 256 * dy) / |dx|): quotient `lift` and remainder `rem` of that step.
+struct HStep { int lift, rem; };
+OCTA_HD inline HStep hline_step(int hx1, int hy1, int hx2, int hy2) {
+    HStep st = {0, 0};
+    if (hy1 == hy2 || (hx1 >> 8) == (hx2 >> 8)) return st;
+    const int dxh = hx2 >= hx1 ? hx2 - hx1 : hx1 - hx2;
+    st.lift = floordivmod_i(256 * (hy2 - hy1), dxh, st.rem);
+    return st;
+}
 
 // One scanline piece (agg render_hline semantics) evaluated for NP adjacent pixels px0..px0+NP-1.
 // Adds, per pixel, C += sum of cover over cells with ex <= px, A += area of cell px.
 // Y[b] is the fractional y reached when the piece crosses the cell boundary x = (px0 + b) * 256, clamped
 // to the piece's ends, in traversal direction; cell px then has cover = Y_out - Y_in.
+// The boundaries inside the piece are y_k = hy1 + floor((base + k * 256 * dy) / |dx|), k = 0, 1, ..: ONE division for the first
+// boundary of the span, the following ones by the DDA step `st` (quotient + remainder carry): floor((n + s) / d) =
+// floor(n / d) + lift + [rem(n) + rem >= d] for any sign of s.
 template <int NP>
-OCTA_HD inline void hline_eval(int hx1, int hy1, int hx2, int hy2, int px0, int (&C)[NP], int (&A)[NP]) {
+OCTA_HD inline void hline_eval(int hx1, int hy1, int hx2, int hy2, HStep st, int px0, int (&C)[NP], int (&A)[NP]) {
     if (hy1 == hy2) return;
     const int ex1 = hx1 >> 8, ex2 = hx2 >> 8;
     const int fx1 = hx1 & 255, fx2 = hx2 & 255;
@@ -316,48 +352,61 @@ OCTA_HD inline void hline_eval(int hx1, int hy1, int hx2, int hy2, int px0, int 
     }
     int Y[NP + 1];
     if (hx2 >= hx1) {
-        // cells ex1 .. ex2 left to right; boundary xb lies between cells xb-1 and xb
+        // cells ex1 .. ex2 left to right; boundary xb lies between cells xb-1 and xb; inside the piece for ex1 < xb <= ex2
         const int dxh = hx2 - hx1;
-        const int base = (256 - fx1) * dy;
+        const int k0 = px0 - ex1 - 1 > 0 ? px0 - ex1 - 1 : 0;       // first boundary of the span that can lie inside
+        int r, q = floordivmod_i((256 - fx1) * dy + k0 * 256 * dy, dxh, r);
 #pragma unroll
         for (int bq = 0; bq <= NP; bq++) {
-            int xb = px0 + bq;
+            const int xb = px0 + bq;
             int v;
             if (xb <= ex1) v = hy1;
             else if (xb > ex2) v = hy2;
-            else v = hy1 + floordiv_i(base + (xb - ex1 - 1) * 256 * dy, dxh);
+            else {
+                v = hy1 + q;
+                r += st.rem;
+                q += st.lift;
+                if (r >= dxh) { r -= dxh; q++; }
+            }
             Y[bq] = v;
         }
 #pragma unroll
-        for (int q = 0; q < NP; q++) {
-            int px = px0 + q;
-            int cov = Y[q + 1] - Y[q];
-            C[q] += Y[q + 1] - hy1;
+        for (int q2 = 0; q2 < NP; q2++) {
+            int px = px0 + q2;
+            int cov = Y[q2 + 1] - Y[q2];
+            C[q2] += Y[q2 + 1] - hy1;
             int fxin = (px == ex1) ? fx1 : 0;
             int fxout = (px == ex2) ? fx2 : 256;
-            A[q] += (fxin + fxout) * cov;
+            A[q2] += (fxin + fxout) * cov;
         }
     } else {
-        // cells ex1 .. ex2 right to left; boundary xb is crossed when entering cell xb-1
+        // cells ex1 .. ex2 right to left; boundary xb is crossed when entering cell xb-1; inside the piece for ex2 < xb <= ex1,
+        // k = ex1 - xb grows towards the LEFT: walk the span's boundaries from its right end
         const int dxh = hx1 - hx2;
-        const int base = fx1 * dy;
+        const int xr = px0 + NP < ex1 ? px0 + NP : ex1;             // rightmost boundary of the span that can lie inside
+        int r, q = floordivmod_i(fx1 * dy + (ex1 - xr) * 256 * dy, dxh, r);
 #pragma unroll
-        for (int bq = 0; bq <= NP; bq++) {
-            int xb = px0 + bq;
+        for (int bq = NP; bq >= 0; bq--) {
+            const int xb = px0 + bq;
             int v;
             if (xb > ex1) v = hy1;
             else if (xb <= ex2) v = hy2;
-            else v = hy1 + floordiv_i(base + (ex1 - xb) * 256 * dy, dxh);
+            else {
+                v = hy1 + q;
+                r += st.rem;
+                q += st.lift;
+                if (r >= dxh) { r -= dxh; q++; }
+            }
             Y[bq] = v;
         }
 #pragma unroll
-        for (int q = 0; q < NP; q++) {
-            int px = px0 + q;
-            int cov = Y[q] - Y[q + 1];
-            C[q] += hy2 - Y[q + 1];
+        for (int q2 = 0; q2 < NP; q2++) {
+            int px = px0 + q2;
+            int cov = Y[q2] - Y[q2 + 1];
+            C[q2] += hy2 - Y[q2 + 1];
             int fxin = (px == ex1) ? fx1 : 256;
             int fxout = (px == ex2) ? fx2 : 0;
-            A[q] += (fxin + fxout) * cov;
+            A[q2] += (fxin + fxout) * cov;
         }
     }
 }
@@ -398,7 +447,7 @@ OCTA_HD inline bool side_row_piece(int4 s, int py, int &hx1, int &hy1, int &hx2,
 template <int NP>
 OCTA_HD inline void side_eval(int4 s, int py, int px0, int (&C)[NP], int (&A)[NP]) {
     int hx1, hy1, hx2, hy2;
-    if (side_row_piece(s, py, hx1, hy1, hx2, hy2)) hline_eval<NP>(hx1, hy1, hx2, hy2, px0, C, A);
+    if (side_row_piece(s, py, hx1, hy1, hx2, hy2)) hline_eval<NP>(hx1, hy1, hx2, hy2, hline_step(hx1, hy1, hx2, hy2), px0, C, A);
 }
 
 // matplotlib fixed_blender_rgba_plain: white with coverage alpha over an opaque grey p
