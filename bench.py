@@ -40,24 +40,30 @@ N_CUS = 256          # MI355X; main() replaces it by the device's own count
 PMC_SUMMARY = os.path.join("profiles", "r03_bench_pmc_summary.csv")
 
 
-def pmc_traffic_per_launch(kernel_name):
+def pmc_traffic_per_launch(kernel_name, grid_threads=None):
     """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 counter passes (PMC_SUMMARY: FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc passes of this bench by tools/profile_bench.sh, values in KB). Correction per
-    MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 128-B requests as 64 B on gfx950, so it is doubled; WRITE_SIZE is taken as
-    reported. None if the file or the kernel is missing."""
+    WRITE_SIZE collected in separate --pmc passes of this bench by tools/profile_bench.sh, values in KB; one row per kernel and launch
+    size, `[grid <threads>]`). Correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 128-B requests as 64 B on gfx950, so it is
+    doubled; WRITE_SIZE is taken as reported. Returns (bytes, file, exact): exact = the file holds a row for launches of
+    `grid_threads` threads; otherwise the rows of another launch size are returned for the caller to scale. None if missing."""
     for cand in (PMC_SUMMARY, os.path.join("profiles", "r02_bench_pmc_summary.csv")):
         path = os.path.join(ROOT, cand)
         if not os.path.exists(path):
             continue
         import csv
-        kb = {}
+        kb, kb_exact = {}, {}
         with open(path) as f:
             for r in csv.DictReader(f):
                 if kernel_name in r["kernel"]:
-                    kb[r["counter"]] = float(r["avg_KB_per_launch"])
+                    if grid_threads is not None and f"[grid {grid_threads}]" in r["kernel"]:
+                        kb_exact[r["counter"]] = float(r["avg_KB_per_launch"])
+                    elif "[grid" not in r["kernel"] or "[grid 32768]" in r["kernel"]:
+                        kb[r["counter"]] = float(r["avg_KB_per_launch"])       # 128-sample launches (all the older files hold)
+        if "FETCH_SIZE" in kb_exact and "WRITE_SIZE" in kb_exact:
+            return (2.0 * kb_exact["FETCH_SIZE"] + kb_exact["WRITE_SIZE"]) * 1024.0, cand, True
         if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
-            return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, cand
-    return None, None
+            return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, cand, False
+    return None, None, False
 
 
 def pmc_child(batch):
@@ -519,11 +525,12 @@ def main():
             if traffic is None:
                 print(f"[bench] live counter passes unavailable ({traffic_src}); using the committed summary", file=sys.stderr)
         if traffic is None:
-            traffic, traffic_src = pmc_traffic_per_launch(dom_name)
+            samples_per_launch = args.steps * B / max(dom_n, 1)
+            traffic, traffic_src, exact = pmc_traffic_per_launch(dom_name, int(min(samples_per_launch, N_CUS * 2)) * 256)
             if traffic is not None:
-                # the committed counter passes ran `--inflight 1 --group 1` (one 128-sample launch at a time): scale to this run's samples per launch
-                traffic = traffic * (args.steps * B / max(dom_n, 1)) / 128.0
-                traffic_src = f"NOT measured in this run: committed file {traffic_src}"
+                if not exact:      # rows of 128-sample launches only: scale (an UNDER-estimate: a full GPU misses L2 more)
+                    traffic = traffic * samples_per_launch / 128.0
+                traffic_src = f"NOT measured in this run: committed file {traffic_src}" + ("" if exact else ", scaled from 128-sample launches")
         geo = np.zeros(4, np.int32)
         _native.check(_native.lib().octa_sim_geometry(N_CUS, geo.ctypes.data), "octa_sim_geometry")
         wg_per_cu = int(geo[1])

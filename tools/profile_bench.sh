@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
 #   1. --kernel-trace --stats of the default bench command        -> gpurun_out/r03_bench_kernel_stats.csv
-#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, one counter per pass -> gpurun_out/r03_bench_pmc_summary.csv
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, one counter per pass, launches of the default shape (4 x 128 samples, one in flight)
+#      -> gpurun_out/r03_bench_pmc_summary.csv
 # (counter passes never combined with tracing: see the task's profiling rules)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -11,9 +12,9 @@ mkdir -p $OUT
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py --no-cpu-baseline --no-pmc > $OUT/${TAG}_bench_stdout.log 2>&1
 find $OUT/prof_kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
 rm -rf $OUT/prof_kt   # the raw trace is large; only the summary is kept
-grep '"metric"' $OUT/${TAG}_bench_stdout.log | tail -1 > $OUT/${TAG}_bench_line.json
+grep '"metric"' $OUT/${TAG}_bench_stdout.log | tail -1 > $OUT/${TAG}_bench_line_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 2 --warmup 1 --inflight 1 --group 1 --no-cpu-baseline --no-train --no-files --no-pmc > $OUT/${TAG}_pmc_$C.log 2>&1
+  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-train --no-files --no-pmc > $OUT/${TAG}_pmc_$C.log 2>&1
 done
 python - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, collections
@@ -25,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != c:
                 continue
-            k = r["Kernel_Name"].replace(",", ";")[:90]
+            k = r["Kernel_Name"].replace(",", ";")[:90] + f" [grid {r['Grid_Size']}]"     # launches of different sizes are different rows
             agg[k][0] += 1
             agg[k][1] += float(r["Counter_Value"])
     for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -38,4 +39,4 @@ print("pmc rows:", len(rows))
 PY
 head -12 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-200
 head -8 $OUT/${TAG}_bench_pmc_summary.csv
-cut -c1-300 $OUT/${TAG}_bench_line.json
+cut -c1-300 $OUT/${TAG}_bench_line_under_rocprof.json
