@@ -942,6 +942,170 @@ conv3x3_nhwc_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned s
     }
 }
 
+// ---- weight gradient, stride 1, 3x3, all taps: raw NHWC tiles in LDS + transposing reads (round 3) ------------------------
+// The kernel above transposes its tiles on the way INTO the LDS (eight 2-byte stores per 16-byte piece: 55 % of its LDS cycles were
+// bank conflicts, and the +-1 pixel shift of the taps is a funnel shift of registers: 440 VALU instructions per 72 MFMAs). Here the
+// tiles stay as they are in memory -- [pixel][32 channels], 64 bytes per pixel, one plane per 32 channels -- and are fetched by
+// the DMA (global_load_lds, 16 bytes per lane, a wave-instruction = 16 pixels of one plane); gfx950's ds_read_b64_tr_b16 transposes
+// on the way OUT: lane i of a 16-lane group addresses 4 channels of pixel i / 4 and receives pixels 0..3 of channel i -- the
+// K-major fragment the MFMA wants (two reads = 8 pixels of one channel per lane). A tap is then a constant added to the pixel
+// index, i.e. an immediate offset of the read: every operand read of the kernel is `base VGPR + immediate`, no shifts, no
+// register transposition. A 32-lane half of the read covers 4 pixels x 64 bytes = 256 contiguous bytes: all 64 banks once.
+// Work split as above: a wave owns one 32 x 32 (co, ci) pair and all nine taps over its share of the tile's rows; the X
+// fragments of a 16-pixel column group are read once per halo row and tap column and serve every tile row they touch
+// ((rows + 2) x 3 fragments for rows x 9 MFMAs).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char *p) {
+    // two transposing reads, pixels +0..3 and +4..7 (256 bytes further) of this lane's channel
+    union { struct { s16x4 lo, hi; } h; bf16x8 v; } u;
+    u.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+    u.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p + 256));
+    return u.v;
+}
+
+// TH_: tile rows (4 or 8; 8 halves the barriers and the halo share of the DMA where the double buffer fits)
+template <int COB, int CIB, int TH_>
+__global__ void __launch_bounds__(CONV_THREADS, (COB == 32 && CIB == 32 ? 2 : 1))
+conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
+                             const unsigned short *__restrict__ dY, float *__restrict__ dW,
+                             int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, const unsigned short *__restrict__ zero16) {
+    constexpr int PAIRS = (COB / 32) * (CIB / 32), KSPLIT = 4 / PAIRS, RPW = TH_ / KSPLIT;   // tile rows per wave
+    constexpr int RG = RPW < 4 ? RPW : 4, NG = RPW / RG;            // rows per operand set (register budget), sets per column group
+    constexpr int XCOLS = TW + 2, XROWS = TH_ + 2, XPIX = XROWS * XCOLS;                     // 34 x (TH_ + 2) halo
+    constexpr int DY_IPP = TH_ * TW / 16, X_IPP = (XPIX + 15) / 16;                          // DMA instructions (16 pixels) per 32-channel plane
+    constexpr int DY_PLANE = DY_IPP * 1024, X_PLANE = X_IPP * 1024;
+    constexpr int DY_INSTR = (COB / 32) * DY_IPP, X_INSTR = (CIB / 32) * X_IPP, N_INSTR = DY_INSTR + X_INSTR;
+    constexpr int IPW = (N_INSTR + 3) / 4;                                                   // per wave and tile
+    constexpr int BUF = (COB / 32) * DY_PLANE + (CIB / 32) * X_PLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int co0 = (blockIdx.y / (Cin / CIB)) * COB, ci0 = (blockIdx.y % (Cin / CIB)) * CIB;
+    const unsigned short *Xs = ci0 < C1 ? X : X2;
+    const int xcs = ci0 < C1 ? C1 : Cin - C1, xcb = ci0 < C1 ? ci0 : ci0 - C1;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wv % PAIRS, kpart = wv / PAIRS;
+    const int cobp = pair % (COB / 32), cibp = pair / (COB / 32);        // this wave's 32-channel planes
+    const int m = lane & 31, kg = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[t][k] = 0.f;
+    const int n_tiles = tiles_x * tiles_y * N;
+
+    // DMA slots of this wave: instruction j = wv + 4 i; lane -> pixel 16 (j % IPP) + lane / 4 of plane j / IPP, channels 8 (lane % 4) ..
+    const int lp = lane >> 2, lq = lane & 3;
+    struct TilePos { int n, ty0, tx0; };
+    auto tile_pos = [&](int tile) {
+        const int n = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
+        return TilePos{n, (tt / tiles_x) * TH_, (tt % tiles_x) * TW};
+    };
+    // part < 0: all of the wave's instructions; otherwise only instruction `part` (the main loop spreads them between its MFMAs)
+    auto issue = [&](const TilePos &tp, unsigned char *buf, int part) {
+        const int n = tp.n, ty0 = tp.ty0, tx0 = tp.tx0;
+#pragma unroll
+        for (int i = 0; i < IPW; i++) {
+            const int j = wv + 4 * i;
+            if (part >= 0 && i != part) continue;
+            if (j < DY_INSTR) {
+                const int plane = j / DY_IPP, p = (j % DY_IPP) * 16 + lp;
+                const int y = ty0 + p / TW, x = tx0 + p % TW;
+                const unsigned short *src = (y < H && x < W) ? dY + (((size_t)n * H + y) * W + x) * Cout + co0 + plane * 32 + lq * 8 : zero16;
+                glds16(src, buf + j * 1024);
+            } else if (j < N_INSTR) {
+                const int jj = j - DY_INSTR, plane = jj / X_IPP, p = (jj % X_IPP) * 16 + lp;
+                const int y = ty0 - 1 + p / XCOLS, x = tx0 - 1 + p % XCOLS;
+                const unsigned short *src = (p < XPIX && y >= 0 && y < H && x >= 0 && x < W) ? Xs + (((size_t)n * H + y) * W + x) * xcs + xcb + plane * 32 + lq * 8 : zero16;
+                glds16(src, buf + j * 1024);
+            }
+        }
+    };
+
+    // lane part of every operand address: pixel (lane / 32) * 8 + (lane % 16) / 4, channels 16 * ((lane / 16) % 2) + 4 * (lane % 4)
+    const int la = (((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    (void)m; (void)kg;
+
+    constexpr int NSTEP = (TW / 16) * NG;                           // operand sets per tile: (column group, row group)
+    constexpr int NMF = (TW / 16) * RPW * 9;                       // MFMAs per wave and tile
+    constexpr int ISTRIDE = (NMF * 2 / 3) / IPW > 0 ? (NMF * 2 / 3) / IPW : 1;   // one DMA instruction every ISTRIDE MFMAs, the last third of the tile carries none
+    struct Frags { bf16x8 b[RG + 2][3], a[RG]; };
+    // operand reads of one 16-pixel column group in the order of their first use (the compiler's lgkmcnt then lets the first tile
+    // row's MFMAs start while the later fragments are still on their way)
+    auto load_frags = [&](const unsigned char *a_base, const unsigned char *b_base, int step, Frags &f) {
+        const int xc = step / NG, row0 = kpart * RPW + (step % NG) * RG;
+#pragma unroll
+        for (int hr = 0; hr < RG + 2; hr++) {
+            if (hr >= 2 && hr - 2 < RG) f.a[hr - 2] = tr_read8(a_base + ((row0 + hr - 2) * TW + xc * 16) * 64);
+#pragma unroll
+            for (int sx = 0; sx < 3; sx++) f.b[hr][sx] = tr_read8(b_base + ((row0 + hr) * XCOLS + xc * 16 + sx) * 64);
+        }
+    };
+    int tile = blockIdx.x, cur = 0;
+    if (tile < n_tiles) issue(tile_pos(tile), smem, -1);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();        // this tile has landed (every wave drained its own DMA queue), the other buffer is free
+        const int nxt = tile + (int)gridDim.x;
+        const bool more = nxt < n_tiles;
+        const TilePos tpn = tile_pos(more ? nxt : tile);
+        unsigned char *nbuf = smem + (cur ^ 1) * BUF;
+        const unsigned char *a_base = smem + cur * BUF + cobp * DY_PLANE + la;
+        const unsigned char *b_base = smem + cur * BUF + (COB / 32) * DY_PLANE + cibp * X_PLANE + la;
+        Frags fr[2];
+        load_frags(a_base, b_base, 0, fr[0]);
+#pragma unroll
+        for (int st = 0; st < NSTEP; st++) {
+            if (st + 1 < NSTEP) load_frags(a_base, b_base, st + 1, fr[(st + 1) & 1]);    // the next set's operands, ahead of this one's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            const Frags &f = fr[st & 1];
+#pragma unroll
+            for (int rr = 0; rr < RG; rr++)
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int sx = 0; sx < 3; sx++) {
+                        acc[3 * r + sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rr], f.b[rr + r][sx], acc[3 * r + sx], 0, 0, 0);
+                        const int q = (st * RG + rr) * 9 + 3 * r + sx;
+                        if (q % ISTRIDE == ISTRIDE - 1 && q / ISTRIDE < IPW) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) issue(tpn, nbuf, q / ISTRIDE);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur ^= 1;
+    }
+    // D[row = co][col = ci]: row = (k&3) + 8*(k>>2) + 4*(lane/32), col = lane % 32
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int co = co0 + cobp * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+            atomicAdd(dW + ((size_t)t * Cout + co) * Cin + ci0 + cibp * 32 + (lane & 31), acc[t][k]);
+        }
+}
+
+template <int COB, int CIB>
+int launch_wgrad_tr(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
+                    int Cout, int num_cus, const unsigned short *zero16, hipStream_t stream) {
+    constexpr int TH_ = (COB == 64 && CIB == 64) ? 8 : 4;   // 64 x 64 channel blocks: the 8-row double buffer fits one CU (152 KB); the smaller blocks keep two workgroups per CU
+    constexpr int XPIX = (TH_ + 2) * (TW + 2);
+    constexpr int BUF = (COB / 32) * (TH_ * TW / 16) * 1024 + (CIB / 32) * ((XPIX + 15) / 16) * 1024;
+    const size_t lds = 2 * (size_t)BUF;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH_ - 1) / TH_;
+    const int blocks = (Cout / COB) * (Cin / CIB);
+    int per_block = (num_cus * (COB == 32 && CIB == 32 ? 2 : 1) + blocks - 1) / blocks;
+    const int n_tiles = tiles_x * tiles_y * N;
+    if (per_block > n_tiles) per_block = n_tiles;
+    if (per_block < 1) per_block = 1;
+    auto kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_>;
+    OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Cin, Cout,
+                       tiles_x, tiles_y, zero16);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <int COB, int CIB, bool MASKED, int ST, int KS = 3>
 int launch_wgrad_impl(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
                  int Cout, int num_cus, int tap_mask, const float *sc1, const float *sh1, const float *sc2, const float *sh2, float slope,
@@ -1000,6 +1164,13 @@ extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const vo
         return launch_wgrad<32, 32, 2>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     }
     if (stride != 1) { octa::set_error("octa_conv3x3_nhwc_wgrad: stride must be 1 or 2"); return -2; }
+    static const int use_tr = [] { const char *e = getenv("OCTA_WGRAD_TR"); return e ? atoi(e) : 1; }();
+    if (use_tr && tap_mask == 0x1ff && !d_scale1 && !d_scale2) {     // raw tiles + transposing reads (see conv3x3_nhwc_wgrad_tr_kernel)
+        if (co64 && ci64) return launch_wgrad_tr<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
+        if (co64) return launch_wgrad_tr<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
+        if (ci64) return launch_wgrad_tr<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
+        return launch_wgrad_tr<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
+    }
     if (co64 && ci64) return launch_wgrad<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
