@@ -1050,13 +1050,17 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
         unsigned char *nbuf = smem + (cur ^ 1) * BUF;
         const unsigned char *a_base = smem + cur * BUF + cobp * DY_PLANE + la;
         const unsigned char *b_base = smem + cur * BUF + (COB / 32) * DY_PLANE + cibp * X_PLANE + la;
-        Frags fr[2];
+        // two operand sets (the next set's reads ahead of this one's MFMAs) where one wave per SIMD has the registers for it; the
+        // 32 x 32 block runs two workgroups per CU on 8-row tiles (HBM-bound layers: bytes in flight matter, not the matrix pipe)
+        constexpr bool PIPE = !(COB == 32 && CIB == 32);
+        Frags fr[PIPE ? 2 : 1];
         load_frags(a_base, b_base, 0, fr[0]);
 #pragma unroll
         for (int st = 0; st < NSTEP; st++) {
-            if (st + 1 < NSTEP) load_frags(a_base, b_base, st + 1, fr[(st + 1) & 1]);    // the next set's operands, ahead of this one's MFMAs
+            if (PIPE && st + 1 < NSTEP) load_frags(a_base, b_base, st + 1, fr[(st + 1) & 1]);
+            if (!PIPE && st > 0) load_frags(a_base, b_base, st, fr[0]);
             __builtin_amdgcn_sched_barrier(0);
-            const Frags &f = fr[st & 1];
+            const Frags &f = fr[PIPE ? (st & 1) : 0];
 #pragma unroll
             for (int rr = 0; rr < RG; rr++)
 #pragma unroll
@@ -1088,7 +1092,7 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
 template <int COB, int CIB>
 int launch_wgrad_tr(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
                     int Cout, int num_cus, const unsigned short *zero16, hipStream_t stream) {
-    constexpr int TH_ = (COB == 64 && CIB == 64) ? 8 : 4;   // 64 x 64 channel blocks: the 8-row double buffer fits one CU (152 KB); the smaller blocks keep two workgroups per CU
+    constexpr int TH_ = (COB == CIB) ? 8 : 4;   // 64 x 64 blocks: the 8-row double buffer fits one CU (152 KB); 32 x 32: two workgroups of 76 KB; the mixed blocks keep 4 rows and two workgroups
     constexpr int XPIX = (TH_ + 2) * (TW + 2);
     constexpr int BUF = (COB / 32) * (TH_ * TW / 16) * 1024 + (CIB / 32) * ((XPIX + 15) / 16) * 1024;
     const size_t lds = 2 * (size_t)BUF;
