@@ -994,7 +994,23 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
     const int n_tiles = tiles_x * tiles_y * N;
 
     // DMA slots of this wave: instruction j = wv + 4 i; lane -> pixel 16 (j % IPP) + lane / 4 of plane j / IPP, channels 8 (lane % 4) ..
+    // Per slot and lane, once: the pixel's row / column relative to the tile origin and its element offset from the origin pixel;
+    // per tile only the origin (scalar), two unsigned range tests and one 64-bit add per slot are left.
     const int lp = lane >> 2, lq = lane & 3;
+    int s_rel[IPW], s_py[IPW], s_px[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; i++) {
+        const int j = wv + 4 * i;
+        if (j < DY_INSTR) {
+            const int plane = j / DY_IPP, p = (j % DY_IPP) * 16 + lp;
+            s_py[i] = p / TW; s_px[i] = p % TW;
+            s_rel[i] = (s_py[i] * W + s_px[i]) * Cout + plane * 32 + lq * 8;
+        } else {
+            const int jj = j - DY_INSTR, plane = jj / X_IPP, p = (jj % X_IPP) * 16 + lp;
+            s_py[i] = p < XPIX ? p / XCOLS - 1 : -(1 << 20); s_px[i] = p % XCOLS - 1;
+            s_rel[i] = (s_py[i] * W + s_px[i]) * xcs + plane * 32 + lq * 8;
+        }
+    }
     struct TilePos { int n, ty0, tx0; };
     auto tile_pos = [&](int tile) {
         const int n = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
@@ -1002,21 +1018,16 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
     };
     // part < 0: all of the wave's instructions; otherwise only instruction `part` (the main loop spreads them between its MFMAs)
     auto issue = [&](const TilePos &tp, unsigned char *buf, int part) {
-        const int n = tp.n, ty0 = tp.ty0, tx0 = tp.tx0;
+        const size_t origin = ((size_t)tp.n * H + tp.ty0) * W + tp.tx0;
+        const unsigned short *dy0 = dY + origin * Cout + co0, *x0 = Xs + origin * xcs + xcb;
 #pragma unroll
         for (int i = 0; i < IPW; i++) {
             const int j = wv + 4 * i;
             if (part >= 0 && i != part) continue;
-            if (j < DY_INSTR) {
-                const int plane = j / DY_IPP, p = (j % DY_IPP) * 16 + lp;
-                const int y = ty0 + p / TW, x = tx0 + p % TW;
-                const unsigned short *src = (y < H && x < W) ? dY + (((size_t)n * H + y) * W + x) * Cout + co0 + plane * 32 + lq * 8 : zero16;
-                glds16(src, buf + j * 1024);
-            } else if (j < N_INSTR) {
-                const int jj = j - DY_INSTR, plane = jj / X_IPP, p = (jj % X_IPP) * 16 + lp;
-                const int y = ty0 - 1 + p / XCOLS, x = tx0 - 1 + p % XCOLS;
-                const unsigned short *src = (p < XPIX && y >= 0 && y < H && x >= 0 && x < W) ? Xs + (((size_t)n * H + y) * W + x) * xcs + xcb + plane * 32 + lq * 8 : zero16;
-                glds16(src, buf + j * 1024);
+            if (j < N_INSTR) {
+                const bool ok = (unsigned)(tp.ty0 + s_py[i]) < (unsigned)H && (unsigned)(tp.tx0 + s_px[i]) < (unsigned)W;
+                const unsigned short *src = (j < DY_INSTR ? dy0 : x0) + s_rel[i];
+                glds16(ok ? src : zero16, buf + j * 1024);
             }
         }
     };
