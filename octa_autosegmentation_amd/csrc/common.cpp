@@ -47,6 +47,7 @@ extern "C" void octa_ctx_destroy(octa_ctx *ctx) {
     ctx->r_tile_list.release();
     ctx->r_counters.release();
     ctx->zero_page.release();
+    ctx->wgrad_ws.release();
     ctx->zero_ring.release();
     delete ctx;
 }

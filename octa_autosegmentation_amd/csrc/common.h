@@ -90,6 +90,7 @@ struct octa_ctx {
     octa::DevBuf r_tile_list;   // int32 [sum tile counts]
     octa::DevBuf r_counters;    // int64 [8] misc device counters
     octa::DevBuf zero_page;     // 256 zero bytes: source of the padding pixels of the DMA-staged convolution (conv.hip)
+    octa::DevBuf wgrad_ws;      // per-workgroup partial weight gradients of conv3x3_nhwc_wgrad_tr_kernel (conv.hip), stream-ordered like the rest
     // ring of pre-zeroed accumulator slots (norm.hip statistics): ONE memset per lap instead of one per launch. Stream-ordered
     // like every other scratch buffer of the context (one context = one stream at a time).
     octa::DevBuf zero_ring;

@@ -969,7 +969,8 @@ template <int COB, int CIB, int TH_>
 __global__ void __launch_bounds__(CONV_THREADS, (COB == 32 && CIB == 32 ? 2 : 1))
 conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                              const unsigned short *__restrict__ dY, float *__restrict__ dW,
-                             int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, const unsigned short *__restrict__ zero16) {
+                             int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, const unsigned short *__restrict__ zero16,
+                             float *__restrict__ ws) {
     constexpr int PAIRS = (COB / 32) * (CIB / 32), KSPLIT = 4 / PAIRS, RPW = TH_ / KSPLIT;   // tile rows per wave
     constexpr int RG = RPW < 4 ? RPW : 4, NG = RPW / RG;            // rows per operand set (register budget), sets per column group
     constexpr int XCOLS = TW + 2, XROWS = TH_ + 2, XPIX = XROWS * XCOLS;                     // 34 x (TH_ + 2) halo
@@ -1091,6 +1092,37 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
         cur ^= 1;
     }
     // D[row = co][col = ci]: row = (k&3) + 8*(k>>2) + 4*(lane/32), col = lane % 32
+    if (KSPLIT > 1) {
+        // the waves that shared a (co, ci) pair fold their partial sums in the LDS first (every lane owns the same 144 addresses in
+        // each of them: plain read-modify-write, one barrier per wave): 1 / KSPLIT of the atomics / workspace traffic below
+        __syncthreads();                                   // every wave is done with the operand buffers
+        float *red = reinterpret_cast<float *>(smem) + pair * (9 * 32 * 32);
+#pragma unroll
+        for (int w = 0; w < KSPLIT; w++) {
+            if (kpart == w) {
+#pragma unroll
+                for (int t = 0; t < 9; t++)
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        float *q = red + (t * 16 + k) * 64 + lane;
+                        if (w == 0) *q = acc[t][k]; else if (w + 1 < KSPLIT) *q += acc[t][k]; else acc[t][k] += *q;
+                    }
+            }
+            if (w + 1 < KSPLIT) __syncthreads();
+        }
+        if (kpart != KSPLIT - 1) return;                   // the last wave of the pair holds the total
+    }
+    if (ws) {
+        // many workgroups per channel block (the wide, few-channel layers: up to 512 workgroups adding into the same 9216 weights):
+        // plain stores of this pair's partial sums, folded by wgrad_tr_reduce_kernel
+        float *mine = ws + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * PAIRS + pair) * (9 * 32 * 32);
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                mine[(t * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[t][k];
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 9; t++)
 #pragma unroll
@@ -1100,24 +1132,67 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
         }
 }
 
+// dW[t][co][ci] = sum over the workgroups of the channel block of their partial 32 x 32 tiles (ws: [block][workgroup][pair][9][32][32]);
+// thread = one weight, consecutive threads = consecutive ci
 template <int COB, int CIB>
-int launch_wgrad_tr(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
+__global__ void __launch_bounds__(256)
+wgrad_tr_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dW, int Cin, int Cout, int per_block) {
+    constexpr int PAIRS = (COB / 32) * (CIB / 32);
+    const int e = blockIdx.x * 256 + threadIdx.x;                 // (t, co, ci) of the whole weight tensor
+    if (e >= 9 * Cout * Cin) return;
+    const int ci = e % Cin, co = (e / Cin) % Cout, t = e / (Cin * Cout);
+    const int blk = (co / COB) * (Cin / CIB) + ci / CIB;
+    const int pair = (co % COB) / 32 + (COB / 32) * ((ci % CIB) / 32);
+    const float *p = ws + ((size_t)blk * per_block * PAIRS + pair) * (9 * 32 * 32) + (t * 32 + co % 32) * 32 + ci % 32;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 3 < per_block; g += 4) {
+        s0 += p[(size_t)g * PAIRS * (9 * 32 * 32)];
+        s1 += p[(size_t)(g + 1) * PAIRS * (9 * 32 * 32)];
+        s2 += p[(size_t)(g + 2) * PAIRS * (9 * 32 * 32)];
+        s3 += p[(size_t)(g + 3) * PAIRS * (9 * 32 * 32)];
+    }
+    for (; g < per_block; g++) s0 += p[(size_t)g * PAIRS * (9 * 32 * 32)];
+    dW[e] = (s0 + s1) + (s2 + s3);
+}
+
+template <int COB, int CIB>
+int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
                     int Cout, int num_cus, const unsigned short *zero16, hipStream_t stream) {
     constexpr int TH_ = (COB == CIB) ? 8 : 4;   // 64 x 64 blocks: the 8-row double buffer fits one CU (152 KB); 32 x 32: two workgroups of 76 KB; the mixed blocks keep 4 rows and two workgroups
     constexpr int XPIX = (TH_ + 2) * (TW + 2);
     constexpr int BUF = (COB / 32) * (TH_ * TW / 16) * 1024 + (CIB / 32) * ((XPIX + 15) / 16) * 1024;
-    const size_t lds = 2 * (size_t)BUF;
+    constexpr int PAIRS_ = (COB / 32) * (CIB / 32);
+    constexpr size_t FOLD = PAIRS_ < 4 ? (size_t)PAIRS_ * 9 * 32 * 32 * sizeof(float) : 0;     // LDS fold of the waves that share a pair
+    const size_t lds = 2 * (size_t)BUF > FOLD ? 2 * (size_t)BUF : FOLD;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH_ - 1) / TH_;
     const int blocks = (Cout / COB) * (Cin / CIB);
     int per_block = (num_cus * (COB == 32 && CIB == 32 ? 2 : 1) + blocks - 1) / blocks;
     const int n_tiles = tiles_x * tiles_y * N;
     if (per_block > n_tiles) per_block = n_tiles;
     if (per_block < 1) per_block = 1;
+    // 16 - 64 workgroups per channel block: partial sums through a workspace + one reduction launch instead of atomics (152^2 256->256
+    // 0.130 -> 0.119 ms, 304^2 128->128 0.133 -> 0.130); with more workgroups per block the reduction's per-thread loop over the partials
+    // costs more than the atomics (1216^2 32->32, 512 workgroups: 0.238 against 0.201 ms), with fewer there is little contention.
+    // (Measured with the atomics removed altogether: 0.188 / 0.112 / 0.408 ms for 1216^2 32->32 / 152^2 256->256 / 512->512.)
+    static const int ws_from = [] { const char *e = getenv("OCTA_WGRAD_WS"); return e ? atoi(e) : 16; }();
+    float *ws = nullptr;
+    if (ws_from > 0 && per_block >= ws_from && per_block <= 64) {
+        if (ctx->wgrad_ws.reserve((size_t)blocks * per_block * ((COB / 32) * (CIB / 32)) * 9 * 32 * 32 * sizeof(float))) return -1;
+        ws = ctx->wgrad_ws.as<float>();
+    } else {
+        OCTA_HIP_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * 9 * (size_t)Cout * Cin, stream));
+    }
     auto kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Cin, Cout,
-                       tiles_x, tiles_y, zero16);
+                       tiles_x, tiles_y, zero16, ws);
     OCTA_HIP_CHECK(hipGetLastError());
+    if (ws) {
+        const int total = 9 * Cout * Cin;
+        hipLaunchKernelGGL((wgrad_tr_reduce_kernel<COB, CIB>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ws, dW, Cin, Cout, per_block);
+        OCTA_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1166,12 +1241,19 @@ extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const vo
     if (C1 <= 0 || C1 > Cin || C1 % 32) { octa::set_error("octa_conv3x3_nhwc_wgrad: the input split must be a multiple of 32 inside the channel range"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
-    OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 9 * (size_t)Cout * Cin, stream));
     const unsigned short *X = static_cast<const unsigned short *>(d_x), *X2 = static_cast<const unsigned short *>(d_x2);
     const unsigned short *dY = static_cast<const unsigned short *>(d_dy);
     const unsigned short *z = zero_page(ctx);
     if (!z) return -1;
     const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0 && C1 % 64 == 0;   // a 64-channel block must not straddle the split
+    static const int use_tr = [] { const char *e = getenv("OCTA_WGRAD_TR"); return e ? atoi(e) : 1; }();
+    if (stride == 1 && use_tr && tap_mask == 0x1ff && !d_scale1 && !d_scale2) {     // raw tiles + transposing reads (see conv3x3_nhwc_wgrad_tr_kernel)
+        if (co64 && ci64) return launch_wgrad_tr<64, 64>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
+        if (co64) return launch_wgrad_tr<64, 32>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
+        if (ci64) return launch_wgrad_tr<32, 64>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
+        return launch_wgrad_tr<32, 32>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
+    }
+    OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 9 * (size_t)Cout * Cin, stream));
     if (stride == 2) {
         if (H % 2 || W % 2) { octa::set_error("octa_conv3x3_nhwc_wgrad: stride-2 layers need even input sizes"); return -2; }
         // two column-parity planes per halo row: 32 input channels per workgroup keep the double buffer inside the LDS
@@ -1179,13 +1261,6 @@ extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const vo
         return launch_wgrad<32, 32, 2>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     }
     if (stride != 1) { octa::set_error("octa_conv3x3_nhwc_wgrad: stride must be 1 or 2"); return -2; }
-    static const int use_tr = [] { const char *e = getenv("OCTA_WGRAD_TR"); return e ? atoi(e) : 1; }();
-    if (use_tr && tap_mask == 0x1ff && !d_scale1 && !d_scale2) {     // raw tiles + transposing reads (see conv3x3_nhwc_wgrad_tr_kernel)
-        if (co64 && ci64) return launch_wgrad_tr<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
-        if (co64) return launch_wgrad_tr<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
-        if (ci64) return launch_wgrad_tr<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
-        return launch_wgrad_tr<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
-    }
     if (co64 && ci64) return launch_wgrad<64, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
