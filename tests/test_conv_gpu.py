@@ -289,7 +289,9 @@ def test_epilogue_statistics_feed_the_norm(hip_lib_built):
     import torch
     from octa_autosegmentation_amd.models import mfma_conv as mc
     g = torch.Generator(device="cuda").manual_seed(31)
-    for (h, w, cin, cout, st) in ((37, 45, 32, 64, 1), (24, 40, 64, 32, 2)):
+    # (203, 70) with 64 output channels takes the 16-row tiles, which write two 8-row slots of the partials layout each (the last tile
+    # row has a lower half outside the image); (216, 64): an even number of 8-row tiles
+    for (h, w, cin, cout, st) in ((37, 45, 32, 64, 1), (24, 40, 64, 32, 2), (203, 70, 32, 64, 1), (216, 64, 64, 128, 1)):
         x = torch.randn(2, h, w, cin, device="cuda", generator=g).to(torch.bfloat16)
         wt = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (3.0 * cin ** 0.5)
         gam, bet = torch.rand(cout, device="cuda", generator=g) + 0.5, torch.randn(cout, device="cuda", generator=g) * 0.1
