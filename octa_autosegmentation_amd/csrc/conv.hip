@@ -964,16 +964,24 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char *p) {
     return u.v;
 }
 
-// TH_: tile rows (4 or 8; 8 halves the barriers and the halo share of the DMA where the double buffer fits)
-template <int COB, int CIB, int TH_>
-__global__ void __launch_bounds__(CONV_THREADS, (COB == 32 && CIB == 32 ? 2 : 1))
+// TH_: tile rows (4 or 8; 8 halves the barriers and the halo share of the DMA where the double buffer fits).
+// ST = 2 (stride-2 layers; dY has Ho x Wo = H / 2 x W / 2 pixels): tap (r, s) pairs output pixel (y, x) with input pixel
+// (2y + r - 1, 2x + s - 1); the X tile keeps the even and the odd halo columns of a row in two planes of 33 pixels ([row][parity][33]),
+// so the 16 input pixels of a K-chunk are consecutive LDS pixels again and a tap is still an immediate offset:
+// ((2y + r) * 2 + s % 2) * 33 + x + s / 2. MASKED: taps outside tap_mask are neither read nor multiplied (the 2 x 2 transposed
+// convolution's weight gradient uses four of the nine).
+template <int COB, int CIB, int TH_, int ST, bool MASKED>
+__global__ void __launch_bounds__(CONV_THREADS, (COB == 32 && CIB == 32 && ST == 1 ? 2 : 1))
 conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                              const unsigned short *__restrict__ dY, float *__restrict__ dW,
-                             int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, const unsigned short *__restrict__ zero16,
-                             float *__restrict__ ws) {
+                             int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask,
+                             const unsigned short *__restrict__ zero16, float *__restrict__ ws) {
     constexpr int PAIRS = (COB / 32) * (CIB / 32), KSPLIT = 4 / PAIRS, RPW = TH_ / KSPLIT;   // tile rows per wave
     constexpr int RG = RPW < 4 ? RPW : 4, NG = RPW / RG;            // rows per operand set (register budget), sets per column group
-    constexpr int XCOLS = TW + 2, XROWS = TH_ + 2, XPIX = XROWS * XCOLS;                     // 34 x (TH_ + 2) halo
+    constexpr int XROWS = ST * (TH_ - 1) + 3;                                                // halo rows
+    constexpr int XCOLS = ST == 1 ? TW + 2 : 2 * (TW + 1);                                   // LDS pixels per halo row (ST = 2: two parity planes of 33)
+    constexpr int XPIX = XROWS * XCOLS;
+    constexpr int NBR = ST * (RG - 1) + 3;                                                   // halo rows one operand set touches
     constexpr int DY_IPP = TH_ * TW / 16, X_IPP = (XPIX + 15) / 16;                          // DMA instructions (16 pixels) per 32-channel plane
     constexpr int DY_PLANE = DY_IPP * 1024, X_PLANE = X_IPP * 1024;
     constexpr int DY_INSTR = (COB / 32) * DY_IPP, X_INSTR = (CIB / 32) * X_IPP, N_INSTR = DY_INSTR + X_INSTR;
@@ -1005,29 +1013,33 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
         if (j < DY_INSTR) {
             const int plane = j / DY_IPP, p = (j % DY_IPP) * 16 + lp;
             s_py[i] = p / TW; s_px[i] = p % TW;
-            s_rel[i] = (s_py[i] * W + s_px[i]) * Cout + plane * 32 + lq * 8;
+            s_rel[i] = (s_py[i] * Wo + s_px[i]) * Cout + plane * 32 + lq * 8;
         } else {
             const int jj = j - DY_INSTR, plane = jj / X_IPP, p = (jj % X_IPP) * 16 + lp;
-            s_py[i] = p < XPIX ? p / XCOLS - 1 : -(1 << 20); s_px[i] = p % XCOLS - 1;
+            const int hy = p / XCOLS, rem = p % XCOLS;
+            const int hx = ST == 1 ? rem : 2 * (rem % (TW + 1)) + rem / (TW + 1);          // halo column of LDS pixel `rem` of the row
+            s_py[i] = (p < XPIX && hx <= ST * TW + 1 - (ST == 1 ? 0 : 1)) ? hy - 1 : -(1 << 20); s_px[i] = hx - 1;
             s_rel[i] = (s_py[i] * W + s_px[i]) * xcs + plane * 32 + lq * 8;
         }
     }
     struct TilePos { int n, ty0, tx0; };
     auto tile_pos = [&](int tile) {
         const int n = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
-        return TilePos{n, (tt / tiles_x) * TH_, (tt % tiles_x) * TW};
+        return TilePos{n, (tt / tiles_x) * TH_, (tt % tiles_x) * TW};      // in output (dY) pixels
     };
     // part < 0: all of the wave's instructions; otherwise only instruction `part` (the main loop spreads them between its MFMAs)
     auto issue = [&](const TilePos &tp, unsigned char *buf, int part) {
-        const size_t origin = ((size_t)tp.n * H + tp.ty0) * W + tp.tx0;
-        const unsigned short *dy0 = dY + origin * Cout + co0, *x0 = Xs + origin * xcs + xcb;
+        const unsigned short *dy0 = dY + (((size_t)tp.n * Ho + tp.ty0) * Wo + tp.tx0) * Cout + co0;
+        const unsigned short *x0 = Xs + (((size_t)tp.n * H + ST * tp.ty0) * W + ST * tp.tx0) * xcs + xcb;
 #pragma unroll
         for (int i = 0; i < IPW; i++) {
             const int j = wv + 4 * i;
             if (part >= 0 && i != part) continue;
             if (j < N_INSTR) {
-                const bool ok = (unsigned)(tp.ty0 + s_py[i]) < (unsigned)H && (unsigned)(tp.tx0 + s_px[i]) < (unsigned)W;
-                const unsigned short *src = (j < DY_INSTR ? dy0 : x0) + s_rel[i];
+                const bool isdy = j < DY_INSTR;
+                const bool ok = isdy ? (unsigned)(tp.ty0 + s_py[i]) < (unsigned)Ho && (unsigned)(tp.tx0 + s_px[i]) < (unsigned)Wo
+                                     : (unsigned)(ST * tp.ty0 + s_py[i]) < (unsigned)H && (unsigned)(ST * tp.tx0 + s_px[i]) < (unsigned)W;
+                const unsigned short *src = (isdy ? dy0 : x0) + s_rel[i];
                 glds16(ok ? src : zero16, buf + j * 1024);
             }
         }
@@ -1040,16 +1052,27 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
     constexpr int NSTEP = (TW / 16) * NG;                           // operand sets per tile: (column group, row group)
     constexpr int NMF = (TW / 16) * RPW * 9;                       // MFMAs per wave and tile
     constexpr int ISTRIDE = (NMF * 2 / 3) / IPW > 0 ? (NMF * 2 / 3) / IPW : 1;   // one DMA instruction every ISTRIDE MFMAs, the last third of the tile carries none
-    struct Frags { bf16x8 b[RG + 2][3], a[RG]; };
+    struct Frags { bf16x8 b[NBR][3], a[RG]; };
     // operand reads of one 16-pixel column group in the order of their first use (the compiler's lgkmcnt then lets the first tile
     // row's MFMAs start while the later fragments are still on their way)
+    auto tap_on = [&](int r, int sx) { return !MASKED || ((tap_mask >> (3 * r + sx)) & 1); };
     auto load_frags = [&](const unsigned char *a_base, const unsigned char *b_base, int step, Frags &f) {
         const int xc = step / NG, row0 = kpart * RPW + (step % NG) * RG;
 #pragma unroll
-        for (int hr = 0; hr < RG + 2; hr++) {
-            if (hr >= 2 && hr - 2 < RG) f.a[hr - 2] = tr_read8(a_base + ((row0 + hr - 2) * TW + xc * 16) * 64);
+        for (int hr = 0; hr < NBR; hr++) {
+            if (ST == 1 ? (hr >= 2 && hr - 2 < RG) : (hr % 2 == 0 && hr / 2 < RG))
+                f.a[ST == 1 ? hr - 2 : hr / 2] = tr_read8(a_base + ((row0 + (ST == 1 ? hr - 2 : hr / 2)) * TW + xc * 16) * 64);
 #pragma unroll
-            for (int sx = 0; sx < 3; sx++) f.b[hr][sx] = tr_read8(b_base + ((row0 + hr) * XCOLS + xc * 16 + sx) * 64);
+            for (int sx = 0; sx < 3; sx++) {
+                if (MASKED) {   // this halo row serves tap row r of tile row rr when hr = ST * rr + r: skip it when none of those taps is wanted
+                    bool any = false;
+#pragma unroll
+                    for (int r = 0; r < 3; r++) if ((hr - r) >= 0 && (hr - r) % ST == 0 && (hr - r) / ST < RG && tap_on(r, sx)) any = true;
+                    if (!any) continue;
+                }
+                const int e = ST == 1 ? (row0 + hr) * XCOLS + xc * 16 + sx : ((ST * row0 + hr) * 2 + (sx & 1)) * (TW + 1) + xc * 16 + (sx >> 1);
+                f.b[hr][sx] = tr_read8(b_base + e * 64);
+            }
         }
     };
     int tile = blockIdx.x, cur = 0;
@@ -1079,7 +1102,7 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
                 for (int r = 0; r < 3; r++)
 #pragma unroll
                     for (int sx = 0; sx < 3; sx++) {
-                        acc[3 * r + sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rr], f.b[rr + r][sx], acc[3 * r + sx], 0, 0, 0);
+                        if (tap_on(r, sx)) acc[3 * r + sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rr], f.b[ST * rr + r][sx], acc[3 * r + sx], 0, 0, 0);
                         const int q = (st * RG + rr) * 9 + 3 * r + sx;
                         if (q % ISTRIDE == ISTRIDE - 1 && q / ISTRIDE < IPW) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -1156,18 +1179,21 @@ wgrad_tr_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dW, int
     dW[e] = (s0 + s1) + (s2 + s3);
 }
 
-template <int COB, int CIB>
+template <int COB, int CIB, int ST = 1>
 int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
-                    int Cout, int num_cus, const unsigned short *zero16, hipStream_t stream) {
-    constexpr int TH_ = (COB == CIB) ? 8 : 4;   // 64 x 64 blocks: the 8-row double buffer fits one CU (152 KB); 32 x 32: two workgroups of 76 KB; the mixed blocks keep 4 rows and two workgroups
-    constexpr int XPIX = (TH_ + 2) * (TW + 2);
+                    int Cout, int num_cus, int tap_mask, const unsigned short *zero16, hipStream_t stream) {
+    // stride 1: 64 x 64 blocks: the 8-row double buffer fits one CU (152 KB); 32 x 32: two workgroups of 76 KB; the mixed blocks keep 4 rows
+    // and two workgroups. Stride 2 (a 9 x 66-pixel halo per 4 output rows): 4 rows, one workgroup per CU
+    constexpr int TH_ = (ST == 1 && COB == CIB) ? 8 : 4;
+    constexpr int XPIX = (ST * (TH_ - 1) + 3) * (ST == 1 ? TW + 2 : 2 * (TW + 1));
     constexpr int BUF = (COB / 32) * (TH_ * TW / 16) * 1024 + (CIB / 32) * ((XPIX + 15) / 16) * 1024;
     constexpr int PAIRS_ = (COB / 32) * (CIB / 32);
     constexpr size_t FOLD = PAIRS_ < 4 ? (size_t)PAIRS_ * 9 * 32 * 32 * sizeof(float) : 0;     // LDS fold of the waves that share a pair
     const size_t lds = 2 * (size_t)BUF > FOLD ? 2 * (size_t)BUF : FOLD;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH_ - 1) / TH_;
+    const int Ho = H / ST, Wo = W / ST;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH_ - 1) / TH_;
     const int blocks = (Cout / COB) * (Cin / CIB);
-    int per_block = (num_cus * (COB == 32 && CIB == 32 ? 2 : 1) + blocks - 1) / blocks;
+    int per_block = (num_cus * (COB == 32 && CIB == 32 && ST == 1 ? 2 : 1) + blocks - 1) / blocks;
     const int n_tiles = tiles_x * tiles_y * N;
     if (per_block > n_tiles) per_block = n_tiles;
     if (per_block < 1) per_block = 1;
@@ -1178,15 +1204,16 @@ int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short
     static const int ws_from = [] { const char *e = getenv("OCTA_WGRAD_WS"); return e ? atoi(e) : 16; }();
     float *ws = nullptr;
     if (ws_from > 0 && per_block >= ws_from && per_block <= 64) {
-        if (ctx->wgrad_ws.reserve((size_t)blocks * per_block * ((COB / 32) * (CIB / 32)) * 9 * 32 * 32 * sizeof(float))) return -1;
+        if (ctx->wgrad_ws.reserve((size_t)blocks * per_block * PAIRS_ * 9 * 32 * 32 * sizeof(float))) return -1;
         ws = ctx->wgrad_ws.as<float>();
     } else {
         OCTA_HIP_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * 9 * (size_t)Cout * Cin, stream));
     }
-    auto kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_>;
+    auto kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_, ST, false>;
+    if (tap_mask != 0x1ff) kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_, ST, true>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Cin, Cout,
-                       tiles_x, tiles_y, zero16, ws);
+    hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Ho, Wo, Cin, Cout,
+                       tiles_x, tiles_y, tap_mask, zero16, ws);
     OCTA_HIP_CHECK(hipGetLastError());
     if (ws) {
         const int total = 9 * Cout * Cin;
@@ -1246,12 +1273,19 @@ extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const vo
     const unsigned short *z = zero_page(ctx);
     if (!z) return -1;
     const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0 && C1 % 64 == 0;   // a 64-channel block must not straddle the split
-    static const int use_tr = [] { const char *e = getenv("OCTA_WGRAD_TR"); return e ? atoi(e) : 1; }();
-    if (stride == 1 && use_tr && tap_mask == 0x1ff && !d_scale1 && !d_scale2) {     // raw tiles + transposing reads (see conv3x3_nhwc_wgrad_tr_kernel)
-        if (co64 && ci64) return launch_wgrad_tr<64, 64>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
-        if (co64) return launch_wgrad_tr<64, 32>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
-        if (ci64) return launch_wgrad_tr<32, 64>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
-        return launch_wgrad_tr<32, 32>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, z, stream);
+    static const int use_tr = [] { const char *e = getenv("OCTA_WGRAD_TR"); return e ? atoi(e) : 2; }();
+    if (use_tr && !d_scale1 && !d_scale2 && (stride == 1 || (stride == 2 && H % 2 == 0 && W % 2 == 0))) {
+        // raw tiles + transposing reads (see conv3x3_nhwc_wgrad_tr_kernel); OCTA_WGRAD_TR=1: stride 1 only, =2 (default): stride 2 as well
+        if (stride == 1) {
+            if (co64 && ci64) return launch_wgrad_tr<64, 64>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
+            if (co64) return launch_wgrad_tr<64, 32>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
+            if (ci64) return launch_wgrad_tr<32, 64>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
+            return launch_wgrad_tr<32, 32>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
+        }
+        if (use_tr >= 2) {
+            if (co64) return launch_wgrad_tr<64, 32, 2>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
+            return launch_wgrad_tr<32, 32, 2>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
+        }
     }
     OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 9 * (size_t)Cout * Cin, stream));
     if (stride == 2) {
