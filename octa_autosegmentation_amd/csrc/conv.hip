@@ -968,8 +968,9 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char *p) {
 // ST = 2 (stride-2 layers; dY has Ho x Wo = H / 2 x W / 2 pixels): tap (r, s) pairs output pixel (y, x) with input pixel
 // (2y + r - 1, 2x + s - 1); the X tile keeps the even and the odd halo columns of a row in two planes of 33 pixels ([row][parity][33]),
 // so the 16 input pixels of a K-chunk are consecutive LDS pixels again and a tap is still an immediate offset:
-// ((2y + r) * 2 + s % 2) * 33 + x + s / 2. MASKED: taps outside tap_mask are neither read nor multiplied (the 2 x 2 transposed
-// convolution's weight gradient uses four of the nine).
+// ((2y + r) * 2 + s % 2) * 33 + x + s / 2. MASKED (the 2 x 2 transposed convolution's weight gradient wants four of the nine taps):
+// all nine are multiplied -- skipping reads and MFMAs behind run-time tests measured slower than the full loop (0.158 against 0.131 ms
+// at 1216^2 32->64) -- and the taps outside tap_mask are left out of the result.
 template <int COB, int CIB, int TH_, int ST, bool MASKED>
 __global__ void __launch_bounds__(CONV_THREADS, (COB == 32 && CIB == 32 && ST == 1 ? 2 : 1))
 conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
@@ -1055,7 +1056,6 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
     struct Frags { bf16x8 b[NBR][3], a[RG]; };
     // operand reads of one 16-pixel column group in the order of their first use (the compiler's lgkmcnt then lets the first tile
     // row's MFMAs start while the later fragments are still on their way)
-    auto tap_on = [&](int r, int sx) { return !MASKED || ((tap_mask >> (3 * r + sx)) & 1); };
     auto load_frags = [&](const unsigned char *a_base, const unsigned char *b_base, int step, Frags &f) {
         const int xc = step / NG, row0 = kpart * RPW + (step % NG) * RG;
 #pragma unroll
@@ -1064,12 +1064,6 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
                 f.a[ST == 1 ? hr - 2 : hr / 2] = tr_read8(a_base + ((row0 + (ST == 1 ? hr - 2 : hr / 2)) * TW + xc * 16) * 64);
 #pragma unroll
             for (int sx = 0; sx < 3; sx++) {
-                if (MASKED) {   // this halo row serves tap row r of tile row rr when hr = ST * rr + r: skip it when none of those taps is wanted
-                    bool any = false;
-#pragma unroll
-                    for (int r = 0; r < 3; r++) if ((hr - r) >= 0 && (hr - r) % ST == 0 && (hr - r) / ST < RG && tap_on(r, sx)) any = true;
-                    if (!any) continue;
-                }
                 const int e = ST == 1 ? (row0 + hr) * XCOLS + xc * 16 + sx : ((ST * row0 + hr) * 2 + (sx & 1)) * (TW + 1) + xc * 16 + (sx >> 1);
                 f.b[hr][sx] = tr_read8(b_base + e * 64);
             }
@@ -1102,7 +1096,7 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
                 for (int r = 0; r < 3; r++)
 #pragma unroll
                     for (int sx = 0; sx < 3; sx++) {
-                        if (tap_on(r, sx)) acc[3 * r + sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rr], f.b[ST * rr + r][sx], acc[3 * r + sx], 0, 0, 0);
+                        acc[3 * r + sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rr], f.b[ST * rr + r][sx], acc[3 * r + sx], 0, 0, 0);
                         const int q = (st * RG + rr) * 9 + 3 * r + sx;
                         if (q % ISTRIDE == ISTRIDE - 1 && q / ISTRIDE < IPW) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -1143,16 +1137,18 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
         for (int t = 0; t < 9; t++)
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                mine[(t * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[t][k];
+                mine[(t * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = (!MASKED || ((tap_mask >> t) & 1)) ? acc[t][k] : 0.f;
         return;
     }
 #pragma unroll
-    for (int t = 0; t < 9; t++)
+    for (int t = 0; t < 9; t++) {
+        if (MASKED && !((tap_mask >> t) & 1)) continue;      // dW was cleared: masked taps come back as zero
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int co = co0 + cobp * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
             atomicAdd(dW + ((size_t)t * Cout + co) * Cin + ci0 + cibp * 32 + (lane & 31), acc[t][k]);
         }
+    }
 }
 
 // dW[t][co][ci] = sum over the workgroups of the channel block of their partial 32 x 32 tiles (ws: [block][workgroup][pair][9][32][32]);
