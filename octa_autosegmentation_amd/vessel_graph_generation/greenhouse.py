@@ -267,11 +267,25 @@ class BatchSimulator:
         import torch
         self.device_index = torch.cuda.current_device() if device_index is None else int(device_index)
         self.device_export = os.environ.get("OCTA_SIM_HOST_EXPORT") != "1"       # 1: the round-2 path (download the node arrays, BFS on the host)
+        self._h = None
+        self._create()
+
+    def _create(self, force_large=False):
+        """Bind to one of the two builds of the kernel (csrc/sim_api.cpp picks from the configuration; force_large: the wide-field one)."""
         h = ctypes.c_void_p()
-        _native.check(self._lib.octa_sim_create(self._ctx, ctypes.byref(self._cfg), self.batch, ctypes.byref(h)),
-                      "octa_sim_create")
+        old = os.environ.get("OCTA_SIM_BUILD")
+        if force_large:
+            os.environ["OCTA_SIM_BUILD"] = "large"
+        try:
+            _native.check(self._lib.octa_sim_create(self._ctx, ctypes.byref(self._cfg), self.batch, ctypes.byref(h)), "octa_sim_create")
+        finally:
+            if force_large:
+                if old is None:
+                    os.environ.pop("OCTA_SIM_BUILD", None)
+                else:
+                    os.environ["OCTA_SIM_BUILD"] = old
         self._h = h
-        self.is_large = bool(self._lib.octa_sim_is_large(h))      # bound to the wide-field build (csrc/sim_api.cpp)
+        self.is_large = bool(self._lib.octa_sim_is_large(h))      # bound to the wide-field build
 
     def close(self):
         if getattr(self, "_h", None):
@@ -284,13 +298,31 @@ class BatchSimulator:
         except Exception:
             pass
 
+    def _launch(self, call):
+        """Run `call` (one of the octa_sim_run* entry points on self._h). When a sample outgrew the DEFAULT build's per-sample capacities
+        (sized for 3 x 3 mm^2: 14 336 nodes per forest, 13 312 sinks ...), bind to the wide-field build -- the same phase code with
+        2^17 / 2^18, same bytes where both fit (tests/test_sim_gpu.py) -- and run again. OCTA_SIM_BUILD=default keeps the error."""
+        rc = call()
+        if rc == -3 and not self.is_large and os.environ.get("OCTA_SIM_BUILD") != "default":
+            stats = np.zeros((self.batch, 32), np.int64)
+            _native.check(self._lib.octa_sim_stats(self._h, stats.ctypes.data), "octa_sim_stats")
+            bits = int(np.bitwise_or.reduce(stats[:, 0]))
+            CAPACITY = 1 | 2 | 4 | 8 | 16 | 32 | 64 | 256 | 512       # node, O2, CO2, group, pair, set, uniform-stream, request, accepted-sink capacities
+            if bits and not (bits & ~CAPACITY):
+                import warnings
+                warnings.warn(f"the default simulator build ran out of per-sample capacity (error bits {bits:#x}); re-running on the wide-field build")
+                self.close()
+                self._create(force_large=True)
+                rc = call()
+        return rc
+
     def run(self, seeds, py_seeds=None):
         """seeds[k] seeds numpy's stream of sample k; py_seeds (default: the same values) CPython's."""
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
         if len(seeds) != self.batch:
             raise ValueError(f"expected {self.batch} seeds")
         py = np.ascontiguousarray(seeds if py_seeds is None else py_seeds, dtype=np.uint64)
-        rc = self._lib.octa_sim_run(self._h, seeds.ctypes.data, py.ctypes.data, self._bif_fn, None, _native.current_stream_ptr())
+        rc = self._launch(lambda: self._lib.octa_sim_run(self._h, seeds.ctypes.data, py.ctypes.data, self._bif_fn, None, _native.current_stream_ptr()))
         _native.check(rc, "octa_sim_run")
         return self._collect()
 
@@ -351,8 +383,8 @@ class BatchSimulator:
         if faz.shape != (self.batch,) or st.shape != (self.batch, 2, 2 * self._cfg.n_trees, 3) or nps.shape != (self.batch, 625) \
                 or pys.shape != (self.batch, 625):
             raise ValueError("run_from_states: array shapes do not match the batch / the forest configuration")
-        rc = self._lib.octa_sim_run_states(self._h, faz.ctypes.data, st.ctypes.data, nps.ctypes.data, pys.ctypes.data, self._bif_fn, None,
-                                           _native.current_stream_ptr())
+        rc = self._launch(lambda: self._lib.octa_sim_run_states(self._h, faz.ctypes.data, st.ctypes.data, nps.ctypes.data, pys.ctypes.data, self._bif_fn,
+                                                                None, _native.current_stream_ptr()))
         _native.check(rc, "octa_sim_run_states")
         return self._collect()
 

@@ -78,6 +78,29 @@ def test_nerve_forest_runs_match_reference_csv(gh, golden, monkeypatch):
     monkeypatch.delenv("OCTA_SIM_BUILD")
 
 
+def test_capacity_overflow_moves_the_run_to_the_wide_field_build(gh, golden, monkeypatch):
+    """A configuration that csrc/sim_api.cpp's rule sends to the default build but that outgrows its per-sample capacities (the docker
+    modes on a 6 x 6 mm^2 field: four times the sinks of 3 x 3) is re-run on the wide-field build by BatchSimulator -- with a warning,
+    and with the bytes a simulator bound to that build from the start produces. OCTA_SIM_BUILD=default keeps the loud error."""
+    from octa_autosegmentation_amd import _native
+    cfg = _cfg(golden, 60, 60)           # sinks pass 13 312 in iteration 98, peak 20 029
+    cfg["Greenhouse"]["param_scale"] = 6
+    sim = gh.BatchSimulator(cfg, 2)
+    assert not sim.is_large
+    with pytest.warns(UserWarning, match="wide-field build"):
+        res = sim.run([3, 4])
+    assert sim.is_large and int(res.stats[:, 0].max()) == 0
+    texts = [gh.edges_to_csv_text(res.sample_edges(k)) for k in range(2)]
+    sim.close()
+    monkeypatch.setenv("OCTA_SIM_BUILD", "large")
+    ref = gh.simulate_batch(cfg, [3, 4])
+    assert [gh.edges_to_csv_text(ref.sample_edges(k)) for k in range(2)] == texts
+    monkeypatch.setenv("OCTA_SIM_BUILD", "default")
+    with pytest.raises(_native.OctaHipError, match="capacity"):
+        gh.simulate_batch(cfg, [3, 4])
+    monkeypatch.delenv("OCTA_SIM_BUILD")
+
+
 @pytest.mark.parametrize("name", ["run_s0_30_20", "run_s3_30_20", "run_s11_20_0", "nerve_s0_12_6", "nerve_s8_20_0", "geom_s0_30_20"])
 def test_wide_field_build_reproduces_the_reference_fixtures(gh, golden, monkeypatch, tmp_path, name):
     """The wide-field build of the simulator (OCTA_SIM_LARGE: 32-bit indices, 64-bit kd elements, per-sample tables in HBM; chosen
