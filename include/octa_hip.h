@@ -235,6 +235,16 @@ int octa_instnorm_lrelu_nhwc_fwd_p(octa_ctx *ctx, const void *d_x, void *d_y, co
                                    float *d_rstd, int B, int C, int64_t hw, float slope, float eps, const float *d_partials, int tiles,
                                    void *stream);
 
+/* 3 x 3 convolution, stride 1, with an explicit padding (round 3): pad = 0 (valid), 1 (same), 2 (full: the data gradient of a valid
+ * convolution), zeros outside the image; reflect = 1 (pad = 1 only) fuses nn.ReflectionPad2d(1) into the halo fetch -- the ResNet
+ * blocks of the reference's generator (models/networks.py:151-176: ReflectionPad2d(1) + Conv2d(3, padding 0)) without a padded or a
+ * cropped copy. d_x [N][H][W][Cin], d_w packed [9][Cout][Cin], d_y [N][H + 2 pad - 2][W + 2 pad - 2][Cout], all bf16; Cin, Cout
+ * multiples of 32. octa_conv3x3_nhwc_wgrad_pad is its weight gradient (d_dw fp32 [9][Cout][Cin], overwritten). */
+int octa_conv3x3_nhwc_fwd_pad(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int pad,
+                              int reflect, void *stream);
+int octa_conv3x3_nhwc_wgrad_pad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin, int Cout, int pad,
+                                int reflect, void *stream);
+
 /* Weight gradient with a stride: stride 2 = d_x is the [N][H][W][Cin] input of a stride-2 layer (H, W even), d_dy its
  * [N][H/2][W/2][Cout] output gradient; tap_mask as above (the 2x2 transposed convolution, written as the adjoint of a
  * stride-2 layer, asks for 4 of the 9 taps). */

@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(CONV_THREADS, (THT == 16 ? 2 : 1))
 conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                          const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
                          int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, const unsigned short *__restrict__ zero16,
-                         float *__restrict__ part, int tap_mask, int osc, int ooy, int oox, int pad, const unsigned short *__restrict__ R) {
+                         float *__restrict__ part, int tap_mask, int osc, int ooy, int oox, int pad, const unsigned short *__restrict__ R, int reflect) {
     constexpr int RPW = THT / 4;                           // tile rows per wave (THT = 8: two, THT = 16: four)
     constexpr int IH = (THT - 1) * ST + KS, IW = (TW - 1) * ST + KS;   // KS x KS taps (3: the U-Net / generator layers, 4: the PatchGAN)
     constexpr int PW = (IW + ST - 1) / ST;                 // pixels per LDS plane row (ST = 2: 33 even / 32 odd columns)
@@ -305,7 +305,11 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
         const int slot = (wv + 4 * i) * 64 + lane, p = slot / PP, q = (slot % PP) ^ glds_swz<PP>(p);
         // LDS pixel p = (halo row * ST + column parity) * PW + column / ST
         const int prow = p / PW, hy = prow / ST, hx = (p % PW) * ST + prow % ST;
-        const int yy = iy0 + hy, xx = ix0 + hx;
+        int yy = iy0 + hy, xx = ix0 + hx;
+        if (reflect) {      // nn.ReflectionPad2d(pad) in front of the convolution: the halo mirrors the image instead of padding it with zeros
+            yy = yy < 0 ? -yy : (yy >= Hv ? 2 * (Hv - 1) - yy : yy);
+            xx = xx < 0 ? -xx : (xx >= Wv ? 2 * (Wv - 1) - xx : xx);
+        }
         bool ok = p < LPIX && hx < IW && yy >= 0 && yy < Hv && xx >= 0 && xx < Wv;
         if (ok && dil == 2) ok = !((yy | xx) & 1);
         const int sy = dil == 2 ? yy >> 1 : yy, sx = dil == 2 ? xx >> 1 : xx;
@@ -559,7 +563,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
 template <int BN, int KCV, int ST = 1, int KS = 3, int THT = TH>
 int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
                      int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, float *part, int tap_mask,
-                     int osc, int ooy, int oox, hipStream_t stream, int pad = 1, const unsigned short *R = nullptr) {
+                     int osc, int ooy, int oox, hipStream_t stream, int pad = 1, const unsigned short *R = nullptr, int reflect = 0) {
     constexpr int IH = (THT - 1) * ST + KS, IW = (TW - 1) * ST + KS, PP = KCV / 8;
     constexpr int BUF = ((IH * ST * ((IW + ST - 1) / ST) * PP + 63) / 64 + KS * KS * BN * PP / 64) * 1024;
     constexpr int OUT = THT * TW * (BN * 2 + 16);
@@ -572,7 +576,7 @@ int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, 
     }
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
-    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask, osc, ooy, oox, pad, R);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask, osc, ooy, oox, pad, R, reflect);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -708,6 +712,29 @@ extern "C" int octa_conv4x4_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void 
     if (Cout % 64 == 0)
         return launch_conv_glds<64, 16, 1, 4>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, nullptr, 0xffff, 1, 0, 0, stream, pad);
     return launch_conv_glds<32, 16, 1, 4>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, nullptr, 0xffff, 1, 0, 0, stream, pad);
+}
+
+// 3 x 3 convolution, stride 1, with an explicit padding: pad = 0 (valid), 1 (same) or 2 (full: what the data gradient of a valid
+// convolution is), zeros outside the image -- or, reflect = 1 with pad = 1, nn.ReflectionPad2d(1) fused into the halo fetch (the
+// ResNet blocks of the generator, models/networks.py:_resblock_nhwc: no padded copy, no cropped copy). Output (H + 2 pad - 2)^2.
+extern "C" int octa_conv3x3_nhwc_fwd_pad(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int pad,
+                                         int reflect, void *stream_) {
+    if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv3x3_nhwc_fwd_pad: null pointer"); return -2; }
+    if (N <= 0 || N > 65535 || H <= 0 || W <= 0 || pad < 0 || pad > 2 || H + 2 * pad < 3 || W + 2 * pad < 3) { octa::set_error("octa_conv3x3_nhwc_fwd_pad: bad shape"); return -2; }
+    if (reflect && (pad != 1 || H < 2 || W < 2)) { octa::set_error("octa_conv3x3_nhwc_fwd_pad: reflection needs pad = 1 and an image of at least 2 x 2"); return -2; }
+    if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd_pad: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const unsigned short *z = zero_page(ctx);
+    if (!z) return -1;
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const unsigned short *X = static_cast<const unsigned short *>(d_x), *Wt = static_cast<const unsigned short *>(d_w);
+    unsigned short *Y = static_cast<unsigned short *>(d_y);
+    if (Cout % 64 == 0) {
+        if (Ho >= 200) return launch_conv_glds<64, 16, 1, 3, 16>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, nullptr, 0x1ff, 1, 0, 0, stream, pad, nullptr, reflect);
+        return launch_conv_glds<64, 16>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, nullptr, 0x1ff, 1, 0, 0, stream, pad, nullptr, reflect);
+    }
+    return launch_conv_glds<32, 16>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, nullptr, 0x1ff, 1, 0, 0, stream, pad, nullptr, reflect);
 }
 
 // ---- weight gradient (stride 1) ----------------------------------------------------------------------------------
@@ -976,7 +1003,7 @@ __global__ void __launch_bounds__(CONV_THREADS, (COB == 32 && CIB == 32 && ST ==
 conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                              const unsigned short *__restrict__ dY, float *__restrict__ dW,
                              int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask,
-                             const unsigned short *__restrict__ zero16, float *__restrict__ ws) {
+                             const unsigned short *__restrict__ zero16, float *__restrict__ ws, int pad, int reflect) {
     constexpr int PAIRS = (COB / 32) * (CIB / 32), KSPLIT = 4 / PAIRS, RPW = TH_ / KSPLIT;   // tile rows per wave
     constexpr int RG = RPW < 4 ? RPW : 4, NG = RPW / RG;            // rows per operand set (register budget), sets per column group
     constexpr int XROWS = ST * (TH_ - 1) + 3;                                                // halo rows
@@ -1019,7 +1046,7 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
             const int jj = j - DY_INSTR, plane = jj / X_IPP, p = (jj % X_IPP) * 16 + lp;
             const int hy = p / XCOLS, rem = p % XCOLS;
             const int hx = ST == 1 ? rem : 2 * (rem % (TW + 1)) + rem / (TW + 1);          // halo column of LDS pixel `rem` of the row
-            s_py[i] = (p < XPIX && hx <= ST * TW + 1 - (ST == 1 ? 0 : 1)) ? hy - 1 : -(1 << 20); s_px[i] = hx - 1;
+            s_py[i] = (p < XPIX && hx <= ST * TW + 1 - (ST == 1 ? 0 : 1)) ? hy - pad : -(1 << 20); s_px[i] = hx - pad;   // pad = 1 but for the valid / full forms (stride 1)
             s_rel[i] = (s_py[i] * W + s_px[i]) * xcs + plane * 32 + lq * 8;
         }
     }
@@ -1041,6 +1068,16 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
                 const bool ok = isdy ? (unsigned)(tp.ty0 + s_py[i]) < (unsigned)Ho && (unsigned)(tp.tx0 + s_px[i]) < (unsigned)Wo
                                      : (unsigned)(ST * tp.ty0 + s_py[i]) < (unsigned)H && (unsigned)(ST * tp.tx0 + s_px[i]) < (unsigned)W;
                 const unsigned short *src = (isdy ? dy0 : x0) + s_rel[i];
+                if (reflect && !isdy && s_py[i] > -(1 << 19)) {
+                    // nn.ReflectionPad2d(1) in front of the convolution: the halo mirrors the image (see octa_conv3x3_nhwc_fwd_pad)
+                    int y = ST * tp.ty0 + s_py[i], x = ST * tp.tx0 + s_px[i];
+                    y = y < 0 ? -y : (y >= H ? 2 * (H - 1) - y : y);
+                    x = x < 0 ? -x : (x >= W ? 2 * (W - 1) - x : x);
+                    const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;      // tiles beyond the image edge reach further than one mirror
+                    src = Xs + (((size_t)tp.n * H + (in ? y : 0)) * W + (in ? x : 0)) * xcs + xcb + ((j - DY_INSTR) / X_IPP) * 32 + lq * 8;
+                    glds16(in ? src : zero16, buf + j * 1024);
+                    continue;
+                }
                 glds16(ok ? src : zero16, buf + j * 1024);
             }
         }
@@ -1177,7 +1214,7 @@ wgrad_tr_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dW, int
 
 template <int COB, int CIB, int ST = 1>
 int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
-                    int Cout, int num_cus, int tap_mask, const unsigned short *zero16, hipStream_t stream) {
+                    int Cout, int num_cus, int tap_mask, const unsigned short *zero16, hipStream_t stream, int pad = 1, int reflect = 0) {
     // stride 1: 64 x 64 blocks: the 8-row double buffer fits one CU (152 KB); 32 x 32: two workgroups of 76 KB; the mixed blocks keep 4 rows
     // and two workgroups. Stride 2 (a 9 x 66-pixel halo per 4 output rows): 4 rows, one workgroup per CU
     constexpr int TH_ = (ST == 1 && COB == CIB) ? 8 : 4;
@@ -1186,7 +1223,7 @@ int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short
     constexpr int PAIRS_ = (COB / 32) * (CIB / 32);
     constexpr size_t FOLD = PAIRS_ < 4 ? (size_t)PAIRS_ * 9 * 32 * 32 * sizeof(float) : 0;     // LDS fold of the waves that share a pair
     const size_t lds = 2 * (size_t)BUF > FOLD ? 2 * (size_t)BUF : FOLD;
-    const int Ho = H / ST, Wo = W / ST;
+    const int Ho = ST == 1 ? H + 2 * pad - 2 : H / ST, Wo = ST == 1 ? W + 2 * pad - 2 : W / ST;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH_ - 1) / TH_;
     const int blocks = (Cout / COB) * (Cin / CIB);
     int per_block = (num_cus * (COB == 32 && CIB == 32 && ST == 1 ? 2 : 1) + blocks - 1) / blocks;
@@ -1209,7 +1246,7 @@ int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short
     if (tap_mask != 0x1ff) kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_, ST, true>;
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Ho, Wo, Cin, Cout,
-                       tiles_x, tiles_y, tap_mask, zero16, ws);
+                       tiles_x, tiles_y, tap_mask, zero16, ws, pad, reflect);
     OCTA_HIP_CHECK(hipGetLastError());
     if (ws) {
         const int total = 9 * Cout * Cin;
@@ -1295,6 +1332,26 @@ extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const vo
     if (co64) return launch_wgrad<64, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     if (ci64) return launch_wgrad<32, 64>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
     return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
+}
+
+// Weight gradient of octa_conv3x3_nhwc_fwd_pad: d_x [N][H][W][Cin], d_dy [N][H + 2 pad - 2][W + 2 pad - 2][Cout], stride 1; reflect = 1
+// (pad = 1): the input was mirrored at its borders (nn.ReflectionPad2d(1) in front of the convolution).
+extern "C" int octa_conv3x3_nhwc_wgrad_pad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin, int Cout, int pad,
+                                           int reflect, void *stream_) {
+    if (!ctx || !d_x || !d_dy || !d_dw) { octa::set_error("octa_conv3x3_nhwc_wgrad_pad: null pointer"); return -2; }
+    if (N <= 0 || H <= 0 || W <= 0 || pad < 0 || pad > 2 || H + 2 * pad < 3 || W + 2 * pad < 3) { octa::set_error("octa_conv3x3_nhwc_wgrad_pad: bad shape"); return -2; }
+    if (reflect && (pad != 1 || H < 2 || W < 2)) { octa::set_error("octa_conv3x3_nhwc_wgrad_pad: reflection needs pad = 1 and an image of at least 2 x 2"); return -2; }
+    if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_wgrad_pad: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const unsigned short *z = zero_page(ctx);
+    if (!z) return -1;
+    const unsigned short *X = static_cast<const unsigned short *>(d_x), *dY = static_cast<const unsigned short *>(d_dy);
+    const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0;
+    if (co64 && ci64) return launch_wgrad_tr<64, 64>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect);
+    if (co64) return launch_wgrad_tr<64, 32>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect);
+    if (ci64) return launch_wgrad_tr<32, 64>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect);
+    return launch_wgrad_tr<32, 32>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect);
 }
 
 extern "C" int octa_conv4x4_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin, int Cout,

@@ -363,6 +363,63 @@ class _Conv3x3NHWC(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
+class _Conv3x3ReflectNHWC(torch.autograd.Function):
+    """nn.ReflectionPad2d(1) + Conv2d(3, padding 0) (the ResNet blocks of the reference's generator, models/networks.py:151-176) in ONE
+    launch per pass: the forward and the weight-gradient kernels mirror the image in their halo fetch (no padded tensor, no crop);
+    the data gradient is the full (pad 2) convolution of dy with the flipped weights, folded back by the reflection's adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        n, h, w, cin = x.shape
+        cout = weight.shape[0]
+        y = torch.empty((n, h, w, cout), dtype=torch.bfloat16, device=x.device)
+        wt = pack_weight(weight, cin)
+        rc = _native.lib().octa_conv3x3_nhwc_fwd_pad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wt.data_ptr()),
+                                                     ctypes.c_void_p(y.data_ptr()), n, h, w, cin, cout, 1, 1, _native.current_stream_ptr())
+        _native.check(rc, "octa_conv3x3_nhwc_fwd_pad")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import resample
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        n, h, w, cin = x.shape
+        cout = dy.shape[3]
+        lib, hctx = _native.lib(), _native.ctx(x.device.index)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wd = pack_weight_dgrad(weight, cin)
+            dxp = torch.empty((n, h + 2, w + 2, cin), dtype=torch.bfloat16, device=x.device)
+            rc = lib.octa_conv3x3_nhwc_fwd_pad(hctx, ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(wd.data_ptr()), ctypes.c_void_p(dxp.data_ptr()),
+                                               n, h, w, cout, cin, 2, 0, _native.current_stream_ptr())
+            _native.check(rc, "octa_conv3x3_nhwc_fwd_pad")
+            dx = torch.empty_like(x)
+            resample._launch("octa_reflect_pad_bwd", dxp, dx, n, h, w, cin, 1)
+        if ctx.needs_input_grad[1]:
+            dwf = torch.empty((9, cout, cin), dtype=torch.float32, device=x.device)
+            rc = lib.octa_conv3x3_nhwc_wgrad_pad(hctx, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(dwf.data_ptr()),
+                                                 n, h, w, cin, cout, 1, 1, _native.current_stream_ptr())
+            _native.check(rc, "octa_conv3x3_nhwc_wgrad_pad")
+            dw = dwf.view(3, 3, cout, cin).permute(2, 3, 0, 1).to(weight.dtype)
+        return dx, dw
+
+
+USE_FUSED_REFLECT = os.environ.get("OCTA_FUSED_REFLECT", "1") != "0"     # A/B switch (development aid)
+
+
+def conv3x3_reflect(x, weight):
+    """ReflectionPad2d(1) + 3x3 convolution without padding; x [N,H,W,Cin] bf16 with Cin, Cout multiples of 32."""
+    if USE_FUSED_REFLECT and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 32 == 0 and weight.shape[0] % 32 == 0 and weight.shape[1] == x.shape[-1]:
+        return _Conv3x3ReflectNHWC.apply(x, weight)
+    from . import resample
+    return conv3x3(resample.reflect_pad(x, 1, "nhwc"), weight, 1)[:, 1:-1, 1:-1, :]
+
+
 class _Conv3x3C1(torch.autograd.Function):
     """First layer: one input channel (no data gradient: the input is the image)."""
 

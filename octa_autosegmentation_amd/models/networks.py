@@ -375,16 +375,17 @@ class ResnetGenerator(nn.Module):
         self.model = nn.Sequential(*m)
 
     # ---- all 3x3 layers channels-last in bf16 on the MFMA convolution (csrc/conv.hip) ----------------------------------
-    # ReflectionPad2d(1) + Conv2d(3, padding 0) = the zero-padded kernel on the reflect-padded tensor, cropped by one pixel.
+    # ReflectionPad2d(1) + Conv2d(3, padding 0): mfma_conv.conv3x3_reflect (round 3; rounds 1-2 ran the zero-padded kernel on a
+    # reflect-padded copy and cropped the result by one pixel).
     # Every 3x3 convolution is followed by InstanceNorm WITHOUT affine, which subtracts the convolution bias again: it is
     # not added here (its gradient is identically zero in the reference too).
     @staticmethod
     def _resblock_nhwc(blk, x):
         from . import mfma_conv as mc
         c1, n1, c2, n2 = blk.conv_block[1], blk.conv_block[2], blk.conv_block[5], blk.conv_block[6]
-        h = mc.conv3x3(resample.reflect_pad(x, 1, "nhwc"), c1.weight, 1)[:, 1:-1, 1:-1, :]
+        h = mc.conv3x3_reflect(x, c1.weight)                                      # reflection fused into the convolution's halo fetch
         h = mc.instance_norm_leaky_relu_nhwc(h, None, None, 0.0, n1.eps)          # InstanceNorm + ReLU
-        h = mc.conv3x3(resample.reflect_pad(h, 1, "nhwc"), c2.weight, 1)[:, 1:-1, 1:-1, :]
+        h = mc.conv3x3_reflect(h, c2.weight)
         h = mc.instance_norm_leaky_relu_nhwc(h, None, None, 1.0, n2.eps)          # InstanceNorm, no activation
         return x + h
 

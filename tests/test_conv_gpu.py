@@ -59,6 +59,44 @@ def test_data_gradient_matches_torch(hip_lib_built, n, h, w, cin, cout, stride):
     _check(got, want)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 76, 76, 64, 64), (1, 37, 45, 32, 64), (1, 19, 23, 64, 32), (1, 210, 40, 64, 64), (1, 8, 9, 128, 128)])
+def test_reflection_fused_convolution_matches_torch(hip_lib_built, n, h, w, cin, cout):
+    """ReflectionPad2d(1) + Conv2d(3, padding 0) of the generator's ResNet blocks (models/networks.py:151-176) with the reflection
+    fused into the halo fetch of the forward and weight-gradient kernels (octa_conv3x3_nhwc_fwd_pad / _wgrad_pad) and the data gradient
+    as the full convolution folded by the reflection's adjoint: output, input gradient and weight gradient against torch fp32 on the
+    same bf16-rounded operands; and against the unfused composition (padded copy + zero-padded kernel + crop)."""
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.models import mfma_conv
+    g = torch.Generator(device="cuda").manual_seed(11 * h + cin)
+    x0 = torch.randn(n, h, w, cin, device="cuda", generator=g).to(torch.bfloat16)
+    wt0 = (torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (3.0 * cin ** 0.5)).to(torch.bfloat16)
+    dy = torch.randn(n, h, w, cout, device="cuda", generator=g).to(torch.bfloat16)
+    xr = x0.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = wt0.float().requires_grad_(True)
+    yr = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    x = x0.clone().requires_grad_(True)
+    wt = wt0.float().requires_grad_(True)
+    y = mfma_conv.conv3x3_reflect(x, wt)
+    assert y.shape == (n, h, w, cout)
+    y.backward(dy)
+    _check(y.detach(), yr.detach().permute(0, 2, 3, 1))
+    # the border pixels' gradient is rounded to bf16 twice (the full convolution's output, then the fold): 2^-7 of the tensor scale
+    want_dx = xr.grad.permute(0, 2, 3, 1)
+    assert (x.grad.float() - want_dx).abs().max().item() <= want_dx.abs().max().item() * 2.0 ** -7, ((x.grad.float() - want_dx).abs().max().item(), want_dx.abs().max().item())
+    assert (x.grad.float() - want_dx)[:, 2:-2, 2:-2].abs().max().item() <= want_dx.abs().max().item() * 2.0 ** -8 + 1e-6      # interior: one rounding
+    rel = (wt.grad - wr.grad).abs().max().item() / wr.grad.abs().max().item()
+    assert rel < 2e-3, rel
+    # the unfused composition gives the same bf16 values up to the summation order
+    old, mfma_conv.USE_FUSED_REFLECT = mfma_conv.USE_FUSED_REFLECT, False
+    try:
+        y2 = mfma_conv.conv3x3_reflect(x0, wt0.float())
+    finally:
+        mfma_conv.USE_FUSED_REFLECT = old
+    assert (y2.float() - y.detach().float()).abs().max().item() <= 2.0 ** -6 * yr.abs().max().item()
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [(1, 16, 32, 32, 32), (2, 24, 40, 64, 64), (1, 37, 45, 64, 32), (2, 19, 70, 32, 64), (1, 8, 32, 128, 128)])
 def test_weight_gradient_matches_torch(hip_lib_built, n, h, w, cin, cout):
     import torch

@@ -239,13 +239,16 @@ def test_translation_transform_from_a_checkpoint_file_runs_the_mfma_generator(ga
     g = torch.Generator().manual_seed(0)
     imgs = [torch.rand(1, 304, 304, generator=g).cuda() for _ in range(4)]
     from octa_autosegmentation_amd.models import mfma_conv
-    calls, orig = [], mfma_conv.conv3x3
+    calls, orig, orig_r = [], mfma_conv.conv3x3, mfma_conv.conv3x3_reflect
     mfma_conv.conv3x3 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    mfma_conv.conv3x3_reflect = lambda *a, **k: (calls.append(2), orig_r(*a, **k))[1]
     try:
         batched = t.batch_apply([{"image": im} for im in imgs])
     finally:
-        mfma_conv.conv3x3 = orig
-    assert len(calls) >= 20          # 2 down + 18 residual + 2 up 3x3 stages went through the MFMA convolution, once for the mini-batch
+        mfma_conv.conv3x3, mfma_conv.conv3x3_reflect = orig, orig_r
+    # 2 down + 2 up 3x3 stages and the 18 convolutions of the residual blocks (reflection fused into their halo fetch) went through the
+    # MFMA convolution, once for the mini-batch
+    assert calls.count(2) == 18 and len(calls) >= 22
     single = [t({"image": im})["image"] for im in imgs]
     cpu = networks.resnetGenerator9()
     cpu.load_state_dict(load_checkpoint_file(path, "cpu")["model"])
