@@ -36,12 +36,35 @@ template <> __device__ __forceinline__ void st<bf16_t>(bf16_t *p, float v) {   /
     *p = (bf16_t)(u >> 16);
 }
 
+// V elements per thread: 1, or 8 bf16 channels of an NHWC tensor as one 16-byte access (C % 8 == 0; round 3: the scalar form moved
+// 2 bytes per lane and spent its time in address arithmetic -- blur_down_bwd 230 us per launch in the GAN-seg step)
+template <class T, int V> __device__ __forceinline__ void ldv(const T *p, float (&o)[V]) {
+    if constexpr (V == 1) o[0] = ld(p);
+    else {
+        const uint4 u = *reinterpret_cast<const uint4 *>(p);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { o[2 * k] = __uint_as_float(w[k] << 16); o[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+    }
+}
+template <class T, int V> __device__ __forceinline__ void stv(T *p, const float (&v)[V]) {
+    if constexpr (V == 1) st(p, v[0]);
+    else {
+        bf16_t h[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) st(&h[k], v[k]);
+        *reinterpret_cast<uint4 *>(p) = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+    }
+}
+
 __device__ __forceinline__ int refl(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * (n - 1) - p : p); }
 
 struct Idx { int b, y, x, c; };
-__device__ __forceinline__ Idx split(long long i, int Hh, int Ww, int C) {
+// i enumerates (b, y, x, c / V); .c is the first channel of the thread's group
+template <int V> __device__ __forceinline__ Idx split(long long i, int Hh, int Ww, int C) {
     Idx r;
-    r.c = (int)(i % C); i /= C;
+    const int CV = C / V;
+    r.c = (int)(i % CV) * V; i /= CV;
     r.x = (int)(i % Ww); i /= Ww;
     r.y = (int)(i % Hh);
     r.b = (int)(i / Hh);
@@ -49,13 +72,15 @@ __device__ __forceinline__ Idx split(long long i, int Hh, int Ww, int C) {
 }
 
 // ---- reflection pad -------------------------------------------------------------------------------------------------
-template <class T>
+template <class T, int V>
 __global__ void __launch_bounds__(256) reflect_pad_fwd_kernel(const T *__restrict__ in, T *__restrict__ out, int H, int W, int C, int pad, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const Idx o = split(i, H + 2 * pad, W + 2 * pad, C);
+    const Idx o = split<V>(i, H + 2 * pad, W + 2 * pad, C);
     const int y = refl(o.y - pad, H), x = refl(o.x - pad, W);
-    out[i] = in[(((long long)o.b * H + y) * W + x) * C + o.c];
+    const T *src = in + (((long long)o.b * H + y) * W + x) * C + o.c;
+    if constexpr (V == 1) out[i] = *src;
+    else *reinterpret_cast<uint4 *>(out + i * V) = *reinterpret_cast<const uint4 *>(src);
 }
 
 // Padded positions that read source index r: r + pad itself, the mirror across the low border (r in 1..pad) and the
@@ -68,36 +93,52 @@ __device__ __forceinline__ int pad_sources(int r, int n, int pad, int *p) {
     return k;
 }
 
-template <class T>
+template <class T, int V>
 __global__ void __launch_bounds__(256) reflect_pad_bwd_kernel(const T *__restrict__ g, T *__restrict__ dx, int H, int W, int C, int pad, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const Idx o = split(i, H, W, C);
+    const Idx o = split<V>(i, H, W, C);
     int py[3], px[3];
     const int ny = pad_sources(o.y, H, pad, py), nx = pad_sources(o.x, W, pad, px);
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    float acc = 0.f;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) acc[v] = 0.f;
     for (int a = 0; a < ny; ++a)
-        for (int b = 0; b < nx; ++b) acc += ld(g + (((long long)o.b * Hp + py[a]) * Wp + px[b]) * C + o.c);
-    st(dx + i, acc);
+        for (int b = 0; b < nx; ++b) {
+            float t[V];
+            ldv<T, V>(g + (((long long)o.b * Hp + py[a]) * Wp + px[b]) * C + o.c, t);
+#pragma unroll
+            for (int v = 0; v < V; v++) acc[v] += t[v];
+        }
+    stv<T, V>(dx + i * V, acc);
 }
 
 // ---- blur + stride 2 ------------------------------------------------------------------------------------------------
-template <class T>
+template <class T, int V>
 __global__ void __launch_bounds__(256) blur_down_fwd_kernel(const T *__restrict__ in, T *__restrict__ out, int H, int W, int C, int Ho, int Wo, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const Idx o = split(i, Ho, Wo, C);
+    const Idx o = split<V>(i, Ho, Wo, C);
     const T *img = in + (long long)o.b * H * W * C + o.c;
     int ys[3], xs[3];
     for (int t = 0; t < 3; ++t) { ys[t] = refl(2 * o.y + t - 1, H); xs[t] = refl(2 * o.x + t - 1, W); }
-    float acc = 0.f;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) acc[v] = 0.f;
     for (int a = 0; a < 3; ++a) {
         const T *row = img + (long long)ys[a] * W * C;
-        const float r = ld(row + (long long)xs[0] * C) + 2.f * ld(row + (long long)xs[1] * C) + ld(row + (long long)xs[2] * C);
-        acc += (a == 1 ? 2.f : 1.f) * r;
+        float r0[V], r1[V], r2[V];
+        ldv<T, V>(row + (long long)xs[0] * C, r0); ldv<T, V>(row + (long long)xs[1] * C, r1); ldv<T, V>(row + (long long)xs[2] * C, r2);
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const float r = r0[v] + 2.f * r1[v] + r2[v];
+            acc[v] += (a == 1 ? 2.f : 1.f) * r;
+        }
     }
-    st(out + i, acc * (1.f / 16.f));
+#pragma unroll
+    for (int v = 0; v < V; v++) acc[v] *= (1.f / 16.f);
+    stv<T, V>(out + i * V, acc);
 }
 
 // Outputs (index, weight*4) whose taps land on source index r of an axis of length n (no of outputs: no).
@@ -112,36 +153,51 @@ __device__ __forceinline__ int down_taps(int r, int n, int no, int *idx, float *
     return k;
 }
 
-template <class T>
+template <class T, int V>
 __global__ void __launch_bounds__(256) blur_down_bwd_kernel(const T *__restrict__ g, T *__restrict__ dx, int H, int W, int C, int Ho, int Wo, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const Idx o = split(i, H, W, C);
+    const Idx o = split<V>(i, H, W, C);
     int iy[9], ix[9];
     float wy[9], wx[9];
     const int ny = down_taps(o.y, H, Ho, iy, wy), nx = down_taps(o.x, W, Wo, ix, wx);
     const T *gi = g + (long long)o.b * Ho * Wo * C + o.c;
-    float acc = 0.f;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) acc[v] = 0.f;
     for (int a = 0; a < ny; ++a) {
-        float r = 0.f;
-        for (int b = 0; b < nx; ++b) r += wx[b] * ld(gi + ((long long)iy[a] * Wo + ix[b]) * C);
-        acc += wy[a] * r;
+        float r[V];
+#pragma unroll
+        for (int v = 0; v < V; v++) r[v] = 0.f;
+        for (int b = 0; b < nx; ++b) {
+            float t[V];
+            ldv<T, V>(gi + ((long long)iy[a] * Wo + ix[b]) * C, t);
+#pragma unroll
+            for (int v = 0; v < V; v++) r[v] += wx[b] * t[v];
+        }
+#pragma unroll
+        for (int v = 0; v < V; v++) acc[v] += wy[a] * r[v];
     }
-    st(dx + i, acc * (1.f / 16.f));
+#pragma unroll
+    for (int v = 0; v < V; v++) acc[v] *= (1.f / 16.f);
+    stv<T, V>(dx + i * V, acc);
 }
 
 // ---- x2 upsampling with the [1 3 3 1] filter ------------------------------------------------------------------------
-template <class T>
+template <class T, int V>
 __global__ void __launch_bounds__(256) blur_up_fwd_kernel(const T *__restrict__ in, T *__restrict__ out, int H, int W, int C, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const Idx o = split(i, 2 * H, 2 * W, C);
+    const Idx o = split<V>(i, 2 * H, 2 * W, C);
     const int my = o.y >> 1, mx = o.x >> 1;
     const int ny = (o.y & 1) ? min(my + 1, H - 1) : max(my - 1, 0), nx = (o.x & 1) ? min(mx + 1, W - 1) : max(mx - 1, 0);
     const T *img = in + (long long)o.b * H * W * C + o.c;
-    const float a = ld(img + ((long long)my * W + mx) * C), b = ld(img + ((long long)my * W + nx) * C);
-    const float c = ld(img + ((long long)ny * W + mx) * C), d = ld(img + ((long long)ny * W + nx) * C);
-    st(out + i, (3.f * (3.f * a + b) + (3.f * c + d)) * (1.f / 16.f));
+    float a[V], b[V], c[V], d[V], r[V];
+    ldv<T, V>(img + ((long long)my * W + mx) * C, a); ldv<T, V>(img + ((long long)my * W + nx) * C, b);
+    ldv<T, V>(img + ((long long)ny * W + mx) * C, c); ldv<T, V>(img + ((long long)ny * W + nx) * C, d);
+#pragma unroll
+    for (int v = 0; v < V; v++) r[v] = (3.f * (3.f * a[v] + b[v]) + (3.f * c[v] + d[v])) * (1.f / 16.f);
+    stv<T, V>(out + i * V, r);
 }
 
 __device__ __forceinline__ int up_taps(int r, int n, int *idx, float *w) {
@@ -153,23 +209,35 @@ __device__ __forceinline__ int up_taps(int r, int n, int *idx, float *w) {
     return k;
 }
 
-template <class T>
+template <class T, int V>
 __global__ void __launch_bounds__(256) blur_up_bwd_kernel(const T *__restrict__ g, T *__restrict__ dx, int H, int W, int C, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const Idx o = split(i, H, W, C);
+    const Idx o = split<V>(i, H, W, C);
     int iy[4], ix[4];
     float wy[4], wx[4];
     up_taps(o.y, H, iy, wy);
     up_taps(o.x, W, ix, wx);
     const T *gi = g + (long long)o.b * 4 * H * W * C + o.c;
-    float acc = 0.f;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) acc[v] = 0.f;
     for (int a = 0; a < 4; ++a) {
-        float r = 0.f;
-        for (int b = 0; b < 4; ++b) r += wx[b] * ld(gi + ((long long)iy[a] * 2 * W + ix[b]) * C);
-        acc += wy[a] * r;
+        float r[V];
+#pragma unroll
+        for (int v = 0; v < V; v++) r[v] = 0.f;
+        for (int b = 0; b < 4; ++b) {
+            float t[V];
+            ldv<T, V>(gi + ((long long)iy[a] * 2 * W + ix[b]) * C, t);
+#pragma unroll
+            for (int v = 0; v < V; v++) r[v] += wx[b] * t[v];
+        }
+#pragma unroll
+        for (int v = 0; v < V; v++) acc[v] += wy[a] * r[v];
     }
-    st(dx + i, acc * (1.f / 16.f));
+#pragma unroll
+    for (int v = 0; v < V; v++) acc[v] *= (1.f / 16.f);
+    stv<T, V>(dx + i * V, acc);
 }
 
 inline unsigned blocks(long long total) { return (unsigned)((total + 255) / 256); }
@@ -184,12 +252,14 @@ bool bad(octa_ctx *ctx, const void *a, const void *b, int dtype, int B, int H, i
 
 }  // namespace
 
+// TOTAL = number of ELEMENTS; the bf16 NHWC form with C % 8 == 0 runs one thread per 8 channels
 #define OCTA_BLUR_LAUNCH(KERNEL, TOTAL, ...)                                                                                    \
     do {                                                                                                                        \
         OCTA_HIP_CHECK(hipSetDevice(ctx->device));                                                                              \
         if ((TOTAL) > 0x7fffffffLL * 256) { octa::set_error("blur: tensor too large"); return -2; }                             \
-        if (dtype == 0) hipLaunchKernelGGL(KERNEL<float>, dim3(blocks(TOTAL)), dim3(256), 0, (hipStream_t)stream, static_cast<const float *>(d_in), static_cast<float *>(d_out), __VA_ARGS__, (long long)(TOTAL)); \
-        else hipLaunchKernelGGL(KERNEL<bf16_t>, dim3(blocks(TOTAL)), dim3(256), 0, (hipStream_t)stream, static_cast<const bf16_t *>(d_in), static_cast<bf16_t *>(d_out), __VA_ARGS__, (long long)(TOTAL)); \
+        if (dtype == 0) hipLaunchKernelGGL((KERNEL<float, 1>), dim3(blocks(TOTAL)), dim3(256), 0, (hipStream_t)stream, static_cast<const float *>(d_in), static_cast<float *>(d_out), __VA_ARGS__, (long long)(TOTAL)); \
+        else if (C % 8 == 0 && ((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 16 == 0)) hipLaunchKernelGGL((KERNEL<bf16_t, 8>), dim3(blocks((TOTAL) / 8)), dim3(256), 0, (hipStream_t)stream, static_cast<const bf16_t *>(d_in), static_cast<bf16_t *>(d_out), __VA_ARGS__, (long long)(TOTAL) / 8); \
+        else hipLaunchKernelGGL((KERNEL<bf16_t, 1>), dim3(blocks(TOTAL)), dim3(256), 0, (hipStream_t)stream, static_cast<const bf16_t *>(d_in), static_cast<bf16_t *>(d_out), __VA_ARGS__, (long long)(TOTAL)); \
         OCTA_HIP_CHECK(hipGetLastError());                                                                                      \
         return 0;                                                                                                               \
     } while (0)

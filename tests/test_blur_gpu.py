@@ -6,7 +6,8 @@ import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(2, 3, 8, 8), (1, 5, 7, 10), (2, 4, 2, 3), (1, 8, 33, 17), (1, 2, 304, 304)]
+SHAPES = [(2, 3, 8, 8), (1, 5, 7, 10), (2, 4, 2, 3), (1, 8, 33, 17), (1, 2, 304, 304),
+          (2, 24, 9, 12)]      # NHWC bf16 with C % 8 == 0 runs the 8-channels-per-thread form (three groups here)
 
 
 def _ref_down(x):
@@ -66,7 +67,7 @@ def test_blur_up_matches_torch(shape, layout, dtype):
     _run(resample.blur_up, _ref_up, shape, layout, dtype)
 
 
-@pytest.mark.parametrize("shape,pad", [((2, 3, 8, 8), 1), ((1, 5, 7, 10), 3), ((2, 4, 2, 3), 1), ((1, 8, 33, 17), 3), ((1, 2, 4, 4), 3),
+@pytest.mark.parametrize("shape,pad", [((2, 3, 8, 8), 1), ((1, 5, 7, 10), 3), ((2, 4, 2, 3), 1), ((1, 8, 33, 17), 3), ((1, 2, 4, 4), 3), ((2, 24, 9, 12), 1),
                                        ((1, 2, 304, 304), 3)])
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
