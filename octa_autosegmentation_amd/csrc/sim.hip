@@ -424,7 +424,10 @@ __device__ inline int uniform_err(const Blk &b, const SimArrays &A) {
 }
 
 // every iteration of ONE sample (or what is left of them after a park), by one workgroup
-__device__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s, const Blk &b) {
+__device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s_in, const Blk &b) {     // inlined: B stays kernel arguments (scalar registers)
+    // wave-uniform by construction (the work queue hands one sample to the whole workgroup); saying so lets the compiler keep the
+    // sample's ~40 array base pointers (SimArrays) in scalar registers instead of 80 vector registers
+    const int s = __builtin_amdgcn_readfirstlane(s_in);
     SimArrays A = sample_arrays(B, s);
     int *req_n = b.coll() + 96;
     BifRequest *reqs = M.reqs + (size_t)s * REQ_PER_SAMPLE;
@@ -439,9 +442,9 @@ __device__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s, c
         if (A.sc->t_begin == 0) A.sc->t_begin = t_kernel;
     }
     b.sync();
-    const int it0 = uni[0];
-    int stage = uni[1];
-    const int skip = uni[2];
+    const int it0 = OCTA_UNI(uni[0]);
+    int stage = OCTA_UNI(uni[1]);
+    const int skip = OCTA_UNI(uni[2]);
     b.sync();
     int parked_at = -1, parked_stage = 0;
     for (int it = it0; it <= n_iter && !skip; it++) {
@@ -525,7 +528,9 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
     while (true) {
         if (b.tid == 0) *next = atomicAdd(B.next_sample, 1);
         b.sync();
-        const int s = *next;
+        // wave-uniform by construction; saying so keeps the sample's ~40 array base pointers (SimArrays) in scalar registers -- as
+        // vector values they were 80 registers of pressure and the main source of the kernel's scratch traffic (716 scratch accesses)
+        const int s = __builtin_amdgcn_readfirstlane(*next);
         b.sync();
         if (s >= B.n_samples) break;
         Blk bs = b;

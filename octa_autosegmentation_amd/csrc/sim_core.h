@@ -172,6 +172,17 @@ struct SimArrays {
     double *nkap[2];   // [NCAP]
     int *npar[2], *nch0[2], *nch1[2];  // [NCAP]
     unsigned char *nnch[2], *nact[2];  // [NCAP]
+    // forest f's arrays by SELECTION, not by indexing: a run-time index into these pointer pairs made the compiler keep the whole
+    // struct in private (scratch) memory -- every use of a base pointer in a phase was a scratch load (716 of them in the
+    // persistent kernel) -- while a select keeps the struct in registers
+    OCTA_HD double *npos_of(int f) const { return f ? npos[1] : npos[0]; }
+    OCTA_HD double *nrad_of(int f) const { return f ? nrad[1] : nrad[0]; }
+    OCTA_HD double *nkap_of(int f) const { return f ? nkap[1] : nkap[0]; }
+    OCTA_HD int *npar_of(int f) const { return f ? npar[1] : npar[0]; }
+    OCTA_HD int *nch0_of(int f) const { return f ? nch0[1] : nch0[0]; }
+    OCTA_HD int *nch1_of(int f) const { return f ? nch1[1] : nch1[0]; }
+    OCTA_HD unsigned char *nnch_of(int f) const { return f ? nnch[1] : nnch[0]; }
+    OCTA_HD unsigned char *nact_of(int f) const { return f ? nact[1] : nact[0]; }
     double *oxy;       // [OCAP*3]
     double *co2;       // [CCAP*3]
     const double *cand;  // [n_max][3] candidate sinks of the CURRENT iteration
@@ -200,6 +211,16 @@ struct SimArrays {
 };
 
 // ------------------------------------------------------------------ execution abstraction
+// A value every lane of the wave holds alike (read from one address after a barrier, a block total ...): telling the compiler keeps it
+// -- and everything derived from it: loop bounds, base pointers, per-iteration parameters -- in scalar registers. Round 3 measured
+// -10 % per-sample device time from the sample index alone (its ~40 array base pointers were 80 vector registers and the main source
+// of register spills).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OCTA_UNI(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define OCTA_UNI(x) (x)
+#endif
+
 struct Blk {
     int tid, nth;
     unsigned char *smem;  // LDS (device) or heap (host emulation); first 2 KiB reserved for collectives
@@ -234,7 +255,7 @@ OCTA_HD inline int blk_scan(const Blk &b, int v, int *excl) {
     }
     b.sync();
     *excl = sh[wv] + inc - v;
-    int tot = sh[64];
+    int tot = OCTA_UNI(sh[64]);
     return tot;
 #else
     (void)b;
@@ -1181,9 +1202,9 @@ struct WalkRec { int nch, c0, c1, cg; double k; };
 OCTA_HD inline WalkRec walk_load(const SimArrays &A, int f, int id, bool want_cg) {
     WalkRec r;
     const int j = id < 0 ? 0 : id;
-    r.nch = A.nnch[f][j]; r.c0 = A.nch0[f][j]; r.c1 = A.nch1[f][j];
+    r.nch = A.nnch_of(f)[j]; r.c0 = A.nch0_of(f)[j]; r.c1 = A.nch1_of(f)[j];
     r.cg = want_cg ? A.child_group[j] : 0;
-    r.k = A.nkap[f][j];
+    r.k = A.nkap_of(f)[j];
     return r;
 }
 OCTA_HD inline int walk_parent(const SeqLds &L, int id) {
@@ -1502,12 +1523,12 @@ OCTA_HD inline int seq_add_node(const SimArrays &A, int f, int &n_nodes, V3 p, d
     int id = n_nodes;
     if (id >= NCAP) { atomic_or_int(&A.sc->err, ERR_NODE_CAP); return -1; }
     n_nodes = id + 1;
-    st3(A.npos[f] + 3 * id, p);
-    A.nrad[f][id] = r; A.nkap[f][id] = kappa; A.npar[f][id] = parent;   // L.rad IS A.nrad[f]
+    st3(A.npos_of(f) + 3 * id, p);
+    A.nrad_of(f)[id] = r; A.nkap_of(f)[id] = kappa; A.npar_of(f)[id] = parent;   // L.rad IS A.nrad_of(f)
     L.par[id] = (idx_t)parent;
-    A.nch0[f][id] = -1; A.nch1[f][id] = -1; A.nnch[f][id] = 0; A.nact[f][id] = 1;
-    if (parent_nch == 0) A.nch0[f][parent] = id; else if (parent_nch == 1) A.nch1[f][parent] = id;
-    A.nnch[f][parent] = (unsigned char)(parent_nch + 1);
+    A.nch0_of(f)[id] = -1; A.nch1_of(f)[id] = -1; A.nnch_of(f)[id] = 0; A.nact_of(f)[id] = 1;
+    if (parent_nch == 0) A.nch0_of(f)[parent] = id; else if (parent_nch == 1) A.nch1_of(f)[parent] = id;
+    A.nnch_of(f)[parent] = (unsigned char)(parent_nch + 1);
     return id;
 }
 
@@ -1515,14 +1536,14 @@ OCTA_HD inline int add_node(const SimArrays &A, int f, V3 p, double r, int paren
     int id = A.sc->n_nodes[f];
     if (id >= NCAP) { atomic_or_int(&A.sc->err, ERR_NODE_CAP); return -1; }
     A.sc->n_nodes[f] = id + 1;
-    st3(A.npos[f] + 3 * id, p);
-    A.nrad[f][id] = r; A.nkap[f][id] = kappa; A.npar[f][id] = parent;
+    st3(A.npos_of(f) + 3 * id, p);
+    A.nrad_of(f)[id] = r; A.nkap_of(f)[id] = kappa; A.npar_of(f)[id] = parent;
     if (rad_mirror) rad_mirror[id] = r;
-    A.nch0[f][id] = -1; A.nch1[f][id] = -1; A.nnch[f][id] = 0; A.nact[f][id] = 1;
+    A.nch0_of(f)[id] = -1; A.nch1_of(f)[id] = -1; A.nnch_of(f)[id] = 0; A.nact_of(f)[id] = 1;
     if (parent >= 0) {
-        int c = A.nnch[f][parent];
-        if (c == 0) A.nch0[f][parent] = id; else if (c == 1) A.nch1[f][parent] = id;
-        A.nnch[f][parent] = (unsigned char)(c + 1);
+        int c = A.nnch_of(f)[parent];
+        if (c == 0) A.nch0_of(f)[parent] = id; else if (c == 1) A.nch1_of(f)[parent] = id;
+        A.nnch_of(f)[parent] = (unsigned char)(c + 1);
     }
     return id;
 }
@@ -1571,8 +1592,8 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     //    the inverted form -- grid over the <= N candidates, every node and sink visiting the cells around itself -- which writes no
     //    cell-ordered coordinates of the big point sets, but evaluates every live candidate against every node in range: 23 + 14 ms per
     //    sample against 14 + 9 ms; the inverted form is kept where the queries are few AND every hit is needed: phase_satisfy_art step 3.)
-    const int n_art = sc->n_nodes[0];
-    const int n_oxy = sc->n_oxy;
+    const int n_art = OCTA_UNI(sc->n_nodes[0]);
+    const int n_oxy = OCTA_UNI(sc->n_oxy);
     unsigned char *okf = A.removed;  // per valid candidate
     double *oxd = A.tmp_dbl;         // oxygen distance per arterial node
     for (int i = b.tid; i < n_art; i += b.nth) oxd[i] = oxygen_distance(A.nrad[0][i], C.ps);
@@ -1675,22 +1696,22 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
 // ------------------------------------------------------------------ phase: nearest active node + dict order
 OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const double *att, int n_att, double delta) {
     SampleScalars *sc = A.sc;
-    const int n_nodes = sc->n_nodes[f];
+    const int n_nodes = OCTA_UNI(sc->n_nodes[f]);
     // active node list (ascending id) and first_att reset
     int n_act = 0;
     {
         const int chunk = (n_nodes + b.nth - 1) / b.nth;
         const int i0 = b.tid * chunk, i1 = (i0 + chunk < n_nodes) ? i0 + chunk : n_nodes;
         int local = 0;
-        for (int i = i0; i < i1; i++) { A.first_att[i] = 0x7fffffff; local += A.nact[f][i] ? 1 : 0; }
+        for (int i = i0; i < i1; i++) { A.first_att[i] = 0x7fffffff; local += A.nact_of(f)[i] ? 1 : 0; }
         int ex;
         n_act = blk_scan(b, local, &ex);
         int run = ex;
-        for (int i = i0; i < i1; i++) if (A.nact[f][i]) A.act_list[run++] = i;
+        for (int i = i0; i < i1; i++) if (A.nact_of(f)[i]) A.act_list[run++] = i;
     }
     b.sync();
     {
-        Grid G = grid_build(b, A, A.npos[f], A.act_list, n_act, delta);
+        Grid G = grid_build(b, A, A.npos_of(f), A.act_list, n_act, delta);
         for (int a = b.tid; a < n_att; a += b.nth) {
             V3 p = ld3(att + 3 * a);
             double bd = INFINITY;
@@ -1790,8 +1811,8 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     const int f = G.f, id = A.gnode[g];
     const double kappa = G.P->kappa, r = G.C->r, gamma = G.gamma, omega = G.P->omega, d = G.P->d;
     R.type = 3; R.grow = 0; R.draw = 0; R.req = -1; R.node = id;
-    const V3 pos = ld3(A.npos[f] + 3 * id);
-    const int ch = A.nch0[f][id];
+    const V3 pos = ld3(A.npos_of(f) + 3 * id);
+    const int ch = A.nch0_of(f)[id];
     const double r1 = G.rad[ch], r2 = r;
     R.r1_used = r1;
     R.child = (idx_t)ch;
@@ -1801,8 +1822,8 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     double phi1 = acos((rp4 + gpow(r1, 4.0) - gpow(r2, 4.0)) / (2 * rp2 * gpow(r1, 2.0))) * rad2deg();
     // phi_2 and the rotation built from it reach the node position (phi_1 only enters angle windows): glibc's values (glibc_trig.h)
     double phi2 = pos_acos((rp4 + gpow(r2, 4.0) - gpow(r1, 4.0)) / (2 * rp2 * gpow(r2, 2.0))) * rad2deg();
-    V3 dist_seg = sub(ld3(A.npos[f] + 3 * ch), pos);
-    V3 prox_seg = sub(pos, ld3(A.npos[f] + 3 * A.npar[f][id]));
+    V3 dist_seg = sub(ld3(A.npos_of(f) + 3 * ch), pos);
+    V3 prox_seg = sub(pos, ld3(A.npos_of(f) + 3 * A.npar_of(f)[id]));
     double nd = norm3(dist_seg), npx = norm3(prox_seg);
     double lo = phi1 + phi2 - gamma / 2, hi = phi1 + phi2 + gamma / 2, pl = phi2 + gamma / 2;
     V3 avg = v3(0, 0, 0);
@@ -1868,8 +1889,8 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
     const int f = G.f, id = A.gnode[g];
     const double r = G.C->r, gamma = G.gamma, omega = G.P->omega, d = G.P->d, kappa = G.P->kappa;
     R.type = 0; R.grow = 0; R.draw = 0; R.req = -1; R.node = id; R.r1_used = 0;
-    const V3 pos = ld3(A.npos[f] + 3 * id);
-    V3 v = sub(pos, ld3(A.npos[f] + 3 * A.npar[f][id]));
+    const V3 pos = ld3(A.npos_of(f) + 3 * id);
+    V3 v = sub(pos, ld3(A.npos_of(f) + 3 * A.npar_of(f)[id]));
     double nv = norm3(v);
     double lim = fmax(gamma / 2, 0.0);
     V3 avg = v3(0, 0, 0);
@@ -1941,8 +1962,8 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
 // parallel speculation over all groups of forest f
 OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
                               const double *att, BifRequest *reqs, int *req_count, int req_cap, int sample) {
-    GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, A.nrad[f]};
-    const int ng = A.sc->n_groups[f];
+    GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, A.nrad_of(f)};
+    const int ng = OCTA_UNI(A.sc->n_groups[f]);
     if (b.tid == 0) { A.sc->pass_counter++; A.sc->pass_tag[f] = A.sc->pass_counter; }
     b.sync();
     const int tag = A.sc->pass_tag[f];
@@ -1954,13 +1975,13 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
             Rec R;
             memset(&R, 0, sizeof(R));
             int id = A.gnode[g];
-            int nch = A.nnch[f][id], par = A.npar[f][id];
+            int nch = A.nnch_of(f)[id], par = A.npar_of(f)[id];
             if (nch == 0) eval_leaf(G, g, R, reqs, req_count, req_cap, sample);
             else if (par >= 0 && nch == 1) eval_inter(G, g, R);
             else { R.type = 0; R.node = id; R.req = -1; }
             A.rec[g] = R;
             grows = (R.type == 1) || (R.type == 3 && R.grow);
-            if (R.type == 3) A.child_group[A.nch0[f][id]] = (tag << (GROUP_BITS + 1)) | ((int)R.grow << GROUP_BITS) | g;
+            if (R.type == 3) A.child_group[A.nch0_of(f)[id]] = (tag << (GROUP_BITS + 1)) | ((int)R.grow << GROUP_BITS) | g;
         }
         int ex;
         int tot = blk_scan(b, grows, &ex);
@@ -2060,7 +2081,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     // radius only inside a Murray walk (lane-parallel, one more round trip per 64 ancestors) and when an inter-node is re-speculated;
     // "has this group's child radius changed since the speculation" is answered by the `changed` bitmap the walks keep.
     SeqLds L;
-    L.rad = A.nrad[f];
+    L.rad = A.nrad_of(f);
     constexpr int DEF_WORDS = (NCAP + 31) / 32, CHG_WORDS = (GCAP + 31) / 32;     // the two bitmaps
     L.par = reinterpret_cast<idx_t *>(b.user());
     double *ltab = reinterpret_cast<double *>(b.user() + (((size_t)NCAP * sizeof(idx_t) + 15) & ~(size_t)15));
@@ -2070,9 +2091,9 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     L.deferred = reinterpret_cast<int *>(etab + 256);
     L.changed = L.deferred + DEF_WORDS;
     unsigned char *side_lds = reinterpret_cast<unsigned char *>(L.changed + CHG_WORDS);
-    const int n_before = sc->n_nodes[f];
+    const int n_before = OCTA_UNI(sc->n_nodes[f]);
     for (int i = b.tid; i < n_before; i += b.nth) {
-        int p = A.npar[f][i];
+        int p = A.npar_of(f)[i];
         L.par[i] = p < 0 ? IDX_NONE : (idx_t)p;
     }
     for (int i = b.tid; i < 384; i += b.nth) ltab[i] = octa_gpow::LOG_TAB[i];
@@ -2091,8 +2112,8 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     if (b.tid < (b.nth >= 64 ? 64 : 1)) {
         GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, L.rad};
         G.wave_coop = b.nth >= 64;
-        const int ng = sc->n_groups[f];
-        const int n_grow = sc->n_grow[f];
+        const int ng = OCTA_UNI(sc->n_groups[f]);
+        const int n_grow = OCTA_UNI(sc->n_grow[f]);
         const int tag = sc->pass_tag[f];
         DirtyList D;
         D.v = b.coll() + 128; D.n = 0; D.cap = 256; D.overflow = false;
@@ -2147,7 +2168,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                     seq_add_node(A, f, n_nodes, v3(o[0], o[1], o[2]), C.r, id, 0, P.kappa, L);
                     seq_add_node(A, f, n_nodes, v3(o[3], o[4], o[5]), C.r, id, 1, P.kappa, L);
                     SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def));
-                    A.nact[f][id] = 0;
+                    A.nact_of(f)[id] = 0;
                     n_bif++;
                 } else {
                     seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 0, P.kappa, L);
@@ -2164,7 +2185,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 if (R.thr <= u && !R.ang_gt90) continue;
                 seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 1, P.kappa, L);
                 SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def));
-                A.nact[f][id] = 0;
+                A.nact_of(f)[id] = 0;
             }
             if (D.overflow && !scan_all) { scan_all = true; D.n = 0; }
         }
@@ -2256,8 +2277,8 @@ OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsign
 OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P) {
     const double zext = C.sz;      // every sink passed is_valid_position: 0 <= z < size_z
     SampleScalars *sc = A.sc;
-    const int nb = sc->new_begin[0], ne = sc->new_end[0];
-    const int n_new = ne - nb, n_oxy = sc->n_oxy;
+    const int nb = OCTA_UNI(sc->new_begin[0]), ne = OCTA_UNI(sc->new_end[0]);
+    const int n_new = ne - nb, n_oxy = OCTA_UNI(sc->n_oxy);
     if (n_new <= 0 || n_oxy <= 0) return;
     const double ek = P.eps_k, ek2 = ek * ek;
     long t0 = OCTA_SUBPROF_T0();
@@ -2301,7 +2322,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     //    hundred removed sinks, every venous node visits the cells around itself and flags the sinks within eps_k (same expression,
     //    same operand order; an existence test). Round 2 binned all ~13 k venous nodes per iteration for these few hundred queries.
     {
-        const int n_ven = sc->n_nodes[1];
+        const int n_ven = OCTA_UNI(sc->n_nodes[1]);
         int *rem = A.tmp_int;                 // removed sinks, ascending
         int n_rem = 0;
         {
@@ -2385,7 +2406,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
         }
         b.sync();
         const int mask = ctl2[1];
-        const int n_co2_0 = sc->n_co2;
+        const int n_co2_0 = OCTA_UNI(sc->n_co2);
         int base = 0;
         for (int e0 = 0; e0 <= mask; e0 += b.nth) {
             const int e = e0 + b.tid;
@@ -2436,8 +2457,8 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
 // ------------------------------------------------------------------ phase: CO2 near new venous nodes removed
 OCTA_HD inline void phase_satisfy_ven(const Blk &b, const SimArrays &A, const IterParams &P) {
     SampleScalars *sc = A.sc;
-    const int nb = sc->new_begin[1], ne = sc->new_end[1];
-    const int n_new = ne - nb, n_co2 = sc->n_co2;
+    const int nb = OCTA_UNI(sc->new_begin[1]), ne = OCTA_UNI(sc->new_end[1]);
+    const int n_new = ne - nb, n_co2 = OCTA_UNI(sc->n_co2);
     if (n_new <= 0 || n_co2 <= 0) return;
     const double ek2 = P.eps_k * P.eps_k;
     const double ek = P.eps_k;
