@@ -425,9 +425,18 @@ __device__ inline int uniform_err(const Blk &b, const SimArrays &A) {
 
 // every iteration of ONE sample (or what is left of them after a park), by one workgroup
 __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s_in, const Blk &b) {     // inlined: B stays kernel arguments (scalar registers)
-    // wave-uniform by construction (the work queue hands one sample to the whole workgroup); saying so lets the compiler keep the
-    // sample's ~40 array base pointers (SimArrays) in scalar registers instead of 80 vector registers
+    // The sample index is wave-uniform by construction, and declaring it so (OCTA_SIM_UNIFORM_S: __builtin_amdgcn_readfirstlane) keeps
+    // the sample's ~40 array base pointers in scalar registers: per-sample device time 566 -> 509 ms, 681 -> 770 samples/s. NOT
+    // enabled: with it, 512-sample batches stopped being reproducible -- about one sample run in 3000 converts a few O2 sinks fewer
+    // into CO2 sources in one iteration (16 events in 50 688 sample runs; none in 60 928 without the declaration and none in 40 448
+    // on the previous build; tools/repro_sim_race.py). The phase in which it happens is known (phase_satisfy_art's conversion: the CO2
+    // count right after it is already low), the mechanism is not (not the LDS set replay, not the ordering or caching of the
+    // venous-proximity flags: each ruled out by a build without it). DESIGN.md 4.1.
+#ifdef OCTA_SIM_UNIFORM_S
     const int s = __builtin_amdgcn_readfirstlane(s_in);
+#else
+    const int s = s_in;
+#endif
     SimArrays A = sample_arrays(B, s);
     int *req_n = b.coll() + 96;
     BifRequest *reqs = M.reqs + (size_t)s * REQ_PER_SAMPLE;
@@ -528,9 +537,7 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
     while (true) {
         if (b.tid == 0) *next = atomicAdd(B.next_sample, 1);
         b.sync();
-        // wave-uniform by construction; saying so keeps the sample's ~40 array base pointers (SimArrays) in scalar registers -- as
-        // vector values they were 80 registers of pressure and the main source of the kernel's scratch traffic (716 scratch accesses)
-        const int s = __builtin_amdgcn_readfirstlane(*next);
+        const int s = *next;
         b.sync();
         if (s >= B.n_samples) break;
         Blk bs = b;

@@ -214,7 +214,10 @@ struct SimArrays {
 // A value every lane of the wave holds alike (read from one address after a barrier, a block total ...): telling the compiler keeps it
 // -- and everything derived from it: loop bounds, base pointers, per-iteration parameters -- in scalar registers. Round 3 measured
 // -10 % per-sample device time from the sample index alone (its ~40 array base pointers were 80 vector registers and the main source
-// of register spills).
+// of register spills). ONLY for values that come out of the LDS or out of registers: wrapped around a load from GLOBAL memory through a
+// uniform pointer it lets the compiler use a scalar load, and the scalar cache is not coherent with the vector stores of the same
+// kernel -- the sample's counters (sc->n_oxy ...) annotated this way made 512-sample batches irreproducible (a few samples per launch
+// read a stale count; caught by tools/validate_many.py, bisected on the GPU).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OCTA_UNI(x) __builtin_amdgcn_readfirstlane(x)
 #else
@@ -930,6 +933,8 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
             if (have) flush(q);
             if (hit) rd[q] = 1;
         }
+        int *pend_n = b.coll() + 396, *pend = b.coll() + 420;        // ranges whose exact extrema the whole workgroup measures (below)
+        if (b.tid == 0) *pend_n = 0;
         b.sync();
         KDP(0);
         // split dimension = the first one with the largest spread
@@ -948,7 +953,14 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
             bool sure = true;
             for (int k = 0; k < 3; k++) if (k != d && !(slo[d] > shi[k])) sure = false;
             if (sure) { rd[q] = (signed char)d; continue; }
-            // overlapping intervals (or a degenerate box): the exact extrema of the range decide, as scipy's do
+            // overlapping intervals (or a degenerate box): the exact extrema of the range decide, as scipy's do. A long range is left
+            // to the whole workgroup: the extreme sinks of the list persist over many iterations, so a near-tie of the ROOT range's
+            // x and y spreads (about one sample in 300) used to cost one thread a scan of all ~10^4 sinks in every iteration it lasted
+            // (measured: 128 ms in the slowest sample of a 512-sample launch, i.e. +20 % on the launch)
+            if ((int)re[q] - (int)rs[q] > 256) {
+                const int slot = atomic_add_int(pend_n, 1);
+                if (slot < 64) { pend[slot] = q; rd[q] = (signed char)-2; continue; }
+            }
             double hi3[3] = {0, 0, 0}, lo3[3] = {0, 0, 0};
             for (int i = rs[q]; i < re[q]; i++) {
                 const double *p = pts + 3 * (int)(kv[i] & KD_IDX_MASK);
@@ -963,6 +975,39 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
             rd[q] = (hi3[d] == lo3[d]) ? (signed char)-1 : (signed char)d;
         }
         b.sync();
+        {
+            const int n_pend = OCTA_UNI(*pend_n) < 64 ? OCTA_UNI(*pend_n) : 64;
+            unsigned long long *ex = reinterpret_cast<unsigned long long *>(b.coll() + 400);      // max xyz, min xyz as sortable words
+            for (int t = 0; t < n_pend; t++) {
+                const int q = OCTA_UNI(pend[t]);
+                for (int k = b.tid; k < 6; k += b.nth) ex[k] = k < 3 ? 0ull : ~0ull;
+                b.sync();
+                double hi3[3] = {0, 0, 0}, lo3[3] = {0, 0, 0};
+                bool any = false;
+                for (int i = (int)rs[q] + b.tid; i < (int)re[q]; i += b.nth) {
+                    const double *p = pts + 3 * (int)(kv[i] & KD_IDX_MASK);
+                    for (int k = 0; k < 3; k++) {
+                        if (!any) { hi3[k] = lo3[k] = p[k]; }
+                        else { hi3[k] = hi3[k] > p[k] ? hi3[k] : p[k]; lo3[k] = lo3[k] < p[k] ? lo3[k] : p[k]; }
+                    }
+                    any = true;
+                }
+                if (any)
+                    for (int k = 0; k < 3; k++) { atomic_max_u64(&ex[k], dbl_sortable(hi3[k])); atomic_min_u64(&ex[3 + k], dbl_sortable(lo3[k])); }
+                b.sync();
+                if (b.tid == 0) {
+                    int d = 0;
+                    double size = 0, lo_d = 0, hi_d = 0;
+                    for (int k = 0; k < 3; k++) {
+                        const double hk = dbl_unsortable(ex[k]), lk = dbl_unsortable(ex[3 + k]);
+                        if (k == 0) { hi_d = hk; lo_d = lk; }
+                        if (hk - lk > size) { d = k; size = hk - lk; hi_d = hk; lo_d = lk; }
+                    }
+                    rd[q] = (hi_d == lo_d) ? (signed char)-1 : (signed char)d;
+                }
+                b.sync();
+            }
+        }
         KDP(1);
         // 2. quantised split-dimension keys, element-parallel with the same chunking
         {
@@ -1592,8 +1637,8 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     //    the inverted form -- grid over the <= N candidates, every node and sink visiting the cells around itself -- which writes no
     //    cell-ordered coordinates of the big point sets, but evaluates every live candidate against every node in range: 23 + 14 ms per
     //    sample against 14 + 9 ms; the inverted form is kept where the queries are few AND every hit is needed: phase_satisfy_art step 3.)
-    const int n_art = OCTA_UNI(sc->n_nodes[0]);
-    const int n_oxy = OCTA_UNI(sc->n_oxy);
+    const int n_art = sc->n_nodes[0];
+    const int n_oxy = sc->n_oxy;
     unsigned char *okf = A.removed;  // per valid candidate
     double *oxd = A.tmp_dbl;         // oxygen distance per arterial node
     for (int i = b.tid; i < n_art; i += b.nth) oxd[i] = oxygen_distance(A.nrad[0][i], C.ps);
@@ -1696,7 +1741,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
 // ------------------------------------------------------------------ phase: nearest active node + dict order
 OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const double *att, int n_att, double delta) {
     SampleScalars *sc = A.sc;
-    const int n_nodes = OCTA_UNI(sc->n_nodes[f]);
+    const int n_nodes = sc->n_nodes[f];
     // active node list (ascending id) and first_att reset
     int n_act = 0;
     {
@@ -1963,7 +2008,7 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
 OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
                               const double *att, BifRequest *reqs, int *req_count, int req_cap, int sample) {
     GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, A.nrad_of(f)};
-    const int ng = OCTA_UNI(A.sc->n_groups[f]);
+    const int ng = A.sc->n_groups[f];
     if (b.tid == 0) { A.sc->pass_counter++; A.sc->pass_tag[f] = A.sc->pass_counter; }
     b.sync();
     const int tag = A.sc->pass_tag[f];
@@ -2091,7 +2136,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     L.deferred = reinterpret_cast<int *>(etab + 256);
     L.changed = L.deferred + DEF_WORDS;
     unsigned char *side_lds = reinterpret_cast<unsigned char *>(L.changed + CHG_WORDS);
-    const int n_before = OCTA_UNI(sc->n_nodes[f]);
+    const int n_before = sc->n_nodes[f];
     for (int i = b.tid; i < n_before; i += b.nth) {
         int p = A.npar_of(f)[i];
         L.par[i] = p < 0 ? IDX_NONE : (idx_t)p;
@@ -2112,8 +2157,8 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     if (b.tid < (b.nth >= 64 ? 64 : 1)) {
         GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, L.rad};
         G.wave_coop = b.nth >= 64;
-        const int ng = OCTA_UNI(sc->n_groups[f]);
-        const int n_grow = OCTA_UNI(sc->n_grow[f]);
+        const int ng = sc->n_groups[f];
+        const int n_grow = sc->n_grow[f];
         const int tag = sc->pass_tag[f];
         DirtyList D;
         D.v = b.coll() + 128; D.n = 0; D.cap = 256; D.overflow = false;
@@ -2277,8 +2322,8 @@ OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsign
 OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P) {
     const double zext = C.sz;      // every sink passed is_valid_position: 0 <= z < size_z
     SampleScalars *sc = A.sc;
-    const int nb = OCTA_UNI(sc->new_begin[0]), ne = OCTA_UNI(sc->new_end[0]);
-    const int n_new = ne - nb, n_oxy = OCTA_UNI(sc->n_oxy);
+    const int nb = sc->new_begin[0], ne = sc->new_end[0];
+    const int n_new = ne - nb, n_oxy = sc->n_oxy;
     if (n_new <= 0 || n_oxy <= 0) return;
     const double ek = P.eps_k, ek2 = ek * ek;
     long t0 = OCTA_SUBPROF_T0();
@@ -2322,7 +2367,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     //    hundred removed sinks, every venous node visits the cells around itself and flags the sinks within eps_k (same expression,
     //    same operand order; an existence test). Round 2 binned all ~13 k venous nodes per iteration for these few hundred queries.
     {
-        const int n_ven = OCTA_UNI(sc->n_nodes[1]);
+        const int n_ven = sc->n_nodes[1];
         int *rem = A.tmp_int;                 // removed sinks, ascending
         int n_rem = 0;
         {
@@ -2406,7 +2451,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
         }
         b.sync();
         const int mask = ctl2[1];
-        const int n_co2_0 = OCTA_UNI(sc->n_co2);
+        const int n_co2_0 = sc->n_co2;
         int base = 0;
         for (int e0 = 0; e0 <= mask; e0 += b.nth) {
             const int e = e0 + b.tid;
@@ -2457,8 +2502,8 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
 // ------------------------------------------------------------------ phase: CO2 near new venous nodes removed
 OCTA_HD inline void phase_satisfy_ven(const Blk &b, const SimArrays &A, const IterParams &P) {
     SampleScalars *sc = A.sc;
-    const int nb = OCTA_UNI(sc->new_begin[1]), ne = OCTA_UNI(sc->new_end[1]);
-    const int n_new = ne - nb, n_co2 = OCTA_UNI(sc->n_co2);
+    const int nb = sc->new_begin[1], ne = sc->new_end[1];
+    const int n_new = ne - nb, n_co2 = sc->n_co2;
     if (n_new <= 0 || n_co2 <= 0) return;
     const double ek2 = P.eps_k * P.eps_k;
     const double ek = P.eps_k;

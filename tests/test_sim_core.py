@@ -106,6 +106,22 @@ def test_nth_element_restatement_matches_scipy(core):
         assert (out == cKDTree(pts).indices).all(), (n, k)
 
 
+    # near-ties of the spreads: the single-precision outer boxes cannot order x against y, and the exact extrema of the range decide --
+    # measured by the whole workgroup for ranges above 256 points (round 3). Spreads equal to the last bit (the first dimension
+    # wins, as in scipy), y larger by one ulp, and a slab thin in x and y so that lower levels tie too
+    for n, variant in ((5000, 0), (5000, 1), (9000, 2), (13000, 0)):
+        pts = rng.uniform(0.05, 0.95, (n, 3)) * np.array([1, 1, 0.0131])
+        pts[0, 0], pts[1, 0], pts[2, 1], pts[3, 1] = 0.0, 1.0, 0.0, 1.0                  # both spreads exactly 1
+        if variant == 1:
+            pts[3, 1] = np.nextafter(1.0, 2.0)                                           # y larger by one ulp: dimension 1 must win
+        if variant == 2:
+            pts[:, :2] = 0.5 + (pts[:, :2] - 0.5) * 1e-3                                 # spreads of 1e-3, equal to ~1e-19 relative
+        pts = np.ascontiguousarray(pts)
+        out = np.zeros(n, np.uint16)
+        core.octa_simcore_kd_indices(pts.ctypes.data, n, out.ctypes.data)
+        assert (out == cKDTree(pts).indices).all(), (n, variant)
+
+
 def test_set_emulation_matches_cpython(core):
     rng = np.random.default_rng(5)
     pts = np.ascontiguousarray(rng.uniform(0, 1, (2500, 3)))
