@@ -425,13 +425,16 @@ __device__ inline int uniform_err(const Blk &b, const SimArrays &A) {
 
 // every iteration of ONE sample (or what is left of them after a park), by one workgroup
 __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s_in, const Blk &b) {     // inlined: B stays kernel arguments (scalar registers)
-    // The sample index is wave-uniform by construction, and declaring it so (OCTA_SIM_UNIFORM_S: __builtin_amdgcn_readfirstlane) keeps
-    // the sample's ~40 array base pointers in scalar registers: per-sample device time 566 -> 509 ms, 681 -> 770 samples/s. NOT
-    // enabled: with it, 512-sample batches stopped being reproducible -- about one sample run in 3000 converts a few O2 sinks fewer
-    // into CO2 sources in one iteration (16 events in 50 688 sample runs; none in 60 928 without the declaration and none in 40 448
-    // on the previous build; tools/repro_sim_race.py). The phase in which it happens is known (phase_satisfy_art's conversion: the CO2
-    // count right after it is already low), the mechanism is not (not the LDS set replay, not the ordering or caching of the
-    // venous-proximity flags: each ruled out by a build without it). DESIGN.md 4.1.
+    // The sample index is wave-uniform by construction, and declaring it so (-DOCTA_SIM_UNIFORM_S: __builtin_amdgcn_readfirstlane)
+    // keeps the sample's ~40 array base pointers in scalar registers: per-sample device time 566 -> 509 ms, 681 -> 770 samples/s.
+    // NOT enabled: with it, 512-sample batches stopped being reproducible -- about one sample run in 3000 converts a few O2 sinks
+    // fewer into CO2 sources in one iteration (16-33 events per 50-100 k sample runs, tools/repro_sim_race.py; none in 101 888 as
+    // shipped, none in 40 448 on the previous build). What round 3 established: the CO2 count is already low right after
+    // phase_satisfy_art; in-kernel checks of the venous-proximity flags against a brute-force evaluation, of their reset and of the
+    // kd rank / index mapping never fire while the events keep occurring; the LDS set replay, an extra barrier and cache-bypassing
+    // flag reads change nothing; inlining kd_build as well (no call left in the kernel) does not help; keeping phase_satisfy_art OUT
+    // of line with the uniform index gives 0 events in 60 928 sample runs at 529 ms per sample (that is what the macro builds). The
+    // cause is not understood, so the default stays the form whose addressing is the previous build's. DESIGN.md 4.1.
 #ifdef OCTA_SIM_UNIFORM_S
     const int s = __builtin_amdgcn_readfirstlane(s_in);
 #else

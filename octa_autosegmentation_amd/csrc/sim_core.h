@@ -2319,6 +2319,9 @@ OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsign
 #endif
 
 // ------------------------------------------------------------------ phase: satisfied O2 sinks -> CO2
+#if defined(OCTA_SIM_UNIFORM_S) && defined(__HIP_DEVICE_COMPILE__)
+__attribute__((noinline))        // see run_sample (sim.hip): with the uniform sample index this phase must stay out of line
+#endif
 OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P) {
     const double zext = C.sz;      // every sink passed is_valid_position: 0 <= z < size_z
     SampleScalars *sc = A.sc;
