@@ -12,27 +12,27 @@ import torch
 
 from .. import _native
 
-_PACKS = {}          # id(weight) -> (version, data_ptr, packed tensor)
+_EPOCH = [0]         # bumped by invalidate_packs(): every packed copy made before is stale
 
 
 def invalidate_packs():
     """Weights were rewritten through .data / load_state_dict (no version bump): forget every packed copy."""
-    _PACKS.clear()
+    _EPOCH[0] += 1
 
 
 def _packed(weight, transposed):
-    key = id(weight)
-    hit = _PACKS.get(key)
-    if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
-        return hit[2]
+    """The kernel's weight layout, cached ON the parameter object (epoch, version, storage address, orientation): a cache keyed by
+    id(weight) served a stale copy when a new parameter was given the id and the storage address of a collected one (two DynUNets
+    built one after the other in a test run: logits off by whole units, about one full test run in eight)."""
+    hit = getattr(weight, "_octa_f32_pack", None)
+    if hit is not None and hit[0] == _EPOCH[0] and hit[1] == weight._version and hit[2] == weight.data_ptr() and hit[3] == transposed:
+        return hit[4]
     w = weight.detach().float()
     if transposed:          # [Cin][Cout][k][k] -> [Cin][k*k][Cout]
         p = w.permute(0, 2, 3, 1).reshape(w.shape[0], w.shape[2] * w.shape[3], w.shape[1]).contiguous()
     else:                   # [Cout][Cin][K][K] -> [Cin][K*K][Cout]
         p = w.permute(1, 2, 3, 0).reshape(w.shape[1], w.shape[2] * w.shape[3], w.shape[0]).contiguous()
-    if len(_PACKS) > 512:
-        _PACKS.clear()
-    _PACKS[key] = (weight._version, weight.data_ptr(), p)
+    weight._octa_f32_pack = (_EPOCH[0], weight._version, weight.data_ptr(), transposed, p)
     return p
 
 

@@ -312,3 +312,34 @@ def test_batched_translation_chain_takes_the_per_sample_decisions():
     random.seed(1); np.random.seed(1); torch.manual_seed(1)
     ref = [nob[i] for i in range(3)]
     assert all(torch.equal(a["image"], b["image"]) for a, b in zip(out, ref))
+
+
+def test_f32_weight_pack_cache_cannot_serve_a_collected_parameters_copy():
+    """models/conv_f32.py caches the kernel's weight layout. Keyed by id(weight) + version + storage address it served a STALE copy when
+    a new parameter was given the id and the address of a collected one (two networks built one after the other; found as a flaky
+    full-size logits test). The cache now lives on the parameter object: build, pack and drop parameters in a loop -- CPython and the
+    allocator reuse ids and addresses readily -- and every pack must be the current parameter's."""
+    import gc
+    import torch
+    from octa_autosegmentation_amd.models import conv_f32
+    reused = 0
+    seen = set()
+    for k in range(40):
+        w = torch.nn.Parameter(torch.full((4, 3, 3, 3), float(k)))
+        key = (id(w), w.data_ptr())
+        reused += key in seen
+        seen.add(key)
+        p = conv_f32._packed(w, False)
+        assert p.shape == (3, 9, 4) and float(p.min()) == float(p.max()) == float(k), k
+        pt = conv_f32._packed(w, True)
+        assert pt.shape == (4, 9, 3) and float(pt.min()) == float(k)
+        assert conv_f32._packed(w, False) is not pt            # the orientation is part of the key
+        with torch.no_grad():
+            w.add_(1.0)                                        # version bump: repacked
+        assert float(conv_f32._packed(w, False).max()) == float(k + 1)
+        w.data.fill_(-1.0)                                     # no version bump: callers invalidate
+        conv_f32.invalidate_packs()
+        assert float(conv_f32._packed(w, False).max()) == -1.0
+        del w, p, pt
+        gc.collect()
+    assert reused > 0          # the situation the old cache got wrong did occur in this loop
