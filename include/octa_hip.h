@@ -269,6 +269,13 @@ int octa_conv3x3_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, fl
 int octa_conv2d_f32_nchw(octa_ctx *ctx, const float *d_x, const float *d_wp, const float *d_bias, float *d_y, int N, int Cin, int H, int W,
                          int Cout, int cout_w, int K, int stride, int pad, int Ho, int Wo, int osc, int ooy, int oox, void *stream);
 
+/* torch.nn.ConvTranspose2d(Cin, Cout, 2, 2, bias=False) in fp32, one launch (DynUNet's upsampling: models/networks.py:6 -> MONAI
+ * UnetUpBlock.transp_conv, on the test.py:79 / validate.py fp32 path): d_x [N][Cin][H][W], d_wp the weights packed [Cin][4][Cout]
+ * (tap 2 a + b), d_y [N][Cout][2H][2W] (8-byte aligned), y(co, 2y + a, 2x + b) = sum_ci x(ci, y, x) w(ci, co, a, b). Same numbers as
+ * four octa_conv2d_f32_nchw calls with osc = 2. */
+int octa_convtranspose2x2_f32_nchw(octa_ctx *ctx, const float *d_x, const float *d_wp, float *d_y, int N, int Cin, int H, int W, int Cout,
+                                   void *stream);
+
 /* 4x4 convolution, stride 1, zero padding `pad`, on the same DMA-staged MFMA kernel (KS = 4 instantiation): the inner
  * layers of the 70x70 PatchGAN (models/networks.py:445-500 NLayerDiscriminator: Conv2d(ndf*m, ndf*2m, 4, 1, 1)).
  * d_x [N][H][W][Cin] bf16, d_w [16][Cout][Cin] bf16 (tap 4r+s), d_y [N][H+2pad-3][W+2pad-3][Cout] bf16; Cin, Cout

@@ -66,6 +66,7 @@ SIGNATURES = {
     "octa_sim_geometry": (c_int, [c_int, c_void_p]),
     "octa_sim_is_large": (c_int, [c_void_p]),
     "octa_conv2d_f32_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14 + [c_void_p]),
+    "octa_convtranspose2x2_f32_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_sim_fields": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, ctypes.c_int64, c_void_p]),
     "octa_instnorm_lrelu_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_float, c_void_p]),
     "octa_instnorm_lrelu_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, ctypes.c_float, c_void_p]),

@@ -4,8 +4,8 @@ ConvTranspose2d layers (models/networks.py:6 -> MONAI) compute in fp32 there. Fo
 (`General.amp: false` training) stays on the torch modules.
 
 Weights are re-laid-out once per weight version as [Cin][K*K][Cout] (output channel innermost: the kernel's weight slice loads are
-then contiguous); a 2x2 stride-2 transposed convolution is four 1x1 launches, one per output parity, reading column blocks of ONE
-packed tensor [Cin][4][Cout]."""
+then contiguous); a 2x2 stride-2 transposed convolution is one launch on the packed tensor [Cin][4][Cout]
+(`octa_convtranspose2x2_f32_nchw`)."""
 import ctypes
 
 import torch
@@ -76,6 +76,12 @@ def forward(conv, x):
         k, Cout = conv.kernel_size[0], conv.out_channels
         wp = _packed(conv.weight, True)
         y = torch.empty((N, Cout, H * k, W * k), dtype=torch.float32, device=x.device)
+        if k == 2:          # one launch, both output parities of a row pair written as 8-byte pairs
+            rc = _native.lib().octa_convtranspose2x2_f32_nchw(
+                _native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                N, Cin, H, W, Cout, _native.current_stream_ptr())
+            _native.check(rc, "octa_convtranspose2x2_f32_nchw")
+            return y
         for a in range(k):
             for b in range(k):
                 _launch(x, wp, (a * k + b) * Cout, None, y, Cout, k * k * Cout, 1, 1, 0, H, W, k, a, b)

@@ -19,6 +19,8 @@ def test_conv2d_f32_matches_torch_cpu(hip_lib_built):
         (torch.nn.Conv2d(128, 256, 3, 1, 1, bias=False), (1, 128, 40, 40)),
         (torch.nn.ConvTranspose2d(64, 32, 2, 2, bias=False), (2, 64, 21, 17)),
         (torch.nn.ConvTranspose2d(512, 256, 1, 1, bias=False), (1, 512, 24, 24)),
+        (torch.nn.ConvTranspose2d(24, 20, 2, 2, bias=False), (3, 24, 9, 33)),       # ragged channel block of the one-launch 2x2 kernel
+        (torch.nn.Conv2d(256, 256, 3, 1, 1, bias=False), (1, 256, 152, 152)),       # the narrow (32-channel) variant chosen for CU balance
     ]
     for mod, shape in cases:
         x = torch.randn(*shape)
@@ -31,6 +33,17 @@ def test_conv2d_f32_matches_torch_cpu(hip_lib_built):
         assert got.shape == ref.shape and got.dtype == torch.float32
         scale = ref.abs().max().item()
         assert (got - ref).abs().max().item() <= 2e-6 * scale + 1e-6, (mod, (got - ref).abs().max().item(), scale)
+    # the one-launch 2x2 transposed convolution gives the bits of four 1x1 launches with scattered stores
+    mod = torch.nn.ConvTranspose2d(64, 32, 2, 2, bias=False).cuda()
+    x = torch.randn(2, 64, 21, 17, device="cuda")
+    with torch.no_grad():
+        one = conv_f32.forward(mod, x)
+        wp = conv_f32._packed(mod.weight, True)
+        four = torch.full_like(one, float("nan"))
+        for a in range(2):
+            for b in range(2):
+                conv_f32._launch(x, wp, (a * 2 + b) * 32, None, four, 32, 4 * 32, 1, 1, 0, 21, 17, 2, a, b)
+    assert torch.equal(one, four)
     # a pass that records gradients stays on the torch modules
     m = torch.nn.Conv2d(8, 8, 3, 1, 1).cuda()
     assert not conv_f32.applies(m, torch.randn(1, 8, 8, 8, device="cuda"))
