@@ -28,6 +28,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
+from ..utils.aside import aside, join_aside  # noqa: F401  (re-exported: models use `aside`, the entry points `join_aside`)
 from ..utils.enums import Phase
 from .model_interface_abc import ModelInterface, Output
 

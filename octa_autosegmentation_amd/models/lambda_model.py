@@ -6,7 +6,7 @@ from typing import Any, Callable, Dict, Tuple
 import torch
 
 from ..utils.enums import Phase
-from .base_model_abc import BaseModelABC
+from .base_model_abc import BaseModelABC, aside
 from .losses import get_loss_function_by_name
 from .model_interface_abc import Output
 
@@ -35,6 +35,11 @@ class LambdaModel(BaseModelABC):
         inputs = mini_batch["image"].to(device, non_blocking=True)
         labels = mini_batch["label"].to(device, non_blocking=True) if phase != Phase.TEST else None
         pred = self.model(inputs).squeeze(-1)
+        if phase == Phase.TRAIN:          # the scored sample's post-processing leaves the training stream (base_model_abc.aside)
+            with aside(pred.device, pred, labels):
+                outputs: Output = {"prediction": [post_transformations["prediction"](i) for i in decollate_batch(pred.detach()[0:1])],
+                                   "label": [post_transformations["label"](i) for i in decollate_batch(labels[0:1])]}
+            return outputs, {self.loss_name: self.loss_function(y_pred=pred.float(), y=labels.float())}
         outputs: Output = {"prediction": [post_transformations["prediction"](i) for i in decollate_batch(pred[0:1])]}
         if phase != Phase.TEST:
             outputs["label"] = [post_transformations["label"](i) for i in decollate_batch(labels[0:1])]
@@ -47,7 +52,12 @@ class LambdaModel(BaseModelABC):
         return self.model(input)
 
     def compute_metric(self, outputs: Output, metrics) -> None:
-        metrics(outputs["prediction"], outputs["label"])
+        t = outputs["prediction"][0]
+        if self.training and torch.is_tensor(t):
+            with aside(t.device):
+                metrics(outputs["prediction"], outputs["label"])
+        else:
+            metrics(outputs["prediction"], outputs["label"])
 
     def plot_sample(self, visualizer, mini_batch: Dict[str, Any], outputs: Output, *, suffix: str = "") -> str:
         return visualizer.plot_sample(mini_batch["image"][0], outputs["prediction"][0], outputs["label"][0], suffix=suffix)

@@ -8,6 +8,7 @@ import math
 
 import torch
 
+from .aside import join_aside
 from .enums import Phase
 
 
@@ -29,6 +30,7 @@ class Metric:
         if not self.scores:
             return torch.tensor(float("nan"))
         dev = next((s.device for s in self.scores if s.is_cuda), torch.device("cpu"))
+        join_aside(dev)                  # scores of training steps are computed on the side stream (utils/aside.py)
         v = torch.stack([s.detach().to(dev, torch.float64).reshape(()) for s in self.scores])
         ok = ~torch.isnan(v)
         n = ok.sum()

@@ -48,6 +48,7 @@ def train(args: argparse.Namespace, config: dict):
     from octa_autosegmentation_amd.data.image_dataset import get_dataset, get_post_transformation
     from octa_autosegmentation_amd.models.model import define_model
     from octa_autosegmentation_amd.models.networks import init_weights
+    from octa_autosegmentation_amd.utils.aside import join_aside
     from octa_autosegmentation_amd.utils.enums import Phase
     from octa_autosegmentation_amd.utils.metrics import MetricsManager
     from octa_autosegmentation_amd.utils.visualizer import Visualizer
@@ -125,6 +126,7 @@ def train(args: argparse.Namespace, config: dict):
         n_img = step * train_loader.batch_size * world
         for lr_scheduler in model.lr_schedulers:
             lr_scheduler.step()
+        join_aside(device)                                       # the metric kernels of the epoch (side stream) before their scores are read
         sums = running.cpu().tolist()
         epoch_metrics["loss"] = {f"train_{k}": v / step for k, v in zip(losses.keys(), sums)}
         epoch_metrics["metric"] = metrics.aggregate_and_reset(prefix=Phase.TRAIN)
