@@ -318,10 +318,14 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--inflight", type=int, default=1, help="launches in flight per GPU (each on its own HIP stream)")
+    ap.add_argument("--inflight", type=int, default=2, help="launches in flight per GPU (each on its own HIP stream); with the default --serial-sim only ONE "
+                    "persistent kernel runs at a time and the other launch is being rasterised meanwhile")
     ap.add_argument("--group", type=int, default=4, help="steps (128-sample batches) simulated by ONE launch of the persistent kernel. Round 3: a "
                     "launch of 4 x 128 samples fills the GPU's 512 workgroup slots (two samples per CU) and the rasteriser then has the whole GPU; "
                     "measured on one box: group / inflight 4/1 681, 4/2 644, 2/2 620, 1/4 616, 2/3 567 samples/s (rounds 1-2: 1 step per launch, 4 in flight)")
+    ap.add_argument("--no-serial-sim", dest="serial_sim", action="store_false", help="with --inflight > 1: let the persistent kernels of several launches share the GPU "
+                    "(default: one persistent kernel at a time, a launch's rasterisation overlaps the NEXT launch's kernel and fills its tail; measured on one box, "
+                    "group 4: in flight 1: 725, 2 serial: 744, 3 serial: 739, 2 concurrent: 644 samples/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 counter passes (roofline.traffic then comes from the committed file)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -356,6 +360,7 @@ def main():
     cfg = load_config()
     B = args.batch
     n_fly = max(1, args.inflight)
+    sim_conc = 1 if (args.serial_sim or n_fly == 1) else n_fly          # persistent kernels on the GPU at a time
     G = max(1, args.group)
     # One launch of the persistent kernel simulates G steps (G x B samples; at most one workgroup per CU, workgroups pull samples
     # from a work queue); n_fly such launches are in flight, each with its own simulator state and HIP stream, so that one launch's
@@ -364,6 +369,12 @@ def main():
     sizes = sorted({G} | ({args.warmup % G} if args.warmup % G else set()) | ({args.steps % G} if args.steps % G else set()))
     gens = {g: [pipeline.TripleGenerator(cfg, B * g) for _ in range(n_fly)] for g in sizes}
     streams = [torch.cuda.Stream() for _ in range(n_fly)]
+    if args.serial_sim and n_fly > 1:
+        import threading
+        gate = threading.Lock()
+        for gl in gens.values():
+            for g_ in gl:
+                g_.sim_gate = gate
 
     def launch(slot, first_step, nsteps):
         seeds = np.concatenate([sharding.rank_seeds(rank, i, B) for i in range(first_step, first_step + nsteps)])
@@ -543,7 +554,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: {B}-sample vessel-graph batch (docker/vessel_graph_gen_docker_config.yml, "
                                    f"I=100+150, N=2000) + tree2img rasterise 304x304 image and 1216x1216 label",
-                       "batch_per_gpu": B, "steps_per_launch": G, "launches_in_flight": n_fly, "parallelism": f"sample-sharded x{world}, no collective"},
+                       "batch_per_gpu": B, "steps_per_launch": G, "launches_in_flight": n_fly, "persistent_kernels_at_a_time": sim_conc, "parallelism": f"sample-sharded x{world}, no collective"},
             "parity": "graph CSV text bit-exact with the REFERENCE (imported and run in the build container) on 8 short + 2 full-length fixture "
                       "runs and on 64 further full-length seeds (tests/golden/sim_wide_golden.npz: SHA-256 of the CSV text of seeds 1000-1063; the "
                       "GPU reproduces all 64, tests/test_sim_gpu.py); label / image pixels bit-exact on the reference's fixtures. The oracle follows "
@@ -567,9 +578,10 @@ def main():
                                                   "reach alone on the GPU; this dependency chain, not HBM, is the binding limit"},
                          "rasteriser": raster},
             "kernel_ms_per_launch": {dom_name: launch_ms, "launches_per_step": dom_n / max(args.steps, 1),
-                                     "cu_occupancy_weighted_ms_per_step": launch_ms * (dom_n / max(args.steps, 1)) / n_fly,
-                                     "note": f"a launch covers {G} steps and {n_fly} launches of up to {N_CUS} workgroups share the {N_CUS} CUs, so a launch "
-                                             "outlasts ms_per_step; the weighted figure is the launch duration per step divided by the launches in flight"},
+                                     "cu_occupancy_weighted_ms_per_step": launch_ms * (dom_n / max(args.steps, 1)) / sim_conc,
+                                     "note": f"a launch covers {G} steps; {n_fly} launches are in flight and {sim_conc} persistent kernel(s) run at a time (the other "
+                                             "launch is being rasterised meanwhile); the weighted figure is the launch duration per step divided by the persistent "
+                                             "kernels running at a time"},
             "cu_time": cu_time,
             "slot_cycle": slot_cycle,
             "host_bifurcation_callback_ms_per_step": bif_ms / args.steps,

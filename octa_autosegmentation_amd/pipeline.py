@@ -46,11 +46,20 @@ class TripleGenerator:
             _native.free_ctx(self._ctx)
             self._ctx = None
 
+    sim_gate = None      # optional threading.Lock shared by the generators of a device (bench.py --serial-sim)
+
     def generate(self, seeds, want_label=True):
         """Returns dict(result=SimulationResult, image=uint8 CUDA [B,H,W], label=uint8 CUDA {0,255} [B,1216,1216])."""
         import time
         t0 = time.time()
-        res = self.sim.run(seeds)
+        if self.sim_gate is not None:
+            # several generators in flight, ONE persistent kernel at a time: the next launch starts when this one has left the GPU,
+            # this launch's rasterisation then shares the GPU with it (and fills the tail of the launch before)
+            with self.sim_gate:
+                t0 = time.time()
+                res = self.sim.run(seeds)
+        else:
+            res = self.sim.run(seeds)
         t1 = time.time()
         with _native.use_ctx(self._ctx):
             out = self._render(res, want_label)

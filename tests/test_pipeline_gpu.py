@@ -70,9 +70,12 @@ def test_device_read_back_matches_host_emulation(hip_lib_built):
     assert (got == want).all(), np.nonzero((got != want).any(axis=1))[0][:10]
 
 
-def test_three_steps_in_flight_are_independent(hip_lib_built):
+@pytest.mark.parametrize("gated", [False, True])
+def test_three_steps_in_flight_are_independent(hip_lib_built, gated):
     """bench.py keeps several steps in flight from a thread pool: each thread must get its own scratch context
-    and stream, and every image / label must still be the oracle's."""
+    and stream, and every image / label must still be the oracle's -- with all persistent kernels resident at once and with
+    bench.py's default, one persistent kernel at a time (TripleGenerator.sim_gate) while the other launches are rasterised."""
+    import threading
     import torch
     from concurrent.futures import ThreadPoolExecutor
     from octa_autosegmentation_amd import graph_io, pipeline
@@ -83,6 +86,10 @@ def test_three_steps_in_flight_are_independent(hip_lib_built):
     cfg["Greenhouse"]["modes"][1]["I"] = 8
     B, n_fly = 4, 3
     gens = [pipeline.TripleGenerator(cfg, B) for _ in range(n_fly)]
+    if gated:
+        gate = threading.Lock()
+        for gen in gens:
+            gen.sim_gate = gate
     streams = [torch.cuda.Stream() for _ in range(n_fly)]
     dev = torch.cuda.current_device()
 
