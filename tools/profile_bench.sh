@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
 #   1. --kernel-trace --stats of the default bench command        -> gpurun_out/r03_bench_kernel_stats.csv
-#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, one counter per pass, launches of the default shape (4 x 128 samples, one in flight)
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, one counter per pass, launches of the default shape (4 x 128 samples; two in flight, one persistent kernel at a time)
 #      -> gpurun_out/r03_bench_pmc_summary.csv
 # (counter passes never combined with tracing: see the task's profiling rules)
 set -u
@@ -11,7 +11,24 @@ OUT=gpurun_out
 mkdir -p $OUT
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py --no-cpu-baseline --no-pmc > $OUT/${TAG}_bench_stdout.log 2>&1
 find $OUT/prof_kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
-rm -rf $OUT/prof_kt   # the raw trace is large; only the summary is kept
+# the stats file averages launches of every size (512-sample launches of the headline leg, 128 / 256-sample launches of the solo, files and
+# on-the-fly legs): the per-size averages of the persistent kernel, from the raw trace, are what bench.py's roofline.avg_launch_ms (HIP
+# events around the 512-sample launches) has to agree with
+python - "$OUT" "$TAG" <<'PY'
+import csv, glob, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(list)
+for f in glob.glob(f"{out}/prof_kt/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "sim_persistent_kernel" in r["Kernel_Name"]:
+            wgs = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
+            agg[wgs].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+with open(f"{out}/{tag}_bench_sim_launches.csv", "w") as f:
+    f.write("kernel,workgroups_per_launch,launches,avg_ms,min_ms,max_ms\n")
+    for wgs, v in sorted(agg.items(), reverse=True):
+        f.write("sim_persistent_kernel,%d,%d,%.3f,%.3f,%.3f\n" % (wgs, len(v), sum(v) / len(v), min(v), max(v)))
+PY
+rm -rf $OUT/prof_kt   # the raw trace is large; only the summaries are kept
 grep '"metric"' $OUT/${TAG}_bench_stdout.log | tail -1 > $OUT/${TAG}_bench_line_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-train --no-files --no-pmc > $OUT/${TAG}_pmc_$C.log 2>&1
