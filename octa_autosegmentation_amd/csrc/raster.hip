@@ -481,13 +481,13 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
 // The band's input rows are staged in LDS with coalesced 16-byte loads; the last row of a band
 // leaves its error terms in LDS for the first row of the next band.
 
+template <bool ST4>
 __global__ void __launch_bounds__(64)
-fs_dither_kernel(const unsigned char *__restrict__ in, int W, int H, int band_rows, unsigned char *__restrict__ out) {
+fs_dither_kernel(const unsigned char *__restrict__ in, int W, int H, int band_rows, int rs, unsigned char *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *errors = reinterpret_cast<int *>(smem);                       // [W+1], padded to 16 B
     const int err_bytes = (((W + 1) * 4 + 15) / 16) * 16;
-    const int rs = ((W + 15) / 16) * 16;                               // staged row stride (bytes)
-    unsigned char *s_in = smem + err_bytes;                            // [band_rows][rs]
+    unsigned char *s_in = smem + err_bytes;                            // [band_rows][rs]; rs = an ODD number of 32-bit words (the 64 lanes read 64 rows at once)
     const int img = blockIdx.x;
     const int lane = threadIdx.x;
     const unsigned char *src = in + (size_t)img * W * H;
@@ -495,7 +495,6 @@ fs_dither_kernel(const unsigned char *__restrict__ in, int W, int H, int band_ro
     for (int i = lane; i <= W; i += 64) errors[i] = 0;
     __syncthreads();
     const bool vec_ok = (W % 16 == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0);
-    const bool st_ok = (W % 4 == 0) && ((reinterpret_cast<size_t>(dst) & 3) == 0);
     for (int band = 0; band < H; band += band_rows) {
         const int rows = min(band_rows, H - band);
         // stage rows [band, band+rows)
@@ -505,7 +504,9 @@ fs_dither_kernel(const unsigned char *__restrict__ in, int W, int H, int band_ro
             const uint4 *g = reinterpret_cast<const uint4 *>(src + (size_t)band * W);
             for (int i = lane; i < total; i += 64) {
                 int r = i / vec_per_row, c = i - r * vec_per_row;
-                *reinterpret_cast<uint4 *>(s_in + r * rs + c * 16) = g[i];
+                const uint4 v = g[i];
+                unsigned *d = reinterpret_cast<unsigned *>(s_in + r * rs + c * 16);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
         } else {
             const int total = rows * W;
@@ -521,40 +522,46 @@ fs_dither_kernel(const unsigned char *__restrict__ in, int W, int H, int band_ro
         int e_out = 0;
         unsigned obuf = 0;
         const int steps = (W + 1) + 2 * (rows - 1);
-        const unsigned char *my_in = s_in + lane * rs;
+        const unsigned *my_w = reinterpret_cast<const unsigned *>(s_in + (row_ok ? lane : 0) * rs);
         unsigned char *my_out_row = dst + (size_t)y * W;
+        // Everything a step reads from LDS is fetched ONE STEP AHEAD (the word holding this lane's next input pixel; for lane 0 the
+        // error term of the row above, left by the previous band), and the error term of the row above inside the band moves down a
+        // lane with a DPP wave shift: the first version paid three dependent LDS round trips per step (ds_bpermute, the error read,
+        // a byte read of the input), ~480 cycles per step for a chain of ~25 integer instructions.
+        // The step itself is straight-line code on selects (one wave per image runs alone on its SIMD: every instruction and every
+        // taken branch of the ~25 000 serial steps is paid in full).
+        unsigned wcur = my_w[0];                                        // x <= 0 at t = 0 for every lane
+        int perr = errors[1];                                           // lane 0, step 0: errors[x + 1]
+        const bool last_row = lane == rows - 1;
         for (int t = 0; t < steps; t++) {
             const int x = t - 2 * lane;
-            int up = __shfl_up(e_out, 1, 64);
-            if (lane == 0) up = (x >= 0 && x < W) ? errors[x + 1] : 0;
-            int my_out = e_out;
-            if (row_ok && x >= 0 && x < W) {
-                int v = (int)my_in[x] + (l + up) / 16;
-                l = v <= 0 ? 0 : (v < 256 ? v : 255);
-                int o = (l > 128) ? 255 : 0;
-                if (st_ok) {
-                    obuf |= (unsigned)o << (8 * (x & 3));
-                    if ((x & 3) == 3) {
-                        *reinterpret_cast<unsigned *>(my_out_row + (x - 3)) = obuf;
-                        obuf = 0;
-                    }
-                } else {
-                    my_out_row[x] = (unsigned char)o;
-                }
-                l -= o;
-                int l2 = l;
-                int d2 = l + l;
-                l += d2;
-                my_out = l + l0;
-                l += d2;
-                l0 = l + l1;
-                l1 = l2;
-                l += d2;
-            } else if (row_ok && x == W) {
-                my_out = l0;
+            const int xn = min(max(x + 1, 0), W - 1);
+            const unsigned wnext = my_w[xn >> 2];
+            const int perr_next = errors[min(t + 2, W)];                // what lane 0 needs in step t + 1 (same address for all lanes: a broadcast)
+            int up = __builtin_amdgcn_update_dpp(0, e_out, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            if (lane == 0) up = (x < W) ? perr : 0;
+            const bool active = row_ok && (unsigned)x < (unsigned)W;
+            const int sh = 8 * (x & 3);
+            const int v = (int)((wcur >> sh) & 255u) + (l + up) / 16;
+            const int lc = v <= 0 ? 0 : (v < 256 ? v : 255);
+            const int o = (lc > 128) ? 255 : 0;
+            const int e = lc - o;
+            // Pillow: l = 7e for the next pixel; errors[x] = 3e + l0; l0 = 5e + l1; l1 = e; at x == W the row leaves l0 behind
+            const int my_out = active ? 3 * e + l0 : ((row_ok && x == W) ? l0 : e_out);
+            l0 = active ? 5 * e + l1 : l0;
+            l1 = active ? e : l1;
+            l = active ? 7 * e : l;
+            if (ST4) {
+                obuf = active ? (obuf | ((unsigned)o << sh)) : obuf;
+                if (active && (x & 3) == 3) *reinterpret_cast<unsigned *>(my_out_row + (x - 3)) = obuf;
+                obuf = (x & 3) == 3 ? 0u : obuf;
+            } else if (active) {
+                my_out_row[x] = (unsigned char)o;
             }
-            if (lane == rows - 1 && x >= 0 && x <= W) errors[x] = my_out;
+            if (last_row && x >= 0 && x <= W) errors[x] = my_out;
             e_out = my_out;
+            wcur = wnext;
+            perr = perr_next;
         }
         __syncthreads();
     }
@@ -652,14 +659,22 @@ extern "C" int octa_fs_dither(octa_ctx *ctx, int B, const uint8_t *d_in, int W, 
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     const int err_bytes = (((W + 1) * 4 + 15) / 16) * 16;
-    const int rs = ((W + 15) / 16) * 16;
+    int rs_words = (W + 3) / 4 + 1;                                    // one spare word; an odd word count keeps the 64 rows on 64 different banks
+    if (rs_words % 2 == 0) rs_words++;
+    const int rs = 4 * rs_words;
     const int lds_budget = 150 * 1024;
     int band_rows = (lds_budget - err_bytes) / rs;
     if (band_rows > 64) band_rows = 64;
     if (band_rows < 1) { octa::set_error("octa_fs_dither: image too wide (%d) for the LDS-staged kernel", W); return -2; }
     const size_t lds = (size_t)err_bytes + (size_t)band_rows * rs;
-    OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fs_dither_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fs_dither_kernel, dim3((unsigned)B), dim3(64), lds, stream, d_in, W, H, band_rows, d_out);
+    // 4-pixel stores when every image row starts on a 4-byte boundary
+    if (W % 4 == 0 && (reinterpret_cast<size_t>(d_out) & 3) == 0) {
+        OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fs_dither_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fs_dither_kernel<true>, dim3((unsigned)B), dim3(64), lds, stream, d_in, W, H, band_rows, rs, d_out);
+    } else {
+        OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fs_dither_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fs_dither_kernel<false>, dim3((unsigned)B), dim3(64), lds, stream, d_in, W, H, band_rows, rs, d_out);
+    }
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }

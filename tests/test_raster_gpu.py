@@ -66,6 +66,21 @@ def test_fs_dither_cases(t2i, raster_golden):
         assert (out == g[f"fs{t}_out"]).all(), f"fs case {t}"
 
 
+def test_fs_dither_random_images_of_odd_sizes_match_the_oracle(t2i):
+    """Widths that are no multiples of 4 / 16, heights that leave a ragged last band of the 64-row wavefront, one-pixel and one-row
+    images, batches, and a full-size noise image (every error term alive, unlike the mostly black labels)."""
+    import torch
+    from oracle import octa_oracle
+    rng = np.random.default_rng(5)
+    for (B, H, W) in [(1, 1, 1), (2, 1, 7), (1, 9, 1), (3, 5, 3), (2, 64, 64), (2, 65, 66), (1, 200, 65), (2, 130, 67), (1, 129, 304), (1, 1216, 1216)]:
+        x = rng.integers(0, 256, (B, H, W), dtype=np.uint8)
+        if H * W > 10000:
+            x[0, : H // 2] = np.minimum(x[0, : H // 2], 140)          # a band around the threshold: long carry chains
+        out = t2i.binarize_label_device(torch.from_numpy(x).cuda()).cpu().numpy()
+        for b in range(B):
+            assert (out[b] == octa_oracle.fs_dither(x[b])).all(), (B, H, W, b)
+
+
 def test_random_vs_oracle_and_ragged_batch(t2i):
     from oracle import octa_oracle
     rng = np.random.default_rng(99)
