@@ -252,19 +252,18 @@ def files_leg(gen, stream, seeds, threads=None):
         writer.wait()
         dt = time.time() - t0
         nbytes = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(out_root) for f in fs)
-        # the reference's entry point itself, pipelined: generate_vessel_graph.py --labels keeps four batches in flight and writes
-        # a finished batch's files while the next ones are simulated
+        # the reference's entry point itself, pipelined: generate_vessel_graph.py --labels simulates and rasterises one 512-sample batch
+        # while the previous one is copied out and written
         shutil.rmtree(out_root, ignore_errors=True)
         os.makedirs(out_root, exist_ok=True)
         import contextlib
         import io
         import generate_vessel_graph
         from octa_autosegmentation_amd.utils import configs
-        n_cli = 8 * len(seeds)
+        n_cli = 4096
         t1 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
-            generate_vessel_graph.main(["--config_file", configs.GENERATOR_CONFIG, "--num_samples", str(n_cli), "--batch", str(len(seeds)), "--inflight", "4",
-                                        "--labels", "--seed", "7000000", "--output.directory", out_root])
+            generate_vessel_graph.main(["--config_file", configs.GENERATOR_CONFIG, "--num_samples", str(n_cli), "--labels", "--seed", "7000000", "--output.directory", out_root])
         dt_cli = time.time() - t1
         n_dirs = len(os.listdir(out_root))
         assert n_dirs == n_cli, (n_dirs, n_cli)
@@ -272,8 +271,8 @@ def files_leg(gen, stream, seeds, threads=None):
                 "unit": "samples/s", "samples": len(seeds), "seconds": dt, "generate_seconds": t_gen, "write_seconds": dt - t_gen,
                 "writer_threads": threads or default_threads(), "bytes_written": nbytes, "where": out_root.rsplit("/", 1)[0],
                 "cli_pipelined": {"value": n_cli / dt_cli, "unit": "samples/s", "samples": n_cli, "seconds": dt_cli,
-                                  "command": f"generate_vessel_graph.py --num_samples {n_cli} --batch {len(seeds)} --inflight 4 --labels",
-                                  "note": "the drop-in CLI end to end, simulator set-up of its four generator threads included (process start excluded): config.yml + CSV + image PNG + label PNG per sample"},
+                                  "command": f"generate_vessel_graph.py --num_samples {n_cli} --labels (defaults: --batch 512 --inflight 2, 16 writer threads)",
+                                  "note": "the drop-in CLI end to end, simulator set-up of its generator threads included (process start excluded): config.yml + CSV + image PNG + label PNG per sample"},
                 "note": "one batch, nothing overlapped: simulate + rasterise on the GPU, then native CSV formatting (byte-identical to numpy's "
                         "str(ndarray) / repr(float), tests/test_fileio.py) and PNG encoding on host threads"}
     finally:

@@ -13,6 +13,8 @@ the next batch.
 import argparse
 import os
 import random
+import sys
+import time
 import warnings
 from datetime import datetime
 from uuid import uuid4
@@ -26,11 +28,13 @@ def main(argv=None):
     parser.add_argument('--config_file', type=str, required=True)
     parser.add_argument('--num_samples', type=int, default=1)
     parser.add_argument('--debug', action="store_true")
-    parser.add_argument('--threads', type=int, default=-1, help="host threads that format and write the files (samples run on the GPU)")
+    parser.add_argument('--threads', type=int, default=-1, help="host threads that format and write the files (samples run on the GPU); default 16: more "
+                        "writers slow the simulator's host-side LAPACK service down (measured: 4 -> 350, 8 -> 501, 12 -> 512, 16 -> 561, 32 -> 435 triples/s)")
     parser.add_argument('--labels', action="store_true", help="also write <name>_label.png (1216x1216, binarised)")
     parser.add_argument('--seed', type=int, default=None)
-    parser.add_argument('--batch', type=int, default=128)
-    parser.add_argument('--inflight', type=int, default=4, help="batches simulated concurrently (one generator thread, HIP stream and simulator state each)")
+    parser.add_argument('--batch', type=int, default=512, help="samples per launch of the simulator (512 = every workgroup slot of an MI355X)")
+    parser.add_argument('--inflight', type=int, default=2, help="generator threads (own simulator state, rasteriser scratch and HIP stream each): one batch is on the GPU "
+                        "while the other threads copy theirs out and hand them to the file writers")
     parser.add_argument('--device', type=int, default=0)
     args, unknown = parser.parse_known_args(argv)
     if args.debug:
@@ -51,12 +55,13 @@ def main(argv=None):
     from octa_autosegmentation_amd.output_files import SampleFileWriter
     torch.cuda.set_device(args.device)
     seed0 = args.seed if args.seed is not None else random.SystemRandom().randrange(0, 2 ** 31 - args.num_samples - 1)
-    writer = SampleFileWriter(args.threads if args.threads > 0 else None)
+    writer = SampleFileWriter(args.threads if args.threads > 0 else 16)
     # Batches are independent: `--inflight` generator threads (own simulator state, rasteriser scratch and HIP stream each) keep
     # that many launches of the persistent kernel on the GPU while this thread hands finished batches to the file writers -- the
     # reference's process pool over samples (generate_vessel_graph.py:112-129) with the roles of CPU and GPU exchanged.
     import queue
     import threading
+    sys.setswitchinterval(0.0005)      # generator threads, the submitting thread and the writers' glue share the GIL: hand it over in 0.5 ms slices, not 5 ms ones
     plan = []
     done = 0
     while done < args.num_samples:
@@ -71,6 +76,27 @@ def main(argv=None):
     failure = []
     stop = threading.Event()
     dev = torch.cuda.current_device()
+    timing = os.environ.get("OCTA_CLI_TIMING", "0") == "1"
+    # At most one GPU's worth of samples (512 workgroup slots on an MI355X: two samples per CU; OCTA_GPU_SLOTS) is simulated and rasterised at a time; batches beyond that
+    # wait here while their threads' finished batches are copied out and handed to the writers. Two reasons (6144 samples in batches
+    # of 512, MI355X): persistent kernels of several launches resident at once double the working set that already misses L2, and the
+    # rasteriser's launch sequence reads sizes back, i.e. waits behind another thread's persistent kernel for as long as that runs.
+    class _SlotGate:
+        def __init__(self, capacity):
+            self.capacity, self.used, self.cv = capacity, 0, threading.Condition()
+
+        def acquire(self, n):
+            with self.cv:
+                while self.used and self.used + n > self.capacity:
+                    self.cv.wait()
+                self.used += n
+
+        def release(self, n):
+            with self.cv:
+                self.used -= n
+                self.cv.notify_all()
+
+    gpu_gate = _SlotGate(int(os.environ.get("OCTA_GPU_SLOTS", "512")))
 
     def generate_batches():
         gens = {}
@@ -86,10 +112,18 @@ def main(argv=None):
                     if B not in gens:
                         gens[B] = pipeline.TripleGenerator(config, B)
                     seeds = np.arange(seed0 + start, seed0 + start + B, dtype=np.int64).astype(np.uint32)
-                    out = gens[B].generate(seeds, want_label=args.labels)
+                    t_a = time.time()
+                    gpu_gate.acquire(B)
+                    try:
+                        out = gens[B].generate(seeds, want_label=args.labels)
+                        stream.synchronize()
+                    finally:
+                        gpu_gate.release(B)
                     res = out["result"]
+                    t_b = time.time()
                     images = out["image"].cpu().numpy()
                     labels = out["label"].cpu().numpy() if args.labels else None
+                    t_c = time.time()
                     vols = None
                     if out_cfg.get("save_3D_volumes"):
                         shape = np.array([config['Greenhouse']['SimulationSpace'][a] for a in ("no_voxel_x", "no_voxel_y", "no_voxel_z")])
@@ -101,6 +135,9 @@ def main(argv=None):
                             v = tree2img.voxelize_edges_device(d_edges, np.array([0, na, len(d_edges)]), vol_dim)
                             vols.append(torch.maximum(v[0], v[1]).cpu().numpy().astype(np.uint8))
                     finished.put((B, res, images, labels, vols))
+                    if timing:
+                        print(f"[cli timing] generator: generate {t_b - t_a:.3f} s (simulator {out['wall']['sim_run_s']:.3f}), wait + copy out {t_c - t_b:.3f}, "
+                              f"hand over {time.time() - t_c:.3f}", file=sys.stderr, flush=True)
         except BaseException as e:                            # noqa: BLE001 -- re-raised by the main thread
             failure.append(e)
             stop.set()
@@ -121,7 +158,9 @@ def main(argv=None):
                 alive -= 1
                 continue
             B, res, images, labels, vols = item
+            t_a = time.time()
             writer.wait()                                  # the previous batch's files (written while the next ones were simulated)
+            t_b = time.time()
             for k in range(B):
                 out_dir = os.path.join(os.path.abspath(out_cfg['directory']), datetime.now().strftime('%Y%m%d_%H%M%S') + "_" + str(uuid4()))
                 name = os.path.basename(out_dir)
@@ -130,6 +169,8 @@ def main(argv=None):
                               label_bits=labels[k] if labels is not None else None, config=config, volume=vols[k] if vols is not None else None,
                               volume_format=out_cfg.get("save_3D_volumes") or "npy")
             done += B
+            if timing:
+                print(f"[cli timing] main: waited {t_b - t_a:.3f} s for the previous batch's files, submitted {B} samples in {time.time() - t_b:.3f}", file=sys.stderr, flush=True)
             print(f"generated {done}/{args.num_samples} vessel graphs")
     finally:
         stop.set()                                         # after a failure here or in a generator: let the other threads run out

@@ -21,14 +21,18 @@ class SampleFileWriter:
     def __init__(self, threads=None):
         self.pool = ThreadPoolExecutor(max_workers=threads or default_threads())
         self.pending = []
+        self._cfg_seen = None         # the last configuration dumped (a deep copy) and its YAML text: a run writes the same config.yml
+        self._cfg_text = None         # next to every sample, and yaml.dump of it costs 1.2 ms of the submitting thread per sample
 
     def submit(self, out_dir, name, edges=None, image=None, label_bits=None, config=None, volume=None, volume_format="npy"):
         """Queue one sample's files. edges float64 [n,7]; image uint8 [H,W]; label_bits uint8 [H,W] (non-zero = white)."""
         os.makedirs(out_dir, exist_ok=True)
         if config is not None:
-            import yaml
-            with open(os.path.join(out_dir, "config.yml"), "w") as f:
-                yaml.dump(config, f)
+            if self._cfg_text is None or config != self._cfg_seen:
+                import copy
+                import yaml
+                self._cfg_seen, self._cfg_text = copy.deepcopy(config), yaml.dump(config)
+            self.pending.append(self.pool.submit(_write_text, os.path.join(out_dir, "config.yml"), self._cfg_text))
         if edges is not None:
             self.pending.append(self.pool.submit(graph_io.write_csv, edges, os.path.join(out_dir, name + ".csv")))
         if image is not None:
@@ -50,6 +54,11 @@ class SampleFileWriter:
     def close(self):
         self.wait()
         self.pool.shutdown()
+
+
+def _write_text(path, text):
+    with open(path, "w") as f:
+        f.write(text)
 
 
 def write_nifti_u8(path, volume):
