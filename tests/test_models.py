@@ -342,4 +342,5 @@ def test_f32_weight_pack_cache_cannot_serve_a_collected_parameters_copy():
         assert float(conv_f32._packed(w, False).max()) == -1.0
         del w, p, pt
         gc.collect()
-    assert reused > 0          # the situation the old cache got wrong did occur in this loop
+    # (`reused` usually is > 0 here -- the id-keyed cache failed this loop whenever it was; whether the interpreter and the allocator
+    # reuse an id together with an address depends on the process's history, so it is not asserted)
