@@ -8,7 +8,7 @@ import threading
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboctahip.so")
+LIB_PATH = os.environ.get("OCTA_HIP_LIB") or os.path.join(HERE, "liboctahip.so")    # OCTA_HIP_LIB: experiment builds (tools/build_sim_variant.py)
 
 _lib = None
 _ctxs = {}

@@ -101,6 +101,9 @@ struct BatchPtrs {
     int *n_per_iter;             // [n_iter]
     int *next_sample;            // [1] work queue of the persistent kernel
     unsigned char *wg_scratch;   // large build: [B][SIM_USER_BYTES] table area of the workgroup that runs sample s (Blk::umem); else null
+#ifdef OCTA_SIM_DEBUG_SAT
+    int *dbg;                    // diagnostic build: [B][n_iter][16] digests of phase_satisfy_art (dumped to $OCTA_SIM_DEBUG_DUMP after a run)
+#endif
     int *trace;                  // [B][n_iter][4] arterial nodes, O2 sinks, venous nodes, CO2 sources at the end of every iteration (greenhouse.py:129-134)
     int n_samples;
     SimConst C;
@@ -145,6 +148,10 @@ __device__ __forceinline__ SimArrays sample_arrays(const BatchPtrs &B, int s) {
     A.grid_pts = B.grid_pts + (size_t)s * GRID_N * 3;
     A.tmp_dbl = B.tmp_dbl + (size_t)s * OCAP * 3;
     A.sc = B.sc + s;
+#ifdef OCTA_SIM_DEBUG_SAT
+    A.dbg = B.dbg ? B.dbg + (size_t)s * B.C.n_iter * 16 : nullptr;
+    A.dbg_it = 0;
+#endif
     return A;
 }
 
@@ -322,7 +329,7 @@ sim_iter_a_kernel(BatchPtrs B, int it, int finish_prev) {
             gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * B.valid_stride, B.valid_count[s], P.N,
                                 B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()),
                                 reinterpret_cast<unsigned *>(b.user()) + 624 + 1248, (int)threadIdx.x, B.C.gs);
-        __syncthreads();
+        octa_block_sync();
         if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
     }
     OCTA_PROF(0, phase_sample(b, A, B.C, P, it));
@@ -425,21 +432,12 @@ __device__ inline int uniform_err(const Blk &b, const SimArrays &A) {
 
 // every iteration of ONE sample (or what is left of them after a park), by one workgroup
 __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s_in, const Blk &b) {     // inlined: B stays kernel arguments (scalar registers)
-    // The sample index is wave-uniform by construction, and declaring it so (-DOCTA_SIM_UNIFORM_S: __builtin_amdgcn_readfirstlane)
-    // keeps the sample's ~40 array base pointers in scalar registers: per-sample device time 566 -> 509 ms, 681 -> 770 samples/s.
-    // NOT enabled: with it, 512-sample batches stopped being reproducible -- about one sample run in 3000 converts a few O2 sinks
-    // fewer into CO2 sources in one iteration (16-33 events per 50-100 k sample runs, tools/repro_sim_race.py; none in 101 888 as
-    // shipped, none in 40 448 on the previous build). What round 3 established: the CO2 count is already low right after
-    // phase_satisfy_art; in-kernel checks of the venous-proximity flags against a brute-force evaluation, of their reset and of the
-    // kd rank / index mapping never fire while the events keep occurring; the LDS set replay, an extra barrier and cache-bypassing
-    // flag reads change nothing; inlining kd_build as well (no call left in the kernel) does not help; keeping phase_satisfy_art OUT
-    // of line with the uniform index gives 0 events in 60 928 sample runs at 529 ms per sample (that is what the macro builds). The
-    // cause is not understood, so the default stays the form whose addressing is the previous build's. DESIGN.md 4.1.
-#ifdef OCTA_SIM_UNIFORM_S
+    // The sample index is wave-uniform by construction; declaring it so keeps the sample's ~40 array base pointers in scalar registers
+    // (per-sample device time 566 -> 509 ms). Round 3 could not ship this: 512-sample batches stopped being reproducible (about one
+    // sample run in 2000 converted a few O2 sinks too few into CO2 sources). Round 4 found the cause -- not the addressing, but a global
+    // store -> barrier -> load hand-over between waves that __syncthreads() does not order on this hardware (sim_core.h:
+    // octa_block_sync). The scalar addressing only shortened the path between the barrier and the first dependent load.
     const int s = __builtin_amdgcn_readfirstlane(s_in);
-#else
-    const int s = s_in;
-#endif
     SimArrays A = sample_arrays(B, s);
     int *req_n = b.coll() + 96;
     BifRequest *reqs = M.reqs + (size_t)s * REQ_PER_SAMPLE;
@@ -479,7 +477,7 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
                     gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * B.valid_stride, B.valid_count[s], P.N,
                                         B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(b.user()),
                                         reinterpret_cast<unsigned *>(b.user()) + 624 + 1248, (int)threadIdx.x, B.C.gs);
-                __syncthreads();
+                octa_block_sync();
                 if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
             }
             OCTA_PROF(0, phase_sample(b, A, B.C, P, it));
@@ -506,6 +504,9 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
                 };
                 OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, results, next_candidates));
             }
+#ifdef OCTA_SIM_DEBUG_SAT
+            A.dbg_it = it;
+#endif
             OCTA_PROF(4, phase_satisfy_art(b, A, B.C, P));
             OCTA_PROF(6, phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven));
             if (b.tid == 0) *req_n = 0;
@@ -761,6 +762,9 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, O
     rc |= dev_alloc(S, &P.n_per_iter, S->iters.size() + 1);  // kept for diagnostics
     rc |= dev_alloc(S, &P.next_sample, 4);
     rc |= dev_alloc(S, &P.trace, nb * (S->iters.size() + 1) * 4);
+#ifdef OCTA_SIM_DEBUG_SAT
+    rc |= dev_alloc(S, &P.dbg, nb * (S->iters.size() + 1) * 16);
+#endif
     P.wg_scratch = nullptr;
 #if OCTA_SIM_LARGE
     rc |= dev_alloc(S, &P.wg_scratch, nb * (size_t)SIM_USER_BYTES);
@@ -939,6 +943,9 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
             OCTA_HIP_CHECK(put(P.nact[f], 1, act.data(), NCAP, n0));
         }
         OCTA_HIP_CHECK(hipMemsetAsync(P.req_count, 0, sizeof(int) * 4, stream));
+#ifdef OCTA_SIM_DEBUG_SAT
+        OCTA_HIP_CHECK(hipMemsetAsync(P.dbg, 0xff, sizeof(int) * (size_t)B * (S->iters.size() + 1) * 16, stream));
+#endif
         OCTA_HIP_CHECK(hipMemsetAsync(P.child_group, 0, sizeof(int) * (size_t)B * NCAP, stream));
         OCTA_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
     }
@@ -1084,6 +1091,13 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
     OCTA_HIP_CHECK(hipMemcpyAsync(S->h_sc.data(), P.sc, sizeof(SampleScalars) * B, hipMemcpyDeviceToHost, stream));
     OCTA_HIP_CHECK(hipStreamSynchronize(stream));
     S->ran = true;
+#ifdef OCTA_SIM_DEBUG_SAT
+    if (const char *path = getenv("OCTA_SIM_DEBUG_DUMP")) {
+        std::vector<int> h((size_t)B * S->iters.size() * 16);
+        OCTA_HIP_CHECK(hipMemcpy(h.data(), P.dbg, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+        if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), sizeof(int), h.size(), fp); fclose(fp); }
+    }
+#endif
     for (int s = 0; s < B; s++)
         if (S->h_sc[s].err) {
             if ((S->h_sc[s].err & ERR_HOST_TIMEOUT) && !S->lockstep)

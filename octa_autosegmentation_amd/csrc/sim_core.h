@@ -208,20 +208,54 @@ struct SimArrays {
     int *tmp_int;        // [OCAP + 2*NCANDCAP] general scratch
     double *tmp_dbl;     // [OCAP*3] general scratch (stable compaction staging)
     SampleScalars *sc;
+#ifdef OCTA_SIM_DEBUG_SAT
+    int *dbg;            // diagnostic build (tools/repro_sim_race.py): [n_iter][16] digest rows of phase_satisfy_art for this sample
+    int dbg_it;
+#endif
 };
 
 // ------------------------------------------------------------------ execution abstraction
 // A value every lane of the wave holds alike (read from one address after a barrier, a block total ...): telling the compiler keeps it
 // -- and everything derived from it: loop bounds, base pointers, per-iteration parameters -- in scalar registers. Round 3 measured
 // -10 % per-sample device time from the sample index alone (its ~40 array base pointers were 80 vector registers and the main source
-// of register spills). ONLY for values that come out of the LDS or out of registers: wrapped around a load from GLOBAL memory through a
-// uniform pointer it lets the compiler use a scalar load, and the scalar cache is not coherent with the vector stores of the same
-// kernel -- the sample's counters (sc->n_oxy ...) annotated this way made 512-sample batches irreproducible (a few samples per launch
-// read a stale count; caught by tools/validate_many.py, bisected on the GPU).
+// of register spills). Used for values that come out of the LDS or out of registers. (Round 3 blamed the irreproducible 512-sample
+// batches it saw with uniform annotations on scalar loads of the sample's counters; round 4 found no scalar load of mutable data in the
+// ISA and traced the events to the barrier, see octa_block_sync below.)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OCTA_UNI(x) __builtin_amdgcn_readfirstlane(x)
 #else
 #define OCTA_UNI(x) (x)
+#endif
+
+// Workgroup barrier of the simulator kernels: __syncthreads() PRECEDED BY s_waitcnt vmcnt(0).
+//
+// Why (round 4; DESIGN.md 4.1 "The barrier that did not order global memory"): hipcc's __syncthreads() is
+//     fence release (workgroup); s_barrier; fence acquire (workgroup)
+// and for gfx90a / gfx942 / gfx950 the workgroup-scope release waits for LDS traffic only (s_waitcnt lgkmcnt(0)) -- LLVM's memory
+// legaliser assumes "the L1 cache keeps all memory operations in order for wavefronts in the same work-group", so global stores may
+// still be in flight when the barrier releases. On MI355X that assumption does not hold for a store by one wave followed, behind the
+// barrier, by a load of the same address by ANOTHER wave of the workgroup: measured with tools/repro_sim_race.py on the end of
+// kd_build (scattered 2-byte stores out_rank[id] = i; barrier; phase_satisfy_art reads kd_rank[sink] on other waves) -- 26-38 sample
+// runs per 50-76 k read stale ranks (always pairs handled by waves other than the first), 0 in 76 288 with the wait in front of the
+// barrier, 38 in 76 288 with only an L1 invalidate behind it (so it is the in-flight store, not a stale line), 0 in 30 208 with one
+// workgroup per CU. Every phase of the simulator hands data from wave to wave through HBM scratch, so the wait belongs to the barrier
+// itself. Cost: 553 -> 557 ms per 512-sample launch. OCTA_SIM_SYNC_DRAIN is the experiment knob that established this
+// (0: plain __syncthreads(); bit 0: the wait; bit 1: buffer_inv sc0 behind the barrier).
+#ifndef OCTA_SIM_SYNC_DRAIN
+#define OCTA_SIM_SYNC_DRAIN 1
+#endif
+#if defined(__HIPCC__)
+__device__ __forceinline__ void octa_block_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+#if OCTA_SIM_SYNC_DRAIN & 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();
+#if OCTA_SIM_SYNC_DRAIN & 2
+    asm volatile("buffer_inv sc0" ::: "memory");
+#endif
+#endif
+}
 #endif
 
 struct Blk {
@@ -230,7 +264,7 @@ struct Blk {
     unsigned char *umem = nullptr;   // the per-phase table area when it is NOT the LDS behind the collectives (large build: HBM scratch)
     OCTA_HD inline void sync() const {
 #if defined(__HIP_DEVICE_COMPILE__)
-        __syncthreads();
+        octa_block_sync();
 #endif
     }
     OCTA_HD inline int *coll() const { return reinterpret_cast<int *>(smem); }
@@ -2319,9 +2353,6 @@ OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsign
 #endif
 
 // ------------------------------------------------------------------ phase: satisfied O2 sinks -> CO2
-#if defined(OCTA_SIM_UNIFORM_S) && defined(__HIP_DEVICE_COMPILE__)
-__attribute__((noinline))        // see run_sample (sim.hip): with the uniform sample index this phase must stay out of line
-#endif
 OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P) {
     const double zext = C.sz;      // every sink passed is_valid_position: 0 <= z < size_z
     SampleScalars *sc = A.sc;
@@ -2419,6 +2450,10 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     OCTA_SUBPROF(sc, 13, t0);
     // 5. CPython set insertion order -> CO2 append order
     bool set_in_lds = false;
+#ifdef OCTA_SIM_DEBUG_SAT
+    int dbg_n_ins = -1, dbg_mask = -1, dbg_base = -1;
+    const int dbg_n_co2_in = sc->n_co2;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     // Usual case (<= LSET_PAIRS hits): the insert stream (sink, hash) is compacted into LDS in parallel, the
     // open-addressing table lives in LDS too (a table never exceeds 8 x its entries), one thread replays the
@@ -2473,6 +2508,9 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
             if (n_co2 > CCAP) { sc->err |= ERR_CO2_CAP; n_co2 = CCAP; }
             sc->n_co2 = n_co2;
         }
+#ifdef OCTA_SIM_DEBUG_SAT
+        dbg_n_ins = n_ins; dbg_mask = mask; dbg_base = base;
+#endif
     }
 #endif
     if (!set_in_lds && b.tid == 0) {
@@ -2495,6 +2533,56 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     }
     b.sync();
     OCTA_SUBPROF(sc, 14, t0);
+#ifdef OCTA_SIM_DEBUG_SAT
+    {   // digest of this call (compared between repeated runs on the host) + in-kernel recounts of every stage of step 5
+        int ex, loc;
+        loc = 0; for (int o = b.tid; o < n_oxy; o += b.nth) loc += A.removed[o] ? 1 : 0;
+        const int c_rem = blk_scan(b, loc, &ex);
+        loc = 0; for (int o = b.tid; o < n_oxy; o += b.nth) loc += (A.removed[o] && A.ven_near[o]) ? 1 : 0;
+        const int c_ven = blk_scan(b, loc, &ex);
+        // distinct sinks named by the sorted pairs (all, and those not near a venous node): byte marks in tmp_dbl
+        unsigned char *mark = reinterpret_cast<unsigned char *>(A.tmp_dbl);
+        for (int o = b.tid; o < 2 * n_oxy; o += b.nth) mark[o] = 0;
+        b.sync();
+        for (int i = b.tid; i < n_pairs; i += b.nth) {
+            const int o = (int)A.kd_idx[A.pairs[i] & IDX_MASK];
+            mark[o] = 1;
+            if (!A.ven_near[o]) mark[n_oxy + o] = 1;
+        }
+        b.sync();
+        loc = 0; for (int o = b.tid; o < n_oxy; o += b.nth) loc += mark[o];
+        const int c_pair_all = blk_scan(b, loc, &ex);
+        loc = 0; for (int o = b.tid; o < n_oxy; o += b.nth) loc += mark[n_oxy + o];
+        const int c_pair_take = blk_scan(b, loc, &ex);
+        loc = 0; for (int o = b.tid; o < n_oxy; o += b.nth) loc += (mark[o] != (A.removed[o] ? 1 : 0)) ? 1 : 0;
+        const int c_pair_vs_removed = blk_scan(b, loc, &ex);
+        int c_slots = -1, c_in_distinct = -1, c_slot_bad = -1;
+        if (set_in_lds) {     // the LDS table and insert stream are still intact (only the collectives area was used since)
+            const unsigned long long *t_hash = reinterpret_cast<const unsigned long long *>(b.user());
+            const int *t_key = reinterpret_cast<const int *>(t_hash + LSET_CAP);
+            const unsigned long long *in_hash = reinterpret_cast<const unsigned long long *>(t_key + LSET_CAP);
+            const int *in_key = reinterpret_cast<const int *>(in_hash + LSET_PAIRS);
+            loc = 0; for (int e = b.tid; e <= dbg_mask; e += b.nth) loc += t_key[e] >= 0 ? 1 : 0;
+            c_slots = blk_scan(b, loc, &ex);
+            loc = 0; for (int e = b.tid; e <= dbg_mask; e += b.nth) { const int k = t_key[e]; if (k >= 0 && (k >= n_oxy || !A.removed[k] || A.ven_near[k])) loc++; }
+            c_slot_bad = blk_scan(b, loc, &ex);
+            for (int o = b.tid; o < n_oxy; o += b.nth) mark[o] = 0;
+            b.sync();
+            for (int i = b.tid; i < dbg_n_ins; i += b.nth) { const int k = in_key[i]; if (k >= 0 && k < n_oxy) mark[k] = 1; }
+            b.sync();
+            loc = 0; for (int o = b.tid; o < n_oxy; o += b.nth) loc += mark[o];
+            c_in_distinct = blk_scan(b, loc, &ex);
+        }
+        b.sync();
+        if (b.tid == 0 && A.dbg) {
+            int *row = A.dbg + 16 * A.dbg_it;
+            row[0] = n_new; row[1] = n_oxy; row[2] = n_pairs; row[3] = c_rem; row[4] = c_ven; row[5] = c_pair_all; row[6] = c_pair_take;
+            row[7] = c_pair_vs_removed; row[8] = dbg_n_ins; row[9] = dbg_mask; row[10] = dbg_base; row[11] = c_slots; row[12] = c_in_distinct;
+            row[13] = c_slot_bad; row[14] = dbg_n_co2_in; row[15] = sc->n_co2;
+        }
+        b.sync();
+    }
+#endif
     // 6. delete the satisfied sinks (order-preserving)
     int keep = compact_points(b, A.oxy, n_oxy, A.removed, A.tmp_dbl);
     if (b.tid == 0) sc->n_oxy = keep;

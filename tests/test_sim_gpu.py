@@ -243,6 +243,36 @@ def test_wide_reference_pin_64_full_length_seeds(gh, golden):
     assert not bad, f"CSV text differs from the reference's for seeds {bad}"
 
 
+def test_full_occupancy_launch_is_deterministic(gh, golden):
+    """Determinism sentinel (round 4). One full-length launch that fills every workgroup slot of the GPU (two samples per CU), run
+    three times on the same seeds: the per-iteration statistics and every double of the edge lists must be identical run to run, and
+    the 64 reference-pinned seeds among them must print the reference's bytes. This is the shape in which round 3's irreproducibility
+    showed (about one sample run in 2000 read a stale kd rank behind a barrier that did not order global memory -- csrc/sim_core.h:
+    octa_block_sync); tools/repro_sim_race.py is the long form of the same check."""
+    import torch
+    wide = np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_wide_golden.npz"))
+    slots = 2 * torch.cuda.get_device_properties(0).multi_processor_count
+    pinned = [int(v) for v in wide["seeds"]][:64]
+    seeds = pinned + [70000 + k for k in range(max(slots - len(pinned), 0))]
+    sim = gh.BatchSimulator(_cfg(golden, 100, 150), len(seeds))
+    first_trace = first_edges = None
+    for rep in range(3):
+        res = sim.run(seeds)
+        assert int(res.stats[:, 0].max()) == 0
+        trace = sim.trace().copy()
+        edges = res.edges.copy()
+        if rep == 0:
+            first_trace, first_edges = trace, edges
+            for k, seed in enumerate(pinned):
+                text = gh.edges_to_csv_text(res.sample_edges(k))
+                assert hashlib.sha256(text.encode()).hexdigest() == str(wide["csv_sha256"][k]), seed
+            continue
+        bad = np.flatnonzero((trace != first_trace).any(axis=(1, 2)))
+        assert bad.size == 0, f"run {rep}: per-iteration statistics of samples {bad[:8].tolist()} differ from the first run's"
+        assert edges.shape == first_edges.shape and (edges == first_edges).all(), f"run {rep}: edge lists differ from the first run's"
+    sim.close()
+
+
 def test_notebook_12x12_full_length_matches_the_reference(gh):
     """f4 at full size: the reference's notebook configuration (example_custom_vessel_simulation.ipynb:138-156: param_scale 12, nerve
     forests with 16 trees, N = 8000 candidates, 400 + 500 iterations) on the wide-field build, every reference-made seed of

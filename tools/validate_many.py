@@ -1,5 +1,8 @@
 """One-off validation: N full-length samples on the GPU vs the CPU oracle (CSV text + radii bits).
-  python tools/validate_many.py [N=64] [first_seed=1000]"""
+  python tools/validate_many.py [N=64] [first_seed=1000]
+  python tools/validate_many.py --digests tools/cache/oracle_digests_1000_512.npz [--reps R]
+The second form compares against per-seed SHA-256 values the oracle produced in the build container (tools/oracle_digests.py):
+every double of every edge list and the CSV text, without spending GPU-box time on the oracle."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, yaml
@@ -13,7 +16,37 @@ def oracle_one(args):
     return seed, e, info["n_art_edges"]
 
 
+def against_digests(path, reps):
+    import hashlib
+    from octa_autosegmentation_amd.utils import configs
+    from octa_autosegmentation_amd import graph_io
+    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
+    d = np.load(path)
+    seeds = [int(v) for v in d["seeds"]]
+    cfg = configs.load_generator_config()
+    sim = greenhouse.BatchSimulator(cfg, len(seeds))
+    for rep in range(reps):
+        t = time.time()
+        res = sim.run(seeds)
+        el = time.time() - t
+        bad_d = bad_t = 0
+        for k, seed in enumerate(seeds):
+            e = np.ascontiguousarray(res.sample_edges(k))
+            if e.shape[0] != int(d["rows"][k]) or hashlib.sha256(e.tobytes()).hexdigest() != str(d["sha_doubles"][k]):
+                bad_d += 1
+                if hashlib.sha256(graph_io.edges_to_csv_text(e).encode()).hexdigest() != str(d["sha_text"][k]):
+                    bad_t += 1
+                    print("seed", seed, "CSV text differs from the oracle's")
+        print(f"RESULT rep {rep}: {len(seeds)} full-length samples ({seeds[0]}..{seeds[-1]}) in {el:.2f} s: samples with differing doubles {bad_d}, "
+              f"with differing CSV text {bad_t}", flush=True)
+    sim.close()
+
+
 if __name__ == "__main__":
+    if "--digests" in sys.argv:
+        a = sys.argv
+        against_digests(a[a.index("--digests") + 1], int(a[a.index("--reps") + 1]) if "--reps" in a else 1)
+        sys.exit(0)
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     from octa_autosegmentation_amd.utils import configs
