@@ -240,19 +240,29 @@ struct SimArrays {
 // barrier, 38 in 76 288 with only an L1 invalidate behind it (so it is the in-flight store, not a stale line), 0 in 30 208 with one
 // workgroup per CU. Every phase of the simulator hands data from wave to wave through HBM scratch, so the wait belongs to the barrier
 // itself. Cost: 553 -> 557 ms per 512-sample launch. OCTA_SIM_SYNC_DRAIN is the experiment knob that established this
-// (0: plain __syncthreads(); bit 0: the wait; bit 1: buffer_inv sc0 behind the barrier).
+// (0: plain __syncthreads(); bit 0: the wait; bit 1: buffer_inv sc0 behind the barrier; bit 2: agent-scope fences instead; bit 3:
+// buffer_inv sc1 behind the barrier).
 #ifndef OCTA_SIM_SYNC_DRAIN
 #define OCTA_SIM_SYNC_DRAIN 1
 #endif
 #if defined(__HIPCC__)
 __device__ __forceinline__ void octa_block_sync() {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if OCTA_SIM_SYNC_DRAIN & 4
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return;
+#endif
 #if OCTA_SIM_SYNC_DRAIN & 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     __syncthreads();
 #if OCTA_SIM_SYNC_DRAIN & 2
     asm volatile("buffer_inv sc0" ::: "memory");
+#endif
+#if OCTA_SIM_SYNC_DRAIN & 8
+    asm volatile("buffer_inv sc1" ::: "memory");
 #endif
 #endif
 }
@@ -268,7 +278,16 @@ struct Blk {
 #endif
     }
     OCTA_HD inline int *coll() const { return reinterpret_cast<int *>(smem); }
+    // The table area of a phase. Default build: reached through a pointer the compiler cannot prove to be LDS (the wide-field build puts
+    // the tables in HBM), so every table access is a FLAT instruction. -DOCTA_SIM_LDS_DS makes it the LDS at compile time (ds_*
+    // instructions: 492 instead of 513 ms per sample, 469 with round 4's batched queries on top) -- NOT the default: with it about one
+    // sample run in 100 is irreproducible again (same stage as the barrier race, octa_block_sync above, but not cured by it), see
+    // DESIGN.md 4.1 and tools/isa/experiments/.
+#if defined(OCTA_SIM_LDS_DS) && !OCTA_SIM_LARGE
+    OCTA_HD inline unsigned char *user() const { return smem + 2048; }
+#else
     OCTA_HD inline unsigned char *user() const { return umem ? umem : smem + 2048; }
+#endif
 };
 
 // exclusive scan of one int per thread; returns block total. Contains block syncs.
