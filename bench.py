@@ -3,9 +3,10 @@
 A step = one pass of the hot path over one batch of seeded samples with the reference's own generator config
 (docker/vessel_graph_gen_docker_config.yml): space-colonisation simulation of B vessel graphs (HIP), 304x304
 arterial/venous rasterisation and max-combine, 1216x1216 label rasterisation + Floyd-Steinberg binarisation.
-Workload = BASELINE.json configs[1] (128-sample batch, rasterise to 1216x1216). `value` counts triples complete in memory
-(edge arrays on the host, images / labels in HBM); the `files` leg of the same run writes the reference's per-sample
-files (graph CSV + image PNG + label PNG) for one batch and reports on-disk triples per second.
+Workload = BASELINE.json configs[1] (128-sample batch, rasterise to 1216x1216). `value` counts triples complete in HBM
+(edge list, image and label are device tensors: the edge list is exported by a kernel and read by the rasteriser where it is);
+`value_with_csv` is the rate of the drop-in CLI writing the reference's per-sample FILES (graph CSV + image PNG + label PNG: the
+triple as SURVEY.md 8d defines it), measured by the `files` leg of the same run.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
 Multi-GPU (driver-launched with torch.distributed.run): samples are independent, every rank generates its own batch with
@@ -36,6 +37,9 @@ UNET_TFLOP_PER_IMAGE = 2.0         # forward 0.666 TFLOP x 3
 UNET_MIN_HBM_GB_PER_IMAGE = 6.0    # activations written once / read once, norm + activation fused
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16
+VOXEL_BYTES_CLI = 1216 * 1216 * 16 * 2      # the volume the CLI shape names, uint16 (47 MB)
+G_TFLOP_FWD_304 = 0.178            # resnetGenerator9 forward at 1x304x304
+D_TFLOP_FWD_304 = 0.018            # patchGAN70x70 forward at 1x304x304
 N_CUS = 256          # MI355X; main() replaces it by the device's own count
 PMC_SUMMARY = os.path.join("profiles", "r03_bench_pmc_summary.csv")
 
@@ -133,7 +137,7 @@ def _oracle_sample(args):
     return len(e)
 
 
-def cpu_baseline(cfg):
+def cpu_baseline(cfg, all_cores=False):
     """The oracle (CPU restatement of the reference, oracle/) on the GPU box's host cores: ONE full-length sample per core on
     all cores at once (the reference's own parallelism: one sample per pool worker, generate_vessel_graph.py:112-129), and the
     single-core figure. Bounded: one wave of samples (about 5-10 s) + one more sample."""
@@ -150,8 +154,15 @@ def cpu_baseline(cfg):
     with get_context("spawn").Pool(workers) as pool:
         pool.map(_oracle_sample, [(cfg, 901 + k) for k in range(workers)])
     dt = time.time() - t0
+    all_info = {"value": None, "cores": cores, "note": "not run by default (one worker per visible core takes ~230 s on the 256-thread host); round 3 measured 1.1 samples/s "
+                                                       "with 256 workers against 2.2 with 64 on the same host; bench.py --cpu-all-cores times it"}
+    if all_cores and cores > workers:
+        t1 = time.time()
+        with get_context("spawn").Pool(cores) as pool:
+            pool.map(_oracle_sample, [(cfg, 2000 + k) for k in range(cores)])
+        all_info = {"value": cores / (time.time() - t1), "cores": cores, "note": "one full-length sample per visible core, all at once"}
     return {"value": workers / dt, "unit": "samples/s", "cores": workers, "kind": "port", "host_cores_visible": cores,
-            "single_core_value": single,
+            "single_core_value": single, "all_cores": all_info,
             "sample": f"{workers} full-length samples (I=100+150, N=2000) incl. 304x304 image + 1216x1216 label, one per core on {workers} cores "
                       f"at once (pool start-up included), oracle/ C++; single core: one sample"}
 
@@ -184,6 +195,67 @@ def cpu_unet_step():
     return {"value": 1.0 / dt, "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "plain torch fp32 on the CPU device",
             "cold_first_step_s": cold, "step_s": times,
             "sample": "DynUNet-S training steps, B=1, 1x1216x1216: one warm-up step, then one timed step"}
+
+
+def voxel_leg(cfg, dev, n_vol=8):
+    """the 3-D voxeliser at the CLI's shape [1216, 1216, 16] (padded to z = 53 as the reference pads,
+    tree2img.py:206-211) on the edge lists of freshly simulated full-length samples; HIP events on the launch stream."""
+    import torch
+    from octa_autosegmentation_amd.utils import sharding
+    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse, tree2img
+    sim = greenhouse.BatchSimulator(cfg, n_vol)
+    res = sim.run(sharding.rank_seeds(0, 970, n_vol))
+    d_edges = res.d_edges if res.d_edges is not None else torch.from_numpy(res.edges).to(dev)
+    off = np.asarray(res.edge_off, dtype=np.int64)
+    dims = [1216, 1216, 16]
+    vol = tree2img.voxelize_edges_device(d_edges, off, dims)            # warm-up (scratch allocation)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    e0.record()
+    for _ in range(reps):
+        vol = tree2img.voxelize_edges_device(d_edges, off, dims)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / (reps * n_vol)
+    padded = int(vol.shape[1]) * int(vol.shape[2]) * int(vol.shape[3]) * 2
+    sim.close()
+    gbs = VOXEL_BYTES_CLI / (ms * 1e-3) / 1e9
+    return {"kernel": "octa_voxelize_3d (voxel_edges_kernel + voxel_widen_kernel)", "bound": "hbm", "ms_per_volume": ms, "volumes": n_vol,
+            "edges_per_volume": float(off[-1]) / n_vol, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_volume": VOXEL_BYTES_CLI, "padded_volume_bytes": padded,
+            "achieved_padded": padded / (ms * 1e-3) / 1e9,
+            "note": "1216 x 1216 x 16 (padded to z = 53: 157 MB written per volume); the per-edge box walk in double arithmetic, not the streaming part, "
+                    "dominates (DESIGN.md 4.2b); the reference takes 58.7 s per volume"}
+
+
+def gan_networks_leg(dev, batch=4, steps=20, warmup=5):
+    """forward passes of the GAN's generator (resnetGenerator9, 0.178 TFLOP at 304^2) and discriminator (patchGAN70x70,
+    0.018 TFLOP) under bf16 autocast on the MFMA / streaming kernels: TFLOP/s against the dense bf16 peak."""
+    import torch
+    from octa_autosegmentation_amd.models import networks
+    out = {}
+    x = torch.rand(batch, 1, 304, 304, device=dev)
+    for name, make, tf in (("resnetGenerator9", networks.resnetGenerator9, G_TFLOP_FWD_304), ("patchGAN70x70", networks.patchGAN70x70, D_TFLOP_FWD_304)):
+        torch.manual_seed(0)
+        net = make().to(dev).eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            for _ in range(warmup):
+                net(x)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                net(x)
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        tfs = tf * batch / (ms * 1e-3)
+        out[name] = {"ms_per_forward": ms, "batch": batch, "imgs_per_s": batch / (ms * 1e-3), "bound": "mfma", "achieved": tfs, "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": tfs / MFMA_BF16_PEAK_TFLOPS}
+    out["note"] = ("forward only, B = 4 at 1 x 304 x 304, bf16 autocast; the 76 x 76 residual stages of the generator are launch- / latency-bound at this "
+                   "batch (DESIGN.md 4.2f), the discriminator is dominated by its one-channel stem / head and the blur kernels")
+    return out
 
 
 def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4):
@@ -332,6 +404,10 @@ def main():
     ap.add_argument("--train-batch", type=int, default=4)
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the on-the-fly generation + training measurement")
     ap.add_argument("--no-files", action="store_true", help="skip the on-disk triples leg")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline with one worker per visible core (BASELINE.md 3: 'all cores'; "
+                    "230 s on the 256-thread host of the GPU box, hence not in the default run)")
+    ap.add_argument("--long", action="store_true", help="also run BASELINE configs[4] at its stated size: a 10 000-sample on-the-fly epoch (2 500 training steps "
+                    "of 4; about a minute and a half on one MI355X, outside the default time budget)")
     args = ap.parse_args()
     if args.pmc_child:
         pmc_child(args.batch)
@@ -350,6 +426,14 @@ def main():
         # and its barrier live on this rank's GPU.
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
     dev = torch.device("cuda", torch.cuda.current_device())
+    rccl_ranks = 1
+    host = None
+    if world > 1:
+        from octa_autosegmentation_amd.utils import sharding as _sh
+        host = _sh.apply_host_budget(generator_threads=max(1, args.inflight))       # per-rank share of the host: service-thread spin, BLAS threads, CPU set
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                                        # every rank that answers adds one: the number of RCCL ranks really in the job
+        rccl_ranks = int(ones.item())
     global N_CUS
     N_CUS = int(torch.cuda.get_device_properties(dev).multi_processor_count)
 
@@ -509,7 +593,23 @@ def main():
         torch.cuda.empty_cache()
         e2e_gan_info = train_synthetic.run(steps=64, batch=args.train_batch, gen_batch=128, seed0=600000, log=False, gan=True, warmup=32)
 
+    per_rank = None
+    if dist is not None:
+        t_all = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(t_all, torch.tensor([dt], dtype=torch.float64, device=dev))
+        per_rank = [B * args.steps / float(t.item()) for t in t_all]
     dt = sharding.max_over_ranks(dt, dist, dev)
+    voxel_info = gan_net_info = long_info = None
+    if rank == 0 and not args.no_train:
+        torch.cuda.empty_cache()
+        voxel_info = voxel_leg(cfg, dev)
+        gan_net_info = gan_networks_leg(dev)
+    if args.long and not args.no_train:
+        import train_synthetic
+        torch.cuda.empty_cache()
+        long_info = train_synthetic.run(steps=2500 // max(world, 1) + 64, batch=args.train_batch, gen_batch=256, seed0=700000, log=False, warmup=64)
+        if long_info is not None:
+            long_info["note"] = "BASELINE configs[4] at its stated size: 10 000 samples per epoch over all ranks (2 500 steps of 4 + warm-up)"
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -561,7 +661,12 @@ def main():
                       "of ~92 000 doubles per full-length sample (last bit), never in a printed digit on those 64 + 10 runs; GPU and oracle agree in "
                       "EVERY double (radii: glibc pow restated; node positions: glibc acos / sin / cos restated, csrc/glibc_trig.h) on the validated "
                       "full-length seeds (profiles/r02_validate_final.log, profiles/r03_validate.log)",
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "rccl_ranks": rccl_ranks, "per_rank_value": per_rank, "host_budget": host,
+            "value_with_csv": (files_info or {}).get("cli_pipelined", {}).get("value") if files_info else None,
+            "value_with_csv_note": "complete ON-DISK triples per second (config.yml + graph CSV + 304x304 image PNG + 1216x1216 label PNG per sample) through the "
+                                   "drop-in CLI generate_vessel_graph.py --labels: the triple as SURVEY.md 8d defines it; `value` counts triples complete in HBM",
+            "roofline": {"bound": "hbm", "binds": "latency: the serial dependency depth of one sample's 250 iterations (see serial_depth), not HBM bandwidth and not the matrix cores",
+                         "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE; {traffic_src})",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -575,7 +680,7 @@ def main():
                                                   "(one sample per CU: the solo leg runs 128 samples) and for ..._all_slots_taken in the timed launches (the co-resident "
                                                   "sample shares the CU's issue slots, LDS and L1); CUs x slots / that time is what the simulator could "
                                                   "reach alone on the GPU; this dependency chain, not HBM, is the binding limit"},
-                         "rasteriser": raster},
+                         "rasteriser": raster, "voxeliser": voxel_info, "gan_networks": gan_net_info},
             "kernel_ms_per_launch": {dom_name: launch_ms, "launches_per_step": dom_n / max(args.steps, 1),
                                      "cu_occupancy_weighted_ms_per_step": launch_ms * (dom_n / max(args.steps, 1)) / sim_conc,
                                      "note": f"a launch covers {G} steps; {n_fly} launches are in flight and {sim_conc} persistent kernel(s) run at a time (the other "
@@ -587,7 +692,7 @@ def main():
             "mailbox_relaunches": relaunches,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = cpu_baseline(cfg, all_cores=args.cpu_all_cores)
             if not args.no_train:
                 line["cpu_baseline"]["unet_train_step"] = cpu_unet_step()
         line["files"] = files_info
@@ -595,6 +700,7 @@ def main():
         line["train_cli"] = cli_info
         line["end_to_end_train"] = e2e_info
         line["end_to_end_gan_seg_train"] = e2e_gan_info
+        line["end_to_end_10k_epoch"] = long_info
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

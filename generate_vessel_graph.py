@@ -5,8 +5,11 @@ same outputs per sample under `<output.directory>/<YYYYmmdd_HHMMSS>_<uuid4>/`: `
 (`node1,node2,radius`), `art_ven_img_gray.png` (+ `art_ven_img_gray.npy` for save_3D_volumes: npy), written
 from GPU results: all samples are simulated in lock-step batches by the HIP simulator and rasterised by the HIP
 rasteriser. Additive flags: `--seed S` (sample k uses random.seed(S+k); np.random.seed(S+k); the reference never
-seeds), `--batch B` (samples per GPU batch, default 128), `--device N`, `--labels` (also write `<name>_label.png`, the
-1216x1216 binarised label visualize_vessel_graphs.py --binarize would render from the CSV: complete triples in one pass).
+seeds), `--batch B` (samples per GPU batch, default 512), `--device N` / `--devices 0-7` (one group of `--inflight` generator threads per
+listed GPU, all taking launches from one queue; the reference fans samples out over every worker of the machine,
+generate_vessel_graph.py:112-129), `--labels` (also write `<name>_label.png`, the 1216x1216 binarised label
+visualize_vessel_graphs.py --binarize would render from the CSV: complete triples in one pass). Under `torch.distributed.run` (one
+process per GPU) every rank takes every WORLD_SIZE-th launch on GPU LOCAL_RANK. Sample k is seeded by `--seed` + k wherever it runs.
 CSV text and PNG files are formatted / encoded natively by a pool of host threads (`--threads`) while the GPU simulates
 the next batch.
 """
@@ -36,6 +39,7 @@ def main(argv=None):
     parser.add_argument('--inflight', type=int, default=2, help="generator threads (own simulator state, rasteriser scratch and HIP stream each): one batch is on the GPU "
                         "while the other threads copy theirs out and hand them to the file writers")
     parser.add_argument('--device', type=int, default=0)
+    parser.add_argument('--devices', type=str, default=None, help="GPUs of this process, e.g. 0-7 / 0,2,5 / all: one generator group per listed GPU (overrides --device)")
     args, unknown = parser.parse_known_args(argv)
     if args.debug:
         warnings.filterwarnings('error')
@@ -53,29 +57,36 @@ def main(argv=None):
 
     import torch
     from octa_autosegmentation_amd.output_files import SampleFileWriter
-    torch.cuda.set_device(args.device)
+    from octa_autosegmentation_amd.utils import sharding
+    # placement: ranks of a torchrun job take every WORLD_SIZE-th launch on their own GPU; inside a process one generator group per device
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.devices is None and "LOCAL_RANK" in os.environ:
+        devices = [int(os.environ["LOCAL_RANK"])]
+    else:
+        devices = sharding.parse_devices(args.devices, torch.cuda.device_count()) or [args.device]
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) if world > 1 else 1
+    budget = sharding.apply_host_budget(local_world=max(local_world, len(set(devices))), generator_threads=args.inflight * len(devices),
+                                        set_affinity=world > 1)
+    torch.cuda.set_device(devices[0])
+    if args.seed is None and world > 1:
+        raise SystemExit("generate_vessel_graph.py under torch.distributed.run needs --seed (every rank must derive the same seeds)")
     seed0 = args.seed if args.seed is not None else random.SystemRandom().randrange(0, 2 ** 31 - args.num_samples - 1)
-    writer = SampleFileWriter(args.threads if args.threads > 0 else 16)
+    writer = SampleFileWriter(args.threads if args.threads > 0 else budget["writers"])
     # Batches are independent: `--inflight` generator threads (own simulator state, rasteriser scratch and HIP stream each) keep
     # that many launches of the persistent kernel on the GPU while this thread hands finished batches to the file writers -- the
     # reference's process pool over samples (generate_vessel_graph.py:112-129) with the roles of CPU and GPU exchanged.
     import queue
     import threading
     sys.setswitchinterval(0.0005)      # generator threads, the submitting thread and the writers' glue share the GIL: hand it over in 0.5 ms slices, not 5 ms ones
-    plan = []
-    done = 0
-    while done < args.num_samples:
-        B = min(args.batch, args.num_samples - done)
-        plan.append((done, B))
-        done += B
+    plan = sharding.plan_batches(args.num_samples, args.batch, rank, world)
+    n_mine = sum(n for _, n in plan)
     n_fly = max(1, min(args.inflight, len(plan)))
     todo = queue.Queue()
     for item in plan:
         todo.put(item)
-    finished = queue.Queue(maxsize=2)                     # bounds the host memory held by batches waiting for the writers
+    finished = queue.Queue(maxsize=max(2, len(devices)))                     # bounds the host memory held by batches waiting for the writers
     failure = []
     stop = threading.Event()
-    dev = torch.cuda.current_device()
     timing = os.environ.get("OCTA_CLI_TIMING", "0") == "1"
     # At most one GPU's worth of samples (512 workgroup slots on an MI355X: two samples per CU; OCTA_GPU_SLOTS) is simulated and rasterised at a time; batches beyond that
     # wait here while their threads' finished batches are copied out and handed to the writers. Two reasons (6144 samples in batches
@@ -96,10 +107,11 @@ def main(argv=None):
                 self.used -= n
                 self.cv.notify_all()
 
-    gpu_gate = _SlotGate(int(os.environ.get("OCTA_GPU_SLOTS", "512")))
+    gates = {d: _SlotGate(int(os.environ.get("OCTA_GPU_SLOTS", "512"))) for d in set(devices)}      # one gate per GPU
 
-    def generate_batches():
+    def generate_batches(dev):
         gens = {}
+        gpu_gate = gates[dev]
         try:
             torch.cuda.set_device(dev)
             stream = torch.cuda.Stream()
@@ -130,7 +142,7 @@ def main(argv=None):
                         vol_dim = [int(d) for d in shape * out_cfg['image_scale_factor']]
                         vols = []
                         for k in range(B):
-                            d_edges = torch.from_numpy(np.ascontiguousarray(res.sample_edges(k))).cuda()
+                            d_edges = torch.from_numpy(np.ascontiguousarray(res.sample_edges(k))).to(torch.device("cuda", dev))
                             na = int(res.n_art[k])
                             v = tree2img.voxelize_edges_device(d_edges, np.array([0, na, len(d_edges)]), vol_dim)
                             vols.append(torch.maximum(v[0], v[1]).cpu().numpy().astype(np.uint8))
@@ -146,7 +158,8 @@ def main(argv=None):
                 g.close()
             finished.put(None)
 
-    threads = [threading.Thread(target=generate_batches, name=f"octa-generator-{i}") for i in range(n_fly)]
+    threads = [threading.Thread(target=generate_batches, args=(d,), name=f"octa-generator-{gi}-{i}") for gi, d in enumerate(devices) for i in range(n_fly)]
+    n_fly = len(threads)
     for t in threads:
         t.start()
     done = 0
@@ -171,7 +184,7 @@ def main(argv=None):
             done += B
             if timing:
                 print(f"[cli timing] main: waited {t_b - t_a:.3f} s for the previous batch's files, submitted {B} samples in {time.time() - t_b:.3f}", file=sys.stderr, flush=True)
-            print(f"generated {done}/{args.num_samples} vessel graphs")
+            print(f"generated {done}/{n_mine} vessel graphs" + (f" (rank {rank} of {world})" if world > 1 else ""))
     finally:
         stop.set()                                         # after a failure here or in a generator: let the other threads run out
         while alive:

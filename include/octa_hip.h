@@ -468,6 +468,10 @@ void octa_bif_native(int n_req, const octa_bif_request *reqs, double *out6, void
 int octa_bif_native_counts(int64_t *h_out2);
 
 int octa_sim_create(octa_ctx *ctx, const octa_sim_config *cfg, int B, octa_sim **out);
+/* The same with the kernel build named by the caller: 0 = chosen from the configuration (octa_sim_create; OCTA_SIM_BUILD overrides),
+ * 1 = the default build (3 x 3 mm^2 capacities), 2 = the wide-field build (the reference's 12 x 12 mm^2 notebook run,
+ * example_custom_vessel_simulation.ipynb:138-156). The Python host re-runs a batch that outgrew the default capacities with 2. */
+int octa_sim_create_ex(octa_ctx *ctx, const octa_sim_config *cfg, int B, int build, octa_sim **out);
 void octa_sim_destroy(octa_sim *sim);
 
 /* Run all iterations for B samples. Synchronous (the bifurcation service needs the host). Returns 0, -1 (runtime

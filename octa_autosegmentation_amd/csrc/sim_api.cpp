@@ -59,17 +59,18 @@ static bool wants_large(const octa_sim_config *c) {
 
 #define FWD(call_s, call_l) (sim->large ? (call_l) : (call_s))
 
-extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *cfg, int B, octa_sim **out) {
-    if (!out || !cfg) { octa::set_error("octa_sim_create: bad arguments"); return -2; }
+extern "C" int octa_sim_create_ex(octa_ctx *ctx, const octa_sim_config *cfg, int B, int build, octa_sim **out) {
+    if (!out || !cfg || build < 0 || build > 2) { octa::set_error("octa_sim_create: bad arguments"); return -2; }
     *out = nullptr;
     octa_sim *sim = new (std::nothrow) octa_sim();
     if (!sim) { octa::set_error("octa_sim_create: out of host memory"); return -1; }
-    sim->large = wants_large(cfg);
+    sim->large = build == 0 ? wants_large(cfg) : build == 2;
     const int rc = sim->large ? octa_simL_create(ctx, cfg, B, &sim->l) : octa_simS_create(ctx, cfg, B, &sim->s);
     if (rc) { delete sim; return rc; }
     *out = sim;
     return 0;
 }
+extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *cfg, int B, octa_sim **out) { return octa_sim_create_ex(ctx, cfg, B, 0, out); }
 extern "C" void octa_sim_destroy(octa_sim *sim) {
     if (!sim) return;
     if (sim->large) octa_simL_destroy(sim->l); else octa_simS_destroy(sim->s);

@@ -89,15 +89,26 @@ class Compose:
             data = t(data)
         return data
 
-    def batchable(self):
+    def batchable(self, has_background=True):
         """True when the chain holds a transform with a mini-batch form (`batch_apply`: the frozen generator of
-        ImageToImageTranslationd) and may be cut there without changing any random decision: the transforms in front of the cut
-        draw from python's `random` and numpy's global stream, those behind it from torch's generator and their own
-        RandomStates, so "all prefixes, one batched call, all suffixes" consumes every stream in the per-sample order."""
+        ImageToImageTranslationd) and may be cut there without changing any random decision. "All prefixes, one batched call, all
+        suffixes" runs sample 2's prefix BEFORE sample 1's suffix, so it consumes every SHARED random stream in the per-sample
+        order only if no such stream is drawn from on both sides of the cut. Every transform declares its streams
+        (`rng_streams(has_background)`: "python" = the global `random`, "numpy" = numpy's global stream, "torch" = torch's global
+        generator; a transform's own RandomState is private and never conflicts); a transform that declares nothing counts as
+        deterministic only if it is not Randomizable and has no `R`."""
         cut = [i for i, t in enumerate(self.transforms) if hasattr(t, "batch_apply")]
         if len(cut) != 1:
             return False
-        return not any(getattr(t, "draws_from_torch", lambda: False)() for t in self.transforms[:cut[0]])
+
+        def streams(ts):
+            out = set()
+            for t in ts:
+                f = getattr(t, "rng_streams", None)
+                out |= set(f(has_background)) if f is not None else set()
+            return out
+
+        return not (streams(self.transforms[:cut[0]]) & streams(self.transforms[cut[0] + 1:]))
 
     def call_batch(self, items):
         """[sample dict] -> [sample dict]: the chain applied to a mini-batch, the `batch_apply` transform once for all samples."""
@@ -136,6 +147,9 @@ class LoadGraphAndFilterByRandomRadiusd(MapTransform):
         self.image_resolutions = image_resolutions
         self.max_dropout_prob = max_dropout_prob
         self.MIP_axis = MIP_axis
+
+    def rng_streams(self, has_background=True):
+        return {"python"}           # tree2img.py:62,78: the dropout draws come from the global `random`
 
     def __call__(self, data):
         data = dict(data)
@@ -190,6 +204,9 @@ class SpeckleBrightnesd(MapTransform):
     torch's CPU generator exactly as in the reference (same values for the same torch.manual_seed), the arithmetic runs
     on the tensor's device."""
 
+    def rng_streams(self, has_background=True):
+        return {"torch"}
+
     def __call__(self, data):
         data = dict(data)
         for key in self.present(data):
@@ -216,6 +233,9 @@ class AddRandomBackgroundNoised(MapTransform):
     def __init__(self, keys, delete_background=True) -> None:
         super().__init__(keys, True)
         self.delete_background = delete_background
+
+    def rng_streams(self, has_background=True):
+        return {"numpy"} if has_background else {"numpy", "torch"}      # torch.rand stands in for a missing background tile
 
     def __call__(self, data):
         data = dict(data)

@@ -55,7 +55,8 @@ class ListDataset:
         run it once per mini-batch (data_transforms.Compose.call_batch) -- same random decisions as sample-by-sample."""
         items = [self.items[j] for j in indices]
         t = self.transform
-        if len(items) > 1 and getattr(t, "batchable", lambda: False)() and all("background" in it for it in items):
+        has_bg = all("background" in it for it in items)
+        if len(items) > 1 and hasattr(t, "batchable") and t.batchable(has_background=has_bg):
             return t.call_batch(items)
         return [t(it) for it in items]
 
@@ -154,7 +155,7 @@ class DeviceLoader:
         self.num_workers, self.prefetch = int(num_workers), prefetch
         self.shard = (0, 1)          # (rank, world): data-parallel ranks take every world-th batch of the SAME permutation
         self.fused = None            # batch-level transform chain (FusedGraphSegBatches) replacing the per-sample one
-        self.perm_generator = None   # data-parallel runs: the permutation's own generator (same on every rank); else torch's global one
+        self.perm_generator = None   # data-parallel runs: the permutation's own generator (same on every rank); else one seeded from torch's global stream at the first epoch
 
     def reseed_augmentations(self, seed):
         """Give the random transforms of this loader their own streams (data-parallel ranks: seed + rank, so rank r's k-th batch
@@ -171,6 +172,10 @@ class DeviceLoader:
 
     def _batches(self):
         n = len(self.dataset)
+        if self.shuffle and self.perm_generator is None:
+            # as torch's DataLoader does: ONE draw from the global generator seeds a private one, so that later permutations (taken by the
+            # producer thread, possibly while the main thread uses the global stream) do not interleave with it
+            self.perm_generator = torch.Generator().manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
         order = torch.randperm(n, generator=self.perm_generator).tolist() if self.shuffle else list(range(n))     # all ranks share this stream, hence the order
         rank, world = self.shard
         starts = list(range(0, n, self.batch_size))
@@ -192,9 +197,15 @@ class DeviceLoader:
         decision of the loader is taken in this thread, in the same order as an inline loader would take it."""
         self._q = queue.Queue(maxsize=self.prefetch)
         self._stop = threading.Event()
+        self._go = threading.Semaphore(0)        # one permit per epoch the consumer has asked for (chains that share global random streams)
         dev = torch.cuda.current_device()
         stream = torch.cuda.Stream()
-        q, stop = self._q, self._stop
+        q, stop, go = self._q, self._stop, self._go
+        # Preparing epoch N + 1 while the consumer still validates / checkpoints after epoch N is only safe when every random decision of
+        # the loader comes from PRIVATE streams: the fused batch chain (own RandomStates + the private permutation generator). The
+        # per-sample chains draw from python's `random`, numpy's global stream and torch's global generator, which the main thread uses
+        # too (GAN image pool, dropout): there the producer waits for the next __iter__ (round 4; ADVICE round 3).
+        lookahead = self.fused is not None
 
         def put(item):
             while not stop.is_set():
@@ -210,6 +221,10 @@ class DeviceLoader:
                 torch.cuda.set_device(dev)
                 with torch.cuda.stream(stream):
                     while not stop.is_set():
+                        if not lookahead:
+                            while not go.acquire(timeout=0.1):
+                                if stop.is_set():
+                                    return
                         for b in self._batches():
                             ev = torch.cuda.Event()
                             ev.record(stream)
@@ -243,6 +258,7 @@ class DeviceLoader:
             return
         if getattr(self, "_thread", None) is None:
             self._start_producer()
+        self._go.release()
         complete = False
         try:
             while True:

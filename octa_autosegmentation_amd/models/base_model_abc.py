@@ -150,7 +150,9 @@ class BaseModelABC(nn.Module, ModelInterface, ABC):
             alias = config["General"].get("inference")
             net = {"S": "segmentor", "G": "generator"}.get(alias, alias)
             cands = [model_path.replace("model.pth", f"{n}_model.pth") for n in dict.fromkeys((net, alias)) if n]
-            cands += [model_path.replace("model.pth", "model_model.pth"), model_path]
+            if net in (None, "model"):       # only the un-named / `model` network may fall back to the generic files: for `S` / `G` another
+                cands += [model_path.replace("model.pth", "model_model.pth")]      # network's checkpoint would be picked silently otherwise
+            cands += [model_path]            # the reference's legacy single file `<epoch>_model.pth` (base_model_abc.py:104-107)
             checkpoint_path = next((c for c in cands if os.path.exists(c)), None)
             if checkpoint_path is None:
                 raise FileNotFoundError(f"no checkpoint for inference={alias!r}; looked for {cands}")

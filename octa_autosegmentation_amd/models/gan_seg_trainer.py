@@ -5,8 +5,6 @@ import os
 from argparse import Namespace
 from copy import deepcopy
 
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
-
 import torch
 
 from ..utils.enums import Phase

@@ -31,7 +31,7 @@ USE_F32_MFMA = True      # fp32 forward passes that record no gradient run csrc/
 # normalise-on-load (the normalised activations never go to HBM: models/mfma_conv.py) is implemented and tested but
 # measured SLOWER on MI355X (37.5 vs 31.9 ms per step): every output-channel block of a layer re-stages and
 # re-normalises the same input tile, which costs more VALU work than the two HBM passes it saves
-USE_LAZY_NORM = False
+USE_LAZY_NORM = __import__('os').environ.get('OCTA_LAZY_NORM', '0') == '1'      # re-measured in round 4 on the DMA-staged kernels: DESIGN.md 4.2c
 # InstanceNorm statistics accumulated in the convolution epilogue (conv.hip _fwd5) instead of a statistics pass:
 # implemented and tested, measured slower too (33.6 vs 32.1 ms: the MFMA kernels are the critical resource, the
 # statistics pass they would save is a cheap HBM-bound stream)

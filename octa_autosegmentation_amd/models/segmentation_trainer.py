@@ -6,9 +6,6 @@ import os
 from argparse import Namespace
 from copy import deepcopy
 
-# MIOpen's exhaustive find mode benchmarks every solver (incl. naive reference kernels) on first use:
-# minutes per process on a fresh box. The fast heuristic mode starts in seconds (set before torch loads MIOpen).
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 import torch
 
 from ..utils.enums import Phase

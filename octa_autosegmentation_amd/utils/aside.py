@@ -4,13 +4,18 @@ The post-transform of the scored sample (sigmoid, threshold, component labelling
 metric counts (utils/metrics.py) are ~35 short kernels that nothing in the step depends on; on the training stream they sit between
 forward and backward (0.3 ms of an 18 ms DynUNet-S step). `aside(device, *tensors)` runs its body on a per-device side stream that
 first waits for what the current stream has queued so far; `join_aside(device)` makes the current stream wait for the side stream
-(before scores or plotted samples are read; `Metric.aggregate` does it for the scores). OCTA_ASIDE=0 keeps everything on one stream."""
+(before scores or plotted samples are read; `Metric.aggregate` does it for the scores). OCTA_ASIDE=0 keeps everything on one stream.
+
+The side stream has its OWN octa_ctx (round 4): a context's grow-only scratch (common.h: one context is used by one stream at a time) is
+shared by the rasteriser and the component filter of the post-transform, and with an inline loader (`train.py --num_workers 0`) the
+calling thread rasterises step k + 1 on the main stream while step k's component labelling may still be running on the side stream."""
 import contextlib
 import os
 
 import torch
 
 _ASIDE = {}
+_ASIDE_CTX = {}
 
 
 def _aside_stream(device):
@@ -33,7 +38,11 @@ def aside(device, *tensors):
     for t in tensors:
         if torch.is_tensor(t) and t.is_cuda:
             t.record_stream(s)             # the allocator must not hand the block out again before the side stream is done with it
-    with torch.cuda.stream(s):
+    from .. import _native
+    idx = s.device.index
+    if idx not in _ASIDE_CTX:
+        _ASIDE_CTX[idx] = _native.new_ctx(idx)          # lives as long as the process, like the stream
+    with torch.cuda.stream(s), _native.use_ctx(_ASIDE_CTX[idx]):
         yield
 
 

@@ -29,3 +29,116 @@ def max_over_ranks(value, dist=None, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def parse_devices(spec, n_visible=None):
+    """`--devices` of the generator CLI: "0-7", "0,2,5", "all" or a single index -> list of device indices (duplicates allowed: two
+    generator groups on one GPU, which is how a one-GPU box exercises the multi-group path). Raises on an index the process cannot see."""
+    if spec is None:
+        return None
+    spec = str(spec).strip().lower()
+    if spec in ("all", "*"):
+        if n_visible is None:
+            raise ValueError("--devices all needs the number of visible GPUs")
+        out = list(range(int(n_visible)))
+    else:
+        out = []
+        for part in spec.split(","):
+            part = part.strip()
+            if not part:
+                continue
+            if "-" in part:
+                a, b = part.split("-", 1)
+                a, b = int(a), int(b)
+                if b < a:
+                    raise ValueError(f"--devices: empty range {part!r}")
+                out.extend(range(a, b + 1))
+            else:
+                out.append(int(part))
+    if not out:
+        raise ValueError("--devices names no device")
+    if n_visible is not None:
+        bad = [d for d in out if d < 0 or d >= int(n_visible)]
+        if bad:
+            raise ValueError(f"--devices: {bad} not among the {n_visible} visible GPUs")
+    return out
+
+
+def plan_batches(num_samples, batch, rank=0, world=1):
+    """(start, count) of every simulator launch this PROCESS runs. Sample k is seeded by seed0 + k wherever it runs, so the plan only
+    decides placement: the whole job is cut into launches of `batch` samples and launch j goes to rank j % world (torchrun: one
+    generator process per GPU; the reference fans samples out over a process pool, generate_vessel_graph.py:112-129). Inside a process
+    the launches are taken from one queue by all of its device groups."""
+    num_samples, batch, rank, world = int(num_samples), int(batch), int(rank), int(world)
+    assert num_samples >= 0 and batch > 0 and 0 <= rank < world
+    plan, done, j = [], 0, 0
+    while done < num_samples:
+        n = min(batch, num_samples - done)
+        if j % world == rank:
+            plan.append((done, n))
+        done += n
+        j += 1
+    return plan
+
+
+def host_budget(local_world, generator_threads=1, cores=None):
+    """Host-side budget of ONE process when `local_world` processes share the node (train.py / bench.py under torchrun, or the generator
+    CLI's device groups counted as local_world): every generator thread runs a mailbox service loop that spins between tickets and calls
+    LAPACK for the leaf bifurcations, and the file writers are host threads too. Returns the knobs the callers apply:
+    `spin_scans` (idle mailbox scans before the service thread starts sleeping; OCTA_SIM_SPIN_SCANS), `writers` (file-writer threads),
+    `blas_threads` (OPENBLAS_NUM_THREADS / OMP_NUM_THREADS for this process) and `cpu_share` (cores this process may count on).
+    Measured on the two-socket 256-thread host of the MI355X boxes: 16 writers per generator process is the optimum when one process
+    has the node to itself (DESIGN.md 4.2b'); the rest scales that down per process and never lets the spinning service threads of
+    all processes exceed half of the cores."""
+    import os
+    cores = int(cores or os.cpu_count() or 1)
+    local_world = max(1, int(local_world))
+    share = max(1, cores // local_world)
+    spinning = max(1, int(generator_threads))
+    return {
+        "cpu_share": share,
+        "spin_scans": 4096 if local_world == 1 and share >= 4 * spinning else (256 if share >= 2 * spinning else 16),
+        "writers": max(2, min(16, share // 2)),
+        "blas_threads": 1,
+    }
+
+
+def affinity_for_local_rank(local_rank, local_world, cores=None):
+    """CPU set of local rank `local_rank`: a contiguous 1/local_world share of the cores. On the two-socket hosts of the MI355X nodes GPUs
+    0-3 hang off socket 0 and 4-7 off socket 1, and Linux numbers the cores socket by socket (SMT siblings in the upper half), so
+    contiguous shares keep a rank's service and writer threads on its GPU's socket. Returns a sorted list; the caller applies it with
+    os.sched_setaffinity (and ignores a refusal: containers may pin the process already)."""
+    import os
+    cores = int(cores or os.cpu_count() or 1)
+    local_world = max(1, int(local_world))
+    local_rank = int(local_rank) % local_world
+    phys = cores // 2 if cores >= 4 else cores            # SMT siblings of core c are c and c + cores/2 on these hosts
+    per = max(1, phys // local_world)
+    base = list(range(local_rank * per, min(phys, (local_rank + 1) * per)))
+    sibs = [c + phys for c in base if c + phys < cores] if cores >= 4 else []
+    return sorted(base + sibs)
+
+
+def apply_host_budget(local_rank=None, local_world=None, generator_threads=1, set_affinity=True):
+    """Apply host_budget() / affinity_for_local_rank() to this process from LOCAL_RANK / LOCAL_WORLD_SIZE (torchrun) unless given.
+    Environment variables the user set win. Returns the budget (with the affinity that was applied, or None)."""
+    import os
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    b = host_budget(local_world, generator_threads)
+    os.environ.setdefault("OCTA_SIM_SPIN_SCANS", str(b["spin_scans"]))
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", str(b["blas_threads"]))
+    os.environ.setdefault("OMP_NUM_THREADS", str(b["blas_threads"]))
+    b["affinity"] = None
+    if set_affinity and local_world > 1 and hasattr(os, "sched_setaffinity") and os.environ.get("OCTA_NO_AFFINITY") != "1":
+        cpus = affinity_for_local_rank(local_rank, local_world)
+        try:
+            allowed = os.sched_getaffinity(0)
+            cpus = [c for c in cpus if c in allowed] or sorted(allowed)
+            os.sched_setaffinity(0, cpus)
+            b["affinity"] = cpus
+        except OSError:
+            pass
+    return b

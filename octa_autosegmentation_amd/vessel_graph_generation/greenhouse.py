@@ -273,17 +273,9 @@ class BatchSimulator:
     def _create(self, force_large=False):
         """Bind to one of the two builds of the kernel (csrc/sim_api.cpp picks from the configuration; force_large: the wide-field one)."""
         h = ctypes.c_void_p()
-        old = os.environ.get("OCTA_SIM_BUILD")
-        if force_large:
-            os.environ["OCTA_SIM_BUILD"] = "large"
-        try:
-            _native.check(self._lib.octa_sim_create(self._ctx, ctypes.byref(self._cfg), self.batch, ctypes.byref(h)), "octa_sim_create")
-        finally:
-            if force_large:
-                if old is None:
-                    os.environ.pop("OCTA_SIM_BUILD", None)
-                else:
-                    os.environ["OCTA_SIM_BUILD"] = old
+        # the build is an ARGUMENT (round 3 set the process-wide OCTA_SIM_BUILD around the call: another generator thread creating a
+        # simulator in that window got the wide-field build too, and setenv raced with the library's getenv)
+        _native.check(self._lib.octa_sim_create_ex(self._ctx, ctypes.byref(self._cfg), self.batch, 2 if force_large else 0, ctypes.byref(h)), "octa_sim_create")
         self._h = h
         self.is_large = bool(self._lib.octa_sim_is_large(h))      # bound to the wide-field build
 
@@ -302,6 +294,10 @@ class BatchSimulator:
         """Run `call` (one of the octa_sim_run* entry points on self._h). When a sample outgrew the DEFAULT build's per-sample capacities
         (sized for 3 x 3 mm^2: 14 336 nodes per forest, 13 312 sinks ...), bind to the wide-field build -- the same phase code with
         2^17 / 2^18, same bytes where both fit (tests/test_sim_gpu.py) -- and run again. OCTA_SIM_BUILD=default keeps the error."""
+        if getattr(self, "_rebound", False):      # the previous batch outgrew the default build: THIS one starts on the configuration's own build again
+            self._rebound = False
+            self.close()
+            self._create()
         rc = call()
         if rc == -3 and not self.is_large and os.environ.get("OCTA_SIM_BUILD") != "default":
             stats = np.zeros((self.batch, 32), np.int64)
@@ -313,6 +309,7 @@ class BatchSimulator:
                 warnings.warn(f"the default simulator build ran out of per-sample capacity (error bits {bits:#x}); re-running on the wide-field build")
                 self.close()
                 self._create(force_large=True)
+                self._rebound = True
                 rc = call()
         return rc
 

@@ -84,15 +84,53 @@ def rasterize_edges_device(d_edges, edge_off, image_resolution, MIP_axis=2, min_
     return out
 
 
+def _rasterize_colorized_cpu(edges, image_resolution, MIP_axis, colorize):
+    """float32 [H, W, 3] in 0..255: white-on-black geometry of the grey image, every edge in the plasma colour of its radius
+    (`continous`: radius / 0.03 clipped to 1; `dicrete`: three classes at 0.01 / 0.02 -- the reference's spellings)."""
+    if colorize not in ("continous", "dicrete"):
+        raise NotImplementedError("Colorize only supports the options 'continous' or 'discrete'!")      # the reference's message
+    try:
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        from matplotlib import cm, collections
+        from matplotlib import pyplot as plt
+    except ImportError as e:  # pragma: no cover
+        raise RuntimeError("rasterize_forest(colorize=...) draws on the CPU with matplotlib, which is not installed") from e
+    axes = [a for a in (0, 1, 2) if a != MIP_axis]
+    no_pixels_x, no_pixels_y = image_resolution
+    scale = max(no_pixels_x, no_pixels_y)
+    widths = edges[:, 6] * 1.3 * scale
+    c = widths / no_pixels_x / 1.3 * 3
+    if colorize == "continous":
+        c = np.minimum(c / 0.03, 1)
+    else:
+        c = np.where(c <= 0.01, 0.1, np.where(c <= 0.02, 0.5, 1.0))
+    segs = [[(e[axes[1]], e[axes[0]]), (e[3 + axes[1]], e[3 + axes[0]])] for e in edges]
+    fig = plt.figure(figsize=(no_pixels_x / 100, no_pixels_y / 100), dpi=100)
+    try:
+        fig.patch.set_facecolor("black")
+        ax = plt.axes([0., 0., 1., 1.], frameon=False, xticks=[], yticks=[])
+        ax.invert_yaxis()
+        ax.add_collection(collections.LineCollection(segs, linewidths=widths, colors=cm.plasma(c), antialiaseds=True, capstyle="round"))
+        fig.canvas.draw()
+        data = np.frombuffer(fig.canvas.buffer_rgba(), dtype=np.uint8)
+        img = data.reshape(fig.canvas.get_width_height()[::-1] + (4,))[:, :, :3]
+        return np.array(img.astype(np.float32))
+    finally:
+        plt.close(fig)
+
+
 def rasterize_forest(forest, image_resolution: Sequence[float], MIP_axis: int = 2, radius_list: list = None,
                      min_radius: float = 0, max_radius: float = 1, max_dropout_prob=0, blackdict=None,
                      colorize: str = None) -> Tuple[np.ndarray, dict]:
     """Same contract as the reference's rasterize_forest (tree2img.py:12-114): returns
     (uint16 [no_pixels_y, no_pixels_x] grey image in 0..255, blackdict)."""
     import torch
-    if colorize is not None:
-        raise NotImplementedError("colorize is a visualisation option outside the MI355X hot path")
     edges, blackdict = select_edges(forest, min_radius, max_radius, max_dropout_prob, blackdict, radius_list)
+    if colorize is not None:
+        # visualisation option (radius-coloured RGB, tree2img.py:87-113), off the hot path: drawn on the CPU by matplotlib's Agg, the
+        # reference's own rasteriser (SURVEY.md 8b allows the CPU here); edge selection, random draws and side effects are the same
+        return _rasterize_colorized_cpu(edges, image_resolution, MIP_axis, colorize), blackdict
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
     if dev is None:
         _native.ctx()  # raises: no CPU fallback

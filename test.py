@@ -71,6 +71,7 @@ def main(argv=None):
             if config["Output"].get("save_comparisons"):
                 plot_sample(save_dir, test_mini_batch["image"][0], outputs["prediction"][0], None,
                             test_mini_batch[f"{input_key}_path"][0], suffix=f"{inference_mode}_{image_name}", full_size=True)
+    test_loader.close()         # one pass: stop the loader's thread
     print(f"wrote {len(written)} predictions to {save_dir}")
     return written
 

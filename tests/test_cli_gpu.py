@@ -83,3 +83,52 @@ def test_generate_cli_keeps_batches_in_flight(tmp_path, hip_lib_built):
         # 304 x 304 x (3 + the voxeliser's padding of the thin axis, tree2img.py: the same volume `npy` output stores)
         assert dims[0] == 3 and dims[1:3] == (304, 304) and dims[3] >= 3 and len(raw) == 352 + dims[1] * dims[2] * dims[3]
     assert not want
+
+
+def test_generate_cli_device_groups_and_rank_plans_give_the_same_files(tmp_path, hip_lib_built, monkeypatch):
+    """--devices (round 4): two generator groups (the one GPU of the box listed twice) taking launches from one queue, and the two halves
+    of a 2-rank torchrun job (RANK 0 and RANK 1 run one after the other), write the same CSV texts as a single-device run: sample k is
+    seeded by --seed + k wherever it runs (the reference fans samples out over a process pool, generate_vessel_graph.py:112-129)."""
+    import hashlib
+    import sys
+    sys.path.insert(0, ROOT)
+    import generate_vessel_graph
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_golden.npz"))
+    cfg = yaml.safe_load(str(g["config_yaml"]))
+    cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = 10, 5
+    cfg_path = tmp_path / "cfg.yml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+
+    def run(out, extra, env=()):
+        for k, v in env:
+            monkeypatch.setenv(k, v)
+        generate_vessel_graph.main(["--config_file", str(cfg_path), "--num_samples", "11", "--batch", "3", "--seed", "40", "--output.directory", str(out)] + extra)
+        for k, _ in env:
+            monkeypatch.delenv(k)
+        texts = []
+        for d in glob.glob(str(out / "*")):
+            name = os.path.basename(d)
+            texts.append(hashlib.sha256(open(os.path.join(d, name + ".csv"), "rb").read()).hexdigest())
+        return sorted(texts)
+
+    one = run(tmp_path / "one", ["--device", "0"])
+    assert len(one) == 11 and len(set(one)) == 11
+    assert run(tmp_path / "two", ["--devices", "0,0", "--inflight", "2"]) == one
+    halves = run(tmp_path / "r0", [], env=(("RANK", "0"), ("WORLD_SIZE", "2"), ("LOCAL_RANK", "0"), ("LOCAL_WORLD_SIZE", "2"), ("OCTA_NO_AFFINITY", "1")))
+    halves += run(tmp_path / "r1", [], env=(("RANK", "1"), ("WORLD_SIZE", "2"), ("LOCAL_RANK", "0"), ("LOCAL_WORLD_SIZE", "2"), ("OCTA_NO_AFFINITY", "1")))
+    assert sorted(halves) == one
+    with pytest.raises(ValueError):
+        generate_vessel_graph.main(["--config_file", str(cfg_path), "--num_samples", "1", "--devices", "0-9", "--output.directory", str(tmp_path / "bad")])
+
+
+def test_side_stream_work_has_its_own_context(hip_lib_built):
+    """utils/aside.py: the scored sample's post-transform (component labelling) runs on a side stream with a context of its own -- the
+    rasteriser of the next step may use the calling thread's context on the main stream at the same time (train.py --num_workers 0)."""
+    import torch
+    from octa_autosegmentation_amd import _native
+    from octa_autosegmentation_amd.utils import aside
+    mine = _native.ctx().value
+    with aside.aside(torch.device("cuda", 0)):
+        inside = _native.ctx().value
+        assert torch.cuda.current_stream() != torch.cuda.default_stream()
+    assert inside != mine and _native.ctx().value == mine

@@ -312,6 +312,21 @@ def test_batched_translation_chain_takes_the_per_sample_decisions():
     random.seed(1); np.random.seed(1); torch.manual_seed(1)
     ref = [nob[i] for i in range(3)]
     assert all(torch.equal(a["image"], b["image"]) for a, b in zip(out, ref))
+    assert not nob.transform.batchable(has_background=False) and nob.transform.batchable(has_background=True)
+    # a chain with the speckle transform (torch's stream) IN FRONT of the cut and another torch user behind it must not be reordered:
+    # the guard reads the transforms' declared streams (round 3 asked for an attribute no transform defined)
+    swapped = [aug[0], aug[2], aug[1], {"name": "SpeckleBrightnesd", "keys": ["image"]}] + aug[3:]
+    sw = ListDataset(items, T.Compose(T.get_data_augmentations(swapped, seed=5)))
+    assert not sw.transform.batchable()
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    out = sw.get_batch([0, 1, 2])
+    sw = ListDataset(items, T.Compose(T.get_data_augmentations(swapped, seed=5)))
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    ref = [sw[i] for i in range(3)]
+    assert all(torch.equal(a["image"], b["image"]) for a, b in zip(out, ref))
+    # one torch user in front of the cut and none behind it is fine
+    front = [aug[0], aug[2], aug[1]] + aug[3:]
+    assert ListDataset(items, T.Compose(T.get_data_augmentations(front, seed=5))).transform.batchable()
 
 
 def test_f32_weight_pack_cache_cannot_serve_a_collected_parameters_copy():

@@ -192,3 +192,42 @@ def test_gtrig_is_glibc_sin_cos_acos(core):
     assert (out[:, 0] == np.array([math.sin(v) for v in x])).all()
     assert (out[:, 1] == np.array([math.cos(v) for v in x])).all()
     assert (out[:, 2] == np.array([math.acos(v) for v in c])).all()
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_phase_code_is_clean_under_address_and_ub_sanitizers(tmp_path, golden, large):
+    """The simulator's phase code (csrc/sim_core.h) compiled for the host with -fsanitize=address,undefined and run on a short seeded
+    simulation in a child process (libasan must be the first library of the process): no report, and the CSV text still equals the
+    reference's. GPU AddressSanitizer is not available on the MI355X pool; this host build found two out-of-bounds writes of the
+    wide-field build in round 3 and is the standing recipe for that class of defect."""
+    import sys
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan not installed")
+    so = str(tmp_path / ("libsimcorehost_asan_large.so" if large else "libsimcorehost_asan.so"))
+    src = os.path.join(ROOT, "tests", "native", "sim_core_host.cpp")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"] + (["-DOCTA_SIM_LARGE=1"] if large else []) + ["-o", so, src])
+    name = "run_s0_30_20"
+    child = f'''
+import ctypes, sys, hashlib
+import numpy as np, yaml
+sys.path.insert(0, {ROOT!r})
+from oracle import sim_oracle
+g = np.load({os.path.join(ROOT, "tests", "golden", "sim_golden.npz")!r})
+cfg = yaml.safe_load(str(g["config_yaml"]))
+cfg["Greenhouse"]["modes"][0]["I"], cfg["Greenhouse"]["modes"][1]["I"] = 30, 20
+l = ctypes.CDLL({so!r})
+l.octa_simcore_host_run.restype = ctypes.c_int
+l.octa_simcore_host_run.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_ulonglong, sim_oracle.BIF_CB, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
+p = sim_oracle.params_from_config(cfg)
+edges = np.zeros((40000, 7)); trace = np.zeros((50, 4), np.int64); info = np.zeros(8, np.int64)
+rc = l.octa_simcore_host_run(ctypes.addressof(p), 0, 0, sim_oracle._bif_cb, edges.ctypes.data, 40000, trace.ctypes.data, info.ctypes.data)
+assert rc == 0 and info[2] == 0, (rc, info)
+text = sim_oracle.edges_to_csv_text(edges[: info[0]])
+assert text.encode() == g["{name}_csv"].tobytes()
+print("SANITIZED-RUN-OK", info[0])
+'''
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=66", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, "-c", child], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "SANITIZED-RUN-OK" in r.stdout and "ERROR: AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout, r.stdout[-3000:]

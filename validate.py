@@ -43,6 +43,7 @@ def main(argv=None):
             # fp32 like the reference's validate.py (no autocast): DynUNet's convolutions on the exact-fp32 MFMA kernel (csrc/conv_f32.hip)
             outputs, losses = model.inference(val_mini_batch, post_transformations_val, device=device, phase=Phase.VALIDATION)
             model.compute_metric(outputs, metrics)
+    val_loader.close()          # one pass: the loader's thread must not go on preparing an epoch nobody reads (nor touch HIP at interpreter shutdown)
     result = {k: float(str(round(v, 3))) for k, v in metrics.aggregate_and_reset(Phase.VALIDATION).items()}
     print(f"Metrics: {result}")
     return result
