@@ -26,6 +26,8 @@
 //
 // All floating point here is IEEE double compiled with -ffp-contract=off.
 
+#include <cstdlib>
+
 #include "common.h"
 #include "raster_core.h"
 
@@ -567,6 +569,94 @@ fs_dither_kernel(const unsigned char *__restrict__ in, int W, int H, int band_ro
     }
 }
 
+// ---- Floyd-Steinberg as a pipeline of waves (round 4) ---------------------------------------------------------------
+// The kernel above runs the 19 bands of a 1216-row label one after the other on ONE wave: (W + 127) x 19 = 25 500 serial steps. Band
+// b + 1 only needs, for its first row at column x, the error term the LAST row of band b left at column x + 1 -- which that row
+// produces 2 x 63 steps after the band's first row reached the column. So the bands run as a pipeline: one workgroup per image, wave w
+// takes bands w, w + NW, ...; the last row of a band leaves its error terms in the band's own LDS row (no reuse, hence no
+// back-pressure) and publishes its step count every DP_PUB steps; the wave of the next band starts each chunk of DP_PUB steps once the
+// producer is DP_LAG steps ahead. 18 x 144 + 1343 = 3 900 step times instead of 25 500. Nothing is staged in LDS but the error rows:
+// a lane keeps the 16 pixels of its row it is working on and the next 16 in registers (two 16-byte loads in flight per lane).
+// Same arithmetic, same order of operations per row as Pillow's (ImagingConvert L -> 1): bit-identical to fs_dither_kernel.
+constexpr int DP_PUB = 16;                    // steps between two publications of a band's progress
+constexpr int DP_LAG = 2 * 63 + DP_PUB + 2;   // steps the producer must be ahead of the start of a consumer chunk
+
+__global__ void __launch_bounds__(1024)
+fs_dither_pipe_kernel(const unsigned char *__restrict__ in, int W, int H, int n_bands, unsigned char *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *progress = reinterpret_cast<int *>(smem);                              // [n_bands] steps completed by band b (INT_MAX: done)
+    int *errs = reinterpret_cast<int *>(smem) + ((n_bands + 3) & ~3);           // [n_bands][W + 2]
+    const int ES = W + 2;
+    const int img = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned char *src = in + (size_t)img * W * H;
+    unsigned char *dst = out + (size_t)img * W * H;
+    for (int i = threadIdx.x; i < n_bands; i += blockDim.x) progress[i] = 0;
+    __syncthreads();
+    for (int b = wv; b < n_bands; b += nw) {
+        const int row0 = b * 64;
+        const int rows = min(64, H - row0);
+        const bool row_ok = lane < rows;
+        const int y = row0 + (row_ok ? lane : 0);
+        const uint4 *my_row = reinterpret_cast<const uint4 *>(src + (size_t)y * W);
+        unsigned char *my_out_row = dst + (size_t)y * W;
+        const int *err_in = b > 0 ? errs + (size_t)(b - 1) * ES : nullptr;
+        int *err_out = errs + (size_t)b * ES;
+        volatile int *prog_in = b > 0 ? progress + (b - 1) : nullptr;
+        const int nblk = W / 16;
+        uint4 cur = my_row[0];
+        uint4 nxt = nblk > 1 ? my_row[1] : make_uint4(0, 0, 0, 0);
+        int l = 0, l0 = 0, l1 = 0, e_out = 0;
+        unsigned obuf = 0;
+        const int steps = (W + 1) + 2 * (rows - 1);
+        const bool last_row = lane == rows - 1;
+        int perr = 0;
+        for (int t0 = 0; t0 < steps; t0 += DP_PUB) {
+            if (prog_in) {                                    // the band above must be DP_LAG steps ahead of this chunk (or finished)
+                const int need = t0 + DP_LAG;
+                while (*prog_in < need) __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            if (t0 == 0) perr = err_in ? err_in[1] : 0;       // lane 0, step 0: errors[x + 1]
+            const int t1 = min(t0 + DP_PUB, steps);
+            for (int t = t0; t < t1; t++) {
+                const int x = t - 2 * lane;
+                const int perr_next = err_in ? err_in[min(t + 2, W)] : 0;          // what lane 0 needs in step t + 1 (one address for all lanes)
+                int up = __builtin_amdgcn_update_dpp(0, e_out, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                if (lane == 0) up = (x < W) ? perr : 0;
+                const bool active = row_ok && (unsigned)x < (unsigned)W;
+                const int sh = 8 * (x & 3);
+                const int v = (int)((cur.x >> sh) & 255u) + (l + up) / 16;
+                const int lc = v <= 0 ? 0 : (v < 256 ? v : 255);
+                const int o = (lc > 128) ? 255 : 0;
+                const int e = lc - o;
+                const int my_out = active ? 3 * e + l0 : ((row_ok && x == W) ? l0 : e_out);
+                l0 = active ? 5 * e + l1 : l0;
+                l1 = active ? e : l1;
+                l = active ? 7 * e : l;
+                obuf = active ? (obuf | ((unsigned)o << sh)) : obuf;
+                if (active && (x & 3) == 3) *reinterpret_cast<unsigned *>(my_out_row + (x - 3)) = obuf;
+                obuf = (x & 3) == 3 ? 0u : obuf;
+                if (last_row && x >= 0 && x <= W) err_out[x] = my_out;
+                e_out = my_out;
+                perr = perr_next;
+                // the lane's pixel window: the next word every 4 pixels, the next 16-byte block every 16 (and the block after that goes in flight)
+                if (x >= 0 && (x & 3) == 3) {
+                    if ((x & 15) == 15) {
+                        cur = nxt;
+                        const int kb = (x >> 4) + 2;
+                        if (kb < nblk && row_ok) nxt = my_row[kb];
+                    } else {
+                        cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) *(volatile int *)(progress + b) = t1 >= steps ? 0x7fffffff : t1;
+        }
+    }
+}
+
 __global__ void max_u8_kernel(const unsigned char *a, const unsigned char *b, unsigned char *o, size_t n) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (i + 16 <= n) {
@@ -658,6 +748,19 @@ extern "C" int octa_fs_dither(octa_ctx *ctx, int B, const uint8_t *d_in, int W, 
     if (!d_in || !d_out || W <= 0 || H <= 0) { octa::set_error("octa_fs_dither: bad arguments"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    {   // the pipelined form (round 4): rows 16-byte aligned, all bands' error rows in LDS; OCTA_DITHER_PIPE=0 keeps the one-wave kernel
+        static const bool pipe_on = [] { const char *e = getenv("OCTA_DITHER_PIPE"); return !(e && e[0] == '0'); }();
+        const int n_bands = (H + 63) / 64;
+        const size_t lds_pipe = ((size_t)((n_bands + 3) & ~3) + (size_t)n_bands * (W + 2)) * sizeof(int);
+        if (pipe_on && W % 16 == 0 && (reinterpret_cast<size_t>(d_in) & 15) == 0 && (reinterpret_cast<size_t>(d_out) & 3) == 0 && n_bands >= 2 &&
+            lds_pipe <= 150 * 1024) {
+            const int nw = n_bands < 16 ? n_bands : 16;
+            OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fs_dither_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe));
+            hipLaunchKernelGGL(fs_dither_pipe_kernel, dim3((unsigned)B), dim3(64 * nw), lds_pipe, stream, d_in, W, H, n_bands, d_out);
+            OCTA_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     const int err_bytes = (((W + 1) * 4 + 15) / 16) * 16;
     int rs_words = (W + 3) / 4 + 1;                                    // one spare word; an odd word count keeps the 64 rows on 64 different banks
     if (rs_words % 2 == 0) rs_words++;

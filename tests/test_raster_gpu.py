@@ -81,6 +81,30 @@ def test_fs_dither_random_images_of_odd_sizes_match_the_oracle(t2i):
             assert (out[b] == octa_oracle.fs_dither(x[b])).all(), (B, H, W, b)
 
 
+def test_fs_dither_pipeline_of_waves_matches_the_oracle_and_the_one_wave_kernel(t2i, monkeypatch):
+    """Round 4: images whose rows are 16-byte aligned take the pipelined kernel (bands of 64 rows on the waves of one workgroup, error
+    rows handed over through LDS): 2 to 19+ bands, ragged last bands, more bands than waves (17 x 64 + 5 rows), batches, noise that keeps
+    every error term alive -- all equal to the oracle, and to the one-wave kernel (OCTA_DITHER_PIPE is read once per process, so the
+    one-wave kernel is reached through a width that is no multiple of 16)."""
+    import torch
+    from oracle import octa_oracle
+    rng = np.random.default_rng(17)
+    for (B, H, W) in [(2, 65, 64), (3, 128, 304), (1, 129, 16), (2, 200, 320), (1, 1093, 1216), (2, 1216, 1216), (1, 1300, 608)]:
+        x = rng.integers(0, 256, (B, H, W), dtype=np.uint8)
+        x[0, : H // 2] = np.minimum(x[0, : H // 2], 140)
+        if B > 1:
+            x[1] = (rng.random((H, W)) < 0.1) * rng.integers(1, 256, (H, W))      # mostly black, like a label
+        out = t2i.binarize_label_device(torch.from_numpy(x).cuda()).cpu().numpy()
+        for b in range(B):
+            assert (out[b] == octa_oracle.fs_dither(x[b])).all(), (B, H, W, b)
+    # same picture through both kernels: pad a 16-aligned image by one column of zeros on the right (the extra column only receives error)
+    x = rng.integers(0, 256, (1, 300, 304), dtype=np.uint8)
+    a = t2i.binarize_label_device(torch.from_numpy(x).cuda()).cpu().numpy()[0]
+    xp = np.concatenate([x, np.zeros((1, 300, 1), np.uint8)], axis=2)
+    bq = t2i.binarize_label_device(torch.from_numpy(np.ascontiguousarray(xp)).cuda()).cpu().numpy()[0]
+    assert (bq == octa_oracle.fs_dither(xp[0])).all() and (a == octa_oracle.fs_dither(x[0])).all()
+
+
 def test_random_vs_oracle_and_ragged_batch(t2i):
     from oracle import octa_oracle
     rng = np.random.default_rng(99)
