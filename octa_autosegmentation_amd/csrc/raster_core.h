@@ -411,6 +411,84 @@ OCTA_HD inline void hline_eval(int hx1, int hy1, int hx2, int hy2, HStep st, int
     }
 }
 
+// One scanline piece walked CELL BY CELL (agg render_hline) inside the pixel columns [bx0, bx0 + bw): emit(px, cover, area) for every
+// cell of the piece in that window; returns the cover of the piece's cells LEFT of bx0 (they reach the window's pixels only as cover
+// carried in: a pixel's C is the cover of all cells at or left of it). Cells right of the window contribute nothing. Same boundary
+// values as hline_eval (Y(xb) = hy1 + floor(... / |dx|), first boundary by one division, the following ones by the DDA step), so
+// carry + sum of the emitted covers up to px equals hline_eval's C[px], and the emitted area its A[px] -- integer for integer. This is
+// the item-parallel form of the fold (round 4): a lane owns one piece and adds its cells into a per-block accumulator.
+template <class F>
+OCTA_HD inline int hline_cells(int hx1, int hy1, int hx2, int hy2, HStep st, int bx0, int bw, F &&emit) {
+    if (hy1 == hy2) return 0;
+    const int ex1 = hx1 >> 8, ex2 = hx2 >> 8;
+    const int fx1 = hx1 & 255, fx2 = hx2 & 255;
+    const int dy = hy2 - hy1;
+    const int bx1 = bx0 + bw - 1;
+    if (ex1 == ex2) {
+        if (ex1 < bx0) return dy;
+        if (ex1 <= bx1) emit(ex1, dy, (fx1 + fx2) * dy);
+        return 0;
+    }
+    if (hx2 >= hx1) {
+        // left to right: boundary xb (between cells xb - 1 and xb) inside the piece for ex1 < xb <= ex2,
+        // Y(xb) = hy1 + floor(((256 - fx1) + (xb - ex1 - 1) * 256) * dy / dxh)
+        if (ex1 > bx1) return 0;
+        if (ex2 < bx0) return dy;
+        const int dxh = hx2 - hx1;
+        int px = ex1 > bx0 ? ex1 : bx0;
+        int r, q, yl, carry = 0;
+        if (px > ex1) {
+            q = floordivmod_i(((256 - fx1) + (px - ex1 - 1) * 256) * dy, dxh, r);      // Y(px) - hy1 = cover of the cells left of px
+            yl = hy1 + q;
+            carry = q;
+            r += st.rem; q += st.lift;
+            if (r >= dxh) { r -= dxh; q++; }
+        } else {
+            yl = hy1;
+            q = floordivmod_i((256 - fx1) * dy, dxh, r);                               // Y(ex1 + 1) - hy1
+        }
+        const int last = ex2 < bx1 ? ex2 : bx1;
+        for (; px <= last; px++) {
+            const int yr = (px == ex2) ? hy2 : hy1 + q;
+            const int cov = yr - yl;
+            const int fxin = (px == ex1) ? fx1 : 0, fxout = (px == ex2) ? fx2 : 256;
+            emit(px, cov, (fxin + fxout) * cov);
+            yl = yr;
+            r += st.rem; q += st.lift;
+            if (r >= dxh) { r -= dxh; q++; }
+        }
+        return carry;
+    }
+    // right to left: cells ex1 down to ex2; boundary xb inside the piece for ex2 < xb <= ex1,
+    // Y(xb) = hy1 + floor((fx1 + (ex1 - xb) * 256) * dy / dxh); a cell is entered at its right boundary and left at its left one
+    if (ex2 > bx1) return 0;
+    if (ex1 < bx0) return dy;
+    const int dxh = hx1 - hx2;
+    int px = ex1 < bx1 ? ex1 : bx1;
+    int r, q, yr;
+    if (px < ex1) {
+        q = floordivmod_i((fx1 + (ex1 - px - 1) * 256) * dy, dxh, r);                  // Y(px + 1) - hy1
+        yr = hy1 + q;
+        r += st.rem; q += st.lift;
+        if (r >= dxh) { r -= dxh; q++; }
+    } else {
+        yr = hy1;
+        q = floordivmod_i(fx1 * dy, dxh, r);                                           // Y(ex1) - hy1
+    }
+    const int first = ex2 > bx0 ? ex2 : bx0;
+    int yl = yr;
+    for (; px >= first; px--) {
+        yl = (px == ex2) ? hy2 : hy1 + q;
+        const int cov = yl - yr;
+        const int fxin = (px == ex1) ? fx1 : 256, fxout = (px == ex2) ? fx2 : 0;
+        emit(px, cov, (fxin + fxout) * cov);
+        yr = yl;
+        r += st.rem; q += st.lift;
+        if (r >= dxh) { r -= dxh; q++; }
+    }
+    return ex2 < bx0 ? hy2 - yl : 0;          // yl = Y(bx0) after the last cell of the window
+}
+
 // The piece of one polygon side (24.8 fixed point) that lies in scanline py, in Agg's render_hline terms:
 // from (hx1, hy1) to (hx2, hy2) with hy in [0, 256]. Returns false if the side does not touch the scanline
 // or the piece has no vertical extent (it then contributes nothing).

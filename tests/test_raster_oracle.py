@@ -75,12 +75,26 @@ def test_kernel_arithmetic_on_host(raster_golden):
         assert n >= 0
         return out
 
+    ch.octa_corehost_rasterize_acc.restype = ctypes.c_long
+    ch.octa_corehost_rasterize_acc.argtypes = ch.octa_corehost_rasterize.argtypes
+
+    def core_acc(e, W, H, mip=2):
+        """the item-parallel form of the fold (round 4): pieces walked cell by cell into per-block accumulators (hline_cells)"""
+        e = np.ascontiguousarray(e, dtype=np.float64)
+        out = np.zeros((H, W), np.uint8)
+        n = ch.octa_corehost_rasterize_acc(e.ctypes.data, len(e), W, H, mip, -np.inf, np.inf, None, out.ctypes.data)
+        assert n >= 0
+        return out
+
     g = raster_golden
     for t in range(int(g["n_syn"])):
         W, H, mip = (int(v) for v in g[f"syn{t}_res"])
         assert (core(g[f"syn{t}_edges"], W, H, mip) == g[f"syn{t}_img"]).all(), f"synthetic case {t}"
+        assert (core_acc(g[f"syn{t}_edges"], W, H, mip) == g[f"syn{t}_img"]).all(), f"synthetic case {t} (accumulator form)"
     assert (core(g["graph0_edges"], 304, 304) == g["graph0_img304"]).all()
     assert (core(g["graph1_edges"], 1216, 1216) == g["graph1_img1216"]).all()
+    assert (core_acc(g["graph0_edges"], 304, 304) == g["graph0_img304"]).all()
+    assert (core_acc(g["graph1_edges"], 1216, 1216) == g["graph1_img1216"]).all()
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/datasets/labels"), reason="reference datasets not present")
