@@ -298,8 +298,9 @@ def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4):
                       "restated from MONAI's documentation (MONAI absent: parity with MONAI itself unpinned)",
             "implementation": "channels-last bf16 on hand-written HIP kernels: MFMA 3x3 conv forward / data gradient / weight "
                               "gradient (csrc/conv.hip; skip-connection gradients in the data-gradient epilogue), NHWC InstanceNorm+LeakyReLU "
-                              "(csrc/norm.hip; the last one fused with the 1x1 output convolution), one-launch weight packing; hipBLASLt "
-                              "only for the 1x1 transposed convolution at the bottleneck; flat RCCL gradient all-reduce"}
+                              "(csrc/norm.hip; the last one fused with the 1x1 output convolution), one-launch weight packing; the 1x1 transposed "
+                              "convolution at the bottleneck on the same MFMA kernels with a one-tap mask (round 4: no vendor-library kernel in the step; "
+                              "OCTA_CONVT1X1=blas is the hipBLASLt route, 1.4 % faster); flat RCCL gradient all-reduce"}
 
 
 def files_leg(gen, stream, seeds, threads=None):

@@ -334,6 +334,9 @@ int octa_speckle_brightness(octa_ctx *ctx, const float *d_img, const float *d_gr
                             int *d_minmax, void *stream);
 int octa_resize_bilinear(octa_ctx *ctx, const void *d_in, int in_dtype, int B, int h, int w, float *d_out, int H, int W,
                          const float *d_mul, const float *d_add, void *stream);
+/* Adjoint of octa_resize_bilinear (float32, identity intensity map): d_dy [B][H][W] -> d_dx [B][h][w], the gradient of the bilinear
+ * up-sampling GanSegModel applies in front of its segmentor (models/gan_seg_model.py:61,101-106: F.interpolate(x, upshape, "bilinear")). */
+int octa_resize_bilinear_bwd(octa_ctx *ctx, const float *d_dy, int B, int h, int w, int H, int W, float *d_dx, void *stream);
 int octa_flip_rot90_rotate(octa_ctx *ctx, const float *d_in, float *d_out, int B, int N, const float *d_angle, const int *d_rot_k,
                            const int *d_flip, float threshold, int use_threshold, void *stream);
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     "octa_instnorm_nhwc_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, ctypes.c_float, c_void_p]),
     "octa_scale_shift_lrelu_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, ctypes.c_float, c_void_p]),
     "octa_resize_bilinear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "octa_resize_bilinear_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "octa_flip_rot90_rotate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int, c_void_p]),
     "octa_remove_small_objects": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint8, c_void_p, c_void_p]),
     "octa_reflect_pad_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -45,6 +45,48 @@ resize_bilinear_kernel(const T *__restrict__ in, int h, int w, float *__restrict
     out[((size_t)b * H + Y) * W + X] = h0l * (w0l * p00 + w1l * p01) + h1l * (w0l * p10 + w1l * p11);
 }
 
+// Adjoint of resize_bilinear_kernel (identity intensity map): dx[iy][ix] = sum over the output pixels whose two-by-two taps include
+// (iy, ix) of their weight for it times dy. Gather form: a thread owns one SOURCE pixel and walks the few output rows / columns that
+// can name it (no atomics, fixed summation order); the weights are recomputed with the forward's own expressions, so forward and
+// adjoint agree to the last bit of every weight (GanSegModel's 304 -> 1216 up-sampling in front of the segmentor,
+// models/gan_seg_model.py:61,101-106).
+__device__ __forceinline__ float tap_weight(float ratio, int src, int n_src, int dst) {      // weight of source index `src` in output index `dst`
+    const float r = src_index(ratio, dst);
+    const int i1 = (int)r;
+    const int p = i1 < n_src - 1 ? 1 : 0;
+    const float l1 = r - (float)i1, l0 = 1.f - l1;
+    float wgt = 0.f;
+    if (i1 == src) wgt += l0;
+    if (i1 + p == src) wgt += l1;
+    return wgt;
+}
+__global__ void __launch_bounds__(256)
+resize_bilinear_bwd_kernel(const float *__restrict__ dy, int h, int w, int H, int W, float *__restrict__ dx) {
+    const int b = blockIdx.z, iy = blockIdx.y, ix = blockIdx.x * 256 + threadIdx.x;
+    if (ix >= w) return;
+    const float rh = (float)h / (float)H, rw = (float)w / (float)W;
+    // output indices that can touch source index i: src_index(dst) in (i - 1, i + 1)  =>  dst in ((i - 0.5) / ratio - 0.5, (i + 1.5) / ratio - 0.5)
+    int y0 = (int)floorf(((float)iy - 0.5f) / rh - 0.5f) - 1, y1 = (int)ceilf(((float)iy + 1.5f) / rh - 0.5f) + 1;
+    int x0 = (int)floorf(((float)ix - 0.5f) / rw - 0.5f) - 1, x1 = (int)ceilf(((float)ix + 1.5f) / rw - 0.5f) + 1;
+    y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+    y1 = y1 > H - 1 ? H - 1 : y1; x1 = x1 > W - 1 ? W - 1 : x1;
+    if (iy == 0) y0 = 0;                 // clamped source coordinates: every output row above the first source row maps onto it
+    if (ix == 0) x0 = 0;
+    float acc = 0.f;
+    const float *g = dy + (size_t)b * H * W;
+    for (int Y = y0; Y <= y1; Y++) {
+        const float wy = tap_weight(rh, iy, h, Y);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int X = x0; X <= x1; X++) {
+            const float wx = tap_weight(rw, ix, w, X);
+            if (wx != 0.f) row += wx * g[(size_t)Y * W + X];
+        }
+        acc += wy * row;
+    }
+    dx[((size_t)b * h + iy) * w + ix] = acc;
+}
+
 // One tap of the rotated image's source: (iy, ix) indexes the image AFTER flip and rot90; map it back to the stored one.
 // torch.rot90(x, k, (H, W)) on a square image: k = 1: out[i][j] = in[j][N-1-i]; k = 2: in[N-1-i][N-1-j]; k = 3: in[N-1-j][i].
 __device__ __forceinline__ float tap(const float *img, int N, int iy, int ix, int k, int flip) {
@@ -189,6 +231,16 @@ extern "C" int octa_resize_bilinear(octa_ctx *ctx, const void *d_in, int in_dtyp
     if (in_dtype == 0) hipLaunchKernelGGL(resize_bilinear_kernel<unsigned char>, grid, dim3(256), 0, stream, static_cast<const unsigned char *>(d_in), h, w, d_out, H, W, d_mul, d_add);
     else if (in_dtype == 1) hipLaunchKernelGGL(resize_bilinear_kernel<float>, grid, dim3(256), 0, stream, static_cast<const float *>(d_in), h, w, d_out, H, W, d_mul, d_add);
     else { octa::set_error("octa_resize_bilinear: in_dtype must be 0 (uint8) or 1 (float32)"); return -2; }
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_resize_bilinear_bwd(octa_ctx *ctx, const float *d_dy, int B, int h, int w, int H, int W, float *d_dx, void *stream_) {
+    if (!ctx || !d_dy || !d_dx || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || B > 65535 || h > 65535) { octa::set_error("octa_resize_bilinear_bwd: bad arguments"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)B);
+    hipLaunchKernelGGL(resize_bilinear_bwd_kernel, grid, dim3(256), 0, stream, d_dy, h, w, H, W, d_dx);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }

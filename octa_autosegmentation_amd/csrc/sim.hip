@@ -20,6 +20,7 @@
 #include "sim_host.h"
 #include <thread>
 #include <cstdlib>
+#include <cstring>
 
 using namespace OCTA_SIMK;
 
@@ -651,7 +652,12 @@ template <class T>
 int dev_alloc(OCTA_SIM_T *S, T **p, size_t count) {
     void *q = nullptr;
     size_t bytes = count * sizeof(T);
-    hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+    // experiment knob (DESIGN.md 4.1 "Open"): OCTA_SIM_ALLOC=finegrained | uncached places the simulator's HBM state in fine-grained /
+    // uncached device memory (other MTYPE: other caching rules of the vector L1 and the L2)
+    static const int alloc_mode = [] { const char *e = getenv("OCTA_SIM_ALLOC"); return !e ? 0 : (!strcmp(e, "finegrained") ? 1 : (!strcmp(e, "uncached") ? 2 : 0)); }();
+    hipError_t e = alloc_mode == 1 ? hipExtMallocWithFlags(&q, bytes ? bytes : 16, hipDeviceMallocFinegrained)
+                 : alloc_mode == 2 ? hipExtMallocWithFlags(&q, bytes ? bytes : 16, hipDeviceMallocUncached)
+                                   : hipMalloc(&q, bytes ? bytes : 16);
     if (e != hipSuccess) { octa::set_error("octa_sim: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return -1; }
     S->allocs.push_back(q);
     S->bytes += bytes;

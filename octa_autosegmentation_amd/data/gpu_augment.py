@@ -35,6 +35,33 @@ def resize_bilinear(x, size, mul=None, add=None):
     return out
 
 
+def resize_bilinear_bwd(dy, size):
+    """Adjoint of resize_bilinear: dy CUDA float32 [B,H,W] -> float32 [B,h,w] with size = (h, w)."""
+    assert dy.is_cuda and dy.dim() == 3 and dy.is_contiguous() and dy.dtype == torch.float32
+    B, H, W = dy.shape
+    dx = torch.empty((B, int(size[0]), int(size[1])), dtype=torch.float32, device=dy.device)
+    rc = _native.lib().octa_resize_bilinear_bwd(_native.ctx(dy.device.index), _p(dy), B, dx.shape[1], dx.shape[2], H, W, _p(dx), _native.current_stream_ptr())
+    _native.check(rc, "octa_resize_bilinear_bwd")
+    return dx
+
+
+class BilinearResize(torch.autograd.Function):
+    """F.interpolate(x, size, mode="bilinear") (align_corners False) on [B, C, h, w] CUDA tensors through csrc/augment.hip, both ways."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        B, C, h, w = x.shape
+        ctx.in_shape, ctx.in_dtype = (h, w), x.dtype
+        y = resize_bilinear(x.reshape(B * C, h, w).float().contiguous(), size)
+        return y.view(B, C, int(size[0]), int(size[1])).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = dy.shape
+        dx = resize_bilinear_bwd(dy.reshape(B * C, H, W).float().contiguous(), ctx.in_shape)
+        return dx.view(B, C, *ctx.in_shape).to(ctx.in_dtype), None
+
+
 def flip_rot90_rotate(x, angle, rot_k=None, flip=None, threshold=None):
     """x: CUDA float32 [B,N,N]; angle float32 [B] (radians), rot_k / flip int32 [B] or None."""
     assert x.is_cuda and x.dim() == 3 and x.shape[1] == x.shape[2] and x.dtype == torch.float32 and x.is_contiguous()

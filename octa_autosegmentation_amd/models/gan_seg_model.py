@@ -55,6 +55,9 @@ class GanSegModel(BaseModelABC):
         super().initialize_model_and_optimizer(init_mini_batch, init_weights, config, args, scaler, phase)
 
     def _up(self, x):
+        if x.is_cuda:          # csrc/augment.hip both ways (round 4: the ATen interpolate kernels were the last vendor kernels of the up-sampling)
+            from ..data.gpu_augment import BilinearResize
+            return BilinearResize.apply(x, tuple(self.upshape))
         return torch.nn.functional.interpolate(x, size=self.upshape, mode="bilinear")
 
     def forward(self, input: torch.Tensor):

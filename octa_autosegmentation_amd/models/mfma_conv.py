@@ -614,21 +614,47 @@ class _ConvT2x2NHWC(torch.autograd.Function):
         return dx, dw
 
 
+# The 1x1 "transposed" layer at the U-Net's bottleneck (512 -> 256 at 152^2). OCTA_CONVT1X1=blas keeps round 3's route (forward and
+# data gradient as hipBLASLt GEMMs through torch, the weight gradient as a hand-split batched GEMM); the default since round 4 is the
+# repository's own MFMA convolution with only the centre tap unmasked -- no vendor kernel is left in the training step.
+USE_BLAS_CONVT1X1 = os.environ.get("OCTA_CONVT1X1", "mfma") == "blas"
+
+
+def _t1x1_packs(weight):
+    """[9][Cout][Cin] bf16 operands of the tap-masked 3x3 kernel for a ConvTranspose2d(k = 1) weight [Cin, Cout, 1, 1]: forward
+    (tap 4 = W^T) and data gradient (tap 4 = W); the masked taps are never fetched. Cached on the parameter (version + storage)."""
+    key = (weight._version, weight.data_ptr())
+    c = getattr(weight, "_octa_t1x1", None)
+    if c is None or c[0] != key:
+        cin, cout = weight.shape[0], weight.shape[1]
+        wm = weight.detach().reshape(cin, cout).to(torch.bfloat16)
+        fwd = torch.zeros((9, cout, cin), dtype=torch.bfloat16, device=weight.device)
+        dg = torch.zeros((9, cin, cout), dtype=torch.bfloat16, device=weight.device)
+        fwd[4] = wm.t()
+        dg[4] = wm
+        c = (key, fwd, dg)
+        weight._octa_t1x1 = c
+    return c[1], c[2]
+
+
 class _ConvT1x1NHWC(torch.autograd.Function):
-    """ConvTranspose2d(kernel 1, stride 1, no bias) = a 1x1 convolution with the transposed weight. Forward and data gradient
-    are plain GEMMs (hipBLASLt through torch: 470-580 TFLOP/s on 512 -> 256 at 152^2); the WEIGHT gradient is a [Cin x Cout]
-    product over K = N*H*W = 92 416 pixels, which hipBLASLt runs as 16 workgroups without split-K (0.30 ms, 81 TFLOP/s,
-    profiles/r01_train_mfma_kernel_stats.csv) -- it is split by hand into 32 batched products with fp32 results (0.055 ms incl.
-    the sum); pixel counts that do not split go to the MFMA weight-gradient kernel with only the centre tap unmasked (0.27 ms)."""
+    """ConvTranspose2d(kernel 1, stride 1, no bias) = a 1x1 convolution with the transposed weight: the MFMA 3x3 kernels with the
+    tap mask 0b000010000 (forward, data gradient on the swapped weight, weight gradient), csrc/conv.hip. OCTA_CONVT1X1=blas: plain
+    GEMMs through torch (hipBLASLt: 470-580 TFLOP/s on 512 -> 256 at 152^2) and the weight gradient -- a [Cin x Cout] product over
+    K = N*H*W = 92 416 pixels that hipBLASLt runs as 16 workgroups without split-K -- split by hand into 32 batched products."""
 
     @staticmethod
     def forward(ctx, x, weight):
         x = x.contiguous()
         n, h, w, cin = x.shape
         cout = weight.shape[1]
+        ctx.w_shape, ctx.w_dtype = weight.shape, weight.dtype
+        if not USE_BLAS_CONVT1X1:
+            fwd, dg = _t1x1_packs(weight)
+            ctx.save_for_backward(x, dg)
+            return conv3x3_nhwc(x, fwd, tap_mask=1 << 4)
         wm = weight.reshape(cin, cout).to(torch.bfloat16)
         ctx.save_for_backward(x, wm)
-        ctx.w_shape, ctx.w_dtype = weight.shape, weight.dtype
         return torch.matmul(x.reshape(n * h * w, cin), wm).view(n, h, w, cout)
 
     @staticmethod
@@ -640,6 +666,13 @@ class _ConvT1x1NHWC(torch.autograd.Function):
         n, h, w, cin = x.shape
         cout = dy.shape[3]
         dx = dw = None
+        if not USE_BLAS_CONVT1X1:
+            if ctx.needs_input_grad[0]:
+                dx = conv3x3_nhwc(dy, wm, tap_mask=1 << 4)          # wm: the data-gradient pack [9][Cin][Cout]
+            if ctx.needs_input_grad[1]:
+                # as a convolution weight [Cout_conv = cout][Cin_conv = cin][3][3] with only tap (1, 1): dW[co][ci] = sum_p dy[p][co] x[p][ci]
+                dw = conv3x3_nhwc_wgrad(x, dy, tap_mask=1 << 4)[:, :, 1, 1].t().reshape(ctx.w_shape).to(ctx.w_dtype)
+            return dx, dw
         if ctx.needs_input_grad[0]:
             dx = torch.matmul(dy.reshape(n * h * w, cout), wm.t()).view(n, h, w, cin)
         if ctx.needs_input_grad[1]:
@@ -651,7 +684,6 @@ class _ConvT1x1NHWC(torch.autograd.Function):
                 dw = torch.bmm(x.reshape(split, m // split, cin).transpose(1, 2), dy.reshape(split, m // split, cout),
                                out_dtype=torch.float32).sum(0)
             else:
-                # as a convolution weight [Cout_conv = cout][Cin_conv = cin][3][3] with only tap (1, 1): dW[co][ci] = sum_p dy[p][co] x[p][ci]
                 dw = conv3x3_nhwc_wgrad(x, dy, tap_mask=1 << 4)[:, :, 1, 1].t()
             dw = dw.reshape(ctx.w_shape).to(ctx.w_dtype)
         return dx, dw

@@ -25,6 +25,32 @@ def test_resize_matches_torch_interpolate(hip_lib_built):
     assert (same - xf).abs().max().item() <= 1e-6           # Resized to the same size is the identity
 
 
+def test_resize_adjoint_matches_torch_autograd(hip_lib_built):
+    """octa_resize_bilinear_bwd (round 4): the gradient of F.interpolate(bilinear) for the GAN-seg model's 304 -> 1216 up-sampling, a
+    non-integer ratio, a down-sampling and the identity; through the autograd function on [B, C, h, w] in fp32 and bf16."""
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.data import gpu_augment
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for (h, w, H, W) in [(304, 304, 1216, 1216), (50, 70, 125, 91), (96, 64, 48, 40), (33, 17, 33, 17), (5, 3, 64, 64)]:
+        x = torch.rand(2, 1, h, w, device="cuda", generator=g, requires_grad=True)
+        dy = torch.randn(2, 1, H, W, device="cuda", generator=g)
+        F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False).backward(dy)
+        want = x.grad.clone()
+        got = gpu_augment.resize_bilinear_bwd(dy.reshape(2, H, W).contiguous(), (h, w)).view(2, 1, h, w)
+        assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), (h, w, H, W)
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = gpu_augment.BilinearResize.apply(x2, (H, W))
+        assert (y2 - F.interpolate(x.detach(), size=(H, W), mode="bilinear", align_corners=False)).abs().max().item() <= 1e-5
+        y2.backward(dy)
+        assert (x2.grad - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    xb = torch.rand(3, 2, 40, 40, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)
+    yb = gpu_augment.BilinearResize.apply(xb, (160, 160))
+    assert yb.dtype == torch.bfloat16 and yb.shape == (3, 2, 160, 160)
+    yb.float().sum().backward()
+    assert xb.grad.dtype == torch.bfloat16 and abs(float(xb.grad.float().sum()) - 3 * 2 * 160 * 160) < 0.02 * 3 * 2 * 160 * 160      # the weights of every output pixel sum to one
+
+
 def test_flip_rot90_rotate_matches_torch(hip_lib_built):
     import torch
     import torch.nn.functional as F
