@@ -39,7 +39,7 @@ constexpr int BLK_H = 4 * NPX;  // a wave owns a 16 x BLK_H pixel block (16/NPX 
 constexpr int ST = 64;          // super-tile width (pixels): 4 blocks
 constexpr int ST_Y = 4 * BLK_H; // super-tile height: 4 blocks (16 waves)
 constexpr int WG = 1024;        // threads per render workgroup
-constexpr int EPT = 4;          // edges tested per thread per scan round
+constexpr int EPT = 4;          // edges tested per thread per scan round (8 measured slower in round 4: bin 602 -> 656 WG-ms per 128 labels)
 constexpr int LIST_CAP = 1024;  // edges per chunk
 constexpr int SLOT_CAP = 4096;  // int4 side slots per chunk (64 KiB; 80 KiB until the fold's accumulators needed 33 KiB, round 4)
 constexpr int ITEM_CAP = 256;   // (side, scanline) work items of one edge inside one wave's block
