@@ -537,7 +537,7 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
 __global__ void __launch_bounds__(SIM_THREADS, SIM_WG_PER_CU * SIM_THREADS / 256)      // HIP's second argument = waves per SIMD: 2 at 256 threads (<= 256 registers per lane)
 sim_persistent_kernel(BatchPtrs B, HostMail M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Blk b = {(int)threadIdx.x, (int)blockDim.x, smem};
+    Blk b = {(int)threadIdx.x, SIM_THREADS, smem};      // the launch shape is fixed (sim_run_impl): as a constant it removes the one-thread (host build) paths and turns every stride into an immediate
     int *next = b.coll() + 104;
     while (true) {
         if (b.tid == 0) *next = atomicAdd(B.next_sample, 1);

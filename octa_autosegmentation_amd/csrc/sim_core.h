@@ -255,7 +255,14 @@ __device__ __forceinline__ void octa_block_sync() {
     return;
 #endif
 #if OCTA_SIM_SYNC_DRAIN & 1
+    // vmcnt(0): the wave's global stores (LLVM leaves them pending at workgroup scope by design); lgkmcnt(0): its LDS stores -- hipcc
+    // 7.2 DROPS the workgroup-release `s_waitcnt lgkmcnt(0)` of a barrier at a loop header when the pending LDS writes arrive over the
+    // back edge only (blk_sort_u32's stage loop; tools/isa/check_barrier_cfg.py finds such barriers in a listing)
+#ifdef OCTA_SIM_SYNC_NO_LGKM
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
 #endif
     __syncthreads();
 #if OCTA_SIM_SYNC_DRAIN & 2
@@ -268,6 +275,9 @@ __device__ __forceinline__ void octa_block_sync() {
 }
 #endif
 
+#ifndef OCTA_SIM_DS_MASK
+#define OCTA_SIM_DS_MASK 0
+#endif
 struct Blk {
     int tid, nth;
     unsigned char *smem;  // LDS (device) or heap (host emulation); first 2 KiB reserved for collectives
@@ -278,16 +288,25 @@ struct Blk {
 #endif
     }
     OCTA_HD inline int *coll() const { return reinterpret_cast<int *>(smem); }
-    // The table area of a phase. Default build: reached through a pointer the compiler cannot prove to be LDS (the wide-field build puts
-    // the tables in HBM), so every table access is a FLAT instruction. -DOCTA_SIM_LDS_DS makes it the LDS at compile time (ds_*
-    // instructions: 492 instead of 513 ms per sample, 469 with round 4's batched queries on top) -- NOT the default: with it about one
-    // sample run in 100 is irreproducible again (same stage as the barrier race, octa_block_sync above, but not cured by it), see
-    // DESIGN.md 4.1 and tools/isa/experiments/.
-#if defined(OCTA_SIM_LDS_DS) && !OCTA_SIM_LARGE
+    // The table area of a phase: the LDS behind the collectives in the default build (ds_* instructions), the workgroup's HBM scratch in
+    // the wide-field build. Until round 4 the default build chose between the two at run time (`umem ? umem : smem + 2048`), so the
+    // compiler could not prove the pointer to be LDS and every table access was a FLAT instruction (1027 of them: 64-bit addresses,
+    // both wait counters): 513 -> 485 ms per sample. -DOCTA_SIM_FLAT_USER restores that form.
+#if !OCTA_SIM_LARGE && !defined(OCTA_SIM_FLAT_USER)
     OCTA_HD inline unsigned char *user() const { return smem + 2048; }
 #else
     OCTA_HD inline unsigned char *user() const { return umem ? umem : smem + 2048; }
 #endif
+    // The same area for ONE tenant (TENANT: 1 kd order, 2 uniform grid, 4 greedy acceptance, 8 ordered pass, 16 compaction tile, 32 pair
+    // sort, 64 set replay): LDS at compile time for the tenants named in OCTA_SIM_DS_MASK (default build only). Round 4 uses it to find
+    // out WHICH tenant's ds_* addressing brings the irreproducibility back (DESIGN.md 4.1 "Open").
+    template <int TENANT>
+    OCTA_HD inline unsigned char *user_of() const {
+#if !OCTA_SIM_LARGE
+        if (OCTA_SIM_DS_MASK & TENANT) return smem + 2048;
+#endif
+        return user();
+    }
 };
 
 // exclusive scan of one int per thread; returns block total. Contains block syncs.
@@ -924,12 +943,12 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
 #else
 #define KDP(slot) do { } while (0)
 #endif
-    kdw_t *kv = reinterpret_cast<kdw_t *>(b.user());
-    idx_t *tab = reinterpret_cast<idx_t *>(b.user() + KD_TAB_OFF);
+    kdw_t *kv = reinterpret_cast<kdw_t *>(b.user_of<1>());
+    idx_t *tab = reinterpret_cast<idx_t *>(b.user_of<1>() + KD_TAB_OFF);
     idx_t *rs = tab, *re = tab + KD_RANGES;                        // range start / end
     idx_t *rs2 = tab + 2 * KD_RANGES, *re2 = tab + 3 * KD_RANGES;  // next level
     signed char *rd = reinterpret_cast<signed char *>(tab + 4 * KD_RANGES); // bbox pass: 1 = holds a needed point; then split dim (-1 = leaf / not needed)
-    unsigned *bbf = reinterpret_cast<unsigned *>(b.user() + KD_MAILBOX_OFF); // [nr][6]: max xyz (rounded up), min xyz (rounded down)
+    unsigned *bbf = reinterpret_cast<unsigned *>(b.user_of<1>() + KD_MAILBOX_OFF); // [nr][6]: max xyz (rounded up), min xyz (rounded down)
     for (int i = b.tid; i < n; i += b.nth) {
         kv[i] = (kdw_t)i;
         xy[2 * i] = (float)pts[3 * i]; xy[2 * i + 1] = (float)pts[3 * i + 1];      // round to nearest: x lies within one float spacing of it
@@ -966,13 +985,18 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
                     atomic_min_u32(&bbf[6 * qq + 3 + k], f32_sortable(nextafterf(mn[k], -INFINITY)));
                 }
             };
+            // the walk keeps the bounds of its range and the start of the next one in registers (round 4: one table read per range
+            // crossed instead of three per element -- every table read is a FLAT instruction in this build)
+            int cs = 0, ce = 0, ns = 0x7fffffff;
+            if (i0 < i1) { cs = rs[q]; ce = re[q]; ns = q + 1 < nr ? (int)rs[q + 1] : 0x7fffffff; }
             for (int i = i0; i < i1; i++) {
-                while (q + 1 < nr && rs[q + 1] <= i) {
+                while (i >= ns) {
                     if (have) { flush(q); have = false; }
                     if (hit) { rd[q] = 1; hit = false; }
                     q++;
+                    cs = ns; ce = re[q]; ns = q + 1 < nr ? (int)rs[q + 1] : 0x7fffffff;
                 }
-                if (i < rs[q] || i >= re[q]) continue;  // element of a finished leaf
+                if (i < cs || i >= ce) continue;  // element of a finished leaf
                 const int id = (int)(kv[i] & KD_IDX_MASK);
                 if (!need || need[id]) hit = true;
                 const float ex = xy[2 * id], ey = xy[2 * id + 1];
@@ -1074,9 +1098,11 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
             }
             int qc = -1, d = -1;
             double mnd = 0, scale = 0;
+            int cs = 0, ce = 0, ns = 0x7fffffff;
+            if (i0 < i1) { cs = rs[q]; ce = re[q]; ns = q + 1 < nr ? (int)rs[q + 1] : 0x7fffffff; }
             for (int i = i0; i < i1; i++) {
-                while (q + 1 < nr && rs[q + 1] <= i) q++;
-                if (i < rs[q] || i >= re[q]) continue;
+                while (i >= ns) { q++; cs = ns; ce = re[q]; ns = q + 1 < nr ? (int)rs[q + 1] : 0x7fffffff; }
+                if (i < cs || i >= ce) continue;
                 if (q != qc) {
                     qc = q; d = rd[q];
                     if (d >= 0) {
@@ -1098,7 +1124,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
         // 3. nth_element per range: long ranges by one wave each, short ranges by a quarter wave each
 #if defined(__HIP_DEVICE_COMPILE__)
         {
-            idx_t *mb = reinterpret_cast<idx_t *>(b.user() + KD_MAILBOX_OFF);
+            idx_t *mb = reinterpret_cast<idx_t *>(b.user_of<1>() + KD_MAILBOX_OFF);
             const int wv = b.tid >> 6, nw = (b.nth + 63) >> 6;
             for (int q = wv; q < nr; q += nw) {
                 int d = rd[q];
@@ -1113,7 +1139,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
         b.sync();
         KDP(3);
         {
-            idx_t *mb = reinterpret_cast<idx_t *>(b.user() + KD_MAILBOX_OFF);
+            idx_t *mb = reinterpret_cast<idx_t *>(b.user_of<1>() + KD_MAILBOX_OFF);
             const int team = b.tid >> 4, nteam = b.nth >> 4;
             for (int q0 = 0; q0 < nr; q0 += nteam) {
                 int q = q0 + team;
@@ -1198,8 +1224,8 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
     if (nc > GRID_MAX) nc = GRID_MAX;
     G.nx = G.ny = nc; G.x0 = G.y0 = -0.1; G.inv = 1.0 / cell;
     const int ncell = nc * nc;
-    int *hist = reinterpret_cast<int *>(b.user());  // [ncell + 1]
-    idx_t *items = reinterpret_cast<idx_t *>(b.user() + (size_t)(GRID_MAX * GRID_MAX + 1) * 4);  // [GRID_N]
+    int *hist = reinterpret_cast<int *>(b.user_of<2>());  // [ncell + 1]
+    idx_t *items = reinterpret_cast<idx_t *>(b.user_of<2>() + (size_t)(GRID_MAX * GRID_MAX + 1) * 4);  // [GRID_N]
     static_assert((size_t)(GRID_MAX * GRID_MAX + 1) * 4 + (size_t)GRID_N * sizeof(idx_t) <= (size_t)SIM_USER_BYTES, "grid table layout");
     G.cell_end = hist; G.items = items; G.spts = A.grid_pts;
     if (n > GRID_N) n = GRID_N;
@@ -1255,16 +1281,61 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
     b.sync();
     return G;
 }
-// visits every point of the cells overlapping [px-radius, px+radius] x [py-radius, py+radius]:
-// ITEM = point id, PT = its coordinates (V3)
-#define OCTA_GRID_FOR(G, px, py, radius, ITEM, PT)                                                              \
-    for (int _cy = grid_cy(G, (py) - (radius)), _cy1 = grid_cy(G, (py) + (radius)),                               \
-             _cx0 = grid_cx(G, (px) - (radius)), _cx1 = grid_cx(G, (px) + (radius)); _cy <= _cy1; _cy++)          \
-        for (int _c0 = _cy * (G).nx + _cx0, _k = _c0 ? (G).cell_end[_c0 - 1] : 0,                                \
-                 _k1 = (G).cell_end[_cy * (G).nx + _cx1]; _k < _k1; _k++)                                         \
-            for (int _once = 1; _once;)                                                                           \
-                for (const V3 PT = ld3((G).spts + 3 * _k); _once;)                                                \
-                    for (const int ITEM = (int)(G).items[_k]; _once; _once = 0)
+// visits every point of the cells overlapping [px-radius, px+radius] x [py-radius, py+radius]: body(item = point id, pt = coordinates).
+// Three cell rows per round (a query radius never exceeds the cell edge, so one round is the rule): the bounds of the rows' runs come
+// out of the LDS together, then the first GRID_VB points of EVERY run are fetched together -- their loads are independent -- and only
+// then handed to the body; runs longer than that continue GRID_VB points at a time. Round 4: the macro this replaces fetched one point
+// per loop trip, i.e. one dependent L2 / HBM round trip per visited point (~10 per query, 43 queries per thread and assignment:
+// that chain, not bandwidth, was the 57 ms of phase_assign). The order of the visits is row by row as before; every consumer is
+// order-free anyway (existence tests, arg-min with an explicit id tie-break, pair lists that are sorted afterwards).
+constexpr int GRID_VB = 4;
+template <class F>
+OCTA_HD inline void grid_visit(const Grid &G, double px, double py, double radius, F &&body) {
+    const int cy0 = grid_cy(G, py - radius), cy1 = grid_cy(G, py + radius);
+    const int cx0 = grid_cx(G, px - radius), cx1 = grid_cx(G, px + radius);
+    for (int cyb = cy0; cyb <= cy1; cyb += 3) {
+        int k0[3], k1[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int row = cyb + r;
+            k0[r] = k1[r] = 0;
+            if (row <= cy1) {
+                const int c0 = row * G.nx + cx0;
+                k0[r] = c0 ? G.cell_end[c0 - 1] : 0;
+                k1[r] = G.cell_end[row * G.nx + cx1];
+            }
+        }
+        V3 pt[3][GRID_VB];
+        int it[3][GRID_VB];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int u = 0; u < GRID_VB; u++) {
+                const int k = k0[r] + u < k1[r] ? k0[r] + u : k0[r];      // k0[r] is a valid slot whenever the grid holds a point; an empty grid has no run
+                pt[r][u] = k0[r] < k1[r] ? ld3(G.spts + 3 * k) : v3(0, 0, 0);
+                it[r][u] = k0[r] < k1[r] ? (int)G.items[k] : 0;
+            }
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int u = 0; u < GRID_VB; u++)
+                if (k0[r] + u < k1[r]) body(it[r][u], pt[r][u]);
+            for (int kb = k0[r] + GRID_VB; kb < k1[r]; kb += GRID_VB) {
+                V3 q[GRID_VB];
+                int iq[GRID_VB];
+#pragma unroll
+                for (int u = 0; u < GRID_VB; u++) {
+                    const int k = kb + u < k1[r] ? kb + u : kb;
+                    q[u] = ld3(G.spts + 3 * k);
+                    iq[u] = (int)G.items[k];
+                }
+#pragma unroll
+                for (int u = 0; u < GRID_VB; u++)
+                    if (kb + u < k1[r]) body(iq[u], q[u]);
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------ Murray propagation (one thread)
 // dirty list of the ordered pass: inter-node groups that did not sprout under the speculation but whose
@@ -1700,12 +1771,12 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
         for (int vi = b.tid; vi < n_valid; vi += b.nth) {
             V3 c = ld3(cand + 3 * vlist[vi]);
             bool ok = true;
-            OCTA_GRID_FOR(G, c.x, c.y, en, j, q) {
+            grid_visit(G, c.x, c.y, en, [&](int j, const V3 &q) {
                 if (ok) {
                     double d2 = sqdist(q, c);
                     if (d2 <= en2 && !(sqrt(d2) > oxd[j])) ok = false;
                 }
-            }
+            });
             okf[vi] = ok ? 1 : 0;
         }
         b.sync();
@@ -1716,10 +1787,9 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
             if (!okf[vi]) continue;
             V3 c = ld3(cand + 3 * vlist[vi]);
             bool ok = true;
-            OCTA_GRID_FOR(G, c.x, c.y, es, j, q) {
-                (void)j;
+            grid_visit(G, c.x, c.y, es, [&](int, const V3 &q) {
                 if (ok && sqrt(sqdist(q, c)) <= es) ok = false;
-            }
+            });
             okf[vi] = ok ? 1 : 0;
         }
         b.sync();
@@ -1737,7 +1807,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     }
     b.sync();
     // 3. ordered greedy acceptance against the sinks accepted earlier in this call (strict >)
-    double *acc = reinterpret_cast<double *>(b.user());  // [ACCCAP][3]
+    double *acc = reinterpret_cast<double *>(b.user_of<4>());  // [ACCCAP][3]
     int *ctl = b.coll() + 100;
     if (b.tid == 0) ctl[0] = 0;
     b.sync();
@@ -1814,10 +1884,10 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
             V3 p = ld3(att + 3 * a);
             double bd = INFINITY;
             int best = -1;
-            OCTA_GRID_FOR(G, p.x, p.y, delta, j, q) {
+            grid_visit(G, p.x, p.y, delta, [&](int j, const V3 &q) {
                 double d2 = sqdist(q, p);
                 if (d2 < bd || (d2 == bd && j < best)) { bd = d2; best = j; }
-            }
+            });
             int r = (best >= 0 && sqrt(bd) <= delta) ? best : -1;
             A.nn[a] = r;
             if (r >= 0) atomic_min_int(&A.first_att[r], a);
@@ -1896,14 +1966,48 @@ struct GrowCtx {
     const double *att;
     double gamma;
     const double *rad;  // radii of forest f: HBM array, or the LDS copy during the ordered pass
-    bool wave_coop = false;   // the caller is a whole wave executing uniformly (ordered pass): attractor loops are shared by its lanes
 };
 
 // acos / cos / sin whose results reach a node position: glibc's, bit for bit (glibc_trig.h), inside the restated domain
 OCTA_HD inline double pos_acos(double c) { return (c > 0.0 && c <= 1.0) ? octa_gtrig::gacos(c) : acos(c); }
 OCTA_HD inline double pos_cos(double x) { return (x >= 0.0 && x < 2.4) ? octa_gtrig::gcos(x) : cos(x); }
 OCTA_HD inline double pos_sin(double x) { return (x >= 0.0 && x < 2.4) ? octa_gtrig::gsin(x) : sin(x); }
+// The attractors of one group, in attractor order: body(position). A visit is two dependent loads (the sorted key, then the
+// attractor it names) in front of a few hundred cycles of arithmetic (angles, acos); one at a time the speculation was a chain of
+// ~100-250 such round trips per thread and iteration (round 4: pre_art + pre_ven 61 ms per sample). Here the keys run two batches ahead
+// of the arithmetic and the positions one batch ahead, ATT_B attractors per batch; the order of the visits is unchanged.
+constexpr int ATT_B = 4;
+template <class F>
+OCTA_HD inline void for_each_attractor(const SimArrays &A, const double *att, int s, int cnt, F &&body) {
+    if (cnt <= 0) return;
+    int a1[ATT_B] = {}, a2[ATT_B] = {};
+    V3 p0[ATT_B] = {}, p1[ATT_B] = {};
+    auto keys = [&](int k0, int *a) {
+#pragma unroll
+        for (int u = 0; u < ATT_B; u++) a[u] = (int)(A.sorted[s + (k0 + u < cnt ? k0 + u : cnt - 1)] & IDX_MASK);
+    };
+    auto points = [&](const int *a, V3 *p) {
+#pragma unroll
+        for (int u = 0; u < ATT_B; u++) p[u] = ld3(att + 3 * a[u]);
+    };
+    keys(0, a1);
+    points(a1, p0);
+    keys(ATT_B, a1);
+    for (int k0 = 0; k0 < cnt; k0 += ATT_B) {
+        if (k0 + ATT_B < cnt) points(a1, p1);           // batch k0 + ATT_B: its keys arrived one batch ago
+        if (k0 + 2 * ATT_B < cnt) keys(k0 + 2 * ATT_B, a2);
+#pragma unroll
+        for (int u = 0; u < ATT_B; u++)
+            if (k0 + u < cnt) body(p0[u]);
+#pragma unroll
+        for (int u = 0; u < ATT_B; u++) { p0[u] = p1[u]; a1[u] = a2[u]; }
+    }
+}
+
 // inter-node sprouting (greenhouse.py:259-306) for group g with the CURRENT child radius
+// WAVE_COOP: the caller is a whole wave executing uniformly (the ordered pass on the device): the attractor loop is shared by its lanes.
+// A compile-time choice (round 4): as a run-time flag both loops were compiled into the ordered pass.
+template <bool WAVE_COOP>
 OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     const SimArrays &A = *G.A;
     const int f = G.f, id = A.gnode[g];
@@ -1928,7 +2032,7 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     int kept = 0;
     const int s = A.gstart[g], cnt = A.gcount[g];
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (G.wave_coop) {
+    if (WAVE_COOP) {
         // re-speculation inside the ordered pass: the 64 lanes take one attractor each (angles, unit vector), the kept unit vectors
         // are then summed in attractor order with lane reads -- the same operations in the same order as the loop below
         const int lane = (int)(threadIdx.x & 63);
@@ -1954,16 +2058,15 @@ OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
         }
     } else
 #endif
-    for (int k = 0; k < cnt; k++) {
-        int a = (int)(A.sorted[s + k] & IDX_MASK);
-        V3 w = sub(ld3(G.att + 3 * a), pos);
+    for_each_attractor(A, G.att, s, cnt, [&](const V3 &ap_) {
+        V3 w = sub(ap_, pos);
         double ad = angle_uv(dist_seg, nd, w), ap = angle_uv(prox_seg, npx, w);
         if (lo <= ad && ad <= hi && ap <= pl) {
             V3 u = unit(w);
             avg = kept == 0 ? u : add(avg, u);
             kept++;
         }
-    }
+    });
     if (kept == 0) return;
     V3 dv = unit(dist_seg);
     V3 cr = cross(dv, avg);
@@ -1995,9 +2098,8 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
     int kept = 0;
     double sum = 0;
     const int s = A.gstart[g], cnt = A.gcount[g];
-    for (int k = 0; k < cnt; k++) {
-        int a = (int)(A.sorted[s + k] & IDX_MASK);
-        V3 w = sub(ld3(G.att + 3 * a), pos);
+    for_each_attractor(A, G.att, s, cnt, [&](const V3 &ap_) {
+        V3 w = sub(ap_, pos);
         double an = angle_uv(v, nv, w);
         if (an <= lim) {
             V3 u = unit(w);
@@ -2005,14 +2107,13 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
             sum += an;
             kept++;
         }
-    }
+    });
     if (kept == 0) return;
     double mean = sum / (double)kept, var = 0;
-    for (int k = 0; k < cnt; k++) {
-        int a = (int)(A.sorted[s + k] & IDX_MASK);
-        double an = angle_uv(v, nv, sub(ld3(G.att + 3 * a), pos));
+    for_each_attractor(A, G.att, s, cnt, [&](const V3 &ap_) {
+        double an = angle_uv(v, nv, sub(ap_, pos));
         if (an <= lim) var += (an - mean) * (an - mean);
-    }
+    });
     double sd = sqrt(var / (double)kept);
     const double vc0 = G.C->fc0 - pos.x, vc1 = G.C->fc1 - pos.y;
     R.type = 1;
@@ -2028,11 +2129,9 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
                 st3(Q.pos, pos);
                 Q.r = r; Q.kappa = kappa; Q.d = d;
                 int w = 0;
-                for (int k = 0; k < cnt; k++) {
-                    int a = (int)(A.sorted[s + k] & IDX_MASK);
-                    V3 p = ld3(G.att + 3 * a);
+                for_each_attractor(A, G.att, s, cnt, [&](const V3 &p) {
                     if (angle_uv(v, nv, sub(p, pos)) <= lim) { st3(Q.atts + 3 * w, p); w++; }
-                }
+                });
                 R.req = q;
             } else {
                 atomic_or_int(&A.sc->err, kept > MAXKEPT ? ERR_KEPT_CAP : ERR_REQ_CAP);
@@ -2075,7 +2174,7 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
             int id = A.gnode[g];
             int nch = A.nnch_of(f)[id], par = A.npar_of(f)[id];
             if (nch == 0) eval_leaf(G, g, R, reqs, req_count, req_cap, sample);
-            else if (par >= 0 && nch == 1) eval_inter(G, g, R);
+            else if (par >= 0 && nch == 1) eval_inter<false>(G, g, R);
             else { R.type = 0; R.node = id; R.req = -1; }
             A.rec[g] = R;
             grows = (R.type == 1) || (R.type == 3 && R.grow);
@@ -2181,8 +2280,8 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     SeqLds L;
     L.rad = A.nrad_of(f);
     constexpr int DEF_WORDS = (NCAP + 31) / 32, CHG_WORDS = (GCAP + 31) / 32;     // the two bitmaps
-    L.par = reinterpret_cast<idx_t *>(b.user());
-    double *ltab = reinterpret_cast<double *>(b.user() + (((size_t)NCAP * sizeof(idx_t) + 15) & ~(size_t)15));
+    L.par = reinterpret_cast<idx_t *>(b.user_of<8>());
+    double *ltab = reinterpret_cast<double *>(b.user_of<8>() + (((size_t)NCAP * sizeof(idx_t) + 15) & ~(size_t)15));
     uint64_t *etab = reinterpret_cast<uint64_t *>(ltab + 384);
     static_assert((size_t)NCAP * sizeof(idx_t) + 16 + 384 * 8 + 256 * 8 + (DEF_WORDS + CHG_WORDS) * 4 + SEQ_SIDE_LDS <= (size_t)SIM_USER_BYTES, "ordered-pass table layout");
     L.log_tab = ltab; L.exp_tab = etab;
@@ -2209,7 +2308,6 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     // only differ inside murray_to_root. One thread alone on the host build.
     if (b.tid < (b.nth >= 64 ? 64 : 1)) {
         GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, L.rad};
-        G.wave_coop = b.nth >= 64;
         const int ng = sc->n_groups[f];
         const int n_grow = sc->n_grow[f];
         const int tag = sc->pass_tag[f];
@@ -2273,7 +2371,11 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 }
             } else {
                 if (changed_get(L, g)) {      // a walk of this pass rewrote the child's radius (every rewrite changes it: the walk stops at old == new)
-                    SEQT(1, eval_inter(G, g, R));
+#if defined(__HIP_DEVICE_COMPILE__)
+                    SEQT(1, eval_inter<true>(G, g, R));      // the device's workgroups have at least one whole wave (SIM_THREADS_PER_WG >= 64)
+#else
+                    SEQT(1, eval_inter<false>(G, g, R));
+#endif
                     respec++;
                 }
                 if (!R.grow) continue;
@@ -2331,7 +2433,7 @@ OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsign
             if (!removed[i]) { if (w != i) { pts[3 * w] = pts[3 * i]; pts[3 * w + 1] = pts[3 * i + 1]; pts[3 * w + 2] = pts[3 * i + 2]; } w++; }
         return w;
     }
-    double *tile = reinterpret_cast<double *>(b.user());
+    double *tile = reinterpret_cast<double *>(b.user_of<16>());
     static_assert((size_t)COMPACT_TILE * 24 <= (size_t)SIM_USER_BYTES, "compaction tile");
     const int chunk = (n + b.nth - 1) / b.nth;
     const int i0 = b.tid * chunk < n ? b.tid * chunk : n, i1 = (i0 + chunk < n) ? i0 + chunk : n;
@@ -2392,13 +2494,13 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
         Grid G = grid_build(b, A, A.npos[0], new_ids, n_new, ek);
         for (int o = b.tid; o < n_oxy; o += b.nth) {
             V3 p = ld3(A.oxy + 3 * o);
-            OCTA_GRID_FOR(G, p.x, p.y, ek, j, q) {
+            grid_visit(G, p.x, p.y, ek, [&](int j, const V3 &q) {
                 if (sqdist(p, q) <= ek2) {
-                    int q = atomic_add_int(&ctl[0], 1);
-                    if (q < PCAP) A.pairs[q] = ((unsigned)(j - nb) << IDX_BITS) | (unsigned)o;
+                    int slot = atomic_add_int(&ctl[0], 1);
+                    if (slot < PCAP) A.pairs[slot] = ((unsigned)(j - nb) << IDX_BITS) | (unsigned)o;
                     A.removed[o] = 1;
                 }
-            }
+            });
         }
         b.sync();
     }
@@ -2449,16 +2551,16 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
             for (int u = 0; u < VB; u++) {
                 if (j0 + u * b.nth >= n_ven) break;
                 const V3 q = qv[u];
-                OCTA_GRID_FOR(G, q.x, q.y, ek, o, p) {
+                grid_visit(G, q.x, q.y, ek, [&](int o, const V3 &p) {
                     if (sqrt(sqdist(q, p)) <= ek) A.ven_near[o] = 1;
-                }
+                });
             }
         }
         b.sync();
     }
     OCTA_SUBPROF(sc, 12, t0);
     // 4. sort the pairs: new nodes in order, hits in cKDTree order
-    unsigned *keys = reinterpret_cast<unsigned *>(b.user());
+    unsigned *keys = reinterpret_cast<unsigned *>(b.user_of<32>());
     int n_pow2 = 1;
     while (n_pow2 < n_pairs) n_pow2 <<= 1;
     for (int i = b.tid; i < n_pow2; i += b.nth) keys[i] = i < n_pairs ? A.pairs[i] : 0xffffffffu;
@@ -2479,7 +2581,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     // insertions, and the occupied slots are read out in slot order by the whole block.
     if (n_pairs <= LSET_PAIRS) {
         set_in_lds = true;
-        unsigned long long *t_hash = reinterpret_cast<unsigned long long *>(b.user());        // [LSET_CAP]
+        unsigned long long *t_hash = reinterpret_cast<unsigned long long *>(b.user_of<64>());        // [LSET_CAP]
         int *t_key = reinterpret_cast<int *>(t_hash + LSET_CAP);                               // [LSET_CAP]
         unsigned long long *in_hash = reinterpret_cast<unsigned long long *>(t_key + LSET_CAP);  // [LSET_PAIRS]
         int *in_key = reinterpret_cast<int *>(in_hash + LSET_PAIRS);                           // [LSET_PAIRS]
@@ -2625,10 +2727,9 @@ OCTA_HD inline void phase_satisfy_ven(const Blk &b, const SimArrays &A, const It
         for (int o = b.tid; o < n_co2; o += b.nth) {
             V3 p = ld3(A.co2 + 3 * o);
             bool hit = false;
-            OCTA_GRID_FOR(G, p.x, p.y, ek, j, q) {
-                (void)j;
+            grid_visit(G, p.x, p.y, ek, [&](int, const V3 &q) {
                 if (!hit && sqdist(p, q) <= ek2) hit = true;
-            }
+            });
             A.removed[o] = hit ? 1 : 0;
         }
         b.sync();
