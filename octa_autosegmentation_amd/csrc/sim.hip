@@ -435,9 +435,9 @@ __device__ inline int uniform_err(const Blk &b, const SimArrays &A) {
 __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M, const int s_in, const Blk &b) {     // inlined: B stays kernel arguments (scalar registers)
     // The sample index is wave-uniform by construction; declaring it so keeps the sample's ~40 array base pointers in scalar registers
     // (per-sample device time 566 -> 509 ms). Round 3 could not ship this: 512-sample batches stopped being reproducible (about one
-    // sample run in 2000 converted a few O2 sinks too few into CO2 sources). Round 4 found the cause -- not the addressing, but a global
-    // store -> barrier -> load hand-over between waves that __syncthreads() does not order on this hardware (sim_core.h:
-    // octa_block_sync). The scalar addressing only shortened the path between the barrier and the first dependent load.
+    // sample run in 2000 converted a few O2 sinks too few into CO2 sources). Round 4 found the cause -- not the addressing, but a barrier
+    // in the pair sort's stage loop that the compiler left without its LDS wait (sim_core.h: octa_block_sync). The scalar
+    // addressing only shortened the path between a stage's last LDS store and that barrier.
     const int s = __builtin_amdgcn_readfirstlane(s_in);
     SimArrays A = sample_arrays(B, s);
     int *req_n = b.coll() + 96;

@@ -220,28 +220,29 @@ struct SimArrays {
 // -10 % per-sample device time from the sample index alone (its ~40 array base pointers were 80 vector registers and the main source
 // of register spills). Used for values that come out of the LDS or out of registers. (Round 3 blamed the irreproducible 512-sample
 // batches it saw with uniform annotations on scalar loads of the sample's counters; round 4 found no scalar load of mutable data in the
-// ISA and traced the events to the barrier, see octa_block_sync below.)
+// ISA and traced the events to a barrier without its LDS wait, see octa_block_sync below.)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OCTA_UNI(x) __builtin_amdgcn_readfirstlane(x)
 #else
 #define OCTA_UNI(x) (x)
 #endif
 
-// Workgroup barrier of the simulator kernels: __syncthreads() PRECEDED BY s_waitcnt vmcnt(0).
+// Workgroup barrier of the simulator kernels: __syncthreads() PRECEDED BY an explicit s_waitcnt vmcnt(0) lgkmcnt(0).
 //
-// Why (round 4; DESIGN.md 4.1 "The barrier that did not order global memory"): hipcc's __syncthreads() is
+// Why (round 4; DESIGN.md 4.1 "The barrier the compiler left without its LDS wait"): hipcc's __syncthreads() is
 //     fence release (workgroup); s_barrier; fence acquire (workgroup)
-// and for gfx90a / gfx942 / gfx950 the workgroup-scope release waits for LDS traffic only (s_waitcnt lgkmcnt(0)) -- LLVM's memory
-// legaliser assumes "the L1 cache keeps all memory operations in order for wavefronts in the same work-group", so global stores may
-// still be in flight when the barrier releases. On MI355X that assumption does not hold for a store by one wave followed, behind the
-// barrier, by a load of the same address by ANOTHER wave of the workgroup: measured with tools/repro_sim_race.py on the end of
-// kd_build (scattered 2-byte stores out_rank[id] = i; barrier; phase_satisfy_art reads kd_rank[sink] on other waves) -- 26-38 sample
-// runs per 50-76 k read stale ranks (always pairs handled by waves other than the first), 0 in 76 288 with the wait in front of the
-// barrier, 38 in 76 288 with only an L1 invalidate behind it (so it is the in-flight store, not a stale line), 0 in 30 208 with one
-// workgroup per CU. Every phase of the simulator hands data from wave to wave through HBM scratch, so the wait belongs to the barrier
-// itself. Cost: 553 -> 557 ms per 512-sample launch. OCTA_SIM_SYNC_DRAIN is the experiment knob that established this
-// (0: plain __syncthreads(); bit 0: the wait; bit 1: buffer_inv sc0 behind the barrier; bit 2: agent-scope fences instead; bit 3:
-// buffer_inv sc1 behind the barrier).
+// and the release should become s_waitcnt lgkmcnt(0) in front of the barrier. hipcc 7.2 DROPS that wait when the barrier stands at a
+// loop header and the pending LDS stores arrive over the back edge only -- blk_sort_u32's stage loop: a wave's last exchange of one
+// stage could still be in the LDS queue when another wave read the key in the next stage; with two workgroups per CU about one
+// 512-sample launch in six lost a sink from the sorted pair list. Measured with tools/repro_sim_race.py on the shipped sources
+// (30 208 sample runs each): lgkmcnt(0) only: 0 events; vmcnt(0) only: 127; neither (plain __syncthreads(), FLAT-addressed tables):
+// 26-38 per 50-76 k. The vmcnt half is insurance for the hand-overs through HBM scratch (LLVM leaves global stores pending at
+// workgroup scope by design: "the L1 keeps all memory operations in order for wavefronts in the same work-group"; nothing measured
+// here contradicts that) and costs nothing measurable. While the tables were FLAT-addressed, vmcnt(0) alone cured the events --
+// FLAT stores to the LDS count in vmcnt too -- which round 4 first misread as a global-memory ordering problem.
+// tools/isa/check_barrier_cfg.py finds barriers reachable with LDS stores pending in a listing. OCTA_SIM_SYNC_DRAIN is the experiment
+// knob (0: plain __syncthreads(); bit 0: the wait; bit 1: buffer_inv sc0 behind the barrier; bit 2: agent-scope fences instead;
+// bit 3: buffer_inv sc1 behind the barrier); OCTA_SIM_SYNC_NO_LGKM / OCTA_SIM_SYNC_NO_VM keep one half of the wait only.
 #ifndef OCTA_SIM_SYNC_DRAIN
 #define OCTA_SIM_SYNC_DRAIN 1
 #endif
@@ -255,11 +256,10 @@ __device__ __forceinline__ void octa_block_sync() {
     return;
 #endif
 #if OCTA_SIM_SYNC_DRAIN & 1
-    // vmcnt(0): the wave's global stores (LLVM leaves them pending at workgroup scope by design); lgkmcnt(0): its LDS stores -- hipcc
-    // 7.2 DROPS the workgroup-release `s_waitcnt lgkmcnt(0)` of a barrier at a loop header when the pending LDS writes arrive over the
-    // back edge only (blk_sort_u32's stage loop; tools/isa/check_barrier_cfg.py finds such barriers in a listing)
-#ifdef OCTA_SIM_SYNC_NO_LGKM
+#if defined(OCTA_SIM_SYNC_NO_LGKM)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif defined(OCTA_SIM_SYNC_NO_VM)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
@@ -291,15 +291,15 @@ struct Blk {
     // The table area of a phase: the LDS behind the collectives in the default build (ds_* instructions), the workgroup's HBM scratch in
     // the wide-field build. Until round 4 the default build chose between the two at run time (`umem ? umem : smem + 2048`), so the
     // compiler could not prove the pointer to be LDS and every table access was a FLAT instruction (1027 of them: 64-bit addresses,
-    // both wait counters): 513 -> 485 ms per sample. -DOCTA_SIM_FLAT_USER restores that form.
+    // both wait counters): 513 -> 492 ms per sample. -DOCTA_SIM_FLAT_USER restores that form.
 #if !OCTA_SIM_LARGE && !defined(OCTA_SIM_FLAT_USER)
     OCTA_HD inline unsigned char *user() const { return smem + 2048; }
 #else
     OCTA_HD inline unsigned char *user() const { return umem ? umem : smem + 2048; }
 #endif
     // The same area for ONE tenant (TENANT: 1 kd order, 2 uniform grid, 4 greedy acceptance, 8 ordered pass, 16 compaction tile, 32 pair
-    // sort, 64 set replay): LDS at compile time for the tenants named in OCTA_SIM_DS_MASK (default build only). Round 4 uses it to find
-    // out WHICH tenant's ds_* addressing brings the irreproducibility back (DESIGN.md 4.1 "Open").
+    // sort, 64 set replay): LDS at compile time for the tenants named in OCTA_SIM_DS_MASK (only meaningful with -DOCTA_SIM_FLAT_USER).
+    // Round 4 used it to find WHICH tenant's ds_* addressing brought the irreproducibility back: 32, the pair sort.
     template <int TENANT>
     OCTA_HD inline unsigned char *user_of() const {
 #if !OCTA_SIM_LARGE
