@@ -76,11 +76,11 @@ struct BatchPtrs {
     unsigned char *nnch[2], *nact[2];
     double *oxy, *co2, *cand, *py_u;
     unsigned *py_state;   // [B][625] CPython generator states behind the stump draws (input of py_uniform_kernel)
-    int *nn, *first_att, *act_list;
+    int *nn, *act_list;
     unsigned *sorted;
     int *gnode, *gstart, *gcount;
     Rec *rec;
-    int *glist, *child_group, *node_group;
+    int *glist, *child_group;
     idx_t *kd_idx, *kd_rank;
     unsigned char *removed, *ven_near;
     unsigned long long *hashes;
@@ -127,7 +127,6 @@ __device__ __forceinline__ SimArrays sample_arrays(const BatchPtrs &B, int s) {
     A.cand = B.cand + (size_t)s * NCANDCAP * 3;
     A.py_u = B.py_u + (size_t)s * PYCAP;
     A.nn = B.nn + (size_t)s * OCAP;
-    A.first_att = B.first_att + (size_t)s * NCAP;
     A.act_list = B.act_list + (size_t)s * NCAP;
     A.sorted = B.sorted + (size_t)s * SORTCAP;
     A.gnode = B.gnode + (size_t)s * GCAP;
@@ -136,7 +135,6 @@ __device__ __forceinline__ SimArrays sample_arrays(const BatchPtrs &B, int s) {
     A.rec = B.rec + (size_t)s * GCAP;
     A.glist = B.glist + (size_t)s * GCAP;
     A.child_group = B.child_group + (size_t)s * NCAP;
-    A.node_group = B.node_group + (size_t)s * NCAP;
     A.kd_idx = B.kd_idx + (size_t)s * OCAP;
     A.kd_rank = B.kd_rank + (size_t)s * OCAP;
     A.removed = B.removed + (size_t)s * OCAP;
@@ -483,9 +481,18 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
             }
             OCTA_PROF(0, phase_sample(b, A, B.C, P, it));
             OCTA_PROF(1, phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art));
+#if OCTA_SIM_DUP & 4
+            phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art);
+#endif
             if (b.tid == 0) *req_n = 0;
             b.sync();
             OCTA_PROF(2, phase_pre(b, A, B.C, P, 0, A.oxy, reqs, req_n, REQ_PER_SAMPLE, s));
+#if OCTA_SIM_DUP & 32
+            b.sync();
+            if (b.tid == 0) *req_n = 0;
+            b.sync();
+            phase_pre(b, A, B.C, P, 0, A.oxy, reqs, req_n, REQ_PER_SAMPLE, s);
+#endif
             if (mail_roundtrip(b, A, M, s, *req_n, 2 * it + 1, t_kernel)) { parked_at = it; parked_stage = 1; break; }
         }
         if (stage <= 1) {
@@ -510,9 +517,18 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
 #endif
             OCTA_PROF(4, phase_satisfy_art(b, A, B.C, P));
             OCTA_PROF(6, phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven));
+#if OCTA_SIM_DUP & 4
+            phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven);
+#endif
             if (b.tid == 0) *req_n = 0;
             b.sync();
             OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, reqs, req_n, REQ_PER_SAMPLE, s));
+#if OCTA_SIM_DUP & 32
+            b.sync();
+            if (b.tid == 0) *req_n = 0;
+            b.sync();
+            phase_pre(b, A, B.C, P, 1, A.co2, reqs, req_n, REQ_PER_SAMPLE, s);
+#endif
             if (mail_roundtrip(b, A, M, s, *req_n, 2 * it + 2, t_kernel)) { parked_at = it; parked_stage = 2; break; }
         }
         stage = 0;
@@ -740,10 +756,10 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, O
     }
     rc |= dev_alloc(S, &P.oxy, nb * OCAP * 3); rc |= dev_alloc(S, &P.co2, nb * CCAP * 3);
     rc |= dev_alloc(S, &P.cand, nb * NCANDCAP * 3); rc |= dev_alloc(S, &P.py_u, nb * PYCAP); rc |= dev_alloc(S, &P.py_state, nb * 625);
-    rc |= dev_alloc(S, &P.nn, nb * OCAP); rc |= dev_alloc(S, &P.first_att, nb * NCAP); rc |= dev_alloc(S, &P.act_list, nb * NCAP);
+    rc |= dev_alloc(S, &P.nn, nb * OCAP); rc |= dev_alloc(S, &P.act_list, nb * NCAP);
     rc |= dev_alloc(S, &P.sorted, nb * SORTCAP); rc |= dev_alloc(S, &P.gnode, nb * GCAP); rc |= dev_alloc(S, &P.gstart, nb * GCAP);
     rc |= dev_alloc(S, &P.gcount, nb * GCAP); rc |= dev_alloc(S, &P.rec, nb * GCAP);
-    rc |= dev_alloc(S, &P.glist, nb * GCAP); rc |= dev_alloc(S, &P.child_group, nb * NCAP); rc |= dev_alloc(S, &P.node_group, nb * NCAP);
+    rc |= dev_alloc(S, &P.glist, nb * GCAP); rc |= dev_alloc(S, &P.child_group, nb * NCAP);
     rc |= dev_alloc(S, &P.kd_idx, nb * OCAP); rc |= dev_alloc(S, &P.kd_rank, nb * OCAP);
     rc |= dev_alloc(S, &P.removed, nb * OCAP); rc |= dev_alloc(S, &P.ven_near, nb * OCAP); rc |= dev_alloc(S, &P.hashes, nb * OCAP);
     rc |= dev_alloc(S, &P.pairs, nb * PCAP); rc |= dev_alloc(S, &P.set_hash, nb * SETCAP); rc |= dev_alloc(S, &P.set_key, nb * SETCAP);

@@ -189,13 +189,11 @@ struct SimArrays {
     const double *py_u;  // [PYCAP]
     // scratch
     int *nn;             // [OCAP] nearest active node per attractor
-    int *first_att;      // [NCAP]
     int *act_list;       // [NCAP]
-    unsigned *sorted;    // [SORTCAP] sorted (first_att<<14 | attractor) keys
+    unsigned *sorted;    // [SORTCAP] attractors grouped by their nearest node (groups in dict order, members ascending)
     int *gnode, *gstart, *gcount;  // [GCAP]
     Rec *rec;            // [GCAP]
     int *glist;          // [GCAP] groups that grow under the speculation, ascending (dict order)
-    int *node_group;     // [NCAP] group index of a node during assignment
     int *child_group;    // [NCAP] tag<<14 | grow<<13 | group of the inter-node whose first child this node is
     idx_t *kd_idx, *kd_rank;  // [OCAP]
     unsigned char *removed;  // [OCAP]
@@ -277,6 +275,12 @@ __device__ __forceinline__ void octa_block_sync() {
 
 #ifndef OCTA_SIM_DS_MASK
 #define OCTA_SIM_DS_MASK 0
+#endif
+// Measurement knob (tools/sim_traffic.py): run an idempotent part of an iteration TWICE, so that the difference of the kernel's
+// FETCH_SIZE / WRITE_SIZE counters against the plain build is that part's share of the L2-miss traffic. Bits: 1 kd order, 2 every
+// uniform grid's build, 4 assignment (both forests), 8 the candidate tests' queries, 32 speculation (both forests).
+#ifndef OCTA_SIM_DUP
+#define OCTA_SIM_DUP 0
 #endif
 struct Blk {
     int tid, nth;
@@ -937,7 +941,7 @@ static_assert(KD_MAILBOX_OFF + (KD_BOX_BYTES > KD_MAILBOX_BYTES ? KD_BOX_BYTES :
 // whose x and y boxes are thinner than the slab, and those are measured exactly).
 OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_idx, idx_t *out_rank,
                               float *xy, double zlo, double zhi, long *kdprof = nullptr, const unsigned char *need = nullptr) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OCTA_SIM_PROF_ASSIGN)
 #define KDP(slot) do { if (kdprof && b.tid == 0) { long _t = (long)wall_clock64(); kdprof[slot] += _t - _kt; _kt = _t; } } while (0)
     long _kt = (long)wall_clock64();
 #else
@@ -1205,7 +1209,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
 constexpr int GRID_N = NCAP > OCAP ? NCAP : OCAP;  // points per grid
 struct Grid {
     int nx, ny;
-    double x0, y0, inv;
+    double x0, y0, inv, cell;
     const int *cell_end;           // LDS [nx*ny]: end offset of each cell (its start is the end of the previous cell)
     const idx_t *items;   // LDS [n]: point ids in cell order
     const double *spts;            // HBM [n][3]: coordinates in cell order
@@ -1215,14 +1219,14 @@ OCTA_HD inline int grid_cx(const Grid &G, double x) { return grid_clampi((int)fl
 OCTA_HD inline int grid_cy(const Grid &G, double y) { return grid_clampi((int)floor((y - G.y0) * G.inv), G.ny - 1); }
 
 // ids: optional list of point ids (n entries) -- point i is pts[3*ids[i]]; items then hold ids[i]
-OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius) {
+OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius, int div) {
     Grid G;
     const double span = 1.2;
-    double cell = fmax(radius, span / GRID_MAX);
+    double cell = fmax(radius / div, span / GRID_MAX);
     int nc = (int)ceil(span / cell);
     if (nc < 1) nc = 1;
     if (nc > GRID_MAX) nc = GRID_MAX;
-    G.nx = G.ny = nc; G.x0 = G.y0 = -0.1; G.inv = 1.0 / cell;
+    G.nx = G.ny = nc; G.x0 = G.y0 = -0.1; G.inv = 1.0 / cell; G.cell = cell;
     const int ncell = nc * nc;
     int *hist = reinterpret_cast<int *>(b.user_of<2>());  // [ncell + 1]
     idx_t *items = reinterpret_cast<idx_t *>(b.user_of<2>() + (size_t)(GRID_MAX * GRID_MAX + 1) * 4);  // [GRID_N]
@@ -1280,6 +1284,13 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
     }
     b.sync();
     return G;
+}
+// div: cells per query radius along an axis (1: a query visits 3 x 3 cells)
+OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius, int div = 1) {
+#if OCTA_SIM_DUP & 2
+    grid_build_once(b, A, pts, ids, n, radius, div);
+#endif
+    return grid_build_once(b, A, pts, ids, n, radius, div);
 }
 // visits every point of the cells overlapping [px-radius, px+radius] x [py-radius, py+radius]: body(item = point id, pt = coordinates).
 // Three cell rows per round (a query radius never exceeds the cell edge, so one round is the rule): the bounds of the rows' runs come
@@ -1768,6 +1779,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     for (int i = b.tid; i < n_art; i += b.nth) oxd[i] = oxygen_distance(A.nrad[0][i], C.ps);
     {
         Grid G = grid_build(b, A, A.npos[0], nullptr, n_art, en);
+        for (int rep = 0; rep < ((OCTA_SIM_DUP & 8) ? 2 : 1); rep++)
         for (int vi = b.tid; vi < n_valid; vi += b.nth) {
             V3 c = ld3(cand + 3 * vlist[vi]);
             bool ok = true;
@@ -1783,6 +1795,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     }
     {
         Grid G = grid_build(b, A, A.oxy, nullptr, n_oxy, es);
+        for (int rep = 0; rep < ((OCTA_SIM_DUP & 8) ? 2 : 1); rep++)
         for (int vi = b.tid; vi < n_valid; vi += b.nth) {
             if (!okf[vi]) continue;
             V3 c = ld3(cand + 3 * vlist[vi]);
@@ -1865,21 +1878,35 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
 OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const double *att, int n_att, double delta) {
     SampleScalars *sc = A.sc;
     const int n_nodes = sc->n_nodes[f];
-    // active node list (ascending id) and first_att reset
+#if defined(OCTA_SIM_PROF_ASSIGN) && defined(__HIP_DEVICE_COMPILE__)
+    // diagnostic build: the kd slots of the phase profile hold this phase's steps (both forests): active list, grid, queries, heads,
+    // counts + starts, member scatter, member order
+    long _at = (long)wall_clock64();
+#define ASP(slot) do { if (b.tid == 0) { long _t = (long)wall_clock64(); sc->kdprof[slot] += _t - _at; _at = _t; } } while (0)
+#else
+#define ASP(slot) do { } while (0)
+#endif
+    // active node list (ascending id)
     int n_act = 0;
     {
         const int chunk = (n_nodes + b.nth - 1) / b.nth;
         const int i0 = b.tid * chunk, i1 = (i0 + chunk < n_nodes) ? i0 + chunk : n_nodes;
         int local = 0;
-        for (int i = i0; i < i1; i++) { A.first_att[i] = 0x7fffffff; local += A.nact_of(f)[i] ? 1 : 0; }
+        for (int i = i0; i < i1; i++) local += A.nact_of(f)[i] ? 1 : 0;
         int ex;
         n_act = blk_scan(b, local, &ex);
         int run = ex;
         for (int i = i0; i < i1; i++) if (A.nact_of(f)[i]) A.act_list[run++] = i;
     }
     b.sync();
+    ASP(0);
     {
         Grid G = grid_build(b, A, A.npos_of(f), A.act_list, n_act, delta);
+        ASP(1);
+        // (Round 4 measured a pruned nearest-neighbour search on a grid of four cells per radius -- rows outwards from the query's own, a
+        // row dropped or cut as soon as the best distance allows: fewer points read per query, results identical -- and it was SLOWER,
+        // 48 -> 53 ms per sample: the pruning makes every row pair a dependent round trip, and this loop is bound by round trips, not
+        // by the points it reads, which come out of the L2.)
         for (int a = b.tid; a < n_att; a += b.nth) {
             V3 p = ld3(att + 3 * a);
             double bd = INFINITY;
@@ -1888,73 +1915,133 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
                 double d2 = sqdist(q, p);
                 if (d2 < bd || (d2 == bd && j < best)) { bd = d2; best = j; }
             });
-            int r = (best >= 0 && sqrt(bd) <= delta) ? best : -1;
-            A.nn[a] = r;
-            if (r >= 0) atomic_min_int(&A.first_att[r], a);
+            A.nn[a] = (best >= 0 && sqrt(bd) <= delta) ? best : -1;
         }
         b.sync();
+        ASP(2);
     }
-    // dict order without a sort: attractor a heads a group iff it is the first hit of its node, so an
-    // ordered compaction of the heads IS the dict order; members are scattered with a per-group cursor
-    // and each (short) member list is put back into attractor order by one thread.
+    // Group bookkeeping -- dict order without a sort: attractor a heads a group iff it is the first hit of its node, so an ordered
+    // compaction of the heads IS the dict order; members are scattered with a per-group cursor and each (short) member list is put
+    // back into attractor order by one thread. The grid is dead, so the tables of these steps live in the table area (LDS in the
+    // default build): every step is a scatter or an atomic on a few-KB table, which in HBM scratch was a 128-byte line in and out of
+    // the L2 per 4-byte update (round 4: this phase was 30 % of the kernel's L2-miss traffic, its write side most of all).
+    //   fa[n_nodes]: first attractor of a node, then -(group + 1);  gc / cur[n_groups]: member count / scatter cursor;
+    //   srt[<= n_att]: members grouped.  fa always fits; the rest falls back to the HBM arrays when the counts are too large.
+    int *fa = reinterpret_cast<int *>(b.user());
+    static_assert((size_t)NCAP * 4 <= (size_t)SIM_USER_BYTES, "first-attractor table");
+    for (int i = b.tid; i < n_nodes; i += b.nth) fa[i] = 0x7fffffff;
+    b.sync();
+    for (int a = b.tid; a < n_att; a += b.nth) { const int r = A.nn[a]; if (r >= 0) atomic_min_int(&fa[r], a); }
+    b.sync();
     int n_groups = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    {   // ordered compaction of the heads, a contiguous segment of the attractors per wave, 64 consecutive ones per step
+        const int lane = b.tid & 63, wv = b.tid >> 6, nw = (b.nth + 63) >> 6;
+        const int seg = ((n_att + nw * 64 - 1) / (nw * 64)) * 64;
+        const int s0 = wv * seg < n_att ? wv * seg : n_att, s1 = s0 + seg < n_att ? s0 + seg : n_att;
+        int cnt = 0;
+        for (int a0 = s0; a0 < s1; a0 += 64) {
+            const int a = a0 + lane;
+            bool h = false;
+            if (a < s1) { const int r = A.nn[a]; h = r >= 0 && fa[r] == a; }
+            cnt += __popcll(__ballot(h));
+        }
+        int ex;
+        n_groups = blk_scan(b, lane == 0 ? cnt : 0, &ex);
+        int base = __shfl(ex, 0, 64);
+        for (int a0 = s0; a0 < s1; a0 += 64) {
+            const int a = a0 + lane;
+            bool h = false;
+            int r = -1;
+            if (a < s1) { r = A.nn[a]; h = r >= 0 && fa[r] == a; }
+            const unsigned long long m = __ballot(h);
+            if (h) {
+                const int g = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (g < GCAP) { A.gnode[g] = r; fa[r] = -(g + 1); }      // (a reader of fa[r] on another lane holds a different a: no match either way)
+            }
+            base += __popcll(m);
+        }
+    }
+#else
     {
         const int chunk = (n_att + b.nth - 1) / b.nth;
         const int i0 = b.tid * chunk, i1 = (i0 + chunk < n_att) ? i0 + chunk : n_att;
         int local = 0;
-        for (int a = i0; a < i1; a++) { int r = A.nn[a]; local += (r >= 0 && A.first_att[r] == a) ? 1 : 0; }
+        for (int a = i0; a < i1; a++) { int r = A.nn[a]; local += (r >= 0 && fa[r] == a) ? 1 : 0; }
         int ex;
         n_groups = blk_scan(b, local, &ex);
         int g = ex;
         for (int a = i0; a < i1; a++) {
             int r = A.nn[a];
-            if (r >= 0 && A.first_att[r] == a) {
-                if (g < GCAP) { A.gnode[g] = r; A.node_group[r] = g; A.gcount[g] = 0; }
+            if (r >= 0 && fa[r] == a) {
+                if (g < GCAP) { A.gnode[g] = r; fa[r] = -(g + 1); }
                 g++;
             }
         }
     }
+#endif
     b.sync();
+    ASP(3);
     if (n_groups > GCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_GROUP_CAP); n_groups = GCAP; }
-    int *cursor = A.tmp_int;
-    for (int a = b.tid; a < n_att; a += b.nth) {
-        int r = A.nn[a];
-        if (r >= 0) { int g = A.node_group[r]; if (g < GCAP) atomic_add_int(&A.gcount[g], 1); }
-    }
-    b.sync();
     int n_sorted = 0;
-    {
-        const int chunk = (n_groups + b.nth - 1) / b.nth;
-        const int g0 = b.tid * chunk, g1 = (g0 + chunk < n_groups) ? g0 + chunk : n_groups;
-        int local = 0;
-        for (int g = g0; g < g1; g++) local += A.gcount[g];
-        int ex;
-        n_sorted = blk_scan(b, local, &ex);
-        int run = ex;
-        for (int g = g0; g < g1; g++) { A.gstart[g] = run; cursor[g] = run; run += A.gcount[g]; }
-    }
-    b.sync();
-    if (n_sorted > SORTCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_OXY_CAP); }
-    for (int a = b.tid; a < n_att; a += b.nth) {
-        int r = A.nn[a];
-        if (r >= 0) {
-            int g = A.node_group[r];
-            if (g < GCAP) { int pos = atomic_add_int(&cursor[g], 1); if (pos < SORTCAP) A.sorted[pos] = (unsigned)a; }
+    // staged: the tables are in the table area and the results are copied out; otherwise the HBM arrays themselves are the tables
+    auto book = [&](int *gc, int *cur, unsigned *srt, const bool staged) __attribute__((always_inline)) {
+        for (int g = b.tid; g < n_groups; g += b.nth) gc[g] = 0;
+        b.sync();
+        for (int a = b.tid; a < n_att; a += b.nth) {
+            const int r = A.nn[a];
+            if (r >= 0) { const int v = fa[r]; if (v < 0) atomic_add_int(&gc[-v - 1], 1); }
         }
-    }
-    b.sync();
-    for (int g = b.tid; g < n_groups; g += b.nth) {
-        unsigned *v = A.sorted + A.gstart[g];
-        const int cnt = A.gcount[g];
-        for (int i = 1; i < cnt; i++) {
-            unsigned x = v[i];
-            int j = i - 1;
-            while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; j--; }
-            v[j + 1] = x;
+        b.sync();
+        {
+            const int chunk = (n_groups + b.nth - 1) / b.nth;
+            const int g0 = b.tid * chunk, g1 = (g0 + chunk < n_groups) ? g0 + chunk : n_groups;
+            int local = 0;
+            for (int g = g0; g < g1; g++) local += gc[g];
+            int ex;
+            n_sorted = blk_scan(b, local, &ex);
+            int run = ex;
+            for (int g = g0; g < g1; g++) { const int c = gc[g]; A.gstart[g] = run; cur[g] = run; if (staged) A.gcount[g] = c; run += c; }
         }
-    }
+        b.sync();
+        ASP(4);
+        if (n_sorted > SORTCAP) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_OXY_CAP); }
+        for (int a = b.tid; a < n_att; a += b.nth) {
+            const int r = A.nn[a];
+            if (r >= 0) {
+                const int v = fa[r];
+                if (v < 0) { const int pos = atomic_add_int(&cur[-v - 1], 1); if (pos < SORTCAP) srt[pos] = (unsigned)a; }
+            }
+        }
+        b.sync();
+        ASP(5);
+        for (int g = b.tid; g < n_groups; g += b.nth) {
+            const int cnt = gc[g];
+            unsigned *v = srt + (cur[g] - cnt);      // the cursor ended at the group's end
+            for (int i = 1; i < cnt; i++) {
+                unsigned x = v[i];
+                int j = i - 1;
+                while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; j--; }
+                v[j + 1] = x;
+            }
+        }
+        if (staged) {
+            b.sync();
+            const int n_out = n_sorted < SORTCAP ? n_sorted : SORTCAP;
+            for (int k = b.tid; k < n_out; k += b.nth) A.sorted[k] = srt[k];
+        }
+    };
+#ifdef OCTA_SIM_ASSIGN_FORCE_HBM
+    const bool fits = false;
+#else
+    const bool fits = (size_t)4 * ((size_t)n_nodes + 2 * (size_t)n_groups + (size_t)n_att) <= (size_t)SIM_USER_BYTES;
+#endif
+    if (fits) book(fa + n_nodes, fa + n_nodes + n_groups, reinterpret_cast<unsigned *>(fa + n_nodes + 2 * n_groups), true);
+    else book(A.gcount, A.tmp_int, A.sorted, false);
     if (b.tid == 0) { sc->n_groups[f] = n_groups; sc->n_sorted[f] = n_sorted; }
     b.sync();
+    ASP(6);
+#undef ASP
 }
 
 // ------------------------------------------------------------------ per-node growth geometry
@@ -2512,6 +2599,9 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     if (n_pairs == 0) return;  // nothing satisfied: no conversion, no deletion (uniform across the block)
     // 2. cKDTree order of the O2 list, only as deep as the hit sinks need it; pairs get kd ranks
     kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank, reinterpret_cast<float *>(A.hashes) /* free until step 3 */, 0.0, zext, sc->kdprof, A.removed);
+#if OCTA_SIM_DUP & 1
+    kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank, reinterpret_cast<float *>(A.hashes), 0.0, zext, nullptr, A.removed);
+#endif
     for (int i = b.tid; i < n_pairs; i += b.nth) {
         unsigned pr = A.pairs[i];
         A.pairs[i] = (pr & ~IDX_MASK) | (unsigned)A.kd_rank[pr & IDX_MASK];

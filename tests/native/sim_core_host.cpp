@@ -120,17 +120,16 @@ int octa_simcore_host_run(const host_sim_params *hp, unsigned np_seed, unsigned 
     std::vector<double> oxy((size_t)OCAP * 3), co2((size_t)CCAP * 3), cand((size_t)NCANDCAP * 3), tmp_dbl((size_t)OCAP * 3);
     std::vector<double> grid_pts((size_t)GRID_N * 3);
     A.grid_pts = grid_pts.data();
-    std::vector<int> nn(OCAP), first_att(NCAP), act_list(NCAP), gnode(GCAP), gstart(GCAP), gcount(GCAP), set_key(SETCAP), tmp_int(OCAP + 2 * NCANDCAP);
+    std::vector<int> nn(OCAP), act_list(NCAP), gnode(GCAP), gstart(GCAP), gcount(GCAP), set_key(SETCAP), tmp_int(OCAP + 2 * NCANDCAP);
     std::vector<unsigned> sorted(SORTCAP), pairs(PCAP);
     std::vector<Rec> rec(GCAP);
     std::vector<int> glist(GCAP), child_group(NCAP, 0);
-    std::vector<int> node_group(NCAP, 0);
-    A.glist = glist.data(); A.child_group = child_group.data(); A.node_group = node_group.data();
+    A.glist = glist.data(); A.child_group = child_group.data();
     std::vector<idx_t> kd_idx(OCAP), kd_rank(OCAP);
     std::vector<unsigned char> removed(OCAP), ven_near(OCAP);
     std::vector<unsigned long long> hashes(OCAP), set_hash(SETCAP);
     A.oxy = oxy.data(); A.co2 = co2.data(); A.cand = cand.data(); A.py_u = S.py_u.data();
-    A.nn = nn.data(); A.first_att = first_att.data(); A.act_list = act_list.data(); A.sorted = sorted.data();
+    A.nn = nn.data(); A.act_list = act_list.data(); A.sorted = sorted.data();
     A.gnode = gnode.data(); A.gstart = gstart.data(); A.gcount = gcount.data(); A.rec = rec.data();
     A.kd_idx = kd_idx.data(); A.kd_rank = kd_rank.data(); A.removed = removed.data(); A.ven_near = ven_near.data();
     A.hashes = hashes.data(); A.pairs = pairs.data(); A.set_hash = set_hash.data(); A.set_key = set_key.data();

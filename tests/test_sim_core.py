@@ -159,6 +159,26 @@ def test_phases_reproduce_reference_csv(core, golden):
         assert e_or.shape == (info[0], 7) and (e_or == edges[: info[0]]).all(), name
 
 
+def test_assignment_bookkeeping_fallback_to_hbm_arrays(golden):
+    """phase_assign keeps its group tables in the table area when they fit (sim_core.h); a forest too large for that uses the HBM
+    arrays instead. -DOCTA_SIM_ASSIGN_FORCE_HBM takes that path always: same CSV bytes, same trace."""
+    lib = _load_core("libsimcorehost_assign_hbm.so", ["-DOCTA_SIM_ASSIGN_FORCE_HBM"])
+    for name in ("run_s0_30_20", "run_s5_10_5"):
+        seed, i1, i2 = (int(v) for v in golden[name + "_seed_I"])
+        cfg = yaml.safe_load(str(golden["config_yaml"]))
+        cfg["Greenhouse"]["modes"][0]["I"] = i1
+        cfg["Greenhouse"]["modes"][1]["I"] = i2
+        p = sim_oracle.params_from_config(cfg)
+        edges = np.zeros((40000, 7))
+        trace = np.zeros((max(i1 + i2, 1), 4), np.int64)
+        info = np.zeros(8, np.int64)
+        rc = lib.octa_simcore_host_run(ctypes.addressof(p), seed, seed, sim_oracle._bif_cb, edges.ctypes.data, 40000,
+                                       trace.ctypes.data, info.ctypes.data)
+        assert rc == 0 and info[2] == 0
+        assert (trace[: info[7]] == golden[name + "_trace"]).all(), name
+        assert sim_oracle.edges_to_csv_text(edges[: info[0]]).encode() == golden[name + "_csv"].tobytes(), name
+
+
 def test_phases_reproduce_reference_csv_on_other_masks(core, tmp_path):
     """The device phase code (host build) on the reference-made fixtures for other mask shapes and the z source walls
     (tests/golden/sim_masks_golden.npz; simulation_space.py:29-34, 70-76, forest.py:153-181)."""
