@@ -1919,6 +1919,15 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
         }
         b.sync();
         ASP(2);
+#if defined(OCTA_SIM_ASSIGN_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+        {
+            long vis = 0;
+            for (int a = 0; a < n_att; a++) { V3 p = ld3(att + 3 * a); grid_visit(G, p.x, p.y, delta, [&](int, const V3 &) { vis++; }); }
+            static int *prev_nn[2] = {nullptr, nullptr};
+            fprintf(stderr, "assign f=%d n_nodes=%d n_act=%d n_att=%d visited/query=%.1f cells=%d\n", f, n_nodes, n_act, n_att, n_att ? (double)vis / n_att : 0.0, G.nx);
+            (void)prev_nn;
+        }
+#endif
     }
     // Group bookkeeping -- dict order without a sort: attractor a heads a group iff it is the first hit of its node, so an ordered
     // compaction of the heads IS the dict order; members are scattered with a per-group cursor and each (short) member list is put
@@ -2252,26 +2261,89 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
     b.sync();
     const int tag = A.sc->pass_tag[f];
     int n_grow = 0;
+    // Leaves and inter-nodes are evaluated by different code of a few thousand instructions each, and the groups come in dict order,
+    // i.e. mixed: taken 64 consecutive groups at a time EVERY wave ran both evaluations one after the other (a full-length sample:
+    // ~3000 leaf and ~600 inter-node groups per pass towards the end, 57 of 57 waves mixed). The groups are therefore split by kind
+    // first (two id lists in the table area, order irrelevant), each list is evaluated by whole waves, and the list of the groups
+    // that grow -- which has to be in group order -- comes from one ordered compaction of a flag per group afterwards.
+    idx_t *leaf = reinterpret_cast<idx_t *>(b.user());
+    idx_t *inter = leaf + GCAP;
+    unsigned char *growf = reinterpret_cast<unsigned char *>(inter + GCAP);
+    static_assert((size_t)2 * GCAP * sizeof(idx_t) + (size_t)GCAP <= (size_t)SIM_USER_BYTES, "speculation lists");
+    int *cnt = b.coll() + 110;       // [0] leaves, [1] inter-nodes
+    if (b.tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+    b.sync();
     for (int base = 0; base < ng; base += b.nth) {
-        int g = base + b.tid;
-        int grows = 0;
+        const int g = base + b.tid;
+        int cls = -1;                 // 0 leaf, 1 inter-node, 2 neither
         if (g < ng) {
-            Rec R;
-            memset(&R, 0, sizeof(R));
-            int id = A.gnode[g];
-            int nch = A.nnch_of(f)[id], par = A.npar_of(f)[id];
-            if (nch == 0) eval_leaf(G, g, R, reqs, req_count, req_cap, sample);
-            else if (par >= 0 && nch == 1) eval_inter<false>(G, g, R);
-            else { R.type = 0; R.node = id; R.req = -1; }
-            A.rec[g] = R;
-            grows = (R.type == 1) || (R.type == 3 && R.grow);
-            if (R.type == 3) A.child_group[A.nch0_of(f)[id]] = (tag << (GROUP_BITS + 1)) | ((int)R.grow << GROUP_BITS) | g;
+            const int id = A.gnode[g];
+            const int nch = A.nnch_of(f)[id], par = A.npar_of(f)[id];
+            cls = nch == 0 ? 0 : ((par >= 0 && nch == 1) ? 1 : 2);
+            if (cls == 2) {
+                Rec R;
+                memset(&R, 0, sizeof(R));
+                R.type = 0; R.node = id; R.req = -1;
+                A.rec[g] = R;
+            }
+            growf[g] = 0;
         }
-        int ex;
-        int tot = blk_scan(b, grows, &ex);
-        if (grows) A.glist[n_grow + ex] = g;
-        n_grow += tot;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int lane = b.tid & 63;
+        for (int c = 0; c < 2; c++) {
+            const unsigned long long m = __ballot(cls == c);
+            if (m) {
+                int at = 0;
+                if (lane == (int)__ffsll((long long)m) - 1) at = atomic_add_int(&cnt[c], (int)__popcll(m));
+                at = __shfl(at, (int)__ffsll((long long)m) - 1, 64);
+                if (cls == c) (c == 0 ? leaf : inter)[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = (idx_t)g;
+            }
+        }
+#else
+        if (cls == 0) leaf[cnt[0]++] = (idx_t)g;
+        if (cls == 1) inter[cnt[1]++] = (idx_t)g;
+#endif
     }
+    b.sync();
+    const int n_leaf = cnt[0], n_inter = cnt[1];
+    for (int k = b.tid; k < n_leaf; k += b.nth) {
+        const int g = (int)leaf[k];
+        Rec R;
+        memset(&R, 0, sizeof(R));
+        eval_leaf(G, g, R, reqs, req_count, req_cap, sample);
+        A.rec[g] = R;
+        growf[g] = R.type == 1 ? 1 : 0;
+    }
+    for (int k = b.tid; k < n_inter; k += b.nth) {
+        const int g = (int)inter[k];
+        Rec R;
+        memset(&R, 0, sizeof(R));
+        eval_inter<false>(G, g, R);
+        A.rec[g] = R;
+        growf[g] = (R.type == 3 && R.grow) ? 1 : 0;
+        if (R.type == 3) A.child_group[A.nch0_of(f)[A.gnode[g]]] = (tag << (GROUP_BITS + 1)) | ((int)R.grow << GROUP_BITS) | g;
+    }
+    b.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+    {   // ordered compaction of the flags: a contiguous segment of the groups per wave, 64 consecutive ones per step
+        const int lane = b.tid & 63, wv = b.tid >> 6, nw = (b.nth + 63) >> 6;
+        const int seg = ((ng + nw * 64 - 1) / (nw * 64)) * 64;
+        const int s0 = wv * seg < ng ? wv * seg : ng, s1 = s0 + seg < ng ? s0 + seg : ng;
+        int c = 0;
+        for (int g0 = s0; g0 < s1; g0 += 64) c += (int)__popcll(__ballot(g0 + lane < s1 && growf[g0 + lane]));
+        int ex;
+        n_grow = blk_scan(b, lane == 0 ? c : 0, &ex);
+        int at = __shfl(ex, 0, 64);
+        for (int g0 = s0; g0 < s1; g0 += 64) {
+            const bool gr = g0 + lane < s1 && growf[g0 + lane];
+            const unsigned long long m = __ballot(gr);
+            if (gr) A.glist[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = g0 + lane;
+            at += (int)__popcll(m);
+        }
+    }
+#else
+    for (int g = 0; g < ng; g++) if (growf[g]) A.glist[n_grow++] = g;
+#endif
     if (b.tid == 0) A.sc->n_grow[f] = n_grow;
     b.sync();
 }
