@@ -941,7 +941,7 @@ static_assert(KD_MAILBOX_OFF + (KD_BOX_BYTES > KD_MAILBOX_BYTES ? KD_BOX_BYTES :
 // whose x and y boxes are thinner than the slab, and those are measured exactly).
 OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_idx, idx_t *out_rank,
                               float *xy, double zlo, double zhi, long *kdprof = nullptr, const unsigned char *need = nullptr) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(OCTA_SIM_PROF_ASSIGN)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OCTA_SIM_PROF_ASSIGN) && !defined(OCTA_SIM_PROF_SAMPLE)
 #define KDP(slot) do { if (kdprof && b.tid == 0) { long _t = (long)wall_clock64(); kdprof[slot] += _t - _kt; _kt = _t; } } while (0)
     long _kt = (long)wall_clock64();
 #else
@@ -989,27 +989,50 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
                     atomic_min_u32(&bbf[6 * qq + 3 + k], f32_sortable(nextafterf(mn[k], -INFINITY)));
                 }
             };
-            // the walk keeps the bounds of its range and the start of the next one in registers (round 4: one table read per range
-            // crossed instead of three per element -- every table read is a FLAT instruction in this build)
-            int cs = 0, ce = 0, ns = 0x7fffffff;
-            if (i0 < i1) { cs = rs[q]; ce = re[q]; ns = q + 1 < nr ? (int)rs[q + 1] : 0x7fffffff; }
-            for (int i = i0; i < i1; i++) {
-                while (i >= ns) {
-                    if (have) { flush(q); have = false; }
-                    if (hit) { rd[q] = 1; hit = false; }
-                    q++;
-                    cs = ns; ce = re[q]; ns = q + 1 < nr ? (int)rs[q + 1] : 0x7fffffff;
+            // KB elements per round: the range walk and the element words come out of the LDS first, then the KB coordinate pairs (and
+            // need flags) of the live ones are fetched TOGETHER, then folded in element order (round 4: 30.9 -> 27.1 ms per sample; the
+            // same batching in the key pass below measured slower, 18.9 -> 21.7, and is not used there). The walk keeps the bounds of
+            // its range and the start of the next one in registers: one table read per range crossed instead of three per element.
+            constexpr int KB = 8;
+            int qw = q, cs = 0, ce = 0, ns = 0x7fffffff;
+            if (i0 < i1) { cs = rs[qw]; ce = re[qw]; ns = qw + 1 < nr ? (int)rs[qw + 1] : 0x7fffffff; }
+            for (int ib = i0; ib < i1; ib += KB) {
+                int eq[KB], eid[KB];
+                kdw_t ew[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) ew[k] = kv[ib + k < i1 ? ib + k : i1 - 1];
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    const int i = ib + k;
+                    eq[k] = -1; eid[k] = 0;
+                    if (i < i1) {
+                        while (i >= ns) { qw++; cs = ns; ce = re[qw]; ns = qw + 1 < nr ? (int)rs[qw + 1] : 0x7fffffff; }
+                        if (i >= cs && i < ce) { eq[k] = qw; eid[k] = (int)(ew[k] & KD_IDX_MASK); }
+                    }
                 }
-                if (i < cs || i >= ce) continue;  // element of a finished leaf
-                const int id = (int)(kv[i] & KD_IDX_MASK);
-                if (!need || need[id]) hit = true;
-                const float ex = xy[2 * id], ey = xy[2 * id + 1];
-                if (!have) { mx[0] = mn[0] = ex; mx[1] = mn[1] = ey; }
-                else {
-                    mx[0] = mx[0] > ex ? mx[0] : ex; mn[0] = mn[0] < ex ? mn[0] : ex;
-                    mx[1] = mx[1] > ey ? mx[1] : ey; mn[1] = mn[1] < ey ? mn[1] : ey;
+                float ex[KB], ey[KB];
+                unsigned char nd[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    ex[k] = xy[2 * eid[k]]; ey[k] = xy[2 * eid[k] + 1];
+                    nd[k] = need ? need[eid[k]] : (unsigned char)1;
                 }
-                have = true;
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    if (eq[k] < 0) continue;    // element of a finished leaf / beyond the chunk
+                    if (eq[k] != q) {
+                        if (have) { flush(q); have = false; }
+                        if (hit) { rd[q] = 1; hit = false; }
+                        q = eq[k];
+                    }
+                    if (nd[k]) hit = true;
+                    if (!have) { mx[0] = mn[0] = ex[k]; mx[1] = mn[1] = ey[k]; }
+                    else {
+                        mx[0] = mx[0] > ex[k] ? mx[0] : ex[k]; mn[0] = mn[0] < ex[k] ? mn[0] : ex[k];
+                        mx[1] = mx[1] > ey[k] ? mx[1] : ey[k]; mn[1] = mn[1] < ey[k] ? mn[1] : ey[k];
+                    }
+                    have = true;
+                }
             }
             if (have) flush(q);
             if (hit) rd[q] = 1;
@@ -1740,6 +1763,14 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     const double fcx = C.fc0 * GSd, fcy = C.fc1 * GSd, fr = sc->faz_radius * GSd * 0.5;
     int *vlist = A.tmp_int;               // valid candidate indices, in order
     int *plist = A.tmp_int + NCANDCAP;    // passing candidate indices, in order
+#if defined(OCTA_SIM_PROF_SAMPLE) && defined(__HIP_DEVICE_COMPILE__)
+    // diagnostic build: the kd slots of the phase profile hold this phase's steps: validity, grid over the arterial nodes, radius test,
+    // grid over the sinks, nearest-sink test, compaction of the passers, greedy acceptance + append
+    long _st = (long)wall_clock64();
+#define SSP(slot) do { if (b.tid == 0) { long _t = (long)wall_clock64(); sc->kdprof[slot] += _t - _st; _st = _t; } } while (0)
+#else
+#define SSP(slot) do { } while (0)
+#endif
     // 1. is_valid_position (simulation_space.py:89-98), ordered compaction
     int n_valid = 0;
     {
@@ -1767,6 +1798,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
         for (int i = i0; i < i1; i++) if (A.removed[i]) vlist[run++] = i;
     }
     b.sync();
+    SSP(0);
     // 2. tests against all arterial nodes (ball en, oxygen distance) and existing sinks (NN <= es). The candidates are the queries:
     //    a candidate stops at the first node / sink that rejects it, and most are rejected by one of the first few. (Round 3 measured
     //    the inverted form -- grid over the <= N candidates, every node and sink visiting the cells around itself -- which writes no
@@ -1779,6 +1811,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     for (int i = b.tid; i < n_art; i += b.nth) oxd[i] = oxygen_distance(A.nrad[0][i], C.ps);
     {
         Grid G = grid_build(b, A, A.npos[0], nullptr, n_art, en);
+        SSP(1);
         for (int rep = 0; rep < ((OCTA_SIM_DUP & 8) ? 2 : 1); rep++)
         for (int vi = b.tid; vi < n_valid; vi += b.nth) {
             V3 c = ld3(cand + 3 * vlist[vi]);
@@ -1792,9 +1825,11 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
             okf[vi] = ok ? 1 : 0;
         }
         b.sync();
+        SSP(2);
     }
     {
         Grid G = grid_build(b, A, A.oxy, nullptr, n_oxy, es);
+        SSP(3);
         for (int rep = 0; rep < ((OCTA_SIM_DUP & 8) ? 2 : 1); rep++)
         for (int vi = b.tid; vi < n_valid; vi += b.nth) {
             if (!okf[vi]) continue;
@@ -1806,6 +1841,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
             okf[vi] = ok ? 1 : 0;
         }
         b.sync();
+        SSP(4);
     }
     int n_pass = 0;
     {
@@ -1819,6 +1855,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
         for (int vi = i0; vi < i1; vi++) if (okf[vi]) plist[run++] = vlist[vi];
     }
     b.sync();
+    SSP(5);
     // 3. ordered greedy acceptance against the sinks accepted earlier in this call (strict >)
     double *acc = reinterpret_cast<double *>(b.user_of<4>());  // [ACCCAP][3]
     int *ctl = b.coll() + 100;
@@ -1872,6 +1909,8 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     b.sync();
     if (b.tid == 0) sc->n_oxy = n_oxy + acc_n;
     b.sync();
+    SSP(6);
+#undef SSP
 }
 
 // ------------------------------------------------------------------ phase: nearest active node + dict order
@@ -2266,46 +2305,47 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
     // ~3000 leaf and ~600 inter-node groups per pass towards the end, 57 of 57 waves mixed). The groups are therefore split by kind
     // first (two id lists in the table area, order irrelevant), each list is evaluated by whole waves, and the list of the groups
     // that grow -- which has to be in group order -- comes from one ordered compaction of a flag per group afterwards.
-    idx_t *leaf = reinterpret_cast<idx_t *>(b.user());
-    idx_t *inter = leaf + GCAP;
-    unsigned char *growf = reinterpret_cast<unsigned char *>(inter + GCAP);
-    static_assert((size_t)2 * GCAP * sizeof(idx_t) + (size_t)GCAP <= (size_t)SIM_USER_BYTES, "speculation lists");
-    int *cnt = b.coll() + 110;       // [0] leaves, [1] inter-nodes
-    if (b.tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+    // ... and inside a kind by the number of attractors (16 buckets; a counting sort in the table area): the attractor loops of a
+    // wave run as long as its longest group, and the counts range from 1 to ~10 around a mean of 2.
+    idx_t *leaf = reinterpret_cast<idx_t *>(b.user());            // [n_leaf] leaves, then [n_inter] inter-nodes behind them
+    idx_t *posv = leaf + GCAP;                                    // [ng] rank of a group inside its bucket
+    unsigned char *keyv = reinterpret_cast<unsigned char *>(posv + GCAP);      // [ng] bucket: kind * 16 + min(count, 15); 32 = neither
+    unsigned char *growf = keyv + GCAP;                           // [ng] the group grows
+    static_assert((size_t)2 * GCAP * sizeof(idx_t) + (size_t)2 * GCAP <= (size_t)SIM_USER_BYTES, "speculation lists");
+    int *cnt = b.coll() + 110;       // [32] bucket sizes, then bucket starts
+    static_assert(110 + 32 <= 396, "bucket counters in the collectives area");
+    for (int k = b.tid; k < 32; k += b.nth) cnt[k] = 0;
     b.sync();
-    for (int base = 0; base < ng; base += b.nth) {
-        const int g = base + b.tid;
-        int cls = -1;                 // 0 leaf, 1 inter-node, 2 neither
-        if (g < ng) {
-            const int id = A.gnode[g];
-            const int nch = A.nnch_of(f)[id], par = A.npar_of(f)[id];
-            cls = nch == 0 ? 0 : ((par >= 0 && nch == 1) ? 1 : 2);
-            if (cls == 2) {
-                Rec R;
-                memset(&R, 0, sizeof(R));
-                R.type = 0; R.node = id; R.req = -1;
-                A.rec[g] = R;
-            }
-            growf[g] = 0;
+    for (int g = b.tid; g < ng; g += b.nth) {
+        const int id = A.gnode[g];
+        const int nch = A.nnch_of(f)[id], par = A.npar_of(f)[id];
+        const int cls = nch == 0 ? 0 : ((par >= 0 && nch == 1) ? 1 : 2);
+        int key = 32;
+        if (cls == 2) {
+            Rec R;
+            memset(&R, 0, sizeof(R));
+            R.type = 0; R.node = id; R.req = -1;
+            A.rec[g] = R;
+        } else {
+            const int c = A.gcount[g];
+            key = cls * 16 + (c < 15 ? c : 15);
+            posv[g] = (idx_t)atomic_add_int(&cnt[key], 1);
         }
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int lane = b.tid & 63;
-        for (int c = 0; c < 2; c++) {
-            const unsigned long long m = __ballot(cls == c);
-            if (m) {
-                int at = 0;
-                if (lane == (int)__ffsll((long long)m) - 1) at = atomic_add_int(&cnt[c], (int)__popcll(m));
-                at = __shfl(at, (int)__ffsll((long long)m) - 1, 64);
-                if (cls == c) (c == 0 ? leaf : inter)[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = (idx_t)g;
-            }
-        }
-#else
-        if (cls == 0) leaf[cnt[0]++] = (idx_t)g;
-        if (cls == 1) inter[cnt[1]++] = (idx_t)g;
-#endif
+        keyv[g] = (unsigned char)key;
+        growf[g] = 0;
     }
     b.sync();
-    const int n_leaf = cnt[0], n_inter = cnt[1];
+    const int n_leaf = [&] { int t = 0; for (int k = 0; k < 16; k++) t += cnt[k]; return t; }();
+    const int n_inter = [&] { int t = 0; for (int k = 16; k < 32; k++) t += cnt[k]; return t; }();
+    b.sync();
+    if (b.tid == 0) { int run = 0; for (int k = 0; k < 32; k++) { const int c = cnt[k]; cnt[k] = run; run += c; } }
+    b.sync();
+    for (int g = b.tid; g < ng; g += b.nth) {
+        const int key = keyv[g];
+        if (key < 32) leaf[cnt[key] + (int)posv[g]] = (idx_t)g;
+    }
+    b.sync();
+    const idx_t *inter = leaf + n_leaf;
     for (int k = b.tid; k < n_leaf; k += b.nth) {
         const int g = (int)leaf[k];
         Rec R;
