@@ -489,7 +489,11 @@ in_nhwc_bwd_apply(const unsigned short *__restrict__ x, const unsigned short *__
 
 int nhwc_splits(const octa_ctx *ctx, int B, long hw) {
     long s = (4L * ctx->num_cus + B - 1) / B;
-    const long by_size = hw / 512 > 0 ? hw / 512 : 1;
+    // at least this many pixels per workgroup. 512 until round 4: a 76 x 76 x 256 plane of the GAN's residual stages then ran on 11 x B
+    // workgroups (17 % of the CUs at B = 4); 128: GAN-seg step 56.8 -> 55.4 ms, U-Net step unchanged (OCTA_NORM_MIN_PIXELS = 16 ... 512
+    // measured, profiles/r04_norm_min_pixels.log)
+    static const long min_px = [] { const char *e = getenv("OCTA_NORM_MIN_PIXELS"); const long v = e ? atol(e) : 128; return v > 0 ? v : 128; }();
+    const long by_size = hw / min_px > 0 ? hw / min_px : 1;
     if (s > by_size) s = by_size;
     if (s < 1) s = 1;
     if (s > 1024) s = 1024;

@@ -1812,11 +1812,9 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     {
         Grid G = grid_build(b, A, A.npos[0], nullptr, n_art, en);
         SSP(1);
-        for (int rep = 0; rep < ((OCTA_SIM_DUP & 8) ? 2 : 1); rep++) {
-        V3 c_next = b.tid < n_valid ? ld3(cand + 3 * vlist[b.tid]) : v3(0, 0, 0);
+        for (int rep = 0; rep < ((OCTA_SIM_DUP & 8) ? 2 : 1); rep++)
         for (int vi = b.tid; vi < n_valid; vi += b.nth) {
-            const V3 c = c_next;
-            if (vi + b.nth < n_valid) c_next = ld3(cand + 3 * vlist[vi + b.nth]);
+            const V3 c = ld3(cand + 3 * vlist[vi]);
             bool ok = true;
             grid_visit(G, c.x, c.y, en, [&](int j, const V3 &q) {
                 if (ok) {
@@ -1825,7 +1823,6 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
                 }
             });
             okf[vi] = ok ? 1 : 0;
-        }
         }
         b.sync();
         SSP(2);
@@ -1949,12 +1946,10 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
         // row dropped or cut as soon as the best distance allows: fewer points read per query, results identical -- and it was SLOWER,
         // 48 -> 53 ms per sample: the pruning makes every row pair a dependent round trip, and this loop is bound by round trips, not
         // by the points it reads, which come out of the L2.)
-        // the query loops of this file are chains of dependent L2 / HBM round trips (query point -> cell bounds -> points, ~1.5 us each
-        // with 512 workgroups on the memory system): the next query's point is fetched while the current query runs
-        V3 p_next = b.tid < n_att ? ld3(att + 3 * b.tid) : v3(0, 0, 0);
+        // (fetching the next query's point while the current query runs -- here and in the other three query loops -- changes nothing:
+        // measured in round 4)
         for (int a = b.tid; a < n_att; a += b.nth) {
-            const V3 p = p_next;
-            if (a + b.nth < n_att) p_next = ld3(att + 3 * (a + b.nth));
+            const V3 p = ld3(att + 3 * a);
             double bd = INFINITY;
             int best = -1;
             grid_visit(G, p.x, p.y, delta, [&](int j, const V3 &q) {
@@ -2698,10 +2693,8 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
         for (int j = b.tid; j < n_new; j += b.nth) new_ids[j] = nb + j;
         b.sync();
         Grid G = grid_build(b, A, A.npos[0], new_ids, n_new, ek);
-        V3 p_next = b.tid < n_oxy ? ld3(A.oxy + 3 * b.tid) : v3(0, 0, 0);
         for (int o = b.tid; o < n_oxy; o += b.nth) {
-            const V3 p = p_next;
-            if (o + b.nth < n_oxy) p_next = ld3(A.oxy + 3 * (o + b.nth));
+            const V3 p = ld3(A.oxy + 3 * o);
             grid_visit(G, p.x, p.y, ek, [&](int j, const V3 &q) {
                 if (sqdist(p, q) <= ek2) {
                     int slot = atomic_add_int(&ctl[0], 1);
@@ -2935,10 +2928,8 @@ OCTA_HD inline void phase_satisfy_ven(const Blk &b, const SimArrays &A, const It
         for (int j = b.tid; j < n_new; j += b.nth) new_ids[j] = nb + j;
         b.sync();
         Grid G = grid_build(b, A, A.npos[1], new_ids, n_new, ek);
-        V3 p_next = b.tid < n_co2 ? ld3(A.co2 + 3 * b.tid) : v3(0, 0, 0);
         for (int o = b.tid; o < n_co2; o += b.nth) {
-            const V3 p = p_next;
-            if (o + b.nth < n_co2) p_next = ld3(A.co2 + 3 * (o + b.nth));
+            const V3 p = ld3(A.co2 + 3 * o);
             bool hit = false;
             grid_visit(G, p.x, p.y, ek, [&](int, const V3 &q) {
                 if (!hit && sqdist(p, q) <= ek2) hit = true;
