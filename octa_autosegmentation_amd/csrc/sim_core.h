@@ -286,6 +286,7 @@ struct Blk {
     int tid, nth;
     unsigned char *smem;  // LDS (device) or heap (host emulation); first 2 KiB reserved for collectives
     unsigned char *umem = nullptr;   // the per-phase table area when it is NOT the LDS behind the collectives (large build: HBM scratch)
+    mutable unsigned scan_calls = 0; // blk_scan's slot toggle (per thread; all threads of a workgroup make the same calls)
     OCTA_HD inline void sync() const {
 #if defined(__HIP_DEVICE_COMPILE__)
         octa_block_sync();
@@ -313,29 +314,35 @@ struct Blk {
     }
 };
 
-// exclusive scan of one int per thread; returns block total. Contains block syncs.
+// Inclusive prefix sum over the 64 lanes of a wave with DPP adds: four shifts inside the rows of 16 lanes, then lane 15 of rows 0 / 2 onto
+// rows 1 / 3 and lane 31 onto rows 2 and 3. Six VALU instructions; `__shfl_up` is six `ds_bpermute` round trips through the LDS unit.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+#endif
+
+// exclusive scan of one int per thread; returns block total. Contains ONE block sync (round 4; three until then): the wave totals go
+// into one of two alternating slots of the collectives area (every thread makes the same calls, so the slots alternate alike), and
+// every thread sums the totals of the waves in front of it itself. A wave can only reach the call after next -- which writes the
+// same slot again -- through the next call's barrier, i.e. after every wave has read this call's totals.
 OCTA_HD inline int blk_scan(const Blk &b, int v, int *excl) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int lane = b.tid & 63, wv = b.tid >> 6, nw = (b.nth + 63) >> 6;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int u = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += u;
-    }
-    int *sh = b.coll();
-    b.sync();
+    const int inc = wave_scan_incl(v);
+    int *sh = b.coll() + ((b.scan_calls++ & 1u) ? 16 : 0);
     if (lane == 63 || b.tid == b.nth - 1) sh[wv] = inc;
     b.sync();
-    if (b.tid == 0) {
-        int s = 0;
-        for (int k = 0; k < nw; k++) { int t = sh[k]; sh[k] = s; s += t; }
-        sh[64] = s;
-    }
-    b.sync();
-    *excl = sh[wv] + inc - v;
-    int tot = OCTA_UNI(sh[64]);
-    return tot;
+    int base = 0, tot = 0;
+    for (int k = 0; k < nw; k++) { const int t = sh[k]; base += k < wv ? t : 0; tot += t; }
+    *excl = base + inc - v;
+    return OCTA_UNI(tot);
 #else
     (void)b;
     *excl = 0;
@@ -348,6 +355,13 @@ OCTA_HD inline void atomic_min_int(int *p, int v) {
     atomicMin(p, v);
 #else
     if (v < *p) *p = v;
+#endif
+}
+OCTA_HD inline int atomic_min_ret_int(int *p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicMin(p, v);
+#else
+    int o = *p; if (v < o) *p = v; return o;
 #endif
 }
 OCTA_HD inline int atomic_add_int(int *p, int v) {
@@ -941,7 +955,7 @@ static_assert(KD_MAILBOX_OFF + (KD_BOX_BYTES > KD_MAILBOX_BYTES ? KD_BOX_BYTES :
 // whose x and y boxes are thinner than the slab, and those are measured exactly).
 OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_idx, idx_t *out_rank,
                               float *xy, double zlo, double zhi, long *kdprof = nullptr, const unsigned char *need = nullptr) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(OCTA_SIM_PROF_ASSIGN) && !defined(OCTA_SIM_PROF_SAMPLE)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OCTA_SIM_PROF_ASSIGN) && !defined(OCTA_SIM_PROF_SAMPLE) && !defined(OCTA_SIM_PROF_SET)
 #define KDP(slot) do { if (kdprof && b.tid == 0) { long _t = (long)wall_clock64(); kdprof[slot] += _t - _kt; _kt = _t; } } while (0)
     long _kt = (long)wall_clock64();
 #else
@@ -2780,63 +2794,202 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     const int dbg_n_co2_in = sc->n_co2;
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-    // Usual case (<= LSET_PAIRS hits): the insert stream (sink, hash) is compacted into LDS in parallel, the
-    // open-addressing table lives in LDS too (a table never exceeds 8 x its entries), one thread replays the
-    // insertions, and the occupied slots are read out in slot order by the whole block.
-    if (n_pairs <= LSET_PAIRS) {
-        set_in_lds = true;
-        unsigned long long *t_hash = reinterpret_cast<unsigned long long *>(b.user_of<64>());        // [LSET_CAP]
-        int *t_key = reinterpret_cast<int *>(t_hash + LSET_CAP);                               // [LSET_CAP]
-        unsigned long long *in_hash = reinterpret_cast<unsigned long long *>(t_key + LSET_CAP);  // [LSET_PAIRS]
-        int *in_key = reinterpret_cast<int *>(in_hash + LSET_PAIRS);                           // [LSET_PAIRS]
+    // Usual case (<= LSET_PAIRS hits): the insert stream (sink, hash) is compacted into the table area in parallel and the set is
+    // replayed there by the WHOLE workgroup (round 4; one wave inserting key after key until then: 21 ms per sample, the other three
+    // waves idle). What makes a parallel replay possible: a CPython set that only grows never moves an entry inside one table, so
+    // the slot of the k-th distinct key is the first slot of ITS probe sequence that no earlier key of the same table holds -- a
+    // fixed point that insertion with priorities computes in any order (a key that finds a slot held by a later key takes it and
+    // carries the displaced key on along that key's own sequence). A resize re-inserts the entries in the old table's slot order,
+    // which is the same operation with the old slot as the priority. The resizes happen at fixed counts of distinct keys
+    // (5, 19, 77, 307, ... -> 32, 128, 512, 2048 slots), so the replay is one priority insertion per table generation:
+    //   fp[OCAP]: first arrival of a sink (duplicates of a key never touch the table), later own[slot] = priority of the slot's entry,
+    //   at the end the slot's key (-1: empty) -- the table the read-out below walks;
+    //   in_key / in_hash: arrivals; dk / dh: distinct keys in arrival order; ord0 / ord1: entry of a priority (this / next generation).
+#if defined(OCTA_SIM_PROF_SET)
+    // diagnostic build: the kd slots of the phase profile hold the steps of the set replay: insert stream, distinct keys, generations,
+    // key table, read-out
+    long _pt = (long)wall_clock64();
+#define PSP(slot) do { if (b.tid == 0) { long _t = (long)wall_clock64(); sc->kdprof[slot] += _t - _pt; _pt = _t; } } while (0)
+#else
+#define PSP(slot) do { } while (0)
+#endif
+    constexpr int EMPTY = 0x7fffffff;
+    // own: [max(OCAP, s_max)] ints; in_key / in_hash: [n_pairs]; dk / dh / ord0 / ord1: [number of distinct sinks]. Returns the table's mask;
+    // own[slot] then holds the slot's key (-1: empty).
+    auto replay = [&](int *own, int *in_key, unsigned long long *in_hash, int *dk, unsigned long long *dh, int *ord0, int *ord1,
+                      const int s_max) __attribute__((always_inline)) -> int {
         int n_ins = 0;
         for (int p0 = 0; p0 < n_pairs; p0 += b.nth) {          // ordered compaction of the insert stream, b.nth pairs per round
             const int i = p0 + b.tid;
             int o = -1, take = 0;
+            unsigned long long hsh = 0;
             if (i < n_pairs) {
-                o = (int)A.kd_idx[A.pairs[i] & IDX_MASK];
+                o = (int)A.kd_idx[keys[i] & IDX_MASK];         // the sorted pairs are still in the LDS
                 take = A.ven_near[o] ? 0 : 1;
+                hsh = A.hashes[o];                             // fetched beside the flag, not behind it
             }
             int ex;
             const int tot = blk_scan(b, take, &ex);
-            if (take) { in_key[n_ins + ex] = o; in_hash[n_ins + ex] = A.hashes[o]; }
+            if (take) { in_key[n_ins + ex] = o; in_hash[n_ins + ex] = hsh; }
             n_ins += tot;
         }
         b.sync();
-        int *ctl2 = b.coll() + 100;
-        if (b.tid < 64) {                       // the first wave replays the insertions, its lanes share the resizes' bulk loops
-            PySetView S;
-            S.hash = t_hash; S.key = t_key; S.err = &sc->err; S.cap = LSET_CAP;
-            S.lane = b.tid; S.nl = b.nth >= 64 ? 64 : 1;
-            pyset_init(S);
-            for (int i = 0; i < n_ins; i++) pyset_add(S, in_key[i], in_hash[i]);
-            if (b.tid == 0) ctl2[1] = S.mask;
+        PSP(0);
+        // distinct keys in arrival order
+        for (int i = b.tid; i < n_ins; i += b.nth) own[in_key[i]] = EMPTY;
+        b.sync();
+        for (int i = b.tid; i < n_ins; i += b.nth) atomic_min_int(&own[in_key[i]], i);
+        b.sync();
+        int D = 0;
+        for (int p0 = 0; p0 < n_ins; p0 += b.nth) {
+            const int i = p0 + b.tid;
+            const bool first = i < n_ins && own[in_key[i]] == i;
+            int ex;
+            const int tot = blk_scan(b, first ? 1 : 0, &ex);
+            if (first) { dk[D + ex] = in_key[i]; dh[D + ex] = in_hash[i]; }
+            D += tot;
         }
         b.sync();
-        const int mask = ctl2[1];
-        const int n_co2_0 = sc->n_co2;
-        int base = 0;
-        for (int e0 = 0; e0 <= mask; e0 += b.nth) {
-            const int e = e0 + b.tid;
-            const int k = (e <= mask) ? t_key[e] : -1;
-            int ex2;
-            const int tot = blk_scan(b, k >= 0 ? 1 : 0, &ex2);
-            if (k >= 0) {
-                const int dst = n_co2_0 + base + ex2;
-                if (dst < CCAP) { A.co2[3 * dst] = A.oxy[3 * k]; A.co2[3 * dst + 1] = A.oxy[3 * k + 1]; A.co2[3 * dst + 2] = A.oxy[3 * k + 2]; }
+        PSP(1);
+        // one priority insertion per table generation
+        int S = 8, n_prev = 0;
+        int *ord = ord0, *ord_next = ord1;
+        while (true) {
+            const int thr = (3 * (S - 1) + 4) / 5;            // the insertion that makes fill * 5 >= mask * 3 resizes the table
+            const int upto = D < thr ? D : thr;               // distinct keys of this generation's table
+            const unsigned long long mask = (unsigned long long)(S - 1);
+            for (int p = n_prev + b.tid; p < upto; p += b.nth) ord[p] = p;      // behind the re-inserted entries: the arrivals, in order
+            for (int e = b.tid; e < S; e += b.nth) own[e] = EMPTY;
+            b.sync();
+            for (int p = b.tid; p < upto; p += b.nth) {
+                int cur = p;
+                // CPython's probe sequence: slot i, then up to nine slots behind it (if they fit), then i = 5 i + 1 + (perturb >>= 5)
+                unsigned long long hsh = dh[ord[cur]], i = hsh & mask, perturb = hsh;
+                int lin = 0, nlin = (i + 9 <= mask) ? 9 : 0;
+                auto next = [&] {
+                    if (lin < nlin) { lin++; return; }
+                    perturb >>= 5;
+                    i = (i * 5 + 1 + perturb) & mask;
+                    nlin = (i + 9 <= mask) ? 9 : 0; lin = 0;
+                };
+                while (true) {
+                    const int slot = (int)i + lin;
+                    const int old = atomic_min_ret_int(&own[slot], cur);
+                    if (old == EMPTY) break;                  // an empty slot: placed
+                    if (old > cur) {                          // a later entry held it: it moves on along ITS sequence, from behind this slot
+                        cur = old;
+                        hsh = dh[ord[cur]]; i = hsh & mask; perturb = hsh; lin = 0; nlin = (i + 9 <= mask) ? 9 : 0;
+                        while ((int)i + lin != slot) next();  // (its first visit of the slot is the one it was placed by)
+                    }
+                    next();
+                }
             }
-            base += tot;
+            b.sync();
+            if (D < thr) break;                               // no resize behind this generation: its table is the set
+            const int minused = upto > 50000 ? upto * 2 : upto * 4;
+            int newS = 8;
+            while (newS <= minused) newS <<= 1;
+            if (newS > s_max) { if (b.tid == 0) atomic_or_int(&sc->err, ERR_SET_CAP); break; }
+            // the entries in slot order = the priorities of the re-insertion
+            {
+                const int lane = b.tid & 63, wv = b.tid >> 6, nw = (b.nth + 63) >> 6;
+                const int seg = ((S + nw * 64 - 1) / (nw * 64)) * 64;
+                const int s0 = wv * seg < S ? wv * seg : S, s1 = s0 + seg < S ? s0 + seg : S;
+                int c = 0;
+                for (int e0 = s0; e0 < s1; e0 += 64) c += (int)__popcll(__ballot(e0 + lane < s1 && own[e0 + lane] != EMPTY));
+                int ex;
+                blk_scan(b, lane == 0 ? c : 0, &ex);
+                int at = __shfl(ex, 0, 64);
+                for (int e0 = s0; e0 < s1; e0 += 64) {
+                    const int pr = e0 + lane < s1 ? own[e0 + lane] : EMPTY;
+                    const unsigned long long m = __ballot(pr != EMPTY);
+                    if (pr != EMPTY) ord_next[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = ord[pr];
+                    at += (int)__popcll(m);
+                }
+            }
+            b.sync();
+            { int *t = ord; ord = ord_next; ord_next = t; }
+            n_prev = upto;
+            S = newS;
+        }
+        PSP(2);
+        for (int e = b.tid; e < S; e += b.nth) { const int pr = own[e]; own[e] = pr == EMPTY ? -1 : dk[ord[pr]]; }
+        b.sync();
+        PSP(3);
+#ifdef OCTA_SIM_DEBUG_SAT
+        dbg_n_ins = n_ins;
+#endif
+        return S - 1;
+    };
+    // the tables of the replay: in the table area for the usual <= LSET_PAIRS hits; in the sample's HBM scratch for the few iterations
+    // with more (the first iteration of a mode runs with the mode's raw radii: thousands of hits -- replayed by ONE thread until
+    // round 4, 16 of the 21 ms per sample this step took)
+    constexpr bool HBM_REPLAY = (size_t)PCAP + OCAP <= (size_t)OCAP + 2 * (size_t)NCANDCAP && (size_t)OCAP * 2 <= (size_t)OCAP * 3
+                                && PCAP <= SETCAP && OCAP <= SETCAP;
+    const int *t_key = nullptr;
+    int mask = -1;
+    if (n_pairs <= LSET_PAIRS) {
+        constexpr int S_MAX = LSET_CAP / 2;
+        int *own = reinterpret_cast<int *>(b.user_of<64>());                              // [max(OCAP, S_MAX)]
+        constexpr int OWN_N = OCAP > S_MAX ? OCAP : S_MAX;
+        int *in_key = own + OWN_N;                                                        // [LSET_PAIRS]
+        int *dk = in_key + LSET_PAIRS, *ord0 = dk + LSET_PAIRS, *ord1 = ord0 + LSET_PAIRS;
+        unsigned long long *in_hash = reinterpret_cast<unsigned long long *>(ord1 + LSET_PAIRS + ((OWN_N + 4 * LSET_PAIRS) & 1));
+        unsigned long long *dh = in_hash + LSET_PAIRS;
+        static_assert((size_t)(OWN_N + 4 * LSET_PAIRS + 1) * 4 + (size_t)2 * LSET_PAIRS * 8 <= (size_t)SIM_USER_BYTES, "set replay layout");
+        static_assert((size_t)LSET_PAIRS * 4 <= (size_t)OWN_N * 4, "the sorted pairs (start of the table area) end before the insert stream");
+        mask = replay(own, in_key, in_hash, dk, dh, ord0, ord1, S_MAX);
+        t_key = own;
+        set_in_lds = true;
+    } else if (HBM_REPLAY && n_pairs <= PCAP) {
+        // own: set_key [SETCAP]; in_key: tmp_int [PCAP]; ord0: tmp_int behind it [OCAP]; in_hash: set_hash [PCAP]; dh, dk, ord1: tmp_dbl
+        int *own = A.set_key;
+        int *in_key = A.tmp_int, *ord0 = A.tmp_int + PCAP;
+        unsigned long long *in_hash = A.set_hash;
+        unsigned long long *dh = reinterpret_cast<unsigned long long *>(A.tmp_dbl);
+        int *dk = reinterpret_cast<int *>(A.tmp_dbl + OCAP), *ord1 = dk + OCAP;
+        mask = replay(own, in_key, in_hash, dk, dh, ord0, ord1, SETCAP / 2);
+        t_key = own;
+        set_in_lds = true;
+    }
+    if (set_in_lds) {
+        const int n_co2_0 = sc->n_co2;
+        // read-out in slot order: a contiguous run of slots per thread, ONE block scan, then the converted sinks' coordinates fetched
+        // eight at a time (one scan and one dependent fetch per 256 slots until round 4)
+        int base = 0;
+        {
+            const int per = (mask + 1 + b.nth - 1) / b.nth;
+            const int e0 = b.tid * per < mask + 1 ? b.tid * per : mask + 1, e1 = e0 + per < mask + 1 ? e0 + per : mask + 1;
+            int cnt = 0;
+            for (int e = e0; e < e1; e++) cnt += t_key[e] >= 0 ? 1 : 0;
+            int ex2;
+            base = blk_scan(b, cnt, &ex2);
+            int dst = n_co2_0 + ex2;
+            constexpr int RB = 8;
+            for (int eb = e0; eb < e1; eb += RB) {
+                int k[RB];
+                V3 v[RB];
+#pragma unroll
+                for (int u = 0; u < RB; u++) { k[u] = eb + u < e1 ? t_key[eb + u] : -1; }
+#pragma unroll
+                for (int u = 0; u < RB; u++) v[u] = ld3(A.oxy + 3 * (k[u] >= 0 ? k[u] : 0));
+#pragma unroll
+                for (int u = 0; u < RB; u++)
+                    if (k[u] >= 0) { if (dst < CCAP) st3(A.co2 + 3 * dst, v[u]); dst++; }
+            }
         }
         b.sync();
+        PSP(4);
         if (b.tid == 0) {
             int n_co2 = n_co2_0 + base;
             if (n_co2 > CCAP) { sc->err |= ERR_CO2_CAP; n_co2 = CCAP; }
             sc->n_co2 = n_co2;
         }
 #ifdef OCTA_SIM_DEBUG_SAT
-        dbg_n_ins = n_ins; dbg_mask = mask; dbg_base = base;
+        dbg_mask = mask; dbg_base = base;
 #endif
     }
+#undef PSP
 #endif
     if (!set_in_lds && b.tid == 0) {
         PySetView S;
@@ -2883,10 +3036,8 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
         const int c_pair_vs_removed = blk_scan(b, loc, &ex);
         int c_slots = -1, c_in_distinct = -1, c_slot_bad = -1;
         if (set_in_lds) {     // the LDS table and insert stream are still intact (only the collectives area was used since)
-            const unsigned long long *t_hash = reinterpret_cast<const unsigned long long *>(b.user());
-            const int *t_key = reinterpret_cast<const int *>(t_hash + LSET_CAP);
-            const unsigned long long *in_hash = reinterpret_cast<const unsigned long long *>(t_key + LSET_CAP);
-            const int *in_key = reinterpret_cast<const int *>(in_hash + LSET_PAIRS);
+            const int *t_key = reinterpret_cast<const int *>(b.user());
+            const int *in_key = t_key + (OCAP > LSET_CAP / 2 ? OCAP : LSET_CAP / 2);
             loc = 0; for (int e = b.tid; e <= dbg_mask; e += b.nth) loc += t_key[e] >= 0 ? 1 : 0;
             c_slots = blk_scan(b, loc, &ex);
             loc = 0; for (int e = b.tid; e <= dbg_mask; e += b.nth) { const int k = t_key[e]; if (k >= 0 && (k >= n_oxy || !A.removed[k] || A.ven_near[k])) loc++; }
