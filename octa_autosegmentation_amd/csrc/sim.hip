@@ -456,6 +456,10 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
     const int skip = OCTA_UNI(uni[2]);
     b.sync();
     int parked_at = -1, parked_stage = 0;
+#if defined(OCTA_SIM_DEBUG_SAT) && defined(OCTA_SIM_ITER_PROF)
+    long iter_prof_prev[16];
+    for (int k = 0; k < 16; k++) iter_prof_prev[k] = A.sc->prof[k];
+#endif
     for (int it = it0; it <= n_iter && !skip; it++) {
         if (stage == 0) {
             if (uniform_err(b, A)) break;
@@ -531,6 +535,13 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
 #endif
             if (mail_roundtrip(b, A, M, s, *req_n, 2 * it + 2, t_kernel)) { parked_at = it; parked_stage = 2; break; }
         }
+#if defined(OCTA_SIM_DEBUG_SAT) && defined(OCTA_SIM_ITER_PROF)
+        // diagnostic build (tools/sim_iter_profile.py): the row of iteration `it` holds the 16 phase timers' growth during it
+        if (b.tid == 0 && A.dbg) {
+            int *row = A.dbg + 16 * it;
+            for (int k = 0; k < 16; k++) { row[k] = (int)(A.sc->prof[k] - iter_prof_prev[k]); iter_prof_prev[k] = A.sc->prof[k]; }
+        }
+#endif
         stage = 0;
     }
     // sign-off: the host leaves its service loop when every SAMPLE has passed here (or when the launch has completed)

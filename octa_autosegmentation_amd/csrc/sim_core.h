@@ -3011,7 +3011,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     }
     b.sync();
     OCTA_SUBPROF(sc, 14, t0);
-#ifdef OCTA_SIM_DEBUG_SAT
+#if defined(OCTA_SIM_DEBUG_SAT) && !defined(OCTA_SIM_ITER_PROF)
     {   // digest of this call (compared between repeated runs on the host) + in-kernel recounts of every stage of step 5
         int ex, loc;
         loc = 0; for (int o = b.tid; o < n_oxy; o += b.nth) loc += A.removed[o] ? 1 : 0;
