@@ -46,6 +46,18 @@ constexpr int ITEM_CAP = 256;   // (side, scanline) work items of one edge insid
 
 // ---- kernel 1: per-edge record ---------------------------------------------------------------
 
+// Inclusive prefix sum over the 64 lanes of a wave by DPP adds (four shifts inside the rows of 16 lanes, lane 15 of rows 0 / 2 onto rows
+// 1 / 3, lane 31 onto rows 2 and 3): six VALU instructions where six `__shfl_up` steps are six ds_bpermute round trips.
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 __global__ void __launch_bounds__(256)
 raster_meta_kernel(const double *__restrict__ edges, const unsigned char *__restrict__ keep, long n_total, int W, int H,
                    int ax_x, int ax_y, double min_radius, double max_radius, EdgeMeta *__restrict__ meta,
@@ -405,13 +417,8 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                         if (hi >= lo && xmin <= bx0 + 15) { r0 = lo - by0; nr = hi - lo + 1; }
                     }
                 }
-                int inc = nr;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    int u = __shfl_up(inc, d, 64);
-                    if (lane >= d) inc += u;
-                }
-                const int total = __shfl(inc, 63, 64);
+                const int inc = wave_scan_incl(nr);
+                const int total = __builtin_amdgcn_readlane(inc, 63);
                 if (total <= ITEM_CAP) {
                     done = true;
                     const int ex0 = inc - nr;
@@ -440,10 +447,12 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                         const int4 av = *reinterpret_cast<const int4 *>(w_area + lane * 4);
                         const int s4 = cv.x + cv.y + cv.z + cv.w;
                         int pre = w_carry[myrow];
-#pragma unroll
-                        for (int d = 1; d < 4; d++) {
-                            const int u = __shfl_up(s4, d, 4);
-                            if ((lane & 3) >= d) pre += u;
+                        {   // the cover of the cells to the left inside the row: the three lanes in front, by DPP row shifts
+                            const int u1 = __builtin_amdgcn_update_dpp(0, s4, 0x111, 0xf, 0xf, true);
+                            const int u2 = __builtin_amdgcn_update_dpp(0, s4, 0x112, 0xf, 0xf, true);
+                            const int u3 = __builtin_amdgcn_update_dpp(0, s4, 0x113, 0xf, 0xf, true);
+                            const int q = lane & 3;
+                            pre += (q >= 1 ? u1 : 0) + (q >= 2 ? u2 : 0) + (q >= 3 ? u3 : 0);
                         }
                         C[0] = pre + cv.x; C[1] = C[0] + cv.y; C[2] = C[1] + cv.z; C[3] = C[2] + cv.w;
                         A[0] = av.x; A[1] = av.y; A[2] = av.z; A[3] = av.w;
