@@ -194,31 +194,24 @@ struct ListEntry {
     float inv_len2, reach; // 1/|v|^2 and half width + margin
 };
 
-// block-wide exclusive scan of two ints per thread over WG threads (wave shuffles + LDS)
+// block-wide exclusive scan of two ints per thread over WG threads: DPP wave scans, the wave totals through LDS, every thread sums
+// the totals in front of its wave itself (round 4: ds_bpermute scans, a serial pass of thread 0 and one more barrier until then)
 __device__ __forceinline__ void block_scan2(int a, int b, int *sh /*[2*16+2]*/, int &ea, int &eb, int &ta, int &tb) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int ia = a, ib = b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
-        if (lane >= d) { ia += ua; ib += ub; }
-    }
+    const int ia = wave_scan_incl(a), ib = wave_scan_incl(b);
     if (lane == 63) { sh[wv] = ia; sh[16 + wv] = ib; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int sa = 0, sb = 0;
-        for (int k = 0; k < WG / 64; k++) {
-            int va = sh[k], vb = sh[16 + k];
-            sh[k] = sa; sh[16 + k] = sb;
-            sa += va; sb += vb;
-        }
-        sh[32] = sa; sh[33] = sb;
+    int sa = 0, sb = 0, fa = 0, fb = 0;
+#pragma unroll
+    for (int k = 0; k < WG / 64; k++) {
+        const int va = sh[k], vb = sh[16 + k];
+        fa += k < wv ? va : 0; fb += k < wv ? vb : 0;
+        sa += va; sb += vb;
     }
-    __syncthreads();
-    ea = sh[wv] + ia - a;
-    eb = sh[16 + wv] + ib - b;
-    ta = sh[32];
-    tb = sh[33];
+    ea = fa + ia - a;
+    eb = fb + ib - b;
+    ta = sa;
+    tb = sb;
     __syncthreads();
 }
 
