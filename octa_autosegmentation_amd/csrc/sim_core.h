@@ -1250,13 +1250,15 @@ struct Grid {
     const int *cell_end;           // LDS [nx*ny]: end offset of each cell (its start is the end of the previous cell)
     const idx_t *items;   // LDS [n]: point ids in cell order
     const double *spts;            // HBM [n][3]: coordinates in cell order
+    const float *sptf;             // ... or, for a grid built `as_float`, the coordinates ROUNDED to single precision (12 B per point)
+    const double *src;             // the point list the grid was built over (item id -> exact coordinates)
 };
 OCTA_HD inline int grid_clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 OCTA_HD inline int grid_cx(const Grid &G, double x) { return grid_clampi((int)floor((x - G.x0) * G.inv), G.nx - 1); }
 OCTA_HD inline int grid_cy(const Grid &G, double y) { return grid_clampi((int)floor((y - G.y0) * G.inv), G.ny - 1); }
 
 // ids: optional list of point ids (n entries) -- point i is pts[3*ids[i]]; items then hold ids[i]
-OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius, int div) {
+OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius, int div, bool as_float) {
     Grid G;
     const double span = 1.2;
     double cell = fmax(radius / div, span / GRID_MAX);
@@ -1268,7 +1270,7 @@ OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const doub
     int *hist = reinterpret_cast<int *>(b.user_of<2>());  // [ncell + 1]
     idx_t *items = reinterpret_cast<idx_t *>(b.user_of<2>() + (size_t)(GRID_MAX * GRID_MAX + 1) * 4);  // [GRID_N]
     static_assert((size_t)(GRID_MAX * GRID_MAX + 1) * 4 + (size_t)GRID_N * sizeof(idx_t) <= (size_t)SIM_USER_BYTES, "grid table layout");
-    G.cell_end = hist; G.items = items; G.spts = A.grid_pts;
+    G.cell_end = hist; G.items = items; G.spts = A.grid_pts; G.sptf = reinterpret_cast<const float *>(A.grid_pts); G.src = pts;
     if (n > GRID_N) n = GRID_N;
     b.sync();
     for (int c = b.tid; c <= ncell; c += b.nth) hist[c] = 0;
@@ -1316,18 +1318,21 @@ OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const doub
             if (i0 + k * b.nth < n) {
                 int pos = atomic_add_int(&hist[grid_cy(G, p[k].y) * nc + grid_cx(G, p[k].x)], 1);  // hist[c] ends as the END of cell c
                 items[pos] = (idx_t)id[k];
-                st3(A.grid_pts + 3 * pos, p[k]);
+                if (as_float) { float *f = reinterpret_cast<float *>(A.grid_pts) + 3 * pos; f[0] = (float)p[k].x; f[1] = (float)p[k].y; f[2] = (float)p[k].z; }
+                else st3(A.grid_pts + 3 * pos, p[k]);
             }
     }
     b.sync();
     return G;
 }
-// div: cells per query radius along an axis (1: a query visits 3 x 3 cells)
-OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius, int div = 1) {
+// div: cells per query radius along an axis (1: a query visits 3 x 3 cells). as_float: the cell-ordered copy holds the coordinates rounded
+// to single precision (grid_visit_f; the caller decides exactly with Grid::src where the rounding could matter)
+OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius, int div = 1,
+                               bool as_float = false) {
 #if OCTA_SIM_DUP & 2
-    grid_build_once(b, A, pts, ids, n, radius, div);
+    grid_build_once(b, A, pts, ids, n, radius, div, as_float);
 #endif
-    return grid_build_once(b, A, pts, ids, n, radius, div);
+    return grid_build_once(b, A, pts, ids, n, radius, div, as_float);
 }
 // visits every point of the cells overlapping [px-radius, px+radius] x [py-radius, py+radius]: body(item = point id, pt = coordinates).
 // Three cell rows per round (a query radius never exceeds the cell edge, so one round is the rule): the bounds of the rows' runs come
@@ -1337,8 +1342,21 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
 // that chain, not bandwidth, was the 57 ms of phase_assign). The order of the visits is row by row as before; every consumer is
 // order-free anyway (existence tests, arg-min with an explicit id tie-break, pair lists that are sorted afterwards).
 constexpr int GRID_VB = 4;
-template <class F>
-OCTA_HD inline void grid_visit(const Grid &G, double px, double py, double radius, F &&body) {
+// single-precision copy: |rounded - exact| <= 2^-24 |x| per coordinate, |x| < 1.2 on every point list of the simulator (unit square
+// plus margins), so a distance measured in single precision from the ROUNDED query to a rounded point is off by less than
+// 2 x sqrt(3) x 7.2e-8 (both roundings) + ~1e-8 (the arithmetic) = 2.6e-7; GRID_F_TAU leaves a margin on top
+constexpr double GRID_F_TAU = 4e-7;
+struct Pt3f { float x, y, z; };
+OCTA_HD inline float sqdist_f(Pt3f a, float cx, float cy, float cz) { const float dx = a.x - cx, dy = a.y - cy, dz = a.z - cz; return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
+template <bool FLT> struct GridPt;
+template <> struct GridPt<false> { typedef V3 T; static OCTA_HD inline V3 load(const Grid &G, int k) { return ld3(G.spts + 3 * k); } static OCTA_HD inline V3 zero() { return v3(0, 0, 0); } };
+template <> struct GridPt<true> {
+    typedef Pt3f T;
+    static OCTA_HD inline Pt3f load(const Grid &G, int k) { const float *f = G.sptf + 3 * k; Pt3f r = {f[0], f[1], f[2]}; return r; }
+    static OCTA_HD inline Pt3f zero() { Pt3f r = {0.f, 0.f, 0.f}; return r; }
+};
+template <bool FLT, class F>
+OCTA_HD inline void grid_visit_impl(const Grid &G, double px, double py, double radius, F &&body) {
     const int cy0 = grid_cy(G, py - radius), cy1 = grid_cy(G, py + radius);
     const int cx0 = grid_cx(G, px - radius), cx1 = grid_cx(G, px + radius);
     for (int cyb = cy0; cyb <= cy1; cyb += 3) {
@@ -1353,14 +1371,14 @@ OCTA_HD inline void grid_visit(const Grid &G, double px, double py, double radiu
                 k1[r] = G.cell_end[row * G.nx + cx1];
             }
         }
-        V3 pt[3][GRID_VB];
+        typename GridPt<FLT>::T pt[3][GRID_VB];
         int it[3][GRID_VB];
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int u = 0; u < GRID_VB; u++) {
                 const int k = k0[r] + u < k1[r] ? k0[r] + u : k0[r];      // k0[r] is a valid slot whenever the grid holds a point; an empty grid has no run
-                pt[r][u] = k0[r] < k1[r] ? ld3(G.spts + 3 * k) : v3(0, 0, 0);
+                pt[r][u] = k0[r] < k1[r] ? GridPt<FLT>::load(G, k) : GridPt<FLT>::zero();
                 it[r][u] = k0[r] < k1[r] ? (int)G.items[k] : 0;
             }
 #pragma unroll
@@ -1369,12 +1387,12 @@ OCTA_HD inline void grid_visit(const Grid &G, double px, double py, double radiu
             for (int u = 0; u < GRID_VB; u++)
                 if (k0[r] + u < k1[r]) body(it[r][u], pt[r][u]);
             for (int kb = k0[r] + GRID_VB; kb < k1[r]; kb += GRID_VB) {
-                V3 q[GRID_VB];
+                typename GridPt<FLT>::T q[GRID_VB];
                 int iq[GRID_VB];
 #pragma unroll
                 for (int u = 0; u < GRID_VB; u++) {
                     const int k = kb + u < k1[r] ? kb + u : kb;
-                    q[u] = ld3(G.spts + 3 * k);
+                    q[u] = GridPt<FLT>::load(G, k);
                     iq[u] = (int)G.items[k];
                 }
 #pragma unroll
@@ -1384,6 +1402,11 @@ OCTA_HD inline void grid_visit(const Grid &G, double px, double py, double radiu
         }
     }
 }
+template <class F>
+OCTA_HD inline void grid_visit(const Grid &G, double px, double py, double radius, F &&body) { grid_visit_impl<false>(G, px, py, radius, body); }
+// over a grid built `as_float`: body(item, Pt3f = the point ROUNDED to single precision)
+template <class F>
+OCTA_HD inline void grid_visit_f(const Grid &G, double px, double py, double radius, F &&body) { grid_visit_impl<true>(G, px, py, radius, body); }
 
 // ------------------------------------------------------------------ Murray propagation (one thread)
 // dirty list of the ordered pass: inter-node groups that did not sprout under the speculation but whose
@@ -1773,6 +1796,10 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     (void)iter;
     const double en = fmax(P.eps_n, P.eps_k), es = P.eps_s;
     const double en2 = en * en;
+    // thresholds of the single-precision tests, rounded AWAY from the sure side (one float spacing is ~1e-7 relative: far inside the margin)
+    const float en_hi2f = nextafterf((float)((en + GRID_F_TAU) * (en + GRID_F_TAU)), INFINITY);
+    const float es_lo2f = es > GRID_F_TAU ? nextafterf((float)((es - GRID_F_TAU) * (es - GRID_F_TAU)), -INFINITY) : 0.f;
+    const float es_hi2f = nextafterf((float)((es + GRID_F_TAU) * (es + GRID_F_TAU)), INFINITY);
     const double GSd = C.gs;
     const double fcx = C.fc0 * GSd, fcy = C.fc1 * GSd, fr = sc->faz_radius * GSd * 0.5;
     int *vlist = A.tmp_int;               // valid candidate indices, in order
@@ -1824,16 +1851,27 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
     double *oxd = A.tmp_dbl;         // oxygen distance per arterial node
     for (int i = b.tid; i < n_art; i += b.nth) oxd[i] = oxygen_distance(A.nrad[0][i], C.ps);
     {
-        Grid G = grid_build(b, A, A.npos[0], nullptr, n_art, en);
+        // both grids of this phase hold single-precision copies of their points (12 instead of 24 bytes per visited point, one load
+        // instruction instead of two): the distance to the rounded point decides unless it lies within GRID_F_TAU of the threshold --
+        // then the exact point is fetched and the reference's own expression evaluated (about one test in 10^5)
+        Grid G = grid_build(b, A, A.npos[0], nullptr, n_art, en, 1, true);
         SSP(1);
         for (int rep = 0; rep < ((OCTA_SIM_DUP & 8) ? 2 : 1); rep++)
         for (int vi = b.tid; vi < n_valid; vi += b.nth) {
             const V3 c = ld3(cand + 3 * vlist[vi]);
             bool ok = true;
-            grid_visit(G, c.x, c.y, en, [&](int j, const V3 &q) {
+            const float cxf = (float)c.x, cyf = (float)c.y, czf = (float)c.z;
+            grid_visit_f(G, c.x, c.y, en, [&](int j, const Pt3f &qf) {
                 if (ok) {
-                    double d2 = sqdist(q, c);
-                    if (d2 <= en2 && !(sqrt(d2) > oxd[j])) ok = false;
+                    const float d2f = sqdist_f(qf, cxf, cyf, czf);
+                    if (d2f <= en_hi2f) {
+                        const double lim = fmin(en, oxd[j]), lo = lim - GRID_F_TAU, hi = lim + GRID_F_TAU;
+                        if (lo > 0.0 && (double)d2f < lo * lo) ok = false;
+                        else if ((double)d2f <= hi * hi) {
+                            const double d2 = sqdist(ld3(G.src + 3 * j), c);
+                            if (d2 <= en2 && !(sqrt(d2) > oxd[j])) ok = false;
+                        }
+                    }
                 }
             });
             okf[vi] = ok ? 1 : 0;
@@ -1842,15 +1880,20 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
         SSP(2);
     }
     {
-        Grid G = grid_build(b, A, A.oxy, nullptr, n_oxy, es);
+        Grid G = grid_build(b, A, A.oxy, nullptr, n_oxy, es, 1, true);
         SSP(3);
         for (int rep = 0; rep < ((OCTA_SIM_DUP & 8) ? 2 : 1); rep++)
         for (int vi = b.tid; vi < n_valid; vi += b.nth) {
             if (!okf[vi]) continue;
             V3 c = ld3(cand + 3 * vlist[vi]);
             bool ok = true;
-            grid_visit(G, c.x, c.y, es, [&](int, const V3 &q) {
-                if (ok && sqrt(sqdist(q, c)) <= es) ok = false;
+            const float cxf = (float)c.x, cyf = (float)c.y, czf = (float)c.z;
+            grid_visit_f(G, c.x, c.y, es, [&](int j, const Pt3f &qf) {
+                if (ok) {
+                    const float d2f = sqdist_f(qf, cxf, cyf, czf);
+                    if (d2f < es_lo2f) ok = false;
+                    else if (d2f <= es_hi2f && sqrt(sqdist(ld3(G.src + 3 * j), c)) <= es) ok = false;
+                }
             });
             okf[vi] = ok ? 1 : 0;
         }
