@@ -1997,30 +1997,52 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
     b.sync();
     ASP(0);
     {
-        Grid G = grid_build(b, A, A.npos_of(f), A.act_list, n_act, delta);
+        Grid G = grid_build(b, A, A.npos_of(f), A.act_list, n_act, delta, 1, true);
         ASP(1);
         // (Round 4 measured a pruned nearest-neighbour search on a grid of four cells per radius -- rows outwards from the query's own, a
         // row dropped or cut as soon as the best distance allows: fewer points read per query, results identical -- and it was SLOWER,
-        // 48 -> 53 ms per sample: the pruning makes every row pair a dependent round trip, and this loop is bound by round trips, not
-        // by the points it reads, which come out of the L2.)
-        // (fetching the next query's point while the current query runs -- here and in the other three query loops -- changes nothing:
-        // measured in round 4)
+        // 48 -> 53 ms per sample: the pruning makes every row pair a dependent round trip. Fetching the next query's point while the
+        // current query runs changes nothing.)
+        // The nearest node is chosen on single-precision copies of the nodes: the smallest and the second smallest rounded distance are
+        // kept; if they are farther apart than the rounding can move them the winner is certain, and so is "within delta" unless the
+        // winner's distance lies in the band around delta (then its exact coordinates decide). Otherwise -- a near tie, including the
+        // exact ties the index breaks -- the query is repeated on the exact coordinates (the nodes' own array, by item id).
+        const float big = 3.0e38f;
         for (int a = b.tid; a < n_att; a += b.nth) {
             const V3 p = ld3(att + 3 * a);
-            double bd = INFINITY;
-            int best = -1;
-            grid_visit(G, p.x, p.y, delta, [&](int j, const V3 &q) {
-                double d2 = sqdist(q, p);
-                if (d2 < bd || (d2 == bd && j < best)) { bd = d2; best = j; }
+            const float pxf = (float)p.x, pyf = (float)p.y, pzf = (float)p.z;
+            float m1 = big, m2 = big;
+            int j1 = -1;
+            grid_visit_f(G, p.x, p.y, delta, [&](int j, const Pt3f &qf) {
+                const float d2 = sqdist_f(qf, pxf, pyf, pzf);
+                if (d2 < m1) { m2 = m1; m1 = d2; j1 = j; }
+                else if (d2 < m2) m2 = d2;
             });
-            A.nn[a] = (best >= 0 && sqrt(bd) <= delta) ? best : -1;
+            int r = -1;
+            if (j1 >= 0) {
+                const double d1 = sqrt((double)m1);
+                const double lim2 = (d1 + 2.0 * GRID_F_TAU) * (d1 + 2.0 * GRID_F_TAU);
+                if ((double)m2 > lim2) {                              // the winner is certain
+                    if (d1 < delta - GRID_F_TAU) r = j1;
+                    else if (d1 <= delta + GRID_F_TAU) r = sqrt(sqdist(ld3(G.src + 3 * j1), p)) <= delta ? j1 : -1;
+                } else if (d1 <= delta + 3.0 * GRID_F_TAU) {          // near tie of candidates that may be in range: exact arg-min (distance, then id)
+                    double bd = INFINITY;
+                    int best = -1;
+                    grid_visit_f(G, p.x, p.y, delta, [&](int j, const Pt3f &) {
+                        const double d2 = sqdist(ld3(G.src + 3 * j), p);
+                        if (d2 < bd || (d2 == bd && j < best)) { bd = d2; best = j; }
+                    });
+                    r = (best >= 0 && sqrt(bd) <= delta) ? best : -1;
+                }
+            }
+            A.nn[a] = r;
         }
         b.sync();
         ASP(2);
 #if defined(OCTA_SIM_ASSIGN_STATS) && !defined(__HIP_DEVICE_COMPILE__)
         {
             long vis = 0;
-            for (int a = 0; a < n_att; a++) { V3 p = ld3(att + 3 * a); grid_visit(G, p.x, p.y, delta, [&](int, const V3 &) { vis++; }); }
+            for (int a = 0; a < n_att; a++) { V3 p = ld3(att + 3 * a); grid_visit_f(G, p.x, p.y, delta, [&](int, const Pt3f &) { vis++; }); }
             static int *prev_nn[2] = {nullptr, nullptr};
             fprintf(stderr, "assign f=%d n_nodes=%d n_act=%d n_att=%d visited/query=%.1f cells=%d\n", f, n_nodes, n_act, n_att, n_att ? (double)vis / n_att : 0.0, G.nx);
             (void)prev_nn;
