@@ -1342,10 +1342,10 @@ OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *p
 // that chain, not bandwidth, was the 57 ms of phase_assign). The order of the visits is row by row as before; every consumer is
 // order-free anyway (existence tests, arg-min with an explicit id tie-break, pair lists that are sorted afterwards).
 constexpr int GRID_VB = 4;
-// single-precision copy: |rounded - exact| <= 2^-24 |x| per coordinate, |x| < 1.2 on every point list of the simulator (unit square
-// plus margins), so a distance measured in single precision from the ROUNDED query to a rounded point is off by less than
-// 2 x sqrt(3) x 7.2e-8 (both roundings) + ~1e-8 (the arithmetic) = 2.6e-7; GRID_F_TAU leaves a margin on top
-constexpr double GRID_F_TAU = 4e-7;
+// single-precision copy: |rounded - exact| <= 2^-24 |x| per coordinate. The simulator's point lists live in the unit square plus a
+// margin of a few growth steps; for |x| < 4 a distance measured in single precision from the ROUNDED query to a rounded point is off
+// by less than 2 x sqrt(3) x 2.4e-7 (both roundings) + ~1e-8 (the arithmetic) = 8.4e-7 < GRID_F_TAU
+constexpr double GRID_F_TAU = 1e-6;
 struct Pt3f { float x, y, z; };
 OCTA_HD inline float sqdist_f(Pt3f a, float cx, float cy, float cz) { const float dx = a.x - cx, dy = a.y - cy, dz = a.z - cz; return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
 template <bool FLT> struct GridPt;
