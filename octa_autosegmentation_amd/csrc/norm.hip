@@ -489,10 +489,12 @@ in_nhwc_bwd_apply(const unsigned short *__restrict__ x, const unsigned short *__
 
 int nhwc_splits(const octa_ctx *ctx, int B, long hw) {
     long s = (4L * ctx->num_cus + B - 1) / B;
-    // at least this many pixels per workgroup. 512 until round 4: a 76 x 76 x 256 plane of the GAN's residual stages then ran on 11 x B
-    // workgroups (17 % of the CUs at B = 4); 128: GAN-seg step 56.8 -> 55.4 ms, U-Net step unchanged (OCTA_NORM_MIN_PIXELS = 16 ... 512
-    // measured, profiles/r04_norm_min_pixels.log)
-    static const long min_px = [] { const char *e = getenv("OCTA_NORM_MIN_PIXELS"); const long v = e ? atol(e) : 128; return v > 0 ? v : 128; }();
+    // at least this many pixels per workgroup: 512, and 128 for planes below 256 x 256 (round 4: a 76 x 76 x 256 plane of the GAN's
+    // residual stages ran on 11 x B workgroups, 17 % of the CUs at B = 4; GAN-seg step 56.8 -> 55.4 ms, U-Net step unchanged;
+    // profiles/r04_norm_min_pixels.log). For the planes of these networks the bound, not the batch size, decides the split count at
+    // B <= 4, so an image's partial sums are formed alike alone and in a batch (tests/test_training_cli_gpu.py compares the two).
+    static const long min_px_env = [] { const char *e = getenv("OCTA_NORM_MIN_PIXELS"); return e ? atol(e) : 0L; }();
+    const long min_px = min_px_env > 0 ? min_px_env : (hw < 65536 ? 128 : 512);
     const long by_size = hw / min_px > 0 ? hw / min_px : 1;
     if (s > by_size) s = by_size;
     if (s < 1) s = 1;
