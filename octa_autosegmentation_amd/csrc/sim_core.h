@@ -2039,15 +2039,6 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
         }
         b.sync();
         ASP(2);
-#if defined(OCTA_SIM_ASSIGN_STATS) && !defined(__HIP_DEVICE_COMPILE__)
-        {
-            long vis = 0;
-            for (int a = 0; a < n_att; a++) { V3 p = ld3(att + 3 * a); grid_visit_f(G, p.x, p.y, delta, [&](int, const Pt3f &) { vis++; }); }
-            static int *prev_nn[2] = {nullptr, nullptr};
-            fprintf(stderr, "assign f=%d n_nodes=%d n_act=%d n_att=%d visited/query=%.1f cells=%d\n", f, n_nodes, n_act, n_att, n_att ? (double)vis / n_att : 0.0, G.nx);
-            (void)prev_nn;
-        }
-#endif
     }
     // Group bookkeeping -- dict order without a sort: attractor a heads a group iff it is the first hit of its node, so an ordered
     // compaction of the heads IS the dict order; members are scattered with a per-group cursor and each (short) member list is put
