@@ -780,13 +780,20 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
             ms[w] = bits;
             nS += __popcll(bits);
         }
-        int inc = nS;
-#pragma unroll
-        for (int d = 1; d < TW; d <<= 1) {
-            int u = __shfl_up(inc, d, TW);
-            if (tl >= d) inc += u;
+        // prefix sum of the chunk counts over the team: DPP adds (a 16-lane team is one DPP row) instead of ds_bpermute steps
+        int inc, totS;
+        if (TW == 64) {
+            inc = wave_scan_incl(nS);
+            totS = __builtin_amdgcn_readlane(inc, 63);
+        } else {
+            static_assert(TW == 64 || TW == 16, "team width");
+            inc = nS;
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+            totS = __shfl(inc, TW - 1, TW);
         }
-        const int totS = __shfl(inc, TW - 1, TW);
         const int preS = inc - nS;
         const int cut = base + totS;
         // left of the cut: post the positions of the elements > pivot, ranked from the left
