@@ -1531,7 +1531,7 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
         }
         bool stop = false;
         if (eager_n > 0) {
-            int onpath = __shfl_up(mine, 1, 64);
+            int onpath = __builtin_amdgcn_update_dpp(0, mine, 0x138, 0xf, 0xf, false);     // wave_shr:1: the node of the lane in front (lane 0: set below)
             if (lane == 0) onpath = below;
             double v_pw = 0, v_old = 0;  // lane j: sum of the off-path child powers, radius before the walk
             if (lane < eager_n) {
@@ -1589,7 +1589,7 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
         }
         __builtin_amdgcn_wave_barrier();
         if (ended) break;
-        below = __shfl(mine, 63, 64);
+        below = __builtin_amdgcn_readlane(mine, 63);
         first = cur;
     }
     return steps;
@@ -2075,7 +2075,7 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
         }
         int ex;
         n_groups = blk_scan(b, lane == 0 ? cnt : 0, &ex);
-        int base = __shfl(ex, 0, 64);
+        int base = __builtin_amdgcn_readfirstlane(ex);
         for (int a0 = s0; a0 < s1; a0 += 64) {
             const int a = a0 + lane;
             bool h = false;
@@ -2452,7 +2452,7 @@ OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &
         for (int g0 = s0; g0 < s1; g0 += 64) c += (int)__popcll(__ballot(g0 + lane < s1 && growf[g0 + lane]));
         int ex;
         n_grow = blk_scan(b, lane == 0 ? c : 0, &ex);
-        int at = __shfl(ex, 0, 64);
+        int at = __builtin_amdgcn_readfirstlane(ex);
         for (int g0 = s0; g0 < s1; g0 += 64) {
             const bool gr = g0 + lane < s1 && growf[g0 + lane];
             const unsigned long long m = __ballot(gr);
@@ -2962,7 +2962,7 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
                 for (int e0 = s0; e0 < s1; e0 += 64) c += (int)__popcll(__ballot(e0 + lane < s1 && own[e0 + lane] != EMPTY));
                 int ex;
                 blk_scan(b, lane == 0 ? c : 0, &ex);
-                int at = __shfl(ex, 0, 64);
+                int at = __builtin_amdgcn_readfirstlane(ex);
                 for (int e0 = s0; e0 < s1; e0 += 64) {
                     const int pr = e0 + lane < s1 ? own[e0 + lane] : EMPTY;
                     const unsigned long long m = __ballot(pr != EMPTY);
