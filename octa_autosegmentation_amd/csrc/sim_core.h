@@ -754,9 +754,20 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
             return;
         }
         --depth;
-        if (tl == 0) kd_median_to_first(a, first, last);
+        // __move_median_to_first(first, first + 1, mid, last - 1): the four words are fetched together (every lane the same addresses: LDS
+        // broadcasts), the median is chosen on registers by all lanes alike, lane 0 stores the swap and the pivot never is read back
+        // (round 4: lane 0 walking kd_median_to_first was ~five dependent LDS round trips per pass)
+        kdw_t pk;
+        {
+            const int iA = first + 1, iB = first + (last - first) / 2, iC = last - 1;
+            const kdw_t x0 = a.kv[first], xa = a.kv[iA], xb = a.kv[iB], xc = a.kv[iC];
+            const bool ab = kd_less_w(a, xa, xb), bc = kd_less_w(a, xb, xc), ac = kd_less_w(a, xa, xc);
+            const int im = ab ? (bc ? iB : (ac ? iC : iA)) : (ac ? iA : (bc ? iC : iB));
+            pk = im == iA ? xa : (im == iB ? xb : xc);
+            __builtin_amdgcn_wave_barrier();
+            if (tl == 0) { a.kv[first] = pk; a.kv[im] = x0; }
+        }
         __builtin_amdgcn_wave_barrier();
-        const kdw_t pk = a.kv[first];
         const int base = first + 1, m = last - base;
         const int c = ((m + TW - 1) / TW) | 1;  // odd chunk length: lanes hit distinct LDS banks
         int p0 = base + tl * c;
