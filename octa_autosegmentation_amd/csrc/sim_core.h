@@ -910,6 +910,7 @@ __device__ inline void kd_nth_element_wave_long(const KdPair &a, int first, int 
 // s_lo[k] > s_hi[j] for both others; a range whose intervals overlap (two spreads equal to 1e-7 relative: about once per thousand
 // builds) is measured exactly by its thread. The quantisation of the keys needs no exact bounds at all (kd_quant is monotone for any
 // offset / scale; values outside clamp).
+OCTA_HD inline unsigned f32_bits(float v) { unsigned u; memcpy(&u, &v, 4); return u; }
 OCTA_HD inline unsigned f32_sortable(float v) {
     unsigned u;
     memcpy(&u, &v, 4);
@@ -972,7 +973,8 @@ static_assert(KD_MAILBOX_OFF + (KD_BOX_BYTES > KD_MAILBOX_BYTES ? KD_BOX_BYTES :
 // largest HBM/L2 read stream); zlo / zhi: bounds of every point's z (the slab is thin: z wins the "largest spread" only for ranges
 // whose x and y boxes are thinner than the slab, and those are measured exactly).
 OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_idx, idx_t *out_rank,
-                              float *xy, double zlo, double zhi, long *kdprof = nullptr, const unsigned char *need = nullptr) {
+                              float *xy, double zlo, double zhi, long *kdprof = nullptr, const unsigned char *need = nullptr,
+                              const bool flag_in_sign = false) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(OCTA_SIM_PROF_ASSIGN) && !defined(OCTA_SIM_PROF_SAMPLE) && !defined(OCTA_SIM_PROF_SET)
 #define KDP(slot) do { if (kdprof && b.tid == 0) { long _t = (long)wall_clock64(); kdprof[slot] += _t - _kt; _kt = _t; } } while (0)
     long _kt = (long)wall_clock64();
@@ -987,7 +989,10 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
     unsigned *bbf = reinterpret_cast<unsigned *>(b.user_of<1>() + KD_MAILBOX_OFF); // [nr][6]: max xyz (rounded up), min xyz (rounded down)
     for (int i = b.tid; i < n; i += b.nth) {
         kv[i] = (kdw_t)i;
-        xy[2 * i] = (float)pts[3 * i]; xy[2 * i + 1] = (float)pts[3 * i + 1];      // round to nearest: x lies within one float spacing of it
+        // round to nearest: x lies within one float spacing of it. flag_in_sign (the caller vouches for x >= 0: the sinks are valid
+        // positions): the "rank is needed" flag rides in the sign of x -- one gather less per element and level of the box pass
+        const float fx = (float)pts[3 * i];
+        xy[2 * i] = (flag_in_sign && need[i]) ? -fx : fx; xy[2 * i + 1] = (float)pts[3 * i + 1];
     }
     if (b.tid == 0) { rs[0] = 0; re[0] = (idx_t)n; }
     const float z_up = f32_round_up(zhi), z_dn = f32_round_down(zlo);
@@ -1046,8 +1051,9 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
                 unsigned char nd[KB];
 #pragma unroll
                 for (int k = 0; k < KB; k++) {
-                    ex[k] = xy[2 * eid[k]]; ey[k] = xy[2 * eid[k] + 1];
-                    nd[k] = need ? need[eid[k]] : (unsigned char)1;
+                    const float sx = xy[2 * eid[k]];
+                    ex[k] = flag_in_sign ? fabsf(sx) : sx; ey[k] = xy[2 * eid[k] + 1];
+                    nd[k] = flag_in_sign ? (unsigned char)(f32_bits(sx) >> 31) : (need ? need[eid[k]] : (unsigned char)1);
                 }
 #pragma unroll
                 for (int k = 0; k < KB; k++) {
@@ -1173,7 +1179,8 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
                 if (d >= 0) {
                     const unsigned id = (unsigned)(kv[i] & KD_IDX_MASK);
                     // x / y: the rounded coordinate (rounding is monotone, so the key still is); z: the double itself
-                    const double cv = d < 2 ? (double)xy[2 * id + d] : pts[3 * id + 2];
+                    const float fv = d < 2 ? xy[2 * id + d] : 0.f;
+                    const double cv = d < 2 ? (double)((flag_in_sign && d == 0) ? fabsf(fv) : fv) : pts[3 * id + 2];
                     kv[i] = (kd_quant(cv, mnd, scale) << KD_IDX_BITS) | (kdw_t)id;
                 }
             }
@@ -2800,9 +2807,9 @@ OCTA_HD inline void phase_satisfy_art(const Blk &b, const SimArrays &A, const Si
     b.sync();
     if (n_pairs == 0) return;  // nothing satisfied: no conversion, no deletion (uniform across the block)
     // 2. cKDTree order of the O2 list, only as deep as the hit sinks need it; pairs get kd ranks
-    kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank, reinterpret_cast<float *>(A.hashes) /* free until step 3 */, 0.0, zext, sc->kdprof, A.removed);
+    kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank, reinterpret_cast<float *>(A.hashes) /* free until step 3 */, 0.0, zext, sc->kdprof, A.removed, true);
 #if OCTA_SIM_DUP & 1
-    kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank, reinterpret_cast<float *>(A.hashes), 0.0, zext, nullptr, A.removed);
+    kd_build(b, A.oxy, n_oxy, A.kd_idx, A.kd_rank, reinterpret_cast<float *>(A.hashes), 0.0, zext, nullptr, A.removed, true);
 #endif
     for (int i = b.tid; i < n_pairs; i += b.nth) {
         unsigned pr = A.pairs[i];
