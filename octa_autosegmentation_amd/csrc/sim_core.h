@@ -350,6 +350,36 @@ OCTA_HD inline int blk_scan(const Blk &b, int v, int *excl) {
 #endif
 }
 
+// Ordered compaction of the indices 0 .. n-1 that satisfy pred, with coalesced access: every wave takes a contiguous segment, its lanes 64
+// consecutive indices per step (ballot + population counts give the positions), ONE block scan of the waves' counts in between. pred(i)
+// is evaluated twice (count, emit); emit(i, position). Returns the number of kept indices. The chunk-per-thread form this replaces
+// (thread t walks indices t * chunk ...) made every lane of a load touch its own cache line. Host build: one thread, a plain loop.
+template <class Pred, class Emit>
+OCTA_HD inline int ordered_compact(const Blk &b, int n, Pred pred, Emit emit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = b.tid & 63, wv = b.tid >> 6, nw = (b.nth + 63) >> 6;
+    const int seg = ((n + nw * 64 - 1) / (nw * 64)) * 64;
+    const int s0 = wv * seg < n ? wv * seg : n, s1 = s0 + seg < n ? s0 + seg : n;
+    int c = 0;
+    for (int i0 = s0; i0 < s1; i0 += 64) c += (int)__popcll(__ballot(i0 + lane < s1 && pred(i0 + lane)));
+    int ex;
+    const int tot = blk_scan(b, lane == 0 ? c : 0, &ex);
+    int at = __builtin_amdgcn_readfirstlane(ex);
+    for (int i0 = s0; i0 < s1; i0 += 64) {
+        const bool keep = i0 + lane < s1 && pred(i0 + lane);
+        const unsigned long long m = __ballot(keep);
+        if (keep) emit(i0 + lane, at + (int)__popcll(m & ((1ull << lane) - 1ull)));
+        at += (int)__popcll(m);
+    }
+    return tot;
+#else
+    (void)b;
+    int at = 0;
+    for (int i = 0; i < n; i++) if (pred(i)) { emit(i, at); at++; }
+    return at;
+#endif
+}
+
 OCTA_HD inline void atomic_min_int(int *p, int v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicMin(p, v);
@@ -1838,31 +1868,22 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
 #define SSP(slot) do { } while (0)
 #endif
     // 1. is_valid_position (simulation_space.py:89-98), ordered compaction
-    int n_valid = 0;
-    {
-        const int chunk = (N + b.nth - 1) / b.nth;   // <= 64 for N <= 8192 with 128+ threads; mask below needs chunk <= 64
-        const int i0 = b.tid * chunk, i1 = (i0 + chunk < N) ? i0 + chunk : N;
-        int local = 0;
-        for (int i = i0; i < i1; i++) {
-            V3 p = ld3(cand + 3 * i);
-            int ok = !(p.x >= C.sx || p.y >= C.sy || p.z >= C.sz || p.x < 0 || p.y < 0 || p.z < 0);
-            if (ok && C.fixed) {
-                // geometry[(pos * geometry_size).astype(np.uint16)] > 0: the candidate came from a valid voxel, but (v + u) / gs * gs may
-                // land one voxel below v
-                const int vi = (int)(unsigned short)(int)(p.x * GSd), vj = (int)(unsigned short)(int)(p.y * GSd), vk = (int)(unsigned short)(int)(p.z * GSd);
-                ok = vi < C.gshape[0] && vj < C.gshape[1] && vk < C.gshape[2] && C.mask[((size_t)vi * C.gshape[1] + vj) * C.gshape[2] + vk] != 0;
-            } else if (ok) {
-                double dd = sqrt((p.x - fcx) * (p.x - fcx) + (p.y - fcy) * (p.y - fcy));
-                ok = dd > fr;
-            }
-            A.removed[i] = (unsigned char)ok;
-            local += ok;
+    for (int i = b.tid; i < N; i += b.nth) {
+        V3 p = ld3(cand + 3 * i);
+        int ok = !(p.x >= C.sx || p.y >= C.sy || p.z >= C.sz || p.x < 0 || p.y < 0 || p.z < 0);
+        if (ok && C.fixed) {
+            // geometry[(pos * geometry_size).astype(np.uint16)] > 0: the candidate came from a valid voxel, but (v + u) / gs * gs may
+            // land one voxel below v
+            const int vi = (int)(unsigned short)(int)(p.x * GSd), vj = (int)(unsigned short)(int)(p.y * GSd), vk = (int)(unsigned short)(int)(p.z * GSd);
+            ok = vi < C.gshape[0] && vj < C.gshape[1] && vk < C.gshape[2] && C.mask[((size_t)vi * C.gshape[1] + vj) * C.gshape[2] + vk] != 0;
+        } else if (ok) {
+            double dd = sqrt((p.x - fcx) * (p.x - fcx) + (p.y - fcy) * (p.y - fcy));
+            ok = dd > fr;
         }
-        int ex;
-        n_valid = blk_scan(b, local, &ex);
-        int run = ex;
-        for (int i = i0; i < i1; i++) if (A.removed[i]) vlist[run++] = i;
+        A.removed[i] = (unsigned char)ok;
     }
+    b.sync();
+    const int n_valid = ordered_compact(b, N, [&](int i) { return A.removed[i] != 0; }, [&](int i, int pos) { vlist[pos] = i; });
     b.sync();
     SSP(0);
     // 2. tests against all arterial nodes (ball en, oxygen distance) and existing sinks (NN <= es). The candidates are the queries:
@@ -1925,17 +1946,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
         b.sync();
         SSP(4);
     }
-    int n_pass = 0;
-    {
-        const int chunk = (n_valid + b.nth - 1) / b.nth;
-        const int i0 = b.tid * chunk, i1 = (i0 + chunk < n_valid) ? i0 + chunk : n_valid;
-        int local = 0;
-        for (int vi = i0; vi < i1; vi++) local += okf[vi] ? 1 : 0;
-        int ex;
-        n_pass = blk_scan(b, local, &ex);
-        int run = ex;
-        for (int vi = i0; vi < i1; vi++) if (okf[vi]) plist[run++] = vlist[vi];
-    }
+    const int n_pass = ordered_compact(b, n_valid, [&](int vi) { return okf[vi] != 0; }, [&](int vi, int pos) { plist[pos] = vlist[vi]; });
     b.sync();
     SSP(5);
     // 3. ordered greedy acceptance against the sinks accepted earlier in this call (strict >)
@@ -2008,17 +2019,8 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
 #define ASP(slot) do { } while (0)
 #endif
     // active node list (ascending id)
-    int n_act = 0;
-    {
-        const int chunk = (n_nodes + b.nth - 1) / b.nth;
-        const int i0 = b.tid * chunk, i1 = (i0 + chunk < n_nodes) ? i0 + chunk : n_nodes;
-        int local = 0;
-        for (int i = i0; i < i1; i++) local += A.nact_of(f)[i] ? 1 : 0;
-        int ex;
-        n_act = blk_scan(b, local, &ex);
-        int run = ex;
-        for (int i = i0; i < i1; i++) if (A.nact_of(f)[i]) A.act_list[run++] = i;
-    }
+    const unsigned char *nact = A.nact_of(f);
+    const int n_act = ordered_compact(b, n_nodes, [&](int i) { return nact[i] != 0; }, [&](int i, int pos) { A.act_list[pos] = i; });
     b.sync();
     ASP(0);
     {
@@ -2731,34 +2733,42 @@ OCTA_HD inline int compact_points(const Blk &b, double *pts, int n, const unsign
     }
     double *tile = reinterpret_cast<double *>(b.user_of<16>());
     static_assert((size_t)COMPACT_TILE * 24 <= (size_t)SIM_USER_BYTES, "compaction tile");
-    const int chunk = (n + b.nth - 1) / b.nth;
-    const int i0 = b.tid * chunk < n ? b.tid * chunk : n, i1 = (i0 + chunk < n) ? i0 + chunk : n;
-    int local = 0;
-    for (int i = i0; i < i1; i++) local += removed[i] ? 0 : 1;
-    int ex;
-    const int n_keep = blk_scan(b, local, &ex);
-    if (n_keep == n) return n_keep;                                   // nothing removed (uniform)
-    const int group = chunk > 0 ? (COMPACT_TILE / chunk > 0 ? COMPACT_TILE / chunk : 1) : b.nth;   // threads per tile
-    int *ctl = b.coll() + 106;                                        // [0] first destination of the tile, [1] its end
-    for (int t0 = 0; t0 < b.nth; t0 += group) {
-        const int t1 = t0 + group < b.nth ? t0 + group : b.nth;
-        b.sync();
-        if (b.tid == t0) ctl[0] = ex;
-        if (b.tid == t1 - 1) ctl[1] = ex + local;
-        b.sync();
-        const int base = ctl[0], kept = ctl[1] - ctl[0];
-        if (b.tid >= t0 && b.tid < t1) {
-            int w = ex - base;
-            for (int i = i0; i < i1; i++)
-                if (!removed[i]) { tile[3 * w] = pts[3 * i]; tile[3 * w + 1] = pts[3 * i + 1]; tile[3 * w + 2] = pts[3 * i + 2]; w++; }
-        }
-        b.sync();
-        // the tile's first source index is t0 * chunk: points in front of the first removal keep their place (base == source)
-        if (base != (t0 * chunk < n ? t0 * chunk : n) || kept != ((t1 * chunk < n ? t1 * chunk : n) - (t0 * chunk < n ? t0 * chunk : n)))
+#if defined(__HIP_DEVICE_COMPILE__)
+    // a tile = COMPACT_TILE consecutive points; every wave takes a contiguous quarter of it, its lanes 64 consecutive points per step
+    // (coalesced flags and coordinates; round 4: a contiguous chunk per THREAD made every lane of a load touch its own cache line)
+    const int lane = b.tid & 63, wv = b.tid >> 6, nw = (b.nth + 63) >> 6;
+    int base = 0;                                                     // kept points in front of the tile = its first destination
+    for (int t0 = 0; t0 < n; t0 += COMPACT_TILE) {
+        const int tn = n - t0 < COMPACT_TILE ? n - t0 : COMPACT_TILE;
+        const int seg = ((tn + nw * 64 - 1) / (nw * 64)) * 64;
+        const int s0 = t0 + (wv * seg < tn ? wv * seg : tn), s1 = s0 + seg < t0 + tn ? s0 + seg : t0 + tn;
+        int c = 0;
+        for (int i0 = s0; i0 < s1; i0 += 64) c += (int)__popcll(__ballot(i0 + lane < s1 && !removed[i0 + lane]));
+        int ex;
+        const int kept = blk_scan(b, lane == 0 ? c : 0, &ex);
+        if (base != t0 || kept != tn) {                               // (uniform) points in front of the first removal keep their place
+            int at = __builtin_amdgcn_readfirstlane(ex);
+            for (int i0 = s0; i0 < s1; i0 += 64) {
+                const bool keep = i0 + lane < s1 && !removed[i0 + lane];
+                const unsigned long long m = __ballot(keep);
+                if (keep) {
+                    const int w = at + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    const V3 v = ld3(pts + 3 * (size_t)(i0 + lane));
+                    tile[3 * w] = v.x; tile[3 * w + 1] = v.y; tile[3 * w + 2] = v.z;
+                }
+                at += (int)__popcll(m);
+            }
+            b.sync();
             for (int j = b.tid; j < kept * 3; j += b.nth) pts[(size_t)3 * base + j] = tile[j];
+            b.sync();                                                 // the tile is reused; the next tile's sources lie behind this one's destinations
+        }
+        base += kept;
     }
-    b.sync();
-    return n_keep;
+    return base;
+#else
+    (void)tile;
+    return n;    // (not reached: the host build has one thread)
+#endif
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
