@@ -1313,7 +1313,8 @@ OCTA_HD inline int grid_cx(const Grid &G, double x) { return grid_clampi((int)fl
 OCTA_HD inline int grid_cy(const Grid &G, double y) { return grid_clampi((int)floor((y - G.y0) * G.inv), G.ny - 1); }
 
 // ids: optional list of point ids (n entries) -- point i is pts[3*ids[i]]; items then hold ids[i]
-OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius, int div, bool as_float) {
+OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius, int div, bool as_float,
+                                    const unsigned char *mask) {
     Grid G;
     const double span = 1.2;
     double cell = fmax(radius / div, span / GRID_MAX);
@@ -1334,16 +1335,18 @@ OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const doub
     constexpr int GB = 4;
     for (int i0 = b.tid; i0 < n; i0 += GB * b.nth) {
         double px[GB], py[GB];
+        bool live[GB];
 #pragma unroll
         for (int k = 0; k < GB; k++) {
             const int i = i0 + k * b.nth;
             const int ic = i < n ? i : n - 1;
             const double *p = pts + 3 * (ids ? ids[ic] : ic);
             px[k] = p[0]; py[k] = p[1];
+            live[k] = i < n && (!mask || mask[ic]);
         }
 #pragma unroll
         for (int k = 0; k < GB; k++)
-            if (i0 + k * b.nth < n) atomic_add_int(&hist[grid_cy(G, py[k]) * nc + grid_cx(G, px[k])], 1);
+            if (live[k]) atomic_add_int(&hist[grid_cy(G, py[k]) * nc + grid_cx(G, px[k])], 1);
     }
     b.sync();
     {   // exclusive scan over the cells: contiguous chunk per thread + ONE block scan
@@ -1361,16 +1364,18 @@ OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const doub
     for (int i0 = b.tid; i0 < n; i0 += GB * b.nth) {
         V3 p[GB];
         int id[GB];
+        bool live[GB];
 #pragma unroll
         for (int k = 0; k < GB; k++) {
             const int i = i0 + k * b.nth;
             const int ic = i < n ? i : n - 1;
             id[k] = ids ? ids[ic] : ic;
             p[k] = ld3(pts + 3 * id[k]);
+            live[k] = i < n && (!mask || mask[ic]);
         }
 #pragma unroll
         for (int k = 0; k < GB; k++)
-            if (i0 + k * b.nth < n) {
+            if (live[k]) {
                 int pos = atomic_add_int(&hist[grid_cy(G, p[k].y) * nc + grid_cx(G, p[k].x)], 1);  // hist[c] ends as the END of cell c
                 items[pos] = (idx_t)id[k];
                 if (as_float) { float *f = reinterpret_cast<float *>(A.grid_pts) + 3 * pos; f[0] = (float)p[k].x; f[1] = (float)p[k].y; f[2] = (float)p[k].z; }
@@ -1381,13 +1386,14 @@ OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const doub
     return G;
 }
 // div: cells per query radius along an axis (1: a query visits 3 x 3 cells). as_float: the cell-ordered copy holds the coordinates rounded
-// to single precision (grid_visit_f; the caller decides exactly with Grid::src where the rounding could matter)
+// to single precision (grid_visit_f; the caller decides exactly with Grid::src where the rounding could matter). mask (optional, without
+// ids): only the points i with mask[i] != 0 enter the grid -- the list is streamed once, coalesced, instead of gathered through an id list
 OCTA_HD inline Grid grid_build(const Blk &b, const SimArrays &A, const double *pts, const int *ids, int n, double radius, int div = 1,
-                               bool as_float = false) {
+                               bool as_float = false, const unsigned char *mask = nullptr) {
 #if OCTA_SIM_DUP & 2
-    grid_build_once(b, A, pts, ids, n, radius, div, as_float);
+    grid_build_once(b, A, pts, ids, n, radius, div, as_float, mask);
 #endif
-    return grid_build_once(b, A, pts, ids, n, radius, div, as_float);
+    return grid_build_once(b, A, pts, ids, n, radius, div, as_float, mask);
 }
 // visits every point of the cells overlapping [px-radius, px+radius] x [py-radius, py+radius]: body(item = point id, pt = coordinates).
 // Three cell rows per round (a query radius never exceeds the cell edge, so one round is the rule): the bounds of the rows' runs come
@@ -2019,12 +2025,11 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
 #define ASP(slot) do { } while (0)
 #endif
     // active node list (ascending id)
-    const unsigned char *nact = A.nact_of(f);
-    const int n_act = ordered_compact(b, n_nodes, [&](int i) { return nact[i] != 0; }, [&](int i, int pos) { A.act_list[pos] = i; });
-    b.sync();
+    // the grid over the ACTIVE nodes is built straight from the activity flags (no list of the active nodes: the node positions are
+    // streamed once per pass, coalesced, instead of gathered through the list)
     ASP(0);
     {
-        Grid G = grid_build(b, A, A.npos_of(f), A.act_list, n_act, delta, 1, true);
+        Grid G = grid_build(b, A, A.npos_of(f), nullptr, n_nodes, delta, 1, true, A.nact_of(f));
         ASP(1);
         // (Round 4 measured a pruned nearest-neighbour search on a grid of four cells per radius -- rows outwards from the query's own, a
         // row dropped or cut as soon as the best distance allows: fewer points read per query, results identical -- and it was SLOWER,
