@@ -186,9 +186,10 @@ def use_ctx(h):
 
 
 def ctx(device_index=None):
-    """Context (grow-only device scratch) for one GPU, one per calling THREAD unless use_ctx() is active: an
-    octa_ctx must not be used from two threads at once (include/octa_hip.h), and pipelines keep several steps in
-    flight from a thread pool."""
+    """Context (grow-only device scratch) for one GPU, one per calling THREAD and current STREAM unless use_ctx() is active: an
+    octa_ctx must not be used from two threads at once (include/octa_hip.h), pipelines keep several steps in flight from a thread
+    pool, and its scratch is stream-ordered (common.h: one context = one stream at a time) -- the autograd thread runs the backward
+    nodes of a step that used two streams on those two streams, interleaved (models/gan_seg_model.py)."""
     import torch
     if getattr(_tls, "ctx", None) is not None:
         return _tls.ctx
@@ -196,7 +197,7 @@ def ctx(device_index=None):
         raise OctaHipError("no ROCm GPU visible to torch; the HIP path cannot run (no CPU fallback)")
     if device_index is None:
         device_index = torch.cuda.current_device()
-    key = (int(device_index), threading.get_ident())
+    key = (int(device_index), threading.get_ident(), torch.cuda.current_stream(int(device_index)).cuda_stream)
     with _lock:
         h = _ctxs.get(key)
     if h is None:

@@ -197,6 +197,12 @@ class BaseModelABC(nn.Module, ModelInterface, ABC):
         dev = next(self.parameters()).device
         return torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=self.amp and dev.type == "cuda")
 
+    def backward_scope(self):
+        """Scope of a `loss.backward()` of the step: weight gradients of the MFMA convolutions run on a side stream beside the
+        data-gradient / norm chain and are joined when the scope ends (models/mfma_conv.py: overlapped_wgrad)."""
+        from . import mfma_conv
+        return mfma_conv.overlapped_wgrad(next(self.parameters()).device)
+
     def zero_grads(self, optimizer_name):
         if optimizer_name in self._arenas:
             self._arenas[optimizer_name].zero()
@@ -224,7 +230,8 @@ class BaseModelABC(nn.Module, ModelInterface, ABC):
         with self.autocast():
             outputs, losses = self.inference(mini_batch, post_transformations, device, phase=Phase.TRAIN)
             loss = sum(list(losses.values()))
-        loss.backward()
+        with self.backward_scope():
+            loss.backward()
         self.exchange_gradients("optimizer")
         self.optimizer.step()
         return outputs, LossValues(losses)

@@ -60,6 +60,17 @@ class GanSegModel(BaseModelABC):
             return BilinearResize.apply(x, tuple(self.upshape))
         return torch.nn.functional.interpolate(x, size=self.upshape, mode="bilinear")
 
+    # OCTA_GAN_STREAMS=0: the whole step on the current stream (the order of the reference's optimize_parameters)
+    def _side_stream(self, device):
+        import os
+        if device.type != "cuda" or os.environ.get("OCTA_GAN_STREAMS", "1") == "0":
+            return None, None, None
+        if getattr(self, "_d_side", None) is None:
+            from .. import _native
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            object.__setattr__(self, "_d_side", (torch.cuda.Stream(device=idx), _native.new_ctx(idx)))
+        return self._d_side[0], self._d_side[1], torch.cuda.current_stream(device)
+
     def forward(self, input: torch.Tensor):
         if self.segmentor is not None:
             return self.segmentor(self._up(input))
@@ -84,28 +95,49 @@ class GanSegModel(BaseModelABC):
         real_B: torch.Tensor = mini_batch["real_B"].to(device, non_blocking=True)
         real_A_seg: torch.Tensor = mini_batch["real_A_seg"].to(device, non_blocking=True)
         nA = real_A.shape[0]
-        # ---- discriminator
-        self.zero_grads("optimizer_D")
+        side, sctx, main = self._side_stream(real_A.device)
+        # ---- generator forward (root of both updates)
         with self.autocast():
             if self.compute_identity_seg or self.compute_identity:
                 g_both = self.generator(torch.cat((real_A, real_B), dim=0))
                 fake_B, idt_B = g_both[:nA], g_both[nA:]
             else:
                 fake_B, idt_B = self.generator(real_A), None
-            self.discriminator.requires_grad_(True)
-            d_both = self.discriminator(torch.cat((fake_B.detach(), real_B), dim=0)).float()
-            loss_D_fake = self.dg_loss(d_both[:nA], False)
-            loss_D_real = self.dg_loss(d_both[nA:], True)
-            loss_D = 0.5 * (loss_D_fake + loss_D_real)
-        loss_D.backward()
-        self.exchange_gradients("optimizer_D")
-        self.optimizer_D.step()
-        # ---- generator + segmentor
+        # ---- discriminator update, then D(fake_B) with the updated, frozen discriminator: a chain of ~250 short dependent launches
+        # (4x4 convolutions at 304^2 and below) that nothing of the segmentor's passes depends on. With two streams it runs BESIDE
+        # the segmentor's pseudo-label pass and its forward pass over (idt_B | fake_B) -- MFMA-heavy launches that leave the gaps
+        # between D's launches unused otherwise (round 4: 733 dependent launches, 41 ms of kernels in a 56 ms step).
+        def d_chain():
+            self.zero_grads("optimizer_D")
+            with self.autocast():
+                self.discriminator.requires_grad_(True)
+                d_both = self.discriminator(torch.cat((fake_B.detach(), real_B), dim=0)).float()
+                l_fake = self.dg_loss(d_both[:nA], False)
+                l_real = self.dg_loss(d_both[nA:], True)
+                l_d = 0.5 * (l_fake + l_real)
+            with self.backward_scope():
+                l_d.backward()
+            self.exchange_gradients("optimizer_D")
+            self.optimizer_D.step()
+            with self.autocast():
+                self.discriminator.requires_grad_(False)
+                p_fake = self.discriminator(fake_B)
+                l_g = self.dg_loss(p_fake.float(), True)
+            return l_fake, l_real, l_g
+
+        if side is not None:
+            from .. import _native
+            side.wait_stream(main)
+            for t in (fake_B, real_B):
+                t.record_stream(side)
+            with torch.cuda.stream(side), _native.use_ctx(sctx):
+                loss_D_fake, loss_D_real, loss_G = d_chain()
+        else:
+            loss_D_fake, loss_D_real, loss_G = d_chain()
+        # ---- segmentor passes (current stream)
         self.zero_grads("optimizer_G")
         self.zero_grads("optimizer_S")
         with self.autocast():
-            self.discriminator.requires_grad_(False)
-            pred_fake_B = self.discriminator(fake_B)
             with torch.no_grad():
                 real_B_seg = (self.segmentor(self._up(real_B)) > 0.5).float()          # pseudo-labels (gan_seg_model.py:133-134)
             if self.compute_identity_seg:
@@ -113,7 +145,10 @@ class GanSegModel(BaseModelABC):
                 idt_B_seg, fake_B_seg = both[:real_B.shape[0]], both[real_B.shape[0]:]
             else:
                 idt_B_seg, fake_B_seg = None, self.segmentor(self._up(fake_B))
-            loss_G = self.dg_loss(pred_fake_B.float(), True)
+            if side is not None:
+                main.wait_stream(side)
+                for t in (loss_D_fake, loss_D_real, loss_G):
+                    t.record_stream(main)
             zero = torch.zeros((), device=real_A.device)
             loss_G_idt = self.criterionIdt(idt_B.float(), real_B.float()) if self.compute_identity else zero
             loss_G = loss_G + loss_G_idt
@@ -125,7 +160,10 @@ class GanSegModel(BaseModelABC):
                 loss_S_idt = zero
                 loss_SS = loss_S
             loss_GS = loss_G + loss_SS
-        loss_GS.backward()
+        with self.backward_scope():
+            loss_GS.backward()
+        if side is not None:
+            main.wait_stream(side)          # the discriminator branch of the backward pass ran on the side stream
         self.discriminator.requires_grad_(True)
         self.exchange_gradients("optimizer_G", "optimizer_S")
         self.optimizer_G.step()

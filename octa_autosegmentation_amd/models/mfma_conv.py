@@ -16,6 +16,73 @@ def _pad32(c):
     return (c + 31) // 32 * 32
 
 
+# ---- weight gradients on a side stream ---------------------------------------------------------------------------------
+# In the backward pass the data-gradient chain (conv dgrad -> norm statistics -> norm apply -> conv dgrad ...) is the critical path;
+# a layer's WEIGHT gradient is a leaf: nothing needs it before the optimiser step. Inside `overlapped_wgrad()` (the trainers wrap
+# `loss.backward()` in it, models/base_model_abc.py) every weight-gradient launch goes to a per-device side stream with its own
+# octa_ctx: MFMA-bound weight-gradient kernels then share the GPU with the HBM-bound norm passes of the layers further down instead
+# of taking turns with them. The result is accumulated into `weight.grad` ON THAT STREAM (set when absent; in place when the gradient
+# is a view of a flat arena or a second use of the weight in the same graph) and the Function reports None to autograd, so no node
+# of the graph ever reads a tensor the current stream has not produced. Leaving the context makes the current stream wait for the
+# side stream -- before the all-reduce and the optimiser step. Outside the context (tests, user code calling .backward() directly)
+# everything runs on the current stream as before.
+# MEASURED (round 5, profiles/r05_stream_overlap_ab.log, same box): U-Net step B = 4 19.3 ms with the side stream against 19.0 without,
+# B = 8 38.7 against 35.5 -- every kernel of the step fills the GPU on its own, co-resident weight-gradient and norm workgroups only
+# evict each other's lines. Hence OFF by default; OCTA_WGRAD_STREAM=1 switches it on (tests/test_models_gpu.py keeps it correct).
+USE_WGRAD_STREAM = os.environ.get("OCTA_WGRAD_STREAM", "0") == "1"
+_WG_SIDE = {}            # device index -> (stream, octa_ctx)
+_wg_tls = __import__("threading").local()
+_WG_ACTIVE = {"on": False}      # set by overlapped_wgrad(); read by the autograd thread
+
+
+def _wgrad_side(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _WG_SIDE:
+        _WG_SIDE[idx] = (torch.cuda.Stream(device=idx), _native.new_ctx(idx))      # live as long as the process
+    return _WG_SIDE[idx]
+
+
+class overlapped_wgrad:
+    """with overlapped_wgrad(device): loss.backward()"""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.on = USE_WGRAD_STREAM and self.device.type == "cuda"
+
+    def __enter__(self):
+        if self.on:
+            self.prev = _WG_ACTIVE["on"]
+            _WG_ACTIVE["on"] = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _WG_ACTIVE["on"] = self.prev
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            if idx in _WG_SIDE:
+                torch.cuda.current_stream(idx).wait_stream(_WG_SIDE[idx][0])
+        return False
+
+
+def _wgrad_to(weight, fn, *operands):
+    """dW = fn() for `weight`. Inside overlapped_wgrad(): computed and accumulated into weight.grad on the side stream, returns None
+    (autograd then has nothing to accumulate); otherwise returns fn()'s result on the current stream."""
+    if not (_WG_ACTIVE["on"] and weight.is_cuda and weight.is_leaf):
+        return fn()
+    side, sctx = _wgrad_side(weight.device)
+    side.wait_stream(torch.cuda.current_stream(weight.device))     # the operands (dy above all) are complete on the current stream
+    for t in operands:
+        if torch.is_tensor(t):
+            t.record_stream(side)          # the allocator must not reuse their blocks before the side stream is done
+    with torch.cuda.stream(side), _native.use_ctx(sctx):
+        dw = fn()
+        if weight.grad is None:
+            weight.grad = dw if dw.is_contiguous() else dw.contiguous()
+        else:
+            weight.grad.add_(dw)
+    return None
+
+
 USE_PACK_PLAN = True
 
 
@@ -357,9 +424,9 @@ class _Conv3x3NHWC(torch.autograd.Function):
             raise RuntimeError("skip gradient posted but the encoder convolution computes no input gradient")
         if ctx.needs_input_grad[1]:
             if st == 1:
-                dw = conv3x3_nhwc_wgrad(xp, dy)[:, :cin].to(weight.dtype)
+                dw = _wgrad_to(weight, lambda: conv3x3_nhwc_wgrad(xp, dy)[:, :cin].to(weight.dtype), xp, dy)
             else:
-                dw = _s2_wgrad(xp, dy)[:, :cin].to(weight.dtype)
+                dw = _wgrad_to(weight, lambda: _s2_wgrad(xp, dy)[:, :cin].to(weight.dtype), xp, dy)
         return dx, dw, None, None, None
 
 
@@ -401,11 +468,13 @@ class _Conv3x3ReflectNHWC(torch.autograd.Function):
             dx = torch.empty_like(x)
             resample._launch("octa_reflect_pad_bwd", dxp, dx, n, h, w, cin, 1)
         if ctx.needs_input_grad[1]:
-            dwf = torch.empty((9, cout, cin), dtype=torch.float32, device=x.device)
-            rc = lib.octa_conv3x3_nhwc_wgrad_pad(hctx, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(dwf.data_ptr()),
-                                                 n, h, w, cin, cout, 1, 1, _native.current_stream_ptr())
-            _native.check(rc, "octa_conv3x3_nhwc_wgrad_pad")
-            dw = dwf.view(3, 3, cout, cin).permute(2, 3, 0, 1).to(weight.dtype)
+            def wg():
+                dwf = torch.empty((9, cout, cin), dtype=torch.float32, device=x.device)
+                rc = lib.octa_conv3x3_nhwc_wgrad_pad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
+                                                     ctypes.c_void_p(dwf.data_ptr()), n, h, w, cin, cout, 1, 1, _native.current_stream_ptr())
+                _native.check(rc, "octa_conv3x3_nhwc_wgrad_pad")
+                return dwf.view(3, 3, cout, cin).permute(2, 3, 0, 1).to(weight.dtype)
+            dw = _wgrad_to(weight, wg, x, dy)
         return dx, dw
 
 
@@ -435,6 +504,7 @@ class _Conv3x3C1(torch.autograd.Function):
         _native.check(rc, "octa_conv3x3_c1_fwd")
         ctx.save_for_backward(x)
         ctx.w_shape, ctx.w_dtype = weight.shape, weight.dtype
+        ctx.weight_ref = weight
         return y
 
     @staticmethod
@@ -445,11 +515,13 @@ class _Conv3x3C1(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         n, h, w, _ = x.shape
         cout = dy.shape[3]
-        dw = torch.empty((cout, 9), dtype=torch.float32, device=x.device)
-        rc = _native.lib().octa_conv3x3_c1_wgrad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
-                                                 ctypes.c_void_p(dw.data_ptr()), n, h, w, cout, _native.current_stream_ptr())
-        _native.check(rc, "octa_conv3x3_c1_wgrad")
-        return None, dw.view(ctx.w_shape).to(ctx.w_dtype)
+        def wg():
+            dw = torch.empty((cout, 9), dtype=torch.float32, device=x.device)
+            rc = _native.lib().octa_conv3x3_c1_wgrad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
+                                                     ctypes.c_void_p(dw.data_ptr()), n, h, w, cout, _native.current_stream_ptr())
+            _native.check(rc, "octa_conv3x3_c1_wgrad")
+            return dw.view(ctx.w_shape).to(ctx.w_dtype)
+        return None, _wgrad_to(ctx.weight_ref, wg, x, dy)
 
 
 def conv3x3(x, weight, stride=1, want_stats=False, mailbox=None):
@@ -499,10 +571,13 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
             rc = lib.octa_conv3x3_nhwc_fwd2(hctx, _p(dy), None, cout, _p(wd), _p(dx1), _p(dx2), c1, n, h, w, cout, c1 + c2, 1, 1, 0x1ff, st)
             _native.check(rc, "octa_conv3x3_nhwc_fwd2 (data gradient)")
         if ctx.needs_input_grad[2]:
-            dwf = torch.empty((9, cout, c1 + c2), dtype=torch.float32, device=x1.device)
-            rc = lib.octa_conv3x3_nhwc_wgrad2(hctx, _p(x1), _p(x2), c1, _p(dy), _p(dwf), n, h, w, c1 + c2, cout, 0x1ff, st)
-            _native.check(rc, "octa_conv3x3_nhwc_wgrad2")
-            dw = dwf.view(3, 3, cout, c1 + c2).permute(2, 3, 0, 1).to(weight.dtype)
+            def wg():
+                dwf = torch.empty((9, cout, c1 + c2), dtype=torch.float32, device=x1.device)
+                rc = lib.octa_conv3x3_nhwc_wgrad2(_native.ctx(x1.device.index), _p(x1), _p(x2), c1, _p(dy), _p(dwf), n, h, w, c1 + c2, cout, 0x1ff,
+                                                  _native.current_stream_ptr())
+                _native.check(rc, "octa_conv3x3_nhwc_wgrad2")
+                return dwf.view(3, 3, cout, c1 + c2).permute(2, 3, 0, 1).to(weight.dtype)
+            dw = _wgrad_to(weight, wg, x1, x2, dy)
         if ctx.mailbox is not None and dx2 is not None and ctx.needs_input_grad[1]:
             assert ctx.mailbox.pending is None
             ctx.mailbox.pending, dx2 = dx2, None          # collected by the encoder convolution's data-gradient epilogue
@@ -610,7 +685,7 @@ class _ConvT2x2NHWC(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv3x3_nhwc(dy, pack_convt2x2(weight)[0], stride=2, tap_mask=0b110110000)
         if ctx.needs_input_grad[1]:
-            dw = _s2_wgrad(dy, x, taps2=((1, 2), (1, 2)))[:, :, 1:, 1:].to(weight.dtype)
+            dw = _wgrad_to(weight, lambda: _s2_wgrad(dy, x, taps2=((1, 2), (1, 2)))[:, :, 1:, 1:].to(weight.dtype), x, dy)
         return dx, dw
 
 
@@ -975,11 +1050,14 @@ class _Conv4x4NHWC(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             n, h, w, cin = x.shape
             cout = dy.shape[3]
-            d = torch.empty((16, cout, cin), dtype=torch.float32, device=x.device)
-            rc = _native.lib().octa_conv4x4_nhwc_wgrad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
-                                                       ctypes.c_void_p(d.data_ptr()), n, h, w, cin, cout, _native.current_stream_ptr())
-            _native.check(rc, "octa_conv4x4_nhwc_wgrad")
-            dw = d.view(4, 4, cout, cin).permute(2, 3, 0, 1).to(weight.dtype)
+
+            def wg():
+                d = torch.empty((16, cout, cin), dtype=torch.float32, device=x.device)
+                rc = _native.lib().octa_conv4x4_nhwc_wgrad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
+                                                           ctypes.c_void_p(d.data_ptr()), n, h, w, cin, cout, _native.current_stream_ptr())
+                _native.check(rc, "octa_conv4x4_nhwc_wgrad")
+                return d.view(4, 4, cout, cin).permute(2, 3, 0, 1).to(weight.dtype)
+            dw = _wgrad_to(weight, wg, x, dy)
         return dx, dw
 
 
