@@ -26,6 +26,7 @@ import numpy as np
 
 # one HIP hardware queue per step in flight (the runtime's default of 4 would make streams share queues)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("OCTA_STRICT", "1")      # a measured pass that leaves the hand-written kernels for the vendor libraries is an error (models/networks.py)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -41,7 +42,7 @@ VOXEL_BYTES_CLI = 1216 * 1216 * 16 * 2      # the volume the CLI
 G_TFLOP_FWD_304 = 0.178            # resnetGenerator9 forward at 1x304x304
 D_TFLOP_FWD_304 = 0.018            # patchGAN70x70 forward at 1x304x304
 N_CUS = 256          # MI355X; main() replaces it by the device's own count
-PMC_SUMMARY = os.path.join("profiles", "r03_bench_pmc_summary.csv")
+PMC_SUMMARY = os.path.join("profiles", "r05_bench_pmc_summary.csv")     # this round's counter passes (tools/profile_bench.sh); used only when the live passes fail
 
 
 def pmc_traffic_per_launch(kernel_name, grid_threads=None):
@@ -50,7 +51,7 @@ def pmc_traffic_per_launch(kernel_name, grid_threads=None):
     size, `[grid <threads>]`). Correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 128-B requests as 64 B on gfx950, so it is
     doubled; WRITE_SIZE is taken as reported. Returns (bytes, file, exact): exact = the file holds a row for launches of
     `grid_threads` threads; otherwise the rows of another launch size are returned for the caller to scale. None if missing."""
-    for cand in (PMC_SUMMARY, os.path.join("profiles", "r02_bench_pmc_summary.csv")):
+    for cand in (PMC_SUMMARY,):
         path = os.path.join(ROOT, cand)
         if not os.path.exists(path):
             continue
@@ -74,21 +75,26 @@ def pmc_child(batch):
     """Hidden mode (`bench.py --pmc-child`): one warm-up and one measured 128-sample launch of the simulator with the GPU to itself;
     run under `rocprofv3 --pmc <counter>` by pmc_traffic_live()."""
     import torch
+    from octa_autosegmentation_amd import pipeline
     from octa_autosegmentation_amd.utils import sharding
-    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
     torch.cuda.set_device(0)
-    sim = greenhouse.BatchSimulator(load_config(), batch)
+    gen = pipeline.TripleGenerator(load_config(), batch)       # simulator + both rasterisations + dither: the rasteriser's kernels are counted too
     for i in range(2):
-        res = sim.run(sharding.rank_seeds(0, 800 + i, batch))
-        assert int(res.stats[:, 0].max()) == 0
-    sim.close()
+        out = gen.generate(sharding.rank_seeds(0, 800 + i, batch))
+        torch.cuda.synchronize()
+        assert int(out["result"].stats[:, 0].max()) == 0
+    gen.close()
 
 
-def pmc_traffic_live(kernel_name, batch):
+RASTER_KERNELS = ("raster_meta_kernel", "raster_scan", "raster_tess_kernel", "raster_render_kernel", "fs_dither", "read_back_kernel", "max_u8")
+
+
+def pmc_traffic_live(kernel_name, batch, extra=None):
     """HBM-side bytes per launch of `kernel_name`, measured IN THIS RUN when rocprofv3 is on PATH: one separate counter pass per
     counter (FETCH_SIZE, WRITE_SIZE; --pmc alone, no tracing -- MI355X_MICROARCH.md's recipe) over `bench.py --pmc-child` (two
-    launches of one `batch`-sample batch). Same correction as the file-based figure: 2 x FETCH_SIZE + WRITE_SIZE, counters in KB.
-    Returns (bytes per launch, description) or (None, reason)."""
+    generate() calls of one `batch`-sample batch: simulator launch + rasteriser launch sequences + dither). Same correction as the
+    file-based figure: 2 x FETCH_SIZE + WRITE_SIZE, counters in KB. Returns (bytes per launch, description) or (None, reason).
+    `extra` (a dict) receives, per rasteriser kernel, its launches and the SUM of its traffic over one generate() call."""
     import csv
     import glob
     import subprocess
@@ -108,8 +114,19 @@ def pmc_traffic_live(kernel_name, batch):
             tot, n = 0.0, 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") == c and kernel_name in row.get("Kernel_Name", ""):
+                    if row.get("Counter_Name") != c:
+                        continue
+                    kn = row.get("Kernel_Name", "")
+                    if kernel_name in kn:
                         tot += float(row["Counter_Value"]); n += 1
+                    elif extra is not None:
+                        for rk in RASTER_KERNELS:
+                            if rk in kn:
+                                e = extra.setdefault(f"{rk} [grid {row.get('Grid_Size', '?')}]", {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "launches": 0})
+                                e[c] += float(row["Counter_Value"]) / 2.0          # the child runs generate() twice
+                                if c == "FETCH_SIZE":
+                                    e["launches"] += 0.5
+                                break
             if n == 0:
                 return None, f"no {c} rows for {kernel_name}"
             kb[c] = tot / n
@@ -258,7 +275,56 @@ def gan_networks_leg(dev, batch=4, steps=20, warmup=5):
     return out
 
 
-def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4):
+def allreduce_leg(tr, dev, dist, world, reps=20):
+    """the ONE exchange of the data-parallel step -- an RCCL all-reduce over the flat fp32 gradient buffer of DynUNet-S
+    (7.37 M parameters, 29.5 MB) -- timed on its own with HIP events on the current stream, `reps` times back to back. With several ranks
+    it runs on the job's process group (barrier first, MAX over ranks); with one rank a one-rank RCCL group is created for the measurement
+    (communicator set-up, the collective's launch and its device-side copy are real; there is no wire)."""
+    import torch
+    import torch.distributed as tdist
+    n = sum(p.numel() for p in tr.model.parameters() if p.requires_grad)
+    flat = torch.zeros(n, dtype=torch.float32, device=dev)
+    own_group = False
+    try:
+        if dist is None:
+            if not tdist.is_available():
+                return {"value": None, "note": "torch.distributed unavailable"}
+            if not tdist.is_initialized():
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                tdist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+                own_group = True
+        for _ in range(3):
+            tdist.all_reduce(flat)
+        torch.cuda.synchronize()
+        if world > 1:
+            tdist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            tdist.all_reduce(flat)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        if world > 1:
+            t = torch.tensor([ms], dtype=torch.float64, device=dev)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            ms = float(t.item())
+        bus = 2.0 * (world - 1) / max(world, 1) * n * 4 / (ms * 1e-3) / 1e9 if world > 1 else None
+        return {"value": ms, "unit": "ms", "ranks": world, "bytes": n * 4, "bus_GBps": bus,
+                "note": ("RCCL all-reduce(sum) of the flat fp32 gradient arena, once per optimiser step (models/base_model_abc.py: GradArena)"
+                         + ("" if world > 1 else "; ONE rank: a one-rank RCCL group made for this measurement -- no wire, the figure is the collective's launch + device-side "
+                                                 "cost and becomes the real exchange when the driver runs --gpus N"))}
+    except Exception as e:  # noqa: BLE001 -- a report, never a reason to lose the bench line
+        return {"value": None, "note": f"{type(e).__name__}: {e}"}
+    finally:
+        if own_group:
+            tdist.destroy_process_group()
+
+
+def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4, with_allreduce=False):
     import torch
     from octa_autosegmentation_amd.models.segmentation_trainer import SegmentationTrainer
     cfg = {"General": {"amp": True, "model": {"name": "DynUNet", "spatial_dims": 2, "in_channels": 1, "out_channels": 1,
@@ -285,8 +351,10 @@ def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4):
         dt = float(t.item())
     ips = world * batch * steps / dt
     per_gpu = ips / world
+    allreduce = allreduce_leg(tr, dev, dist, world) if with_allreduce else None
     return {"metric": "DynUNet-S training imgs/s @1x1216x1216", "value": ips, "unit": "imgs/s", "dtype": "bf16",
             "batch_per_gpu": batch, "ms_per_step": dt / steps * 1e3, "tflops": UNET_TFLOP_PER_IMAGE * ips,
+            "allreduce_ms_per_step": allreduce,
             "roofline": {"mfma": {"achieved": UNET_TFLOP_PER_IMAGE * per_gpu, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": UNET_TFLOP_PER_IMAGE * per_gpu / MFMA_BF16_PEAK_TFLOPS},
                          "hbm": {"achieved": UNET_MIN_HBM_GB_PER_IMAGE * per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -407,8 +475,10 @@ def main():
     ap.add_argument("--no-files", action="store_true", help="skip the on-disk triples leg")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline with one worker per visible core (BASELINE.md 3: 'all cores'; "
                     "230 s on the 256-thread host of the GPU box, hence not in the default run)")
-    ap.add_argument("--long", action="store_true", help="also run BASELINE configs[4] at its stated size: a 10 000-sample on-the-fly epoch (2 500 training steps "
-                    "of 4; about a minute and a half on one MI355X, outside the default time budget)")
+    ap.add_argument("--no-long", dest="long", action="store_false", help="skip BASELINE configs[4] at its stated size: a 10 000-sample on-the-fly epoch (2 500 training "
+                    "steps of 4 over all ranks; about a minute on one MI355X). Round 5: part of the DEFAULT run, so that the driver's line carries end_to_end_10k_epoch")
+    ap.add_argument("--long", dest="long", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(long=True)
     args = ap.parse_args()
     if args.pmc_child:
         pmc_child(args.batch)
@@ -509,6 +579,19 @@ def main():
     la = lb = 0
     bif_ms = 0.0
     relaunches = 0
+    # does the host's bifurcation service ever gate a workgroup? Device side: the "mailbox" phase timer (octa_sim_stats slot 13, 100 MHz ticks) is
+    # the time a sample's workgroup spent waiting for its answers over the whole run; host side: the service loop's record
+    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse as _gh
+    svc = [o["result"].service for o in outs]
+    wait_ms = float(np.mean([o["result"].stats[:, 13].mean() for o in outs])) * 1e-5
+    mailbox = {"service": _gh.bifurcation_service_kind()[0], "why_not_native": _gh.bifurcation_service_kind()[1],
+               "tickets_per_launch": float(np.mean([v["tickets"] for v in svc])), "parked_workgroups": int(sum(v["parked"] for v in svc)),
+               "relaunches": int(sum(v["relaunches"] for v in svc)), "longest_callback_ms": float(max(v["max_callback_ms"] for v in svc)),
+               "longest_service_absence_ms": float(max(v["max_absence_ms"] for v in svc)),
+               "device_wait_ms_per_sample": wait_ms, "per_sample_device_ms": None,
+               "note": "host_bifurcation_callback_ms_per_step is host LAPACK time summed over a step's samples; it runs beside the kernel. What a "
+                       "workgroup pays is device_wait_ms_per_sample (its ~55 round trips of the whole run together, the other workgroup of the CU keeps "
+                       "working meanwhile); a stall would show as parked_workgroups / relaunches > 0 (a workgroup that waited 20 ms leaves the kernel)"}
     for out in outs:
         r = out["result"]
         tm = r.timing
@@ -520,6 +603,7 @@ def main():
     # included; slots 10-15 are sub-timers of those phases) while n_fly launches share the GPU
     phase_ms = lambda st: float(st[:, 8:18].sum(axis=1).mean()) * 1e-5
     sample_ms_loaded = float(np.mean([phase_ms(o["result"].stats) for o in outs]))
+    mailbox["per_sample_device_ms"] = sample_ms_loaded
     # share of the CU time the simulator's workgroups held during the timed steps: per-sample spans on the device's common 100 MHz
     # clock (octa_sim_spans), clipped to a window inside the steady state (between the quartiles of the first-taken / last-left times)
     sp = np.concatenate([o["result"].spans for o in outs]).astype(np.float64) / 1e8
@@ -576,11 +660,22 @@ def main():
     gens = {}
     if not args.no_train:
         torch.cuda.empty_cache()
-        train_info = unet_train_bench(dev, args.train_batch, dist, world)
+        train_info = unet_train_bench(dev, args.train_batch, dist, world, with_allreduce=True)
+        # B in {4, 8, 16} at 1 x 1216 x 1216 (12.9 / 25.7 GiB of activations)
+        train_info["other_batch_sizes"] = {}
+        for b_ in (8, 16):
+            torch.cuda.empty_cache()
+            r_ = unet_train_bench(dev, b_, dist, world, steps=8, warmup=2)
+            train_info["other_batch_sizes"][f"B{b_}"] = {"value": r_["value"], "unit": "imgs/s", "ms_per_step": r_["ms_per_step"], "batch_per_gpu": b_,
+                                                         "mfma_frac": r_["roofline"]["mfma"]["frac"]}
     cli_info = None
     if not args.no_train and not args.no_end_to_end and world == 1:
         torch.cuda.empty_cache()
         cli_info = train_cli_leg()
+    elif world > 1:
+        cli_info = {"value": None, "skipped": f"world size {world}: this leg drives train.py's main() in-process on graphs it generates under /dev/shm of ONE rank; the "
+                                              "data-parallel trainer is measured by unet_train / end_to_end_* (every rank) and train.py under torch.distributed.run by "
+                                              "tests/test_training_cli.py (two gloo ranks)"}
     # BASELINE.json configs[4]: on-the-fly simulation + rasterisation + GPU augmentation feeding the same training step
     e2e_info = e2e_gan_info = None
     if not args.no_train and not args.no_end_to_end:
@@ -632,7 +727,20 @@ def main():
         traffic = None
         if world == 1 and not args.no_pmc and la == 0:
             per_launch = max(1, args.steps * B // max(dom_n, 1))            # samples one launch of this run simulates
-            traffic, traffic_src = pmc_traffic_live(dom_name, per_launch)
+            raster_extra = {}
+            traffic, traffic_src = pmc_traffic_live(dom_name, per_launch, raster_extra)
+            if traffic is not None and raster is not None and raster_extra:
+                per_kernel = {k: {"launches": v["launches"], "fetch_bytes": 2.0 * v["FETCH_SIZE"] * 1024.0, "write_bytes": v["WRITE_SIZE"] * 1024.0,
+                                  "bytes": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0} for k, v in sorted(raster_extra.items())}
+                total = sum(v["bytes"] for v in per_kernel.values())
+                algo = per_launch * (RASTER_BYTES_1216 + 2 * RASTER_BYTES_304)
+                raster["traffic"] = {"bytes": total, "samples": per_launch, "algorithmic_bytes": algo, "ratio": total / algo,
+                                     "write_bytes": sum(v["write_bytes"] for v in per_kernel.values()),
+                                     "output_bytes": per_launch * (1216 * 1216 * 2 + 3 * 304 * 304),
+                                     "per_kernel": per_kernel,
+                                     "unit": "bytes per generate() of `samples` triples: both 304^2 rasterisations + max, CSV read-back emulation, the 1216^2 label "
+                                             "rasterisation and the dither together (2 x FETCH_SIZE + WRITE_SIZE of the same two counter passes as roofline.traffic); "
+                                             "output_bytes = grey label + binarised label + two 304^2 rasters + their maximum"}
             if traffic is None:
                 print(f"[bench] live counter passes unavailable ({traffic_src}); using the committed summary", file=sys.stderr)
         if traffic is None:
@@ -691,6 +799,7 @@ def main():
             "slot_cycle": slot_cycle,
             "host_bifurcation_callback_ms_per_step": bif_ms / args.steps,
             "mailbox_relaunches": relaunches,
+            "mailbox": mailbox,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, all_cores=args.cpu_all_cores)

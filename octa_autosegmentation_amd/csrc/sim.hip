@@ -575,6 +575,10 @@ sim_persistent_kernel(BatchPtrs B, HostMail M) {
         Blk bs = b;
         if (B.wg_scratch) bs.umem = B.wg_scratch + (size_t)s * SIM_USER_BYTES;     // large build: this sample's table area in HBM
         run_sample(B, M, s, bs);
+        // blk_scan alternates two LDS slots by a call counter that lives in the Blk: the per-sample COPY must hand its count back, or the
+        // first scan of the next sample could write the slot the last scan of this one is still being read from (today two barriers at
+        // the loop head separate them; this makes it hold by construction)
+        b.scan_calls = bs.scan_calls;
     }
 }
 

@@ -96,7 +96,8 @@ class Compose:
         order only if no such stream is drawn from on both sides of the cut. Every transform declares its streams
         (`rng_streams(has_background)`: "python" = the global `random`, "numpy" = numpy's global stream, "torch" = torch's global
         generator; a transform's own RandomState is private and never conflicts); a transform that declares nothing counts as
-        deterministic only if it is not Randomizable and has no `R`."""
+        deterministic only if it is not Randomizable and has no `R` -- an undeclared Randomizable that was never seeded still draws from
+        the CLASS-level `Randomizable.R`, which every unseeded instance shares: that is a shared stream ("class_R")."""
         cut = [i for i, t in enumerate(self.transforms) if hasattr(t, "batch_apply")]
         if len(cut) != 1:
             return False
@@ -105,7 +106,11 @@ class Compose:
             out = set()
             for t in ts:
                 f = getattr(t, "rng_streams", None)
-                out |= set(f(has_background)) if f is not None else set()
+                if f is not None:
+                    out |= set(f(has_background))
+                elif isinstance(t, Randomizable) or hasattr(t, "R"):
+                    if getattr(t, "R", None) is Randomizable.R:      # never seeded: the class-level RandomState all unseeded instances share
+                        out.add("class_R")
             return out
 
         return not (streams(self.transforms[:cut[0]]) & streams(self.transforms[cut[0] + 1:]))

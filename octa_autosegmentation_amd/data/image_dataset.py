@@ -204,7 +204,10 @@ class DeviceLoader:
         # Preparing epoch N + 1 while the consumer still validates / checkpoints after epoch N is only safe when every random decision of
         # the loader comes from PRIVATE streams: the fused batch chain (own RandomStates + the private permutation generator). The
         # per-sample chains draw from python's `random`, numpy's global stream and torch's global generator, which the main thread uses
-        # too (GAN image pool, dropout): there the producer waits for the next __iter__ (round 4).
+        # too (GAN image pool, dropout): there the producer waits for the next __iter__ (round 4). This gate orders the streams
+        # BETWEEN epochs only: within an epoch the producer still runs up to `prefetch` mini-batches ahead of the consumer on those global
+        # streams, exactly as the reference's DataLoader workers run ahead of its training loop -- a main thread that draws from the
+        # global generators while an epoch is being served interleaves with the loader (there as here).
         lookahead = self.fused is not None
 
         def put(item):

@@ -2,9 +2,9 @@
 process per GPU:
 
 * optimisers: one Adam per entry of `optimizer_mapping` (lr from the config, betas (0.5, 0.999) unless overridden,
-  `Train.weight_decay`), LambdaLR constant then linear to zero over `Train.epochs_decay` -- one scheduler per optimiser
-  (the reference attaches every scheduler to the LAST optimiser, base_model_abc.py:63-64 uses the stale loop variable;
-  with one optimiser, i.e. the segmentation configs, the two are identical);
+  `Train.weight_decay`), LambdaLR constant then linear to zero over `Train.epochs_decay` -- attached the way the reference
+  attaches them (every scheduler to the LAST optimiser, base_model_abc.py:63-64 uses the stale loop variable; said once at
+  construction when it matters; `Train.lr_scheduler_per_optimizer: true` gives one per optimiser);
 * initialisation: He-normal through `init_weights` ('relu' gain for resnet generators, 'leaky_relu' otherwise) or, with
   `args.start_epoch > 0`, resume from `<save_dir>/checkpoints/<epoch>_<net>_model.pth` + `<epoch>_<optimizer>_model.pth`
   (what train.py writes; the reference reads `<epoch>_<optimizer>.pth`, which its own train.py never creates -- both names
@@ -124,7 +124,20 @@ class BaseModelABC(nn.Module, ModelInterface, ABC):
             def schedule(step: int):
                 return 1 if step < (max_epochs - decay) else (max_epochs - step) * (1 / max(1, decay))
 
-            self.lr_schedulers = [torch.optim.lr_scheduler.LambdaLR(getattr(self, name), schedule) for name in self.optimizer_mapping]
+            # The reference builds one LambdaLR per optimiser NAME but hands every one of them the LAST optimiser (base_model_abc.py:63-64:
+            # `getattr(self, optim_name)` with the previous loop's stale variable): in a multi-optimiser model (GanSegModel: G, D, S) only
+            # the last optimiser (S) ever decays, G and D keep their initial learning rate. Identical results need the same behaviour, so
+            # it is the DEFAULT; `Train.lr_scheduler_per_optimizer: true` attaches one scheduler to each optimiser instead. With one
+            # optimiser (the segmentation configs) or `epochs_decay: 0` (configs/config_gan_ves_seg.yml) the two are the same thing.
+            names = list(self.optimizer_mapping)
+            per_optimizer = bool(tr.get("lr_scheduler_per_optimizer", False))
+            if len(names) > 1 and decay > 0:
+                _log(f"NOTE: {len(names)} optimisers with Train.epochs_decay = {decay}: " +
+                     ("one LambdaLR per optimiser (Train.lr_scheduler_per_optimizer: true) -- NOT what the reference does."
+                      if per_optimizer else
+                      f"as in the reference (models/base_model_abc.py:63-64), every LambdaLR is attached to the LAST optimiser ({names[-1]}): "
+                      f"{', '.join(names[:-1])} keep their initial learning rate. Train.lr_scheduler_per_optimizer: true decays all of them."))
+            self.lr_schedulers = [torch.optim.lr_scheduler.LambdaLR(getattr(self, name if per_optimizer else names[-1]), schedule) for name in names]
             if getattr(args, "start_epoch", 0) > 0:
                 self._resume(model_path, device)
             else:

@@ -697,8 +697,11 @@ USE_BLAS_CONVT1X1 = os.environ.get("OCTA_CONVT1X1", "mfma") == "blas"
 
 def _t1x1_packs(weight):
     """[9][Cout][Cin] bf16 operands of the tap-masked 3x3 kernel for a ConvTranspose2d(k = 1) weight [Cin, Cout, 1, 1]: forward
-    (tap 4 = W^T) and data gradient (tap 4 = W); the masked taps are never fetched. Cached on the parameter (version + storage)."""
-    key = (weight._version, weight.data_ptr())
+    (tap 4 = W^T) and data gradient (tap 4 = W); the masked taps are never fetched. Cached on the parameter: version counter + storage
+    + the invalidation epoch that invalidate_all_pack_plans() bumps (writes through `.data` -- dist.broadcast(p.data), EMA, checkpoint
+    surgery -- move neither the counter nor the storage)."""
+    from . import conv_f32
+    key = (conv_f32._EPOCH[0], weight._version, weight.data_ptr())
     c = getattr(weight, "_octa_t1x1", None)
     if c is None or c[0] != key:
         cin, cout = weight.shape[0], weight.shape[1]
@@ -769,6 +772,9 @@ def conv_transpose_kxk_nhwc(x, weight, k):
         return _ConvT2x2NHWC.apply(x, weight)
     if k == 1 and x.shape[-1] % 32 == 0 and weight.shape[1] % 32 == 0 and USE_MFMA_CONVT:
         return _ConvT1x1NHWC.apply(x, weight)
+    from . import networks
+    networks._vendor_fallback("DynUNet transposed convolution (NHWC)", f"k = {k}, {x.shape[-1]} -> {weight.shape[1]} channels: GEMM through hipBLASLt "
+                              "(the MFMA kernels need k in (1, 2) and channel counts % 32 == 0)")
     return _conv_transpose_kxk_gemm(x, weight, k)
 
 
@@ -883,6 +889,8 @@ def conv1x1_bias_nhwc(x, weight, bias):
     """1x1 convolution head: weight [Cout, Cin, 1, 1], bias [Cout] -> [N,H,W,Cout] bf16."""
     if weight.shape[0] == 1 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 256 and 256 % (x.shape[-1] // 8) == 0:
         return _Head1NHWC.apply(x, weight, bias)
+    from . import networks
+    networks._vendor_fallback("DynUNet output block (NHWC)", f"{x.shape[-1]} -> {weight.shape[0]} channels: GEMM through hipBLASLt (the streaming head covers one output channel)")
     n, h, w, cin = x.shape
     y = torch.matmul(x.reshape(n * h * w, cin), weight.reshape(weight.shape[0], cin).t().to(torch.bfloat16))
     if bias is not None:

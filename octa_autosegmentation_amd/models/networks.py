@@ -38,6 +38,59 @@ USE_LAZY_NORM = __import__('os').environ.get('OCTA_LAZY_NORM', '0') == '1'      
 import os as _os
 USE_EPILOGUE_STATS = _os.environ.get('OCTA_EPI_STATS', '0') == '1'
 
+# ---- which kernels ran ------------------------------------------------------------------------------------------------
+# The product path of a CUDA forward is the hand-written HIP kernels (csrc/conv.hip, conv_f32.hip, norm.hip, thin_conv.hip,
+# blur.hip). Whenever a CUDA forward is about to leave them for the torch modules (MIOpen / hipBLASLt) WITHOUT having been told to
+# -- shapes the kernels do not cover, fp32 passes that record gradients (`General.amp: false` training), fp32 passes of the GAN
+# networks -- `_vendor_fallback` counts it, warns ONCE per (place, reason), and raises under OCTA_STRICT=1 (tests/conftest.py and
+# bench.py set it: the measured and the tested path is the HIP path or nothing). Deliberate use of the torch modules as the
+# REFERENCE of a parity test is not a fallback: `with vendor_reference():` (or USE_MFMA_CONV = False) says so.
+import collections as _collections
+import contextlib as _contextlib
+import warnings as _warnings
+
+PATH_COUNTS = _collections.Counter()     # 'mfma' (bf16 NHWC passes), 'f32_mfma' (exact-fp32 convolutions), 'vendor' (fallbacks)
+_WARNED = set()
+_REFERENCE_DEPTH = [0]
+
+
+class VendorFallbackError(RuntimeError):
+    pass
+
+
+@_contextlib.contextmanager
+def vendor_reference():
+    """The torch modules (vendor libraries on the GPU) are wanted here: the reference side of a parity test, a timing comparison."""
+    _REFERENCE_DEPTH[0] += 1
+    try:
+        yield
+    finally:
+        _REFERENCE_DEPTH[0] -= 1
+
+
+def _vendor_fallback(where, why):
+    if _REFERENCE_DEPTH[0] > 0 or not USE_MFMA_CONV:
+        return
+    PATH_COUNTS['vendor'] += 1
+    msg = (f"{where}: this CUDA forward leaves the hand-written HIP kernels for the torch modules (MIOpen / hipBLASLt): {why}. "
+           "Results stay correct, speed and the no-vendor-kernel claim do not; OCTA_STRICT=1 turns this into an error.")
+    if _os.environ.get('OCTA_STRICT', '0') == '1':
+        raise VendorFallbackError(msg)
+    if (where, why) not in _WARNED:
+        _WARNED.add((where, why))
+        _warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def _why_not_own_kernels(c, x):
+    if x.dtype == torch.float32 and torch.is_grad_enabled() and (x.requires_grad or c.weight.requires_grad):
+        return "fp32 pass that records gradients (the exact-fp32 MFMA kernels are forward-only; train with General.amp: true)"
+    if x.dtype == torch.float32:
+        return "fp32 layer shape outside csrc/conv_f32.hip (kernel/stride 1/1, 3/1, 3/2, transposed 1/1, 2/2)"
+    return f"{x.dtype} modules path: the bf16 NHWC path did not apply ({_LAST_MFMA_REFUSAL[0] or 'not a bf16 / bf16-autocast pass'})"
+
+
+_LAST_MFMA_REFUSAL = [None]
+
 
 class _Conv(nn.Module):
     """MONAI `Convolution(conv_only=True)`: a container whose only child is `conv`."""
@@ -57,7 +110,11 @@ class _Conv(nn.Module):
             # fp32 without gradients (test.py / validate.py, as the reference runs them: no autocast): exact-fp32 MFMA convolution
             from . import conv_f32
             if conv_f32.applies(c, x):
+                PATH_COUNTS['f32_mfma'] += 1
                 return conv_f32.forward(c, x)
+        if x.is_cuda:
+            _vendor_fallback(f"DynUNet {type(c).__name__}({c.in_channels}->{c.out_channels}, k{c.kernel_size[0]}, s{c.stride[0]})",
+                             _why_not_own_kernels(c, x))
         if (FAST_CONVT and isinstance(c, nn.ConvTranspose2d) and c.kernel_size == c.stride and c.kernel_size[0] == c.kernel_size[1]
                 and c.padding == (0, 0) and c.output_padding == (0, 0) and c.bias is None and c.groups == 1):
             # kernel == stride: every input pixel owns a disjoint k x k output patch, so the transposed conv is one
@@ -87,6 +144,8 @@ class UnetBasicBlock(nn.Module):
         if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and USE_FUSED_NORM:
             from .fused_ops import instance_norm_leaky_relu
             return instance_norm_leaky_relu(x, norm.weight, norm.bias, self.lrelu.negative_slope, norm.eps)
+        if x.is_cuda and USE_FUSED_NORM:
+            _vendor_fallback("DynUNet InstanceNorm + LeakyReLU", f"dtype {x.dtype} (csrc/norm.hip covers float32 and bfloat16)")
         return self.lrelu(norm(x))
 
     def forward(self, x):
@@ -202,26 +261,34 @@ class DynUNet(nn.Module):
         return mc.lazy_norm(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps)
 
     def _mfma_path_ok(self, x):
+        why = self._mfma_refusal(x)
+        _LAST_MFMA_REFUSAL[0] = why
+        return why is None
+
+    def _mfma_refusal(self, x):
+        """None when the bf16 NHWC path on the hand-written kernels applies, else the reason it does not."""
         if not (USE_MFMA_CONV and x.is_cuda and x.dim() == 4):
-            return False
+            return "USE_MFMA_CONV off, CPU tensor or not [N, C, H, W]"
         # bf16 arithmetic only where the caller asked for it (bf16 input or bf16 autocast, as the trainers do);
         # fp32 inputs keep the fp32 modules (logits within 1e-4 of the CPU reference)
         if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)):
-            return False
+            return "not a bf16 / bf16-autocast pass"
         blocks = [self.input_block, *self.downsamples, self.bottleneck, *[u.conv_block for u in self.upsamples]]
         for b in blocks:
             for c in (b.conv1.conv, b.conv2.conv):
                 if c.kernel_size != (3, 3) or c.stride[0] not in (1, 2) or c.out_channels % 32 or c.bias is not None:
-                    return False
+                    return f"convolution {c.in_channels}->{c.out_channels} k{c.kernel_size} s{c.stride} bias={c.bias is not None}: the MFMA path needs 3x3, stride 1 / 2, out_channels % 32 == 0, no bias"
         for u in self.upsamples:
             t = u.transp_conv.conv
             if t.kernel_size != t.stride or t.kernel_size[0] not in (1, 2) or t.bias is not None:
-                return False
+                return f"transposed convolution k{t.kernel_size} s{t.stride}: the MFMA path needs kernel == stride in (1, 2), no bias"
         down = 1
         for d in self.downsamples:
             down *= d.conv1.conv.stride[0]
         down *= self.bottleneck.conv1.conv.stride[0]      # a strided bottleneck halves the map once more: odd sizes take the torch path
-        return x.shape[2] % down == 0 and x.shape[3] % down == 0
+        if x.shape[2] % down or x.shape[3] % down:
+            return f"input {x.shape[2]}x{x.shape[3]} is not divisible by the total stride {down}"
+        return None
 
     def _forward_nhwc(self, x):
         from . import mfma_conv as mc
@@ -245,6 +312,7 @@ class DynUNet(nn.Module):
 
     def forward(self, x):
         if self._mfma_path_ok(x):
+            PATH_COUNTS['mfma'] += 1
             return self._forward_nhwc(x)
         skips = [self.input_block(x)]
         for d in self.downsamples:
@@ -402,7 +470,10 @@ class ResnetGenerator(nn.Module):
     def forward(self, x):
         use_mfma = (USE_MFMA_CONV and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
         if not use_mfma:
+            if x.is_cuda:
+                _vendor_fallback("ResnetGenerator", f"{x.dtype} pass without bf16 autocast (its HIP path is the bf16 one)")
             return self.model(x)
+        PATH_COUNTS['mfma'] += 1
         from . import mfma_conv as mc
         mc.plan_for_module(self)
         mods = list(self.model)
@@ -434,6 +505,8 @@ class ResnetGenerator(nn.Module):
             elif not on_path and nhwc:
                 x, nhwc = x.permute(0, 3, 1, 2).contiguous(), False
             if not on_path:
+                if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, ResnetBlock, nn.InstanceNorm2d)):
+                    _vendor_fallback("ResnetGenerator", f"layer {i} ({type(m).__name__}) has no HIP kernel for its shape")
                 x = m(x)
                 i += 1
             elif isinstance(m, ResnetBlock):
@@ -473,7 +546,10 @@ class NLayerDiscriminator(nn.Module):
     def forward(self, x):
         use_mfma = (USE_MFMA_CONV and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
         if not use_mfma:
+            if x.is_cuda:
+                _vendor_fallback("NLayerDiscriminator", f"{x.dtype} pass without bf16 autocast (its HIP path is the bf16 one)")
             return self.model(x)
+        PATH_COUNTS['mfma'] += 1
         from . import mfma_conv as mc
         from . import thin_conv as tc
         mc.plan_for_module(self)
@@ -510,6 +586,8 @@ class NLayerDiscriminator(nn.Module):
                 x = m(x, "nhwc")
                 i += 1
             else:
+                if isinstance(m, (nn.Conv2d, nn.InstanceNorm2d)):
+                    _vendor_fallback("NLayerDiscriminator", f"layer {i} ({type(m).__name__}) has no HIP kernel for its shape")
                 x = m(x)
                 i += 1
         return x.permute(0, 3, 1, 2).contiguous() if nhwc else x

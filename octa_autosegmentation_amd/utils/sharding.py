@@ -103,20 +103,66 @@ def host_budget(local_world, generator_threads=1, cores=None):
     }
 
 
-def affinity_for_local_rank(local_rank, local_world, cores=None):
-    """CPU set of local rank `local_rank`: a contiguous 1/local_world share of the cores. On the two-socket hosts of the MI355X nodes GPUs
-    0-3 hang off socket 0 and 4-7 off socket 1, and Linux numbers the cores socket by socket (SMT siblings in the upper half), so
-    contiguous shares keep a rank's service and writer threads on its GPU's socket. Returns a sorted list; the caller applies it with
+def _cpu_topology():
+    """[(package id, [logical CPUs of one physical core])] from /sys/devices/system/cpu/cpu*/topology, sorted by package then core;
+    None when the files are not there (non-Linux, restricted containers)."""
+    import glob
+    import os
+    cores = {}
+    for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*"):
+        try:
+            cpu = int(os.path.basename(d)[3:])
+            with open(os.path.join(d, "topology", "thread_siblings_list")) as f:
+                sib = f.read().strip()
+            with open(os.path.join(d, "topology", "physical_package_id")) as f:
+                pkg = int(f.read().strip())
+        except (OSError, ValueError):
+            continue
+        members = []
+        for part in sib.split(","):
+            lo, _, hi = part.partition("-")
+            members += list(range(int(lo), int(hi or lo) + 1))
+        cores[(pkg, min(members))] = sorted(members)
+        del cpu
+    if not cores:
+        return None
+    return [(k[0], v) for k, v in sorted(cores.items())]
+
+
+def affinity_for_local_rank(local_rank, local_world, cores=None, topology="auto"):
+    """CPU set of local rank `local_rank`: a contiguous 1/local_world share of the PHYSICAL cores with all their SMT siblings, taken from
+    the host's own topology files (packages in order, so that on the two-socket MI355X nodes -- GPUs 0-3 on socket 0, 4-7 on socket 1 --
+    a rank's service and writer threads stay on its GPU's socket whatever the kernel's CPU numbering is). `topology`: "auto" reads
+    /sys/devices/system/cpu; a list [(package, [cpus of a core])] is used as given (tests); None or an unreadable /sys falls back to the
+    numbering of those hosts (core c and its sibling c + cores/2). Returns a sorted list; the caller applies it with
     os.sched_setaffinity (and ignores a refusal: containers may pin the process already)."""
     import os
-    cores = int(cores or os.cpu_count() or 1)
     local_world = max(1, int(local_world))
     local_rank = int(local_rank) % local_world
-    phys = cores // 2 if cores >= 4 else cores            # SMT siblings of core c are c and c + cores/2 on these hosts
+    topo = _cpu_topology() if topology == "auto" and cores is None else (topology if isinstance(topology, list) else None)
+    if topo:
+        per = max(1, len(topo) // local_world)
+        mine = topo[local_rank * per:(local_rank + 1) * per] or topo[-per:]
+        return sorted(c for _, members in mine for c in members)
+    cores = int(cores or os.cpu_count() or 1)
+    phys = cores // 2 if cores >= 4 else cores            # fallback: SMT siblings of core c are c and c + cores/2
     per = max(1, phys // local_world)
     base = list(range(local_rank * per, min(phys, (local_rank + 1) * per)))
     sibs = [c + phys for c in base if c + phys < cores] if cores >= 4 else []
     return sorted(base + sibs)
+
+
+def _limit_blas_threads(n):
+    """The BLAS that numpy (and the native bifurcation service, which dlopens the same library) already LOADED reads
+    OPENBLAS_NUM_THREADS at load time only: set the count through the library itself (threadpoolctl -> openblas_set_num_threads).
+    Returns the libraries that were limited (for the bench line), or a reason."""
+    try:
+        import threadpoolctl
+        ctl = threadpoolctl.ThreadpoolController().select(user_api="blas")
+        ctl.limit(limits=int(n))           # stays in force for the life of the process (no context manager: never restored)
+        return [f"{lib.internal_api}:{lib.num_threads}" for lib in ctl.lib_controllers]
+    except Exception as e:  # noqa: BLE001 -- a budget, not a requirement
+        return f"not applied ({type(e).__name__}: {e})"
 
 
 def apply_host_budget(local_rank=None, local_world=None, generator_threads=1, set_affinity=True):
@@ -129,8 +175,11 @@ def apply_host_budget(local_rank=None, local_world=None, generator_threads=1, se
         local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
     b = host_budget(local_world, generator_threads)
     os.environ.setdefault("OCTA_SIM_SPIN_SCANS", str(b["spin_scans"]))
-    os.environ.setdefault("OPENBLAS_NUM_THREADS", str(b["blas_threads"]))
+    user_set = "OPENBLAS_NUM_THREADS" in os.environ
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", str(b["blas_threads"]))      # for libraries loaded from here on and for child processes
     os.environ.setdefault("OMP_NUM_THREADS", str(b["blas_threads"]))
+    # numpy / torch are imported long before this call in every entry point: the already-loaded BLAS is limited through its own API
+    b["blas_limited"] = "left alone (OPENBLAS_NUM_THREADS set by the user)" if user_set else _limit_blas_threads(b["blas_threads"])
     b["affinity"] = None
     if set_affinity and local_world > 1 and hasattr(os, "sched_setaffinity") and os.environ.get("OCTA_NO_AFFINITY") != "1":
         cpus = affinity_for_local_rank(local_rank, local_world)

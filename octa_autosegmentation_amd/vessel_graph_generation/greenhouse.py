@@ -183,7 +183,6 @@ _native_state = {"ready": None, "kappas": ()}
 
 def _numpy_blas_path():
     import glob
-    import os
     cands = glob.glob(os.path.join(os.path.dirname(np.__file__), "..", "numpy.libs", "libscipy_openblas64_*.so"))
     return cands[0] if cands else None
 
@@ -224,8 +223,27 @@ def _enable_native_bifurcation_service(config):
             lib.octa_bif_native(m, recs.ctypes.data, got.ctypes.data, None)
             if (got == want).all():
                 fn = ctypes.cast(lib.octa_bif_native, ctypes.c_void_p)
+                why = None
+            else:
+                why = f"the native service differs from the numpy formula on {int((got != want).any(axis=1).sum())} of {m} self-check requests"
+        else:
+            why = "octa_bif_native_init could not bind cblas_dgemm / cblas_ddot / LAPACKE_dgeev in " + path
+    else:
+        why = "numpy's bundled OpenBLAS (numpy.libs/libscipy_openblas64_*.so) was not found"
     _native_state["ready"], _native_state["kappas"] = fn, key
+    _native_state["kind"], _native_state["why_not_native"] = ("native" if why is None else "python"), why
+    # said once per process and configuration: the Python callback gives the same bytes but serves a request in ~36 us instead of ~4
+    import sys
+    if why is None:
+        print(f"[octa] leaf-bifurcation service: native C++ on {os.path.basename(path)} (bit-for-bit self-check on {m} requests passed)", file=sys.stderr)
+    else:
+        print(f"[octa] leaf-bifurcation service: PYTHON callback (about 10x slower per request, same results): {why}", file=sys.stderr)
     return fn
+
+
+def bifurcation_service_kind():
+    """'native' / 'python' (None before the first simulator was built) and, for 'python', why the native service was not taken."""
+    return _native_state.get("kind"), _native_state.get("why_not_native")
 
 
 class SimulationResult:

@@ -8,6 +8,9 @@ import pytest
 # (round 3 had this default at import time in models/*_trainer.py); the tests' reference path asks for the heuristic mode here, before
 # torch loads the library.
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+# A CUDA forward that silently leaves the hand-written kernels for the vendor libraries is an ERROR in the tests (models/networks.py:
+# _vendor_fallback); the reference side of a parity test says `with networks.vendor_reference():` or sets USE_MFMA_CONV = False.
+os.environ.setdefault("OCTA_STRICT", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

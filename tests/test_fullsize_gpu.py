@@ -132,14 +132,14 @@ def test_whole_network_at_1216_against_fp32_on_the_same_bf16_weights(hip_lib_bui
     got_out, got_g = run(True, True)
     rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-30)).item()
     e_got, e_ac = rel(got_out, ref_out), rel(ac_out, ref_out)
-    assert e_got <= max(1.5 * e_ac, 0.02), (e_got, e_ac)
+    assert e_got <= 1.5 * e_ac + 0.005, (e_got, e_ac)
     worst = (0.0, "", 0.0)
     for k, b in ref_g.items():
         if b.norm().item() < 1e-12 or k not in got_g:
             continue
         r_got, r_ac = rel(got_g[k], b), rel(ac_g[k], b)
         worst = max(worst, (r_got, k, r_ac))
-        assert r_got <= max(2.0 * r_ac, 0.05) + 0.1, (k, r_got, r_ac)
+        assert r_got <= 2.0 * r_ac + 0.01, (k, r_got, r_ac)      # round 4 allowed a flat 10 % on top
     print(f"logits: rel. error {e_got:.4f} (torch autocast {e_ac:.4f}); worst gradient tensor {worst[1]}: {worst[0]:.4f} (torch autocast {worst[2]:.4f})")
 
 

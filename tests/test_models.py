@@ -113,6 +113,44 @@ def test_gan_seg_training_step_runs_on_cpu():
     assert out["prediction"].shape == (1, 1, 64, 64)
 
 
+def test_lr_schedulers_attach_like_the_reference_by_default():
+    """reference models/base_model_abc.py:63-64: every LambdaLR is built on the LAST optimiser (stale loop variable), so with
+    Train.epochs_decay > 0 only optimizer_S of the GAN-seg model decays; Train.lr_scheduler_per_optimizer: true is the other behaviour."""
+    from octa_autosegmentation_amd.models.gan_seg_trainer import GanSegTrainer
+    base = {"General": {"amp": False, "model": {"name": "GanSegModel", "model_g": {"name": "resnetGenerator9"}, "model_d": {"name": "patchGAN70x70"},
+                                                  "model_s": dict(CFG["General"]["model"]), "upshape": (64, 64)}},
+            "Train": {"lr": 2e-4, "loss_dg": "LSGANLoss", "loss_s": "DiceBCELoss", "epochs": 4, "epochs_decay": 2}}
+    lr = lambda o: o.param_groups[0]["lr"]
+    tr = GanSegTrainer(base, "cpu")
+    assert all(s.optimizer is tr.optimizer_S for s in tr.lr_schedulers) and len(tr.lr_schedulers) == 3
+    for _ in range(3):
+        for o in (tr.optimizer_G, tr.optimizer_D, tr.optimizer_S):
+            o.step()
+        for s in tr.lr_schedulers:
+            s.step()
+    assert lr(tr.optimizer_G) == lr(tr.optimizer_D) == 2e-4 and abs(lr(tr.optimizer_S) - 1e-4) < 1e-12     # epoch 3 of 4, decay over 2
+    cfg2 = {**base, "Train": {**base["Train"], "lr_scheduler_per_optimizer": True}}
+    tr2 = GanSegTrainer(cfg2, "cpu")
+    assert [s.optimizer for s in tr2.lr_schedulers] == [tr2.optimizer_G, tr2.optimizer_D, tr2.optimizer_S]
+
+
+def test_t1x1_packs_follow_the_invalidation_epoch():
+    """A write through `.data` moves neither the version counter nor the storage: the cached packs of the 1x1 transposed convolution
+    must be rebuilt after invalidate_all_pack_plans() (round-4 advisor item)."""
+    from octa_autosegmentation_amd.models import mfma_conv
+    w = torch.nn.Parameter(torch.randn(64, 32, 1, 1))
+    f0, d0 = mfma_conv._t1x1_packs(w)
+    assert mfma_conv._t1x1_packs(w)[0] is f0                         # cached
+    w.data.mul_(2.0)
+    assert mfma_conv._t1x1_packs(w)[0] is f0                         # nothing moved: stale, as documented
+    holder = torch.nn.Module()
+    holder.w = w
+    mfma_conv.invalidate_all_pack_plans(holder)
+    f1, d1 = mfma_conv._t1x1_packs(w)
+    assert f1 is not f0 and torch.equal(f1[4].float(), w.detach().reshape(64, 32).t().to(torch.bfloat16).float())
+    assert torch.equal(d1[4].float(), w.detach().reshape(64, 32).to(torch.bfloat16).float())
+
+
 def test_noise_transforms_match_the_reference_fixture():
     """a17: SpeckleBrightnesd and AddRandomBackgroundNoised against tests/golden/noise_golden.npz -- outputs of the reference's own
     classes (tools/make_golden_noise.py) -- with the same generator seeds: CPU tensors, bit for bit (same torch / numpy draws, same

@@ -103,29 +103,104 @@ def test_gan_seg_step_on_gpu_trains_generator_through_mfma_segmentor():
     assert out["prediction"].shape == (1, 1, 128, 128)
 
 
-def test_resnet_generator_mfma_blocks_match_torch_autocast():
-    """ResNet-9 generator: residual blocks on the MFMA path vs the torch modules, both under bf16 autocast."""
+def _rel(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _three_way(net, x, target):
+    """One forward + backward of `net` three ways with the SAME bf16-rounded parameters: the torch modules in fp32 (the reference), the
+    torch modules under bf16 autocast (the yardstick of what bf16 activations cost through this depth), and the product path (bf16
+    autocast on the hand-written kernels, counted). Returns {way: (output, input gradient, {name: weight gradient})}."""
+    from octa_autosegmentation_amd.models import networks
+    res = {}
+    for way in ("fp32", "autocast", "mfma"):
+        net.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        before = networks.PATH_COUNTS["mfma"]
+        if way == "mfma":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = net(xi)
+            assert networks.PATH_COUNTS["mfma"] == before + 1, "the bf16 pass did not take the hand-written kernels"
+        else:
+            with networks.vendor_reference(), torch.backends.cudnn.flags(enabled=False), torch.autocast("cuda", dtype=torch.bfloat16, enabled=way == "autocast"):
+                old, networks.USE_MFMA_CONV = networks.USE_MFMA_CONV, False
+                try:
+                    y = net(xi)
+                finally:
+                    networks.USE_MFMA_CONV = old
+            assert networks.PATH_COUNTS["mfma"] == before
+        ((y.float() - target) ** 2).mean().backward()
+        res[way] = (y.float().detach(), xi.grad.detach().float(), {k: p.grad.detach().float().clone() for k, p in net.named_parameters()
+                                                                   if p.grad is not None and p.dim() == 4})
+    return res
+
+
+def _assert_within_bf16_budget(res, tag):
+    """Per-tensor relative L2 error of the product path against the fp32 run: at most twice the torch-autocast run's own error + 1 %
+    (output, input gradient and EVERY convolution weight gradient)."""
+    ref, ac, got = res["fp32"], res["autocast"], res["mfma"]
+    rows = [("output", _rel(got[0], ref[0]), _rel(ac[0], ref[0])), ("d/dx", _rel(got[1], ref[1]), _rel(ac[1], ref[1]))]
+    assert set(got[2]) == set(ref[2]), "a convolution weight is missing its gradient on the product path"
+    rows += [(k, _rel(got[2][k], ref[2][k]), _rel(ac[2][k], ref[2][k])) for k in ref[2] if ref[2][k].norm().item() > 1e-12]
+    worst = max(rows, key=lambda r: r[1] - 2.0 * r[2])
+    print(f"[{tag}] output {rows[0][1]:.4f} (torch autocast {rows[0][2]:.4f}), d/dx {rows[1][1]:.4f} ({rows[1][2]:.4f}), worst tensor {worst[0]}: "
+          f"{worst[1]:.4f} ({worst[2]:.4f})", flush=True)
+    for name, r_got, r_ac in rows:
+        assert r_got <= 2.0 * r_ac + 0.01, (tag, name, r_got, r_ac)
+    return rows
+
+
+def _bf16_params(net):
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    from octa_autosegmentation_amd.models import mfma_conv
+    mfma_conv.invalidate_all_pack_plans(net)
+
+
+def test_resnet_generator_mfma_path_against_fp32_on_the_same_weights():
+    """ResNet-9 generator (reference models/networks.py:291-443), He-initialised: output, input gradient and every convolution weight
+    gradient of the bf16 / MFMA path against an fp32 run of the torch modules on the same bf16-rounded weights (round 4 compared with
+    torch's own autocast by cosine > 0.9, which a wrong tap in one of nine blocks would have passed)."""
     from octa_autosegmentation_amd.models import networks
     torch.manual_seed(2)
     g = networks.resnetGenerator9().cuda()
     networks.init_weights(g, "kaiming", nonlinearity="relu")
-    x = torch.rand(2, 1, 64, 64, device="cuda")
-    outs, grads = [], []
-    for mfma in (False, True):
-        networks.USE_MFMA_CONV = mfma
-        try:
-            g.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = g(x)
-            y.float().mean().backward()
-            outs.append(y.float().detach())
-            grads.append(g.model[1].weight.grad.float().clone())     # stem weight: gradient through all nine blocks
-        finally:
-            networks.USE_MFMA_CONV = True
-    ref32 = None
-    assert (outs[0] - outs[1]).abs().max().item() < 0.06              # sigmoid outputs in [0, 1], bf16 through 9 blocks
-    cos = torch.dot(grads[0].flatten(), grads[1].flatten()) / (grads[0].norm() * grads[1].norm())
-    assert cos.item() > 0.9
+    _bf16_params(g)
+    x = torch.rand(2, 1, 128, 128, device="cuda").to(torch.bfloat16).float()
+    target = torch.rand(2, 1, 128, 128, device="cuda")
+    _assert_within_bf16_budget(_three_way(g, x, target), "generator")
+
+
+def test_a_wrong_tap_in_one_residual_block_fails_the_budget():
+    """Teeth of the test above: the product path runs with taps (0, 0) and (2, 2) of ONE residual convolution exchanged (block 5 of 9,
+    second convolution; the fp32 reference keeps the right weights) -- the comparison must fail."""
+    from octa_autosegmentation_amd.models import mfma_conv, networks
+    torch.manual_seed(2)
+    g = networks.resnetGenerator9().cuda()
+    networks.init_weights(g, "kaiming", nonlinearity="relu")
+    _bf16_params(g)
+    x = torch.rand(2, 1, 128, 128, device="cuda").to(torch.bfloat16).float()
+    target = torch.rand(2, 1, 128, 128, device="cuda")
+    conv = g.model[12 + 4].conv_block[5]
+    real_pack = mfma_conv.pack_weight
+
+    def wrong_pack(w, cin_pad=None):
+        t = real_pack(w, cin_pad)
+        if w is conv.weight:
+            t = t.clone()
+            t[0], t[8] = t[8].clone(), t[0].clone()
+        return t
+    mfma_conv.pack_weight = wrong_pack
+    try:
+        res = _three_way(g, x, target)
+    finally:
+        mfma_conv.pack_weight = real_pack
+    r_got, r_ac = _rel(res["mfma"][0], res["fp32"][0]), _rel(res["autocast"][0], res["fp32"][0])
+    print(f"[generator, one wrong tap] output {r_got:.4f} (torch autocast {r_ac:.4f}; budget {2 * r_ac + 0.01:.4f})", flush=True)
+    assert r_got > 2.0 * r_ac + 0.01, (r_got, r_ac)
+    with pytest.raises(AssertionError):
+        _assert_within_bf16_budget(res, "generator, one wrong tap")
 
 
 def test_conv4x4_mfma_matches_torch():
@@ -152,32 +227,18 @@ def test_conv4x4_mfma_matches_torch():
         assert (wa.grad - wr.grad).abs().max().item() <= 1e-3 * sc(wr.grad)       # fp32 accumulation order only
 
 
-def test_patchgan_mfma_layers_match_torch_autocast():
-    """PatchGAN under bf16 autocast: inner layers on the MFMA / NHWC kernels vs the plain torch modules under the same autocast."""
+def test_patchgan_mfma_path_against_fp32_on_the_same_weights():
+    """PatchGAN (reference models/networks.py:445-506), He-initialised: output, input gradient (what trains the generator) and every
+    convolution weight gradient of the bf16 / MFMA path against an fp32 run of the torch modules on the same bf16-rounded weights."""
     from octa_autosegmentation_amd.models import networks
     torch.manual_seed(4)
     net = networks.patchGAN70x70().cuda()
-    networks.init_weights(net, "kaiming") if hasattr(networks, "init_weights") else None
-    x = torch.rand(2, 1, 128, 128, device="cuda")
-    outs, grads = [], []
-    for flag in (True, False):
-        networks.USE_MFMA_CONV = flag
-        try:
-            net.zero_grad(set_to_none=True)
-            xi = x.clone().requires_grad_(True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = net(xi)
-            (y.float() ** 2).mean().backward()
-            outs.append(y.float().detach())
-            grads.append((xi.grad.detach(), {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if p.grad is not None and p.dim() == 4}))
-        finally:
-            networks.USE_MFMA_CONV = True
-    assert outs[0].shape == outs[1].shape == (2, 1, 14, 14)
-    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
-    assert cos(outs[0], outs[1]) > 0.99
-    assert cos(grads[0][0], grads[1][0]) > 0.9
-    assert set(grads[0][1]) == set(grads[1][1])                       # every convolution weight has a gradient on both paths
-    assert min(cos(grads[0][1][k], grads[1][1][k]) for k in grads[1][1]) > 0.9
+    networks.init_weights(net, "kaiming")
+    _bf16_params(net)
+    x = torch.rand(2, 1, 128, 128, device="cuda").to(torch.bfloat16).float()
+    res = _three_way(net, x, torch.zeros(2, 1, 14, 14, device="cuda"))
+    assert res["mfma"][0].shape == (2, 1, 14, 14)
+    _assert_within_bf16_budget(res, "discriminator")
 
 
 # ---- a21 on the device (round 3): the reference-made fixture of the joint G / D / S update on cuda --------------------------------
@@ -197,8 +258,10 @@ def test_gan_seg_fixture_on_cuda_fp32(tag, idt):
     vendor library picks its fp32 algorithms per run -- 3.3e-6 / 1.3e-4 / 1.2e-3 / 2.4e-2): step-1 losses 1e-4 relative, step-1 gradient
     norms 1e-3 (one backward pass, no update behind it), step-2 losses 5e-3 and step-2 gradient norms 5e-2 (the first Adam step is
     lr * sign(g): parameters with rounding-noise gradients move either way)."""
+    from octa_autosegmentation_amd.models import networks
     from tests.test_models import run_gan_seg_fixture
-    losses, gnorm, sums, g = run_gan_seg_fixture(tag, idt, device="cuda", amp=False)
+    with networks.vendor_reference():         # `amp: False` on the GPU is the torch modules' fp32 path by design (loud elsewhere: OCTA_STRICT)
+        losses, gnorm, sums, g = run_gan_seg_fixture(tag, idt, device="cuda", amp=False)
     _report(tag, "fp32 step-1 losses", losses[0], g[f"{tag}_losses"][0])
     _report(tag, "fp32 step-2 losses", losses[1], g[f"{tag}_losses"][1])
     _report(tag, "fp32 step-1 grad norms", gnorm[0], g[f"{tag}_grad_norms_steps"][0])

@@ -55,6 +55,16 @@ def test_host_budget_and_affinity_shares():
     assert sorted(c for s in shares for c in s) == list(range(256))      # disjoint and complete
     assert all(max(s[:16]) < 64 for s in shares[:4]) and all(min(s[:16]) >= 64 for s in shares[4:])   # GPUs 0-3 / 4-7: socket 0 / 1
     assert sharding.affinity_for_local_rank(0, 1, 8) == list(range(8))
+    # another kernel numbering (round-4 advisor item): sockets interleaved (package = cpu % 2), SMT sibling of core c is c + 16 -- the
+    # shares follow the host's topology files, not a fixed formula: still disjoint, complete, whole cores, and one socket per rank
+    topo = sorted((c % 2, [c, c + 16]) for c in range(16))
+    shares = [sharding.affinity_for_local_rank(r, 8, topology=topo) for r in range(8)]
+    assert sorted(c for s in shares for c in s) == list(range(32)) and all(len(s) == 4 for s in shares)
+    assert all({c % 16 for c in s} == {c for c in s if c < 16} for s in shares)                     # a core comes with its sibling
+    assert all(len({c % 2 for c in s}) == 1 for s in shares)                                           # one socket per rank
+    assert [s[0] % 2 for s in shares] == [0, 0, 0, 0, 1, 1, 1, 1]                                      # local ranks 0-3 / 4-7: socket 0 / 1
+    real = sharding.affinity_for_local_rank(0, 1)                                                      # this host's own topology
+    assert real == sorted(real) and len(real) >= 1
 
 
 def _worker(rank, world, port, out):

@@ -243,6 +243,23 @@ def test_wide_reference_pin_64_full_length_seeds(gh, golden):
     assert not bad, f"CSV text differs from the reference's for seeds {bad}"
 
 
+def test_oracle_digests_every_double_of_128_full_length_seeds(gh, golden):
+    """tests/golden/sim_digests_golden.npz: SHA-256 of every double of the edge lists (and of the CSV text) of 128 full-length seeds
+    (200000..200127), made by the ORACLE in the build container (tools/oracle_digests.py; the first 128 entries of the 512-seed file
+    tools/validate_many.py --digests compares against). "Bit-exact" in the product's own sense -- radii and node positions to the last
+    bit, not only the printed digits -- checked in every -m gpu run (round-4 advisor item: the long form used to exit 0 on a mismatch)."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_digests_golden.npz"))
+    seeds = [int(v) for v in d["seeds"]]
+    res = gh.simulate_batch(_cfg(golden, 100, 150), seeds)
+    assert int(np.asarray(res.stats)[:, 0].max()) == 0
+    bad = []
+    for k, seed in enumerate(seeds):
+        e = np.ascontiguousarray(res.sample_edges(k))
+        if e.shape[0] != int(d["rows"][k]) or int(res.n_art[k]) != int(d["n_art"][k]) or hashlib.sha256(e.tobytes()).hexdigest() != str(d["sha_doubles"][k]):
+            bad.append(seed)
+    assert not bad, f"edge lists differ from the oracle's in some double for seeds {bad}"
+
+
 def test_full_occupancy_launch_is_deterministic(gh, golden):
     """Determinism sentinel (round 4). One full-length launch that fills every workgroup slot of the GPU (two samples per CU), run
     three times on the same seeds: the per-iteration statistics and every double of the edge lists must be identical run to run, and

@@ -25,11 +25,16 @@ def against_digests(path, reps):
     seeds = [int(v) for v in d["seeds"]]
     cfg = configs.load_generator_config()
     sim = greenhouse.BatchSimulator(cfg, len(seeds))
+    failed = 0
     for rep in range(reps):
         t = time.time()
         res = sim.run(seeds)
         el = time.time() - t
         bad_d = bad_t = 0
+        err = int(np.asarray(res.stats)[:, 0].max())
+        if err:
+            print(f"rep {rep}: the simulator reported error / capacity bits 0x{err:x}")
+            failed += 1
         for k, seed in enumerate(seeds):
             e = np.ascontiguousarray(res.sample_edges(k))
             if e.shape[0] != int(d["rows"][k]) or hashlib.sha256(e.tobytes()).hexdigest() != str(d["sha_doubles"][k]):
@@ -39,14 +44,16 @@ def against_digests(path, reps):
                     print("seed", seed, "CSV text differs from the oracle's")
         print(f"RESULT rep {rep}: {len(seeds)} full-length samples ({seeds[0]}..{seeds[-1]}) in {el:.2f} s: samples with differing doubles {bad_d}, "
               f"with differing CSV text {bad_t}", flush=True)
+        failed += int(bad_d > 0 or bad_t > 0)
     sim.close()
+    return failed
 
 
 if __name__ == "__main__":
     if "--digests" in sys.argv:
         a = sys.argv
-        against_digests(a[a.index("--digests") + 1], int(a[a.index("--reps") + 1]) if "--reps" in a else 1)
-        sys.exit(0)
+        bad_reps = against_digests(a[a.index("--digests") + 1], int(a[a.index("--reps") + 1]) if "--reps" in a else 1)
+        sys.exit(1 if bad_reps else 0)          # a mismatch (or an error bit) in any repetition fails the command
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     from octa_autosegmentation_amd.utils import configs
