@@ -22,8 +22,6 @@ from . import resample
 # CUDA tensors go through the fused HIP InstanceNorm+LeakyReLU kernels (csrc/norm.hip); set to False to run the
 # plain torch modules (used by the parity tests as the reference).
 USE_FUSED_NORM = True
-# transposed convolutions with kernel == stride as GEMM + pixel shuffle (same parameters, same result)
-FAST_CONVT = False  # measured slower than MIOpen at 1216^2 (65 vs 53 ms per step): kept for experiments only
 # CUDA inputs run channels-last in bf16 through the hand-written MFMA convolution (csrc/conv.hip) and the NHWC
 # norm kernels; False = torch/MIOpen modules (the fp32 reference path of the parity tests)
 USE_MFMA_CONV = True
@@ -115,19 +113,6 @@ class _Conv(nn.Module):
         if x.is_cuda:
             _vendor_fallback(f"DynUNet {type(c).__name__}({c.in_channels}->{c.out_channels}, k{c.kernel_size[0]}, s{c.stride[0]})",
                              _why_not_own_kernels(c, x))
-        if (FAST_CONVT and isinstance(c, nn.ConvTranspose2d) and c.kernel_size == c.stride and c.kernel_size[0] == c.kernel_size[1]
-                and c.padding == (0, 0) and c.output_padding == (0, 0) and c.bias is None and c.groups == 1):
-            # kernel == stride: every input pixel owns a disjoint k x k output patch, so the transposed conv is one
-            # GEMM [Cout*k*k, Cin] x [Cin, H*W] per image plus a pixel shuffle -- no col2im scatter (MIOpen's path
-            # spends 11 ms of a 53 ms step in Col2Im2dU here).
-            k = c.kernel_size[0]
-            B, Cin, H, W = x.shape
-            Cout = c.out_channels
-            wm = c.weight.reshape(Cin, Cout * k * k).t()
-            y = torch.matmul(wm, x.reshape(B, Cin, H * W))
-            if k == 1:
-                return y.reshape(B, Cout, H, W)
-            return y.reshape(B, Cout, k, k, H, W).permute(0, 1, 4, 2, 5, 3).reshape(B, Cout, H * k, W * k)
         return c(x)
 
 

@@ -176,20 +176,6 @@ def test_noise_transforms_match_the_reference_fixture():
         assert torch.equal(o3, gnet.eval()(img.unsqueeze(0)).squeeze(0))
 
 
-def test_convt_as_gemm_matches_conv_transpose():
-    torch.manual_seed(0)
-    for k, cin, cout in ((2, 8, 4), (1, 6, 3)):
-        m = networks._Conv(cin, cout, k, k, transposed=True)
-        x = torch.randn(2, cin, 5, 7, requires_grad=True)
-        networks.FAST_CONVT = True
-        y = m(x); y.sum().backward(); g1 = x.grad.clone(); gw1 = m.conv.weight.grad.clone()
-        x.grad = None; m.conv.weight.grad = None
-        networks.FAST_CONVT = False
-        y2 = m(x); y2.sum().backward()
-        networks.FAST_CONVT = True
-        assert torch.allclose(y, y2, atol=1e-5) and torch.allclose(g1, x.grad, atol=1e-5) and torch.allclose(gw1, m.conv.weight.grad, atol=1e-4)
-
-
 def test_checkpoint_files_round_trip_and_metrics_csv(tmp_path):
     """File names, dict keys and resume order of the reference's trainer."""
     from octa_autosegmentation_amd.models.segmentation_trainer import SegmentationTrainer

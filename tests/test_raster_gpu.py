@@ -49,6 +49,30 @@ def test_labels_bit_exact(t2i, raster_golden):
         assert (out[k] == label).all()
 
 
+def test_18_shipped_labels_bit_exact_in_one_ragged_batch(t2i, raster_golden):
+    """The reference's shipped csv <-> label pairs (round-4 verdict item 5): raster_golden.npz's two + the 16 of
+    tests/golden/raster_shipped_golden.npz (tools/make_golden_raster_shipped.py) as ONE ragged batch (13.2 k - 14.3 k edges each) through
+    octa_rasterize_2d at 1216 x 1216 and octa_fs_dither: every label PNG bit for bit, every 304 x 304 / 1216 x 1216 raster by its SHA-256."""
+    import os
+    import torch
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "raster_shipped_golden.npz"))
+    n = len(g["names"])
+    assert n >= 16
+    edges = [raster_golden["graph0_edges"], raster_golden["graph1_edges"]] + [g[f"edges_{k}"] for k in range(n)]
+    grey = dev_raster(t2i, edges, [1216, 1216])
+    small = dev_raster(t2i, edges, [304, 304])
+    bits = t2i.binarize_label_device(torch.from_numpy(grey).cuda()).cpu().numpy()
+    for k in range(2):
+        assert (grey[k] == raster_golden[f"graph{k}_img1216"]).all() and (small[k] == raster_golden[f"graph{k}_img304"]).all()
+        assert (bits[k] == np.unpackbits(raster_golden[f"graph{k}_label_packed"])[: 1216 * 1216].reshape(1216, 1216) * 255).all()
+    for k in range(n):
+        name = str(g["names"][k])
+        assert hashlib.sha256(grey[2 + k].tobytes()).hexdigest() == str(g[f"img1216_sha256_{k}"]), name
+        assert hashlib.sha256(small[2 + k].tobytes()).hexdigest() == str(g[f"img304_sha256_{k}"]), name
+        label = np.unpackbits(g[f"label_packed_{k}"])[: 1216 * 1216].reshape(1216, 1216) * 255
+        assert (bits[2 + k] == label).all(), name
+
+
 def test_synthetic_cases(t2i, raster_golden):
     g = raster_golden
     for t in range(int(g["n_syn"])):

@@ -97,6 +97,22 @@ def test_kernel_arithmetic_on_host(raster_golden):
     assert (core_acc(g["graph1_edges"], 1216, 1216) == g["graph1_img1216"]).all()
 
 
+def test_oracle_reproduces_16_more_shipped_pairs():
+    """tests/golden/raster_shipped_golden.npz (tools/make_golden_raster_shipped.py): 16 further csv <-> label pairs the reference ships
+    (datasets/vessel_graphs/*.csv <-> datasets/labels/*.png), as data: edge array, the shipped label's bits, SHA-256 of the reference's own
+    304 x 304 and 1216 x 1216 rasters. The oracle must reproduce all of them; with raster_golden.npz's two that is 18 shipped labels."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "raster_shipped_golden.npz"))
+    names = [str(n) for n in g["names"]]
+    assert len(names) >= 16
+    for k, name in enumerate(names):
+        e = g[f"edges_{k}"]
+        assert hashlib.sha256(octa_oracle.rasterize(e, [304, 304]).tobytes()).hexdigest() == str(g[f"img304_sha256_{k}"]), name
+        img = octa_oracle.rasterize(e, [1216, 1216])
+        assert hashlib.sha256(img.tobytes()).hexdigest() == str(g[f"img1216_sha256_{k}"]), name
+        label = np.unpackbits(g[f"label_packed_{k}"])[: 1216 * 1216].reshape(1216, 1216) * 255
+        assert (octa_oracle.fs_dither(img) == label).all(), name
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/datasets/labels"), reason="reference datasets not present")
 def test_oracle_reproduces_shipped_labels_sample():
     """In the build container only: a spread of the 500 shipped csv<->label pairs."""
