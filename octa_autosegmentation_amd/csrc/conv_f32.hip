@@ -159,7 +159,9 @@ int launch_f32(const float *zero, const float *X, const float *Wp, const float *
 const float *zero_word(octa_ctx *ctx) {               // what the padding lanes of a slice fetch read
     if (!ctx->zero_page.p) {
         if (ctx->zero_page.reserve(256)) return nullptr;
-        if (hipMemset(ctx->zero_page.p, 0, ctx->zero_page.cap) != hipSuccess) { octa::set_error("conv_f32: zero page memset failed"); ctx->zero_page.release(); return nullptr; }
+        // hipMemset on device memory may return before the fill has run, and it runs on the NULL stream, which torch's (non-blocking) streams do
+        // not wait for: the first DMA-staged launch of a fresh context could fetch its padding from an uncleared page. Wait for the device once.
+        if (hipMemset(ctx->zero_page.p, 0, ctx->zero_page.cap) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { octa::set_error("conv_f32: zero page memset failed"); ctx->zero_page.release(); return nullptr; }
     }
     return ctx->zero_page.as<float>();
 }

@@ -25,6 +25,9 @@ from .losses import get_loss_function_by_name
 from .model_interface_abc import Output
 
 
+_D_SIDE = {}          # device index -> (side stream of the discriminator chain, its octa context)
+
+
 class GanSegModel(BaseModelABC):
     def __init__(self, MODEL_DICT: dict, model_g: dict, model_d: dict, model_s: dict, compute_identity=True, compute_identity_seg=True,
                  phase: Phase = Phase.TRAIN, inference: str = None, upshape: Tuple[int, int] = (1216, 1216), **kwargs):
@@ -65,11 +68,11 @@ class GanSegModel(BaseModelABC):
         import os
         if device.type != "cuda" or os.environ.get("OCTA_GAN_STREAMS", "1") == "0":
             return None, None, None
-        if getattr(self, "_d_side", None) is None:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in _D_SIDE:                                   # one per device for the life of the process (like utils/aside.py)
             from .. import _native
-            idx = device.index if device.index is not None else torch.cuda.current_device()
-            object.__setattr__(self, "_d_side", (torch.cuda.Stream(device=idx), _native.new_ctx(idx)))
-        return self._d_side[0], self._d_side[1], torch.cuda.current_stream(device)
+            _D_SIDE[idx] = (torch.cuda.Stream(device=idx), _native.new_ctx(idx))
+        return _D_SIDE[idx][0], _D_SIDE[idx][1], torch.cuda.current_stream(device)
 
     def forward(self, input: torch.Tensor):
         if self.segmentor is not None:
