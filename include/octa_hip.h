@@ -234,6 +234,17 @@ int octa_instnorm_lrelu_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const voi
 int octa_instnorm_lrelu_nhwc_fwd_p(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b, float *d_mean,
                                    float *d_rstd, int B, int C, int64_t hw, float slope, float eps, const float *d_partials, int tiles,
                                    void *stream);
+/* The same statistics in SLOT form (round 5): MONAI's UnetBasicBlock is conv -> InstanceNorm(affine) -> LeakyReLU (imported at
+ * models/networks.py:6); octa_conv3x3_nhwc_fwd7 is octa_conv3x3_nhwc_fwd2 (one or two virtually concatenated inputs, stride 1 or 2,
+ * plain single output d_y [N][Ho][Wo][Cout]) whose epilogue also adds, per output channel, the sum and the sum of squares of the
+ * bf16-rounded results of every output tile to d_stat_slots = double[nslot][N][Cout][2] (ZERO on entry, 1 <= nslot <= 1024; tile t adds
+ * to slot t % nslot, so the chain of same-address atomics stays short). octa_instnorm_lrelu_nhwc_fwd_s is
+ * octa_instnorm_lrelu_nhwc_fwd with those slots instead of its own statistics pass over d_x: one launch, one read of d_x. */
+int octa_conv3x3_nhwc_fwd7(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, int N, int H, int W,
+                           int Cin, int Cout, int stride, double *d_stat_slots, int nslot, void *stream);
+int octa_instnorm_lrelu_nhwc_fwd_s(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b, float *d_mean,
+                                   float *d_rstd, int B, int C, int64_t hw, float slope, float eps, const double *d_stat_slots, int nslot,
+                                   void *stream);
 
 /* 3 x 3 convolution, stride 1, with an explicit padding (round 3): pad = 0 (valid), 1 (same), 2 (full: the data gradient of a valid
  * convolution), zeros outside the image; reflect = 1 (pad = 1 only) fuses nn.ReflectionPad2d(1) into the halo fetch -- the ResNet

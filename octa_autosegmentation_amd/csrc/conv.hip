@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(CONV_THREADS, (THT == 16 ? 2 : 1))
 conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                          const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, unsigned short *__restrict__ Y2, int CY1,
                          int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, int tiles_x, const unsigned short *__restrict__ zero16,
-                         float *__restrict__ part, int tap_mask, int osc, int ooy, int oox, int pad, const unsigned short *__restrict__ R, int reflect) {
+                         float *__restrict__ part, int tap_mask, int osc, int ooy, int oox, int pad, const unsigned short *__restrict__ R, int reflect,
+                         int nslot) {
     constexpr int RPW = THT / 4;                           // tile rows per wave (THT = 8: two, THT = 16: four)
     constexpr int IH = (THT - 1) * ST + KS, IW = (TW - 1) * ST + KS;   // KS x KS taps (3: the U-Net / generator layers, 4: the PatchGAN)
     constexpr int PW = (IW + ST - 1) / ST;                 // pixels per LDS plane row (ST = 2: 33 even / 32 odd columns)
@@ -478,17 +479,67 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
     const int ys = co0 < CY1 ? CY1 : Cout - CY1, yb = co0 < CY1 ? co0 : co0 - CY1;
     constexpr int OP = BN * 2 + 16;
     unsigned char *s_out = smem;
+    // InstanceNorm statistics of the layer that follows, slot form (round 5; nslot > 0): the sum and the sum of squares of the bf16-ROUNDED
+    // results per output channel ride in the conversion loop -- a lane holds ONE channel (m) of 16 pixels per fragment, v_cvt_pk_bf16_f32
+    // rounds two of them at once and two v_dot2c_f32_bf16 (pair . (1, 1), pair . pair) add both to the running sums: 1.5 VALU instructions
+    // per value where the per-tile form below spends ~5 (conversion again, range masks, multiply-add). Results of an edge tile that lie
+    // outside the image are never stored: they are cleared first, so the sums need no masks.
+    const bool stat_slots = STATS && nslot > 0;
+    float q1[NB], q2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) { q1[nb] = 0.f; q2[nb] = 0.f; }
+    if (stat_slots && !(ty0 + THT <= Ho && tx0 + TW <= Wo)) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; rr++) {
+            const bool row_in = ty0 + RPW * wv + rr < Ho;
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    if (!(row_in && tx0 + (k & 3) + 8 * (k >> 2) + 4 * kg < Wo)) acc[rr][nb][k] = 0.f;
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < RPW; rr++)
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int px = (k & 3) + 8 * (k >> 2) + 4 * kg;
-                *reinterpret_cast<unsigned short *>(s_out + ((RPW * wv + rr) * TW + px) * OP + (nb * 32 + m) * 2) = f2bf(acc[rr][nb][k]);
+            for (int k = 0; k < 16; k += 2) {
+                const int px = (k & 3) + 8 * (k >> 2) + 4 * kg;          // k even: pixels px and px + 1 of the lane's channel
+                const unsigned pk = octa_pack_bf16x2(acc[rr][nb][k], acc[rr][nb][k + 1]);
+                unsigned char *d = s_out + ((RPW * wv + rr) * TW + px) * OP + (nb * 32 + m) * 2;
+                *reinterpret_cast<unsigned short *>(d) = (unsigned short)(pk & 0xffffu);
+                *reinterpret_cast<unsigned short *>(d + OP) = (unsigned short)(pk >> 16);
+                if (stat_slots) {
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+                    const bf2 v = __builtin_bit_cast(bf2, pk), one = __builtin_bit_cast(bf2, 0x3f803f80u);
+                    q1[nb] = __builtin_amdgcn_fdot2_f32_bf16(v, one, q1[nb], false);
+                    q2[nb] = __builtin_amdgcn_fdot2_f32_bf16(v, v, q2[nb], false);
+                }
             }
+    // the four waves' sums meet in LDS BEHIND the output tile (free since the last slice was consumed), so that the barrier the tile needs
+    // anyway also publishes them: no barrier of its own
+    float *s_red = reinterpret_cast<float *>(smem + ((THT * TW * OP + 15) / 16) * 16);   // [4 waves][BN][2]
+    if (stat_slots) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            const float a1 = q1[nb] + __shfl_xor(q1[nb], 32, 64), a2 = q2[nb] + __shfl_xor(q2[nb], 32, 64);
+            if (kg == 0) { s_red[(wv * BN + nb * 32 + m) * 2] = a1; s_red[(wv * BN + nb * 32 + m) * 2 + 1] = a2; }
+        }
+    }
     __syncthreads();
+    if (stat_slots && threadIdx.x < BN) {
+        // ONE pair of double atomics per channel and tile goes to slot (tile % nslot) of sums[nslot][N][Cout][2] (pre-zeroed by the caller):
+        // the norm's apply pass adds the slots up (csrc/norm.hip). Spreading the tiles of an image over the slots keeps the chain of
+        // same-address atomics short (5776 tiles per 1216^2 image -> 361 per address at 16 slots). Issued in front of the tile's stores.
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; w4++) { a1 += s_red[(w4 * BN + threadIdx.x) * 2]; a2 += s_red[(w4 * BN + threadIdx.x) * 2 + 1]; }
+        double *dst = reinterpret_cast<double *>(part) + (((size_t)(tile % nslot) * gridDim.z + n) * Cout + co0 + threadIdx.x) * 2;
+        atomicAdd(dst, (double)a1);
+        atomicAdd(dst + 1, (double)a2);
+    }
     constexpr int PIECES = BN / 8;
     for (int i = threadIdx.x; i < THT * TW * PIECES; i += CONV_THREADS) {
         const int p = i / PIECES, q = i % PIECES;
@@ -515,7 +566,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
     }
     // InstanceNorm statistics of the layer that follows: per tile and output channel the sum and the sum of squares of the
     // bf16-ROUNDED results (what a statistics pass would read back) -> part[n][tile][Cout][2]; saves that pass over Y.
-    if (STATS) {
+    if (STATS && nslot == 0) {
         float s1[NB], s2[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) { s1[nb] = 0.f; s2[nb] = 0.f; }
@@ -565,10 +616,10 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
 template <int BN, int KCV, int ST = 1, int KS = 3, int THT = TH>
 int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *Wt, unsigned short *Y, unsigned short *Y2,
                      int CY1, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int dil, const unsigned short *zero16, float *part, int tap_mask,
-                     int osc, int ooy, int oox, hipStream_t stream, int pad = 1, const unsigned short *R = nullptr, int reflect = 0) {
+                     int osc, int ooy, int oox, hipStream_t stream, int pad = 1, const unsigned short *R = nullptr, int reflect = 0, int nslot = 0) {
     constexpr int IH = (THT - 1) * ST + KS, IW = (TW - 1) * ST + KS, PP = KCV / 8;
     constexpr int BUF = ((IH * ST * ((IW + ST - 1) / ST) * PP + 63) / 64 + KS * KS * BN * PP / 64) * 1024;
-    constexpr int OUT = THT * TW * (BN * 2 + 16);
+    constexpr int OUT = THT * TW * (BN * 2 + 16) + 16 + 4 * BN * 2 * 4;      // output tile + the statistics epilogue's [4 waves][BN][2] floats behind it
     const size_t lds = 2 * BUF > OUT ? 2 * BUF : OUT;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + THT - 1) / THT;
     auto kern = conv3x3_nhwc_glds_kernel<BN, KCV, false, false, ST, KS, THT>;
@@ -578,7 +629,7 @@ int launch_conv_glds(const unsigned short *X, const unsigned short *X2, int C1, 
     }
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
-    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask, osc, ooy, oox, pad, R, reflect);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, X2, C1, Wt, Y, Y2, CY1, H, W, Cin, Ho, Wo, Cout, dil, tiles_x, zero16, part, tap_mask, osc, ooy, oox, pad, R, reflect, nslot);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -601,11 +652,12 @@ int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const
 
 extern "C" int octa_conv_stat_tiles(int Ho, int Wo) { return ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH); }
 
-extern "C" int octa_conv3x3_nhwc_fwd6(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
-                                      int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
-                                      int out_scale, int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1,
-                                      const float *d_scale2, const float *d_shift2, float slope, float *d_stat_partials,
-                                      const void *d_residual, void *stream_) {
+namespace {
+int conv3x3_fwd_impl(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+                     int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
+                     int out_scale, int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1,
+                     const float *d_scale2, const float *d_shift2, float slope, float *d_stat_partials,
+                     const void *d_residual, double *d_stat_slots, int nslot, void *stream_) {
     if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv3x3_nhwc_fwd: null pointer"); return -2; }
     if (N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: bad shape"); return -2; }
     if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
@@ -622,6 +674,9 @@ extern "C" int octa_conv3x3_nhwc_fwd6(octa_ctx *ctx, const void *d_x, const void
         octa::set_error("octa_conv3x3_nhwc_fwd: output scatter must be scale 1 or 2 with offsets below the scale");
         return -2;
     }
+    if (d_stat_slots && (nslot <= 0 || nslot > 1024 || d_stat_partials || d_scale1 || d_scale2)) { octa::set_error("octa_conv3x3_nhwc_fwd: statistics slots need 1..1024 slots, no per-tile partials beside them and the DMA-staged kernel"); return -2; }
+    if (!d_stat_slots) nslot = 0;
+    if (d_stat_slots) d_stat_partials = reinterpret_cast<float *>(d_stat_slots);      // one kernel argument: read as double slots when nslot > 0
     if (d_stat_partials && (out_scale != 1 || d_y2)) { octa::set_error("octa_conv3x3_nhwc_fwd: statistics need a plain single output"); return -2; }
     const unsigned short *Rz = static_cast<const unsigned short *>(d_residual);
     if (Rz && (out_scale != 1 || d_y2 || d_scale1 || d_scale2 || d_stat_partials || d_residual == d_y)) {
@@ -644,25 +699,47 @@ extern "C" int octa_conv3x3_nhwc_fwd6(octa_ctx *ctx, const void *d_x, const void
         const unsigned short *z = zero_page(ctx);
         if (!z) return -1;
         if (stride == 2)
-            return wide ? launch_conv_glds<64, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz)
-                        : launch_conv_glds<32, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz);
+            return wide ? launch_conv_glds<64, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz, 0, nslot)
+                        : launch_conv_glds<32, 16, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, 1, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz, 0, nslot);
         // 16-row tiles (a wave owns four tile rows: 6 operand reads per 8 MFMAs instead of 4 per 4, 72 MFMAs per barrier) from
         // 200 output rows up: 8-14 % faster on the 304^2 / 608^2 layers (256->128 at 304^2: 1.0 PFLOP/s), no gain at 152^2
         // (half as many workgroups: tail effects) and on the HBM-bound 1216^2 layers. OCTA_CONV_TALL=0 disables.
         static const int tall = [] { const char *e = getenv("OCTA_CONV_TALL"); return e ? atoi(e) : 200; }();
         if (glds_mode == 16 && tall && wide && stride == 1 && tap_mask == 0x1ff && out_scale == 1 && Ho >= tall)
-            return launch_conv_glds<64, 16, 1, 3, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, 1, 0, 0, stream, 1, Rz);
+            return launch_conv_glds<64, 16, 1, 3, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, 1, 0, 0, stream, 1, Rz, 0, nslot);
         if (glds_mode == 16)
-            return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz)
-                        : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz);
-        return wide ? launch_conv_glds<64, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz)
-                    : launch_conv_glds<32, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz);
+            return wide ? launch_conv_glds<64, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz, 0, nslot)
+                        : launch_conv_glds<32, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz, 0, nslot);
+        return wide ? launch_conv_glds<64, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz, 0, nslot)
+                    : launch_conv_glds<32, 32>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, out_scale, out_off_y, out_off_x, stream, 1, Rz, 0, nslot);
     }
     if (Rz) { octa::set_error("octa_conv3x3_nhwc_fwd: the residual is implemented in the DMA-staged kernel only (OCTA_CONV_GLDS=0 is set)"); return -2; }
+    if (nslot) { octa::set_error("octa_conv3x3_nhwc_fwd: statistics slots are implemented in the DMA-staged kernel only (OCTA_CONV_GLDS=0 is set)"); return -2; }
     if (stride == 1) return wide ? launch_conv<64, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream)
                                  : launch_conv<32, 1>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream);
     return wide ? launch_conv<64, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream)
                 : launch_conv<32, 2>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, tap_mask, out_scale, out_off_y, out_off_x, d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, stream);
+}
+}  // namespace
+
+extern "C" int octa_conv3x3_nhwc_fwd6(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,
+                                      int CY1, int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask,
+                                      int out_scale, int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1,
+                                      const float *d_scale2, const float *d_shift2, float slope, float *d_stat_partials,
+                                      const void *d_residual, void *stream_) {
+    return conv3x3_fwd_impl(ctx, d_x, d_x2, C1, d_w, d_y, d_y2, CY1, N, H, W, Cin, Cout, stride, in_dilation, tap_mask, out_scale, out_off_y, out_off_x,
+                            d_scale1, d_shift1, d_scale2, d_shift2, slope, d_stat_partials, d_residual, nullptr, 0, stream_);
+}
+
+// fwd7 = fwd2 + the InstanceNorm statistics of the RESULT in slot form (round 5): d_stat_slots is double[nslot][N][Cout][2], zero on entry;
+// every output tile adds the sum and the sum of squares of its bf16-rounded results per channel to slot (tile % nslot). Replaces the
+// statistics pass of the norm layer that follows (reference: MONAI UnetBasicBlock conv -> InstanceNorm, models/networks.py:6);
+// octa_instnorm_lrelu_nhwc_fwd_s consumes the slots. Plain single output, stride 1 or 2, no input dilation mask restrictions beyond fwd2's.
+extern "C" int octa_conv3x3_nhwc_fwd7(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, int N, int H, int W,
+                                      int Cin, int Cout, int stride, double *d_stat_slots, int nslot, void *stream_) {
+    if (!d_stat_slots) { octa::set_error("octa_conv3x3_nhwc_fwd7: null statistics slots"); return -2; }
+    return conv3x3_fwd_impl(ctx, d_x, d_x2, C1, d_w, d_y, nullptr, Cout, N, H, W, Cin, Cout, stride, 1, 0x1ff, 1, 0, 0, nullptr, nullptr, nullptr, nullptr,
+                            0.f, nullptr, nullptr, d_stat_slots, nslot, stream_);
 }
 
 extern "C" int octa_conv3x3_nhwc_fwd5(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_w, void *d_y, void *d_y2,

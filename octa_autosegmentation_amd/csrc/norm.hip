@@ -371,11 +371,13 @@ in_nhwc_stats(const unsigned short *__restrict__ x, const unsigned short *__rest
 __global__ void __launch_bounds__(NT)
 in_nhwc_fwd_apply(const unsigned short *__restrict__ x, unsigned short *__restrict__ y, const float *__restrict__ w,
                   const float *__restrict__ bias, long hw, int C, int splits, const double *__restrict__ sums, float slope, float eps,
-                  float *__restrict__ mean_out, float *__restrict__ rstd_out, int b0) {
+                  float *__restrict__ mean_out, float *__restrict__ rstd_out, int b0, int nslot = 1, long slot_stride = 0) {
     __shared__ float s_g[NHWC_MAXC], s_sh[NHWC_MAXC];
     const int b = blockIdx.y + b0, s = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += NT) {
-        const double sa = sums[((long)b * C + c) * 2], sq = sums[((long)b * C + c) * 2 + 1];
+        // nslot > 1: the sums come from the producing convolution's epilogue, spread over slots [nslot][B][C][2] (csrc/conv.hip, fwd7)
+        double sa = 0, sq = 0;
+        for (int k = 0; k < nslot; k++) { sa += sums[k * slot_stride + ((long)b * C + c) * 2]; sq += sums[k * slot_stride + ((long)b * C + c) * 2 + 1]; }
         const double mean_d = sa / (double)hw;
         double var = sq / (double)hw - mean_d * mean_d;
         if (var < 0) var = 0;
@@ -690,6 +692,23 @@ extern "C" int octa_instnorm_lrelu_nhwc_fwd_p(octa_ctx *ctx, const void *d_x, vo
     const int splits = nhwc_splits(ctx, B, hw);
     hipLaunchKernelGGL(in_nhwc_fwd_apply, dim3((unsigned)splits, (unsigned)B), dim3(NT), 0, stream, static_cast<const unsigned short *>(d_x),
                        static_cast<unsigned short *>(d_y), d_w, d_b, (long)hw, C, splits, sums, slope, eps, d_mean, d_rstd, 0);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Forward with the statistics in SLOT form (round 5): sums double[nslot][B][C][2] accumulated by the epilogue of the convolution that wrote
+// x (octa_conv3x3_nhwc_fwd7). One launch: the apply pass adds the slots up while it derives scale / shift.
+extern "C" int octa_instnorm_lrelu_nhwc_fwd_s(octa_ctx *ctx, const void *d_x, void *d_y, const float *d_w, const float *d_b, float *d_mean,
+                                              float *d_rstd, int B, int C, int64_t hw, float slope, float eps, const double *d_stat_slots,
+                                              int nslot, void *stream_) {
+    if (!ctx || !d_x || !d_y || !d_mean || !d_rstd || !d_stat_slots || nslot <= 0 || nslot > 1024) { octa::set_error("octa_instnorm_lrelu_nhwc_fwd_s: bad arguments"); return -2; }
+    if (nhwc_check("octa_instnorm_lrelu_nhwc_fwd_s", B, C, hw)) return -2;
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const int splits = nhwc_splits(ctx, B, hw);
+    hipLaunchKernelGGL(in_nhwc_fwd_apply, dim3((unsigned)splits, (unsigned)B), dim3(NT), 0, stream, static_cast<const unsigned short *>(d_x),
+                       static_cast<unsigned short *>(d_y), d_w, d_b, (long)hw, C, splits, d_stat_slots, slope, eps, d_mean, d_rstd, 0, nslot,
+                       (long)B * C * 2);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }

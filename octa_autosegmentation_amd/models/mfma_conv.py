@@ -257,15 +257,45 @@ def conv3x3_nhwc_wgrad(x, dy, tap_mask=0x1ff):
     return dw.view(3, 3, cout, cin).permute(2, 3, 0, 1)
 
 
+STAT_SLOTS = int(os.environ.get("OCTA_STAT_SLOTS", "16"))      # slots the tiles of an image spread their statistics atomics over
+_STAT_RINGS = {}
+
+
+def _stat_slots(device, n, cout):
+    """Zeroed double[STAT_SLOTS][n][cout][2] from a per-(device, stream) ring: ONE fill per lap instead of one per layer. A slice is
+    consumed by the two launches enqueued right behind it (convolution, norm apply) on the same stream; the lap's fill is enqueued on
+    that stream too, so it is ordered behind every earlier consumer."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    need = STAT_SLOTS * n * cout * 2
+    ring = _STAT_RINGS.get(key)
+    if ring is None or ring[0].numel() < 8 * need:
+        ring = [torch.zeros(max(4 << 20, 8 * need), dtype=torch.float64, device=device), 0]
+        _STAT_RINGS[key] = ring
+    if ring[1] + need > ring[0].numel():
+        ring[0].zero_()
+        ring[1] = 0
+    t = ring[0][ring[1]:ring[1] + need].view(STAT_SLOTS, n, cout, 2)
+    ring[1] += need
+    return t
+
+
 def _conv_fwd_stats(x1, x2, wt, stride, want_stats):
-    """Forward launch over one or two inputs (virtual concatenation); optionally also the per-tile InstanceNorm
-    statistics of the result (float32 [N][tiles][Cout][2]) accumulated in the kernel's epilogue."""
+    """Forward launch over one or two inputs (virtual concatenation); optionally also the InstanceNorm statistics of the result,
+    accumulated in the kernel's epilogue: want_stats = True / "slots" -> double [STAT_SLOTS][N][Cout][2] (round 5: octa_conv3x3_nhwc_fwd7),
+    "tiles" -> the round-1 per-tile partials float32 [N][tiles][Cout][2] (octa_conv3x3_nhwc_fwd5; kept for its tests)."""
     n, h, w, c1 = x1.shape
     c2 = x2.shape[3] if x2 is not None else 0
     cout = wt.shape[1]
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x1.device)
     part = None
+    if want_stats and want_stats != "tiles":
+        part = _stat_slots(x1.device, n, cout)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        rc = _native.lib().octa_conv3x3_nhwc_fwd7(_native.ctx(x1.device.index), pp(x1), pp(x2), c1, pp(wt), pp(y), n, h, w, c1 + c2, cout, int(stride),
+                                                  pp(part), STAT_SLOTS, _native.current_stream_ptr())
+        _native.check(rc, "octa_conv3x3_nhwc_fwd7")
+        return y, part
     if want_stats:
         tiles = _native.lib().octa_conv_stat_tiles(ho, wo)
         part = torch.empty((n, tiles, cout, 2), dtype=torch.float32, device=x1.device)
@@ -383,6 +413,7 @@ class _Conv3x3NHWC(torch.autograd.Function):
     def forward(ctx, x, weight, stride, want_stats=False, mailbox=None):
         cin = weight.shape[1]
         ctx.mailbox = None
+        ctx.set_materialize_grads(False)      # the statistics output is not differentiable: no zero "gradient" of it (a fill launch per layer)
         if mailbox is not None and USE_SKIP_GRAD_FUSION and x.requires_grad and x.shape[-1] % 32 == 0 and not (int(stride) == 2 and USE_PARITY_SCATTER):
             ctx.mailbox = mailbox
             mailbox.armed = True
@@ -398,6 +429,8 @@ class _Conv3x3NHWC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dpart=None):
         xp, weight = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None, None
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
@@ -544,6 +577,7 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, weight, want_stats=False, mailbox=None):
+        ctx.set_materialize_grads(False)
         ctx.mailbox = mailbox if (mailbox is not None and mailbox.armed) else None
         x1, x2 = x1.contiguous(), x2.contiguous()
         c1, c2 = x1.shape[3], x2.shape[3]
@@ -558,6 +592,8 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dpart=None):
         x1, x2, weight = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None, None
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
@@ -601,7 +637,11 @@ class _InstNormLReLUNHWC(torch.autograd.Function):
         w = weight.float().contiguous() if weight is not None else None
         b = bias.float().contiguous() if bias is not None else None
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-        if partials is not None:
+        if partials is not None and partials.dtype == torch.float64:       # slot form (octa_conv3x3_nhwc_fwd7)
+            rc = _native.lib().octa_instnorm_lrelu_nhwc_fwd_s(_native.ctx(x.device.index), p(x), p(y), p(w), p(b), p(mean), p(rstd), B, C, hw,
+                                                              float(slope), float(eps), p(partials), int(partials.shape[0]),
+                                                              _native.current_stream_ptr())
+        elif partials is not None:
             rc = _native.lib().octa_instnorm_lrelu_nhwc_fwd_p(_native.ctx(x.device.index), p(x), p(y), p(w), p(b), p(mean), p(rstd), B, C, hw,
                                                               float(slope), float(eps), p(partials), int(partials.shape[1]),
                                                               _native.current_stream_ptr())

@@ -30,11 +30,13 @@ USE_F32_MFMA = True      # fp32 forward passes that record no gradient run csrc/
 # measured SLOWER on MI355X (37.5 vs 31.9 ms per step): every output-channel block of a layer re-stages and
 # re-normalises the same input tile, which costs more VALU work than the two HBM passes it saves
 USE_LAZY_NORM = __import__('os').environ.get('OCTA_LAZY_NORM', '0') == '1'      # re-measured in round 4 on the DMA-staged kernels: DESIGN.md 4.2c
-# InstanceNorm statistics accumulated in the convolution epilogue (conv.hip _fwd5) instead of a statistics pass:
-# implemented and tested, measured slower too (33.6 vs 32.1 ms: the MFMA kernels are the critical resource, the
-# statistics pass they would save is a cheap HBM-bound stream)
+# InstanceNorm statistics accumulated in the convolution's epilogue instead of a statistics pass over the stored tensor. Rounds 1-4: per-tile
+# partials + a fold launch (conv.hip _fwd5), measured slower every time (33.6 vs 32.1, 20.0 vs 18.4 ms). Round 5: slot form (conv.hip
+# octa_conv3x3_nhwc_fwd7 -- the sums ride in the bf16 conversion loop as v_dot2c_f32_bf16, the waves meet behind the output tile in LDS under
+# the barrier the tile needs anyway, one pair of double atomics per channel and tile into 16 slots; the apply pass adds the slots): same box,
+# B = 4 at 1216^2: 18.7 -> 18.5 ms per step (profiles/r05_unet_epilogue_stats_ab.log). Default ON; OCTA_EPI_STATS=0 runs the statistics pass.
 import os as _os
-USE_EPILOGUE_STATS = _os.environ.get('OCTA_EPI_STATS', '0') == '1'
+USE_EPILOGUE_STATS = _os.environ.get('OCTA_EPI_STATS', '1') != '0'
 
 # ---- which kernels ran ------------------------------------------------------------------------------------------------
 # The product path of a CUDA forward is the hand-written HIP kernels (csrc/conv.hip, conv_f32.hip, norm.hip, thin_conv.hip,
@@ -223,8 +225,10 @@ class DynUNet(nn.Module):
                 y = mc.conv3x3(xt, c1.weight, st, USE_EPILOGUE_STATS, mb_recv if sk is None else None)
             y, part = y if USE_EPILOGUE_STATS else (y, None)
             y = mc.instance_norm_leaky_relu_nhwc(y, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps, part)
-            y = mc.conv3x3(y, c2.weight, 1, USE_EPILOGUE_STATS)
-            y, part = y if USE_EPILOGUE_STATS else (y, None)
+            fused_head = head is not None and mc.norm_lrelu_head1_ok(c2.weight.shape[0], head.weight)
+            want2 = USE_EPILOGUE_STATS and not fused_head        # the norm + head layer runs its own statistics pass over the raw tensor
+            y = mc.conv3x3(y, c2.weight, 1, want2)
+            y, part = y if want2 else (y, None)
             if head is not None and part is None and mc.norm_lrelu_head1_ok(y.shape[-1], head.weight):
                 # last block: norm + activation + the 1x1 output convolution in one pair of passes, nothing normalised goes to HBM
                 return mc.instance_norm_leaky_relu_head1_nhwc(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps,

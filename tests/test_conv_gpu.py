@@ -333,11 +333,28 @@ def test_epilogue_statistics_feed_the_norm(hip_lib_built):
         x = torch.randn(2, h, w, cin, device="cuda", generator=g).to(torch.bfloat16)
         wt = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (3.0 * cin ** 0.5)
         gam, bet = torch.rand(cout, device="cuda", generator=g) + 0.5, torch.randn(cout, device="cuda", generator=g) * 0.1
-        y, part = mc.conv3x3(x, wt, st, True)
-        a = mc.instance_norm_leaky_relu_nhwc(y, gam, bet, partials=part)
-        b = mc.instance_norm_leaky_relu_nhwc(y, gam, bet)
-        assert (a.float() - b.float()).abs().max().item() <= 2.0 ** -7 * b.float().abs().max().item()
-        assert (a != b).float().mean().item() < 0.01      # a handful of values may round the other way
+        for form in ("slots", "tiles"):         # round 5: double slots + atomics (the default form); round 1: per-tile float partials
+            y, part = mc.conv3x3(x, wt, st, form)
+            assert part.dtype == (torch.float64 if form == "slots" else torch.float32)
+            a = mc.instance_norm_leaky_relu_nhwc(y, gam, bet, partials=part)
+            b = mc.instance_norm_leaky_relu_nhwc(y, gam, bet)
+            assert (a.float() - b.float()).abs().max().item() <= 2.0 ** -7 * b.float().abs().max().item()
+            assert (a != b).float().mean().item() < 0.01      # a handful of values may round the other way
+            if form == "slots":
+                # the slots hold exactly the sums of the stored bf16 values (fp32 within a tile, double across tiles)
+                yf = y.double()
+                want = torch.stack((yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))), dim=-1)            # [N][C][2]
+                got = part.sum(dim=0)
+                assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item(), (h, w, cin, cout, st)
+    # two virtually concatenated inputs (the decoder's convolution) with statistics
+    x1 = torch.randn(2, 40, 72, 64, device="cuda", generator=g).to(torch.bfloat16)
+    x2 = torch.randn(2, 40, 72, 32, device="cuda", generator=g).to(torch.bfloat16)
+    wt = torch.randn(32, 96, 3, 3, device="cuda", generator=g) / (3.0 * 96 ** 0.5)
+    y, part = mc.conv3x3_cat(x1, x2, wt, True)
+    yf = y.double()
+    want = torch.stack((yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))), dim=-1)
+    assert (part.sum(dim=0) - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    assert torch.equal(y, mc.conv3x3_cat(x1, x2, wt))                 # the statistics epilogue does not change the stored result
 
 
 def test_weight_pack_plan_is_bit_exact_and_follows_updates(hip_lib_built):

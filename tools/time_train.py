@@ -9,7 +9,7 @@ CFG = {"General": {"amp": True, "model": {"name": "DynUNet", "spatial_dims": 2, 
        "Train": {"lr": 1e-4, "loss": "DiceBCELoss", "epochs": 30, "epochs_decay": 10}}
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 1216
-cl = (sys.argv[3] != "nchw") if len(sys.argv) > 3 else True
+cl = (sys.argv[3] == "channels_last") if len(sys.argv) > 3 else False      # default: the bench's configuration (plain parameters: the pack plan covers them)
 tr = SegmentationTrainer(CFG, "cuda", channels_last=cl)
 x = torch.rand(B, 1, res, res, device="cuda"); y = (torch.rand(B, 1, res, res, device="cuda") > 0.8).float()
 for i in range(3):
