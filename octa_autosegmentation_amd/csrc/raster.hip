@@ -150,35 +150,58 @@ raster_scan_sums_kernel(int *__restrict__ block_sums, int nb, long *__restrict__
 }
 
 // one thread per edge: the stroke polygon's sides, clipped and converted to 24.8 fixed point, into the edge's
-// nv + EXTRA_SLOTS slots (side k in slot k, extra clip pieces behind them, unused slots zero)
-__global__ void __launch_bounds__(256)
+// nv + EXTRA_SLOTS slots (side k in slot k, extra clip pieces behind them, unused slots zero).
+// Round 5: the edges of a workgroup own ONE contiguous run of the side array (their offsets come from an exclusive scan), so the
+// sides are staged in LDS and written out by consecutive threads, 16 bytes each. Thread-per-edge stores straight to HBM put every
+// lane's 16 bytes on a line of their own: the counters showed 4.7 GB written per 512 graphs for 1.5 GB of sides.
+constexpr int TESS_STAGE = 3072;               // int4 slots (48 KiB): 128 edges x 24 slots (a 1.8-pixel stroke has 10 sides + 4 spare); longer runs fall back to direct stores
+constexpr int TESS_WG = 128;
+
+__global__ void __launch_bounds__(TESS_WG)
 raster_tess_kernel(const EdgeMeta *__restrict__ meta, const int *__restrict__ off, const int *__restrict__ block_sums,
                    long n_total, int W, int H, int4 *__restrict__ sides, int *__restrict__ err_flag) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    const EdgeMeta m = meta[i];
-    if (m.nv <= 0) return;
-    int4 *out = sides + ((long)off[i] + (long)block_sums[i / SCAN_BLK]);
-    const int nv = m.nv;
-    for (int k = nv; k < nv + EXTRA_SLOTS; k++) out[k] = make_int4(0, 0, 0, 0);
-    const double ddx = m.x1 - m.x0, ddy = m.y1 - m.y0;
-    const double len = sqrt(ddx * ddx + ddy * ddy);
-    double fx, fy;
-    stroke_vertex(m, len, 0, &fx, &fy);
-    double ax = fx, ay = fy;
-    int extra = 0;
-    for (int v = 1; v <= nv; v++) {
-        double bx = fx, by = fy;
-        if (v < nv) stroke_vertex(m, len, v, &bx, &by);
-        SideSink sink;
-        sink.n = 0;
-        clip_side(sink, (double)W, (double)H, ax, ay, bx, by);
-        out[v - 1] = sink.n > 0 ? sink.piece[0] : make_int4(0, 0, 0, 0);
-        for (int q = 1; q < sink.n; q++) {
-            if (extra < EXTRA_SLOTS) out[nv + extra++] = sink.piece[q];
-            else atomicExch(err_flag, 2);
+    __shared__ int4 s_stage[TESS_STAGE];
+    __shared__ long s_run[2];                  // first slot of the workgroup's run, one past its last slot
+    const long i0 = (long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
+    const bool valid = i < n_total;
+    EdgeMeta m;
+    m.nv = 0;
+    if (valid) m = meta[i];
+    const int nv = m.nv > 0 ? m.nv : 0;
+    const long goff = valid ? (long)off[i] + (long)block_sums[i / SCAN_BLK] : 0;
+    if (threadIdx.x == 0) s_run[0] = goff;
+    const long last = (i0 + blockDim.x < n_total ? i0 + blockDim.x : n_total) - 1;
+    if (i == last) s_run[1] = goff + (nv > 0 ? nv + EXTRA_SLOTS : 0);
+    __syncthreads();
+    const long base = s_run[0];
+    const int run = (int)(s_run[1] - base);
+    const bool staged = run <= TESS_STAGE;
+    if (nv > 0) {
+        int4 *out = staged ? s_stage + (goff - base) : sides + goff;
+        for (int k = nv; k < nv + EXTRA_SLOTS; k++) out[k] = make_int4(0, 0, 0, 0);
+        const double ddx = m.x1 - m.x0, ddy = m.y1 - m.y0;
+        const double len = sqrt(ddx * ddx + ddy * ddy);
+        double fx, fy;
+        stroke_vertex(m, len, 0, &fx, &fy);
+        double ax = fx, ay = fy;
+        int extra = 0;
+        for (int v = 1; v <= nv; v++) {
+            double bx = fx, by = fy;
+            if (v < nv) stroke_vertex(m, len, v, &bx, &by);
+            SideSink sink;
+            sink.n = 0;
+            clip_side(sink, (double)W, (double)H, ax, ay, bx, by);
+            out[v - 1] = sink.n > 0 ? sink.piece[0] : make_int4(0, 0, 0, 0);
+            for (int q = 1; q < sink.n; q++) {
+                if (extra < EXTRA_SLOTS) out[nv + extra++] = sink.piece[q];
+                else atomicExch(err_flag, 2);
+            }
+            ax = bx; ay = by;
         }
-        ax = bx; ay = by;
+    }
+    if (staged) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < run; j += blockDim.x) sides[base + j] = s_stage[j];
     }
 }
 
@@ -233,7 +256,15 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
     static_assert(NPX == 4 && BLK_H == 16, "the accumulator fold reads a lane's four cells as one 16-byte piece");
 
     const int img = blockIdx.y;
-    const int tile = blockIdx.x;
+    // XCD-aware tile order (round 5): workgroups go to the 8 XCDs round robin (workgroup b -> XCD b % 8), each XCD has its own L2, and a
+    // 128-byte line of the image is shared by two horizontally adjacent super-tiles (64 bytes each). In plain order the two halves were
+    // written through two different L2s -- every line left for HBM twice, half-filled (counters: 1.76 x the image bytes). Workgroups b and
+    // b + 8 run on the same XCD back to back: they take the tile pair (2k, 2k + 1), so the halves meet in one L2.
+    int tile = blockIdx.x;
+    {
+        const int g16 = tile & ~15;
+        if (g16 + 16 <= (int)gridDim.x) tile = g16 + 2 * (tile & 7) + ((tile >> 3) & 1);
+    }
     const int tx0 = (tile % tiles_x) * ST, ty0 = (tile / tiles_x) * ST_Y;
     const int tx1 = min(tx0 + ST, W) - 1, ty1 = min(ty0 + ST_Y, H) - 1;
     const long e_begin = edge_off[img], e_end = edge_off[img + 1];
@@ -480,19 +511,31 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 6), (unsigned long long)(_t - _tp)); }
     }
 
-    if (prow < H) {
-        unsigned char *o = out + ((size_t)img * H + prow) * (size_t)W + pcol;
-        if (NPX == 4 && pcol + 3 < W && ((((size_t)img * H + prow) * (size_t)W + pcol) & 3) == 0) {
-            unsigned v = 0;
+    // Store (round 5): a wave's block is 16 pixels wide, so its lanes' 4-byte pieces filled a 64-byte row segment of the super-tile from four
+    // different waves at four different times (counters: 1.75 x the image bytes written). The finished super-tile goes through LDS (the
+    // side slots are dead by now) and leaves as whole 64-byte row segments, 16 bytes per thread.
+    __syncthreads();
+    unsigned *s_tile = reinterpret_cast<unsigned *>(s_slots);              // [ST_Y rows][ST / 4 words]
+    {
+        unsigned v = 0;
 #pragma unroll
-            for (int q = 0; q < NPX; q++) v |= pix[q] << (8 * q);
-            *reinterpret_cast<unsigned *>(o) = v;
-        } else if (NPX == 2 && pcol + 1 < W && ((((size_t)img * H + prow) * (size_t)W + pcol) & 1) == 0) {
-            *reinterpret_cast<unsigned short *>(o) = (unsigned short)(pix[0] | (pix[NPX - 1] << 8));
-        } else {
-#pragma unroll
-            for (int q = 0; q < NPX; q++)
-                if (pcol + q < W) o[q] = (unsigned char)pix[q];
+        for (int q = 0; q < NPX; q++) v |= pix[q] << (8 * q);
+        s_tile[(prow - ty0) * (ST / 4) + (pcol - tx0) / 4] = v;
+    }
+    __syncthreads();
+    static_assert(NPX == 4, "the staged store packs a lane's four pixels into one word");
+    if (threadIdx.x < ST_Y * (ST / 16)) {
+        const int r = threadIdx.x / (ST / 16), c16 = threadIdx.x % (ST / 16);
+        const int y = ty0 + r, x = tx0 + 16 * c16;
+        if (y < H && x < W) {
+            const size_t o = ((size_t)img * H + y) * (size_t)W + x;
+            const uint4 v = *reinterpret_cast<const uint4 *>(s_tile + r * (ST / 4) + 4 * c16);
+            if (x + 15 < W && (o & 15) == 0) {
+                *reinterpret_cast<uint4 *>(out + o) = v;
+            } else {
+                const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+                for (int k = 0; k < 16 && x + k < W; k++) out[o + k] = (unsigned char)(wds[k >> 2] >> (8 * (k & 3)));
+            }
         }
     }
 }
@@ -601,6 +644,7 @@ fs_dither_kernel(const unsigned char *__restrict__ in, int W, int H, int band_ro
 constexpr int DP_PUB = 16;                    // steps between two publications of a band's progress
 constexpr int DP_LAG = 2 * 63 + DP_PUB + 2;   // steps the producer must be ahead of the start of a consumer chunk
 
+template <int DQ>          // words (4 pixels each) per store burst: 4, 8 or 16
 __global__ void __launch_bounds__(1024)
 fs_dither_pipe_kernel(const unsigned char *__restrict__ in, int W, int H, int n_bands, unsigned char *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -627,7 +671,9 @@ fs_dither_pipe_kernel(const unsigned char *__restrict__ in, int W, int H, int n_
         uint4 cur = my_row[0];
         uint4 nxt = nblk > 1 ? my_row[1] : make_uint4(0, 0, 0, 0);
         int l = 0, l0 = 0, l1 = 0, e_out = 0;
-        unsigned obuf = 0;
+        unsigned obuf = 0, ow[DQ];               // ow[0 .. DQ - 2]: the finished words of the current burst, oldest first (ow[DQ - 1] unused)
+#pragma unroll
+        for (int k = 0; k < DQ; k++) ow[k] = 0u;
         const int steps = (W + 1) + 2 * (rows - 1);
         const bool last_row = lane == rows - 1;
         int perr = 0;
@@ -655,8 +701,28 @@ fs_dither_pipe_kernel(const unsigned char *__restrict__ in, int W, int H, int n_
                 l1 = active ? e : l1;
                 l = active ? 7 * e : l;
                 obuf = active ? (obuf | ((unsigned)o << sh)) : obuf;
-                if (active && (x & 3) == 3) *reinterpret_cast<unsigned *>(my_out_row + (x - 3)) = obuf;
-                obuf = (x & 3) == 3 ? 0u : obuf;
+                // DQ words (16 / 32 / 64 pixels) per store burst (round 5; 4 pixels until then): the lanes of a wave write 64 different rows, so
+                // every store opens a line of its own in the L2, and with 4-byte pieces the lines were evicted half-written again and again
+                // (counters: 9 x the output bytes written, 5 x the input bytes fetched). The finished words wait in a shift queue of DQ - 1
+                // registers; every DQ words DQ / 4 16-byte stores go out back to back (W % 16 == 0 and 16-byte aligned rows are the kernel's
+                // precondition; the tail of a row whose width is no multiple of the burst goes out in 16-byte pieces).
+                if ((x & 3) == 3) {
+                    constexpr int PX = 4 * DQ;
+                    if (active && ((x & (PX - 1)) == PX - 1 || x == W - 1)) {
+                        const int nq = ((x & (PX - 1)) >> 4) + 1;             // 16-byte pieces queued (1 .. DQ / 4), the newest last
+                        uint4 *o16 = reinterpret_cast<uint4 *>(my_out_row + (x & ~(PX - 1)));
+                        // the queue is right-aligned: piece j of the burst (j = 0 oldest of a FULL burst) holds words 4j .. 4j + 3, the last word is obuf
+#pragma unroll
+                        for (int j = 0; j < DQ / 4; j++) {
+                            const int jj = j - (DQ / 4 - nq);                 // position of piece j in this (possibly short) burst
+                            if (jj >= 0) o16[jj] = make_uint4(ow[4 * j], ow[4 * j + 1], ow[4 * j + 2], j == DQ / 4 - 1 ? obuf : ow[4 * j + 3]);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < DQ - 2; k++) ow[k] = ow[k + 1];
+                    ow[DQ - 2] = obuf;
+                    obuf = 0u;
+                }
                 if (last_row && x >= 0 && x <= W) err_out[x] = my_out;
                 e_out = my_out;
                 perr = perr_next;
@@ -748,7 +814,7 @@ extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, co
         OCTA_HIP_CHECK(hipStreamSynchronize(stream));
         if (total_sides > 0x7fffffffL) { octa::set_error("octa_rasterize_2d: %ld polygon sides exceed the 32-bit offset range", total_sides); return -2; }
         if (ctx->r_sides.reserve(sizeof(int4) * (size_t)(total_sides + 1))) return -1;
-        hipLaunchKernelGGL(raster_tess_kernel, g, dim3(256), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(), ctx->r_tile_count.as<int>(),
+        hipLaunchKernelGGL(raster_tess_kernel, dim3((unsigned)((n_total + TESS_WG - 1) / TESS_WG)), dim3(TESS_WG), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(), ctx->r_tile_count.as<int>(),
                            ctx->r_seg_total.as<int>(), n_total, W, H, ctx->r_sides.as<int4>(), ctx->r_counters.as<int>());
     } else {
         if (ctx->r_sides.reserve(sizeof(int4))) return -1;
@@ -772,11 +838,15 @@ extern "C" int octa_fs_dither(octa_ctx *ctx, int B, const uint8_t *d_in, int W, 
         static const bool pipe_on = [] { const char *e = getenv("OCTA_DITHER_PIPE"); return !(e && e[0] == '0'); }();
         const int n_bands = (H + 63) / 64;
         const size_t lds_pipe = ((size_t)((n_bands + 3) & ~3) + (size_t)n_bands * (W + 2)) * sizeof(int);
-        if (pipe_on && W % 16 == 0 && (reinterpret_cast<size_t>(d_in) & 15) == 0 && (reinterpret_cast<size_t>(d_out) & 3) == 0 && n_bands >= 2 &&
+        if (pipe_on && W % 16 == 0 && (reinterpret_cast<size_t>(d_in) & 15) == 0 && (reinterpret_cast<size_t>(d_out) & 15) == 0 && n_bands >= 2 &&
             lds_pipe <= 150 * 1024) {
             const int nw = n_bands < 16 ? n_bands : 16;
-            OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fs_dither_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe));
-            hipLaunchKernelGGL(fs_dither_pipe_kernel, dim3((unsigned)B), dim3(64 * nw), lds_pipe, stream, d_in, W, H, n_bands, d_out);
+            // OCTA_DITHER_BURST = 16 | 32 | 64 pixels per store burst (development aid). Measured per 128 labels at 1216^2 (profiles/r05_raster_pmc.log):
+            // 16: 488 MB written, 1.94 ms; 32: 306 MB, 1.98 ms; 64: 227 MB, 2.14 ms (the shift queue); 4 (round 4): 613 MB. Default 32.
+            static const int burst = [] { const char *e = getenv("OCTA_DITHER_BURST"); const int v = e ? atoi(e) : 32; return v == 64 || v == 16 ? v : 32; }();
+            auto kern = burst == 64 ? fs_dither_pipe_kernel<16> : (burst == 32 ? fs_dither_pipe_kernel<8> : fs_dither_pipe_kernel<4>);
+            OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe));
+            hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64 * nw), lds_pipe, stream, d_in, W, H, n_bands, d_out);
             OCTA_HIP_CHECK(hipGetLastError());
             return 0;
         }
