@@ -219,6 +219,14 @@ int octa_conv3x3_nhwc_fwd6(octa_ctx *ctx, const void *d_x, const void *d_x2, int
                            int N, int H, int W, int Cin, int Cout, int stride, int in_dilation, int tap_mask, int out_scale,
                            int out_off_y, int out_off_x, const float *d_scale1, const float *d_shift1, const float *d_scale2,
                            const float *d_shift2, float slope, float *d_stat_partials, const void *d_residual, void *stream);
+/* The two layers of the U-Net whose output is twice the size of their input, with the four output parities fused (round 5): the data
+ * gradient of a stride-2 3x3 convolution (MONAI UnetBasicBlock with stride 2) and the 2x2 stride-2 transposed convolution (UnetUpBlock.transp_conv;
+ * both imported at models/networks.py:6). d_x [N][H][W][Cin] bf16 is the SMALL image, d_w [9][Cout][Cin] bf16 the pack the zero-insertion form
+ * reads (octa_conv3x3_nhwc_fwd2 with in_dilation = 2 computes the same sums, three quarters of them against inserted zeros), d_y
+ * [N][2H][2W][Cout] bf16. tap_mask: 0x1ff (data gradient of a stride-2 layer) or 0b000011011 (the transposed convolution: one tap per parity).
+ * d_residual (shape of d_y, NULL = none) is added as octa_conv3x3_nhwc_fwd6 adds it. Cin, Cout multiples of 32. */
+int octa_conv3x3_s2t_nhwc(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int tap_mask,
+                          const void *d_residual, void *stream);
 /* InstanceNorm(affine) + LeakyReLU + 1x1 convolution to ONE channel with bias, fused: the last norm of DynUNet's decoder followed
  * by UnetOutBlock (MONAI, imported at models/networks.py:6; 32 -> 1 channels at 1216^2). d_x [B][hw][C] bf16 (the raw output of the last
  * 3x3 convolution), d_w / d_b the norm's affine parameters (NULL = none), d_head_w float32[C], d_head_b float32[1] or NULL ->

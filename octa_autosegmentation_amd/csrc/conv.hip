@@ -648,6 +648,164 @@ int launch_conv(const unsigned short *X, const unsigned short *X2, int C1, const
                                                   nullptr, nullptr, 0.f, nullptr, stream);
 }
 
+// ---- stride-2 "up" convolution with the four output parities fused (round 5) ------------------------------------------------------
+// Two layers of the U-Net produce an image TWICE the size of their input: the data gradient of a stride-2 3x3 convolution and the 2x2
+// stride-2 transposed convolution (= the data gradient of a stride-2 layer whose taps r, s = 0 are zero; MONAI UnetBasicBlock stride 2 /
+// UnetUpBlock.transp_conv, imported at models/networks.py:6). Rounds 1-4 ran them through the stride-1 kernel on a VIRTUALLY zero-inserted
+// input (dil = 2): three of four multiply-adds hit an inserted zero. Here a workgroup takes an 8 x 32 tile of the SMALL image and produces
+// the 16 x 64 output pixels above it: out[2h + a][2w + b] = sum over the taps of parity class (a, b) of in[h + oy][w + ox] . Wt[3 kr + ks]
+// with, per axis, tap k = 1 -> class 0, offset 0; k = 0 -> class 1, offset 0; k = 2 -> class 1, offset +1 (Wt = the SAME flipped,
+// transposed pack the zero-insertion form reads: mfma_conv.pack_weight_dgrad / pack_convt2x2()[1]). One accumulator set per class (4 x RPW x NB
+// fragments), 9 MFMA groups per 16-channel slice for four times the output pixels: a quarter of the matrix work, the input read once,
+// the output leaving as whole rows through LDS. DMA staging, swizzle and operand layout as conv3x3_nhwc_glds_kernel (KCV = 16).
+template <int BN>
+__global__ void __launch_bounds__(CONV_THREADS, 2)
+conv3x3_s2t_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ Wt, unsigned short *__restrict__ Y, int H, int W, int Cin,
+                   int Cout, int tiles_x, const unsigned short *__restrict__ zero16, int tap_mask, const unsigned short *__restrict__ R) {
+    constexpr int KCV = 16, PP = 2, NB = BN / 32, RPW = 2;
+    constexpr int IH = TH + 1, IW = TW + 1, LPIX = IH * IW;
+    constexpr int IN_INSTR = (LPIX * PP + 63) / 64, W_INSTR = 9 * BN * PP / 64;
+    constexpr int IN_BYTES = IN_INSTR * 1024, BUF = IN_BYTES + W_INSTR * 1024;
+    constexpr int IN_PW = (IN_INSTR + 3) / 4, W_PW = (W_INSTR + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tile = blockIdx.x, n = blockIdx.z, co0 = blockIdx.y * BN;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;            // small-image coordinates
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, kg = lane >> 5;
+    int in_src[IN_PW], w_src[W_PW];
+#pragma unroll
+    for (int i = 0; i < IN_PW; i++) {
+        const int slot = (wv + 4 * i) * 64 + lane, p = slot / PP, q = (slot % PP) ^ glds_swz<PP>(p);
+        const int yy = ty0 + p / IW, xx = tx0 + p % IW;
+        const bool ok = p < LPIX && yy < H && xx < W;
+        in_src[i] = ok ? ((yy * W + xx) << 2) | q : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < W_PW; i++) {
+        const int slot = (wv + 4 * i) * 64 + lane, rw = slot / PP, q = (slot % PP) ^ glds_swz<PP>(rw);
+        w_src[i] = ((rw / BN) * Cout + co0 + rw % BN) * Cin + q * 8;
+    }
+    const unsigned short *img = X + (size_t)n * H * W * Cin;
+    auto issue = [&](int c0, unsigned char *buf) {
+#pragma unroll
+        for (int i = 0; i < IN_PW; i++) {
+            const int j = wv + 4 * i;
+            if (j < IN_INSTR) {
+                const unsigned short *src = in_src[i] < 0 ? zero16 : img + (size_t)(in_src[i] >> 2) * Cin + c0 + (in_src[i] & 3) * 8;
+                glds16(src, buf + j * 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W_PW; i++) {
+            const int j = wv + 4 * i;
+            if (j < W_INSTR && ((tap_mask >> (j * (64 / PP) / BN)) & 1)) glds16(Wt + w_src[i] + c0, buf + IN_BYTES + j * 1024);
+        }
+    };
+    f32x16 acc[4][RPW][NB];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int a = 0; a < RPW; a++)
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[c][a][b][k] = 0.f;
+    const int nsl = Cin / KCV;
+    issue(0, smem);
+    for (int k = 0; k < nsl; k++) {
+        __syncthreads();
+        if (k + 1 < nsl) issue((k + 1) * KCV, smem + ((k + 1) & 1) * BUF);
+        const unsigned char *s_in = smem + (k & 1) * BUF, *s_w = s_in + IN_BYTES;
+        // the six operand fragments of this wave's two small rows: halo rows 2 wv .. 2 wv + 2, column shifts 0 / 1
+        bf16x8 a[3][2];
+#pragma unroll
+        for (int hr = 0; hr < 3; hr++)
+#pragma unroll
+            for (int ox = 0; ox < 2; ox++) {
+                const int p = (RPW * wv + hr) * IW + m + ox;
+                a[hr][ox] = *reinterpret_cast<const bf16x8 *>(s_in + (p * PP + (kg ^ glds_swz<PP>(p))) * 16);
+            }
+#pragma unroll
+        for (int kr = 0; kr < 3; kr++)
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+                if (!((tap_mask >> (3 * kr + ks)) & 1)) continue;          // wave-uniform: the transposed convolution has one tap per class
+                const int cls = (kr != 1 ? 2 : 0) + (ks != 1 ? 1 : 0), oy = kr == 2 ? 1 : 0, ox = ks == 2 ? 1 : 0;
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    const int rw = (3 * kr + ks) * BN + nb * 32 + m;
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(s_w + (rw * PP + (kg ^ glds_swz<PP>(rw))) * 16);
+#pragma unroll
+                    for (int rr = 0; rr < RPW; rr++)
+                        acc[cls][rr][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr + oy][ox], b, acc[cls][rr][nb], 0, 0, 0);
+                }
+            }
+    }
+    // epilogue: the 16 x 64 output pixels in two passes of 8 output rows (waves 2 p, 2 p + 1 hold them) through LDS, whole rows out
+    const int Ho = 2 * H, Wo = 2 * W;
+    constexpr int OP = BN * 2 + 16;
+    unsigned char *s_out = smem;
+    constexpr int PIECES = BN / 8;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        __syncthreads();
+        if ((wv >> 1) == pass) {
+#pragma unroll
+            for (int cls = 0; cls < 4; cls++)
+#pragma unroll
+                for (int rr = 0; rr < RPW; rr++) {
+                    const int orow = 2 * (RPW * (wv & 1) + rr) + (cls >> 1);           // 0 .. 7 inside the pass
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int k = 0; k < 16; k += 2) {
+                            const int px = (k & 3) + 8 * (k >> 2) + 4 * kg;              // small-image column; k + 1 is px + 1
+                            const unsigned pk = octa_pack_bf16x2(acc[cls][rr][nb][k], acc[cls][rr][nb][k + 1]);
+                            unsigned char *d = s_out + (orow * (2 * TW) + 2 * px + (cls & 1)) * OP + (nb * 32 + m) * 2;
+                            *reinterpret_cast<unsigned short *>(d) = (unsigned short)(pk & 0xffffu);
+                            *reinterpret_cast<unsigned short *>(d + 2 * OP) = (unsigned short)(pk >> 16);
+                        }
+                }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * (2 * TW) * PIECES; i += CONV_THREADS) {
+            const int p = i / PIECES, q = i % PIECES;
+            const int oy = 2 * ty0 + 8 * pass + p / (2 * TW), ox = 2 * tx0 + p % (2 * TW);
+            if (oy < Ho && ox < Wo) {
+                const size_t off = (((size_t)n * Ho + oy) * Wo + ox) * Cout + co0 + q * 8;
+                uint4 v = *reinterpret_cast<const uint4 *>(s_out + p * OP + q * 16);
+                if (R) {        // the other gradient of a skip tensor, added as octa_conv3x3_nhwc_fwd6 adds it (fp32 add of the rounded values, rounded again)
+                    const uint4 r = *reinterpret_cast<const uint4 *>(R + off);
+                    unsigned av[4] = {v.x, v.y, v.z, v.w};
+                    const unsigned bv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        av[k] = octa_pack_bf16x2(__uint_as_float(av[k] << 16) + __uint_as_float(bv[k] << 16),
+                                                 __uint_as_float(av[k] & 0xffff0000u) + __uint_as_float(bv[k] & 0xffff0000u));
+                    v = make_uint4(av[0], av[1], av[2], av[3]);
+                }
+                *reinterpret_cast<uint4 *>(Y + off) = v;
+            }
+        }
+    }
+}
+
+template <int BN>
+int launch_conv_s2t(const unsigned short *X, const unsigned short *Wt, unsigned short *Y, int N, int H, int W, int Cin, int Cout, const unsigned short *zero16,
+                    int tap_mask, const unsigned short *R, hipStream_t stream) {
+    constexpr int PP = 2;
+    constexpr int BUF = (((TH + 1) * (TW + 1) * PP + 63) / 64 + 9 * BN * PP / 64) * 1024;
+    constexpr int OUT = 8 * (2 * TW) * (BN * 2 + 16);
+    const size_t lds = 2 * BUF > OUT ? 2 * BUF : OUT;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    auto kern = conv3x3_s2t_kernel<BN>;
+    OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(Cout / BN), (unsigned)N);
+    hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, stream, X, Wt, Y, H, W, Cin, Cout, tiles_x, zero16, tap_mask, R);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int octa_conv_stat_tiles(int Ho, int Wo) { return ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH); }
@@ -774,6 +932,28 @@ extern "C" int octa_conv3x3_nhwc_fwd2(octa_ctx *ctx, const void *d_x, const void
 extern "C" int octa_conv3x3_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin,
                                      int Cout, int stride, int in_dilation, void *stream_) {
     return octa_conv3x3_nhwc_fwd2(ctx, d_x, nullptr, Cin, d_w, d_y, nullptr, Cout, N, H, W, Cin, Cout, stride, in_dilation, 0x1ff, stream_);
+}
+
+// d_x [N][H][W][Cin] bf16 (the SMALL image), d_w [9][Cout][Cin] bf16 packed as for the zero-insertion form (octa_conv3x3_nhwc_fwd2 with
+// in_dilation = 2 gives the same result: tests/test_conv_gpu.py), d_y [N][2H][2W][Cout] bf16; tap_mask as there (0x1ff: data gradient of a
+// stride-2 3x3 layer; 0b000011011: the 2x2 stride-2 transposed convolution); d_residual (shape of d_y, may be NULL) is added as in _fwd6.
+extern "C" int octa_conv3x3_s2t_nhwc(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int tap_mask,
+                                     const void *d_residual, void *stream_) {
+    if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv3x3_s2t_nhwc: null pointer"); return -2; }
+    if (N <= 0 || N > 65535 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_s2t_nhwc: bad shape"); return -2; }
+    if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_s2t_nhwc: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
+    tap_mask &= 0x1ff;
+    if (tap_mask == 0 || d_residual == d_y) { octa::set_error("octa_conv3x3_s2t_nhwc: empty tap mask or residual aliasing the output"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const unsigned short *z = zero_page(ctx);
+    if (!z) return -1;
+    const unsigned short *X = static_cast<const unsigned short *>(d_x), *Wt = static_cast<const unsigned short *>(d_w), *R = static_cast<const unsigned short *>(d_residual);
+    unsigned short *Y = static_cast<unsigned short *>(d_y);
+    // 32 output channels per workgroup everywhere: 128 accumulator registers, two workgroups per CU. The 64-channel form (256 accumulator
+    // registers in AGPRs, one workgroup of four waves per CU) measured slower on every layer (data gradients 159 / 238 / 260 us against
+    // 123 / 169 / 262, transposed convolutions 90 / 118 / 128 against 74 / 96 / 129; zero-insertion form: 180 / 212 / 296 and 112 / 131 / 245).
+    return launch_conv_s2t<32>(X, Wt, Y, N, H, W, Cin, Cout, z, tap_mask, R, stream);
 }
 
 extern "C" int octa_conv4x4_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int pad,

@@ -242,6 +242,26 @@ def conv3x3_nhwc(x, wt, stride=1, in_dilation=1, tap_mask=0x1ff, residual=None):
     return y
 
 
+# The parity-fused kernel for the two layers that double the image (round 5, csrc/conv.hip conv3x3_s2t_kernel). OCTA_S2T=0 keeps the
+# zero-insertion form of rounds 1-4 (the stride-1 kernel on a virtually dilated input: 4 x the multiply-adds).
+USE_S2T = os.environ.get("OCTA_S2T", "1") != "0"
+
+
+def conv3x3_s2t_nhwc(x, wt, tap_mask=0x1ff, residual=None):
+    """x [N,H,W,Cin] bf16 (the small image), wt [9,Cout,Cin] bf16 as conv3x3_nhwc(..., in_dilation=2) takes it -> [N,2H,2W,Cout] bf16."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and wt.dtype == torch.bfloat16 and wt.is_contiguous() and wt.shape[2] == x.shape[3]
+    n, h, w, cin = x.shape
+    cout = wt.shape[1]
+    y = torch.empty((n, 2 * h, 2 * w, cout), dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        assert residual.shape == y.shape and residual.dtype == torch.bfloat16 and residual.is_contiguous()
+    rc = _native.lib().octa_conv3x3_s2t_nhwc(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wt.data_ptr()),
+                                             ctypes.c_void_p(y.data_ptr()), n, h, w, cin, cout, int(tap_mask),
+                                             ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, _native.current_stream_ptr())
+    _native.check(rc, "octa_conv3x3_s2t_nhwc")
+    return y
+
+
 def conv3x3_nhwc_wgrad(x, dy, tap_mask=0x1ff):
     """x [N,H,W,Cin] bf16, dy [N,H,W,Cout] bf16 (stride-1 layer) -> dW as a torch conv weight gradient
     [Cout, Cin, 3, 3] float32 (taps cleared in tap_mask come back as zero)."""
@@ -450,7 +470,10 @@ class _Conv3x3NHWC(torch.autograd.Function):
                 res = None
                 if ctx.mailbox is not None:
                     res, ctx.mailbox.pending = ctx.mailbox.pending, None       # the decoder's gradient of the same tensor, if posted
-                dx = conv3x3_nhwc(dy, pack_weight_dgrad(weight, xp.shape[-1]), stride=1, in_dilation=st, residual=res)
+                if st == 2 and USE_S2T:
+                    dx = conv3x3_s2t_nhwc(dy, pack_weight_dgrad(weight, xp.shape[-1]), 0x1ff, res)
+                else:
+                    dx = conv3x3_nhwc(dy, pack_weight_dgrad(weight, xp.shape[-1]), stride=1, in_dilation=st, residual=res)
             if xp.shape[-1] != cin:
                 dx = dx[..., :cin].contiguous()
         elif ctx.mailbox is not None and ctx.mailbox.pending is not None:
@@ -711,7 +734,10 @@ class _ConvT2x2NHWC(torch.autograd.Function):
             y = conv_transpose_2x2_fwd(x, weight)
         else:
             # the 3x3 form wc has taps r, s in {1, 2}; flipped for the data-gradient form they sit at r, s in {0, 1}
-            y = conv3x3_nhwc(x, pack_convt2x2(weight)[1], stride=1, in_dilation=2, tap_mask=0b000011011)
+            if USE_S2T:
+                y = conv3x3_s2t_nhwc(x, pack_convt2x2(weight)[1], 0b000011011)
+            else:
+                y = conv3x3_nhwc(x, pack_convt2x2(weight)[1], stride=1, in_dilation=2, tap_mask=0b000011011)
         ctx.save_for_backward(x, weight)
         return y
 

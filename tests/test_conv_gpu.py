@@ -321,6 +321,50 @@ def test_dynunet_mfma_path_matches_torch_reference(hip_lib_built):
         assert abs(a.norm().item() / b.norm().item() - 1.0) < dev_ac + 0.3, (k, a.norm().item(), c.norm().item(), b.norm().item())
 
 
+def test_parity_fused_up_convolution_equals_the_zero_insertion_form(hip_lib_built):
+    """octa_conv3x3_s2t_nhwc (round 5: the data gradient of a stride-2 layer and the 2x2 transposed convolution with the four output
+    parities fused) against the zero-insertion form of rounds 1-4 on the same packed weights -- the same sums in another order (fp32
+    accumulation, one bf16 rounding) -- and, through the autograd bindings, against torch fp32. Odd small sizes, both channel widths,
+    the residual, the one-tap-per-class mask of the transposed convolution."""
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.models import mfma_conv as mc
+    g = torch.Generator(device="cuda").manual_seed(77)
+    for (n, h, w, cin, cout, mask) in ((2, 19, 37, 64, 32, 0x1ff), (1, 8, 32, 32, 64, 0x1ff), (2, 33, 70, 128, 64, 0x1ff), (1, 76, 76, 256, 128, 0b000011011),
+                                       (2, 5, 3, 64, 32, 0b000011011), (1, 152, 152, 64, 32, 0x1ff)):
+        x = torch.randn(n, h, w, cin, device="cuda", generator=g).to(torch.bfloat16)
+        wt = (torch.randn(9, cout, cin, device="cuda", generator=g) / (3.0 * cin ** 0.5)).to(torch.bfloat16)
+        if mask != 0x1ff:
+            keep = torch.tensor([(mask >> t) & 1 for t in range(9)], device="cuda", dtype=torch.bfloat16)
+            wt = wt * keep[:, None, None]
+        res = torch.randn(n, 2 * h, 2 * w, cout, device="cuda", generator=g).to(torch.bfloat16)
+        for r in (None, res):
+            a = mc.conv3x3_s2t_nhwc(x, wt, mask, r)
+            if r is None:
+                b = mc.conv3x3_nhwc(x, wt, stride=1, in_dilation=2, tap_mask=mask)
+            else:
+                b = mc.conv3x3_nhwc(x, wt, stride=1, in_dilation=2, tap_mask=0x1ff, residual=r)      # the residual epilogue lives in the unmasked kernel (masked taps are zero)
+            assert a.shape == b.shape == (n, 2 * h, 2 * w, cout)
+            scale = b.float().abs().max().item()
+            assert (a.float() - b.float()).abs().max().item() <= 2.0 ** -7 * scale, (n, h, w, cin, cout, mask)
+            assert (a != b).float().mean().item() < 0.02           # summation order only: a few values round the other way
+    # through autograd: stride-2 layer and transposed convolution against torch fp32 on the same bf16-rounded operands
+    x = torch.randn(2, 40, 64, 32, device="cuda", generator=g).to(torch.bfloat16)
+    w2 = (torch.randn(64, 32, 3, 3, device="cuda", generator=g) / 17.0).to(torch.bfloat16).float()
+    xm, wm = x.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    ym = mc.conv3x3(xm, wm, 2)
+    dy = torch.randn(ym.shape, device="cuda", generator=g).to(torch.bfloat16)
+    ym.backward(dy)
+    xr, wr = x.float().permute(0, 3, 1, 2).requires_grad_(True), w2.clone().requires_grad_(True)
+    F.conv2d(xr, wr, stride=2, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    assert (xm.grad.float() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() <= 2.0 ** -8 * xr.grad.abs().max().item() + 1e-6
+    wt2 = (torch.randn(64, 32, 2, 2, device="cuda", generator=g) / 11.0).to(torch.bfloat16).float()
+    xm, wm = torch.randn(2, 21, 30, 64, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True), wt2.clone().requires_grad_(True)
+    ym = mc.conv_transpose_kxk_nhwc(xm, wm, 2)
+    yr = F.conv_transpose2d(xm.detach().float().permute(0, 3, 1, 2), wt2, stride=2)
+    assert (ym.float() - yr.permute(0, 2, 3, 1)).abs().max().item() <= 2.0 ** -8 * yr.abs().max().item() + 1e-6
+
+
 def test_epilogue_statistics_feed_the_norm(hip_lib_built):
     """InstanceNorm statistics accumulated in the convolution's epilogue give the same normalised tensor as the
     statistics pass over the stored result (same bf16 values, fp32 / double sums in a different order)."""
