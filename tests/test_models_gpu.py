@@ -351,3 +351,66 @@ def test_grad_arena_and_rccl_on_device_equal_the_plain_step(one_rank_rccl):
             assert a.flat.is_cuda and a.flat.numel() == 7_368_769 and float(a.flat.abs().sum()) > 0
         traj[use] = np.array(vals)
     assert np.allclose(traj[False], traj[True], rtol=2e-2), traj          # six optimiser steps: same run-to-run spread
+
+
+# ---- round 5: which path ran, and the opt-in side stream ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("cfg_file", ["config_ves_seg-S.yml", "config_ves_seg-S_GAN.yml", "config_gan_ves_seg.yml"])
+def test_reference_configs_never_leave_the_hand_written_kernels(cfg_file):
+    """The model sections of the three shipped training configs (reference configs/config_ves_seg-S.yml:6-13, -S_GAN.yml, config_gan_ves_seg.yml)
+    with `amp: true` as shipped: two training steps and an evaluation pass count ZERO vendor fallbacks and at least one pass on the MFMA /
+    exact-fp32 kernels (OCTA_STRICT=1 in tests/conftest.py would also have raised)."""
+    import os
+    import yaml
+    from octa_autosegmentation_amd.models import networks
+    from octa_autosegmentation_amd.models.gan_seg_trainer import GanSegTrainer
+    from octa_autosegmentation_amd.models.segmentation_trainer import SegmentationTrainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", cfg_file)))
+    assert cfg["General"]["amp"] is True
+    small = {"General": {"amp": True, "model": cfg["General"]["model"]}, "Train": {k: v for k, v in cfg["Train"].items() if k in ("lr", "loss", "loss_dg", "loss_s", "epochs", "epochs_decay")}}
+    before = dict(networks.PATH_COUNTS)
+    torch.manual_seed(0)
+    if cfg["General"]["model"]["name"] == "GanSegModel":
+        small["General"]["model"] = {**cfg["General"]["model"], "upshape": (256, 256)}
+        tr = GanSegTrainer(small, "cuda", upshape=(256, 256))
+        batch = {"real_A": torch.rand(2, 1, 64, 64, device="cuda"), "real_B": torch.rand(2, 1, 64, 64, device="cuda"),
+                 "real_A_seg": (torch.rand(2, 1, 256, 256, device="cuda") > 0.7).float()}
+        for _ in range(2):
+            tr.perform_training_step(batch)
+        with torch.no_grad():
+            tr.impl.eval()
+            tr.impl(torch.rand(1, 1, 64, 64, device="cuda"))                    # fp32 inference of the segmentor: csrc/conv_f32.hip
+    else:
+        tr = SegmentationTrainer(small, "cuda")
+        x, y = torch.rand(2, 1, 256, 256, device="cuda"), (torch.rand(2, 1, 256, 256, device="cuda") > 0.7).float()
+        for _ in range(2):
+            tr.perform_training_step({"image": x, "label": y})
+        with torch.no_grad():
+            tr.impl.eval()
+            tr.impl(x[:1])
+    torch.cuda.synchronize()
+    after = networks.PATH_COUNTS
+    assert after["vendor"] == before.get("vendor", 0), "a pass of a shipped config fell back to the torch modules"
+    assert after["mfma"] > before.get("mfma", 0) and after["f32_mfma"] > before.get("f32_mfma", 0)
+
+
+def test_weight_gradients_on_the_side_stream_give_the_same_step(monkeypatch):
+    """OCTA_WGRAD_STREAM=1 (opt-in, measured slower: models/mfma_conv.py): weight gradients computed and accumulated on a side stream,
+    joined before the optimiser step -- same kernels, same sums: parameters after two steps are bit-identical to the serial step's."""
+    from octa_autosegmentation_amd.models import mfma_conv
+    from octa_autosegmentation_amd.models.segmentation_trainer import SegmentationTrainer
+    cfg = {"General": {"amp": True, "model": {"name": "DynUNet", "spatial_dims": 2, "in_channels": 1, "out_channels": 1, "kernel_size": [3, 3, 3, 3, 3],
+                                               "strides": [1, 2, 2, 2, 1], "upsample_kernel_size": [1, 2, 2, 2, 1]}},
+           "Train": {"lr": 1e-3, "loss": "DiceBCELoss", "epochs": 10, "epochs_decay": 0}}
+    x, y = torch.rand(2, 1, 128, 160, device="cuda"), (torch.rand(2, 1, 128, 160, device="cuda") > 0.7).float()
+    outs = []
+    for side in (False, True):
+        monkeypatch.setattr(mfma_conv, "USE_WGRAD_STREAM", side)
+        torch.manual_seed(5)
+        tr = SegmentationTrainer(cfg, "cuda")
+        for _ in range(2):
+            tr.perform_training_step({"image": x, "label": y})
+        torch.cuda.synchronize()
+        outs.append([p.detach().clone() for p in tr.model.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))

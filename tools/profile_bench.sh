@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r03}
 OUT=gpurun_out
 mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py --no-cpu-baseline --no-pmc > $OUT/${TAG}_bench_stdout.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py --no-cpu-baseline --no-pmc --no-long > $OUT/${TAG}_bench_stdout.log 2>&1
 find $OUT/prof_kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
 # the stats file averages launches of every size (512-sample launches of the headline leg, 128 / 256-sample launches of the solo, files and
 # on-the-fly legs): the per-size averages of the persistent kernel, from the raw trace, are what bench.py's roofline.avg_launch_ms (HIP
@@ -40,7 +40,7 @@ PY
 rm -rf $OUT/prof_kt   # the raw trace is large; only the summaries are kept
 grep '"metric"' $OUT/${TAG}_bench_stdout.log | tail -1 > $OUT/${TAG}_bench_line_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-train --no-files --no-pmc > $OUT/${TAG}_pmc_$C.log 2>&1
+  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_$C -- python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-train --no-files --no-pmc --no-long > $OUT/${TAG}_pmc_$C.log 2>&1
 done
 python - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, collections

@@ -6,7 +6,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r01}
 OUT=gpurun_out
-CMD="python tools/time_train.py 4 1216 nchw"
+CMD="python tools/time_train.py 4 1216"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ptrain_kt -- $CMD > $OUT/${TAG}_train_kt.log 2>&1
 find $OUT/ptrain_kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_train_mfma_kernel_stats.csv
 COUNTERS=${COUNTERS:-"SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU FETCH_SIZE WRITE_SIZE"}
