@@ -395,22 +395,32 @@ def test_reference_configs_never_leave_the_hand_written_kernels(cfg_file):
     assert after["mfma"] > before.get("mfma", 0) and after["f32_mfma"] > before.get("f32_mfma", 0)
 
 
-def test_weight_gradients_on_the_side_stream_give_the_same_step(monkeypatch):
+def test_weight_gradients_on_the_side_stream_give_the_same_gradients(monkeypatch):
     """OCTA_WGRAD_STREAM=1 (opt-in, measured slower: models/mfma_conv.py): weight gradients computed and accumulated on a side stream,
-    joined before the optimiser step -- same kernels, same sums: parameters after two steps are bit-identical to the serial step's."""
+    joined when the backward scope ends -- same kernels, same operands: every parameter gradient equals the serial pass's up to the
+    order of the weight-gradient kernels' fp32 atomics (1e-4 of the tensor's scale), and a second backward accumulates in place."""
     from octa_autosegmentation_amd.models import mfma_conv
-    from octa_autosegmentation_amd.models.segmentation_trainer import SegmentationTrainer
+    from octa_autosegmentation_amd.models.segmentation_trainer import IDENTITY_POST, SegmentationTrainer
+    from octa_autosegmentation_amd.utils.enums import Phase
     cfg = {"General": {"amp": True, "model": {"name": "DynUNet", "spatial_dims": 2, "in_channels": 1, "out_channels": 1, "kernel_size": [3, 3, 3, 3, 3],
                                                "strides": [1, 2, 2, 2, 1], "upsample_kernel_size": [1, 2, 2, 2, 1]}},
            "Train": {"lr": 1e-3, "loss": "DiceBCELoss", "epochs": 10, "epochs_decay": 0}}
     x, y = torch.rand(2, 1, 128, 160, device="cuda"), (torch.rand(2, 1, 128, 160, device="cuda") > 0.7).float()
-    outs = []
-    for side in (False, True):
+    torch.manual_seed(5)
+    tr = SegmentationTrainer(cfg, "cuda")
+    grads = []
+    for side in (False, True, True):
         monkeypatch.setattr(mfma_conv, "USE_WGRAD_STREAM", side)
-        torch.manual_seed(5)
-        tr = SegmentationTrainer(cfg, "cuda")
-        for _ in range(2):
-            tr.perform_training_step({"image": x, "label": y})
+        if len(grads) < 2:
+            tr.impl.zero_grads("optimizer")
+        with tr.impl.autocast():
+            _, losses = tr.impl.inference({"image": x, "label": y}, IDENTITY_POST, torch.device("cuda"), phase=Phase.TRAIN)
+            loss = sum(losses.values())
+        with tr.impl.backward_scope():
+            loss.backward()
         torch.cuda.synchronize()
-        outs.append([p.detach().clone() for p in tr.model.parameters()])
-    assert all(torch.equal(a, b) for a, b in zip(*outs))
+        grads.append({k: p.grad.detach().clone() for k, p in tr.model.named_parameters()})
+    for k, g0 in grads[0].items():
+        scale = g0.abs().max().item() + 1e-12
+        assert (grads[1][k] - g0).abs().max().item() <= 1e-4 * scale, k                 # side stream == serial
+        assert (grads[2][k] - 2 * g0).abs().max().item() <= 2e-4 * scale, k             # the third backward accumulated onto the second

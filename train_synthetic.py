@@ -194,7 +194,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--gen-batch", type=int, default=256)
+    ap.add_argument("--gen-batch", type=int, default=512, help="samples per generator launch: 512 fills every workgroup slot of an MI355X (two per CU), where the persistent kernel is cheapest per sample")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gan", action="store_true", help="feed the GAN-seg trainer (configs[4]) instead of the segmentation trainer")
     a = ap.parse_args()
