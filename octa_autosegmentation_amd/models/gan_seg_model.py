@@ -109,7 +109,9 @@ class GanSegModel(BaseModelABC):
         # ---- discriminator update, then D(fake_B) with the updated, frozen discriminator: a chain of ~250 short dependent launches
         # (4x4 convolutions at 304^2 and below) that nothing of the segmentor's passes depends on. With two streams it runs BESIDE
         # the segmentor's pseudo-label pass and its forward pass over (idt_B | fake_B) -- MFMA-heavy launches that leave the gaps
-        # between D's launches unused otherwise (round 4: 733 dependent launches, 41 ms of kernels in a 56 ms step).
+        # between D's launches unused otherwise. Measured: 55.3 -> 54.0 ms (profiles/r05_stream_overlap_ab.log). Starting the pseudo-label
+        # pass on the side stream beside the GENERATOR's forward as well was measured too and bought nothing more (54.9 against 56.1 with one
+        # stream on a slower box: the same 1.2 ms) -- the segmentor's launches fill the GPU whoever runs next to them.
         def d_chain():
             self.zero_grads("optimizer_D")
             with self.autocast():

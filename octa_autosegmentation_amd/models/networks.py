@@ -36,7 +36,7 @@ USE_LAZY_NORM = __import__('os').environ.get('OCTA_LAZY_NORM', '0') == '1'      
 # the barrier the tile needs anyway, one pair of double atomics per channel and tile into 16 slots; the apply pass adds the slots): same box,
 # B = 4 at 1216^2: 18.7 -> 18.5 ms per step (profiles/r05_unet_epilogue_stats_ab.log). Default ON; OCTA_EPI_STATS=0 runs the statistics pass.
 import os as _os
-USE_EPILOGUE_STATS = _os.environ.get('OCTA_EPI_STATS', '1') != '0'
+USE_EPILOGUE_STATS = _os.environ.get('OCTA_EPI_STATS', '1') != '0' and _os.environ.get('OCTA_CONV_GLDS', '16') != '0'      # the slots live in the DMA-staged kernel's epilogue
 
 # ---- which kernels ran ------------------------------------------------------------------------------------------------
 # The product path of a CUDA forward is the hand-written HIP kernels (csrc/conv.hip, conv_f32.hip, norm.hip, thin_conv.hip,
