@@ -40,7 +40,10 @@ constexpr int ST = 64;          // super-tile width (pixels): 4 blocks
 constexpr int ST_Y = 4 * BLK_H; // super-tile height: 4 blocks (16 waves)
 constexpr int WG = 1024;        // threads per render workgroup
 constexpr int EPT = 4;          // edges tested per thread per scan round (8 measured slower in round 4: bin 602 -> 656 WG-ms per 128 labels)
-constexpr int LIST_CAP = 1024;  // edges per chunk
+constexpr int LIST_CAP = 512;   // edges per chunk (1024 until round 5: the batched fold's cell lists need the LDS; a 64 x 64 super-tile of a 13 k-edge graph lists 60 - 150)
+constexpr int FB = 4;           // edges folded per batch
+constexpr int FB_MAX_SLOTS = 32;// an edge with more side slots than this is folded on its own
+constexpr int CELL_CAP = 160;   // cells (incl. carried covers) per wave and batch
 constexpr int SLOT_CAP = 4096;  // int4 side slots per chunk (64 KiB; 80 KiB until the fold's accumulators needed 33 KiB, round 4)
 constexpr int ITEM_CAP = 256;   // (side, scanline) work items of one edge inside one wave's block
 
@@ -253,6 +256,9 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
     __shared__ __attribute__((aligned(16))) int s_cov[(WG / 64) * BLK_H * 16];
     __shared__ __attribute__((aligned(16))) int s_area[(WG / 64) * BLK_H * 16];
     __shared__ int s_carry[(WG / 64) * BLK_H];
+    // the batched fold's cell lists (round 5), per wave: key = row << 4 | column (0x100 | row: cover carried in from the left), cover, area
+    __shared__ unsigned short s_ckey[(WG / 64) * CELL_CAP];
+    __shared__ int s_ccov[(WG / 64) * CELL_CAP], s_carea[(WG / 64) * CELL_CAP];
     static_assert(NPX == 4 && BLK_H == 16, "the accumulator fold reads a lane's four cells as one 16-byte piece");
 
     const int img = blockIdx.y;
@@ -391,37 +397,56 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         // which items lie in its row, and it adds their cells with the cheap inner divisions. Integer sums,
         // so the order of the items is irrelevant; very wide strokes fall back to the side loop.
         unsigned short *w_owner = s_owner + wv * ITEM_CAP;
+        unsigned short *w_ckey = s_ckey + wv * CELL_CAP;
+        int *w_ccov = s_ccov + wv * CELL_CAP, *w_carea = s_carea + wv * CELL_CAP;
         const int myrow = lane / (16 / NPX);
-        // the entries whose bounding box misses this wave's block (most of a super-tile's list) are dropped 64 at a time: lane j tests
-        // entry base + j, the ballot's set bits are visited in order
-        for (int base_i = 0; base_i < list_n; base_i += 64) {
-          unsigned long long cand = 0;
-          {
-            const int j = base_i + lane;
-            bool hit = false;
-            if (j < list_n) {
-                const BBox16 b = s_list[j].bb;
-                hit = !(b.x1 < bx0 || b.x0 > bx0 + 15 || b.y1 < by0 || b.y0 > by0 + BLK_H - 1);
+        // the pixel pass of ONE edge: the block's accumulators (cover / area per cell, carried cover per row) -> this lane's four (C, A),
+        // accumulators cleared for the next edge
+        auto pixel_pass = [&](int (&C)[NPX], int (&A)[NPX]) {
+            const int4 cv = *reinterpret_cast<const int4 *>(w_cov + lane * 4);         // lane = row * 4 + column group: its four cells
+            const int4 av = *reinterpret_cast<const int4 *>(w_area + lane * 4);
+            const int s4 = cv.x + cv.y + cv.z + cv.w;
+            int pre = w_carry[myrow];
+            {   // the cover of the cells to the left inside the row: the three lanes in front, by DPP row shifts
+                const int u1 = __builtin_amdgcn_update_dpp(0, s4, 0x111, 0xf, 0xf, true);
+                const int u2 = __builtin_amdgcn_update_dpp(0, s4, 0x112, 0xf, 0xf, true);
+                const int u3 = __builtin_amdgcn_update_dpp(0, s4, 0x113, 0xf, 0xf, true);
+                const int q = lane & 3;
+                pre += (q >= 1 ? u1 : 0) + (q >= 2 ? u2 : 0) + (q >= 3 ? u3 : 0);
             }
-            cand = __ballot(hit);
-          }
-          while (cand) {
-            const int i = base_i + (int)__ffsll((long long)cand) - 1;
-            cand &= cand - 1ull;
-            const ListEntry le = s_list[i];
-            bool touch = !(prow < le.bb.y0 || prow > le.bb.y1 || pcol + NPX - 1 < le.bb.x0 || pcol > le.bb.x1);
-            if (touch) {
-                // the NPX x 1 pixel span of this lane cannot be touched if its centre is farther from the
-                // segment than half width + half diagonal of the span + slack for the fp32 test,
-                // the 1/256 vertex rounding and the snap of axis-aligned paths (already in ax..vy)
-                float cx = (float)pcol + 0.5f * NPX - le.ax, cy = (float)prow + 0.5f - le.ay;
-                float t = (cx * le.vx + cy * le.vy) * le.inv_len2;
-                t = fminf(fmaxf(t, 0.f), 1.f);
-                float ex = cx - t * le.vx, ey = cy - t * le.vy;
-                float lim = le.reach + 0.5f * sqrtf((float)(NPX * NPX + 1)) + 0.01f;
-                if (ex * ex + ey * ey > lim * lim) touch = false;
+            C[0] = pre + cv.x; C[1] = C[0] + cv.y; C[2] = C[1] + cv.z; C[3] = C[2] + cv.w;
+            A[0] = av.x; A[1] = av.y; A[2] = av.z; A[3] = av.w;
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<int4 *>(w_cov + lane * 4) = make_int4(0, 0, 0, 0);
+            *reinterpret_cast<int4 *>(w_area + lane * 4) = make_int4(0, 0, 0, 0);
+            if ((lane & 3) == 0) w_carry[myrow] = 0;
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto blend4 = [&](const int (&C)[NPX], const int (&A)[NPX]) {
+#pragma unroll
+            for (int q = 0; q < NPX; q++) {
+                int v = (C[q] << 9) - A[q];
+                int c = v >> 9;
+                if (c < 0) c = -c;
+                if (c > 255) c = 255;
+                pix[q] = blend_white(pix[q], (unsigned)c);
             }
-            if (!__any(touch)) continue;
+        };
+        // rows of polygon side `sd` inside this wave's block: first row (relative) and count
+        auto side_rows = [&](const int4 sd, int &r0, int &nr) {
+            r0 = 0; nr = 0;
+            if (sd.y != sd.w) {
+                const int ey1 = sd.y >> 8, ey2 = sd.w >> 8;
+                int lo = ey1 < ey2 ? ey1 : ey2, hi = ey1 < ey2 ? ey2 : ey1;
+                const int xmin = (sd.x < sd.z ? sd.x : sd.z) >> 8;  // pieces right of the block add nothing
+                lo = lo > by0 ? lo : by0;
+                hi = hi < by0 + BLK_H - 1 ? hi : by0 + BLK_H - 1;
+                if (hi >= lo && xmin <= bx0 + 15) { r0 = lo - by0; nr = hi - lo + 1; }
+            }
+        };
+        // ONE edge folded on its own (rounds 3-4's path; now the fallback for strokes with more sides than a batch takes, for item or cell
+        // counts beyond the LDS lists, and -- via the side loop -- for very wide strokes)
+        auto fold_one = [&](const ListEntry &le, bool touch) {
             int C[NPX], A[NPX];
 #pragma unroll
             for (int q = 0; q < NPX; q++) { C[q] = 0; A[q] = 0; }
@@ -430,17 +455,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
             bool done = false;
             if (ns <= 64) {
                 int r0 = 0, nr = 0;
-                if (lane < ns) {
-                    const int4 sd = sl[lane];
-                    if (sd.y != sd.w) {
-                        const int ey1 = sd.y >> 8, ey2 = sd.w >> 8;
-                        int lo = ey1 < ey2 ? ey1 : ey2, hi = ey1 < ey2 ? ey2 : ey1;
-                        const int xmin = (sd.x < sd.z ? sd.x : sd.z) >> 8;  // pieces right of the block add nothing
-                        lo = lo > by0 ? lo : by0;
-                        hi = hi < by0 + BLK_H - 1 ? hi : by0 + BLK_H - 1;
-                        if (hi >= lo && xmin <= bx0 + 15) { r0 = lo - by0; nr = hi - lo + 1; }
-                    }
-                }
+                if (lane < ns) side_rows(sl[lane], r0, nr);
                 const int inc = wave_scan_incl(nr);
                 const int total = __builtin_amdgcn_readlane(inc, 63);
                 if (total <= ITEM_CAP) {
@@ -448,10 +463,6 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                     const int ex0 = inc - nr;
                     for (int t = 0; t < nr; t++) w_owner[ex0 + t] = (unsigned short)((lane << 8) | (r0 + t));
                     __builtin_amdgcn_wave_barrier();
-                    // Item-parallel fold (round 4): lane = (side, scanline) item walks ITS piece cell by cell and adds cover / area into the
-                    // block's accumulators (integer sums: the order of the items is irrelevant); one pass over the pixels then turns the
-                    // accumulators into alpha and clears them. Before, every item was evaluated once per 4-pixel span of its row by the
-                    // pixel lanes of that row, rows in lock step: ~15 % of the lanes busy.
                     for (int base = 0; base < total; base += 64) {
                         if (base + lane < total) {
                             const unsigned ow = w_owner[base + lane];
@@ -466,46 +477,182 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-                    {
-                        const int4 cv = *reinterpret_cast<const int4 *>(w_cov + lane * 4);         // lane = row * 4 + column group: its four cells
-                        const int4 av = *reinterpret_cast<const int4 *>(w_area + lane * 4);
-                        const int s4 = cv.x + cv.y + cv.z + cv.w;
-                        int pre = w_carry[myrow];
-                        {   // the cover of the cells to the left inside the row: the three lanes in front, by DPP row shifts
-                            const int u1 = __builtin_amdgcn_update_dpp(0, s4, 0x111, 0xf, 0xf, true);
-                            const int u2 = __builtin_amdgcn_update_dpp(0, s4, 0x112, 0xf, 0xf, true);
-                            const int u3 = __builtin_amdgcn_update_dpp(0, s4, 0x113, 0xf, 0xf, true);
-                            const int q = lane & 3;
-                            pre += (q >= 1 ? u1 : 0) + (q >= 2 ? u2 : 0) + (q >= 3 ? u3 : 0);
-                        }
-                        C[0] = pre + cv.x; C[1] = C[0] + cv.y; C[2] = C[1] + cv.z; C[3] = C[2] + cv.w;
-                        A[0] = av.x; A[1] = av.y; A[2] = av.z; A[3] = av.w;
-                        __builtin_amdgcn_wave_barrier();
-                        *reinterpret_cast<int4 *>(w_cov + lane * 4) = make_int4(0, 0, 0, 0);
-                        *reinterpret_cast<int4 *>(w_area + lane * 4) = make_int4(0, 0, 0, 0);
-                        if ((lane & 3) == 0) w_carry[myrow] = 0;
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                    pixel_pass(C, A);
                 }
             }
             if (!done && touch) {
                 for (int k = 0; k < ns; k++) {
-                    int4 s = sl[k];
-                    if (s.y == s.w) continue;
-                    side_eval<NPX>(s, prow, pcol, C, A);
+                    int4 sd = sl[k];
+                    if (sd.y == sd.w) continue;
+                    side_eval<NPX>(sd, prow, pcol, C, A);
                 }
             }
-            if (touch) {
+            if (touch) blend4(C, A);
+        };
+        // Round 5: edges folded FOUR AT A TIME up to the pixel pass. A pair (edge, block) has ~3 (side, scanline) items: taken one edge at a
+        // time, the side scan, the item layout and the items' divisions ran with 3 - 14 of 64 lanes busy and were the larger part of the
+        // ~600 instructions a pair cost. A batch lays the sides of up to FB edges out on the lanes (sum of their slots <= 64), the items of all
+        // of them in one list, and every item writes its cells -- (row, column, cover, area), the carried cover of the cells left of the block
+        // as a cell of its own -- into a per-wave cell list, edge by edge contiguous (items come in side order, sides in edge order). Then,
+        // per edge IN LIST ORDER: its cells are added into the block's accumulators, one pixel pass turns them into alpha and blends. Integer
+        // sums per edge as before, so the image is the same bit for bit; an edge without cells in the block skips its pixel pass.
+        unsigned long long fb_pack = 0;   // list indices of the batched edges, 10 bits each (wave-uniform; no array: a dynamic index would go to scratch)
+        auto fb_i = [&](int k) { return (int)((fb_pack >> (10 * k)) & 1023ull); };
+        unsigned fb_touch = 0;            // bit k: this lane's span can be touched by batched edge k
+        int fb_n = 0, fb_slots = 0;
+        // the batched path for the pending edges; false = an item or cell list would overflow (nothing folded: the caller takes them one by one)
+        auto try_batch = [&]() -> bool {
+            if (fb_n == 0) return true;
+            // lane -> (edge k of the batch, side j)
+            int k_of = -1, slot = 0;
+            {
+                int o = 0;
 #pragma unroll
-                for (int q = 0; q < NPX; q++) {
-                    int v = (C[q] << 9) - A[q];
-                    int c = v >> 9;
-                    if (c < 0) c = -c;
-                    if (c > 255) c = 255;
-                    pix[q] = blend_white(pix[q], (unsigned)c);
+                for (int k = 0; k < FB; k++)
+                    if (k < fb_n) {
+                        const int ns = s_list[fb_i(k)].nv + EXTRA_SLOTS;
+                        if (lane >= o && lane < o + ns) { k_of = k; slot = s_list[fb_i(k)].slot_off + (lane - o); }
+                        o += ns;
+                    }
+            }
+            int r0 = 0, nr = 0;
+            if (k_of >= 0) side_rows(s_slots[slot], r0, nr);
+            const int inc = wave_scan_incl(nr);
+            const int total = __builtin_amdgcn_readlane(inc, 63);
+            bool batched = total <= ITEM_CAP;
+            int cend[FB];
+#pragma unroll
+            for (int k = 0; k < FB; k++) cend[k] = 0;
+            if (batched) {
+                const int ex0 = inc - nr;
+                for (int t = 0; t < nr; t++) w_owner[ex0 + t] = (unsigned short)((k_of << 10) | (lane << 4) | (r0 + t));     // edge, side lane, row
+                __builtin_amdgcn_wave_barrier();
+                int cbase = 0;
+                for (int base = 0; base < total && batched; base += 64) {
+                    const bool have = base + lane < total;
+                    int r = 0, ke = 0, hx1 = 0, hy1 = 0, hx2 = 0, hy2 = 0, ncell = 0;
+                    bool piece = false, left = false;
+                    const unsigned ow = have ? w_owner[base + lane] : 0u;
+                    r = (int)(ow & 15u);
+                    ke = (int)(ow >> 10);
+                    // the side's LDS slot is what the side's lane computed above: fetched with ALL lanes active (a lane that has no item in this
+                    // chunk may be the side lane of one that has)
+                    const int sslot = __builtin_amdgcn_ds_bpermute((int)((ow >> 4) & 63u) << 2, slot);
+                    if (have) {
+                        piece = side_row_piece(s_slots[sslot], by0 + r, hx1, hy1, hx2, hy2);
+                        if (piece) {
+                            // cells of the piece inside the block's columns: hline_cells emits exactly one per column of the clipped range,
+                            // and returns a carried cover iff the piece has cells left of the block
+                            const int ea = hx1 >> 8, eb = hx2 >> 8;
+                            const int lo = ea < eb ? ea : eb, hi = ea < eb ? eb : ea;
+                            left = lo < bx0;
+                            const int c0 = lo > bx0 ? lo : bx0, c1 = hi < bx0 + 15 ? hi : bx0 + 15;
+                            ncell = (c1 >= c0 ? c1 - c0 + 1 : 0) + (left ? 1 : 0);
+                        }
+                    }
+                    const int cinc = wave_scan_incl(ncell);
+                    const int ctot = __builtin_amdgcn_readlane(cinc, 63);
+                    if (cbase + ctot > CELL_CAP) { batched = false; break; }
+                    int pos = cbase + cinc - ncell;
+                    if (piece) {
+                        const int carry = hline_cells(hx1, hy1, hx2, hy2, hline_step(hx1, hy1, hx2, hy2), bx0, 16, [&](int px, int c, int a) {
+                            w_ckey[pos] = (unsigned short)((r << 4) | (px - bx0)); w_ccov[pos] = c; w_carea[pos] = a; pos++;
+                        });
+                        if (left) { w_ckey[pos] = (unsigned short)(0x100 | r); w_ccov[pos] = carry; w_carea[pos] = 0; pos++; }
+                    }
+                    // where each edge's cells end (items are in edge order): the last item of edge k in this chunk
+#pragma unroll
+                    for (int k = 0; k < FB; k++) {
+                        const unsigned long long mk = __ballot(have && ke == k);
+                        if (mk) cend[k] = __builtin_amdgcn_readlane(cbase + cinc, 63 - __builtin_clzll(mk));
+                    }
+                    cbase += ctot;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (batched) {
+                int cstart = 0;
+#pragma unroll
+                for (int k = 0; k < FB; k++) {
+                    if (k >= fb_n) break;
+                    const int ce = cend[k] > cstart ? cend[k] : cstart;        // an edge without items keeps the running end
+                    if (ce > cstart) {
+                        for (int c = cstart + lane; c < ce; c += 64) {
+                            const unsigned key = w_ckey[c];
+                            if (key & 0x100u) atomicAdd(w_carry + (key & 15u), w_ccov[c]);
+                            else { atomicAdd(w_cov + (key >> 4) * 16 + (key & 15u), w_ccov[c]); atomicAdd(w_area + (key >> 4) * 16 + (key & 15u), w_carea[c]); }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        int C[NPX], A[NPX];
+                        pixel_pass(C, A);
+                        if ((fb_touch >> k) & 1u) blend4(C, A);
+                    }
+                    cstart = ce;
                 }
             }
-          }
+            return batched;
+        };
+        // ONE site drains what is pending (each lambda is inlined where it is called: one copy of either path): the batch, or -- when its
+        // lists would overflow -- its edges one by one, then `extra` (a wide stroke) on its own
+        auto drain = [&](int extra_i, bool extra_touch) {
+            const bool singles = !try_batch();
+            unsigned long long pk = singles ? fb_pack : 0ull;
+            unsigned tb = singles ? fb_touch : 0u;
+            int n = singles ? fb_n : 0;
+            if (extra_i >= 0) { pk |= (unsigned long long)extra_i << (10 * n); tb |= (extra_touch ? 1u : 0u) << n; n++; }
+            for (int k = 0; k < n; k++) fold_one(s_list[(int)((pk >> (10 * k)) & 1023ull)], (tb >> k) & 1u);
+            fb_n = 0; fb_slots = 0; fb_touch = 0; fb_pack = 0;
+        };
+        // the entries whose bounding box misses this wave's block (most of a super-tile's list) are dropped 64 at a time: lane j tests
+        // entry base + j, the ballot's set bits are visited in order. One loop, one drain site: the last turn (no candidate left) drains
+        // what is pending.
+        {
+            int base_i = 0;
+            unsigned long long cand = 0;
+            for (;;) {
+                while (!cand && base_i < list_n) {
+                    const int j = base_i + lane;
+                    bool hit = false;
+                    if (j < list_n) {
+                        const BBox16 b = s_list[j].bb;
+                        hit = !(b.x1 < bx0 || b.x0 > bx0 + 15 || b.y1 < by0 || b.y0 > by0 + BLK_H - 1);
+                    }
+                    cand = __ballot(hit);
+                    if (!cand) base_i += 64;
+                }
+                int i = -1, ns = 0;
+                bool touch = false;
+                if (cand) {
+                    i = base_i + (int)__ffsll((long long)cand) - 1;
+                    cand &= cand - 1ull;
+                    if (!cand) base_i += 64;
+                    const ListEntry le = s_list[i];
+                    touch = !(prow < le.bb.y0 || prow > le.bb.y1 || pcol + NPX - 1 < le.bb.x0 || pcol > le.bb.x1);
+                    if (touch) {
+                        // the NPX x 1 pixel span of this lane cannot be touched if its centre is farther from the
+                        // segment than half width + half diagonal of the span + slack for the fp32 test,
+                        // the 1/256 vertex rounding and the snap of axis-aligned paths (already in ax..vy)
+                        float cx = (float)pcol + 0.5f * NPX - le.ax, cy = (float)prow + 0.5f - le.ay;
+                        float t = (cx * le.vx + cy * le.vy) * le.inv_len2;
+                        t = fminf(fmaxf(t, 0.f), 1.f);
+                        float ex = cx - t * le.vx, ey = cy - t * le.vy;
+                        float lim = le.reach + 0.5f * sqrtf((float)(NPX * NPX + 1)) + 0.01f;
+                        if (ex * ex + ey * ey > lim * lim) touch = false;
+                    }
+                    if (!__any(touch)) continue;
+                    ns = le.nv + EXTRA_SLOTS;
+                }
+                const bool last = i < 0;
+                const bool wide = !last && ns > FB_MAX_SLOTS;     // a wide stroke (many cap vertices): on its own, after what is pending
+                if (last || wide || fb_n == FB || fb_slots + ns > 64) drain(wide ? i : -1, touch);
+                if (last) break;
+                if (!wide) {
+                    fb_pack |= (unsigned long long)i << (10 * fb_n);
+                    fb_touch |= touch ? (1u << fb_n) : 0u;
+                    fb_n++;
+                    fb_slots += ns;
+                }
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 6), (unsigned long long)(_t - _tp)); }
