@@ -26,6 +26,7 @@
 //
 // All floating point here is IEEE double compiled with -ffp-contract=off.
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -208,6 +209,71 @@ raster_tess_kernel(const EdgeMeta *__restrict__ meta, const int *__restrict__ of
     }
 }
 
+// ---- kernel 4b (round 5): edges per ROW of super-tiles -----------------------------------------------------------
+// The render kernel's workgroup used to stream the graph's WHOLE bounding-box array to find the edges of its 64 x 64 super-tile: 361
+// super-tiles of a 1216^2 label each tested all 13.5 k edges (28 % of the kernel's workgroup time after the fold got faster). One pass
+// per (image, row of super-tiles) now writes, IN LIST ORDER, the indices of the edges whose box meets the row's 64 scanlines (u16: graphs
+// of more than 65 535 edges keep the old scan); a super-tile then tests the ~7 % of the edges that are in its row.
+__global__ void __launch_bounds__(1024)
+raster_rowbin_kernel(const BBox16 *__restrict__ bbox, const long *__restrict__ edge_off, int H, int rows, unsigned short *__restrict__ row_list,
+                     int *__restrict__ row_cnt) {
+    __shared__ int s_w[17];
+    __shared__ int s_base;
+    const int img = blockIdx.y, row = blockIdx.x;
+    const long e_begin = edge_off[img], e_end = edge_off[img + 1];
+    const int n = (int)(e_end - e_begin);
+    const BBox16 *gb = bbox + e_begin;
+    unsigned short *out = row_list + (size_t)e_begin * rows + (size_t)row * n;
+    const int y0 = row * ST_Y, y1 = min(y0 + ST_Y, H) - 1;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024 * 4) {
+        const int e0 = c0 + threadIdx.x * 4;
+        bool hit[4];
+        int h = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            hit[q] = false;
+            if (e0 + q < n) {
+                const BBox16 b = gb[e0 + q];
+                hit[q] = b.x0 <= b.x1 && b.y1 >= y0 && b.y0 <= y1;
+            }
+            h += hit[q] ? 1 : 0;
+        }
+        const int inc = wave_scan_incl(h);
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        int pre = s_base, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const int t = s_w[k]; pre += k < wv ? t : 0; tot += t; }
+        int pos = pre + inc - h;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (hit[q]) out[pos++] = (unsigned short)(e0 + q);
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_cnt[img * rows + row] = s_base;
+}
+
+// The lane index, recomputed where it is asked for: the empty asm keeps the compiler from hoisting it (and everything derived from it: row,
+// column, LDS addresses) out of the fold's loops into registers that then live -- and spill -- across the whole kernel.
+__device__ __forceinline__ int fresh_lane() {
+    int l = (int)(threadIdx.x & 63u);
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
+#ifdef OCTA_RASTER_PROF
+#define RASTER_PROF_BEGIN long _tp = (long)wall_clock64();
+#define RASTER_PROF_MARK(slot) if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + (slot)), (unsigned long long)(_t - _tp)); _tp = _t; }
+#else
+#define RASTER_PROF_BEGIN
+#define RASTER_PROF_MARK(slot)
+#endif
+
 // ---- kernel 5: render ------------------------------------------------------------------------
 
 struct ListEntry {
@@ -223,7 +289,7 @@ struct ListEntry {
 // block-wide exclusive scan of two ints per thread over WG threads: DPP wave scans, the wave totals through LDS, every thread sums
 // the totals in front of its wave itself (round 4: ds_bpermute scans, a serial pass of thread 0 and one more barrier until then)
 __device__ __forceinline__ void block_scan2(int a, int b, int *sh /*[2*16+2]*/, int &ea, int &eb, int &ta, int &tb) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ia = wave_scan_incl(a), ib = wave_scan_incl(b);
     if (lane == 63) { sh[wv] = ia; sh[16 + wv] = ib; }
     __syncthreads();
@@ -245,7 +311,8 @@ __global__ void __launch_bounds__(WG)
 raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict__ bbox,
                      const long *__restrict__ edge_off, const int4 *__restrict__ sides, const int *__restrict__ side_off,
                      const int *__restrict__ side_block_sums, int W, int H, int tiles_x, int tiles_y,
-                     unsigned char *__restrict__ out, int *__restrict__ err_flag) {
+                     unsigned char *__restrict__ out, int *__restrict__ err_flag, const unsigned short *__restrict__ row_list,
+                     const int *__restrict__ row_cnt) {
     __shared__ int4 s_slots[SLOT_CAP];
     __shared__ ListEntry s_list[LIST_CAP];
     __shared__ unsigned short s_owner[(WG / 64) * ITEM_CAP];
@@ -274,15 +341,18 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
     const int tx0 = (tile % tiles_x) * ST, ty0 = (tile / tiles_x) * ST_Y;
     const int tx1 = min(tx0 + ST, W) - 1, ty1 = min(ty0 + ST_Y, H) - 1;
     const long e_begin = edge_off[img], e_end = edge_off[img + 1];
-    const int n_edges = (int)(e_end - e_begin);
+    // the candidates of this super-tile: the edges of its row of super-tiles (raster_rowbin_kernel), or the whole graph
+    const int trow = tile / tiles_x;
+    const unsigned short *rl = row_list ? row_list + (size_t)e_begin * tiles_y + (size_t)trow * (size_t)(e_end - e_begin) : nullptr;
+    const int n_edges = rl ? row_cnt[img * tiles_y + trow] : (int)(e_end - e_begin);      // positions in rl (or edges)
     const EdgeMeta *gm = meta + e_begin;
     const BBox16 *gb = bbox + e_begin;
 
     // wave -> 16x16 block, lane -> 4 adjacent pixels of one row
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the wave index is wave-uniform by construction; saying so keeps the block's origin and the per-wave LDS bases in scalar registers
+    // (round 5: the batched fold had pushed the kernel over its 128 vector registers -- twelve loop invariants spilled at kernel entry)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bx0 = tx0 + (wv & 3) * 16, by0 = ty0 + (wv >> 2) * BLK_H;
-    const int prow = by0 + lane / (16 / NPX);
-    const int pcol = bx0 + (lane % (16 / NPX)) * NPX;
     unsigned pix[NPX];
 #pragma unroll
     for (int q = 0; q < NPX; q++) pix[q] = 0u;
@@ -292,7 +362,9 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
 
     int cursor = 0;
     while (cursor < n_edges) {
-        long _tp = (long)wall_clock64();
+        // phase timers of the render kernel (octa_raster_prof, tools/time_raster.py): a diagnostic build only (-DOCTA_RASTER_PROF) since round 5 --
+        // the kernel sits at its 128 vector / 106 scalar registers, and the timers' clock reads and 64-bit atomics had tipped it into spilling
+        RASTER_PROF_BEGIN
         // ---- phase 1: ordered compaction of the edges that touch this super-tile
         if (threadIdx.x == 0) { s_ctl[1] = 0; s_ctl[2] = 0; }
         __syncthreads();
@@ -300,7 +372,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         bool stop = false;
         while (!stop && cursor < n_edges && list_n < LIST_CAP / 2) {
             if (threadIdx.x == 0) s_ctl[0] = 0x7fffffff;
-            int e0 = cursor + threadIdx.x * EPT;
+            int e0 = cursor + threadIdx.x * EPT;           // position in the candidate list
             BBox16 bb[EPT];
             int cnt[EPT];
             int hits = 0, slots = 0;
@@ -309,10 +381,11 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                 int e = e0 + q;
                 cnt[q] = 0;
                 if (e < n_edges) {
-                    bb[q] = gb[e];
+                    const int ed = rl ? (int)rl[e] : e;     // the edge at that position
+                    bb[q] = gb[ed];
                     bool hit = bb[q].x0 <= bb[q].x1 && bb[q].x1 >= tx0 && bb[q].x0 <= tx1 && bb[q].y1 >= ty0 && bb[q].y0 <= ty1;
                     if (hit) {
-                        int nv = gm[e].nv;
+                        int nv = gm[ed].nv;
                         cnt[q] = nv + EXTRA_SLOTS;
                         hits++;
                         slots += cnt[q];
@@ -327,13 +400,14 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                 if (cnt[q] > 0) {
                     if (pos < LIST_CAP && sp + cnt[q] <= SLOT_CAP) {
                         ListEntry le;
-                        le.edge = e0 + q;
+                        const int ed = rl ? (int)rl[e0 + q] : e0 + q;      // read again (a cache hit) rather than kept: the kernel sits at its register limit
+                        le.edge = ed;
                         le.slot_off = sp;
                         le.nv = cnt[q] - EXTRA_SLOTS;
                         le.bb = bb[q];
-                        le.side_off = side_off[e_begin + e0 + q] + side_block_sums[(e_begin + e0 + q) / SCAN_BLK];
+                        le.side_off = side_off[e_begin + ed] + side_block_sums[(e_begin + ed) / SCAN_BLK];
                         {
-                            const EdgeMeta &em = gm[e0 + q];
+                            const EdgeMeta &em = gm[ed];
                             float vx = (float)(em.x1 - em.x0), vy = (float)(em.y1 - em.y0);
                             le.ax = (float)em.x0; le.ay = (float)em.y0; le.vx = vx; le.vy = vy;
                             float l2 = vx * vx + vy * vy;
@@ -375,7 +449,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 2), (unsigned long long)(_t - _tp)); _tp = _t; }
+        RASTER_PROF_MARK(2)
         if (list_n == 0) continue;
 
         // ---- phase 2: copy the tessellated sides of the listed edges into LDS (16 B per lane, coalesced per edge)
@@ -389,7 +463,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         }
         __syncthreads();
 
-        if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 4), (unsigned long long)(_t - _tp)); _tp = _t; }
+        RASTER_PROF_MARK(4)
         // ---- phase 3: ordered fold of the edges over this wave's 16x16 block.
         // Per edge the work items are (polygon side, scanline) pairs: lane = side counts the rows of its side
         // inside the block, a wave prefix sum lays the items out, lane = item computes the scanline piece
@@ -399,10 +473,10 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         unsigned short *w_owner = s_owner + wv * ITEM_CAP;
         unsigned short *w_ckey = s_ckey + wv * CELL_CAP;
         int *w_ccov = s_ccov + wv * CELL_CAP, *w_carea = s_carea + wv * CELL_CAP;
-        const int myrow = lane / (16 / NPX);
         // the pixel pass of ONE edge: the block's accumulators (cover / area per cell, carried cover per row) -> this lane's four (C, A),
         // accumulators cleared for the next edge
         auto pixel_pass = [&](int (&C)[NPX], int (&A)[NPX]) {
+            const int lane = fresh_lane(), myrow = lane / (16 / NPX);
             const int4 cv = *reinterpret_cast<const int4 *>(w_cov + lane * 4);         // lane = row * 4 + column group: its four cells
             const int4 av = *reinterpret_cast<const int4 *>(w_area + lane * 4);
             const int s4 = cv.x + cv.y + cv.z + cv.w;
@@ -446,7 +520,22 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         };
         // ONE edge folded on its own (rounds 3-4's path; now the fallback for strokes with more sides than a batch takes, for item or cell
         // counts beyond the LDS lists, and -- via the side loop -- for very wide strokes)
-        auto fold_one = [&](const ListEntry &le, bool touch) {
+        auto fold_one = [&](const ListEntry &le) {
+            const int lane = fresh_lane();
+            const int prow = by0 + lane / (16 / NPX), pcol = bx0 + (lane % (16 / NPX)) * NPX;
+            // the NPX x 1 pixel span of this lane cannot be touched if its centre is farther from the segment than half width + half
+            // diagonal of the span + slack for the fp32 test, the 1/256 vertex rounding and the snap of axis-aligned paths (already in
+            // ax..vy); only the side loop of very wide strokes and the blend below ask
+            bool touch = !(prow < le.bb.y0 || prow > le.bb.y1 || pcol + NPX - 1 < le.bb.x0 || pcol > le.bb.x1);
+            if (touch) {
+                float cx = (float)pcol + 0.5f * NPX - le.ax, cy = (float)prow + 0.5f - le.ay;
+                float t = (cx * le.vx + cy * le.vy) * le.inv_len2;
+                t = fminf(fmaxf(t, 0.f), 1.f);
+                float ex = cx - t * le.vx, ey = cy - t * le.vy;
+                float lim = le.reach + 0.5f * sqrtf((float)(NPX * NPX + 1)) + 0.01f;
+                if (ex * ex + ey * ey > lim * lim) touch = false;
+            }
+            if (!__any(touch)) return;
             int C[NPX], A[NPX];
 #pragma unroll
             for (int q = 0; q < NPX; q++) { C[q] = 0; A[q] = 0; }
@@ -498,11 +587,11 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         // sums per edge as before, so the image is the same bit for bit; an edge without cells in the block skips its pixel pass.
         unsigned long long fb_pack = 0;   // list indices of the batched edges, 10 bits each (wave-uniform; no array: a dynamic index would go to scratch)
         auto fb_i = [&](int k) { return (int)((fb_pack >> (10 * k)) & 1023ull); };
-        unsigned fb_touch = 0;            // bit k: this lane's span can be touched by batched edge k
         int fb_n = 0, fb_slots = 0;
         // the batched path for the pending edges; false = an item or cell list would overflow (nothing folded: the caller takes them one by one)
         auto try_batch = [&]() -> bool {
             if (fb_n == 0) return true;
+            const int lane = fresh_lane();
             // lane -> (edge k of the batch, side j)
             int k_of = -1, slot = 0;
             {
@@ -585,7 +674,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                         __builtin_amdgcn_wave_barrier();
                         int C[NPX], A[NPX];
                         pixel_pass(C, A);
-                        if ((fb_touch >> k) & 1u) blend4(C, A);
+                        blend4(C, A);                 // a pixel without coverage blends with alpha 0: unchanged
                     }
                     cstart = ce;
                 }
@@ -594,14 +683,13 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         };
         // ONE site drains what is pending (each lambda is inlined where it is called: one copy of either path): the batch, or -- when its
         // lists would overflow -- its edges one by one, then `extra` (a wide stroke) on its own
-        auto drain = [&](int extra_i, bool extra_touch) {
+        auto drain = [&](int extra_i) {
             const bool singles = !try_batch();
             unsigned long long pk = singles ? fb_pack : 0ull;
-            unsigned tb = singles ? fb_touch : 0u;
             int n = singles ? fb_n : 0;
-            if (extra_i >= 0) { pk |= (unsigned long long)extra_i << (10 * n); tb |= (extra_touch ? 1u : 0u) << n; n++; }
-            for (int k = 0; k < n; k++) fold_one(s_list[(int)((pk >> (10 * k)) & 1023ull)], (tb >> k) & 1u);
-            fb_n = 0; fb_slots = 0; fb_touch = 0; fb_pack = 0;
+            if (extra_i >= 0) { pk |= (unsigned long long)extra_i << (10 * n); n++; }
+            for (int k = 0; k < n; k++) fold_one(s_list[(int)((pk >> (10 * k)) & 1023ull)]);
+            fb_n = 0; fb_slots = 0; fb_pack = 0;
         };
         // the entries whose bounding box misses this wave's block (most of a super-tile's list) are dropped 64 at a time: lane j tests
         // entry base + j, the ballot's set bits are visited in order. One loop, one drain site: the last turn (no candidate left) drains
@@ -621,41 +709,28 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                     if (!cand) base_i += 64;
                 }
                 int i = -1, ns = 0;
-                bool touch = false;
                 if (cand) {
                     i = base_i + (int)__ffsll((long long)cand) - 1;
                     cand &= cand - 1ull;
                     if (!cand) base_i += 64;
-                    const ListEntry le = s_list[i];
-                    touch = !(prow < le.bb.y0 || prow > le.bb.y1 || pcol + NPX - 1 < le.bb.x0 || pcol > le.bb.x1);
-                    if (touch) {
-                        // the NPX x 1 pixel span of this lane cannot be touched if its centre is farther from the
-                        // segment than half width + half diagonal of the span + slack for the fp32 test,
-                        // the 1/256 vertex rounding and the snap of axis-aligned paths (already in ax..vy)
-                        float cx = (float)pcol + 0.5f * NPX - le.ax, cy = (float)prow + 0.5f - le.ay;
-                        float t = (cx * le.vx + cy * le.vy) * le.inv_len2;
-                        t = fminf(fmaxf(t, 0.f), 1.f);
-                        float ex = cx - t * le.vx, ey = cy - t * le.vy;
-                        float lim = le.reach + 0.5f * sqrtf((float)(NPX * NPX + 1)) + 0.01f;
-                        if (ex * ex + ey * ey > lim * lim) touch = false;
-                    }
-                    if (!__any(touch)) continue;
-                    ns = le.nv + EXTRA_SLOTS;
+                    // (rounds 3-4 tested every lane's 4-pixel span against the stroke here and dropped the edge when no lane could be touched:
+                    // 3 % of the candidates, for three LDS reads and ~30 instructions on every one of them. The batch needs no such test -- a
+                    // pixel without coverage blends with alpha 0, an edge without cells in the block skips its pixel pass.)
+                    ns = s_list[i].nv + EXTRA_SLOTS;
                 }
                 const bool last = i < 0;
                 const bool wide = !last && ns > FB_MAX_SLOTS;     // a wide stroke (many cap vertices): on its own, after what is pending
-                if (last || wide || fb_n == FB || fb_slots + ns > 64) drain(wide ? i : -1, touch);
+                if (last || wide || fb_n == FB || fb_slots + ns > 64) drain(wide ? i : -1);
                 if (last) break;
                 if (!wide) {
                     fb_pack |= (unsigned long long)i << (10 * fb_n);
-                    fb_touch |= touch ? (1u << fb_n) : 0u;
                     fb_n++;
                     fb_slots += ns;
                 }
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) { long _t = (long)wall_clock64(); atomicAdd((unsigned long long *)(err_flag + 6), (unsigned long long)(_t - _tp)); }
+        RASTER_PROF_MARK(6)
     }
 
     // Store (round 5): a wave's block is 16 pixels wide, so its lanes' 4-byte pieces filled a 64-byte row segment of the super-tile from four
@@ -667,6 +742,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
         unsigned v = 0;
 #pragma unroll
         for (int q = 0; q < NPX; q++) v |= pix[q] << (8 * q);
+        const int prow = by0 + lane / (16 / NPX), pcol = bx0 + (lane % (16 / NPX)) * NPX;
         s_tile[(prow - ty0) * (ST / 4) + (pcol - tx0) / 4] = v;
     }
     __syncthreads();
@@ -967,10 +1043,26 @@ extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, co
         if (ctx->r_sides.reserve(sizeof(int4))) return -1;
     }
     const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST_Y - 1) / ST_Y;
+    // edges per row of super-tiles (u16 indices inside a graph): every graph must have fewer than 65 536 edges, and one row must be worth it
+    const unsigned short *row_list = nullptr;
+    const int *row_cnt = nullptr;
+    {
+        static const bool rowbin_on = [] { const char *e = getenv("OCTA_RASTER_ROWBIN"); return !(e && e[0] == '0'); }();
+        long max_graph = 0;
+        for (int b = 0; b < B; b++) max_graph = std::max<long>(max_graph, (long)(h_edge_off[b + 1] - h_edge_off[b]));
+        if (rowbin_on && n_total > 0 && tiles_y > 1 && max_graph < 65536) {
+            if (ctx->r_tile_list.reserve(sizeof(unsigned short) * (size_t)n_total * tiles_y + 16)) return -1;
+            if (ctx->r_tile_fill.reserve(sizeof(int) * (size_t)B * tiles_y)) return -1;
+            hipLaunchKernelGGL(raster_rowbin_kernel, dim3((unsigned)tiles_y, (unsigned)B), dim3(1024), 0, stream, ctx->r_ucount.as<BBox16>(),
+                               ctx->r_edge_off.as<long>(), H, tiles_y, ctx->r_tile_list.as<unsigned short>(), ctx->r_tile_fill.as<int>());
+            row_list = ctx->r_tile_list.as<unsigned short>();
+            row_cnt = ctx->r_tile_fill.as<int>();
+        }
+    }
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)B);
     hipLaunchKernelGGL(raster_render_kernel, grid, dim3(WG), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(),
                        ctx->r_ucount.as<BBox16>(), ctx->r_edge_off.as<long>(), ctx->r_sides.as<int4>(), ctx->r_tile_count.as<int>(),
-                       ctx->r_seg_total.as<int>(), W, H, tiles_x, tiles_y, d_out, ctx->r_counters.as<int>());
+                       ctx->r_seg_total.as<int>(), W, H, tiles_x, tiles_y, d_out, ctx->r_counters.as<int>(), row_list, row_cnt);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
