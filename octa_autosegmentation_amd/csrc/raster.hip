@@ -276,14 +276,12 @@ __device__ __forceinline__ int fresh_lane() {
 
 // ---- kernel 5: render ------------------------------------------------------------------------
 
-struct ListEntry {
-    int edge;       // edge index inside the graph
-    int slot_off;   // first LDS slot
-    int nv;         // polygon sides (primary slots)
-    int side_off;   // first slot of the edge in the global side array
+struct ListEntry {      // 24 bytes (48 until round 5: the segment's start / direction / reach for the per-lane miss test lived here; only
+    int edge;           // the one-edge fallback path asks for them now and fetches the edge record itself). edge index inside the graph
+    int slot_off;       // first LDS slot
+    int nv;             // polygon sides (primary slots)
+    int side_off;       // first slot of the edge in the global side array
     BBox16 bb;
-    float ax, ay, vx, vy;  // segment start and direction (pixels), for the conservative miss test
-    float inv_len2, reach; // 1/|v|^2 and half width + margin
 };
 
 // block-wide exclusive scan of two ints per thread over WG threads: DPP wave scans, the wave totals through LDS, every thread sums
@@ -406,14 +404,6 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                         le.nv = cnt[q] - EXTRA_SLOTS;
                         le.bb = bb[q];
                         le.side_off = side_off[e_begin + ed] + side_block_sums[(e_begin + ed) / SCAN_BLK];
-                        {
-                            const EdgeMeta &em = gm[ed];
-                            float vx = (float)(em.x1 - em.x0), vy = (float)(em.y1 - em.y0);
-                            le.ax = (float)em.x0; le.ay = (float)em.y0; le.vx = vx; le.vy = vy;
-                            float l2 = vx * vx + vy * vy;
-                            le.inv_len2 = l2 > 0.f ? 1.0f / l2 : 0.f;
-                            le.reach = (float)em.w + 0.25f;
-                        }
                         s_list[pos] = le;
                     } else {
                         atomicMin(&s_ctl[0], e0 + q);
@@ -528,11 +518,14 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
             // ax..vy); only the side loop of very wide strokes and the blend below ask
             bool touch = !(prow < le.bb.y0 || prow > le.bb.y1 || pcol + NPX - 1 < le.bb.x0 || pcol > le.bb.x1);
             if (touch) {
-                float cx = (float)pcol + 0.5f * NPX - le.ax, cy = (float)prow + 0.5f - le.ay;
-                float t = (cx * le.vx + cy * le.vy) * le.inv_len2;
+                const EdgeMeta &em = gm[le.edge];
+                const float vx = (float)(em.x1 - em.x0), vy = (float)(em.y1 - em.y0), l2 = vx * vx + vy * vy;
+                const float inv_len2 = l2 > 0.f ? 1.0f / l2 : 0.f, reach = (float)em.w + 0.25f;
+                float cx = (float)pcol + 0.5f * NPX - (float)em.x0, cy = (float)prow + 0.5f - (float)em.y0;
+                float t = (cx * vx + cy * vy) * inv_len2;
                 t = fminf(fmaxf(t, 0.f), 1.f);
-                float ex = cx - t * le.vx, ey = cy - t * le.vy;
-                float lim = le.reach + 0.5f * sqrtf((float)(NPX * NPX + 1)) + 0.01f;
+                float ex = cx - t * vx, ey = cy - t * vy;
+                float lim = reach + 0.5f * sqrtf((float)(NPX * NPX + 1)) + 0.01f;
                 if (ex * ex + ey * ey > lim * lim) touch = false;
             }
             if (!__any(touch)) return;
