@@ -185,13 +185,39 @@ raster_tess_kernel(const EdgeMeta *__restrict__ meta, const int *__restrict__ of
         for (int k = nv; k < nv + EXTRA_SLOTS; k++) out[k] = make_int4(0, 0, 0, 0);
         const double ddx = m.x1 - m.x0, ddy = m.y1 - m.y0;
         const double len = sqrt(ddx * ddx + ddy * ddy);
+        // The polygon's vertices in order, with stroke_vertex()'s arithmetic (raster_core.h) but WALKED: per cap the offset vector and the
+        // start angle once, the angle by the same chain of additions (vertex i of a cap is reached after i additions of da, as
+        // agg::math_stroke::calc_cap accumulates it) -- stroke_vertex(v) recomputes atan2 and the whole chain for every vertex (round 5:
+        // 560 -> us per 128 labels for this kernel, a third of it those repeats).
+        const int per = m.n + 2;
+        const double da = M_PI / (m.n + 1);
+        int wi = 0, wcap = 0;
+        double wdx1 = 0, wdy1 = 0, wa1 = 0, wv0x = 0, wv0y = 0;
+        auto next_vertex = [&](double *px, double *py) {
+            if (wi == 0) {
+                wv0x = wcap ? m.x1 : m.x0; wv0y = wcap ? m.y1 : m.y0;
+                const double v1x = wcap ? m.x0 : m.x1, v1y = wcap ? m.y0 : m.y1;
+                wdx1 = (v1y - wv0y) / len;
+                wdy1 = (v1x - wv0x) / len;
+                wdx1 *= m.w;
+                wdy1 *= m.w;
+                *px = wv0x - wdx1; *py = wv0y + wdy1;
+            } else if (wi == per - 1) {
+                *px = wv0x + wdx1; *py = wv0y - wdy1;
+            } else {
+                if (wi == 1) { wa1 = atan2(wdy1, -wdx1); wa1 += da; } else wa1 += da;
+                *px = wv0x + cos(wa1) * m.w;
+                *py = wv0y + sin(wa1) * m.w;
+            }
+            if (++wi == per) { wi = 0; wcap++; }
+        };
         double fx, fy;
-        stroke_vertex(m, len, 0, &fx, &fy);
+        next_vertex(&fx, &fy);
         double ax = fx, ay = fy;
         int extra = 0;
         for (int v = 1; v <= nv; v++) {
             double bx = fx, by = fy;
-            if (v < nv) stroke_vertex(m, len, v, &bx, &by);
+            if (v < nv) next_vertex(&bx, &by);
             SideSink sink;
             sink.n = 0;
             clip_side(sink, (double)W, (double)H, ax, ay, bx, by);
@@ -214,11 +240,13 @@ raster_tess_kernel(const EdgeMeta *__restrict__ meta, const int *__restrict__ of
 // super-tiles of a 1216^2 label each tested all 13.5 k edges (28 % of the kernel's workgroup time after the fold got faster). One pass
 // per (image, row of super-tiles) now writes, IN LIST ORDER, the indices of the edges whose box meets the row's 64 scanlines (u16: graphs
 // of more than 65 535 edges keep the old scan); a super-tile then tests the ~7 % of the edges that are in its row.
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 raster_rowbin_kernel(const BBox16 *__restrict__ bbox, const long *__restrict__ edge_off, int H, int rows, unsigned short *__restrict__ row_list,
                      int *__restrict__ row_cnt) {
-    __shared__ int s_w[17];
-    __shared__ int s_base;
+    // every wave takes a contiguous quarter of the graph's edges: count (ballots), ONE barrier for the four totals, then emit at the running
+    // offset (ballot prefix) -- the boxes are read twice from the L2 instead of once with three barriers per 4096 edges (236 -> ~30 us per
+    // 128 labels)
+    __shared__ int s_tot[4];
     const int img = blockIdx.y, row = blockIdx.x;
     const long e_begin = edge_off[img], e_end = edge_off[img + 1];
     const int n = (int)(e_end - e_begin);
@@ -226,36 +254,27 @@ raster_rowbin_kernel(const BBox16 *__restrict__ bbox, const long *__restrict__ e
     unsigned short *out = row_list + (size_t)e_begin * rows + (size_t)row * n;
     const int y0 = row * ST_Y, y1 = min(y0 + ST_Y, H) - 1;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) s_base = 0;
+    const int seg = ((n + 4 * 64 - 1) / (4 * 64)) * 64;
+    const int s0 = wv * seg < n ? wv * seg : n, s1 = s0 + seg < n ? s0 + seg : n;
+    auto hit_at = [&](int e) {
+        if (e >= s1) return false;
+        const BBox16 b = gb[e];
+        return b.x0 <= b.x1 && b.y1 >= y0 && b.y0 <= y1;
+    };
+    int c = 0;
+    for (int e0 = s0; e0 < s1; e0 += 64) c += (int)__popcll(__ballot(hit_at(e0 + lane)));
+    if (lane == 0) s_tot[wv] = c;
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 1024 * 4) {
-        const int e0 = c0 + threadIdx.x * 4;
-        bool hit[4];
-        int h = 0;
+    int at = 0, tot = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            hit[q] = false;
-            if (e0 + q < n) {
-                const BBox16 b = gb[e0 + q];
-                hit[q] = b.x0 <= b.x1 && b.y1 >= y0 && b.y0 <= y1;
-            }
-            h += hit[q] ? 1 : 0;
-        }
-        const int inc = wave_scan_incl(h);
-        if (lane == 63) s_w[wv] = inc;
-        __syncthreads();
-        int pre = s_base, tot = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { const int t = s_w[k]; pre += k < wv ? t : 0; tot += t; }
-        int pos = pre + inc - h;
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (hit[q]) out[pos++] = (unsigned short)(e0 + q);
-        __syncthreads();
-        if (threadIdx.x == 0) s_base += tot;
-        __syncthreads();
+    for (int k = 0; k < 4; k++) { const int t = s_tot[k]; at += k < wv ? t : 0; tot += t; }
+    for (int e0 = s0; e0 < s1; e0 += 64) {
+        const bool h = hit_at(e0 + lane);
+        const unsigned long long m = __ballot(h);
+        if (h) out[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(e0 + lane);
+        at += (int)__popcll(m);
     }
-    if (threadIdx.x == 0) row_cnt[img * rows + row] = s_base;
+    if (threadIdx.x == 0) row_cnt[img * rows + row] = tot;
 }
 
 // The lane index, recomputed where it is asked for: the empty asm keeps the compiler from hoisting it (and everything derived from it: row,
@@ -1046,7 +1065,7 @@ extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, co
         if (rowbin_on && n_total > 0 && tiles_y > 1 && max_graph < 65536) {
             if (ctx->r_tile_list.reserve(sizeof(unsigned short) * (size_t)n_total * tiles_y + 16)) return -1;
             if (ctx->r_tile_fill.reserve(sizeof(int) * (size_t)B * tiles_y)) return -1;
-            hipLaunchKernelGGL(raster_rowbin_kernel, dim3((unsigned)tiles_y, (unsigned)B), dim3(1024), 0, stream, ctx->r_ucount.as<BBox16>(),
+            hipLaunchKernelGGL(raster_rowbin_kernel, dim3((unsigned)tiles_y, (unsigned)B), dim3(256), 0, stream, ctx->r_ucount.as<BBox16>(),
                                ctx->r_edge_off.as<long>(), H, tiles_y, ctx->r_tile_list.as<unsigned short>(), ctx->r_tile_fill.as<int>());
             row_list = ctx->r_tile_list.as<unsigned short>();
             row_cnt = ctx->r_tile_fill.as<int>();
