@@ -1257,12 +1257,17 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char *p) {
 // ((2y + r) * 2 + s % 2) * 33 + x + s / 2. MASKED (the 2 x 2 transposed convolution's weight gradient wants four of the nine taps):
 // all nine are multiplied -- skipping reads and MFMAs behind run-time tests measured slower than the full loop (0.158 against 0.131 ms
 // at 1216^2 32->64) -- and the taps outside tap_mask are left out of the result.
-template <int COB, int CIB, int TH_, int ST, bool MASKED>
+// REFLECT (stride 1): the halo mirrors the image -- nn.ReflectionPad2d(1) in front of the convolution (octa_conv3x3_nhwc_fwd_pad); a template
+// parameter because the issue code below sits BETWEEN the MFMAs of a wave that has its SIMD to itself: every instruction of it is a cycle
+// the matrix pipe may idle (round 5: with the mirror arithmetic, the dY / X choice and the range tests behind run-time branches one DMA
+// instruction cost 53-84 instructions, 1355 per 144 MFMAs; MFMA busy 32 %, and removing the in-loop DMA alone took 512->512 at 152^2
+// from 0.593 to 0.337 ms).
+template <int COB, int CIB, int TH_, int ST, bool MASKED, bool REFLECT = false>
 __global__ void __launch_bounds__(CONV_THREADS, (COB == 32 && CIB == 32 && ST == 1 ? 2 : 1))
 conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                              const unsigned short *__restrict__ dY, float *__restrict__ dW,
                              int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int tiles_x, int tiles_y, int tap_mask,
-                             const unsigned short *__restrict__ zero16, float *__restrict__ ws, int pad, int reflect) {
+                             const unsigned short *__restrict__ zero16, float *__restrict__ ws, int pad) {
     constexpr int PAIRS = (COB / 32) * (CIB / 32), KSPLIT = 4 / PAIRS, RPW = TH_ / KSPLIT;   // tile rows per wave
     constexpr int RG = RPW < 4 ? RPW : 4, NG = RPW / RG;            // rows per operand set (register budget), sets per column group
     constexpr int XROWS = ST * (TH_ - 1) + 3;                                                // halo rows
@@ -1314,30 +1319,33 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
         const int n = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
         return TilePos{n, (tt / tiles_x) * TH_, (tt % tiles_x) * TW};      // in output (dY) pixels
     };
-    // part < 0: all of the wave's instructions; otherwise only instruction `part` (the main loop spreads them between its MFMAs)
+    // part < 0: all of the wave's instructions; otherwise only instruction `part` (the main loop spreads them between its MFMAs).
+    // Instruction j = wv + 4 i: DY_INSTR is a multiple of four, so slot i is a dY slot for every wave or for none (compile time), and only the
+    // last slot can lie beyond N_INSTR. Per slot: two adds, two unsigned range tests, one 64-bit add, two selects, M0, the load.
+    static_assert(DY_INSTR % 4 == 0, "a DMA slot must not mix dY and X instructions across the waves");
     auto issue = [&](const TilePos &tp, unsigned char *buf, int part) {
         const unsigned short *dy0 = dY + (((size_t)tp.n * Ho + tp.ty0) * Wo + tp.tx0) * Cout + co0;
         const unsigned short *x0 = Xs + (((size_t)tp.n * H + ST * tp.ty0) * W + ST * tp.tx0) * xcs + xcb;
+        const int xy0 = ST * tp.ty0, xx0 = ST * tp.tx0;
 #pragma unroll
         for (int i = 0; i < IPW; i++) {
-            const int j = wv + 4 * i;
             if (part >= 0 && i != part) continue;
-            if (j < N_INSTR) {
-                const bool isdy = j < DY_INSTR;
-                const bool ok = isdy ? (unsigned)(tp.ty0 + s_py[i]) < (unsigned)Ho && (unsigned)(tp.tx0 + s_px[i]) < (unsigned)Wo
-                                     : (unsigned)(ST * tp.ty0 + s_py[i]) < (unsigned)H && (unsigned)(ST * tp.tx0 + s_px[i]) < (unsigned)W;
-                const unsigned short *src = (isdy ? dy0 : x0) + s_rel[i];
-                if (reflect && !isdy && s_py[i] > -(1 << 19)) {
-                    // nn.ReflectionPad2d(1) in front of the convolution: the halo mirrors the image (see octa_conv3x3_nhwc_fwd_pad)
-                    int y = ST * tp.ty0 + s_py[i], x = ST * tp.tx0 + s_px[i];
-                    y = y < 0 ? -y : (y >= H ? 2 * (H - 1) - y : y);
-                    x = x < 0 ? -x : (x >= W ? 2 * (W - 1) - x : x);
-                    const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;      // tiles beyond the image edge reach further than one mirror
-                    src = Xs + (((size_t)tp.n * H + (in ? y : 0)) * W + (in ? x : 0)) * xcs + xcb + ((j - DY_INSTR) / X_IPP) * 32 + lq * 8;
-                    glds16(in ? src : zero16, buf + j * 1024);
-                    continue;
-                }
-                glds16(ok ? src : zero16, buf + j * 1024);
+            const int j = wv + 4 * i;
+            if (4 * i + 3 >= N_INSTR && j >= N_INSTR) continue;
+            if (i < DY_INSTR / 4) {
+                const bool ok = (unsigned)(tp.ty0 + s_py[i]) < (unsigned)Ho && (unsigned)(tp.tx0 + s_px[i]) < (unsigned)Wo;
+                glds16(ok ? dy0 + s_rel[i] : zero16, buf + j * 1024);
+            } else if (!REFLECT) {
+                const bool ok = (unsigned)(xy0 + s_py[i]) < (unsigned)H && (unsigned)(xx0 + s_px[i]) < (unsigned)W;
+                glds16(ok ? x0 + s_rel[i] : zero16, buf + j * 1024);
+            } else {
+                int y = xy0 + s_py[i], x = xx0 + s_px[i];
+                y = y < 0 ? -y : (y >= H ? 2 * (H - 1) - y : y);
+                x = x < 0 ? -x : (x >= W ? 2 * (W - 1) - x : x);
+                // LDS pixels that belong to no halo position (s_py = -2^20) and tiles beyond the image edge (further than one mirror) read zeros
+                const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                const unsigned short *src = Xs + (((size_t)tp.n * H + (in ? y : 0)) * W + (in ? x : 0)) * xcs + xcb + ((j - DY_INSTR) / X_IPP) * 32 + lq * 8;
+                glds16(in ? src : zero16, buf + j * 1024);
             }
         }
     };
@@ -1503,9 +1511,10 @@ int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short
     }
     auto kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_, ST, false>;
     if (tap_mask != 0x1ff) kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_, ST, true>;
+    if constexpr (ST == 1) { if (reflect) kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_, 1, false, true>; }   // (the mirrored form is never masked: octa_conv3x3_nhwc_wgrad_pad)
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Ho, Wo, Cin, Cout,
-                       tiles_x, tiles_y, tap_mask, zero16, ws, pad, reflect);
+                       tiles_x, tiles_y, tap_mask, zero16, ws, pad);
     OCTA_HIP_CHECK(hipGetLastError());
     if (ws) {
         const int total = 9 * Cout * Cin;
