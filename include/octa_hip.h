@@ -163,7 +163,10 @@ int octa_scale_shift_lrelu_nhwc(octa_ctx *ctx, const void *d_x, void *d_y, const
  * Replaces the bias-free 3x3 convolutions of DynUNet's UnetBasicBlock / UnetUpBlock (MONAI, imported at
  * models/networks.py:6; configs/config_ves_seg-S.yml:6-13: filters [32,64,128,256,512], strides [1,2,2,2,1])
  * in models/base_model_abc.py:152-167 (octa_conv2d_{fwd,dgrad}).
- * d_x: [N][H][W][Cin] bf16, d_w: [9][Cout][Cin] bf16 (tap = 3*r + s major, Cin fastest), d_y: [N][Ho][Wo][Cout]
+ * d_x: [N][H][W][Cin] bf16, d_w: the weights [tap = 3*r + s][Cout][Cin] bf16 in SLICE-MAJOR storage order -- element (t, co, ci) at
+ * ((ci / 16 * 9 + t) * Cout + co) * 16 + ci % 16, i.e. [Cin/16][9][Cout][16]: the 16 input channels of one MFMA K-step are contiguous
+ * for all taps and output channels (csrc/conv.hip wt_off(); produced by octa_pack_conv_weights / mfma_conv.slice_major()). Every "d_w packed"
+ * of the MFMA entry points below (3x3, 4x4: 16 taps, the stride-2 "up" form, the padded / mirrored form) uses this order. d_y: [N][Ho][Wo][Cout]
  * bf16; padding 1; stride 1 or 2. in_dilation 2 reads d_x through a virtual zero insertion (x[i/2] at even
  * virtual positions, 0 elsewhere; virtual size 2H x 2W): with flipped + transposed weights that is the
  * data gradient of a stride-2 layer, with in_dilation 1 that of a stride-1 layer.
@@ -322,7 +325,8 @@ int octa_head1_nhwc_fwd_b(octa_ctx *ctx, const void *d_x, const float *d_w, cons
  * {src pointer, off_fwd, off_dg, A, B, BP, KK, kind}: kind 0 = Conv2d weight float32 [A][B][K][K] (KK = K*K);
  * kind 1 = ConvTranspose2d(kernel 2, stride 2) weight [A][B][2][2] read as the 3x3 kernel whose taps r = 0 / s = 0 are
  * zero (KK = 9). Written to d_dst (bf16, element offsets): [KK][A][BP] at off_fwd and, taps reversed, [KK][BP][A] at
- * off_dg; columns B..BP-1 (channel padding to the kernels' multiple of 32) are zero. */
+ * off_dg, both in the slice-major storage order described at octa_conv3x3_nhwc_fwd (a layer whose A is no multiple of 16 keeps its
+ * data-gradient pack tap-major: no MFMA kernel reads it); columns B..BP-1 (channel padding to the kernels' multiple of 32) are zero. */
 int octa_pack_conv_weights(octa_ctx *ctx, const int64_t *d_table, int L, void *d_dst, void *stream);
 
 int octa_conv3x3_nhwc_wgrad2(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H, int W,

@@ -56,6 +56,18 @@ __device__ __forceinline__ unsigned short f2bf(float f) { return octa_f2bf(f); }
 // Xv(yy, xx) = X[yy/dil][xx/dil] if 0 <= yy < H*dil, 0 <= xx < W*dil and yy, xx multiples of dil, else 0.
 // EXTRA = false compiles the plain kernel; true adds normalise-on-load and the statistics epilogue (both measured
 // slower in the U-Net step, kept for experiments -- as a template flag they cost the plain kernel nothing).
+// ---- packed weights: SLICE-MAJOR storage (round 5) ------------------------------------------------------------------------------
+// Every kernel below reads its weights 16 input channels at a time (one K-step of v_mfma_f32_32x32x16_bf16) for all taps and a block of
+// output channels. Rounds 1-4 kept them tap-major, [KK][Cout][Cin] with Cin fastest: a 16-channel slice of a row is then 32 bytes out
+// of Cin * 2, every DMA lane group touches its own cache line for 32 useful bytes, and the vector memory path moved twice to four times
+// the bytes the LDS received (measured: the same loads pointed at one contiguous range took 152^2 512->512 from 929 to 1114 TFLOP/s, no
+// loads in the loop 1815). The storage order is now [Cin/16][KK][Cout][16]: the slice (s, all taps, Cout block) of a workgroup is KK
+// contiguous runs of BN * 32 bytes. Element (tap t, output channel co, input channel ci) lives at wt_off(): callers keep passing the
+// nominal shape [KK][Cout][Cin]; mfma_conv.slice_major() / octa_pack_conv_weights produce the order.
+__host__ __device__ __forceinline__ size_t wt_off(int t, int co, int ci, int KK, int Cout) {
+    return (((size_t)(ci >> 4) * KK + t) * Cout + co) * 16 + (ci & 15);
+}
+
 template <int BN, int ST, bool EXTRA, bool MASKED>
 __global__ void __launch_bounds__(CONV_THREADS)
 conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
@@ -128,7 +140,7 @@ conv3x3_nhwc_kernel(const unsigned short *__restrict__ X, const unsigned short *
             const int row = i >> 2, q = i & 3;
             const int tap = row / BN, co = row % BN;
             if (MASKED && !((tap_mask >> tap) & 1)) continue;   // unused taps are neither staged nor multiplied
-            const uint4 v = *reinterpret_cast<const uint4 *>(Wt + ((size_t)tap * Cout + co0 + co) * Cin + c0 + q * 8);
+            const uint4 v = *reinterpret_cast<const uint4 *>(Wt + wt_off(tap, co0 + co, c0 + q * 8, 9, Cout));
             *reinterpret_cast<uint4 *>(s_w + row * PITCH + q * 16) = v;
         }
         __syncthreads();
@@ -321,7 +333,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
 #pragma unroll
     for (int i = 0; i < W_PW; i++) {
         const int slot = (wv + 4 * i) * 64 + lane, rw = slot / PP, q = (slot % PP) ^ glds_swz<PP>(rw);
-        w_src[i] = ((rw / BN) * Cout + co0 + rw % BN) * Cin + q * 8;
+        w_src[i] = (int)wt_off(rw / BN, co0 + rw % BN, q * 8, KS * KS, Cout);      // + the slice: c0 / 16 * (KK * Cout * 16) elements
     }
     // `part` / `nparts`: issue the wave's DMA instructions i with i % nparts == part (all of them for nparts = 1) -- the main loop spreads
     // them between its MFMA groups, so that their issue (M0 write, address, the VMEM slot: 60-180 cycles each) runs in the matrix
@@ -342,7 +354,7 @@ conv3x3_nhwc_glds_kernel(const unsigned short *__restrict__ X, const unsigned sh
         for (int i = 0; i < W_PW; i++) {
             const int j = wv + 4 * i;
             // (a wave-instruction of weights covers 64 / PP rows of ONE tap, BN being a multiple of that: masked taps are not fetched)
-            if ((IN_PW + i) % nparts == part && j < W_INSTR && (!MASKED || ((tap_mask >> (j * (64 / PP) / BN)) & 1))) glds16(Wt + w_src[i] + c0, buf + IN_BYTES + j * 1024);
+            if ((IN_PW + i) % nparts == part && j < W_INSTR && (!MASKED || ((tap_mask >> (j * (64 / PP) / BN)) & 1))) glds16(Wt + w_src[i] + (size_t)c0 * (KS * KS) * Cout, buf + IN_BYTES + j * 1024);
         }
     };
 
@@ -683,7 +695,7 @@ conv3x3_s2t_kernel(const unsigned short *__restrict__ X, const unsigned short *_
 #pragma unroll
     for (int i = 0; i < W_PW; i++) {
         const int slot = (wv + 4 * i) * 64 + lane, rw = slot / PP, q = (slot % PP) ^ glds_swz<PP>(rw);
-        w_src[i] = ((rw / BN) * Cout + co0 + rw % BN) * Cin + q * 8;
+        w_src[i] = (int)wt_off(rw / BN, co0 + rw % BN, q * 8, 9, Cout);
     }
     const unsigned short *img = X + (size_t)n * H * W * Cin;
     auto issue = [&](int c0, unsigned char *buf) {
@@ -698,7 +710,7 @@ conv3x3_s2t_kernel(const unsigned short *__restrict__ X, const unsigned short *_
 #pragma unroll
         for (int i = 0; i < W_PW; i++) {
             const int j = wv + 4 * i;
-            if (j < W_INSTR && ((tap_mask >> (j * (64 / PP) / BN)) & 1)) glds16(Wt + w_src[i] + c0, buf + IN_BYTES + j * 1024);
+            if (j < W_INSTR && ((tap_mask >> (j * (64 / PP) / BN)) & 1)) glds16(Wt + w_src[i] + (size_t)c0 * 9 * Cout, buf + IN_BYTES + j * 1024);
         }
     };
     f32x16 acc[4][RPW][NB];
@@ -1909,8 +1921,8 @@ extern "C" int octa_conv3x3_c1_wgrad(octa_ctx *ctx, const void *d_x, const void 
 
 // ---- every KxK weight of a network into both MFMA layouts, ONE launch per optimiser step ---------------------------
 // The master weights stay torch parameters (float32 [Cout][Cin][K][K]; MONAI / networks.py state-dict layout); the
-// kernels want bf16 "tap-major" [K*K][Cout][CinP] (forward) and [K*K][CinP][Cout] with the taps reversed (data
-// gradient). Packing layer by layer with torch ops costs ~7 tiny launches per layer and step (flip, permute-copy,
+// kernels want bf16 [K*K][Cout][CinP] (forward) and [K*K][CinP][Cout] with the taps reversed (data gradient), both in
+// the slice-major storage order of wt_off(). Packing layer by layer with torch ops costs ~7 tiny launches per layer and step (flip, permute-copy,
 // cast, zero fill: 0.66 ms of the 20.3 ms U-Net step, profiles/r01_train_mfma_kernel_stats.csv); here a table of
 // descriptors drives one launch. HBM-bound, ~6 B per weight element; nothing to tile.
 namespace {
@@ -1939,13 +1951,16 @@ pack_weights_kernel(const long *__restrict__ table, unsigned short *__restrict__
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < pairs; e += (long)gridDim.x * 256) {
         const long a = e / d.BP, b = e % d.BP;
         for (int t = 0; t < KK; t++)
-            dst[d.off_fwd + (long)t * pairs + e] = b < d.B ? f2bf(pack_src(w, a, b, d.B, t, KK, kind)) : (unsigned short)0;
+            dst[d.off_fwd + (long)wt_off(t, (int)a, (int)b, KK, (int)d.A)] = b < d.B ? f2bf(pack_src(w, a, b, d.B, t, KK, kind)) : (unsigned short)0;
     }
-    // data-gradient layout: a fastest (source re-read through L2, stores coalesced), taps reversed
+    // data-gradient layout: a fastest (source re-read through L2, stores coalesced), taps reversed. Its "input channel" is a: a layer whose A is
+    // no multiple of 16 (the PatchGAN's 512 -> 1 head) has no MFMA data gradient and keeps the tap-major order [KK][BP][A]
+    const bool dg_sliced = d.A % 16 == 0;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < pairs; e += (long)gridDim.x * 256) {
         const long b = e / d.A, a = e % d.A;
         for (int t = 0; t < KK; t++)
-            dst[d.off_dg + (long)(KK - 1 - t) * pairs + e] = b < d.B ? f2bf(pack_src(w, a, b, d.B, t, KK, kind)) : (unsigned short)0;
+            dst[d.off_dg + (dg_sliced ? (long)wt_off(KK - 1 - t, (int)b, (int)a, KK, (int)d.BP) : (long)(KK - 1 - t) * pairs + e)] =
+                b < d.B ? f2bf(pack_src(w, a, b, d.B, t, KK, kind)) : (unsigned short)0;
     }
 }
 

@@ -176,8 +176,17 @@ def _planned(w, kind):
     return ent
 
 
+def slice_major(wt):
+    """Tap-major packed weights [KK][Cout][CinP] -> the storage order the kernels read, [CinP/16][KK][Cout][16] (csrc/conv.hip wt_off():
+    the 16 input channels of one MFMA K-step are contiguous for all taps and output channels, so a workgroup's weight slice is whole
+    cache lines). The nominal shape stays [KK][Cout][CinP] -- the tensor is only ever handed to the kernels."""
+    kk, co, cp = wt.shape
+    assert cp % 16 == 0, "packed weights: input channels must be a multiple of 16"
+    return wt.reshape(kk, co, cp // 16, 16).permute(2, 0, 1, 3).contiguous().view(kk, co, cp)
+
+
 def pack_weight(w, cin_pad=None):
-    """[Cout, Cin, K, K] -> [K*K, Cout, CinP] bf16 (CinP = cin_pad or Cin; padded columns zero)."""
+    """[Cout, Cin, K, K] -> [K*K, Cout, CinP] bf16 (CinP = cin_pad or Cin; padded columns zero), stored slice-major (slice_major())."""
     co, ci, kk = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
     cp = ci if cin_pad is None else cin_pad
     plan, i = _planned(w, 0)
@@ -187,7 +196,7 @@ def pack_weight(w, cin_pad=None):
         wp = w.new_zeros((co, cp) + tuple(w.shape[2:]))
         wp[:, :ci] = w
         w = wp
-    return w.permute(2, 3, 0, 1).reshape(kk, co, cp).to(torch.bfloat16).contiguous()
+    return slice_major(w.permute(2, 3, 0, 1).reshape(kk, co, cp).to(torch.bfloat16))
 
 
 def pack_weight_dgrad(w, cin_pad=None):
@@ -201,7 +210,7 @@ def pack_weight_dgrad(w, cin_pad=None):
         wp = w.new_zeros((co, cp) + tuple(w.shape[2:]))
         wp[:, :ci] = w
         w = wp
-    return w.flip(2, 3).permute(2, 3, 1, 0).reshape(kk, cp, co).to(torch.bfloat16).contiguous()
+    return slice_major(w.flip(2, 3).permute(2, 3, 1, 0).reshape(kk, cp, co).to(torch.bfloat16))
 
 
 def pack_convt2x2(w):
@@ -212,8 +221,8 @@ def pack_convt2x2(w):
         return plan.fwd[i], plan.dg[i]
     wc = w.new_zeros((w.shape[0], w.shape[1], 3, 3))
     wc[:, :, 1:, 1:] = w
-    return (wc.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(torch.bfloat16).contiguous(),
-            wc.flip(2, 3).permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]).to(torch.bfloat16).contiguous())
+    return (slice_major(wc.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(torch.bfloat16)),
+            slice_major(wc.flip(2, 3).permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]).to(torch.bfloat16)))
 
 
 def conv3x3_nhwc(x, wt, stride=1, in_dilation=1, tap_mask=0x1ff, residual=None):
@@ -372,7 +381,7 @@ def conv3x3_s2_dgrad(dy, weight):
     wp = (w9[src] * valid[:, :, None, None]).contiguous()                              # [4][9][ci][co]
     dx = torch.empty((n, 2 * ho, 2 * wo, cin), dtype=torch.bfloat16, device=dy.device)
     for p in range(4):
-        _fwd3(dy, wp[p], dx, cout, cin, masks[p], p >> 1, p & 1)
+        _fwd3(dy, slice_major(wp[p]), dx, cout, cin, masks[p], p >> 1, p & 1)
     return dx
 
 
@@ -384,7 +393,7 @@ def conv_transpose_2x2_fwd(x, weight):
     wp[:, 4] = weight.to(torch.bfloat16).permute(2, 3, 1, 0).reshape(4, cout, cin)
     y = torch.empty((n, 2 * h, 2 * w, cout), dtype=torch.bfloat16, device=x.device)
     for p in range(4):
-        _fwd3(x, wp[p], y, cin, cout, 1 << 4, p >> 1, p & 1)
+        _fwd3(x, slice_major(wp[p]), y, cin, cout, 1 << 4, p >> 1, p & 1)
     return y
 
 
@@ -776,7 +785,7 @@ def _t1x1_packs(weight):
         dg = torch.zeros((9, cin, cout), dtype=torch.bfloat16, device=weight.device)
         fwd[4] = wm.t()
         dg[4] = wm
-        c = (key, fwd, dg)
+        c = (key, slice_major(fwd), slice_major(dg))
         weight._octa_t1x1 = c
     return c[1], c[2]
 

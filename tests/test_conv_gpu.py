@@ -337,6 +337,7 @@ def test_parity_fused_up_convolution_equals_the_zero_insertion_form(hip_lib_buil
         if mask != 0x1ff:
             keep = torch.tensor([(mask >> t) & 1 for t in range(9)], device="cuda", dtype=torch.bfloat16)
             wt = wt * keep[:, None, None]
+        wt = mc.slice_major(wt)                  # nominal [9][Cout][Cin] -> the kernels' storage order (the mask names NOMINAL taps)
         res = torch.randn(n, 2 * h, 2 * w, cout, device="cuda", generator=g).to(torch.bfloat16)
         for r in (None, res):
             a = mc.conv3x3_s2t_nhwc(x, wt, mask, r)
