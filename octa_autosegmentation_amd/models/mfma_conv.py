@@ -185,6 +185,12 @@ def slice_major(wt):
     return wt.reshape(kk, co, cp // 16, 16).permute(2, 0, 1, 3).contiguous().view(kk, co, cp)
 
 
+def tap_major(wt):
+    """Inverse of slice_major(): the nominal [KK][Cout][CinP] view of packed weights (tests, debugging)."""
+    kk, co, cp = wt.shape
+    return wt.reshape(cp // 16, kk, co, 16).permute(1, 2, 0, 3).reshape(kk, co, cp)
+
+
 def pack_weight(w, cin_pad=None):
     """[Cout, Cin, K, K] -> [K*K, Cout, CinP] bf16 (CinP = cin_pad or Cin; padded columns zero), stored slice-major (slice_major())."""
     co, ci, kk = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]

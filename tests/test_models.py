@@ -147,8 +147,8 @@ def test_t1x1_packs_follow_the_invalidation_epoch():
     holder.w = w
     mfma_conv.invalidate_all_pack_plans(holder)
     f1, d1 = mfma_conv._t1x1_packs(w)
-    assert f1 is not f0 and torch.equal(f1[4].float(), w.detach().reshape(64, 32).t().to(torch.bfloat16).float())
-    assert torch.equal(d1[4].float(), w.detach().reshape(64, 32).to(torch.bfloat16).float())
+    assert f1 is not f0 and torch.equal(mfma_conv.tap_major(f1)[4].float(), w.detach().reshape(64, 32).t().to(torch.bfloat16).float())
+    assert torch.equal(mfma_conv.tap_major(d1)[4].float(), w.detach().reshape(64, 32).to(torch.bfloat16).float())
 
 
 def test_noise_transforms_match_the_reference_fixture():

@@ -1,13 +1,8 @@
 #!/bin/bash
-# wgrad sensitivity: base / no shifted-B reads (wrong results, timing only) / no in-loop DMA / CW variants
+# wgrad sensitivity to the DMA's address pattern (timing only)
 cd "$(dirname "$0")/.."
 export OCTA_SKIP_TORCH=1
-for v in base wexp1 wexp3 cw1 cw2; do
+for v in ${VARS:-base wexp8}; do
   echo "== $v"
-  case $v in
-    base) python tools/time_conv.py 4 ;;
-    cw1) OCTA_WGRAD_CW=1 python tools/time_conv.py 4 ;;
-    cw2) OCTA_WGRAD_CW=2 python tools/time_conv.py 4 ;;
-    *) OCTA_HIP_LIB=$PWD/gpurun_variants/liboctahip_$v.so python tools/time_conv.py 4 ;;
-  esac 2>&1 | grep wgrad | awk '{print $5, $6, $7, $8, $9}' | paste -sd' '
+  if [ $v = base ]; then python tools/time_conv.py 4; else OCTA_HIP_LIB=$PWD/gpurun_variants/liboctahip_$v.so python tools/time_conv.py 4; fi 2>&1 | grep wgrad | awk '{print $7, $8}' | paste -sd' '
 done
