@@ -368,6 +368,11 @@ int octa_flip_rot90_rotate(octa_ctx *ctx, const float *d_in, float *d_out, int B
  * gradient d_dw float32 [Cout][9] (overwritten). Streaming kernels: 9 multiply-adds per output are not matrix-core work. */
 int octa_conv3x3_c1_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, void *d_y, int N, int H, int W, int Cout, void *stream);
 int octa_conv3x3_c1_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cout, void *stream);
+/* octa_conv3x3_c1_fwd with the InstanceNorm statistics of its result accumulated in the kernel's epilogue: d_stat double [nslot][N][Cout][2]
+ * (pre-zeroed; sum and sum of squares of the bf16-rounded values per image and channel, spread over the slots -- the contract of
+ * octa_conv3x3_nhwc_fwd7, consumed by octa_instnorm_lrelu_nhwc_fwd_s); d_stat NULL = octa_conv3x3_c1_fwd. W <= 3840. */
+int octa_conv3x3_c1_fwd2(octa_ctx *ctx, const void *d_x, const float *d_w, void *d_y, int N, int H, int W, int Cout, double *d_stat, int nslot,
+                         void *stream);
 
 /* ---- DiceBCELoss in one pass each way --------------------
  * utils/losses.py:111-121: (DiceLoss(sigmoid=True) + BCEWithLogitsLoss) / 2 over logits [B][n] (dtype 0 = float32,

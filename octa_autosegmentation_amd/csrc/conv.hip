@@ -1769,152 +1769,241 @@ extern "C" int octa_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d
 }
 
 // ---- first layer: ONE input channel (the grey image) -> Cout channels, 3x3, padding 1, stride 1 ------------------------
-// 9 multiply-adds per output value: not matrix-core work. A thread owns 8 output channels of one pixel (one 16-byte store);
-// forward and weight gradient are single streaming passes over the Cout-channel tensor (HBM-bound), instead of padding the
-// image to 32 zero channels for the MFMA kernels.
+// 9 multiply-adds per output value: not matrix-core work. Forward and weight gradient are single streaming passes over the Cout-channel
+// tensor (HBM-bound) instead of padding the image to 32 zero channels for the MFMA kernels. Round 5 rewrite of both (rounds 1-4: 333
+// vector instructions per 8-channel item around 72 FMAs -- bounds tests and 64-bit addresses of nine 2-byte global loads per item, the
+// weights read from LDS per FMA; 0.178 ms forward / 0.205 ms weight gradient at 4 x 1216^2 x 32, i.e. 2 TB/s): a workgroup now owns a
+// band of image rows (c1_band()), stages band + halo ONCE as floats with zero borders in LDS (16-byte global loads), a thread owns 8 output
+// channels (weights / accumulators in registers) of pixels 64 / groups apart, so a wave's 16-byte stores / loads of the big tensor are 1 KB
+// contiguous and the inner loop is LDS reads + FMAs only.
 namespace {
 
 __device__ __forceinline__ float bfu(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(256)
-conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restrict__ Wf /* [Cout][9] */, unsigned short *__restrict__ Y,
-                      int N, int H, int W, int Cout) {
-    // VALU-bound (333 vector instructions per 8-channel item: bounds checks, 64-bit addresses, bf16 rounding around 72 FMAs).
-    // Tap-major weights read as 16-byte LDS pieces were measured SLOWER (0.217 vs 0.179 ms at 4 x 1216^2 x 32): the LDS was not
-    // the limiter; weights in registers were slower too (97 VGPRs, fewer waves in flight).
-    extern __shared__ float s_wf[];   // [Cout][9]
-    for (int i = threadIdx.x; i < Cout * 9; i += 256) s_wf[i] = Wf[i];
-    __syncthreads();
-    const int groups = Cout / 8, gshift = 31 - __clz(groups);   // groups is a power of two: no integer divisions per item
-    for (int row = blockIdx.x; row < N * H; row += gridDim.x)
-    for (int j = threadIdx.x; j < W * groups; j += 256) {
-        const int q = j & (groups - 1), x = j >> gshift, y = row % H;
-        const long n = row / H, p = (long)row * W + x;
-        float in[9];
+constexpr int C1_BAND_MAX = 8;   // image rows per workgroup, at most
+// Rows per workgroup: the launch should fill the chip's resident slots once (four 256-thread workgroups per CU by registers) -- the kernels
+// stream, so waves in flight are bytes in flight (4 x 1216^2: 8 rows = 608 workgroups = 2.4 waves per SIMD, 5 rows = 976 = 3.8)
+int c1_band(const octa_ctx *ctx, int N, int H) {
+    long b = ((long)N * H + 4L * ctx->num_cus - 1) / (4L * ctx->num_cus);
+    return (int)(b < 2 ? 2 : (b > C1_BAND_MAX ? C1_BAND_MAX : b));
+}
+
+// rows y0-1 .. y0+rows of image n as floats into s_x[(rows + 2)][W + 2] (column 0 / W+1 and rows outside the image: zero)
+__device__ __forceinline__ void c1_stage_band(const unsigned short *__restrict__ X, float *s_x, long n, int y0, int rows, int H, int W) {
+    const int WP = W + 2;
+    if (W % 8 == 0) {
+        const int pieces = W / 8;
+        for (int i = threadIdx.x; i < (rows + 2) * pieces; i += 256) {
+            const int r = i / pieces, xq = i % pieces, yy = y0 + r - 1;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (yy >= 0 && yy < H) v = *reinterpret_cast<const uint4 *>(X + (n * H + yy) * W + xq * 8);
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+            float *d = s_x + r * WP + 1 + xq * 8;
 #pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int s = 0; s < 3; s++) {
-                const int yy = y + r - 1, xx = x + s - 1;
-                in[3 * r + s] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
-            }
-        unsigned o[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int t = 0; t < 9; t++) { a0 += in[t] * s_wf[(q * 8 + 2 * k) * 9 + t]; a1 += in[t] * s_wf[(q * 8 + 2 * k + 1) * 9 + t]; }
-            o[k] = octa_pack_bf16x2(a0, a1);
+            for (int k = 0; k < 4; k++) { d[2 * k] = __uint_as_float(u[k] << 16); d[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
         }
-        *reinterpret_cast<uint4 *>(Y + p * Cout + q * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int i = threadIdx.x; i < (rows + 2) * 2; i += 256) s_x[(i >> 1) * WP + (i & 1) * (W + 1)] = 0.f;
+    } else {
+        for (int i = threadIdx.x; i < (rows + 2) * WP; i += 256) {
+            const int r = i / WP, xx = i % WP - 1, yy = y0 + r - 1;
+            s_x[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
+        }
     }
 }
 
-constexpr int C1_ROWS = 4;   // output rows per staging step of the weight gradient
-
+// stat != nullptr: also the InstanceNorm statistics of the result -- sum and sum of squares of the bf16-ROUNDED values per image and channel,
+// added (double atomics) to slot blockIdx.x % nslot of stat[nslot][N][Cout][2] (pre-zeroed; the slot form of conv3x3_nhwc_glds_kernel): the
+// norm that follows needs no statistics pass over the tensor.
 __global__ void __launch_bounds__(256)
-conv3x3_c1_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ dY, float *__restrict__ dW /* [Cout][9] */,
-                        int N, int H, int W, int Cout) {
+conv3x3_c1_fwd_kernel(const unsigned short *__restrict__ X, const float *__restrict__ Wf /* [Cout][9] */, unsigned short *__restrict__ Y,
+                      int H, int W, int Cout, double *__restrict__ stat, int nslot, int C1_BAND) {
     extern __shared__ float s_mem[];
-    float *s_acc = s_mem;                 // [Cout][9]
-    float *s_x = s_mem + Cout * 9;        // [C1_ROWS + 2][W + 2]: image rows y0-1 .. y0+C1_ROWS with zero borders
-    for (int i = threadIdx.x; i < Cout * 9; i += 256) s_acc[i] = 0.f;
-    const int groups = Cout / 8, gshift = 31 - __clz(groups);
-    float acc[8][9];
+    float *s_x = s_mem;                                  // [C1_BAND + 2][W + 2]
+    const int groups = Cout / 8, gshift = 31 - __clz(groups);   // groups is a power of two dividing 64
+    const int q = threadIdx.x & (groups - 1), pix0 = threadIdx.x >> gshift, ppi = 256 >> gshift;   // pixels per block-iteration
+    const long n = blockIdx.y;
+    const int y0 = blockIdx.x * C1_BAND, rows = H - y0 < C1_BAND ? H - y0 : C1_BAND, WP = W + 2;
+    // channel pairs as 2-vectors: v_pk_fma_f32 multiplies both by the (broadcast) pixel in one instruction -- 36 instead of 72 per item
+    f32x2 wr[4][9];
 #pragma unroll
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int t = 0; t < 9; t++) acc[k][t] = 0.f;
-    // 256 is a multiple of `groups`, so a thread keeps its channel group q for the whole loop
-    const int q = threadIdx.x & (groups - 1);
-    const int items = W * groups, WP = W + 2;
-    const int HG = (H + C1_ROWS - 1) / C1_ROWS;       // row groups per image: one barrier pair and one staging pass per C1_ROWS rows
-    for (int grp = blockIdx.x; grp < N * HG; grp += gridDim.x) {
-        const int y0 = (grp % HG) * C1_ROWS;
-        const long n = grp / HG;
-        const int rows = H - y0 < C1_ROWS ? H - y0 : C1_ROWS;
-        __syncthreads();
-        for (int r = 0; r < rows + 2; r++) {
-            const int yy = y0 + r - 1;
-            const bool in_y = yy >= 0 && yy < H;
-            for (int i = threadIdx.x; i < WP; i += 256) {
-                const int xx = i - 1;
-                s_x[r * WP + i] = (in_y && xx >= 0 && xx < W) ? bfu(X[(n * H + yy) * W + xx]) : 0.f;
+        for (int t = 0; t < 9; t++) { wr[k][t].x = Wf[(q * 8 + 2 * k) * 9 + t]; wr[k][t].y = Wf[(q * 8 + 2 * k + 1) * 9 + t]; }
+    c1_stage_band(X, s_x, n, y0, rows, H, W);
+    __syncthreads();
+    float s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { s1[k] = 0.f; s2[k] = 0.f; }
+    for (int rr = 0; rr < rows; rr++) {
+        const float *sx = s_x + rr * WP;
+        unsigned short *yrow = Y + ((n * H + y0 + rr) * W) * Cout + q * 8;
+        for (int x = pix0; x < W; x += ppi) {
+            float in[9];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) in[3 * r + c] = sx[r * WP + x + c];
+            unsigned o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                f32x2 a = {0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 9; t++) { const f32x2 i2 = {in[t], in[t]}; a = __builtin_elementwise_fma(i2, wr[k][t], a); }
+                o[k] = octa_pack_bf16x2(a.x, a.y);
+                const float r0 = __uint_as_float(o[k] << 16), r1 = __uint_as_float(o[k] & 0xffff0000u);
+                s1[2 * k] += r0; s2[2 * k] += r0 * r0; s1[2 * k + 1] += r1; s2[2 * k + 1] += r1 * r1;
             }
+            *reinterpret_cast<uint4 *>(yrow + (long)x * Cout) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (stat) {
+        // lanes with the same channel group: lane % groups; then the four waves through LDS, one pair of double atomics per channel
+        __syncthreads();                                  // the band is consumed: its LDS is reused
+        float *s_red = s_mem;                             // [4 waves][Cout][2]
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float a = s1[k], b = s2[k];
+            for (int dlt = groups; dlt < 64; dlt <<= 1) { a += __shfl_xor(a, dlt, 64); b += __shfl_xor(b, dlt, 64); }
+            if ((int)(threadIdx.x & 63) < groups) { s_red[((threadIdx.x >> 6) * Cout + q * 8 + k) * 2] = a; s_red[((threadIdx.x >> 6) * Cout + q * 8 + k) * 2 + 1] = b; }
         }
         __syncthreads();
-        for (int rr = 0; rr < rows; rr++) {
-            const long row = n * H + y0 + rr;
-            const float *sx = s_x + rr * WP;
-            // two 16-byte pieces of dY per trip, both loads issued before either is used
-            for (int j = threadIdx.x; j < items; j += 512) {
-                const int x0 = j >> gshift, j1 = j + 256, x1 = j1 >> gshift;
-                const bool has1 = j1 < items;
-                const uint4 v0 = *reinterpret_cast<const uint4 *>(dY + (row * W + x0) * Cout + q * 8);
-                const uint4 v1 = *reinterpret_cast<const uint4 *>(dY + (row * W + (has1 ? x1 : x0)) * Cout + q * 8);
+        if ((int)threadIdx.x < Cout) {
+            float a = 0.f, b = 0.f;
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    if (h == 1 && !has1) break;
-                    const int x = h ? x1 : x0;
-                    const uint4 v = h ? v1 : v0;
-                    const unsigned u[4] = {v.x, v.y, v.z, v.w};
-                    float d[8];
+            for (int w4 = 0; w4 < 4; w4++) { a += s_red[(w4 * Cout + threadIdx.x) * 2]; b += s_red[(w4 * Cout + threadIdx.x) * 2 + 1]; }
+            double *dst = stat + (((size_t)(blockIdx.x % nslot) * gridDim.y + n) * Cout + threadIdx.x) * 2;
+            atomicAdd(dst, (double)a);
+            atomicAdd(dst + 1, (double)b);
+        }
+    }
+}
+
+// dW[co][t] = sum over the pixels of dY[p][co] * X[p + t]: per workgroup one band; partial sums [band][Cout][9] go to a workspace and are
+// folded by c1_wgrad_reduce_kernel (rounds 1-4: one atomicAdd per workgroup and weight into 288 addresses -- 1216 workgroups queueing on each)
+__global__ void __launch_bounds__(256)
+conv3x3_c1_wgrad_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ dY, float *__restrict__ ws /* [gridDim.y * gridDim.x][Cout][9] */,
+                        int H, int W, int Cout, int C1_BAND) {
+    extern __shared__ float s_mem[];
+    float *s_x = s_mem;                                  // [C1_BAND + 2][W + 2]
+    const int groups = Cout / 8, gshift = 31 - __clz(groups);
+    const int q = threadIdx.x & (groups - 1), pix0 = threadIdx.x >> gshift, ppi = 256 >> gshift;
+    const long n = blockIdx.y;
+    const int y0 = blockIdx.x * C1_BAND, rows = H - y0 < C1_BAND ? H - y0 : C1_BAND, WP = W + 2;
+    f32x2 acc[4][9];                                     // channel pairs: v_pk_fma_f32
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { d[2 * k] = __uint_as_float(u[k] << 16); d[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+    for (int k = 0; k < 4; k++)
 #pragma unroll
-                    for (int r = 0; r < 3; r++)
+        for (int t = 0; t < 9; t++) acc[k][t] = f32x2{0.f, 0.f};
+    c1_stage_band(X, s_x, n, y0, rows, H, W);
+    __syncthreads();
+    for (int rr = 0; rr < rows; rr++) {
+        const float *sx = s_x + rr * WP;
+        const unsigned short *drow = dY + ((n * H + y0 + rr) * W) * Cout + q * 8;
+        // four 16-byte pieces of dY per trip, all loads issued before any is used (three workgroups of 48 KB per CU: the bytes in flight
+        // per wave decide how much of the HBM latency is covered)
+        for (int x = pix0; x < W; x += 4 * ppi) {
+            uint4 v[4];
 #pragma unroll
-                        for (int s = 0; s < 3; s++) {
-                            const float in = sx[r * WP + x + s];
+            for (int h = 0; h < 4; h++) { const int xx = x + h * ppi; v[h] = *reinterpret_cast<const uint4 *>(drow + (long)(xx < W ? xx : x) * Cout); }
 #pragma unroll
-                            for (int k = 0; k < 8; k++) acc[k][3 * r + s] += d[k] * in;
-                        }
-                }
+            for (int h = 0; h < 4; h++) {
+                const int xx = x + h * ppi;
+                if (xx >= W) break;
+                const unsigned u[4] = {v[h].x, v[h].y, v[h].z, v[h].w};
+                f32x2 d[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { d[k].x = __uint_as_float(u[k] << 16); d[k].y = __uint_as_float(u[k] & 0xffff0000u); }
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float in = sx[r * WP + xx + c];
+                        const f32x2 i2 = {in, in};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) acc[k][3 * r + c] = __builtin_elementwise_fma(d[k], i2, acc[k][3 * r + c]);
+                    }
             }
         }
     }
+    __syncthreads();
+    float *s_red = s_mem;                                 // [4 waves][Cout][9]
 #pragma unroll
     for (int k = 0; k < 8; k++)
 #pragma unroll
         for (int t = 0; t < 9; t++) {
-            float a = acc[k][t];
-            // lanes with the same channel group: lane % groups (groups divides 64 for Cout in {8, 16, 32, 64})
+            float a = (k & 1) ? acc[k >> 1][t].y : acc[k >> 1][t].x;
             for (int dlt = groups; dlt < 64; dlt <<= 1) a += __shfl_xor(a, dlt, 64);
-            if ((int)(threadIdx.x & 63) < groups) atomicAdd(&s_acc[(q * 8 + k) * 9 + t], a);
+            if ((int)(threadIdx.x & 63) < groups) s_red[((threadIdx.x >> 6) * Cout + q * 8 + k) * 9 + t] = a;
         }
     __syncthreads();
-    for (int i = threadIdx.x; i < Cout * 9; i += 256) atomicAdd(&dW[i], s_acc[i]);
+    float *mine = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * Cout * 9;
+    for (int i = threadIdx.x; i < Cout * 9; i += 256) mine[i] = (s_red[i] + s_red[Cout * 9 + i]) + (s_red[2 * Cout * 9 + i] + s_red[3 * Cout * 9 + i]);
+}
+
+// dW[e] = sum of the bands' partial sums: 16 outputs x 16 slices of the partials per workgroup (a thread per output alone walks a
+// dependent chain of 600 loads: 43 us)
+__global__ void __launch_bounds__(256)
+c1_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dW, int total, int parts) {
+    __shared__ float s_p[256];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4, e = blockIdx.x * 16 + el;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < total) {
+        int g = sl;
+        for (; g + 16 < parts; g += 32) { s0 += ws[(size_t)g * total + e]; s1 += ws[(size_t)(g + 16) * total + e]; }
+        if (g < parts) s0 += ws[(size_t)g * total + e];
+    }
+    s_p[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < 16 && e < total) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) a += s_p[k * 16 + threadIdx.x];
+        dW[e] = a;
+    }
 }
 
 }  // namespace
 
-extern "C" int octa_conv3x3_c1_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, void *d_y, int N, int H, int W, int Cout, void *stream_) {
+// d_stat / nslot: optional InstanceNorm statistics of the result in slot form (see conv3x3_c1_fwd_kernel; octa_conv3x3_nhwc_fwd7's contract)
+extern "C" int octa_conv3x3_c1_fwd2(octa_ctx *ctx, const void *d_x, const float *d_w, void *d_y, int N, int H, int W, int Cout, double *d_stat,
+                                    int nslot, void *stream_) {
     if (!ctx || !d_x || !d_w || !d_y || N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_c1_fwd: bad arguments"); return -2; }
     if (Cout != 8 && Cout != 16 && Cout != 32 && Cout != 64) { octa::set_error("octa_conv3x3_c1_fwd: Cout must be 8, 16, 32 or 64"); return -2; }
+    if (W > 3840 || N > 65535) { octa::set_error("octa_conv3x3_c1_fwd: W > 3840 or N > 65535"); return -2; }
+    if (d_stat && nslot <= 0) { octa::set_error("octa_conv3x3_c1_fwd: statistics need nslot >= 1"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
-    long blocks = (long)N * H;
-    if (blocks > 32L * ctx->num_cus) blocks = 32L * ctx->num_cus;
-    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * Cout * 9, stream, static_cast<const unsigned short *>(d_x),
-                       d_w, static_cast<unsigned short *>(d_y), N, H, W, Cout);
+    const int band = c1_band(ctx, N, H);
+    size_t lds = sizeof(float) * (size_t)(band + 2) * (W + 2);
+    if (lds < sizeof(float) * 4 * Cout * 2) lds = sizeof(float) * 4 * Cout * 2;
+    OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c1_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel, dim3((unsigned)((H + band - 1) / band), (unsigned)N), dim3(256), lds, stream,
+                       static_cast<const unsigned short *>(d_x), d_w, static_cast<unsigned short *>(d_y), H, W, Cout, d_stat, nslot, band);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+extern "C" int octa_conv3x3_c1_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, void *d_y, int N, int H, int W, int Cout, void *stream_) {
+    return octa_conv3x3_c1_fwd2(ctx, d_x, d_w, d_y, N, H, W, Cout, nullptr, 0, stream_);
 }
 
 extern "C" int octa_conv3x3_c1_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cout, void *stream_) {
     if (!ctx || !d_x || !d_dy || !d_dw || N <= 0 || H <= 0 || W <= 0) { octa::set_error("octa_conv3x3_c1_wgrad: bad arguments"); return -2; }
     if (Cout != 8 && Cout != 16 && Cout != 32 && Cout != 64) { octa::set_error("octa_conv3x3_c1_wgrad: Cout must be 8, 16, 32 or 64"); return -2; }
+    if (W > 3840 || N > 65535) { octa::set_error("octa_conv3x3_c1_wgrad: W > 3840 or N > 65535"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
-    OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * Cout * 9, stream));
-    const int groups = Cout / 8;
-    long blocks = 8L * ctx->num_cus;
-    const long row_groups = (long)N * ((H + C1_ROWS - 1) / C1_ROWS);
-    if (blocks > row_groups) blocks = row_groups;
-    (void)groups;   // gridDim.x * 256 is a multiple of `groups` for any block count (256 % groups == 0)
-    if (W > 4096) { octa::set_error("octa_conv3x3_c1_wgrad: W > 4096"); return -2; }
-    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * (Cout * 9 + (C1_ROWS + 2) * (W + 2)), stream, static_cast<const unsigned short *>(d_x),
-                       static_cast<const unsigned short *>(d_dy), d_dw, N, H, W, Cout);
+    const int band = c1_band(ctx, N, H), bands = (H + band - 1) / band, parts = bands * N, total = Cout * 9;
+    if (ctx->wgrad_ws.reserve((size_t)parts * total * sizeof(float))) return -1;
+    float *ws = ctx->wgrad_ws.as<float>();
+    size_t lds = sizeof(float) * (size_t)(band + 2) * (W + 2);
+    if (lds < sizeof(float) * 4 * total) lds = sizeof(float) * 4 * total;
+    OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c1_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3((unsigned)bands, (unsigned)N), dim3(256), lds, stream, static_cast<const unsigned short *>(d_x),
+                       static_cast<const unsigned short *>(d_dy), ws, H, W, Cout, band);
+    OCTA_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, ws, d_dw, total, parts);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -561,26 +561,36 @@ def conv3x3_reflect(x, weight):
 
 
 class _Conv3x3C1(torch.autograd.Function):
-    """First layer: one input channel (no data gradient: the input is the image)."""
+    """First layer: one input channel (no data gradient: the input is the image). want_stats: also the InstanceNorm statistics of the
+    result in slot form (double [STAT_SLOTS][N][Cout][2], accumulated by the kernel's epilogue: the norm needs no statistics pass)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats=False):
         x = x.contiguous()
         n, h, w, _ = x.shape
         cout = weight.shape[0]
+        ctx.set_materialize_grads(False)
         wf = weight.reshape(cout, 9).float().contiguous()
         y = torch.empty((n, h, w, cout), dtype=torch.bfloat16, device=x.device)
-        rc = _native.lib().octa_conv3x3_c1_fwd(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wf.data_ptr()),
-                                               ctypes.c_void_p(y.data_ptr()), n, h, w, cout, _native.current_stream_ptr())
-        _native.check(rc, "octa_conv3x3_c1_fwd")
+        part = _stat_slots(x.device, n, cout) if want_stats else None
+        rc = _native.lib().octa_conv3x3_c1_fwd2(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wf.data_ptr()),
+                                                ctypes.c_void_p(y.data_ptr()), n, h, w, cout,
+                                                ctypes.c_void_p(part.data_ptr()) if part is not None else None, STAT_SLOTS if part is not None else 0,
+                                                _native.current_stream_ptr())
+        _native.check(rc, "octa_conv3x3_c1_fwd2")
         ctx.save_for_backward(x)
         ctx.w_shape, ctx.w_dtype = weight.shape, weight.dtype
         ctx.weight_ref = weight
+        if want_stats:
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpart=None):
         (x,) = ctx.saved_tensors
+        if dy is None:
+            return None, None, None
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
@@ -592,15 +602,16 @@ class _Conv3x3C1(torch.autograd.Function):
                                                      ctypes.c_void_p(dw.data_ptr()), n, h, w, cout, _native.current_stream_ptr())
             _native.check(rc, "octa_conv3x3_c1_wgrad")
             return dw.view(ctx.w_shape).to(ctx.w_dtype)
-        return None, _wgrad_to(ctx.weight_ref, wg, x, dy)
+        return None, _wgrad_to(ctx.weight_ref, wg, x, dy), None
 
 
 def conv3x3(x, weight, stride=1, want_stats=False, mailbox=None):
+    """want_stats: also return the statistics for instance_norm_leaky_relu_nhwc(..., partials=)."""
     if (x.shape[-1] == 1 and weight.shape[1] == 1 and stride == 1 and weight.shape[0] in (8, 16, 32, 64)
-            and not x.requires_grad):
-        y = _Conv3x3C1.apply(x, weight)              # streaming first-layer kernels: no statistics epilogue (None = the
-        return (y, None) if want_stats else y        # norm runs its own statistics pass)
-    """want_stats: also return the per-tile statistics for instance_norm_leaky_relu_nhwc(..., partials=)."""
+            and not x.requires_grad and x.shape[2] <= 3840):
+        if want_stats == "tiles":                        # the per-tile form belongs to the MFMA kernel: the norm runs its own statistics pass
+            return _Conv3x3C1.apply(x, weight, False), None
+        return _Conv3x3C1.apply(x, weight, bool(want_stats))          # streaming first-layer kernels
     return _Conv3x3NHWC.apply(x, weight, stride, want_stats, mailbox)
 
 

@@ -564,3 +564,36 @@ def test_pack_plan_survives_data_writes_through_init_weights(hip_lib_built):
         c = ref(x).float()
     assert not torch.equal(a, b)
     assert torch.equal(b, c)
+
+
+@pytest.mark.gpu
+def test_first_layer_kernels_match_torch(hip_lib_built):
+    """The one-input-channel 3x3 layer (round 5 rewrite: band staged in LDS, weights / accumulators in registers, statistics epilogue,
+    weight gradient through a workspace): result, statistics slots and weight gradient against torch fp32 on the same bf16-rounded
+    operands. Widths that are no multiple of 8 (scalar staging), heights that are no multiple of the band, every supported Cout."""
+    import torch
+    import torch.nn.functional as F
+    from octa_autosegmentation_amd.models import mfma_conv as mc
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (n, h, w, cout) in ((2, 19, 40, 32), (1, 9, 37, 8), (3, 33, 130, 64), (1, 64, 96, 16), (2, 152, 152, 32)):
+        x = torch.rand(n, h, w, 1, device="cuda", generator=g).to(torch.bfloat16)
+        wt = (torch.randn(cout, 1, 3, 3, device="cuda", generator=g) / 3.0).requires_grad_(True)
+        y, part = mc.conv3x3(x, wt, 1, True)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.detach(), padding=1).permute(0, 2, 3, 1)
+        scale = ref.abs().max().item()
+        assert y.shape == ref.shape and y.dtype == torch.bfloat16
+        assert (y.float() - ref).abs().max().item() <= 2.0 ** -8 * scale + 1e-6
+        # statistics: sums of the ROUNDED values per image and channel, spread over the slots
+        assert part.dtype == torch.float64 and part.shape == (mc.STAT_SLOTS, n, cout, 2)
+        tot = part.sum(0)
+        yf = y.double()
+        assert torch.allclose(tot[..., 0], yf.sum((1, 2)), rtol=1e-5, atol=1e-3 * scale)
+        assert torch.allclose(tot[..., 1], (yf * yf).sum((1, 2)), rtol=1e-5, atol=1e-3 * scale * scale)
+        y_plain = mc.conv3x3(x, wt, 1, False)
+        assert torch.equal(y_plain, y)
+        # weight gradient
+        dy = torch.randn(n, h, w, cout, device="cuda", generator=g).to(torch.bfloat16)
+        (gw,) = torch.autograd.grad(y, wt, dy)
+        w2 = wt.detach().clone().requires_grad_(True)
+        (gr,) = torch.autograd.grad(F.conv2d(x.float().permute(0, 3, 1, 2), w2, padding=1), w2, dy.float().permute(0, 3, 1, 2))
+        assert (gw - gr).abs().max().item() <= 2e-4 * gr.abs().max().item() + 1e-5, (n, h, w, cout)
