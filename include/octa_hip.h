@@ -274,6 +274,16 @@ int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const void *d_x2, i
                              int Cin, int Cout, int stride, int tap_mask, const float *d_scale1, const float *d_shift1,
                              const float *d_scale2, const float *d_shift2, float slope, void *stream);
 
+/* The weight gradient ADDED to a gradient buffer in the parameter's own layout, float32 [Cout][Cin][3][3] (models/networks.py / MONAI
+ * state-dict layout; base_model_abc.py:152-167's `loss.backward()` accumulates into exactly this tensor): the training step passes
+ * `weight.grad`, a view of its flat gradient arena -- no [9][Cout][Cin] temporary, fill, layout copy or accumulation launch per layer.
+ * Operands as octa_conv3x3_nhwc_wgrad4 without the normalise-on-load vectors (stride 1, or 2 with even H, W); taps outside tap_mask add
+ * zero. octa_conv3x3_nhwc_wgrad_pad_acc: the same for octa_conv3x3_nhwc_wgrad_pad. */
+int octa_conv3x3_nhwc_wgrad_acc(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_grad, int N, int H, int W,
+                                int Cin, int Cout, int stride, int tap_mask, int accumulate, void *stream);
+int octa_conv3x3_nhwc_wgrad_pad_acc(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_grad, int N, int H, int W, int Cin, int Cout,
+                                    int pad, int reflect, int accumulate, void *stream);
+
 /* Weight gradient of the stride-1 layer above: d_dw [9][Cout][Cin] float32 (overwritten) =
  * sum over pixels of d_dy[N][H][W][Cout] (bf16) x d_x[N][H][W][Cin] (bf16) shifted by the tap (SURVEY.md 8b:
  * octa_conv2d_wgrad). fp32 accumulation; partial sums of the persistent workgroups meet in fp32 atomics, so the

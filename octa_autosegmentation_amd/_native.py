@@ -94,6 +94,8 @@ SIGNATURES = {
     "octa_dice_bce_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p, c_void_p]),
     "octa_dice_bce_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]),
     "octa_conv3x3_c1_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "octa_conv3x3_nhwc_wgrad_acc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "octa_conv3x3_nhwc_wgrad_pad_acc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_conv3x3_c1_fwd2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "octa_conv3x3_c1_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_conv_stat_tiles": (c_int, [c_int, c_int]),

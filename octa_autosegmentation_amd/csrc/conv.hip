@@ -1491,9 +1491,42 @@ wgrad_tr_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dW, int
     dW[e] = (s0 + s1) + (s2 + s3);
 }
 
+// The partial tiles of the workspace summed STRAIGHT into a gradient buffer in the parameter's own layout, [Cout][Cin][3][3] float32
+// (torch / MONAI state-dict layout), ADDING to what it holds: the training step hands `weight.grad` (a view of the flat gradient arena,
+// cleared once per step) -- no [9][Cout][Cin] temporary, no fill, no layout copy, no autograd accumulation launch per layer (round 5:
+// 21 copies + 15 fills per U-Net step). A workgroup owns (co, 32 ci, all taps): coalesced reads of the partials (ci fastest), an LDS
+// transposition, 288 contiguous floats out. gridDim.z > 1 (many partials: the 1216^2 layers, 512 workgroups): slices of the partials,
+// folded by atomics. accumulate = 0: the buffer is overwritten (cleared first where the slices need atomics).
+template <int COB, int CIB>
+__global__ void __launch_bounds__(288)
+wgrad_tr_acc_kernel(const float *__restrict__ ws, float *__restrict__ grad, int Cin, int Cout, int per_block, int accumulate) {
+    constexpr int PAIRS = (COB / 32) * (CIB / 32);
+    __shared__ float s_t[32][10];
+    const int t = threadIdx.x >> 5, cil = threadIdx.x & 31;
+    const int co = blockIdx.x, ci = blockIdx.y * 32 + cil;
+    const int blk = (co / COB) * (Cin / CIB) + ci / CIB;
+    const int pair = (co % COB) / 32 + (COB / 32) * ((ci % CIB) / 32);
+    const int chunk = (per_block + (int)gridDim.z - 1) / (int)gridDim.z, g0 = blockIdx.z * chunk, g1 = g0 + chunk < per_block ? g0 + chunk : per_block;
+    const float *p = ws + ((size_t)blk * per_block * PAIRS + pair) * (9 * 32 * 32) + (t * 32 + co % 32) * 32 + ci % 32;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = g0;
+    for (; g + 3 < g1; g += 4) {
+        s0 += p[(size_t)g * PAIRS * (9 * 32 * 32)];
+        s1 += p[(size_t)(g + 1) * PAIRS * (9 * 32 * 32)];
+        s2 += p[(size_t)(g + 2) * PAIRS * (9 * 32 * 32)];
+        s3 += p[(size_t)(g + 3) * PAIRS * (9 * 32 * 32)];
+    }
+    for (; g < g1; g++) s0 += p[(size_t)g * PAIRS * (9 * 32 * 32)];
+    s_t[cil][t] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    float *out = grad + ((size_t)co * Cin + blockIdx.y * 32) * 9 + threadIdx.x;      // element (ci = threadIdx.x / 9, tap = threadIdx.x % 9) of this run
+    const float v = s_t[threadIdx.x / 9][threadIdx.x % 9];
+    if (gridDim.z > 1) atomicAdd(out, v); else if (accumulate) *out += v; else *out = v;
+}
+
 template <int COB, int CIB, int ST = 1>
 int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short *X2, int C1, const unsigned short *dY, float *dW, int N, int H, int W, int Cin,
-                    int Cout, int num_cus, int tap_mask, const unsigned short *zero16, hipStream_t stream, int pad = 1, int reflect = 0) {
+                    int Cout, int num_cus, int tap_mask, const unsigned short *zero16, hipStream_t stream, int pad = 1, int reflect = 0, float *acc = nullptr, int accumulate = 1) {
     // stride 1: 64 x 64 blocks: the 8-row double buffer fits one CU (152 KB); 32 x 32: two workgroups of 76 KB; the mixed blocks keep 4 rows
     // and two workgroups. Stride 2 (a 9 x 66-pixel halo per 4 output rows): 4 rows, one workgroup per CU
     constexpr int TH_ = (ST == 1 && COB == CIB) ? 8 : 4;
@@ -1515,7 +1548,7 @@ int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short
     // (Measured with the atomics removed altogether: 0.188 / 0.112 / 0.408 ms for 1216^2 32->32 / 152^2 256->256 / 512->512.)
     static const int ws_from = [] { const char *e = getenv("OCTA_WGRAD_WS"); return e ? atoi(e) : 16; }();
     float *ws = nullptr;
-    if (ws_from > 0 && per_block >= ws_from && per_block <= 64) {
+    if (acc || (ws_from > 0 && per_block >= ws_from && per_block <= 64)) {      // acc: always through the workspace (wgrad_tr_acc_kernel folds it)
         if (ctx->wgrad_ws.reserve((size_t)blocks * per_block * PAIRS_ * 9 * 32 * 32 * sizeof(float))) return -1;
         ws = ctx->wgrad_ws.as<float>();
     } else {
@@ -1528,7 +1561,12 @@ int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short
     hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Ho, Wo, Cin, Cout,
                        tiles_x, tiles_y, tap_mask, zero16, ws, pad);
     OCTA_HIP_CHECK(hipGetLastError());
-    if (ws) {
+    if (acc) {
+        const int slices = per_block > 64 ? (per_block / 32 < 16 ? per_block / 32 : 16) : 1;
+        if (!accumulate && slices > 1) OCTA_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * 9 * (size_t)Cout * Cin, stream));
+        hipLaunchKernelGGL((wgrad_tr_acc_kernel<COB, CIB>), dim3((unsigned)Cout, (unsigned)(Cin / 32), (unsigned)slices), dim3(288), 0, stream, ws, acc, Cin, Cout, per_block, accumulate);
+        OCTA_HIP_CHECK(hipGetLastError());
+    } else if (ws) {
         const int total = 9 * Cout * Cin;
         hipLaunchKernelGGL((wgrad_tr_reduce_kernel<COB, CIB>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ws, dW, Cin, Cout, per_block);
         OCTA_HIP_CHECK(hipGetLastError());
@@ -1569,9 +1607,10 @@ int launch_wgrad(const unsigned short *X, const unsigned short *X2, int C1, cons
 
 }  // namespace
 
-extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
-                                        int W, int Cin, int Cout, int stride, int tap_mask, const float *d_scale1, const float *d_shift1,
-                                        const float *d_scale2, const float *d_shift2, float slope, void *stream_) {
+// acc: d_dw is a gradient buffer in the PARAMETER layout [Cout][Cin][3][3] that receives the result ADDED to its contents (wgrad_tr_acc_kernel)
+static int wgrad4_impl(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
+                       int W, int Cin, int Cout, int stride, int tap_mask, const float *d_scale1, const float *d_shift1,
+                       const float *d_scale2, const float *d_shift2, float slope, void *stream_, int acc /* 0: d_dw [9][Cout][Cin]; 1: add to / 2: overwrite a parameter-layout buffer */) {
     if (!ctx || !d_x || !d_dy || !d_dw) { octa::set_error("octa_conv3x3_nhwc_wgrad: null pointer"); return -2; }
     tap_mask &= 0x1ff;
     if (tap_mask == 0) { octa::set_error("octa_conv3x3_nhwc_wgrad: empty tap mask"); return -2; }
@@ -1590,16 +1629,17 @@ extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const vo
     if (use_tr && !d_scale1 && !d_scale2 && (stride == 1 || (stride == 2 && H % 2 == 0 && W % 2 == 0))) {
         // raw tiles + transposing reads (see conv3x3_nhwc_wgrad_tr_kernel); OCTA_WGRAD_TR=1: stride 1 only, =2 (default): stride 2 as well
         if (stride == 1) {
-            if (co64 && ci64) return launch_wgrad_tr<64, 64>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
-            if (co64) return launch_wgrad_tr<64, 32>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
-            if (ci64) return launch_wgrad_tr<32, 64>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
-            return launch_wgrad_tr<32, 32>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
+            if (co64 && ci64) return launch_wgrad_tr<64, 64>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream, 1, 0, acc ? d_dw : nullptr, acc == 1);
+            if (co64) return launch_wgrad_tr<64, 32>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream, 1, 0, acc ? d_dw : nullptr, acc == 1);
+            if (ci64) return launch_wgrad_tr<32, 64>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream, 1, 0, acc ? d_dw : nullptr, acc == 1);
+            return launch_wgrad_tr<32, 32>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream, 1, 0, acc ? d_dw : nullptr, acc == 1);
         }
         if (use_tr >= 2) {
-            if (co64) return launch_wgrad_tr<64, 32, 2>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
-            return launch_wgrad_tr<32, 32, 2>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream);
+            if (co64) return launch_wgrad_tr<64, 32, 2>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream, 1, 0, acc ? d_dw : nullptr, acc == 1);
+            return launch_wgrad_tr<32, 32, 2>(ctx, X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, z, stream, 1, 0, acc ? d_dw : nullptr, acc == 1);
         }
     }
+    if (acc) { octa::set_error("octa_conv3x3_nhwc_wgrad_acc: needs the transposing-read kernels (no normalise-on-load operands, OCTA_WGRAD_TR unset, even sizes at stride 2)"); return -2; }
     OCTA_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * 9 * (size_t)Cout * Cin, stream));
     if (stride == 2) {
         if (H % 2 || W % 2) { octa::set_error("octa_conv3x3_nhwc_wgrad: stride-2 layers need even input sizes"); return -2; }
@@ -1614,10 +1654,24 @@ extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const vo
     return launch_wgrad<32, 32>(X, X2, C1, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, z, stream);
 }
 
+extern "C" int octa_conv3x3_nhwc_wgrad4(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_dw, int N, int H,
+                                        int W, int Cin, int Cout, int stride, int tap_mask, const float *d_scale1, const float *d_shift1,
+                                        const float *d_scale2, const float *d_shift2, float slope, void *stream_) {
+    return wgrad4_impl(ctx, d_x, d_x2, C1, d_dy, d_dw, N, H, W, Cin, Cout, stride, tap_mask, d_scale1, d_shift1, d_scale2, d_shift2, slope, stream_, 0);
+}
+
+// octa_conv3x3_nhwc_wgrad4 (no normalise-on-load operands) with the result ADDED to d_grad in the parameter's own layout, float32
+// [Cout][Cin][3][3] (models/networks.py / MONAI state-dict layout): what the training step's `weight.grad` is (accumulate = 0: overwritten
+// instead). Taps outside tap_mask contribute zero.
+extern "C" int octa_conv3x3_nhwc_wgrad_acc(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, const void *d_dy, float *d_grad, int N, int H,
+                                           int W, int Cin, int Cout, int stride, int tap_mask, int accumulate, void *stream_) {
+    return wgrad4_impl(ctx, d_x, d_x2, C1, d_dy, d_grad, N, H, W, Cin, Cout, stride, tap_mask, nullptr, nullptr, nullptr, nullptr, 0.f, stream_, accumulate ? 1 : 2);
+}
+
 // Weight gradient of octa_conv3x3_nhwc_fwd_pad: d_x [N][H][W][Cin], d_dy [N][H + 2 pad - 2][W + 2 pad - 2][Cout], stride 1; reflect = 1
 // (pad = 1): the input was mirrored at its borders (nn.ReflectionPad2d(1) in front of the convolution).
-extern "C" int octa_conv3x3_nhwc_wgrad_pad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin, int Cout, int pad,
-                                           int reflect, void *stream_) {
+static int wgrad_pad_impl(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin, int Cout, int pad,
+                          int reflect, void *stream_, int acc) {
     if (!ctx || !d_x || !d_dy || !d_dw) { octa::set_error("octa_conv3x3_nhwc_wgrad_pad: null pointer"); return -2; }
     if (N <= 0 || H <= 0 || W <= 0 || pad < 0 || pad > 2 || H + 2 * pad < 3 || W + 2 * pad < 3) { octa::set_error("octa_conv3x3_nhwc_wgrad_pad: bad shape"); return -2; }
     if (reflect && (pad != 1 || H < 2 || W < 2)) { octa::set_error("octa_conv3x3_nhwc_wgrad_pad: reflection needs pad = 1 and an image of at least 2 x 2"); return -2; }
@@ -1628,10 +1682,21 @@ extern "C" int octa_conv3x3_nhwc_wgrad_pad(octa_ctx *ctx, const void *d_x, const
     if (!z) return -1;
     const unsigned short *X = static_cast<const unsigned short *>(d_x), *dY = static_cast<const unsigned short *>(d_dy);
     const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0;
-    if (co64 && ci64) return launch_wgrad_tr<64, 64>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect);
-    if (co64) return launch_wgrad_tr<64, 32>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect);
-    if (ci64) return launch_wgrad_tr<32, 64>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect);
-    return launch_wgrad_tr<32, 32>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect);
+    if (co64 && ci64) return launch_wgrad_tr<64, 64>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect, acc ? d_dw : nullptr, acc == 1);
+    if (co64) return launch_wgrad_tr<64, 32>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect, acc ? d_dw : nullptr, acc == 1);
+    if (ci64) return launch_wgrad_tr<32, 64>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect, acc ? d_dw : nullptr, acc == 1);
+    return launch_wgrad_tr<32, 32>(ctx, X, nullptr, Cin, dY, d_dw, N, H, W, Cin, Cout, ctx->num_cus, 0x1ff, z, stream, pad, reflect, acc ? d_dw : nullptr, acc == 1);
+}
+
+extern "C" int octa_conv3x3_nhwc_wgrad_pad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin, int Cout, int pad,
+                                           int reflect, void *stream_) {
+    return wgrad_pad_impl(ctx, d_x, d_dy, d_dw, N, H, W, Cin, Cout, pad, reflect, stream_, 0);
+}
+
+// octa_conv3x3_nhwc_wgrad_pad with the result ADDED to d_grad in the parameter layout [Cout][Cin][3][3] (see octa_conv3x3_nhwc_wgrad_acc)
+extern "C" int octa_conv3x3_nhwc_wgrad_pad_acc(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_grad, int N, int H, int W, int Cin, int Cout, int pad,
+                                               int reflect, int accumulate, void *stream_) {
+    return wgrad_pad_impl(ctx, d_x, d_dy, d_grad, N, H, W, Cin, Cout, pad, reflect, stream_, accumulate ? 1 : 2);
 }
 
 extern "C" int octa_conv4x4_nhwc_wgrad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin, int Cout,

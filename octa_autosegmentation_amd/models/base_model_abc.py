@@ -211,10 +211,10 @@ class BaseModelABC(nn.Module, ModelInterface, ABC):
         return torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=self.amp and dev.type == "cuda")
 
     def backward_scope(self):
-        """Scope of a `loss.backward()` of the step: weight gradients of the MFMA convolutions run on a side stream beside the
-        data-gradient / norm chain and are joined when the scope ends (models/mfma_conv.py: overlapped_wgrad)."""
+        """Scope of a `loss.backward()` of the step: the 3x3 weight-gradient launches add their result straight to the parameters' `.grad`
+        (views of the flat gradient arena) instead of handing autograd a tensor per layer (models/mfma_conv.py: direct_weight_grads)."""
         from . import mfma_conv
-        return mfma_conv.overlapped_wgrad(next(self.parameters()).device)
+        return mfma_conv.direct_weight_grads(next(self.parameters()).device)
 
     def zero_grads(self, optimizer_name):
         if optimizer_name in self._arenas:

@@ -17,70 +17,67 @@ def _pad32(c):
 
 
 # ---- weight gradients on a side stream ---------------------------------------------------------------------------------
-# In the backward pass the data-gradient chain (conv dgrad -> norm statistics -> norm apply -> conv dgrad ...) is the critical path;
-# a layer's WEIGHT gradient is a leaf: nothing needs it before the optimiser step. Inside `overlapped_wgrad()` (the trainers wrap
-# `loss.backward()` in it, models/base_model_abc.py) every weight-gradient launch goes to a per-device side stream with its own
-# octa_ctx: MFMA-bound weight-gradient kernels then share the GPU with the HBM-bound norm passes of the layers further down instead
-# of taking turns with them. The result is accumulated into `weight.grad` ON THAT STREAM (set when absent; in place when the gradient
-# is a view of a flat arena or a second use of the weight in the same graph) and the Function reports None to autograd, so no node
-# of the graph ever reads a tensor the current stream has not produced. Leaving the context makes the current stream wait for the
-# side stream -- before the all-reduce and the optimiser step. Outside the context (tests, user code calling .backward() directly)
-# everything runs on the current stream as before.
-# MEASURED (round 5, profiles/r05_stream_overlap_ab.log, same box): U-Net step B = 4 19.3 ms with the side stream against 19.0 without,
-# B = 8 38.7 against 35.5 -- every kernel of the step fills the GPU on its own, co-resident weight-gradient and norm workgroups only
-# evict each other's lines. Hence OFF by default; OCTA_WGRAD_STREAM=1 switches it on (tests/test_models_gpu.py keeps it correct).
-USE_WGRAD_STREAM = os.environ.get("OCTA_WGRAD_STREAM", "0") == "1"
-_WG_SIDE = {}            # device index -> (stream, octa_ctx)
-_wg_tls = __import__("threading").local()
-_WG_ACTIVE = {"on": False}      # set by overlapped_wgrad(); read by the autograd thread
+# Weight gradients straight into `weight.grad` (round 5). A layer's weight gradient is a leaf of the backward graph: nothing reads it
+# before the optimiser step. Inside `direct_weight_grads()` (the trainers wrap `loss.backward()` in it, models/base_model_abc.py
+# backward_scope) the 3x3 weight-gradient launches write their result into the parameter's `.grad` in the parameter's own layout
+# (csrc/conv.hip octa_conv3x3_nhwc_wgrad_acc) -- ADDED to an existing gradient (a view of the data-parallel gradient arena, a second use
+# of the weight), written over a fresh buffer otherwise -- and the Function reports None to autograd: no [9][Cout][Cin] temporary, no
+# fill, no layout copy and no accumulation launch per layer (21 copies + 15 fills per U-Net step, ~3 per convolution of the GAN's
+# generator). Outside the context (tests, torch.autograd.grad, user code calling
+# .backward() directly) and for parameters without a matching float32 `.grad` the gradient is returned to autograd as before.
+# (Measured and removed in round 5: the same scope running the weight-gradient launches on a SIDE STREAM beside the data-gradient / norm
+# chain -- U-Net step 19.3 against 19.0 ms at B = 4, 38.7 against 35.5 at B = 8, profiles/r05_stream_overlap_ab.log: every kernel of the
+# step fills the GPU on its own, co-resident workgroups only evict each other's lines.)
+USE_DIRECT_WGRAD = os.environ.get("OCTA_DIRECT_WGRAD", "1") != "0"
+_WG_ACTIVE = {"on": False}      # set by direct_weight_grads(); read by the autograd thread
+DIRECT_WGRAD_COUNTS = [0, 0]    # weight gradients accumulated in place / returned to autograd
 
 
-def _wgrad_side(device):
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _WG_SIDE:
-        _WG_SIDE[idx] = (torch.cuda.Stream(device=idx), _native.new_ctx(idx))      # live as long as the process
-    return _WG_SIDE[idx]
-
-
-class overlapped_wgrad:
-    """with overlapped_wgrad(device): loss.backward()"""
+class direct_weight_grads:
+    """with direct_weight_grads(device): loss.backward()"""
 
     def __init__(self, device):
-        self.device = torch.device(device)
-        self.on = USE_WGRAD_STREAM and self.device.type == "cuda"
+        self.on = USE_DIRECT_WGRAD and torch.device(device).type == "cuda"
 
     def __enter__(self):
+        self.prev = _WG_ACTIVE["on"]
         if self.on:
-            self.prev = _WG_ACTIVE["on"]
             _WG_ACTIVE["on"] = True
         return self
 
     def __exit__(self, *exc):
-        if self.on:
-            _WG_ACTIVE["on"] = self.prev
-            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-            if idx in _WG_SIDE:
-                torch.cuda.current_stream(idx).wait_stream(_WG_SIDE[idx][0])
+        _WG_ACTIVE["on"] = self.prev
         return False
 
 
-def _wgrad_to(weight, fn, *operands):
-    """dW = fn() for `weight`. Inside overlapped_wgrad(): computed and accumulated into weight.grad on the side stream, returns None
-    (autograd then has nothing to accumulate); otherwise returns fn()'s result on the current stream."""
-    if not (_WG_ACTIVE["on"] and weight.is_cuda and weight.is_leaf):
-        return fn()
-    side, sctx = _wgrad_side(weight.device)
-    side.wait_stream(torch.cuda.current_stream(weight.device))     # the operands (dy above all) are complete on the current stream
-    for t in operands:
-        if torch.is_tensor(t):
-            t.record_stream(side)          # the allocator must not reuse their blocks before the side stream is done
-    with torch.cuda.stream(side), _native.use_ctx(sctx):
-        dw = fn()
-        if weight.grad is None:
-            weight.grad = dw if dw.is_contiguous() else dw.contiguous()
-        else:
-            weight.grad.add_(dw)
-    return None
+def _wgrad_to(weight, fn, into=None):
+    """dW for `weight`: inside direct_weight_grads() `into(grad, accumulate)` writes the gradient into the parameter's float32 `.grad` in
+    place -- added to an existing one, written over a fresh buffer when there is none -- and None goes back to autograd; otherwise
+    fn()'s tensor does."""
+    if into is not None and _WG_ACTIVE["on"] and weight.is_leaf and weight.is_cuda and weight.dtype == torch.float32:
+        g = weight.grad
+        if g is None:
+            g = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            into(g, 0)
+            weight.grad = g
+            DIRECT_WGRAD_COUNTS[0] += 1
+            return None
+        if g.dtype == torch.float32 and g.is_contiguous() and g.shape == weight.shape:
+            into(g, 1)
+            DIRECT_WGRAD_COUNTS[0] += 1
+            return None
+    DIRECT_WGRAD_COUNTS[1] += 1
+    return fn()
+
+
+def _wgrad_acc(x1, x2, dy, grad, accumulate, stride=1, tap_mask=0x1ff):
+    """grad [Cout][Cin][3][3] float32 (+)= weight gradient of the 3x3 layer with input x1 (| x2 on the channel axis) and output gradient dy."""
+    n, h, w, c1 = x1.shape
+    cin = c1 + (x2.shape[3] if x2 is not None else 0)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    rc = _native.lib().octa_conv3x3_nhwc_wgrad_acc(_native.ctx(x1.device.index), p(x1), p(x2), c1, p(dy), p(grad), n, h, w, cin, dy.shape[3], int(stride),
+                                                   int(tap_mask), int(accumulate), _native.current_stream_ptr())
+    _native.check(rc, "octa_conv3x3_nhwc_wgrad_acc")
 
 
 USE_PACK_PLAN = True
@@ -494,10 +491,11 @@ class _Conv3x3NHWC(torch.autograd.Function):
         elif ctx.mailbox is not None and ctx.mailbox.pending is not None:
             raise RuntimeError("skip gradient posted but the encoder convolution computes no input gradient")
         if ctx.needs_input_grad[1]:
+            direct = (lambda g, acc: _wgrad_acc(xp, None, dy, g, acc, st)) if (xp.shape[-1] == cin and (st == 1 or (xp.shape[1] % 2 == 0 and xp.shape[2] % 2 == 0))) else None
             if st == 1:
-                dw = _wgrad_to(weight, lambda: conv3x3_nhwc_wgrad(xp, dy)[:, :cin].to(weight.dtype), xp, dy)
+                dw = _wgrad_to(weight, lambda: conv3x3_nhwc_wgrad(xp, dy)[:, :cin].to(weight.dtype), direct)
             else:
-                dw = _wgrad_to(weight, lambda: _s2_wgrad(xp, dy)[:, :cin].to(weight.dtype), xp, dy)
+                dw = _wgrad_to(weight, lambda: _s2_wgrad(xp, dy)[:, :cin].to(weight.dtype), direct)
         return dx, dw, None, None, None
 
 
@@ -545,7 +543,12 @@ class _Conv3x3ReflectNHWC(torch.autograd.Function):
                                                      ctypes.c_void_p(dwf.data_ptr()), n, h, w, cin, cout, 1, 1, _native.current_stream_ptr())
                 _native.check(rc, "octa_conv3x3_nhwc_wgrad_pad")
                 return dwf.view(3, 3, cout, cin).permute(2, 3, 0, 1).to(weight.dtype)
-            dw = _wgrad_to(weight, wg, x, dy)
+
+            def direct(g, acc):
+                rc = lib.octa_conv3x3_nhwc_wgrad_pad_acc(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
+                                                         ctypes.c_void_p(g.data_ptr()), n, h, w, cin, cout, 1, 1, int(acc), _native.current_stream_ptr())
+                _native.check(rc, "octa_conv3x3_nhwc_wgrad_pad_acc")
+            dw = _wgrad_to(weight, wg, direct)
         return dx, dw
 
 
@@ -602,7 +605,7 @@ class _Conv3x3C1(torch.autograd.Function):
                                                      ctypes.c_void_p(dw.data_ptr()), n, h, w, cout, _native.current_stream_ptr())
             _native.check(rc, "octa_conv3x3_c1_wgrad")
             return dw.view(ctx.w_shape).to(ctx.w_dtype)
-        return None, _wgrad_to(ctx.weight_ref, wg, x, dy), None
+        return None, _wgrad_to(ctx.weight_ref, wg), None
 
 
 def conv3x3(x, weight, stride=1, want_stats=False, mailbox=None):
@@ -662,7 +665,7 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
                                                   _native.current_stream_ptr())
                 _native.check(rc, "octa_conv3x3_nhwc_wgrad2")
                 return dwf.view(3, 3, cout, c1 + c2).permute(2, 3, 0, 1).to(weight.dtype)
-            dw = _wgrad_to(weight, wg, x1, x2, dy)
+            dw = _wgrad_to(weight, wg, lambda g, acc: _wgrad_acc(x1, x2, dy, g, acc))
         if ctx.mailbox is not None and dx2 is not None and ctx.needs_input_grad[1]:
             assert ctx.mailbox.pending is None
             ctx.mailbox.pending, dx2 = dx2, None          # collected by the encoder convolution's data-gradient epilogue
@@ -777,7 +780,7 @@ class _ConvT2x2NHWC(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv3x3_nhwc(dy, pack_convt2x2(weight)[0], stride=2, tap_mask=0b110110000)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad_to(weight, lambda: _s2_wgrad(dy, x, taps2=((1, 2), (1, 2)))[:, :, 1:, 1:].to(weight.dtype), x, dy)
+            dw = _wgrad_to(weight, lambda: _s2_wgrad(dy, x, taps2=((1, 2), (1, 2)))[:, :, 1:, 1:].to(weight.dtype))
         return dx, dw
 
 
@@ -1157,7 +1160,7 @@ class _Conv4x4NHWC(torch.autograd.Function):
                                                            ctypes.c_void_p(d.data_ptr()), n, h, w, cin, cout, _native.current_stream_ptr())
                 _native.check(rc, "octa_conv4x4_nhwc_wgrad")
                 return d.view(4, 4, cout, cin).permute(2, 3, 0, 1).to(weight.dtype)
-            dw = _wgrad_to(weight, wg, x, dy)
+            dw = _wgrad_to(weight, wg)
         return dx, dw
 
 

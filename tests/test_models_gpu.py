@@ -395,10 +395,11 @@ def test_reference_configs_never_leave_the_hand_written_kernels(cfg_file):
     assert after["mfma"] > before.get("mfma", 0) and after["f32_mfma"] > before.get("f32_mfma", 0)
 
 
-def test_weight_gradients_on_the_side_stream_give_the_same_gradients(monkeypatch):
-    """OCTA_WGRAD_STREAM=1 (opt-in, measured slower: models/mfma_conv.py): weight gradients computed and accumulated on a side stream,
-    joined when the backward scope ends -- same kernels, same operands: every parameter gradient equals the serial pass's up to the
-    order of the weight-gradient kernels' fp32 atomics (1e-4 of the tensor's scale), and a second backward accumulates in place."""
+def test_weight_gradients_added_straight_to_the_gradient_arena(monkeypatch):
+    """Round 5 (models/mfma_conv.py direct_weight_grads): inside the trainers' backward scope the 3x3 weight-gradient launches add their
+    result to `weight.grad` in the parameter layout (octa_conv3x3_nhwc_wgrad_acc) and report None to autograd -- same kernels, same
+    operands: every parameter gradient equals the pass that hands autograd one tensor per layer up to the summation order of the
+    partial tiles (1e-4 of the tensor's scale), a second backward accumulates in place, and the convolutions really took that route."""
     from octa_autosegmentation_amd.models import mfma_conv
     from octa_autosegmentation_amd.models.segmentation_trainer import IDENTITY_POST, SegmentationTrainer
     from octa_autosegmentation_amd.utils.enums import Phase
@@ -408,19 +409,22 @@ def test_weight_gradients_on_the_side_stream_give_the_same_gradients(monkeypatch
     x, y = torch.rand(2, 1, 128, 160, device="cuda"), (torch.rand(2, 1, 128, 160, device="cuda") > 0.7).float()
     torch.manual_seed(5)
     tr = SegmentationTrainer(cfg, "cuda")
-    grads = []
-    for side in (False, True, True):
-        monkeypatch.setattr(mfma_conv, "USE_WGRAD_STREAM", side)
+    grads, took = [], []
+    for direct in (False, True, True):
+        monkeypatch.setattr(mfma_conv, "USE_DIRECT_WGRAD", direct)
         if len(grads) < 2:
             tr.impl.zero_grads("optimizer")
+        before = list(mfma_conv.DIRECT_WGRAD_COUNTS)
         with tr.impl.autocast():
             _, losses = tr.impl.inference({"image": x, "label": y}, IDENTITY_POST, torch.device("cuda"), phase=Phase.TRAIN)
             loss = sum(losses.values())
         with tr.impl.backward_scope():
             loss.backward()
         torch.cuda.synchronize()
+        took.append(mfma_conv.DIRECT_WGRAD_COUNTS[0] - before[0])
         grads.append({k: p.grad.detach().clone() for k, p in tr.model.named_parameters()})
+    assert took[0] == 0 and took[1] == took[2] == 17, took        # the 3x3 layers with 32-multiple channels: 9 encoder + 8 decoder (the one-channel first layer goes through autograd)
     for k, g0 in grads[0].items():
         scale = g0.abs().max().item() + 1e-12
-        assert (grads[1][k] - g0).abs().max().item() <= 1e-4 * scale, k                 # side stream == serial
+        assert (grads[1][k] - g0).abs().max().item() <= 1e-4 * scale, k                 # in place == one tensor per layer
         assert (grads[2][k] - 2 * g0).abs().max().item() <= 2e-4 * scale, k             # the third backward accumulated onto the second
