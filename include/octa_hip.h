@@ -390,6 +390,9 @@ int octa_conv3x3_c1_fwd2(octa_ctx *ctx, const void *d_x, const float *d_w, void 
  * sigmoid(logit); the scalar is dice = mean_b(1 - (2 S_py + nr) / (S_p + S_y + dr)), bce = sum_b S_bce / (B n), loss =
  * (dice + bce) / 2. Backward writes dloss/dlogits (same dtype as the logits) scaled by d_grad_out[0]. */
 int octa_dice_bce_fwd(octa_ctx *ctx, const void *d_logits, int dtype, const float *d_y, int B, int64_t n, double *d_sums, void *stream);
+/* The scalar loss from those sums: (mean_b(1 - (2 s0 + nr) / (s1 + s2 + dr)) + sum_b s3 / (B n)) / 2 in double, stored as float32 at d_loss --
+ * utils/losses.py:111-121's (dice + bce) / 2 without the ten scalar torch launches between a step's forward and backward pass. */
+int octa_dice_bce_finish(octa_ctx *ctx, const double *d_sums, int B, int64_t n, double smooth_nr, double smooth_dr, float *d_loss, void *stream);
 int octa_dice_bce_bwd(octa_ctx *ctx, const void *d_logits, int dtype, const float *d_y, int B, int64_t n, const double *d_sums,
                       const float *d_grad_out, float smooth_nr, float smooth_dr, void *d_dlogits, void *stream);
 

@@ -92,6 +92,7 @@ SIGNATURES = {
     "octa_conv4x4_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_conv4x4_nhwc_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_dice_bce_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p, c_void_p]),
+    "octa_dice_bce_finish": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_int64, c_double, c_double, c_void_p, c_void_p]),
     "octa_dice_bce_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]),
     "octa_conv3x3_c1_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_conv3x3_nhwc_wgrad_acc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -88,6 +88,29 @@ extern "C" int octa_dice_bce_fwd(octa_ctx *ctx, const void *d_logits, int dtype,
     return 0;
 }
 
+// loss = (mean_b(1 - (2 s0 + nr) / (s1 + s2 + dr)) + sum_b s3 / (B n)) / 2 from the sums of octa_dice_bce_fwd, in double like the torch
+// expression it replaces (ten scalar launches between the forward pass and the backward pass of every step), rounded to float once
+namespace {
+__global__ void dice_bce_finish_kernel(const double *__restrict__ sums, int B, double n, double nr, double dr, float *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double dice = 0, bce = 0;
+    for (int b = 0; b < B; b++) {
+        dice += 1.0 - (2.0 * sums[4 * b] + nr) / (sums[4 * b + 1] + sums[4 * b + 2] + dr);
+        bce += sums[4 * b + 3];
+    }
+    out[0] = (float)((dice / (double)B + bce / ((double)B * n)) / 2.0);
+}
+}  // namespace
+
+extern "C" int octa_dice_bce_finish(octa_ctx *ctx, const double *d_sums, int B, int64_t n, double smooth_nr, double smooth_dr, float *d_loss, void *stream_) {
+    if (!ctx || !d_sums || !d_loss || B <= 0 || n <= 0) { octa::set_error("octa_dice_bce_finish: bad arguments"); return -2; }
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(dice_bce_finish_kernel, dim3(1), dim3(64), 0, stream, d_sums, B, (double)n, smooth_nr, smooth_dr, d_loss);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int octa_dice_bce_bwd(octa_ctx *ctx, const void *d_logits, int dtype, const float *d_y, int B, int64_t n, const double *d_sums,
                                  const float *d_grad_out, float smooth_nr, float smooth_dr, void *d_dlogits, void *stream_) {
     if (!ctx || !d_logits || !d_y || !d_sums || !d_grad_out || !d_dlogits || B <= 0 || n <= 0 || B > 65535 || (dtype != 0 && dtype != 1)) { octa::set_error("octa_dice_bce_bwd: bad arguments"); return -2; }

@@ -32,11 +32,14 @@ class _FusedDiceBCE(torch.autograd.Function):
         rc = _native.lib().octa_dice_bce_fwd(_native.ctx(x.device.index), p(x), 0 if x.dtype == torch.float32 else 1, p(t), B, n, p(sums),
                                              _native.current_stream_ptr())
         _native.check(rc, "octa_dice_bce_fwd")
-        dice = torch.mean(1.0 - (2.0 * sums[:, 0] + smooth_nr) / (sums[:, 1] + sums[:, 2] + smooth_dr))
-        bce = sums[:, 3].sum() / float(B * n)
+        # (dice + bce) / 2 with dice = mean(1 - (2 s0 + nr) / (s1 + s2 + dr)), bce = sum(s3) / (B n): one scalar launch, double arithmetic
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        rc = _native.lib().octa_dice_bce_finish(_native.ctx(x.device.index), p(sums), B, n, float(smooth_nr), float(smooth_dr), p(loss),
+                                                _native.current_stream_ptr())
+        _native.check(rc, "octa_dice_bce_finish")
         ctx.save_for_backward(x, t, sums)
         ctx.smooth = (float(smooth_nr), float(smooth_dr))
-        return ((dice + bce) / 2).float()
+        return loss
 
     @staticmethod
     def backward(ctx, g):
