@@ -1274,7 +1274,10 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char *p) {
 // the matrix pipe may idle (round 5: with the mirror arithmetic, the dY / X choice and the range tests behind run-time branches one DMA
 // instruction cost 53-84 instructions, 1355 per 144 MFMAs; MFMA busy 32 %, and removing the in-loop DMA alone took 512->512 at 152^2
 // from 0.593 to 0.337 ms).
-template <int COB, int CIB, int TH_, int ST, bool MASKED, bool REFLECT = false>
+// TMASK: taps known at COMPILE time (the 2 x 2 transposed convolution's weight gradient wants taps r, s in {1, 2} of a stride-2 layer:
+// 0b110110000): the MFMAs and operand reads of the other taps are not generated -- 4 of 9 MFMAs per pixel group; the run-time mask of
+// MASKED only leaves taps out of the result.
+template <int COB, int CIB, int TH_, int ST, bool MASKED, bool REFLECT = false, int TMASK = 0x1ff>
 __global__ void __launch_bounds__(CONV_THREADS, (COB == 32 && CIB == 32 && ST == 1 ? 2 : 1))
 conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ X2, int C1,
                              const unsigned short *__restrict__ dY, float *__restrict__ dW,
@@ -1380,6 +1383,7 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
                 f.a[ST == 1 ? hr - 2 : hr / 2] = tr_read8(a_base + ((row0 + (ST == 1 ? hr - 2 : hr / 2)) * TW + xc * 16) * 64);
 #pragma unroll
             for (int sx = 0; sx < 3; sx++) {
+                if (!((TMASK >> sx) & 0x49)) continue;           // no wanted tap in this tap column (bits sx, sx + 3, sx + 6)
                 const int e = ST == 1 ? (row0 + hr) * XCOLS + xc * 16 + sx : ((ST * row0 + hr) * 2 + (sx & 1)) * (TW + 1) + xc * 16 + (sx >> 1);
                 f.b[hr][sx] = tr_read8(b_base + e * 64);
             }
@@ -1412,7 +1416,8 @@ conv3x3_nhwc_wgrad_tr_kernel(const unsigned short *__restrict__ X, const unsigne
                 for (int r = 0; r < 3; r++)
 #pragma unroll
                     for (int sx = 0; sx < 3; sx++) {
-                        acc[3 * r + sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rr], f.b[ST * rr + r][sx], acc[3 * r + sx], 0, 0, 0);
+                        if ((TMASK >> (3 * r + sx)) & 1)
+                            acc[3 * r + sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rr], f.b[ST * rr + r][sx], acc[3 * r + sx], 0, 0, 0);
                         const int q = (st * RG + rr) * 9 + 3 * r + sx;
                         if (q % ISTRIDE == ISTRIDE - 1 && q / ISTRIDE < IPW) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -1556,6 +1561,7 @@ int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short
     }
     auto kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_, ST, false>;
     if (tap_mask != 0x1ff) kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_, ST, true>;
+    if constexpr (ST == 2) { if (tap_mask == 0x1b0) kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_, 2, true, false, 0x1b0>; }      // ConvTranspose2d(k = s = 2)
     if constexpr (ST == 1) { if (reflect) kern = conv3x3_nhwc_wgrad_tr_kernel<COB, CIB, TH_, 1, false, true>; }   // (the mirrored form is never masked: octa_conv3x3_nhwc_wgrad_pad)
     OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)per_block, (unsigned)blocks), dim3(CONV_THREADS), lds, stream, X, X2, C1, dY, dW, N, H, W, Ho, Wo, Cin, Cout,
