@@ -239,6 +239,11 @@ int octa_conv3x3_s2t_nhwc(octa_ctx *ctx, const void *d_x, const void *d_w, void 
 int octa_instnorm_lrelu_head1_nhwc_fwd(octa_ctx *ctx, const void *d_x, const float *d_w, const float *d_b, const float *d_head_w,
                                        const float *d_head_b, float *d_mean, float *d_rstd, void *d_logits, int B, int C, int64_t hw,
                                        float slope, float eps, void *stream);
+/* octa_instnorm_lrelu_head1_nhwc_fwd with the statistics of d_x supplied in slot form (double [nslot][B][C][2]) by the convolution that wrote it
+ * (octa_conv3x3_nhwc_fwd7): the layer then makes no statistics pass of its own. */
+int octa_instnorm_lrelu_head1_nhwc_fwd_s(octa_ctx *ctx, const void *d_x, const float *d_w, const float *d_b, const float *d_head_w,
+                                         const float *d_head_b, float *d_mean, float *d_rstd, void *d_logits, int B, int C, int64_t hw,
+                                         float slope, float eps, const double *d_slots, int nslot, void *stream);
 int octa_instnorm_lrelu_head1_nhwc_bwd(octa_ctx *ctx, const void *d_x, const void *d_dlogits, const float *d_w, const float *d_b,
                                        const float *d_head_w, const float *d_mean, const float *d_rstd, void *d_dx, float *d_dw, float *d_db,
                                        float *d_dhead_w, float *d_dhead_b, int B, int C, int64_t hw, float slope, void *stream);

@@ -281,6 +281,23 @@ __device__ __forceinline__ void nhwc_geometry(int C, int &cg, int &pl, int &npl)
     npl = NT / groups;
 }
 
+// sum over the slots of sums[nslot][.][2] at element e (sum, sum of squares): the loads of eight slots are issued together (index clamped,
+// branch-free) -- a run-time loop with one load per trip waits for memory once per slot in every workgroup's prologue
+__device__ __forceinline__ void slot_sum(const double *__restrict__ sums, long e, int nslot, long slot_stride, double &sa, double &sq) {
+    sa = 0; sq = 0;
+    for (int k0 = 0; k0 < nslot; k0 += 8) {
+        double a[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = k0 + j < nslot ? k0 + j : k0;
+            a[j] = sums[k * slot_stride + e * 2]; q[j] = sums[k * slot_stride + e * 2 + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (k0 + j < nslot) { sa += a[j]; sq += q[j]; }
+    }
+}
+
 // mode 0: (sum x, sum x^2); mode 1: (sum g, sum g*xhat) with g = dy * lrelu'(pre)
 template <int MODE>
 __global__ void __launch_bounds__(NT)
@@ -376,8 +393,8 @@ in_nhwc_fwd_apply(const unsigned short *__restrict__ x, unsigned short *__restri
     const int b = blockIdx.y + b0, s = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += NT) {
         // nslot > 1: the sums come from the producing convolution's epilogue, spread over slots [nslot][B][C][2] (csrc/conv.hip, fwd7)
-        double sa = 0, sq = 0;
-        for (int k = 0; k < nslot; k++) { sa += sums[k * slot_stride + ((long)b * C + c) * 2]; sq += sums[k * slot_stride + ((long)b * C + c) * 2 + 1]; }
+        double sa, sq;
+        slot_sum(sums, (long)b * C + c, nslot, slot_stride, sa, sq);
         const double mean_d = sa / (double)hw;
         double var = sq / (double)hw - mean_d * mean_d;
         if (var < 0) var = 0;
@@ -726,11 +743,13 @@ namespace {
 __global__ void __launch_bounds__(NT)
 in_nhwc_head_fwd(const unsigned short *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, long hw, int C, int splits,
                  const double *__restrict__ sums, float slope, float eps, float *__restrict__ mean_out, float *__restrict__ rstd_out,
-                 const float *__restrict__ headw, const float *__restrict__ headb, unsigned short *__restrict__ logits) {
+                 const float *__restrict__ headw, const float *__restrict__ headb, unsigned short *__restrict__ logits, int nslot = 1,
+                 long slot_stride = 0) {
     __shared__ float s_g[NHWC_MAXC], s_sh[NHWC_MAXC];
     const int b = blockIdx.y, s = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += NT) {
-        const double sa = sums[((long)b * C + c) * 2], sq = sums[((long)b * C + c) * 2 + 1];
+        double sa, sq;                                   // nslot > 1: from the producing convolution's epilogue (octa_conv3x3_nhwc_fwd7)
+        slot_sum(sums, (long)b * C + c, nslot, slot_stride, sa, sq);
         const double mean_d = sa / (double)hw;
         double var = sq / (double)hw - mean_d * mean_d;
         if (var < 0) var = 0;
@@ -944,6 +963,22 @@ extern "C" int octa_instnorm_lrelu_head1_nhwc_fwd(octa_ctx *ctx, const void *d_x
                        (const float *)nullptr, (long)hw, C, splits, slope, sums, 0);
     hipLaunchKernelGGL(in_nhwc_head_fwd, grid, dim3(NT), 0, stream, x, d_w, d_b, (long)hw, C, splits, sums, slope, eps, d_mean, d_rstd, d_head_w,
                        d_head_b, static_cast<unsigned short *>(d_logits));
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// The same layer with the statistics of d_x supplied in slot form by the convolution that wrote it (octa_conv3x3_nhwc_fwd7's d_stat_slots,
+// double [nslot][B][C][2]): no statistics pass over the 1216^2 x 32 tensor in front of the head.
+extern "C" int octa_instnorm_lrelu_head1_nhwc_fwd_s(octa_ctx *ctx, const void *d_x, const float *d_w, const float *d_b, const float *d_head_w,
+                                                    const float *d_head_b, float *d_mean, float *d_rstd, void *d_logits, int B, int C, int64_t hw,
+                                                    float slope, float eps, const double *d_slots, int nslot, void *stream_) {
+    if (!ctx || !d_x || !d_head_w || !d_mean || !d_rstd || !d_logits || !d_slots || nslot <= 0) { octa::set_error("octa_instnorm_lrelu_head1_nhwc_fwd_s: null pointer"); return -2; }
+    if (head_check("octa_instnorm_lrelu_head1_nhwc_fwd_s", B, C, hw)) return -2;
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const int splits = nhwc_splits(ctx, B, hw);
+    hipLaunchKernelGGL(in_nhwc_head_fwd, dim3((unsigned)splits, (unsigned)B), dim3(NT), 0, stream, static_cast<const unsigned short *>(d_x), d_w, d_b, (long)hw, C,
+                       splits, d_slots, slope, eps, d_mean, d_rstd, d_head_w, d_head_b, static_cast<unsigned short *>(d_logits), nslot, (long)B * C * 2);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }

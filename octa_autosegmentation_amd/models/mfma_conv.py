@@ -927,7 +927,7 @@ class _InstNormLReLUHead1NHWC(torch.autograd.Function):
     (csrc/norm.hip octa_instnorm_lrelu_head1_nhwc_*): the normalised tensor and its gradient never reach HBM."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, slope, eps, head_w, head_b):
+    def forward(ctx, x, gamma, beta, slope, eps, head_w, head_b, partials=None):
         x = x.contiguous()
         assert x.dtype == torch.bfloat16 and x.dim() == 4
         B, H, W, C = x.shape
@@ -938,8 +938,13 @@ class _InstNormLReLUHead1NHWC(torch.autograd.Function):
         hb = head_b.float().contiguous() if head_b is not None else None
         mean, rstd = torch.empty(B * C, **f32), torch.empty(B * C, **f32)
         logits = torch.empty((B, H, W, 1), dtype=torch.bfloat16, device=x.device)
-        rc = _native.lib().octa_instnorm_lrelu_head1_nhwc_fwd(_native.ctx(x.device.index), _p(x), _p(g), _p(bt), _p(hw_), _p(hb), _p(mean), _p(rstd),
-                                                              _p(logits), B, C, H * W, float(slope), float(eps), _native.current_stream_ptr())
+        if partials is not None and partials.dtype == torch.float64:       # statistics of x in slot form from the convolution that wrote it
+            rc = _native.lib().octa_instnorm_lrelu_head1_nhwc_fwd_s(_native.ctx(x.device.index), _p(x), _p(g), _p(bt), _p(hw_), _p(hb), _p(mean), _p(rstd),
+                                                                    _p(logits), B, C, H * W, float(slope), float(eps), _p(partials),
+                                                                    int(partials.shape[0]), _native.current_stream_ptr())
+        else:
+            rc = _native.lib().octa_instnorm_lrelu_head1_nhwc_fwd(_native.ctx(x.device.index), _p(x), _p(g), _p(bt), _p(hw_), _p(hb), _p(mean), _p(rstd),
+                                                                  _p(logits), B, C, H * W, float(slope), float(eps), _native.current_stream_ptr())
         _native.check(rc, "octa_instnorm_lrelu_head1_nhwc_fwd")
         ctx.save_for_backward(x, g, bt, hw_, mean, rstd)
         ctx.slope = float(slope)
@@ -965,7 +970,7 @@ class _InstNormLReLUHead1NHWC(torch.autograd.Function):
                                                               _native.current_stream_ptr())
         _native.check(rc, "octa_instnorm_lrelu_head1_nhwc_bwd")
         return (dx, dg.to(g_dtype) if has_g else None, db.to(g_dtype) if has_b else None, None, None,
-                dhw.view(hw_shape).to(hw_dtype), dhb.to(hw_dtype) if has_hb else None)
+                dhw.view(hw_shape).to(hw_dtype), dhb.to(hw_dtype) if has_hb else None, None)
 
 
 USE_FUSED_NORM_HEAD = os.environ.get("OCTA_FUSED_HEAD", "1") != "0"     # A/B switch (development aid)
@@ -975,9 +980,10 @@ def norm_lrelu_head1_ok(c, head_weight):
     return USE_FUSED_NORM_HEAD and head_weight.shape[0] == 1 and head_weight.shape[1] == c and c in (8, 16, 32, 64, 128, 256)
 
 
-def instance_norm_leaky_relu_head1_nhwc(x, gamma, beta, negative_slope, eps, head_weight, head_bias):
-    """x [N,H,W,C] bf16 (raw convolution output) -> logits [N,H,W,1] bf16 = head(lrelu(instance_norm(x)))."""
-    return _InstNormLReLUHead1NHWC.apply(x, gamma, beta, negative_slope, eps, head_weight, head_bias)
+def instance_norm_leaky_relu_head1_nhwc(x, gamma, beta, negative_slope, eps, head_weight, head_bias, partials=None):
+    """x [N,H,W,C] bf16 (raw convolution output) -> logits [N,H,W,1] bf16 = head(lrelu(instance_norm(x))). partials: the slot-form
+    statistics of x from the convolution that wrote it (conv3x3(..., want_stats=True))."""
+    return _InstNormLReLUHead1NHWC.apply(x, gamma, beta, negative_slope, eps, head_weight, head_bias, partials)
 
 
 def conv1x1_bias_nhwc(x, weight, bias):

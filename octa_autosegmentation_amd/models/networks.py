@@ -226,13 +226,14 @@ class DynUNet(nn.Module):
             y, part = y if USE_EPILOGUE_STATS else (y, None)
             y = mc.instance_norm_leaky_relu_nhwc(y, blk.norm1.weight, blk.norm1.bias, blk.lrelu.negative_slope, blk.norm1.eps, part)
             fused_head = head is not None and mc.norm_lrelu_head1_ok(c2.weight.shape[0], head.weight)
-            want2 = USE_EPILOGUE_STATS and not fused_head        # the norm + head layer runs its own statistics pass over the raw tensor
+            want2 = USE_EPILOGUE_STATS
             y = mc.conv3x3(y, c2.weight, 1, want2)
             y, part = y if want2 else (y, None)
-            if head is not None and part is None and mc.norm_lrelu_head1_ok(y.shape[-1], head.weight):
-                # last block: norm + activation + the 1x1 output convolution in one pair of passes, nothing normalised goes to HBM
+            if fused_head:
+                # last block: norm + activation + the 1x1 output convolution in one pair of passes, nothing normalised goes to HBM (the
+                # norm's statistics from conv2's epilogue: no pass over the raw tensor in front of it either)
                 return mc.instance_norm_leaky_relu_head1_nhwc(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps,
-                                                              head.weight, head.bias)
+                                                              head.weight, head.bias, part)
             y = mc.instance_norm_leaky_relu_nhwc(y, blk.norm2.weight, blk.norm2.bias, blk.lrelu.negative_slope, blk.norm2.eps, part)
             if head is not None:
                 return mc.conv1x1_bias_nhwc(y, head.weight, head.bias)
