@@ -1,4 +1,6 @@
-"""Normalise-on-load in the DMA-staged forward kernel (XF variant) against apply pass + plain convolution, DynUNet stride-1 shapes."""
+"""Normalise-on-load convolution (mfma_conv.conv3x3_lazy: whatever kernel the library routes it to) against application pass + plain
+convolution on the DynUNet stride-1 shapes, cold cache. Round 5 used it for the in-LDS transform experiment on the DMA-staged kernels
+(profiles/r05_unet_lazy_norm1_ab.log); the shipped library routes conv3x3_lazy to the register-staged kernel."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
