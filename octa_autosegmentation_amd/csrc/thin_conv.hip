@@ -175,6 +175,90 @@ thin_squeeze_kernel(const bf16_t *__restrict__ a, const float *__restrict__ w, c
     }
 }
 
+// ---- squeeze, wide form (round 5) ---------------------------------------------------------------------------------------
+// The kernel above puts a channel on a lane: 2 bytes per lane and load, 98 loads and a 64-lane butterfly per 8 outputs -- 0.50 ms for the
+// generator's 64 -> 1 head at 8 x 304^2, a tenth of the vector peak (profiles/r05_gan_steady_kernel_stats.csv). Here a thread owns 8 channels
+// (ONE 16-byte piece) of PW consecutive output pixels: per kernel row it loads the PW + K - 1 pieces of the window once (a wave's load is
+// 128 contiguous bytes per pixel), holds the row's K weight octets in registers (tap-major table in LDS, 16-byte reads), accumulates channel
+// PAIRS (v_pk_fma_f32) and folds the C / 8 lanes of a pixel group at the end.
+typedef float tc_f2 __attribute__((ext_vector_type(2)));
+
+template <int K, int PW>
+__global__ void __launch_bounds__(TC_THREADS)
+thin_squeeze_wide_kernel(const bf16_t *__restrict__ a, const float *__restrict__ w, const float *__restrict__ bias, bf16_t *__restrict__ out,
+                         int N, int Ha, int Wa, int Ho, int Wo, int C, int pad, int flip) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KK = K * K;
+    float *wl = reinterpret_cast<float *>(smem);                 // [KK][C]: tap-major (flipped here if asked), channel fastest
+    for (int i = threadIdx.x; i < C * KK; i += TC_THREADS) {
+        const int c = i / KK, t = i % KK;
+        wl[(flip ? KK - 1 - t : t) * C + c] = w[i];
+    }
+    __syncthreads();
+    const int groups = C / 8, gshift = 31 - __clz(groups);       // a power of two <= 64 (host-checked)
+    const int g = threadIdx.x & (groups - 1), q0 = threadIdx.x >> gshift, qstep = TC_THREADS >> gshift;
+    const int oy = blockIdx.x % Ho, n = blockIdx.x / Ho;
+    const float b = bias ? bias[0] : 0.f;
+    const int quads = (Wo + PW - 1) / PW;
+    for (int qd = q0; qd < quads; qd += qstep) {
+        const int ox0 = qd * PW;
+        tc_f2 acc[PW][4];
+#pragma unroll
+        for (int o = 0; o < PW; o++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[o][k] = tc_f2{0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < K; ky++) {
+            const int iy = oy + ky - pad;
+            if (iy < 0 || iy >= Ha) continue;                    // a row of zero padding (uniform over the block)
+            tc_f2 wk[K][4];
+#pragma unroll
+            for (int kx = 0; kx < K; kx++) {
+                const float4 w0 = *reinterpret_cast<const float4 *>(wl + (ky * K + kx) * C + g * 8), w1 = *reinterpret_cast<const float4 *>(wl + (ky * K + kx) * C + g * 8 + 4);
+                wk[kx][0] = tc_f2{w0.x, w0.y}; wk[kx][1] = tc_f2{w0.z, w0.w}; wk[kx][2] = tc_f2{w1.x, w1.y}; wk[kx][3] = tc_f2{w1.z, w1.w};
+            }
+            const bf16_t *row = a + (((size_t)n * Ha + iy) * Wa) * C + g * 8;
+            uint4 v[PW + K - 1];
+#pragma unroll
+            for (int j = 0; j < PW + K - 1; j++) {               // all loads of the row first: independent, index clamped, masked afterwards
+                const int ix = ox0 + j - pad;
+                v[j] = *reinterpret_cast<const uint4 *>(row + (size_t)(ix < 0 ? 0 : (ix >= Wa ? Wa - 1 : ix)) * C);
+            }
+#pragma unroll
+            for (int j = 0; j < PW + K - 1; j++) {
+                const int ix = ox0 + j - pad;
+                const float m = (ix >= 0 && ix < Wa) ? 1.f : 0.f;
+                const unsigned u[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                tc_f2 x2[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) x2[k] = tc_f2{__uint_as_float(u[k] << 16) * m, __uint_as_float(u[k] & 0xffff0000u) * m};
+#pragma unroll
+                for (int kx = 0; kx < K; kx++) {
+                    const int o = j - kx;
+                    if (o >= 0 && o < PW) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) acc[o][k] = __builtin_elementwise_fma(x2[k], wk[kx][k], acc[o][k]);
+                    }
+                }
+            }
+        }
+        float r[PW];
+#pragma unroll
+        for (int o = 0; o < PW; o++) {
+            const tc_f2 t = (acc[o][0] + acc[o][1]) + (acc[o][2] + acc[o][3]);
+            float vsum = t.x + t.y;
+            for (int d = 1; d < groups; d <<= 1) vsum += __shfl_xor(vsum, d, 64);
+            r[o] = vsum + b;
+        }
+        if (g == 0) {
+            bf16_t *dst = out + ((size_t)n * Ho + oy) * Wo + ox0;
+#pragma unroll
+            for (int o = 0; o < PW; o++)
+                if (ox0 + o < Wo) dst[o] = f2bf(r[o]);
+        }
+    }
+}
+
 // ---- wgrad --------------------------------------------------------------------------------------------------------------
 // g[c][t] = sum a[n][y][x][c] * s[n][y+ky-pad][x+kx-pad]. block = WG_ROWS rows of a x one 64-channel chunk, K waves: wave ky
 // owns window row ky (K accumulators per lane), its window of s slides along the row (one LDS broadcast per pixel); the values of
@@ -290,6 +374,16 @@ extern "C" int octa_thinconv_squeeze(octa_ctx *ctx, const void *d_a, const void 
     const unsigned grid = (unsigned)((long long)N * Ho);
     const size_t lds = (size_t)C * (K * K + 1) * sizeof(float);
     if (lds > 64 * 1024) { octa::set_error("octa_thinconv_squeeze: %d x %d weights of %d channels do not fit the LDS", K, K, C); return -2; }
+    // wide form: a thread per 8 channels of 4 output pixels (OCTA_THIN_WIDE=0: the lane-per-channel kernels of rounds 1-4)
+    static const int wide = [] { const char *e = getenv("OCTA_THIN_WIDE"); return e ? atoi(e) : 1; }();
+    const int groups = C / 8;
+    if (wide && C % 8 == 0 && groups <= 64 && (groups & (groups - 1)) == 0 && (size_t)C * K * K * sizeof(float) <= 64 * 1024) {
+        const size_t wlds = (size_t)C * K * K * sizeof(float);
+        if (K == 7) hipLaunchKernelGGL((thin_squeeze_wide_kernel<7, 4>), dim3(grid), dim3(TC_THREADS), wlds, stream, (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho, Wo, C, pad, flip);
+        else hipLaunchKernelGGL((thin_squeeze_wide_kernel<4, 4>), dim3(grid), dim3(TC_THREADS), wlds, stream, (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho, Wo, C, pad, flip);
+        OCTA_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (K == 7) hipLaunchKernelGGL((thin_squeeze_kernel<7, 8>), dim3(grid), dim3(TC_THREADS), lds, stream, (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho, Wo, C, pad, flip);
     else hipLaunchKernelGGL((thin_squeeze_kernel<4, 8>), dim3(grid), dim3(TC_THREADS), lds, stream, (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho, Wo, C, pad, flip);
     OCTA_HIP_CHECK(hipGetLastError());
