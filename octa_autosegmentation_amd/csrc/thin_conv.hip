@@ -319,19 +319,115 @@ thin_wgrad_kernel(const bf16_t *__restrict__ a, const bf16_t *__restrict__ s, fl
     if (ky == 0) dst[KK] = asum;
 }
 
-// sum of the per-block partials: a block takes 64 consecutive outputs x 4 slices of the partial list
+// ---- wgrad, wide form (round 5) -------------------------------------------------------------------------------------------
+// As the squeeze kernel: a lane per channel meant 2 bytes per lane and load and K waves re-reading the row (0.54 + 0.42 ms per GAN-seg step
+// for the generator's two 7 x 7 layers). Here a thread owns 8 channels (one 16-byte piece) of 4 consecutive pixels; wave ky still owns
+// window row ky (K x 4 pair accumulators per thread), the window of s comes from the staged rows in LDS, the pixel lanes of a channel group
+// are folded once per block and the partial sums keep the layout the reduction kernel expects. Rows per block: WG_ROWS_WIDE.
+constexpr int WG_ROWS_WIDE = 4;
+
+template <int K>
+__global__ void __launch_bounds__(K * 64)
+thin_wgrad_wide_kernel(const bf16_t *__restrict__ a, const bf16_t *__restrict__ s, float *__restrict__ partial,
+                       int N, int Ha, int Wa, int Hs, int Ws, int C, int pad, int flip) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KK = K * K, PW = 4;
+    const int wrow = Wa + K - 1 + PW;                            // PW columns of slack behind each row (a quad may hang over the row's end)
+    float *srow = reinterpret_cast<float *>(smem);               // [K][wrow]
+    const int lane = threadIdx.x & 63, ky = threadIdx.x >> 6;
+    const int groups = C / 8, gshift = 31 - __clz(groups);       // a power of two <= 64 (host-checked)
+    const int g = lane & (groups - 1), q0 = lane >> gshift, qstep = 64 >> gshift;
+    tc_f2 acc[K][4], asum[4];
+#pragma unroll
+    for (int kx = 0; kx < K; kx++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[kx][k] = tc_f2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; k++) asum[k] = tc_f2{0.f, 0.f};
+    const int quads = (Wa + PW - 1) / PW;
+    for (int r = 0; r < WG_ROWS_WIDE; r++) {
+        const long long rowid = (long long)blockIdx.x * WG_ROWS_WIDE + r;
+        if (rowid >= (long long)N * Ha) break;
+        const int n = (int)(rowid / Ha), qy = (int)(rowid % Ha);
+        __syncthreads();
+        for (int i = threadIdx.x; i < K * wrow; i += K * 64) {
+            const int wy = i / wrow, j = i % wrow;
+            const int iy = qy + wy - pad, ix = j - pad;
+            srow[i] = (iy >= 0 && iy < Hs && ix >= 0 && ix < Ws) ? bf2f(s[((size_t)n * Hs + iy) * Ws + ix]) : 0.f;
+        }
+        __syncthreads();
+        const bf16_t *arow = a + (((size_t)n * Ha + qy) * Wa) * C + g * 8;
+        const float *sr = srow + ky * wrow;
+        for (int qd = q0; qd < quads; qd += qstep) {
+            const int x0 = qd * PW;
+            uint4 v[PW];
+#pragma unroll
+            for (int o = 0; o < PW; o++) v[o] = *reinterpret_cast<const uint4 *>(arow + (size_t)(x0 + o < Wa ? x0 + o : Wa - 1) * C);
+            float sw[PW + K - 1];
+#pragma unroll
+            for (int j = 0; j < PW + K - 1; j++) sw[j] = sr[x0 + j];
+#pragma unroll
+            for (int o = 0; o < PW; o++) {
+                const float m = x0 + o < Wa ? 1.f : 0.f;
+                const unsigned u[4] = {v[o].x, v[o].y, v[o].z, v[o].w};
+                tc_f2 a2[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { a2[k] = tc_f2{__uint_as_float(u[k] << 16) * m, __uint_as_float(u[k] & 0xffff0000u) * m}; asum[k] += a2[k]; }
+#pragma unroll
+                for (int kx = 0; kx < K; kx++) {
+                    const tc_f2 s2 = {sw[o + kx], sw[o + kx]};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[kx][k] = __builtin_elementwise_fma(a2[k], s2, acc[kx][k]);
+                }
+            }
+        }
+    }
+    // fold the pixel lanes of every channel group (lanes g, g + groups, ...), then lane g writes its 8 channels
+#pragma unroll
+    for (int kx = 0; kx < K; kx++)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            for (int d = groups; d < 64; d <<= 1) { acc[kx][k].x += __shfl_xor(acc[kx][k].x, d, 64); acc[kx][k].y += __shfl_xor(acc[kx][k].y, d, 64); }
+    if (ky == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            for (int d = groups; d < 64; d <<= 1) { asum[k].x += __shfl_xor(asum[k].x, d, 64); asum[k].y += __shfl_xor(asum[k].y, d, 64); }
+    }
+    if (lane < groups) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                float *dst = partial + ((size_t)blockIdx.x * C + g * 8 + 2 * k + h) * (KK + 1);
+#pragma unroll
+                for (int kx = 0; kx < K; kx++) {
+                    const int t = ky * K + kx;
+                    dst[flip ? KK - 1 - t : t] = h ? acc[kx][k].y : acc[kx][k].x;
+                }
+                if (ky == 0) dst[KK] = h ? asum[k].y : asum[k].x;
+            }
+    }
+}
+
+// sum of the per-block partials: a block takes 16 consecutive outputs x 16 slices of the partial list (round 5: 64 x 4 left a thread a
+// dependent chain of 300 loads: 82 us for 3 200 outputs)
 __global__ void __launch_bounds__(TC_THREADS)
 thin_wgrad_reduce_kernel(const float *__restrict__ partial, int n_blocks, int C, int KK, float *__restrict__ g, float *__restrict__ asum) {
-    __shared__ float part[4][64];
+    __shared__ float part[16][16];
     const int total = C * (KK + 1);
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-    float v = 0.f;
-    if (i < total)
-        for (int b = slice; b < n_blocks; b += 4) v += partial[(size_t)b * total + i];
-    part[slice][threadIdx.x & 63] = v;
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4, i = blockIdx.x * 16 + el;
+    float v0 = 0.f, v1 = 0.f;
+    if (i < total) {
+        int b = slice;
+        for (; b + 16 < n_blocks; b += 32) { v0 += partial[(size_t)b * total + i]; v1 += partial[(size_t)(b + 16) * total + i]; }
+        if (b < n_blocks) v0 += partial[(size_t)b * total + i];
+    }
+    part[slice][el] = v0 + v1;
     __syncthreads();
     if (slice != 0 || i >= total) return;
-    v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) v += part[k][el];
     const int c = i / (KK + 1), t = i % (KK + 1);
     if (t < KK) g[(size_t)c * KK + t] = v;
     else if (asum) asum[c] = v;
@@ -403,13 +499,24 @@ extern "C" int octa_thinconv_wgrad(octa_ctx *ctx, const void *d_a, const void *d
     if (Hs <= 0 || Ws <= 0) { octa::set_error("octa_thinconv_wgrad: bad s extent"); return -2; }
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
-    const unsigned blocks = (unsigned)(((long long)N * Ha + WG_ROWS - 1) / WG_ROWS);
+    unsigned blocks = (unsigned)(((long long)N * Ha + WG_ROWS - 1) / WG_ROWS);
     const size_t lds = (size_t)K * (Wa + K - 1 + 2 * K) * sizeof(float);
     if (lds > 60 * 1024) { octa::set_error("octa_thinconv_wgrad: rows of %d pixels do not fit the LDS window", Wa); return -2; }
+    static const int wide = [] { const char *e = getenv("OCTA_THIN_WIDE"); return e ? atoi(e) : 1; }();
+    const int groups = C / 8;
+    const int total = C * (K * K + 1);
+    if (wide && groups <= 64 && (groups & (groups - 1)) == 0) {
+        // (fewer, larger blocks than octa_thinconv_wgrad_scratch_floats sized the scratch for)
+        blocks = (unsigned)(((long long)N * Ha + WG_ROWS_WIDE - 1) / WG_ROWS_WIDE);
+        if (K == 7) hipLaunchKernelGGL(thin_wgrad_wide_kernel<7>, dim3(blocks), dim3(7 * 64), lds, stream, (const bf16_t *)d_a, (const bf16_t *)d_s, (float *)d_scratch, N, Ha, Wa, Hs, Ws, C, pad, flip);
+        else hipLaunchKernelGGL(thin_wgrad_wide_kernel<4>, dim3(blocks), dim3(4 * 64), lds, stream, (const bf16_t *)d_a, (const bf16_t *)d_s, (float *)d_scratch, N, Ha, Wa, Hs, Ws, C, pad, flip);
+        hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(TC_THREADS), 0, stream, (const float *)d_scratch, (int)blocks, C, K * K, (float *)d_g, (float *)d_asum);
+        OCTA_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (K == 7) hipLaunchKernelGGL(thin_wgrad_kernel<7>, dim3(blocks, C / 64), dim3(7 * 64), lds, stream, (const bf16_t *)d_a, (const bf16_t *)d_s, (float *)d_scratch, N, Ha, Wa, Hs, Ws, C, pad, flip);
     else hipLaunchKernelGGL(thin_wgrad_kernel<4>, dim3(blocks, C / 64), dim3(4 * 64), lds, stream, (const bf16_t *)d_a, (const bf16_t *)d_s, (float *)d_scratch, N, Ha, Wa, Hs, Ws, C, pad, flip);
-    const int total = C * (K * K + 1);
-    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(TC_THREADS), 0, stream, (const float *)d_scratch, (int)blocks, C, K * K, (float *)d_g, (float *)d_asum);
+    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(TC_THREADS), 0, stream, (const float *)d_scratch, (int)blocks, C, K * K, (float *)d_g, (float *)d_asum);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }
