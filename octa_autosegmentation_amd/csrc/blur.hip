@@ -64,6 +64,16 @@ struct Idx { int b, y, x, c; };
 template <int V> __device__ __forceinline__ Idx split(long long i, int Hh, int Ww, int C) {
     Idx r;
     const int CV = C / V;
+    if (i <= 0x7fffffffLL) {
+        // the tensors of these networks: 32-bit unsigned divisions (round 5: the three 64-bit divide / modulo pairs were most of the
+        // instructions of these kernels -- ~100 each, against a few 16-byte loads and one store per thread)
+        unsigned u = (unsigned)i;
+        r.c = (int)(u % (unsigned)CV) * V; u /= (unsigned)CV;
+        r.x = (int)(u % (unsigned)Ww); u /= (unsigned)Ww;
+        r.y = (int)(u % (unsigned)Hh);
+        r.b = (int)(u / (unsigned)Hh);
+        return r;
+    }
     r.c = (int)(i % CV) * V; i /= CV;
     r.x = (int)(i % Ww); i /= Ww;
     r.y = (int)(i % Hh);
