@@ -240,9 +240,15 @@ raster_tess_kernel(const EdgeMeta *__restrict__ meta, const int *__restrict__ of
 // super-tiles of a 1216^2 label each tested all 13.5 k edges (28 % of the kernel's workgroup time after the fold got faster). One pass
 // per (image, row of super-tiles) now writes, IN LIST ORDER, the indices of the edges whose box meets the row's 64 scanlines (u16: graphs
 // of more than 65 535 edges keep the old scan); a super-tile then tests the ~7 % of the edges that are in its row.
+struct RowRec {          // 16 bytes: a candidate of a row of super-tiles, everything the render kernel's compaction needs of it
+    unsigned short edge, nv;     // index inside the graph (< 65 536), polygon sides
+    int side_off;                // first slot of the edge in the global side array
+    BBox16 bb;
+};
+
 __global__ void __launch_bounds__(256)
-raster_rowbin_kernel(const BBox16 *__restrict__ bbox, const long *__restrict__ edge_off, int H, int rows, unsigned short *__restrict__ row_list,
-                     int *__restrict__ row_cnt) {
+raster_rowbin_kernel(const BBox16 *__restrict__ bbox, const long *__restrict__ edge_off, int H, int rows, RowRec *__restrict__ row_list,
+                     int *__restrict__ row_cnt, const EdgeMeta *__restrict__ meta, const int *__restrict__ side_off, const int *__restrict__ side_block_sums) {
     // every wave takes a contiguous quarter of the graph's edges: count (ballots), ONE barrier for the four totals, then emit at the running
     // offset (ballot prefix) -- the boxes are read twice from the L2 instead of once with three barriers per 4096 edges (236 -> ~30 us per
     // 128 labels)
@@ -251,7 +257,7 @@ raster_rowbin_kernel(const BBox16 *__restrict__ bbox, const long *__restrict__ e
     const long e_begin = edge_off[img], e_end = edge_off[img + 1];
     const int n = (int)(e_end - e_begin);
     const BBox16 *gb = bbox + e_begin;
-    unsigned short *out = row_list + (size_t)e_begin * rows + (size_t)row * n;
+    RowRec *out = row_list + (size_t)e_begin * rows + (size_t)row * n;
     const int y0 = row * ST_Y, y1 = min(y0 + ST_Y, H) - 1;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seg = ((n + 4 * 64 - 1) / (4 * 64)) * 64;
@@ -271,7 +277,17 @@ raster_rowbin_kernel(const BBox16 *__restrict__ bbox, const long *__restrict__ e
     for (int e0 = s0; e0 < s1; e0 += 64) {
         const bool h = hit_at(e0 + lane);
         const unsigned long long m = __ballot(h);
-        if (h) out[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(e0 + lane);
+        if (h) {
+            // the candidate's whole record (round 5, last change): the render kernel's compaction read the index here, then the box, the side
+            // count and the side offset of that edge from three more arrays -- four dependent loads in front of its first block scan
+            const int e = e0 + lane;
+            RowRec r;
+            r.edge = (unsigned short)e;
+            r.nv = (unsigned short)meta[e_begin + e].nv;
+            r.side_off = side_off[e_begin + e] + side_block_sums[(e_begin + e) / SCAN_BLK];
+            r.bb = gb[e];
+            out[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = r;
+        }
         at += (int)__popcll(m);
     }
     if (threadIdx.x == 0) row_cnt[img * rows + row] = tot;
@@ -328,7 +344,7 @@ __global__ void __launch_bounds__(WG)
 raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict__ bbox,
                      const long *__restrict__ edge_off, const int4 *__restrict__ sides, const int *__restrict__ side_off,
                      const int *__restrict__ side_block_sums, int W, int H, int tiles_x, int tiles_y,
-                     unsigned char *__restrict__ out, int *__restrict__ err_flag, const unsigned short *__restrict__ row_list,
+                     unsigned char *__restrict__ out, int *__restrict__ err_flag, const RowRec *__restrict__ row_list,
                      const int *__restrict__ row_cnt) {
     __shared__ int4 s_slots[SLOT_CAP];
     __shared__ ListEntry s_list[LIST_CAP];
@@ -360,7 +376,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
     const long e_begin = edge_off[img], e_end = edge_off[img + 1];
     // the candidates of this super-tile: the edges of its row of super-tiles (raster_rowbin_kernel), or the whole graph
     const int trow = tile / tiles_x;
-    const unsigned short *rl = row_list ? row_list + (size_t)e_begin * tiles_y + (size_t)trow * (size_t)(e_end - e_begin) : nullptr;
+    const RowRec *rl = row_list ? row_list + (size_t)e_begin * tiles_y + (size_t)trow * (size_t)(e_end - e_begin) : nullptr;
     const int n_edges = rl ? row_cnt[img * tiles_y + trow] : (int)(e_end - e_begin);      // positions in rl (or edges)
     const EdgeMeta *gm = meta + e_begin;
     const BBox16 *gb = bbox + e_begin;
@@ -398,11 +414,12 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                 int e = e0 + q;
                 cnt[q] = 0;
                 if (e < n_edges) {
-                    const int ed = rl ? (int)rl[e] : e;     // the edge at that position
-                    bb[q] = gb[ed];
+                    int nv_rec = 0;
+                    if (rl) { const RowRec rc = rl[e]; bb[q] = rc.bb; nv_rec = rc.nv; }      // ONE 16-byte load per candidate
+                    else bb[q] = gb[e];
                     bool hit = bb[q].x0 <= bb[q].x1 && bb[q].x1 >= tx0 && bb[q].x0 <= tx1 && bb[q].y1 >= ty0 && bb[q].y0 <= ty1;
                     if (hit) {
-                        int nv = gm[ed].nv;
+                        int nv = rl ? nv_rec : gm[e].nv;
                         cnt[q] = nv + EXTRA_SLOTS;
                         hits++;
                         slots += cnt[q];
@@ -417,12 +434,17 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                 if (cnt[q] > 0) {
                     if (pos < LIST_CAP && sp + cnt[q] <= SLOT_CAP) {
                         ListEntry le;
-                        const int ed = rl ? (int)rl[e0 + q] : e0 + q;      // read again (a cache hit) rather than kept: the kernel sits at its register limit
-                        le.edge = ed;
                         le.slot_off = sp;
                         le.nv = cnt[q] - EXTRA_SLOTS;
                         le.bb = bb[q];
-                        le.side_off = side_off[e_begin + ed] + side_block_sums[(e_begin + ed) / SCAN_BLK];
+                        if (rl) {
+                            const RowRec rc = rl[e0 + q];                  // read again (a cache hit) rather than kept: the kernel sits at its register limit
+                            le.edge = rc.edge;
+                            le.side_off = rc.side_off;
+                        } else {
+                            le.edge = e0 + q;
+                            le.side_off = side_off[e_begin + e0 + q] + side_block_sums[(e_begin + e0 + q) / SCAN_BLK];
+                        }
                         s_list[pos] = le;
                     } else {
                         atomicMin(&s_ctl[0], e0 + q);
@@ -1056,18 +1078,19 @@ extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, co
     }
     const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST_Y - 1) / ST_Y;
     // edges per row of super-tiles (u16 indices inside a graph): every graph must have fewer than 65 536 edges, and one row must be worth it
-    const unsigned short *row_list = nullptr;
+    const RowRec *row_list = nullptr;
     const int *row_cnt = nullptr;
     {
         static const bool rowbin_on = [] { const char *e = getenv("OCTA_RASTER_ROWBIN"); return !(e && e[0] == '0'); }();
         long max_graph = 0;
         for (int b = 0; b < B; b++) max_graph = std::max<long>(max_graph, (long)(h_edge_off[b + 1] - h_edge_off[b]));
         if (rowbin_on && n_total > 0 && tiles_y > 1 && max_graph < 65536) {
-            if (ctx->r_tile_list.reserve(sizeof(unsigned short) * (size_t)n_total * tiles_y + 16)) return -1;
+            if (ctx->r_tile_list.reserve(sizeof(RowRec) * (size_t)n_total * tiles_y + 16)) return -1;
             if (ctx->r_tile_fill.reserve(sizeof(int) * (size_t)B * tiles_y)) return -1;
             hipLaunchKernelGGL(raster_rowbin_kernel, dim3((unsigned)tiles_y, (unsigned)B), dim3(256), 0, stream, ctx->r_ucount.as<BBox16>(),
-                               ctx->r_edge_off.as<long>(), H, tiles_y, ctx->r_tile_list.as<unsigned short>(), ctx->r_tile_fill.as<int>());
-            row_list = ctx->r_tile_list.as<unsigned short>();
+                               ctx->r_edge_off.as<long>(), H, tiles_y, ctx->r_tile_list.as<RowRec>(), ctx->r_tile_fill.as<int>(), ctx->r_edge_meta.as<EdgeMeta>(),
+                               ctx->r_tile_count.as<int>(), ctx->r_seg_total.as<int>());
+            row_list = ctx->r_tile_list.as<RowRec>();
             row_cnt = ctx->r_tile_fill.as<int>();
         }
     }
