@@ -340,6 +340,10 @@ __device__ __forceinline__ void block_scan2(int a, int b, int *sh /*[2*16+2]*/, 
     __syncthreads();
 }
 
+// RB: the candidates come as records from raster_rowbin_kernel (the usual case); false: every edge of the graph is a candidate and its box,
+// side count and side offset are looked up here (graphs of 65 536 edges and more, OCTA_RASTER_ROWBIN=0). Two instantiations: the look-up
+// path's three array pointers cost the record path scalar registers it spills
+template <bool RB>
 __global__ void __launch_bounds__(WG)
 raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict__ bbox,
                      const long *__restrict__ edge_off, const int4 *__restrict__ sides, const int *__restrict__ side_off,
@@ -376,8 +380,8 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
     const long e_begin = edge_off[img], e_end = edge_off[img + 1];
     // the candidates of this super-tile: the edges of its row of super-tiles (raster_rowbin_kernel), or the whole graph
     const int trow = tile / tiles_x;
-    const RowRec *rl = row_list ? row_list + (size_t)e_begin * tiles_y + (size_t)trow * (size_t)(e_end - e_begin) : nullptr;
-    const int n_edges = rl ? row_cnt[img * tiles_y + trow] : (int)(e_end - e_begin);      // positions in rl (or edges)
+    const RowRec *rl = RB ? row_list + (size_t)e_begin * tiles_y + (size_t)trow * (size_t)(e_end - e_begin) : nullptr;
+    const int n_edges = RB ? row_cnt[img * tiles_y + trow] : (int)(e_end - e_begin);      // positions in rl (or edges)
     const EdgeMeta *gm = meta + e_begin;
     const BBox16 *gb = bbox + e_begin;
 
@@ -414,12 +418,10 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                 int e = e0 + q;
                 cnt[q] = 0;
                 if (e < n_edges) {
-                    int nv_rec = 0;
-                    if (rl) { const RowRec rc = rl[e]; bb[q] = rc.bb; nv_rec = rc.nv; }      // ONE 16-byte load per candidate
-                    else bb[q] = gb[e];
+                    bb[q] = RB ? rl[e].bb : gb[e];                 // (the record's other half is read in the hit branch: the same 16-byte line)
                     bool hit = bb[q].x0 <= bb[q].x1 && bb[q].x1 >= tx0 && bb[q].x0 <= tx1 && bb[q].y1 >= ty0 && bb[q].y0 <= ty1;
                     if (hit) {
-                        int nv = rl ? nv_rec : gm[e].nv;
+                        int nv = RB ? (int)rl[e].nv : gm[e].nv;
                         cnt[q] = nv + EXTRA_SLOTS;
                         hits++;
                         slots += cnt[q];
@@ -437,7 +439,7 @@ raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict
                         le.slot_off = sp;
                         le.nv = cnt[q] - EXTRA_SLOTS;
                         le.bb = bb[q];
-                        if (rl) {
+                        if constexpr (RB) {
                             const RowRec rc = rl[e0 + q];                  // read again (a cache hit) rather than kept: the kernel sits at its register limit
                             le.edge = rc.edge;
                             le.side_off = rc.side_off;
@@ -1095,7 +1097,7 @@ extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, co
         }
     }
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)B);
-    hipLaunchKernelGGL(raster_render_kernel, grid, dim3(WG), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(),
+    hipLaunchKernelGGL((row_list ? raster_render_kernel<true> : raster_render_kernel<false>), grid, dim3(WG), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(),
                        ctx->r_ucount.as<BBox16>(), ctx->r_edge_off.as<long>(), ctx->r_sides.as<int4>(), ctx->r_tile_count.as<int>(),
                        ctx->r_seg_total.as<int>(), W, H, tiles_x, tiles_y, d_out, ctx->r_counters.as<int>(), row_list, row_cnt);
     OCTA_HIP_CHECK(hipGetLastError());
