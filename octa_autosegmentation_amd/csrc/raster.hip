@@ -42,9 +42,15 @@ constexpr int ST_Y = 4 * BLK_H; // super-tile height: 4 blocks (16 waves)
 constexpr int WG = 1024;        // threads per render workgroup
 constexpr int EPT = 4;          // edges tested per thread per scan round (8 measured slower in round 4: bin 602 -> 656 WG-ms per 128 labels)
 constexpr int LIST_CAP = 512;   // edges per chunk (1024 until round 5: the batched fold's cell lists need the LDS; a 64 x 64 super-tile of a 13 k-edge graph lists 60 - 150)
-constexpr int FB = 4;           // edges folded per batch
+#ifndef OCTA_RASTER_FB
+#define OCTA_RASTER_FB 4
+#endif
+#ifndef OCTA_RASTER_CELL_CAP
+#define OCTA_RASTER_CELL_CAP 160
+#endif
+constexpr int FB = OCTA_RASTER_FB;   // edges folded per batch (their list indices travel in one 64-bit word, 10 bits each: at most 6)
 constexpr int FB_MAX_SLOTS = 32;// an edge with more side slots than this is folded on its own
-constexpr int CELL_CAP = 160;   // cells (incl. carried covers) per wave and batch
+constexpr int CELL_CAP = OCTA_RASTER_CELL_CAP;   // cells (incl. carried covers) per wave and batch
 constexpr int SLOT_CAP = 4096;  // int4 side slots per chunk (64 KiB; 80 KiB until the fold's accumulators needed 33 KiB, round 4)
 constexpr int ITEM_CAP = 256;   // (side, scanline) work items of one edge inside one wave's block
 
