@@ -38,8 +38,11 @@ using namespace octa_raster;
 constexpr int NPX = 4;          // adjacent pixels of one row per lane (register pressure vs. division reuse)
 constexpr int BLK_H = 4 * NPX;  // a wave owns a 16 x BLK_H pixel block (16/NPX lanes per row)
 constexpr int ST = 64;          // super-tile width (pixels): 4 blocks
-constexpr int ST_Y = 4 * BLK_H; // super-tile height: 4 blocks (16 waves)
-constexpr int WG = 1024;        // threads per render workgroup
+#ifndef OCTA_RASTER_WG
+#define OCTA_RASTER_WG 512
+#endif
+constexpr int WG = OCTA_RASTER_WG;             // threads per render workgroup: 16 waves (8: a 64 x 32 super-tile)
+constexpr int ST_Y = (WG / 64 / 4) * BLK_H;    // super-tile height: a wave per 16 x 16 block, four blocks across
 constexpr int EPT = 4;          // edges tested per thread per scan round (8 measured slower in round 4: bin 602 -> 656 WG-ms per 128 labels)
 constexpr int LIST_CAP = 512;   // edges per chunk (1024 until round 5: the batched fold's cell lists need the LDS; a 64 x 64 super-tile of a 13 k-edge graph lists 60 - 150)
 #ifndef OCTA_RASTER_FB
@@ -51,7 +54,7 @@ constexpr int LIST_CAP = 512;   // edges per chunk (1024 until round 5: the batc
 constexpr int FB = OCTA_RASTER_FB;   // edges folded per batch (their list indices travel in one 64-bit word, 10 bits each: at most 6)
 constexpr int FB_MAX_SLOTS = 32;// an edge with more side slots than this is folded on its own
 constexpr int CELL_CAP = OCTA_RASTER_CELL_CAP;   // cells (incl. carried covers) per wave and batch
-constexpr int SLOT_CAP = 4096;  // int4 side slots per chunk (64 KiB; 80 KiB until the fold's accumulators needed 33 KiB, round 4)
+constexpr int SLOT_CAP = 4 * WG;  // int4 side slots per chunk (64 KiB; 80 KiB until the fold's accumulators needed 33 KiB, round 4)
 constexpr int ITEM_CAP = 256;   // (side, scanline) work items of one edge inside one wave's block
 
 // ---- kernel 1: per-edge record ---------------------------------------------------------------
