@@ -41,21 +41,34 @@ constexpr int ST = 64;          // super-tile width (pixels): 4 blocks
 #ifndef OCTA_RASTER_WG
 #define OCTA_RASTER_WG 512
 #endif
-constexpr int WG = OCTA_RASTER_WG;             // threads per render workgroup: 16 waves (8: a 64 x 32 super-tile)
+// Round 5 (last): the render workgroup is 512 threads on a 64 x 32 super-tile and its LDS lists are sized so that THREE fit a CU (52.9 KB,
+// 77 registers: six waves per SIMD). One 1024-thread workgroup per CU (rounds 2-5: 145 KB of LDS) kept the vector pipe 55 % busy at four
+// waves per SIMD, sixteen waves waiting at every barrier for the slowest block: labels 8.38 ms per 128; two workgroups of 512: 7.15; three:
+// 6.26 (256 threads: 7.96). The capacities below only decide how often a list is worked off in several chunks / an edge folds alone.
+constexpr int WG = OCTA_RASTER_WG;             // threads per render workgroup: 8 waves = a 64 x 32 super-tile (1024: 64 x 64)
 constexpr int ST_Y = (WG / 64 / 4) * BLK_H;    // super-tile height: a wave per 16 x 16 block, four blocks across
 constexpr int EPT = 4;          // edges tested per thread per scan round (8 measured slower in round 4: bin 602 -> 656 WG-ms per 128 labels)
-constexpr int LIST_CAP = 512;   // edges per chunk (1024 until round 5: the batched fold's cell lists need the LDS; a 64 x 64 super-tile of a 13 k-edge graph lists 60 - 150)
+#ifndef OCTA_RASTER_LIST_CAP
+#define OCTA_RASTER_LIST_CAP 256
+#endif
+constexpr int LIST_CAP = OCTA_RASTER_LIST_CAP;   // edges per chunk (1024 until round 5: the batched fold's cell lists need the LDS; a 64 x 64 super-tile of a 13 k-edge graph lists 60 - 150)
 #ifndef OCTA_RASTER_FB
 #define OCTA_RASTER_FB 4
 #endif
 #ifndef OCTA_RASTER_CELL_CAP
-#define OCTA_RASTER_CELL_CAP 160
+#define OCTA_RASTER_CELL_CAP 128
 #endif
 constexpr int FB = OCTA_RASTER_FB;   // edges folded per batch (their list indices travel in one 64-bit word, 10 bits each: at most 6)
 constexpr int FB_MAX_SLOTS = 32;// an edge with more side slots than this is folded on its own
 constexpr int CELL_CAP = OCTA_RASTER_CELL_CAP;   // cells (incl. carried covers) per wave and batch
-constexpr int SLOT_CAP = 4 * WG;  // int4 side slots per chunk (64 KiB; 80 KiB until the fold's accumulators needed 33 KiB, round 4)
-constexpr int ITEM_CAP = 256;   // (side, scanline) work items of one edge inside one wave's block
+#ifndef OCTA_RASTER_SLOTS_PER_THREAD
+#define OCTA_RASTER_SLOTS_PER_THREAD 2
+#endif
+constexpr int SLOT_CAP = OCTA_RASTER_SLOTS_PER_THREAD * WG;  // int4 side slots per chunk (64 KiB; 80 KiB until the fold's accumulators needed 33 KiB, round 4)
+#ifndef OCTA_RASTER_ITEM_CAP
+#define OCTA_RASTER_ITEM_CAP 192
+#endif
+constexpr int ITEM_CAP = OCTA_RASTER_ITEM_CAP;   // (side, scanline) work items of one edge inside one wave's block
 
 // ---- kernel 1: per-edge record ---------------------------------------------------------------
 
