@@ -365,8 +365,11 @@ __device__ __forceinline__ void block_scan2(int a, int b, int *sh /*[2*16+2]*/, 
 // RB: the candidates come as records from raster_rowbin_kernel (the usual case); false: every edge of the graph is a candidate and its box,
 // side count and side offset are looked up here (graphs of 65 536 edges and more, OCTA_RASTER_ROWBIN=0). Two instantiations: the look-up
 // path's three array pointers cost the record path scalar registers it spills
+#ifndef OCTA_RASTER_MIN_WGS
+#define OCTA_RASTER_MIN_WGS 1
+#endif
 template <bool RB>
-__global__ void __launch_bounds__(WG)
+__global__ void __launch_bounds__(WG, OCTA_RASTER_MIN_WGS)
 raster_render_kernel(const EdgeMeta *__restrict__ meta, const BBox16 *__restrict__ bbox,
                      const long *__restrict__ edge_off, const int4 *__restrict__ sides, const int *__restrict__ side_off,
                      const int *__restrict__ side_block_sums, int W, int H, int tiles_x, int tiles_y,
