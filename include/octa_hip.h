@@ -523,6 +523,11 @@ int octa_sim_create(octa_ctx *ctx, const octa_sim_config *cfg, int B, octa_sim *
 int octa_sim_create_ex(octa_ctx *ctx, const octa_sim_config *cfg, int B, int build, octa_sim **out);
 void octa_sim_destroy(octa_sim *sim);
 
+/* Persistent-kernel launches of this process so far (any simulator, any thread): with several generators in flight a caller that has just
+ * finished its own octa_sim_run can wait for the count to move -- the next launch is then on the GPU -- before it enqueues its rasterisation
+ * (the pipeline does: enqueued at the same moment, the rasteriser can take the CUs first and delay the whole launch by its own duration). */
+long long octa_sim_launch_count(void);
+
 /* Run all iterations for B samples. Synchronous (the bifurcation service needs the host). Returns 0, -1 (runtime
  * failure), -2 (bad arguments) or -3 (a sample set error bits: capacity, or 0x800 = the host did not answer in time). */
 int octa_sim_run(octa_sim *sim, const uint32_t *h_np_seeds, const uint64_t *h_py_seeds, octa_bif_fn bif, void *user,

@@ -52,6 +52,7 @@ using namespace OCTA_SIMK;
 #define octa_sim_kat_kd_order OCTA_SIM_FN(kat_kd_order)
 struct OCTA_SIM_T;
 extern "C" void octa_sim_destroy(OCTA_SIM_T *S);
+extern "C" void octa_sim_note_launch(void);
 
 namespace {
 
@@ -1040,6 +1041,7 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
             hipLaunchKernelGGL(sim_persistent_kernel, dim3((unsigned)grid), dim3(SIM_THREADS), SIM_LDS, stream, P, M);
             OCTA_HIP_CHECK(hipGetLastError());
             OCTA_HIP_CHECK(hipEventRecord(S->ev[1], stream));
+            octa_sim_note_launch();          // process-wide count of persistent-kernel launches (csrc/sim_api.cpp: octa_sim_launch_count)
             launches++;
             long idle = 0;
             auto last_progress = clk::now(), iter_start = last_progress;

@@ -37,6 +37,16 @@ OCTA_DECL(L, octa_simL_impl)
 int octa_simS_kat_kd_order(octa_ctx *, const double *, int64_t, const uint8_t *, int32_t *);
 }
 
+// Persistent-kernel launches of this process so far, both builds (round 5). A generator that has just finished its own launch waits for the
+// NEXT launch to be on the GPU before it enqueues its rasterisation (pipeline.py): the render workgroups (145 KB of LDS: a CU to themselves)
+// and the next launch's 512 simulator workgroups otherwise race for the CUs the finished launch has just left -- when the rasteriser wins,
+// the whole rasterisation (45 ms per 512 triples) runs before the launch can place its workgroups: one launch in three measured 462
+// instead of 410 ms.
+#include <atomic>
+static std::atomic<long long> g_sim_launches{0};
+extern "C" void octa_sim_note_launch(void) { g_sim_launches.fetch_add(1, std::memory_order_release); }
+extern "C" long long octa_sim_launch_count(void) { return g_sim_launches.load(std::memory_order_acquire); }
+
 struct octa_sim {
     bool large = false;
     octa_simS_impl *s = nullptr;

@@ -58,6 +58,19 @@ class TripleGenerator:
             with self.sim_gate:
                 t0 = time.time()
                 res = self.sim.run(seeds)
+                n_launch = _native.lib().octa_sim_launch_count()
+            # The rasterisation of this batch must not race the NEXT launch for the CUs this launch has just left: a render workgroup
+            # takes a whole CU (145 KB of LDS), and when the rasteriser is placed first the next launch cannot start before the whole
+            # rasterisation is through (one launch in three: 462 instead of 410 ms). So: wait until the next launch is on the GPU -- its
+            # workgroups then hold every slot and the render workgroups get what finished samples leave --, or until none is coming.
+            t_w = time.time()
+            while _native.lib().octa_sim_launch_count() == n_launch:
+                waited = time.time() - t_w
+                if waited > 0.05 or (waited > 0.002 and not self.sim_gate.locked()):
+                    break
+                time.sleep(0.0002)
+            else:
+                time.sleep(0.0005)         # the launch call has returned: give the dispatcher the time to place the workgroups
         else:
             res = self.sim.run(seeds)
         t1 = time.time()
