@@ -1,7 +1,7 @@
 #!/bin/bash
 # what happens between two persistent-kernel launches of the headline leg
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rm -rf /tmp/ktb; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ktb -- python bench.py --no-train --no-files --no-long --no-cpu-baseline --no-pmc > /tmp/ktb.log 2>&1
+rm -rf /tmp/ktb; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ktb -- python bench.py ${BENCH_ARGS:---steps 20 --warmup 5} --no-train --no-files --no-long --no-cpu-baseline --no-pmc > /tmp/ktb.log 2>&1
 python - <<'PY'
 import csv, glob, re
 rows = []
