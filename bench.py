@@ -530,6 +530,8 @@ def main():
     sizes = sorted({G} | ({args.warmup % G} if args.warmup % G else set()) | ({args.steps % G} if args.steps % G else set()))
     gens = {g: [pipeline.TripleGenerator(cfg, B * g) for _ in range(n_fly)] for g in sizes}
     streams = [torch.cuda.Stream() for _ in range(n_fly)]
+    if os.environ.get("OCTA_BENCH_PLAN_AHEAD") == "1":
+        pipeline.TripleGenerator.plan_ahead = True
     if args.serial_sim and n_fly > 1:
         import threading
         gate = threading.Lock()

@@ -72,6 +72,17 @@ int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, const int64_t
                       const uint8_t *d_keep, int no_pixels_x, int no_pixels_y, int mip_axis,
                       double min_radius, double max_radius, uint8_t *d_out, void *stream);
 
+/* octa_rasterize_2d in two calls, for callers that share the GPU with a long-running kernel (pipeline.py: the generator rasterises one
+ * batch while the persistent simulator kernel of the next one holds the CUs). _plan takes octa_rasterize_2d's arguments without d_out, runs
+ * the per-edge records and the side-offset scan and performs the rasteriser's ONE host synchronisation (the side array is sized from the
+ * scan total) and every scratch allocation; _draw enqueues tessellation, row binning and the ordered fold on `stream` and never waits for
+ * the device. A context holds one plan: every _draw consumes the plan of the _plan before it (-2 without one). Same stream for both.
+ * octa_rasterize_2d(...) == _plan(...) followed by _draw(d_out). */
+int octa_rasterize_2d_plan(octa_ctx *ctx, int B, const double *d_edges, const int64_t *h_edge_off,
+                           const uint8_t *d_keep, int no_pixels_x, int no_pixels_y, int mip_axis,
+                           double min_radius, double max_radius, void *stream);
+int octa_rasterize_2d_draw(octa_ctx *ctx, uint8_t *d_out, void *stream);
+
 /* Diagnostics of the last octa_rasterize_2d call: h_out4 = {error flag, ticks in edge binning, ticks in
  * stroke tessellation, ticks in the ordered fold}; ticks are 100 MHz wall-clock ticks summed over workgroups. */
 int octa_raster_prof(octa_ctx *ctx, int64_t *h_out4);

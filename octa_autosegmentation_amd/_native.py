@@ -25,6 +25,8 @@ SIGNATURES = {
     "octa_ctx_scratch_bytes": (c_size_t, [c_void_p]),
     "octa_rasterize_2d": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double,
                                   c_double, c_void_p, c_void_p]),
+    "octa_rasterize_2d_plan": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_void_p]),
+    "octa_rasterize_2d_draw": (c_int, [c_void_p, c_void_p, c_void_p]),
     "octa_raster_prof": (c_int, [c_void_p, c_void_p]),
     "octa_fs_dither": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "octa_voxel_padded_dims": (c_int, [c_void_p, c_void_p]),

@@ -89,6 +89,8 @@ struct octa_ctx {
     octa::DevBuf r_tile_total;  // int64 [B]
     octa::DevBuf r_tile_list;   // int32 [sum tile counts]
     octa::DevBuf r_counters;    // int64 [8] misc device counters
+    // what octa_rasterize_2d_plan left for octa_rasterize_2d_draw (raster.hip)
+    struct RasterPlan { bool valid = false, rowbin = false; int B = 0, W = 0, H = 0; long n_total = 0; } r_plan;
     octa::DevBuf zero_page;     // 256 zero bytes: source of the padding pixels of the DMA-staged convolution (conv.hip)
     octa::DevBuf wgrad_ws;      // per-workgroup partial weight gradients of conv3x3_nhwc_wgrad_tr_kernel (conv.hip), stream-ordered like the rest
     // ring of pre-zeroed accumulator slots (norm.hip statistics): ONE memset per lap instead of one per launch. Stream-ordered

@@ -1057,12 +1057,17 @@ __global__ void max_u8_kernel(const unsigned char *a, const unsigned char *b, un
 
 // ---- C-ABI -----------------------------------------------------------------------------------
 
-extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, const int64_t *h_edge_off,
-                                 const uint8_t *d_keep, int no_pixels_x, int no_pixels_y, int mip_axis,
-                                 double min_radius, double max_radius, uint8_t *d_out, void *stream_) {
+// The rasteriser in two calls (round 5). _plan: per-edge records, side offsets, and the ONE host synchronisation of the rasteriser (the
+// side array is sized from the scan total) -- a few short kernels; _draw: tessellation, row binning and the ordered fold, enqueued
+// without touching the host or the allocator. A pipeline that shares the GPU with a long kernel plans while the GPU is free and draws
+// whenever it likes: nothing of the heavy part can end up queued behind a host wait (pipeline.py). octa_rasterize_2d = both.
+extern "C" int octa_rasterize_2d_plan(octa_ctx *ctx, int B, const double *d_edges, const int64_t *h_edge_off,
+                                      const uint8_t *d_keep, int no_pixels_x, int no_pixels_y, int mip_axis,
+                                      double min_radius, double max_radius, void *stream_) {
     if (!ctx) { octa::set_error("octa_rasterize_2d: null ctx"); return -2; }
+    ctx->r_plan = octa_ctx::RasterPlan();
     if (B <= 0) return 0;
-    if (!h_edge_off || !d_out) { octa::set_error("octa_rasterize_2d: null pointer"); return -2; }
+    if (!h_edge_off) { octa::set_error("octa_rasterize_2d: null pointer"); return -2; }
     if (mip_axis < 0 || mip_axis > 2) { octa::set_error("octa_rasterize_2d: MIP_axis must be 0, 1 or 2"); return -2; }
     const int W = no_pixels_x, H = no_pixels_y;
     if (W <= 0 || H <= 0 || W > 16000 || H > 16000) { octa::set_error("octa_rasterize_2d: bad resolution %dx%d", W, H); return -2; }
@@ -1102,15 +1107,12 @@ extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, co
         OCTA_HIP_CHECK(hipStreamSynchronize(stream));
         if (total_sides > 0x7fffffffL) { octa::set_error("octa_rasterize_2d: %ld polygon sides exceed the 32-bit offset range", total_sides); return -2; }
         if (ctx->r_sides.reserve(sizeof(int4) * (size_t)(total_sides + 1))) return -1;
-        hipLaunchKernelGGL(raster_tess_kernel, dim3((unsigned)((n_total + TESS_WG - 1) / TESS_WG)), dim3(TESS_WG), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(), ctx->r_tile_count.as<int>(),
-                           ctx->r_seg_total.as<int>(), n_total, W, H, ctx->r_sides.as<int4>(), ctx->r_counters.as<int>());
     } else {
         if (ctx->r_sides.reserve(sizeof(int4))) return -1;
     }
-    const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST_Y - 1) / ST_Y;
+    const int tiles_y = (H + ST_Y - 1) / ST_Y;
     // edges per row of super-tiles (u16 indices inside a graph): every graph must have fewer than 65 536 edges, and one row must be worth it
-    const RowRec *row_list = nullptr;
-    const int *row_cnt = nullptr;
+    bool rowbin = false;
     {
         static const bool rowbin_on = [] { const char *e = getenv("OCTA_RASTER_ROWBIN"); return !(e && e[0] == '0'); }();
         long max_graph = 0;
@@ -1118,6 +1120,32 @@ extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, co
         if (rowbin_on && n_total > 0 && tiles_y > 1 && max_graph < 65536) {
             if (ctx->r_tile_list.reserve(sizeof(RowRec) * (size_t)n_total * tiles_y + 16)) return -1;
             if (ctx->r_tile_fill.reserve(sizeof(int) * (size_t)B * tiles_y)) return -1;
+            rowbin = true;
+        }
+    }
+    ctx->r_plan.valid = true; ctx->r_plan.rowbin = rowbin;
+    ctx->r_plan.B = B; ctx->r_plan.W = W; ctx->r_plan.H = H; ctx->r_plan.n_total = n_total;
+    return 0;
+}
+
+extern "C" int octa_rasterize_2d_draw(octa_ctx *ctx, uint8_t *d_out, void *stream_) {
+    if (!ctx) { octa::set_error("octa_rasterize_2d: null ctx"); return -2; }
+    if (!ctx->r_plan.valid) { octa::set_error("octa_rasterize_2d_draw: no plan (octa_rasterize_2d_plan must precede every draw)"); return -2; }
+    if (!d_out) { octa::set_error("octa_rasterize_2d: null pointer"); return -2; }
+    const int B = ctx->r_plan.B, W = ctx->r_plan.W, H = ctx->r_plan.H;
+    const long n_total = ctx->r_plan.n_total;
+    const bool rowbin = ctx->r_plan.rowbin;
+    ctx->r_plan.valid = false;                  // the scratch holds ONE plan; it is consumed here
+    hipStream_t stream = (hipStream_t)stream_;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n_total > 0)
+        hipLaunchKernelGGL(raster_tess_kernel, dim3((unsigned)((n_total + TESS_WG - 1) / TESS_WG)), dim3(TESS_WG), 0, stream, ctx->r_edge_meta.as<EdgeMeta>(), ctx->r_tile_count.as<int>(),
+                           ctx->r_seg_total.as<int>(), n_total, W, H, ctx->r_sides.as<int4>(), ctx->r_counters.as<int>());
+    const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST_Y - 1) / ST_Y;
+    const RowRec *row_list = nullptr;
+    const int *row_cnt = nullptr;
+    {
+        if (rowbin) {
             hipLaunchKernelGGL(raster_rowbin_kernel, dim3((unsigned)tiles_y, (unsigned)B), dim3(256), 0, stream, ctx->r_ucount.as<BBox16>(),
                                ctx->r_edge_off.as<long>(), H, tiles_y, ctx->r_tile_list.as<RowRec>(), ctx->r_tile_fill.as<int>(), ctx->r_edge_meta.as<EdgeMeta>(),
                                ctx->r_tile_count.as<int>(), ctx->r_seg_total.as<int>());
@@ -1131,6 +1159,15 @@ extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, co
                        ctx->r_seg_total.as<int>(), W, H, tiles_x, tiles_y, d_out, ctx->r_counters.as<int>(), row_list, row_cnt);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+extern "C" int octa_rasterize_2d(octa_ctx *ctx, int B, const double *d_edges, const int64_t *h_edge_off,
+                                 const uint8_t *d_keep, int no_pixels_x, int no_pixels_y, int mip_axis,
+                                 double min_radius, double max_radius, uint8_t *d_out, void *stream_) {
+    if (B > 0 && !d_out) { octa::set_error("octa_rasterize_2d: null pointer"); return -2; }
+    const int rc = octa_rasterize_2d_plan(ctx, B, d_edges, h_edge_off, d_keep, no_pixels_x, no_pixels_y, mip_axis, min_radius, max_radius, stream_);
+    if (rc || B <= 0) return rc;
+    return octa_rasterize_2d_draw(ctx, d_out, stream_);
 }
 
 extern "C" int octa_fs_dither(octa_ctx *ctx, int B, const uint8_t *d_in, int W, int H, uint8_t *d_out, void *stream_) {

@@ -28,6 +28,7 @@ class TripleGenerator:
         self.device = torch.device("cuda", torch.cuda.current_device() if device_index is None else device_index)
         self.sim = greenhouse.BatchSimulator(config, batch, self.device.index)
         self._ctx = _native.new_ctx(self.device.index)   # this slot's rasteriser scratch
+        self._ctx_label = _native.new_ctx(self.device.index)   # a second one: image and label rasterisation are planned together (_plan)
         g, o = config["Greenhouse"], config.get("output", {})
         shape = np.array([g["SimulationSpace"][k] for k in ("no_voxel_x", "no_voxel_y", "no_voxel_z")])
         vol = [int(d) for d in shape * o.get("image_scale_factor", 304)]          # generate_vessel_graph.py:43
@@ -42,16 +43,18 @@ class TripleGenerator:
 
     def close(self):
         self.sim.close()
-        if self._ctx is not None:
-            _native.free_ctx(self._ctx)
-            self._ctx = None
+        for name in ("_ctx", "_ctx_label"):
+            if getattr(self, name) is not None:
+                _native.free_ctx(getattr(self, name))
+                setattr(self, name, None)
 
+    plan_ahead = False   # without a gate: plan before drawing all the same (experiments with several persistent kernels at a time)
     sim_gate = None      # optional threading.Lock shared by the generators of a device (bench.py --serial-sim)
 
     def generate(self, seeds, want_label=True):
         """Returns dict(result=SimulationResult, image=uint8 CUDA [B,H,W], label=uint8 CUDA {0,255} [B,1216,1216])."""
         import time
-        t0 = time.time()
+        t0 = t_req = t_rel = time.time()
         if self.sim_gate is not None:
             # several generators in flight, ONE persistent kernel at a time: the next launch starts when this one has left the GPU,
             # this launch's rasterisation then shares the GPU with it (and fills the tail of the launch before)
@@ -59,11 +62,14 @@ class TripleGenerator:
                 t0 = time.time()
                 res = self.sim.run(seeds)
                 n_launch = _native.lib().octa_sim_launch_count()
+                # every host wait of the rasterisation happens HERE, while the GPU is free: what is enqueued later (behind the next
+                # launch's workgroups) is then never cut in two by a wait -- the second half used to queue behind the launch AFTER the next
+                plans = None if self.time_render else self._plan(res, want_label)
             # The rasterisation of this batch must not race the NEXT launch for the CUs this launch has just left: a render workgroup
             # takes a whole CU (145 KB of LDS), and when the rasteriser is placed first the next launch cannot start before the whole
             # rasterisation is through (one launch in three: 462 instead of 410 ms). So: wait until the next launch is on the GPU -- its
             # workgroups then hold every slot and the render workgroups get what finished samples leave --, or until none is coming.
-            t_w = time.time()
+            t_w = t_rel = time.time()
             while _native.lib().octa_sim_launch_count() == n_launch:
                 waited = time.time() - t_w
                 if waited > 0.05 or (waited > 0.002 and not self.sim_gate.locked()):
@@ -73,13 +79,64 @@ class TripleGenerator:
                 time.sleep(0.0005)         # the launch call has returned: give the dispatcher the time to place the workgroups
         else:
             res = self.sim.run(seeds)
+            t_rel = time.time()
+            plans = self._plan(res, want_label) if (self.plan_ahead and not self.time_render) else None
         t1 = time.time()
-        with _native.use_ctx(self._ctx):
-            out = self._render(res, want_label)
-        out["wall"] = {"t_start": t0, "sim_run_s": t1 - t0, "render_enqueue_s": time.time() - t1}     # host-side stamps (bench.py's slot accounting)
+        out = self._render(res, want_label, plans)
+        out["wall"] = {"t_start": t0, "sim_run_s": t1 - t0, "render_enqueue_s": time.time() - t1,      # host-side stamps (bench.py's slot accounting)
+                       "t_request": t_req, "t_released": t_rel}                                                               # when the call asked for the gate
         return out
 
-    def _render(self, res, want_label):
+    def _plan(self, res, want_label):
+        """The host-synchronising part of the rasterisation of `res` (tree2img.rasterize_edges_device_plan): CSV read-back emulation,
+        per-edge records and side-offset scans of the image and of the label rasterisation, each on its own context."""
+        import torch
+        B = self.batch
+        off, n_art = res.edge_off, res.n_art
+        # the simulator exported the edge list on the device (round 3): no host BFS, no PCIe round trip of ~93 MB per 128 samples
+        d_edges = res.d_edges if res.d_edges is not None else torch.from_numpy(res.edges).to(self.device, non_blocking=True)
+        d_rb = None
+        with _native.use_ctx(self._ctx):
+            if self.image_mode == "cli":
+                # 2B graphs: arterial_k, venous_k interleaved -> max of the pairs (np.maximum(art_mat, ven_mat))
+                split = np.empty(2 * B + 1, np.int64)
+                split[0::2] = off
+                split[1::2] = off[:-1] + n_art
+                p_img = tree2img.rasterize_edges_device_plan(d_edges, split, self.image_res, self.proj_axis)
+            else:
+                d_rb = graph_io.edges_as_read_back_device(d_edges)
+                p_img = tree2img.rasterize_edges_device_plan(d_rb, off, self.image_res, self.proj_axis, min_radius=self.image_min_radius)
+        p_lab = None
+        if want_label:
+            with _native.use_ctx(self._ctx_label):
+                if d_rb is None:
+                    d_rb = graph_io.edges_as_read_back_device(d_edges)
+                p_lab = tree2img.rasterize_edges_device_plan(d_rb, off, self.label_res, 2, min_radius=self.label_min_radius)
+        return dict(image=p_img, label=p_lab, keep=(d_edges, d_rb))
+
+    def _render(self, res, want_label, plans=None):
+        import torch
+        B = self.batch
+        if plans is not None:
+            # planned while the GPU was free (generate): nothing below waits for the device
+            image = tree2img.rasterize_edges_device_draw(plans["image"])
+            if self.image_mode == "cli":
+                pair = image.view(B, 2, image.shape[1], image.shape[2])
+                with _native.use_ctx(self._ctx):
+                    image = tree2img.maximum_u8_device(pair[:, 0].contiguous(), pair[:, 1].contiguous())
+            out = dict(result=res, image=image)
+            if want_label:
+                grey = tree2img.rasterize_edges_device_draw(plans["label"])
+                out["label_grey"] = grey
+                with _native.use_ctx(self._ctx_label):
+                    out["label"] = tree2img.binarize_label_device(grey)
+            return out
+        with _native.use_ctx(self._ctx):
+            return self._render_timed(res, want_label)
+
+    def _render_timed(self, res, want_label):
+        """The rasterisation stage by stage in one go (plan and draw back to back), with HIP events around the stages when
+        `time_render` is set -- what bench.py's rasteriser figures are read from."""
         import torch
         B = self.batch
         off, n_art = res.edge_off, res.n_art

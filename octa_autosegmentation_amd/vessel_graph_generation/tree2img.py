@@ -58,12 +58,10 @@ def select_edges(forest, min_radius=0, max_radius=1, max_dropout_prob=0, blackdi
     return edges, blackdict
 
 
-def rasterize_edges_device(d_edges, edge_off, image_resolution, MIP_axis=2, min_radius=0.0, max_radius=1.0,
-                           d_keep=None, out=None):
-    """Batched device entry: d_edges float64 CUDA tensor [n_total,7], edge_off int64 host array [B+1].
-
-    Returns a uint8 CUDA tensor [B, no_pixels_y, no_pixels_x]. Asynchronous on the current stream.
-    """
+def rasterize_edges_device_plan(d_edges, edge_off, image_resolution, MIP_axis=2, min_radius=0.0, max_radius=1.0, d_keep=None):
+    """First half of rasterize_edges_device (octa_rasterize_2d_plan): the per-edge records and the side-offset scan, with the
+    rasteriser's one host synchronisation. Returns the token rasterize_edges_device_draw takes; the context's scratch holds ONE plan,
+    so plan and draw of a call pair must not be interleaved with another pair on the same context (_native.use_ctx)."""
     import torch
     no_pixels_x, no_pixels_y = int(image_resolution[0]), int(image_resolution[1])
     edge_off = np.ascontiguousarray(edge_off, dtype=np.int64)
@@ -72,16 +70,34 @@ def rasterize_edges_device(d_edges, edge_off, image_resolution, MIP_axis=2, min_
         raise ValueError("d_edges must be a contiguous float64 CUDA tensor")
     if d_edges.numel() != int(edge_off[-1]) * 7:
         raise ValueError("edge_off[-1] does not match the number of edges")
-    if out is None:
-        out = torch.empty((B, no_pixels_y, no_pixels_x), dtype=torch.uint8, device=d_edges.device)
     h = _native.ctx(d_edges.device.index)
-    rc = _native.lib().octa_rasterize_2d(
+    rc = _native.lib().octa_rasterize_2d_plan(
         h, B, ctypes.c_void_p(d_edges.data_ptr()), ctypes.c_void_p(edge_off.ctypes.data),
         ctypes.c_void_p(d_keep.data_ptr()) if d_keep is not None else None,
-        no_pixels_x, no_pixels_y, int(MIP_axis), float(min_radius), float(max_radius),
-        ctypes.c_void_p(out.data_ptr()), _native.current_stream_ptr())
-    _native.check(rc, "octa_rasterize_2d")
+        no_pixels_x, no_pixels_y, int(MIP_axis), float(min_radius), float(max_radius), _native.current_stream_ptr())
+    _native.check(rc, "octa_rasterize_2d_plan")
+    return dict(ctx=h, shape=(B, no_pixels_y, no_pixels_x), device=d_edges.device)
+
+
+def rasterize_edges_device_draw(plan, out=None):
+    """Second half (octa_rasterize_2d_draw): tessellation, row binning and the ordered fold of the planned call, enqueued on the
+    current stream without a host synchronisation. Returns the uint8 CUDA tensor [B, no_pixels_y, no_pixels_x]."""
+    import torch
+    if out is None:
+        out = torch.empty(plan["shape"], dtype=torch.uint8, device=plan["device"])
+    if plan["shape"][0] > 0:
+        rc = _native.lib().octa_rasterize_2d_draw(plan["ctx"], ctypes.c_void_p(out.data_ptr()), _native.current_stream_ptr())
+        _native.check(rc, "octa_rasterize_2d_draw")
     return out
+
+
+def rasterize_edges_device(d_edges, edge_off, image_resolution, MIP_axis=2, min_radius=0.0, max_radius=1.0,
+                           d_keep=None, out=None):
+    """Batched device entry: d_edges float64 CUDA tensor [n_total,7], edge_off int64 host array [B+1].
+
+    Returns a uint8 CUDA tensor [B, no_pixels_y, no_pixels_x]. Asynchronous on the current stream.
+    """
+    return rasterize_edges_device_draw(rasterize_edges_device_plan(d_edges, edge_off, image_resolution, MIP_axis, min_radius, max_radius, d_keep), out)
 
 
 def _rasterize_colorized_cpu(edges, image_resolution, MIP_axis, colorize):

@@ -39,6 +39,34 @@ def test_full_graphs_bit_exact(t2i, raster_golden):
     assert hashlib.sha256(out[0].tobytes()).hexdigest() == str(g["graph0_img1216_minr_sha256"])
 
 
+def test_plan_and_draw_are_the_two_halves_of_one_call(t2i, raster_golden):
+    """octa_rasterize_2d_plan / _draw (pipeline.py plans two rasterisations while the GPU is free and draws them later): two plans on two
+    contexts, drawn in the other order, give the golden images; a context holds one plan and a draw consumes it."""
+    import torch
+    from octa_autosegmentation_amd import _native
+    g = raster_golden
+    e0, e1 = np.asarray(g["graph0_edges"], np.float64), np.asarray(g["graph1_edges"], np.float64)
+    off = np.array([0, len(e0), len(e0) + len(e1)], np.int64)
+    d = torch.from_numpy(np.concatenate([e0, e1])).cuda()
+    a, b = _native.new_ctx(), _native.new_ctx()
+    try:
+        with _native.use_ctx(a):
+            p_small = t2i.rasterize_edges_device_plan(d, off, [304, 304])
+        with _native.use_ctx(b):
+            p_large = t2i.rasterize_edges_device_plan(d, off, [1216, 1216])
+        del d                                           # the plans hold everything the draws read
+        torch.cuda.empty_cache()
+        large = t2i.rasterize_edges_device_draw(p_large).cpu().numpy()
+        small = t2i.rasterize_edges_device_draw(p_small).cpu().numpy()
+        assert (small[0] == g["graph0_img304"]).all() and (small[1] == g["graph1_img304"]).all()
+        assert (large[0] == g["graph0_img1216"]).all() and (large[1] == g["graph1_img1216"]).all()
+        with pytest.raises(_native.OctaHipError, match="no plan"):
+            t2i.rasterize_edges_device_draw(p_small)    # consumed
+    finally:
+        _native.free_ctx(a)
+        _native.free_ctx(b)
+
+
 def test_labels_bit_exact(t2i, raster_golden):
     import torch
     g = raster_golden
