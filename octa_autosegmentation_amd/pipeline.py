@@ -48,7 +48,7 @@ class TripleGenerator:
                 _native.free_ctx(getattr(self, name))
                 setattr(self, name, None)
 
-    plan_ahead = False   # without a gate: plan before drawing all the same (experiments with several persistent kernels at a time)
+    plan_ahead = False   # plan both rasterisations (octa_rasterize_2d_plan) right after the simulator call, draw later without host waits
     sim_gate = None      # optional threading.Lock shared by the generators of a device (bench.py --serial-sim)
 
     def generate(self, seeds, want_label=True):
@@ -62,14 +62,16 @@ class TripleGenerator:
                 t0 = time.time()
                 res = self.sim.run(seeds)
                 n_launch = _native.lib().octa_sim_launch_count()
-                # every host wait of the rasterisation happens HERE, while the GPU is free: what is enqueued later (behind the next
-                # launch's workgroups) is then never cut in two by a wait -- the second half used to queue behind the launch AFTER the next
-                plans = None if self.time_render else self._plan(res, want_label)
+            t_rel = time.time()
+            # plan_ahead: every host wait of the rasterisation happens HERE, while the next launch is still being prepared on the host
+            # (~9 ms) and the GPU is free; what is enqueued later (behind the next launch's workgroups) is then never cut in two by a
+            # wait. Measured neutral to slightly negative (1114 against 1122 samples/s), hence not the default.
+            plans = self._plan(res, want_label) if (self.plan_ahead and not self.time_render) else None
             # The rasterisation of this batch must not race the NEXT launch for the CUs this launch has just left: a render workgroup
             # takes a whole CU (145 KB of LDS), and when the rasteriser is placed first the next launch cannot start before the whole
             # rasterisation is through (one launch in three: 462 instead of 410 ms). So: wait until the next launch is on the GPU -- its
             # workgroups then hold every slot and the render workgroups get what finished samples leave --, or until none is coming.
-            t_w = t_rel = time.time()
+            t_w = time.time()
             while _native.lib().octa_sim_launch_count() == n_launch:
                 waited = time.time() - t_w
                 if waited > 0.05 or (waited > 0.002 and not self.sim_gate.locked()):

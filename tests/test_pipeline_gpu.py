@@ -70,11 +70,12 @@ def test_device_read_back_matches_host_emulation(hip_lib_built):
     assert (got == want).all(), np.nonzero((got != want).any(axis=1))[0][:10]
 
 
-@pytest.mark.parametrize("gated", [False, True])
+@pytest.mark.parametrize("gated", [False, True, "planned"])
 def test_three_steps_in_flight_are_independent(hip_lib_built, gated):
     """bench.py keeps several steps in flight from a thread pool: each thread must get its own scratch context
     and stream, and every image / label must still be the oracle's -- with all persistent kernels resident at once and with
-    bench.py's default, one persistent kernel at a time (TripleGenerator.sim_gate) while the other launches are rasterised."""
+    bench.py's default, one persistent kernel at a time (TripleGenerator.sim_gate) while the other launches are rasterised; "planned":
+    the gated form with both rasterisations planned ahead (octa_rasterize_2d_plan / _draw on two contexts per slot)."""
     import threading
     import torch
     from concurrent.futures import ThreadPoolExecutor
@@ -90,6 +91,7 @@ def test_three_steps_in_flight_are_independent(hip_lib_built, gated):
         gate = threading.Lock()
         for gen in gens:
             gen.sim_gate = gate
+            gen.plan_ahead = gated == "planned"
     streams = [torch.cuda.Stream() for _ in range(n_fly)]
     dev = torch.cuda.current_device()
 
