@@ -2130,7 +2130,8 @@ extern "C" int octa_pack_conv_weights(octa_ctx *ctx, const int64_t *d_table, int
     if (!ctx || !d_table || !d_dst || L <= 0 || L > 65535) { octa::set_error("octa_pack_conv_weights: bad arguments"); return -2; }
     hipStream_t stream = (hipStream_t)stream_;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(64, (unsigned)L), dim3(256), 0, stream, reinterpret_cast<const long *>(d_table),
+    // 256 workgroups per layer: the launch lasts as long as the largest layer's share (512 x 512 x 9: 85 us with 64 workgroups on it, one per step)
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(256, (unsigned)L), dim3(256), 0, stream, reinterpret_cast<const long *>(d_table),
                        static_cast<unsigned short *>(d_dst));
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
