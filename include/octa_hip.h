@@ -428,7 +428,13 @@ int octa_thinconv_expand(octa_ctx *ctx, const void *d_s, const void *d_w, const 
                          int pad, int flip, float slope, void *stream);
 int octa_thinconv_squeeze(octa_ctx *ctx, const void *d_a, const void *d_w, const void *d_bias, void *d_out, int N, int Ha, int Wa, int C, int K,
                           int pad, int flip, void *stream);
+/* (octa_thinconv_squeeze also takes K = 3 with 8, 16, 32 or 64 channels: the data gradient of the one-channel 3 x 3 first layer whose forward and
+ * weight gradient are octa_conv3x3_c1_fwd2 / octa_conv3x3_c1_wgrad -- dx = squeeze(dy, w, K = 3, pad = 1, flip = 1) -- for a segmentor whose
+ * input image is another network's output, models/gan_seg_model.py:147-149.) */
 long long octa_thinconv_wgrad_scratch_floats(int N, int Ha, int C, int K);
+/* LeakyReLU' on a gradient by the sign of the layer's bf16 OUTPUT: out[i] = y[i] > 0 ? dy[i] : bf16(dy[i] * slope), n elements, 16-byte aligned
+ * tensors. The expand layer fuses LeakyReLU into its forward (the PatchGAN stem, models/networks.py:433-436); this is the first step of its backward. */
+int octa_lrelu_bwd_bf16(octa_ctx *ctx, const void *d_y, const void *d_dy, void *d_out, int64_t n, float slope, void *stream);
 int octa_thinconv_wgrad(octa_ctx *ctx, const void *d_a, const void *d_s, void *d_scratch, void *d_g, void *d_asum, int N, int Ha, int Wa, int Hs,
                         int Ws, int C, int K, int pad, int flip, void *stream);
 

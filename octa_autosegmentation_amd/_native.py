@@ -56,6 +56,7 @@ SIGNATURES = {
     "octa_sim_np_state": (c_int, [c_void_p, c_int, c_void_p]),
     "octa_thinconv_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p]),
     "octa_thinconv_squeeze": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "octa_lrelu_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, ctypes.c_float, c_void_p]),
     "octa_thinconv_wgrad_scratch_floats": (ctypes.c_longlong, [c_int, c_int, c_int, c_int]),
     "octa_thinconv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_sim_spans": (c_int, [c_void_p, c_void_p]),

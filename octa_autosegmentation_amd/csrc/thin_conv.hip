@@ -433,6 +433,29 @@ thin_wgrad_reduce_kernel(const float *__restrict__ partial, int n_blocks, int C,
     else if (asum) asum[c] = v;
 }
 
+// LeakyReLU' applied to an incoming gradient by the sign of the layer's OUTPUT (slope > 0: the output's sign is its input's): out = y > 0 ? dy :
+// dy * slope, one rounding. The expand layer fuses the activation into its forward; its backward used three torch launches for this (compare,
+// scale, select: 125 us per 94 MB gradient of the discriminator's stem against ~40 us here).
+__global__ void __launch_bounds__(256)
+lrelu_bwd_kernel(const bf16_t *__restrict__ y, const bf16_t *__restrict__ dy, bf16_t *__restrict__ out, long n8, long n, float slope) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const uint4 a = reinterpret_cast<const uint4 *>(y)[i], g = reinterpret_cast<const uint4 *>(dy)[i];
+        const unsigned av[4] = {a.x, a.y, a.z, a.w}, gv[4] = {g.x, g.y, g.z, g.w};
+        unsigned r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bf16_t y0 = (bf16_t)(av[k] & 0xffffu), y1 = (bf16_t)(av[k] >> 16), g0 = (bf16_t)(gv[k] & 0xffffu), g1 = (bf16_t)(gv[k] >> 16);
+            const bf16_t o0 = bf2f(y0) > 0.f ? g0 : f2bf(bf2f(g0) * slope), o1 = bf2f(y1) > 0.f ? g1 : f2bf(bf2f(g1) * slope);
+            r[k] = (unsigned)o0 | ((unsigned)o1 << 16);
+        }
+        reinterpret_cast<uint4 *>(out)[i] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 8 * n8)) {          // the last n % 8 elements
+        const long i = 8 * n8 + threadIdx.x;
+        out[i] = bf2f(y[i]) > 0.f ? dy[i] : f2bf(bf2f(dy[i]) * slope);
+    }
+}
+
 bool shape_ok(const char *fn, int N, int H, int W, int C, int K, int pad) {
     if (N <= 0 || H <= 0 || W <= 0 || (K != 4 && K != 7) || pad < 0 || pad >= K || H + 2 * pad < K || W + 2 * pad < K) {
         octa::set_error("%s: unsupported shape (N %d, H %d, W %d, K %d, pad %d; K is 4 or 7)", fn, N, H, W, K, pad);
@@ -463,6 +486,20 @@ extern "C" int octa_thinconv_expand(octa_ctx *ctx, const void *d_s, const void *
 extern "C" int octa_thinconv_squeeze(octa_ctx *ctx, const void *d_a, const void *d_w, const void *d_bias, void *d_out, int N, int Ha, int Wa, int C,
                                      int K, int pad, int flip, void *stream_) {
     if (!ctx || !d_a || !d_w || !d_out) { octa::set_error("octa_thinconv_squeeze: null argument"); return -2; }
+    if (K == 3) {
+        // the data gradient of a one-channel 3 x 3 first layer (C -> 1; csrc/conv.hip's c1 kernels are its forward and weight gradient): the
+        // segmentor's input in the GAN-seg step is the generator's image, so the gradient has to reach it. Wide form only: 8 - 64 channels
+        if (N <= 0 || Ha <= 0 || Wa <= 0 || pad < 0 || pad >= K || Ha + 2 * pad < K || Wa + 2 * pad < K || (C != 8 && C != 16 && C != 32 && C != 64)) {
+            octa::set_error("octa_thinconv_squeeze: K = 3 needs 8, 16, 32 or 64 channels (N %d, H %d, W %d, C %d, pad %d)", N, Ha, Wa, C, pad);
+            return -2;
+        }
+        OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+        const int Ho3 = Ha + 2 * pad - K + 1, Wo3 = Wa + 2 * pad - K + 1;
+        hipLaunchKernelGGL((thin_squeeze_wide_kernel<3, 4>), dim3((unsigned)((long long)N * Ho3)), dim3(TC_THREADS), (size_t)C * 9 * sizeof(float), (hipStream_t)stream_,
+                           (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho3, Wo3, C, pad, flip);
+        OCTA_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (!shape_ok("octa_thinconv_squeeze", N, Ha, Wa, C, K, pad)) return -2;
     OCTA_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
@@ -482,6 +519,19 @@ extern "C" int octa_thinconv_squeeze(octa_ctx *ctx, const void *d_a, const void 
     }
     if (K == 7) hipLaunchKernelGGL((thin_squeeze_kernel<7, 8>), dim3(grid), dim3(TC_THREADS), lds, stream, (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho, Wo, C, pad, flip);
     else hipLaunchKernelGGL((thin_squeeze_kernel<4, 8>), dim3(grid), dim3(TC_THREADS), lds, stream, (const bf16_t *)d_a, (const float *)d_w, (const float *)d_bias, (bf16_t *)d_out, N, Ha, Wa, Ho, Wo, C, pad, flip);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int octa_lrelu_bwd_bf16(octa_ctx *ctx, const void *d_y, const void *d_dy, void *d_out, int64_t n, float slope, void *stream_) {
+    if (!ctx || !d_y || !d_dy || !d_out || n <= 0) { octa::set_error("octa_lrelu_bwd_bf16: bad arguments"); return -2; }
+    if ((reinterpret_cast<size_t>(d_y) | reinterpret_cast<size_t>(d_dy) | reinterpret_cast<size_t>(d_out)) & 15) { octa::set_error("octa_lrelu_bwd_bf16: the tensors must be 16-byte aligned"); return -2; }
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const long n8 = (long)(n / 8);
+    long blocks = (n8 + 255) / 256;
+    if (blocks > 16L * ctx->num_cus) blocks = 16L * ctx->num_cus;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16_t *)d_y, (const bf16_t *)d_dy, (bf16_t *)d_out, n8, (long)n, slope);
     OCTA_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -563,9 +563,15 @@ def conv3x3_reflect(x, weight):
     return conv3x3(resample.reflect_pad(x, 1, "nhwc"), weight, 1)[:, 1:-1, 1:-1, :]
 
 
+USE_C1_DGRAD = os.environ.get("OCTA_C1_DGRAD", "1") != "0"      # A/B switch of the one-channel layer's streaming data gradient (round 5)
+
+
 class _Conv3x3C1(torch.autograd.Function):
-    """First layer: one input channel (no data gradient: the input is the image). want_stats: also the InstanceNorm statistics of the
-    result in slot form (double [STAT_SLOTS][N][Cout][2], accumulated by the kernel's epilogue: the norm needs no statistics pass)."""
+    """First layer: one input channel. want_stats: also the InstanceNorm statistics of the result in slot form (double
+    [STAT_SLOTS][N][Cout][2], accumulated by the kernel's epilogue: the norm needs no statistics pass). The data gradient -- needed when
+    the image is itself a network's output: the segmentor behind the generator in the GAN-seg step -- is the C -> 1 streaming kernel of
+    csrc/thin_conv.hip with the flipped taps (round 5; until then such an input took the matrix-core kernels with the image zero-padded to
+    32 channels: a 757 MB fill + copy in front of the layer and a 32-channel data gradient + slice copy behind it)."""
 
     @staticmethod
     def forward(ctx, x, weight, want_stats=False):
@@ -584,6 +590,7 @@ class _Conv3x3C1(torch.autograd.Function):
         ctx.save_for_backward(x)
         ctx.w_shape, ctx.w_dtype = weight.shape, weight.dtype
         ctx.weight_ref = weight
+        ctx.wf = wf if ctx.needs_input_grad[0] else None        # the taps as the forward used them (fp32 [Cout][9]): the data gradient's weights
         if want_stats:
             ctx.mark_non_differentiable(part)
             return y, part
@@ -605,13 +612,20 @@ class _Conv3x3C1(torch.autograd.Function):
                                                      ctypes.c_void_p(dw.data_ptr()), n, h, w, cout, _native.current_stream_ptr())
             _native.check(rc, "octa_conv3x3_c1_wgrad")
             return dw.view(ctx.w_shape).to(ctx.w_dtype)
-        return None, _wgrad_to(ctx.weight_ref, wg), None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dx[n][y][x] = sum_co sum_t dy[n][y + 1 - ky][x + 1 - kx][co] * w[co][t]: the C -> 1 convolution of dy with the flipped kernel, pad K - 1 - 1
+            dx = torch.empty((n, h, w, 1), dtype=torch.bfloat16, device=x.device)
+            rc = _native.lib().octa_thinconv_squeeze(_native.ctx(x.device.index), ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(ctx.wf.data_ptr()), None,
+                                                     ctypes.c_void_p(dx.data_ptr()), n, h, w, cout, 3, 1, 1, _native.current_stream_ptr())
+            _native.check(rc, "octa_thinconv_squeeze")
+        return dx, _wgrad_to(ctx.weight_ref, wg) if ctx.needs_input_grad[1] else None, None
 
 
 def conv3x3(x, weight, stride=1, want_stats=False, mailbox=None):
     """want_stats: also return the statistics for instance_norm_leaky_relu_nhwc(..., partials=)."""
     if (x.shape[-1] == 1 and weight.shape[1] == 1 and stride == 1 and weight.shape[0] in (8, 16, 32, 64)
-            and not x.requires_grad and x.shape[2] <= 3840):
+            and x.shape[2] <= 3840 and (USE_C1_DGRAD or not x.requires_grad)):
         if want_stats == "tiles":                        # the per-tile form belongs to the MFMA kernel: the norm runs its own statistics pass
             return _Conv3x3C1.apply(x, weight, False), None
         return _Conv3x3C1.apply(x, weight, bool(want_stats))          # streaming first-layer kernels

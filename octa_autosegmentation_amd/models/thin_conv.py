@@ -76,7 +76,10 @@ class _ConvFrom1(torch.autograd.Function):
         k, pad, slope, has_bias, x_dtype = ctx.cfg
         dy = _bf16c(dy)
         if slope != 1.0:                                   # LeakyReLU': the sign of the output is the sign of its input (slope > 0)
-            dy = torch.where(y > 0, dy, dy * slope)
+            g = torch.empty_like(dy)                       # one launch instead of torch's compare, scale and select (same values: y > 0 ? dy : bf16(dy * slope))
+            _native.check(_native.lib().octa_lrelu_bwd_bf16(_native.ctx(dy.device.index), _ptr(y), _ptr(dy), _ptr(g), dy.numel(), float(slope),
+                                                           _native.current_stream_ptr()), "octa_lrelu_bwd_bf16")
+            dy = g
         dx = _squeeze(dy, _w2d(weight), None, k, k - 1 - pad, True).to(x_dtype) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):

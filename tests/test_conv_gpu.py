@@ -597,3 +597,15 @@ def test_first_layer_kernels_match_torch(hip_lib_built):
         w2 = wt.detach().clone().requires_grad_(True)
         (gr,) = torch.autograd.grad(F.conv2d(x.float().permute(0, 3, 1, 2), w2, padding=1), w2, dy.float().permute(0, 3, 1, 2))
         assert (gw - gr).abs().max().item() <= 2e-4 * gr.abs().max().item() + 1e-5, (n, h, w, cout)
+        # data gradient (the image is another network's output: the segmentor behind the generator): the streaming C -> 1 kernel against fp32,
+        # and the weight gradient unchanged by asking for it
+        xg = x.clone().requires_grad_(True)
+        yg = mc.conv3x3(xg, wt, 1, False)
+        assert torch.equal(yg, y)
+        gx, gw2 = torch.autograd.grad(yg, (xg, wt), dy)
+        x32 = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+        (gxr,) = torch.autograd.grad(F.conv2d(x32, wt.detach(), padding=1), x32, dy.float().permute(0, 3, 1, 2))
+        gxr = gxr.permute(0, 2, 3, 1)
+        assert gx.shape == x.shape and gx.dtype == torch.bfloat16
+        assert (gx.float() - gxr).abs().max().item() <= 2.0 ** -8 * gxr.abs().max().item() + 1e-6, (n, h, w, cout)
+        assert torch.equal(gw2, gw)

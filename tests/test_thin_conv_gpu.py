@@ -72,3 +72,19 @@ def test_unsupported_shapes_are_refused(hip_lib_built):
     conv = torch.nn.Conv2d(1, 48, 7).cuda()
     with pytest.raises(_native.OctaHipError):
         thin_conv.conv_from_1(torch.zeros(1, 16, 16, device="cuda"), conv)
+
+
+def test_lrelu_backward_kernel_equals_the_torch_expression(hip_lib_built):
+    """octa_lrelu_bwd_bf16 (one launch in the backward of the expand layer with its fused LeakyReLU) against torch.where(y > 0, dy, dy * slope),
+    bit for bit, including a length that is no multiple of the 8-element vectors."""
+    import ctypes
+    from octa_autosegmentation_amd import _native
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for n in (8 * 1000 + 5, 3, 64 * 303 * 303):
+        y = torch.randn(n, device="cuda", generator=g).to(torch.bfloat16)
+        y[::17] = 0.0
+        dy = torch.randn(n, device="cuda", generator=g).to(torch.bfloat16)
+        out = torch.empty_like(dy)
+        _native.check(_native.lib().octa_lrelu_bwd_bf16(_native.ctx(0), ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                       n, 0.2, _native.current_stream_ptr()), "octa_lrelu_bwd_bf16")
+        assert torch.equal(out, torch.where(y > 0, dy, dy * 0.2)), n
