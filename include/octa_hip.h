@@ -282,6 +282,11 @@ int octa_conv3x3_nhwc_fwd_pad(octa_ctx *ctx, const void *d_x, const void *d_w, v
                               int reflect, void *stream);
 int octa_conv3x3_nhwc_wgrad_pad(octa_ctx *ctx, const void *d_x, const void *d_dy, float *d_dw, int N, int H, int W, int Cin, int Cout, int pad,
                                 int reflect, void *stream);
+/* octa_conv3x3_nhwc_fwd_pad with the InstanceNorm statistics of the result accumulated by the kernel's epilogue in slot form (d_stat_slots: double
+ * [nslot][N][Cout][2], zeroed by the caller, consumed by octa_instnorm_lrelu_nhwc_fwd_s; as octa_conv3x3_nhwc_fwd7): the generator's residual
+ * blocks are reflect-padded convolution -> InstanceNorm (models/networks.py:151-176), 18 per pass. NULL slots = octa_conv3x3_nhwc_fwd_pad. */
+int octa_conv3x3_nhwc_fwd_pad_s(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int pad,
+                                int reflect, double *d_stat_slots, int nslot, void *stream);
 
 /* Weight gradient with a stride: stride 2 = d_x is the [N][H][W][Cin] input of a stride-2 layer (H, W even), d_dy its
  * [N][H/2][W/2][Cout] output gradient; tap_mask as above (the 2x2 transposed convolution, written as the adjoint of a

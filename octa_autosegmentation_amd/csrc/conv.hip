@@ -988,9 +988,22 @@ extern "C" int octa_conv4x4_nhwc_fwd(octa_ctx *ctx, const void *d_x, const void 
 // 3 x 3 convolution, stride 1, with an explicit padding: pad = 0 (valid), 1 (same) or 2 (full: what the data gradient of a valid
 // convolution is), zeros outside the image -- or, reflect = 1 with pad = 1, nn.ReflectionPad2d(1) fused into the halo fetch (the
 // ResNet blocks of the generator, models/networks.py:_resblock_nhwc: no padded copy, no cropped copy). Output (H + 2 pad - 2)^2.
+extern "C" int octa_conv3x3_nhwc_fwd_pad_s(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int pad,
+                                           int reflect, double *d_stat_slots, int nslot, void *stream_);
 extern "C" int octa_conv3x3_nhwc_fwd_pad(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int pad,
                                          int reflect, void *stream_) {
+    return octa_conv3x3_nhwc_fwd_pad_s(ctx, d_x, d_w, d_y, N, H, W, Cin, Cout, pad, reflect, nullptr, 0, stream_);
+}
+
+// ... with the InstanceNorm statistics of the result accumulated by the epilogue in slot form (d_stat_slots: double [nslot][N][Cout][2], zeroed by
+// the caller; as octa_conv3x3_nhwc_fwd7): the generator's residual blocks are reflect-padded convolution -> InstanceNorm, 18 of them per pass,
+// and each paid a statistics launch over a tensor that had just been written (round 5). NULL slots = octa_conv3x3_nhwc_fwd_pad.
+extern "C" int octa_conv3x3_nhwc_fwd_pad_s(octa_ctx *ctx, const void *d_x, const void *d_w, void *d_y, int N, int H, int W, int Cin, int Cout, int pad,
+                                           int reflect, double *d_stat_slots, int nslot, void *stream_) {
     if (!ctx || !d_x || !d_w || !d_y) { octa::set_error("octa_conv3x3_nhwc_fwd_pad: null pointer"); return -2; }
+    if (d_stat_slots && (nslot <= 0 || nslot > 1024)) { octa::set_error("octa_conv3x3_nhwc_fwd_pad_s: statistics slots need 1..1024 slots"); return -2; }
+    if (!d_stat_slots) nslot = 0;
+    float *part = reinterpret_cast<float *>(d_stat_slots);      // one kernel argument: read as double slots when nslot > 0
     if (N <= 0 || N > 65535 || H <= 0 || W <= 0 || pad < 0 || pad > 2 || H + 2 * pad < 3 || W + 2 * pad < 3) { octa::set_error("octa_conv3x3_nhwc_fwd_pad: bad shape"); return -2; }
     if (reflect && (pad != 1 || H < 2 || W < 2)) { octa::set_error("octa_conv3x3_nhwc_fwd_pad: reflection needs pad = 1 and an image of at least 2 x 2"); return -2; }
     if (Cin % 32 || Cout % 32 || Cin <= 0 || Cout <= 0) { octa::set_error("octa_conv3x3_nhwc_fwd_pad: Cin and Cout must be multiples of 32 (got %d, %d)", Cin, Cout); return -2; }
@@ -1002,10 +1015,10 @@ extern "C" int octa_conv3x3_nhwc_fwd_pad(octa_ctx *ctx, const void *d_x, const v
     const unsigned short *X = static_cast<const unsigned short *>(d_x), *Wt = static_cast<const unsigned short *>(d_w);
     unsigned short *Y = static_cast<unsigned short *>(d_y);
     if (Cout % 64 == 0) {
-        if (Ho >= 200) return launch_conv_glds<64, 16, 1, 3, 16>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, nullptr, 0x1ff, 1, 0, 0, stream, pad, nullptr, reflect);
-        return launch_conv_glds<64, 16>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, nullptr, 0x1ff, 1, 0, 0, stream, pad, nullptr, reflect);
+        if (Ho >= 200) return launch_conv_glds<64, 16, 1, 3, 16>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, part, 0x1ff, 1, 0, 0, stream, pad, nullptr, reflect, nslot);
+        return launch_conv_glds<64, 16>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, part, 0x1ff, 1, 0, 0, stream, pad, nullptr, reflect, nslot);
     }
-    return launch_conv_glds<32, 16>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, nullptr, 0x1ff, 1, 0, 0, stream, pad, nullptr, reflect);
+    return launch_conv_glds<32, 16>(X, nullptr, Cin, Wt, Y, nullptr, Cout, N, H, W, Cin, Ho, Wo, Cout, 1, z, part, 0x1ff, 1, 0, 0, stream, pad, nullptr, reflect, nslot);
 }
 
 // ---- weight gradient (stride 1) ----------------------------------------------------------------------------------

@@ -505,22 +505,31 @@ class _Conv3x3ReflectNHWC(torch.autograd.Function):
     the data gradient is the full (pad 2) convolution of dy with the flipped weights, folded back by the reflection's adjoint."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats=False):
         x = x.contiguous()
         n, h, w, cin = x.shape
         cout = weight.shape[0]
+        ctx.set_materialize_grads(False)
         y = torch.empty((n, h, w, cout), dtype=torch.bfloat16, device=x.device)
         wt = pack_weight(weight, cin)
-        rc = _native.lib().octa_conv3x3_nhwc_fwd_pad(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wt.data_ptr()),
-                                                     ctypes.c_void_p(y.data_ptr()), n, h, w, cin, cout, 1, 1, _native.current_stream_ptr())
-        _native.check(rc, "octa_conv3x3_nhwc_fwd_pad")
+        part = _stat_slots(x.device, n, cout) if want_stats else None       # InstanceNorm statistics from the epilogue (slot form, as conv3x3)
+        rc = _native.lib().octa_conv3x3_nhwc_fwd_pad_s(_native.ctx(x.device.index), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wt.data_ptr()),
+                                                       ctypes.c_void_p(y.data_ptr()), n, h, w, cin, cout, 1, 1,
+                                                       ctypes.c_void_p(part.data_ptr()) if part is not None else None, STAT_SLOTS if part is not None else 0,
+                                                       _native.current_stream_ptr())
+        _native.check(rc, "octa_conv3x3_nhwc_fwd_pad_s")
         ctx.save_for_backward(x, weight)
+        if want_stats:
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpart=None):
         from . import resample
         x, weight = ctx.saved_tensors
+        if dy is None:
+            return None, None, None
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
@@ -549,18 +558,20 @@ class _Conv3x3ReflectNHWC(torch.autograd.Function):
                                                          ctypes.c_void_p(g.data_ptr()), n, h, w, cin, cout, 1, 1, int(acc), _native.current_stream_ptr())
                 _native.check(rc, "octa_conv3x3_nhwc_wgrad_pad_acc")
             dw = _wgrad_to(weight, wg, direct)
-        return dx, dw
+        return dx, dw, None
 
 
 USE_FUSED_REFLECT = os.environ.get("OCTA_FUSED_REFLECT", "1") != "0"     # A/B switch (development aid)
 
 
-def conv3x3_reflect(x, weight):
-    """ReflectionPad2d(1) + 3x3 convolution without padding; x [N,H,W,Cin] bf16 with Cin, Cout multiples of 32."""
+def conv3x3_reflect(x, weight, want_stats=False):
+    """ReflectionPad2d(1) + 3x3 convolution without padding; x [N,H,W,Cin] bf16 with Cin, Cout multiples of 32. want_stats: returns
+    (y, statistics slots for instance_norm_leaky_relu_nhwc(..., partials=)) -- None for the slots where the fused kernel does not apply."""
     if USE_FUSED_REFLECT and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 32 == 0 and weight.shape[0] % 32 == 0 and weight.shape[1] == x.shape[-1]:
-        return _Conv3x3ReflectNHWC.apply(x, weight)
+        return _Conv3x3ReflectNHWC.apply(x, weight, bool(want_stats))
     from . import resample
-    return conv3x3(resample.reflect_pad(x, 1, "nhwc"), weight, 1)[:, 1:-1, 1:-1, :]
+    y = conv3x3(resample.reflect_pad(x, 1, "nhwc"), weight, 1)[:, 1:-1, 1:-1, :]
+    return (y, None) if want_stats else y
 
 
 USE_C1_DGRAD = os.environ.get("OCTA_C1_DGRAD", "1") != "0"      # A/B switch of the one-channel layer's streaming data gradient (round 5)

@@ -441,10 +441,12 @@ class ResnetGenerator(nn.Module):
     def _resblock_nhwc(blk, x):
         from . import mfma_conv as mc
         c1, n1, c2, n2 = blk.conv_block[1], blk.conv_block[2], blk.conv_block[5], blk.conv_block[6]
-        h = mc.conv3x3_reflect(x, c1.weight)                                      # reflection fused into the convolution's halo fetch
-        h = mc.instance_norm_leaky_relu_nhwc(h, None, None, 0.0, n1.eps)          # InstanceNorm + ReLU
-        h = mc.conv3x3_reflect(h, c2.weight)
-        h = mc.instance_norm_leaky_relu_nhwc(h, None, None, 1.0, n2.eps)          # InstanceNorm, no activation
+        # reflection fused into the convolution's halo fetch; the norms' statistics come from the convolutions' epilogues (round 5: 18 statistics
+        # launches per generator pass gone)
+        h, part = mc.conv3x3_reflect(x, c1.weight, True) if USE_EPILOGUE_STATS else (mc.conv3x3_reflect(x, c1.weight), None)
+        h = mc.instance_norm_leaky_relu_nhwc(h, None, None, 0.0, n1.eps, part)    # InstanceNorm + ReLU
+        h, part = mc.conv3x3_reflect(h, c2.weight, True) if USE_EPILOGUE_STATS else (mc.conv3x3_reflect(h, c2.weight), None)
+        h = mc.instance_norm_leaky_relu_nhwc(h, None, None, 1.0, n2.eps, part)    # InstanceNorm, no activation
         return x + h
 
     @staticmethod

@@ -95,6 +95,17 @@ def test_reflection_fused_convolution_matches_torch(hip_lib_built, n, h, w, cin,
     finally:
         mfma_conv.USE_FUSED_REFLECT = old
     assert (y2.float() - y.detach().float()).abs().max().item() <= 2.0 ** -6 * yr.abs().max().item()
+    # statistics from the epilogue (the generator's residual blocks: reflect-padded convolution -> InstanceNorm): the same result, and the
+    # slots hold the sums of the ROUNDED values per image and channel; the norm fed with them equals the norm that makes its own pass
+    y3, part = mfma_conv.conv3x3_reflect(x0, wt0.float(), True)
+    assert torch.equal(y3, y.detach())
+    tot, yf = part.sum(0), y3.double()
+    scale = yr.abs().max().item()
+    assert torch.allclose(tot[..., 0], yf.sum((1, 2)), rtol=1e-5, atol=1e-3 * scale)
+    assert torch.allclose(tot[..., 1], (yf * yf).sum((1, 2)), rtol=1e-5, atol=1e-3 * scale * scale)
+    z_slots = mfma_conv.instance_norm_leaky_relu_nhwc(y3, None, None, 0.0, 1e-5, part)
+    z_pass = mfma_conv.instance_norm_leaky_relu_nhwc(y3, None, None, 0.0, 1e-5)
+    assert (z_slots.float() - z_pass.float()).abs().max().item() <= 2.0 ** -7 * z_pass.float().abs().max().item()
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(1, 16, 32, 32, 32), (2, 24, 40, 64, 64), (1, 37, 45, 64, 32), (2, 19, 70, 32, 64), (1, 8, 32, 128, 128)])
