@@ -19,6 +19,7 @@
 #include "common.h"
 #include "sim_host.h"
 #include <thread>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -926,23 +927,48 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
         std::vector<unsigned> py_mt((size_t)B * 625);
         const int n0 = 2 * S->cfg.n_trees;
         std::vector<double> npos((size_t)B * 2 * n0 * 3);
-        SampleInit I;
-        I.want_py_u = false;             // the uniforms are drawn on the device from the generator state (py_uniform_kernel)
-        for (int s = 0; s < B; s++) {
-            src.fill(S->cfg, s, &I);
-            memset(&sc[s], 0, sizeof(SampleScalars));
-            sc[s].faz_radius = I.faz_radius;
-            sc[s].py_cap = PYCAP;
-            sc[s].n_nodes[0] = sc[s].n_nodes[1] = n0;
-            memcpy(&mt[(size_t)s * 625], I.np_state.mt, 624 * 4);
-            mt[(size_t)s * 625 + 624] = (unsigned)I.np_state.idx;
-            vcount[s] = (unsigned)(I.valid.size() / 3);
-            if (vcount[s] == 0) { octa::set_error("octa_sim_run: sample %d has no valid voxel", s); return -2; }
-            if (P.valid_stride) memcpy(&valid[(size_t)s * P.valid_stride], I.valid.data(), I.valid.size() * 2);
-            memcpy(&py_mt[(size_t)s * 625], I.py_state.mt, 624 * 4);
-            py_mt[(size_t)s * 625 + 624] = (unsigned)I.py_state.idx;
-            for (int f = 0; f < 2; f++) memcpy(&npos[((size_t)s * 2 + f) * n0 * 3], I.pos[f].data(), sizeof(double) * n0 * 3);
+        static const bool time_init = getenv("OCTA_SIM_TIME_INIT") != nullptr;
+        const auto t_init0 = std::chrono::steady_clock::now();
+        // the samples are independent: a few host threads share them (round 5: 5.6 of the 6.9 ms this block takes for 512 samples were this
+        // loop on one core, and the block sits between two persistent kernels of the pipeline). OCTA_SIM_INIT_THREADS overrides.
+        static const int init_threads = [] {
+            if (const char *e = getenv("OCTA_SIM_INIT_THREADS")) { const int v = atoi(e); if (v >= 1) return v < 64 ? v : 64; }
+            int world = 1;
+            if (const char *e = getenv("WORLD_SIZE")) { const int v = atoi(e); if (v > 1) world = v; }
+            const int hw = (int)std::thread::hardware_concurrency();
+            const int v = hw / (2 * world);                 // half of this rank's share of the host: the service threads and the trainer need the rest
+            return v < 1 ? 1 : (v > 8 ? 8 : v);
+        }();
+        std::atomic<int> bad_sample{-1};
+        auto fill_range = [&](int s_begin, int s_end) {
+            SampleInit I;
+            I.want_py_u = false;             // the uniforms are drawn on the device from the generator state (py_uniform_kernel)
+            for (int s = s_begin; s < s_end; s++) {
+                src.fill(S->cfg, s, &I);
+                memset(&sc[s], 0, sizeof(SampleScalars));
+                sc[s].faz_radius = I.faz_radius;
+                sc[s].py_cap = PYCAP;
+                sc[s].n_nodes[0] = sc[s].n_nodes[1] = n0;
+                memcpy(&mt[(size_t)s * 625], I.np_state.mt, 624 * 4);
+                mt[(size_t)s * 625 + 624] = (unsigned)I.np_state.idx;
+                vcount[s] = (unsigned)(I.valid.size() / 3);
+                if (vcount[s] == 0) { int none = -1; bad_sample.compare_exchange_strong(none, s); continue; }
+                if (P.valid_stride) memcpy(&valid[(size_t)s * P.valid_stride], I.valid.data(), I.valid.size() * 2);
+                memcpy(&py_mt[(size_t)s * 625], I.py_state.mt, 624 * 4);
+                py_mt[(size_t)s * 625 + 624] = (unsigned)I.py_state.idx;
+                for (int f = 0; f < 2; f++) memcpy(&npos[((size_t)s * 2 + f) * n0 * 3], I.pos[f].data(), sizeof(double) * n0 * 3);
+            }
+        };
+        {
+            const int nt = B >= 64 ? (init_threads < B / 32 ? init_threads : B / 32) : 1;
+            std::vector<std::thread> pool;
+            const int per = (B + nt - 1) / nt;
+            for (int t = 1; t < nt; t++) pool.emplace_back(fill_range, t * per < B ? t * per : B, (t + 1) * per < B ? (t + 1) * per : B);
+            fill_range(0, per < B ? per : B);
+            for (auto &th : pool) th.join();
         }
+        if (bad_sample.load() >= 0) { octa::set_error("octa_sim_run: sample %d has no valid voxel", bad_sample.load()); return -2; }
+        if (time_init) fprintf(stderr, "[octa_sim] host init: per-sample fill %.2f ms for %d samples\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init0).count(), B);
         OCTA_HIP_CHECK(hipMemcpyAsync(P.sc, sc.data(), sizeof(SampleScalars) * B, hipMemcpyHostToDevice, stream));
         OCTA_HIP_CHECK(hipMemcpyAsync(P.mt_state, mt.data(), mt.size() * 4, hipMemcpyHostToDevice, stream));
         if (P.valid_stride) OCTA_HIP_CHECK(hipMemcpyAsync(P.valid, valid.data(), valid.size() * 2, hipMemcpyHostToDevice, stream));
@@ -986,6 +1012,7 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
 #endif
         OCTA_HIP_CHECK(hipMemsetAsync(P.child_group, 0, sizeof(int) * (size_t)B * NCAP, stream));
         OCTA_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
+        if (time_init) fprintf(stderr, "[octa_sim] host init: %.2f ms in all (fill + copies + fills)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init0).count());
     }
     // ---- iterations
     auto serve = [&](int slot) -> int {

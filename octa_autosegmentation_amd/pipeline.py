@@ -72,13 +72,33 @@ class TripleGenerator:
             # rasterisation is through (one launch in three: 462 instead of 410 ms). So: wait until the next launch is on the GPU -- its
             # workgroups then hold every slot and the render workgroups get what finished samples leave --, or until none is coming.
             t_w = time.time()
+            successor = True
             while _native.lib().octa_sim_launch_count() == n_launch:
                 waited = time.time() - t_w
-                if waited > 0.05 or (waited > 0.002 and not self.sim_gate.locked()):
+                if waited > 0.002 and not self.sim_gate.locked():
+                    successor = False
+                    break
+                if waited > 0.05:          # somebody holds the gate and takes its time: do not wait for it any longer
                     break
                 time.sleep(0.0002)
             else:
                 time.sleep(0.0005)         # the launch call has returned: give the dispatcher the time to place the workgroups
+            if not successor:
+                # Nobody is at the gate: the GPU is free and the rasterisation may as well run now -- but a launch must not ARRIVE while
+                # the render kernel is being dispatched: a render kernel that starts within a fraction of a millisecond of a persistent
+                # kernel keeps the CUs it got for its whole duration (its next workgroup takes the slot its last one leaves), the
+                # simulator workgroups without a slot wait for other SAMPLES to finish, and the launch lasts two samples (672 instead of
+                # 410 ms; the state then repeats launch after launch: the headline's slow mode, 1018 instead of 1130 samples/s,
+                # tools/exp_r05_slowmode.sh). With the gate held during the enqueue a launch comes either before the rasterisation
+                # (and is waited for above) or a few milliseconds after the render kernel has the GPU, which costs nothing measurable.
+                with self.sim_gate:
+                    if _native.lib().octa_sim_launch_count() == n_launch:
+                        t1 = time.time()
+                        out = self._render(res, want_label, plans)
+                        time.sleep(0.002)
+                        out["wall"] = {"t_start": t0, "sim_run_s": t1 - t0, "render_enqueue_s": time.time() - t1, "t_request": t_req, "t_released": t_rel}
+                        return out
+                time.sleep(0.0005)         # a launch slipped in between: it is resident now
         else:
             res = self.sim.run(seeds)
             t_rel = time.time()
