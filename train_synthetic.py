@@ -107,15 +107,12 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
                 out = None
                 while not stop.is_set():
                     if not limit or i < limit:
-                        if burst and i > 0:
-                            want_gpu.set()                                  # the trainer steps aside at its next step boundary (see `burst` below)
-                            while not trainer_aside.wait(0.05):
-                                if stop.is_set():
-                                    break
+                        if i > 0:
+                            turns.ask(stop)                                 # the trainer steps aside at its next step boundary (see `turns` below)
                         try:
                             out = gen.generate(sharding.rank_seeds(rank, i, gen_batch, base=seed0))
                         finally:
-                            want_gpu.clear(); trainer_aside.clear(); gpu_back.set()
+                            turns.hand_back()
                     ready = torch.cuda.Event()
                     ready.record(gen_stream)
                     if os.environ.get("OCTA_E2E_DEBUG"):
@@ -132,23 +129,16 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
         except BaseException as e:                                          # noqa: BLE001 -- handed to the consumer, which re-raises
             failure.append(e)
 
-    # Taking turns (round 5): the persistent kernel's workgroups hold every CU's LDS and registers, so a training step that shares the GPU
-    # with a generator launch takes 112 instead of 17 ms while the launch itself stretches from 410 to 729 ms (tools/exp_r05_e2e_idle.sh).
-    # The producer asks for the GPU before a launch; the trainer answers at its next step boundary with its queued kernels drained and
-    # waits until the simulator call has returned (the rasterisation that follows shares the GPU with training as before).
-    # OCTA_E2E_BURST=0: both share the GPU (rounds 1-4).
-    burst = os.environ.get("OCTA_E2E_BURST", "1") != "0"
-    want_gpu, trainer_aside, gpu_back = threading.Event(), threading.Event(), threading.Event()
+    # Taking turns (round 5, utils/turns.py): the persistent kernel's workgroups hold every CU's LDS and registers, so a training step that shares
+    # the GPU with a generator launch takes 112 instead of 17 ms while the launch itself stretches from 410 to 729 ms
+    # (tools/exp_r05_e2e_idle.sh). The producer asks for the GPU before a launch; the trainer answers at its next step boundary with its queued
+    # kernels drained and waits until the simulator call has returned (the rasterisation that follows shares the GPU with training as
+    # before). OCTA_E2E_BURST=0: both share the GPU (rounds 1-4).
+    from octa_autosegmentation_amd.utils.turns import GpuTurns
+    turns = GpuTurns(enabled=os.environ.get("OCTA_E2E_BURST", "1") != "0")
 
     def step_aside_if_asked():
-        if not (burst and want_gpu.is_set()):
-            return
-        torch.cuda.current_stream().synchronize()
-        gpu_back.clear()
-        trainer_aside.set()
-        while not gpu_back.wait(0.05):
-            if failure or not th.is_alive():
-                break
+        turns.step_aside_if_asked(lambda: torch.cuda.current_stream().synchronize(), lambda: th.is_alive() and not failure)
 
     def next_batch():
         """Blocks for the producer's next batch; a dead producer is an error here, not a silent stall (the reference swallows
