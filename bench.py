@@ -794,7 +794,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: {B}-sample vessel-graph batch (docker/vessel_graph_gen_docker_config.yml, "
                                    f"I=100+150, N=2000) + tree2img rasterise 304x304 image and 1216x1216 label",
-                       "batch_per_gpu": B, "steps_per_launch": G, "launches_in_flight": n_fly, "persistent_kernels_at_a_time": sim_conc, "parallelism": f"sample-sharded x{world}, no collective"},
+                       "batch_per_gpu": B, "steps_per_launch": G, "launches_in_flight": n_fly, "persistent_kernels_at_a_time": sim_conc, "parallelism": f"sample-sharded x{world}, no collective",
+                       "set_up": "every full-size generator primed once before the clock starts (a synthetic edge list through its rasteriser: scratch growth and kernel loading; nothing simulated)"},
             "parity": "graph CSV text bit-exact with the REFERENCE (imported and run in the build container) on 8 short + 2 full-length fixture "
                       "runs and on 64 further full-length seeds (tests/golden/sim_wide_golden.npz: SHA-256 of the CSV text of seeds 1000-1063; the "
                       "GPU reproduces all 64, tests/test_sim_gpu.py); label / image pixels bit-exact on the reference's fixtures. The oracle follows "
