@@ -11,6 +11,7 @@
 // library). Host code only (no HIP).
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -36,6 +37,7 @@ struct Native {
     octa_bif_fn fallback = nullptr;
     void *fallback_user = nullptr;
     long n_native = 0, n_fallback = 0;
+    std::atomic<int64_t> lwork3{0};     // dgeev's workspace size for a 3 x 3 matrix with right eigenvectors (0: not asked yet)
 } g;
 
 // returns false when the request must go to the numpy fallback
@@ -60,7 +62,7 @@ bool eval_one(const octa_bif_request &q, double *out6) {
     double nrm = std::sqrt(g.ddot(3, ac, 1, ac, 1));
     if (nrm != 0.0) for (int k = 0; k < 3; k++) ac[k] = ac[k] / nrm;
     // np.cov of X = (atts - c)^T: row means (again sequential), in-place centring, dot, scale
-    std::vector<double> Z((size_t)n * 3), Y((size_t)n * 3);   // Z[i][k] = X[k][i]
+    double Z[3 * OCTA_BIF_MAX_ATTS], Y[3 * OCTA_BIF_MAX_ATTS];   // Z[i][k] = X[k][i] (on the stack: a request is answered while a workgroup waits)
     for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) Z[3 * i + k] = A[3 * i + k] - c[k];
     double avg[3];
     for (int k = 0; k < 3; k++) {
@@ -69,25 +71,31 @@ bool eval_one(const octa_bif_request &q, double *out6) {
         avg[k] = s / (double)n;
     }
     for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) Z[3 * i + k] -= avg[k];
-    Y = Z;  // X.T.conj(): a C-contiguous copy
+    memcpy(Y, Z, sizeof(double) * 3 * (size_t)n);  // X.T.conj(): a C-contiguous copy
     double cm[9];
     // X (3 x n, F-contiguous = Z transposed) @ Y (n x 3, C-contiguous): row-major gemm with A transposed
-    g.dgemm(101 /*RowMajor*/, 112 /*Trans*/, 111 /*NoTrans*/, 3, 3, n, 1.0, Z.data(), 3, Y.data(), 3, 0.0, cm, 3);
+    g.dgemm(101 /*RowMajor*/, 112 /*Trans*/, 111 /*NoTrans*/, 3, 3, n, 1.0, Z, 3, Y, 3, 0.0, cm, 3);
     const double fact = 1.0 / (double)(n - 1);
     for (int k = 0; k < 9; k++) cm[k] *= fact;
     // np.linalg.eig: dgeev on the column-major copy, right eigenvectors only
     double af[9], wr[3], wi[3], vr[9], vl[1], wq;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) af[j * 3 + i] = cm[i * 3 + j];
     const int64_t N = 3, one = 1;
-    int64_t lwork = -1, info = 0;
-    double af2[9];
-    memcpy(af2, af, sizeof(af));
-    g.dgeev("N", "V", &N, af2, &N, wr, wi, vl, &one, vr, &N, &wq, &lwork, &info);
-    if (info != 0) return false;
-    lwork = (int64_t)wq;
-    if (lwork < 1 || lwork > 4096) return false;
-    std::vector<double> work((size_t)lwork);
-    g.dgeev("N", "V", &N, af, &N, wr, wi, vl, &one, vr, &N, work.data(), &lwork, &info);
+    int64_t info = 0;
+    // the workspace size LAPACK asks for depends on (jobvl, jobvr, n) only: queried once (numpy queries per call, with the same answer)
+    int64_t lwork = g.lwork3.load(std::memory_order_relaxed);
+    if (lwork == 0) {
+        int64_t query = -1;
+        double af2[9];
+        memcpy(af2, af, sizeof(af));
+        g.dgeev("N", "V", &N, af2, &N, wr, wi, vl, &one, vr, &N, &wq, &query, &info);
+        if (info != 0) return false;
+        lwork = (int64_t)wq;
+        if (lwork < 1 || lwork > 4096) return false;
+        g.lwork3.store(lwork, std::memory_order_relaxed);
+    }
+    double work[4096];
+    g.dgeev("N", "V", &N, af, &N, wr, wi, vl, &one, vr, &N, work, &lwork, &info);
     if (info != 0) return false;
     for (int k = 0; k < 3; k++) {
         if (wi[k] != 0.0) return false;                 // complex pair: numpy switches dtype, let it handle that
@@ -117,6 +125,7 @@ extern "C" int octa_bif_native_init(const char *blas_path, int n_kappa, const do
     g.dgeev = (dgeev_fn)dlsym(h, "scipy_dgeev_64_");
     if (!g.dgemm || !g.ddot || !g.dgeev) { octa::set_error("octa_bif_native_init: BLAS/LAPACK symbols not found in %s", blas_path); g.dgemm = nullptr; return -1; }
     g.handle = h;
+    g.lwork3.store(0);
     g.kappa.assign(kappas, kappas + n_kappa);
     g.cs.assign(cs, cs + n_kappa);
     g.sn.assign(sn, sn + n_kappa);

@@ -390,6 +390,9 @@ __device__ inline int mail_roundtrip(const Blk &b, const SimArrays &A, const Hos
     if (b.tid == 0) {
         *park = 0;
         if (n_req > REQ_PER_SAMPLE) { atomicOr(&A.sc->err, ERR_REQ_CAP); n_req = REQ_PER_SAMPLE; }
+#ifdef OCTA_SIM_PROF_MAIL            // diagnostic build: kd slots 0..2 = ticks spent publishing (fences + stores), polls, round trips
+        const long t_pub = (long)wall_clock64();
+#endif
         __threadfence_system();      // the request records (written by the whole block before the barrier)
         __hip_atomic_store(M.req_n + s, n_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_exchange(M.req_ticket + s, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -412,6 +415,9 @@ __device__ inline int mail_roundtrip(const Blk &b, const SimArrays &A, const Hos
             }
         }
         A.sc->prof[5] += (long)wall_clock64() - t0;
+#ifdef OCTA_SIM_PROF_MAIL
+        A.sc->kdprof[0] += t0 - t_pub; A.sc->kdprof[1] += polls; A.sc->kdprof[2] += 1;
+#endif
         __threadfence_system();
     }
     b.sync();

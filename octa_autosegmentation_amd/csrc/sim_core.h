@@ -1005,7 +1005,7 @@ static_assert(KD_MAILBOX_OFF + (KD_BOX_BYTES > KD_MAILBOX_BYTES ? KD_BOX_BYTES :
 OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_idx, idx_t *out_rank,
                               float *xy, double zlo, double zhi, long *kdprof = nullptr, const unsigned char *need = nullptr,
                               const bool flag_in_sign = false) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(OCTA_SIM_PROF_ASSIGN) && !defined(OCTA_SIM_PROF_SAMPLE) && !defined(OCTA_SIM_PROF_SET)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OCTA_SIM_PROF_ASSIGN) && !defined(OCTA_SIM_PROF_SAMPLE) && !defined(OCTA_SIM_PROF_SET) && !defined(OCTA_SIM_PROF_MAIL)
 #define KDP(slot) do { if (kdprof && b.tid == 0) { long _t = (long)wall_clock64(); kdprof[slot] += _t - _kt; _kt = _t; } } while (0)
     long _kt = (long)wall_clock64();
 #else
