@@ -1159,9 +1159,11 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
         S->ms_b += ms; S->n_b++;
     }
     S->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-    S->h_sc.resize(B);
-    OCTA_HIP_CHECK(hipMemcpyAsync(S->h_sc.data(), P.sc, sizeof(SampleScalars) * B, hipMemcpyDeviceToHost, stream));
-    OCTA_HIP_CHECK(hipStreamSynchronize(stream));
+    if (S->lockstep) {                   // (the persistent form has fetched the samples' scalars at its last kernel boundary)
+        S->h_sc.resize(B);
+        OCTA_HIP_CHECK(hipMemcpyAsync(S->h_sc.data(), P.sc, sizeof(SampleScalars) * B, hipMemcpyDeviceToHost, stream));
+        OCTA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
     S->ran = true;
 #ifdef OCTA_SIM_DEBUG_SAT
     if (const char *path = getenv("OCTA_SIM_DEBUG_DUMP")) {
