@@ -184,8 +184,14 @@ raster_scan_sums_kernel(int *__restrict__ block_sums, int nb, long *__restrict__
 // Round 5: the edges of a workgroup own ONE contiguous run of the side array (their offsets come from an exclusive scan), so the
 // sides are staged in LDS and written out by consecutive threads, 16 bytes each. Thread-per-edge stores straight to HBM put every
 // lane's 16 bytes on a line of their own: the counters showed 4.7 GB written per 512 graphs for 1.5 GB of sides.
-constexpr int TESS_STAGE = 3072;               // int4 slots (48 KiB): 128 edges x 24 slots (a 1.8-pixel stroke has 10 sides + 4 spare); longer runs fall back to direct stores
-constexpr int TESS_WG = 128;
+#ifndef OCTA_TESS_STAGE
+#define OCTA_TESS_STAGE 2048
+#endif
+constexpr int TESS_STAGE = OCTA_TESS_STAGE;               // int4 slots (32 KiB): 128 edges x 16 slots (a 1.8-pixel stroke has 10 sides + 4 spare); longer runs fall back to direct stores. 3072 (48 KiB, three workgroups per CU) measured 8.25 / 3.50 ms per 128 labels / image pairs against 8.13 / 3.45 here, 1536: 8.12 / 3.39
+#ifndef OCTA_TESS_WG
+#define OCTA_TESS_WG 128
+#endif
+constexpr int TESS_WG = OCTA_TESS_WG;
 
 __global__ void __launch_bounds__(TESS_WG)
 raster_tess_kernel(const EdgeMeta *__restrict__ meta, const int *__restrict__ off, const int *__restrict__ block_sums,
