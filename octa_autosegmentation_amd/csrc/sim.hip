@@ -672,6 +672,8 @@ struct OCTA_SIM_T {
     double diag_max_gap_ms = 0, diag_max_bif_ms = 0;
     long diag_tickets = 0, diag_relaunches = 0, diag_parked = 0;
     bool ran = false;
+    void *init_stage = nullptr;     // pinned staging of a run's per-sample set-up (valid-voxel lists, generator states)
+    size_t init_stage_bytes = 0;
     // host copies for export
     std::vector<SampleScalars> h_sc;
     // kernel timing of the last run (HIP events on the launch stream)
@@ -815,6 +817,12 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, O
     rc |= dev_alloc(S, &P.wg_scratch, nb * (size_t)SIM_USER_BYTES);
 #endif
     P.n_samples = B;
+    if (!rc) {       // pinned staging of a run's per-sample set-up (sim_run_impl): allocated here, not in the first run
+        const size_t n_mt = (size_t)B * 625, n_valid = (size_t)B * P.valid_stride;
+        const size_t stage_need = ((n_valid * 2 + 255) & ~(size_t)255) + 2 * n_mt * 4;
+        if (hipHostMalloc(&S->init_stage, stage_need) != hipSuccess) { octa::set_error("octa_sim_create: hipHostMalloc (set-up staging) failed"); S->init_stage = nullptr; rc = -1; }
+        else { S->init_stage_bytes = stage_need; memset(S->init_stage, 0, stage_need); }
+    }
     if (!rc) {
         hipError_t e1 = hipHostMalloc((void **)&S->h_reqs, sizeof(BifRequest) * 2 * REQ_CAP);
         hipError_t e2 = hipHostMalloc((void **)&S->h_results, sizeof(double) * 2 * REQ_CAP * 6);
@@ -866,6 +874,7 @@ extern "C" void octa_sim_destroy(OCTA_SIM_T *S) {
     if (S->mail.req_n) e = hipHostFree(S->mail.req_n);
     for (int k = 0; k < 3; k++) if (S->ev[k]) e = hipEventDestroy(S->ev[k]);
     if (S->export_stage) e = hipHostFree(S->export_stage);
+    if (S->init_stage) e = hipHostFree(S->init_stage);
     if (S->export_stream) e = hipStreamDestroy(S->export_stream);
     if (S->d_edge_off) e = hipFree(S->d_edge_off);
     (void)e;
@@ -927,10 +936,21 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
     // ---- host init of every sample (FAZ radius, validity mask, stumps, RNG streams)
     {
         std::vector<SampleScalars> sc(B);
-        std::vector<unsigned> mt((size_t)B * 625);
-        std::vector<unsigned short> valid((size_t)B * P.valid_stride, 0);
+        // the large staging arrays (18 MB of valid-voxel lists, 2.6 MB of generator states for 512 samples) live in ONE pinned block that a
+        // simulator keeps: allocated and zero-filled per run they cost ~3 ms of page faults and a pageable copy, between two kernels
+        const size_t n_mt = (size_t)B * 625, n_valid = (size_t)B * P.valid_stride;
+        const size_t stage_need = ((n_valid * 2 + 255) & ~(size_t)255) + 2 * n_mt * 4;
+        if (S->init_stage_bytes < stage_need) {
+            if (S->init_stage) OCTA_HIP_CHECK(hipHostFree(S->init_stage));
+            S->init_stage = nullptr; S->init_stage_bytes = 0;
+            OCTA_HIP_CHECK(hipHostMalloc(&S->init_stage, stage_need));
+            S->init_stage_bytes = stage_need;
+            memset(S->init_stage, 0, stage_need);
+        }
+        unsigned short *valid = static_cast<unsigned short *>(S->init_stage);       // entries behind a sample's count are never read
+        unsigned *mt = reinterpret_cast<unsigned *>(static_cast<char *>(S->init_stage) + ((n_valid * 2 + 255) & ~(size_t)255));
+        unsigned *py_mt = mt + n_mt;
         std::vector<unsigned> vcount(B);
-        std::vector<unsigned> py_mt((size_t)B * 625);
         const int n0 = 2 * S->cfg.n_trees;
         std::vector<double> npos((size_t)B * 2 * n0 * 3);
         static const bool time_init = getenv("OCTA_SIM_TIME_INIT") != nullptr;
@@ -976,10 +996,10 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
         if (bad_sample.load() >= 0) { octa::set_error("octa_sim_run: sample %d has no valid voxel", bad_sample.load()); return -2; }
         if (time_init) fprintf(stderr, "[octa_sim] host init: per-sample fill %.2f ms for %d samples\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init0).count(), B);
         OCTA_HIP_CHECK(hipMemcpyAsync(P.sc, sc.data(), sizeof(SampleScalars) * B, hipMemcpyHostToDevice, stream));
-        OCTA_HIP_CHECK(hipMemcpyAsync(P.mt_state, mt.data(), mt.size() * 4, hipMemcpyHostToDevice, stream));
-        if (P.valid_stride) OCTA_HIP_CHECK(hipMemcpyAsync(P.valid, valid.data(), valid.size() * 2, hipMemcpyHostToDevice, stream));
+        OCTA_HIP_CHECK(hipMemcpyAsync(P.mt_state, mt, n_mt * 4, hipMemcpyHostToDevice, stream));
+        if (P.valid_stride) OCTA_HIP_CHECK(hipMemcpyAsync(P.valid, valid, n_valid * 2, hipMemcpyHostToDevice, stream));
         OCTA_HIP_CHECK(hipMemcpyAsync(P.valid_count, vcount.data(), vcount.size() * 4, hipMemcpyHostToDevice, stream));
-        OCTA_HIP_CHECK(hipMemcpyAsync(P.py_state, py_mt.data(), py_mt.size() * 4, hipMemcpyHostToDevice, stream));
+        OCTA_HIP_CHECK(hipMemcpyAsync(P.py_state, py_mt, n_mt * 4, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(py_uniform_kernel, dim3((unsigned)B), dim3(64), 0, stream, P.py_state, P.py_u, PYCAP);
         OCTA_HIP_CHECK(hipGetLastError());
         OCTA_HIP_CHECK(hipMemcpyAsync(P.iters, S->iters.data(), sizeof(IterParams) * S->iters.size(), hipMemcpyHostToDevice, stream));
