@@ -589,10 +589,14 @@ def main():
     if args.warmup:
         run_steps(0, args.warmup)
     barrier()
+    import gc
+    gc.collect()
+    gc.disable()                       # no collector pause between two launches of the timed region (it holds every thread: 5 launches are timed)
     t0 = time.time()
     outs = run_steps(args.warmup, args.steps)
     barrier()
     dt = time.time() - t0
+    gc.enable()
     # where a slot's time goes (host clock, mean over the timed launches): simulator call (host init + kernel + download + BFS export),
     # render enqueue, wait for the render kernels; `kernel` is the device time of the persistent kernel inside the simulator call
     slot_cycle = None
