@@ -452,6 +452,41 @@ def train_cli_leg(n_graphs=128, epochs=4, extra_args=()):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def launcher_selftest(args):
+    """The N-rank skeleton of main() with a stub body, on gloo (no GPU): process group from the launcher's environment, the rank count by
+    all-reduce, a barrier-bracketed timed region, MAX of the wall time over ranks, per-rank values by all-gather, ONE JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    from octa_autosegmentation_amd.utils import sharding
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    ones = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(ones)
+        dist.barrier()
+    t0 = time.time()
+    seeds = np.concatenate([sharding.rank_seeds(rank, i, args.batch) for i in range(args.steps)])      # the stub step: this rank's seed blocks
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    per_rank = None
+    if world > 1:
+        t_all = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(t_all, torch.tensor([dt], dtype=torch.float64))
+        per_rank = [args.batch * args.steps / float(t.item()) for t in t_all]
+        s_all = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(s_all, torch.tensor([int(seeds.min()), int(seeds.max())]))
+    dt = sharding.max_over_ranks(dt, dist if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest", "value": world * args.batch * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "rccl_ranks": int(ones.item()), "per_rank_value": per_rank, "self_launched": os.environ.get("OCTA_SELF_LAUNCHED") == "1",
+                          "seed_ranges": [[int(a), int(b)] for a, b in (t.tolist() for t in s_all)] if world > 1 else None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -478,10 +513,22 @@ def main():
     ap.add_argument("--no-long", dest="long", action="store_false", help="skip BASELINE configs[4] at its stated size: a 10 000-sample on-the-fly epoch (2 500 training "
                     "steps of 4 over all ranks; about a minute on one MI355X). Round 5: part of the DEFAULT run, so that the driver's line carries end_to_end_10k_epoch")
     ap.add_argument("--long", dest="long", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)      # tests/test_bench_launcher.py: the launcher + one-line contract on gloo ranks, no GPU
     ap.set_defaults(long=True)
     args = ap.parse_args()
     if args.pmc_child:
         pmc_child(args.batch)
+        return
+    # `python bench.py --gpus N` starts its own N ranks (one per GPU, RCCL over 127.0.0.1); under torch.distributed.run nothing is re-executed
+    from octa_autosegmentation_amd.utils import launch as _launch
+    try:
+        if _launch.needs_self_launch(args.gpus):
+            sys.exit(_launch.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus, need_devices=not args.launcher_selftest))
+        _launch.check_world(args.gpus)
+    except _launch.LaunchError as e:
+        sys.exit(f"bench.py: {e}")
+    if args.launcher_selftest:
+        launcher_selftest(args)
         return
 
     # stdout carries exactly ONE line, the JSON record: libraries that print banners from C (RCCL's version block at communicator
@@ -743,6 +790,12 @@ def main():
         if long_info is not None:
             long_info["note"] = "BASELINE configs[4] at its stated size: 10 000 samples per epoch over all ranks (2 500 steps of 4 + warm-up)"
 
+    if dist is not None:
+        # every collective of the run is behind us: the group ends HERE, so that rank 0's host-side legs below (the CPU baseline on the host's
+        # cores, the counter passes) hold no other rank inside a collective -- the other ranks simply leave
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     if rank == 0:
         value = world * B * args.steps / dt
         per_gpu = value / world
@@ -808,6 +861,7 @@ def main():
                       "EVERY double (radii: glibc pow restated; node positions: glibc acos / sin / cos restated, csrc/glibc_trig.h) on the validated "
                       "full-length seeds (profiles/r02_validate_final.log, profiles/r03_validate.log)",
             "rccl_ranks": rccl_ranks, "per_rank_value": per_rank, "host_budget": host,
+            "self_launched": os.environ.get("OCTA_SELF_LAUNCHED") == "1",
             "value_with_csv": (files_info or {}).get("cli_pipelined", {}).get("value") if files_info else None,
             "value_with_csv_note": "complete ON-DISK triples per second (config.yml + graph CSV + 304x304 image PNG + 1216x1216 label PNG per sample) through the "
                                    "drop-in CLI generate_vessel_graph.py --labels: the triple as SURVEY.md 8d defines it; `value` counts triples complete in HBM",
@@ -838,8 +892,10 @@ def main():
             "mailbox_relaunches": relaunches,
             "mailbox": mailbox,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, all_cores=args.cpu_all_cores)
+            if world > 1:
+                line["cpu_baseline"]["note_ranks"] = f"timed by rank 0 after the process group ended (the other {world - 1} ranks had left: the host's cores were free)"
             if not args.no_train:
                 line["cpu_baseline"]["unet_train_step"] = cpu_unet_step()
         line["files"] = files_info
@@ -850,8 +906,6 @@ def main():
         line["end_to_end_10k_epoch"] = long_info
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
