@@ -17,8 +17,12 @@ import threading
 
 
 class GpuTurns:
-    def __init__(self, enabled=True, poll_s=0.05):
+    def __init__(self, enabled=True, poll_s=0.05, aligned=False):
+        """aligned: several ranks train in lock step (one gradient all-reduce per step), so a turn given at one rank's own moment stalls
+        every rank; with aligned=True turns are only given where the caller says `at_boundary` -- a step every rank reaches together
+        (the step that needs the next generator batch) -- so that the ranks' stalls coincide instead of adding up."""
         self.enabled = bool(enabled)
+        self.aligned = bool(aligned)
         self.poll_s = float(poll_s)
         self._want, self._aside, self._back = threading.Event(), threading.Event(), threading.Event()
 
@@ -40,10 +44,12 @@ class GpuTurns:
         self._back.set()
 
     # ---- consumer side
-    def step_aside_if_asked(self, drain, producer_alive=lambda: True):
+    def step_aside_if_asked(self, drain, producer_alive=lambda: True, at_boundary=True):
         """If the producer has asked: `drain()` (wait for the consumer's own queued GPU work), tell the producer, and wait for hand_back()
-        -- or for the producer to die. Returns True when a turn was given away."""
+        -- or for the producer to die. Returns True when a turn was given away. An aligned instance only gives turns `at_boundary`."""
         if not (self.enabled and self._want.is_set()):
+            return False
+        if self.aligned and not at_boundary:
             return False
         drain()
         self._back.clear()

@@ -87,3 +87,23 @@ def test_a_stopped_run_releases_the_producer_and_a_dead_producer_releases_the_co
     t0 = time.time()
     assert turns2.step_aside_if_asked(lambda: None, dead.is_alive) is True
     assert time.time() - t0 < 1.0
+
+
+def test_aligned_turns_are_only_given_at_the_boundary_every_rank_shares():
+    """Several ranks (train_synthetic.py with WORLD_SIZE > 1): a turn given mid-batch would stall every rank at the step's all-reduce, each
+    rank at its own moment; an aligned instance keeps training through a mid-batch request and gives the turn at the batch boundary."""
+    turns = GpuTurns(poll_s=0.005, aligned=True)
+    granted = []
+    th = threading.Thread(target=lambda: granted.append(turns.ask()))
+    th.start()
+    time.sleep(0.02)                                                   # the producer is asking now
+    drains = []
+    for step in range(5):                                              # mid-batch steps: asked, but not the agreed step
+        assert turns.step_aside_if_asked(lambda: drains.append(step), th.is_alive, at_boundary=False) is False
+    assert not drains and not granted
+    releaser = threading.Timer(0.03, turns.hand_back)
+    releaser.start()
+    assert turns.step_aside_if_asked(lambda: drains.append("boundary"), lambda: True, at_boundary=True) is True
+    th.join(1.0)
+    releaser.join()
+    assert drains == ["boundary"] and granted == [True]

@@ -137,8 +137,14 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
     from octa_autosegmentation_amd.utils.turns import GpuTurns
     turns = GpuTurns(enabled=os.environ.get("OCTA_E2E_BURST", "1") != "0")
 
-    def step_aside_if_asked():
-        turns.step_aside_if_asked(lambda: torch.cuda.current_stream().synchronize(), lambda: th.is_alive() and not failure)
+    # Several ranks (round 6, advisor): a rank that steps aside stalls EVERY rank at the step's gradient all-reduce, so turns given away at each
+    # rank's own moment would add up (world x 410 ms per generator batch). With world > 1 a turn is only given at the step where the rank needs its
+    # next generator batch -- the same step on every rank, since all ranks consume gen_batch / batch steps per batch -- and while waiting for that
+    # batch: the ranks' stalls then coincide instead of queueing behind each other. OCTA_E2E_ALIGN=0/1 overrides.
+    turns.aligned = os.environ.get("OCTA_E2E_ALIGN", "1" if world > 1 else "0") == "1"
+
+    def step_aside_if_asked(at_batch_boundary=True):
+        turns.step_aside_if_asked(lambda: torch.cuda.current_stream().synchronize(), lambda: th.is_alive() and not failure, at_boundary=at_batch_boundary)
 
     def next_batch():
         """Blocks for the producer's next batch; a dead producer is an error here, not a silent stall (the reference swallows
@@ -166,7 +172,7 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
                 if world > 1:
                     dist.barrier()
                 t0 = time.time()
-            step_aside_if_asked()
+            step_aside_if_asked(at_batch_boundary=images is None or pos + batch > images.shape[0])
             if images is None or pos + batch > images.shape[0]:
                 images, labels, ready = next_batch()
                 # the batch was written on the generator's stream and its blocks belong to that stream's pool: order the
