@@ -1005,7 +1005,7 @@ static_assert(KD_MAILBOX_OFF + (KD_BOX_BYTES > KD_MAILBOX_BYTES ? KD_BOX_BYTES :
 OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_idx, idx_t *out_rank,
                               float *xy, double zlo, double zhi, long *kdprof = nullptr, const unsigned char *need = nullptr,
                               const bool flag_in_sign = false) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(OCTA_SIM_PROF_ASSIGN) && !defined(OCTA_SIM_PROF_SAMPLE) && !defined(OCTA_SIM_PROF_SET) && !defined(OCTA_SIM_PROF_MAIL)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OCTA_SIM_PROF_ASSIGN) && !defined(OCTA_SIM_PROF_SAMPLE) && !defined(OCTA_SIM_PROF_SET) && !defined(OCTA_SIM_PROF_MAIL) && !defined(OCTA_SIM_PROF_SEQ) && !defined(OCTA_SIM_PROF_SEQ2)
 #define KDP(slot) do { if (kdprof && b.tid == 0) { long _t = (long)wall_clock64(); kdprof[slot] += _t - _kt; _kt = _t; } } while (0)
     long _kt = (long)wall_clock64();
 #else
@@ -1490,12 +1490,22 @@ OCTA_HD inline void dirty_insert(DirtyList &D, int g) {
 // State of the ordered pass that lives in LDS / registers instead of HBM.
 struct SeqLds {
     double *rad;               // [NCAP] radii of the forest: the HBM array itself (L2-resident during the pass; round 2 kept an LDS copy)
-    idx_t *par;       // [NCAP] parent id, 0xffff = none (LDS)
+    idx_t *par;       // [NCAP] node word (LDS): parent id (PAR_MASK = none) | PAR_DEF (marked for the flush) | PAR_TAG (carries this pass's tag):
+                      // ONE LDS read per ancestor of a walk's chain enumeration (round 6: parent, deferred bit and tag were three)
     const double *log_tab;     // glibc pow tables (gpow.h) (LDS)
     const uint64_t *exp_tab;
     int *deferred;             // [NCAP / 32] bitmap: radius to be recomputed when the pass ends (2 KiB, LDS)
     int *changed;              // [GCAP / 32] bitmap over this pass's groups: a walk rewrote the radius of the group's child (1 KiB, LDS)
+    double *fl_val;            // [MURRAY_FLUSH_LDS] radii the flush has finished, by list slot (LDS, round 6)
+    int *fl_done;              // [MURRAY_FLUSH_LDS / 32] bitmap: slot finished in an earlier round
+    int *slot_of;              // [NCAP] (HBM scratch) list slot of a deferred node, written by the walk that marks it
 };
+constexpr int MURRAY_FLUSH_LDS = 256;   // deferred nodes of a pass the one-wave flush keeps in the LDS (4 per lane)
+// PAR_TAG: the node carries THIS pass's tag in child_group, i.e. it is the child of an inter-node group of the pass. A walk that meets
+// no such node has no eager part and needs no topology record from HBM at all (round 6).
+constexpr int PAR_BITS = (int)sizeof(idx_t) * 8 - 2;
+constexpr unsigned PAR_MASK = (1u << PAR_BITS) - 1u, PAR_DEF = 1u << PAR_BITS, PAR_TAG = 2u << PAR_BITS;
+static_assert((unsigned)NCAP <= PAR_MASK, "node ids fit the parent field of a node word");
 OCTA_HD inline bool changed_get(const SeqLds &L, int g) { return ((unsigned)L.changed[g >> 5] >> (g & 31)) & 1u; }
 OCTA_HD inline void changed_set(const SeqLds &L, int g) { L.changed[g >> 5] |= (int)(1u << (g & 31)); }   // the ordered pass's wave only, all lanes alike
 OCTA_HD inline bool deferred_get(const SeqLds &L, int id) { return ((unsigned)L.deferred[id >> 5] >> (id & 31)) & 1u; }
@@ -1510,8 +1520,8 @@ OCTA_HD inline WalkRec walk_load(const SimArrays &A, int f, int id, bool want_cg
 }
 OCTA_HD inline int walk_parent(const SeqLds &L, int id) {
     if (id < 0) return -1;
-    idx_t p = L.par[id];
-    return p == IDX_NONE ? -1 : (int)p;
+    const unsigned p = (unsigned)L.par[id] & PAR_MASK;
+    return p == PAR_MASK ? -1 : (int)p;
 }
 
 // Murray's law from node id towards the root (arterial_tree.py:174-184): the reference recomputes (r_c0^k + r_c1^k)^(1/k) for
@@ -1540,10 +1550,10 @@ __device__ inline bool murray_pending_above(const SimArrays &A, int start, int c
         int nn = 0, mine = -1;
         bool ended = false;
         for (; nn < 64; nn++) {
-            const int p = walk_parent(L, cur);
-            if (p < 0 || deferred_get(L, cur)) { ended = true; break; }
+            const unsigned w = (unsigned)L.par[cur], p = w & PAR_MASK;
+            if (p == PAR_MASK || (w & PAR_DEF)) { ended = true; break; }
             if (lane == nn) mine = cur;
-            cur = p;
+            cur = (int)p;
         }
         const int cg = lane < nn ? A.child_group[mine] : 0;
         if (__ballot(lane < nn && (cg >> (GROUP_BITS + 1)) == pass_tag && (cg & ((1 << GROUP_BITS) - 1)) > cur_g)) return true;
@@ -1556,7 +1566,11 @@ __device__ inline bool murray_pending_above(const SimArrays &A, int start, int c
 // chain -- two pow evaluations per node, operands fetched with readlane -- is executed uniformly; (4) the lanes store the new radii
 // / mark the deferred nodes. Floating-point addition is commutative, so "on-path power + other power" is bit-identical to the
 // reference's c0-then-c1 order. Returns the eager steps; n_def counts the nodes appended to the deferred list (A.act_list).
-__device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L, int &n_def) {
+__device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L, int &n_def
+#ifdef OCTA_SIM_PROF_SEQ2
+                                      , long *seq2_dbg = nullptr
+#endif
+                                      ) {
     if (id < 0) return 0;
     const int lane = (int)(threadIdx.x & 63);
     double *rad = L.rad;
@@ -1566,23 +1580,44 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
     bool defer_rest = false;     // an earlier chunk ended its eager part: nothing pending above
     while (true) {
         int cur = first, nn = 0, mine = -1;
+        unsigned minew = 0, tags = 0;
         bool ended = false;
+#ifdef OCTA_SIM_PROF_SEQ2
+        const long _c0 = (long)wall_clock64();
+#endif
         for (; nn < 64; nn++) {
-            const int p = walk_parent(L, cur);
-            if (p < 0 || deferred_get(L, cur)) { ended = true; break; }
-            if (lane == nn) mine = cur;
-            cur = p;
+            const unsigned w = (unsigned)L.par[cur], p = w & PAR_MASK;
+            if (p == PAR_MASK || (w & PAR_DEF)) { ended = true; break; }
+            if (lane == nn) { mine = cur; minew = w; }
+            tags |= w;
+            cur = (int)p;
         }
+        bool any_tag = (tags & PAR_TAG) != 0;
         if (nn == 0) break;
         int eager_n = 0;
         WalkRec r;
         r.nch = 0; r.c0 = r.c1 = -1; r.cg = 0; r.k = 0;
-        if (!defer_rest) {
+        // round 6: only a node that carries this pass's tag can be pending, and the tags are an LDS bitmap: three walks in four meet none
+        // on their way to the first marked node / the root and are over after the chain walk -- no topology records, no tags from HBM
+        if (!defer_rest && !any_tag && !ended) {
+            int c2 = cur;
+            while (true) {
+                const unsigned w2 = (unsigned)L.par[c2], p2 = w2 & PAR_MASK;
+                if (p2 == PAR_MASK || (w2 & PAR_DEF)) break;
+                if (w2 & PAR_TAG) { any_tag = true; break; }
+                c2 = (int)p2;
+            }
+        }
+        if (!defer_rest && any_tag) {
             if (lane < nn) r = walk_load(A, f, mine, true);
             const unsigned long long pend = __ballot(lane < nn && (r.cg >> (GROUP_BITS + 1)) == pass_tag && (r.cg & ((1 << GROUP_BITS) - 1)) > cur_g);
             if (!ended && murray_pending_above(A, cur, cur_g, pass_tag, L)) eager_n = nn;
             else eager_n = pend ? 64 - __builtin_clzll(pend) : 0;
         }
+#ifdef OCTA_SIM_PROF_SEQ2
+        const long _c1 = (long)wall_clock64();
+        if (seq2_dbg) { seq2_dbg[5] += eager_n > 0; seq2_dbg[6] += nn; seq2_dbg[0] += _c1 - _c0; }
+#endif
         bool stop = false;
         if (eager_n > 0) {
             int onpath = __builtin_amdgcn_update_dpp(0, mine, 0x138, 0xf, 0xf, false);     // wave_shr:1: the node of the lane in front (lane 0: set below)
@@ -1631,12 +1666,17 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
                 }
             }
             if (lane < done) rad[mine] = my_rp;
+#ifdef OCTA_SIM_PROF_SEQ2
+            if (seq2_dbg) seq2_dbg[4] += (long)wall_clock64() - _c1;
+#endif
         }
         if (stop) break;          // the reference's walk ends here: nothing above changes
         if (eager_n < nn) {
             if (lane >= eager_n && lane < nn) {
                 atomic_or_int(&L.deferred[mine >> 5], (int)(1u << (mine & 31)));
+                L.par[mine] = (idx_t)(minew | PAR_DEF);      // a plain store: the lanes' nodes are distinct words
                 A.act_list[n_def + lane - eager_n] = mine;
+                L.slot_of[mine] = n_def + lane - eager_n;
             }
             n_def += nn - eager_n;
             defer_rest = true;
@@ -1682,6 +1722,8 @@ OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g,
     }
     for (; k < path_len; k++) {
         atomic_or_int(&L.deferred[id >> 5], (int)(1u << (id & 31)));
+        L.par[id] = (idx_t)((unsigned)L.par[id] | PAR_DEF);
+        L.slot_of[id] = n_def;
         A.act_list[n_def++] = id;
         id = walk_parent(L, id);
     }
@@ -1706,38 +1748,94 @@ OCTA_HD inline int murray_flush(const Blk &b, const SimArrays &A, int f, const S
 #if defined(__HIP_DEVICE_COMPILE__)
     if (n_def <= MURRAY_EPT * 64) {
         // the usual case (about 135 marked nodes per pass): ONE wave runs the rounds -- its LDS accesses are ordered, so the two block
-        // barriers per round are not needed and the finished count is a ballot
+        // barriers per round are not needed and the finished count is a ballot.
+        // Round 6: the rounds no longer talk through HBM. A round used to read the children's radii from the global array the round before
+        // had written them to (store -> L2 -> load: ~2 us per round, ~30 rounds per pass, 31 ms per sample). Now every marked node has a
+        // list slot (slot_of, written by the walk that marked it), a finished radius goes to fl_val[slot] in the LDS with a bit in fl_done,
+        // and a parent reads its marked children from there; the radii of the UNMARKED children (final already) are fetched once, all at
+        // once, before the first round, and raised to the parent's kappa there. The global array still receives every radius (one store,
+        // nobody waits for it). Same values: a radius is a pure function of the children's radii, and a + b == b + a.
+        static_assert(MURRAY_EPT * 64 <= MURRAY_FLUSH_LDS, "flush slots");
         if (b.tid < 64) {
-            int node[MURRAY_EPT], c0[MURRAY_EPT], c1[MURRAY_EPT];
+            const int lane = b.tid;
+            int node[MURRAY_EPT], s0[MURRAY_EPT], s1[MURRAY_EPT];
             double kk[MURRAY_EPT], acc[MURRAY_EPT];
-            int pend[MURRAY_EPT];
+            int pend[MURRAY_EPT];     // 1: marked child 0 not in yet, 2: marked child 1 not in yet, 4: radius not written yet, 8: written in this round
+            for (int w = lane; w < MURRAY_FLUSH_LDS / 32; w += 64) L.fl_done[w] = 0;
+            int c0[MURRAY_EPT], c1[MURRAY_EPT], nch[MURRAY_EPT];
             for (int e = 0; e < MURRAY_EPT; e++) {
-                const int idx = b.tid + e * 64;
-                pend[e] = 0; node[e] = 0; c0[e] = c1[e] = 0; kk[e] = 1; acc[e] = 0;
-                if (idx < n_def) {
-                    node[e] = A.act_list[idx];
+                const int idx = lane + e * 64;
+                pend[e] = 0; node[e] = 0; c0[e] = c1[e] = 0; nch[e] = 0; kk[e] = 1; acc[e] = 0; s0[e] = s1[e] = 0;
+                if (idx < n_def) node[e] = A.act_list[idx];
+            }
+            for (int e = 0; e < MURRAY_EPT; e++) {
+                if (lane + e * 64 < n_def) {
                     const WalkRec r = walk_load(A, f, node[e], false);
-                    c0[e] = r.c0; c1[e] = r.c1; kk[e] = r.k;
-                    pend[e] = 4 | (r.nch >= 1 ? 1 : 0) | (r.nch >= 2 ? 2 : 0);
+                    c0[e] = r.c0; c1[e] = r.c1; kk[e] = r.k; nch[e] = r.nch;
                 }
             }
+            // third round trip, all entries at once: the slot of a marked child, the radius of an unmarked one
+            double cv0[MURRAY_EPT], cv1[MURRAY_EPT];     // the children's radii: fetched here (unmarked) or read from fl_val when they come in
+            unsigned ready = 0;                          // bit 2e + c: child c of entry e has its radius in cv, its power not yet in acc
+            for (int e = 0; e < MURRAY_EPT; e++) {
+                cv0[e] = cv1[e] = 0.5;
+                if (lane + e * 64 >= n_def) continue;
+                pend[e] = 4;
+                if (nch[e] >= 1) { if (deferred_get(L, c0[e])) { pend[e] |= 1; s0[e] = L.slot_of[c0[e]]; } else { cv0[e] = rad[c0[e]]; ready |= 1u << (2 * e); } }
+                if (nch[e] >= 2) { if (deferred_get(L, c1[e])) { pend[e] |= 2; s1[e] = L.slot_of[c1[e]]; } else { cv1[e] = rad[c1[e]]; ready |= 2u << (2 * e); } }
+            }
+            // One pow evaluation per step for the whole wave, whatever entry and child it belongs to: written entry by entry (round 5) a round
+            // executed up to 3 x MURRAY_EPT evaluations one after the other -- every `if` with a taker among the 64 lanes --, ~2 us per round
+            // and 31 ms per sample although a round's takers are a handful of lanes with one item each.
+            auto drain = [&](unsigned items) {
+                while (__ballot(items != 0)) {
+                    const bool on = items != 0;
+                    const int t = on ? (int)__ffs((int)items) - 1 : 0;
+                    if (on) items &= items - 1u;
+                    double x = 0.5, k = 2.0;
+#pragma unroll
+                    for (int e = 0; e < MURRAY_EPT; e++) if ((t >> 1) == e) { x = (t & 1) ? cv1[e] : cv0[e]; k = kk[e]; }
+                    if (!on) { x = 0.5; k = 2.0; }
+                    const double pw = octa_gpow::gpow_t(x, k, L.log_tab, L.exp_tab);
+#pragma unroll
+                    for (int e = 0; e < MURRAY_EPT; e++) if (on && (t >> 1) == e) acc[e] = acc[e] + pw;
+                }
+            };
+            drain(ready);
+            __builtin_amdgcn_wave_barrier();
             int done = 0;
             while (done < n_def) {
                 rounds++;
+                ready = 0;
                 for (int e = 0; e < MURRAY_EPT; e++) {
                     if (!(pend[e] & 4)) continue;
-                    if ((pend[e] & 1) && !deferred_get(L, c0[e])) { acc[e] = acc[e] + octa_gpow::gpow_t(rad[c0[e]], kk[e], L.log_tab, L.exp_tab); pend[e] &= ~1; }
-                    if ((pend[e] & 2) && !deferred_get(L, c1[e])) { acc[e] = acc[e] + octa_gpow::gpow_t(rad[c1[e]], kk[e], L.log_tab, L.exp_tab); pend[e] &= ~2; }
-                    if (!(pend[e] & 3)) {
-                        rad[node[e]] = octa_gpow::gpow_t(acc[e], 1.0 / kk[e], L.log_tab, L.exp_tab);
-                        pend[e] = 8;
-                    }
+                    if ((pend[e] & 1) && (((unsigned)L.fl_done[s0[e] >> 5] >> (s0[e] & 31)) & 1u)) { cv0[e] = L.fl_val[s0[e]]; ready |= 1u << (2 * e); pend[e] &= ~1; }
+                    if ((pend[e] & 2) && (((unsigned)L.fl_done[s1[e] >> 5] >> (s1[e] & 31)) & 1u)) { cv1[e] = L.fl_val[s1[e]]; ready |= 2u << (2 * e); pend[e] &= ~2; }
+                }
+                drain(ready);
+                unsigned fin = 0;
+                for (int e = 0; e < MURRAY_EPT; e++) if ((pend[e] & 4) && !(pend[e] & 3)) fin |= 1u << e;
+                while (__ballot(fin != 0)) {
+                    const bool on = fin != 0;
+                    const int t = on ? (int)__ffs((int)fin) - 1 : 0;
+                    if (on) fin &= fin - 1u;
+                    double a = 0.5, k = 2.0;
+#pragma unroll
+                    for (int e = 0; e < MURRAY_EPT; e++) if (t == e) { a = acc[e]; k = kk[e]; }
+                    if (!on) { a = 0.5; k = 2.0; }
+                    const double rp = octa_gpow::gpow_t(a, 1.0 / k, L.log_tab, L.exp_tab);
+#pragma unroll
+                    for (int e = 0; e < MURRAY_EPT; e++)
+                        if (on && t == e) { L.fl_val[lane + e * 64] = rp; rad[node[e]] = rp; pend[e] = 8; }
                 }
                 __builtin_amdgcn_wave_barrier();
                 for (int e = 0; e < MURRAY_EPT; e++) {
-                    const bool fin = pend[e] == 8;
-                    if (fin) { atomic_and_int(&L.deferred[node[e] >> 5], (int)~(1u << (node[e] & 31))); pend[e] = 0; }
-                    done += (int)__popcll(__ballot(fin));
+                    const unsigned long long fb = __ballot(pend[e] == 8);       // slots e * 64 + lane
+                    if (pend[e] == 8) pend[e] = 0;
+                    if (fb) {
+                        if (lane == 0) { L.fl_done[2 * e] |= (int)(unsigned)fb; L.fl_done[2 * e + 1] |= (int)(unsigned)(fb >> 32); }
+                        done += (int)__popcll(fb);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -2205,6 +2303,15 @@ struct GrowCtx {
     const double *att;
     double gamma;
     const double *rad;  // radii of forest f: HBM array, or the LDS copy during the ordered pass
+    const double *log_tab = octa_gpow::LOG_TAB;      // glibc pow tables: the constant arrays, or the ordered pass's LDS copies (round 6: a
+    const uint64_t *exp_tab = octa_gpow::EXP_TAB;    // re-speculation's eight pow evaluations each made two dependent trips to the global tables)
+    // the sprout's radius r_2 = r and kappa are constants of a pass (greenhouse.py:262): its three powers are evaluated once per pass, not per group
+    double r2k = 0, r24 = 0, r22 = 0;
+    OCTA_HD void init_powers() {
+        r2k = octa_gpow::gpow_t(C->r, P->kappa, log_tab, exp_tab);
+        r24 = octa_gpow::gpow_t(C->r, 4.0, log_tab, exp_tab);
+        r22 = octa_gpow::gpow_t(C->r, 2.0, log_tab, exp_tab);
+    }
 };
 
 // acos / cos / sin whose results reach a node position: glibc's, bit for bit (glibc_trig.h), inside the restated domain
@@ -2249,20 +2356,34 @@ OCTA_HD inline void for_each_attractor(const SimArrays &A, const double *att, in
 template <bool WAVE_COOP>
 OCTA_HD inline void eval_inter(const GrowCtx &G, int g, Rec &R) {
     const SimArrays &A = *G.A;
-    const int f = G.f, id = A.gnode[g];
+    // the ordered pass re-speculates with the group's record in hand: node and child come from it, not from two more dependent loads
+    const int f = G.f, id = WAVE_COOP ? R.node : A.gnode[g];
     const double kappa = G.P->kappa, r = G.C->r, gamma = G.gamma, omega = G.P->omega, d = G.P->d;
+    const int ch = WAVE_COOP ? (int)R.child : A.nch0_of(f)[id];
     R.type = 3; R.grow = 0; R.draw = 0; R.req = -1; R.node = id;
     const V3 pos = ld3(A.npos_of(f) + 3 * id);
-    const int ch = A.nch0_of(f)[id];
     const double r1 = G.rad[ch], r2 = r;
     R.r1_used = r1;
     R.child = (idx_t)ch;
-    using octa_gpow::gpow;
-    double rp = gpow(gpow(r1, kappa) + gpow(r2, kappa), 1 / kappa);
-    double rp4 = gpow(rp, 4.0), rp2 = gpow(rp, 2.0);
-    double phi1 = acos((rp4 + gpow(r1, 4.0) - gpow(r2, 4.0)) / (2 * rp2 * gpow(r1, 2.0))) * rad2deg();
+    const double *lt = G.log_tab;
+    const uint64_t *et = G.exp_tab;
+    auto gpow = [lt, et](double x, double y) { return octa_gpow::gpow_t(x, y, lt, et); };
+    (void)r2;
+    double rp = gpow(gpow(r1, kappa) + G.r2k, 1 / kappa);
+    double rp4, rp2, r14, r12;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (WAVE_COOP) {
+        // the four remaining powers are independent: four lanes evaluate one each (one pow latency instead of four in a row; the wave has
+        // nothing else to do -- every lane of the ordered pass computes the same values)
+        const int lane = (int)(threadIdx.x & 63);
+        const double v = gpow((lane & 2) ? r1 : rp, (lane & 1) ? 2.0 : 4.0);
+        rp4 = readlane_f64(v, 0); rp2 = readlane_f64(v, 1); r14 = readlane_f64(v, 2); r12 = readlane_f64(v, 3);
+    } else
+#endif
+    { rp4 = gpow(rp, 4.0); rp2 = gpow(rp, 2.0); r14 = gpow(r1, 4.0); r12 = gpow(r1, 2.0); }
+    double phi1 = acos((rp4 + r14 - G.r24) / (2 * rp2 * r12)) * rad2deg();
     // phi_2 and the rotation built from it reach the node position (phi_1 only enters angle windows): glibc's values (glibc_trig.h)
-    double phi2 = pos_acos((rp4 + gpow(r2, 4.0) - gpow(r1, 4.0)) / (2 * rp2 * gpow(r2, 2.0))) * rad2deg();
+    double phi2 = pos_acos((rp4 + G.r24 - r14) / (2 * rp2 * G.r22)) * rad2deg();
     V3 dist_seg = sub(ld3(A.npos_of(f) + 3 * ch), pos);
     V3 prox_seg = sub(pos, ld3(A.npos_of(f) + 3 * A.npar_of(f)[id]));
     double nd = norm3(dist_seg), npx = norm3(prox_seg);
@@ -2399,6 +2520,7 @@ OCTA_HD inline void eval_leaf(const GrowCtx &G, int g, Rec &R, BifRequest *reqs,
 OCTA_HD inline void phase_pre(const Blk &b, const SimArrays &A, const SimConst &C, const IterParams &P, int f,
                               const double *att, BifRequest *reqs, int *req_count, int req_cap, int sample) {
     GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, A.nrad_of(f)};
+    G.init_powers();
     const int ng = A.sc->n_groups[f];
     if (b.tid == 0) { A.sc->pass_counter++; A.sc->pass_tag[f] = A.sc->pass_counter; }
     b.sync();
@@ -2580,37 +2702,70 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     // The radii stay where they are, in HBM / L2 (round 3; an LDS copy of NCAP doubles alone is 112 KiB): the pass's wave reads a
     // radius only inside a Murray walk (lane-parallel, one more round trip per 64 ancestors) and when an inter-node is re-speculated;
     // "has this group's child radius changed since the speculation" is answered by the `changed` bitmap the walks keep.
+#if defined(OCTA_SIM_PROF_SEQ) && defined(__HIP_DEVICE_COMPILE__)
+    // diagnostic build: kd slots 0..6 = set-up, the wave's loop, walks, flush (ticks), visits, walks, deferred nodes (counts)
+    const long _q0 = (long)wall_clock64();
+#endif
     SeqLds L;
     L.rad = A.nrad_of(f);
     constexpr int DEF_WORDS = (NCAP + 31) / 32, CHG_WORDS = (GCAP + 31) / 32;     // the two bitmaps
     L.par = reinterpret_cast<idx_t *>(b.user_of<8>());
     double *ltab = reinterpret_cast<double *>(b.user_of<8>() + (((size_t)NCAP * sizeof(idx_t) + 15) & ~(size_t)15));
     uint64_t *etab = reinterpret_cast<uint64_t *>(ltab + 384);
-    static_assert((size_t)NCAP * sizeof(idx_t) + 16 + 384 * 8 + 256 * 8 + (DEF_WORDS + CHG_WORDS) * 4 + SEQ_SIDE_LDS <= (size_t)SIM_USER_BYTES, "ordered-pass table layout");
+    constexpr int FLD_WORDS = MURRAY_FLUSH_LDS / 32;
+    static_assert((size_t)NCAP * sizeof(idx_t) + 16 + 384 * 8 + 256 * 8 + (DEF_WORDS + CHG_WORDS + FLD_WORDS) * 4 + MURRAY_FLUSH_LDS * 8 + SEQ_SIDE_LDS <= (size_t)SIM_USER_BYTES, "ordered-pass table layout");
+    static_assert((DEF_WORDS + CHG_WORDS + FLD_WORDS) % 2 == 0, "fl_val is 8-byte aligned");
     L.log_tab = ltab; L.exp_tab = etab;
     L.deferred = reinterpret_cast<int *>(etab + 256);
     L.changed = L.deferred + DEF_WORDS;
-    unsigned char *side_lds = reinterpret_cast<unsigned char *>(L.changed + CHG_WORDS);
+    L.fl_done = L.changed + CHG_WORDS;
+    L.fl_val = reinterpret_cast<double *>(L.fl_done + FLD_WORDS);
+    L.slot_of = A.tmp_int;                 // [NCAP] of the general scratch: free between the assignment and the satisfaction steps
+    static_assert(NCAP <= OCAP + 2 * NCANDCAP, "slot_of fits the scratch");
+    unsigned char *side_lds = reinterpret_cast<unsigned char *>(L.fl_val + MURRAY_FLUSH_LDS);
     const int n_before = sc->n_nodes[f];
+    const int tag_now = sc->pass_tag[f];
+    // node words into the LDS: the parent, and whether the node carries this pass's tag (phase_pre tagged the child of every inter-node group)
     for (int i = b.tid; i < n_before; i += b.nth) {
-        int p = A.npar_of(f)[i];
-        L.par[i] = p < 0 ? IDX_NONE : (idx_t)p;
+        const int p = A.npar_of(f)[i];
+        const bool tg = (A.child_group[i] >> (GROUP_BITS + 1)) == tag_now;
+        L.par[i] = (idx_t)((p < 0 ? PAR_MASK : (unsigned)p) | (tg ? PAR_TAG : 0u));
     }
     for (int i = b.tid; i < 384; i += b.nth) ltab[i] = octa_gpow::LOG_TAB[i];
     for (int i = b.tid; i < 256; i += b.nth) etab[i] = octa_gpow::EXP_TAB[i];
     for (int i = b.tid; i < DEF_WORDS + CHG_WORDS; i += b.nth) L.deferred[i] = 0;      // both bitmaps
     if (b.tid == 0) b.coll()[91] = 0;
     b.sync();
+#if defined(OCTA_SIM_PROF_SEQ) && defined(__HIP_DEVICE_COMPILE__)
+    const long _q1 = (long)wall_clock64();
+    if (b.tid == 0) sc->kdprof[0] += _q1 - _q0;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SEQT(slot, stmt) do { long _t0 = (long)wall_clock64(); stmt; t_acc[slot] += (long)wall_clock64() - _t0; } while (0)
 #else
 #define SEQT(slot, stmt) do { stmt; } while (0)
 #endif
     long t_acc[4] = {0, 0, 0, 0};  // murray, re-speculation, visits, -
+#if defined(OCTA_SIM_PROF_SEQ2) && defined(__HIP_DEVICE_COMPILE__)
+    // second diagnostic build of the pass: kd slots 0..6 = ticks in the walks' chain enumeration (tag test included), in leaf bodies, in inter-node
+    // bodies (walks excluded), in re-speculations, in the walks' eager parts; walks with an eager part, ancestors enumerated (counts)
+    long q2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long _v0 = 0, _v1 = 0;
+#define SEQ2_TOP() do { _v0 = (long)wall_clock64(); } while (0)
+#define SEQ2_SEL() do { _v1 = (long)wall_clock64(); (void)_v0; } while (0)
+#define SEQ2_END(slot, cnt, walk_before) do { q2[slot] += (long)wall_clock64() - _v1 - (t_acc[0] - (walk_before)); (void)(cnt); } while (0)
+#define SEQ2_ARG , q2
+#else
+#define SEQ2_TOP() do { } while (0)
+#define SEQ2_SEL() do { } while (0)
+#define SEQ2_END(slot, cnt, walk_before) do { } while (0)
+#define SEQ2_ARG
+#endif
     // The first wave runs the pass with all lanes doing the same thing (same values, same stores); the lanes
     // only differ inside murray_to_root. One thread alone on the host build.
     if (b.tid < (b.nth >= 64 ? 64 : 1)) {
-        GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, L.rad};
+        GrowCtx G = {&A, &C, &P, f, att, f == 0 ? P.gamma_art : P.gamma_ven, L.rad, L.log_tab, L.exp_tab};
+        G.init_powers();
         const int ng = sc->n_groups[f];
         const int n_grow = sc->n_grow[f];
         const int tag = sc->pass_tag[f];
@@ -2628,20 +2783,22 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
         const int INF = 0x7fffffff;
         int gi = 0;
         int last_g = -1;
+        int d_head = INF;
         bool scan_all = false;  // fallback when the dirty list overflows: visit every remaining group
         while (true) {
             int g;
             Rec R;
+            SEQ2_TOP();
             if (scan_all) {
                 g = last_g + 1;
                 if (g >= ng) break;
                 R = A.rec[g];
             } else {
                 const int g1 = W.group(gi);
-                int g2 = D.n > 0 ? D.v[0] : INF;
+                const int g2 = d_head;            // head of the dirty list, kept in a register: it only changes in a walk or when it is taken
                 g = g1 < g2 ? g1 : g2;
                 if (g == INF) break;
-                if (g == g2) { for (int k = 1; k < D.n; k++) D.v[k - 1] = D.v[k]; D.n--; }
+                if (g == g2) { for (int k = 1; k < D.n; k++) D.v[k - 1] = D.v[k]; D.n--; d_head = D.n > 0 ? D.v[0] : INF; }
                 if (g == g1) {
                     R = W.record(gi);
                     gi++;
@@ -2651,6 +2808,8 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
             }
             last_g = g;
             t_acc[2]++;
+            SEQ2_SEL();
+            const long _wb = t_acc[0]; (void)_wb;
             if (R.type == 0) continue;
             const int id = R.node;
             if (R.type == 1) {
@@ -2666,12 +2825,15 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                     const double *o = bif_results + 6 * (size_t)R.req;
                     seq_add_node(A, f, n_nodes, v3(o[0], o[1], o[2]), C.r, id, 0, P.kappa, L);
                     seq_add_node(A, f, n_nodes, v3(o[3], o[4], o[5]), C.r, id, 1, P.kappa, L);
-                    SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def));
+                    SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def SEQ2_ARG));
+                    d_head = D.n > 0 ? D.v[0] : INF;
+                    t_acc[3]++;
                     A.nact_of(f)[id] = 0;
                     n_bif++;
                 } else {
                     seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 0, P.kappa, L);
                 }
+                SEQ2_END(1, 3, _wb);
             } else {
                 if (changed_get(L, g)) {      // a walk of this pass rewrote the child's radius (every rewrite changes it: the walk stops at old == new)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2681,14 +2843,17 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
 #endif
                     respec++;
                 }
-                if (!R.grow) continue;
+                if (!R.grow) { SEQ2_END(2, 4, _wb); continue; }
                 if (py_pos >= py_cap) { err |= ERR_PY_CAP; break; }
                 const double u = U.at(py_pos);
                 py_pos++;
-                if (R.thr <= u && !R.ang_gt90) continue;
+                if (R.thr <= u && !R.ang_gt90) { SEQ2_END(2, 4, _wb); continue; }
                 seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 1, P.kappa, L);
-                SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def));
+                SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def SEQ2_ARG));
+                d_head = D.n > 0 ? D.v[0] : INF;
+                t_acc[3]++;
                 A.nact_of(f)[id] = 0;
+                SEQ2_END(2, 4, _wb);
             }
             if (D.overflow && !scan_all) { scan_all = true; D.n = 0; }
         }
@@ -2704,6 +2869,13 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
             sc->n_bif += n_bif;
             sc->respec += respec;
             sc->kdprof[7] += t_acc[0]; (void)t_acc[1]; (void)t_acc[2];
+#if defined(OCTA_SIM_PROF_SEQ2) && defined(__HIP_DEVICE_COMPILE__)
+            q2[3] = t_acc[1];
+            for (int k = 0; k < 7; k++) sc->kdprof[k] += q2[k];
+#endif
+#if defined(OCTA_SIM_PROF_SEQ) && defined(__HIP_DEVICE_COMPILE__)
+            sc->kdprof[1] += (long)wall_clock64() - _q1; sc->kdprof[2] += t_acc[0]; sc->kdprof[4] += t_acc[2]; sc->kdprof[5] += t_acc[3]; sc->kdprof[6] += n_def;
+#endif
         }
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2714,11 +2886,20 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     (void)side; (void)side_lds;
 #endif
 #undef SEQT
+#undef SEQ2_TOP
+#undef SEQ2_SEL
+#undef SEQ2_END
+#undef SEQ2_ARG
     b.sync();
     {
         long t0 = OCTA_FLUSH_T0();
         const int rounds = murray_flush(b, A, f, L, b.coll()[91]);
-        if (b.tid == 0) { sc->kdprof[7] += OCTA_FLUSH_T0() - t0; sc->flush_rounds += rounds; }
+        if (b.tid == 0) {
+            sc->kdprof[7] += OCTA_FLUSH_T0() - t0; sc->flush_rounds += rounds;
+#if defined(OCTA_SIM_PROF_SEQ) && defined(__HIP_DEVICE_COMPILE__)
+            sc->kdprof[3] += OCTA_FLUSH_T0() - t0;
+#endif
+        }
     }
     b.sync();
 }

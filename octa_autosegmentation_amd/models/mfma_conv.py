@@ -29,7 +29,11 @@ def _pad32(c):
 # chain -- U-Net step 19.3 against 19.0 ms at B = 4, 38.7 against 35.5 at B = 8, profiles/r05_stream_overlap_ab.log: every kernel of the
 # step fills the GPU on its own, co-resident workgroups only evict each other's lines.)
 USE_DIRECT_WGRAD = os.environ.get("OCTA_DIRECT_WGRAD", "1") != "0"
-_WG_ACTIVE = {"on": False}      # set by direct_weight_grads(); read by the autograd thread
+# set by direct_weight_grads(); read by the autograd ENGINE's thread (not the caller's: a thread-local would never be seen there), hence
+# process-wide -- and hence one backward scope at a time: a second thread entering while one is open is refused (its backward would get
+# None for its weight gradients and find them written into .grad), torch.autograd.grad / .backward() outside a scope are unaffected
+_WG_ACTIVE = {"on": False, "owner": None}
+_WGRAD_TR = int(os.environ.get("OCTA_WGRAD_TR", "2"))     # the C side's selection of the transposing-read kernels (conv.hip): only they write into .grad
 DIRECT_WGRAD_COUNTS = [0, 0]    # weight gradients accumulated in place / returned to autograd
 
 
@@ -40,13 +44,18 @@ class direct_weight_grads:
         self.on = USE_DIRECT_WGRAD and torch.device(device).type == "cuda"
 
     def __enter__(self):
-        self.prev = _WG_ACTIVE["on"]
+        import threading
+        me = threading.get_ident()
+        self.prev = (_WG_ACTIVE["on"], _WG_ACTIVE["owner"])
         if self.on:
-            _WG_ACTIVE["on"] = True
+            if _WG_ACTIVE["on"] and _WG_ACTIVE["owner"] not in (None, me):
+                raise RuntimeError("direct_weight_grads(): another thread is inside a backward scope; the in-place weight gradients need one backward at a time "
+                                   "(OCTA_DIRECT_WGRAD=0 returns every gradient through autograd)")
+            _WG_ACTIVE["on"], _WG_ACTIVE["owner"] = True, me
         return self
 
     def __exit__(self, *exc):
-        _WG_ACTIVE["on"] = self.prev
+        _WG_ACTIVE["on"], _WG_ACTIVE["owner"] = self.prev
         return False
 
 
@@ -291,6 +300,7 @@ def conv3x3_nhwc_wgrad(x, dy, tap_mask=0x1ff):
 
 STAT_SLOTS = int(os.environ.get("OCTA_STAT_SLOTS", "16"))      # slots the tiles of an image spread their statistics atomics over
 _STAT_RINGS = {}
+_STAT_LOCK = __import__("threading").Lock()                  # two threads running forwards on one stream must not be handed overlapping slices
 
 
 def _stat_slots(device, n, cout):
@@ -299,15 +309,16 @@ def _stat_slots(device, n, cout):
     that stream too, so it is ordered behind every earlier consumer."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     need = STAT_SLOTS * n * cout * 2
-    ring = _STAT_RINGS.get(key)
-    if ring is None or ring[0].numel() < 8 * need:
-        ring = [torch.zeros(max(4 << 20, 8 * need), dtype=torch.float64, device=device), 0]
-        _STAT_RINGS[key] = ring
-    if ring[1] + need > ring[0].numel():
-        ring[0].zero_()
-        ring[1] = 0
-    t = ring[0][ring[1]:ring[1] + need].view(STAT_SLOTS, n, cout, 2)
-    ring[1] += need
+    with _STAT_LOCK:
+        ring = _STAT_RINGS.get(key)
+        if ring is None or ring[0].numel() < 8 * need:
+            ring = [torch.zeros(max(4 << 20, 8 * need), dtype=torch.float64, device=device), 0]
+            _STAT_RINGS[key] = ring
+        if ring[1] + need > ring[0].numel():
+            ring[0].zero_()
+            ring[1] = 0
+        t = ring[0][ring[1]:ring[1] + need].view(STAT_SLOTS, n, cout, 2)
+        ring[1] += need
     return t
 
 
@@ -491,7 +502,7 @@ class _Conv3x3NHWC(torch.autograd.Function):
         elif ctx.mailbox is not None and ctx.mailbox.pending is not None:
             raise RuntimeError("skip gradient posted but the encoder convolution computes no input gradient")
         if ctx.needs_input_grad[1]:
-            direct = (lambda g, acc: _wgrad_acc(xp, None, dy, g, acc, st)) if (xp.shape[-1] == cin and (st == 1 or (xp.shape[1] % 2 == 0 and xp.shape[2] % 2 == 0))) else None
+            direct = (lambda g, acc: _wgrad_acc(xp, None, dy, g, acc, st)) if (xp.shape[-1] == cin and _WGRAD_TR >= st and (st == 1 or (xp.shape[1] % 2 == 0 and xp.shape[2] % 2 == 0))) else None
             if st == 1:
                 dw = _wgrad_to(weight, lambda: conv3x3_nhwc_wgrad(xp, dy)[:, :cin].to(weight.dtype), direct)
             else:
@@ -690,7 +701,7 @@ class _Conv3x3CatNHWC(torch.autograd.Function):
                                                   _native.current_stream_ptr())
                 _native.check(rc, "octa_conv3x3_nhwc_wgrad2")
                 return dwf.view(3, 3, cout, c1 + c2).permute(2, 3, 0, 1).to(weight.dtype)
-            dw = _wgrad_to(weight, wg, lambda g, acc: _wgrad_acc(x1, x2, dy, g, acc))
+            dw = _wgrad_to(weight, wg, (lambda g, acc: _wgrad_acc(x1, x2, dy, g, acc)) if _WGRAD_TR >= 1 else None)
         if ctx.mailbox is not None and dx2 is not None and ctx.needs_input_grad[1]:
             assert ctx.mailbox.pending is None
             ctx.mailbox.pending, dx2 = dx2, None          # collected by the encoder convolution's data-gradient epilogue

@@ -31,6 +31,9 @@ def main():
         print(f"rep {rep}: wall {dt * 1e3:.0f} ms, kernel {res.timing['kernel_b_ms']:.0f} ms, per-sample phases sum {ph[:10].sum():.1f} ms")
         print("  " + "  ".join(f"{n} {v:.1f}" for n, v in zip(NAMES, ph)))
         print("  kd: " + "  ".join(f"{n} {v:.1f}" for n, v in zip(KD, kd)))
+        if os.environ.get("OCTA_PHASES_RAW"):     # diagnostic builds keep counts in the kd slots: raw means, and the samples' scalar statistics
+            print("  kd raw: " + "  ".join(f"{v:.0f}" for v in st[:, 24:32].mean(axis=0)))
+            print("  stats[0:8] (err, py_pos, murray_steps, n_bif, respec, ...): " + "  ".join(f"{v:.0f}" for v in st[:, 0:8].mean(axis=0)))
     sim.close()
 
 
