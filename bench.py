@@ -387,9 +387,8 @@ def files_leg(gen, stream, seeds, threads=None):
             labels = out["label"].cpu().numpy()
         t_gen = time.time() - t0
         res = out["result"]
-        for k in range(len(seeds)):
-            name = f"sample_{int(seeds[k])}"
-            writer.submit(os.path.join(out_root, name), name, edges=res.sample_edges(k), image=images[k], label_bits=labels[k])
+        names = [f"sample_{int(s_)}" for s_ in seeds]
+        writer.submit_batch([os.path.join(out_root, n_) for n_ in names], names, edges=res.edges, edge_off=res.edge_off, images=images, label_bits=labels)
         writer.wait()
         dt = time.time() - t0
         nbytes = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(out_root) for f in fs)

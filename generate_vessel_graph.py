@@ -85,6 +85,12 @@ def main(argv=None):
     for item in plan:
         todo.put(item)
     finished = queue.Queue(maxsize=max(2, len(devices)))                     # bounds the host memory held by batches waiting for the writers
+    # pinned staging sets (output_files.HostStaging): one per batch between its copy-out and the end of its file writes -- a batch being
+    # written, the ones waiting in `finished`, one per generator thread being filled
+    from octa_autosegmentation_amd.output_files import HostStaging
+    staging = queue.Queue()
+    for _ in range(args.inflight * len(devices) + max(2, len(devices)) + 1):
+        staging.put(HostStaging())
     failure = []
     stop = threading.Event()
     timing = os.environ.get("OCTA_CLI_TIMING", "0") == "1"
@@ -133,8 +139,15 @@ def main(argv=None):
                         gpu_gate.release(B)
                     res = out["result"]
                     t_b = time.time()
-                    images = out["image"].cpu().numpy()
-                    labels = out["label"].cpu().numpy() if args.labels else None
+                    # copy-out into a pinned staging set that is this batch's until its files are written (round 6: pageable .cpu() copies of
+                    # ~0.5 GB per batch; the label leaves the GPU as mode "1" rows, an eighth of its bytes)
+                    stage = staging.get()
+                    want_3d = bool(out_cfg.get("save_3D_volumes"))
+                    host = stage.fetch(images=out["image"], labels=tree2img.pack_label_bits_device(out["label"]) if args.labels else None,
+                                       edges=res.d_edges if (res.d_edges is not None and out_cfg.get('save_trees', True) and not want_3d) else None)
+                    images, labels = host["images"], host["labels"]
+                    if host["edges"] is not None:
+                        res._edges = host["edges"]
                     t_c = time.time()
                     vols = None
                     if out_cfg.get("save_3D_volumes"):
@@ -146,7 +159,7 @@ def main(argv=None):
                             na = int(res.n_art[k])
                             v = tree2img.voxelize_edges_device(d_edges, np.array([0, na, len(d_edges)]), vol_dim)
                             vols.append(torch.maximum(v[0], v[1]).cpu().numpy().astype(np.uint8))
-                    finished.put((B, res, images, labels, vols))
+                    finished.put((B, res, images, labels, vols, stage, int(out["label"].shape[2]) if args.labels else 0))
                     if timing:
                         print(f"[cli timing] generator: generate {t_b - t_a:.3f} s (simulator {out['wall']['sim_run_s']:.3f}), wait + copy out {t_c - t_b:.3f}, "
                               f"hand over {time.time() - t_c:.3f}", file=sys.stderr, flush=True)
@@ -170,17 +183,29 @@ def main(argv=None):
             if item is None:
                 alive -= 1
                 continue
-            B, res, images, labels, vols = item
+            B, res, images, labels, vols, stage, gen_label_width = item
             t_a = time.time()
             writer.wait()                                  # the previous batch's files (written while the next ones were simulated)
             t_b = time.time()
-            for k in range(B):
-                out_dir = os.path.join(os.path.abspath(out_cfg['directory']), datetime.now().strftime('%Y%m%d_%H%M%S') + "_" + str(uuid4()))
-                name = os.path.basename(out_dir)
-                writer.submit(out_dir, name, edges=res.sample_edges(k) if out_cfg.get('save_trees', True) else None,
-                              image=images[k] if out_cfg.get("save_2D_image", True) else None,
-                              label_bits=labels[k] if labels is not None else None, config=config, volume=vols[k] if vols is not None else None,
-                              volume_format=out_cfg.get("save_3D_volumes") or "npy")
+            stamp = datetime.now().strftime('%Y%m%d_%H%M%S')
+            root_dir = os.path.abspath(out_cfg['directory'])
+            out_dirs = [os.path.join(root_dir, stamp + "_" + str(uuid4())) for _ in range(B)]
+            names = [os.path.basename(d) for d in out_dirs]
+            if vols is None:
+                # one native call per batch (csrc/fileio.cpp octa_write_sample_files): its threads take the samples from a counter
+                writer.submit_batch(out_dirs, names, edges=res.edges if out_cfg.get('save_trees', True) else None, edge_off=res.edge_off,
+                                    images=images if out_cfg.get("save_2D_image", True) else None, label_bits=labels,
+                                    label_width=gen_label_width if labels is not None else None, config=config, on_done=lambda st=stage: staging.put(st))
+            else:
+                if labels is not None:                         # the per-sample writers take one byte per pixel
+                    labels = np.unpackbits(labels, axis=2)[:, :, :gen_label_width] * np.uint8(255)
+                images = np.array(images)
+                staging.put(stage)                             # everything this path hands on is a copy
+                for k in range(B):
+                    writer.submit(out_dirs[k], names[k], edges=res.sample_edges(k) if out_cfg.get('save_trees', True) else None,
+                                  image=images[k] if out_cfg.get("save_2D_image", True) else None,
+                                  label_bits=labels[k] if labels is not None else None, config=config, volume=vols[k],
+                                  volume_format=out_cfg.get("save_3D_volumes") or "npy")
             done += B
             if timing:
                 print(f"[cli timing] main: waited {t_b - t_a:.3f} s for the previous batch's files, submitted {B} samples in {time.time() - t_b:.3f}", file=sys.stderr, flush=True)

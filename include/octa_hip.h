@@ -126,6 +126,18 @@ int64_t octa_csv_parse_edges(const char *text, int64_t len, double *h_out, int64
 int octa_py_random_advance(uint32_t *state625, int64_t n_draws);
 int octa_png_write_gray8(const char *path, const uint8_t *h_pixels, int width, int height, int level);
 int octa_png_write_bits(const char *path, const uint8_t *h_pixels, int width, int height, int level);
+/* The files of a whole batch in one call, written by `threads` native threads (round 6): per sample k the directory dirs[k] (created
+ * with its parents) receives config.yml (config_text, when given), <names[k]>.csv (rows edge_off[k] .. edge_off[k+1] of h_edges, when
+ * given), art_ven_img_gray.png (h_images [n][image_h][image_w], when given) and <names[k]>_label.png (h_labels [n][label_h][label_w],
+ * non-zero = white -- or packed rows, see below --, when given): generate_vessel_graph.py:43-86 + visualize_vessel_graphs.py:95-101 for n samples, outside the
+ * interpreter lock. Returns 0, or < 0 with the first failure in octa_last_error(). */
+int octa_write_sample_files(int64_t n_samples, const char *const *dirs, const char *const *names, const double *h_edges,
+                            const int64_t *edge_off, const uint8_t *h_images, int image_w, int image_h, const uint8_t *h_labels,
+                            int label_w, int label_h, int labels_packed, const char *config_text, int64_t config_len, int png_level, int threads);
+/* labels_packed != 0: h_labels holds mode "1" rows already, [n][label_h][(label_w + 7) / 8] bytes (bit 7 of a byte = its first pixel), as
+ * octa_pack_bits writes them ON THE DEVICE: d_in uint8 [n_rows][width] (non-zero = white) -> d_out uint8 [n_rows][(width + 7) / 8]; an eighth of
+ * the label bytes crosses PCIe. */
+int octa_pack_bits(octa_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, int64_t n_rows, int width, void *stream);
 
 /* ---- CSV round trip of node positions ------------------------------------
  * Replaces the text round trip str(np.ndarray) -> float() of generate_vessel_graph.py:59-66 +

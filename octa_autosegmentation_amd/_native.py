@@ -46,6 +46,9 @@ SIGNATURES = {
     "octa_py_random_advance": (c_int, [c_void_p, ctypes.c_int64]),
     "octa_png_write_gray8": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int]),
     "octa_png_write_bits": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int]),
+    "octa_write_sample_files": (c_int, [ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                        ctypes.c_char_p, ctypes.c_int64, c_int, c_int]),
+    "octa_pack_bits": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_void_p]),
     "octa_background_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),
     "octa_speckle_brightness": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "octa_sim_create": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),

@@ -77,7 +77,40 @@ read_back_kernel(const double *__restrict__ in, double *__restrict__ out, long n
     if (bad) atomicAdd(flag, 1);
 }
 
+// mode "1" rows of binarised labels (visualize_vessel_graphs.py:99 -> PNG bit depth 1): bit 7 of byte x / 8 is pixel x, non-zero = white.
+// One thread per output byte; eight pixels are one 64-bit load when the row allows it. 1.48 MB in, 185 KB out per 1216 x 1216 label:
+// what crosses PCIe for the label file is an eighth of the byte image.
+__global__ void __launch_bounds__(256)
+pack_bits_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, long n_rows, int width, int row_bytes) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * row_bytes) return;
+    const long row = t / row_bytes;
+    const int bx = (int)(t - row * row_bytes);
+    const uint8_t *src = in + row * width + 8 * bx;
+    unsigned b = 0;
+    if (8 * bx + 8 <= width && ((size_t)src & 7) == 0) {
+        unsigned long long v = *reinterpret_cast<const unsigned long long *>(src);
+        v |= v >> 4; v |= v >> 2; v |= v >> 1;
+        v &= 0x0101010101010101ull;
+        b = (unsigned)((v * 0x8040201008040201ull) >> 56);
+    } else {
+        for (int k = 0; k < 8 && 8 * bx + k < width; k++) if (src[k]) b |= 0x80u >> k;
+    }
+    out[t] = (uint8_t)b;
+}
+
 }  // namespace
+
+extern "C" int octa_pack_bits(octa_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, int64_t n_rows, int width, void *stream_) {
+    if (!ctx || n_rows < 0 || width <= 0 || (n_rows > 0 && (!d_in || !d_out))) { octa::set_error("octa_pack_bits: bad arguments"); return -2; }
+    if (n_rows == 0) return 0;
+    OCTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const int rb = (width + 7) / 8;
+    const long total = (long)n_rows * rb;
+    hipLaunchKernelGGL(pack_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, d_in, d_out, (long)n_rows, width, rb);
+    OCTA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 extern "C" int octa_edges_read_back(octa_ctx *ctx, const double *d_edges, double *d_out, int64_t n_edges, int *h_n_unhandled,
                                     void *stream_) {

@@ -19,7 +19,9 @@ def default_threads():
 
 class SampleFileWriter:
     def __init__(self, threads=None):
-        self.pool = ThreadPoolExecutor(max_workers=threads or default_threads())
+        self.threads = threads or default_threads()
+        self.pool = ThreadPoolExecutor(max_workers=self.threads)
+        self.batch_pool = ThreadPoolExecutor(max_workers=2)       # each job is ONE native call that runs its own `threads` threads
         self.pending = []
         self._cfg_seen = None         # the last configuration dumped (a deep copy) and its YAML text: a run writes the same config.yml
         self._cfg_text = None         # next to every sample, and yaml.dump of it costs 1.2 ms of the submitting thread per sample
@@ -45,6 +47,53 @@ class SampleFileWriter:
             else:
                 self.pending.append(self.pool.submit(np.save, os.path.join(out_dir, "art_ven_img_gray.npy"), volume))
 
+    def submit_batch(self, out_dirs, names, edges=None, edge_off=None, images=None, label_bits=None, config=None, label_width=None, on_done=None):
+        """Queue the files of a whole batch as ONE native call (csrc/fileio.cpp octa_write_sample_files: its own threads take the samples
+        from a counter, nothing runs under the interpreter lock). out_dirs / names: per sample; edges float64 [rows, 7] of the whole batch
+        with edge_off int64 [B + 1]; images uint8 [B, h, w]; label_bits uint8 [B, H, W] (non-zero = white) -- or, with label_width = W, the
+        rows packed on the device, uint8 [B, H, (W + 7) // 8] (tree2img.pack_label_bits_device). on_done() is called when the files are
+        written (or the call has failed): the caller's staging buffers are free again. Round 6: submitted sample by sample (four futures
+        each) the CLI's on-disk rate was bound by the lock the generator threads need too."""
+        import ctypes
+        from . import _native
+        B = len(out_dirs)
+        assert len(names) == B
+        cfg = None
+        if config is not None:
+            if self._cfg_text is None or config != self._cfg_seen:
+                import copy
+                import yaml
+                self._cfg_seen, self._cfg_text = copy.deepcopy(config), yaml.dump(config)
+            cfg = self._cfg_text.encode()
+        e = off = None
+        if edges is not None:
+            e = np.ascontiguousarray(edges, dtype=np.float64).reshape(-1, 7)
+            off = np.ascontiguousarray(edge_off, dtype=np.int64)
+            assert len(off) == B + 1 and int(off[-1]) <= len(e)
+        img = np.ascontiguousarray(images, dtype=np.uint8) if images is not None else None
+        lab = np.ascontiguousarray(label_bits, dtype=np.uint8) if label_bits is not None else None
+        assert img is None or (img.ndim == 3 and img.shape[0] == B)
+        assert lab is None or (lab.ndim == 3 and lab.shape[0] == B)
+        packed = label_width is not None
+        lab_w = int(label_width) if packed else (int(lab.shape[2]) if lab is not None else 0)
+        assert lab is None or not packed or lab.shape[2] == (lab_w + 7) // 8
+        dirs_c = (ctypes.c_char_p * B)(*[os.fsencode(d) for d in out_dirs])
+        names_c = (ctypes.c_char_p * B)(*[os.fsencode(n) for n in names])
+        threads = self.threads
+
+        def job(keep=(e, off, img, lab, dirs_c, names_c, cfg)):        # the arrays stay alive until the call has returned
+            p = lambda a: ctypes.c_void_p(a.ctypes.data) if a is not None else None
+            rc = _native.lib().octa_write_sample_files(
+                B, ctypes.cast(dirs_c, ctypes.c_void_p), ctypes.cast(names_c, ctypes.c_void_p), p(e), p(off), p(img), int(img.shape[2]) if img is not None else 0,
+                int(img.shape[1]) if img is not None else 0, p(lab), lab_w,
+                int(lab.shape[1]) if lab is not None else 0, 1 if packed else 0, cfg, len(cfg) if cfg is not None else 0, -1, int(threads))
+            try:
+                _native.check(rc, "octa_write_sample_files")
+            finally:
+                if on_done is not None:
+                    on_done()
+        self.pending.append(self.batch_pool.submit(job))
+
     def wait(self):
         """Block until everything queued so far is on disk; a failed write raises here."""
         pending, self.pending = self.pending, []
@@ -54,6 +103,39 @@ class SampleFileWriter:
     def close(self):
         self.wait()
         self.pool.shutdown()
+        self.batch_pool.shutdown()
+
+
+class HostStaging:
+    """Pinned host buffers a generator thread copies a finished batch into (edge list, images, packed label rows): the writers' inputs.
+    Round 6: `tensor.cpu()` allocated and page-faulted ~0.5 GB of pageable memory per 512-sample batch and copied into it through the
+    runtime's bounce buffers; a pinned block that is kept is one DMA. A set is in use from `fetch` until the writer's `on_done`."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def _get(self, key, shape, dtype):
+        import torch
+        n = int(np.prod(shape))
+        t = self.buf.get(key)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty((max(n, 1) * 9 // 8,), dtype=dtype, pin_memory=True)         # a little headroom: batches differ in their edge counts
+            self.buf[key] = t
+        return t[:n].view(shape)
+
+    def fetch(self, **tensors):
+        """CUDA tensors -> numpy views of pinned copies (None stays None); one stream synchronisation for all of them."""
+        import torch
+        out = {}
+        for k, t in tensors.items():
+            if t is None:
+                out[k] = None
+                continue
+            h = self._get(k, tuple(t.shape), t.dtype)
+            h.copy_(t, non_blocking=True)
+            out[k] = h
+        torch.cuda.current_stream().synchronize()
+        return {k: (v.numpy() if v is not None else None) for k, v in out.items()}
 
 
 def _write_text(path, text):

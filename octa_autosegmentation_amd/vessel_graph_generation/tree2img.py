@@ -207,6 +207,21 @@ def binarize_label_device(d_img):
     return out
 
 
+def pack_label_bits_device(d_bits, out=None):
+    """Mode "1" rows of binarised labels on the device (csrc/graphio.hip octa_pack_bits): uint8 CUDA [B,H,W] (non-zero = white) ->
+    uint8 CUDA [B,H,(W+7)//8], bit 7 of a byte = its first pixel -- the rows a 1-bit PNG stores (visualize_vessel_graphs.py:99)."""
+    import torch
+    if d_bits.dtype != torch.uint8 or not d_bits.is_cuda or not d_bits.is_contiguous() or d_bits.dim() != 3:
+        raise ValueError("d_bits must be a contiguous uint8 CUDA tensor [B,H,W]")
+    B, H, W = d_bits.shape
+    if out is None:
+        out = torch.empty((B, H, (W + 7) // 8), dtype=torch.uint8, device=d_bits.device)
+    rc = _native.lib().octa_pack_bits(_native.ctx(d_bits.device.index), ctypes.c_void_p(d_bits.data_ptr()), ctypes.c_void_p(out.data_ptr()), B * H, W,
+                                      _native.current_stream_ptr())
+    _native.check(rc, "octa_pack_bits")
+    return out
+
+
 def maximum_u8_device(a, b):
     """np.maximum(art_mat, ven_mat) of generate_vessel_graph.py:83 on device."""
     import torch

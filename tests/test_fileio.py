@@ -113,3 +113,53 @@ def test_nifti_writer_header_and_voxels(tmp_path):
     assert (back == vol).all()
     with pytest.raises(ValueError):
         write_nifti_u8(str(tmp_path / "x.nii"), vol.astype(np.float32))
+
+
+def test_batch_writer_writes_the_files_of_the_per_sample_path(tmp_path, hip_lib_built):
+    """octa_write_sample_files (one native call per batch, its own threads: the CLI's path since round 6) against the per-sample
+    writers it replaces: every file byte for byte -- config.yml, <name>.csv (ragged row counts, an EMPTY graph), art_ven_img_gray.png,
+    <name>_label.png -- and directories created with their parents; a failure names the file."""
+    import filecmp
+    from octa_autosegmentation_amd import _native
+    from octa_autosegmentation_amd.output_files import SampleFileWriter
+    rng = np.random.default_rng(5)
+    rows = [700, 0, 1, 333, 1200]
+    B = len(rows)
+    off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    e = np.zeros((int(off[-1]), 7))
+    e[:, 0:3] = rng.uniform(0, 1, (len(e), 3))
+    e[:, 3:6] = e[:, 0:3] + rng.normal(0, 0.01, (len(e), 3))
+    e[:, 6] = rng.uniform(1e-4, 1e-2, len(e))
+    e[5, 0:3] = [1e-9, 0.5, 123.0]                                     # a scientific-notation row
+    img = rng.integers(0, 256, (B, 76, 52), dtype=np.uint8)
+    lab = ((rng.uniform(0, 1, (B, 67, 131)) > 0.7) * 255).astype(np.uint8)      # a width that is not a multiple of 8
+    cfg = {"Greenhouse": {"d": 0.1, "modes": [{"I": 3}]}, "output": {"directory": "x"}}
+    w = SampleFileWriter(3)
+    try:
+        w.submit_batch([str(tmp_path / "new" / "deep" / f"d{k}") for k in range(B)], [f"s{k}" for k in range(B)], edges=e, edge_off=off, images=img, label_bits=lab, config=cfg)
+        for k in range(B):
+            w.submit(str(tmp_path / "old" / f"d{k}"), f"s{k}", edges=e[off[k]:off[k + 1]], image=img[k], label_bits=lab[k], config=cfg)
+        w.wait()
+        for k in range(B):
+            for f in (f"s{k}.csv", "art_ven_img_gray.png", f"s{k}_label.png", "config.yml"):
+                assert filecmp.cmp(tmp_path / "new" / "deep" / f"d{k}" / f, tmp_path / "old" / f"d{k}" / f, shallow=False), (k, f)
+        # labels handed over as mode "1" rows (what tree2img.pack_label_bits_device makes on the GPU): the same files, and the caller is told
+        done = []
+        w.submit_batch([str(tmp_path / "packed" / f"d{k}") for k in range(B)], [f"s{k}" for k in range(B)], label_bits=np.packbits(lab > 0, axis=2),
+                       label_width=lab.shape[2], on_done=lambda: done.append(1))
+        w.wait()
+        assert done == [1]
+        for k in range(B):
+            assert filecmp.cmp(tmp_path / "packed" / f"d{k}" / f"s{k}_label.png", tmp_path / "old" / f"d{k}" / f"s{k}_label.png", shallow=False)
+        # only what was asked for
+        w.submit_batch([str(tmp_path / "part" / "a")], ["a"], images=img[:1])
+        w.wait()
+        assert sorted(os.listdir(tmp_path / "part" / "a")) == ["art_ven_img_gray.png"]
+        # a directory that cannot be created fails loudly, with its name
+        (tmp_path / "file").write_text("x")
+        w.submit_batch([str(tmp_path / "file" / "sub")], ["a"], images=img[:1])
+        with pytest.raises(_native.OctaHipError, match="file"):
+            w.wait()
+    finally:
+        w.pending = []
+        w.close()

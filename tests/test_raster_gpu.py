@@ -222,3 +222,14 @@ def test_max_u8(t2i):
     a = torch.randint(0, 256, (3, 77, 91), dtype=torch.uint8, device="cuda")
     b = torch.randint(0, 256, (3, 77, 91), dtype=torch.uint8, device="cuda")
     assert torch.equal(t2i.maximum_u8_device(a, b), torch.maximum(a, b))
+
+
+def test_label_bits_packed_on_the_device_are_numpys_packbits(t2i):
+    """octa_pack_bits: the mode "1" rows of binarised labels (visualize_vessel_graphs.py:99), bit 7 of a byte = its first pixel, for widths
+    that are and are not multiples of eight and values that are merely non-zero."""
+    import torch
+    for shape in ((2, 1216, 1216), (3, 37, 53), (1, 5, 8), (2, 9, 131)):
+        a = torch.randint(0, 3, shape, dtype=torch.uint8, device="cuda") * 127        # 0, 127, 254: non-zero = white
+        got = t2i.pack_label_bits_device(a).cpu().numpy()
+        assert got.shape == (shape[0], shape[1], (shape[2] + 7) // 8)
+        assert (got == np.packbits(a.cpu().numpy() > 0, axis=2)).all()
