@@ -400,7 +400,7 @@ def files_leg(gen, stream, seeds, threads=None):
         import io
         import generate_vessel_graph
         from octa_autosegmentation_amd.utils import configs
-        n_cli = 4096
+        n_cli = 8192                 # round 6: 16 launches of 512 (4096 until round 5: the set-up of the generator threads was a fifth of the leg)
         t1 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
             generate_vessel_graph.main(["--config_file", configs.GENERATOR_CONFIG, "--num_samples", str(n_cli), "--labels", "--seed", "7000000", "--output.directory", out_root])
@@ -576,11 +576,10 @@ def main():
     sizes = sorted({G} | ({args.warmup % G} if args.warmup % G else set()) | ({args.steps % G} if args.steps % G else set()))
     gens = {g: [pipeline.TripleGenerator(cfg, B * g) for _ in range(n_fly)] for g in sizes}
     streams = [torch.cuda.Stream() for _ in range(n_fly)]
-    if os.environ.get("OCTA_BENCH_PLAN_AHEAD") == "1":
-        pipeline.TripleGenerator.plan_ahead = True
+    if os.environ.get("OCTA_BENCH_PLAN_AHEAD") in ("0", "1"):            # A/B aid; the class default is the planned form since round 6
+        pipeline.TripleGenerator.plan_ahead = os.environ["OCTA_BENCH_PLAN_AHEAD"] == "1"
     if args.serial_sim and n_fly > 1:
-        import threading
-        gate = threading.Lock()
+        gate = pipeline.SimGate()
         for gl in gens.values():
             for g_ in gl:
                 g_.sim_gate = gate
@@ -600,20 +599,9 @@ def main():
     # launch only ONE slot's full-size generator runs before the clock starts; the other slot's first launch would grow its rasteriser scratch
     # (2.7 GB of polygon sides, 1.4 GB of row lists: hipMalloc + an implicit device synchronisation each), its output pool and load the render
     # kernels inside the timed region. A synthetic edge list of a launch's size goes through the image and the label rasterisation of each.
-    def prime(gen):
-        n_samples = gen.batch
-        per = 9600                                                     # edges per sample of the docker configuration: 8.6 - 9.4 k
-        g = torch.Generator(device=dev).manual_seed(1)
-        e = torch.rand((n_samples * per, 7), device=dev, dtype=torch.float64, generator=g)
-        e[:, 3:6] = e[:, 0:3] + (e[:, 3:6] - 0.5) * 0.03               # short segments
-        e[:, 6] = 0.002 + 0.004 * e[:, 6]
-        off = np.arange(n_samples + 1, dtype=np.int64) * per
-        n_art = np.full(n_samples, per // 2, np.int64)
-        fake = type("Primer", (), {"d_edges": e, "edges": None, "edge_off": off, "n_art": n_art})()
-        gen._render(fake, True)
     for g_ in gens[G]:
         with torch.cuda.stream(streams[gens[G].index(g_)]):
-            prime(g_)
+            g_.prime()
     torch.cuda.synchronize()
 
     def run_steps(first, count):
@@ -638,11 +626,13 @@ def main():
     import gc
     gc.collect()
     gc.disable()                       # no collector pause between two launches of the timed region (it holds every thread: 5 launches are timed)
-    t0 = time.time()
-    outs = run_steps(args.warmup, args.steps)
-    barrier()
-    dt = time.time() - t0
-    gc.enable()
+    try:
+        t0 = time.time()
+        outs = run_steps(args.warmup, args.steps)
+        barrier()
+        dt = time.time() - t0
+    finally:
+        gc.enable()
     # where a slot's time goes (host clock, mean over the timed launches): simulator call (host init + kernel + download + BFS export),
     # render enqueue, wait for the render kernels; `kernel` is the device time of the persistent kernel inside the simulator call
     slot_cycle = None
@@ -851,7 +841,9 @@ def main():
             "config": {"workload": f"configs[1]: {B}-sample vessel-graph batch (docker/vessel_graph_gen_docker_config.yml, "
                                    f"I=100+150, N=2000) + tree2img rasterise 304x304 image and 1216x1216 label",
                        "batch_per_gpu": B, "steps_per_launch": G, "launches_in_flight": n_fly, "persistent_kernels_at_a_time": sim_conc, "parallelism": f"sample-sharded x{world}, no collective",
-                       "set_up": "every full-size generator primed once before the clock starts (a synthetic edge list through its rasteriser: scratch growth and kernel loading; nothing simulated)"},
+                       "set_up": "every full-size generator primed once before the clock starts (TripleGenerator.prime: a synthetic edge list through its rasteriser: scratch growth and kernel "
+                                 "loading; nothing simulated); Python's cyclic garbage collector is off inside the timed region (gc.disable: a collection holds every thread)",
+                       "ordering": "a launch's rasterisation is ordered behind the NEXT launch on the device (csrc/order.hip gate kernel on the rasteriser's stream; no host polling or sleeps)"},
             "parity": "graph CSV text bit-exact with the REFERENCE (imported and run in the build container) on 8 short + 2 full-length fixture "
                       "runs and on 64 further full-length seeds (tests/golden/sim_wide_golden.npz: SHA-256 of the CSV text of seeds 1000-1063; the "
                       "GPU reproduces all 64, tests/test_sim_gpu.py); label / image pixels bit-exact on the reference's fixtures. The oracle follows "

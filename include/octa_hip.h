@@ -557,10 +557,16 @@ int octa_sim_create(octa_ctx *ctx, const octa_sim_config *cfg, int B, octa_sim *
 int octa_sim_create_ex(octa_ctx *ctx, const octa_sim_config *cfg, int B, int build, octa_sim **out);
 void octa_sim_destroy(octa_sim *sim);
 
-/* Persistent-kernel launches of this process so far (any simulator, any thread): with several generators in flight a caller that has just
- * finished its own octa_sim_run can wait for the count to move -- the next launch is then on the GPU -- before it enqueues its rasterisation
- * (the pipeline does: enqueued at the same moment, the rasteriser can take the CUs first and delay the whole launch by its own duration). */
+/* Ordering a rasterisation behind the NEXT launch of the persistent kernel, on the device (round 6; csrc/order.hip, csrc/sim_api.cpp).
+ * Every persistent-kernel launch of the process takes a ticket; octa_sim_launch_count() is the last ticket issued (after a caller's own
+ * octa_sim_run returned under the generators' common lock: that run's ticket). octa_order_wait_launch enqueues a one-wave gate kernel on
+ * `stream`: what is enqueued behind it runs once the launch with `ticket` has all its workgroups on the GPU (they sign in as they start)
+ * plus settle_us, or after timeout_us. Why: nothing co-resides with the simulator's workgroups, and a rasterisation dispatched while a
+ * launch is being placed takes CUs it then keeps -- the launch lasts two samples. d_out3 (optional, device int[3]):
+ * 1 = resident / 2 = timed out, 100 MHz ticks waited, workgroups signed in. The reference has no counterpart: its samples run in separate
+ * processes on CPU cores (generate_vessel_graph.py:112-129). */
 long long octa_sim_launch_count(void);
+int octa_order_wait_launch(octa_ctx *ctx, long long ticket, int timeout_us, int settle_us, int *d_out3, void *stream);
 
 /* Run all iterations for B samples. Synchronous (the bifurcation service needs the host). Returns 0, -1 (runtime
  * failure), -2 (bad arguments) or -3 (a sample set error bits: capacity, or 0x800 = the host did not answer in time). */

@@ -104,6 +104,7 @@ SIGNATURES = {
     "octa_conv3x3_nhwc_wgrad_acc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_conv3x3_nhwc_wgrad_pad_acc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_sim_launch_count": (ctypes.c_longlong, []),
+    "octa_order_wait_launch": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "octa_conv3x3_c1_fwd2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "octa_conv3x3_c1_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "octa_conv_stat_tiles": (c_int, [c_int, c_int]),

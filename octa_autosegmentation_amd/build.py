@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liboctahip.so")
-SOURCES = ["common.cpp", "bif_native.cpp", "fileio.cpp", "sim_api.cpp", "raster.hip", "sim.hip", "sim.hip@large", "voxel.hip", "graphio.hip", "norm.hip", "conv.hip", "conv_f32.hip", "augment.hip", "postproc.hip", "loss.hip", "blur.hip", "thin_conv.hip"]
+SOURCES = ["common.cpp", "bif_native.cpp", "fileio.cpp", "sim_api.cpp", "raster.hip", "sim.hip", "sim.hip@large", "voxel.hip", "graphio.hip", "order.hip", "norm.hip", "conv.hip", "conv_f32.hip", "augment.hip", "postproc.hip", "loss.hip", "blur.hip", "thin_conv.hip"]
 HEADERS = ["common.h", "raster_core.h", "sim_core.h", "sim_host.h", "gpow.h", "glibc_pow_tables.h", "glibc_trig.h", "glibc_trig_tables.h",
            os.path.join("..", "..", "include", "octa_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-ldl", "-lz"]

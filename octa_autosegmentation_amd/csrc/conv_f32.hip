@@ -2,7 +2,10 @@
 // accumulation -- no bf16 / xf32 rounding anywhere), NCHW, for the paths of the reference that run WITHOUT mixed precision:
 //   * test.py:79 and validate.py (model.inference outside torch.cuda.amp.autocast): every convolution of DynUNet
 //     (models/networks.py:6 -> MONAI DynUNet: 3x3 stride 1 / 2, 2x2 stride-2 and 1x1 transposed, 1x1 head with bias);
-//   * `General.amp: false` forward passes that need no gradient.
+//   * `General.amp: false` forward passes that need no gradient;
+//   * round 6: the same for the GAN networks -- test.py with `General.inference: G` and the frozen generator of the docker pipeline
+//     (test.py:75-82, docker/dockershell.sh:14-16) run ResnetGenerator in fp32: 7x7 stem / head behind a reflection pad, 3x3 layers with
+//     zero padding or none (behind ReflectionPad2d(1)); NLayerDiscriminator's 4x4 stride-1 layers.
 // north_star asks for segmentation logits within 1e-4 of the reference's fp32 CPU path: with exact fp32 products and fp32 sums the
 // only difference left is the summation order (tests/test_conv_f32_gpu.py: 1x1x1216x1216 DynUNet logits against the CPU modules).
 //
@@ -31,7 +34,9 @@ template <int K, int S, int MB, bool TR = false>
 __global__ void __launch_bounds__(F_THREADS)
 conv_f32_kernel(const float *__restrict__ X, const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ Y,
                 int Cin, int H, int W, int Cout, int CoutW, int Ho, int Wo, int pad, int tiles_x, int osc, int ooy, int oox, const float *__restrict__ zero) {
-    constexpr int KC = S == 2 ? 4 : 8;                   // input channels per slice (stride 2: the halo tile is 4x the output tile, half the depth keeps the prefetch in registers)
+    // input channels per slice (stride 2: the halo tile is 4x the output tile, half the depth keeps the prefetch in registers; the 4x4 and 7x7
+    // layers of the GAN networks, round 6: 16 / 49 taps per channel -- 4 / 2 channels keep the weight slice at 16 / 25 KB of LDS)
+    constexpr int KC = K >= 7 ? 2 : ((S == 2 || K >= 4) ? 4 : 8);
     constexpr int IH = (F_TH - 1) * S + K, IW = (F_TW - 1) * S + K;
     constexpr int IWP = IW | 1;                          // odd row pitch: the two half-waves (channels ci, ci + 1) start on different banks
     constexpr int BM = 32 * MB, KK = K * K;
@@ -169,7 +174,7 @@ const float *zero_word(octa_ctx *ctx) {               // what the padding lanes 
 }  // namespace
 
 // Single-precision convolution, NCHW (see the file header). d_wp: weights packed as [Cin][K*K][cout_w] with cout_w >= Cout (a
-// view of a larger packed tensor may be passed: rows are cout_w apart); d_bias: [Cout] or NULL. K / stride in {1/1, 3/1, 3/2}.
+// view of a larger packed tensor may be passed: rows are cout_w apart); d_bias: [Cout] or NULL. K / stride in {1/1, 3/1, 3/2, 4/1, 7/1}.
 // The output tensor is [N][Cout][Ho * osc][Wo * osc]; osc = 1 writes it densely, osc = 2 writes the pixels of
 // parity (ooy, oox) only (one of the four 1x1 products of a 2x2 stride-2 transposed convolution).
 extern "C" int octa_conv2d_f32_nchw(octa_ctx *ctx, const float *d_x, const float *d_wp, const float *d_bias, float *d_y, int N, int Cin, int H, int W,
@@ -204,8 +209,10 @@ extern "C" int octa_conv2d_f32_nchw(octa_ctx *ctx, const float *d_x, const float
     OCTA_F32_CASE(1, 1)
     OCTA_F32_CASE(3, 1)
     OCTA_F32_CASE(3, 2)
+    OCTA_F32_CASE(4, 1)          // PatchGAN (models/networks.py:445-506: 4x4, stride 1, padding 1)
+    OCTA_F32_CASE(7, 1)          // the generator's stem and head (models/networks.py:404-421: 7x7 behind ReflectionPad2d(3))
 #undef OCTA_F32_CASE
-    octa::set_error("octa_conv2d_f32_nchw: kernel size %d with stride %d is not instantiated (1/1, 3/1, 3/2)", K, stride);
+    octa::set_error("octa_conv2d_f32_nchw: kernel size %d with stride %d is not instantiated (1/1, 3/1, 3/2, 4/1, 7/1)", K, stride);
     return -2;
 }
 

@@ -9,6 +9,7 @@
 // A (b, c) plane is split over `splits` workgroups so that >= ~2 workgroups per CU are in flight even for
 // the 128-plane top level; kernel 1 leaves per-split partial sums, kernel 2 folds them (a few floats) and
 // streams the plane with 16-byte accesses.
+#include <type_traits>
 #include "common.h"
 #include <cstdlib>
 
@@ -71,17 +72,21 @@ __global__ void __launch_bounds__(NT) in_fwd_stats(const T *__restrict__ x, long
     long e0, e1;
     chunk_of(hw, splits, s, Vec<T>::N, e0, e1);
     const T *px = x + plane * hw;
-    float sum = 0.f, sq = 0.f;
+    // fp32 activations (the reference's fp32 passes: test.py, validate.py, the frozen generator) accumulate in double: E[x^2] - mean^2 on
+    // single-precision sums loses every digit of the variance of a nearly constant channel (round 6: the reference-made GAN fixture, whose
+    // channels are, came out 5e-3 off; the torch modules 8e-4). bf16 activations keep the float sums: their rounding is far above this.
+    typedef typename std::conditional<std::is_same<T, float>::value, double, float>::type acc_t;
+    acc_t sum = 0, sq = 0;
     const bool vec = (hw % Vec<T>::N == 0) && ((reinterpret_cast<size_t>(px) & 15) == 0);
     if (vec) {
         for (long i = e0 + (long)threadIdx.x * Vec<T>::N; i + Vec<T>::N <= e1; i += (long)NT * Vec<T>::N) {
             float v[8];
             Vec<T>::load(px + i, v);
 #pragma unroll
-            for (int k = 0; k < Vec<T>::N; k++) { sum += v[k]; sq += v[k] * v[k]; }
+            for (int k = 0; k < Vec<T>::N; k++) { sum += (acc_t)v[k]; sq += (acc_t)v[k] * (acc_t)v[k]; }
         }
     } else {
-        for (long i = e0 + threadIdx.x; i < e1; i += NT) { float v = Vec<T>::ld1(px + i); sum += v; sq += v * v; }
+        for (long i = e0 + threadIdx.x; i < e1; i += NT) { const acc_t v = (acc_t)Vec<T>::ld1(px + i); sum += v; sq += v * v; }
     }
     double a = sum, b = sq;
     block_reduce2(a, b, sh);
@@ -102,7 +107,9 @@ __global__ void __launch_bounds__(NT) in_fwd_apply(const T *__restrict__ x, T *_
     if (var < 0) var = 0;
     const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
     if (s == 0 && threadIdx.x == 0) { mean_out[plane] = mean; rstd_out[plane] = rstd; }
-    const float g = w ? w[c] * rstd : rstd, sh = (bias ? bias[c] : 0.f) - mean * g;
+    // fp32: (x - mean) * g + b as torch evaluates it -- x * g - mean * g cancels in single precision where |mean| >> std; bf16: one fma
+    constexpr bool F32 = std::is_same<T, float>::value;
+    const float g = w ? w[c] * rstd : rstd, b0 = bias ? bias[c] : 0.f, sh = b0 - mean * g;
     long e0, e1;
     chunk_of(hw, splits, s, Vec<T>::N, e0, e1);
     const T *px = x + plane * hw;
@@ -113,11 +120,15 @@ __global__ void __launch_bounds__(NT) in_fwd_apply(const T *__restrict__ x, T *_
             float v[8];
             Vec<T>::load(px + i, v);
 #pragma unroll
-            for (int k = 0; k < Vec<T>::N; k++) { float z = v[k] * g + sh; v[k] = z > 0.f ? z : z * slope; }
+            for (int k = 0; k < Vec<T>::N; k++) { float z = F32 ? (v[k] - mean) * g + b0 : v[k] * g + sh; v[k] = z > 0.f ? z : z * slope; }
             Vec<T>::store(py + i, v);
         }
     } else {
-        for (long i = e0 + threadIdx.x; i < e1; i += NT) { float z = Vec<T>::ld1(px + i) * g + sh; Vec<T>::st1(py + i, z > 0.f ? z : z * slope); }
+        for (long i = e0 + threadIdx.x; i < e1; i += NT) {
+            const float xv = Vec<T>::ld1(px + i);
+            float z = F32 ? (xv - mean) * g + b0 : xv * g + sh;
+            Vec<T>::st1(py + i, z > 0.f ? z : z * slope);
+        }
     }
 }
 

@@ -53,7 +53,8 @@ using namespace OCTA_SIMK;
 #define octa_sim_kat_kd_order OCTA_SIM_FN(kat_kd_order)
 struct OCTA_SIM_T;
 extern "C" void octa_sim_destroy(OCTA_SIM_T *S);
-extern "C" void octa_sim_note_launch(void);
+extern "C" long long octa_sim_next_ticket(void);
+extern "C" int *octa_sim_launch_flag(int device);
 
 namespace {
 
@@ -366,6 +367,8 @@ struct HostMail {
     int *done;           // pinned host [1]                     device -> host: workgroups that have left the kernel
     long timeout_ticks;  // device-side bound on one wait for the host (100 MHz wall clock)
     long park_ticks;     // a workgroup that has waited this long parks (0: never, wait until timeout_ticks as round 1 did)
+    int *launch_flag;    // device [8]: the launches' sign-in block (csrc/sim_api.cpp octa_sim_launch_flag), or NULL
+    int ticket;          // this launch's ticket
 };
 constexpr int REQ_PER_SAMPLE = OCTA_SIM_LARGE ? 256 : 32;    // bifurcation requests of one sample per mailbox round trip (6.2 KB each, pinned host memory)
 constexpr int ERR_HOST_TIMEOUT = 2048;
@@ -573,6 +576,14 @@ __global__ void __launch_bounds__(SIM_THREADS, SIM_WG_PER_CU * SIM_THREADS / 256
 sim_persistent_kernel(BatchPtrs B, HostMail M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Blk b = {(int)threadIdx.x, SIM_THREADS, smem};      // the launch shape is fixed (sim_run_impl): as a constant it removes the one-thread (host build) paths and turns every stride into an immediate
+    // sign in: a rasterisation ordered behind this launch waits (on its own stream, csrc/order.hip) until the launch's workgroups are resident
+    if (threadIdx.x == 0 && M.launch_flag) {
+        if (blockIdx.x == 0) {
+            __hip_atomic_store(M.launch_flag + 3 + (M.ticket & 1), (int)gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(M.launch_flag, M.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_fetch_add(M.launch_flag + 1 + (M.ticket & 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     int *next = b.coll() + 104;
     while (true) {
         if (b.tid == 0) *next = atomicAdd(B.next_sample, 1);
@@ -660,12 +671,13 @@ struct OCTA_SIM_T {
     BifRequest *h_reqs = nullptr;   // pinned [2*REQ_CAP]
     double *h_results = nullptr;    // pinned [2*REQ_CAP*6]
     int *h_req_count = nullptr;     // pinned [2]
-    HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};  // pinned mailbox of the persistent form
+    HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};  // pinned mailbox of the persistent form
     bool lockstep = false;          // OCTA_SIM_LOCKSTEP=1: two launches per iteration (the round-1 form)
     double mail_timeout_ms = 30000; // OCTA_SIM_MAIL_TIMEOUT_MS: device-side bound on one wait for the host when parking is off
     double park_ms = 20.0;          // OCTA_SIM_PARK_MS: a workgroup that has waited this long for its answer parks (0: never). Normal answers
                                     // take tens of microseconds; 3 ms (until the end of round 2) also parked workgroups whenever a busy host
                                     // descheduled the service thread for a few milliseconds, and a park costs a drain + relaunch
+    int last_ticket = 0;            // ticket of the last persistent-kernel launch of this simulator
     int grid_cap = 512;             // workgroups per launch of the persistent kernel (SIM_WG_PER_CU per CU; OCTA_SIM_GRID overrides)
     int test_stall_ms = 0;          // OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once with a ticket pending
     long spin_scans = 4096;         // idle mailbox scans before the service thread starts sleeping 20 us between scans
@@ -1089,12 +1101,19 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
             for (int s = 0; s < 3 * B + 1; s++) M.req_n[s] = 0;
             std::vector<int> seen(B, 0);
             OCTA_HIP_CHECK(hipMemsetAsync(P.next_sample, 0, sizeof(int), stream));
+            // this launch's ticket and its sign-in counter (csrc/sim_api.cpp): the counter of the launch before the previous one is reused
+            M.launch_flag = octa_sim_launch_flag(S->ctx->device);
+            M.ticket = (int)(octa_sim_next_ticket() & 0x3fffffff);
+            if (M.launch_flag) {
+                OCTA_HIP_CHECK(hipMemsetAsync(M.launch_flag + 1 + (M.ticket & 1), 0, sizeof(int), stream));
+                OCTA_HIP_CHECK(hipMemsetAsync(M.launch_flag + 3 + (M.ticket & 1), 0, sizeof(int), stream));
+            }
+            S->last_ticket = M.ticket;
             OCTA_HIP_CHECK(hipEventRecord(S->ev[0], stream));
             const int grid = B < S->grid_cap ? B : S->grid_cap;
             hipLaunchKernelGGL(sim_persistent_kernel, dim3((unsigned)grid), dim3(SIM_THREADS), SIM_LDS, stream, P, M);
             OCTA_HIP_CHECK(hipGetLastError());
             OCTA_HIP_CHECK(hipEventRecord(S->ev[1], stream));
-            octa_sim_note_launch();          // process-wide count of persistent-kernel launches (csrc/sim_api.cpp: octa_sim_launch_count)
             launches++;
             long idle = 0;
             auto last_progress = clk::now(), iter_start = last_progress;

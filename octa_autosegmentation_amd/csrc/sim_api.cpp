@@ -42,10 +42,32 @@ int octa_simS_kat_kd_order(octa_ctx *, const double *, int64_t, const uint8_t *,
 // and the next launch's 512 simulator workgroups otherwise race for the CUs the finished launch has just left -- when the rasteriser wins,
 // the whole rasterisation (45 ms per 512 triples) runs before the launch can place its workgroups: one launch in three measured 462
 // instead of 410 ms.
+//
+// Round 6: the order is kept ON THE DEVICE. Every launch takes a ticket (octa_sim_next_ticket) and its workgroups sign in on a small block
+// of device memory (octa_sim_launch_flag: [0] = highest ticket whose first workgroup has started, [1 + t % 2] = workgroups of ticket t that
+// have started, [3 + t % 2] = its grid size); a rasterisation that must come behind launch t is preceded, on its own stream, by a one-wave
+// gate kernel that leaves when launch t is resident (csrc/order.hip: octa_order_wait_launch). Round 5 polled octa_sim_launch_count from
+// Python and slept "to give the dispatcher time": two of two driver-command runs of that build sat in its slow mode.
 #include <atomic>
+#include <mutex>
 static std::atomic<long long> g_sim_launches{0};
-extern "C" void octa_sim_note_launch(void) { g_sim_launches.fetch_add(1, std::memory_order_release); }
+extern "C" long long octa_sim_next_ticket(void) { return g_sim_launches.fetch_add(1, std::memory_order_acq_rel) + 1; }
 extern "C" long long octa_sim_launch_count(void) { return g_sim_launches.load(std::memory_order_acquire); }
+extern "C" int *octa_sim_launch_flag(int device) {
+    static std::mutex m;
+    static int *flags[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(m);
+    if (!flags[device]) {
+        int prev = 0;
+        if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) return nullptr;
+        int *p = nullptr;
+        if (hipMalloc(&p, 64) != hipSuccess || hipMemset(p, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipSetDevice(prev); return nullptr; }
+        (void)hipSetDevice(prev);
+        flags[device] = p;
+    }
+    return flags[device];
+}
 
 struct octa_sim {
     bool large = false;

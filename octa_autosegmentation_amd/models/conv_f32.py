@@ -55,7 +55,9 @@ def supported(conv):
     if isinstance(conv, torch.nn.ConvTranspose2d):
         return k == s and k[0] in (1, 2) and p == (0, 0) and tuple(conv.output_padding) == (0, 0) and conv.bias is None
     if isinstance(conv, torch.nn.Conv2d):
-        return (k[0], s[0]) in ((1, 1), (3, 1), (3, 2)) and p[0] == k[0] // 2 and conv.padding_mode == "zeros"
+        # zero padding up to half the kernel: DynUNet's "same" layers, the GAN networks' 3x3 / 7x7 layers behind a reflection pad (padding 0)
+        # and PatchGAN's 4x4 layers with padding 1
+        return (k[0], s[0]) in ((1, 1), (3, 1), (3, 2), (4, 1), (7, 1)) and 0 <= p[0] <= k[0] // 2 and conv.padding_mode == "zeros"
     return False
 
 
@@ -87,7 +89,7 @@ def forward(conv, x):
                 _launch(x, wp, (a * k + b) * Cout, None, y, Cout, k * k * Cout, 1, 1, 0, H, W, k, a, b)
         return y
     K, s, Cout = conv.kernel_size[0], conv.stride[0], conv.out_channels
-    pad = K // 2
+    pad = conv.padding[0]
     Ho, Wo = (H + 2 * pad - K) // s + 1, (W + 2 * pad - K) // s + 1
     wp = _packed(conv.weight, False)
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None

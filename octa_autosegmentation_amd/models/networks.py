@@ -85,7 +85,7 @@ def _why_not_own_kernels(c, x):
     if x.dtype == torch.float32 and torch.is_grad_enabled() and (x.requires_grad or c.weight.requires_grad):
         return "fp32 pass that records gradients (the exact-fp32 MFMA kernels are forward-only; train with General.amp: true)"
     if x.dtype == torch.float32:
-        return "fp32 layer shape outside csrc/conv_f32.hip (kernel/stride 1/1, 3/1, 3/2, transposed 1/1, 2/2)"
+        return "fp32 layer shape outside csrc/conv_f32.hip (kernel/stride 1/1, 3/1, 3/2, 4/1, 7/1, transposed 1/1, 2/2)"
     return f"{x.dtype} modules path: the bf16 NHWC path did not apply ({_LAST_MFMA_REFUSAL[0] or 'not a bf16 / bf16-autocast pass'})"
 
 
@@ -393,6 +393,44 @@ class Upsample(nn.Module):
         return y if self.odd else y[:, :, :-1, :-1]
 
 
+def _f32_inference_applies(x):
+    """A plain fp32 CUDA forward that records no gradient and runs outside autocast: what test.py / validate.py and the frozen generator
+    of the data pipeline do in the reference (test.py:75-82, docker/dockershell.sh:14-16)."""
+    return (USE_MFMA_CONV and USE_F32_MFMA and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled()
+            and not torch.is_grad_enabled())
+
+
+def _run_f32(mods, x, who):
+    """The GAN networks' module lists in fp32 on own kernels (round 6): every convolution on the exact-fp32 MFMA kernel (csrc/conv_f32.hip:
+    1x1, 3x3, 4x4, 7x7, bias included), InstanceNorm2d(affine=False) fused with the ReLU / LeakyReLU behind it (csrc/norm.hip, fp32 NCHW),
+    reflection pads and anti-aliased resampling on csrc/blur.hip (their modules' own GPU path); residual sums, the first layer's LeakyReLU
+    and the Sigmoid are element-wise torch ops. No vendor-library kernel (MIOpen) runs."""
+    from . import conv_f32
+    from .fused_ops import instance_norm_leaky_relu
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, ResnetBlock):
+            x = x + _run_f32(list(m.conv_block), x, who)
+            i += 1
+        elif isinstance(m, nn.Conv2d):
+            if conv_f32.applies(m, x):
+                x = conv_f32.forward(m, x)
+            else:
+                _vendor_fallback(who, f"fp32 layer {i} ({m.kernel_size}, stride {m.stride}, padding {m.padding}) is outside csrc/conv_f32.hip")
+                x = m(x)
+            i += 1
+        elif isinstance(m, nn.InstanceNorm2d) and not m.affine and not m.track_running_stats:
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            slope = 0.0 if isinstance(nxt, nn.ReLU) else (float(nxt.negative_slope) if isinstance(nxt, nn.LeakyReLU) else None)
+            x = instance_norm_leaky_relu(x.contiguous(), None, None, 1.0 if slope is None else slope, m.eps)
+            i += 1 if slope is None else 2
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
 class ReflectionPad2d(nn.ReflectionPad2d):
     """nn.ReflectionPad2d whose GPU path is the gather kernels of csrc/blur.hip (torch's backward scatters with atomics)."""
 
@@ -462,8 +500,11 @@ class ResnetGenerator(nn.Module):
     def forward(self, x):
         use_mfma = (USE_MFMA_CONV and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
         if not use_mfma:
+            if _f32_inference_applies(x):
+                PATH_COUNTS['f32'] = PATH_COUNTS.get('f32', 0) + 1
+                return _run_f32(list(self.model), x, "ResnetGenerator")
             if x.is_cuda:
-                _vendor_fallback("ResnetGenerator", f"{x.dtype} pass without bf16 autocast (its HIP path is the bf16 one)")
+                _vendor_fallback("ResnetGenerator", f"{x.dtype} pass that is neither bf16 autocast nor gradient-free fp32 (the exact-fp32 MFMA kernels are forward-only)")
             return self.model(x)
         PATH_COUNTS['mfma'] += 1
         from . import mfma_conv as mc
@@ -538,8 +579,11 @@ class NLayerDiscriminator(nn.Module):
     def forward(self, x):
         use_mfma = (USE_MFMA_CONV and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
         if not use_mfma:
+            if _f32_inference_applies(x):
+                PATH_COUNTS['f32'] = PATH_COUNTS.get('f32', 0) + 1
+                return _run_f32(list(self.model), x, "NLayerDiscriminator")
             if x.is_cuda:
-                _vendor_fallback("NLayerDiscriminator", f"{x.dtype} pass without bf16 autocast (its HIP path is the bf16 one)")
+                _vendor_fallback("NLayerDiscriminator", f"{x.dtype} pass that is neither bf16 autocast nor gradient-free fp32 (the exact-fp32 MFMA kernels are forward-only)")
             return self.model(x)
         PATH_COUNTS['mfma'] += 1
         from . import mfma_conv as mc

@@ -16,6 +16,68 @@ from . import _native, graph_io
 from .vessel_graph_generation import greenhouse, tree2img
 
 
+class SimGate:
+    """The lock the generators of one device share so that ONE persistent kernel runs at a time, with what the device-side ordering needs:
+    how many threads are waiting for it (is a successor launch coming?) and the completion event of a rasterisation that went ahead without
+    one (the next launch is ordered behind it). Reentrant use is not supported."""
+
+    def __init__(self, timeout_us=50000, settle_us=200):
+        import threading
+        self._lock = threading.Lock()
+        self._meta = threading.Lock()
+        self._waiting = 0
+        self._holder = None
+        self._barrier = None
+        self.timeout_us, self.settle_us = int(timeout_us), int(settle_us)
+
+    def __enter__(self):
+        """Taken for a LAUNCH: counted as waiting while blocked."""
+        with self._meta:
+            self._waiting += 1
+        self._lock.acquire()
+        with self._meta:
+            self._waiting -= 1
+            self._holder = "launch"
+        return self
+
+    def __exit__(self, *exc):
+        self._holder = None
+        self._lock.release()
+        return False
+
+    def enter_for_render(self):
+        """Taken to enqueue a rasterisation that has no successor launch. Returns True with the gate held, or False when a LAUNCH holds it or
+        is waiting for it (that launch is the successor after all); waits only for another rasterisation's enqueue (milliseconds)."""
+        while True:
+            if self._lock.acquire(blocking=False):
+                with self._meta:
+                    if self._waiting > 0:              # a launch arrived first in spirit: let it have the gate
+                        self._lock.release()
+                        return False
+                    self._holder = "render"
+                return True
+            if self._holder != "render":
+                return False
+            import time
+            time.sleep(0.0002)                         # another slot is enqueueing its rasterisation with the gate held
+
+    def waiting(self):
+        with self._meta:
+            return self._waiting
+
+    def locked(self):
+        return self._lock.locked()
+
+    def set_barrier(self, event):
+        with self._meta:
+            self._barrier = event
+
+    def take_barrier(self):
+        with self._meta:
+            ev, self._barrier = self._barrier, None
+            return ev
+
+
 class TripleGenerator:
     def __init__(self, config, batch, device_index=None, label_resolution=(1216, 1216), label_min_radius=0.0, image_mode="cli",
                  image_min_radius=0.0):
@@ -48,61 +110,75 @@ class TripleGenerator:
                 _native.free_ctx(getattr(self, name))
                 setattr(self, name, None)
 
-    plan_ahead = False   # plan both rasterisations (octa_rasterize_2d_plan) right after the simulator call, draw later without host waits
-    sim_gate = None      # optional threading.Lock shared by the generators of a device (bench.py --serial-sim)
+    # plan both rasterisations (octa_rasterize_2d_plan: every host wait of the rasteriser) right after the simulator call, while the successor
+    # launch is still being prepared on the host and the GPU is free; what is enqueued behind the gate kernel is then never cut in two by a
+    # wait. Round 6 default: with the device-side ordering 1155 - 1162 against 1139 - 1151 samples/s (three alternating pairs on one box),
+    # enqueueing a launch's rasterisation takes 0.3 ms instead of 178 (profiles/r06_order_runs.log).
+    plan_ahead = True
+    sim_gate = None      # optional SimGate shared by the generators of a device (bench.py --serial-sim): ONE persistent kernel at a time
+
+    def prime(self, edges_per_sample=9600):
+        """One-time set-up of this generator's rasteriser (scratch growth -- 2.7 GB of polygon sides, 1.4 GB of row lists: hipMalloc + an
+        implicit device synchronisation each --, its output pool and the render kernels' code objects) on a synthetic edge list of a launch's
+        size: nothing is simulated. Callers that time launches (bench.py) prime every generator before the clock starts."""
+        import torch
+        n = self.batch
+        g = torch.Generator(device=self.device).manual_seed(1)
+        e = torch.rand((n * edges_per_sample, 7), device=self.device, dtype=torch.float64, generator=g)
+        e[:, 3:6] = e[:, 0:3] + (e[:, 3:6] - 0.5) * 0.03               # short segments
+        e[:, 6] = 0.002 + 0.004 * e[:, 6]
+        off = np.arange(n + 1, dtype=np.int64) * edges_per_sample
+        fake = type("Primer", (), {"d_edges": e, "edges": None, "edge_off": off, "n_art": np.full(n, edges_per_sample // 2, np.int64)})()
+        self._render(fake, True)
 
     def generate(self, seeds, want_label=True):
         """Returns dict(result=SimulationResult, image=uint8 CUDA [B,H,W], label=uint8 CUDA {0,255} [B,1216,1216])."""
         import time
+        import torch
         t0 = t_req = t_rel = time.time()
-        if self.sim_gate is not None:
-            # several generators in flight, ONE persistent kernel at a time: the next launch starts when this one has left the GPU,
-            # this launch's rasterisation then shares the GPU with it (and fills the tail of the launch before)
-            with self.sim_gate:
+        gate = self.sim_gate
+        if gate is not None:
+            # Several generators in flight, ONE persistent kernel at a time: the next launch starts when this one has left the GPU, and this
+            # launch's rasterisation then shares the GPU with it (it fills the tail of that launch). The ORDER of the two matters -- a
+            # rasterisation dispatched while the next launch's workgroups are being placed takes CUs it keeps, and the launch lasts two
+            # samples (DESIGN.md 5) -- and it is kept on the device (round 6; round 5 polled a launch counter and slept):
+            #   * a successor is waiting at the gate: this rasterisation's stream waits, in a one-wave gate kernel, until the successor's
+            #     launch (ticket + 1) is resident (csrc/order.hip); its render workgroups then get what finished samples leave;
+            #   * nobody is waiting: the GPU is free, the rasterisation goes at once -- with the gate held while it is enqueued, and the NEXT
+            #     launch, whoever makes it, is ordered behind this rasterisation's completion event on its own stream.
+            with gate:
                 t0 = time.time()
+                pending = gate.take_barrier()
+                if pending is not None:
+                    torch.cuda.current_stream().wait_event(pending)         # a rasterisation without successor went ahead of this launch
                 res = self.sim.run(seeds)
-                n_launch = _native.lib().octa_sim_launch_count()
+                ticket = _native.lib().octa_sim_launch_count()
+                successor = gate.waiting() > 0
             t_rel = time.time()
-            # plan_ahead: every host wait of the rasterisation happens HERE, while the next launch is still being prepared on the host
-            # (~9 ms) and the GPU is free; what is enqueued later (behind the next launch's workgroups) is then never cut in two by a
-            # wait. Measured neutral to slightly negative (DESIGN.md 5: 1114 against 1122 samples/s), hence not the default.
             plans = self._plan(res, want_label) if (self.plan_ahead and not self.time_render) else None
-            # The rasterisation of this batch must not race the NEXT launch for the CUs this launch has just left: a render workgroup
-            # takes a whole CU (145 KB of LDS), and when the rasteriser is placed first the next launch cannot start before the whole
-            # rasterisation is through (one launch in three: 462 instead of 410 ms). So: wait until the next launch is on the GPU -- its
-            # workgroups then hold every slot and the render workgroups get what finished samples leave --, or until none is coming.
-            t_w = time.time()
-            successor = True
-            while _native.lib().octa_sim_launch_count() == n_launch:
-                waited = time.time() - t_w
-                if waited > 0.002 and not self.sim_gate.locked():
-                    successor = False
-                    break
-                if waited > 0.05:          # somebody holds the gate and takes its time: do not wait for it any longer
-                    break
-                time.sleep(0.0002)
-            else:
-                time.sleep(0.0005)         # the launch call has returned: give the dispatcher the time to place the workgroups
             if not successor:
-                # Nobody is at the gate: the GPU is free and the rasterisation may as well run now -- but a launch must not ARRIVE while
-                # the render kernel is being dispatched: a render kernel that starts within a fraction of a millisecond of a persistent
-                # kernel keeps the CUs it got for its whole duration (its next workgroup takes the slot its last one leaves), the
-                # simulator workgroups without a slot wait for other SAMPLES to finish, and the launch lasts two samples (672 instead of
-                # 410 ms; the state then repeats launch after launch: the headline's slow mode, 1018 instead of 1130 samples/s,
-                # tools/exp_r05_slowmode.sh). With the gate held during the enqueue a launch comes either before the rasterisation
-                # (and is waited for above) or a few milliseconds after the render kernel has the GPU, which costs nothing measurable.
-                with self.sim_gate:
-                    if _native.lib().octa_sim_launch_count() == n_launch:
+                if gate.enter_for_render():
+                    try:
                         t1 = time.time()
                         out = self._render(res, want_label, plans)
-                        time.sleep(0.002)
-                        out["wall"] = {"t_start": t0, "sim_run_s": t1 - t0, "render_enqueue_s": time.time() - t1, "t_request": t_req, "t_released": t_rel}
-                        return out
-                time.sleep(0.0005)         # a launch slipped in between: it is resident now
-        else:
-            res = self.sim.run(seeds)
-            t_rel = time.time()
-            plans = self._plan(res, want_label) if (self.plan_ahead and not self.time_render) else None
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        gate.set_barrier(ev)
+                    finally:
+                        gate.__exit__()
+                else:
+                    successor = True                   # a launch took the gate (or stands at it) since this one released it: ticket + 1
+            if successor:
+                _native.check(_native.lib().octa_order_wait_launch(_native.ctx(self.device.index), ticket + 1, gate.timeout_us, gate.settle_us, None,
+                                                                   _native.current_stream_ptr()), "octa_order_wait_launch")
+                t1 = time.time()
+                out = self._render(res, want_label, plans)
+            out["wall"] = {"t_start": t0, "sim_run_s": t1 - t0, "render_enqueue_s": time.time() - t1, "t_request": t_req, "t_released": t_rel,
+                           "ordered_behind_successor": bool(successor)}
+            return out
+        res = self.sim.run(seeds)
+        t_rel = time.time()
+        plans = self._plan(res, want_label) if (self.plan_ahead and not self.time_render) else None
         t1 = time.time()
         out = self._render(res, want_label, plans)
         out["wall"] = {"t_start": t0, "sim_run_s": t1 - t0, "render_enqueue_s": time.time() - t1,      # host-side stamps (bench.py's slot accounting)

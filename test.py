@@ -50,11 +50,11 @@ def main(argv=None):
     model = define_model(config, phase=Phase.TEST)
     model.initialize_model_and_optimizer(None, init_weights, config, args, scaler, phase=Phase.TEST)
     model.eval()
-    # The reference's test.py evaluates in fp32 (no autocast, test.py:79). Segmentation networks do so here too: every DynUNet
-    # convolution runs the exact-fp32 MFMA kernel (csrc/conv_f32.hip; logits within 1e-4 of the CPU path, tests/test_conv_f32_gpu.py).
-    # The contrast-adaptation generator (`General.inference: G`) keeps bf16 autocast: its layers run on the bf16 MFMA kernels.
+    # The reference's test.py evaluates in fp32 (no autocast, test.py:79), and so does this one for every network: DynUNet's and -- since
+    # round 6 -- the contrast-adaptation generator's (`General.inference: G`) convolutions run the exact-fp32 MFMA kernels
+    # (csrc/conv_f32.hip; within 1e-4 of the CPU modules, tests/test_conv_f32_gpu.py, tests/test_networks_golden.py).
     import contextlib
-    precision = model.autocast if config["General"].get("inference") in ("G", "generator") else contextlib.nullcontext
+    precision = contextlib.nullcontext
     written = []
     with torch.no_grad():
         for num_sample, test_mini_batch in enumerate(test_loader):

@@ -88,7 +88,7 @@ def test_three_steps_in_flight_are_independent(hip_lib_built, gated):
     B, n_fly = 4, 3
     gens = [pipeline.TripleGenerator(cfg, B) for _ in range(n_fly)]
     if gated:
-        gate = threading.Lock()
+        gate = pipeline.SimGate()
         for gen in gens:
             gen.sim_gate = gate
             gen.plan_ahead = gated == "planned"
@@ -135,3 +135,45 @@ def test_on_the_fly_gan_seg_training_runs(hip_lib_built):
     import train_synthetic
     res = train_synthetic.run(steps=20, batch=2, gen_batch=16, warmup=1, log=False, gan=True)
     assert res["value"] > 0 and np.isfinite(res["first_loss"]) and np.isfinite(res["last_loss"]) and res["n_gpus"] == 1
+
+
+def test_order_gate_waits_for_a_launch_on_the_device_and_gives_up_at_its_timeout():
+    """csrc/order.hip: the one-wave gate kernel a rasterisation's stream waits in until the NEXT persistent-kernel launch is resident (round 6:
+    the order is kept on the device; round 5 polled a counter from Python and slept). A ticket that has been launched passes at once with its
+    workgroups signed in; a ticket nobody launches is given up after the timeout; a launch made WHILE the gate waits releases it."""
+    import threading
+    import time
+    import torch
+    from octa_autosegmentation_amd import _native
+    from octa_autosegmentation_amd.vessel_graph_generation import greenhouse
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_golden.npz"))
+    cfg = yaml.safe_load(str(g["config_yaml"]))
+    cfg["Greenhouse"]["modes"][0]["I"] = 6
+    cfg["Greenhouse"]["modes"][1]["I"] = 3
+    lib, ctx = _native.lib(), _native.ctx(0)
+    sim = greenhouse.BatchSimulator(cfg, 8, 0)
+    out = torch.zeros(3, dtype=torch.int32, device="cuda")
+    wait = lambda ticket, timeout_us, st: _native.check(lib.octa_order_wait_launch(ctx, ticket, timeout_us, 100, out.data_ptr(), st.cuda_stream), "octa_order_wait_launch")
+    try:
+        sim.run(np.arange(8) + 11)
+        t_mine = lib.octa_sim_launch_count()
+        st = torch.cuda.Stream()
+        wait(t_mine, 2_000_000, st)                         # already launched (and over): passes at once, all 8 workgroups had signed in
+        st.synchronize()
+        state, ticks, signed = out.cpu().tolist()
+        assert state == 1 and signed == 8 and ticks < 100_000, (state, ticks, signed)
+        t0 = time.time()
+        wait(t_mine + 1, 30_000, st)                        # nobody launches ticket + 1: given up after 30 ms
+        st.synchronize()
+        state, ticks, _ = out.cpu().tolist()
+        assert state == 2 and 2_500_000 <= ticks <= 5_000_000 and time.time() - t0 < 1.0, (state, ticks)
+        wait(t_mine + 1, 5_000_000, st)                     # ... and a launch made while the gate waits releases it
+        th = threading.Thread(target=lambda: (time.sleep(0.05), torch.cuda.set_device(0), sim.run(np.arange(8) + 19)))
+        th.start()
+        st.synchronize()
+        th.join()
+        state, ticks, signed = out.cpu().tolist()
+        assert state == 1 and signed >= 6 and 3_000_000 <= ticks <= 200_000_000, (state, ticks, signed)
+        assert lib.octa_sim_launch_count() == t_mine + 1
+    finally:
+        sim.close()

@@ -25,7 +25,7 @@ def main():
     B, G, n_fly = 128, args.group, args.inflight
     gens = [pipeline.TripleGenerator(cfg, B * G) for _ in range(n_fly)]
     streams = [torch.cuda.Stream() for _ in range(n_fly)]
-    gate = threading.Lock()
+    gate = pipeline.SimGate()
     for g in gens:
         g.sim_gate = gate
 
