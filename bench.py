@@ -367,8 +367,8 @@ def unet_train_bench(dev, batch, dist, world, steps=20, warmup=4, with_allreduce
             "implementation": "channels-last bf16 on hand-written HIP kernels: MFMA 3x3 conv forward / data gradient / weight "
                               "gradient (csrc/conv.hip; skip-connection gradients in the data-gradient epilogue), NHWC InstanceNorm+LeakyReLU "
                               "(csrc/norm.hip; the last one fused with the 1x1 output convolution), one-launch weight packing; the 1x1 transposed "
-                              "convolution at the bottleneck on the same MFMA kernels with a one-tap mask (round 4: no vendor-library kernel in the step; "
-                              "OCTA_CONVT1X1=blas is the hipBLASLt route, 1.4 % faster); flat RCCL gradient all-reduce"}
+                              "convolution at the bottleneck on the same MFMA kernels with a one-tap mask (round 4: no vendor-library kernel in the step); "
+                              "flat RCCL gradient all-reduce"}
 
 
 def files_leg(gen, stream, seeds, threads=None):
@@ -576,8 +576,6 @@ def main():
     sizes = sorted({G} | ({args.warmup % G} if args.warmup % G else set()) | ({args.steps % G} if args.steps % G else set()))
     gens = {g: [pipeline.TripleGenerator(cfg, B * g) for _ in range(n_fly)] for g in sizes}
     streams = [torch.cuda.Stream() for _ in range(n_fly)]
-    if os.environ.get("OCTA_BENCH_PLAN_AHEAD") in ("0", "1"):            # A/B aid; the class default is the planned form since round 6
-        pipeline.TripleGenerator.plan_ahead = os.environ["OCTA_BENCH_PLAN_AHEAD"] == "1"
     if args.serial_sim and n_fly > 1:
         gate = pipeline.SimGate()
         for gl in gens.values():

@@ -119,7 +119,7 @@ def main(argv=None):
     # pipeline.SimGate per device, a launch's rasterisation on the GPU together with the NEXT launch's kernel, their order kept on the device
     # (csrc/order.hip). Smaller batches keep the slot gate: their whole generate() call holds its share of the GPU.
     sim_gates = {d: pipeline.SimGate() for d in set(devices)}
-    use_sim_gate = os.environ.get("OCTA_CLI_SIM_GATE", "1") == "1"
+    use_sim_gate = True
 
     def generate_batches(dev):
         gens = {}

@@ -864,7 +864,7 @@ int conv3x3_fwd_impl(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, c
     unsigned short *Y = static_cast<unsigned short *>(d_y), *Y2 = static_cast<unsigned short *>(d_y2);
     const bool wide = (Cout % 64 == 0) && (CY1 % 64 == 0);   // a 64-channel block must not straddle the output split
     // plain stride-1 layers: the DMA-staged kernel (OCTA_CONV_GLDS=0 selects the register-staged one, =16 (default) / =32 the slice depth)
-    static const int glds_mode = [] { const char *e = getenv("OCTA_CONV_GLDS"); return e ? atoi(e) : 16; }();
+    constexpr int glds_mode = 16;        // DMA-staged kernels with 16-channel slices (rounds 3-5 A/B'd 0 / 16 / 32 through OCTA_CONV_GLDS; 16 ships)
     if (glds_mode && !d_scale1 && !d_scale2) {
         const unsigned short *z = zero_page(ctx);
         if (!z) return -1;
@@ -874,7 +874,7 @@ int conv3x3_fwd_impl(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1, c
         // 16-row tiles (a wave owns four tile rows: 6 operand reads per 8 MFMAs instead of 4 per 4, 72 MFMAs per barrier) from
         // 200 output rows up: 8-14 % faster on the 304^2 / 608^2 layers (256->128 at 304^2: 1.0 PFLOP/s), no gain at 152^2
         // (half as many workgroups: tail effects) and on the HBM-bound 1216^2 layers. OCTA_CONV_TALL=0 disables.
-        static const int tall = [] { const char *e = getenv("OCTA_CONV_TALL"); return e ? atoi(e) : 200; }();
+        constexpr int tall = 200;
         if (glds_mode == 16 && tall && wide && stride == 1 && tap_mask == 0x1ff && out_scale == 1 && Ho >= tall)
             return launch_conv_glds<64, 16, 1, 3, 16>(X, X2, C1, Wt, Y, Y2, CY1, N, H, W, Cin, Ho, Wo, Cout, in_dilation, z, d_stat_partials, tap_mask, 1, 0, 0, stream, 1, Rz, 0, nslot);
         if (glds_mode == 16)
@@ -1564,7 +1564,7 @@ int launch_wgrad_tr(octa_ctx *ctx, const unsigned short *X, const unsigned short
     // 0.130 -> 0.119 ms, 304^2 128->128 0.133 -> 0.130); with more workgroups per block the reduction's per-thread loop over the partials
     // costs more than the atomics (1216^2 32->32, 512 workgroups: 0.238 against 0.201 ms), with fewer there is little contention.
     // (Measured with the atomics removed altogether: 0.188 / 0.112 / 0.408 ms for 1216^2 32->32 / 152^2 256->256 / 512->512.)
-    static const int ws_from = [] { const char *e = getenv("OCTA_WGRAD_WS"); return e ? atoi(e) : 16; }();
+    constexpr int ws_from = 16;
     float *ws = nullptr;
     if (acc || (ws_from > 0 && per_block >= ws_from && per_block <= 64)) {      // acc: always through the workspace (wgrad_tr_acc_kernel folds it)
         if (ctx->wgrad_ws.reserve((size_t)blocks * per_block * PAIRS_ * 9 * 32 * 32 * sizeof(float))) return -1;
@@ -1644,7 +1644,7 @@ static int wgrad4_impl(octa_ctx *ctx, const void *d_x, const void *d_x2, int C1,
     const unsigned short *z = zero_page(ctx);
     if (!z) return -1;
     const bool co64 = Cout % 64 == 0, ci64 = Cin % 64 == 0 && C1 % 64 == 0;   // a 64-channel block must not straddle the split
-    static const int use_tr = [] { const char *e = getenv("OCTA_WGRAD_TR"); return e ? atoi(e) : 2; }();
+    constexpr int use_tr = 2;           // transposing-read weight-gradient kernels at stride 1 and 2 (the round-3/4 switch OCTA_WGRAD_TR is gone)
     if (use_tr && !d_scale1 && !d_scale2 && (stride == 1 || (stride == 2 && H % 2 == 0 && W % 2 == 0))) {
         // raw tiles + transposing reads (see conv3x3_nhwc_wgrad_tr_kernel); OCTA_WGRAD_TR=1: stride 1 only, =2 (default): stride 2 as well
         if (stride == 1) {

@@ -523,7 +523,7 @@ int nhwc_splits(const octa_ctx *ctx, int B, long hw) {
     // residual stages ran on 11 x B workgroups, 17 % of the CUs at B = 4; GAN-seg step 56.8 -> 55.4 ms, U-Net step unchanged;
     // profiles/r04_norm_min_pixels.log). For the planes of these networks the bound, not the batch size, decides the split count at
     // B <= 4, so an image's partial sums are formed alike alone and in a batch (tests/test_training_cli_gpu.py compares the two).
-    static const long min_px_env = [] { const char *e = getenv("OCTA_NORM_MIN_PIXELS"); return e ? atol(e) : 0L; }();
+    constexpr long min_px_env = 0L;
     const long min_px = min_px_env > 0 ? min_px_env : (hw < 65536 ? 128 : 512);
     const long by_size = hw / min_px > 0 ? hw / min_px : 1;
     if (s > by_size) s = by_size;

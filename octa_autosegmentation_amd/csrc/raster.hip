@@ -1120,7 +1120,7 @@ extern "C" int octa_rasterize_2d_plan(octa_ctx *ctx, int B, const double *d_edge
     // edges per row of super-tiles (u16 indices inside a graph): every graph must have fewer than 65 536 edges, and one row must be worth it
     bool rowbin = false;
     {
-        static const bool rowbin_on = [] { const char *e = getenv("OCTA_RASTER_ROWBIN"); return !(e && e[0] == '0'); }();
+        constexpr bool rowbin_on = true;
         long max_graph = 0;
         for (int b = 0; b < B; b++) max_graph = std::max<long>(max_graph, (long)(h_edge_off[b + 1] - h_edge_off[b]));
         if (rowbin_on && n_total > 0 && tiles_y > 1 && max_graph < 65536) {
@@ -1191,7 +1191,7 @@ extern "C" int octa_fs_dither(octa_ctx *ctx, int B, const uint8_t *d_in, int W, 
             const int nw = n_bands < 16 ? n_bands : 16;
             // OCTA_DITHER_BURST = 16 | 32 | 64 pixels per store burst (development aid). Measured per 128 labels at 1216^2 (profiles/r05_raster_pmc.log):
             // 16: 488 MB written, 1.94 ms; 32: 306 MB, 1.98 ms; 64: 227 MB, 2.14 ms (the shift queue); 4 (round 4): 613 MB. Default 32.
-            static const int burst = [] { const char *e = getenv("OCTA_DITHER_BURST"); const int v = e ? atoi(e) : 32; return v == 64 || v == 16 ? v : 32; }();
+            constexpr int burst = 32;      // pixels per store burst (16 / 32 / 64 measured in round 5: 32 ships)
             auto kern = burst == 64 ? fs_dither_pipe_kernel<16> : (burst == 32 ? fs_dither_pipe_kernel<8> : fs_dither_pipe_kernel<4>);
             OCTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe));
             hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64 * nw), lds_pipe, stream, d_in, W, H, n_bands, d_out);

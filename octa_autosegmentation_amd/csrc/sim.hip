@@ -965,7 +965,7 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
         std::vector<unsigned> vcount(B);
         const int n0 = 2 * S->cfg.n_trees;
         std::vector<double> npos((size_t)B * 2 * n0 * 3);
-        static const bool time_init = getenv("OCTA_SIM_TIME_INIT") != nullptr;
+        constexpr bool time_init = false;      // development aid: host-init timing on stderr
         const auto t_init0 = std::chrono::steady_clock::now();
         // the samples are independent: a few host threads share them (round 5: 5.6 of the 6.9 ms this block takes for 512 samples were this
         // loop on one core, and the block sits between two persistent kernels of the pipeline). OCTA_SIM_INIT_THREADS overrides.

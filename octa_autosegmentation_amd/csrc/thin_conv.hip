@@ -508,7 +508,7 @@ extern "C" int octa_thinconv_squeeze(octa_ctx *ctx, const void *d_a, const void 
     const size_t lds = (size_t)C * (K * K + 1) * sizeof(float);
     if (lds > 64 * 1024) { octa::set_error("octa_thinconv_squeeze: %d x %d weights of %d channels do not fit the LDS", K, K, C); return -2; }
     // wide form: a thread per 8 channels of 4 output pixels (OCTA_THIN_WIDE=0: the lane-per-channel kernels of rounds 1-4)
-    static const int wide = [] { const char *e = getenv("OCTA_THIN_WIDE"); return e ? atoi(e) : 1; }();
+    constexpr int wide = 1;
     const int groups = C / 8;
     if (wide && C % 8 == 0 && groups <= 64 && (groups & (groups - 1)) == 0 && (size_t)C * K * K * sizeof(float) <= 64 * 1024) {
         const size_t wlds = (size_t)C * K * K * sizeof(float);
@@ -552,7 +552,7 @@ extern "C" int octa_thinconv_wgrad(octa_ctx *ctx, const void *d_a, const void *d
     unsigned blocks = (unsigned)(((long long)N * Ha + WG_ROWS - 1) / WG_ROWS);
     const size_t lds = (size_t)K * (Wa + K - 1 + 2 * K) * sizeof(float);
     if (lds > 60 * 1024) { octa::set_error("octa_thinconv_wgrad: rows of %d pixels do not fit the LDS window", Wa); return -2; }
-    static const int wide = [] { const char *e = getenv("OCTA_THIN_WIDE"); return e ? atoi(e) : 1; }();
+    constexpr int wide = 1;
     const int groups = C / 8;
     const int total = C * (K * K + 1);
     if (wide && groups <= 64 && (groups & (groups - 1)) == 0) {

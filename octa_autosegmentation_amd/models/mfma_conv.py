@@ -28,12 +28,12 @@ def _pad32(c):
 # (Measured and removed in round 5: the same scope running the weight-gradient launches on a SIDE STREAM beside the data-gradient / norm
 # chain -- U-Net step 19.3 against 19.0 ms at B = 4, 38.7 against 35.5 at B = 8, profiles/r05_stream_overlap_ab.log: every kernel of the
 # step fills the GPU on its own, co-resident workgroups only evict each other's lines.)
-USE_DIRECT_WGRAD = os.environ.get("OCTA_DIRECT_WGRAD", "1") != "0"
+USE_DIRECT_WGRAD = True         # module switch (tests / tools may clear it): every gradient then returns through autograd
 # set by direct_weight_grads(); read by the autograd ENGINE's thread (not the caller's: a thread-local would never be seen there), hence
 # process-wide -- and hence one backward scope at a time: a second thread entering while one is open is refused (its backward would get
 # None for its weight gradients and find them written into .grad), torch.autograd.grad / .backward() outside a scope are unaffected
 _WG_ACTIVE = {"on": False, "owner": None}
-_WGRAD_TR = int(os.environ.get("OCTA_WGRAD_TR", "2"))     # the C side's selection of the transposing-read kernels (conv.hip): only they write into .grad
+_WGRAD_TR = 2                   # the C side runs the transposing-read kernels at stride 1 and 2 (csrc/conv.hip use_tr): only they write into .grad
 DIRECT_WGRAD_COUNTS = [0, 0]    # weight gradients accumulated in place / returned to autograd
 
 
@@ -50,7 +50,7 @@ class direct_weight_grads:
         if self.on:
             if _WG_ACTIVE["on"] and _WG_ACTIVE["owner"] not in (None, me):
                 raise RuntimeError("direct_weight_grads(): another thread is inside a backward scope; the in-place weight gradients need one backward at a time "
-                                   "(OCTA_DIRECT_WGRAD=0 returns every gradient through autograd)")
+                                   "(mfma_conv.USE_DIRECT_WGRAD = False returns every gradient through autograd)")
             _WG_ACTIVE["on"], _WG_ACTIVE["owner"] = True, me
         return self
 
@@ -265,7 +265,7 @@ def conv3x3_nhwc(x, wt, stride=1, in_dilation=1, tap_mask=0x1ff, residual=None):
 
 # The parity-fused kernel for the two layers that double the image (round 5, csrc/conv.hip conv3x3_s2t_kernel). OCTA_S2T=0 keeps the
 # zero-insertion form of rounds 1-4 (the stride-1 kernel on a virtually dilated input: 4 x the multiply-adds).
-USE_S2T = os.environ.get("OCTA_S2T", "1") != "0"
+USE_S2T = True
 
 
 def conv3x3_s2t_nhwc(x, wt, tap_mask=0x1ff, residual=None):
@@ -298,7 +298,7 @@ def conv3x3_nhwc_wgrad(x, dy, tap_mask=0x1ff):
     return dw.view(3, 3, cout, cin).permute(2, 3, 0, 1)
 
 
-STAT_SLOTS = int(os.environ.get("OCTA_STAT_SLOTS", "16"))      # slots the tiles of an image spread their statistics atomics over
+STAT_SLOTS = 16      # slots the tiles of an image spread their statistics atomics over
 _STAT_RINGS = {}
 _STAT_LOCK = __import__("threading").Lock()                  # two threads running forwards on one stream must not be handed overlapping slices
 
@@ -432,7 +432,7 @@ def _pad_channels(x, mult=32):
 
 # A/B switch (development aid). The residual epilogue exists in the DMA-staged kernel only: with OCTA_CONV_GLDS=0 (the
 # register-staged kernel) the mailbox is never armed and autograd adds the two skip gradients itself.
-USE_SKIP_GRAD_FUSION = os.environ.get("OCTA_SKIP_FUSION", "1") != "0" and os.environ.get("OCTA_CONV_GLDS", "16") != "0"
+USE_SKIP_GRAD_FUSION = True
 
 
 class SkipGradMailbox:
@@ -572,7 +572,7 @@ class _Conv3x3ReflectNHWC(torch.autograd.Function):
         return dx, dw, None
 
 
-USE_FUSED_REFLECT = os.environ.get("OCTA_FUSED_REFLECT", "1") != "0"     # A/B switch (development aid)
+USE_FUSED_REFLECT = True     # module switch (development aid)
 
 
 def conv3x3_reflect(x, weight, want_stats=False):
@@ -585,7 +585,7 @@ def conv3x3_reflect(x, weight, want_stats=False):
     return (y, None) if want_stats else y
 
 
-USE_C1_DGRAD = os.environ.get("OCTA_C1_DGRAD", "1") != "0"      # A/B switch of the one-channel layer's streaming data gradient (round 5)
+USE_C1_DGRAD = True      # module switch: the one-channel layer's streaming data gradient (round 5)
 
 
 class _Conv3x3C1(torch.autograd.Function):
@@ -820,10 +820,10 @@ class _ConvT2x2NHWC(torch.autograd.Function):
         return dx, dw
 
 
-# The 1x1 "transposed" layer at the U-Net's bottleneck (512 -> 256 at 152^2). OCTA_CONVT1X1=blas keeps round 3's route (forward and
-# data gradient as hipBLASLt GEMMs through torch, the weight gradient as a hand-split batched GEMM); the default since round 4 is the
-# repository's own MFMA convolution with only the centre tap unmasked -- no vendor kernel is left in the training step.
-USE_BLAS_CONVT1X1 = os.environ.get("OCTA_CONVT1X1", "mfma") == "blas"
+# The 1x1 "transposed" layer at the U-Net's bottleneck (512 -> 256 at 152^2) runs the repository's own MFMA convolution with only the centre
+# tap unmasked: no vendor kernel is left in the training step. (Round 3's route through hipBLASLt -- plain GEMMs through torch, the weight
+# gradient split by hand into batched products; 1.4 % faster on the whole step -- left the product in round 6: tools/micro/try_bmm_splitk.py
+# keeps the measurement.)
 
 
 def _t1x1_packs(weight):
@@ -848,9 +848,7 @@ def _t1x1_packs(weight):
 
 class _ConvT1x1NHWC(torch.autograd.Function):
     """ConvTranspose2d(kernel 1, stride 1, no bias) = a 1x1 convolution with the transposed weight: the MFMA 3x3 kernels with the
-    tap mask 0b000010000 (forward, data gradient on the swapped weight, weight gradient), csrc/conv.hip. OCTA_CONVT1X1=blas: plain
-    GEMMs through torch (hipBLASLt: 470-580 TFLOP/s on 512 -> 256 at 152^2) and the weight gradient -- a [Cin x Cout] product over
-    K = N*H*W = 92 416 pixels that hipBLASLt runs as 16 workgroups without split-K -- split by hand into 32 batched products."""
+    tap mask 0b000010000 (forward, data gradient on the swapped weight, weight gradient), csrc/conv.hip."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -858,13 +856,9 @@ class _ConvT1x1NHWC(torch.autograd.Function):
         n, h, w, cin = x.shape
         cout = weight.shape[1]
         ctx.w_shape, ctx.w_dtype = weight.shape, weight.dtype
-        if not USE_BLAS_CONVT1X1:
-            fwd, dg = _t1x1_packs(weight)
-            ctx.save_for_backward(x, dg)
-            return conv3x3_nhwc(x, fwd, tap_mask=1 << 4)
-        wm = weight.reshape(cin, cout).to(torch.bfloat16)
-        ctx.save_for_backward(x, wm)
-        return torch.matmul(x.reshape(n * h * w, cin), wm).view(n, h, w, cout)
+        fwd, dg = _t1x1_packs(weight)
+        ctx.save_for_backward(x, dg)
+        return conv3x3_nhwc(x, fwd, tap_mask=1 << 4)
 
     @staticmethod
     def backward(ctx, dy):
@@ -875,26 +869,11 @@ class _ConvT1x1NHWC(torch.autograd.Function):
         n, h, w, cin = x.shape
         cout = dy.shape[3]
         dx = dw = None
-        if not USE_BLAS_CONVT1X1:
-            if ctx.needs_input_grad[0]:
-                dx = conv3x3_nhwc(dy, wm, tap_mask=1 << 4)          # wm: the data-gradient pack [9][Cin][Cout]
-            if ctx.needs_input_grad[1]:
-                # as a convolution weight [Cout_conv = cout][Cin_conv = cin][3][3] with only tap (1, 1): dW[co][ci] = sum_p dy[p][co] x[p][ci]
-                dw = conv3x3_nhwc_wgrad(x, dy, tap_mask=1 << 4)[:, :, 1, 1].t().reshape(ctx.w_shape).to(ctx.w_dtype)
-            return dx, dw
         if ctx.needs_input_grad[0]:
-            dx = torch.matmul(dy.reshape(n * h * w, cout), wm.t()).view(n, h, w, cin)
+            dx = conv3x3_nhwc(dy, wm, tap_mask=1 << 4)          # wm: the data-gradient pack [9][Cin][Cout]
         if ctx.needs_input_grad[1]:
-            m = n * h * w
-            split = next((s_ for s_ in (32, 16, 8, 4) if m % s_ == 0 and m // s_ >= 512), 0)
-            if split:
-                # split-K by hand: S independent [Cin x m/S] x [m/S x Cout] products with fp32 results (hipBLASLt batched GEMM,
-                # S x 8 workgroups instead of 16), summed in fp32: 0.055 ms against 0.30 (one GEMM) / 0.27 (tap-masked MFMA kernel)
-                dw = torch.bmm(x.reshape(split, m // split, cin).transpose(1, 2), dy.reshape(split, m // split, cout),
-                               out_dtype=torch.float32).sum(0)
-            else:
-                dw = conv3x3_nhwc_wgrad(x, dy, tap_mask=1 << 4)[:, :, 1, 1].t()
-            dw = dw.reshape(ctx.w_shape).to(ctx.w_dtype)
+            # as a convolution weight [Cout_conv = cout][Cin_conv = cin][3][3] with only tap (1, 1): dW[co][ci] = sum_p dy[p][co] x[p][ci]
+            dw = conv3x3_nhwc_wgrad(x, dy, tap_mask=1 << 4)[:, :, 1, 1].t().reshape(ctx.w_shape).to(ctx.w_dtype)
         return dx, dw
 
 
@@ -1009,7 +988,7 @@ class _InstNormLReLUHead1NHWC(torch.autograd.Function):
                 dhw.view(hw_shape).to(hw_dtype), dhb.to(hw_dtype) if has_hb else None, None)
 
 
-USE_FUSED_NORM_HEAD = os.environ.get("OCTA_FUSED_HEAD", "1") != "0"     # A/B switch (development aid)
+USE_FUSED_NORM_HEAD = True     # module switch (development aid)
 
 
 def norm_lrelu_head1_ok(c, head_weight):

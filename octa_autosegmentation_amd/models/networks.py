@@ -29,14 +29,14 @@ USE_F32_MFMA = True      # fp32 forward passes that record no gradient run csrc/
 # normalise-on-load (the normalised activations never go to HBM: models/mfma_conv.py) is implemented and tested but
 # measured SLOWER on MI355X (37.5 vs 31.9 ms per step): every output-channel block of a layer re-stages and
 # re-normalises the same input tile, which costs more VALU work than the two HBM passes it saves
-USE_LAZY_NORM = __import__('os').environ.get('OCTA_LAZY_NORM', '0') == '1'      # re-measured in round 4 on the DMA-staged kernels: DESIGN.md 4.2c
+USE_LAZY_NORM = False      # module switch (tests set it): normalise-on-load, re-measured in rounds 4 and 5 on the DMA-staged kernels and slower
 # InstanceNorm statistics accumulated in the convolution's epilogue instead of a statistics pass over the stored tensor. Rounds 1-4: per-tile
 # partials + a fold launch (conv.hip _fwd5), measured slower every time (33.6 vs 32.1, 20.0 vs 18.4 ms). Round 5: slot form (conv.hip
 # octa_conv3x3_nhwc_fwd7 -- the sums ride in the bf16 conversion loop as v_dot2c_f32_bf16, the waves meet behind the output tile in LDS under
 # the barrier the tile needs anyway, one pair of double atomics per channel and tile into 16 slots; the apply pass adds the slots): same box,
-# B = 4 at 1216^2: 18.7 -> 18.5 ms per step (profiles/r05_unet_epilogue_stats_ab.log). Default ON; OCTA_EPI_STATS=0 runs the statistics pass.
+# B = 4 at 1216^2: 18.7 -> 18.5 ms per step (profiles/r05_unet_epilogue_stats_ab.log). Default ON; networks.USE_EPILOGUE_STATS = False runs the statistics pass.
 import os as _os
-USE_EPILOGUE_STATS = _os.environ.get('OCTA_EPI_STATS', '1') != '0' and _os.environ.get('OCTA_CONV_GLDS', '16') != '0'      # the slots live in the DMA-staged kernel's epilogue
+USE_EPILOGUE_STATS = True      # module switch; the slots live in the DMA-staged kernel's epilogue
 
 # ---- which kernels ran ------------------------------------------------------------------------------------------------
 # The product path of a CUDA forward is the hand-written HIP kernels (csrc/conv.hip, conv_f32.hip, norm.hip, thin_conv.hip,

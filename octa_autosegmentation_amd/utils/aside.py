@@ -4,7 +4,7 @@ The post-transform of the scored sample (sigmoid, threshold, component labelling
 metric counts (utils/metrics.py) are ~35 short kernels that nothing in the step depends on; on the training stream they sit between
 forward and backward (0.3 ms of an 18 ms DynUNet-S step). `aside(device, *tensors)` runs its body on a per-device side stream that
 first waits for what the current stream has queued so far; `join_aside(device)` makes the current stream wait for the side stream
-(before scores or plotted samples are read; `Metric.aggregate` does it for the scores). OCTA_ASIDE=0 keeps everything on one stream.
+(before scores or plotted samples are read; `Metric.aggregate` does it for the scores). aside.ENABLED = False keeps everything on one stream.
 
 The side stream has its OWN octa_ctx (round 4): a context's grow-only scratch (common.h: one context is used by one stream at a time) is
 shared by the rasteriser and the component filter of the post-transform, and with an inline loader (`train.py --num_workers 0`) the
@@ -14,13 +14,14 @@ import os
 
 import torch
 
+ENABLED = True       # module switch: False keeps the scored sample's post-transform and metric kernels on the training stream
 _ASIDE = {}
 _ASIDE_CTX = {}
 
 
 def _aside_stream(device):
     device = torch.device(device)
-    if device.type != "cuda" or os.environ.get("OCTA_ASIDE", "1") == "0":
+    if device.type != "cuda" or not ENABLED:
         return None
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _ASIDE:

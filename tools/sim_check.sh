@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: the regular build after a simulator change: phase times at full occupancy, 2 x 512 oracle digests, (optionally) the simulator's -m gpu tests and a repro run
-# usage: tools/exp_r06_check.sh TAG [tests] [repro_reps]
+# usage: tools/sim_check.sh TAG [tests] [repro_reps]
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
 export PYTHONUNBUFFERED=1
 TAG=${1:-cur}

@@ -74,9 +74,6 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
     dev = torch.device("cuda", torch.cuda.current_device())
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend="nccl", device_id=dev)
-    if os.environ.get("OCTA_E2E_TORCH"):                                   # development aid: torch modules instead of the MFMA path
-        from octa_autosegmentation_amd.models import networks as _nw
-        _nw.USE_MFMA_CONV = False
     if gan:
         # BASELINE configs[4] proper: the on-the-fly stream feeds the joint GAN contrast-adaptation + segmentation step
         # (configs/config_gan_ves_seg.yml; graph loader with min_radius [0, 0]). real_B (real OCTA scans) and the background
@@ -103,21 +100,16 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
             torch.cuda.set_device(dev)
             i = 0
             with torch.cuda.stream(gen_stream):
-                limit = int(os.environ.get("OCTA_E2E_GEN_LIMIT", "0"))      # development aid: stop generating after N batches
                 out = None
                 while not stop.is_set():
-                    if not limit or i < limit:
-                        if i > 0:
-                            turns.ask(stop)                                 # the trainer steps aside at its next step boundary (see `turns` below)
-                        try:
-                            out = gen.generate(sharding.rank_seeds(rank, i, gen_batch, base=seed0))
-                        finally:
-                            turns.hand_back()
+                    if i > 0:
+                        turns.ask(stop)                                     # the trainer steps aside at its next step boundary (see `turns` below)
+                    try:
+                        out = gen.generate(sharding.rank_seeds(rank, i, gen_batch, base=seed0))
+                    finally:
+                        turns.hand_back()
                     ready = torch.cuda.Event()
                     ready.record(gen_stream)
-                    if os.environ.get("OCTA_E2E_DEBUG"):
-                        gen_stream.synchronize()
-                        print(f"   generator batch {i} done t={time.time():.2f}", file=sys.stderr, flush=True)
                     item = (out["image"], out["label_grey"], ready)
                     while not stop.is_set():
                         try:
@@ -182,9 +174,6 @@ def run(steps, batch, gen_batch, seed0=0, warmup=3, log=True, gan=False):
                 images.record_stream(cur)
                 labels.record_stream(cur)
                 pos = 0
-            if os.environ.get("OCTA_E2E_DEBUG"):
-                torch.cuda.synchronize()
-                print(f"step {step} t={time.time():.2f} pos={pos}", file=sys.stderr, flush=True)
             mb = aug(images[pos:pos + batch].contiguous(), labels[pos:pos + batch].contiguous())
             pos += batch
             if gan:
