@@ -146,35 +146,43 @@ class TripleGenerator:
             #     launch (ticket + 1) is resident (csrc/order.hip); its render workgroups then get what finished samples leave;
             #   * nobody is waiting: the GPU is free, the rasterisation goes at once -- with the gate held while it is enqueued, and the NEXT
             #     launch, whoever makes it, is ordered behind this rasterisation's completion event on its own stream.
+            # The launch and the rasterisation run on two streams this generator owns, of DIFFERENT queue priority: the runtime keeps a pool
+            # of hardware queues per priority, so the spinning gate kernel can never sit in front of the launch it waits for in one hardware
+            # queue (two streams of equal priority may share one: measured as a 5 s gate time-out in the full test suite), and the
+            # dispatcher prefers the simulator's workgroups when both kinds are pending.
+            if self._gated_streams is None:
+                self._gated_streams = (torch.cuda.Stream(device=self.device, priority=-1), torch.cuda.Stream(device=self.device, priority=0))
+            sim_stream, render_stream = self._gated_streams
+            caller = torch.cuda.current_stream()
+            entered = torch.cuda.Event()
+            entered.record(caller)
             with gate:
                 t0 = time.time()
-                pending = gate.take_barrier()
-                if pending is not None:
-                    torch.cuda.current_stream().wait_event(pending)         # a rasterisation without successor went ahead of this launch
-                res = self.sim.run(seeds)
+                with torch.cuda.stream(sim_stream):
+                    sim_stream.wait_event(entered)                          # what the caller enqueued before this call
+                    pending = gate.take_barrier()
+                    if pending is not None:
+                        sim_stream.wait_event(pending)                      # a rasterisation without successor went ahead of this launch
+                    res = self.sim.run(seeds)
+                    ready = torch.cuda.Event()
+                    ready.record(sim_stream)                                # behind the edge export of this run
                 ticket = _native.lib().octa_sim_launch_count()
                 successor = gate.waiting() > 0
             t_rel = time.time()
-            plans = self._plan(res, want_label) if (self.plan_ahead and not self.time_render) else None
-            if not successor:
-                if gate.enter_for_render():
-                    try:
-                        t1 = time.time()
-                        out = self._render(res, want_label, plans)
-                        ev = torch.cuda.Event()
-                        ev.record()
-                        gate.set_barrier(ev)
-                    finally:
-                        gate.__exit__()
-                else:
-                    successor = True                   # a launch took the gate (or stands at it) since this one released it: ticket + 1
-            if successor:
-                _native.check(_native.lib().octa_order_wait_launch(_native.ctx(self.device.index), ticket + 1, gate.timeout_us, gate.settle_us, None,
-                                                                   _native.current_stream_ptr()), "octa_order_wait_launch")
-                t1 = time.time()
-                out = self._render(res, want_label, plans)
-            out["wall"] = {"t_start": t0, "sim_run_s": t1 - t0, "render_enqueue_s": time.time() - t1, "t_request": t_req, "t_released": t_rel,
-                           "ordered_behind_successor": bool(successor)}
+            with torch.cuda.stream(render_stream):
+                render_stream.wait_event(ready)
+                if res.d_edges is not None:
+                    res.d_edges.record_stream(render_stream)
+                out = self._ordered_render(gate, res, want_label, successor, ticket)
+                done = torch.cuda.Event()
+                done.record(render_stream)
+            caller.wait_event(done)                                        # the caller's stream sees finished outputs, as with one stream
+            for k in ("image", "label", "label_grey"):
+                if out.get(k) is not None:
+                    out[k].record_stream(caller)
+            if res.d_edges is not None:
+                res.d_edges.record_stream(caller)
+            out["wall"].update({"t_start": t0, "sim_run_s": out["wall"]["t1"] - t0, "t_request": t_req, "t_released": t_rel})
             return out
         res = self.sim.run(seeds)
         t_rel = time.time()
@@ -183,6 +191,33 @@ class TripleGenerator:
         out = self._render(res, want_label, plans)
         out["wall"] = {"t_start": t0, "sim_run_s": t1 - t0, "render_enqueue_s": time.time() - t1,      # host-side stamps (bench.py's slot accounting)
                        "t_request": t_req, "t_released": t_rel}                                                               # when the call asked for the gate
+        return out
+
+    _gated_streams = None    # (simulator stream, rasteriser stream) of a gated generator, made on first use (see generate)
+
+    def _ordered_render(self, gate, res, want_label, successor, ticket):
+        """The rasterisation of a gated launch on the CURRENT stream, ordered against the launches (see generate)."""
+        import time
+        import torch
+        plans = self._plan(res, want_label) if (self.plan_ahead and not self.time_render) else None
+        if not successor:
+            if gate.enter_for_render():
+                try:
+                    t1 = time.time()
+                    out = self._render(res, want_label, plans)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    gate.set_barrier(ev)
+                finally:
+                    gate.__exit__()
+            else:
+                successor = True                   # a launch took the gate (or stands at it) since this one released it: ticket + 1
+        if successor:
+            _native.check(_native.lib().octa_order_wait_launch(_native.ctx(self.device.index), ticket + 1, gate.timeout_us, gate.settle_us, None,
+                                                               _native.current_stream_ptr()), "octa_order_wait_launch")
+            t1 = time.time()
+            out = self._render(res, want_label, plans)
+        out["wall"] = {"t1": t1, "render_enqueue_s": time.time() - t1, "ordered_behind_successor": bool(successor)}
         return out
 
     def _plan(self, res, want_label):

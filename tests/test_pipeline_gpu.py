@@ -140,7 +140,10 @@ def test_on_the_fly_gan_seg_training_runs(hip_lib_built):
 def test_order_gate_waits_for_a_launch_on_the_device_and_gives_up_at_its_timeout():
     """csrc/order.hip: the one-wave gate kernel a rasterisation's stream waits in until the NEXT persistent-kernel launch is resident (round 6:
     the order is kept on the device; round 5 polled a counter from Python and slept). A ticket that has been launched passes at once with its
-    workgroups signed in; a ticket nobody launches is given up after the timeout; a launch made WHILE the gate waits releases it."""
+    workgroups signed in; a ticket nobody launches is given up after the timeout; a launch made WHILE the gate waits releases it. The gate
+    and the launch sit on streams of different queue priority, as in pipeline.TripleGenerator: two streams of EQUAL priority may share a
+    hardware queue, and the spinning gate would then hold the very launch it waits for behind itself until its time-out (seen in the full
+    test suite, where earlier tests had used up the queues)."""
     import threading
     import time
     import torch
@@ -154,10 +157,16 @@ def test_order_gate_waits_for_a_launch_on_the_device_and_gives_up_at_its_timeout
     sim = greenhouse.BatchSimulator(cfg, 8, 0)
     out = torch.zeros(3, dtype=torch.int32, device="cuda")
     wait = lambda ticket, timeout_us, st: _native.check(lib.octa_order_wait_launch(ctx, ticket, timeout_us, 100, out.data_ptr(), st.cuda_stream), "octa_order_wait_launch")
+    hi = torch.cuda.Stream(priority=-1)
+
+    def run(first_seed):
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(hi):
+            sim.run(np.arange(8) + first_seed)
     try:
-        sim.run(np.arange(8) + 11)
+        run(11)
         t_mine = lib.octa_sim_launch_count()
-        st = torch.cuda.Stream()
+        st = torch.cuda.Stream(priority=0)
         wait(t_mine, 2_000_000, st)                         # already launched (and over): passes at once, all 8 workgroups had signed in
         st.synchronize()
         state, ticks, signed = out.cpu().tolist()
@@ -168,7 +177,7 @@ def test_order_gate_waits_for_a_launch_on_the_device_and_gives_up_at_its_timeout
         state, ticks, _ = out.cpu().tolist()
         assert state == 2 and 2_500_000 <= ticks <= 5_000_000 and time.time() - t0 < 1.0, (state, ticks)
         wait(t_mine + 1, 5_000_000, st)                     # ... and a launch made while the gate waits releases it
-        th = threading.Thread(target=lambda: (time.sleep(0.05), torch.cuda.set_device(0), sim.run(np.arange(8) + 19)))
+        th = threading.Thread(target=lambda: (time.sleep(0.05), run(19)))
         th.start()
         st.synchronize()
         th.join()
