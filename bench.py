@@ -642,6 +642,15 @@ def main():
                       "render_wait_ms": 1e3 * float(np.mean([x["t_done"] - x["t_start"] - x["sim_run_s"] - x["render_enqueue_s"] for x in w])),
                       "launch_to_done_ms": 1e3 * float(np.mean([x["t_done"] - x["t_start"] for x in w]))}
         print(f"[bench] slot cycle: {slot_cycle}", file=sys.stderr)
+        # launch by launch (stderr only): kernel time, whether the rasterisation was ordered behind a successor and what its gate kernel saw
+        for o in sorted(outs, key=lambda o_: o_["wall"]["t_start"]):
+            g_ = o["wall"].get("gate")
+            print(f"[bench]   launch ticket {o['wall'].get('ticket')}: start {o['wall']['t_start'] - t0:7.3f} s  kernel {o['result'].timing['kernel_b_ms']:6.1f} ms  sim call {1e3 * o['wall']['sim_run_s']:6.1f}  "
+                  f"successor {o['wall'].get('ordered_behind_successor')}  gate {g_.cpu().tolist() if g_ is not None else None}", file=sys.stderr)
+            sp_ = o["result"].spans.astype(np.float64) / 1e5                 # ms on the device's 100 MHz clock
+            b0 = sp_[:, 0].min()
+            print("[bench]     sample starts after the first (ms): " + " ".join(f"p{q}={np.percentile(sp_[:, 0] - b0, q):.1f}" for q in (25, 50, 60, 75, 90, 100))
+                  + "   ends: " + " ".join(f"p{q}={np.percentile(sp_[:, 1] - b0, q):.1f}" for q in (0, 25, 50, 75, 100)), file=sys.stderr)
     ka = kb = 0.0
     la = lb = 0
     bif_ms = 0.0

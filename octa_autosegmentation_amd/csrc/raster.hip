@@ -39,38 +39,39 @@ constexpr int NPX = 4;          // adjacent pixels of one row per lane (register
 constexpr int BLK_H = 4 * NPX;  // a wave owns a 16 x BLK_H pixel block (16/NPX lanes per row)
 constexpr int ST = 64;          // super-tile width (pixels): 4 blocks
 #ifndef OCTA_RASTER_WG
-#define OCTA_RASTER_WG 1024
+#define OCTA_RASTER_WG 512
 #endif
-// The render workgroup is 1024 threads on a 64 x 64 super-tile with 145 KB of LDS: ONE per CU, and -- the point -- no room beside a
-// simulator workgroup (80 KB of LDS). Round 5 measured the denser forms: 512 threads on 64 x 32 with lists cut to 79 / 53 KB (two / three
-// workgroups per CU, -DOCTA_RASTER_WG=512 -DOCTA_RASTER_SLOTS_PER_THREAD=2 -DOCTA_RASTER_LIST_CAP=256 -DOCTA_RASTER_CELL_CAP=128
-// -DOCTA_RASTER_ITEM_CAP=192) rasterise 128 labels in 7.15 / 6.22 ms instead of 8.38 ALONE -- the kernel is short of waves: 55 % vector-pipe
-// utilisation at four per SIMD -- but in the generator's pipeline such a workgroup fits beside ONE simulator workgroup, takes the place
-// the second one of the next launch is waiting for, and is replaced by the next render workgroup when it leaves: the persistent kernel went
-// from 413 to 574 ms per launch and the headline from 1131 to 846 samples/s (518 ms / 932 with the rasterisation held back until the next
-// launch was resident; raised wave priority for the simulator: no change). The exclusive form is the system's optimum while both share a GPU.
+// The render workgroup: 512 threads on a 64 x 32 super-tile with 53 KB of LDS -- three per CU, six waves per SIMD, and room beside ONE
+// simulator workgroup (80 KB). Rounds 4-5 shipped 1024 threads on 64 x 64 with 145 KB (ONE per CU, four waves per SIMD, 55 % vector-pipe
+// utilisation: 8.0 ms per 128 labels against 6.1 for this form) because in the generator's pipeline the dense form was a disaster: a render
+// workgroup dispatched while a launch was being placed took the slot the launch's second workgroup of that CU was waiting for and was replaced
+// by the next render workgroup when it left -- 846 against 1131 samples/s. Round 6 removed the cause instead of the symptom: a launch's
+// rasterisation is ordered behind the NEXT launch on the device (csrc/order.hip) and runs at the lower queue priority (pipeline.py), so render
+// workgroups only ever take what finished samples leave, half a CU at a time: 1168 - 1176 samples/s against 1134 - 1155 for the exclusive
+// form on one box, alternating (profiles/r06_raster_dense_ab.log). -DOCTA_RASTER_WG=1024 -DOCTA_RASTER_SLOTS_PER_THREAD=4
+// -DOCTA_RASTER_LIST_CAP=512 -DOCTA_RASTER_CELL_CAP=160 -DOCTA_RASTER_ITEM_CAP=256 builds the exclusive form.
 constexpr int WG = OCTA_RASTER_WG;             // threads per render workgroup: 8 waves = a 64 x 32 super-tile (1024: 64 x 64)
 constexpr int ST_Y = (WG / 64 / 4) * BLK_H;    // super-tile height: a wave per 16 x 16 block, four blocks across
 constexpr int EPT = 4;          // edges tested per thread per scan round (8 measured slower in round 4: bin 602 -> 656 WG-ms per 128 labels)
 #ifndef OCTA_RASTER_LIST_CAP
-#define OCTA_RASTER_LIST_CAP 512
+#define OCTA_RASTER_LIST_CAP 256
 #endif
 constexpr int LIST_CAP = OCTA_RASTER_LIST_CAP;   // edges per chunk (1024 until round 5: the batched fold's cell lists need the LDS; a 64 x 64 super-tile of a 13 k-edge graph lists 60 - 150)
 #ifndef OCTA_RASTER_FB
 #define OCTA_RASTER_FB 4
 #endif
 #ifndef OCTA_RASTER_CELL_CAP
-#define OCTA_RASTER_CELL_CAP 160
+#define OCTA_RASTER_CELL_CAP 128
 #endif
 constexpr int FB = OCTA_RASTER_FB;   // edges folded per batch (their list indices travel in one 64-bit word, 10 bits each: at most 6)
 constexpr int FB_MAX_SLOTS = 32;// an edge with more side slots than this is folded on its own
 constexpr int CELL_CAP = OCTA_RASTER_CELL_CAP;   // cells (incl. carried covers) per wave and batch
 #ifndef OCTA_RASTER_SLOTS_PER_THREAD
-#define OCTA_RASTER_SLOTS_PER_THREAD 4
+#define OCTA_RASTER_SLOTS_PER_THREAD 2
 #endif
 constexpr int SLOT_CAP = OCTA_RASTER_SLOTS_PER_THREAD * WG;  // int4 side slots per chunk (64 KiB; 80 KiB until the fold's accumulators needed 33 KiB, round 4)
 #ifndef OCTA_RASTER_ITEM_CAP
-#define OCTA_RASTER_ITEM_CAP 256
+#define OCTA_RASTER_ITEM_CAP 192
 #endif
 constexpr int ITEM_CAP = OCTA_RASTER_ITEM_CAP;   // (side, scanline) work items of one edge inside one wave's block
 

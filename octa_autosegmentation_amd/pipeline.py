@@ -10,6 +10,8 @@ Mirrors what the reference produces with
   * label : all edges, positions as read back from the CSV text, rasterised at 1216x1216 and
             Floyd-Steinberg binarised (visualize_vessel_graphs.py:95-99).
 """
+import ctypes
+
 import numpy as np
 
 from . import _native, graph_io
@@ -18,8 +20,17 @@ from .vessel_graph_generation import greenhouse, tree2img
 
 class SimGate:
     """The lock the generators of one device share so that ONE persistent kernel runs at a time, with what the device-side ordering needs:
-    how many threads are waiting for it (is a successor launch coming?) and the completion event of a rasterisation that went ahead without
-    one (the next launch is ordered behind it). Reentrant use is not supported."""
+    how many threads are waiting for it (is a successor launch coming?) and the events the NEXT launch has to be ordered behind.
+
+    Why a launch must find the GPU free of every LDS-using workgroup (round 6, found with per-sample start times in bench.py's log): two
+    simulator workgroups fill a CU's 160 KB of LDS exactly (80 KB each), and the hardware allocates LDS contiguously. A workgroup with ANY
+    LDS that is resident while a launch is placed -- the edge-export kernel of the launch before (57 KB), a scan kernel of the rasteriser's
+    planning step (2 KB), a render workgroup -- pushes the first simulator workgroup of that CU to an odd offset; when the small one leaves,
+    neither hole fits the second simulator workgroup, and the CU runs ONE sample at a time for the whole launch: the launch "lasts two
+    samples" (660 instead of 400 ms; rounds 4-5 called it the headline's slow mode and blamed the dispatcher). So every launch waits, on
+    its own stream, for: the export (and planning) of the launch before, every rasterisation up to the one before last (the last one is
+    held back by the gate kernel until this launch is resident), and a rasterisation that went ahead without a successor. Reentrant use is
+    not supported."""
 
     def __init__(self, timeout_us=50000, settle_us=200):
         import threading
@@ -28,6 +39,9 @@ class SimGate:
         self._waiting = 0
         self._holder = None
         self._barrier = None
+        self._seq = 0                      # launches made through this gate
+        self._drain = []                   # events of the launch before: edge export, rasteriser planning
+        self._renders = []                 # (launch number, completion event) of rasterisations not yet known to be over
         self.timeout_us, self.settle_us = int(timeout_us), int(settle_us)
 
     def __enter__(self):
@@ -67,6 +81,29 @@ class SimGate:
 
     def locked(self):
         return self._lock.locked()
+
+    def order_launch(self, stream):
+        """Called with the gate held, before a launch is enqueued on `stream`: the stream waits for everything that must be off the GPU when
+        the launch's workgroups are placed. Returns this launch's number."""
+        with self._meta:
+            self._seq += 1
+            n = self._seq
+            drain, self._drain = self._drain, []
+            barrier, self._barrier = self._barrier, None
+            old = [ev for k, ev in self._renders if k <= n - 2]
+            self._renders = [(k, ev) for k, ev in self._renders if k > n - 2]
+        for ev in drain + old + ([barrier] if barrier is not None else []):
+            stream.wait_event(ev)
+        return n
+
+    def after_launch(self, *events):
+        """Called with the gate held, after the launch: what the NEXT launch waits for (edge export, planning kernels)."""
+        with self._meta:
+            self._drain = [ev for ev in events if ev is not None]
+
+    def note_render(self, n, event):
+        with self._meta:
+            self._renders.append((n, event))
 
     def set_barrier(self, event):
         with self._meta:
@@ -160,22 +197,30 @@ class TripleGenerator:
                 t0 = time.time()
                 with torch.cuda.stream(sim_stream):
                     sim_stream.wait_event(entered)                          # what the caller enqueued before this call
-                    pending = gate.take_barrier()
-                    if pending is not None:
-                        sim_stream.wait_event(pending)                      # a rasterisation without successor went ahead of this launch
+                    n_launch = gate.order_launch(sim_stream)                # ... and what must be off the GPU when this launch is placed
                     res = self.sim.run(seeds)
                     ready = torch.cuda.Event()
                     ready.record(sim_stream)                                # behind the edge export of this run
                 ticket = _native.lib().octa_sim_launch_count()
+                # the rasteriser's planning step (per-edge records, scans, its one host wait) INSIDE the gate: its kernels use LDS, and the
+                # successor's launch must not be placed beside them (SimGate); the successor's host-side set-up (~5 ms) has not begun yet
+                planned = None
+                with torch.cuda.stream(render_stream):
+                    render_stream.wait_event(ready)
+                    if res.d_edges is not None:
+                        res.d_edges.record_stream(render_stream)
+                    plans = self._plan(res, want_label) if (self.plan_ahead and not self.time_render) else None
+                    if plans is not None:
+                        planned = torch.cuda.Event()
+                        planned.record(render_stream)
+                gate.after_launch(ready, planned)
                 successor = gate.waiting() > 0
             t_rel = time.time()
             with torch.cuda.stream(render_stream):
-                render_stream.wait_event(ready)
-                if res.d_edges is not None:
-                    res.d_edges.record_stream(render_stream)
-                out = self._ordered_render(gate, res, want_label, successor, ticket)
+                out = self._ordered_render(gate, res, want_label, successor, ticket, plans)
                 done = torch.cuda.Event()
                 done.record(render_stream)
+            gate.note_render(n_launch, done)
             caller.wait_event(done)                                        # the caller's stream sees finished outputs, as with one stream
             for k in ("image", "label", "label_grey"):
                 if out.get(k) is not None:
@@ -195,11 +240,10 @@ class TripleGenerator:
 
     _gated_streams = None    # (simulator stream, rasteriser stream) of a gated generator, made on first use (see generate)
 
-    def _ordered_render(self, gate, res, want_label, successor, ticket):
+    def _ordered_render(self, gate, res, want_label, successor, ticket, plans):
         """The rasterisation of a gated launch on the CURRENT stream, ordered against the launches (see generate)."""
         import time
         import torch
-        plans = self._plan(res, want_label) if (self.plan_ahead and not self.time_render) else None
         if not successor:
             if gate.enter_for_render():
                 try:
@@ -212,12 +256,14 @@ class TripleGenerator:
                     gate.__exit__()
             else:
                 successor = True                   # a launch took the gate (or stands at it) since this one released it: ticket + 1
+        gate_out = None
         if successor:
-            _native.check(_native.lib().octa_order_wait_launch(_native.ctx(self.device.index), ticket + 1, gate.timeout_us, gate.settle_us, None,
-                                                               _native.current_stream_ptr()), "octa_order_wait_launch")
+            gate_out = torch.zeros(3, dtype=torch.int32, device=self.device)        # what the gate kernel saw: 1 resident / 2 timed out, ticks waited, workgroups signed in
+            _native.check(_native.lib().octa_order_wait_launch(_native.ctx(self.device.index), ticket + 1, gate.timeout_us, gate.settle_us,
+                                                               ctypes.c_void_p(gate_out.data_ptr()), _native.current_stream_ptr()), "octa_order_wait_launch")
             t1 = time.time()
             out = self._render(res, want_label, plans)
-        out["wall"] = {"t1": t1, "render_enqueue_s": time.time() - t1, "ordered_behind_successor": bool(successor)}
+        out["wall"] = {"t1": t1, "render_enqueue_s": time.time() - t1, "ordered_behind_successor": bool(successor), "gate": gate_out, "ticket": int(ticket)}
         return out
 
     def _plan(self, res, want_label):

@@ -16,6 +16,7 @@ export PYTHONUNBUFFERED=1
 for rep in $(seq 1 "$REPS"); do
   for spec in "$@"; do
     label=${spec%%::*}; rest=${spec#*::}; envs=${rest%%::*}; cmd=${rest#*::}
+    envs=$(eval echo "$envs")
     out=$(env $envs bash -c "$cmd" 2>>gpurun_out/ab/"$TAG".err | grep -v "amdgpu.ids" | tail -n 1)
     echo "$label rep $rep: $out" | tee -a gpurun_out/ab/"$TAG".log
   done
