@@ -582,14 +582,41 @@ def main():
             for g_ in gl:
                 g_.sim_gate = gate
 
-    def launch(slot, first_step, nsteps):
+    def launch(slot, first_step, nsteps, wait=True):
         seeds = np.concatenate([sharding.rank_seeds(rank, i, B) for i in range(first_step, first_step + nsteps)])
         torch.cuda.set_device(dev)
         with torch.cuda.stream(streams[slot]):
             out = gens[nsteps][slot].generate(seeds)
+            if wait:
+                finish(slot, out)
+        return out
+
+    def finish(slot, out):
+        ev = out.get("done_event")
+        if ev is not None:
+            ev.synchronize()
+        else:
             streams[slot].synchronize()
         out["wall"]["t_done"] = time.time()
-        return out
+
+    def chain(slot, groups):
+        # A slot asks for its NEXT launch before it waits for its previous result (round 6): the thread then stands at the gate while the
+        # other slot's kernel runs, so every finished launch finds a successor waiting and its rasterisation is ordered behind that launch
+        # (and runs in its tail) instead of going ahead alone with the next launch ordered behind ALL of it. Stream order keeps it safe: a
+        # generator's launches share one stream, its rasterisations another.
+        outs = []
+        for f0, n in groups:
+            same_gen = bool(outs) and outs[-1]["steps"] == n
+            if outs and not same_gen:
+                finish(slot, outs[-1])
+            o = launch(slot, f0, n, wait=False)
+            o["steps"] = n
+            if outs and same_gen:
+                finish(slot, outs[-1])
+            outs.append(o)
+        if outs:
+            finish(slot, outs[-1])
+        return outs
 
     pool = ThreadPoolExecutor(max_workers=n_fly)
 
@@ -606,7 +633,7 @@ def main():
         # slot-affine: launch j runs on slot j % n_fly, one launch per slot at a time
         groups = [(first + k, min(G, count - k)) for k in range(0, count, G)]
         chains = [[g for j, g in enumerate(groups) if j % n_fly == s] for s in range(n_fly)]
-        futs = [pool.submit(lambda ch=ch, s=s: [launch(s, f0, n) for f0, n in ch]) for s, ch in enumerate(chains)]
+        futs = [pool.submit(chain, s, ch) for s, ch in enumerate(chains)]
         outs = []
         for f in futs:
             outs.extend(f.result())
@@ -647,6 +674,9 @@ def main():
             g_ = o["wall"].get("gate")
             print(f"[bench]   launch ticket {o['wall'].get('ticket')}: start {o['wall']['t_start'] - t0:7.3f} s  kernel {o['result'].timing['kernel_b_ms']:6.1f} ms  sim call {1e3 * o['wall']['sim_run_s']:6.1f}  "
                   f"successor {o['wall'].get('ordered_behind_successor')}  gate {g_.cpu().tolist() if g_ is not None else None}", file=sys.stderr)
+            if o["wall"].get("host"):
+                print(f"[bench]     host: gate -> run {o['wall']['host']['gate_to_run_ms']:.1f} ms, run {o['wall']['host']['run_ms']:.1f} (loop {o['result'].timing['loop_wall_ms']:.1f}, kernel {o['result'].timing['kernel_b_ms']:.1f}), "
+                      f"plan inside the gate {o['wall']['host']['plan_in_gate_ms']:.1f}; waited for the gate {1e3 * (o['wall']['t_start'] - o['wall']['t_request']):.1f}", file=sys.stderr)
             sp_ = o["result"].spans.astype(np.float64) / 1e5                 # ms on the device's 100 MHz clock
             b0 = sp_[:, 0].min()
             print("[bench]     sample starts after the first (ms): " + " ".join(f"p{q}={np.percentile(sp_[:, 0] - b0, q):.1f}" for q in (25, 50, 60, 75, 90, 100))
@@ -850,7 +880,8 @@ def main():
                        "batch_per_gpu": B, "steps_per_launch": G, "launches_in_flight": n_fly, "persistent_kernels_at_a_time": sim_conc, "parallelism": f"sample-sharded x{world}, no collective",
                        "set_up": "every full-size generator primed once before the clock starts (TripleGenerator.prime: a synthetic edge list through its rasteriser: scratch growth and kernel "
                                  "loading; nothing simulated); Python's cyclic garbage collector is off inside the timed region (gc.disable: a collection holds every thread)",
-                       "ordering": "a launch's rasterisation is ordered behind the NEXT launch on the device (csrc/order.hip gate kernel on the rasteriser's stream; no host polling or sleeps)"},
+                       "ordering": "a launch's rasterisation is ordered behind the NEXT launch on the device (csrc/order.hip gate kernel on the rasteriser's stream; no host polling or sleeps); "
+                                   "a slot asks for its next launch before it waits for its previous result, so every finished launch finds its successor at the gate"},
             "parity": "graph CSV text bit-exact with the REFERENCE (imported and run in the build container) on 8 short + 2 full-length fixture "
                       "runs and on 64 further full-length seeds (tests/golden/sim_wide_golden.npz: SHA-256 of the CSV text of seeds 1000-1063; the "
                       "GPU reproduces all 64, tests/test_sim_gpu.py); label / image pixels bit-exact on the reference's fixtures. The oracle follows "

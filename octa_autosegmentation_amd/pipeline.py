@@ -198,7 +198,9 @@ class TripleGenerator:
                 with torch.cuda.stream(sim_stream):
                     sim_stream.wait_event(entered)                          # what the caller enqueued before this call
                     n_launch = gate.order_launch(sim_stream)                # ... and what must be off the GPU when this launch is placed
+                    t_r0 = time.time()
                     res = self.sim.run(seeds)
+                    t_r1 = time.time()
                     ready = torch.cuda.Event()
                     ready.record(sim_stream)                                # behind the edge export of this run
                 ticket = _native.lib().octa_sim_launch_count()
@@ -216,18 +218,20 @@ class TripleGenerator:
                 gate.after_launch(ready, planned)
                 successor = gate.waiting() > 0
             t_rel = time.time()
+            host_stamps = {"gate_to_run_ms": 1e3 * (t_r0 - t0), "run_ms": 1e3 * (t_r1 - t_r0), "plan_in_gate_ms": 1e3 * (t_rel - t_r1)}
             with torch.cuda.stream(render_stream):
                 out = self._ordered_render(gate, res, want_label, successor, ticket, plans)
                 done = torch.cuda.Event()
                 done.record(render_stream)
             gate.note_render(n_launch, done)
+            out["done_event"] = done                                       # for callers that keep several results of one generator in flight
             caller.wait_event(done)                                        # the caller's stream sees finished outputs, as with one stream
             for k in ("image", "label", "label_grey"):
                 if out.get(k) is not None:
                     out[k].record_stream(caller)
             if res.d_edges is not None:
                 res.d_edges.record_stream(caller)
-            out["wall"].update({"t_start": t0, "sim_run_s": out["wall"]["t1"] - t0, "t_request": t_req, "t_released": t_rel})
+            out["wall"].update({"t_start": t0, "sim_run_s": out["wall"]["t1"] - t0, "t_request": t_req, "t_released": t_rel, "host": host_stamps})
             return out
         res = self.sim.run(seeds)
         t_rel = time.time()
