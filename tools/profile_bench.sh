@@ -6,7 +6,7 @@
 # (counter passes never combined with tracing: see the task's profiling rules)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r03}
+TAG=${1:-r06}
 OUT=gpurun_out
 mkdir -p $OUT
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py --no-cpu-baseline --no-pmc --no-long > $OUT/${TAG}_bench_stdout.log 2>&1
