@@ -674,9 +674,13 @@ struct OCTA_SIM_T {
     HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};  // pinned mailbox of the persistent form
     bool lockstep = false;          // OCTA_SIM_LOCKSTEP=1: two launches per iteration (the round-1 form)
     double mail_timeout_ms = 30000; // OCTA_SIM_MAIL_TIMEOUT_MS: device-side bound on one wait for the host when parking is off
-    double park_ms = 20.0;          // OCTA_SIM_PARK_MS: a workgroup that has waited this long for its answer parks (0: never). Normal answers
+    double park_ms = 100.0;         // OCTA_SIM_PARK_MS: a workgroup that has waited this long for its answer parks (0: never). Normal answers
                                     // take tens of microseconds; 3 ms (until the end of round 2) also parked workgroups whenever a busy host
-                                    // descheduled the service thread for a few milliseconds, and a park costs a drain + relaunch
+                                    // descheduled the service thread for a few milliseconds, and a park costs a drain + relaunch. Round 6:
+                                    // 20 -> 100 ms. A parked sample is re-run ALONE at the launch's end (+400 ms for a 512-sample launch);
+                                    // one headline run in ~16 lost a launch that way to a host stall of a few tens of milliseconds, which
+                                    // costs its own length when it is waited out. The episodes parking exists for (a launch whose tickets
+                                    // the host stops seeing) take 80 ms longer to resolve.
     int last_ticket = 0;            // ticket of the last persistent-kernel launch of this simulator
     int grid_cap = 512;             // workgroups per launch of the persistent kernel (SIM_WG_PER_CU per CU; OCTA_SIM_GRID overrides)
     int test_stall_ms = 0;          // OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once with a ticket pending

@@ -5,7 +5,7 @@ Round 1's driver run lost a generator thread to error bit 0x800 (a workgroup wai
 activity of other host threads, the host stops seeing the launch's tickets until the kernel ends although it scans the mailbox
 continuously and the workgroup reads its own ticket back correctly -- a running kernel's writes to pinned host memory are not
 guaranteed to reach the host before the kernel ends. The protocol therefore no longer depends on it: a workgroup that has
-waited 20 ms (OCTA_SIM_PARK_MS) PARKS (records its resume point, leaves the kernel), the host serves parked requests at the kernel boundary and
+waited 100 ms (OCTA_SIM_PARK_MS; 20 ms until round 5) PARKS (records its resume point, leaves the kernel), the host serves parked requests at the kernel boundary and
 launches again. These tests pin that results stay bit-identical through parking, that the loops around the simulator survive
 device-wide waits, allocations and frees from other threads, and that failures of the generator thread are errors, not warnings.
 """
