@@ -84,6 +84,7 @@ struct BatchPtrs {
     int *gnode, *gstart, *gcount;
     Rec *rec;
     int *glist, *child_group;
+    FlushRec *fl_rec;   // [B][2][MURRAY_FLUSH_LDS] deferred Murray flush records (sim_core.h)
     idx_t *kd_idx, *kd_rank;
     unsigned char *removed, *ven_near;
     unsigned long long *hashes;
@@ -138,6 +139,7 @@ __device__ __forceinline__ SimArrays sample_arrays(const BatchPtrs &B, int s) {
     A.rec = B.rec + (size_t)s * GCAP;
     A.glist = B.glist + (size_t)s * GCAP;
     A.child_group = B.child_group + (size_t)s * NCAP;
+    A.fl_rec = B.fl_rec + (size_t)s * 2 * MURRAY_FLUSH_LDS;
     A.kd_idx = B.kd_idx + (size_t)s * OCAP;
     A.kd_rank = B.kd_rank + (size_t)s * OCAP;
     A.removed = B.removed + (size_t)s * OCAP;
@@ -323,7 +325,7 @@ sim_iter_a_kernel(BatchPtrs B, int it, int finish_prev) {
             tr[0] = A.sc->n_nodes[0]; tr[1] = A.sc->n_oxy; tr[2] = A.sc->n_nodes[1]; tr[3] = A.sc->n_co2;
         }
     }
-    if (it >= B.C.n_iter) return;
+    if (it >= B.C.n_iter) { murray_flush_pending(b, A); return; }      // the run is over: the radii the last passes left for "the other forest's next pass"
     const IterParams P = B.iters[it];
     {
         long _t0 = (long)wall_clock64();
@@ -555,6 +557,7 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
 #endif
         stage = 0;
     }
+    if (parked_at < 0 && !skip) murray_flush_pending(b, A);      // the run is over (block-uniform): radii left for "the other forest's next pass"
     // sign-off: the host leaves its service loop when every SAMPLE has passed here (or when the launch has completed)
     b.sync();
     if (b.tid == 0) {
@@ -800,7 +803,7 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, O
     rc |= dev_alloc(S, &P.nn, nb * OCAP); rc |= dev_alloc(S, &P.act_list, nb * NCAP);
     rc |= dev_alloc(S, &P.sorted, nb * SORTCAP); rc |= dev_alloc(S, &P.gnode, nb * GCAP); rc |= dev_alloc(S, &P.gstart, nb * GCAP);
     rc |= dev_alloc(S, &P.gcount, nb * GCAP); rc |= dev_alloc(S, &P.rec, nb * GCAP);
-    rc |= dev_alloc(S, &P.glist, nb * GCAP); rc |= dev_alloc(S, &P.child_group, nb * NCAP);
+    rc |= dev_alloc(S, &P.glist, nb * GCAP); rc |= dev_alloc(S, &P.child_group, nb * NCAP); rc |= dev_alloc(S, &P.fl_rec, nb * 2 * MURRAY_FLUSH_LDS);
     rc |= dev_alloc(S, &P.kd_idx, nb * OCAP); rc |= dev_alloc(S, &P.kd_rank, nb * OCAP);
     rc |= dev_alloc(S, &P.removed, nb * OCAP); rc |= dev_alloc(S, &P.ven_near, nb * OCAP); rc |= dev_alloc(S, &P.hashes, nb * OCAP);
     rc |= dev_alloc(S, &P.pairs, nb * PCAP); rc |= dev_alloc(S, &P.set_hash, nb * SETCAP); rc |= dev_alloc(S, &P.set_key, nb * SETCAP);

@@ -132,6 +132,9 @@ struct __attribute__((aligned(8))) Rec {
     unsigned int child;     // inter nodes: the (only) child
 };
 
+// one marked node of a deferred Murray flush (round 6: murray_flush_prepare_wave -> murray_flush_rounds_wave)
+struct __attribute__((aligned(8))) FlushRec { double kk, acc; int node, pend, s0, s1; };
+
 struct __attribute__((aligned(8))) BifRequest {
     int sample, n;
     double pos[3];
@@ -163,6 +166,7 @@ struct SampleScalars {
     int resume_it, resume_stage;   // stage 0: top of iteration resume_it; 1: behind its arterial mailbox
     int parked, finished;
     long t_begin, t_end;           // 100 MHz wall clock when a workgroup first took the sample / last left it
+    int fl_pending[2];             // marked nodes of forest f whose Murray radii are still to be evaluated from A.fl_rec (deferred flush, round 6)
 };
 
 // pointers to ONE sample's slices
@@ -195,6 +199,7 @@ struct SimArrays {
     Rec *rec;            // [GCAP]
     int *glist;          // [GCAP] groups that grow under the speculation, ascending (dict order)
     int *child_group;    // [NCAP] tag<<14 | grow<<13 | group of the inter-node whose first child this node is
+    FlushRec *fl_rec;    // [2][256] records of the forests' deferred Murray flushes (MURRAY_FLUSH_LDS each)
     idx_t *kd_idx, *kd_rank;  // [OCAP]
     unsigned char *removed;  // [OCAP]
     unsigned char *ven_near; // [OCAP]
@@ -1739,6 +1744,126 @@ OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g,
 #define OCTA_MURRAY_EPT 4
 #endif
 constexpr int MURRAY_EPT = OCTA_MURRAY_EPT;
+#if defined(__HIP_DEVICE_COMPILE__)
+// The one-wave flush in two halves (round 6). PREPARE (the pass's own wave, right behind its last visit; 64 lanes, four list slots each):
+// topology records of the marked nodes, the list slots of their marked children, the radii of their unmarked children (final already) raised
+// to the node's kappa -- everything that needs the pass's LDS state (marked bitmap) and three parallel round trips to HBM -- written as one
+// 32-byte record per slot. ROUNDS (any ONE wave, later): children before parents through fl_val / fl_done in the LDS, one pow evaluation per
+// step for the whole wave. The rounds are a dependency chain of ~30 levels x 2 evaluations (27 ms per sample) that nothing reads before the
+// OTHER forest's ordered pass is over (arterial radii: phase_sample / phase_pre of the next iteration; venous radii: the next phase_pre of
+// the venous side), so they run as a side job of that pass on a wave that idles there (phase_seq).
+__device__ inline void murray_flush_prepare_wave(const SimArrays &A, int f, const SeqLds &L, int n_def, FlushRec *recs) {
+    const int lane = (int)(threadIdx.x & 63);
+    double *rad = L.rad;
+    int node[MURRAY_EPT], s0[MURRAY_EPT], s1[MURRAY_EPT];
+    double kk[MURRAY_EPT], acc[MURRAY_EPT];
+    int pend[MURRAY_EPT];     // 1: marked child 0 not in yet, 2: marked child 1 not in yet, 4: radius not written yet
+    int c0[MURRAY_EPT], c1[MURRAY_EPT], nch[MURRAY_EPT];
+    for (int e = 0; e < MURRAY_EPT; e++) {
+        const int idx = lane + e * 64;
+        pend[e] = 0; node[e] = 0; c0[e] = c1[e] = 0; nch[e] = 0; kk[e] = 1; acc[e] = 0; s0[e] = s1[e] = 0;
+        if (idx < n_def) node[e] = A.act_list[idx];
+    }
+    for (int e = 0; e < MURRAY_EPT; e++) {
+        if (lane + e * 64 < n_def) {
+            const WalkRec r = walk_load(A, f, node[e], false);
+            c0[e] = r.c0; c1[e] = r.c1; kk[e] = r.k; nch[e] = r.nch;
+        }
+    }
+    // third round trip, all entries at once: the slot of a marked child, the radius of an unmarked one
+    double cv0[MURRAY_EPT], cv1[MURRAY_EPT];
+    unsigned ready = 0;                          // bit 2e + c: child c of entry e has its radius in cv, its power not yet in acc
+    for (int e = 0; e < MURRAY_EPT; e++) {
+        cv0[e] = cv1[e] = 0.5;
+        if (lane + e * 64 >= n_def) continue;
+        pend[e] = 4;
+        if (nch[e] >= 1) { if (deferred_get(L, c0[e])) { pend[e] |= 1; s0[e] = L.slot_of[c0[e]]; } else { cv0[e] = rad[c0[e]]; ready |= 1u << (2 * e); } }
+        if (nch[e] >= 2) { if (deferred_get(L, c1[e])) { pend[e] |= 2; s1[e] = L.slot_of[c1[e]]; } else { cv1[e] = rad[c1[e]]; ready |= 2u << (2 * e); } }
+    }
+    // One pow evaluation per step for the whole wave, whatever entry and child it belongs to (written entry by entry a step executed up to
+    // 3 x MURRAY_EPT evaluations one after the other -- every `if` with a taker among the 64 lanes)
+    while (__ballot(ready != 0)) {
+        const bool on = ready != 0;
+        const int t = on ? (int)__ffs((int)ready) - 1 : 0;
+        if (on) ready &= ready - 1u;
+        double x = 0.5, k = 2.0;
+#pragma unroll
+        for (int e = 0; e < MURRAY_EPT; e++) if ((t >> 1) == e) { x = (t & 1) ? cv1[e] : cv0[e]; k = kk[e]; }
+        if (!on) { x = 0.5; k = 2.0; }
+        const double pw = octa_gpow::gpow_t(x, k, L.log_tab, L.exp_tab);
+#pragma unroll
+        for (int e = 0; e < MURRAY_EPT; e++) if (on && (t >> 1) == e) acc[e] = acc[e] + pw;
+    }
+    for (int e = 0; e < MURRAY_EPT; e++) {
+        const int idx = lane + e * 64;
+        if (idx < n_def) { FlushRec r; r.kk = kk[e]; r.acc = acc[e]; r.node = node[e]; r.pend = pend[e]; r.s0 = s0[e]; r.s1 = s1[e]; recs[idx] = r; }
+    }
+}
+
+// rad: the forest's radii; fl_val [MURRAY_FLUSH_LDS] doubles and fl_done [MURRAY_FLUSH_LDS / 32] ints of LDS that belong to the calling wave
+__device__ inline int murray_flush_rounds_wave(double *rad, const double *log_tab, const uint64_t *exp_tab, double *fl_val, int *fl_done,
+                                               const FlushRec *recs, int n_def) {
+    const int lane = (int)(threadIdx.x & 63);
+    int node[MURRAY_EPT], s0[MURRAY_EPT], s1[MURRAY_EPT], pend[MURRAY_EPT];
+    double kk[MURRAY_EPT], acc[MURRAY_EPT], cv0[MURRAY_EPT], cv1[MURRAY_EPT];
+    for (int w = lane; w < MURRAY_FLUSH_LDS / 32; w += 64) fl_done[w] = 0;
+    for (int e = 0; e < MURRAY_EPT; e++) {
+        const int idx = lane + e * 64;
+        node[e] = 0; s0[e] = s1[e] = 0; pend[e] = 0; kk[e] = 1; acc[e] = 0; cv0[e] = cv1[e] = 0.5;
+        if (idx < n_def) { const FlushRec r = recs[idx]; node[e] = r.node; s0[e] = r.s0; s1[e] = r.s1; pend[e] = r.pend; kk[e] = r.kk; acc[e] = r.acc; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int rounds = 0, done = 0;
+    while (done < n_def) {
+        rounds++;
+        unsigned ready = 0;
+        for (int e = 0; e < MURRAY_EPT; e++) {
+            if (!(pend[e] & 4)) continue;
+            if ((pend[e] & 1) && (((unsigned)fl_done[s0[e] >> 5] >> (s0[e] & 31)) & 1u)) { cv0[e] = fl_val[s0[e]]; ready |= 1u << (2 * e); pend[e] &= ~1; }
+            if ((pend[e] & 2) && (((unsigned)fl_done[s1[e] >> 5] >> (s1[e] & 31)) & 1u)) { cv1[e] = fl_val[s1[e]]; ready |= 2u << (2 * e); pend[e] &= ~2; }
+        }
+        while (__ballot(ready != 0)) {
+            const bool on = ready != 0;
+            const int t = on ? (int)__ffs((int)ready) - 1 : 0;
+            if (on) ready &= ready - 1u;
+            double x = 0.5, k = 2.0;
+#pragma unroll
+            for (int e = 0; e < MURRAY_EPT; e++) if ((t >> 1) == e) { x = (t & 1) ? cv1[e] : cv0[e]; k = kk[e]; }
+            if (!on) { x = 0.5; k = 2.0; }
+            const double pw = octa_gpow::gpow_t(x, k, log_tab, exp_tab);
+#pragma unroll
+            for (int e = 0; e < MURRAY_EPT; e++) if (on && (t >> 1) == e) acc[e] = acc[e] + pw;
+        }
+        unsigned fin = 0;
+        for (int e = 0; e < MURRAY_EPT; e++) if ((pend[e] & 4) && !(pend[e] & 3)) fin |= 1u << e;
+        while (__ballot(fin != 0)) {
+            const bool on = fin != 0;
+            const int t = on ? (int)__ffs((int)fin) - 1 : 0;
+            if (on) fin &= fin - 1u;
+            double a = 0.5, k = 2.0;
+#pragma unroll
+            for (int e = 0; e < MURRAY_EPT; e++) if (t == e) { a = acc[e]; k = kk[e]; }
+            if (!on) { a = 0.5; k = 2.0; }
+            const double rp = octa_gpow::gpow_t(a, 1.0 / k, log_tab, exp_tab);
+#pragma unroll
+            for (int e = 0; e < MURRAY_EPT; e++)
+                if (on && t == e) { fl_val[lane + e * 64] = rp; rad[node[e]] = rp; pend[e] = 8; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int e = 0; e < MURRAY_EPT; e++) {
+            const unsigned long long fb = __ballot(pend[e] == 8);       // slots e * 64 + lane
+            if (pend[e] == 8) pend[e] = 0;
+            if (fb) {
+                if (lane == 0) { fl_done[2 * e] |= (int)(unsigned)fb; fl_done[2 * e + 1] |= (int)(unsigned)(fb >> 32); }
+                done += (int)__popcll(fb);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return rounds;
+}
+#endif
+
 OCTA_HD inline int murray_flush(const Blk &b, const SimArrays &A, int f, const SeqLds &L, int n_def) {
     if (n_def <= 0) return 0;
     int *ctl = b.coll() + 90;
@@ -1748,97 +1873,15 @@ OCTA_HD inline int murray_flush(const Blk &b, const SimArrays &A, int f, const S
 #if defined(__HIP_DEVICE_COMPILE__)
     if (n_def <= MURRAY_EPT * 64) {
         // the usual case (about 135 marked nodes per pass): ONE wave runs the rounds -- its LDS accesses are ordered, so the two block
-        // barriers per round are not needed and the finished count is a ballot.
-        // Round 6: the rounds no longer talk through HBM. A round used to read the children's radii from the global array the round before
-        // had written them to (store -> L2 -> load: ~2 us per round, ~30 rounds per pass, 31 ms per sample). Now every marked node has a
-        // list slot (slot_of, written by the walk that marked it), a finished radius goes to fl_val[slot] in the LDS with a bit in fl_done,
-        // and a parent reads its marked children from there; the radii of the UNMARKED children (final already) are fetched once, all at
-        // once, before the first round, and raised to the parent's kappa there. The global array still receives every radius (one store,
-        // nobody waits for it). Same values: a radius is a pure function of the children's radii, and a + b == b + a.
+        // barriers per round are not needed and the finished count is a ballot. (phase_seq normally defers the rounds to the other
+        // forest's pass; this synchronous form serves the end of a run.)
         static_assert(MURRAY_EPT * 64 <= MURRAY_FLUSH_LDS, "flush slots");
         if (b.tid < 64) {
-            const int lane = b.tid;
-            int node[MURRAY_EPT], s0[MURRAY_EPT], s1[MURRAY_EPT];
-            double kk[MURRAY_EPT], acc[MURRAY_EPT];
-            int pend[MURRAY_EPT];     // 1: marked child 0 not in yet, 2: marked child 1 not in yet, 4: radius not written yet, 8: written in this round
-            for (int w = lane; w < MURRAY_FLUSH_LDS / 32; w += 64) L.fl_done[w] = 0;
-            int c0[MURRAY_EPT], c1[MURRAY_EPT], nch[MURRAY_EPT];
-            for (int e = 0; e < MURRAY_EPT; e++) {
-                const int idx = lane + e * 64;
-                pend[e] = 0; node[e] = 0; c0[e] = c1[e] = 0; nch[e] = 0; kk[e] = 1; acc[e] = 0; s0[e] = s1[e] = 0;
-                if (idx < n_def) node[e] = A.act_list[idx];
-            }
-            for (int e = 0; e < MURRAY_EPT; e++) {
-                if (lane + e * 64 < n_def) {
-                    const WalkRec r = walk_load(A, f, node[e], false);
-                    c0[e] = r.c0; c1[e] = r.c1; kk[e] = r.k; nch[e] = r.nch;
-                }
-            }
-            // third round trip, all entries at once: the slot of a marked child, the radius of an unmarked one
-            double cv0[MURRAY_EPT], cv1[MURRAY_EPT];     // the children's radii: fetched here (unmarked) or read from fl_val when they come in
-            unsigned ready = 0;                          // bit 2e + c: child c of entry e has its radius in cv, its power not yet in acc
-            for (int e = 0; e < MURRAY_EPT; e++) {
-                cv0[e] = cv1[e] = 0.5;
-                if (lane + e * 64 >= n_def) continue;
-                pend[e] = 4;
-                if (nch[e] >= 1) { if (deferred_get(L, c0[e])) { pend[e] |= 1; s0[e] = L.slot_of[c0[e]]; } else { cv0[e] = rad[c0[e]]; ready |= 1u << (2 * e); } }
-                if (nch[e] >= 2) { if (deferred_get(L, c1[e])) { pend[e] |= 2; s1[e] = L.slot_of[c1[e]]; } else { cv1[e] = rad[c1[e]]; ready |= 2u << (2 * e); } }
-            }
-            // One pow evaluation per step for the whole wave, whatever entry and child it belongs to: written entry by entry (round 5) a round
-            // executed up to 3 x MURRAY_EPT evaluations one after the other -- every `if` with a taker among the 64 lanes --, ~2 us per round
-            // and 31 ms per sample although a round's takers are a handful of lanes with one item each.
-            auto drain = [&](unsigned items) {
-                while (__ballot(items != 0)) {
-                    const bool on = items != 0;
-                    const int t = on ? (int)__ffs((int)items) - 1 : 0;
-                    if (on) items &= items - 1u;
-                    double x = 0.5, k = 2.0;
-#pragma unroll
-                    for (int e = 0; e < MURRAY_EPT; e++) if ((t >> 1) == e) { x = (t & 1) ? cv1[e] : cv0[e]; k = kk[e]; }
-                    if (!on) { x = 0.5; k = 2.0; }
-                    const double pw = octa_gpow::gpow_t(x, k, L.log_tab, L.exp_tab);
-#pragma unroll
-                    for (int e = 0; e < MURRAY_EPT; e++) if (on && (t >> 1) == e) acc[e] = acc[e] + pw;
-                }
-            };
-            drain(ready);
+            FlushRec *recs = A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS;
+            murray_flush_prepare_wave(A, f, L, n_def, recs);
             __builtin_amdgcn_wave_barrier();
-            int done = 0;
-            while (done < n_def) {
-                rounds++;
-                ready = 0;
-                for (int e = 0; e < MURRAY_EPT; e++) {
-                    if (!(pend[e] & 4)) continue;
-                    if ((pend[e] & 1) && (((unsigned)L.fl_done[s0[e] >> 5] >> (s0[e] & 31)) & 1u)) { cv0[e] = L.fl_val[s0[e]]; ready |= 1u << (2 * e); pend[e] &= ~1; }
-                    if ((pend[e] & 2) && (((unsigned)L.fl_done[s1[e] >> 5] >> (s1[e] & 31)) & 1u)) { cv1[e] = L.fl_val[s1[e]]; ready |= 2u << (2 * e); pend[e] &= ~2; }
-                }
-                drain(ready);
-                unsigned fin = 0;
-                for (int e = 0; e < MURRAY_EPT; e++) if ((pend[e] & 4) && !(pend[e] & 3)) fin |= 1u << e;
-                while (__ballot(fin != 0)) {
-                    const bool on = fin != 0;
-                    const int t = on ? (int)__ffs((int)fin) - 1 : 0;
-                    if (on) fin &= fin - 1u;
-                    double a = 0.5, k = 2.0;
-#pragma unroll
-                    for (int e = 0; e < MURRAY_EPT; e++) if (t == e) { a = acc[e]; k = kk[e]; }
-                    if (!on) { a = 0.5; k = 2.0; }
-                    const double rp = octa_gpow::gpow_t(a, 1.0 / k, L.log_tab, L.exp_tab);
-#pragma unroll
-                    for (int e = 0; e < MURRAY_EPT; e++)
-                        if (on && t == e) { L.fl_val[lane + e * 64] = rp; rad[node[e]] = rp; pend[e] = 8; }
-                }
-                __builtin_amdgcn_wave_barrier();
-                for (int e = 0; e < MURRAY_EPT; e++) {
-                    const unsigned long long fb = __ballot(pend[e] == 8);       // slots e * 64 + lane
-                    if (pend[e] == 8) pend[e] = 0;
-                    if (fb) {
-                        if (lane == 0) { L.fl_done[2 * e] |= (int)(unsigned)fb; L.fl_done[2 * e + 1] |= (int)(unsigned)(fb >> 32); }
-                        done += (int)__popcll(fb);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
+            __threadfence_block();
+            rounds = murray_flush_rounds_wave(rad, L.log_tab, L.exp_tab, L.fl_val, L.fl_done, recs, n_def);
         }
         b.sync();
         return rounds;
@@ -2841,7 +2884,23 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
 #else
 #define SEQT(slot, stmt) do { stmt; } while (0)
 #endif
+    // deferred Murray flush (round 6): the rounds of the OTHER forest's last pass run here as a side job (third wave); this pass's own marked
+    // nodes are only prepared at its end and evaluated beside the other forest's next pass. Nothing reads a forest's upper radii in between:
+    // arterial radii are read by phase_sample / phase_pre of the next iteration (behind the venous pass), venous radii by the next venous
+    // phase_pre (behind the arterial pass).
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int pend_other = OCTA_UNI(sc->fl_pending[1 - f]), pend_own = OCTA_UNI(sc->fl_pending[f]);
+#endif
     long t_acc[4] = {0, 0, 0, 0};  // murray, re-speculation, visits, -
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (pend_own > 0) {       // (the passes alternate between the forests, so this forest's last flush has run beside the other's pass; kept for callers that break the order)
+        if (b.tid < 64) {
+            murray_flush_rounds_wave(L.rad, L.log_tab, L.exp_tab, L.fl_val, L.fl_done, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS, pend_own);
+            if (b.tid == 0) sc->fl_pending[f] = 0;
+        }
+        b.sync();
+    }
+#endif
 #if defined(OCTA_SIM_PROF_SEQ2) && defined(__HIP_DEVICE_COMPILE__)
     // second diagnostic build of the pass: kd slots 0..6 = ticks in the walks' chain enumeration (tag test included), in leaf bodies, in inter-node
     // bodies (walks excluded), in re-speculations, in the walks' eager parts; walks with an eager part, ancestors enumerated (counts)
@@ -2961,7 +3020,11 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
             if (err) sc->err |= err;
             sc->murray_steps += steps + n_def;
             sc->murray_deferred += n_def;
+#if defined(__HIP_DEVICE_COMPILE__)
+            b.coll()[91] = n_def <= MURRAY_EPT * 64 ? 0 : n_def;        // > 0: evaluated at once by the whole workgroup, below
+#else
             b.coll()[91] = n_def;
+#endif
             sc->n_bif += n_bif;
             sc->respec += respec;
             sc->kdprof[7] += t_acc[0]; (void)t_acc[1]; (void)t_acc[2];
@@ -2973,10 +3036,23 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
             sc->kdprof[1] += (long)wall_clock64() - _q1; sc->kdprof[2] += t_acc[0]; sc->kdprof[4] += t_acc[2]; sc->kdprof[5] += t_acc[3]; sc->kdprof[6] += n_def;
 #endif
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (n_def > 0 && n_def <= MURRAY_EPT * 64) {
+            // this pass's marked nodes: records now (they need the marked bitmap, which dies with the pass), rounds beside the other forest's pass
+            const long tp0 = (long)wall_clock64();
+            murray_flush_prepare_wave(A, f, L, n_def, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS);
+            if (b.tid == 0) { sc->fl_pending[f] = n_def; sc->kdprof[7] += (long)wall_clock64() - tp0; }
+        }
+#endif
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     else if (b.tid < 128) {
         side(side_lds);
+    } else if (b.tid < 192) {
+        if (pend_other > 0) {
+            const int rounds = murray_flush_rounds_wave(A.nrad_of(1 - f), L.log_tab, L.exp_tab, L.fl_val, L.fl_done, A.fl_rec + (size_t)(1 - f) * MURRAY_FLUSH_LDS, pend_other);
+            if (b.tid == 128) { sc->fl_pending[1 - f] = 0; sc->flush_rounds += rounds; }
+        }
     }
 #else
     (void)side; (void)side_lds;
@@ -2998,6 +3074,27 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
         }
     }
     b.sync();
+}
+
+// The run is over (or a caller wants final radii): evaluate whatever a forest's last ordered pass left for "the other forest's next pass".
+// One wave, the constant pow tables, fl_val / fl_done at the start of the table area.
+OCTA_HD inline void murray_flush_pending(const Blk &b, const SimArrays &A) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    b.sync();
+    double *fl_val = reinterpret_cast<double *>(b.user_of<8>());
+    int *fl_done = reinterpret_cast<int *>(fl_val + MURRAY_FLUSH_LDS);
+    for (int f = 0; f < 2; f++) {
+        const int n = OCTA_UNI(A.sc->fl_pending[f]);
+        if (n <= 0) continue;              // block-uniform
+        if (b.tid < 64) {
+            const int rounds = murray_flush_rounds_wave(A.nrad_of(f), octa_gpow::LOG_TAB, octa_gpow::EXP_TAB, fl_val, fl_done, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS, n);
+            if (b.tid == 0) { A.sc->fl_pending[f] = 0; A.sc->flush_rounds += rounds; }
+        }
+        b.sync();
+    }
+#else
+    (void)b; (void)A;
+#endif
 }
 
 // stable removal of flagged points from an ordered list (element_mesh.py:196-211 delete_all), IN PLACE: a point only moves towards
