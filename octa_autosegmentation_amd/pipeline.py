@@ -166,6 +166,18 @@ class TripleGenerator:
         e[:, 6] = 0.002 + 0.004 * e[:, 6]
         off = np.arange(n + 1, dtype=np.int64) * edges_per_sample
         fake = type("Primer", (), {"d_edges": e, "edges": None, "edge_off": off, "n_art": np.full(n, edges_per_sample // 2, np.int64)})()
+        if self.sim_gate is not None and self._gated_streams is None:
+            # the two streams of a gated generator, each used once: their hardware queues exist before the first timed launch
+            self._gated_streams = (torch.cuda.Stream(device=self.device, priority=-1), torch.cuda.Stream(device=self.device, priority=0))
+            for st in self._gated_streams:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=self.device)
+                st.synchronize()
+        if self._gated_streams is not None:
+            with torch.cuda.stream(self._gated_streams[1]):
+                self._render(fake, True)
+                self._gated_streams[1].synchronize()
+            return
         self._render(fake, True)
 
     def generate(self, seeds, want_label=True):
