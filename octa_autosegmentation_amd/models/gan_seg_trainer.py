@@ -14,7 +14,8 @@ from .segmentation_trainer import _complete
 
 
 class GanSegTrainer:
-    def __init__(self, config, device, upshape=(1216, 1216)):
+    def __init__(self, config, device, upshape=(1216, 1216), args=None):
+        """args: the command line namespace of train.py (`start_epoch` > 0 resumes from `Output.save_dir`/checkpoints/`epoch`_*); None = a fresh model."""
         self.device = torch.device(device)
         self.config = _complete(config, self.device)
         self.config["General"]["model"].setdefault("upshape", tuple(upshape))
@@ -22,7 +23,7 @@ class GanSegTrainer:
         tr.setdefault("loss_dg", "LSGANLoss"); tr.setdefault("loss_s", "DiceBCELoss")
         tr.setdefault("epochs", 100); tr.setdefault("epochs_decay", 0)
         self.impl = define_model(deepcopy(self.config), Phase.TRAIN)
-        self.impl.initialize_model_and_optimizer(None, init_weights, self.config, Namespace(start_epoch=0, epoch="latest"), None, Phase.TRAIN)
+        self.impl.initialize_model_and_optimizer(None, init_weights, self.config, args or Namespace(start_epoch=0, epoch="latest"), None, Phase.TRAIN)
         self.impl.train()
 
     def __getattr__(self, name):            # generator, discriminator, segmentor, optimizer_G/D/S, lr_schedulers, ...

@@ -132,6 +132,27 @@ def test_lr_schedulers_attach_like_the_reference_by_default():
     cfg2 = {**base, "Train": {**base["Train"], "lr_scheduler_per_optimizer": True}}
     tr2 = GanSegTrainer(cfg2, "cpu")
     assert [s.optimizer for s in tr2.lr_schedulers] == [tr2.optimizer_G, tr2.optimizer_D, tr2.optimizer_S]
+    for _ in range(3):
+        for o in (tr2.optimizer_G, tr2.optimizer_D, tr2.optimizer_S):
+            o.step()
+        for s in tr2.lr_schedulers:
+            s.step()
+    assert all(abs(lr(o) - 1e-4) < 1e-12 for o in (tr2.optimizer_G, tr2.optimizer_D, tr2.optimizer_S))
+    # a save / resume of the multi-optimiser model under both settings (advisor, round 5): optimiser state comes back per optimiser, the
+    # schedulers are NOT part of a checkpoint (as in the reference) and re-attach by the setting of the resuming run
+    import tempfile
+    from types import SimpleNamespace
+    from octa_autosegmentation_amd.utils import checkpoints
+    from octa_autosegmentation_amd.utils.enums import Phase
+    with tempfile.TemporaryDirectory() as d:
+        checkpoints.save_epoch(d, tr, 2, base, save_interval=10, save_best=False)
+        for per in (False, True):
+            cfg3 = {"General": dict(base["General"]), "Train": {**base["Train"], "lr_scheduler_per_optimizer": per}, "Output": {"save_dir": d}}
+            tr3 = GanSegTrainer(cfg3, "cpu", args=SimpleNamespace(start_epoch=3, epoch="latest"))
+            want = [tr3.optimizer_G, tr3.optimizer_D, tr3.optimizer_S] if per else [tr3.optimizer_S] * 3
+            assert [s.optimizer for s in tr3.lr_schedulers] == want
+            for k, v in tr.generator.state_dict().items():
+                assert torch.equal(v, tr3.generator.state_dict()[k]), k
 
 
 def test_t1x1_packs_follow_the_invalidation_epoch():
