@@ -199,7 +199,7 @@ struct SimArrays {
     Rec *rec;            // [GCAP]
     int *glist;          // [GCAP] groups that grow under the speculation, ascending (dict order)
     int *child_group;    // [NCAP] tag<<14 | grow<<13 | group of the inter-node whose first child this node is
-    FlushRec *fl_rec;    // [2][256] records of the forests' deferred Murray flushes (MURRAY_FLUSH_LDS each)
+    FlushRec *fl_rec;    // [2][MURRAY_FLUSH_LDS] records of the forests' deferred Murray flushes
     idx_t *kd_idx, *kd_rank;  // [OCAP]
     unsigned char *removed;  // [OCAP]
     unsigned char *ven_near; // [OCAP]
@@ -1505,7 +1505,8 @@ struct SeqLds {
     int *fl_done;              // [MURRAY_FLUSH_LDS / 32] bitmap: slot finished in an earlier round
     int *slot_of;              // [NCAP] (HBM scratch) list slot of a deferred node, written by the walk that marks it
 };
-constexpr int MURRAY_FLUSH_LDS = 256;   // deferred nodes of a pass the one-wave flush keeps in the LDS (4 per lane)
+constexpr int MURRAY_FLUSH_WAVE = 256;  // deferred nodes one wave of the flush keeps in registers (4 per lane)
+constexpr int MURRAY_FLUSH_LDS = 3 * MURRAY_FLUSH_WAVE;   // deferred nodes of a pass whose finished radii / done bits live in the LDS: up to three waves share the rounds
 // PAR_TAG: the node carries THIS pass's tag in child_group, i.e. it is the child of an inter-node group of the pass. A walk that meets
 // no such node has no eager part and needs no topology record from HBM at all (round 6).
 constexpr int PAR_BITS = (int)sizeof(idx_t) * 8 - 2;
@@ -1752,8 +1753,9 @@ constexpr int MURRAY_EPT = OCTA_MURRAY_EPT;
 // step for the whole wave. The rounds are a dependency chain of ~30 levels x 2 evaluations (27 ms per sample) that nothing reads before the
 // OTHER forest's ordered pass is over (arterial radii: phase_sample / phase_pre of the next iteration; venous radii: the next phase_pre of
 // the venous side), so they run as a side job of that pass on a wave that idles there (phase_seq).
-__device__ inline void murray_flush_prepare_wave(const SimArrays &A, int f, const SeqLds &L, int n_def, FlushRec *recs) {
-    const int lane = (int)(threadIdx.x & 63);
+__device__ inline void murray_flush_prepare_wave(const SimArrays &A, int f, const SeqLds &L, int n_def, FlushRec *recs, int base = 0) {
+    // entries [base, base + MURRAY_FLUSH_WAVE) of the list (a longer list is prepared chunk by chunk: the entries are independent here)
+    const int lane = (int)(threadIdx.x & 63) + base;
     double *rad = L.rad;
     int node[MURRAY_EPT], s0[MURRAY_EPT], s1[MURRAY_EPT];
     double kk[MURRAY_EPT], acc[MURRAY_EPT];
@@ -1801,12 +1803,18 @@ __device__ inline void murray_flush_prepare_wave(const SimArrays &A, int f, cons
 }
 
 // rad: the forest's radii; fl_val [MURRAY_FLUSH_LDS] doubles and fl_done [MURRAY_FLUSH_LDS / 32] ints of LDS that belong to the calling wave
+// base: this wave's entries are [base, base + MURRAY_FLUSH_WAVE) of a list of n_def; the waves of a longer list run side by side WITHOUT
+// barriers: a slot's radius is stored before its done bit (one wave's LDS operations execute in order), a wave that finds nothing ready
+// looks again. With at most two children per node the sum of a node is the same in whatever order the children finish.
+// cleared: the caller zeroed fl_done in front of a barrier (several waves); otherwise this wave clears it (one wave alone).
 __device__ inline int murray_flush_rounds_wave(double *rad, const double *log_tab, const uint64_t *exp_tab, double *fl_val, int *fl_done,
-                                               const FlushRec *recs, int n_def) {
-    const int lane = (int)(threadIdx.x & 63);
+                                               const FlushRec *recs, int n_def, int base = 0, bool cleared = false) {
+    const int lane = (int)(threadIdx.x & 63) + base;
     int node[MURRAY_EPT], s0[MURRAY_EPT], s1[MURRAY_EPT], pend[MURRAY_EPT];
     double kk[MURRAY_EPT], acc[MURRAY_EPT], cv0[MURRAY_EPT], cv1[MURRAY_EPT];
-    for (int w = lane; w < MURRAY_FLUSH_LDS / 32; w += 64) fl_done[w] = 0;
+    if (!cleared) for (int w = lane - base; w < MURRAY_FLUSH_LDS / 32; w += 64) fl_done[w] = 0;
+    n_def = n_def - base < MURRAY_FLUSH_WAVE ? n_def : base + MURRAY_FLUSH_WAVE;      // one past this wave's last entry
+    const int n_own = n_def - base;
     for (int e = 0; e < MURRAY_EPT; e++) {
         const int idx = lane + e * 64;
         node[e] = 0; s0[e] = s1[e] = 0; pend[e] = 0; kk[e] = 1; acc[e] = 0; cv0[e] = cv1[e] = 0.5;
@@ -1814,13 +1822,27 @@ __device__ inline int murray_flush_rounds_wave(double *rad, const double *log_ta
     }
     __builtin_amdgcn_wave_barrier();
     int rounds = 0, done = 0;
-    while (done < n_def) {
+    auto done_word = [&](int slot) { return (unsigned)__hip_atomic_load(fl_done + (slot >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    while (done < n_own) {
         rounds++;
         unsigned ready = 0;
-        for (int e = 0; e < MURRAY_EPT; e++) {
-            if (!(pend[e] & 4)) continue;
-            if ((pend[e] & 1) && (((unsigned)fl_done[s0[e] >> 5] >> (s0[e] & 31)) & 1u)) { cv0[e] = fl_val[s0[e]]; ready |= 1u << (2 * e); pend[e] &= ~1; }
-            if ((pend[e] & 2) && (((unsigned)fl_done[s1[e] >> 5] >> (s1[e] & 31)) & 1u)) { cv1[e] = fl_val[s1[e]]; ready |= 2u << (2 * e); pend[e] &= ~2; }
+        {   // the done words of all waiting children first (independent LDS reads, one wait), then the finished children's radii (likewise)
+            unsigned dw0[MURRAY_EPT], dw1[MURRAY_EPT];
+#pragma unroll
+            for (int e = 0; e < MURRAY_EPT; e++) {
+                dw0[e] = (pend[e] & 1) ? done_word(s0[e]) : 0u;
+                dw1[e] = (pend[e] & 2) ? done_word(s1[e]) : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < MURRAY_EPT; e++) {
+                if ((pend[e] & 1) && ((dw0[e] >> (s0[e] & 31)) & 1u)) { ready |= 1u << (2 * e); pend[e] &= ~1; }
+                if ((pend[e] & 2) && ((dw1[e] >> (s1[e] & 31)) & 1u)) { ready |= 2u << (2 * e); pend[e] &= ~2; }
+            }
+#pragma unroll
+            for (int e = 0; e < MURRAY_EPT; e++) {
+                if (ready & (1u << (2 * e))) cv0[e] = *(volatile double *)(fl_val + s0[e]);
+                if (ready & (2u << (2 * e))) cv1[e] = *(volatile double *)(fl_val + s1[e]);
+            }
         }
         while (__ballot(ready != 0)) {
             const bool on = ready != 0;
@@ -1847,18 +1869,25 @@ __device__ inline int murray_flush_rounds_wave(double *rad, const double *log_ta
             const double rp = octa_gpow::gpow_t(a, 1.0 / k, log_tab, exp_tab);
 #pragma unroll
             for (int e = 0; e < MURRAY_EPT; e++)
-                if (on && t == e) { fl_val[lane + e * 64] = rp; rad[node[e]] = rp; pend[e] = 8; }
+                if (on && t == e) { *(volatile double *)(fl_val + lane + e * 64) = rp; rad[node[e]] = rp; pend[e] = 8; }
         }
         __builtin_amdgcn_wave_barrier();
+        bool any = false;
         for (int e = 0; e < MURRAY_EPT; e++) {
-            const unsigned long long fb = __ballot(pend[e] == 8);       // slots e * 64 + lane
+            const unsigned long long fb = __ballot(pend[e] == 8);       // slots base + e * 64 + (lane - base)
             if (pend[e] == 8) pend[e] = 0;
             if (fb) {
-                if (lane == 0) { fl_done[2 * e] |= (int)(unsigned)fb; fl_done[2 * e + 1] |= (int)(unsigned)(fb >> 32); }
+                if (lane == base) {
+                    int *w = fl_done + (base >> 5) + 2 * e;
+                    __hip_atomic_fetch_or(w, (int)(unsigned)fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(w + 1, (int)(unsigned)(fb >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 done += (int)__popcll(fb);
+                any = true;
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (!any) __builtin_amdgcn_s_sleep(2);                    // waiting for another wave's slots: leave the issue port to the SIMD's other wave
     }
     return rounds;
 }
@@ -2872,7 +2901,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     }
     for (int i = b.tid; i < 384; i += b.nth) ltab[i] = octa_gpow::LOG_TAB[i];
     for (int i = b.tid; i < 256; i += b.nth) etab[i] = octa_gpow::EXP_TAB[i];
-    for (int i = b.tid; i < DEF_WORDS + CHG_WORDS; i += b.nth) L.deferred[i] = 0;      // both bitmaps
+    for (int i = b.tid; i < DEF_WORDS + CHG_WORDS + FLD_WORDS; i += b.nth) L.deferred[i] = 0;      // both bitmaps and the flush's done bits (adjacent)
     if (b.tid == 0) b.coll()[91] = 0;
     b.sync();
 #if defined(OCTA_SIM_PROF_SEQ) && defined(__HIP_DEVICE_COMPILE__)
@@ -2894,10 +2923,12 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     long t_acc[4] = {0, 0, 0, 0};  // murray, re-speculation, visits, -
 #if defined(__HIP_DEVICE_COMPILE__)
     if (pend_own > 0) {       // (the passes alternate between the forests, so this forest's last flush has run beside the other's pass; kept for callers that break the order)
-        if (b.tid < 64) {
-            murray_flush_rounds_wave(L.rad, L.log_tab, L.exp_tab, L.fl_val, L.fl_done, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS, pend_own);
-            if (b.tid == 0) sc->fl_pending[f] = 0;
-        }
+        const int wv = b.tid >> 6;
+        if (wv * MURRAY_FLUSH_WAVE < pend_own)
+            murray_flush_rounds_wave(L.rad, L.log_tab, L.exp_tab, L.fl_val, L.fl_done, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS, pend_own, wv * MURRAY_FLUSH_WAVE, true);
+        b.sync();
+        if (b.tid == 0) sc->fl_pending[f] = 0;
+        for (int i = b.tid; i < FLD_WORDS; i += b.nth) L.fl_done[i] = 0;
         b.sync();
     }
 #endif
@@ -3021,7 +3052,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
             sc->murray_steps += steps + n_def;
             sc->murray_deferred += n_def;
 #if defined(__HIP_DEVICE_COMPILE__)
-            b.coll()[91] = n_def <= MURRAY_EPT * 64 ? 0 : n_def;        // > 0: evaluated at once by the whole workgroup, below
+            b.coll()[91] = n_def <= MURRAY_FLUSH_LDS ? 0 : n_def;        // > 0: evaluated at once by the whole workgroup, below
 #else
             b.coll()[91] = n_def;
 #endif
@@ -3037,21 +3068,27 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
 #endif
         }
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (n_def > 0 && n_def <= MURRAY_EPT * 64) {
+        if (n_def > 0 && n_def <= MURRAY_FLUSH_LDS) {
             // this pass's marked nodes: records now (they need the marked bitmap, which dies with the pass), rounds beside the other forest's pass
             const long tp0 = (long)wall_clock64();
-            murray_flush_prepare_wave(A, f, L, n_def, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS);
+            for (int base = 0; base < n_def; base += MURRAY_FLUSH_WAVE)
+                murray_flush_prepare_wave(A, f, L, n_def, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS, base);
             if (b.tid == 0) { sc->fl_pending[f] = n_def; sc->kdprof[7] += (long)wall_clock64() - tp0; }
         }
 #endif
     }
 #if defined(__HIP_DEVICE_COMPILE__)
-    else if (b.tid < 128) {
-        side(side_lds);
-    } else if (b.tid < 192) {
-        if (pend_other > 0) {
-            const int rounds = murray_flush_rounds_wave(A.nrad_of(1 - f), L.log_tab, L.exp_tab, L.fl_val, L.fl_done, A.fl_rec + (size_t)(1 - f) * MURRAY_FLUSH_LDS, pend_other);
-            if (b.tid == 128) { sc->fl_pending[1 - f] = 0; sc->flush_rounds += rounds; }
+    else {
+        // the other forest's deferred rounds: the third wave takes the first 256 list slots, the fourth the next, the second -- behind its
+        // side job, which only the arterial pass has -- the last; the waves of one list run side by side without barriers
+        static_assert(SIM_THREADS_PER_WG == 256, "the ordered pass hands its side work to waves 1 - 3");
+        const int wv = b.tid >> 6;
+        if (wv == 1) side(side_lds);
+        const int base = (wv == 2 ? 0 : (wv == 3 ? 1 : 2)) * MURRAY_FLUSH_WAVE;
+        if (base < pend_other) {
+            const int rounds = murray_flush_rounds_wave(A.nrad_of(1 - f), L.log_tab, L.exp_tab, L.fl_val, L.fl_done, A.fl_rec + (size_t)(1 - f) * MURRAY_FLUSH_LDS,
+                                                        pend_other, base, true);
+            if (b.tid == 128) sc->flush_rounds += rounds;
         }
     }
 #else
@@ -3063,6 +3100,9 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
 #undef SEQ2_END
 #undef SEQ2_ARG
     b.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (b.tid == 0 && pend_other > 0) sc->fl_pending[1 - f] = 0;
+#endif
     {
         long t0 = OCTA_FLUSH_T0();
         const int rounds = murray_flush(b, A, f, L, b.coll()[91]);
@@ -3086,8 +3126,12 @@ OCTA_HD inline void murray_flush_pending(const Blk &b, const SimArrays &A) {
     for (int f = 0; f < 2; f++) {
         const int n = OCTA_UNI(A.sc->fl_pending[f]);
         if (n <= 0) continue;              // block-uniform
-        if (b.tid < 64) {
-            const int rounds = murray_flush_rounds_wave(A.nrad_of(f), octa_gpow::LOG_TAB, octa_gpow::EXP_TAB, fl_val, fl_done, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS, n);
+        for (int i = b.tid; i < MURRAY_FLUSH_LDS / 32; i += b.nth) fl_done[i] = 0;
+        b.sync();
+        const int wv = b.tid >> 6;
+        if (wv * MURRAY_FLUSH_WAVE < n) {
+            const int rounds = murray_flush_rounds_wave(A.nrad_of(f), octa_gpow::LOG_TAB, octa_gpow::EXP_TAB, fl_val, fl_done, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS, n,
+                                                        wv * MURRAY_FLUSH_WAVE, true);
             if (b.tid == 0) { A.sc->fl_pending[f] = 0; A.sc->flush_rounds += rounds; }
         }
         b.sync();
