@@ -371,6 +371,7 @@ struct HostMail {
     long park_ticks;     // a workgroup that has waited this long parks (0: never, wait until timeout_ticks as round 1 did)
     int *launch_flag;    // device [8]: the launches' sign-in block (csrc/sim_api.cpp octa_sim_launch_flag), or NULL
     int ticket;          // this launch's ticket
+    long *req_time;      // pinned host [B]: device clock at publication (-DOCTA_SIM_PROF_MAIL builds write it, OCTA_SIM_MAIL_DIAG=1 reads it)
 };
 constexpr int REQ_PER_SAMPLE = OCTA_SIM_LARGE ? 256 : 32;    // bifurcation requests of one sample per mailbox round trip (6.2 KB each, pinned host memory)
 constexpr int ERR_HOST_TIMEOUT = 2048;
@@ -397,6 +398,7 @@ __device__ inline int mail_roundtrip(const Blk &b, const SimArrays &A, const Hos
         if (n_req > REQ_PER_SAMPLE) { atomicOr(&A.sc->err, ERR_REQ_CAP); n_req = REQ_PER_SAMPLE; }
 #ifdef OCTA_SIM_PROF_MAIL            // diagnostic build: kd slots 0..2 = ticks spent publishing (fences + stores), polls, round trips
         const long t_pub = (long)wall_clock64();
+        __hip_atomic_store(M.req_time + s, t_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
         __threadfence_system();      // the request records (written by the whole block before the barrier)
         __hip_atomic_store(M.req_n + s, n_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -674,7 +676,7 @@ struct OCTA_SIM_T {
     BifRequest *h_reqs = nullptr;   // pinned [2*REQ_CAP]
     double *h_results = nullptr;    // pinned [2*REQ_CAP*6]
     int *h_req_count = nullptr;     // pinned [2]
-    HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};  // pinned mailbox of the persistent form
+    HostMail mail = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr};  // pinned mailbox of the persistent form
     bool lockstep = false;          // OCTA_SIM_LOCKSTEP=1: two launches per iteration (the round-1 form)
     double mail_timeout_ms = 30000; // OCTA_SIM_MAIL_TIMEOUT_MS: device-side bound on one wait for the host when parking is off
     double park_ms = 100.0;         // OCTA_SIM_PARK_MS: a workgroup that has waited this long for its answer parks (0: never). Normal answers
@@ -689,7 +691,7 @@ struct OCTA_SIM_T {
     int test_stall_ms = 0;          // OCTA_SIM_TEST_HOST_STALL_MS (test hook): the service thread sleeps once with a ticket pending
     long spin_scans = 4096;         // idle mailbox scans before the service thread starts sleeping 20 us between scans
     double diag_max_gap_ms = 0, diag_max_bif_ms = 0;
-    long diag_tickets = 0, diag_relaunches = 0, diag_parked = 0;
+    long diag_tickets = 0, diag_relaunches = 0, diag_parked = 0, diag_passes = 0;
     bool ran = false;
     void *init_stage = nullptr;     // pinned staging of a run's per-sample set-up (valid-voxel lists, generator states)
     size_t init_stage_bytes = 0;
@@ -852,9 +854,9 @@ extern "C" int octa_sim_create(octa_ctx *ctx, const octa_sim_config *c, int B, O
         const unsigned fl = hipHostMallocCoherent | hipHostMallocMapped;
         hipError_t e1 = hipHostMalloc((void **)&S->mail.reqs, sizeof(BifRequest) * nb * REQ_PER_SAMPLE, fl);
         hipError_t e2 = hipHostMalloc((void **)&S->mail.results, sizeof(double) * nb * REQ_PER_SAMPLE * 6, fl);
-        hipError_t e3 = hipHostMalloc((void **)&S->mail.req_n, sizeof(int) * (nb * 3 + 16), fl);
+        hipError_t e3 = hipHostMalloc((void **)&S->mail.req_n, sizeof(int) * (nb * 5 + 18), fl);      // + [B] longs: publication stamps of the diagnostic build
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { octa::set_error("octa_sim_create: hipHostMalloc (mailbox) failed"); rc = -1; }
-        else { S->mail.req_ticket = S->mail.req_n + nb; S->mail.resp_ticket = S->mail.req_n + 2 * nb; S->mail.done = S->mail.req_n + 3 * nb; }
+        else { S->mail.req_ticket = S->mail.req_n + nb; S->mail.resp_ticket = S->mail.req_n + 2 * nb; S->mail.done = S->mail.req_n + 3 * nb; S->mail.req_time = reinterpret_cast<long *>(S->mail.req_n + ((3 * nb + 16 + 1) & ~(size_t)1)); }
         const char *ls = getenv("OCTA_SIM_LOCKSTEP");
         S->lockstep = ls && ls[0] == '1';
         if (const char *e = getenv("OCTA_SIM_MAIL_TIMEOUT_MS")) { double v = atof(e); if (v >= 1.0) S->mail_timeout_ms = v; }
@@ -1089,10 +1091,16 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
         using clk = std::chrono::steady_clock;
         M.timeout_ticks = (long)(S->mail_timeout_ms * 1e5);
         M.park_ticks = (long)(S->park_ms * 1e5);
-        S->diag_max_gap_ms = 0; S->diag_tickets = 0; S->diag_max_bif_ms = 0; S->diag_relaunches = 0; S->diag_parked = 0;
+        S->diag_max_gap_ms = 0; S->diag_tickets = 0; S->diag_max_bif_ms = 0; S->diag_relaunches = 0; S->diag_parked = 0; S->diag_passes = 0;
         S->h_sc.resize(B);
         bool stalled_once = false;
         double ms_kernels = 0;
+        // OCTA_SIM_MAIL_DIAG=1 (tools/sim_mailbox_profile.py): what a ticket waits for, from the host's side -- passes of this loop, and, with a
+        // -DOCTA_SIM_PROF_MAIL library, the device's publication stamp against the host's clock
+        const bool mail_diag = getenv("OCTA_SIM_MAIL_DIAG") != nullptr;
+        double diag_min_d = 1e300, diag_sum_serv = 0;
+        std::vector<double> diag_lat;
+        long pass_hist[6] = {0, 0, 0, 0, 0, 0};
         int launches = 0;
         auto answer = [&](int s, int n) {
             if (n > REQ_PER_SAMPLE) n = REQ_PER_SAMPLE;
@@ -1106,6 +1114,7 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
         };
         while (true) {
             for (int s = 0; s < 3 * B + 1; s++) M.req_n[s] = 0;
+            memset(M.req_time, 0, sizeof(long) * (size_t)B);
             std::vector<int> seen(B, 0);
             OCTA_HIP_CHECK(hipMemsetAsync(P.next_sample, 0, sizeof(int), stream));
             // this launch's ticket and its sign-in counter (csrc/sim_api.cpp): the counter of the launch before the previous one is reused
@@ -1130,9 +1139,11 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
                     const auto t = clk::now();
                     const double it_ms = std::chrono::duration<double, std::milli>(t - iter_start).count();
                     if (it_ms > S->diag_max_gap_ms) S->diag_max_gap_ms = it_ms;
+                    if (mail_diag) pass_hist[it_ms < 0.01 ? 0 : it_ms < 0.03 ? 1 : it_ms < 0.1 ? 2 : it_ms < 0.3 ? 3 : it_ms < 1.0 ? 4 : 5]++;
                     iter_start = t;
                 }
                 bool any = false;
+                S->diag_passes++;
                 for (int s = 0; s < B; s++) {
                     const int t = __atomic_load_n(M.req_ticket + s, __ATOMIC_ACQUIRE);
                     if (t == seen[s]) continue;
@@ -1141,8 +1152,15 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
                         stalled_once = true;
                         std::this_thread::sleep_for(std::chrono::milliseconds(S->test_stall_ms));
                     }
+                    const auto h_seen = clk::now();
                     answer(s, __atomic_load_n(M.req_n + s, __ATOMIC_RELAXED));
                     __atomic_store_n(M.resp_ticket + s, t, __ATOMIC_RELEASE);
+                    if (mail_diag) {      // host clock at sighting / answer against the device's publication stamp (clock offset = the smallest difference seen)
+                        const double d = std::chrono::duration<double, std::micro>(h_seen - wall0).count() - (double)__atomic_load_n(M.req_time + s, __ATOMIC_RELAXED) * 1e-2;
+                        if (d < diag_min_d) diag_min_d = d;
+                        diag_sum_serv += std::chrono::duration<double, std::micro>(clk::now() - h_seen).count();
+                        diag_lat.push_back(d);
+                    }
                     seen[s] = t;
                     S->diag_tickets++;
                 }
@@ -1180,6 +1198,18 @@ int sim_run_impl(OCTA_SIM_T *S, const SampleSource &src, octa_bif_fn bif, void *
         }
         const float ms = (float)ms_kernels;
         S->ms_b = ms; S->n_b = launches;
+        if (mail_diag) {
+            fprintf(stderr, "[octa] mailbox service: %ld passes over %d tickets in %.1f ms of kernel (%.2f us per pass; <10 us %ld, <30 %ld, <100 %ld, <300 %ld, <1000 %ld, longer %ld; longest %.3f ms), "
+                            "%ld tickets, %.1f ms in the callback\n", S->diag_passes, B, ms_kernels, 1e3 * ms_kernels / (double)(S->diag_passes ? S->diag_passes : 1),
+                    pass_hist[0], pass_hist[1], pass_hist[2], pass_hist[3], pass_hist[4], pass_hist[5], S->diag_max_gap_ms, S->diag_tickets, S->ms_host_bif);
+            if (!diag_lat.empty() && S->mail.req_time[0] != 0) {
+                long h[7] = {0, 0, 0, 0, 0, 0, 0};
+                double sum = 0;
+                for (double d : diag_lat) { const double x = d - diag_min_d; sum += x; h[x < 10 ? 0 : x < 30 ? 1 : x < 100 ? 2 : x < 300 ? 3 : x < 1000 ? 4 : x < 3000 ? 5 : 6]++; }
+                fprintf(stderr, "[octa]   publication (device clock) -> seen by the host, above the fastest ticket: %.1f us on average (<10 us %ld, <30 %ld, <100 %ld, <300 %ld, <1000 %ld, <3000 %ld, "
+                                "longer %ld); seen -> answered %.1f us\n", sum / (double)diag_lat.size(), h[0], h[1], h[2], h[3], h[4], h[5], h[6], diag_sum_serv / (double)diag_lat.size());
+            }
+        }
     } else
     for (int it = 0; it <= C.n_iter; it++) {
         float ms = 0;
