@@ -33,7 +33,10 @@ OCTA_HD inline double asf64(uint64_t u) { double f; memcpy(&f, &u, 8); return f;
 OCTA_HD inline double fma_(double a, double b, double c) { return ::fma(a, b, c); }
 
 // log_tab / exp_tab: LOG_TAB / EXP_TAB or copies of them (the ordered pass keeps copies in LDS)
-OCTA_HD inline double gpow_t(double x, double y, const double *log_tab, const uint64_t *exp_tab) {
+// UNI: every lane of the wave passes the same (x, y) -- the table indices are declared wave-uniform, so that with the constant tables
+// (LOG_TAB / EXP_TAB) the entries come through the scalar data cache instead of an LDS / vector-memory round trip per lookup.
+template <bool UNI>
+OCTA_HD inline double gpow_impl(double x, double y, const double *log_tab, const uint64_t *exp_tab) {
     const uint64_t ix = asu64(x), iy = asu64(y);
     const uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52);
     // glibc's special-case gate: x subnormal/zero/negative/inf/nan, or |y| tiny/huge/inf/nan
@@ -42,6 +45,9 @@ OCTA_HD inline double gpow_t(double x, double y, const double *log_tab, const ui
     const uint64_t OFF = 0x3fe6955500000000ULL;
     uint64_t tmp = ix - OFF;
     int i = (int)((tmp >> (52 - 7)) % 128);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (UNI) i = __builtin_amdgcn_readfirstlane(i);
+#endif
     int k = (int)((int64_t)tmp >> 52);
     uint64_t iz = ix - (tmp & (0xfffULL << 52));
     double z = asf64(iz), kd = (double)k;
@@ -80,6 +86,9 @@ OCTA_HD inline double gpow_t(double x, double y, const double *log_tab, const ui
     double rr = fma_(kd2, NEGLN2LON, fma_(kd2, NEGLN2HIN, ehi));
     rr += elo;
     uint64_t idx = 2 * (ki % 128);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (UNI) idx = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+#endif
     uint64_t top = ki << (52 - 7);
     double etail = asf64(exp_tab[idx]);
     uint64_t sbits = exp_tab[idx + 1] + top;
@@ -91,6 +100,9 @@ OCTA_HD inline double gpow_t(double x, double y, const double *log_tab, const ui
     return fma_(scale, tm, scale);
 }
 
+OCTA_HD inline double gpow_t(double x, double y, const double *log_tab, const uint64_t *exp_tab) { return gpow_impl<false>(x, y, log_tab, exp_tab); }
 OCTA_HD inline double gpow(double x, double y) { return gpow_t(x, y, LOG_TAB, EXP_TAB); }
+// wave-uniform arguments (device: all lanes of the calling wave active and equal)
+OCTA_HD inline double gpow_u(double x, double y) { return gpow_impl<true>(x, y, LOG_TAB, EXP_TAB); }
 
 }  // namespace octa_gpow

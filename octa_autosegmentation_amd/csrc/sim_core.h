@@ -1044,7 +1044,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
         }
         b.sync();
         {
-            const int chunk = (n + b.nth - 1) / b.nth;
+            const int chunk = ((n + b.nth - 1) / b.nth) | 1;      // odd: the lanes' element words lie in distinct LDS banks
             const int i0 = b.tid * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
             int q = 0;
             if (i0 < i1) {  // last range starting at or before i0
@@ -1188,7 +1188,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
         KDP(1);
         // 2. quantised split-dimension keys, element-parallel with the same chunking
         {
-            const int chunk = (n + b.nth - 1) / b.nth;
+            const int chunk = ((n + b.nth - 1) / b.nth) | 1;      // odd: the lanes' element words lie in distinct LDS banks
             const int i0 = b.tid * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
             int q = 0;
             if (i0 < i1) {
@@ -1356,7 +1356,7 @@ OCTA_HD inline Grid grid_build_once(const Blk &b, const SimArrays &A, const doub
     b.sync();
     {   // exclusive scan over the cells: contiguous chunk per thread + ONE block scan
         const int total = ncell + 1;
-        const int chunk = (total + b.nth - 1) / b.nth;
+        const int chunk = ((total + b.nth - 1) / b.nth) | 1;      // odd: distinct LDS banks across the lanes
         const int c0 = b.tid * chunk, c1 = (c0 + chunk < total) ? c0 + chunk : total;
         int local = 0;
         for (int c = c0; c < c1; c++) local += hist[c];
@@ -1572,6 +1572,12 @@ __device__ inline bool murray_pending_above(const SimArrays &A, int start, int c
 // chain -- two pow evaluations per node, operands fetched with readlane -- is executed uniformly; (4) the lanes store the new radii
 // / mark the deferred nodes. Floating-point addition is commutative, so "on-path power + other power" is bit-identical to the
 // reference's c0-then-c1 order. Returns the eager steps; n_def counts the nodes appended to the deferred list (A.act_list).
+// the chain's two evaluations per node have wave-uniform operands: table entries through the scalar cache (round 6; -DOCTA_WALK_POW_LDS: the LDS tables)
+#ifdef OCTA_WALK_POW_LDS
+#define OCTA_WALK_POW(x, y) octa_gpow::gpow_t((x), (y), L.log_tab, L.exp_tab)
+#else
+#define OCTA_WALK_POW(x, y) octa_gpow::gpow_u((x), (y))
+#endif
 __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g, int pass_tag, DirtyList *D, const SeqLds &L, int &n_def
 #ifdef OCTA_SIM_PROF_SEQ2
                                       , long *seq2_dbg = nullptr
@@ -1653,10 +1659,10 @@ __device__ inline long murray_to_root(const SimArrays &A, int f, int id, int cur
                 if (j == 0 && below < 0) {
                     s = pw_j;
                 } else {
-                    s = octa_gpow::gpow_t(rp_prev, k, L.log_tab, L.exp_tab);
+                    s = OCTA_WALK_POW(rp_prev, k);
                     if (nch >= 2) s = s + pw_j;
                 }
-                const double rp = octa_gpow::gpow_t(s, inv_k, L.log_tab, L.exp_tab);
+                const double rp = OCTA_WALK_POW(s, inv_k);
                 steps++;
                 if (old_j == rp) { stop = true; break; }
                 if (lane == j) my_rp = rp;
@@ -2412,7 +2418,7 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
         }
         b.sync();
         {
-            const int chunk = (n_groups + b.nth - 1) / b.nth;
+            const int chunk = ((n_groups + b.nth - 1) / b.nth) | 1;      // odd: distinct LDS banks across the lanes
             const int g0 = b.tid * chunk, g1 = (g0 + chunk < n_groups) ? g0 + chunk : n_groups;
             int local = 0;
             for (int g = g0; g < g1; g++) local += gc[g];
