@@ -17,6 +17,6 @@ for B in [int(a) for a in sys.argv[1:]] or [512]:
     st = res.stats.astype(np.float64)
     kd = st[:, 24:32]
     rt = kd[:, 2].sum()
-    print(f"B={B}: kernel {res.timing['kernel_b_ms']:.1f} ms; per round trip: wait {st[:, 13].sum() / rt * 10:.1f} us, publish {kd[:, 0].sum() / rt * 10:.2f} us, "
+    print(f"B={B}: kernel {res.timing['kernel_b_ms']:.1f} ms; per round trip: wait {st[:, 13].sum() / rt * 1e-2:.1f} us, publish {kd[:, 0].sum() / rt * 1e-2:.2f} us, "
           f"polls {kd[:, 1].sum() / rt:.1f}; round trips per sample {rt / B:.1f}, wait per sample {st[:, 13].mean() * 1e-5:.2f} ms")
     sim.close()
