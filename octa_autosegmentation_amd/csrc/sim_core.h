@@ -1505,7 +1505,11 @@ struct SeqLds {
     int *fl_done;              // [MURRAY_FLUSH_LDS / 32] bitmap: slot finished in an earlier round
     int *slot_of;              // [NCAP] (HBM scratch) list slot of a deferred node, written by the walk that marks it
 };
-constexpr int MURRAY_FLUSH_WAVE = 256;  // deferred nodes one wave of the flush keeps in registers (4 per lane)
+#ifndef OCTA_MURRAY_EPT
+#define OCTA_MURRAY_EPT 4      // (-DOCTA_MURRAY_EPT=1: 64-slot waves -- a test build in which nearly every pass takes the three-wave and the whole-workgroup forms)
+#endif
+constexpr int MURRAY_EPT = OCTA_MURRAY_EPT;
+constexpr int MURRAY_FLUSH_WAVE = MURRAY_EPT * 64;  // deferred nodes one wave of the flush keeps in registers (MURRAY_EPT per lane)
 constexpr int MURRAY_FLUSH_LDS = 3 * MURRAY_FLUSH_WAVE;   // deferred nodes of a pass whose finished radii / done bits live in the LDS: up to three waves share the rounds
 // PAR_TAG: the node carries THIS pass's tag in child_group, i.e. it is the child of an inter-node group of the pass. A walk that meets
 // no such node has no eager part and needs no topology record from HBM at all (round 6).
@@ -1747,10 +1751,6 @@ OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g,
 // looks at its marked nodes, adds the k-th power of every child that is final by now and, once both are in, writes the node's
 // radius; the bits are cleared between two syncs, so a round only sees children finished in earlier rounds. Rounds = height of
 // the marked forest. Up to MURRAY_EPT nodes per thread keep their operands in registers; a longer list re-reads them per round.
-#ifndef OCTA_MURRAY_EPT
-#define OCTA_MURRAY_EPT 4
-#endif
-constexpr int MURRAY_EPT = OCTA_MURRAY_EPT;
 #if defined(__HIP_DEVICE_COMPILE__)
 // The one-wave flush in two halves (round 6). PREPARE (the pass's own wave, right behind its last visit; 64 lanes, four list slots each):
 // topology records of the marked nodes, the list slots of their marked children, the radii of their unmarked children (final already) raised
@@ -1809,20 +1809,23 @@ __device__ inline void murray_flush_prepare_wave(const SimArrays &A, int f, cons
 }
 
 // rad: the forest's radii; fl_val [MURRAY_FLUSH_LDS] doubles and fl_done [MURRAY_FLUSH_LDS / 32] ints of LDS that belong to the calling wave
-// base: this wave's entries are [base, base + MURRAY_FLUSH_WAVE) of a list of n_def; the waves of a longer list run side by side WITHOUT
-// barriers: a slot's radius is stored before its done bit (one wave's LDS operations execute in order), a wave that finds nothing ready
-// looks again. With at most two children per node the sum of a node is the same in whatever order the children finish.
+// (w, nw): wave w of nw (1 ... 3) that share the list -- the list is dealt out in blocks of 64 slots, block b to wave b % nw (entry e of
+// this wave: slots (e * nw + w) * 64 ...), so that a list of up to 64 * nw nodes has ONE node per lane: a round then costs one child
+// power and one root per lane instead of up to MURRAY_EPT of each in turn. The waves run side by side WITHOUT barriers: a slot's radius
+// is stored before its done bit (one wave's LDS operations execute in order), a wave that finds nothing ready looks again. With at most
+// two children per node the sum of a node is the same in whatever order the children finish.
 // cleared: the caller zeroed fl_done in front of a barrier (several waves); otherwise this wave clears it (one wave alone).
 __device__ inline int murray_flush_rounds_wave(double *rad, const double *log_tab, const uint64_t *exp_tab, double *fl_val, int *fl_done,
-                                               const FlushRec *recs, int n_def, int base = 0, bool cleared = false) {
-    const int lane = (int)(threadIdx.x & 63) + base;
+                                               const FlushRec *recs, int n_def, int w = 0, int nw = 1, bool cleared = false) {
+    const int lane = (int)(threadIdx.x & 63);
     int node[MURRAY_EPT], s0[MURRAY_EPT], s1[MURRAY_EPT], pend[MURRAY_EPT];
     double kk[MURRAY_EPT], acc[MURRAY_EPT], cv0[MURRAY_EPT], cv1[MURRAY_EPT];
-    if (!cleared) for (int w = lane - base; w < MURRAY_FLUSH_LDS / 32; w += 64) fl_done[w] = 0;
-    n_def = n_def - base < MURRAY_FLUSH_WAVE ? n_def : base + MURRAY_FLUSH_WAVE;      // one past this wave's last entry
-    const int n_own = n_def - base;
+    if (!cleared) for (int i = lane; i < MURRAY_FLUSH_LDS / 32; i += 64) fl_done[i] = 0;
+    int n_own = 0;
+#pragma unroll
+    for (int e = 0; e < MURRAY_EPT; e++) { const int left = n_def - (e * nw + w) * 64; n_own += left < 0 ? 0 : (left > 64 ? 64 : left); }
     for (int e = 0; e < MURRAY_EPT; e++) {
-        const int idx = lane + e * 64;
+        const int idx = (e * nw + w) * 64 + lane;
         node[e] = 0; s0[e] = s1[e] = 0; pend[e] = 0; kk[e] = 1; acc[e] = 0; cv0[e] = cv1[e] = 0.5;
         if (idx < n_def) { const FlushRec r = recs[idx]; node[e] = r.node; s0[e] = r.s0; s1[e] = r.s1; pend[e] = r.pend; kk[e] = r.kk; acc[e] = r.acc; }
     }
@@ -1875,18 +1878,18 @@ __device__ inline int murray_flush_rounds_wave(double *rad, const double *log_ta
             const double rp = octa_gpow::gpow_t(a, 1.0 / k, log_tab, exp_tab);
 #pragma unroll
             for (int e = 0; e < MURRAY_EPT; e++)
-                if (on && t == e) { *(volatile double *)(fl_val + lane + e * 64) = rp; rad[node[e]] = rp; pend[e] = 8; }
+                if (on && t == e) { *(volatile double *)(fl_val + (e * nw + w) * 64 + lane) = rp; rad[node[e]] = rp; pend[e] = 8; }
         }
         __builtin_amdgcn_wave_barrier();
         bool any = false;
         for (int e = 0; e < MURRAY_EPT; e++) {
-            const unsigned long long fb = __ballot(pend[e] == 8);       // slots base + e * 64 + (lane - base)
+            const unsigned long long fb = __ballot(pend[e] == 8);       // slots (e * nw + w) * 64 + lane
             if (pend[e] == 8) pend[e] = 0;
             if (fb) {
-                if (lane == base) {
-                    int *w = fl_done + (base >> 5) + 2 * e;
-                    __hip_atomic_fetch_or(w, (int)(unsigned)fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_or(w + 1, (int)(unsigned)(fb >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) {
+                    int *dw = fl_done + 2 * (e * nw + w);
+                    __hip_atomic_fetch_or(dw, (int)(unsigned)fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(dw + 1, (int)(unsigned)(fb >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 done += (int)__popcll(fb);
                 any = true;
@@ -2930,8 +2933,8 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
 #if defined(__HIP_DEVICE_COMPILE__)
     if (pend_own > 0) {       // (the passes alternate between the forests, so this forest's last flush has run beside the other's pass; kept for callers that break the order)
         const int wv = b.tid >> 6;
-        if (wv * MURRAY_FLUSH_WAVE < pend_own)
-            murray_flush_rounds_wave(L.rad, L.log_tab, L.exp_tab, L.fl_val, L.fl_done, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS, pend_own, wv * MURRAY_FLUSH_WAVE, true);
+        if (wv < 3 && wv * 64 < pend_own)
+            murray_flush_rounds_wave(L.rad, L.log_tab, L.exp_tab, L.fl_val, L.fl_done, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS, pend_own, wv, 3, true);
         b.sync();
         if (b.tid == 0) sc->fl_pending[f] = 0;
         for (int i = b.tid; i < FLD_WORDS; i += b.nth) L.fl_done[i] = 0;
@@ -3085,15 +3088,18 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     else {
-        // the other forest's deferred rounds: the third wave takes the first 256 list slots, the fourth the next, the second -- behind its
-        // side job, which only the arterial pass has -- the last; the waves of one list run side by side without barriers
+        // the other forest's deferred rounds, its list dealt out in blocks of 64 slots: beside the venous pass to the third, fourth and second
+        // wave (all idle there); beside the arterial pass to the third and fourth only -- the second carries the candidate stream for most of
+        // that pass, and slots it took would hold up the other waves' parents -- unless the (venous) list is longer than the two can hold.
+        // The waves of one list run side by side without barriers.
         static_assert(SIM_THREADS_PER_WG == 256, "the ordered pass hands its side work to waves 1 - 3");
         const int wv = b.tid >> 6;
         if (wv == 1) side(side_lds);
-        const int base = (wv == 2 ? 0 : (wv == 3 ? 1 : 2)) * MURRAY_FLUSH_WAVE;
-        if (base < pend_other) {
+        const int nw = (f == 1 || pend_other > 2 * MURRAY_FLUSH_WAVE) ? 3 : 2;
+        const int w = wv == 2 ? 0 : (wv == 3 ? 1 : 2);
+        if (w < nw && w * 64 < pend_other) {
             const int rounds = murray_flush_rounds_wave(A.nrad_of(1 - f), L.log_tab, L.exp_tab, L.fl_val, L.fl_done, A.fl_rec + (size_t)(1 - f) * MURRAY_FLUSH_LDS,
-                                                        pend_other, base, true);
+                                                        pend_other, w, nw, true);
             if (b.tid == 128) sc->flush_rounds += rounds;
         }
     }
@@ -3135,9 +3141,9 @@ OCTA_HD inline void murray_flush_pending(const Blk &b, const SimArrays &A) {
         for (int i = b.tid; i < MURRAY_FLUSH_LDS / 32; i += b.nth) fl_done[i] = 0;
         b.sync();
         const int wv = b.tid >> 6;
-        if (wv * MURRAY_FLUSH_WAVE < n) {
+        if (wv < 3 && wv * 64 < n) {
             const int rounds = murray_flush_rounds_wave(A.nrad_of(f), octa_gpow::LOG_TAB, octa_gpow::EXP_TAB, fl_val, fl_done, A.fl_rec + (size_t)f * MURRAY_FLUSH_LDS, n,
-                                                        wv * MURRAY_FLUSH_WAVE, true);
+                                                        wv, 3, true);
             if (b.tid == 0) { A.sc->fl_pending[f] = 0; A.sc->flush_rounds += rounds; }
         }
         b.sync();
