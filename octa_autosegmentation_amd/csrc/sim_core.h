@@ -1762,14 +1762,14 @@ OCTA_HD inline long murray_to_root(const SimArrays &A, int f, int id, int cur_g,
 __device__ inline void murray_flush_prepare_wave(const SimArrays &A, int f, const SeqLds &L, int n_def, FlushRec *recs, int base = 0) {
     // entries [base, base + MURRAY_FLUSH_WAVE) of the list (a longer list is prepared chunk by chunk: the entries are independent here)
     const int lane = (int)(threadIdx.x & 63) + base;
-    double *rad = L.rad;
     int node[MURRAY_EPT], s0[MURRAY_EPT], s1[MURRAY_EPT];
-    double kk[MURRAY_EPT], acc[MURRAY_EPT];
-    int pend[MURRAY_EPT];     // 1: marked child 0 not in yet, 2: marked child 1 not in yet, 4: radius not written yet
+    double kk[MURRAY_EPT];
+    int pend[MURRAY_EPT];     // 1: marked child 0 not in yet (s0 = its list slot), 2: marked child 1 likewise, 4: radius not written yet,
+                              // 16 / 32: child 0 / 1 is NOT marked -- its radius is final already and s0 / s1 is its node: the rounds fetch it
     int c0[MURRAY_EPT], c1[MURRAY_EPT], nch[MURRAY_EPT];
     for (int e = 0; e < MURRAY_EPT; e++) {
         const int idx = lane + e * 64;
-        pend[e] = 0; node[e] = 0; c0[e] = c1[e] = 0; nch[e] = 0; kk[e] = 1; acc[e] = 0; s0[e] = s1[e] = 0;
+        pend[e] = 0; node[e] = 0; c0[e] = c1[e] = 0; nch[e] = 0; kk[e] = 1; s0[e] = s1[e] = 0;
         if (idx < n_def) node[e] = A.act_list[idx];
     }
     for (int e = 0; e < MURRAY_EPT; e++) {
@@ -1778,33 +1778,17 @@ __device__ inline void murray_flush_prepare_wave(const SimArrays &A, int f, cons
             c0[e] = r.c0; c1[e] = r.c1; kk[e] = r.k; nch[e] = r.nch;
         }
     }
-    // third round trip, all entries at once: the slot of a marked child, the radius of an unmarked one
-    double cv0[MURRAY_EPT], cv1[MURRAY_EPT];
-    unsigned ready = 0;                          // bit 2e + c: child c of entry e has its radius in cv, its power not yet in acc
+    // third round trip, all entries at once: the list slot of a marked child. (The powers of the unmarked children -- final radii -- were
+    // evaluated here until the list was dealt out to three waves: they are the first thing the rounds' waves do now, off the pass's wave.)
     for (int e = 0; e < MURRAY_EPT; e++) {
-        cv0[e] = cv1[e] = 0.5;
         if (lane + e * 64 >= n_def) continue;
         pend[e] = 4;
-        if (nch[e] >= 1) { if (deferred_get(L, c0[e])) { pend[e] |= 1; s0[e] = L.slot_of[c0[e]]; } else { cv0[e] = rad[c0[e]]; ready |= 1u << (2 * e); } }
-        if (nch[e] >= 2) { if (deferred_get(L, c1[e])) { pend[e] |= 2; s1[e] = L.slot_of[c1[e]]; } else { cv1[e] = rad[c1[e]]; ready |= 2u << (2 * e); } }
-    }
-    // One pow evaluation per step for the whole wave, whatever entry and child it belongs to (written entry by entry a step executed up to
-    // 3 x MURRAY_EPT evaluations one after the other -- every `if` with a taker among the 64 lanes)
-    while (__ballot(ready != 0)) {
-        const bool on = ready != 0;
-        const int t = on ? (int)__ffs((int)ready) - 1 : 0;
-        if (on) ready &= ready - 1u;
-        double x = 0.5, k = 2.0;
-#pragma unroll
-        for (int e = 0; e < MURRAY_EPT; e++) if ((t >> 1) == e) { x = (t & 1) ? cv1[e] : cv0[e]; k = kk[e]; }
-        if (!on) { x = 0.5; k = 2.0; }
-        const double pw = octa_gpow::gpow_t(x, k, L.log_tab, L.exp_tab);
-#pragma unroll
-        for (int e = 0; e < MURRAY_EPT; e++) if (on && (t >> 1) == e) acc[e] = acc[e] + pw;
+        if (nch[e] >= 1) { if (deferred_get(L, c0[e])) { pend[e] |= 1; s0[e] = L.slot_of[c0[e]]; } else { pend[e] |= 16; s0[e] = c0[e]; } }
+        if (nch[e] >= 2) { if (deferred_get(L, c1[e])) { pend[e] |= 2; s1[e] = L.slot_of[c1[e]]; } else { pend[e] |= 32; s1[e] = c1[e]; } }
     }
     for (int e = 0; e < MURRAY_EPT; e++) {
         const int idx = lane + e * 64;
-        if (idx < n_def) { FlushRec r; r.kk = kk[e]; r.acc = acc[e]; r.node = node[e]; r.pend = pend[e]; r.s0 = s0[e]; r.s1 = s1[e]; recs[idx] = r; }
+        if (idx < n_def) { FlushRec r; r.kk = kk[e]; r.acc = 0.0; r.node = node[e]; r.pend = pend[e]; r.s0 = s0[e]; r.s1 = s1[e]; recs[idx] = r; }
     }
 }
 
@@ -1828,6 +1812,12 @@ __device__ inline int murray_flush_rounds_wave(double *rad, const double *log_ta
         const int idx = (e * nw + w) * 64 + lane;
         node[e] = 0; s0[e] = s1[e] = 0; pend[e] = 0; kk[e] = 1; acc[e] = 0; cv0[e] = cv1[e] = 0.5;
         if (idx < n_def) { const FlushRec r = recs[idx]; node[e] = r.node; s0[e] = r.s0; s1[e] = r.s1; pend[e] = r.pend; kk[e] = r.kk; acc[e] = r.acc; }
+    }
+    unsigned ready0 = 0;          // the unmarked children: radii final since the pass ended, fetched here and raised in the first round
+    for (int e = 0; e < MURRAY_EPT; e++) {
+        if (pend[e] & 16) { cv0[e] = rad[s0[e]]; ready0 |= 1u << (2 * e); }
+        if (pend[e] & 32) { cv1[e] = rad[s1[e]]; ready0 |= 2u << (2 * e); }
+        pend[e] &= ~48;
     }
     __builtin_amdgcn_wave_barrier();
     int rounds = 0, done = 0;
@@ -1853,6 +1843,8 @@ __device__ inline int murray_flush_rounds_wave(double *rad, const double *log_ta
                 if (ready & (2u << (2 * e))) cv1[e] = *(volatile double *)(fl_val + s1[e]);
             }
         }
+        ready |= ready0;          // (first round: the unmarked children fetched above)
+        ready0 = 0;
         while (__ballot(ready != 0)) {
             const bool on = ready != 0;
             const int t = on ? (int)__ffs((int)ready) - 1 : 0;
