@@ -577,7 +577,7 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
 // and workgroups that park leave early: with one workgroup PER SAMPLE the CUs waited for the hardware dispatcher to place the
 // next launch's workgroups (measured: 76 % of the CU time used with 2-12 launches in flight, whatever their size); resident
 // workgroups that refill themselves only leave the CU idle at the very end of a launch.
-__global__ void __launch_bounds__(SIM_THREADS, SIM_WG_PER_CU * SIM_THREADS / 256)      // HIP's second argument = waves per SIMD: 2 at 256 threads (<= 256 registers per lane)
+__global__ void __launch_bounds__(SIM_THREADS, SIM_WG_PER_CU * SIM_THREADS / 256) __attribute__((amdgpu_waves_per_eu(SIM_WG_PER_CU * SIM_THREADS / 256, SIM_WG_PER_CU * SIM_THREADS / 256)))      // waves per SIMD: 2 at 256 threads (<= 256 registers per lane, accumulation registers included; with the explicit attribute the compiler WARNS when it cannot keep to that -- an experiment of round 6 took 32 accumulation registers on top of 256 and the kernel silently ran one workgroup per CU)
 sim_persistent_kernel(BatchPtrs B, HostMail M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Blk b = {(int)threadIdx.x, SIM_THREADS, smem};      // the launch shape is fixed (sim_run_impl): as a constant it removes the one-thread (host build) paths and turns every stride into an immediate
