@@ -2999,6 +2999,9 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
             const long _wb = t_acc[0]; (void)_wb;
             if (R.type == 0) continue;
             const int id = R.node;
+            // ONE inlined copy of the walk serves both kinds of growth (round 6: the pass's loop is tens of KB of code; a second copy of
+            // murray_to_root in it is a few KB more for the instruction cache to hold)
+            bool walk = false;
             if (R.type == 1) {
                 bool bif = false;
                 if (R.draw) {
@@ -3012,15 +3015,11 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                     const double *o = bif_results + 6 * (size_t)R.req;
                     seq_add_node(A, f, n_nodes, v3(o[0], o[1], o[2]), C.r, id, 0, P.kappa, L);
                     seq_add_node(A, f, n_nodes, v3(o[3], o[4], o[5]), C.r, id, 1, P.kappa, L);
-                    SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def SEQ2_ARG));
-                    d_head = D.n > 0 ? D.v[0] : INF;
-                    t_acc[3]++;
-                    A.nact_of(f)[id] = 0;
+                    walk = true;
                     n_bif++;
                 } else {
                     seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 0, P.kappa, L);
                 }
-                SEQ2_END(1, 3, _wb);
             } else {
                 if (changed_get(L, g)) {      // a walk of this pass rewrote the child's radius (every rewrite changes it: the walk stops at old == new)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -3036,12 +3035,15 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 py_pos++;
                 if (R.thr <= u && !R.ang_gt90) { SEQ2_END(2, 4, _wb); continue; }
                 seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 1, P.kappa, L);
+                walk = true;
+            }
+            if (walk) {
                 SEQT(0, steps += murray_to_root(A, f, id, g, tag, &D, L, n_def SEQ2_ARG));
                 d_head = D.n > 0 ? D.v[0] : INF;
                 t_acc[3]++;
                 A.nact_of(f)[id] = 0;
-                SEQ2_END(2, 4, _wb);
             }
+            SEQ2_END(R.type == 1 ? 1 : 2, 3, _wb);
             if (D.overflow && !scan_all) { scan_all = true; D.n = 0; }
         }
         sc->new_begin[f] = n_before;
