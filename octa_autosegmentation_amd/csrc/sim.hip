@@ -356,6 +356,30 @@ sim_iter_b_kernel(BatchPtrs B, int it) {
     OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, B.reqs + REQ_CAP, B.req_count + 1, REQ_CAP, s));
 }
 
+#ifdef OCTA_SIM_CODE_SIZE_PROBE
+// diagnostic (never launched): one kernel per phase, so that `hipcc -save-temps -DOCTA_SIM_CODE_SIZE_PROBE` lists every phase's code size
+// (`; codeLenInByte` in the .s; tools/sim_code_size.sh) -- the persistent kernel inlines all of them, and its hot loops compete for an instruction
+// cache of 64 KB per two CUs
+#define OCTA_PROBE_KERNEL(name, call) \
+    __global__ void __launch_bounds__(SIM_THREADS) name(BatchPtrs B, int it) { \
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; \
+        const int s = blockIdx.x; \
+        SimArrays A = sample_arrays(B, s); \
+        Blk b = {(int)threadIdx.x, (int)blockDim.x, smem}; \
+        const IterParams P = B.iters[it]; \
+        call; \
+    }
+OCTA_PROBE_KERNEL(probe_phase_sample, phase_sample(b, A, B.C, P, it))
+OCTA_PROBE_KERNEL(probe_phase_assign_art, phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art))
+OCTA_PROBE_KERNEL(probe_phase_pre_art, phase_pre(b, A, B.C, P, 0, A.oxy, B.reqs, B.req_count, REQ_CAP, s))
+OCTA_PROBE_KERNEL(probe_phase_seq_art, phase_seq(b, A, B.C, P, 0, A.oxy, B.bif_results))
+OCTA_PROBE_KERNEL(probe_phase_seq_ven, phase_seq(b, A, B.C, P, 1, A.co2, B.bif_results))
+OCTA_PROBE_KERNEL(probe_phase_satisfy_art, phase_satisfy_art(b, A, B.C, P))
+OCTA_PROBE_KERNEL(probe_phase_satisfy_ven, phase_satisfy_ven(b, A, P))
+OCTA_PROBE_KERNEL(probe_kd_build, kd_build(b, A.oxy, A.sc->n_oxy, A.kd_idx, A.kd_rank, reinterpret_cast<float *>(A.hashes), 0.0, B.C.sz, nullptr, A.removed, true))
+#undef OCTA_PROBE_KERNEL
+#endif
+
 // ---- persistent form: one launch runs all iterations of every sample; a workgroup only waits for the host
 // when ITS sample posted leaf-bifurcation requests (about one pass in ten), through a mailbox in pinned host
 // memory. Samples are no longer in lock step, so a launch lasts as long as its slowest sample's SUM of phases
