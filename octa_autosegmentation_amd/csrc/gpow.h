@@ -24,6 +24,9 @@
 #endif
 #endif
 #define OCTA_CONST static constexpr
+#ifndef OCTA_UNLIKELY
+#define OCTA_UNLIKELY(c) __builtin_expect(!!(c), 0)      // cold blocks leave the hot path's cache lines (the simulator kernel is short of instruction cache: DESIGN.md 4.1)
+#endif
 #include "glibc_pow_tables.h"
 
 namespace octa_gpow {
@@ -40,7 +43,7 @@ OCTA_HD inline double gpow_impl(double x, double y, const double *log_tab, const
     const uint64_t ix = asu64(x), iy = asu64(y);
     const uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52);
     // glibc's special-case gate: x subnormal/zero/negative/inf/nan, or |y| tiny/huge/inf/nan
-    if (topx - 0x001u >= 0x7ffu - 0x001u || (topy & 0x7ffu) - 0x3beu >= 0x43eu - 0x3beu) return NAN;
+    if (OCTA_UNLIKELY(topx - 0x001u >= 0x7ffu - 0x001u || (topy & 0x7ffu) - 0x3beu >= 0x43eu - 0x3beu)) return NAN;
     // ---- log_inline
     const uint64_t OFF = 0x3fe6955500000000ULL;
     uint64_t tmp = ix - OFF;
@@ -76,7 +79,7 @@ OCTA_HD inline double gpow_impl(double x, double y, const double *log_tab, const
     // ---- exp_inline
     uint32_t abstop = (uint32_t)(asu64(ehi) >> 52) & 0x7ffu;
     // |ehi| in [2^-54, 2^9): the only branch the simulator can reach
-    if (abstop - 0x3c9u >= 0x408u - 0x3c9u) {
+    if (OCTA_UNLIKELY(abstop - 0x3c9u >= 0x408u - 0x3c9u)) {
         if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + ehi;  // tiny exponent: glibc returns 1 + x (WANT_ROUNDING)
         return NAN;
     }

@@ -434,8 +434,8 @@ __device__ inline int mail_roundtrip(const Blk &b, const SimArrays &A, const Hos
             __builtin_amdgcn_s_sleep(64);
             polls++;
             const long waited = (long)wall_clock64() - t0;
-            if (M.park_ticks > 0 && waited > M.park_ticks) { *park = 1; break; }
-            if (waited > M.timeout_ticks) {      // only without parking (OCTA_SIM_PARK_MS=0): the round-1 behaviour
+            if (OCTA_UNLIKELY(M.park_ticks > 0 && waited > M.park_ticks)) { *park = 1; break; }
+            if (OCTA_UNLIKELY(waited > M.timeout_ticks)) {      // only without parking (OCTA_SIM_PARK_MS=0): the round-1 behaviour
                 atomicOr(&A.sc->err, ERR_HOST_TIMEOUT);
                 A.sc->prof[11] = __hip_atomic_load(M.resp_ticket + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                 A.sc->prof[12] = t0 - t_kernel;

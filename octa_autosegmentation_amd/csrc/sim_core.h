@@ -618,7 +618,7 @@ OCTA_HD inline void pyset_add(PySetView &s, int key, unsigned long long hash) {
             if (s.key[e] < 0) {
                 s.fill++; s.used++;
                 s.key[e] = key; s.hash[e] = hash;
-                if ((long)s.fill * 5 < (long)s.mask * 3) return;
+                if (!OCTA_UNLIKELY(!((long)s.fill * 5 < (long)s.mask * 3))) return;
                 pyset_resize(s, s.used > 50000 ? s.used * 2 : s.used * 4);
                 return;
             }
@@ -647,7 +647,7 @@ struct KdPair {
     int d;               // split dimension of the range being partitioned
 };
 OCTA_HD inline bool kd_less_w(const KdPair &a, kdw_t x, kdw_t y) {
-    if ((x ^ y) >> KD_IDX_BITS) return x < y;
+    if (!OCTA_UNLIKELY(!((x ^ y) >> KD_IDX_BITS))) return x < y;
     const unsigned xi = (unsigned)(x & KD_IDX_MASK), yi = (unsigned)(y & KD_IDX_MASK);
     const double fx = a.pts[3 * xi + a.d], fy = a.pts[3 * yi + a.d];
     if (fx == fy) return xi < yi;
@@ -783,7 +783,7 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
     while ((n >> (lg + 1)) > 0) lg++;
     int depth = depth_left >= 0 ? depth_left : lg * 2;     // a range handed over by kd_nth_element_wave_long keeps its introselect budget
     while (last - first > 3) {
-        if (depth == 0) {
+        if (OCTA_UNLIKELY(depth == 0)) {
             if (tl == 0) { kd_heap_select(a, first, nth + 1, last); kd_swap(a, first, nth); }
             __builtin_amdgcn_wave_barrier();
             return;
@@ -820,7 +820,7 @@ __device__ inline void kd_nth_element_team(const KdPair &a, int first, int nth, 
             for (int i = 0; i < lim; i++) {
                 const kdw_t x = a.kv[q0 + i];
                 bool lt = x < pk;
-                if (!((x ^ pk) >> KD_IDX_BITS)) lt = kd_less_w(a, x, pk);     // same bucket as the pivot: exact (rare)
+                if (OCTA_UNLIKELY(!((x ^ pk) >> KD_IDX_BITS))) lt = kd_less_w(a, x, pk);     // same bucket as the pivot: exact (rare)
                 if (lt) bits |= 1ull << i;
             }
             ms[w] = bits;
@@ -1129,7 +1129,7 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
             if (shi[2] > shi[d]) d = 2;
             bool sure = true;
             for (int k = 0; k < 3; k++) if (k != d && !(slo[d] > shi[k])) sure = false;
-            if (sure) { rd[q] = (signed char)d; continue; }
+            if (!OCTA_UNLIKELY(!sure)) { rd[q] = (signed char)d; continue; }
             // overlapping intervals (or a degenerate box): the exact extrema of the range decide, as scipy's do. A long range is left
             // to the whole workgroup: the extreme sinks of the list persist over many iterations, so a near-tie of the ROOT range's
             // x and y spreads (about one sample in 300) used to cost one thread a scan of all ~10^4 sinks in every iteration it lasted
@@ -1486,7 +1486,7 @@ OCTA_HD inline void dirty_insert(DirtyList &D, int g) {
     int i = 0;
     while (i < D.n && D.v[i] < g) i++;
     if (i < D.n && D.v[i] == g) return;
-    if (D.n >= D.cap) { D.overflow = true; return; }
+    if (OCTA_UNLIKELY(D.n >= D.cap)) { D.overflow = true; return; }
     for (int k = D.n; k > i; k--) D.v[k] = D.v[k - 1];
     D.v[i] = g;
     D.n++;
@@ -1993,7 +1993,7 @@ OCTA_HD inline int murray_flush(const Blk &b, const SimArrays &A, int f, const S
 OCTA_HD inline int seq_add_node(const SimArrays &A, int f, int &n_nodes, V3 p, double r, int parent, int parent_nch,
                                 double kappa, const SeqLds &L) {
     int id = n_nodes;
-    if (id >= NCAP) { atomic_or_int(&A.sc->err, ERR_NODE_CAP); return -1; }
+    if (OCTA_UNLIKELY(id >= NCAP)) { atomic_or_int(&A.sc->err, ERR_NODE_CAP); return -1; }
     n_nodes = id + 1;
     st3(A.npos_of(f) + 3 * id, p);
     A.nrad_of(f)[id] = r; A.nkap_of(f)[id] = kappa; A.npar_of(f)[id] = parent;   // L.rad IS A.nrad_of(f)
@@ -2006,7 +2006,7 @@ OCTA_HD inline int seq_add_node(const SimArrays &A, int f, int &n_nodes, V3 p, d
 
 OCTA_HD inline int add_node(const SimArrays &A, int f, V3 p, double r, int parent, double kappa, double *rad_mirror = nullptr) {
     int id = A.sc->n_nodes[f];
-    if (id >= NCAP) { atomic_or_int(&A.sc->err, ERR_NODE_CAP); return -1; }
+    if (OCTA_UNLIKELY(id >= NCAP)) { atomic_or_int(&A.sc->err, ERR_NODE_CAP); return -1; }
     A.sc->n_nodes[f] = id + 1;
     st3(A.npos_of(f) + 3 * id, p);
     A.nrad_of(f)[id] = r; A.nkap_of(f)[id] = kappa; A.npar_of(f)[id] = parent;
@@ -2090,7 +2090,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
                     if (d2f <= en_hi2f) {
                         const double lim = fmin(en, oxd[j]), lo = lim - GRID_F_TAU, hi = lim + GRID_F_TAU;
                         if (lo > 0.0 && (double)d2f < lo * lo) ok = false;
-                        else if ((double)d2f <= hi * hi) {
+                        else if (OCTA_UNLIKELY((double)d2f <= hi * hi)) {
                             const double d2 = sqdist(ld3(G.src + 3 * j), c);
                             if (d2 <= en2 && !(sqrt(d2) > oxd[j])) ok = false;
                         }
@@ -2115,7 +2115,7 @@ OCTA_HD inline void phase_sample(const Blk &b, const SimArrays &A, const SimCons
                 if (ok) {
                     const float d2f = sqdist_f(qf, cxf, cyf, czf);
                     if (d2f < es_lo2f) ok = false;
-                    else if (d2f <= es_hi2f && sqrt(sqdist(ld3(G.src + 3 * j), c)) <= es) ok = false;
+                    else if (OCTA_UNLIKELY(d2f <= es_hi2f) && sqrt(sqdist(ld3(G.src + 3 * j), c)) <= es) ok = false;
                 }
             });
             okf[vi] = ok ? 1 : 0;
@@ -2321,10 +2321,10 @@ OCTA_HD inline void phase_assign(const Blk &b, const SimArrays &A, int f, const 
             if (j1 >= 0) {
                 const double d1 = sqrt((double)m1);
                 const double lim2 = (d1 + 2.0 * GRID_F_TAU) * (d1 + 2.0 * GRID_F_TAU);
-                if ((double)m2 > lim2) {                              // the winner is certain
+                if (!OCTA_UNLIKELY(!((double)m2 > lim2))) {                              // the winner is certain
                     if (d1 < delta - GRID_F_TAU) r = j1;
-                    else if (d1 <= delta + GRID_F_TAU) r = sqrt(sqdist(ld3(G.src + 3 * j1), p)) <= delta ? j1 : -1;
-                } else if (d1 <= delta + 3.0 * GRID_F_TAU) {          // near tie of candidates that may be in range: exact arg-min (distance, then id)
+                    else if (OCTA_UNLIKELY(d1 <= delta + GRID_F_TAU)) r = sqrt(sqdist(ld3(G.src + 3 * j1), p)) <= delta ? j1 : -1;
+                } else if (OCTA_UNLIKELY(d1 <= delta + 3.0 * GRID_F_TAU)) {          // near tie of candidates that may be in range: exact arg-min (distance, then id)
                     double bd = INFINITY;
                     int best = -1;
                     grid_visit_f(G, p.x, p.y, delta, [&](int j, const Pt3f &) {
@@ -2484,9 +2484,9 @@ struct GrowCtx {
 };
 
 // acos / cos / sin whose results reach a node position: glibc's, bit for bit (glibc_trig.h), inside the restated domain
-OCTA_HD inline double pos_acos(double c) { return (c > 0.0 && c <= 1.0) ? octa_gtrig::gacos(c) : acos(c); }
-OCTA_HD inline double pos_cos(double x) { return (x >= 0.0 && x < 2.4) ? octa_gtrig::gcos(x) : cos(x); }
-OCTA_HD inline double pos_sin(double x) { return (x >= 0.0 && x < 2.4) ? octa_gtrig::gsin(x) : sin(x); }
+OCTA_HD inline double pos_acos(double c) { if (OCTA_UNLIKELY(!(c > 0.0 && c <= 1.0))) return acos(c); return octa_gtrig::gacos(c); }      // (the library fallbacks are cold code: out of the hot path's cache lines)
+OCTA_HD inline double pos_cos(double x) { if (OCTA_UNLIKELY(!(x >= 0.0 && x < 2.4))) return cos(x); return octa_gtrig::gcos(x); }
+OCTA_HD inline double pos_sin(double x) { if (OCTA_UNLIKELY(!(x >= 0.0 && x < 2.4))) return sin(x); return octa_gtrig::gsin(x); }
 // The attractors of one group, in attractor order: body(position). A visit is two dependent loads (the sorted key, then the
 // attractor it names) in front of a few hundred cycles of arithmetic (angles, acos); one at a time the speculation was a chain of
 // ~100-250 such round trips per thread and iteration (round 4: pre_art + pre_ven 61 ms per sample). Here the keys run two batches ahead
@@ -2976,7 +2976,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
             int g;
             Rec R;
             SEQ2_TOP();
-            if (scan_all) {
+            if (OCTA_UNLIKELY(scan_all)) {
                 g = last_g + 1;
                 if (g >= ng) break;
                 R = A.rec[g];
@@ -3005,13 +3005,13 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
             if (R.type == 1) {
                 bool bif = false;
                 if (R.draw) {
-                    if (py_pos >= py_cap) { err |= ERR_PY_CAP; break; }
+                    if (OCTA_UNLIKELY(py_pos >= py_cap)) { err |= ERR_PY_CAP; break; }
                     const double u = U.at(py_pos);
                     py_pos++;
                     bif = (R.thr > u) && R.ang_gt90;
                 }
                 if (bif) {
-                    if (R.req < 0) { err |= ERR_MISSING_BIF; continue; }
+                    if (OCTA_UNLIKELY(R.req < 0)) { err |= ERR_MISSING_BIF; continue; }
                     const double *o = bif_results + 6 * (size_t)R.req;
                     seq_add_node(A, f, n_nodes, v3(o[0], o[1], o[2]), C.r, id, 0, P.kappa, L);
                     seq_add_node(A, f, n_nodes, v3(o[3], o[4], o[5]), C.r, id, 1, P.kappa, L);
@@ -3030,7 +3030,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                     respec++;
                 }
                 if (!R.grow) { SEQ2_END(2, 4, _wb); continue; }
-                if (py_pos >= py_cap) { err |= ERR_PY_CAP; break; }
+                if (OCTA_UNLIKELY(py_pos >= py_cap)) { err |= ERR_PY_CAP; break; }
                 const double u = U.at(py_pos);
                 py_pos++;
                 if (R.thr <= u && !R.ang_gt90) { SEQ2_END(2, 4, _wb); continue; }
@@ -3044,7 +3044,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                 A.nact_of(f)[id] = 0;
             }
             SEQ2_END(R.type == 1 ? 1 : 2, 3, _wb);
-            if (D.overflow && !scan_all) { scan_all = true; D.n = 0; }
+            if (OCTA_UNLIKELY(D.overflow && !scan_all)) { scan_all = true; D.n = 0; }
         }
         sc->new_begin[f] = n_before;
         sc->new_end[f] = n_nodes;
