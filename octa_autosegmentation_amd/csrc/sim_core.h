@@ -3010,7 +3010,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                     py_pos++;
                     bif = (R.thr > u) && R.ang_gt90;
                 }
-                if (bif) {
+                if (OCTA_UNLIKELY(bif)) {
                     if (OCTA_UNLIKELY(R.req < 0)) { err |= ERR_MISSING_BIF; continue; }
                     const double *o = bif_results + 6 * (size_t)R.req;
                     seq_add_node(A, f, n_nodes, v3(o[0], o[1], o[2]), C.r, id, 0, P.kappa, L);
@@ -3021,7 +3021,7 @@ OCTA_HD inline void phase_seq(const Blk &b, const SimArrays &A, const SimConst &
                     seq_add_node(A, f, n_nodes, ld3(R.newpos), C.r, id, 0, P.kappa, L);
                 }
             } else {
-                if (changed_get(L, g)) {      // a walk of this pass rewrote the child's radius (every rewrite changes it: the walk stops at old == new)
+                if (OCTA_UNLIKELY(changed_get(L, g))) {      // (one visit in eleven) a walk of this pass rewrote the child's radius (every rewrite changes it: the walk stops at old == new)
 #if defined(__HIP_DEVICE_COMPILE__)
                     SEQT(1, eval_inter<true>(G, g, R));      // the device's workgroups have at least one whole wave (SIM_THREADS_PER_WG >= 64)
 #else
