@@ -1237,7 +1237,8 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
                 else kd_nth_element_team<64, 1>(kp, s, s + (e - s) / 2, e, true, mb);
             }
         }
-        b.sync();
+        // (no barrier here: the quarter-wave partitions below work on OTHER ranges -- their own elements, their own mailbox slots -- so a wave
+        // that is through with its long ranges goes on with the short ones)
         KDP(3);
         {
             idx_t *mb = reinterpret_cast<idx_t *>(b.user_of<1>() + KD_MAILBOX_OFF);
@@ -1284,9 +1285,9 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
             }
             nr = base < KD_RANGES ? base : KD_RANGES;
         }
-        b.sync();
+        // (no barrier here: the next level's first step writes the box table and the range flags -- neither is read after the scan's own barriers
+        // above -- and its barrier comes before anything reads the new ranges)
         { idx_t *t = rs; rs = rs2; rs2 = t; t = re; re = re2; re2 = t; }
-        b.sync();
         KDP(5);
     }
     for (int i = b.tid; i < n; i += b.nth) { const idx_t id = (idx_t)(kv[i] & KD_IDX_MASK); out_idx[i] = id; out_rank[id] = (idx_t)i; }
