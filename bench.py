@@ -171,8 +171,8 @@ def cpu_baseline(cfg, all_cores=False):
     with get_context("spawn").Pool(workers) as pool:
         pool.map(_oracle_sample, [(cfg, 901 + k) for k in range(workers)])
     dt = time.time() - t0
-    all_info = {"value": None, "cores": cores, "note": "not run by default (one worker per visible core takes ~230 s on the 256-thread host); round 3 measured 1.1 samples/s "
-                                                       "with 256 workers against 2.2 with 64 on the same host; bench.py --cpu-all-cores times it"}
+    all_info = {"value": None, "cores": cores, "note": "not run by default (one worker per visible core takes ~230 s on the 256-thread host); measured with --cpu-all-cores: 1.13 samples/s "
+                                                       "with 256 workers against 2.40 with 64 on the same host (round 6; round 3: 1.1 against 2.2)"}
     if all_cores and cores > workers:
         t1 = time.time()
         with get_context("spawn").Pool(cores) as pool:
