@@ -491,7 +491,7 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
     }
     b.sync();
     const int it0 = OCTA_UNI(uni[0]);
-    int stage = OCTA_UNI(uni[1]);
+    const int stage = OCTA_UNI(uni[1]);
     const int skip = OCTA_UNI(uni[2]);
     b.sync();
     int parked_at = -1, parked_stage = 0;
@@ -499,20 +499,51 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
     long iter_prof_prev[16];
     for (int k = 0; k < 16; k++) iter_prof_prev[k] = A.sc->prof[k];
 #endif
-    for (int it = it0; it <= n_iter && !skip; it++) {
-        if (stage == 0) {
-            if (uniform_err(b, A)) break;
-            if (it > 0) {
-                const IterParams Pp = B.iters[it - 1];
-                OCTA_PROF(8, phase_seq(b, A, B.C, Pp, 1, A.co2, results));
-                OCTA_PROF(9, phase_satisfy_ven(b, A, Pp));
+    // Half-steps (round 6): h = 2 * it + (1 behind the arterial mailbox of iteration it). A half-step is
+    //   A: the ordered pass + satisfaction step of the forest whose bifurcation requests the previous mailbox answered -- arterial when h is odd,
+    //      venous (of iteration it - 1) when h is even --, then
+    //   B: [even: the iteration's O2 sampling,] assignment + speculation of the OTHER forest and its mailbox.
+    // Written as ONE loop body with the forest a run-time value, the three per-forest phases are inlined ONCE instead of once per forest: the kernel is
+    // 150 KB of code smaller (522 KB before; its hot loops compete for an instruction cache of 64 KB per two CUs) and the two workgroups
+    // of a CU run the same instructions whichever forest they are at. Selecting a forest's arrays at run time costs nothing measurable.
+    for (int h = 2 * it0 + stage; h <= 2 * n_iter && !skip; h++) {
+        const int it = h >> 1;
+        const int odd = __builtin_amdgcn_readfirstlane(h & 1);
+        if (uniform_err(b, A)) break;
+        // ---- A
+        const int it_a = odd ? it : it - 1;
+        if (it_a >= 0) {
+            const IterParams Pa = B.iters[it_a];
+            const int fa = odd ? 0 : 1;
+            // the candidate stream of the NEXT iteration (numpy MT19937, one wave) runs beside the ordered ARTERIAL pass: it only depends on the
+            // generator state, and the candidate buffer is free once phase_sample has consumed it
+            const int n_next = (odd && it + 1 < n_iter) ? B.iters[it + 1].N : 0;
+            auto next_candidates = [&](unsigned char *lds) {
+                if (n_next <= 0) return;
+                const long _t0 = (long)wall_clock64();
+                gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * B.valid_stride, B.valid_count[s], n_next,
+                                    B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(lds),
+                                    B.cand_idx + (size_t)s * NCANDCAP, (int)(threadIdx.x & 63), B.C.gs);
+                if ((threadIdx.x & 63) == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
+            };
+            OCTA_PROF(odd ? 3 : 8, phase_seq(b, A, B.C, Pa, fa, fa ? A.co2 : A.oxy, results, next_candidates));
+            if (odd) {
+#ifdef OCTA_SIM_DEBUG_SAT
+                A.dbg_it = it;
+#endif
+                OCTA_PROF(4, phase_satisfy_art(b, A, B.C, Pa));
+            } else {
+                OCTA_PROF(9, phase_satisfy_ven(b, A, Pa));
                 if (b.tid == 0) {      // iteration it - 1 is complete: the reference's per-step statistics
                     int *tr = B.trace + ((size_t)s * n_iter + (it - 1)) * 4;
                     tr[0] = A.sc->n_nodes[0]; tr[1] = A.sc->n_oxy; tr[2] = A.sc->n_nodes[1]; tr[3] = A.sc->n_co2;
                 }
             }
-            if (it >= n_iter) break;
-            const IterParams P = B.iters[it];
+        }
+        if (!odd && it >= n_iter) break;
+        // ---- B
+        const IterParams P = B.iters[it];
+        if (!odd) {
             if (it == 0) {   // later iterations get their candidates from the side job of the previous ordered arterial pass
                 long _t0 = (long)wall_clock64();
                 if (threadIdx.x < 64)
@@ -523,65 +554,34 @@ __device__ __forceinline__ void run_sample(const BatchPtrs &B, const HostMail &M
                 if (threadIdx.x == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
             }
             OCTA_PROF(0, phase_sample(b, A, B.C, P, it));
-            OCTA_PROF(1, phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art));
-#if OCTA_SIM_DUP & 4
-            phase_assign(b, A, 0, A.oxy, A.sc->n_oxy, P.delta_art);
-#endif
-            if (b.tid == 0) *req_n = 0;
-            b.sync();
-            OCTA_PROF(2, phase_pre(b, A, B.C, P, 0, A.oxy, reqs, req_n, REQ_PER_SAMPLE, s));
-#if OCTA_SIM_DUP & 32
-            b.sync();
-            if (b.tid == 0) *req_n = 0;
-            b.sync();
-            phase_pre(b, A, B.C, P, 0, A.oxy, reqs, req_n, REQ_PER_SAMPLE, s);
-#endif
-            if (mail_roundtrip(b, A, M, s, *req_n, 2 * it + 1, t_kernel)) { parked_at = it; parked_stage = 1; break; }
         }
-        if (stage <= 1) {
-            const IterParams P = B.iters[it];
-            if (uniform_err(b, A)) break;
-            {
-                // the candidate stream of the NEXT iteration (numpy MT19937, one wave) runs beside the ordered arterial pass:
-                // it only depends on the generator state, and the candidate buffer is free once phase_sample has consumed it
-                const int n_next = it + 1 < n_iter ? B.iters[it + 1].N : 0;
-                auto next_candidates = [&](unsigned char *lds) {
-                    if (n_next <= 0) return;
-                    const long _t0 = (long)wall_clock64();
-                    gen_candidates_wave(B.mt_state + (size_t)s * 625, B.valid + (size_t)s * B.valid_stride, B.valid_count[s], n_next,
-                                        B.cand + (size_t)s * NCANDCAP * 3, reinterpret_cast<unsigned *>(lds),
-                                        B.cand_idx + (size_t)s * NCANDCAP, (int)(threadIdx.x & 63), B.C.gs);
-                    if ((threadIdx.x & 63) == 0) A.sc->prof[10] += (long)wall_clock64() - _t0;
-                };
-                OCTA_PROF(3, phase_seq(b, A, B.C, P, 0, A.oxy, results, next_candidates));
-            }
-#ifdef OCTA_SIM_DEBUG_SAT
-            A.dbg_it = it;
-#endif
-            OCTA_PROF(4, phase_satisfy_art(b, A, B.C, P));
-            OCTA_PROF(6, phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven));
+        {
+            const int g = odd;                                   // the forest that is assigned and speculated now
+            const double *att = g ? A.co2 : A.oxy;
+            const int n_att = g ? A.sc->n_co2 : A.sc->n_oxy;
+            const double delta = g ? P.delta_ven : P.delta_art;
+            OCTA_PROF(g ? 6 : 1, phase_assign(b, A, g, att, n_att, delta));
 #if OCTA_SIM_DUP & 4
-            phase_assign(b, A, 1, A.co2, A.sc->n_co2, P.delta_ven);
+            phase_assign(b, A, g, att, n_att, delta);
 #endif
             if (b.tid == 0) *req_n = 0;
             b.sync();
-            OCTA_PROF(7, phase_pre(b, A, B.C, P, 1, A.co2, reqs, req_n, REQ_PER_SAMPLE, s));
+            OCTA_PROF(g ? 7 : 2, phase_pre(b, A, B.C, P, g, att, reqs, req_n, REQ_PER_SAMPLE, s));
 #if OCTA_SIM_DUP & 32
             b.sync();
             if (b.tid == 0) *req_n = 0;
             b.sync();
-            phase_pre(b, A, B.C, P, 1, A.co2, reqs, req_n, REQ_PER_SAMPLE, s);
+            phase_pre(b, A, B.C, P, g, att, reqs, req_n, REQ_PER_SAMPLE, s);
 #endif
-            if (mail_roundtrip(b, A, M, s, *req_n, 2 * it + 2, t_kernel)) { parked_at = it; parked_stage = 2; break; }
+            if (mail_roundtrip(b, A, M, s, *req_n, 2 * it + 1 + odd, t_kernel)) { parked_at = it; parked_stage = 1 + odd; break; }
         }
 #if defined(OCTA_SIM_DEBUG_SAT) && defined(OCTA_SIM_ITER_PROF)
         // diagnostic build (tools/sim_iter_profile.py): the row of iteration `it` holds the 16 phase timers' growth during it
-        if (b.tid == 0 && A.dbg) {
+        if (odd && b.tid == 0 && A.dbg) {
             int *row = A.dbg + 16 * it;
             for (int k = 0; k < 16; k++) { row[k] = (int)(A.sc->prof[k] - iter_prof_prev[k]); iter_prof_prev[k] = A.sc->prof[k]; }
         }
 #endif
-        stage = 0;
     }
     if (parked_at < 0 && !skip) murray_flush_pending(b, A);      // the run is over (block-uniform): radii left for "the other forest's next pass"
     // sign-off: the host leaves its service loop when every SAMPLE has passed here (or when the launch has completed)
