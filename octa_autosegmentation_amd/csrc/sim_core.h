@@ -1022,6 +1022,13 @@ OCTA_HD inline void kd_build(const Blk &b, const double *pts, int n, idx_t *out_
     idx_t *rs2 = tab + 2 * KD_RANGES, *re2 = tab + 3 * KD_RANGES;  // next level
     signed char *rd = reinterpret_cast<signed char *>(tab + 4 * KD_RANGES); // bbox pass: 1 = holds a needed point; then split dim (-1 = leaf / not needed)
     unsigned *bbf = reinterpret_cast<unsigned *>(b.user_of<1>() + KD_MAILBOX_OFF); // [nr][6]: max xyz (rounded up), min xyz (rounded down)
+#if defined(__HIP_DEVICE_COMPILE__) && !OCTA_SIM_LARGE
+    // Round 6: the element array is sized for OCAP sinks but most builds have far fewer -- when 12 bytes per sink fit it, the single-precision (x, y)
+    // copies live in the LDS BEHIND the n element words instead of in HBM scratch: the box and key passes of every level gather them (63 % of the builds,
+    // 22 % of the gathered elements of a run). One code path: the pointer is generic, the loads are FLAT.
+    if ((size_t)n * (sizeof(kdw_t) + 8) + 8 <= (size_t)KD_TAB_OFF)
+        xy = reinterpret_cast<float *>(b.user_of<1>() + (((size_t)n * sizeof(kdw_t) + 7) & ~(size_t)7));
+#endif
     for (int i = b.tid; i < n; i += b.nth) {
         kv[i] = (kdw_t)i;
         // round to nearest: x lies within one float spacing of it. flag_in_sign (the caller vouches for x >= 0: the sinks are valid
